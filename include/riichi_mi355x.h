@@ -1,0 +1,249 @@
+/*
+ * riichi_mi355x.h — C-ABI of the MI355X-native batched Riichi Mahjong step path.
+ *
+ * This is the drop-in boundary for the hot path of smly/RiichiEnv:
+ *   RiichiEnv.__new__/reset/step/get_observations/done/scores/ranks/mjai_log
+ *       (reference: riichienv-python/src/env.rs:82-118, 799-851, 857-872, 741-765,
+ *        353-356, 401-404, 673-689, 729-739)
+ *   Observation.legal_actions()/mask()          (observation/python.rs:93-111)
+ *   HandEvaluator.calc / get_waits / is_tenpai  (hand_evaluator.rs:77-213)
+ *   calculate_score                             (score.rs:13-52)
+ *
+ * One handle = one shard of independent games on one GPU.  All entry points are
+ * plain C: opaque handle, caller-allocated arrays, int return code (0 = OK,
+ * negative = RMJ_ERR_*).  No torch / C++ types cross this boundary.  A handle is
+ * thread-compatible (use one handle per host thread / per GPU).
+ *
+ * The library has NO CPU fallback: every compute entry point returns
+ * RMJ_ERR_NO_DEVICE when no HIP device is usable.
+ */
+#ifndef RIICHI_MI355X_H
+#define RIICHI_MI355X_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ------------------------------------------------------------------ constants */
+#define RMJ_OK 0
+#define RMJ_ERR_ARG (-1)       /* bad argument (ValueError in the reference binding) */
+#define RMJ_ERR_NO_DEVICE (-2) /* no usable HIP device / HIP runtime failure at init */
+#define RMJ_ERR_HIP (-3)       /* HIP runtime error (see rmj_last_error) */
+#define RMJ_ERR_RANGE (-4)     /* index out of range */
+
+#define RMJ_NP 4                /* seats in the 4-player state layout */
+#define RMJ_MAX_LEGAL 64        /* max legal actions per seat (reference worst case ~56) */
+#define RMJ_ACTION_SPACE_4P 82  /* action.rs:11 */
+#define RMJ_ACTION_SPACE_3P 60  /* action.rs:12 */
+#define RMJ_MAX_DISCARDS 32
+#define RMJ_WALL_4P 136
+
+/* ActionType, action.rs:55-68 */
+enum {
+    RMJ_DISCARD = 0, RMJ_CHI = 1, RMJ_PON = 2, RMJ_DAIMINKAN = 3, RMJ_RON = 4, RMJ_RIICHI = 5,
+    RMJ_TSUMO = 6, RMJ_PASS = 7, RMJ_ANKAN = 8, RMJ_KAKAN = 9, RMJ_KYUSHU = 10, RMJ_KITA = 11
+};
+/* Phase, action.rs:29-33 */
+enum { RMJ_WAIT_ACT = 0, RMJ_WAIT_RESPONSE = 1 };
+/* MeldType, types.rs:54-62 */
+enum { RMJ_MELD_CHI = 0, RMJ_MELD_PON = 1, RMJ_MELD_DAIMINKAN = 2, RMJ_MELD_ANKAN = 3, RMJ_MELD_KAKAN = 4 };
+
+/* GameRule bits, rule.rs:10-22 (bit i = i-th field) */
+#define RMJ_RULE_RON_ON_ANKAN_KOKUSHI 1u
+#define RMJ_RULE_KOKUSHI13_DOUBLE 2u
+#define RMJ_RULE_SUUANKOU_TANKI_DOUBLE 4u
+#define RMJ_RULE_JUNSEI_CHUUREN_DOUBLE 8u
+#define RMJ_RULE_DAISUUSHII_DOUBLE 16u
+#define RMJ_RULE_PAO_LIABILITY_ONLY 32u
+#define RMJ_RULE_SANCHAHO_DRAW 64u
+#define RMJ_RULE_KUIKAE_FORBIDDEN 128u
+#define RMJ_RULE_TENHOU (RMJ_RULE_SANCHAHO_DRAW | RMJ_RULE_KUIKAE_FORBIDDEN)          /* rule.rs:31-44 */
+#define RMJ_RULE_MJSOUL (1u | 2u | 4u | 8u | 16u | 32u | RMJ_RULE_KUIKAE_FORBIDDEN) /* rule.rs:46-57 */
+
+/*
+ * Packed action (u64), used for step() input and for the legal-action lists:
+ *   bits  0..7   action type (RMJ_*), 0xFF = "no action from this seat"
+ *   bits  8..15  tile (136-id), 0xFF = None
+ *   bits 16..23  number of consume tiles (0..4)
+ *   bits 24..55  consume tiles c0..c3 (ascending, as Action::new sorts them; action.rs:97-98)
+ */
+typedef uint64_t rmj_action_t;
+#define RMJ_NO_ACTION 0xFFFFFFFFFFFFFFFFull
+#define RMJ_TILE_NONE 0xFFu
+
+/* MJAI event record emitted by the device; formatted to the reference's JSON
+ * strings (alphabetical keys, state/mod.rs:2094-2148) by rmj_format_event. */
+enum {
+    RMJ_EV_NONE = 0, RMJ_EV_START_GAME = 1, RMJ_EV_START_KYOKU = 2, RMJ_EV_TSUMO = 3, RMJ_EV_DAHAI = 4,
+    RMJ_EV_REACH = 5, RMJ_EV_REACH_ACCEPTED = 6, RMJ_EV_CHI = 7, RMJ_EV_PON = 8, RMJ_EV_DAIMINKAN = 9,
+    RMJ_EV_ANKAN = 10, RMJ_EV_KAKAN = 11, RMJ_EV_DORA = 12, RMJ_EV_HORA = 13, RMJ_EV_RYUKYOKU = 14,
+    RMJ_EV_END_KYOKU = 15, RMJ_EV_END_GAME = 16, RMJ_EV_KITA = 17,
+    RMJ_EV_TEHAI = 18 /* continuation of START_KYOKU: payload[0..25] = 26 hand tiles (2 seats) */
+};
+/* ryukyoku reasons (state/mod.rs:1846-1968) */
+enum {
+    RMJ_RK_EXHAUSTIVE = 0, RMJ_RK_NAGASHI = 1, RMJ_RK_KYUSHU = 2, RMJ_RK_SUFUURENTA = 3, RMJ_RK_SUUKANSANSEN = 4,
+    RMJ_RK_SUUCHA_RIICHI = 5, RMJ_RK_SANCHAHO = 6, RMJ_RK_ILLEGAL = 7 /* + actor = offender */
+};
+typedef struct RmjEvent { /* 32 bytes */
+    uint8_t type;        /* RMJ_EV_* */
+    uint8_t actor;       /* actor / oya (start_kyoku) / offender (illegal ryukyoku) */
+    uint8_t target;      /* target / kyoku number (start_kyoku) */
+    uint8_t tile;        /* pai / dora_marker */
+    uint8_t consumed[4]; /* consumed tiles; start_kyoku: [bakaze, honba, kyotaku_lo, kyotaku_hi] */
+    int32_t deltas[4];   /* hora/ryukyoku deltas; start_kyoku: scores */
+    uint8_t flags;       /* dahai: tsumogiri; hora: is_tsumo; ryukyoku: reason; n_consumed for melds in bits 4..7 */
+    uint8_t n_ura;
+    uint8_t ura[5];
+    uint8_t pad;
+} RmjEvent;
+
+/* ------------------------------------------------------------------ state peek/poke view
+ * Mirrors GameState/PlayerState/WallState (state/mod.rs:31-91, state/player.rs:6-39,
+ * state/wall.rs:8-19).  Used by tests (the reference's Python setters, env.rs:134-622)
+ * and by parity checks: the oracle fills the same struct. */
+typedef struct RmjMeldView {
+    uint8_t meld_type, n_tiles, tiles[4], opened;
+    int8_t from_who;
+    int16_t called_tile; /* -1 = None */
+} RmjMeldView;
+
+typedef struct RmjPlayerView {
+    uint8_t hand_len, hand[14];
+    uint8_t n_melds;
+    RmjMeldView melds[4];
+    uint8_t n_discards, discards[RMJ_MAX_DISCARDS];
+    uint32_t discard_from_hand_bits, discard_is_riichi_bits;
+    int8_t riichi_declaration_index; /* -1 = None */
+    int32_t score, score_delta;
+    uint8_t riichi_declared, riichi_stage, double_riichi_declared, missed_agari_riichi, missed_agari_doujun,
+        nagashi_eligible, ippatsu_cycle;
+    int8_t pao_daisangen, pao_daisuushi; /* liable seat for yaku 37 / 50, -1 = none */
+    uint8_t n_forbidden, forbidden[2];
+    int16_t riichi_sutehai, last_tedashi; /* -1 = None */
+} RmjPlayerView;
+
+typedef struct RmjStateView {
+    uint8_t wall_len, wall[RMJ_WALL_4P]; /* WallState.tiles (after reverse; draw = pop from end) */
+    uint8_t n_dora, dora[5];
+    uint8_t rinshan_draw_count, pending_kan_dora_count, drawable_count;
+    uint64_t wall_seed, hand_index;
+    RmjPlayerView players[RMJ_NP];
+    uint8_t current_player, is_done, needs_tsumo, phase, active_mask;
+    uint32_t turn_count, riichi_sticks;
+    int16_t last_discard_pid, last_discard_tile; /* -1 = None */
+    int16_t pending_kan_pid;                     /* -1 = None */
+    rmj_action_t pending_kan_action;
+    uint8_t oya, honba, kyoku_idx, round_wind, is_rinshan_flag, is_first_turn;
+    int16_t riichi_pending_acceptance, drawn_tile; /* -1 = None */
+    int16_t last_error_pid;                        /* -1 = no error (quirk Q9) */
+} RmjStateView;
+
+/* ------------------------------------------------------------------ configuration */
+typedef struct RmjConfig {
+    uint32_t n_games;     /* games in this shard */
+    uint8_t game_mode;    /* 0..2 = 4p-red-{single,east,half}; 3..5 = 3p (env.rs:93-100) */
+    uint8_t skip_mjai_logging;
+    uint8_t round_wind;   /* constructor round_wind (env.rs:113) */
+    uint8_t reserved0;
+    uint32_t rule_bits;   /* RMJ_RULE_* */
+    int32_t device;       /* HIP device ordinal */
+    uint64_t base_seed;   /* episode seed of game g = base_seed + game_offset + g unless `seeds` given */
+    uint64_t game_offset; /* global index of this shard's first game (multi-GPU sharding by index) */
+    const uint64_t* seeds;/* optional [n_games] explicit episode seeds (RiichiEnv(seed=...)) */
+    uint32_t event_ring;  /* per-game MJAI event ring capacity (power of two, >= 64) */
+    uint32_t reserved1;
+} RmjConfig;
+
+typedef struct rmj_env* rmj_handle;
+
+/* ------------------------------------------------------------------ lifecycle */
+const char* rmj_version(void);
+const char* rmj_last_error(void);
+int rmj_device_count(void);
+/* RiichiEnv.__new__ (env.rs:82-118): allocates SoA state for n_games, runs the constructor's
+ * own _initialize_round (state/mod.rs:165) for every game. */
+int rmj_create(const RmjConfig* cfg, rmj_handle* out);
+int rmj_destroy(rmj_handle h);
+
+/* RiichiEnv.reset (env.rs:799-851) for the games selected by `select` (NULL = all).
+ * Optional per-game arrays (NULL = reference defaults): walls [n][136] in the reference's
+ * `wall=` orientation, oya [n], round_wind [n], scores [n][4], honba [n], kyotaku [n]. */
+int rmj_reset(rmj_handle h, const uint8_t* select, const uint8_t* walls, const uint8_t* oya, const uint8_t* round_wind,
+              const int32_t* scores, const uint8_t* honba, const uint32_t* kyotaku);
+
+/* RiichiEnv.step (env.rs:857-872): actions[n][4] packed, RMJ_NO_ACTION for seats that do not act.
+ * Games that are done are left untouched (state/mod.rs:331-333). */
+int rmj_step(rmj_handle h, const rmj_action_t* actions);
+/* Same, `actions` is a device pointer (zero-copy from a GPU policy). */
+int rmj_step_device(rmj_handle h, const rmj_action_t* d_actions);
+/* Device-side uniform-random policy (RandomAgent, src/riichienv/agents/random_agent.py:6-15,
+ * keyed per (game, step, seat) — SURVEY §8(c)): choice = mix(policy_seed, global_game, step_no, seat) % n_legal
+ * over the ordered legal list.  Runs n_steps batched steps; with auto_reset != 0 a finished game is
+ * re-`reset()` (defaults) at the start of the next step instead of stepping. */
+int rmj_step_random(rmj_handle h, uint64_t policy_seed, uint32_t n_steps, int auto_reset);
+/* Fill actions[n][4] with what the device policy would choose for the CURRENT state (no step). */
+int rmj_random_actions(rmj_handle h, uint64_t policy_seed, rmj_action_t* actions);
+
+/* ------------------------------------------------------------------ observations */
+int rmj_get_status(rmj_handle h, uint8_t* active_mask, uint8_t* phase, uint8_t* done); /* each [n] */
+int rmj_get_legal(rmj_handle h, rmj_action_t* legal /*[n][4][64]*/, uint8_t* counts /*[n][4]*/);
+int rmj_get_mask(rmj_handle h, uint8_t* mask /*[n][4][82]*/);
+int rmj_get_waits(rmj_handle h, uint64_t* waits /*[n][4] bit t = tile type t*/);
+int rmj_get_scores(rmj_handle h, int32_t* scores /*[n][4]*/);
+int rmj_get_ranks(rmj_handle h, uint8_t* ranks /*[n][4], 1-based, ties by seat (env.rs:673-689)*/);
+int rmj_get_step_counts(rmj_handle h, uint64_t* steps /*[n]*/);
+int rmj_total_steps(rmj_handle h, uint64_t* total);
+int rmj_peek_state(rmj_handle h, uint32_t game, RmjStateView* out);
+int rmj_poke_state(rmj_handle h, uint32_t game, const RmjStateView* in); /* recomputes legal actions */
+
+/* MJAI events: total number emitted so far per game, and a window of records. */
+int rmj_get_event_counts(rmj_handle h, uint32_t* counts /*[n]*/);
+int rmj_get_events(rmj_handle h, uint32_t game, uint32_t first, uint32_t max_events, RmjEvent* out, uint32_t* n_out);
+/* Formats one event (START_KYOKU consumes the 2 TEHAI continuation records that follow it; returns
+ * the number of records consumed, or <0).  seat = -1 -> full log string, 0..3 -> per-seat masked view. */
+int rmj_format_event(const RmjEvent* ev, uint32_t n_avail, int seat, char* buf, uint32_t cap);
+
+/* ------------------------------------------------------------------ batched hand math (kernel gate) */
+typedef struct RmjHandCase {
+    uint8_t n_tiles, tiles[14];
+    uint8_t n_melds;
+    RmjMeldView melds[4];
+    uint8_t win_tile;
+    uint8_t n_dora, dora[5], n_ura, ura[5];
+    /* Conditions, types.rs:193-210 */
+    uint8_t tsumo, riichi, double_riichi, ippatsu, haitei, houtei, rinshan, chankan, tsumo_first_turn;
+    uint8_t player_wind, round_wind, kita_count, is_sanma;
+    uint32_t honba;
+} RmjHandCase;
+typedef struct RmjHandResult { /* WinResult, types.rs:282-293 */
+    uint8_t is_win, yakuman, has_win_shape, n_yaku;
+    uint8_t yaku[20];
+    uint32_t han, fu, ron_agari, tsumo_agari_oya, tsumo_agari_ko;
+    uint64_t waits; /* HandEvaluator.get_waits of the tiles/melds (13-tile hands), bit per type */
+    uint8_t is_tenpai, is_agari, pad[6];
+} RmjHandResult;
+int rmj_eval_hands(int device, const RmjHandCase* cases, uint32_t n, RmjHandResult* out);
+/* agari.rs:65-73 / hand_evaluator.rs:178-213 over raw 34-histograms */
+int rmj_agari_counts(int device, const uint8_t* counts /*[n][34]*/, uint32_t n, uint8_t* is_agari, uint8_t* is_tenpai,
+                     uint64_t* waits);
+/* score.rs:13-52 */
+int rmj_calculate_score(int device, const uint8_t* han, const uint8_t* fu, const uint8_t* is_oya, const uint8_t* is_tsumo,
+                        const uint32_t* honba, const uint8_t* num_players, uint32_t n, uint32_t* out /*[n][4] total,ron,oya,ko*/);
+
+/* ------------------------------------------------------------------ measurement */
+typedef struct RmjBenchResult {
+    double total_ms;      /* HIP-event time over the timed region (stream of the handle) */
+    double step_kernel_ms;/* average duration of one step-kernel launch, HIP events around each launch */
+    uint64_t env_steps;   /* sum over games of step calls that advanced the game */
+    uint32_t launches;
+    uint32_t reserved;
+} RmjBenchResult;
+int rmj_bench_rollout(rmj_handle h, uint64_t policy_seed, uint32_t warmup, uint32_t steps, RmjBenchResult* out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RIICHI_MI355X_H */

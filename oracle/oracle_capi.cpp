@@ -1,0 +1,428 @@
+// ORACLE — TEST INFRASTRUCTURE ONLY.  Not part of the product path.
+// C wrapper (ctypes-friendly) around the CPU restatement in riichi_core.hpp /
+// riichi_state.hpp.  Uses the POD views of include/riichi_mi355x.h so tests can
+// compare the oracle and the HIP path byte for byte.
+#include <chrono>
+#include <cstdio>
+#include <cstring>
+#include <thread>
+
+#include "../include/riichi_mi355x.h"
+#include "riichi_state.hpp"
+
+using namespace orc;
+
+static rmj_action_t pack_action(const Action& a) {
+    uint64_t v = (uint64_t)a.type;
+    v |= (uint64_t)(a.tile < 0 ? 0xFF : a.tile) << 8;
+    v |= (uint64_t)a.consume.size() << 16;
+    for (size_t i = 0; i < a.consume.size() && i < 4; i++) v |= (uint64_t)a.consume[i] << (24 + 8 * i);
+    return v;
+}
+static Action unpack_action(rmj_action_t v, int actor) {
+    Action a;
+    a.type = (ActionType)(v & 0xFF);
+    int t = (v >> 8) & 0xFF;
+    a.tile = t == 0xFF ? -1 : t;
+    int n = (v >> 16) & 0xFF;
+    for (int i = 0; i < n && i < 4; i++) a.consume.push_back((uint8_t)((v >> (24 + 8 * i)) & 0xFF));
+    std::sort(a.consume.begin(), a.consume.end());
+    a.actor = actor;
+    return a;
+}
+
+static Meld meld_from_view(const RmjMeldView& v) {
+    Meld m;
+    m.meld_type = (MeldType)v.meld_type;
+    for (int i = 0; i < v.n_tiles; i++) m.tiles.push_back(v.tiles[i]);
+    m.opened = v.opened;
+    m.from_who = v.from_who;
+    m.called_tile = v.called_tile;
+    return m;
+}
+static void meld_to_view(const Meld& m, RmjMeldView& v) {
+    std::memset(&v, 0, sizeof(v));
+    v.meld_type = m.meld_type;
+    v.n_tiles = (uint8_t)m.tiles.size();
+    for (size_t i = 0; i < m.tiles.size() && i < 4; i++) v.tiles[i] = m.tiles[i];
+    v.opened = m.opened;
+    v.from_who = m.from_who;
+    v.called_tile = (int16_t)m.called_tile;
+}
+
+// policy choice shared (by definition, not by code) with the HIP path; see include/riichi_mi355x.h rmj_step_random
+static inline uint64_t policy_choice(uint64_t seed, uint64_t game, uint64_t step, uint32_t seat, uint32_t n) {
+    return splitmix64(splitmix64(seed + game) + step * 4 + seat) % n;
+}
+
+extern "C" {
+
+// ---------------------------------------------------------------- hand math
+int orc_eval_hands(const RmjHandCase* cases, uint32_t n, RmjHandResult* out) {
+    for (uint32_t k = 0; k < n; k++) {
+        const RmjHandCase& c = cases[k];
+        RmjHandResult& r = out[k];
+        std::memset(&r, 0, sizeof(r));
+        std::vector<uint8_t> tiles(c.tiles, c.tiles + c.n_tiles);
+        std::vector<Meld> melds;
+        for (int i = 0; i < c.n_melds; i++) melds.push_back(meld_from_view(c.melds[i]));
+        HandEvaluator he(tiles, melds, c.is_sanma != 0);
+        Conditions cd;
+        cd.tsumo = c.tsumo; cd.riichi = c.riichi; cd.double_riichi = c.double_riichi; cd.ippatsu = c.ippatsu;
+        cd.haitei = c.haitei; cd.houtei = c.houtei; cd.rinshan = c.rinshan; cd.chankan = c.chankan;
+        cd.tsumo_first_turn = c.tsumo_first_turn;
+        cd.player_wind = c.player_wind % 4; cd.round_wind = c.round_wind % 4;
+        cd.honba = c.honba; cd.kita_count = c.kita_count; cd.is_sanma = c.is_sanma;
+        std::vector<uint8_t> dora(c.dora, c.dora + c.n_dora), ura(c.ura, c.ura + c.n_ura);
+        WinResult w = he.calc(c.win_tile, dora, ura, cd);
+        r.is_win = w.is_win; r.yakuman = w.yakuman; r.has_win_shape = w.has_win_shape;
+        r.n_yaku = (uint8_t)std::min<size_t>(w.yaku.size(), 20);
+        for (int i = 0; i < r.n_yaku; i++) r.yaku[i] = (uint8_t)w.yaku[i];
+        r.han = w.han; r.fu = w.fu; r.ron_agari = w.ron_agari; r.tsumo_agari_oya = w.tsumo_agari_oya;
+        r.tsumo_agari_ko = w.tsumo_agari_ko;
+        for (uint8_t t : he.get_waits_u8()) r.waits |= 1ull << t;
+        r.is_tenpai = he.is_tenpai();
+        Hand h14 = he.hand;
+        if (he.current_total() == 13) h14.add(c.win_tile / 4);
+        r.is_agari = is_agari(h14);
+    }
+    return 0;
+}
+
+int orc_agari_counts(const uint8_t* counts, uint32_t n, uint8_t* agari, uint8_t* tenpai, uint64_t* waits) {
+    for (uint32_t k = 0; k < n; k++) {
+        Hand h;
+        std::memcpy(h.counts, counts + 34 * k, 34);
+        agari[k] = is_agari(h);
+        // hand_evaluator.rs:178-213 semantics on a raw histogram (no melds): only 13-tile hands have waits
+        uint64_t w = 0;
+        bool tp = false;
+        if (h.total() == 13) {
+            for (int i = 0; i < 34; i++)
+                if (h.counts[i] < 4) {
+                    h.add((uint8_t)i);
+                    if (is_agari(h)) { w |= 1ull << i; tp = true; }
+                    h.remove((uint8_t)i);
+                }
+        }
+        tenpai[k] = tp;
+        waits[k] = w;
+    }
+    return 0;
+}
+// agari.rs:15-63 free function (with neighbour pruning) — used by hands_negative.json check
+int orc_is_tenpai_free(const uint8_t* counts34) {
+    Hand h;
+    std::memcpy(h.counts, counts34, 34);
+    return is_tenpai_counts(h);
+}
+
+int orc_calculate_score(const uint8_t* han, const uint8_t* fu, const uint8_t* is_oya, const uint8_t* is_tsumo,
+                        const uint32_t* honba, const uint8_t* np, uint32_t n, uint32_t* out) {
+    for (uint32_t k = 0; k < n; k++) {
+        Score s = calculate_score(han[k], fu[k], is_oya[k], is_tsumo[k], honba[k], np[k]);
+        out[4 * k] = s.total; out[4 * k + 1] = s.pay_ron; out[4 * k + 2] = s.pay_tsumo_oya; out[4 * k + 3] = s.pay_tsumo_ko;
+    }
+    return 0;
+}
+
+int orc_find_divisions(const uint8_t* counts34, uint8_t* out /*[max][9]: head,n,(k,t)x4... */, int max_div) {
+    Hand h;
+    std::memcpy(h.counts, counts34, 34);
+    auto d = find_divisions(h);
+    int n = 0;
+    for (auto& dv : d) {
+        if (n >= max_div) break;
+        uint8_t* o = out + 10 * n;
+        o[0] = dv.head;
+        o[1] = (uint8_t)dv.body.size();
+        for (size_t i = 0; i < dv.body.size() && i < 4; i++) {
+            o[2 + 2 * i] = dv.body[i].koutsu;
+            o[3 + 2 * i] = dv.body[i].t;
+        }
+        n++;
+    }
+    return (int)d.size();
+}
+
+void orc_tid_to_mjai(uint8_t tid, char* buf) { std::strcpy(buf, tid_to_mjai(tid).c_str()); }
+
+// ---------------------------------------------------------------- game
+void* orc_game_new(int game_mode, int skip_log, uint64_t seed, int has_seed, int round_wind, uint32_t rule_bits) {
+    std::optional<uint64_t> s;
+    if (has_seed) s = seed;
+    return new GameState((uint8_t)game_mode, skip_log != 0, s, (uint8_t)round_wind, GameRule::from_bits(rule_bits));
+}
+void orc_game_free(void* g) { delete (GameState*)g; }
+
+// wall: NULL or 136 tiles; oya/round_wind/honba/kyotaku <0 = default; scores NULL = default
+void orc_game_reset(void* gp, const uint8_t* wall, int oya, int round_wind, const int32_t* scores, int honba, int kyotaku) {
+    GameState* g = (GameState*)gp;
+    std::vector<uint8_t> w;
+    if (wall) w.assign(wall, wall + 136);
+    std::vector<int32_t> sc;
+    if (scores) sc.assign(scores, scores + 4);
+    g->env_reset(oya, wall ? &w : nullptr, round_wind, scores ? &sc : nullptr, honba, kyotaku);
+}
+
+void orc_game_step(void* gp, const rmj_action_t* actions /*[4]*/) {
+    GameState* g = (GameState*)gp;
+    std::map<uint8_t, Action> acts;
+    for (int p = 0; p < 4; p++)
+        if (actions[p] != RMJ_NO_ACTION && (actions[p] & 0xFF) != 0xFF) acts[(uint8_t)p] = unpack_action(actions[p], p);
+    g->step(acts);
+}
+
+int orc_game_legal(void* gp, int pid, rmj_action_t* out /*[64]*/) {
+    GameState* g = (GameState*)gp;
+    auto l = g->_get_legal_actions_internal((uint8_t)pid);
+    int n = 0;
+    for (auto& a : l) {
+        if (n < RMJ_MAX_LEGAL) out[n] = pack_action(a);
+        n++;
+    }
+    return n;
+}
+// observation/python.rs:98-111
+int orc_game_mask(void* gp, int pid, uint8_t* mask82) {
+    GameState* g = (GameState*)gp;
+    std::memset(mask82, 0, 82);
+    for (auto& a : g->_get_legal_actions_internal((uint8_t)pid)) {
+        int id = a.encode();
+        if (id >= 0 && id < 82) mask82[id] = 1;
+    }
+    return 0;
+}
+int orc_action_encode(rmj_action_t a) { return unpack_action(a, -1).encode(); }
+
+uint64_t orc_game_waits(void* gp, int pid) {
+    GameState* g = (GameState*)gp;
+    uint64_t w = 0;
+    for (uint8_t t : g->observation_waits(pid)) w |= 1ull << t;
+    return w;
+}
+
+void orc_game_status(void* gp, uint8_t* active_mask, uint8_t* phase, uint8_t* done) {
+    GameState* g = (GameState*)gp;
+    uint8_t m = 0;
+    // env.rs:870-871: observations are produced for active_players (after a finished game: legal list empty)
+    for (uint8_t p : g->active_players) m |= 1u << p;
+    *active_mask = m;
+    *phase = g->phase;
+    *done = g->is_done;
+}
+uint64_t orc_game_step_count(void* gp) { return ((GameState*)gp)->step_count; }
+
+void orc_game_peek(void* gp, RmjStateView* v) {
+    GameState* g = (GameState*)gp;
+    std::memset(v, 0, sizeof(*v));
+    v->wall_len = (uint8_t)g->wall.tiles.size();
+    for (size_t i = 0; i < g->wall.tiles.size() && i < 136; i++) v->wall[i] = g->wall.tiles[i];
+    v->n_dora = (uint8_t)g->wall.dora_indicators.size();
+    for (size_t i = 0; i < g->wall.dora_indicators.size() && i < 5; i++) v->dora[i] = g->wall.dora_indicators[i];
+    v->rinshan_draw_count = g->wall.rinshan_draw_count;
+    v->pending_kan_dora_count = g->wall.pending_kan_dora_count;
+    v->drawable_count = g->wall.drawable_count;
+    v->wall_seed = g->wall.seed ? *g->wall.seed : 0;
+    v->hand_index = g->wall.hand_index;
+    for (int p = 0; p < 4; p++) {
+        const PlayerState& P = g->players[p];
+        RmjPlayerView& q = v->players[p];
+        q.hand_len = (uint8_t)P.hand.size();
+        for (size_t i = 0; i < P.hand.size() && i < 14; i++) q.hand[i] = P.hand[i];
+        q.n_melds = (uint8_t)P.melds.size();
+        for (size_t i = 0; i < P.melds.size() && i < 4; i++) meld_to_view(P.melds[i], q.melds[i]);
+        q.n_discards = (uint8_t)P.discards.size();
+        for (size_t i = 0; i < P.discards.size() && i < RMJ_MAX_DISCARDS; i++) {
+            q.discards[i] = P.discards[i];
+            if (P.discard_from_hand[i]) q.discard_from_hand_bits |= 1u << i;
+            if (P.discard_is_riichi[i]) q.discard_is_riichi_bits |= 1u << i;
+        }
+        q.riichi_declaration_index = (int8_t)P.riichi_declaration_index;
+        q.score = P.score;
+        q.score_delta = P.score_delta;
+        q.riichi_declared = P.riichi_declared;
+        q.riichi_stage = P.riichi_stage;
+        q.double_riichi_declared = P.double_riichi_declared;
+        q.missed_agari_riichi = P.missed_agari_riichi;
+        q.missed_agari_doujun = P.missed_agari_doujun;
+        q.nagashi_eligible = P.nagashi_eligible;
+        q.ippatsu_cycle = P.ippatsu_cycle;
+        q.pao_daisangen = q.pao_daisuushi = -1;
+        auto f = P.pao.find(37);
+        if (f != P.pao.end()) q.pao_daisangen = (int8_t)f->second;
+        f = P.pao.find(50);
+        if (f != P.pao.end()) q.pao_daisuushi = (int8_t)f->second;
+        q.n_forbidden = (uint8_t)P.forbidden_discards.size();
+        for (size_t i = 0; i < P.forbidden_discards.size() && i < 2; i++) q.forbidden[i] = P.forbidden_discards[i];
+        q.riichi_sutehai = (int16_t)g->riichi_sutehais[p];
+        q.last_tedashi = (int16_t)g->last_tedashis[p];
+    }
+    v->current_player = g->current_player;
+    v->is_done = g->is_done;
+    v->needs_tsumo = g->needs_tsumo;
+    v->phase = g->phase;
+    for (uint8_t p : g->active_players) v->active_mask |= 1u << p;
+    v->turn_count = g->turn_count;
+    v->riichi_sticks = g->riichi_sticks;
+    v->last_discard_pid = g->last_discard ? g->last_discard->first : -1;
+    v->last_discard_tile = g->last_discard ? g->last_discard->second : -1;
+    v->pending_kan_pid = g->pending_kan ? g->pending_kan->first : -1;
+    v->pending_kan_action = g->pending_kan ? pack_action(g->pending_kan->second) : 0;
+    v->oya = g->oya;
+    v->honba = g->honba;
+    v->kyoku_idx = g->kyoku_idx;
+    v->round_wind = g->round_wind;
+    v->is_rinshan_flag = g->is_rinshan_flag;
+    v->is_first_turn = g->is_first_turn;
+    v->riichi_pending_acceptance = (int16_t)g->riichi_pending_acceptance;
+    v->drawn_tile = (int16_t)g->drawn_tile;
+    v->last_error_pid = -1;
+    if (g->last_error) v->last_error_pid = (int16_t)std::atoi(g->last_error->c_str() + 32);
+}
+
+// test hook mirroring the reference's Python setters (env.rs:134-622)
+void orc_game_poke(void* gp, const RmjStateView* v) {
+    GameState* g = (GameState*)gp;
+    g->wall.tiles.assign(v->wall, v->wall + v->wall_len);
+    g->wall.dora_indicators.assign(v->dora, v->dora + v->n_dora);
+    g->wall.rinshan_draw_count = v->rinshan_draw_count;
+    g->wall.pending_kan_dora_count = v->pending_kan_dora_count;
+    g->wall.drawable_count = v->drawable_count;
+    g->wall.hand_index = v->hand_index;
+    for (int p = 0; p < 4; p++) {
+        PlayerState& P = g->players[p];
+        const RmjPlayerView& q = v->players[p];
+        P.hand.assign(q.hand, q.hand + q.hand_len);
+        P.melds.clear();
+        for (int i = 0; i < q.n_melds; i++) P.melds.push_back(meld_from_view(q.melds[i]));
+        P.discards.assign(q.discards, q.discards + q.n_discards);
+        P.discard_from_hand.clear();
+        P.discard_is_riichi.clear();
+        for (int i = 0; i < q.n_discards; i++) {
+            P.discard_from_hand.push_back((q.discard_from_hand_bits >> i) & 1);
+            P.discard_is_riichi.push_back((q.discard_is_riichi_bits >> i) & 1);
+        }
+        P.riichi_declaration_index = q.riichi_declaration_index;
+        P.score = q.score;
+        P.score_delta = q.score_delta;
+        P.riichi_declared = q.riichi_declared;
+        P.riichi_stage = q.riichi_stage;
+        P.double_riichi_declared = q.double_riichi_declared;
+        P.missed_agari_riichi = q.missed_agari_riichi;
+        P.missed_agari_doujun = q.missed_agari_doujun;
+        P.nagashi_eligible = q.nagashi_eligible;
+        P.ippatsu_cycle = q.ippatsu_cycle;
+        P.pao.clear();
+        if (q.pao_daisangen >= 0) P.pao[37] = (uint8_t)q.pao_daisangen;
+        if (q.pao_daisuushi >= 0) P.pao[50] = (uint8_t)q.pao_daisuushi;
+        P.forbidden_discards.assign(q.forbidden, q.forbidden + q.n_forbidden);
+        g->riichi_sutehais[p] = q.riichi_sutehai;
+        g->last_tedashis[p] = q.last_tedashi;
+    }
+    g->current_player = v->current_player;
+    g->is_done = v->is_done;
+    g->needs_tsumo = v->needs_tsumo;
+    g->phase = (Phase)v->phase;
+    g->active_players.clear();
+    for (int p = 0; p < 4; p++)
+        if (v->active_mask & (1u << p)) g->active_players.push_back((uint8_t)p);
+    g->turn_count = v->turn_count;
+    g->riichi_sticks = v->riichi_sticks;
+    if (v->last_discard_pid >= 0)
+        g->last_discard = std::make_pair((uint8_t)v->last_discard_pid, (uint8_t)v->last_discard_tile);
+    else
+        g->last_discard.reset();
+    if (v->pending_kan_pid >= 0)
+        g->pending_kan = std::make_pair((uint8_t)v->pending_kan_pid, unpack_action(v->pending_kan_action, v->pending_kan_pid));
+    else
+        g->pending_kan.reset();
+    g->oya = v->oya;
+    g->honba = v->honba;
+    g->kyoku_idx = v->kyoku_idx;
+    g->round_wind = v->round_wind;
+    g->is_rinshan_flag = v->is_rinshan_flag;
+    g->is_first_turn = v->is_first_turn;
+    g->riichi_pending_acceptance = v->riichi_pending_acceptance;
+    g->drawn_tile = v->drawn_tile;
+    // claims are recomputed for a WaitResponse poke from the last discard (what the reference tests do by hand)
+    g->current_claims.clear();
+    if (g->phase == WAIT_RESPONSE && g->last_discard && !g->pending_kan) {
+        for (uint8_t i = 0; i < 4; i++) {
+            if (i == g->last_discard->first) continue;
+            if (!(v->active_mask & (1u << i))) continue;
+            auto r = g->_get_claim_actions_for_player(i, g->last_discard->first, g->last_discard->second);
+            if (!r.first.empty()) g->current_claims[i] = r.first;
+        }
+    }
+}
+
+uint32_t orc_game_log_len(void* gp, int seat) {
+    GameState* g = (GameState*)gp;
+    return (uint32_t)(seat < 0 ? g->mjai_log.size() : g->mjai_log_per_player[seat].size());
+}
+int orc_game_log_get(void* gp, int seat, uint32_t idx, char* buf, uint32_t cap) {
+    GameState* g = (GameState*)gp;
+    const std::string& s = seat < 0 ? g->mjai_log[idx] : g->mjai_log_per_player[seat][idx];
+    if (s.size() + 1 > cap) return -1;
+    std::memcpy(buf, s.c_str(), s.size() + 1);
+    return (int)s.size();
+}
+
+// Random-policy actions for the current state (same definition as rmj_random_actions)
+void orc_game_random_actions(void* gp, uint64_t policy_seed, uint64_t global_game, rmj_action_t* out /*[4]*/) {
+    GameState* g = (GameState*)gp;
+    for (int p = 0; p < 4; p++) out[p] = RMJ_NO_ACTION;
+    if (g->is_done) return;
+    for (uint8_t p : g->active_players) {
+        auto l = g->_get_legal_actions_internal(p);
+        if (l.empty()) continue;
+        uint64_t c = policy_choice(policy_seed, global_game, g->step_count, p, (uint32_t)l.size());
+        out[p] = pack_action(l[c]);
+    }
+}
+
+// ---------------------------------------------------------------- CPU baseline (bench.py cpu_baseline leg)
+// Runs `n_games` independent random-agent games (sharded over `threads`) for at least `min_steps_per_game`
+// env.step calls each with auto-reset, returns total env steps; seconds via *secs.
+uint64_t orc_bench_rollout(int game_mode, uint32_t rule_bits, int skip_log, uint32_t n_games, uint64_t base_seed,
+                           uint64_t policy_seed, uint32_t steps_per_game, int threads, double* secs) {
+    std::vector<uint64_t> counts(threads, 0);
+    auto t0 = std::chrono::steady_clock::now();
+    auto work = [&](int tid) {
+        uint64_t total = 0;
+        for (uint32_t gi = tid; gi < n_games; gi += threads) {
+            GameState g((uint8_t)game_mode, skip_log != 0, base_seed + gi, 0, GameRule::from_bits(rule_bits));
+            g.env_reset(-1, nullptr, -1, nullptr, -1, -1);
+            for (uint32_t s = 0; s < steps_per_game; s++) {
+                if (g.is_done) {
+                    g.env_reset(-1, nullptr, -1, nullptr, -1, -1);
+                    continue;
+                }
+                std::map<uint8_t, Action> acts;
+                for (uint8_t p : g.active_players) {
+                    // faithful to the reference loop: legal actions are generated for the observation
+                    // (state/mod.rs:205) and again inside step() for validation (state/mod.rs:343)
+                    auto l = g._get_legal_actions_internal(p);
+                    if (l.empty()) continue;
+                    (void)g.observation_waits(p);
+                    uint64_t c = policy_choice(policy_seed, gi, g.step_count, p, (uint32_t)l.size());
+                    acts[p] = l[c];
+                }
+                g.step(acts);
+                total++;
+            }
+        }
+        counts[tid] = total;
+    };
+    std::vector<std::thread> th;
+    for (int t = 0; t < threads; t++) th.emplace_back(work, t);
+    for (auto& t : th) t.join();
+    auto t1 = std::chrono::steady_clock::now();
+    *secs = std::chrono::duration<double>(t1 - t0).count();
+    uint64_t sum = 0;
+    for (auto c : counts) sum += c;
+    return sum;
+}
+
+}  // extern "C"

@@ -1,0 +1,76 @@
+"""Pins the ORACLE hand mathematics against the reference's own golden vectors:
+riichienv-core/benches/data/agari_{4p,3p}.json (816 + 402 cases), hands_negative.json (200)
+and the score table of riichienv-core/tests/agari_correctness.rs:288-326.
+"""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from oracle import oracle
+from riichienv_amd import abi
+
+
+def _load(golden_dir, name):
+    with open(os.path.join(golden_dir, name)) as f:
+        return json.load(f)["cases"]
+
+
+@pytest.mark.parametrize("name", ["agari_4p.json", "agari_3p.json"])
+def test_agari_fixtures(golden_dir, name):
+    cases = _load(golden_dir, name)
+    res = oracle.eval_hands([abi.hand_case_from_fixture(c) for c in cases])
+    for i, (c, r) in enumerate(zip(cases, res)):
+        e = c["expected"]
+        assert r.is_agari == 1, (name, i)
+        assert bool(r.is_win) == e["is_win"], (name, i)
+        assert r.han == e["han"], (name, i, list(r.yaku[: r.n_yaku]), e)
+        assert r.fu == e["fu"], (name, i)
+        # the fixtures are in the reference's emission order: pin order, not only the set
+        assert list(r.yaku[: r.n_yaku]) == e["yaku"], (name, i)
+
+
+def test_negative_hands(golden_dir):
+    cases = _load(golden_dir, "hands_negative.json")
+    counts = np.array([c["counts_34"] for c in cases], dtype=np.uint8)
+    ag, tp, waits = oracle.agari_counts(counts)
+    L = oracle.lib()
+    for i, c in enumerate(cases):
+        total = int(counts[i].sum())
+        assert total in (13, 14)
+        assert ag[i] == 0, i  # negative = not a winning shape
+        if total == 13:
+            assert bool(tp[i]) == c["is_tenpai"], i
+            assert bool(L.orc_is_tenpai_free(counts[i].ctypes.data)) == c["is_tenpai"], i
+
+
+SCORE_ROWS = [  # riichienv-core/tests/agari_correctness.rs:288-326
+    (1, 30, 0, 0, 0, 4, 1000, 0, 0), (1, 30, 0, 1, 0, 4, 0, 500, 300), (3, 30, 1, 0, 0, 4, 5800, 0, 0),
+    (5, 0, 0, 0, 0, 4, 8000, 0, 0), (5, 0, 1, 1, 0, 4, 0, 0, 4000), (5, 0, 0, 1, 0, 4, 0, 4000, 2000),
+    (6, 0, 0, 0, 0, 4, 12000, 0, 0), (8, 0, 0, 0, 0, 4, 16000, 0, 0), (11, 0, 0, 0, 0, 4, 24000, 0, 0),
+    (13, 0, 0, 0, 0, 4, 32000, 0, 0), (13, 0, 1, 0, 0, 4, 48000, 0, 0), (13, 0, 0, 1, 0, 4, 0, 16000, 8000),
+    (13, 0, 1, 1, 0, 4, 0, 0, 16000), (26, 0, 0, 0, 0, 4, 64000, 0, 0), (26, 0, 1, 0, 0, 4, 96000, 0, 0),
+    (26, 0, 0, 1, 0, 4, 0, 32000, 16000), (26, 0, 1, 1, 0, 4, 0, 0, 32000), (26, 0, 0, 0, 2, 4, 64600, 0, 0),
+    (26, 0, 1, 1, 2, 4, 0, 200, 32200), (39, 0, 0, 0, 0, 4, 96000, 0, 0), (39, 0, 1, 1, 0, 4, 0, 0, 48000),
+    (52, 0, 0, 0, 0, 4, 128000, 0, 0), (65, 0, 0, 0, 0, 4, 160000, 0, 0), (13, 0, 0, 0, 0, 3, 32000, 0, 0),
+    (13, 0, 0, 1, 0, 3, 0, 16000, 8000), (26, 0, 0, 0, 0, 3, 64000, 0, 0), (26, 0, 1, 1, 0, 3, 0, 0, 32000),
+    # riichienv-core/src/tests.rs:78-90 (no kiriage mangan)
+    (4, 30, 0, 1, 0, 4, 0, 3900, 2000),
+]
+
+
+def test_score_rows():
+    r = np.array(SCORE_ROWS)
+    out = oracle.calculate_score(r[:, 0], r[:, 1], r[:, 2], r[:, 3], r[:, 4], r[:, 5])
+    assert (out[:, 1] == r[:, 6]).all()
+    assert (out[:, 2] == r[:, 7]).all()
+    assert (out[:, 3] == r[:, 8]).all()
+
+
+def test_tid_to_mjai():
+    # parser.rs:301-334; README.md:94 sample, tests/test_mjai_parity.py:12-18 ('5mr')
+    assert oracle.tid_to_mjai(16) == "5mr" and oracle.tid_to_mjai(52) == "5pr" and oracle.tid_to_mjai(88) == "5sr"
+    assert oracle.tid_to_mjai(0) == "1m" and oracle.tid_to_mjai(17) == "5m" and oracle.tid_to_mjai(35) == "9m"
+    assert oracle.tid_to_mjai(36) == "1p" and oracle.tid_to_mjai(107) == "9s"
+    assert [oracle.tid_to_mjai(108 + 4 * i) for i in range(7)] == list("ESWNPFC")

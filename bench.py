@@ -1,0 +1,117 @@
+#!/usr/bin/env python3
+"""bench.py — env.step()/s of the MI355X-native batched Riichi step path.
+
+One "step" = one batched env.step over every game of the shard (device-side RandomAgent policy,
+auto-reset of finished games), i.e. one launch of the step kernel.  Workload at N=1:
+BASELINE.json configs[2] — 65 536 parallel 4p-red-half games, RandomAgent, MJAI logging on.
+N>1: one process per GPU (torch.distributed.run), games sharded by global index, no collective
+on the data path (weak scaling: 65 536 games per GPU).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+B_STEP_4P = 1688          # algorithmic bytes per env.step per 4P game
+HBM_PEAK = 8.0e12         # B/s, /opt/skills/guides/MI355X_MICROARCH.md (HBM3E peak, spec)
+
+
+def cpu_baseline(game_mode, rule_bits, policy_seed, target_s=15.0):
+    """Oracle (CPU restatement of riichienv-core, kind="port") on the host cores: bounded sample."""
+    from oracle import oracle
+
+    threads = os.cpu_count() or 1
+    n_games = threads * 8
+    # calibrate with a short run, then size the sample for ~target_s seconds
+    steps, secs = oracle.bench_rollout(game_mode, rule_bits, False, n_games, 0, policy_seed, 200, threads)
+    rate = steps / max(secs, 1e-9)
+    per_game = int(max(200, min(200000, rate * target_s / n_games)))
+    steps, secs = oracle.bench_rollout(game_mode, rule_bits, False, n_games, 0, policy_seed, per_game, threads)
+    return {"value": steps / secs, "unit": "env.step/s", "cores": threads, "kind": "port",
+            "sample": f"{n_games} games x {per_game} steps, {threads} threads, {secs:.1f}s, "
+                      "oracle/ C++ restatement with MJAI logging on (Rust toolchain unavailable)"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=2000)
+    ap.add_argument("--warmup", type=int, default=200)
+    ap.add_argument("--games", type=int, default=65536, help="games per GPU")
+    ap.add_argument("--mode", type=int, default=2, help="0/1/2 = 4p-red-single/east/half")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+
+    from riichienv_amd import abi, vecenv
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the product path has no CPU fallback")
+
+    policy_seed = 0xC0FFEE
+    env = vecenv.VecRiichiEnv(args.games, game_mode=args.mode, seed=0, rule_bits=abi.RULE_TENHOU, device=local_rank,
+                              game_offset=rank * args.games, event_ring=64)
+    env.reset()
+    env.step_random(policy_seed, args.warmup, auto_reset=True)
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    barrier()
+    t0 = time.perf_counter()
+    r = env.bench_rollout(policy_seed, 0, args.steps)   # exactly K launches, HIP events on the kernel's stream
+    barrier()
+    t1 = time.perf_counter()
+    wall = t1 - t0
+    steps_local = float(r.env_steps)
+    if dist is not None:
+        t = torch.tensor([wall, steps_local], device="cuda", dtype=torch.float64)
+        tmax = t.clone()
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        wall = float(tmax[0])
+        steps_total = float(t[1])
+    else:
+        steps_total = steps_local
+
+    if rank == 0:
+        kernel_s = r.step_kernel_ms * 1e-3
+        achieved = B_STEP_4P * args.games / kernel_s
+        out = {
+            "metric": "env.step()/s (whole node) at 65 536 parallel 4p games; bit-exact MJAI parity",
+            "value": steps_total / wall, "unit": "env.step/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": wall * 1e3 / args.steps, "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
+            "config": {"workload": f"{args.games} parallel {['4p-red-single','4p-red-east','4p-red-half'][args.mode]} "
+                                   "games per GPU, device RandomAgent, auto-reset, MJAI logging on",
+                       "games_per_gpu": args.games, "sharding": "by game index, no collectives"},
+            "roofline": {"bound": "hbm", "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK, "traffic": None, "kernel": "k_step",
+                         "kernel_ms": r.step_kernel_ms, "bytes_per_launch": B_STEP_4P * args.games},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(args.mode, abi.RULE_TENHOU, policy_seed)
+        print(json.dumps(out))
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

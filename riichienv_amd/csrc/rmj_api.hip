@@ -1,0 +1,1018 @@
+// Kernels + C-ABI (include/riichi_mi355x.h) of the MI355X-native batched Riichi step path.
+// Build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -shared -fPIC rmj_api.hip -o libriichi_mi355x.so
+//
+// Launch geometry: 256-thread workgroups = 4 wavefronts = 4 games; grid = ceil(B/4) (16 384
+// workgroups at B = 65 536, i.e. 64 per CU: far above the ">>256 workgroups" rule).  The
+// blockIdx -> game map is launch-invariant, so a game is always served by the same XCD
+// (block b runs on XCD b % 8) and its 640-byte record is re-read from that XCD's L2 / MALL.
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/riichi_mi355x.h"
+#include "rmj_step.hip.h"
+
+using namespace rmj;
+
+#define WPB 4
+#define STEP_F_RANDOM 1u
+#define STEP_F_AUTORESET 2u
+
+struct BlockShared {
+    GState st[WPB];
+    WaveScratch x[WPB];
+};
+
+__device__ __forceinline__ void load_state(GState& S, const GState* src, int lane) {
+    if (lane < (int)(sizeof(GState) / 16)) reinterpret_cast<uint4*>(&S)[lane] = reinterpret_cast<const uint4*>(src)[lane];
+    wave_sync();
+}
+__device__ __forceinline__ void store_state(const GState& S, GState* dst, int lane) {
+    wave_sync();
+    if (lane < (int)(sizeof(GState) / 16)) reinterpret_cast<uint4*>(dst)[lane] = reinterpret_cast<const uint4*>(&S)[lane];
+}
+
+// RiichiEnv.reset defaults (env.rs:799-851) executed on device: reset() + _initialize_round(0,0,0,0,None,default scores)
+__device__ inline void device_env_reset_default(Ctx& c) {
+    c.S.ev_count = 0;  // GameState::reset clears the logs (state/mod.rs:171-187)
+    emit_simple(c, RMJ_EV_START_GAME);
+    const int32_t sc[4] = {25000, 25000, 25000, 25000};
+    shuffle_wall(c);
+    init_round(c, 0, 0, 0, 0, sc);
+}
+
+__global__ __launch_bounds__(256) void k_step(Env E, const uint64_t* __restrict__ actions, uint64_t policy_seed, uint32_t flags) {
+    __shared__ BlockShared sh;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const uint32_t g = blockIdx.x * WPB + wave;
+    if (g >= E.n_games) return;
+    GState& S = sh.st[wave];
+    load_state(S, E.core + g, lane);
+    Ctx c{S, E, sh.x[wave], g, lane, E.wall + (size_t)g * RMJ_WALL_STRIDE, E.legal + (size_t)g * 4 * RMJ_MAX_LEGAL};
+    if (S.is_done && (flags & STEP_F_AUTORESET)) {
+        device_env_reset_default(c);
+    } else {
+        uint64_t acts[4];
+        if (flags & STEP_F_RANDOM) {
+            // RandomAgent (random_agent.py:6-15), keyed per (game, step, seat): see rmj_step_random in the header
+            uint64_t gs = sm64(policy_seed + E.game_offset + g);
+            for (int p = 0; p < 4; p++) {
+                acts[p] = RMJ_NO_ACTION;
+                int n = E.nlegal[(size_t)g * 4 + p];
+                if (((S.active_mask >> p) & 1u) && n > 0 && !S.is_done) {
+                    uint64_t ch = sm64(gs + (uint64_t)S.step_count * 4ull + (uint64_t)p) % (uint64_t)n;
+                    acts[p] = c.Lg[p * RMJ_MAX_LEGAL + ch];
+                }
+            }
+        } else {
+            for (int p = 0; p < 4; p++) acts[p] = actions[(size_t)g * 4 + p];
+        }
+        step_game(c, acts);
+    }
+    finalize_outputs(c, true);
+    store_state(S, E.core + g, lane);
+}
+
+// Device policy without stepping (rmj_random_actions)
+__global__ void k_random_actions(Env E, uint64_t policy_seed, uint64_t* out) {
+    uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= E.n_games) return;
+    const GState& S = E.core[g];
+    uint64_t gs = sm64(policy_seed + E.game_offset + g);
+    for (int p = 0; p < 4; p++) {
+        uint64_t a = RMJ_NO_ACTION;
+        int n = E.nlegal[(size_t)g * 4 + p];
+        if (((S.active_mask >> p) & 1u) && n > 0 && !S.is_done) {
+            uint64_t ch = sm64(gs + (uint64_t)S.step_count * 4ull + (uint64_t)p) % (uint64_t)n;
+            a = E.legal[((size_t)g * 4 + p) * RMJ_MAX_LEGAL + ch];
+        }
+        out[(size_t)g * 4 + p] = a;
+    }
+}
+
+struct ResetArgs {
+    const uint8_t* select;
+    const uint8_t* walls;       // [n][136] reference orientation (draw order)
+    const uint8_t* oya;
+    const uint8_t* round_wind;
+    const int32_t* scores;      // [n][4]
+    const uint8_t* honba;
+    const uint32_t* kyotaku;
+    const uint64_t* seeds;      // ctor only
+    uint64_t base_seed;
+    uint32_t is_ctor;
+};
+
+__global__ __launch_bounds__(256) void k_reset(Env E, ResetArgs A) {
+    __shared__ BlockShared sh;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const uint32_t g = blockIdx.x * WPB + wave;
+    if (g >= E.n_games) return;
+    if (!A.is_ctor && A.select && !A.select[g]) return;
+    GState& S = sh.st[wave];
+    if (A.is_ctor) {
+        for (int i = lane; i < (int)(sizeof(GState) / 4); i += 64) reinterpret_cast<uint32_t*>(&S)[i] = 0u;
+        wave_sync();
+    } else {
+        load_state(S, E.core + g, lane);
+    }
+    Ctx c{S, E, sh.x[wave], g, lane, E.wall + (size_t)g * RMJ_WALL_STRIDE, E.legal + (size_t)g * 4 * RMJ_MAX_LEGAL};
+    int32_t sc[4] = {25000, 25000, 25000, 25000};
+    if (A.is_ctor) {  // GameState::new, state/mod.rs:98-167
+        S.wall_seed = A.seeds ? A.seeds[g] : A.base_seed + E.game_offset + g;
+        S.hand_index = 0;
+        S.last_error_pid = 0xFF;
+        S.pending_kan_pid = 0xFF;
+        S.riichi_pending = 0xFF;
+        S.drawn_tile = 0xFF;
+        S.last_discard_pid = 0xFF;
+        for (int p = 0; p < 4; p++) S.p[p].score = 25000;
+        emit_simple(c, RMJ_EV_START_GAME);
+        shuffle_wall(c);
+        init_round(c, 0, (int)E.ctor_round_wind, 0, 0, nullptr);
+    } else {          // env.rs:799-851
+        S.ev_count = 0;
+        emit_simple(c, RMJ_EV_START_GAME);
+        if (A.scores)
+            for (int p = 0; p < 4; p++) sc[p] = A.scores[(size_t)g * 4 + p];
+        if (A.walls) {
+            for (int i = lane; i < 136; i += 64) c.X.tiles[i] = A.walls[(size_t)g * 136 + (135 - i)];  // load_wall: reverse
+            wave_sync();
+        } else {
+            shuffle_wall(c);
+        }
+        init_round(c, A.oya ? A.oya[g] : 0, A.round_wind ? A.round_wind[g] : 0, A.honba ? A.honba[g] : 0,
+                   A.kyotaku ? A.kyotaku[g] : 0u, sc);
+    }
+    finalize_outputs(c, true);
+    store_state(S, E.core + g, lane);
+}
+
+// recompute observation outputs of one game after rmj_poke_state
+__global__ __launch_bounds__(64) void k_refresh(Env E, uint32_t g) {
+    __shared__ GState st;
+    __shared__ WaveScratch x;
+    const int lane = threadIdx.x & 63;
+    load_state(st, E.core + g, lane);
+    Ctx c{st, E, x, g, lane, E.wall + (size_t)g * RMJ_WALL_STRIDE, E.legal + (size_t)g * 4 * RMJ_MAX_LEGAL};
+    bool keep = st.phase == RMJ_WAIT_RESPONSE && st.pending_kan_pid != 0xFF;  // chankan claims are not reconstructible
+    if (!keep) {
+        finalize_outputs(c, false);
+        store_state(st, E.core + g, lane);
+    }
+}
+
+__global__ void k_sum_steps(const GState* core, uint32_t n, unsigned long long* out) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    unsigned long long v = 0;
+    for (; i < n; i += gridDim.x * blockDim.x) v += core[i].step_count;
+    for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
+    if ((threadIdx.x & 63) == 0 && v) atomicAdd(out, v);
+}
+__global__ void k_gather_steps(const GState* core, uint32_t n, uint64_t* out) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = core[i].step_count;
+}
+__global__ void k_gather_scores(const GState* core, uint32_t n, int32_t* out, uint32_t* evc) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) {
+        for (int p = 0; p < 4; p++) out[(size_t)i * 4 + p] = core[i].p[p].score;
+        evc[i] = core[i].ev_count;
+    }
+}
+
+// ---------------------------------------------------------------- batched hand math kernels (one wave per case)
+__device__ inline MeldAgg agg_from_views(const RmjHandCase& hc) {
+    MeldAgg m;
+    m.n = hc.n_melds > 4 ? 4 : hc.n_melds;
+    m.n_kan = m.n_ankan = m.n_nonchi = 0;
+    m.menzen = true;
+    m.types = 0;
+    m.fu = 0;
+    m.aka = 0;
+    for (int i = 0; i < 4; i++) {
+        m.mtypes[i] = 0;
+        m.mtype[i] = 0;
+        m.t0[i] = 0;
+        if (i < m.n) {
+            const RmjMeldView& v = hc.melds[i];
+            int nt = v.n_tiles > 4 ? 4 : v.n_tiles;
+            uint64_t mm = 0;
+            int tmin = 99;
+            for (int k = 0; k < nt; k++) {
+                int t = v.tiles[k];
+                mm |= 1ull << (t >> 2);
+                m.aka += is_aka(t);
+                tmin = min(tmin, t >> 2);
+            }
+            m.mtypes[i] = mm;
+            m.types |= mm;
+            m.mtype[i] = v.meld_type;
+            int t0 = (v.meld_type == RMJ_MELD_CHI) ? tmin : (v.tiles[0] >> 2);  // chi tiles are sorted (hand_evaluator.rs:63-65)
+            m.t0[i] = (uint8_t)t0;
+            if (v.opened) m.menzen = false;
+            bool kan = v.meld_type >= RMJ_MELD_DAIMINKAN;
+            m.n_kan += kan;
+            m.n_ankan += (v.meld_type == RMJ_MELD_ANKAN);
+            m.n_nonchi += (v.meld_type != RMJ_MELD_CHI);
+            bool trip = nt >= 3 && v.meld_type != RMJ_MELD_CHI && (v.tiles[0] >> 2) == (v.tiles[1] >> 2);
+            if (v.meld_type == RMJ_MELD_CHI && nt >= 3) {  // sorted types: equal first two only for degenerate input
+                int a = 99, b = 99;
+                for (int k = 0; k < nt; k++) {
+                    int t = v.tiles[k] >> 2;
+                    if (t < a) { b = a; a = t; } else if (t < b) b = t;
+                }
+                trip = a == b;
+            }
+            if (trip) {
+                int f = v.opened ? 2 : 4;
+                if (t_is_terminal(t0)) f *= 2;
+                if (kan) f *= 4;
+                m.fu += f;
+            }
+        }
+    }
+    return m;
+}
+
+__global__ __launch_bounds__(256) void k_eval_hands(const RmjHandCase* cases, uint32_t n, RmjHandResult* out) {
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const uint32_t k = blockIdx.x * WPB + wave;
+    if (k >= n) return;
+    const RmjHandCase& hc = cases[k];
+    CalcIn in;
+    in.ma = agg_from_views(hc);
+    PH full = {0, 0, 0, 0};
+    int aka = in.ma.aka;
+    int nt = hc.n_tiles > 14 ? 14 : hc.n_tiles;
+    for (int j = 0; j < nt; j++) {
+        ph_add(full, hc.tiles[j] >> 2);
+        aka += is_aka(hc.tiles[j]);
+    }
+    PH hand = full;
+    for (int i = 0; i < in.ma.n; i++) {  // HandEvaluator::new, hand_evaluator.rs:43-62
+        const RmjMeldView& v = hc.melds[i];
+        if (v.meld_type >= RMJ_MELD_DAIMINKAN) {
+            int t34 = v.tiles[0] >> 2;
+            if (ph_cnt(hand, t34) == 4) ph_sub(hand, t34);
+        }
+        for (int q = 0; q < v.n_tiles && q < 4; q++) ph_add(full, v.tiles[q] >> 2);
+    }
+    const bool sanma = hc.is_sanma != 0;
+    const int total = ph_total(hand) + 3 * in.ma.n;
+    uint64_t waits = 0;
+    if (total == 13) waits = wave_waits(hand, lane);
+    const int win34 = hc.win_tile >> 2;
+    PH h14 = hand, f14 = full;
+    if (total == 13) {
+        ph_add(h14, win34);
+        ph_add(f14, win34);
+        aka += is_aka(hc.win_tile);
+    }
+    RmjHandResult r;
+    memset(&r, 0, sizeof(r));
+    r.waits = waits;
+    r.is_tenpai = waits != 0ull;
+    bool ag = is_agari(h14);
+    r.is_agari = ag;
+    if (ag) {
+        int dora = 0, ura = 0;
+        for (int q = 0; q < hc.n_dora && q < 5; q++) {
+            int nt34 = next_dora34(hc.dora[q] >> 2, sanma);
+            dora += ph_cnt(f14, nt34);
+            if (sanma && nt34 == 30) dora += hc.kita_count;
+        }
+        for (int q = 0; q < hc.n_ura && q < 5; q++) {
+            int nt34 = next_dora34(hc.ura[q] >> 2, sanma);
+            ura += ph_cnt(f14, nt34);
+            if (sanma && nt34 == 30) ura += hc.kita_count;
+        }
+        in.hand14 = h14;
+        in.win34 = win34;
+        uint32_t cf = 0;
+        if (hc.tsumo) cf |= CF_TSUMO;
+        if (hc.riichi) cf |= CF_RIICHI;
+        if (hc.double_riichi) cf |= CF_DOUBLE_RIICHI;
+        if (hc.ippatsu) cf |= CF_IPPATSU;
+        if (hc.haitei) cf |= CF_HAITEI;
+        if (hc.houtei) cf |= CF_HOUTEI;
+        if (hc.rinshan) cf |= CF_RINSHAN;
+        if (hc.chankan) cf |= CF_CHANKAN;
+        if (hc.tsumo_first_turn) cf |= CF_FIRST_TURN;
+        in.cf = cf;
+        in.dora = dora & 0xFF; in.aka = aka & 0xFF; in.ura = ura & 0xFF;
+        in.nuki = sanma ? hc.kita_count : 0;
+        in.round_wind34 = 27 + (hc.round_wind & 3);
+        in.seat_wind34 = 27 + (hc.player_wind & 3);
+        in.sanma = sanma;
+        in.honba = hc.honba;
+        CalcOut o = wave_calc(in, lane);
+        r.is_win = o.is_win;
+        r.yakuman = o.yakuman;
+        r.has_win_shape = 1;
+        r.han = (uint32_t)o.han;
+        r.fu = (uint32_t)o.fu;
+        r.ron_agari = o.ron;
+        r.tsumo_agari_oya = o.tsumo_oya;
+        r.tsumo_agari_ko = o.tsumo_ko;
+        r.n_yaku = (uint8_t)yaku_list(o.kind, o.ym, r.yaku, 20);
+    }
+    if (lane == 0) out[k] = r;
+}
+
+__global__ __launch_bounds__(256) void k_agari_counts(const uint8_t* counts, uint32_t n, uint8_t* agari, uint8_t* tenpai, uint64_t* waits) {
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const uint32_t k = blockIdx.x * WPB + wave;
+    if (k >= n) return;
+    PH h = {0, 0, 0, 0};
+    for (int t = 0; t < 34; t++) {
+        uint32_t cnt = counts[(size_t)k * 34 + t];
+        int s = t_suit(t);
+        ph_addv(h, s, (cnt & 7u) << (3 * (t - 9 * s)));
+    }
+    bool ag = is_agari(h);
+    uint64_t w = 0;
+    if (ph_total(h) == 13) w = wave_waits(h, lane);
+    if (lane == 0) {
+        agari[k] = ag;
+        tenpai[k] = w != 0ull;
+        waits[k] = w;
+    }
+}
+
+__global__ void k_score(const uint8_t* han, const uint8_t* fu, const uint8_t* oya, const uint8_t* tsumo, const uint32_t* honba,
+                        const uint8_t* np, uint32_t n, uint32_t* out) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    ScoreOut s = calc_score(han[i], fu[i], oya[i] != 0, tsumo[i] != 0, honba[i], np[i]);
+    out[4 * i] = s.total; out[4 * i + 1] = s.ron; out[4 * i + 2] = s.tsumo_oya; out[4 * i + 3] = s.tsumo_ko;
+}
+
+// ================================================================= host side
+static thread_local std::string g_err;
+static int fail(int code, const std::string& msg) {
+    g_err = msg;
+    return code;
+}
+#define HIPCHK(x)                                                                          \
+    do {                                                                                   \
+        hipError_t e_ = (x);                                                               \
+        if (e_ != hipSuccess) return fail(RMJ_ERR_HIP, std::string(#x) + ": " + hipGetErrorString(e_)); \
+    } while (0)
+
+struct rmj_env {
+    RmjConfig cfg;
+    Env d;
+    hipStream_t stream = nullptr;
+    uint64_t* d_actions = nullptr;
+    unsigned long long* d_counter = nullptr;
+    uint32_t ring = 0;
+};
+
+static int ensure_device(int device) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return fail(RMJ_ERR_NO_DEVICE, "no HIP device available (this library has no CPU fallback)");
+    if (device < 0 || device >= n) return fail(RMJ_ERR_NO_DEVICE, "device ordinal out of range");
+    if (hipSetDevice(device) != hipSuccess) return fail(RMJ_ERR_NO_DEVICE, "hipSetDevice failed");
+    return RMJ_OK;
+}
+static inline dim3 game_grid(uint32_t n) { return dim3((n + WPB - 1) / WPB); }
+
+template <typename T>
+static int upload(const T* src, size_t count, T** dst) {
+    *dst = nullptr;
+    if (!src) return RMJ_OK;
+    HIPCHK(hipMalloc(dst, count * sizeof(T)));
+    HIPCHK(hipMemcpy(*dst, src, count * sizeof(T), hipMemcpyHostToDevice));
+    return RMJ_OK;
+}
+
+extern "C" {
+
+const char* rmj_version(void) { return "riichi_mi355x 0.1 (gfx950)"; }
+const char* rmj_last_error(void) { return g_err.c_str(); }
+int rmj_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+int rmj_create(const RmjConfig* cfg, rmj_handle* out) {
+    if (!cfg || !out || cfg->n_games == 0) return fail(RMJ_ERR_ARG, "bad config");
+    if (cfg->game_mode > 2) return fail(RMJ_ERR_ARG, "game_mode 3..5 (sanma) is not built in this round");
+    int rc = ensure_device(cfg->device);
+    if (rc) return rc;
+    rmj_env* h = new rmj_env();
+    h->cfg = *cfg;
+    uint32_t ring = cfg->event_ring ? cfg->event_ring : 64;
+    uint32_t r2 = 64;
+    while (r2 < ring) r2 <<= 1;
+    h->ring = r2;
+    const size_t B = cfg->n_games;
+    Env& d = h->d;
+    memset(&d, 0, sizeof(d));
+    HIPCHK(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
+    HIPCHK(hipMalloc(&d.core, B * sizeof(GState)));
+    HIPCHK(hipMalloc(&d.wall, B * RMJ_WALL_STRIDE));
+    HIPCHK(hipMalloc(&d.legal, B * 4 * RMJ_MAX_LEGAL * sizeof(uint64_t)));
+    HIPCHK(hipMalloc(&d.nlegal, B * 4));
+    HIPCHK(hipMalloc(&d.mask, B * 4 * 82));
+    HIPCHK(hipMalloc(&d.waits, B * 4 * sizeof(uint64_t)));
+    HIPCHK(hipMalloc(&d.status, B * sizeof(uint32_t)));
+    HIPCHK(hipMalloc(&d.events, B * (size_t)r2 * sizeof(RmjEvent)));
+    HIPCHK(hipMalloc(&h->d_actions, B * 4 * sizeof(uint64_t)));
+    HIPCHK(hipMalloc(&h->d_counter, sizeof(unsigned long long)));
+    HIPCHK(hipMemsetAsync(d.legal, 0, B * 4 * RMJ_MAX_LEGAL * sizeof(uint64_t), h->stream));
+    HIPCHK(hipMemsetAsync(d.nlegal, 0, B * 4, h->stream));
+    HIPCHK(hipMemsetAsync(d.events, 0, B * (size_t)r2 * sizeof(RmjEvent), h->stream));
+    d.ring_mask = r2 - 1;
+    d.n_games = cfg->n_games;
+    d.rule_bits = cfg->rule_bits;
+    d.game_mode = cfg->game_mode;
+    d.skip_log = cfg->skip_mjai_logging;
+    d.ctor_round_wind = cfg->round_wind;
+    d.game_offset = cfg->game_offset;
+    ResetArgs A;
+    memset(&A, 0, sizeof(A));
+    A.is_ctor = 1;
+    A.base_seed = cfg->base_seed;
+    uint64_t* d_seeds = nullptr;
+    if (cfg->seeds) {
+        HIPCHK(hipMalloc(&d_seeds, B * sizeof(uint64_t)));
+        HIPCHK(hipMemcpy(d_seeds, cfg->seeds, B * sizeof(uint64_t), hipMemcpyHostToDevice));
+        A.seeds = d_seeds;
+    }
+    hipLaunchKernelGGL(k_reset, game_grid(cfg->n_games), dim3(256), 0, h->stream, d, A);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(h->stream));
+    if (d_seeds) hipFree(d_seeds);
+    h->cfg.seeds = nullptr;
+    *out = h;
+    return RMJ_OK;
+}
+
+int rmj_destroy(rmj_handle h) {
+    if (!h) return RMJ_OK;
+    hipSetDevice(h->cfg.device);
+    hipStreamSynchronize(h->stream);
+    hipFree(h->d.core); hipFree(h->d.wall); hipFree(h->d.legal); hipFree(h->d.nlegal); hipFree(h->d.mask);
+    hipFree(h->d.waits); hipFree(h->d.status); hipFree(h->d.events); hipFree(h->d_actions); hipFree(h->d_counter);
+    hipStreamDestroy(h->stream);
+    delete h;
+    return RMJ_OK;
+}
+
+int rmj_reset(rmj_handle h, const uint8_t* select, const uint8_t* walls, const uint8_t* oya, const uint8_t* round_wind,
+              const int32_t* scores, const uint8_t* honba, const uint32_t* kyotaku) {
+    if (!h) return fail(RMJ_ERR_ARG, "null handle");
+    HIPCHK(hipSetDevice(h->cfg.device));
+    const size_t B = h->cfg.n_games;
+    uint8_t *d_sel, *d_walls, *d_oya, *d_rw, *d_honba;
+    int32_t* d_sc;
+    uint32_t* d_ky;
+    int rc;
+    if ((rc = upload(select, B, &d_sel))) return rc;
+    if ((rc = upload(walls, B * 136, &d_walls))) return rc;
+    if ((rc = upload(oya, B, &d_oya))) return rc;
+    if ((rc = upload(round_wind, B, &d_rw))) return rc;
+    if ((rc = upload(scores, B * 4, &d_sc))) return rc;
+    if ((rc = upload(honba, B, &d_honba))) return rc;
+    if ((rc = upload(kyotaku, B, &d_ky))) return rc;
+    ResetArgs A;
+    memset(&A, 0, sizeof(A));
+    A.select = d_sel; A.walls = d_walls; A.oya = d_oya; A.round_wind = d_rw; A.scores = d_sc; A.honba = d_honba; A.kyotaku = d_ky;
+    hipLaunchKernelGGL(k_reset, game_grid(h->cfg.n_games), dim3(256), 0, h->stream, h->d, A);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(h->stream));
+    hipFree(d_sel); hipFree(d_walls); hipFree(d_oya); hipFree(d_rw); hipFree(d_sc); hipFree(d_honba); hipFree(d_ky);
+    return RMJ_OK;
+}
+
+int rmj_step_device(rmj_handle h, const rmj_action_t* d_actions) {
+    if (!h || !d_actions) return fail(RMJ_ERR_ARG, "null argument");
+    HIPCHK(hipSetDevice(h->cfg.device));
+    hipLaunchKernelGGL(k_step, game_grid(h->cfg.n_games), dim3(256), 0, h->stream, h->d, (const uint64_t*)d_actions, 0ull, 0u);
+    HIPCHK(hipGetLastError());
+    return RMJ_OK;
+}
+int rmj_step(rmj_handle h, const rmj_action_t* actions) {
+    if (!h || !actions) return fail(RMJ_ERR_ARG, "null argument");
+    HIPCHK(hipSetDevice(h->cfg.device));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    HIPCHK(hipMemcpy(h->d_actions, actions, (size_t)h->cfg.n_games * 4 * sizeof(uint64_t), hipMemcpyHostToDevice));
+    return rmj_step_device(h, h->d_actions);
+}
+int rmj_step_random(rmj_handle h, uint64_t policy_seed, uint32_t n_steps, int auto_reset) {
+    if (!h) return fail(RMJ_ERR_ARG, "null handle");
+    HIPCHK(hipSetDevice(h->cfg.device));
+    uint32_t flags = STEP_F_RANDOM | (auto_reset ? STEP_F_AUTORESET : 0u);
+    for (uint32_t s = 0; s < n_steps; s++)
+        hipLaunchKernelGGL(k_step, game_grid(h->cfg.n_games), dim3(256), 0, h->stream, h->d, (const uint64_t*)nullptr, policy_seed, flags);
+    HIPCHK(hipGetLastError());
+    return RMJ_OK;
+}
+int rmj_random_actions(rmj_handle h, uint64_t policy_seed, rmj_action_t* actions) {
+    if (!h || !actions) return fail(RMJ_ERR_ARG, "null argument");
+    HIPCHK(hipSetDevice(h->cfg.device));
+    uint32_t n = h->cfg.n_games;
+    hipLaunchKernelGGL(k_random_actions, dim3((n + 255) / 256), dim3(256), 0, h->stream, h->d, policy_seed, h->d_actions);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(h->stream));
+    HIPCHK(hipMemcpy(actions, h->d_actions, (size_t)n * 4 * sizeof(uint64_t), hipMemcpyDeviceToHost));
+    return RMJ_OK;
+}
+
+#define SYNC_FETCH(dst, src, bytes)                                   \
+    do {                                                              \
+        HIPCHK(hipSetDevice(h->cfg.device));                          \
+        HIPCHK(hipStreamSynchronize(h->stream));                      \
+        HIPCHK(hipMemcpy(dst, src, bytes, hipMemcpyDeviceToHost));    \
+    } while (0)
+
+int rmj_get_status(rmj_handle h, uint8_t* active_mask, uint8_t* phase, uint8_t* done) {
+    if (!h) return fail(RMJ_ERR_ARG, "null handle");
+    std::vector<uint32_t> st(h->cfg.n_games);
+    SYNC_FETCH(st.data(), h->d.status, st.size() * 4);
+    for (size_t i = 0; i < st.size(); i++) {
+        if (active_mask) active_mask[i] = st[i] & 0xFF;
+        if (phase) phase[i] = (st[i] >> 8) & 0xFF;
+        if (done) done[i] = (st[i] >> 16) & 0xFF;
+    }
+    return RMJ_OK;
+}
+int rmj_get_legal(rmj_handle h, rmj_action_t* legal, uint8_t* counts) {
+    if (!h) return fail(RMJ_ERR_ARG, "null handle");
+    size_t B = h->cfg.n_games;
+    if (legal) SYNC_FETCH(legal, h->d.legal, B * 4 * RMJ_MAX_LEGAL * sizeof(uint64_t));
+    if (counts) SYNC_FETCH(counts, h->d.nlegal, B * 4);
+    return RMJ_OK;
+}
+int rmj_get_mask(rmj_handle h, uint8_t* mask) {
+    if (!h || !mask) return fail(RMJ_ERR_ARG, "null argument");
+    SYNC_FETCH(mask, h->d.mask, (size_t)h->cfg.n_games * 4 * 82);
+    return RMJ_OK;
+}
+int rmj_get_waits(rmj_handle h, uint64_t* waits) {
+    if (!h || !waits) return fail(RMJ_ERR_ARG, "null argument");
+    SYNC_FETCH(waits, h->d.waits, (size_t)h->cfg.n_games * 4 * sizeof(uint64_t));
+    return RMJ_OK;
+}
+static int fetch_scores(rmj_handle h, std::vector<int32_t>& sc, std::vector<uint32_t>& evc) {
+    uint32_t n = h->cfg.n_games;
+    int32_t* d_sc;
+    uint32_t* d_ev;
+    HIPCHK(hipSetDevice(h->cfg.device));
+    HIPCHK(hipMalloc(&d_sc, (size_t)n * 16));
+    HIPCHK(hipMalloc(&d_ev, (size_t)n * 4));
+    hipLaunchKernelGGL(k_gather_scores, dim3((n + 255) / 256), dim3(256), 0, h->stream, h->d.core, n, d_sc, d_ev);
+    sc.resize((size_t)n * 4);
+    evc.resize(n);
+    HIPCHK(hipStreamSynchronize(h->stream));
+    HIPCHK(hipMemcpy(sc.data(), d_sc, (size_t)n * 16, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(evc.data(), d_ev, (size_t)n * 4, hipMemcpyDeviceToHost));
+    hipFree(d_sc);
+    hipFree(d_ev);
+    return RMJ_OK;
+}
+int rmj_get_scores(rmj_handle h, int32_t* scores) {
+    if (!h || !scores) return fail(RMJ_ERR_ARG, "null argument");
+    std::vector<int32_t> sc;
+    std::vector<uint32_t> ev;
+    int rc = fetch_scores(h, sc, ev);
+    if (rc) return rc;
+    memcpy(scores, sc.data(), sc.size() * 4);
+    return RMJ_OK;
+}
+int rmj_get_ranks(rmj_handle h, uint8_t* ranks) {  // env.rs:673-689
+    if (!h || !ranks) return fail(RMJ_ERR_ARG, "null argument");
+    std::vector<int32_t> sc;
+    std::vector<uint32_t> ev;
+    int rc = fetch_scores(h, sc, ev);
+    if (rc) return rc;
+    for (uint32_t g = 0; g < h->cfg.n_games; g++)
+        for (int a = 0; a < 4; a++) {
+            int r = 1;
+            for (int b = 0; b < 4; b++)
+                if (sc[g * 4 + b] > sc[g * 4 + a] || (sc[g * 4 + b] == sc[g * 4 + a] && b < a)) r++;
+            ranks[g * 4 + a] = (uint8_t)r;
+        }
+    return RMJ_OK;
+}
+int rmj_get_event_counts(rmj_handle h, uint32_t* counts) {
+    if (!h || !counts) return fail(RMJ_ERR_ARG, "null argument");
+    std::vector<int32_t> sc;
+    std::vector<uint32_t> ev;
+    int rc = fetch_scores(h, sc, ev);
+    if (rc) return rc;
+    memcpy(counts, ev.data(), ev.size() * 4);
+    return RMJ_OK;
+}
+int rmj_get_step_counts(rmj_handle h, uint64_t* steps) {
+    if (!h || !steps) return fail(RMJ_ERR_ARG, "null argument");
+    uint32_t n = h->cfg.n_games;
+    uint64_t* d;
+    HIPCHK(hipSetDevice(h->cfg.device));
+    HIPCHK(hipMalloc(&d, (size_t)n * 8));
+    hipLaunchKernelGGL(k_gather_steps, dim3((n + 255) / 256), dim3(256), 0, h->stream, h->d.core, n, d);
+    HIPCHK(hipStreamSynchronize(h->stream));
+    HIPCHK(hipMemcpy(steps, d, (size_t)n * 8, hipMemcpyDeviceToHost));
+    hipFree(d);
+    return RMJ_OK;
+}
+int rmj_total_steps(rmj_handle h, uint64_t* total) {
+    if (!h || !total) return fail(RMJ_ERR_ARG, "null argument");
+    HIPCHK(hipSetDevice(h->cfg.device));
+    HIPCHK(hipMemsetAsync(h->d_counter, 0, 8, h->stream));
+    hipLaunchKernelGGL(k_sum_steps, dim3(512), dim3(256), 0, h->stream, h->d.core, h->cfg.n_games, h->d_counter);
+    unsigned long long v = 0;
+    HIPCHK(hipStreamSynchronize(h->stream));
+    HIPCHK(hipMemcpy(&v, h->d_counter, 8, hipMemcpyDeviceToHost));
+    *total = v;
+    return RMJ_OK;
+}
+
+int rmj_get_events(rmj_handle h, uint32_t game, uint32_t first, uint32_t max_events, RmjEvent* out, uint32_t* n_out) {
+    if (!h || !out || !n_out) return fail(RMJ_ERR_ARG, "null argument");
+    if (game >= h->cfg.n_games) return fail(RMJ_ERR_RANGE, "game index out of range");
+    GState st;
+    SYNC_FETCH(&st, h->d.core + game, sizeof(GState));
+    uint32_t total = st.ev_count;
+    uint32_t lo = total > h->ring ? total - h->ring : 0;
+    if (first < lo) return fail(RMJ_ERR_RANGE, "requested events already overwritten in the ring (create with a larger event_ring)");
+    uint32_t n = 0;
+    std::vector<RmjEvent> ring(h->ring);
+    HIPCHK(hipMemcpy(ring.data(), h->d.events + (size_t)game * h->ring, (size_t)h->ring * sizeof(RmjEvent), hipMemcpyDeviceToHost));
+    for (uint32_t i = first; i < total && n < max_events; i++) out[n++] = ring[i & (h->ring - 1)];
+    *n_out = n;
+    return RMJ_OK;
+}
+
+// ---- state peek / poke ------------------------------------------------------------------
+static void to_view(const GState& S, const uint8_t* W, RmjStateView* v) {
+    memset(v, 0, sizeof(*v));
+    int len = (int)S.live_end - (int)S.rinshan_count;
+    if (len < 0) len = 0;
+    v->wall_len = (uint8_t)len;
+    for (int i = 0; i < len && i < 136; i++) v->wall[i] = W[S.rinshan_count + i];
+    v->n_dora = S.n_dora;
+    for (int i = 0; i < 5; i++) v->dora[i] = i < S.n_dora ? S.dora[i] : 0;
+    v->rinshan_draw_count = S.rinshan_count;
+    v->pending_kan_dora_count = S.pending_kan_dora;
+    v->drawable_count = S.drawable_count;
+    v->wall_seed = S.wall_seed;
+    v->hand_index = S.hand_index;
+    for (int p = 0; p < 4; p++) {
+        const PState& P = S.p[p];
+        RmjPlayerView& q = v->players[p];
+        q.hand_len = P.hand_len;
+        for (int i = 0; i < P.hand_len && i < 14; i++) q.hand[i] = P.hand[i];
+        q.n_melds = P.n_melds;
+        for (int m = 0; m < P.n_melds && m < 4; m++) {
+            RmjMeldView& mv = q.melds[m];
+            mv.meld_type = P.meld_type[m];
+            mv.n_tiles = P.meld_type[m] >= RMJ_MELD_DAIMINKAN ? 4 : 3;
+            for (int k = 0; k < mv.n_tiles; k++) mv.tiles[k] = P.meld_tiles[m][k];
+            mv.opened = P.meld_type[m] != RMJ_MELD_ANKAN;
+            mv.from_who = P.meld_from[m] == 0xFF ? -1 : (int8_t)P.meld_from[m];
+            mv.called_tile = P.meld_called[m] == 0xFF ? -1 : (int16_t)P.meld_called[m];
+        }
+        q.n_discards = P.n_discards;
+        for (int i = 0; i < P.n_discards && i < RMJ_MAX_DISCARDS; i++) q.discards[i] = P.discards[i];
+        q.discard_from_hand_bits = P.discard_from_hand_bits;
+        q.discard_is_riichi_bits = P.discard_is_riichi_bits;
+        q.riichi_declaration_index = P.riichi_decl_idx == 0xFF ? -1 : (int8_t)P.riichi_decl_idx;
+        q.score = P.score;
+        q.score_delta = P.score_delta;
+        q.riichi_declared = (P.flags & PF_RIICHI_DECLARED) != 0;
+        q.riichi_stage = (P.flags & PF_RIICHI_STAGE) != 0;
+        q.double_riichi_declared = (P.flags & PF_DOUBLE_RIICHI) != 0;
+        q.missed_agari_riichi = (P.flags & PF_MISSED_RIICHI) != 0;
+        q.missed_agari_doujun = (P.flags & PF_MISSED_DOUJUN) != 0;
+        q.nagashi_eligible = (P.flags & PF_NAGASHI) != 0;
+        q.ippatsu_cycle = (P.flags & PF_IPPATSU) != 0;
+        q.pao_daisangen = P.pao37 == 0xFF ? -1 : (int8_t)P.pao37;
+        q.pao_daisuushi = P.pao50 == 0xFF ? -1 : (int8_t)P.pao50;
+        q.n_forbidden = P.n_forbidden;
+        for (int i = 0; i < P.n_forbidden && i < 2; i++) q.forbidden[i] = P.forbidden[i];
+        q.riichi_sutehai = P.riichi_sutehai == 0xFF ? -1 : (int16_t)P.riichi_sutehai;
+        q.last_tedashi = P.last_tedashi == 0xFF ? -1 : (int16_t)P.last_tedashi;
+    }
+    v->current_player = S.current_player;
+    v->is_done = S.is_done;
+    v->needs_tsumo = S.needs_tsumo;
+    v->phase = S.phase;
+    v->active_mask = S.active_mask;
+    v->turn_count = S.turn_count;
+    v->riichi_sticks = S.riichi_sticks;
+    v->last_discard_pid = S.last_discard_pid == 0xFF ? -1 : (int16_t)S.last_discard_pid;
+    v->last_discard_tile = S.last_discard_pid == 0xFF ? -1 : (int16_t)S.last_discard_tile;
+    v->pending_kan_pid = S.pending_kan_pid == 0xFF ? -1 : (int16_t)S.pending_kan_pid;
+    v->pending_kan_action = S.pending_kan_pid == 0xFF ? 0 : S.pending_kan_action;
+    v->oya = S.oya;
+    v->honba = S.honba;
+    v->kyoku_idx = S.kyoku_idx;
+    v->round_wind = S.round_wind;
+    v->is_rinshan_flag = S.is_rinshan;
+    v->is_first_turn = S.is_first_turn;
+    v->riichi_pending_acceptance = S.riichi_pending == 0xFF ? -1 : (int16_t)S.riichi_pending;
+    v->drawn_tile = S.drawn_tile == 0xFF ? -1 : (int16_t)S.drawn_tile;
+    v->last_error_pid = S.last_error_pid == 0xFF ? -1 : (int16_t)S.last_error_pid;
+}
+
+int rmj_peek_state(rmj_handle h, uint32_t game, RmjStateView* out) {
+    if (!h || !out) return fail(RMJ_ERR_ARG, "null argument");
+    if (game >= h->cfg.n_games) return fail(RMJ_ERR_RANGE, "game index out of range");
+    GState st;
+    uint8_t W[RMJ_WALL_STRIDE];
+    SYNC_FETCH(&st, h->d.core + game, sizeof(GState));
+    HIPCHK(hipMemcpy(W, h->d.wall + (size_t)game * RMJ_WALL_STRIDE, RMJ_WALL_STRIDE, hipMemcpyDeviceToHost));
+    to_view(st, W, out);
+    return RMJ_OK;
+}
+
+int rmj_poke_state(rmj_handle h, uint32_t game, const RmjStateView* v) {
+    if (!h || !v) return fail(RMJ_ERR_ARG, "null argument");
+    if (game >= h->cfg.n_games) return fail(RMJ_ERR_RANGE, "game index out of range");
+    GState S;
+    uint8_t W[RMJ_WALL_STRIDE];
+    SYNC_FETCH(&S, h->d.core + game, sizeof(GState));
+    HIPCHK(hipMemcpy(W, h->d.wall + (size_t)game * RMJ_WALL_STRIDE, RMJ_WALL_STRIDE, hipMemcpyDeviceToHost));
+    S.rinshan_count = v->rinshan_draw_count;
+    int len = v->wall_len;
+    if (S.rinshan_count + len > 136) return fail(RMJ_ERR_ARG, "wall too long");
+    for (int i = 0; i < len; i++) W[S.rinshan_count + i] = v->wall[i];
+    S.live_end = (uint8_t)(S.rinshan_count + len);
+    S.n_dora = v->n_dora > 5 ? 5 : v->n_dora;
+    for (int i = 0; i < S.n_dora; i++) S.dora[i] = v->dora[i];
+    S.pending_kan_dora = v->pending_kan_dora_count;
+    S.drawable_count = v->drawable_count;
+    S.hand_index = (uint32_t)v->hand_index;
+    for (int p = 0; p < 4; p++) {
+        PState& P = S.p[p];
+        const RmjPlayerView& q = v->players[p];
+        if (q.hand_len > 14 || q.n_melds > 4 || q.n_discards > RMJ_MAX_DISCARDS) return fail(RMJ_ERR_ARG, "player view out of range");
+        P.hand_len = q.hand_len;
+        for (int i = 0; i < q.hand_len; i++) P.hand[i] = q.hand[i];
+        P.n_melds = q.n_melds;
+        for (int m = 0; m < q.n_melds; m++) {
+            const RmjMeldView& mv = q.melds[m];
+            P.meld_type[m] = mv.meld_type;
+            uint8_t t[4] = {0, 0, 0, 0};
+            int nt = mv.n_tiles > 4 ? 4 : mv.n_tiles;
+            for (int k = 0; k < nt; k++) t[k] = mv.tiles[k];
+            for (int a = 0; a < nt; a++)
+                for (int b = 0; b + 1 < nt; b++)
+                    if (t[b] > t[b + 1]) std::swap(t[b], t[b + 1]);
+            for (int k = 0; k < 4; k++) P.meld_tiles[m][k] = t[k];
+            P.meld_from[m] = mv.from_who < 0 ? 0xFF : (uint8_t)mv.from_who;
+            P.meld_called[m] = mv.called_tile < 0 ? 0xFF : (uint8_t)mv.called_tile;
+        }
+        P.n_discards = q.n_discards;
+        P.discard_type_mask = 0;
+        for (int i = 0; i < q.n_discards; i++) {
+            P.discards[i] = q.discards[i];
+            P.discard_type_mask |= 1ull << (q.discards[i] >> 2);
+        }
+        P.discard_from_hand_bits = q.discard_from_hand_bits;
+        P.discard_is_riichi_bits = q.discard_is_riichi_bits;
+        P.riichi_decl_idx = q.riichi_declaration_index < 0 ? 0xFF : (uint8_t)q.riichi_declaration_index;
+        P.score = q.score;
+        P.score_delta = q.score_delta;
+        P.flags = (q.riichi_declared ? PF_RIICHI_DECLARED : 0) | (q.riichi_stage ? PF_RIICHI_STAGE : 0) |
+                  (q.double_riichi_declared ? PF_DOUBLE_RIICHI : 0) | (q.missed_agari_riichi ? PF_MISSED_RIICHI : 0) |
+                  (q.missed_agari_doujun ? PF_MISSED_DOUJUN : 0) | (q.nagashi_eligible ? PF_NAGASHI : 0) |
+                  (q.ippatsu_cycle ? PF_IPPATSU : 0);
+        P.pao37 = q.pao_daisangen < 0 ? 0xFF : (uint8_t)q.pao_daisangen;
+        P.pao50 = q.pao_daisuushi < 0 ? 0xFF : (uint8_t)q.pao_daisuushi;
+        P.n_forbidden = q.n_forbidden > 2 ? 2 : q.n_forbidden;
+        for (int i = 0; i < P.n_forbidden; i++) P.forbidden[i] = q.forbidden[i];
+        P.riichi_sutehai = q.riichi_sutehai < 0 ? 0xFF : (uint8_t)q.riichi_sutehai;
+        P.last_tedashi = q.last_tedashi < 0 ? 0xFF : (uint8_t)q.last_tedashi;
+    }
+    S.current_player = v->current_player;
+    S.is_done = v->is_done;
+    S.needs_tsumo = v->needs_tsumo;
+    S.phase = v->phase;
+    S.active_mask = v->active_mask;
+    S.turn_count = v->turn_count;
+    S.riichi_sticks = v->riichi_sticks;
+    S.last_discard_pid = v->last_discard_pid < 0 ? 0xFF : (uint8_t)v->last_discard_pid;
+    S.last_discard_tile = v->last_discard_pid < 0 ? 0 : (uint8_t)v->last_discard_tile;
+    S.pending_kan_pid = v->pending_kan_pid < 0 ? 0xFF : (uint8_t)v->pending_kan_pid;
+    S.pending_kan_action = v->pending_kan_pid < 0 ? 0 : v->pending_kan_action;
+    S.oya = v->oya;
+    S.honba = v->honba;
+    S.kyoku_idx = v->kyoku_idx;
+    S.round_wind = v->round_wind;
+    S.is_rinshan = v->is_rinshan_flag;
+    S.is_first_turn = v->is_first_turn;
+    S.riichi_pending = v->riichi_pending_acceptance < 0 ? 0xFF : (uint8_t)v->riichi_pending_acceptance;
+    S.drawn_tile = v->drawn_tile < 0 ? 0xFF : (uint8_t)v->drawn_tile;
+    S.last_error_pid = v->last_error_pid < 0 ? 0xFF : (uint8_t)v->last_error_pid;
+    HIPCHK(hipMemcpy(h->d.core + game, &S, sizeof(GState), hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(h->d.wall + (size_t)game * RMJ_WALL_STRIDE, W, RMJ_WALL_STRIDE, hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(k_refresh, dim3(1), dim3(64), 0, h->stream, h->d, game);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(h->stream));
+    return RMJ_OK;
+}
+
+// ---- MJAI formatting (state/mod.rs:2094-2148; parser.rs:301-334) -------------------------
+static std::string mjai_tile(uint8_t tid) {
+    if (tid == 16) return "5mr";
+    if (tid == 52) return "5pr";
+    if (tid == 88) return "5sr";
+    if (tid < 108) {
+        static const char sc[3] = {'m', 'p', 's'};
+        std::string s;
+        s += (char)('1' + (tid % 36) / 4);
+        s += sc[tid / 36];
+        return s;
+    }
+    static const char* hon[7] = {"E", "S", "W", "N", "P", "F", "C"};
+    int num = (tid - 108) / 4;
+    if (num < 7) return hon[num];
+    return std::to_string(num + 1) + "z";
+}
+static std::string jtiles(const uint8_t* t, int n) {
+    std::string s = "[";
+    for (int i = 0; i < n; i++) {
+        if (i) s += ",";
+        s += "\"" + mjai_tile(t[i]) + "\"";
+    }
+    return s + "]";
+}
+static std::string jints(const int32_t* v, int n) {
+    std::string s = "[";
+    for (int i = 0; i < n; i++) {
+        if (i) s += ",";
+        s += std::to_string(v[i]);
+    }
+    return s + "]";
+}
+
+int rmj_format_event(const RmjEvent* ev, uint32_t n_avail, int seat, char* buf, uint32_t cap) {
+    if (!ev || !buf || n_avail == 0) return RMJ_ERR_ARG;
+    std::string s;
+    int used = 1;
+    const RmjEvent& e = ev[0];
+    auto A = [&](int a) { return std::to_string(a); };
+    int ncons = e.flags >> 4;
+    switch (e.type) {
+        case RMJ_EV_START_GAME: s = "{\"type\":\"start_game\"}"; break;
+        case RMJ_EV_END_KYOKU: s = "{\"type\":\"end_kyoku\"}"; break;
+        case RMJ_EV_END_GAME: s = "{\"type\":\"end_game\"}"; break;
+        case RMJ_EV_START_KYOKU: {
+            if (n_avail < 3 || ev[1].type != RMJ_EV_TEHAI || ev[2].type != RMJ_EV_TEHAI) return RMJ_ERR_ARG;
+            used = 3;
+            static const char* winds[4] = {"E", "S", "W", "N"};
+            uint32_t kyotaku = e.consumed[2] | (e.consumed[3] << 8);
+            s = std::string("{\"bakaze\":\"") + winds[e.consumed[0] & 3] + "\",\"dora_marker\":\"" + mjai_tile(e.tile) + "\",\"honba\":" +
+                A(e.consumed[1]) + ",\"kyoku\":" + A(e.target) + ",\"kyotaku\":" + A((int)kyotaku) + ",\"oya\":" + A(e.actor) +
+                ",\"scores\":" + jints(e.deltas, 4) + ",\"tehais\":[";
+            for (int p = 0; p < 4; p++) {
+                const uint8_t* pl = reinterpret_cast<const uint8_t*>(&ev[1 + p / 2]) + 4 + 13 * (p & 1);
+                if (p) s += ",";
+                if (seat < 0 || seat == p) s += jtiles(pl, 13);
+                else {
+                    s += "[";
+                    for (int k = 0; k < 13; k++) s += k ? ",\"?\"" : "\"?\"";
+                    s += "]";
+                }
+            }
+            s += "],\"type\":\"start_kyoku\"}";
+            break;
+        }
+        case RMJ_EV_TSUMO:
+            s = "{\"actor\":" + A(e.actor) + ",\"pai\":\"" + ((seat < 0 || seat == e.actor) ? mjai_tile(e.tile) : std::string("?")) +
+                "\",\"type\":\"tsumo\"}";
+            break;
+        case RMJ_EV_DAHAI:
+            s = "{\"actor\":" + A(e.actor) + ",\"pai\":\"" + mjai_tile(e.tile) + "\",\"tsumogiri\":" + ((e.flags & 1) ? "true" : "false") +
+                ",\"type\":\"dahai\"}";
+            break;
+        case RMJ_EV_REACH: s = "{\"actor\":" + A(e.actor) + ",\"type\":\"reach\"}"; break;
+        case RMJ_EV_REACH_ACCEPTED: s = "{\"actor\":" + A(e.actor) + ",\"type\":\"reach_accepted\"}"; break;
+        case RMJ_EV_CHI:
+        case RMJ_EV_PON:
+        case RMJ_EV_DAIMINKAN:
+            s = "{\"actor\":" + A(e.actor) + ",\"consumed\":" + jtiles(e.consumed, ncons) + ",\"pai\":\"" + mjai_tile(e.tile) +
+                "\",\"target\":" + A(e.target) + ",\"type\":\"" +
+                (e.type == RMJ_EV_CHI ? "chi" : (e.type == RMJ_EV_PON ? "pon" : "daiminkan")) + "\"}";
+            break;
+        case RMJ_EV_ANKAN:
+        case RMJ_EV_KAKAN:
+            s = "{\"actor\":" + A(e.actor) + ",\"consumed\":" + jtiles(e.consumed, ncons) + ",\"pai\":\"" + mjai_tile(e.tile) +
+                "\",\"type\":\"" + (e.type == RMJ_EV_ANKAN ? "ankan" : "kakan") + "\"}";
+            break;
+        case RMJ_EV_DORA: s = "{\"dora_marker\":\"" + mjai_tile(e.tile) + "\",\"type\":\"dora\"}"; break;
+        case RMJ_EV_HORA:
+            s = "{\"actor\":" + A(e.actor) + ",\"deltas\":" + jints(e.deltas, 4) + ",\"target\":" + A(e.target) +
+                ((e.flags & 1) ? ",\"tsumo\":true" : "") + ",\"type\":\"hora\",\"ura_markers\":" + jtiles(e.ura, e.n_ura) + "}";
+            break;
+        case RMJ_EV_RYUKYOKU: {
+            static const char* reasons[7] = {"exhaustive_draw", "nagashimangan", "kyushu_kyuhai", "sufuurenta", "suukansansen", "suucha_riichi",
+                                             "sanchaho"};
+            std::string r = e.flags < 7 ? reasons[e.flags] : ("Error: Illegal Action by Player " + A(e.actor));
+            s = "{\"deltas\":" + jints(e.deltas, 4) + ",\"reason\":\"" + r + "\",\"type\":\"ryukyoku\"}";
+            break;
+        }
+        default: return RMJ_ERR_ARG;
+    }
+    if (s.size() + 1 > cap) return RMJ_ERR_RANGE;
+    memcpy(buf, s.c_str(), s.size() + 1);
+    return used;
+}
+
+// ---- batched hand math ---------------------------------------------------------------------
+int rmj_eval_hands(int device, const RmjHandCase* cases, uint32_t n, RmjHandResult* out) {
+    if (!cases || !out) return fail(RMJ_ERR_ARG, "null argument");
+    int rc = ensure_device(device);
+    if (rc) return rc;
+    if (n == 0) return RMJ_OK;
+    RmjHandCase* d_in;
+    RmjHandResult* d_out;
+    HIPCHK(hipMalloc(&d_in, (size_t)n * sizeof(RmjHandCase)));
+    HIPCHK(hipMalloc(&d_out, (size_t)n * sizeof(RmjHandResult)));
+    HIPCHK(hipMemcpy(d_in, cases, (size_t)n * sizeof(RmjHandCase), hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(k_eval_hands, game_grid(n), dim3(256), 0, 0, d_in, n, d_out);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipDeviceSynchronize());
+    HIPCHK(hipMemcpy(out, d_out, (size_t)n * sizeof(RmjHandResult), hipMemcpyDeviceToHost));
+    hipFree(d_in);
+    hipFree(d_out);
+    return RMJ_OK;
+}
+int rmj_agari_counts(int device, const uint8_t* counts, uint32_t n, uint8_t* is_agari_out, uint8_t* is_tenpai, uint64_t* waits) {
+    if (!counts || !is_agari_out || !is_tenpai || !waits) return fail(RMJ_ERR_ARG, "null argument");
+    int rc = ensure_device(device);
+    if (rc) return rc;
+    if (n == 0) return RMJ_OK;
+    uint8_t *d_c, *d_a, *d_t;
+    uint64_t* d_w;
+    HIPCHK(hipMalloc(&d_c, (size_t)n * 34));
+    HIPCHK(hipMalloc(&d_a, n));
+    HIPCHK(hipMalloc(&d_t, n));
+    HIPCHK(hipMalloc(&d_w, (size_t)n * 8));
+    HIPCHK(hipMemcpy(d_c, counts, (size_t)n * 34, hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(k_agari_counts, game_grid(n), dim3(256), 0, 0, d_c, n, d_a, d_t, d_w);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipDeviceSynchronize());
+    HIPCHK(hipMemcpy(is_agari_out, d_a, n, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(is_tenpai, d_t, n, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(waits, d_w, (size_t)n * 8, hipMemcpyDeviceToHost));
+    hipFree(d_c); hipFree(d_a); hipFree(d_t); hipFree(d_w);
+    return RMJ_OK;
+}
+int rmj_calculate_score(int device, const uint8_t* han, const uint8_t* fu, const uint8_t* is_oya, const uint8_t* is_tsumo,
+                        const uint32_t* honba, const uint8_t* num_players, uint32_t n, uint32_t* out) {
+    if (!han || !fu || !is_oya || !is_tsumo || !honba || !num_players || !out) return fail(RMJ_ERR_ARG, "null argument");
+    int rc = ensure_device(device);
+    if (rc) return rc;
+    if (n == 0) return RMJ_OK;
+    uint8_t *d_h, *d_f, *d_o, *d_t, *d_n;
+    uint32_t *d_hb, *d_out;
+    if ((rc = upload(han, n, &d_h)) || (rc = upload(fu, n, &d_f)) || (rc = upload(is_oya, n, &d_o)) || (rc = upload(is_tsumo, n, &d_t)) ||
+        (rc = upload(num_players, n, &d_n)) || (rc = upload(honba, n, &d_hb)))
+        return rc;
+    HIPCHK(hipMalloc(&d_out, (size_t)n * 16));
+    hipLaunchKernelGGL(k_score, dim3((n + 255) / 256), dim3(256), 0, 0, d_h, d_f, d_o, d_t, d_hb, d_n, n, d_out);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipDeviceSynchronize());
+    HIPCHK(hipMemcpy(out, d_out, (size_t)n * 16, hipMemcpyDeviceToHost));
+    hipFree(d_h); hipFree(d_f); hipFree(d_o); hipFree(d_t); hipFree(d_n); hipFree(d_hb); hipFree(d_out);
+    return RMJ_OK;
+}
+
+// ---- measurement -----------------------------------------------------------------------------
+int rmj_bench_rollout(rmj_handle h, uint64_t policy_seed, uint32_t warmup, uint32_t steps, RmjBenchResult* out) {
+    if (!h || !out) return fail(RMJ_ERR_ARG, "null argument");
+    HIPCHK(hipSetDevice(h->cfg.device));
+    int rc = rmj_step_random(h, policy_seed, warmup, 1);
+    if (rc) return rc;
+    uint64_t before = 0, after = 0;
+    if ((rc = rmj_total_steps(h, &before))) return rc;
+    hipEvent_t e0, e1;
+    HIPCHK(hipEventCreate(&e0));
+    HIPCHK(hipEventCreate(&e1));
+    HIPCHK(hipEventRecord(e0, h->stream));
+    if ((rc = rmj_step_random(h, policy_seed, steps, 1))) return rc;
+    HIPCHK(hipEventRecord(e1, h->stream));
+    HIPCHK(hipEventSynchronize(e1));
+    float ms = 0.f;
+    HIPCHK(hipEventElapsedTime(&ms, e0, e1));
+    if ((rc = rmj_total_steps(h, &after))) return rc;
+    hipEventDestroy(e0);
+    hipEventDestroy(e1);
+    out->total_ms = ms;
+    out->launches = steps;
+    out->step_kernel_ms = steps ? ms / steps : 0.0;
+    out->env_steps = after - before;
+    out->reserved = 0;
+    return RMJ_OK;
+}
+
+}  // extern "C"

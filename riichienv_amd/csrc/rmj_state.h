@@ -1,0 +1,82 @@
+// Device-resident game state layout (one 640-byte record per game) and the slabs around it.
+//
+// Layout rationale: the step path runs ONE WAVEFRONT PER GAME, so the
+// coalesced access pattern is "64 lanes read one game's contiguous record" (40 lanes x 16 B),
+// not "64 lanes read field f of 64 games".  State is therefore split by FIELD GROUP into
+// separate HBM slabs (structure-of-arrays at slab granularity), each slab holding one
+// contiguous, 16-byte-aligned record per game:
+//     core  [B] x 640 B   GState   (hands, melds, discards, flags, scores, globals)
+//     wall  [B] x 144 B            (136 tile ids, immutable within a kyoku; cursors live in core)
+//     legal [B] x 4 x 64 x 8 B     (ordered legal-action lists = current_claims of the reference)
+//     nlegal[B] x 4 B, mask [B] x 4 x 82 B, waits [B] x 4 x 8 B, status [B] x 4 B
+//     events[B] x ring x 32 B      (binary MJAI records, host-formatted)
+//
+// Mirrors: GameState (state/mod.rs:31-91), PlayerState (state/player.rs:6-39),
+// WallState (state/wall.rs:8-19) of the reference.
+#pragma once
+#include <stdint.h>
+
+#define RMJ_WALL_STRIDE 144
+
+// PState.flags bits (state/player.rs:19-37)
+#define PF_RIICHI_DECLARED 1u
+#define PF_RIICHI_STAGE 2u
+#define PF_DOUBLE_RIICHI 4u
+#define PF_MISSED_RIICHI 8u
+#define PF_MISSED_DOUJUN 16u
+#define PF_NAGASHI 32u
+#define PF_IPPATSU 64u
+
+struct alignas(16) PState {  // 128 bytes
+    uint8_t hand[14];        // 136-ids; 13 sorted + drawn tile last (state/mod.rs:1575-1579)
+    uint8_t hand_len;
+    uint8_t n_melds;
+    uint8_t meld_type[4];    // RMJ_MELD_*
+    uint8_t meld_from[4];    // from_who, 0xFF = -1
+    uint8_t meld_called[4];  // called_tile, 0xFF = None
+    uint8_t meld_tiles[4][4];// sorted 136-ids (3 for chi/pon, 4 for kans)
+    uint8_t n_discards;
+    uint8_t flags;           // PF_*
+    uint8_t pao37, pao50;    // liable seat for daisangen / daisuushi, 0xFF = none
+    uint8_t n_forbidden;
+    uint8_t forbidden[2];    // 136-ids, compared by type (legal_actions.rs:82-88)
+    uint8_t riichi_decl_idx; // 0xFF = None
+    uint8_t riichi_sutehai;  // 0xFF = None
+    uint8_t last_tedashi;    // 0xFF = None
+    uint8_t pad0[2];
+    int32_t score, score_delta;
+    uint32_t discard_from_hand_bits, discard_is_riichi_bits;
+    uint64_t discard_type_mask;  // derived cache: bit t set iff some discard has type t
+    uint8_t discards[32];
+    uint8_t pad1[16];
+};
+
+struct alignas(16) GState {  // 4*128 + 128 = 640 bytes
+    PState p[4];
+    uint64_t wall_seed;       // WallState.seed (episode seed)
+    uint64_t pending_kan_action;
+    uint32_t hand_index;      // WallState.hand_index
+    uint32_t step_count;      // env.step calls that advanced this game
+    uint32_t ev_count;        // MJAI events emitted so far
+    uint32_t turn_count;
+    uint32_t riichi_sticks;
+    uint8_t current_player, phase, active_mask, is_done;
+    uint8_t needs_tsumo, oya, honba, kyoku_idx;
+    uint8_t round_wind, is_rinshan, is_first_turn, riichi_pending;  // riichi_pending: 0xFF none
+    uint8_t drawn_tile, last_discard_pid, last_discard_tile, pending_kan_pid;  // 0xFF none
+    // wall cursors over the fixed 136-array W (= WallState.tiles before any pop/remove):
+    //   tiles.pop()      -> W[--live_end]
+    //   tiles.remove(0)  -> W[rinshan_count++]
+    //   tiles[i]         -> W[i + rinshan_count]   (so dora k = W[4+2k], ura k = W[5+2k])
+    uint8_t live_end, rinshan_count, pending_kan_dora, drawable_count;
+    uint8_t n_dora, dora[5];
+    uint8_t ron_offer_mask;   // seats whose stored claim list contains Ron (state/mod.rs:902-917)
+    uint8_t last_error_pid;   // 0xFF none (quirk Q9)
+    uint8_t wall_total;       // 136 (4P) / 108 (3P)
+    uint8_t pad[128 - 8 - 8 - 20 - 16 - 4 - 6 - 3];
+};
+
+#ifdef __cplusplus
+static_assert(sizeof(PState) == 128, "PState must be 128 bytes");
+static_assert(sizeof(GState) == 640, "GState must be 640 bytes");
+#endif

@@ -1,0 +1,1513 @@
+// One-wavefront-per-game state machine for gfx950.
+//
+// All 64 lanes of a wave own ONE game whose 640-byte record sits in LDS for the duration of
+// the kernel.  Control flow is wave-uniform (every lane walks the same transition); the lanes
+// split only inside the data-parallel helpers:
+//   * waits / tenpai probes: lane = candidate tile (34 lanes) + __ballot
+//   * legal-action enumeration (discards, pon pairs, chi combos, kakan): lane = candidate,
+//     __ballot + prefix popcount gives each surviving candidate its slot in the ORDERED list
+//   * hand sort / wall permutation: rank-by-counting, lane = element
+//   * yaku: lane = candidate head (rmj_hand.hip.h)
+//
+// Reference semantics: riichienv-core/src/state/mod.rs (step, _resolve_discard, _resolve_kan,
+// _accept_riichi, _deal_next, _initialize_next_round, _initialize_round, _trigger_ryukyoku,
+// check_abortive_draw, _reveal_kan_dora), state/legal_actions.rs, riichienv-python/src/env.rs.
+#pragma once
+#include "../../include/riichi_mi355x.h"
+#include "rmj_hand.hip.h"
+#include "rmj_state.h"
+
+namespace rmj {
+
+struct Env {
+    GState* core;
+    uint8_t* wall;        // [B][RMJ_WALL_STRIDE]
+    uint64_t* legal;      // [B][4][64]
+    uint8_t* nlegal;      // [B][4]
+    uint8_t* mask;        // [B][4][82]
+    uint64_t* waits;      // [B][4]
+    uint32_t* status;     // [B]  active_mask | phase<<8 | done<<16
+    RmjEvent* events;     // [B][ring]
+    uint32_t ring_mask;   // ring-1
+    uint32_t n_games;
+    uint32_t rule_bits;
+    uint32_t game_mode;
+    uint32_t skip_log;
+    uint32_t ctor_round_wind;
+    uint64_t game_offset;
+};
+
+struct WaveScratch {      // per-wave LDS scratch
+    uint64_t keys[136];
+    uint8_t tiles[144];
+    uint8_t maskbuf[4 * 82 + 8];
+    uint64_t legal[4][RMJ_MAX_LEGAL];  // lists produced this launch (copied to HBM by finalize_outputs)
+    uint64_t wout[4];                  // waits produced this launch
+    int nl[4];                         // list lengths produced this launch
+};
+
+struct Ctx {
+    GState& S;
+    const Env& E;
+    WaveScratch& X;
+    uint32_t g;
+    int lane;
+    uint8_t* W;       // this game's wall (global)
+    uint64_t* Lg;     // this game's legal lists [4][64] in HBM (read for validation, written by finalize)
+};
+
+__device__ __forceinline__ void wave_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+}
+__device__ __forceinline__ uint64_t lanemask_lt(int lane) { return (1ull << lane) - 1ull; }
+
+// ---------------------------------------------------------------- packed actions
+__device__ __forceinline__ uint64_t mk_action(uint32_t type, uint32_t tile, uint32_t n, uint32_t c0 = 0, uint32_t c1 = 0, uint32_t c2 = 0,
+                                              uint32_t c3 = 0) {
+    return (uint64_t)type | ((uint64_t)tile << 8) | ((uint64_t)n << 16) | ((uint64_t)c0 << 24) | ((uint64_t)c1 << 32) |
+           ((uint64_t)c2 << 40) | ((uint64_t)c3 << 48);
+}
+__device__ __forceinline__ uint32_t a_type(uint64_t a) { return (uint32_t)(a & 0xFF); }
+__device__ __forceinline__ uint32_t a_tile(uint64_t a) { return (uint32_t)((a >> 8) & 0xFF); }
+__device__ __forceinline__ uint32_t a_n(uint64_t a) { return (uint32_t)((a >> 16) & 0xFF); }
+__device__ __forceinline__ uint32_t a_c(uint64_t a, int i) { return (uint32_t)((a >> (24 + 8 * i)) & 0xFF); }
+// canonical form: consume tiles ascending (Action::new, action.rs:97-98), unused bytes zero
+__device__ inline uint64_t a_canon(uint64_t a) {
+    if (a == RMJ_NO_ACTION) return a;
+    uint32_t n = a_n(a);
+    if (n > 4) n = 4;
+    uint32_t c[4];
+#pragma unroll
+    for (int i = 0; i < 4; i++) c[i] = (uint32_t)i < n ? a_c(a, i) : 0xFFFFu;
+#pragma unroll
+    for (int i = 0; i < 4; i++)
+#pragma unroll
+        for (int j = 0; j < 3; j++)
+            if (c[j] > c[j + 1]) { uint32_t t = c[j]; c[j] = c[j + 1]; c[j + 1] = t; }
+#pragma unroll
+    for (int i = 0; i < 4; i++)
+        if ((uint32_t)i >= n) c[i] = 0;
+    return mk_action(a_type(a), a_tile(a), n, c[0], c[1], c[2], c[3]);
+}
+// action.rs:158-227
+__device__ inline int a_encode(uint64_t a) {
+    uint32_t ty = a_type(a), tile = a_tile(a);
+    switch (ty) {
+        case RMJ_DISCARD: return tile / 4;
+        case RMJ_RIICHI: return 37;
+        case RMJ_CHI: {
+            uint32_t tt = tile / 4, x = a_c(a, 0) / 4, y = a_c(a, 1) / 4;
+            uint32_t lo = min(tt, min(x, y)), hi = max(tt, max(x, y));
+            return tt == lo ? 38 : (tt == hi ? 40 : 39);
+        }
+        case RMJ_PON: return 41;
+        case RMJ_DAIMINKAN: return 42 + tile / 4;
+        case RMJ_ANKAN:
+        case RMJ_KAKAN: return 42 + a_c(a, 0) / 4;
+        case RMJ_RON:
+        case RMJ_TSUMO: return 79;
+        case RMJ_KYUSHU: return 80;
+        case RMJ_PASS: return 81;
+        default: return -1;
+    }
+}
+// validation match, state/mod.rs:344-393 (quirk Q13)
+__device__ inline bool a_match(uint64_t l, uint64_t act) {
+    uint32_t lt = a_type(l);
+    if (lt != a_type(act)) return false;
+    bool tiles_match = a_tile(l) == a_tile(act);
+    bool cons_match = (l >> 16) == (act >> 16);
+    bool act_empty = a_n(act) == 0;
+    if (tiles_match) {
+        if (cons_match) return true;
+        if (act_empty && lt == RMJ_KAKAN) return true;
+        if (act_empty && (lt == RMJ_DISCARD || lt == RMJ_RIICHI || lt == RMJ_TSUMO || lt == RMJ_RON || lt == RMJ_PASS)) return true;
+    }
+    if (cons_match && (lt == RMJ_ANKAN || lt == RMJ_KAKAN)) return true;
+    if (a_tile(act) == RMJ_TILE_NONE) return lt == RMJ_TSUMO || lt == RMJ_RON || lt == RMJ_RIICHI || lt == RMJ_KYUSHU || lt == RMJ_KITA;
+    return false;
+}
+
+__device__ __forceinline__ uint64_t sm64(uint64_t x) {  // state/wall.rs:83-88
+    uint64_t z = x + 0x9E3779B97F4A7C15ull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+
+// ---------------------------------------------------------------- events
+__device__ inline void emit_raw(Ctx& c, const RmjEvent& ev) {
+    if (c.E.skip_log) return;
+    uint32_t idx = c.S.ev_count & c.E.ring_mask;
+    RmjEvent* dst = c.E.events + (size_t)c.g * (c.E.ring_mask + 1u) + idx;
+    if (c.lane == 0) {
+        const uint4* s = reinterpret_cast<const uint4*>(&ev);
+        uint4* d = reinterpret_cast<uint4*>(dst);
+        d[0] = s[0];
+        d[1] = s[1];
+    }
+    c.S.ev_count += 1;
+}
+__device__ inline RmjEvent ev_zero(uint8_t type) {
+    RmjEvent e;
+    uint32_t* p = reinterpret_cast<uint32_t*>(&e);
+#pragma unroll
+    for (int i = 0; i < 8; i++) p[i] = 0;
+    e.type = type;
+    return e;
+}
+__device__ inline void emit_simple(Ctx& c, uint8_t type, uint8_t actor = 0, uint8_t tile = 0, uint8_t flags = 0) {
+    RmjEvent e = ev_zero(type);
+    e.actor = actor;
+    e.tile = tile;
+    e.flags = flags;
+    emit_raw(c, e);
+}
+__device__ inline void emit_meld(Ctx& c, uint8_t type, uint8_t actor, uint8_t target, uint8_t tile, uint64_t act) {
+    RmjEvent e = ev_zero(type);
+    e.actor = actor;
+    e.target = target;
+    e.tile = tile;
+    uint32_t n = a_n(act);
+    for (int i = 0; i < 4; i++) e.consumed[i] = (uint32_t)i < n ? (uint8_t)a_c(act, i) : 0;
+    e.flags = (uint8_t)(n << 4);
+    emit_raw(c, e);
+}
+
+// ---------------------------------------------------------------- small helpers
+__device__ __forceinline__ bool rule(const Ctx& c, uint32_t bit) { return (c.E.rule_bits & bit) != 0; }
+__device__ __forceinline__ bool is_terminal_tile136(int t) {  // types.rs:362-367
+    int tt = t / 4;
+    return tt >= 27 || (tt % 9) == 0 || (tt % 9) == 8;
+}
+__device__ __forceinline__ int next_dora34(int t, bool sanma) {  // hand_evaluator.rs:286-300 / _3p.rs:300-311
+    if (sanma) {
+        if (t == 0) return 8;
+        if (t == 8) return 0;
+        if (t < 9) return t;
+    }
+    if (t < 27) return (t % 9 == 8) ? t - 8 : t + 1;
+    if (t < 31) return t == 30 ? 27 : t + 1;
+    return t == 33 ? 31 : t + 1;
+}
+__device__ __forceinline__ bool is_aka(int t) { return t == 16 || t == 52 || t == 88; }
+
+// concealed histogram of a seat (optionally skipping hand index `skip`)
+__device__ inline PH build_ph(const PState& P, int skip = -1) {
+    PH h = {0, 0, 0, 0};
+    int n = P.hand_len;
+    for (int j = 0; j < n; j++)
+        if (j != skip) ph_add(h, P.hand[j] >> 2);
+    return h;
+}
+__device__ inline MeldAgg build_meld_agg(const PState& P) {
+    MeldAgg m;
+    m.n = P.n_melds;
+    m.n_kan = m.n_ankan = m.n_nonchi = 0;
+    m.menzen = true;
+    m.types = 0;
+    m.fu = 0;
+    m.aka = 0;
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        m.mtypes[i] = 0;
+        m.mtype[i] = 0;
+        m.t0[i] = 0;
+        if (i < m.n) {
+            uint8_t ty = P.meld_type[i];
+            int nt = (ty >= RMJ_MELD_DAIMINKAN) ? 4 : 3;
+            uint64_t mm = 0;
+            for (int k = 0; k < nt; k++) {
+                int t = P.meld_tiles[i][k];
+                mm |= 1ull << (t >> 2);
+                m.aka += is_aka(t);
+            }
+            m.mtypes[i] = mm;
+            m.types |= mm;
+            m.mtype[i] = ty;
+            int t0 = P.meld_tiles[i][0] >> 2;  // tiles sorted by id -> lowest type first (== chi sort)
+            m.t0[i] = (uint8_t)t0;
+            bool opened = ty != RMJ_MELD_ANKAN;
+            if (opened) m.menzen = false;
+            bool kan = ty >= RMJ_MELD_DAIMINKAN;
+            m.n_kan += kan;
+            m.n_ankan += (ty == RMJ_MELD_ANKAN);
+            m.n_nonchi += (ty != RMJ_MELD_CHI);
+            if (ty != RMJ_MELD_CHI) {  // tiles[0] == tiles[1]
+                int f = opened ? 2 : 4;
+                if (t_is_terminal(t0)) f *= 2;
+                if (kan) f *= 4;
+                m.fu += f;
+            }
+        }
+    }
+    return m;
+}
+
+// rank-sort the first n tiles of a hand (ids are unique)
+__device__ inline void sort_hand(Ctx& c, PState& P, int n) {
+    int t = 0, r = 0;
+    if (c.lane < n) {
+        t = P.hand[c.lane];
+        for (int k = 0; k < n; k++) r += (P.hand[k] < t);
+    }
+    wave_sync();
+    if (c.lane < n) P.hand[r] = (uint8_t)t;
+    wave_sync();
+}
+// remove hand[idx] keeping order
+__device__ inline void hand_remove_at(Ctx& c, PState& P, int idx) {
+    int n = P.hand_len;
+    int t = 0;
+    if (c.lane > idx && c.lane < n) t = P.hand[c.lane];
+    wave_sync();
+    if (c.lane > idx && c.lane < n) P.hand[c.lane - 1] = (uint8_t)t;
+    wave_sync();
+    P.hand_len = (uint8_t)(n - 1);
+}
+__device__ inline int hand_find(const Ctx& c, const PState& P, int tile) {  // position() of a 136-id, -1 if absent
+    bool hit = c.lane < P.hand_len && P.hand[c.lane] == tile;
+    uint64_t b = __ballot(hit);
+    return b ? (__ffsll((long long)b) - 1) : -1;
+}
+
+// ---------------------------------------------------------------- calc glue (HandEvaluator::new + calc)
+struct Cond {
+    uint32_t cf;
+    uint32_t honba;
+};
+// seat's concealed tiles = hand minus `skip_idx` (-1: none); win tile added iff total == 13
+__device__ __noinline__ CalcOut seat_calc(Ctx& c, int seat, int skip_idx, int win_tile, uint32_t cf, uint32_t honba, bool use_ura) {
+    GState& S = c.S;
+    PState& P = S.p[seat];
+    CalcIn in;
+    in.ma = build_meld_agg(P);
+    PH h = build_ph(P, skip_idx);
+    int aka = in.ma.aka;
+    for (int j = 0; j < P.hand_len; j++)
+        if (j != skip_idx) aka += is_aka(P.hand[j]);
+    int total = ph_total(h) + 3 * in.ma.n;
+    int win34 = win_tile >> 2;
+    if (total == 13) {
+        ph_add(h, win34);
+        aka += is_aka(win_tile);
+    }
+    CalcOut out;
+    out.shape = false; out.is_win = false; out.yakuman = false; out.han = 0; out.fu = 0; out.yakuman_count = 0; out.kind = 0; out.ym = 0;
+    out.ron = out.tsumo_oya = out.tsumo_ko = 0;
+    if (!is_agari(h)) return out;
+    // full histogram for dora counting
+    PH full = h;
+    for (int i = 0; i < in.ma.n; i++) {
+        int nt = (P.meld_type[i] >= RMJ_MELD_DAIMINKAN) ? 4 : 3;
+        for (int k = 0; k < nt; k++) ph_add(full, P.meld_tiles[i][k] >> 2);
+    }
+    int dora = 0, ura = 0;
+    for (int k = 0; k < S.n_dora; k++) dora += ph_cnt(full, next_dora34(S.dora[k] >> 2, false));
+    if (use_ura)
+        for (int k = 0; k < S.n_dora; k++) {  // _get_ura_indicators, state/mod.rs:2048-2057
+            int idx = 5 + 2 * k;              // W index (rinshan shift folded into the fixed array)
+            if (idx < S.live_end) ura += ph_cnt(full, next_dora34(c.W[idx] >> 2, false));
+        }
+    in.hand14 = h;
+    in.win34 = win34;
+    in.cf = cf;
+    in.dora = dora; in.aka = aka; in.ura = ura; in.nuki = 0;
+    in.round_wind34 = 27 + (S.round_wind & 3);
+    in.seat_wind34 = 27 + ((seat + 4 - S.oya) & 3);
+    in.sanma = false;
+    in.honba = honba;
+    return wave_calc(in, c.lane);
+}
+__device__ inline uint32_t base_cf(const PState& P) {
+    uint32_t cf = 0;
+    if (P.flags & PF_RIICHI_DECLARED) cf |= CF_RIICHI;
+    if (P.flags & PF_DOUBLE_RIICHI) cf |= CF_DOUBLE_RIICHI;
+    if (P.flags & PF_IPPATSU) cf |= CF_IPPATSU;
+    return cf;
+}
+
+// ---------------------------------------------------------------- legal actions
+__device__ inline void put_legal(Ctx& c, int seat, int pos, uint64_t a) {
+    if (c.lane == 0 && pos < RMJ_MAX_LEGAL) c.X.legal[seat][pos] = a;
+}
+
+// legal_actions.rs:254-508.  Writes the claim list (+Pass) for seat i; returns true iff seat i has claims.
+__device__ __noinline__ bool gen_claims(Ctx& c, int i, int pid, int tile) {
+    GState& S = c.S;
+    PState& P = S.p[i];
+    const int lane = c.lane;
+    const int tt = tile >> 2;
+    const int hl = P.hand_len;
+    int n = 0;
+    PH h = build_ph(P);
+    uint64_t W = 0;
+    if (ph_total(h) + 3 * P.n_melds == 13) W = wave_waits(h, lane);
+    c.X.wout[i] = W;
+    bool in_discards = (P.discard_type_mask >> tt) & 1ull;
+    bool in_missed = (P.flags & PF_MISSED_DOUJUN) || ((P.flags & PF_RIICHI_DECLARED) && (P.flags & PF_MISSED_RIICHI));
+    if (!in_discards && !in_missed) {
+        bool furiten = (W & P.discard_type_mask) != 0ull || (P.flags & (PF_MISSED_RIICHI | PF_MISSED_DOUJUN));
+        if (!furiten && ((W >> tt) & 1ull)) {
+            uint32_t cf = base_cf(P);
+            if (S.drawable_count == 0 && !S.is_rinshan) cf |= CF_HOUTEI;
+            CalcOut r = seat_calc(c, i, -1, tile, cf, S.honba, false);
+            if (r.is_win) {
+                put_legal(c, i, n++, mk_action(RMJ_RON, tile, 0));
+                S.ron_offer_mask |= (uint8_t)(1u << i);
+            } else if (r.shape) {
+                P.flags |= PF_MISSED_DOUJUN;  // state/mod.rs:1386-1389
+            }
+        }
+    }
+    const bool riichi = P.flags & PF_RIICHI_DECLARED;
+    const bool kuikae = rule(c, RMJ_RULE_KUIKAE_FORBIDDEN);
+    uint8_t ht = lane < hl ? P.hand[lane] : 0xFF;
+    int hty = ht >> 2;
+    if (!riichi && S.drawable_count > 0) {
+        uint64_t mb = __ballot(lane < hl && hty == tt);
+        int count = __popcll(mb);
+        if (count >= 2 && hl >= 3) {
+            bool ok = kuikae ? (hl - count) > 0 : (hl - 2) > 0;
+            if (ok) {
+                int i0 = __ffsll((long long)mb) - 1;
+                uint64_t m1 = mb & (mb - 1);
+                int i1 = __ffsll((long long)m1) - 1;
+                put_legal(c, i, n++, mk_action(RMJ_PON, tile, 2, P.hand[i0], P.hand[i1]));
+                if (count >= 3) {
+                    uint64_t m2 = m1 & (m1 - 1);
+                    int i2 = __ffsll((long long)m2) - 1;
+                    put_legal(c, i, n++, mk_action(RMJ_PON, tile, 2, P.hand[i0], P.hand[i2]));
+                    put_legal(c, i, n++, mk_action(RMJ_PON, tile, 2, P.hand[i1], P.hand[i2]));
+                }
+            }
+        }
+        if (count >= 3) {
+            int i0 = __ffsll((long long)mb) - 1;
+            uint64_t m1 = mb & (mb - 1);
+            int i1 = __ffsll((long long)m1) - 1;
+            uint64_t m2 = m1 & (m1 - 1);
+            int i2 = __ffsll((long long)m2) - 1;
+            put_legal(c, i, n++, mk_action(RMJ_DAIMINKAN, tile, 3, P.hand[i0], P.hand[i1], P.hand[i2]));
+        }
+    }
+    // Chi: lane = pattern*16 + a*4 + b
+    bool shimocha = i == ((pid + 1) & 3);
+    if (!riichi && S.drawable_count > 0 && shimocha && hl >= 3 && tt < 27) {
+        int r9 = tt % 9;
+        int k = lane >> 4, a = (lane >> 2) & 3, b = lane & 3;
+        // per-pattern type pair
+        int ta = k == 0 ? tt - 2 : (k == 1 ? tt - 1 : tt + 1);
+        int tb = k == 0 ? tt - 1 : (k == 1 ? tt + 1 : tt + 2);
+        bool pat_ok = k == 0 ? (r9 >= 2) : (k == 1 ? (r9 >= 1 && r9 <= 7) : (k == 2 ? (r9 <= 6) : false));
+        // ballots must be executed by all lanes: build the six type masks uniformly
+        uint64_t m_m2 = __ballot(lane < hl && hty == tt - 2), m_m1 = __ballot(lane < hl && hty == tt - 1);
+        uint64_t m_p1 = __ballot(lane < hl && hty == tt + 1), m_p2 = __ballot(lane < hl && hty == tt + 2);
+        uint64_t m_0 = __ballot(lane < hl && hty == tt);
+        uint64_t m_p3 = __ballot(lane < hl && hty == tt + 3), m_m3 = __ballot(lane < hl && hty == tt - 3);
+        uint64_t ma = k == 0 ? m_m2 : (k == 1 ? m_m1 : m_p1);
+        uint64_t mbb = k == 0 ? m_m1 : (k == 1 ? m_p1 : m_p2);
+        // kuikae: forbidden = {tt} (+ tt+3 for pattern 2 if r9<=5, + tt-3 for pattern 0 if r9>=3)
+        int forb = __popcll(m_0);
+        if (k == 2 && r9 <= 5) forb += __popcll(m_p3);
+        if (k == 0 && r9 >= 3) forb += __popcll(m_m3);
+        bool kk_ok = kuikae ? (hl - 2 - forb) > 0 : (hl - 2) > 0;
+        bool valid = lane < 48 && pat_ok && a < __popcll(ma) && b < __popcll(mbb) && kk_ok;
+        uint64_t act = 0;
+        if (valid) {
+            uint64_t x = ma;
+            for (int q = 0; q < a; q++) x &= x - 1;
+            int ia = __ffsll((long long)x) - 1;
+            uint64_t y = mbb;
+            for (int q = 0; q < b; q++) y &= y - 1;
+            int ib = __ffsll((long long)y) - 1;
+            act = mk_action(RMJ_CHI, tile, 2, P.hand[ia], P.hand[ib]);
+        }
+        (void)ta; (void)tb;
+        uint64_t vb = __ballot(valid);
+        if (valid) {
+            int pos = n + __popcll(vb & lanemask_lt(lane));
+            if (pos < RMJ_MAX_LEGAL) c.X.legal[i][pos] = act;
+        }
+        n += __popcll(vb);
+    }
+    if (n > 0) {
+        put_legal(c, i, n, mk_action(RMJ_PASS, RMJ_TILE_NONE, 0));
+        c.X.nl[i] = n + 1;
+        return true;
+    }
+    c.X.nl[i] = 0;
+    return false;
+}
+
+// bit j set iff HandEvaluator(hand minus hand[j]).is_tenpai()  (legal_actions.rs:77-131)
+__device__ __noinline__ uint32_t tenpai_after_discard(Ctx& c, const PState& P) {
+    uint32_t out = 0;
+    int hl = P.hand_len;
+    if (hl + 3 * P.n_melds != 14) return 0;
+    PH full = build_ph(P);
+    int prev_ty = -1;
+    bool prev_res = false;
+    for (int j = 0; j < hl; j++) {
+        int ty = P.hand[j] >> 2;
+        bool res;
+        if (ty == prev_ty) res = prev_res;
+        else {
+            PH h = full;
+            ph_sub(h, ty);
+            res = wave_waits(h, c.lane) != 0ull;
+        }
+        prev_ty = ty;
+        prev_res = res;
+        if (res) out |= 1u << j;
+    }
+    return out;
+}
+
+// legal_actions.rs:11-252 (WaitAct branch) for the current player
+__device__ __noinline__ void gen_act_legal(Ctx& c, int pid) {
+    GState& S = c.S;
+    PState& P = S.p[pid];
+    const int lane = c.lane;
+    const int hl = P.hand_len;
+    int n = 0;
+    const bool r_decl = P.flags & PF_RIICHI_DECLARED, r_stage = P.flags & PF_RIICHI_STAGE;
+    const bool drawn = S.drawn_tile != 0xFF;
+    c.X.wout[pid] = 0;
+    // 1. Tsumo
+    if (drawn && !r_stage) {
+        int tile = S.drawn_tile;
+        int idx = -1;  // rposition
+        {
+            uint64_t b = __ballot(lane < hl && P.hand[lane] == tile);
+            if (b) idx = 63 - __clzll((long long)b);
+        }
+        uint32_t cf = base_cf(P) | CF_TSUMO;
+        if (S.drawable_count == 0 && !S.is_rinshan) cf |= CF_HAITEI;
+        if (S.is_rinshan) cf |= CF_RINSHAN;
+        if (S.is_first_turn && P.n_discards == 0) cf |= CF_FIRST_TURN;  // quirk Q5
+        CalcOut r = seat_calc(c, pid, idx, tile, cf, S.honba, false);
+        if (r.is_win && (r.yakuman || r.han >= 1)) put_legal(c, pid, n++, mk_action(RMJ_TSUMO, tile, 0));
+    }
+    // 2. Discard / Riichi
+    uint8_t ht = lane < hl ? P.hand[lane] : 0xFF;
+    bool forb = false;
+    for (int f = 0; f < P.n_forbidden; f++) forb = forb || ((P.forbidden[f] >> 2) == (ht >> 2));
+    if (r_decl) {
+        if (drawn) put_legal(c, pid, n++, mk_action(RMJ_DISCARD, S.drawn_tile, 0));
+    } else {
+        uint32_t tp = 0;
+        bool need_tp = r_stage;
+        bool all_closed = true;
+        for (int i = 0; i < P.n_melds; i++) all_closed = all_closed && (P.meld_type[i] == RMJ_MELD_ANKAN);
+        bool riichi_pre = !r_stage && P.score >= 1000 && S.drawable_count >= 4 && all_closed;
+        if (need_tp || riichi_pre) tp = tenpai_after_discard(c, P);
+        bool ok = lane < hl && !forb && (!r_stage || ((tp >> lane) & 1u));
+        uint64_t vb = __ballot(ok);
+        if (ok) {
+            int pos = n + __popcll(vb & lanemask_lt(lane));
+            if (pos < RMJ_MAX_LEGAL) c.X.legal[pid][pos] = mk_action(RMJ_DISCARD, ht, 0);
+        }
+        n += __popcll(vb);
+        if (riichi_pre && tp != 0u) put_legal(c, pid, n++, mk_action(RMJ_RIICHI, RMJ_TILE_NONE, 0));
+    }
+    // 3. Kan
+    if (S.drawable_count > 0 && drawn) {
+        if (!r_decl && !r_stage) {
+            // Ankan: types with 4 copies, ascending type.  lane = hand index, a type is reported by its first holder.
+            int ty = ht >> 2;
+            uint64_t same = 0;
+            // count copies of my type: hand is sorted except the last (drawn) tile -> use ballots per lane via loop over hand
+            int cnt = 0, first = 1;
+            for (int k = 0; k < hl; k++) {
+                int tk = P.hand[k] >> 2;
+                cnt += (tk == ty);
+                if (k < lane && tk == ty) first = 0;
+            }
+            (void)same;
+            bool is4 = lane < hl && cnt == 4 && first;
+            // order by type: rank among reporting lanes by type value
+            uint64_t rb = __ballot(is4);
+            if (rb) {
+                int rank = 0;
+                for (uint64_t q = rb; q; q &= q - 1) {
+                    int l2 = __ffsll((long long)q) - 1;
+                    int t2 = P.hand[l2] >> 2;
+                    rank += (t2 < ty);
+                }
+                if (is4) {
+                    uint32_t lo = (uint32_t)ty * 4u;
+                    int pos = n + rank;
+                    if (pos < RMJ_MAX_LEGAL) c.X.legal[pid][pos] = mk_action(RMJ_ANKAN, lo, 4, lo, lo + 1, lo + 2, lo + 3);
+                }
+                n += __popcll(rb);
+            }
+            // Kakan: meld order, then hand order
+            for (int m = 0; m < P.n_melds; m++) {
+                if (P.meld_type[m] == RMJ_MELD_PON) {
+                    int target = P.meld_tiles[m][0] >> 2;
+                    bool hit = lane < hl && (ht >> 2) == target;
+                    uint64_t kb = __ballot(hit);
+                    if (hit) {
+                        int pos = n + __popcll(kb & lanemask_lt(lane));
+                        if (pos < RMJ_MAX_LEGAL)
+                            c.X.legal[pid][pos] =
+                                mk_action(RMJ_KAKAN, ht, 3, P.meld_tiles[m][0], P.meld_tiles[m][1], P.meld_tiles[m][2]);
+                    }
+                    n += __popcll(kb);
+                }
+            }
+        } else if (r_decl) {
+            int t = S.drawn_tile, t34 = t >> 2;
+            PH full = build_ph(P);
+            if (ph_cnt(full, t34) == 4) {
+                PH pre = full;
+                ph_sub(pre, t34);
+                uint64_t wpre = 0, wpost = 0;
+                if (ph_total(pre) + 3 * P.n_melds == 13) wpre = wave_waits(pre, lane);
+                PH post = full;
+                ph_sub(post, t34); ph_sub(post, t34); ph_sub(post, t34); ph_sub(post, t34);
+                if (ph_total(post) + 3 * (P.n_melds + 1) == 13) wpost = wave_waits(post, lane);
+                if (wpre == wpost && wpre != 0ull) {
+                    uint32_t lo = (uint32_t)t34 * 4u;
+                    put_legal(c, pid, n++, mk_action(RMJ_ANKAN, lo, 4, lo, lo + 1, lo + 2, lo + 3));
+                }
+            }
+        }
+    }
+    // 4. Kyushu kyuhai
+    bool no_calls = (S.p[0].n_melds | S.p[1].n_melds | S.p[2].n_melds | S.p[3].n_melds) == 0;
+    if (S.is_first_turn && no_calls && !r_stage) {
+        uint64_t tm = 0;
+        for (int k = 0; k < hl; k++) {
+            int t = P.hand[k];
+            if (is_terminal_tile136(t)) tm |= 1ull << (t >> 2);
+        }
+        if (__popcll(tm) >= 9) put_legal(c, pid, n++, mk_action(RMJ_KYUSHU, RMJ_TILE_NONE, 0));
+    }
+    c.X.nl[pid] = n > RMJ_MAX_LEGAL ? RMJ_MAX_LEGAL : n;
+}
+
+// ---------------------------------------------------------------- transitions
+__device__ void init_next_round(Ctx& c, bool oya_won, bool is_draw);
+__device__ void trigger_ryukyoku(Ctx& c, int reason, int offender);
+
+// state/mod.rs:2021-2046
+__device__ inline void reveal_kan_dora(Ctx& c) {
+    GState& S = c.S;
+    int count = S.n_dora;
+    if (count < 5) {
+        int widx = 4 + 2 * count;  // fixed-array index; tiles[base_idx] with base_idx = widx - rinshan_count
+        if (widx < S.live_end) {
+            uint8_t t = c.W[widx];
+            S.dora[count] = t;
+            S.n_dora = (uint8_t)(count + 1);
+            emit_simple(c, RMJ_EV_DORA, 0, t);
+        }
+    }
+}
+__device__ inline void flush_pending_kan_dora(Ctx& c) {
+    while (c.S.pending_kan_dora > 0) {
+        c.S.pending_kan_dora -= 1;
+        reveal_kan_dora(c);
+    }
+}
+// state/mod.rs:1549-1567
+__device__ inline void accept_riichi(Ctx& c) {
+    GState& S = c.S;
+    if (S.riichi_pending != 0xFF) {
+        int p = S.riichi_pending;
+        S.p[p].score -= 1000;
+        S.p[p].score_delta -= 1000;
+        S.riichi_sticks += 1;
+        S.p[p].flags |= PF_RIICHI_DECLARED | PF_IPPATSU;
+        emit_simple(c, RMJ_EV_REACH_ACCEPTED, (uint8_t)p);
+        S.riichi_pending = 0xFF;
+    }
+}
+// state/mod.rs:2071-2082
+__device__ inline void process_end_game(Ctx& c) {
+    c.S.is_done = 1;
+    emit_simple(c, RMJ_EV_END_KYOKU);
+    emit_simple(c, RMJ_EV_END_GAME);
+}
+// state/mod.rs:1569-1593
+__device__ inline void deal_next(Ctx& c) {
+    GState& S = c.S;
+    S.is_rinshan = 0;
+    if (S.drawable_count == 0) {
+        trigger_ryukyoku(c, RMJ_RK_EXHAUSTIVE, 0);
+        return;
+    }
+    if (S.live_end > S.rinshan_count) {
+        uint8_t t = c.W[--S.live_end];
+        S.drawable_count -= 1;
+        int pid = S.current_player;
+        PState& P = S.p[pid];
+        if (P.hand_len < 14) P.hand[P.hand_len++] = t;
+        S.drawn_tile = t;
+        S.needs_tsumo = 0;
+        S.phase = RMJ_WAIT_ACT;
+        S.active_mask = (uint8_t)(1u << pid);
+        emit_simple(c, RMJ_EV_TSUMO, (uint8_t)pid, t);
+        P.n_forbidden = 0;
+    }
+}
+
+// the build's seed -> wall definition (oracle/riichi_state.hpp build_wall); writes W[0..135] (already reversed)
+__device__ __noinline__ void shuffle_wall(Ctx& c) {
+    GState& S = c.S;
+    uint64_t hs = sm64(S.wall_seed + (uint64_t)S.hand_index);
+    S.hand_index += 1;
+    const int N = 136;
+    for (int i = c.lane; i < N; i += 64) c.X.keys[i] = sm64(hs + (uint64_t)i * 0x9E3779B97F4A7C15ull);
+    wave_sync();
+    for (int i = c.lane; i < N; i += 64) {
+        uint64_t k = c.X.keys[i];
+        int r = 0;
+        for (int j = 0; j < N; j++) {
+            uint64_t kj = c.X.keys[j];
+            r += (kj < k) || (kj == k && j < i);
+        }
+        c.X.tiles[N - 1 - r] = (uint8_t)i;  // w[r] = i, then reverse
+    }
+    wave_sync();
+}
+
+// state/mod.rs:1695-1844.  Wall must already be in c.X.tiles (reversed orientation W).
+__device__ __noinline__ void init_round(Ctx& c, int oya, int round_wind, int honba, uint32_t kyotaku, const int32_t* scores) {
+    GState& S = c.S;
+    const int lane = c.lane;
+    S.oya = (uint8_t)oya;
+    S.kyoku_idx = (uint8_t)oya;
+    S.current_player = (uint8_t)oya;
+    S.honba = (uint8_t)honba;
+    S.riichi_sticks = kyotaku;
+    S.round_wind = (uint8_t)round_wind;
+    for (int p = 0; p < 4; p++) {  // PlayerState::reset_round, state/player.rs:66-86
+        PState& P = S.p[p];
+        P.hand_len = 0; P.n_melds = 0; P.n_discards = 0;
+        P.flags = PF_NAGASHI;
+        P.pao37 = 0xFF; P.pao50 = 0xFF;
+        P.n_forbidden = 0;
+        P.riichi_decl_idx = 0xFF; P.riichi_sutehai = 0xFF; P.last_tedashi = 0xFF;
+        P.score_delta = 0;
+        P.discard_from_hand_bits = 0; P.discard_is_riichi_bits = 0;
+        P.discard_type_mask = 0;
+        if (scores) P.score = scores[p];
+    }
+    S.is_done = 0;
+    S.pending_kan_pid = 0xFF;
+    S.pending_kan_action = 0;
+    S.is_rinshan = 0;
+    S.rinshan_count = 0;
+    S.pending_kan_dora = 0;
+    S.is_first_turn = 1;
+    S.riichi_pending = 0xFF;
+    S.turn_count = 0;
+    S.needs_tsumo = 1;
+    S.last_discard_pid = 0xFF;
+    S.last_discard_tile = 0;
+    S.ron_offer_mask = 0;
+    // publish the wall to HBM (W) and deal from LDS
+    for (int i = lane; i < RMJ_WALL_STRIDE / 4; i += 64)
+        reinterpret_cast<uint32_t*>(c.W)[i] = (i < 34) ? reinterpret_cast<const uint32_t*>(c.X.tiles)[i] : 0u;
+    S.wall_total = 136;
+    S.n_dora = 1;
+    S.dora[0] = c.X.tiles[4];
+    // deal: pop #n = X.tiles[135 - n]
+    if (lane < 52) {
+        int n = lane, p, pos;
+        if (n < 48) {
+            int r = n >> 4, idx = (n & 15) >> 2, k = n & 3;
+            p = (idx + oya) & 3;
+            pos = r * 4 + k;
+        } else {
+            p = ((n - 48) + oya) & 3;
+            pos = 12;
+        }
+        S.p[p].hand[pos] = c.X.tiles[135 - n];
+    }
+    wave_sync();
+    for (int p = 0; p < 4; p++) {
+        S.p[p].hand_len = 13;
+        sort_hand(c, S.p[p], 13);
+    }
+    S.live_end = (uint8_t)(136 - 52);
+    S.drawable_count = (uint8_t)(S.live_end - 14);
+    if (!c.E.skip_log) {
+        RmjEvent e = ev_zero(RMJ_EV_START_KYOKU);
+        e.actor = (uint8_t)oya;
+        e.target = (uint8_t)(oya + 1);
+        e.tile = S.dora[0];
+        e.consumed[0] = (uint8_t)(round_wind & 3);
+        e.consumed[1] = (uint8_t)honba;
+        e.consumed[2] = (uint8_t)(kyotaku & 0xFF);
+        e.consumed[3] = (uint8_t)((kyotaku >> 8) & 0xFF);
+        for (int p = 0; p < 4; p++) e.deltas[p] = S.p[p].score;
+        emit_raw(c, e);
+        for (int half = 0; half < 2; half++) {
+            RmjEvent t = ev_zero(RMJ_EV_TEHAI);
+            t.actor = (uint8_t)half;
+            uint8_t* pl = reinterpret_cast<uint8_t*>(&t) + 4;
+            for (int k = 0; k < 13; k++) {
+                pl[k] = S.p[2 * half].hand[k];
+                pl[13 + k] = S.p[2 * half + 1].hand[k];
+            }
+            emit_raw(c, t);
+        }
+    }
+    S.current_player = (uint8_t)oya;
+    S.phase = RMJ_WAIT_ACT;
+    S.active_mask = (uint8_t)(1u << oya);
+    {
+        uint8_t t = c.X.tiles[--S.live_end];
+        S.drawable_count -= 1;
+        PState& P = S.p[oya];
+        P.hand[P.hand_len++] = t;
+        S.drawn_tile = t;
+        S.needs_tsumo = 0;
+        emit_simple(c, RMJ_EV_TSUMO, (uint8_t)oya, t);
+    }
+}
+
+// state/mod.rs:1595-1688
+__device__ __noinline__ void init_next_round(Ctx& c, bool oya_won, bool is_draw) {
+    GState& S = c.S;
+    if (S.is_done) return;
+    const int np = 4;
+    int32_t sc[4];
+    bool neg = false;
+    int32_t max_score = S.p[0].score;
+    for (int p = 0; p < 4; p++) {
+        sc[p] = S.p[p].score;
+        neg = neg || sc[p] < 0;
+        max_score = max(max_score, sc[p]);
+    }
+    if (neg) { process_end_game(c); return; }
+    int oya = S.oya;
+    int32_t ds = sc[oya];
+    bool top = true;
+    for (int seat = 0; seat < 4; seat++) top = top && (seat == oya || ds > sc[seat] || (ds == sc[seat] && oya <= seat));
+    uint32_t gm = c.E.game_mode;
+    bool last_regular = false;
+    if (gm == 1 || gm == 4) last_regular = S.round_wind == 0 && oya == np - 1;
+    if (gm == 2 || gm == 5) last_regular = S.round_wind == 1 && oya == np - 1;
+    if (oya_won && last_regular && top && ds >= 30000) { process_end_game(c); return; }
+    int next_honba = S.honba, next_oya = oya, next_rw = S.round_wind;
+    if (oya_won) {
+        next_honba = min(next_honba + 1, 255);
+    } else {
+        next_honba = is_draw ? min(next_honba + 1, 255) : 0;
+        next_oya = (next_oya + 1) % np;
+        if (next_oya == 0) next_rw += 1;
+    }
+    bool end = false;
+    if (gm == 1 || gm == 4) end = next_rw >= 1 && (max_score >= 30000 || next_rw > 1);
+    else if (gm == 2 || gm == 5) end = next_rw >= 2 && (max_score >= 30000 || next_rw > 2);
+    else if (gm == 0 || gm == 3) end = true;
+    else end = next_rw >= 1;
+    if (end) { process_end_game(c); return; }
+    emit_simple(c, RMJ_EV_END_KYOKU);
+    uint32_t sticks = S.riichi_sticks;
+    shuffle_wall(c);
+    init_round(c, next_oya, next_rw, next_honba, sticks, sc);
+}
+
+// tenpai of a seat at exhaustive draw: HandEvaluator::is_tenpai (hand_evaluator.rs:178-194)
+__device__ inline bool seat_tenpai(Ctx& c, int seat) {
+    PState& P = c.S.p[seat];
+    PH h = build_ph(P);
+    if (ph_total(h) + 3 * P.n_melds != 13) return false;
+    return wave_waits(h, c.lane) != 0ull;
+}
+
+// state/mod.rs:1846-1968
+__device__ __noinline__ void trigger_ryukyoku(Ctx& c, int reason, int offender) {
+    GState& S = c.S;
+    accept_riichi(c);
+    const int np = 4;
+    bool tenpai[4] = {false, false, false, false};
+    int final_reason = reason;
+    uint32_t nagashi = 0;
+    if (reason == RMJ_RK_EXHAUSTIVE) {
+        for (int i = 0; i < np; i++) tenpai[i] = seat_tenpai(c, i);
+        for (int i = 0; i < np; i++)
+            if (S.p[i].flags & PF_NAGASHI) nagashi |= 1u << i;
+        if (nagashi) {
+            final_reason = RMJ_RK_NAGASHI;
+            for (int w = 0; w < np; w++) {
+                if (!((nagashi >> w) & 1u)) continue;
+                bool is_oya = w == S.oya;
+                ScoreOut s = calc_score(5, 30, is_oya, true, 0, np);
+                for (int i = 0; i < np; i++) {
+                    if (i == w) continue;
+                    int32_t pay = is_oya ? (int32_t)s.tsumo_ko : (i == S.oya ? (int32_t)s.tsumo_oya : (int32_t)s.tsumo_ko);
+                    S.p[i].score -= pay; S.p[i].score_delta -= pay;
+                    S.p[w].score += pay; S.p[w].score_delta += pay;
+                }
+            }
+        } else {
+            int num_tp = tenpai[0] + tenpai[1] + tenpai[2] + tenpai[3];
+            if (num_tp > 0 && num_tp < np) {
+                int32_t pk = 3000 / num_tp, pn = 3000 / (np - num_tp);
+                for (int i = 0; i < np; i++) {
+                    int32_t d = tenpai[i] ? pk : -pn;
+                    S.p[i].score += d;
+                    S.p[i].score_delta = d;
+                }
+            }
+        }
+    } else if (reason == RMJ_RK_ILLEGAL) {
+        int pid = offender;
+        if (pid == S.oya) {
+            int32_t penalty = 4000 * (np - 1), each = penalty / (np - 1);
+            for (int i = 0; i < np; i++) {
+                if (i == pid) { S.p[i].score -= penalty; S.p[i].score_delta = -penalty; }
+                else { S.p[i].score += each; S.p[i].score_delta = each; }
+            }
+        } else {
+            int32_t total = 4000 + 2000 * (np - 2);
+            for (int i = 0; i < np; i++) {
+                if (i == pid) { S.p[i].score -= total; S.p[i].score_delta = -total; }
+                else if (i == S.oya) { S.p[i].score += 4000; S.p[i].score_delta = 4000; }
+                else { S.p[i].score += 2000; S.p[i].score_delta = 2000; }
+            }
+        }
+    }
+    bool renchan;
+    if (final_reason == RMJ_RK_EXHAUSTIVE) renchan = tenpai[S.oya];
+    else if (final_reason == RMJ_RK_NAGASHI) renchan = (nagashi >> S.oya) & 1u;
+    else renchan = true;
+    if (!c.E.skip_log) {
+        RmjEvent e = ev_zero(RMJ_EV_RYUKYOKU);
+        e.flags = (uint8_t)final_reason;
+        e.actor = (uint8_t)offender;
+        for (int i = 0; i < np; i++) e.deltas[i] = S.p[i].score_delta;
+        emit_raw(c, e);
+    }
+    init_next_round(c, renchan, true);
+}
+
+// state/mod.rs:1970-2019
+__device__ inline bool check_abortive_draw(Ctx& c) {
+    GState& S = c.S;
+    bool turns_ok = true, melds_empty = true, all_riichi = true;
+    for (int p = 0; p < 4; p++) {
+        turns_ok = turns_ok && S.p[p].n_discards == 1;
+        melds_empty = melds_empty && S.p[p].n_melds == 0;
+        all_riichi = all_riichi && (S.p[p].flags & PF_RIICHI_DECLARED);
+    }
+    if (turns_ok && melds_empty) {
+        int first = S.p[0].discards[0] >> 2;
+        if (first >= 27 && first <= 30) {
+            bool all = true;
+            for (int p = 0; p < 4; p++) all = all && (S.p[p].discards[0] >> 2) == first;
+            if (all) { trigger_ryukyoku(c, RMJ_RK_SUFUURENTA, 0); return true; }
+        }
+    }
+    int kans = 0, first_owner = -1;
+    bool same = true;
+    for (int p = 0; p < 4; p++)
+        for (int m = 0; m < S.p[p].n_melds; m++)
+            if (S.p[p].meld_type[m] >= RMJ_MELD_DAIMINKAN) {
+                kans++;
+                if (first_owner < 0) first_owner = p;
+                else same = same && (p == first_owner);
+            }
+    if (kans == 4 && !same) { trigger_ryukyoku(c, RMJ_RK_SUUKANSANSEN, 0); return true; }
+    if (all_riichi) { trigger_ryukyoku(c, RMJ_RK_SUUCHA_RIICHI, 0); return true; }
+    return false;
+}
+
+// pao bookkeeping, state/mod.rs:1228-1259 / 1443-1472
+__device__ inline void pao_check(Ctx& c, int claimer, int discarder, int tile) {
+    PState& C = c.S.p[claimer];
+    int tv = tile >> 2;
+    int nd = 0, nw = 0;
+    for (int m = 0; m < C.n_melds; m++) {
+        int t = C.meld_tiles[m][0] >> 2;
+        if (C.meld_type[m] != RMJ_MELD_CHI) {
+            nd += (t >= 31 && t <= 33);
+            nw += (t >= 27 && t <= 30);
+        }
+    }
+    if (tv >= 31 && tv <= 33) {
+        if (nd == 3) C.pao37 = (uint8_t)discarder;
+    } else if (tv >= 27 && tv <= 30) {
+        if (nw == 4) C.pao50 = (uint8_t)discarder;
+    }
+}
+
+__device__ inline void push_meld(PState& P, int type, uint32_t t0, uint32_t t1, uint32_t t2, uint32_t t3, int n, int from, int called) {
+    int m = P.n_melds;
+    if (m >= 4) return;
+    uint32_t v[4] = {t0, t1, t2, n == 4 ? t3 : 0xFFFFu};
+#pragma unroll
+    for (int i = 0; i < 4; i++)
+#pragma unroll
+        for (int j = 0; j < 3; j++)
+            if (v[j] > v[j + 1]) { uint32_t t = v[j]; v[j] = v[j + 1]; v[j + 1] = t; }
+    for (int i = 0; i < 4; i++) P.meld_tiles[m][i] = (i < n) ? (uint8_t)v[i] : 0;
+    P.meld_type[m] = (uint8_t)type;
+    P.meld_from[m] = (uint8_t)from;
+    P.meld_called[m] = (uint8_t)called;
+    P.n_melds = (uint8_t)(m + 1);
+}
+
+// remove each consume tile from the hand (position lookup per tile, order preserved)
+__device__ inline void hand_remove_tiles(Ctx& c, PState& P, uint64_t act) {
+    uint32_t n = a_n(act);
+    for (uint32_t k = 0; k < n && k < 4; k++) {
+        int idx = hand_find(c, P, (int)a_c(act, k));
+        if (idx >= 0) hand_remove_at(c, P, idx);
+    }
+}
+
+// state/mod.rs:1415-1547
+__device__ __noinline__ void resolve_kan(Ctx& c, int pid, uint64_t action) {
+    GState& S = c.S;
+    PState& P = S.p[pid];
+    uint32_t ty = a_type(action);
+    if (ty != RMJ_KAKAN) {
+        hand_remove_tiles(c, P, action);
+        if (ty == RMJ_ANKAN) {
+            push_meld(P, RMJ_MELD_ANKAN, a_c(action, 0), a_c(action, 1), a_c(action, 2), a_c(action, 3), (int)min(a_n(action), 4u), 0xFF, 0xFF);
+        } else {
+            int discarder = S.last_discard_pid, tile = S.last_discard_tile;
+            push_meld(P, RMJ_MELD_DAIMINKAN, a_c(action, 0), a_c(action, 1), a_c(action, 2), (uint32_t)tile, 4, discarder, tile);
+            pao_check(c, pid, discarder, tile);
+        }
+    }
+    S.is_first_turn = 0;
+    for (int p = 0; p < 4; p++) S.p[p].flags &= ~PF_IPPATSU;
+    if (S.drawable_count > 0) {
+        uint8_t t = c.W[S.rinshan_count];
+        S.rinshan_count += 1;
+        S.drawable_count -= 1;
+        if (P.hand_len < 14) P.hand[P.hand_len++] = t;
+        S.drawn_tile = t;
+        S.is_rinshan = 1;
+        if (ty == RMJ_ANKAN) {
+            uint32_t tile = a_tile(action) != RMJ_TILE_NONE ? a_tile(action) : a_c(action, 0);
+            emit_meld(c, RMJ_EV_ANKAN, (uint8_t)pid, 0, (uint8_t)tile, action);
+        } else if (ty == RMJ_DAIMINKAN) {
+            emit_meld(c, RMJ_EV_DAIMINKAN, (uint8_t)pid, S.last_discard_pid, S.last_discard_tile, action);
+        }
+        flush_pending_kan_dora(c);
+        if (ty == RMJ_ANKAN) reveal_kan_dora(c);
+        else S.pending_kan_dora += 1;
+        emit_simple(c, RMJ_EV_TSUMO, (uint8_t)pid, t);
+        S.phase = RMJ_WAIT_ACT;
+        S.active_mask = (uint8_t)(1u << pid);
+    }
+}
+
+// state/mod.rs:1317-1413
+__device__ inline void resolve_discard(Ctx& c, int pid, int tile, bool tsumogiri) {
+    GState& S = c.S;
+    PState& P = S.p[pid];
+    S.is_rinshan = 0;
+    P.flags &= ~PF_IPPATSU;
+    int nd = P.n_discards;
+    if (nd < RMJ_MAX_DISCARDS) {
+        P.discards[nd] = (uint8_t)tile;
+        if (!tsumogiri) P.discard_from_hand_bits |= 1u << nd;
+        if (P.flags & PF_RIICHI_STAGE) P.discard_is_riichi_bits |= 1u << nd;
+        P.n_discards = (uint8_t)(nd + 1);
+    }
+    P.discard_type_mask |= 1ull << (tile >> 2);
+    S.last_discard_pid = (uint8_t)pid;
+    S.last_discard_tile = (uint8_t)tile;
+    S.drawn_tile = 0xFF;
+    if (!tsumogiri) P.last_tedashi = (uint8_t)tile;
+    S.needs_tsumo = 1;
+    if (P.flags & PF_RIICHI_STAGE) {
+        P.flags |= PF_RIICHI_DECLARED;
+        if (S.is_first_turn) P.flags |= PF_DOUBLE_RIICHI;
+        P.riichi_decl_idx = (uint8_t)(P.n_discards - 1);
+        P.flags &= ~PF_RIICHI_STAGE;
+        S.riichi_pending = (uint8_t)pid;
+    }
+    flush_pending_kan_dora(c);
+    emit_simple(c, RMJ_EV_DAHAI, (uint8_t)pid, (uint8_t)tile, tsumogiri ? 1 : 0);
+    P.flags &= ~PF_MISSED_DOUJUN;
+    if (!is_terminal_tile136(tile)) P.flags &= ~PF_NAGASHI;
+    S.active_mask = 0;
+    S.ron_offer_mask = 0;
+    uint32_t claim_active = 0;
+    for (int i = 0; i < 4; i++) {
+        c.X.nl[i] = 0;
+        if (i == pid) continue;
+        if (gen_claims(c, i, pid, tile)) claim_active |= 1u << i;
+    }
+    if (claim_active) {
+        S.phase = RMJ_WAIT_RESPONSE;
+        S.active_mask = (uint8_t)claim_active;
+    } else {
+        if (S.riichi_pending != 0xFF) accept_riichi(c);
+        if (!check_abortive_draw(c)) {
+            S.turn_count += 1;
+            S.current_player = (uint8_t)((pid + 1) & 3);
+            deal_next(c);
+            if (S.turn_count >= 4) S.is_first_turn = 0;
+        }
+    }
+}
+
+__device__ inline int yakuman_val(const Ctx& c, int yid) {
+    if (yid == 47 && rule(c, RMJ_RULE_JUNSEI_CHUUREN_DOUBLE)) return 2;
+    if (yid == 48 && rule(c, RMJ_RULE_SUUANKOU_TANKI_DOUBLE)) return 2;
+    if (yid == 49 && rule(c, RMJ_RULE_KOKUSHI13_DOUBLE)) return 2;
+    if (yid == 50 && rule(c, RMJ_RULE_DAISUUSHII_DOUBLE)) return 2;
+    return 1;
+}
+// double-yakuman cap, state/mod.rs:720-745 / 1005-1030
+__device__ inline void cap_double(const Ctx& c, CalcOut& r, bool is_oya, bool tsumo, uint32_t honba) {
+    if (r.yakuman && r.han > 13) {
+        int cap = 0;
+        if (((r.ym >> 47) & 1) && !rule(c, RMJ_RULE_JUNSEI_CHUUREN_DOUBLE)) cap += 13;
+        if (((r.ym >> 48) & 1) && !rule(c, RMJ_RULE_SUUANKOU_TANKI_DOUBLE)) cap += 13;
+        if (((r.ym >> 49) & 1) && !rule(c, RMJ_RULE_KOKUSHI13_DOUBLE)) cap += 13;
+        if (((r.ym >> 50) & 1) && !rule(c, RMJ_RULE_DAISUUSHII_DOUBLE)) cap += 13;
+        if (cap > 0) {
+            int h = r.han > cap ? r.han - cap : 0;
+            r.han = h < 13 ? 13 : h;
+            ScoreOut s = calc_score((uint32_t)r.han, 0, is_oya, tsumo, honba, 4);
+            r.ron = s.ron; r.tsumo_oya = s.tsumo_oya; r.tsumo_ko = s.tsumo_ko;
+        }
+    }
+}
+// sums yakuman values over the (unordered) yakuman id set; pao liability for 37 / 50
+__device__ inline void yakuman_totals(const Ctx& c, const CalcOut& r, const PState& P, int& total_val, int& pao_val, int& pao_payer) {
+    total_val = 0; pao_val = 0;
+    const int ids[15] = {35, 36, 37, 38, 39, 40, 41, 42, 43, 44, 45, 47, 48, 49, 50};
+    // reference iterates res.yaku in emission order; pao_payer = liable seat of the LAST matching id in that order.
+    // Emission order puts 37 before 50 (ORDER_YAKUMAN), and a hand cannot hold both, so order is immaterial here.
+    for (int k = 0; k < 15; k++) {
+        int y = ids[k];
+        if (!((r.ym >> y) & 1ull)) continue;
+        int v = yakuman_val(c, y);
+        total_val += v;
+        if (y == 37 && P.pao37 != 0xFF) { pao_val += v; pao_payer = P.pao37; }
+        if (y == 50 && P.pao50 != 0xFF) { pao_val += v; pao_payer = P.pao50; }
+    }
+}
+
+__device__ inline void emit_hora(Ctx& c, int actor, int target, const int32_t* deltas, bool tsumo, bool riichi) {
+    if (c.E.skip_log) return;
+    GState& S = c.S;
+    RmjEvent e = ev_zero(RMJ_EV_HORA);
+    e.actor = (uint8_t)actor;
+    e.target = (uint8_t)target;
+    for (int i = 0; i < 4; i++) e.deltas[i] = deltas[i];
+    e.flags = tsumo ? 1 : 0;
+    int nu = 0;
+    if (riichi)
+        for (int k = 0; k < S.n_dora; k++) {
+            int idx = 5 + 2 * k;
+            if (idx < S.live_end && nu < 5) e.ura[nu++] = c.W[idx];
+        }
+    e.n_ura = (uint8_t)nu;
+    emit_raw(c, e);
+}
+
+// ---------------------------------------------------------------- step (state/mod.rs:330-1315)
+__device__ inline void step_game(Ctx& c, const uint64_t acts_in[4]) {
+    GState& S = c.S;
+    const int lane = c.lane;
+    if (S.is_done) return;
+    S.step_count += 1;
+    uint64_t acts[4];
+    for (int p = 0; p < 4; p++) acts[p] = ((acts_in[p] & 0xFF) == 0xFF) ? RMJ_NO_ACTION : a_canon(acts_in[p]);
+    // ---- validation against the stored legal lists
+    for (int pid = 0; pid < 4; pid++) {
+        if (acts[pid] == RMJ_NO_ACTION) continue;
+        int n = c.E.nlegal[(size_t)c.g * 4 + pid];
+        bool active = (S.active_mask >> pid) & 1u;
+        bool valid;
+        if (!active || n == 0) {
+            // _get_legal_actions_internal for a non-active seat: [] in WaitAct, [Pass] in WaitResponse
+            valid = S.phase == RMJ_WAIT_RESPONSE && a_match(mk_action(RMJ_PASS, RMJ_TILE_NONE, 0), acts[pid]);
+        } else {
+            bool hit = lane < n && a_match(c.Lg[pid * RMJ_MAX_LEGAL + lane], acts[pid]);
+            valid = __ballot(hit) != 0ull;
+        }
+        if (!valid) {
+            S.last_error_pid = (uint8_t)pid;
+            trigger_ryukyoku(c, RMJ_RK_ILLEGAL, pid);
+            return;
+        }
+    }
+    if (S.phase == RMJ_WAIT_ACT) {
+        const int pid = S.current_player;
+        const uint64_t act = acts[pid];
+        if (act == RMJ_NO_ACTION) return;
+        PState& P = S.p[pid];
+        const uint32_t ty = a_type(act);
+        if (ty == RMJ_DISCARD) {
+            if (a_tile(act) == RMJ_TILE_NONE) return;
+            int tile = (int)a_tile(act);
+            bool tsumogiri = false, valid = false;
+            if (S.drawn_tile != 0xFF && S.drawn_tile == tile) { tsumogiri = true; valid = true; }
+            int idx = hand_find(c, P, tile);
+            if (idx >= 0) {
+                hand_remove_at(c, P, idx);
+                sort_hand(c, P, P.hand_len);
+                valid = true;
+            }
+            if (valid) resolve_discard(c, pid, tile, tsumogiri);
+        } else if (ty == RMJ_KYUSHU) {
+            trigger_ryukyoku(c, RMJ_RK_KYUSHU, 0);
+        } else if (ty == RMJ_RIICHI) {
+            if (P.score >= 1000 && S.drawable_count >= 4 && !(P.flags & (PF_RIICHI_DECLARED | PF_RIICHI_STAGE))) {
+                P.flags |= PF_RIICHI_STAGE;
+                emit_simple(c, RMJ_EV_REACH, (uint8_t)pid);
+                if (a_tile(act) != RMJ_TILE_NONE) {  // unreachable through validation (quirk Q13), kept for parity
+                    int t = (int)a_tile(act);
+                    bool tsumogiri = S.drawn_tile != 0xFF && S.drawn_tile == t;
+                    P.riichi_sutehai = (uint8_t)t;
+                    if (!tsumogiri) P.last_tedashi = (uint8_t)t;
+                    int idx = hand_find(c, P, t);
+                    if (idx >= 0) { hand_remove_at(c, P, idx); sort_hand(c, P, P.hand_len); }
+                    resolve_discard(c, pid, t, tsumogiri);
+                }
+            }
+        } else if (ty == RMJ_ANKAN) {
+            int tile = a_tile(act) != RMJ_TILE_NONE ? (int)a_tile(act) : (a_n(act) ? (int)a_c(act, 0) : 0);
+            uint32_t ronners = 0;
+            if (rule(c, RMJ_RULE_RON_ON_ANKAN_KOKUSHI)) {
+                S.ron_offer_mask = 0;
+                for (int i = 0; i < 4; i++) {
+                    c.X.nl[i] = 0;
+                    if (i == pid) continue;
+                    PState& Q = S.p[i];
+                    if ((Q.discard_type_mask >> (tile >> 2)) & 1ull) continue;
+                    uint32_t cf = CF_CHANKAN | ((Q.flags & PF_RIICHI_DECLARED) ? CF_RIICHI : 0u);
+                    CalcOut r = seat_calc(c, i, -1, tile, cf, 0, false);
+                    if (r.is_win && ((r.ym >> 42) & 1ull || (r.ym >> 49) & 1ull)) {
+                        ronners |= 1u << i;
+                        put_legal(c, i, 0, mk_action(RMJ_RON, tile, 0));
+                        put_legal(c, i, 1, mk_action(RMJ_PASS, RMJ_TILE_NONE, 0));
+                        c.X.nl[i] = 2;
+                        S.ron_offer_mask |= (uint8_t)(1u << i);
+                    }
+                }
+            }
+            if (ronners) {
+                S.pending_kan_pid = (uint8_t)pid;
+                S.pending_kan_action = act;
+                S.phase = RMJ_WAIT_RESPONSE;
+                S.active_mask = (uint8_t)ronners;
+                S.last_discard_pid = (uint8_t)pid;
+                S.last_discard_tile = (uint8_t)tile;
+            } else {
+                resolve_kan(c, pid, act);
+            }
+        } else if (ty == RMJ_KAKAN) {
+            int tile = a_tile(act) != RMJ_TILE_NONE ? (int)a_tile(act) : (a_n(act) ? (int)a_c(act, 0) : 0);
+            int idx = hand_find(c, P, tile);
+            if (idx >= 0) hand_remove_at(c, P, idx);
+            for (int m = 0; m < P.n_melds; m++)
+                if (P.meld_type[m] == RMJ_MELD_PON && (P.meld_tiles[m][0] >> 2) == (tile >> 2)) {
+                    P.meld_type[m] = RMJ_MELD_KAKAN;
+                    // insert keeping ascending ids
+                    uint32_t v[4] = {P.meld_tiles[m][0], P.meld_tiles[m][1], P.meld_tiles[m][2], (uint32_t)tile};
+                    for (int a = 0; a < 4; a++)
+                        for (int b = 0; b < 3; b++)
+                            if (v[b] > v[b + 1]) { uint32_t t = v[b]; v[b] = v[b + 1]; v[b + 1] = t; }
+                    for (int a = 0; a < 4; a++) P.meld_tiles[m][a] = (uint8_t)v[a];
+                    break;
+                }
+            emit_meld(c, RMJ_EV_KAKAN, (uint8_t)pid, 0, (uint8_t)tile, act);
+            flush_pending_kan_dora(c);
+            uint32_t ronners = 0;
+            S.ron_offer_mask = 0;
+            for (int i = 0; i < 4; i++) {
+                c.X.nl[i] = 0;
+                if (i == pid) continue;
+                PState& Q = S.p[i];
+                PH h = build_ph(Q);
+                uint64_t W = 0;
+                if (ph_total(h) + 3 * Q.n_melds == 13) W = wave_waits(h, lane);
+                c.X.wout[i] = W;
+                bool furiten = (W & Q.discard_type_mask) != 0ull || (Q.flags & (PF_MISSED_RIICHI | PF_MISSED_DOUJUN));
+                if (furiten || !((W >> (tile >> 2)) & 1ull)) continue;
+                uint32_t cf = base_cf(Q) | CF_CHANKAN;
+                CalcOut r = seat_calc(c, i, -1, tile, cf, S.honba, false);
+                if (r.is_win && (r.yakuman || r.han >= 1)) {
+                    ronners |= 1u << i;
+                    put_legal(c, i, 0, mk_action(RMJ_RON, tile, 0));
+                    put_legal(c, i, 1, mk_action(RMJ_PASS, RMJ_TILE_NONE, 0));
+                    c.X.nl[i] = 2;
+                    S.ron_offer_mask |= (uint8_t)(1u << i);
+                }
+            }
+            if (ronners) {
+                S.pending_kan_pid = (uint8_t)pid;
+                S.pending_kan_action = act;
+                S.phase = RMJ_WAIT_RESPONSE;
+                S.active_mask = (uint8_t)ronners;
+                S.last_discard_pid = (uint8_t)pid;
+                S.last_discard_tile = (uint8_t)tile;
+            } else {
+                resolve_kan(c, pid, act);
+            }
+        } else if (ty == RMJ_TSUMO) {
+            uint32_t cf = base_cf(P) | CF_TSUMO;
+            if (S.drawable_count == 0 && !S.is_rinshan) cf |= CF_HAITEI;
+            if (S.is_rinshan) cf |= CF_RINSHAN;
+            bool no_melds = (S.p[0].n_melds | S.p[1].n_melds | S.p[2].n_melds | S.p[3].n_melds) == 0;
+            if (S.is_first_turn && no_melds) cf |= CF_FIRST_TURN;  // quirk Q5 (settlement form)
+            int win_tile = S.drawn_tile != 0xFF ? S.drawn_tile : 0;
+            bool riichi = P.flags & PF_RIICHI_DECLARED;
+            CalcOut res = seat_calc(c, pid, -1, win_tile, cf, S.honba, riichi);
+            cap_double(c, res, pid == S.oya, true, S.honba);
+            if (res.is_win) {
+                int32_t deltas[4] = {0, 0, 0, 0};
+                int32_t total_win = 0;
+                int pao_payer = -1, pao_val = 0, total_val = 0;
+                if (res.yakuman) yakuman_totals(c, res, P, total_val, pao_val, pao_payer);
+                if (pao_val > 0) {
+                    int32_t unit = pid == S.oya ? 48000 : 32000;
+                    int32_t honba_total = (int32_t)S.honba * 3 * 100;
+                    if (pao_payer >= 0) {
+                        if (rule(c, RMJ_RULE_PAO_LIABILITY_ONLY)) {
+                            int32_t pao_amt = pao_val * unit + honba_total;
+                            int32_t non = total_val - pao_val;
+                            deltas[pao_payer] -= pao_amt;
+                            total_win += pao_amt;
+                            if (non > 0)
+                                for (int i = 0; i < 4; i++)
+                                    if (i != pid) {
+                                        int32_t pay = (pid == S.oya) ? non * 16000 : (i == S.oya ? non * 16000 : non * 8000);
+                                        deltas[i] -= pay;
+                                        total_win += pay;
+                                    }
+                        } else {
+                            int32_t full = total_val * unit + honba_total;
+                            deltas[pao_payer] -= full;
+                            total_win += full;
+                        }
+                    }
+                } else {
+                    for (int i = 0; i < 4; i++)
+                        if (i != pid) {
+                            int32_t pay = (pid == S.oya) ? (int32_t)res.tsumo_ko : (i == S.oya ? (int32_t)res.tsumo_oya : (int32_t)res.tsumo_ko);
+                            deltas[i] = -pay;
+                            total_win += pay;
+                        }
+                }
+                total_win += (int32_t)(S.riichi_sticks * 1000u);
+                S.riichi_sticks = 0;
+                deltas[pid] += total_win;
+                for (int i = 0; i < 4; i++) { S.p[i].score += deltas[i]; S.p[i].score_delta = deltas[i]; }
+                emit_hora(c, pid, pid, deltas, true, riichi);
+                init_next_round(c, pid == S.oya, false);
+            } else {
+                S.current_player = (uint8_t)((S.current_player + 1) & 3);
+                deal_next(c);
+            }
+        }
+        return;
+    }
+    // ---- WaitResponse (state/mod.rs:900-1314)
+    for (int pid = 0; pid < 4; pid++)
+        if ((S.ron_offer_mask >> pid) & 1u) {
+            bool roned = acts[pid] != RMJ_NO_ACTION && a_type(acts[pid]) == RMJ_RON;
+            if (!roned) {
+                S.p[pid].flags |= PF_MISSED_DOUJUN;
+                if (S.p[pid].flags & PF_RIICHI_DECLARED) S.p[pid].flags |= PF_MISSED_RIICHI;
+            }
+        }
+    uint32_t ron_mask = 0;
+    int claimer = -1;
+    uint64_t claim = 0;
+    for (int pid = 0; pid < 4; pid++) {  // active_players is in ascending seat order (state/mod.rs:1378-1395)
+        if (!((S.active_mask >> pid) & 1u) || acts[pid] == RMJ_NO_ACTION) continue;
+        uint32_t ty = a_type(acts[pid]);
+        if (ty == RMJ_RON) ron_mask |= 1u << pid;
+        else if (ty == RMJ_PON || ty == RMJ_DAIMINKAN || ty == RMJ_CHI) {
+            if (claimer >= 0) {
+                bool old_pon = a_type(claim) == RMJ_PON || a_type(claim) == RMJ_DAIMINKAN;
+                bool new_pon = ty == RMJ_PON || ty == RMJ_DAIMINKAN;
+                if (!old_pon && new_pon) { claimer = pid; claim = acts[pid]; }
+            } else { claimer = pid; claim = acts[pid]; }
+        }
+    }
+    if (ron_mask) {
+        if (__popc(ron_mask) >= 3 && rule(c, RMJ_RULE_SANCHAHO_DRAW)) { trigger_ryukyoku(c, RMJ_RK_SANCHAHO, 0); return; }
+        int target = S.last_discard_pid != 0xFF ? S.last_discard_pid : S.current_player;
+        int win_tile = S.last_discard_pid != 0xFF ? S.last_discard_tile : 0;
+        int32_t total_d[4] = {0, 0, 0, 0};
+        bool oya_won = false, deposit_taken = false, honba_taken = false;
+        for (int dist = 1; dist < 4; dist++) {  // winners sorted by distance from the discarder (state/mod.rs:954)
+            int w = (target + dist) & 3;
+            if (!((ron_mask >> w) & 1u)) continue;
+            PState& Wp = S.p[w];
+            uint32_t ron_honba = 0;
+            if (!honba_taken) { honba_taken = true; ron_honba = S.honba; }
+            uint32_t cf = base_cf(Wp);
+            if (S.drawable_count == 0 && !S.is_rinshan) cf |= CF_HOUTEI;
+            if (S.pending_kan_pid != 0xFF) cf |= CF_CHANKAN;
+            bool riichi = Wp.flags & PF_RIICHI_DECLARED;
+            CalcOut res = seat_calc(c, w, -1, win_tile, cf, ron_honba, riichi);
+            cap_double(c, res, w == S.oya, false, ron_honba);
+            if (res.is_win) {
+                int32_t score = (int32_t)res.ron;
+                int pao_payer = target;
+                int32_t pao_amt = 0;
+                if (res.yakuman) {
+                    int total_val = 0, pao_val = 0, pp = -1;
+                    yakuman_totals(c, res, Wp, total_val, pao_val, pp);
+                    if (pp >= 0) {
+                        pao_payer = pp;
+                        int32_t unit = (w == S.oya) ? 48000 : 32000;
+                        int32_t honba_ron = (int32_t)ron_honba * 3 * 100;
+                        int32_t split_base = rule(c, RMJ_RULE_PAO_LIABILITY_ONLY) ? pao_val * unit : total_val * unit;
+                        pao_amt = split_base / 2 + honba_ron;
+                    }
+                }
+                int32_t this_d[4] = {0, 0, 0, 0};
+                this_d[w] += score;
+                this_d[pao_payer] -= pao_amt;
+                this_d[target] -= score - pao_amt;
+                total_d[w] += score;
+                total_d[pao_payer] -= pao_amt;
+                total_d[target] -= score - pao_amt;
+                if (!deposit_taken) {
+                    int32_t sp = (int32_t)(S.riichi_sticks * 1000u);
+                    total_d[w] += sp;
+                    this_d[w] += sp;
+                    S.riichi_sticks = 0;
+                    deposit_taken = true;
+                }
+                if (w == S.oya) oya_won = true;
+                emit_hora(c, w, target, this_d, false, riichi);
+            }
+        }
+        for (int i = 0; i < 4; i++) { S.p[i].score += total_d[i]; S.p[i].score_delta = total_d[i]; }
+        init_next_round(c, oya_won, false);
+    } else if (claimer >= 0) {
+        PState& C = S.p[claimer];
+        accept_riichi(c);
+        S.is_rinshan = 0;
+        S.is_first_turn = 0;
+        C.flags &= ~PF_MISSED_DOUJUN;
+        if (S.last_discard_pid != 0xFF) S.p[S.last_discard_pid].flags &= ~PF_NAGASHI;
+        for (int p = 0; p < 4; p++) S.p[p].flags &= ~PF_IPPATSU;
+        uint32_t ty = a_type(claim);
+        if (ty == RMJ_DAIMINKAN) {
+            S.current_player = (uint8_t)claimer;
+            S.active_mask = (uint8_t)(1u << claimer);
+            C.n_forbidden = 0;
+            resolve_kan(c, claimer, claim);
+            return;
+        }
+        hand_remove_tiles(c, C, claim);
+        int discarder = S.last_discard_pid, tile = S.last_discard_tile;
+        push_meld(C, ty == RMJ_PON ? RMJ_MELD_PON : RMJ_MELD_CHI, a_c(claim, 0), a_c(claim, 1), (uint32_t)tile, 0, 3, discarder, tile);
+        emit_meld(c, ty == RMJ_PON ? RMJ_EV_PON : RMJ_EV_CHI, (uint8_t)claimer, (uint8_t)discarder, (uint8_t)tile, claim);
+        if (ty == RMJ_PON) pao_check(c, claimer, discarder, tile);
+        S.current_player = (uint8_t)claimer;
+        S.phase = RMJ_WAIT_ACT;
+        S.active_mask = (uint8_t)(1u << claimer);
+        C.n_forbidden = 0;
+        if (ty == RMJ_PON) {
+            C.forbidden[0] = (uint8_t)tile;
+            C.n_forbidden = 1;
+        } else {
+            C.forbidden[0] = (uint8_t)tile;
+            C.n_forbidden = 1;
+            int t34 = tile >> 2;
+            int x = (int)a_c(claim, 0) >> 2, y = (int)a_c(claim, 1) >> 2;
+            int lo = min(x, y), hi = max(x, y);
+            if (lo == t34 + 1 && hi == t34 + 2) {
+                if (t34 % 9 <= 5) { C.forbidden[1] = (uint8_t)((t34 + 3) * 4); C.n_forbidden = 2; }
+            } else if (t34 >= 2 && hi == t34 - 1 && lo == t34 - 2 && t34 % 9 >= 3) {
+                C.forbidden[1] = (uint8_t)((t34 - 3) * 4);
+                C.n_forbidden = 2;
+            }
+        }
+        S.needs_tsumo = 0;
+        S.drawn_tile = 0xFF;
+    } else {
+        S.active_mask = 0;
+        S.ron_offer_mask = 0;
+        if (S.pending_kan_pid != 0xFF) {
+            int pk = S.pending_kan_pid;
+            uint64_t pa = S.pending_kan_action;
+            S.pending_kan_pid = 0xFF;
+            S.pending_kan_action = 0;
+            resolve_kan(c, pk, pa);
+        } else {
+            accept_riichi(c);
+            S.turn_count += 1;
+            S.current_player = (uint8_t)((S.current_player + 1) & 3);
+            deal_next(c);
+            if (S.turn_count >= 4) S.is_first_turn = 0;
+        }
+    }
+}
+
+// After a transition: produce the observation-side outputs for the new state
+// (get_observations(active_players), env.rs:870-871 -> state/mod.rs:189-263; mask: observation/python.rs:98-111)
+__device__ inline void finalize_outputs(Ctx& c, bool claims_fresh) {
+    GState& S = c.S;
+    const int lane = c.lane;
+    if (S.is_done) {
+        for (int p = 0; p < 4; p++) { c.X.nl[p] = 0; c.X.wout[p] = 0; }
+    } else if (S.phase == RMJ_WAIT_ACT) {
+        for (int p = 0; p < 4; p++) { c.X.nl[p] = 0; c.X.wout[p] = 0; }
+        gen_act_legal(c, S.current_player);
+    } else if (!claims_fresh) {
+        // WaitResponse that was not produced in this launch (e.g. after rmj_poke_state): rebuild claims
+        if (S.pending_kan_pid == 0xFF && S.last_discard_pid != 0xFF) {
+            uint32_t want = S.active_mask, got = 0;
+            S.ron_offer_mask = 0;
+            for (int i = 0; i < 4; i++) {
+                c.X.nl[i] = 0;
+                c.X.wout[i] = 0;
+                if (i == S.last_discard_pid || !((want >> i) & 1u)) continue;
+                if (gen_claims(c, i, S.last_discard_pid, S.last_discard_tile)) got |= 1u << i;
+            }
+            (void)got;
+        }
+    }
+    wave_sync();
+    // masks + list publication
+    for (int i = lane; i < (4 * 82 + 3) / 4; i += 64) reinterpret_cast<uint32_t*>(c.X.maskbuf)[i] = 0u;
+    wave_sync();
+    for (int p = 0; p < 4; p++) {
+        int n = c.X.nl[p];
+        if (!((S.active_mask >> p) & 1u)) n = 0;
+        if (lane < n) {
+            uint64_t a = c.X.legal[p][lane];
+            c.Lg[p * RMJ_MAX_LEGAL + lane] = a;
+            int id = a_encode(a);
+            if (id >= 0 && id < 82) c.X.maskbuf[p * 82 + id] = 1;
+        }
+    }
+    wave_sync();
+    uint32_t* mout = reinterpret_cast<uint32_t*>(c.E.mask + (size_t)c.g * 328);
+    for (int i = lane; i < 82; i += 64) mout[i] = reinterpret_cast<const uint32_t*>(c.X.maskbuf)[i];
+    if (lane < 4) {
+        int n = c.X.nl[0];
+        n = lane == 1 ? c.X.nl[1] : n;
+        n = lane == 2 ? c.X.nl[2] : n;
+        n = lane == 3 ? c.X.nl[3] : n;
+        if (!((S.active_mask >> lane) & 1u)) n = 0;
+        c.E.nlegal[(size_t)c.g * 4 + lane] = (uint8_t)n;
+        uint64_t w = c.X.wout[0];
+        w = lane == 1 ? c.X.wout[1] : w;
+        w = lane == 2 ? c.X.wout[2] : w;
+        w = lane == 3 ? c.X.wout[3] : w;
+        if (!((S.active_mask >> lane) & 1u)) w = 0;
+        c.E.waits[(size_t)c.g * 4 + lane] = w;
+    }
+    if (lane == 0) c.E.status[c.g] = (uint32_t)S.active_mask | ((uint32_t)S.phase << 8) | ((uint32_t)S.is_done << 16);
+}
+
+}  // namespace rmj

@@ -1,0 +1,287 @@
+"""Batched Riichi Mahjong environment on MI355X — Python binding of the C-ABI
+(include/riichi_mi355x.h, built to riichienv_amd/libriichi_mi355x.so).
+
+`VecRiichiEnv` is the batched counterpart of the reference's `RiichiEnv`
+(riichienv-python/src/env.rs:74-872): N independent games stepped in lock-step by HIP
+kernels.  There is NO CPU fallback: importing works anywhere (so the symbol table can be
+checked), but every compute call raises if the HIP library or a GPU is missing.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import json
+import os
+
+import numpy as np
+
+from . import abi
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libriichi_mi355x.so")
+_LIB = None
+
+# every symbol include/riichi_mi355x.h declares
+EXPORTS = [
+    "rmj_version", "rmj_last_error", "rmj_device_count", "rmj_create", "rmj_destroy", "rmj_reset", "rmj_step",
+    "rmj_step_device", "rmj_step_random", "rmj_random_actions", "rmj_get_status", "rmj_get_legal", "rmj_get_mask",
+    "rmj_get_waits", "rmj_get_scores", "rmj_get_ranks", "rmj_get_step_counts", "rmj_total_steps", "rmj_peek_state",
+    "rmj_poke_state", "rmj_get_event_counts", "rmj_get_events", "rmj_format_event", "rmj_eval_hands",
+    "rmj_agari_counts", "rmj_calculate_score", "rmj_bench_rollout",
+]
+
+
+class RmjError(RuntimeError):
+    pass
+
+
+def load_lib():
+    """Load the HIP library; raises (never falls back) if it has not been built."""
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    if not os.path.exists(LIB_PATH):
+        raise RmjError(f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                       "(hipcc --offload-arch=gfx950). There is no CPU fallback.")
+    L = C.CDLL(LIB_PATH)
+    L.rmj_version.restype = C.c_char_p
+    L.rmj_last_error.restype = C.c_char_p
+    vp = C.c_void_p
+    L.rmj_create.argtypes = [C.POINTER(abi.Config), C.POINTER(vp)]
+    L.rmj_destroy.argtypes = [vp]
+    L.rmj_reset.argtypes = [vp] * 8
+    L.rmj_step.argtypes = [vp, vp]
+    L.rmj_step_device.argtypes = [vp, vp]
+    L.rmj_step_random.argtypes = [vp, C.c_uint64, C.c_uint32, C.c_int]
+    L.rmj_random_actions.argtypes = [vp, C.c_uint64, vp]
+    L.rmj_get_status.argtypes = [vp, vp, vp, vp]
+    L.rmj_get_legal.argtypes = [vp, vp, vp]
+    L.rmj_get_mask.argtypes = [vp, vp]
+    L.rmj_get_waits.argtypes = [vp, vp]
+    L.rmj_get_scores.argtypes = [vp, vp]
+    L.rmj_get_ranks.argtypes = [vp, vp]
+    L.rmj_get_step_counts.argtypes = [vp, vp]
+    L.rmj_total_steps.argtypes = [vp, C.POINTER(C.c_uint64)]
+    L.rmj_peek_state.argtypes = [vp, C.c_uint32, C.POINTER(abi.StateView)]
+    L.rmj_poke_state.argtypes = [vp, C.c_uint32, C.POINTER(abi.StateView)]
+    L.rmj_get_event_counts.argtypes = [vp, vp]
+    L.rmj_get_events.argtypes = [vp, C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(abi.Event), C.POINTER(C.c_uint32)]
+    L.rmj_format_event.argtypes = [C.POINTER(abi.Event), C.c_uint32, C.c_int, C.c_char_p, C.c_uint32]
+    L.rmj_eval_hands.argtypes = [C.c_int, C.POINTER(abi.HandCase), C.c_uint32, C.POINTER(abi.HandResult)]
+    L.rmj_agari_counts.argtypes = [C.c_int, vp, C.c_uint32, vp, vp, vp]
+    L.rmj_calculate_score.argtypes = [C.c_int] + [vp] * 6 + [C.c_uint32, vp]
+    L.rmj_bench_rollout.argtypes = [vp, C.c_uint64, C.c_uint32, C.c_uint32, C.POINTER(abi.BenchResult)]
+    _LIB = L
+    return L
+
+
+def _chk(rc):
+    if rc != 0:
+        raise RmjError(f"rmj error {rc}: {load_lib().rmj_last_error().decode()}")
+
+
+GAME_MODES = {"4p-red-single": 0, "4p-red-east": 1, "4p-red-half": 2, "3p-red-single": 3, "3p-red-east": 4,
+              "3p-red-half": 5}
+
+
+def _mode_id(game_mode) -> int:
+    # env.rs:93-100
+    if game_mode is None:
+        return 0
+    if isinstance(game_mode, str):
+        return GAME_MODES.get(game_mode, 0)
+    return int(game_mode)
+
+
+def _opt(arr, dtype, shape):
+    if arr is None:
+        return None, None
+    a = np.ascontiguousarray(arr, dtype=dtype).reshape(shape)
+    return a, a.ctypes.data
+
+
+class VecRiichiEnv:
+    """N independent games on one GPU (one shard of a batch sharded by game index)."""
+
+    def __init__(self, n_games, game_mode=0, seed=0, seeds=None, rule_bits=abi.RULE_TENHOU, skip_mjai_logging=False,
+                 round_wind=0, device=0, game_offset=0, event_ring=64):
+        self.L = load_lib()
+        self.n = int(n_games)
+        cfg = abi.Config()
+        cfg.n_games = self.n
+        cfg.game_mode = _mode_id(game_mode)
+        cfg.skip_mjai_logging = int(bool(skip_mjai_logging))
+        cfg.round_wind = round_wind
+        cfg.rule_bits = rule_bits
+        cfg.device = device
+        cfg.base_seed = int(seed) & 0xFFFFFFFFFFFFFFFF
+        cfg.game_offset = int(game_offset)
+        self._seeds = None
+        if seeds is not None:
+            self._seeds = np.ascontiguousarray(seeds, dtype=np.uint64)
+            assert self._seeds.shape == (self.n,)
+            cfg.seeds = self._seeds.ctypes.data_as(C.POINTER(C.c_uint64))
+        cfg.event_ring = event_ring
+        self.game_mode = cfg.game_mode
+        self.game_offset = int(game_offset)
+        self.h = C.c_void_p()
+        _chk(self.L.rmj_create(C.byref(cfg), C.byref(self.h)))
+
+    def close(self):
+        if getattr(self, "h", None) is not None and self.h:
+            self.L.rmj_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- RiichiEnv.reset (env.rs:799-851), batched
+    def reset(self, select=None, walls=None, oya=None, round_wind=None, scores=None, honba=None, kyotaku=None):
+        n = self.n
+        if scores is not None and np.asarray(scores).reshape(n, -1).shape[1] != 4:
+            raise ValueError("scores length does not match number of players 4")  # env.rs:815-823
+        keep = []
+        ptrs = []
+        for arr, dt, shp in ((select, np.uint8, (n,)), (walls, np.uint8, (n, 136)), (oya, np.uint8, (n,)),
+                             (round_wind, np.uint8, (n,)), (scores, np.int32, (n, 4)), (honba, np.uint8, (n,)),
+                             (kyotaku, np.uint32, (n,))):
+            a, p = _opt(arr, dt, shp)
+            keep.append(a)
+            ptrs.append(p)
+        _chk(self.L.rmj_reset(self.h, *ptrs))
+
+    # ---- RiichiEnv.step (env.rs:857-872), batched
+    def step(self, actions):
+        a = np.ascontiguousarray(actions, dtype=np.uint64).reshape(self.n, 4)
+        _chk(self.L.rmj_step(self.h, a.ctypes.data))
+
+    def step_random(self, policy_seed, n_steps=1, auto_reset=False):
+        _chk(self.L.rmj_step_random(self.h, policy_seed, n_steps, int(auto_reset)))
+
+    def random_actions(self, policy_seed):
+        a = np.zeros((self.n, 4), np.uint64)
+        _chk(self.L.rmj_random_actions(self.h, policy_seed, a.ctypes.data))
+        return a
+
+    # ---- observations
+    def status(self):
+        a, p, d = (np.zeros(self.n, np.uint8) for _ in range(3))
+        _chk(self.L.rmj_get_status(self.h, a.ctypes.data, p.ctypes.data, d.ctypes.data))
+        return a, p, d
+
+    def done(self):
+        return self.status()[2].astype(bool)
+
+    def legal(self):
+        l = np.zeros((self.n, 4, abi.MAX_LEGAL), np.uint64)
+        c = np.zeros((self.n, 4), np.uint8)
+        _chk(self.L.rmj_get_legal(self.h, l.ctypes.data, c.ctypes.data))
+        return l, c
+
+    def mask(self):
+        m = np.zeros((self.n, 4, 82), np.uint8)
+        _chk(self.L.rmj_get_mask(self.h, m.ctypes.data))
+        return m
+
+    def waits(self):
+        w = np.zeros((self.n, 4), np.uint64)
+        _chk(self.L.rmj_get_waits(self.h, w.ctypes.data))
+        return w
+
+    def scores(self):
+        s = np.zeros((self.n, 4), np.int32)
+        _chk(self.L.rmj_get_scores(self.h, s.ctypes.data))
+        return s
+
+    def ranks(self):
+        r = np.zeros((self.n, 4), np.uint8)
+        _chk(self.L.rmj_get_ranks(self.h, r.ctypes.data))
+        return r
+
+    def step_counts(self):
+        s = np.zeros(self.n, np.uint64)
+        _chk(self.L.rmj_get_step_counts(self.h, s.ctypes.data))
+        return s
+
+    def total_steps(self):
+        t = C.c_uint64()
+        _chk(self.L.rmj_total_steps(self.h, C.byref(t)))
+        return t.value
+
+    def peek(self, g) -> abi.StateView:
+        v = abi.StateView()
+        _chk(self.L.rmj_peek_state(self.h, g, C.byref(v)))
+        return v
+
+    def poke(self, g, v: abi.StateView):
+        _chk(self.L.rmj_poke_state(self.h, g, C.byref(v)))
+
+    def event_counts(self):
+        c = np.zeros(self.n, np.uint32)
+        _chk(self.L.rmj_get_event_counts(self.h, c.ctypes.data))
+        return c
+
+    def events(self, g, first=0, max_events=1 << 16):
+        buf = (abi.Event * max_events)()
+        n = C.c_uint32()
+        _chk(self.L.rmj_get_events(self.h, g, first, max_events, buf, C.byref(n)))
+        return buf, n.value
+
+    def mjai_log(self, g, seat=-1, first=0):
+        """MJAI JSON strings of game g (seat=-1: full log; 0..3: that seat's masked view,
+        state/mod.rs:2094-2148)."""
+        buf, n = self.events(g, first)
+        out = []
+        s = C.create_string_buffer(2048)
+        i = 0
+        while i < n:
+            used = self.L.rmj_format_event(C.cast(C.byref(buf, i * C.sizeof(abi.Event)), C.POINTER(abi.Event)), n - i, seat,
+                                           s, 2048)
+            if used <= 0:
+                raise RmjError(f"cannot format event {i} of game {g} (type {buf[i].type})")
+            out.append(s.value.decode())
+            i += used
+        return out
+
+    def bench_rollout(self, policy_seed, warmup, steps) -> abi.BenchResult:
+        r = abi.BenchResult()
+        _chk(self.L.rmj_bench_rollout(self.h, policy_seed, warmup, steps, C.byref(r)))
+        return r
+
+
+# ---- batched hand math (kernel gate) -----------------------------------------------------
+def eval_hands(cases, device=0):
+    L = load_lib()
+    arr = (abi.HandCase * len(cases))(*cases)
+    out = (abi.HandResult * len(cases))()
+    _chk(L.rmj_eval_hands(device, arr, len(cases), out))
+    return list(out)
+
+
+def agari_counts(counts, device=0):
+    L = load_lib()
+    counts = np.ascontiguousarray(counts, dtype=np.uint8)
+    n = counts.shape[0]
+    ag = np.zeros(n, np.uint8)
+    tp = np.zeros(n, np.uint8)
+    w = np.zeros(n, np.uint64)
+    _chk(L.rmj_agari_counts(device, counts.ctypes.data, n, ag.ctypes.data, tp.ctypes.data, w.ctypes.data))
+    return ag, tp, w
+
+
+def calculate_score(han, fu, is_oya, is_tsumo, honba, num_players, device=0):
+    L = load_lib()
+    a = [np.ascontiguousarray(x, dtype=np.uint8) for x in (han, fu, is_oya, is_tsumo)]
+    hb = np.ascontiguousarray(honba, dtype=np.uint32)
+    npl = np.ascontiguousarray(num_players, dtype=np.uint8)
+    n = len(a[0])
+    out = np.zeros((n, 4), np.uint32)
+    _chk(L.rmj_calculate_score(device, a[0].ctypes.data, a[1].ctypes.data, a[2].ctypes.data, a[3].ctypes.data,
+                               hb.ctypes.data, npl.ctypes.data, n, out.ctypes.data))
+    return out
+
+
+def mjai_log_dicts(strings):
+    return [json.loads(s) for s in strings]

@@ -1,0 +1,95 @@
+"""GPU parity (the hot path): VecRiichiEnv through the C-ABI vs the oracle, game by game and
+step by step — full state, ordered legal lists, masks, waits, MJAI event strings, scores."""
+import numpy as np
+import pytest
+
+from riichienv_amd import abi
+from tests.parity_util import diff_dict, fmt_action, normalize_view
+
+pytestmark = pytest.mark.gpu
+
+
+def _compare(env, games, g_ids, step_no, check_state=True):
+    act, ph, dn = env.status()
+    legal, cnt = env.legal()
+    mask = env.mask()
+    waits = env.waits()
+    for g in g_ids:
+        o = games[g]
+        oa, op, od = o.status()
+        assert dn[g] == od, (g, step_no, "done")
+        assert act[g] == oa and ph[g] == op, (g, step_no, "active/phase", act[g], oa, ph[g], op)
+        if check_state:
+            d = diff_dict(normalize_view(env.peek(g)), normalize_view(o.peek()))
+            assert not d, (g, step_no, d[:10])
+        if od:
+            assert cnt[g].sum() == 0
+            continue
+        for s in range(4):
+            if (oa >> s) & 1:
+                ol = o.legal(s)
+                gl = [int(x) for x in legal[g, s, : cnt[g, s]]]
+                assert gl == ol, (g, step_no, s, [fmt_action(a) for a in gl], [fmt_action(a) for a in ol])
+                assert (mask[g, s] == o.mask(s)).all(), (g, step_no, s)
+                assert int(waits[g, s]) == o.waits(s), (g, step_no, s)
+            else:
+                assert cnt[g, s] == 0 and mask[g, s].sum() == 0
+
+
+@pytest.mark.parametrize("mode,rule", [(2, abi.RULE_TENHOU), (1, abi.RULE_MJSOUL)])
+def test_random_rollout_parity(mode, rule):
+    """configs[1]-style: random-agent self-play, every step compared with the oracle."""
+    from oracle import oracle
+    from riichienv_amd import vecenv
+
+    n, seed, pseed = 48, 1000, 77
+    env = vecenv.VecRiichiEnv(n, game_mode=mode, seed=seed, rule_bits=rule, event_ring=8192)
+    games = [oracle.Game(game_mode=mode, seed=seed + g, rule_bits=rule) for g in range(n)]
+    _compare(env, games, range(n), -1)  # constructor state (shuffle #0)
+    env.reset()
+    for o in games:
+        o.reset()
+    _compare(env, games, range(n), 0)
+    for step in range(1, 2500):
+        acts = np.array([games[g].random_actions(pseed, g) for g in range(n)], dtype=np.uint64)
+        dev = env.random_actions(pseed)
+        assert (dev == acts).all(), step
+        env.step(acts)
+        for g in range(n):
+            games[g].step([int(x) for x in acts[g]])
+        # full state on a rotating subset (peek is a D2H copy per game), outputs on all games
+        _compare(env, games, range(n), step, check_state=False)
+        _compare(env, games, [step % n, (step * 7) % n], step, check_state=True)
+        if all(o.status()[2] for o in games):
+            break
+    assert all(o.status()[2] for o in games)
+    sc = env.scores()
+    for g in range(n):
+        _compare(env, games, [g], 99999)
+        assert env.mjai_log(g) == games[g].log(), g
+        for seat in range(4):
+            assert env.mjai_log(g, seat) == games[g].log(seat), (g, seat)
+        assert list(sc[g]) == [p.score for p in games[g].peek().players]
+
+
+def test_step_random_device_policy_matches_oracle():
+    """rmj_step_random (policy fused on device, auto-reset) against the oracle driven by the same policy."""
+    from oracle import oracle
+    from riichienv_amd import vecenv
+
+    n, seed, pseed, steps = 32, 5, 4242, 1500
+    env = vecenv.VecRiichiEnv(n, game_mode=0, seed=seed, event_ring=64)
+    games = [oracle.Game(game_mode=0, seed=seed + g) for g in range(n)]
+    env.reset()
+    for o in games:
+        o.reset()
+    env.step_random(pseed, steps, auto_reset=True)
+    for g, o in enumerate(games):
+        for _ in range(steps):
+            if o.status()[2]:
+                o.reset()
+                continue
+            o.step(o.random_actions(pseed, g))
+    _compare(env, games, range(n), steps)
+    assert list(env.step_counts()) == [o.step_count for o in games]
+    assert env.total_steps() == sum(o.step_count for o in games)

@@ -44,7 +44,7 @@ __device__ inline void device_env_reset_default(Ctx& c) {
     init_round(c, 0, 0, 0, 0, sc);
 }
 
-__global__ __launch_bounds__(256) void k_step(Env E, const uint64_t* __restrict__ actions, uint64_t policy_seed, uint32_t flags) {
+__global__ __launch_bounds__(256, 4) void k_step(Env E, const uint64_t* __restrict__ actions, uint64_t policy_seed, uint32_t flags) {
     __shared__ BlockShared sh;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const uint32_t g = blockIdx.x * WPB + wave;
@@ -106,7 +106,7 @@ struct ResetArgs {
     uint32_t is_ctor;
 };
 
-__global__ __launch_bounds__(256) void k_reset(Env E, ResetArgs A) {
+__global__ __launch_bounds__(256, 4) void k_reset(Env E, ResetArgs A) {
     __shared__ BlockShared sh;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const uint32_t g = blockIdx.x * WPB + wave;
@@ -152,7 +152,7 @@ __global__ __launch_bounds__(256) void k_reset(Env E, ResetArgs A) {
 }
 
 // recompute observation outputs of one game after rmj_poke_state
-__global__ __launch_bounds__(64) void k_refresh(Env E, uint32_t g) {
+__global__ __launch_bounds__(64, 4) void k_refresh(Env E, uint32_t g) {
     __shared__ GState st;
     __shared__ WaveScratch x;
     const int lane = threadIdx.x & 63;

@@ -26,6 +26,7 @@
 #define PF_MISSED_DOUJUN 16u
 #define PF_NAGASHI 32u
 #define PF_IPPATSU 64u
+#define PF_WAITS_VALID 128u /* derived cache bit: waits13 is current (never exported) */
 
 struct alignas(16) PState {  // 128 bytes
     uint8_t hand[14];        // 136-ids; 13 sorted + drawn tile last (state/mod.rs:1575-1579)
@@ -48,7 +49,8 @@ struct alignas(16) PState {  // 128 bytes
     uint32_t discard_from_hand_bits, discard_is_riichi_bits;
     uint64_t discard_type_mask;  // derived cache: bit t set iff some discard has type t
     uint8_t discards[32];
-    uint8_t pad1[16];
+    uint64_t waits13;            // derived cache: get_waits of the 13-tile hand (valid iff PF_WAITS_VALID)
+    uint8_t pad1[8];
 };
 
 struct alignas(16) GState {  // 4*128 + 128 = 640 bytes

@@ -329,22 +329,40 @@ __device__ inline uint32_t base_cf(const PState& P) {
     return cf;
 }
 
+// cached get_waits of a seat's 13-tile hand (hand_evaluator.rs:196-213); 0 when the seat holds 14
+__device__ inline uint64_t seat_waits(Ctx& c, int seat) {
+    PState& P = c.S.p[seat];
+    if (P.flags & PF_WAITS_VALID) return P.waits13;
+    PH h = build_ph(P);
+    if (ph_total(h) + 3 * P.n_melds != 13) return 0ull;
+    uint64_t W = wave_waits(h, c.lane);
+    P.waits13 = W;
+    P.flags |= PF_WAITS_VALID;
+    return W;
+}
+__device__ __forceinline__ void waits_invalidate(PState& P) { P.flags &= ~PF_WAITS_VALID; }
+// cheap in-line win-shape probe so that the (large, out-of-line) yaku evaluation is entered only for complete hands
+__device__ inline bool seat_shape(Ctx& c, int seat, int skip_idx, int win_tile) {
+    PState& P = c.S.p[seat];
+    PH h = build_ph(P, skip_idx);
+    if (ph_total(h) + 3 * P.n_melds == 13) ph_add(h, win_tile >> 2);
+    return is_agari(h);
+}
+
 // ---------------------------------------------------------------- legal actions
 __device__ inline void put_legal(Ctx& c, int seat, int pos, uint64_t a) {
     if (c.lane == 0 && pos < RMJ_MAX_LEGAL) c.X.legal[seat][pos] = a;
 }
 
 // legal_actions.rs:254-508.  Writes the claim list (+Pass) for seat i; returns true iff seat i has claims.
-__device__ __noinline__ bool gen_claims(Ctx& c, int i, int pid, int tile) {
+__device__ inline bool gen_claims(Ctx& c, int i, int pid, int tile) {
     GState& S = c.S;
     PState& P = S.p[i];
     const int lane = c.lane;
     const int tt = tile >> 2;
     const int hl = P.hand_len;
     int n = 0;
-    PH h = build_ph(P);
-    uint64_t W = 0;
-    if (ph_total(h) + 3 * P.n_melds == 13) W = wave_waits(h, lane);
+    uint64_t W = seat_waits(c, i);
     c.X.wout[i] = W;
     bool in_discards = (P.discard_type_mask >> tt) & 1ull;
     bool in_missed = (P.flags & PF_MISSED_DOUJUN) || ((P.flags & PF_RIICHI_DECLARED) && (P.flags & PF_MISSED_RIICHI));
@@ -443,7 +461,7 @@ __device__ __noinline__ bool gen_claims(Ctx& c, int i, int pid, int tile) {
 }
 
 // bit j set iff HandEvaluator(hand minus hand[j]).is_tenpai()  (legal_actions.rs:77-131)
-__device__ __noinline__ uint32_t tenpai_after_discard(Ctx& c, const PState& P) {
+__device__ inline uint32_t tenpai_after_discard(Ctx& c, const PState& P) {
     uint32_t out = 0;
     int hl = P.hand_len;
     if (hl + 3 * P.n_melds != 14) return 0;
@@ -467,7 +485,7 @@ __device__ __noinline__ uint32_t tenpai_after_discard(Ctx& c, const PState& P) {
 }
 
 // legal_actions.rs:11-252 (WaitAct branch) for the current player
-__device__ __noinline__ void gen_act_legal(Ctx& c, int pid) {
+__device__ inline void gen_act_legal(Ctx& c, int pid) {
     GState& S = c.S;
     PState& P = S.p[pid];
     const int lane = c.lane;
@@ -488,8 +506,10 @@ __device__ __noinline__ void gen_act_legal(Ctx& c, int pid) {
         if (S.drawable_count == 0 && !S.is_rinshan) cf |= CF_HAITEI;
         if (S.is_rinshan) cf |= CF_RINSHAN;
         if (S.is_first_turn && P.n_discards == 0) cf |= CF_FIRST_TURN;  // quirk Q5
-        CalcOut r = seat_calc(c, pid, idx, tile, cf, S.honba, false);
-        if (r.is_win && (r.yakuman || r.han >= 1)) put_legal(c, pid, n++, mk_action(RMJ_TSUMO, tile, 0));
+        if (seat_shape(c, pid, idx, tile)) {
+            CalcOut r = seat_calc(c, pid, idx, tile, cf, S.honba, false);
+            if (r.is_win && (r.yakuman || r.han >= 1)) put_legal(c, pid, n++, mk_action(RMJ_TSUMO, tile, 0));
+        }
     }
     // 2. Discard / Riichi
     uint8_t ht = lane < hl ? P.hand[lane] : 0xFF;
@@ -818,10 +838,7 @@ __device__ __noinline__ void init_next_round(Ctx& c, bool oya_won, bool is_draw)
 
 // tenpai of a seat at exhaustive draw: HandEvaluator::is_tenpai (hand_evaluator.rs:178-194)
 __device__ inline bool seat_tenpai(Ctx& c, int seat) {
-    PState& P = c.S.p[seat];
-    PH h = build_ph(P);
-    if (ph_total(h) + 3 * P.n_melds != 13) return false;
-    return wave_waits(h, c.lane) != 0ull;
+    return seat_waits(c, seat) != 0ull;
 }
 
 // state/mod.rs:1846-1968
@@ -959,6 +976,7 @@ __device__ inline void push_meld(PState& P, int type, uint32_t t0, uint32_t t1, 
 
 // remove each consume tile from the hand (position lookup per tile, order preserved)
 __device__ inline void hand_remove_tiles(Ctx& c, PState& P, uint64_t act) {
+    waits_invalidate(P);
     uint32_t n = a_n(act);
     for (uint32_t k = 0; k < n && k < 4; k++) {
         int idx = hand_find(c, P, (int)a_c(act, k));
@@ -1022,7 +1040,10 @@ __device__ inline void resolve_discard(Ctx& c, int pid, int tile, bool tsumogiri
     S.last_discard_pid = (uint8_t)pid;
     S.last_discard_tile = (uint8_t)tile;
     S.drawn_tile = 0xFF;
-    if (!tsumogiri) P.last_tedashi = (uint8_t)tile;
+    if (!tsumogiri) {
+        P.last_tedashi = (uint8_t)tile;
+        waits_invalidate(P);  // the 13-tile hand changed; a tsumogiri leaves it (and the cache) intact
+    }
     S.needs_tsumo = 1;
     if (P.flags & PF_RIICHI_STAGE) {
         P.flags |= PF_RIICHI_DECLARED;
@@ -1186,6 +1207,7 @@ __device__ inline void step_game(Ctx& c, const uint64_t acts_in[4]) {
                     PState& Q = S.p[i];
                     if ((Q.discard_type_mask >> (tile >> 2)) & 1ull) continue;
                     uint32_t cf = CF_CHANKAN | ((Q.flags & PF_RIICHI_DECLARED) ? CF_RIICHI : 0u);
+                    if (!seat_shape(c, i, -1, tile)) continue;
                     CalcOut r = seat_calc(c, i, -1, tile, cf, 0, false);
                     if (r.is_win && ((r.ym >> 42) & 1ull || (r.ym >> 49) & 1ull)) {
                         ronners |= 1u << i;
@@ -1210,6 +1232,7 @@ __device__ inline void step_game(Ctx& c, const uint64_t acts_in[4]) {
             int tile = a_tile(act) != RMJ_TILE_NONE ? (int)a_tile(act) : (a_n(act) ? (int)a_c(act, 0) : 0);
             int idx = hand_find(c, P, tile);
             if (idx >= 0) hand_remove_at(c, P, idx);
+            waits_invalidate(P);
             for (int m = 0; m < P.n_melds; m++)
                 if (P.meld_type[m] == RMJ_MELD_PON && (P.meld_tiles[m][0] >> 2) == (tile >> 2)) {
                     P.meld_type[m] = RMJ_MELD_KAKAN;
@@ -1229,9 +1252,7 @@ __device__ inline void step_game(Ctx& c, const uint64_t acts_in[4]) {
                 c.X.nl[i] = 0;
                 if (i == pid) continue;
                 PState& Q = S.p[i];
-                PH h = build_ph(Q);
-                uint64_t W = 0;
-                if (ph_total(h) + 3 * Q.n_melds == 13) W = wave_waits(h, lane);
+                uint64_t W = seat_waits(c, i);
                 c.X.wout[i] = W;
                 bool furiten = (W & Q.discard_type_mask) != 0ull || (Q.flags & (PF_MISSED_RIICHI | PF_MISSED_DOUJUN));
                 if (furiten || !((W >> (tile >> 2)) & 1ull)) continue;

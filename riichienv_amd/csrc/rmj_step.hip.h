@@ -251,7 +251,10 @@ __device__ inline void sort_hand(Ctx& c, PState& P, int n) {
     int t = 0, r = 0;
     if (c.lane < n) {
         t = P.hand[c.lane];
-        for (int k = 0; k < n; k++) r += (P.hand[k] < t);
+        for (int k = 0; k < n; k++) {  // stable rank: poked test states may repeat an id
+            int hk = P.hand[k];
+            r += (hk < t) || (hk == t && k < c.lane);
+        }
     }
     wave_sync();
     if (c.lane < n) P.hand[r] = (uint8_t)t;
@@ -332,9 +335,9 @@ __device__ inline uint32_t base_cf(const PState& P) {
 // cached get_waits of a seat's 13-tile hand (hand_evaluator.rs:196-213); 0 when the seat holds 14
 __device__ inline uint64_t seat_waits(Ctx& c, int seat) {
     PState& P = c.S.p[seat];
+    if (P.hand_len + 3 * P.n_melds != 13) return 0ull;
     if (P.flags & PF_WAITS_VALID) return P.waits13;
     PH h = build_ph(P);
-    if (ph_total(h) + 3 * P.n_melds != 13) return 0ull;
     uint64_t W = wave_waits(h, c.lane);
     P.waits13 = W;
     P.flags |= PF_WAITS_VALID;
@@ -493,7 +496,7 @@ __device__ inline void gen_act_legal(Ctx& c, int pid) {
     int n = 0;
     const bool r_decl = P.flags & PF_RIICHI_DECLARED, r_stage = P.flags & PF_RIICHI_STAGE;
     const bool drawn = S.drawn_tile != 0xFF;
-    c.X.wout[pid] = 0;
+    c.X.wout[pid] = seat_waits(c, pid);  // non-empty only for a (poked) 13-tile holder, state/mod.rs:220-225
     // 1. Tsumo
     if (drawn && !r_stage) {
         int tile = S.drawn_tile;

@@ -1,0 +1,526 @@
+"""Behavioural KATs transcribed from the reference's own tests (file:line cited per scenario).  Each scenario
+takes an env factory (oracle, HIP, or the dual adapter that cross-checks both after every call) and asserts the
+values the reference's tests assert.  State is poked exactly like the reference's Python setters
+(tests/env/helper.py:4-70 -> env.rs:134-622)."""
+import json
+
+from riichienv_amd import abi
+from riichienv_amd.abi import (ANKAN, CHI, DAIMINKAN, DISCARD, KAKAN, KYUSHU, PASS, PON, RIICHI, RON, TSUMO, WAIT_ACT,
+                               WAIT_RESPONSE, pack_action, unpack_action)
+
+PON_M, CHI_M, DAIMINKAN_M, ANKAN_M, KAKAN_M = abi.MELD_PON, abi.MELD_CHI, abi.MELD_DAIMINKAN, abi.MELD_ANKAN, abi.MELD_KAKAN
+
+
+def tiles(s):
+    """'23m11p0s' -> 136-ids; 0 = red five (id 16/52/88); copies handed out in order (skipping the red copy)."""
+    out, digits, used = [], [], {}
+    for ch in s:
+        if ch.isdigit():
+            digits.append(int(ch))
+        else:
+            suit = "mpsz".index(ch)
+            for d in digits:
+                if d == 0:
+                    out.append(suit * 36 + 16)
+                    continue
+                t = suit * 9 + d - 1
+                k = used.get(t, 1 if (suit < 3 and d == 5) else 0)
+                out.append(t * 4 + k)
+                used[t] = k + 1
+            digits = []
+    return out
+
+
+def set_meld(mv, mtype, mtiles, opened=True, from_who=-1, called=-1):
+    mv.meld_type = mtype
+    mv.n_tiles = len(mtiles)
+    for i, t in enumerate(sorted(mtiles)):
+        mv.tiles[i] = t
+    mv.opened = 1 if opened else 0
+    mv.from_who = from_who
+    mv.called_tile = called
+
+
+def setup(env, hands=None, melds=None, active_players=None, current_player=0, phase=WAIT_ACT, needs_tsumo=False,
+          drawn_tile=None, wall=None, discards=None, riichi_declared=None, points=None, oya=None, round_wind=None,
+          mutate=None, reset_kw=None):
+    """helper_setup_env (tests/env/helper.py:4-70): reset(wall, oya) then overwrite state."""
+    kw = dict(reset_kw or {})
+    if wall is not None:
+        kw["wall"] = wall
+    if oya is not None:
+        kw["oya"] = oya
+    env.reset(**kw)
+    v = env.peek()
+    if hands is not None:
+        for p in range(4):
+            if hands[p] is not None:
+                h = sorted(hands[p])
+                v.players[p].hand_len = len(h)
+                for i, t in enumerate(h):
+                    v.players[p].hand[i] = t
+    if melds is not None:
+        for p in range(4):
+            if melds[p]:
+                v.players[p].n_melds = len(melds[p])
+                for i, m in enumerate(melds[p]):
+                    set_meld(v.players[p].melds[i], *m)
+    if current_player is not None:
+        v.current_player = current_player
+    if active_players is not None:
+        v.active_mask = sum(1 << p for p in active_players)
+    elif current_player is not None and phase == WAIT_ACT:
+        v.active_mask = 1 << current_player
+    if phase is not None:
+        v.phase = phase
+    v.needs_tsumo = 1 if needs_tsumo else 0
+    if drawn_tile is not None:
+        v.drawn_tile = drawn_tile
+        pl = v.players[current_player]
+        h = list(pl.hand[: pl.hand_len]) + [drawn_tile]
+        h = sorted(h)  # helper.py:52-55 appends then sorts
+        pl.hand_len = len(h)
+        for i, t in enumerate(h):
+            pl.hand[i] = t
+    else:
+        v.drawn_tile = -1
+    if discards is not None:
+        for p in range(4):
+            v.players[p].n_discards = len(discards[p])
+            for i, t in enumerate(discards[p]):
+                v.players[p].discards[i] = t
+    if riichi_declared is not None:
+        for p in range(4):
+            v.players[p].riichi_declared = 1 if riichi_declared[p] else 0
+    if points is not None:
+        for p in range(4):
+            v.players[p].score = points[p]
+    if round_wind is not None:
+        v.round_wind = round_wind
+    if mutate:
+        mutate(v)
+    env.poke(v)
+    return env
+
+
+def evs(env, seat=-1):
+    return [json.loads(s) for s in env.log(seat)]
+
+
+def find(legal, atype, tile=None):
+    for a in legal:
+        t, tl, c = unpack_action(a)
+        if t == atype and (tile is None or tl == tile):
+            return a
+    return None
+
+
+# ---------------------------------------------------------------------------------------------------------
+def sc_paishan_dora_indices(make):
+    """tests/env/test_paishan.py:23-40,67-90: wall=list(range(136)) -> dora 131, ura 130; after one rinshan
+    draw the kan-dora is 129 and the ura markers are 130, 128."""
+    env = setup(make(), wall=list(range(136)))
+    v = env.peek()
+    assert v.n_dora == 1 and v.dora[0] == 131
+    assert v.wall[5] == 130  # ura = tiles[5]
+    # give seat 0 four 1m so that an ankan flips the kan dora; riichi first so that ura markers are emitted
+    env2 = setup(make(), wall=list(range(136)), hands=[[0, 1, 2] + tiles("234p234s11z")[0:8] + [124, 125], None, None, None],
+                 drawn_tile=3)
+    a = find(env2.legal(0), ANKAN)
+    assert a is not None
+    env2.step({0: a})
+    v = env2.peek()
+    assert v.n_dora == 2 and v.dora[1] == 129 and v.rinshan_draw_count == 1
+    assert [v.wall[5 - 1], v.wall[7 - 1]] == [130, 128]  # tiles[] shifted by one after remove(0)
+    t = [e["type"] for e in evs(env2)]
+    i = t.index("ankan")
+    assert t[i: i + 3] == ["ankan", "dora", "tsumo"]  # tests/env/test_kan_dora_timing_events.py:16-66
+    assert evs(env2)[i + 2]["pai"] == abi_mjai(135)  # rinshan = tiles[0] of the reversed wall
+
+
+def abi_mjai(tid):
+    from oracle import oracle
+
+    return oracle.tid_to_mjai(tid)
+
+
+def sc_kakan_dora_timing(make):
+    """tests/env/test_kan_dora_timing_events.py:68-139: kakan -> tsumo -> dora -> dahai."""
+    env = setup(make(), hands=[[4, 5, 6, 7, 8, 9, 10, 11, 12, 60], None, None, None], melds=[[(PON_M, [0, 1, 2], True, 1, 0)], [], [], []],
+                drawn_tile=3)
+    a = find(env.legal(0), KAKAN)
+    assert a is not None and unpack_action(a) == (KAKAN, 3, [0, 1, 2])
+    env.step({0: a})
+    act, ph, dn = env.status()
+    if ph == WAIT_RESPONSE:  # somebody may hold a chankan ron with a random deal; pass
+        env.step({s: pack_action(PASS) for s in range(4) if (act >> s) & 1})
+    d = find(env.legal(0), DISCARD)
+    env.step({0: d})
+    t = [e["type"] for e in evs(env)]
+    k = t.index("kakan")
+    rest = t[k:]
+    assert rest.index("tsumo") < rest.index("dora") < rest.index("dahai")
+
+
+def sc_daiminkan_dora_timing(make):
+    """tests/env/test_kan_dora_timing_events.py:141-215: daiminkan -> tsumo -> dora -> dahai."""
+    env = setup(make(), hands=[[4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15], [72, 73, 74, 16, 17, 18, 19, 20, 21, 22, 23, 24, 25], None, None],
+                drawn_tile=75)
+    env.step({0: pack_action(DISCARD, 75)})
+    act, ph, dn = env.status()
+    assert ph == WAIT_RESPONSE and (act >> 1) & 1
+    k = find(env.legal(1), DAIMINKAN)
+    assert k is not None and unpack_action(k) == (DAIMINKAN, 75, [72, 73, 74])
+    acts = {s: pack_action(PASS) for s in range(4) if (act >> s) & 1}
+    acts[1] = k
+    env.step(acts)
+    env.step({1: find(env.legal(1), DISCARD)})
+    t = [e["type"] for e in evs(env)]
+    i = t.index("daiminkan")
+    rest = t[i:]
+    assert rest.index("tsumo") < rest.index("dora") < rest.index("dahai")
+
+
+def sc_south_round_tsumo(make):
+    """tests/test_env_scoring.py:109-153: oya tsumo, South round: yaku {1,11,27,32}, deltas[0] == 18000."""
+    env = make(round_wind=1)
+    hand = [112, 113, 114] + [0, 4, 8, 5, 9, 12, 16, 20, 24] + [13]
+
+    def mut(v):
+        v.is_first_turn = 0
+        v.players[0].n_discards = 1
+        v.players[0].discards[0] = 0
+        v.drawn_tile = 14  # NOT appended to the hand in the reference test
+
+    setup(env, hands=[hand, None, None, None], mutate=mut, reset_kw={"round_wind": 1})
+    sk = next(e for e in evs(env) if e["type"] == "start_kyoku")
+    assert sk["bakaze"] == "S"
+    env.step({0: pack_action(TSUMO)})
+    hora = next(e for e in reversed(evs(env)) if e["type"] == "hora")
+    assert hora["deltas"] == [18000, -6000, -6000, -6000]
+    assert hora["tsumo"] is True and hora["actor"] == 0 and hora["target"] == 0
+
+
+def sc_illegal_discard_penalty(make):
+    """tests/env/test_illegal_actions.py:5-58: oya chombo -12000 / +4000 each, renchan honba 1, last_error set."""
+    env = make(game_mode=1)
+    env.reset()
+    v = env.peek()
+    hand = list(v.players[0].hand[: v.players[0].hand_len])
+    bad = next(t for t in range(136) if t not in hand)
+    env.step({0: pack_action(DISCARD, bad)})
+    r = [e for e in evs(env) if e["type"] == "ryukyoku"][-1]
+    assert r["reason"] == "Error: Illegal Action by Player 0"
+    assert r["deltas"] == [-12000, 4000, 4000, 4000]
+    assert env.scores() == [13000, 29000, 29000, 29000]
+    v = env.peek()
+    assert (v.is_done, v.oya, v.honba, v.kyoku_idx, v.players[0].hand_len, v.last_error_pid) == (0, 0, 1, 0, 14, 0)
+    t = [e["type"] for e in evs(env)]
+    assert t.index("ryukyoku") < t.index("end_kyoku")
+
+
+def sc_illegal_out_of_turn(make):
+    """tests/env/test_illegal_actions.py:60-121: non-dealer chombo -8000, oya +4000, others +2000; the lowest
+    offending seat is punished."""
+    env = make(game_mode=1)
+    env.reset()
+    v = env.peek()
+    valid = v.players[0].hand[v.players[0].hand_len - 1]
+    env.step({0: pack_action(DISCARD, valid), 1: pack_action(DISCARD, 0), 2: pack_action(DISCARD, 0)})
+    assert env.scores() == [29000, 17000, 27000, 27000]
+    v = env.peek()
+    assert (v.honba, v.oya) == (1, 0)
+
+
+def sc_claim_priority_pon_over_chi(make):
+    """tests/env/rule_validation/test_claim_priority.py:11-56."""
+    # (the reference pads the hands with repeated ids; here the padding is physically valid: <= 4 copies per type)
+    env = setup(make(seed=1), hands=[[57] + list(range(0, 12)), [62, 65] + list(range(108, 119)),
+                                    [56, 58] + list(range(120, 130)) + [131],
+                                    [12, 16, 19, 21, 48, 59, 64, 77, 81, 89, 104, 130, 133]], current_player=0, active_players=[0],
+                drawn_tile=100)
+    env.step({0: pack_action(DISCARD, 57)})
+    act, ph, dn = env.status()
+    assert ph == WAIT_RESPONSE and act == 0b0110
+    env.step({1: pack_action(CHI, 57, [62, 65]), 2: pack_action(PON, 57, [56, 58])})
+    act, ph, dn = env.status()
+    assert ph == WAIT_ACT and act == 0b0100
+    assert evs(env)[-1]["type"] == "pon"
+
+
+def sc_kuikae_suji(make):
+    """tests/env/rule_validation/test_kuikae.py:7-42: after chi 1s with 2s3s, 4s (type 21) may not be discarded."""
+    junk = [0, 12, 24, 36, 48, 60, 108, 112, 116]  # isolated tiles (the reference pads with nine copies of id 0)
+    env = setup(make(), hands=[list(range(120, 133)), [72] + list(range(1, 12)) + [13], [79, 82, 85, 86] + junk,
+                               [2, 3, 14, 15, 26, 27, 38, 39, 50, 51, 62, 63, 110]], current_player=1, wall=list(range(136)))
+    env.step({1: pack_action(DISCARD, 72)})
+    act, ph, dn = env.status()
+    assert ph == WAIT_RESPONSE and (act >> 2) & 1
+    assert find(env.legal(2), CHI) is not None
+    acts = {s: pack_action(PASS) for s in range(4) if (act >> s) & 1}
+    acts[2] = pack_action(CHI, 72, [79, 82])
+    env.step(acts)
+    for a in env.legal(2):
+        t, tl, c = unpack_action(a)
+        assert not (t == DISCARD and tl // 4 == 21)
+        assert not (t == DISCARD and tl // 4 == 18)
+
+
+def sc_kuikae_deadlock(make):
+    """tests/env/rule_validation/test_kuikae.py:44-78 / src/tests.rs:274-310: chi is not offered when every
+    remaining tile would be forbidden."""
+    env = setup(make(), hands=[[0, 12, 24, 36], [72] + list(range(1, 12)) + [13], [79, 82, 85, 86],
+                               [2, 3, 14, 15, 26, 27, 38, 39, 50, 51, 62, 63, 110]],
+                melds=[[(PON_M, [108, 109, 110], True, 1, -1), (PON_M, [112, 113, 114], True, 1, -1), (PON_M, [116, 117, 118], True, 1, -1)], [], [], []],
+                current_player=1, wall=list(range(136)))
+    env.step({1: pack_action(DISCARD, 72)})
+    act, ph, dn = env.status()
+    assert ph == WAIT_ACT and act == 0b0100  # nobody could claim; seat 2 drew
+
+
+def sc_sufuurenta(make):
+    """tests/test_midway_draw.py:7-32."""
+    scattered = [0, 4, 8, 36, 40, 44, 72, 76, 80, 112, 116, 120, 124]
+    env = setup(make(), hands=[scattered[:] for _ in range(4)], wall=list(range(136)))
+    winds = [108, 109, 110, 111]
+    for i in range(4):
+        v = env.peek()
+        p = v.current_player
+        pl = v.players[p]
+        h = list(pl.hand[: pl.hand_len])
+        h[0] = winds[i]
+        for k, t in enumerate(h):
+            pl.hand[k] = t
+        v.drawn_tile = winds[i]
+        env.poke(v)
+        env.step({p: pack_action(DISCARD, winds[i])})
+        assert bool(env.status()[2]) == (i == 3)
+    assert any(e.get("reason") == "sufuurenta" for e in evs(env) if e["type"] == "ryukyoku")
+
+
+def sc_suukansansen(make):
+    """tests/test_midway_draw.py:34-56."""
+    scattered = [0, 4, 8, 36, 40, 44, 72, 76, 80, 112, 116, 120, 124]
+    env = setup(make(), hands=[scattered[:] for _ in range(4)],
+                melds=[[(ANKAN_M, [0, 1, 2, 3], False), (ANKAN_M, [4, 5, 6, 7], False)],
+                       [(ANKAN_M, [8, 9, 10, 11], False), (ANKAN_M, [12, 13, 14, 15], False)], [], []],
+                current_player=1, drawn_tile=108, wall=list(range(136)))
+    env.step({1: pack_action(DISCARD, 108)})
+    assert env.status()[2] == 1
+    assert any(e.get("reason") == "suukansansen" for e in evs(env) if e["type"] == "ryukyoku")
+
+
+def sc_chankan_ron(make):
+    """tests/env/agari/test_chankan.py:7-59: kakan of 1m, seat 1 waits on 1m-4m -> Ron offered, chankan yaku,
+    single-round game ends."""
+    h0 = tiles("02346789m01234p")
+    env = setup(make(game_mode=0), hands=[h0, tiles("23m11p234s456s"), [], []],
+                melds=[[(PON_M, [0, 1, 2], True, 1, -1)], [(PON_M, tiles("999m"), True, 0, -1)], [], []], drawn_tile=3)
+    env.step({0: pack_action(KAKAN, 3, [0, 1, 2])})
+    act, ph, dn = env.status()
+    assert ph == WAIT_RESPONSE and act == 0b0010
+    ron = find(env.legal(1), RON)
+    assert ron is not None and unpack_action(ron)[1] == 3
+    env.step({1: ron})
+    assert env.status()[2] == 1
+    hora = next(e for e in evs(env) if e["type"] == "hora")
+    assert hora["actor"] == 1 and hora["target"] == 0
+    # 2m3m +1m, 11p, 234s 456s, pon 999m, chankan only: 1 han 30 fu ko ron = 1000
+    assert hora["deltas"] == [-1000, 1000, 0, 0]
+
+
+def sc_chankan_pass(make):
+    """tests/env/agari/test_chankan.py:61-110: chankan passed -> kakan resolves with a rinshan draw."""
+    env = setup(make(game_mode=1), hands=[[4, 8, 12, 16, 20, 24, 28, 32, 36, 40], tiles("23m11p234s456s"), None, None],
+                melds=[[(PON_M, [0, 1, 2], True, 1, -1)], [(PON_M, [132, 133, 134], True, 0, -1)], [], []], drawn_tile=3)
+    env.step({0: pack_action(KAKAN, 3, [0, 1, 2])})
+    act, ph, dn = env.status()
+    assert ph == WAIT_RESPONSE and (act >> 1) & 1
+    env.step({s: pack_action(PASS) for s in range(4) if (act >> s) & 1})
+    act, ph, dn = env.status()
+    assert ph == WAIT_ACT and act == 0b0001
+    v = env.peek()
+    assert v.players[1].missed_agari_doujun == 1  # state/mod.rs:902-917
+    assert v.players[0].melds[0].meld_type == KAKAN_M and v.is_rinshan_flag == 1
+    t = [e["type"] for e in evs(env)]
+    assert t[-2:] == ["kakan", "tsumo"]
+
+
+def _pao_setup(make, rule_bits, oya):
+    env = make(rule_bits=rule_bits)
+    setup(env, oya=oya, hands=[[132, 133, 0, 1, 2, 4, 5], [134] + list(range(40, 52)), None, None],
+          melds=[[(PON_M, [124, 125, 126], True, 2, 124), (PON_M, [128, 129, 130], True, 3, 128)], [], [], []],
+          current_player=1, active_players=[1], drawn_tile=None)
+    env.step({1: pack_action(DISCARD, 134)})
+    act, ph, dn = env.status()
+    acts = {s: pack_action(PASS) for s in range(4) if (act >> s) & 1}
+    acts[0] = pack_action(PON, 134, [132, 133])
+    env.step(acts)
+    assert env.peek().players[0].pao_daisangen == 1  # tests/env/agari/test_pao.py:45-46
+    env.step({0: pack_action(DISCARD, 4)})
+    return env
+
+
+def sc_pao_daisangen_tsumo(make):
+    """tests/env/agari/test_pao.py:7-76: oya daisangen tsumo with pao: liable seat pays all 48000."""
+    env = _pao_setup(make, abi.RULE_TENHOU, 0)
+    act, ph, dn = env.status()
+    if ph == WAIT_RESPONSE:
+        env.step({s: pack_action(PASS) for s in range(4) if (act >> s) & 1})
+    v = env.peek()
+    v.current_player = 0
+    v.phase = WAIT_ACT
+    v.active_mask = 1
+    for p in range(1, 4):  # undo the draw the engine dealt to the next seat: keep 13-tile hands
+        if v.players[p].hand_len == 14:
+            v.players[p].hand_len = 13
+    v.drawn_tile = 6
+    pl = v.players[0]
+    h = sorted(list(pl.hand[: pl.hand_len]) + [6])
+    pl.hand_len = len(h)
+    for i, t in enumerate(h):
+        pl.hand[i] = t
+    env.poke(v)
+    env.step({0: find(env.legal(0), TSUMO)})
+    hora = next(e for e in reversed(evs(env)) if e["type"] == "hora")
+    assert hora["deltas"] == [48000, -48000, 0, 0]
+
+
+def sc_pao_mjsoul_composite_tsumo(make):
+    """src/tests.rs:1783-1884 (MjSoul liability-only split) realised on the state machine: ko winner (seat 0, oya 1)
+    tsumo daisangen (pao by seat 3) + tsuuiisou: pao 32000 + ko share 8000 = 40000, oya 16000, other ko 8000."""
+    env = make(rule_bits=abi.RULE_MJSOUL)
+    # seat 0: pon haku, pon hatsu (from seat 2), pon chun from seat 3 -> pao 37 -> seat 3; hand EE SS + S wins
+    hand0 = [132, 133, 108, 109, 112, 113, 114]
+    setup(env, oya=1, hands=[hand0, list(range(60, 73)), None, [134] + list(range(40, 52))],
+          melds=[[(PON_M, [124, 125, 126], True, 2, 124), (PON_M, [128, 129, 130], True, 2, 128)], [], [], []],
+          current_player=3, active_players=[3])
+    env.step({3: pack_action(DISCARD, 134)})
+    act, ph, dn = env.status()
+    acts = {s: pack_action(PASS) for s in range(4) if (act >> s) & 1}
+    acts[0] = pack_action(PON, 134, [132, 133])
+    env.step(acts)
+    assert env.peek().players[0].pao_daisangen == 3
+    env.step({0: pack_action(DISCARD, 114)})  # keep EE SS: shanpon-less tanki? -> 108,109,112,113 : wait E/S
+    act, ph, dn = env.status()
+    if ph == WAIT_RESPONSE:
+        env.step({s: pack_action(PASS) for s in range(4) if (act >> s) & 1})
+    v = env.peek()
+    for p in range(1, 4):
+        if v.players[p].hand_len == 14:
+            v.players[p].hand_len = 13
+    v.current_player = 0
+    v.phase = WAIT_ACT
+    v.active_mask = 1
+    v.drawn_tile = 110
+    pl = v.players[0]
+    h = sorted(list(pl.hand[: pl.hand_len]) + [110])
+    pl.hand_len = len(h)
+    for i, t in enumerate(h):
+        pl.hand[i] = t
+    env.poke(v)
+    ts = find(env.legal(0), TSUMO)
+    assert ts is not None
+    env.step({0: ts})
+    hora = next(e for e in reversed(evs(env)) if e["type"] == "hora")
+    # daisangen (pao) + tsuuiisou: total 2 yakuman
+    assert hora["deltas"] == [64000, -16000, -8000, -40000]
+
+
+def sc_riichi_sequence(make):
+    """docs/RULES.md:64-78, tests/env/rule_validation/test_riichi_sequence.py: reach -> dahai -> reach_accepted
+    -> tsumo; riichi discard restricted to tenpai-keeping tiles; stick paid on acceptance; ippatsu tsumo."""
+    # seat 0: 123m 456m 789m 234p 5p + draw 9s -> riichi by discarding 9s (wait 5p) ; wall fixed so nobody calls
+    hand = tiles("123456789m2345p")
+    env = setup(make(game_mode=1), hands=[hand, tiles("1199s1155z22266z")[0:13], tiles("147m258p369s1234z")[0:13], tiles("147m258p369s5677z")[0:13]],
+                drawn_tile=107, wall=list(range(136)))
+    r = find(env.legal(0), RIICHI)
+    assert r is not None
+    env.step({0: r})
+    v = env.peek()
+    assert v.players[0].riichi_stage == 1 and v.players[0].riichi_declared == 0
+    disc = [unpack_action(a)[1] for a in env.legal(0) if unpack_action(a)[0] == DISCARD]
+    # tenpai-keeping discards only: 9s (tanki 5p/…)/2p/5p
+    assert 107 in disc and all(unpack_action(a)[0] == DISCARD for a in env.legal(0))
+    env.step({0: pack_action(DISCARD, 107)})
+    act, ph, dn = env.status()
+    while ph == WAIT_RESPONSE:
+        env.step({s: pack_action(PASS) for s in range(4) if (act >> s) & 1})
+        act, ph, dn = env.status()
+    t = [e["type"] for e in evs(env)]
+    i = t.index("reach")
+    assert t[i: i + 4] == ["reach", "dahai", "reach_accepted", "tsumo"]
+    v = env.peek()
+    assert v.players[0].score == 24000 and v.riichi_sticks == 1 and v.players[0].ippatsu_cycle == 1
+    assert v.players[0].riichi_declared == 1 and v.players[0].double_riichi_declared == 1
+
+
+def sc_kyushu_kyuhai(make):
+    """tests/env/actions/test_kyushu_kyuhai.py: 9 terminal kinds on the first turn -> KyushuKyuhai legal; abortive
+    draw with renchan (honba+1)."""
+    hand = tiles("19m19p19s1234z") + tiles("2m3p")[0:2]
+    env = setup(make(game_mode=1), hands=[hand[:13], None, None, None], drawn_tile=128)
+    k = find(env.legal(0), KYUSHU)
+    assert k is not None
+    assert env.mask(0)[80] == 1
+    env.step({0: k})
+    r = [e for e in evs(env) if e["type"] == "ryukyoku"][-1]
+    assert r["reason"] == "kyushu_kyuhai" and r["deltas"] == [0, 0, 0, 0]
+    v = env.peek()
+    assert (v.honba, v.oya, v.is_done) == (1, 0, 0)
+
+
+def sc_double_ron_honba_sticks(make):
+    """state/mod.rs:945-1142: two winners sorted by distance from the discarder; honba and riichi sticks only to
+    the first; sanchaho not triggered with two."""
+    hand2 = tiles("234m234p234s55p") + [96, 100]  # 7s8s -> waits 6s/9s
+    hand3 = tiles("345m345p345s66p") + [96 + 1, 100 + 1]  # 7s8s -> waits 6s/9s
+    env = setup(make(game_mode=1), hands=[tiles("19m19p1s1234567z")[0:12], None, hand2, hand3], drawn_tile=92,
+                mutate=lambda v: (setattr(v, "honba", 2), setattr(v, "riichi_sticks", 1), setattr(v, "is_first_turn", 0)),
+                wall=list(range(136)))
+    env.step({0: pack_action(DISCARD, 92)})  # 6s
+    act, ph, dn = env.status()
+    assert ph == WAIT_RESPONSE and (act & 0b1100) == 0b1100
+    acts = {s: pack_action(PASS) for s in range(4) if (act >> s) & 1}
+    acts[2] = find(env.legal(2), RON)
+    acts[3] = find(env.legal(3), RON)
+    env.step(acts)
+    h = [e for e in evs(env) if e["type"] == "hora"]
+    assert [e["actor"] for e in h] == [2, 3]
+    # seat 2: tanyao + pinfu + sanshoku(234) menzen ron = 4 han 30 fu -> 7700 (no kiriage) + honba 600 + stick 1000
+    assert h[0]["deltas"] == [-8300, 0, 9300, 0]
+    # seat 3: tanyao + pinfu + sanshoku(345) = 7700, no honba, no stick
+    assert h[1]["deltas"] == [-7700, 0, 0, 7700]
+    assert env.scores() == [25000 - 16000, 25000, 25000 + 9300, 25000 + 7700]
+
+
+def sc_tobi_and_agariyame(make):
+    """src/tests.rs:375-425: negative score ends the game; dealer top >= 30000 winning the last regular round ends it."""
+    env = make(game_mode=2)
+    hand = tiles("123456789m1134p")
+
+    def mut(v):
+        v.round_wind = 1
+        v.oya = 3
+        v.kyoku_idx = 3
+        v.current_player = 3
+        v.active_mask = 8
+        v.is_first_turn = 0
+        for p, s in enumerate([20000, 20000, 20000, 40000]):
+            v.players[p].score = s
+        v.players[3].n_discards = 1
+        v.players[3].discards[0] = 108
+
+    setup(env, hands=[None, None, None, hand], current_player=3, drawn_tile=tiles("2p")[0], mutate=mut)
+    ts = find(env.legal(3), TSUMO)
+    assert ts is not None
+    env.step({3: ts})
+    assert env.status()[2] == 1  # agari-yame
+    assert [e["type"] for e in evs(env)][-2:] == ["end_kyoku", "end_game"]
+
+
+SCENARIOS = [sc_paishan_dora_indices, sc_kakan_dora_timing, sc_daiminkan_dora_timing, sc_south_round_tsumo,
+             sc_illegal_discard_penalty, sc_illegal_out_of_turn, sc_claim_priority_pon_over_chi, sc_kuikae_suji,
+             sc_kuikae_deadlock, sc_sufuurenta, sc_suukansansen, sc_chankan_ron, sc_chankan_pass, sc_pao_daisangen_tsumo,
+             sc_pao_mjsoul_composite_tsumo, sc_riichi_sequence, sc_kyushu_kyuhai, sc_double_ron_honba_sticks,
+             sc_tobi_and_agariyame]

@@ -1,0 +1,66 @@
+"""CPU-side checks of the boundary: the C-ABI library loads, exports every symbol include/riichi_mi355x.h
+declares, struct layouts agree with the header, and compute entry points fail loudly without a GPU."""
+import ctypes as C
+import os
+import re
+
+import pytest
+
+from riichienv_amd import abi, vecenv
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol():
+    hdr = open(os.path.join(ROOT, "include", "riichi_mi355x.h")).read()
+    declared = set(re.findall(r"\b(rmj_[a-z_]+)\s*\(", hdr))
+    declared -= {"rmj_env"}
+    assert declared == set(vecenv.EXPORTS), declared ^ set(vecenv.EXPORTS)
+    lib = vecenv.load_lib()
+    for sym in declared:
+        assert getattr(lib, sym) is not None
+    assert b"gfx950" in lib.rmj_version()
+
+
+def test_struct_sizes_match_header():
+    # sizes implied by the C declarations (natural alignment)
+    assert C.sizeof(abi.Event) == 32
+    # compile-time check against the real header through the oracle's C++ translation unit sizes
+    import subprocess
+    import tempfile
+
+    src = r'''
+#include <cstdio>
+#include "riichi_mi355x.h"
+int main(){printf("%zu %zu %zu %zu %zu %zu\n", sizeof(RmjStateView), sizeof(RmjPlayerView), sizeof(RmjHandCase), sizeof(RmjHandResult), sizeof(RmjConfig), sizeof(RmjEvent));}
+'''
+    with tempfile.TemporaryDirectory() as d:
+        p = os.path.join(d, "s.cpp")
+        open(p, "w").write(src)
+        exe = os.path.join(d, "s")
+        subprocess.check_call(["g++", "-I", os.path.join(ROOT, "include"), p, "-o", exe])
+        out = subprocess.check_output([exe]).decode().split()
+    got = [C.sizeof(x) for x in (abi.StateView, abi.PlayerView, abi.HandCase, abi.HandResult, abi.Config, abi.Event)]
+    assert got == [int(x) for x in out], (got, out)
+
+
+def test_pack_unpack_roundtrip():
+    a = abi.pack_action(abi.CHI, 57, [65, 62])
+    assert abi.unpack_action(a) == (abi.CHI, 57, [62, 65])  # Action::new sorts (action.rs:97-98)
+    assert abi.unpack_action(abi.pack_action(abi.RIICHI)) == (abi.RIICHI, None, [])
+
+
+def test_no_cpu_fallback():
+    """Without a HIP device the product path must fail loudly (never route through the oracle)."""
+    import torch
+
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    lib = vecenv.load_lib()
+    assert lib.rmj_device_count() == 0
+    with pytest.raises(vecenv.RmjError):
+        vecenv.VecRiichiEnv(4)
+    with pytest.raises(vecenv.RmjError):
+        vecenv.eval_hands([abi.HandCase()])
+    src = open(os.path.join(ROOT, "riichienv_amd", "vecenv.py")).read()
+    assert "oracle" not in src.replace("oracle/oracle.py", "")

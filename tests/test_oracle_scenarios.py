@@ -1,0 +1,10 @@
+"""Oracle vs the reference's behavioural KATs (tests/scenarios.py cites each reference test)."""
+import pytest
+
+from tests.env_adapters import OracleEnv
+from tests.scenarios import SCENARIOS
+
+
+@pytest.mark.parametrize("sc", SCENARIOS, ids=lambda f: f.__name__)
+def test_oracle_scenario(sc):
+    sc(lambda **kw: OracleEnv(**kw))

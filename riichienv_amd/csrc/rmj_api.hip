@@ -36,7 +36,8 @@ __device__ __forceinline__ void store_state(const GState& S, GState* dst, int la
 }
 
 // RiichiEnv.reset defaults (env.rs:799-851) executed on device: reset() + _initialize_round(0,0,0,0,None,default scores)
-__device__ inline void device_env_reset_default(Ctx& c) {
+__device__ __noinline__ void ol_env_reset_default(CtxV v) {
+    CTX_FROM(v);
     c.S.ev_count = 0;  // GameState::reset clears the logs (state/mod.rs:171-187)
     emit_simple(c, RMJ_EV_START_GAME);
     const int32_t sc[4] = {25000, 25000, 25000, 25000};
@@ -53,7 +54,7 @@ __global__ __launch_bounds__(256, 4) void k_step(Env E, const uint64_t* __restri
     load_state(S, E.core + g, lane);
     Ctx c{S, E, sh.x[wave], g, lane, E.wall + (size_t)g * RMJ_WALL_STRIDE, E.legal + (size_t)g * 4 * RMJ_MAX_LEGAL};
     if (S.is_done && (flags & STEP_F_AUTORESET)) {
-        device_env_reset_default(c);
+        ol_env_reset_default(ctx_pack(c));
     } else {
         uint64_t acts[4];
         if (flags & STEP_F_RANDOM) {

@@ -56,6 +56,25 @@ struct Ctx {
     uint64_t* Lg;     // this game's legal lists [4][64] in HBM (read for validation, written by finalize)
 };
 
+// By-value view of a Ctx for out-of-line (rare-path) functions.  Passing Ctx& to a non-inlined function would
+// make the caller's Ctx escape to scratch and turn every LDS access of the hot path into a flat access; passing
+// the members by value keeps the caller's Ctx in registers (address spaces stay inferable).
+struct CtxV {
+    GState* S;
+    WaveScratch* X;
+    uint8_t* W;
+    uint64_t* Lg;
+    const Env* E;
+    uint32_t g;
+    int lane;
+};
+#define CTX_FROM(v) Ctx c{*(v).S, *(v).E, *(v).X, (v).g, (v).lane, (v).W, (v).Lg}
+__device__ __forceinline__ CtxV ctx_pack(const Ctx& c) {
+    CtxV v;
+    v.S = &c.S; v.X = &c.X; v.W = c.W; v.Lg = c.Lg; v.E = &c.E; v.g = c.g; v.lane = c.lane;
+    return v;
+}
+
 __device__ __forceinline__ void wave_sync() {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     __builtin_amdgcn_wave_barrier();
@@ -138,7 +157,7 @@ __device__ __forceinline__ uint64_t sm64(uint64_t x) {  // state/wall.rs:83-88
 }
 
 // ---------------------------------------------------------------- events
-__device__ inline void emit_raw(Ctx& c, const RmjEvent& ev) {
+__device__ __forceinline__ void emit_raw(Ctx& c, const RmjEvent& ev) {
     if (c.E.skip_log) return;
     uint32_t idx = c.S.ev_count & c.E.ring_mask;
     RmjEvent* dst = c.E.events + (size_t)c.g * (c.E.ring_mask + 1u) + idx;
@@ -158,14 +177,14 @@ __device__ inline RmjEvent ev_zero(uint8_t type) {
     e.type = type;
     return e;
 }
-__device__ inline void emit_simple(Ctx& c, uint8_t type, uint8_t actor = 0, uint8_t tile = 0, uint8_t flags = 0) {
+__device__ __forceinline__ void emit_simple(Ctx& c, uint8_t type, uint8_t actor = 0, uint8_t tile = 0, uint8_t flags = 0) {
     RmjEvent e = ev_zero(type);
     e.actor = actor;
     e.tile = tile;
     e.flags = flags;
     emit_raw(c, e);
 }
-__device__ inline void emit_meld(Ctx& c, uint8_t type, uint8_t actor, uint8_t target, uint8_t tile, uint64_t act) {
+__device__ __forceinline__ void emit_meld(Ctx& c, uint8_t type, uint8_t actor, uint8_t target, uint8_t tile, uint64_t act) {
     RmjEvent e = ev_zero(type);
     e.actor = actor;
     e.target = target;
@@ -195,7 +214,7 @@ __device__ __forceinline__ int next_dora34(int t, bool sanma) {  // hand_evaluat
 __device__ __forceinline__ bool is_aka(int t) { return t == 16 || t == 52 || t == 88; }
 
 // concealed histogram of a seat (optionally skipping hand index `skip`)
-__device__ inline PH build_ph(const PState& P, int skip = -1) {
+__device__ __forceinline__ PH build_ph(const PState& P, int skip = -1) {
     PH h = {0, 0, 0, 0};
     int n = P.hand_len;
     for (int j = 0; j < n; j++)
@@ -247,7 +266,7 @@ __device__ inline MeldAgg build_meld_agg(const PState& P) {
 }
 
 // rank-sort the first n tiles of a hand (ids are unique)
-__device__ inline void sort_hand(Ctx& c, PState& P, int n) {
+__device__ __forceinline__ void sort_hand(Ctx& c, PState& P, int n) {
     int t = 0, r = 0;
     if (c.lane < n) {
         t = P.hand[c.lane];
@@ -261,7 +280,7 @@ __device__ inline void sort_hand(Ctx& c, PState& P, int n) {
     wave_sync();
 }
 // remove hand[idx] keeping order
-__device__ inline void hand_remove_at(Ctx& c, PState& P, int idx) {
+__device__ __forceinline__ void hand_remove_at(Ctx& c, PState& P, int idx) {
     int n = P.hand_len;
     int t = 0;
     if (c.lane > idx && c.lane < n) t = P.hand[c.lane];
@@ -270,7 +289,7 @@ __device__ inline void hand_remove_at(Ctx& c, PState& P, int idx) {
     wave_sync();
     P.hand_len = (uint8_t)(n - 1);
 }
-__device__ inline int hand_find(const Ctx& c, const PState& P, int tile) {  // position() of a 136-id, -1 if absent
+__device__ __forceinline__ int hand_find(const Ctx& c, const PState& P, int tile) {  // position() of a 136-id, -1 if absent
     bool hit = c.lane < P.hand_len && P.hand[c.lane] == tile;
     uint64_t b = __ballot(hit);
     return b ? (__ffsll((long long)b) - 1) : -1;
@@ -282,7 +301,7 @@ struct Cond {
     uint32_t honba;
 };
 // seat's concealed tiles = hand minus `skip_idx` (-1: none); win tile added iff total == 13
-__device__ __noinline__ CalcOut seat_calc(Ctx& c, int seat, int skip_idx, int win_tile, uint32_t cf, uint32_t honba, bool use_ura) {
+__device__ __forceinline__ CalcOut seat_calc_impl(Ctx& c, int seat, int skip_idx, int win_tile, uint32_t cf, uint32_t honba, bool use_ura) {
     GState& S = c.S;
     PState& P = S.p[seat];
     CalcIn in;
@@ -324,6 +343,13 @@ __device__ __noinline__ CalcOut seat_calc(Ctx& c, int seat, int skip_idx, int wi
     in.honba = honba;
     return wave_calc(in, c.lane);
 }
+__device__ __noinline__ CalcOut ol_seat_calc(CtxV v, int seat, int skip_idx, int win_tile, uint32_t cf, uint32_t honba, bool use_ura) {
+    CTX_FROM(v);
+    return seat_calc_impl(c, seat, skip_idx, win_tile, cf, honba, use_ura);
+}
+__device__ __forceinline__ CalcOut seat_calc(Ctx& c, int seat, int skip_idx, int win_tile, uint32_t cf, uint32_t honba, bool use_ura) {
+    return ol_seat_calc(ctx_pack(c), seat, skip_idx, win_tile, cf, honba, use_ura);
+}
 __device__ inline uint32_t base_cf(const PState& P) {
     uint32_t cf = 0;
     if (P.flags & PF_RIICHI_DECLARED) cf |= CF_RIICHI;
@@ -333,7 +359,7 @@ __device__ inline uint32_t base_cf(const PState& P) {
 }
 
 // cached get_waits of a seat's 13-tile hand (hand_evaluator.rs:196-213); 0 when the seat holds 14
-__device__ inline uint64_t seat_waits(Ctx& c, int seat) {
+__device__ __forceinline__ uint64_t seat_waits(Ctx& c, int seat) {
     PState& P = c.S.p[seat];
     if (P.hand_len + 3 * P.n_melds != 13) return 0ull;
     if (P.flags & PF_WAITS_VALID) return P.waits13;
@@ -345,7 +371,7 @@ __device__ inline uint64_t seat_waits(Ctx& c, int seat) {
 }
 __device__ __forceinline__ void waits_invalidate(PState& P) { P.flags &= ~PF_WAITS_VALID; }
 // cheap in-line win-shape probe so that the (large, out-of-line) yaku evaluation is entered only for complete hands
-__device__ inline bool seat_shape(Ctx& c, int seat, int skip_idx, int win_tile) {
+__device__ __forceinline__ bool seat_shape(Ctx& c, int seat, int skip_idx, int win_tile) {
     PState& P = c.S.p[seat];
     PH h = build_ph(P, skip_idx);
     if (ph_total(h) + 3 * P.n_melds == 13) ph_add(h, win_tile >> 2);
@@ -353,12 +379,12 @@ __device__ inline bool seat_shape(Ctx& c, int seat, int skip_idx, int win_tile) 
 }
 
 // ---------------------------------------------------------------- legal actions
-__device__ inline void put_legal(Ctx& c, int seat, int pos, uint64_t a) {
+__device__ __forceinline__ void put_legal(Ctx& c, int seat, int pos, uint64_t a) {
     if (c.lane == 0 && pos < RMJ_MAX_LEGAL) c.X.legal[seat][pos] = a;
 }
 
 // legal_actions.rs:254-508.  Writes the claim list (+Pass) for seat i; returns true iff seat i has claims.
-__device__ inline bool gen_claims(Ctx& c, int i, int pid, int tile) {
+__device__ __forceinline__ bool gen_claims(Ctx& c, int i, int pid, int tile) {
     GState& S = c.S;
     PState& P = S.p[i];
     const int lane = c.lane;
@@ -464,7 +490,7 @@ __device__ inline bool gen_claims(Ctx& c, int i, int pid, int tile) {
 }
 
 // bit j set iff HandEvaluator(hand minus hand[j]).is_tenpai()  (legal_actions.rs:77-131)
-__device__ inline uint32_t tenpai_after_discard(Ctx& c, const PState& P) {
+__device__ __forceinline__ uint32_t tenpai_after_discard(Ctx& c, const PState& P) {
     uint32_t out = 0;
     int hl = P.hand_len;
     if (hl + 3 * P.n_melds != 14) return 0;
@@ -488,7 +514,7 @@ __device__ inline uint32_t tenpai_after_discard(Ctx& c, const PState& P) {
 }
 
 // legal_actions.rs:11-252 (WaitAct branch) for the current player
-__device__ inline void gen_act_legal(Ctx& c, int pid) {
+__device__ __forceinline__ void gen_act_legal(Ctx& c, int pid) {
     GState& S = c.S;
     PState& P = S.p[pid];
     const int lane = c.lane;
@@ -614,11 +640,13 @@ __device__ inline void gen_act_legal(Ctx& c, int pid) {
 }
 
 // ---------------------------------------------------------------- transitions
-__device__ void init_next_round(Ctx& c, bool oya_won, bool is_draw);
-__device__ void trigger_ryukyoku(Ctx& c, int reason, int offender);
+__device__ void ol_init_next_round(CtxV v, bool oya_won, bool is_draw);
+__device__ void ol_trigger_ryukyoku(CtxV v, int reason, int offender);
+__device__ __forceinline__ void init_next_round(Ctx& c, bool oya_won, bool is_draw) { ol_init_next_round(ctx_pack(c), oya_won, is_draw); }
+__device__ __forceinline__ void trigger_ryukyoku(Ctx& c, int reason, int offender) { ol_trigger_ryukyoku(ctx_pack(c), reason, offender); }
 
 // state/mod.rs:2021-2046
-__device__ inline void reveal_kan_dora(Ctx& c) {
+__device__ __forceinline__ void reveal_kan_dora(Ctx& c) {
     GState& S = c.S;
     int count = S.n_dora;
     if (count < 5) {
@@ -631,14 +659,14 @@ __device__ inline void reveal_kan_dora(Ctx& c) {
         }
     }
 }
-__device__ inline void flush_pending_kan_dora(Ctx& c) {
+__device__ __forceinline__ void flush_pending_kan_dora(Ctx& c) {
     while (c.S.pending_kan_dora > 0) {
         c.S.pending_kan_dora -= 1;
         reveal_kan_dora(c);
     }
 }
 // state/mod.rs:1549-1567
-__device__ inline void accept_riichi(Ctx& c) {
+__device__ __forceinline__ void accept_riichi(Ctx& c) {
     GState& S = c.S;
     if (S.riichi_pending != 0xFF) {
         int p = S.riichi_pending;
@@ -657,7 +685,7 @@ __device__ inline void process_end_game(Ctx& c) {
     emit_simple(c, RMJ_EV_END_GAME);
 }
 // state/mod.rs:1569-1593
-__device__ inline void deal_next(Ctx& c) {
+__device__ __forceinline__ void deal_next(Ctx& c) {
     GState& S = c.S;
     S.is_rinshan = 0;
     if (S.drawable_count == 0) {
@@ -680,7 +708,7 @@ __device__ inline void deal_next(Ctx& c) {
 }
 
 // the build's seed -> wall definition (oracle/riichi_state.hpp build_wall); writes W[0..135] (already reversed)
-__device__ __noinline__ void shuffle_wall(Ctx& c) {
+__device__ inline void shuffle_wall(Ctx& c) {
     GState& S = c.S;
     uint64_t hs = sm64(S.wall_seed + (uint64_t)S.hand_index);
     S.hand_index += 1;
@@ -700,7 +728,7 @@ __device__ __noinline__ void shuffle_wall(Ctx& c) {
 }
 
 // state/mod.rs:1695-1844.  Wall must already be in c.X.tiles (reversed orientation W).
-__device__ __noinline__ void init_round(Ctx& c, int oya, int round_wind, int honba, uint32_t kyotaku, const int32_t* scores) {
+__device__ inline void init_round(Ctx& c, int oya, int round_wind, int honba, uint32_t kyotaku, const int32_t* scores) {
     GState& S = c.S;
     const int lane = c.lane;
     S.oya = (uint8_t)oya;
@@ -797,7 +825,8 @@ __device__ __noinline__ void init_round(Ctx& c, int oya, int round_wind, int hon
 }
 
 // state/mod.rs:1595-1688
-__device__ __noinline__ void init_next_round(Ctx& c, bool oya_won, bool is_draw) {
+__device__ __noinline__ void ol_init_next_round(CtxV v, bool oya_won, bool is_draw) {
+    CTX_FROM(v);
     GState& S = c.S;
     if (S.is_done) return;
     const int np = 4;
@@ -845,7 +874,8 @@ __device__ inline bool seat_tenpai(Ctx& c, int seat) {
 }
 
 // state/mod.rs:1846-1968
-__device__ __noinline__ void trigger_ryukyoku(Ctx& c, int reason, int offender) {
+__device__ __noinline__ void ol_trigger_ryukyoku(CtxV v, int reason, int offender) {
+    CTX_FROM(v);
     GState& S = c.S;
     accept_riichi(c);
     const int np = 4;
@@ -912,7 +942,7 @@ __device__ __noinline__ void trigger_ryukyoku(Ctx& c, int reason, int offender) 
 }
 
 // state/mod.rs:1970-2019
-__device__ inline bool check_abortive_draw(Ctx& c) {
+__device__ __forceinline__ bool check_abortive_draw(Ctx& c) {
     GState& S = c.S;
     bool turns_ok = true, melds_empty = true, all_riichi = true;
     for (int p = 0; p < 4; p++) {
@@ -978,7 +1008,7 @@ __device__ inline void push_meld(PState& P, int type, uint32_t t0, uint32_t t1, 
 }
 
 // remove each consume tile from the hand (position lookup per tile, order preserved)
-__device__ inline void hand_remove_tiles(Ctx& c, PState& P, uint64_t act) {
+__device__ __forceinline__ void hand_remove_tiles(Ctx& c, PState& P, uint64_t act) {
     waits_invalidate(P);
     uint32_t n = a_n(act);
     for (uint32_t k = 0; k < n && k < 4; k++) {
@@ -988,7 +1018,10 @@ __device__ inline void hand_remove_tiles(Ctx& c, PState& P, uint64_t act) {
 }
 
 // state/mod.rs:1415-1547
-__device__ __noinline__ void resolve_kan(Ctx& c, int pid, uint64_t action) {
+__device__ void ol_resolve_kan(CtxV v, int pid, uint64_t action);
+__device__ __forceinline__ void resolve_kan(Ctx& c, int pid, uint64_t action) { ol_resolve_kan(ctx_pack(c), pid, action); }
+__device__ __noinline__ void ol_resolve_kan(CtxV v, int pid, uint64_t action) {
+    CTX_FROM(v);
     GState& S = c.S;
     PState& P = S.p[pid];
     uint32_t ty = a_type(action);
@@ -1027,7 +1060,7 @@ __device__ __noinline__ void resolve_kan(Ctx& c, int pid, uint64_t action) {
 }
 
 // state/mod.rs:1317-1413
-__device__ inline void resolve_discard(Ctx& c, int pid, int tile, bool tsumogiri) {
+__device__ __forceinline__ void resolve_discard(Ctx& c, int pid, int tile, bool tsumogiri) {
     GState& S = c.S;
     PState& P = S.p[pid];
     S.is_rinshan = 0;
@@ -1139,7 +1172,7 @@ __device__ inline void emit_hora(Ctx& c, int actor, int target, const int32_t* d
 }
 
 // ---------------------------------------------------------------- step (state/mod.rs:330-1315)
-__device__ inline void step_game(Ctx& c, const uint64_t acts_in[4]) {
+__device__ __forceinline__ void step_game(Ctx& c, const uint64_t acts_in[4]) {
     GState& S = c.S;
     const int lane = c.lane;
     if (S.is_done) return;
@@ -1478,7 +1511,7 @@ __device__ inline void step_game(Ctx& c, const uint64_t acts_in[4]) {
 
 // After a transition: produce the observation-side outputs for the new state
 // (get_observations(active_players), env.rs:870-871 -> state/mod.rs:189-263; mask: observation/python.rs:98-111)
-__device__ inline void finalize_outputs(Ctx& c, bool claims_fresh) {
+__device__ __forceinline__ void finalize_outputs(Ctx& c, bool claims_fresh) {
     GState& S = c.S;
     const int lane = c.lane;
     if (S.is_done) {

@@ -157,42 +157,40 @@ __device__ __forceinline__ uint64_t sm64(uint64_t x) {  // state/wall.rs:83-88
 }
 
 // ---------------------------------------------------------------- events
-__device__ __forceinline__ void emit_raw(Ctx& c, const RmjEvent& ev) {
+// 8 wave-uniform dwords -> one 32-byte record (two 16-byte stores from lane 0; no stack object, no scratch)
+__device__ __forceinline__ void emit_words(Ctx& c, uint32_t w0, uint32_t w1, uint32_t w2, uint32_t w3, uint32_t w4, uint32_t w5,
+                                           uint32_t w6, uint32_t w7) {
     if (c.E.skip_log) return;
     uint32_t idx = c.S.ev_count & c.E.ring_mask;
-    RmjEvent* dst = c.E.events + (size_t)c.g * (c.E.ring_mask + 1u) + idx;
+    uint4* dst = reinterpret_cast<uint4*>(c.E.events + (size_t)c.g * (c.E.ring_mask + 1u) + idx);
     if (c.lane == 0) {
-        const uint4* s = reinterpret_cast<const uint4*>(&ev);
-        uint4* d = reinterpret_cast<uint4*>(dst);
-        d[0] = s[0];
-        d[1] = s[1];
+        dst[0] = make_uint4(w0, w1, w2, w3);
+        dst[1] = make_uint4(w4, w5, w6, w7);
     }
     c.S.ev_count += 1;
 }
+__device__ __forceinline__ void emit_raw(Ctx& c, const RmjEvent& ev) {  // rare paths (struct built on the stack)
+    uint32_t p[8];
+    __builtin_memcpy(p, &ev, 32);  // (no type punning through a uint32_t*: strict aliasing)
+    emit_words(c, p[0], p[1], p[2], p[3], p[4], p[5], p[6], p[7]);
+}
 __device__ inline RmjEvent ev_zero(uint8_t type) {
     RmjEvent e;
-    uint32_t* p = reinterpret_cast<uint32_t*>(&e);
-#pragma unroll
-    for (int i = 0; i < 8; i++) p[i] = 0;
+    __builtin_memset(&e, 0, sizeof(e));
     e.type = type;
     return e;
 }
 __device__ __forceinline__ void emit_simple(Ctx& c, uint8_t type, uint8_t actor = 0, uint8_t tile = 0, uint8_t flags = 0) {
-    RmjEvent e = ev_zero(type);
-    e.actor = actor;
-    e.tile = tile;
-    e.flags = flags;
-    emit_raw(c, e);
+    emit_words(c, (uint32_t)type | ((uint32_t)actor << 8) | ((uint32_t)tile << 24), 0, 0, 0, 0, 0, (uint32_t)flags, 0);
 }
 __device__ __forceinline__ void emit_meld(Ctx& c, uint8_t type, uint8_t actor, uint8_t target, uint8_t tile, uint64_t act) {
-    RmjEvent e = ev_zero(type);
-    e.actor = actor;
-    e.target = target;
-    e.tile = tile;
     uint32_t n = a_n(act);
-    for (int i = 0; i < 4; i++) e.consumed[i] = (uint32_t)i < n ? (uint8_t)a_c(act, i) : 0;
-    e.flags = (uint8_t)(n << 4);
-    emit_raw(c, e);
+    uint32_t cons = 0;
+#pragma unroll
+    for (int i = 0; i < 4; i++)
+        if ((uint32_t)i < n) cons |= a_c(act, i) << (8 * i);
+    emit_words(c, (uint32_t)type | ((uint32_t)actor << 8) | ((uint32_t)target << 16) | ((uint32_t)tile << 24), cons, 0, 0, 0, 0,
+               (n << 4) & 0xFFu, 0);
 }
 
 // ---------------------------------------------------------------- small helpers
@@ -1200,7 +1198,7 @@ __device__ __forceinline__ void step_game(Ctx& c, const uint64_t acts_in[4]) {
     }
     if (S.phase == RMJ_WAIT_ACT) {
         const int pid = S.current_player;
-        const uint64_t act = acts[pid];
+        const uint64_t act = pid == 0 ? acts[0] : (pid == 1 ? acts[1] : (pid == 2 ? acts[2] : acts[3]));
         if (act == RMJ_NO_ACTION) return;
         PState& P = S.p[pid];
         const uint32_t ty = a_type(act);

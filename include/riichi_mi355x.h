@@ -233,6 +233,10 @@ int rmj_agari_counts(int device, const uint8_t* counts /*[n][34]*/, uint32_t n, 
 int rmj_calculate_score(int device, const uint8_t* han, const uint8_t* fu, const uint8_t* is_oya, const uint8_t* is_tsumo,
                         const uint32_t* honba, const uint8_t* num_players, uint32_t n, uint32_t* out /*[n][4] total,ron,oya,ko*/);
 
+/* shanten.rs:244-261 calculate_shanten / :470-484 calculate_shanten_3p over raw 34-histograms
+ * (len_div3 = tile count / 3; -1 = complete hand).  Tables are generated at first use, on the host. */
+int rmj_shanten(int device, const uint8_t* counts /*[n][34]*/, uint32_t n, int sanma, int8_t* out /*[n]*/);
+
 /* ------------------------------------------------------------------ measurement */
 typedef struct RmjBenchResult {
     double total_ms;      /* HIP-event time over the timed region (stream of the handle) */

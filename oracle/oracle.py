@@ -53,6 +53,7 @@ def lib():
         L.orc_calculate_score.argtypes = [C.c_void_p] * 6 + [C.c_uint32, C.c_void_p]
         L.orc_find_divisions.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
         L.orc_action_encode.argtypes = [C.c_uint64]
+        L.orc_shanten.argtypes = [C.c_void_p, C.c_uint32, C.c_int, C.c_void_p]
         L.orc_tid_to_mjai.argtypes = [C.c_uint8, C.c_char_p]
         L.orc_bench_rollout.restype = C.c_uint64
         L.orc_bench_rollout.argtypes = [C.c_int, C.c_uint32, C.c_int, C.c_uint32, C.c_uint64, C.c_uint64, C.c_uint32,
@@ -86,6 +87,13 @@ def calculate_score(han, fu, is_oya, is_tsumo, honba, np_):
     out = np.zeros((n, 4), np.uint32)
     lib().orc_calculate_score(a[0].ctypes.data, a[1].ctypes.data, a[2].ctypes.data, a[3].ctypes.data, hb.ctypes.data,
                               npl.ctypes.data, n, out.ctypes.data)
+    return out
+
+
+def shanten(counts, sanma=False):
+    counts = np.ascontiguousarray(counts, dtype=np.uint8)
+    out = np.zeros(counts.shape[0], np.int8)
+    lib().orc_shanten(counts.ctypes.data, counts.shape[0], int(sanma), out.ctypes.data)
     return out
 
 

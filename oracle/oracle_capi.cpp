@@ -9,6 +9,7 @@
 
 #include "../include/riichi_mi355x.h"
 #include "riichi_state.hpp"
+#include "riichi_shanten.hpp"
 
 using namespace orc;
 
@@ -143,6 +144,17 @@ int orc_find_divisions(const uint8_t* counts34, uint8_t* out /*[max][9]: head,n,
         n++;
     }
     return (int)d.size();
+}
+
+// shanten.rs:244-261 / :470-484
+int orc_shanten(const uint8_t* counts, uint32_t n, int sanma, int8_t* out) {
+    for (uint32_t k = 0; k < n; k++) {
+        const uint8_t* c = counts + 34 * (size_t)k;
+        int total = 0;
+        for (int i = 0; i < 34; i++) total += c[i];
+        out[k] = (int8_t)calc_shanten_from_counts(c, total / 3, sanma != 0);
+    }
+    return 0;
 }
 
 void orc_tid_to_mjai(uint8_t tid, char* buf) { std::strcpy(buf, tid_to_mjai(tid).c_str()); }

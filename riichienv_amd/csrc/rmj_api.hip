@@ -14,6 +14,7 @@
 
 #include "../../include/riichi_mi355x.h"
 #include "rmj_step.hip.h"
+#include "rmj_shanten.hip.h"
 
 using namespace rmj;
 
@@ -342,6 +343,21 @@ __global__ __launch_bounds__(256) void k_agari_counts(const uint8_t* counts, uin
         tenpai[k] = w != 0ull;
         waits[k] = w;
     }
+}
+
+// shanten.rs:244-261 / :470-484 (calculate_shanten / calculate_shanten_3p over raw histograms): one thread per hand
+__global__ void k_shanten(ShantenTables T, const uint8_t* counts, uint32_t n, int sanma, int8_t* out) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    PH h = {0, 0, 0, 0};
+    int total = 0;
+    for (int t = 0; t < 34; t++) {
+        uint32_t c = counts[(size_t)i * 34 + t];
+        total += (int)c;
+        int s = t_suit(t);
+        ph_addv(h, s, (c & 7u) << (3 * (t - 9 * s)));
+    }
+    out[i] = (int8_t)sh_shanten(h, total / 3, sanma != 0, T);
 }
 
 __global__ void k_score(const uint8_t* han, const uint8_t* fu, const uint8_t* oya, const uint8_t* tsumo, const uint32_t* honba,
@@ -985,6 +1001,50 @@ int rmj_calculate_score(int device, const uint8_t* han, const uint8_t* fu, const
     HIPCHK(hipDeviceSynchronize());
     HIPCHK(hipMemcpy(out, d_out, (size_t)n * 16, hipMemcpyDeviceToHost));
     hipFree(d_h); hipFree(d_f); hipFree(d_o); hipFree(d_t); hipFree(d_n); hipFree(d_hb); hipFree(d_out);
+    return RMJ_OK;
+}
+
+// ---- shanten (row A7) -------------------------------------------------------------------------------
+static int shanten_tables_for(int device, ShantenTables* out) {
+    static ShantenTables cache[64];
+    static bool have[64] = {false};
+    if (device < 0 || device >= 64) return fail(RMJ_ERR_ARG, "device ordinal");
+    if (!have[device]) {
+        const ShantenHostTables& H = shanten_host_tables();
+        uint64_t *ds, *dh;
+        uint32_t *r9, *r7;
+        HIPCHK(hipMalloc(&ds, H.suit.size() * 8));
+        HIPCHK(hipMalloc(&dh, H.honor.size() * 8));
+        HIPCHK(hipMalloc(&r9, H.rank9.size() * 4));
+        HIPCHK(hipMalloc(&r7, H.rank7.size() * 4));
+        HIPCHK(hipMemcpy(ds, H.suit.data(), H.suit.size() * 8, hipMemcpyHostToDevice));
+        HIPCHK(hipMemcpy(dh, H.honor.data(), H.honor.size() * 8, hipMemcpyHostToDevice));
+        HIPCHK(hipMemcpy(r9, H.rank9.data(), H.rank9.size() * 4, hipMemcpyHostToDevice));
+        HIPCHK(hipMemcpy(r7, H.rank7.data(), H.rank7.size() * 4, hipMemcpyHostToDevice));
+        cache[device].suit = ds; cache[device].honor = dh; cache[device].rank9 = r9; cache[device].rank7 = r7;
+        have[device] = true;
+    }
+    *out = cache[device];
+    return RMJ_OK;
+}
+int rmj_shanten(int device, const uint8_t* counts, uint32_t n, int sanma, int8_t* out) {
+    if (!counts || !out) return fail(RMJ_ERR_ARG, "null argument");
+    int rc = ensure_device(device);
+    if (rc) return rc;
+    if (n == 0) return RMJ_OK;
+    ShantenTables T;
+    if ((rc = shanten_tables_for(device, &T))) return rc;
+    uint8_t* d_c;
+    int8_t* d_o;
+    HIPCHK(hipMalloc(&d_c, (size_t)n * 34));
+    HIPCHK(hipMalloc(&d_o, n));
+    HIPCHK(hipMemcpy(d_c, counts, (size_t)n * 34, hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(k_shanten, dim3((n + 255) / 256), dim3(256), 0, 0, T, d_c, n, sanma, d_o);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipDeviceSynchronize());
+    HIPCHK(hipMemcpy(out, d_o, n, hipMemcpyDeviceToHost));
+    hipFree(d_c);
+    hipFree(d_o);
     return RMJ_OK;
 }
 

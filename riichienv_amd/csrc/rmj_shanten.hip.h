@@ -1,0 +1,291 @@
+// Shanten (row A7): replacement-number tables generated FROM FIRST PRINCIPLES at library init
+// (no data copied from the reference's nyanten_*.bin blobs) + device lookup.
+//
+// Reference semantics: shanten.rs:163-261 (calc_normal / calc_chitoi / calc_kokushi /
+// calc_shanten_from_counts), :407-461 (3P relocation of 1m/9m into empty honor slots).
+// The reference looks the "replacement number" up in Cryolite/nyanten tables; the quantity itself is
+//   r(c, m) = min over winning shapes t (m mentsu + 1 pair, every tile count <= 4) of sum_i max(0, t_i - c_i)
+// and shanten = r - 1.  Here the same quantity is tabulated per suit for (k mentsu, p pair) by a DP over tile
+// ranks (state = sequences started at the two previous ranks) and suits are merged by a (min,+) convolution.
+#pragma once
+#include <stdint.h>
+
+#include <vector>
+
+#include "rmj_hand.hip.h"
+
+namespace rmj {
+
+#define SH_SUIT_ENTRIES 405350
+#define SH_HONOR_ENTRIES 43130
+
+struct ShantenTables {             // device pointers
+    const uint64_t* suit;          // [405350] 10 x 4-bit costs: idx = p*5 + k
+    const uint64_t* honor;         // [43130]
+    const uint32_t* rank9;         // [9][15][5]
+    const uint32_t* rank7;         // [7][15][5]
+};
+
+// ---------------------------------------------------------------- host-side generator
+struct ShantenHostTables {
+    std::vector<uint64_t> suit, honor;
+    std::vector<uint32_t> rank9, rank7;
+};
+
+inline void sh_rank_table(int n, std::vector<uint32_t>& T) {
+    // N[i][s] = number of ways to fill ranks i..n-1 with digits 0..4 and total (incl. s) <= 14
+    std::vector<std::vector<uint64_t>> N(n + 1, std::vector<uint64_t>(16, 0));
+    for (int s = 0; s <= 14; s++) N[n][s] = 1;
+    for (int i = n - 1; i >= 0; i--)
+        for (int s = 0; s <= 14; s++) {
+            uint64_t v = 0;
+            for (int d = 0; d <= 4 && s + d <= 14; d++) v += N[i + 1][s + d];
+            N[i][s] = v;
+        }
+    T.assign((size_t)n * 15 * 5, 0);
+    for (int i = 0; i < n; i++)
+        for (int s = 0; s <= 14; s++) {
+            uint64_t acc = 0;
+            for (int c = 0; c <= 4; c++) {
+                T[((size_t)i * 15 + s) * 5 + c] = (uint32_t)acc;
+                if (s + c <= 14) acc += N[i + 1][s + c];
+            }
+        }
+}
+
+struct SuitDP {  // f[k][p][y1][y2], y* in 0..2 (three identical sequences == three triplets, so y <= 2 WLOG)
+    uint8_t f[5][2][3][3];
+};
+
+inline void sh_gen_suit(ShantenHostTables& H) {
+    H.suit.assign(SH_SUIT_ENTRIES, 0);
+    size_t leaf = 0;
+    SuitDP stack[10];
+    for (auto& k : stack[0].f)
+        for (auto& p : k)
+            for (auto& a : p)
+                for (auto& b : a) b = 99;
+    stack[0].f[0][0][0][0] = 0;
+    int digits[9] = {0};
+    // iterative DFS in lexicographic order (digit 0..4 per rank, running sum <= 14)
+    struct Rec {
+        int i, sum;
+    };
+    std::vector<Rec> st;
+    // recursive lambda
+    struct Gen {
+        ShantenHostTables& H;
+        size_t& leaf;
+        SuitDP* stack;
+        void go(int i, int sum) {
+            if (i == 9) {
+                uint64_t v = 0;
+                for (int p = 0; p < 2; p++)
+                    for (int k = 0; k < 5; k++) {
+                        uint8_t c = stack[9].f[k][p][0][0];
+                        if (c > 14) c = 15;
+                        v |= (uint64_t)c << (4 * (p * 5 + k));
+                    }
+                H.suit[leaf++] = v;
+                return;
+            }
+            for (int c = 0; c <= 4 && sum + c <= 14; c++) {
+                SuitDP& in = stack[i];
+                SuitDP& out = stack[i + 1];
+                for (auto& k : out.f)
+                    for (auto& p : k)
+                        for (auto& a : p)
+                            for (auto& b : a) b = 99;
+                for (int k = 0; k < 5; k++)
+                    for (int p = 0; p < 2; p++)
+                        for (int y1 = 0; y1 < 3; y1++)
+                            for (int y2 = 0; y2 < 3; y2++) {
+                                int base = in.f[k][p][y1][y2];
+                                if (base >= 99) continue;
+                                for (int x = 0; x <= 1; x++)
+                                    for (int z = 0; z <= 1 - p; z++)
+                                        for (int y = 0; y <= (i <= 6 ? 2 : 0); y++) {
+                                            int t = 3 * x + 2 * z + y + y1 + y2;
+                                            if (t > 4) continue;
+                                            int k2 = k + x + y;
+                                            if (k2 > 4) continue;
+                                            int cost = base + (t > c ? t - c : 0);
+                                            uint8_t& dst = out.f[k2][p + z][y][y1];
+                                            if (cost < dst) dst = (uint8_t)cost;
+                                        }
+                            }
+                go(i + 1, sum + c);
+            }
+        }
+    } gen{H, leaf, stack};
+    (void)digits;
+    (void)st;
+    gen.go(0, 0);
+}
+
+inline void sh_gen_honor(ShantenHostTables& H) {
+    H.honor.assign(SH_HONOR_ENTRIES, 0);
+    size_t leaf = 0;
+    uint8_t stack[8][5][2];
+    for (auto& k : stack[0])
+        for (auto& p : k) p = 99;
+    stack[0][0][0] = 0;
+    struct Gen {
+        ShantenHostTables& H;
+        size_t& leaf;
+        uint8_t (*stack)[5][2];
+        void go(int i, int sum) {
+            if (i == 7) {
+                uint64_t v = 0;
+                for (int p = 0; p < 2; p++)
+                    for (int k = 0; k < 5; k++) {
+                        uint8_t c = stack[7][k][p];
+                        if (c > 14) c = 15;
+                        v |= (uint64_t)c << (4 * (p * 5 + k));
+                    }
+                H.honor[leaf++] = v;
+                return;
+            }
+            for (int c = 0; c <= 4 && sum + c <= 14; c++) {
+                for (int k = 0; k < 5; k++)
+                    for (int p = 0; p < 2; p++) stack[i + 1][k][p] = 99;
+                for (int k = 0; k < 5; k++)
+                    for (int p = 0; p < 2; p++) {
+                        int base = stack[i][k][p];
+                        if (base >= 99) continue;
+                        for (int x = 0; x <= 1; x++)
+                            for (int z = 0; z <= 1 - p; z++) {
+                                int t = 3 * x + 2 * z;
+                                if (t > 4 || k + x > 4) continue;
+                                int cost = base + (t > c ? t - c : 0);
+                                uint8_t& dst = stack[i + 1][k + x][p + z];
+                                if (cost < dst) dst = (uint8_t)cost;
+                            }
+                    }
+                go(i + 1, sum + c);
+            }
+        }
+    } gen{H, leaf, stack};
+    gen.go(0, 0);
+}
+
+inline const ShantenHostTables& shanten_host_tables() {
+    static ShantenHostTables H;
+    static bool done = false;
+    if (!done) {
+        sh_rank_table(9, H.rank9);
+        sh_rank_table(7, H.rank7);
+        sh_gen_suit(H);
+        sh_gen_honor(H);
+        done = true;
+    }
+    return H;
+}
+
+// ---------------------------------------------------------------- device lookup
+__device__ __forceinline__ uint32_t sh_rank(uint32_t x, int n, const uint32_t* T) {  // x: n fields of 3 bits
+    uint32_t h = 0, s = 0;
+    for (int i = 0; i < n; i++) {
+        uint32_t c = (x >> (3 * i)) & 7u;
+        if (c > 4u) c = 4u;
+        if (s + c > 14u) c = 14u - s;
+        h += T[(i * 15 + s) * 5 + c];
+        s += c;
+    }
+    return h;
+}
+// (min,+) merge of two packed cost vectors (idx = p*5 + k, 4 bits each, 15 = infeasible)
+__device__ __forceinline__ uint64_t sh_merge(uint64_t a, uint64_t b) {
+    uint64_t out = 0;
+#pragma unroll
+    for (int p = 0; p < 2; p++)
+#pragma unroll
+        for (int k = 0; k < 5; k++) {
+            uint32_t best = 15;
+#pragma unroll
+            for (int p1 = 0; p1 <= p; p1++)
+#pragma unroll
+                for (int k1 = 0; k1 <= k; k1++) {
+                    uint32_t va = (uint32_t)(a >> (4 * (p1 * 5 + k1))) & 15u;
+                    uint32_t vb = (uint32_t)(b >> (4 * ((p - p1) * 5 + (k - k1)))) & 15u;
+                    uint32_t v = va + vb;
+                    best = v < best ? v : best;
+                }
+            out |= (uint64_t)best << (4 * (p * 5 + k));
+        }
+    return out;
+}
+// shanten.rs:186-196
+__device__ __forceinline__ int sh_normal(const PH& h, int m, const ShantenTables& T) {
+    uint64_t a = T.suit[sh_rank(h.a, 9, T.rank9)];
+    uint64_t b = T.suit[sh_rank(h.b, 9, T.rank9)];
+    uint64_t c = T.suit[sh_rank(h.c, 9, T.rank9)];
+    uint64_t d = T.honor[sh_rank(h.d, 7, T.rank7)];
+    uint64_t r = sh_merge(sh_merge(a, b), sh_merge(c, d));
+    if (m > 4) m = 4;
+    int rep = (int)((r >> (4 * (5 + m))) & 15u);
+    return rep - 1;
+}
+// shanten.rs:198-211 ; sanma: 2m-8m skipped (shanten.rs:437-452) — they are absent from a sanma hand anyway
+__device__ __forceinline__ int sh_chiitoi(PH h, bool sanma) {
+    if (sanma) h.a &= (7u | (7u << 24));
+    uint64_t pres = ph_presence(h);
+    int kinds = __popcll(pres);
+    // count >= 2  <=> bit1 or bit2 of the field
+    int pairs = __popc(((h.a >> 1) | (h.a >> 2)) & O9_1) + __popc(((h.b >> 1) | (h.b >> 2)) & O9_1) +
+                __popc(((h.c >> 1) | (h.c >> 2)) & O9_1) + __popc(((h.d >> 1) | (h.d >> 2)) & O7_1);
+    int red = kinds < 7 ? 7 - kinds : 0;
+    return 7 - pairs + red - 1;
+}
+// shanten.rs:213-226
+__device__ __forceinline__ int sh_kokushi(const PH& h) {
+    int kinds = 0;
+    bool pair = false;
+#pragma unroll
+    for (int s = 0; s < 3; s++) {
+        uint32_t x = ph_get(h, s);
+        uint32_t c0 = x & 7u, c8 = (x >> 24) & 7u;
+        kinds += (c0 > 0u) + (c8 > 0u);
+        pair = pair || c0 >= 2u || c8 >= 2u;
+    }
+#pragma unroll
+    for (int i = 0; i < 7; i++) {
+        uint32_t c = (h.d >> (3 * i)) & 7u;
+        kinds += c > 0u;
+        pair = pair || c >= 2u;
+    }
+    return 14 - kinds - (pair ? 1 : 0) - 1;
+}
+// shanten.rs:407-435: relocate 1m / 9m counts into empty honor slots (3P)
+__device__ __forceinline__ PH sh_relocate_3p(const PH& h) {
+    PH t = h;
+    uint32_t mc[2] = {h.a & 7u, (h.a >> 24) & 7u};
+    t.a &= ~(7u | (7u << 24));
+    int slot = 0;
+#pragma unroll
+    for (int i = 0; i < 2; i++) {
+        if (mc[i] == 0u) continue;
+        while (slot < 7 && ((t.d >> (3 * slot)) & 7u) != 0u) slot++;
+        if (slot < 7) {
+            t.d |= mc[i] << (3 * slot);
+            slot++;
+        } else {
+            t.a |= mc[i] << (i == 0 ? 0 : 24);
+        }
+    }
+    return t;
+}
+// shanten.rs:228-241 (4P) / :454-468 (3P)
+__device__ __forceinline__ int sh_shanten(const PH& h, int len_div3, bool sanma, const ShantenTables& T) {
+    int s = sh_normal(sanma ? sh_relocate_3p(h) : h, len_div3, T);
+    if (s <= 0 || len_div3 < 4) return s;
+    int c = sh_chiitoi(h, sanma);
+    s = c < s ? c : s;
+    if (s > 0) {
+        int k = sh_kokushi(h);
+        s = k < s ? k : s;
+    }
+    return s;
+}
+
+}  // namespace rmj

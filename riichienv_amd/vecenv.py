@@ -26,7 +26,7 @@ EXPORTS = [
     "rmj_step_device", "rmj_step_random", "rmj_random_actions", "rmj_get_status", "rmj_get_legal", "rmj_get_mask",
     "rmj_get_waits", "rmj_get_scores", "rmj_get_ranks", "rmj_get_step_counts", "rmj_total_steps", "rmj_peek_state",
     "rmj_poke_state", "rmj_get_event_counts", "rmj_get_events", "rmj_format_event", "rmj_eval_hands",
-    "rmj_agari_counts", "rmj_calculate_score", "rmj_bench_rollout",
+    "rmj_agari_counts", "rmj_calculate_score", "rmj_shanten", "rmj_bench_rollout",
 ]
 
 
@@ -69,6 +69,7 @@ def load_lib():
     L.rmj_eval_hands.argtypes = [C.c_int, C.POINTER(abi.HandCase), C.c_uint32, C.POINTER(abi.HandResult)]
     L.rmj_agari_counts.argtypes = [C.c_int, vp, C.c_uint32, vp, vp, vp]
     L.rmj_calculate_score.argtypes = [C.c_int] + [vp] * 6 + [C.c_uint32, vp]
+    L.rmj_shanten.argtypes = [C.c_int, vp, C.c_uint32, C.c_int, vp]
     L.rmj_bench_rollout.argtypes = [vp, C.c_uint64, C.c_uint32, C.c_uint32, C.POINTER(abi.BenchResult)]
     _LIB = L
     return L
@@ -280,6 +281,16 @@ def calculate_score(han, fu, is_oya, is_tsumo, honba, num_players, device=0):
     out = np.zeros((n, 4), np.uint32)
     _chk(L.rmj_calculate_score(device, a[0].ctypes.data, a[1].ctypes.data, a[2].ctypes.data, a[3].ctypes.data,
                                hb.ctypes.data, npl.ctypes.data, n, out.ctypes.data))
+    return out
+
+
+def shanten(counts, sanma=False, device=0):
+    """calculate_shanten / calculate_shanten_3p (shanten.rs:244-261, 470-484) over [n,34] histograms."""
+    L = load_lib()
+    counts = np.ascontiguousarray(counts, dtype=np.uint8)
+    n = counts.shape[0]
+    out = np.zeros(n, np.int8)
+    _chk(L.rmj_shanten(device, counts.ctypes.data, n, int(sanma), out.ctypes.data))
     return out
 
 

@@ -100,3 +100,27 @@ def test_score_table():
                                                   [0, 3], [3, 4], indexing="ij")
     args = [x.ravel() for x in (han, fu, oya, tsumo, honba, npl)]
     assert (vecenv.calculate_score(*args) == oracle.calculate_score(*args)).all()
+
+
+def test_shanten_kats_and_random():
+    """Row A7: rmj_shanten (tables generated from first principles) vs the reference's KATs and vs the oracle's
+    plain enumeration, 4P and 3P, for 13/14-tile hands and for hands with melds (10/11/7/8/4/5 tiles)."""
+    from oracle import oracle
+    from riichienv_amd import vecenv
+    from tests.test_oracle_shanten import KATS, counts_of
+
+    c = np.array([counts_of(h) for h, _, _ in KATS])
+    s4 = vecenv.shanten(c, sanma=False)
+    s3 = vecenv.shanten(c, sanma=True)
+    for i, (h, e4, e3) in enumerate(KATS):
+        assert s4[i] == e4, (h, s4[i], e4)
+        if e3 is not None:
+            assert s3[i] == e3, (h, s3[i], e3)
+    rng = np.random.default_rng(99)
+    hands = np.concatenate([_random_hands(rng, 400, size) for size in (13, 14, 10, 11, 7, 8, 4, 5, 1, 2)])
+    assert (vecenv.shanten(hands, False) == oracle.shanten(hands, False)).all()
+    # sanma hands: no 2m-8m
+    sh = hands.copy()
+    sh[:, 1:8] = 0
+    assert (vecenv.shanten(sh, True) == oracle.shanten(sh, True)).all()
+    assert (vecenv.shanten(sh, False) == oracle.shanten(sh, False)).all()

@@ -14,7 +14,6 @@
 
 #include "../../include/riichi_mi355x.h"
 #include "rmj_step.hip.h"
-#include "rmj_shanten.hip.h"
 
 using namespace rmj;
 
@@ -407,6 +406,8 @@ static int upload(const T* src, size_t count, T** dst) {
     return RMJ_OK;
 }
 
+static int shanten_tables_for(int device, ShantenTables* out);
+
 extern "C" {
 
 const char* rmj_version(void) { return "riichi_mi355x 0.1 (gfx950)"; }
@@ -452,6 +453,7 @@ int rmj_create(const RmjConfig* cfg, rmj_handle* out) {
     d.skip_log = cfg->skip_mjai_logging;
     d.ctor_round_wind = cfg->round_wind;
     d.game_offset = cfg->game_offset;
+    if ((rc = shanten_tables_for(cfg->device, &d.sh))) return rc;
     ResetArgs A;
     memset(&A, 0, sizeof(A));
     A.is_ctor = 1;

@@ -288,4 +288,42 @@ __device__ __forceinline__ int sh_shanten(const PH& h, int len_div3, bool sanma,
     return s;
 }
 
+// Wave-cooperative 4P shanten of ONE wave-uniform hand (used as a sound prefilter for the riichi probe):
+// lane = tile rank computes its term of the perfect hash in parallel, four segmented wave sums, four table loads.
+__device__ __forceinline__ int sh_shanten_wave(const PH& h, int len_div3, const ShantenTables& T, int lane) {
+    uint32_t val = 0;
+    int q = t_suit(lane < 34 ? lane : 0);
+    if (lane < 34) {
+        int i = lane - 9 * q;
+        uint32_t x = ph_get(h, q);
+        uint32_t c = (x >> (3 * i)) & 7u;
+        uint32_t s = (uint32_t)field_sum(x & ((1u << (3 * i)) - 1u));
+        if (c > 4u) c = 4u;
+        if (s > 14u) s = 14u;
+        if (s + c > 14u) c = 14u - s;
+        val = (q < 3 ? T.rank9 : T.rank7)[(i * 15 + s) * 5 + c];
+    }
+    uint32_t r0 = (lane < 34 && q == 0) ? val : 0u, r1 = (lane < 34 && q == 1) ? val : 0u;
+    uint32_t r2 = (lane < 34 && q == 2) ? val : 0u, r3 = (lane < 34 && q == 3) ? val : 0u;
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+        r0 += __shfl_xor(r0, off, 64);
+        r1 += __shfl_xor(r1, off, 64);
+        r2 += __shfl_xor(r2, off, 64);
+        r3 += __shfl_xor(r3, off, 64);
+    }
+    uint64_t a = T.suit[r0], b = T.suit[r1], c = T.suit[r2], d = T.honor[r3];
+    uint64_t r = sh_merge(sh_merge(a, b), sh_merge(c, d));
+    int m = len_div3 > 4 ? 4 : len_div3;
+    int sres = (int)((r >> (4 * (5 + m))) & 15u) - 1;
+    if (sres <= 0 || len_div3 < 4) return sres;
+    int ch = sh_chiitoi(h, false);
+    sres = ch < sres ? ch : sres;
+    if (sres > 0) {
+        int k = sh_kokushi(h);
+        sres = k < sres ? k : sres;
+    }
+    return sres;
+}
+
 }  // namespace rmj

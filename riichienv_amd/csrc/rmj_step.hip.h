@@ -15,6 +15,7 @@
 #pragma once
 #include "../../include/riichi_mi355x.h"
 #include "rmj_hand.hip.h"
+#include "rmj_shanten.hip.h"
 #include "rmj_state.h"
 
 namespace rmj {
@@ -35,6 +36,7 @@ struct Env {
     uint32_t skip_log;
     uint32_t ctor_round_wind;
     uint64_t game_offset;
+    ShantenTables sh;     // replacement-number tables (prefilter of the riichi probe)
 };
 
 struct WaveScratch {      // per-wave LDS scratch
@@ -493,6 +495,9 @@ __device__ __forceinline__ uint32_t tenpai_after_discard(Ctx& c, const PState& P
     int hl = P.hand_len;
     if (hl + 3 * P.n_melds != 14) return 0;
     PH full = build_ph(P);
+    // Sound prefilter: a tenpai 13-tile subset implies replacement number <= 1 for the 14 tiles
+    // (swap the discard for the winning tile), i.e. shanten(14) <= 0.  Only then run the exact probes.
+    if (sh_shanten_wave(full, hl / 3, c.E.sh, c.lane) > 0) return 0;
     int prev_ty = -1;
     bool prev_res = false;
     for (int j = 0; j < hl; j++) {

@@ -233,6 +233,13 @@ int rmj_agari_counts(int device, const uint8_t* counts /*[n][34]*/, uint32_t n, 
 int rmj_calculate_score(int device, const uint8_t* han, const uint8_t* fu, const uint8_t* is_oya, const uint8_t* is_tsumo,
                         const uint32_t* honba, const uint8_t* num_players, uint32_t n, uint32_t* out /*[n][4] total,ron,oya,ko*/);
 
+/* Observation.encode() (observation/python.rs:457-806, docs/FEATURE_ENCODING.md): 74 x 34 f32, channel-major, for
+ * every seat of every game: out[n][4][74][34].  only_active != 0 -> seats that are not to act get zeros. */
+#define RMJ_ENC_CHANNELS 74
+#define RMJ_ENC_WIDTH_4P 34
+int rmj_encode(rmj_handle h, int only_active, float* out);
+int rmj_encode_device(rmj_handle h, int only_active, float* d_out); /* device pointer, asynchronous on the handle's stream */
+
 /* shanten.rs:244-261 calculate_shanten / :470-484 calculate_shanten_3p over raw 34-histograms
  * (len_div3 = tile count / 3; -1 = complete hand).  Tables are generated at first use, on the host. */
 int rmj_shanten(int device, const uint8_t* counts /*[n][34]*/, uint32_t n, int sanma, int8_t* out /*[n]*/);

@@ -53,6 +53,7 @@ def lib():
         L.orc_calculate_score.argtypes = [C.c_void_p] * 6 + [C.c_uint32, C.c_void_p]
         L.orc_find_divisions.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
         L.orc_action_encode.argtypes = [C.c_uint64]
+        L.orc_game_encode.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
         L.orc_shanten.argtypes = [C.c_void_p, C.c_uint32, C.c_int, C.c_void_p]
         L.orc_tid_to_mjai.argtypes = [C.c_uint8, C.c_char_p]
         L.orc_bench_rollout.restype = C.c_uint64
@@ -172,6 +173,11 @@ class Game:
         for i in range(n):
             self.L.orc_game_log_get(self.h, seat, i, buf, 4096)
             out.append(buf.value.decode())
+        return out
+
+    def encode(self, pid):
+        out = np.zeros((74, 34), np.float32)
+        self.L.orc_game_encode(self.h, pid, out.ctypes.data)
         return out
 
     def random_actions(self, policy_seed, global_game):

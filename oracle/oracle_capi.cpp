@@ -369,6 +369,131 @@ void orc_game_poke(void* gp, const RmjStateView* v) {
     }
 }
 
+// observation/helpers.rs:24-50 (136-id in, 136-id out)
+static uint8_t obs_get_next_tile(uint32_t tile) {
+    uint32_t tile_type = (tile / 4) / 9, tile_num = (tile / 4) % 9;
+    if (tile_type < 3) {
+        uint32_t next_num = tile_num == 8 ? 0 : tile_num + 1;
+        return (uint8_t)((tile_type * 9 + next_num) * 4);
+    }
+    uint32_t base = tile / 4;
+    if (base >= 27 && base < 31) return (uint8_t)((27 + (base - 27 + 1) % 4) * 4);
+    if (base >= 31 && base < 34) return (uint8_t)((31 + (base - 31 + 1) % 3) * 4);
+    return (uint8_t)tile;
+}
+
+// Observation.encode(): observation/python.rs:457-806 over the snapshot of state/mod.rs:189-263
+void orc_game_encode(void* gp, int pid, float* arr /*[74][34]*/) {
+    GameState* g = (GameState*)gp;
+    const int W = 34;
+    std::memset(arr, 0, sizeof(float) * 74 * W);
+    auto A = [&](int ch, int t) -> float& { return arr[ch * W + t]; };
+    const PlayerState& P = g->players[pid];
+    int rel[4] = {pid, (pid + 1) % 4, (pid + 2) % 4, (pid + 3) % 4};
+    uint8_t counts[34] = {0};
+    for (uint8_t t : P.hand) {
+        int idx = t / 4;
+        counts[idx]++;
+        if (t == 16 || t == 52 || t == 88) A(4, idx) = 1.0f;
+    }
+    for (int i = 0; i < 34; i++)
+        for (int k = 0; k < 4; k++)
+            if (counts[i] >= k + 1) A(k, i) = 1.0f;
+    for (size_t m = 0; m < P.melds.size() && m < 4; m++)
+        for (uint8_t t : P.melds[m].tiles) A(5 + (int)m, t / 4) = 1.0f;
+    for (uint8_t t : g->wall.dora_indicators) A(9, t / 4) = 1.0f;
+    {
+        const auto& d = P.discards;
+        for (size_t i = 0; i < 4 && i < d.size(); i++) A(10 + (int)i, d[d.size() - 1 - i] / 4) = 1.0f;
+    }
+    for (int i = 1; i < 4; i++) {
+        const auto& d = g->players[(pid + i) % 4].discards;
+        for (size_t j = 0; j < 4 && j < d.size(); j++) A(14 + (i - 1) * 4 + (int)j, d[d.size() - 1 - j] / 4) = 1.0f;
+    }
+    for (int c = 0; c < 4; c++) {
+        float v = (float)g->players[rel[c]].discards.size() / 24.0f;
+        for (int k = 0; k < W; k++) A(26 + c, k) = v;
+    }
+    int tiles_used = 0;
+    for (auto& q : g->players) {
+        tiles_used += (int)q.discards.size();
+        for (auto& m : q.melds) tiles_used += (int)m.tiles.size();
+    }
+    tiles_used += (int)P.hand.size() + (int)g->wall.dora_indicators.size();
+    float tl = (float)std::max(136 - tiles_used, 0) / 70.0f;
+    for (int k = 0; k < W; k++) A(30, k) = tl;
+    if (P.riichi_declared)
+        for (int k = 0; k < W; k++) A(31, k) = 1.0f;
+    for (int i = 1; i < 4; i++)
+        if (g->players[(pid + i) % 4].riichi_declared)
+            for (int k = 0; k < W; k++) A(32 + (i - 1), k) = 1.0f;
+    if (27 + g->round_wind < 34) A(35, 27 + g->round_wind) = 1.0f;
+    int seat = (pid + 4 - g->oya) % 4;
+    A(36, 27 + seat) = 1.0f;
+    for (int k = 0; k < W; k++) {
+        A(37, k) = (float)g->honba / 10.0f;
+        A(38, k) = (float)g->riichi_sticks / 5.0f;
+    }
+    for (int c = 0; c < 4; c++) {
+        int32_t sc = g->players[rel[c]].score;
+        float a = (float)std::min(std::max(sc, 0), 100000) / 100000.0f;
+        float b = (float)std::min(std::max(sc, 0), 30000) / 30000.0f;
+        for (int k = 0; k < W; k++) {
+            A(39 + c, k) = a;
+            A(43 + c, k) = b;
+        }
+    }
+    std::vector<uint8_t> waits = g->observation_waits(pid);
+    for (uint8_t t : waits) A(47, t) = 1.0f;
+    for (int k = 0; k < W; k++) A(48, k) = waits.empty() ? 0.0f : 1.0f;
+    int rank = 0;
+    for (auto& q : g->players)
+        if (q.score > P.score) rank++;
+    if (rank < 4)
+        for (int k = 0; k < W; k++) A(49 + rank, k) = 1.0f;
+    for (int k = 0; k < W; k++) {
+        A(53, k) = (float)g->kyoku_idx / 8.0f;
+        A(54, k) = ((float)g->round_wind * 4.0f + (float)g->kyoku_idx) / 7.0f;
+    }
+    uint8_t dora_counts[4] = {0, 0, 0, 0};
+    for (int q = 0; q < 4; q++) {
+        for (auto& m : g->players[q].melds)
+            for (uint8_t tile : m.tiles)
+                for (uint8_t di : g->wall.dora_indicators)
+                    if ((tile / 4) == (obs_get_next_tile(di) / 4)) dora_counts[q]++;
+        for (uint8_t tile : g->players[q].discards)
+            for (uint8_t di : g->wall.dora_indicators)
+                if ((tile / 4) == (obs_get_next_tile(di) / 4)) dora_counts[q]++;
+    }
+    for (uint8_t tile : P.hand)
+        for (uint8_t di : g->wall.dora_indicators)
+            if ((tile / 4) == (obs_get_next_tile(di) / 4)) dora_counts[pid]++;
+    for (int c = 0; c < 4; c++) {
+        float v = (float)dora_counts[rel[c]] / 12.0f;
+        float mv = (float)g->players[rel[c]].melds.size() / 4.0f;
+        for (int k = 0; k < W; k++) {
+            A(55 + c, k) = v;
+            A(59 + c, k) = mv;
+        }
+    }
+    uint8_t seen[34] = {0};
+    for (uint8_t t : P.hand) seen[t / 4]++;
+    for (auto& q : g->players) {
+        for (auto& m : q.melds)
+            for (uint8_t t : m.tiles) seen[t / 4]++;
+        for (uint8_t t : q.discards) seen[t / 4]++;
+    }
+    for (uint8_t t : g->wall.dora_indicators) seen[t / 4]++;
+    for (int i = 0; i < 34; i++) A(63, i) = (float)seen[i] / 4.0f;
+    {
+        const auto& d = P.discards;
+        for (size_t i = 0; i < 4 && 4 + i < d.size(); i++) A(64 + (int)i, d[d.size() - 1 - (4 + i)] / 4) = 1.0f;
+        const auto& e = g->players[(pid + 1) % 4].discards;
+        for (size_t i = 0; i < 2 && 4 + i < e.size(); i++) A(68 + (int)i, e[e.size() - 1 - (4 + i)] / 4) = 1.0f;
+    }
+    // ch 70-73: tsumogiri_flags is never filled (observation/mod.rs:105) -> zeros
+}
+
 uint32_t orc_game_log_len(void* gp, int seat) {
     GameState* g = (GameState*)gp;
     return (uint32_t)(seat < 0 ? g->mjai_log.size() : g->mjai_log_per_player[seat].size());

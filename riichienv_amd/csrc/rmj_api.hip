@@ -14,6 +14,7 @@
 
 #include "../../include/riichi_mi355x.h"
 #include "rmj_step.hip.h"
+#include "rmj_encode.hip.h"
 
 using namespace rmj;
 
@@ -342,6 +343,30 @@ __global__ __launch_bounds__(256) void k_agari_counts(const uint8_t* counts, uin
         tenpai[k] = w != 0ull;
         waits[k] = w;
     }
+}
+
+// Observation.encode() for every (game, seat): out[g][seat][74][34] f32 (zeros for skipped seats)
+struct EncShared {
+    GState st;
+    float buf[4][ENC_FLOATS];
+};
+__global__ __launch_bounds__(256) void k_encode(Env E, int only_active, float* __restrict__ out) {
+    __shared__ EncShared sh;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const uint32_t g = blockIdx.x;
+    if (threadIdx.x < sizeof(GState) / 16) reinterpret_cast<uint4*>(&sh.st)[threadIdx.x] = reinterpret_cast<const uint4*>(E.core + g)[threadIdx.x];
+    __syncthreads();
+    const GState& S = sh.st;
+    float* buf = sh.buf[wave];
+    bool want = !only_active || (((S.active_mask >> wave) & 1u) && !S.is_done);
+    if (want) encode_seat(S, wave, buf, lane);
+    else {
+        for (int i = lane; i < ENC_FLOATS; i += 64) buf[i] = 0.0f;
+        wave_sync();
+    }
+    float4* dst = reinterpret_cast<float4*>(out + ((size_t)g * 4 + wave) * ENC_FLOATS);
+    const float4* src = reinterpret_cast<const float4*>(buf);
+    for (int i = lane; i < ENC_FLOATS / 4; i += 64) dst[i] = src[i];
 }
 
 // shanten.rs:244-261 / :470-484 (calculate_shanten / calculate_shanten_3p over raw histograms): one thread per hand
@@ -1003,6 +1028,28 @@ int rmj_calculate_score(int device, const uint8_t* han, const uint8_t* fu, const
     HIPCHK(hipDeviceSynchronize());
     HIPCHK(hipMemcpy(out, d_out, (size_t)n * 16, hipMemcpyDeviceToHost));
     hipFree(d_h); hipFree(d_f); hipFree(d_o); hipFree(d_t); hipFree(d_n); hipFree(d_hb); hipFree(d_out);
+    return RMJ_OK;
+}
+
+// ---- feature encoder (row A14) --------------------------------------------------------------------
+int rmj_encode_device(rmj_handle h, int only_active, float* d_out) {
+    if (!h || !d_out) return fail(RMJ_ERR_ARG, "null argument");
+    HIPCHK(hipSetDevice(h->cfg.device));
+    hipLaunchKernelGGL(k_encode, dim3(h->cfg.n_games), dim3(256), 0, h->stream, h->d, only_active, d_out);
+    HIPCHK(hipGetLastError());
+    return RMJ_OK;
+}
+int rmj_encode(rmj_handle h, int only_active, float* out) {
+    if (!h || !out) return fail(RMJ_ERR_ARG, "null argument");
+    HIPCHK(hipSetDevice(h->cfg.device));
+    size_t bytes = (size_t)h->cfg.n_games * 4 * ENC_FLOATS * sizeof(float);
+    float* d;
+    HIPCHK(hipMalloc(&d, bytes));
+    int rc = rmj_encode_device(h, only_active, d);
+    if (rc) return rc;
+    HIPCHK(hipStreamSynchronize(h->stream));
+    HIPCHK(hipMemcpy(out, d, bytes, hipMemcpyDeviceToHost));
+    hipFree(d);
     return RMJ_OK;
 }
 

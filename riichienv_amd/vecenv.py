@@ -26,7 +26,7 @@ EXPORTS = [
     "rmj_step_device", "rmj_step_random", "rmj_random_actions", "rmj_get_status", "rmj_get_legal", "rmj_get_mask",
     "rmj_get_waits", "rmj_get_scores", "rmj_get_ranks", "rmj_get_step_counts", "rmj_total_steps", "rmj_peek_state",
     "rmj_poke_state", "rmj_get_event_counts", "rmj_get_events", "rmj_format_event", "rmj_eval_hands",
-    "rmj_agari_counts", "rmj_calculate_score", "rmj_shanten", "rmj_bench_rollout",
+    "rmj_agari_counts", "rmj_calculate_score", "rmj_shanten", "rmj_encode", "rmj_encode_device", "rmj_bench_rollout",
 ]
 
 
@@ -69,6 +69,8 @@ def load_lib():
     L.rmj_eval_hands.argtypes = [C.c_int, C.POINTER(abi.HandCase), C.c_uint32, C.POINTER(abi.HandResult)]
     L.rmj_agari_counts.argtypes = [C.c_int, vp, C.c_uint32, vp, vp, vp]
     L.rmj_calculate_score.argtypes = [C.c_int] + [vp] * 6 + [C.c_uint32, vp]
+    L.rmj_encode.argtypes = [vp, C.c_int, vp]
+    L.rmj_encode_device.argtypes = [vp, C.c_int, vp]
     L.rmj_shanten.argtypes = [C.c_int, vp, C.c_uint32, C.c_int, vp]
     L.rmj_bench_rollout.argtypes = [vp, C.c_uint64, C.c_uint32, C.c_uint32, C.POINTER(abi.BenchResult)]
     _LIB = L
@@ -244,6 +246,12 @@ class VecRiichiEnv:
                 raise RmjError(f"cannot format event {i} of game {g} (type {buf[i].type})")
             out.append(s.value.decode())
             i += used
+        return out
+
+    def encode(self, only_active=False):
+        """Observation.encode() of every seat: float32 [n, 4, 74, 34] (observation/python.rs:457-806)."""
+        out = np.zeros((self.n, 4, 74, 34), np.float32)
+        _chk(self.L.rmj_encode(self.h, int(only_active), out.ctypes.data))
         return out
 
     def bench_rollout(self, policy_seed, warmup, steps) -> abi.BenchResult:

@@ -93,3 +93,33 @@ def test_step_random_device_policy_matches_oracle():
     _compare(env, games, range(n), steps)
     assert list(env.step_counts()) == [o.step_count for o in games]
     assert env.total_steps() == sum(o.step_count for o in games)
+
+
+def test_encode_parity_along_rollout():
+    """Row A14: rmj_encode (74 x 34 f32 for every seat) bit-exact vs the oracle along a random rollout."""
+    from oracle import oracle
+    from riichienv_amd import vecenv
+
+    n, seed, pseed = 24, 321, 5
+    env = vecenv.VecRiichiEnv(n, game_mode=2, seed=seed)
+    games = [oracle.Game(game_mode=2, seed=seed + g) for g in range(n)]
+    env.reset()
+    for o in games:
+        o.reset()
+    for step in range(400):
+        acts = np.array([games[g].random_actions(pseed, g) for g in range(n)], dtype=np.uint64)
+        env.step(acts)
+        for g in range(n):
+            games[g].step([int(x) for x in acts[g]])
+        if step % 7 == 0:
+            enc = env.encode()
+            act, ph, dn = env.status()
+            enc_act = env.encode(only_active=True)
+            for g in range(n):
+                for s in range(4):
+                    ref = games[g].encode(s)
+                    assert enc[g, s].tobytes() == ref.tobytes(), (step, g, s, np.argwhere(enc[g, s] != ref)[:5])
+                    if (act[g] >> s) & 1 and not dn[g]:
+                        assert enc_act[g, s].tobytes() == ref.tobytes()
+                    else:
+                        assert not enc_act[g, s].any()

@@ -1,0 +1,505 @@
+"""Drop-in, reference-named scalar API over the batched HIP path (n = 1 `VecRiichiEnv`).
+
+Mirrors the user-facing surface of smly/RiichiEnv for the step hot path so that the README loop and the
+reference's own tests read the same (names, argument meaning, error behaviour):
+
+    RiichiEnv        riichienv-python/src/env.rs:74-872
+    Action / ActionType / Phase     riichienv-core/src/action.rs:29-149, 350-545
+    Observation      riichienv-core/src/observation/python.rs:76-133, 457-806
+    GameRule         riichienv-core/src/rule.rs:10-57
+    Meld / MeldType  riichienv-core/src/types.rs:54-190
+    RandomAgent      src/riichienv/agents/random_agent.py:6-15
+
+Everything computes through the C-ABI library (HIP); there is no CPU fallback.
+"""
+from __future__ import annotations
+
+import enum
+import json
+import random
+
+import numpy as np
+
+from . import abi, vecenv
+
+
+class ActionType(enum.IntEnum):  # action.rs:55-68 (pyclass rename_all = SCREAMING_SNAKE_CASE)
+    DISCARD = 0
+    CHI = 1
+    PON = 2
+    DAIMINKAN = 3
+    RON = 4
+    RIICHI = 5
+    TSUMO = 6
+    PASS = 7
+    ANKAN = 8
+    KAKAN = 9
+    KYUSHU_KYUHAI = 10
+    KITA = 11
+
+
+class Phase(enum.IntEnum):  # action.rs:29-33
+    WaitAct = 0
+    WaitResponse = 1
+
+
+class MeldType(enum.IntEnum):  # types.rs:54-62
+    Chi = 0
+    Pon = 1
+    Daiminkan = 2
+    Ankan = 3
+    Kakan = 4
+
+
+_HONORS = ["E", "S", "W", "N", "P", "F", "C"]
+
+
+def tid_to_mjai(tid: int) -> str:  # parser.rs:301-334
+    if tid == 16:
+        return "5mr"
+    if tid == 52:
+        return "5pr"
+    if tid == 88:
+        return "5sr"
+    if tid < 108:
+        return f"{(tid % 36) // 4 + 1}{'mps'[tid // 36]}"
+    return _HONORS[(tid - 108) // 4]
+
+
+class Action:
+    """action.rs:76-105: consume_tiles are sorted on construction."""
+
+    __slots__ = ("action_type", "tile", "consume_tiles", "actor")
+
+    def __init__(self, type=ActionType.PASS, tile=None, consume_tiles=(), actor=None):
+        self.action_type = ActionType(int(type))
+        self.tile = None if tile is None else int(tile)
+        self.consume_tiles = sorted(int(t) for t in consume_tiles)
+        self.actor = actor
+
+    @staticmethod
+    def _from_packed(v: int, actor=None) -> "Action":
+        t, tile, cons = abi.unpack_action(int(v))
+        return Action(ActionType(t), tile, cons, actor)
+
+    def _pack(self) -> int:
+        return abi.pack_action(int(self.action_type), self.tile, self.consume_tiles)
+
+    def encode(self) -> int:  # action.rs:158-227
+        t = self.action_type
+        if t == ActionType.DISCARD:
+            if self.tile is None:
+                raise ValueError("Discard action requires a tile")
+            return self.tile // 4
+        if t == ActionType.RIICHI:
+            return 37
+        if t == ActionType.CHI:
+            if self.tile is None:
+                raise ValueError("Chi action requires a target tile")
+            target = self.tile // 4
+            ts = sorted({c // 4 for c in self.consume_tiles} | {target})
+            if len(ts) != 3:
+                raise ValueError(f"Invalid Chi tiles: target={self.tile}, consumed={self.consume_tiles}")
+            return 38 if target == ts[0] else (39 if target == ts[1] else 40)
+        if t == ActionType.PON:
+            return 41
+        if t == ActionType.DAIMINKAN:
+            if self.tile is None:
+                raise ValueError("Daiminkan action requires a tile")
+            return 42 + self.tile // 4
+        if t in (ActionType.ANKAN, ActionType.KAKAN):
+            if not self.consume_tiles:
+                raise ValueError("Ankan/Kakan action requires consumed tiles")
+            return 42 + self.consume_tiles[0] // 4
+        if t in (ActionType.RON, ActionType.TSUMO):
+            return 79
+        if t == ActionType.KYUSHU_KYUHAI:
+            return 80
+        if t == ActionType.PASS:
+            return 81
+        raise ValueError("Kita action is not valid in 4-player mode")
+
+    def to_mjai(self) -> str:  # action.rs:107-149 (serde_json BTreeMap -> alphabetical keys)
+        names = {ActionType.DISCARD: "dahai", ActionType.CHI: "chi", ActionType.PON: "pon", ActionType.DAIMINKAN: "daiminkan",
+                 ActionType.ANKAN: "ankan", ActionType.KAKAN: "kakan", ActionType.RIICHI: "reach", ActionType.TSUMO: "hora",
+                 ActionType.RON: "hora", ActionType.KYUSHU_KYUHAI: "ryukyoku", ActionType.KITA: "kita", ActionType.PASS: "none"}
+        d = {"type": names[self.action_type]}
+        if self.actor is not None:
+            d["actor"] = self.actor
+        if self.tile is not None and self.action_type not in (ActionType.TSUMO, ActionType.RON, ActionType.RIICHI):
+            d["pai"] = tid_to_mjai(self.tile)
+        if self.consume_tiles:
+            d["consumed"] = [tid_to_mjai(t) for t in self.consume_tiles]
+        return json.dumps(dict(sorted(d.items())), separators=(",", ":"))
+
+    def __eq__(self, o):
+        return (isinstance(o, Action) and self.action_type == o.action_type and self.tile == o.tile
+                and self.consume_tiles == o.consume_tiles and self.actor == o.actor)
+
+    def __repr__(self):
+        return (f"Action(action_type={self.action_type.name}, tile={self.tile}, consume_tiles={self.consume_tiles}, "
+                f"actor={self.actor})")
+
+
+class Meld:  # types.rs:98-190
+    def __init__(self, meld_type, tiles, opened, from_who=-1, called_tile=None):
+        self.meld_type = MeldType(int(meld_type))
+        self.tiles = list(tiles)
+        self.opened = bool(opened)
+        self.from_who = from_who
+        self.called_tile = called_tile
+
+    def __repr__(self):
+        return f"Meld({self.meld_type.name}, {self.tiles}, opened={self.opened}, from_who={self.from_who})"
+
+
+class GameRule:  # rule.rs:10-57
+    FIELDS = ["allows_ron_on_ankan_for_kokushi_musou", "is_kokushi_musou_13machi_double", "is_suuankou_tanki_double",
+              "is_junsei_chuurenpoutou_double", "is_daisuushii_double", "yakuman_pao_is_liability_only", "sanchaho_is_draw",
+              "kuikae_forbidden"]
+
+    def __init__(self, allows_ron_on_ankan_for_kokushi_musou=False, is_kokushi_musou_13machi_double=False,
+                 is_suuankou_tanki_double=False, is_junsei_chuurenpoutou_double=False, is_daisuushii_double=False,
+                 yakuman_pao_is_liability_only=False, sanchaho_is_draw=False, kuikae_forbidden=True):
+        for k, v in zip(self.FIELDS, (allows_ron_on_ankan_for_kokushi_musou, is_kokushi_musou_13machi_double,
+                                      is_suuankou_tanki_double, is_junsei_chuurenpoutou_double, is_daisuushii_double,
+                                      yakuman_pao_is_liability_only, sanchaho_is_draw, kuikae_forbidden)):
+            setattr(self, k, bool(v))
+
+    @staticmethod
+    def default_tenhou():
+        return GameRule(sanchaho_is_draw=True, kuikae_forbidden=True)
+
+    @staticmethod
+    def default_mjsoul():
+        return GameRule(True, True, True, True, True, True, False, True)
+
+    def bits(self) -> int:
+        return sum((1 << i) for i, k in enumerate(self.FIELDS) if getattr(self, k))
+
+
+class Observation:
+    """Per-seat snapshot (observation/mod.rs:24-56; state/mod.rs:189-263)."""
+
+    def __init__(self, player_id, view, legal, mask, waits, new_events, events, encoder):
+        pid = player_id
+        self.player_id = pid
+        self.hands = [list(p.hand[: p.hand_len]) if i == pid else [] for i, p in enumerate(view.players)]
+        self.hand = self.hands[pid]
+        self.melds = [[Meld(m.meld_type, list(m.tiles[: m.n_tiles]), bool(m.opened), m.from_who,
+                            None if m.called_tile < 0 else m.called_tile) for m in p.melds[: p.n_melds]] for p in view.players]
+        self.discards = [list(p.discards[: p.n_discards]) for p in view.players]
+        self.dora_indicators = list(view.dora[: view.n_dora])
+        self.scores = [p.score for p in view.players]
+        self.riichi_declared = [bool(p.riichi_declared) for p in view.players]
+        self.honba = view.honba
+        self.riichi_sticks = view.riichi_sticks
+        self.round_wind = view.round_wind
+        self.oya = view.oya
+        self.kyoku_index = view.kyoku_idx
+        self.waits = [t for t in range(34) if (waits >> t) & 1]
+        self.is_tenpai = bool(self.waits)
+        self.riichi_sutehais = [None if p.riichi_sutehai < 0 else p.riichi_sutehai for p in view.players]
+        self.last_tedashis = [None if p.last_tedashi < 0 else p.last_tedashi for p in view.players]
+        self.last_discard = None if view.last_discard_pid < 0 else view.last_discard_tile
+        self.drawn_tile = None if view.drawn_tile < 0 else view.drawn_tile
+        self._legal_actions = legal
+        self._mask = mask
+        self._new_events = new_events
+        self.events = events
+        self._encoder = encoder
+
+    def legal_actions(self):  # observation/python.rs:93-96
+        return list(self._legal_actions)
+
+    def mask(self) -> bytes:  # observation/python.rs:98-111
+        return bytes(self._mask)
+
+    def new_events(self):
+        return list(self._new_events)
+
+    def find_action(self, action_id):  # observation/mod.rs:117-129
+        for a in self._legal_actions:
+            try:
+                if a.encode() == action_id:
+                    return a
+            except ValueError:
+                pass
+        return None
+
+    def encode(self) -> bytes:  # observation/python.rs:457-806 -> 74*34 f32, channel-major
+        return self._encoder(self.player_id).tobytes()
+
+
+class RiichiEnv:
+    """Scalar environment with the reference's method names, backed by one game on the GPU."""
+
+    def __init__(self, game_mode=None, skip_mjai_logging=False, seed=None, round_wind=None, rule=None, device=0):
+        self._mode = vecenv._mode_id(game_mode)
+        self._rule = rule or GameRule.default_tenhou()
+        s = random.getrandbits(63) if seed is None else int(seed)
+        self._v = vecenv.VecRiichiEnv(1, game_mode=self._mode, seeds=np.array([s], np.uint64), rule_bits=self._rule.bits(),
+                                      skip_mjai_logging=skip_mjai_logging, round_wind=round_wind or 0, device=device,
+                                      event_ring=8192)
+        self._cursor = [0, 0, 0, 0]  # player_event_counts (state/mod.rs:211-218)
+
+    # ---- core loop -----------------------------------------------------------------------------------
+    def reset(self, oya=None, wall=None, round_wind=None, scores=None, honba=None, kyotaku=None, seed=None):
+        if scores is not None and len(scores) != 4:
+            raise ValueError(f"scores length {len(scores)} does not match number of players 4")  # env.rs:815-823
+        self._v.reset(walls=None if wall is None else np.array(wall, np.uint8)[None], oya=None if oya is None else [oya],
+                      round_wind=None if round_wind is None else [round_wind],
+                      scores=None if scores is None else np.array(scores, np.int32)[None],
+                      honba=None if honba is None else [honba], kyotaku=None if kyotaku is None else [kyotaku])
+        self._cursor = [0, 0, 0, 0]
+        return self.get_observations(self.active_players)
+
+    def step(self, actions):
+        a = np.full((1, 4), abi.NO_ACTION, np.uint64)
+        for pid, act in dict(actions).items():
+            a[0, int(pid)] = act._pack()
+        self._v.step(a)
+        if self._v.peek(0).last_error_pid >= 0:  # env.rs:865-869 (quirk Q9)
+            return {}
+        return self.get_observations(self.active_players)
+
+    def get_observations(self, players=None):
+        pids = list(range(4)) if players is None else list(players)
+        view = self._v.peek(0)
+        legal, cnt = self._v.legal()
+        mask = self._v.mask()
+        waits = self._v.waits()
+        act = view.active_mask
+        enc = {}
+
+        def encoder(pid):
+            if "a" not in enc:
+                enc["a"] = self._v.encode()
+            return enc["a"][0, pid]
+
+        out = {}
+        for pid in pids:
+            active = bool((act >> pid) & 1) and not view.is_done and (
+                (view.phase == Phase.WaitAct and view.current_player == pid) or view.phase == Phase.WaitResponse)
+            la = [Action._from_packed(x, pid) for x in legal[0, pid, : cnt[0, pid]]] if active else []
+            w = int(waits[0, pid]) if active else self._waits_of(view, pid)
+            log = self._v.mjai_log(0, pid)
+            new = log[self._cursor[pid]:]
+            self._cursor[pid] = len(log)
+            out[pid] = Observation(pid, view, la, mask[0, pid] if active else np.zeros(82, np.uint8), w, new, log, encoder)
+        return out
+
+    def get_observation(self, player_id):
+        return self.get_observations([player_id])[player_id]
+
+    def _waits_of(self, view, pid):
+        p = view.players[pid]
+        if p.hand_len + 3 * p.n_melds != 13:
+            return 0
+        hc = abi.HandCase()
+        hc.n_tiles = p.hand_len
+        for i in range(p.hand_len):
+            hc.tiles[i] = p.hand[i]
+        hc.n_melds = p.n_melds
+        for i in range(p.n_melds):
+            hc.melds[i] = p.melds[i]
+        return vecenv.eval_hands([hc])[0].waits
+
+    def _get_legal_actions(self, pid):
+        legal, cnt = self._v.legal()
+        return [Action._from_packed(x, pid) for x in legal[0, pid, : cnt[0, pid]]]
+
+    def done(self):
+        return bool(self._v.done()[0])
+
+    def scores(self):
+        return [int(x) for x in self._v.scores()[0]]
+
+    def ranks(self):  # env.rs:673-689
+        return [int(x) for x in self._v.ranks()[0]]
+
+    def points(self, rule_name="basic"):  # env.rs:691-727
+        presets = {"basic": (1.0, 25000.0, [50.0, 10.0, -10.0, -50.0]), "ouza-tyoujyo": (0.0, 25000.0, [100.0, 40.0, -40.0, -100.0]),
+                   "ouza-normal": (0.0, 25000.0, [50.0, 20.0, -20.0, -50.0])}
+        if rule_name not in presets:
+            raise ValueError(f"Unknown preset rule: {rule_name}")
+        w, base, uma = presets[rule_name]
+        return [(s - base) / 1000.0 * w + uma[r - 1] for s, r in zip(self.scores(), self.ranks())]
+
+    @property
+    def mjai_log(self):  # env.rs:729-739
+        return [json.loads(s) for s in self._v.mjai_log(0)]
+
+    # ---- state getters (env.rs:134-622) ----------------------------------------------------------------
+    def _view(self):
+        return self._v.peek(0)
+
+    def _poke(self, fn):
+        v = self._v.peek(0)
+        fn(v)
+        self._v.poke(0, v)
+
+    @property
+    def phase(self):
+        return Phase(self._view().phase)
+
+    @phase.setter
+    def phase(self, ph):
+        self._poke(lambda v: setattr(v, "phase", int(ph)))
+
+    @property
+    def current_player(self):
+        return self._view().current_player
+
+    @current_player.setter
+    def current_player(self, p):
+        self._poke(lambda v: setattr(v, "current_player", int(p)))
+
+    @property
+    def active_players(self):
+        m = self._view().active_mask
+        return [p for p in range(4) if (m >> p) & 1]
+
+    @active_players.setter
+    def active_players(self, ps):
+        self._poke(lambda v: setattr(v, "active_mask", sum(1 << int(p) for p in ps)))
+
+    @property
+    def hands(self):
+        v = self._view()
+        return [list(p.hand[: p.hand_len]) for p in v.players]
+
+    @hands.setter
+    def hands(self, hs):
+        def f(v):
+            for p, h in enumerate(hs):
+                v.players[p].hand_len = len(h)
+                for i, t in enumerate(h):
+                    v.players[p].hand[i] = t
+        self._poke(f)
+
+    @property
+    def melds(self):
+        v = self._view()
+        return [[Meld(m.meld_type, list(m.tiles[: m.n_tiles]), bool(m.opened), m.from_who,
+                      None if m.called_tile < 0 else m.called_tile) for m in p.melds[: p.n_melds]] for p in v.players]
+
+    @melds.setter
+    def melds(self, ms):
+        def f(v):
+            for p, lst in enumerate(ms):
+                v.players[p].n_melds = len(lst)
+                for i, m in enumerate(lst):
+                    mv = v.players[p].melds[i]
+                    mv.meld_type = int(m.meld_type)
+                    mv.n_tiles = len(m.tiles)
+                    for k, t in enumerate(sorted(m.tiles)):
+                        mv.tiles[k] = t
+                    mv.opened = int(m.opened)
+                    mv.from_who = m.from_who
+                    mv.called_tile = -1 if m.called_tile is None else m.called_tile
+        self._poke(f)
+
+    @property
+    def discards(self):
+        v = self._view()
+        return [list(p.discards[: p.n_discards]) for p in v.players]
+
+    @discards.setter
+    def discards(self, ds):
+        def f(v):
+            for p, d in enumerate(ds):
+                v.players[p].n_discards = len(d)
+                for i, t in enumerate(d):
+                    v.players[p].discards[i] = t
+        self._poke(f)
+
+    @property
+    def drawn_tile(self):
+        d = self._view().drawn_tile
+        return None if d < 0 else d
+
+    @drawn_tile.setter
+    def drawn_tile(self, t):
+        self._poke(lambda v: setattr(v, "drawn_tile", -1 if t is None else int(t)))
+
+    @property
+    def needs_tsumo(self):
+        return bool(self._view().needs_tsumo)
+
+    @needs_tsumo.setter
+    def needs_tsumo(self, b):
+        self._poke(lambda v: setattr(v, "needs_tsumo", int(bool(b))))
+
+    @property
+    def is_first_turn(self):
+        return bool(self._view().is_first_turn)
+
+    @is_first_turn.setter
+    def is_first_turn(self, b):
+        self._poke(lambda v: setattr(v, "is_first_turn", int(bool(b))))
+
+    @property
+    def riichi_declared(self):
+        return [bool(p.riichi_declared) for p in self._view().players]
+
+    @riichi_declared.setter
+    def riichi_declared(self, bs):
+        def f(v):
+            for p, b in enumerate(bs):
+                v.players[p].riichi_declared = int(bool(b))
+        self._poke(f)
+
+    @property
+    def dora_indicators(self):
+        v = self._view()
+        return list(v.dora[: v.n_dora])
+
+    @property
+    def wall(self):
+        v = self._view()
+        return list(v.wall[: v.wall_len])
+
+    @property
+    def pao(self):
+        out = []
+        for p in self._view().players:
+            d = {}
+            if p.pao_daisangen >= 0:
+                d[37] = p.pao_daisangen
+            if p.pao_daisuushi >= 0:
+                d[50] = p.pao_daisuushi
+            out.append(d)
+        return out
+
+    oya = property(lambda self: self._view().oya)
+    honba = property(lambda self: self._view().honba)
+    kyoku_idx = property(lambda self: self._view().kyoku_idx)
+    round_wind = property(lambda self: self._view().round_wind)
+    riichi_sticks = property(lambda self: self._view().riichi_sticks)
+    turn_count = property(lambda self: self._view().turn_count)
+    drawable_count = property(lambda self: self._view().drawable_count)
+    rinshan_draw_count = property(lambda self: self._view().rinshan_draw_count)
+
+    def set_scores(self, scores):  # env.rs:636-671
+        def f(v):
+            for p, s in enumerate(scores):
+                v.players[p].score = int(s)
+        self._poke(f)
+
+    def set_state(self, oya=None, round_wind=None):
+        def f(v):
+            if oya is not None:
+                v.oya = oya
+                v.kyoku_idx = oya
+            if round_wind is not None:
+                v.round_wind = round_wind
+        self._poke(f)
+
+
+class RandomAgent:  # src/riichienv/agents/random_agent.py:6-15
+    def __init__(self, seed=None):
+        self._rng = random.Random(seed)
+
+    def act(self, obs: Observation) -> Action:
+        return self._rng.choice(obs.legal_actions())

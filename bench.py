@@ -17,6 +17,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 B_STEP_4P = 1688          # algorithmic bytes per env.step per 4P game
+B_STEP_3P = 1280          # 3P: 2*512 + 12 + 180 + 64
 HBM_PEAK = 8.0e12         # B/s, /opt/skills/guides/MI355X_MICROARCH.md (HBM3E peak, spec)
 
 
@@ -42,7 +43,7 @@ def main():
     ap.add_argument("--steps", type=int, default=2000)
     ap.add_argument("--warmup", type=int, default=200)
     ap.add_argument("--games", type=int, default=65536, help="games per GPU")
-    ap.add_argument("--mode", type=int, default=2, help="0/1/2 = 4p-red-single/east/half")
+    ap.add_argument("--mode", type=int, default=2, help="0/1/2 = 4p-red-single/east/half, 3/4/5 = 3p-red-single/east/half")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -92,18 +93,19 @@ def main():
 
     if rank == 0:
         kernel_s = r.step_kernel_ms * 1e-3
-        achieved = B_STEP_4P * args.games / kernel_s
+        b_step = B_STEP_3P if args.mode >= 3 else B_STEP_4P
+        achieved = b_step * args.games / kernel_s
         out = {
             "metric": "env.step()/s (whole node) at 65 536 parallel 4p games; bit-exact MJAI parity",
             "value": steps_total / wall, "unit": "env.step/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": wall * 1e3 / args.steps, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
-            "config": {"workload": f"{args.games} parallel {['4p-red-single','4p-red-east','4p-red-half'][args.mode]} "
+            "config": {"workload": f"{args.games} parallel {['4p-red-single','4p-red-east','4p-red-half','3p-red-single','3p-red-east','3p-red-half'][args.mode]} "
                                    "games per GPU, device RandomAgent, auto-reset, MJAI logging on",
                        "games_per_gpu": args.games, "sharding": "by game index, no collectives"},
             "roofline": {"bound": "hbm", "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK, "traffic": None, "kernel": "k_step",
-                         "kernel_ms": r.step_kernel_ms, "bytes_per_launch": B_STEP_4P * args.games},
+                         "kernel_ms": r.step_kernel_ms, "bytes_per_launch": b_step * args.games},
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.mode, abi.RULE_TENHOU, policy_seed)

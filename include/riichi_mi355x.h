@@ -123,6 +123,7 @@ typedef struct RmjPlayerView {
     int8_t pao_daisangen, pao_daisuushi; /* liable seat for yaku 37 / 50, -1 = none */
     uint8_t n_forbidden, forbidden[2];
     int16_t riichi_sutehai, last_tedashi; /* -1 = None */
+    uint8_t n_kita, kita[4];              /* 3P: kita_tiles (state_3p/player.rs:38) */
 } RmjPlayerView;
 
 typedef struct RmjStateView {

@@ -171,9 +171,9 @@ void orc_game_free(void* g) { delete (GameState*)g; }
 void orc_game_reset(void* gp, const uint8_t* wall, int oya, int round_wind, const int32_t* scores, int honba, int kyotaku) {
     GameState* g = (GameState*)gp;
     std::vector<uint8_t> w;
-    if (wall) w.assign(wall, wall + 136);
+    if (wall) w.assign(wall, wall + (g->sanma ? 108 : 136));
     std::vector<int32_t> sc;
-    if (scores) sc.assign(scores, scores + 4);
+    if (scores) sc.assign(scores, scores + g->NP);
     g->env_reset(oya, wall ? &w : nullptr, round_wind, scores ? &sc : nullptr, honba, kyotaku);
 }
 
@@ -200,8 +200,8 @@ int orc_game_mask(void* gp, int pid, uint8_t* mask82) {
     GameState* g = (GameState*)gp;
     std::memset(mask82, 0, 82);
     for (auto& a : g->_get_legal_actions_internal((uint8_t)pid)) {
-        int id = a.encode();
-        if (id >= 0 && id < 82) mask82[id] = 1;
+        int id = g->sanma ? a.encode_3p() : a.encode();  // observation_3p/python.rs:100-112: 60 ids in 3P
+        if (id >= 0 && id < (g->sanma ? 60 : 82)) mask82[id] = 1;
     }
     return 0;
 }
@@ -269,6 +269,8 @@ void orc_game_peek(void* gp, RmjStateView* v) {
         for (size_t i = 0; i < P.forbidden_discards.size() && i < 2; i++) q.forbidden[i] = P.forbidden_discards[i];
         q.riichi_sutehai = (int16_t)g->riichi_sutehais[p];
         q.last_tedashi = (int16_t)g->last_tedashis[p];
+        q.n_kita = (uint8_t)P.kita_tiles.size();
+        for (size_t i = 0; i < P.kita_tiles.size() && i < 4; i++) q.kita[i] = P.kita_tiles[i];
     }
     v->current_player = g->current_player;
     v->is_done = g->is_done;
@@ -331,6 +333,7 @@ void orc_game_poke(void* gp, const RmjStateView* v) {
         P.forbidden_discards.assign(q.forbidden, q.forbidden + q.n_forbidden);
         g->riichi_sutehais[p] = q.riichi_sutehai;
         g->last_tedashis[p] = q.last_tedashi;
+        P.kita_tiles.assign(q.kita, q.kita + q.n_kita);
     }
     g->current_player = v->current_player;
     g->is_done = v->is_done;

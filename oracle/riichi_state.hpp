@@ -71,6 +71,26 @@ struct Action {
             default: return -1;
         }
     }
+    // action.rs:262-346 (3P compact action space, 60 ids); -1 on error
+    int encode_3p() const {
+        static const int compact[34] = {0, -1, -1, -1, -1, -1, -1, -1, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17, 18,
+                                        19, 20, 21, 22, 23, 24, 25, 26};
+        switch (type) {
+            case AT_DISCARD: return tile >= 0 ? compact[tile / 4] : -1;
+            case AT_RIICHI: return 27;
+            case AT_CHI: return -1;
+            case AT_PON: return 28;
+            case AT_DAIMINKAN: return (tile >= 0 && compact[tile / 4] >= 0) ? 29 + compact[tile / 4] : -1;
+            case AT_ANKAN:
+            case AT_KAKAN: return (!consume.empty() && compact[consume[0] / 4] >= 0) ? 29 + compact[consume[0] / 4] : -1;
+            case AT_RON:
+            case AT_TSUMO: return 56;
+            case AT_KYUSHU: return 57;
+            case AT_PASS: return 58;
+            case AT_KITA: return 59;
+            default: return -1;
+        }
+    }
 };
 
 // rule.rs:10-57
@@ -141,18 +161,31 @@ struct WallState {
     uint8_t rinshan_draw_count = 0, pending_kan_dora_count = 0, drawable_count = 0;
     std::optional<uint64_t> seed;
     uint64_t hand_index = 0;
+    bool sanma = false;  // state_3p/wall.rs: 108 tiles, dora/ura pre-extracted
+    uint8_t dora_tiles[5] = {0, 0, 0, 0, 0}, ura_tiles[5] = {0, 0, 0, 0, 0};
 
     void finish_load() {
         dora_indicators.clear();
-        if (tiles.size() > 5) dora_indicators.push_back(tiles[4]);
+        if (sanma) {
+            // state_3p/wall.rs:104-109 (shuffle) and :137-147 (load_wall: t[99-2i] / t[98-2i] before reversal,
+            // i.e. tiles[8+2i] / tiles[9+2i] after it; extracted only for a 108-tile wall)
+            if (tiles.size() == 108)
+                for (int i = 0; i < 5; i++) {
+                    dora_tiles[i] = tiles[8 + 2 * i];
+                    ura_tiles[i] = tiles[9 + 2 * i];
+                }
+            dora_indicators.push_back(dora_tiles[0]);
+        } else if (tiles.size() > 5)
+            dora_indicators.push_back(tiles[4]);
         rinshan_draw_count = 0;
         pending_kan_dora_count = 0;
         drawable_count = 0;
     }
     // state/wall.rs:36-67 (RNG replaced, digest/salt skipped — see header)
     void shuffle() {
-        std::vector<uint8_t> ids(136);
-        for (int i = 0; i < 136; i++) ids[i] = (uint8_t)i;
+        std::vector<uint8_t> ids;
+        for (int i = 0; i < 136; i++)
+            if (!(sanma && i / 4 >= 1 && i / 4 <= 7)) ids.push_back((uint8_t)i);  // types.rs:378-382
         uint64_t s = seed ? *seed : 0;
         std::vector<uint8_t> w = build_wall(s, hand_index, ids);
         hand_index += 1;
@@ -180,6 +213,7 @@ struct PlayerState {
     bool missed_agari_riichi = false, missed_agari_doujun = false, nagashi_eligible = true, ippatsu_cycle = false;
     std::map<uint8_t, uint8_t> pao;  // yaku id -> liable seat
     std::vector<uint8_t> forbidden_discards;
+    std::vector<uint8_t> kita_tiles;  // state_3p/player.rs:38
     // state/player.rs:66-86
     void reset_round() {
         hand.clear();
@@ -193,6 +227,7 @@ struct PlayerState {
         nagashi_eligible = true;
         ippatsu_cycle = false;
         forbidden_discards.clear();
+        kita_tiles.clear();
         score_delta = 0;
         pao.clear();
     }
@@ -226,7 +261,9 @@ inline std::string json_int_array(It b, It e) {
 }
 
 struct GameState {
-    static constexpr int NP = 4;
+    int NP = 4;          // 4 (state/) or 3 (state_3p/)
+    bool sanma = false;  // game_mode >= 3 (game_variant.rs:12-37)
+    int32_t start_score() const { return sanma ? 35000 : 25000; }  // state_3p/game_mode.rs:31-33
     WallState wall;
     PlayerState players[4];
     uint8_t current_player = 0;
@@ -257,9 +294,12 @@ struct GameState {
     // state/mod.rs:98-167
     GameState(uint8_t game_mode_, bool skip_log, std::optional<uint64_t> seed, uint8_t round_wind_, GameRule rule_)
         : game_mode(game_mode_), skip_mjai_logging(skip_log), rule(rule_) {
+        sanma = game_mode_ >= 3;
+        NP = sanma ? 3 : 4;
+        wall.sanma = sanma;
         wall.seed = seed;
         round_wind = round_wind_;
-        for (auto& p : players) p.score = 25000;
+        for (auto& p : players) p.score = start_score();
         if (!skip_mjai_logging) push_event("{\"type\":\"start_game\"}", "start_game", -1, nullptr);
         _initialize_round(0, round_wind, 0, 0, nullptr, nullptr);
     }
@@ -278,7 +318,7 @@ struct GameState {
     void env_reset(int oya_, const std::vector<uint8_t>* wall_, int round_wind_, const std::vector<int32_t>* scores,
                    int honba_, int kyotaku_) {
         reset();
-        std::vector<int32_t> def(4, 25000);
+        std::vector<int32_t> def(NP, start_score());
         _initialize_round((uint8_t)(oya_ < 0 ? 0 : oya_), (uint8_t)(round_wind_ < 0 ? 0 : round_wind_),
                           (uint8_t)(honba_ < 0 ? 0 : honba_), (uint32_t)(kyotaku_ < 0 ? 0 : kyotaku_), wall_,
                           scores ? scores : &def);
@@ -326,7 +366,7 @@ struct GameState {
 
     // state/mod.rs:189-263 : waits for the observation (13-tile hands only)
     std::vector<uint8_t> observation_waits(int pid) const {
-        HandEvaluator he(players[pid].hand, players[pid].melds);
+        HandEvaluator he(players[pid].hand, players[pid].melds, sanma);
         return he.get_waits_u8();
     }
 
@@ -345,8 +385,10 @@ struct GameState {
                 c.riichi = P.riichi_declared;
                 c.double_riichi = P.double_riichi_declared;
                 c.ippatsu = P.ippatsu_cycle;
-                c.player_wind = (uint8_t)((pid + 4 - oya) % 4);
+                c.player_wind = (uint8_t)((pid + NP - oya) % NP);
                 c.round_wind = round_wind % 4;
+                c.is_sanma = sanma;
+                c.num_players = (uint8_t)NP;
                 c.haitei = wall.drawable_count == 0 && !is_rinshan_flag;
                 c.rinshan = is_rinshan_flag;
                 c.tsumo_first_turn = is_first_turn && P.discards.empty();
@@ -358,7 +400,7 @@ struct GameState {
                         hand.erase(hand.begin() + i);
                         break;
                     }
-                HandEvaluator he(hand, P.melds);
+                HandEvaluator he(hand, P.melds, sanma);
                 WinResult r = he.calc(tile, wall.dora_indicators, {}, c);
                 if (r.is_win && (r.yakuman || r.han >= 1)) legals.push_back(Action(AT_TSUMO, tile, {}, pid));
             }
@@ -374,7 +416,7 @@ struct GameState {
                     std::vector<uint8_t> th = P.hand;
                     int idx = vec_position(th, t);
                     if (idx >= 0) th.erase(th.begin() + idx);
-                    HandEvaluator he(th, P.melds);
+                    HandEvaluator he(th, P.melds, sanma);
                     if (he.is_tenpai()) legals.push_back(Action(AT_DISCARD, t, {}, pid));
                 }
             } else {
@@ -387,12 +429,13 @@ struct GameState {
                 bool all_closed = true;
                 for (auto& m : P.melds)
                     if (m.opened) all_closed = false;
-                if (P.score >= 1000 && wall.drawable_count >= 4 && all_closed) {
+                // quirk Q8: 4P needs drawable_count >= 4, 3P only > 0 (state_3p/legal_actions.rs:116)
+                if (P.score >= 1000 && (sanma ? wall.drawable_count > 0 : wall.drawable_count >= 4) && all_closed) {
                     bool can = false;
                     for (size_t skip = 0; skip < P.hand.size(); skip++) {
                         std::vector<uint8_t> th = P.hand;
                         th.erase(th.begin() + skip);
-                        HandEvaluator he(th, P.melds);
+                        HandEvaluator he(th, P.melds, sanma);
                         if (he.is_tenpai()) {
                             can = true;
                             break;
@@ -424,7 +467,7 @@ struct GameState {
                         std::vector<uint8_t> pre = P.hand;
                         int pos = vec_position(pre, t);
                         if (pos >= 0) pre.erase(pre.begin() + pos);
-                        HandEvaluator cpre(pre, P.melds);
+                        HandEvaluator cpre(pre, P.melds, sanma);
                         std::vector<uint8_t> wpre = cpre.get_waits_u8();
                         std::sort(wpre.begin(), wpre.end());
                         std::vector<uint8_t> post;
@@ -438,7 +481,7 @@ struct GameState {
                         am.opened = false;
                         am.from_who = -1;
                         mpost.push_back(am);
-                        HandEvaluator cpost(post, mpost);
+                        HandEvaluator cpost(post, mpost, sanma);
                         std::vector<uint8_t> wpost = cpost.get_waits_u8();
                         std::sort(wpost.begin(), wpost.end());
                         if (wpre == wpost && !wpre.empty())
@@ -460,6 +503,10 @@ struct GameState {
                     }
                 if (distinct >= 9) legals.push_back(Action(AT_KYUSHU, -1, {}, pid));
             }
+            // 5. Kita (state_3p/legal_actions.rs:241-243, sanma.rs:146-169)
+            if (sanma && drawn_tile >= 0 && wall.drawable_count > 0)
+                for (uint8_t t : P.hand)
+                    if (t / 4 == 30) legals.push_back(Action(AT_KITA, t, {}, pid));
         } else {
             auto it = current_claims.find(pid);
             if (it != current_claims.end())
@@ -481,14 +528,16 @@ struct GameState {
             if (d / 4 == tile_class) in_discards = true;
         bool in_missed = P.missed_agari_doujun || (P.riichi_declared && P.missed_agari_riichi);
         if (!in_discards && !in_missed) {
-            HandEvaluator he(hand, P.melds);
+            HandEvaluator he(hand, P.melds, sanma);
             Conditions c;
             c.tsumo = false;
             c.riichi = P.riichi_declared;
             c.double_riichi = P.double_riichi_declared;
             c.ippatsu = P.ippatsu_cycle;
-            c.player_wind = (uint8_t)((i + 4 - oya) % 4);
+            c.player_wind = (uint8_t)((i + NP - oya) % NP);
             c.round_wind = round_wind % 4;
+            c.is_sanma = sanma;
+            c.num_players = (uint8_t)NP;
             c.houtei = wall.drawable_count == 0 && !is_rinshan_flag;
             c.riichi_sticks = riichi_sticks;
             c.honba = honba;
@@ -550,7 +599,7 @@ struct GameState {
             }
         }
         // 3. Chi
-        bool is_shimocha = i == (pid + 1) % 4;
+        bool is_shimocha = !sanma && i == (pid + 1) % 4;  // no Chi in 3P (state_3p/legal_actions.rs:386)
         if (!P.riichi_declared && wall.drawable_count > 0 && is_shimocha && hand.size() >= 3) {
             int t_val = tile / 4;
             if (t_val < 27) {
@@ -668,7 +717,8 @@ struct GameState {
                 }
                 case AT_KYUSHU: _trigger_ryukyoku("kyushu_kyuhai"); break;
                 case AT_RIICHI: {
-                    if (P.score >= 1000 && wall.drawable_count >= 4 && !P.riichi_declared && !P.riichi_stage) {
+                    if (P.score >= 1000 && (sanma ? wall.drawable_count > 0 : wall.drawable_count >= 4) && !P.riichi_declared &&
+                        !P.riichi_stage) {
                         P.riichi_stage = true;
                         ev_simple_actor("reach", pid);
                         if (act.tile >= 0) {
@@ -703,7 +753,9 @@ struct GameState {
                             c.chankan = true;
                             c.player_wind = (uint8_t)((i + NP - oya) % NP);
                             c.round_wind = round_wind % 4;
-                            HandEvaluator he(Q.hand, Q.melds);
+                            c.is_sanma = sanma;
+                            c.num_players = (uint8_t)NP;
+                            HandEvaluator he(Q.hand, Q.melds, sanma);
                             WinResult r = he.calc(tile, wall.dora_indicators, {}, c);
                             bool kok = false;
                             for (uint32_t y : r.yaku)
@@ -757,7 +809,9 @@ struct GameState {
                         c.chankan = true;
                         c.riichi_sticks = riichi_sticks;
                         c.honba = honba;
-                        HandEvaluator he(Q.hand, Q.melds);
+                        c.is_sanma = sanma;
+                        c.num_players = (uint8_t)NP;
+                        HandEvaluator he(Q.hand, Q.melds, sanma);
                         bool furiten = false;
                         for (uint8_t w : he.get_waits_u8()) {
                             for (uint8_t d : Q.discards)
@@ -798,7 +852,10 @@ struct GameState {
                     c.round_wind = round_wind % 4;
                     c.riichi_sticks = riichi_sticks;
                     c.honba = honba;
-                    HandEvaluator he(P.hand, P.melds);
+                    c.is_sanma = sanma;
+                    c.num_players = (uint8_t)NP;
+                    if (sanma) c.kita_count = (uint8_t)P.kita_tiles.size();  // state_3p/mod.rs:635
+                    HandEvaluator he(P.hand, P.melds, sanma);
                     uint8_t win_tile = drawn_tile >= 0 ? (uint8_t)drawn_tile : 0;
                     std::vector<uint8_t> ura;
                     if (P.riichi_declared) ura = _get_ura_indicators();
@@ -821,7 +878,8 @@ struct GameState {
                             }
                         }
                         if (pao_val > 0) {
-                            int32_t unit = pid == oya ? 48000 : 32000;
+                            // state_3p/mod.rs:713-721: (np-1)*16000 for the dealer, 16000+(np-2)*8000 otherwise
+                            int32_t unit = pid == oya ? (NP - 1) * 16000 : 16000 + (NP - 2) * 8000;
                             int32_t honba_total = (int32_t)honba * (NP - 1) * 100;
                             if (pao_payer >= 0) {
                                 if (rule.yakuman_pao_is_liability_only) {
@@ -887,7 +945,7 @@ struct GameState {
                             std::vector<std::string> um;
                             if (P.riichi_declared)
                                 for (uint8_t t : _get_ura_indicators()) um.push_back(tid_to_mjai(t));
-                            push_event("{\"actor\":" + std::to_string(pid) + ",\"deltas\":" + json_int_array(deltas, deltas + 4) +
+                            push_event("{\"actor\":" + std::to_string(pid) + ",\"deltas\":" + json_int_array(deltas, deltas + NP) +
                                            ",\"target\":" + std::to_string(pid) + ",\"tsumo\":true,\"type\":\"hora\",\"ura_markers\":" +
                                            json_str_array(um) + "}",
                                        "hora", pid, nullptr);
@@ -899,6 +957,9 @@ struct GameState {
                     }
                     break;
                 }
+                case AT_KITA:
+                    if (sanma) handle_kita(pid, act);  // state_3p/mod.rs:833
+                    break;
                 default: break;
             }
         } else {
@@ -924,7 +985,7 @@ struct GameState {
                 const Action& act = it->second;
                 if (act.type == AT_RON) {
                     ron_claims.push_back(pid);
-                } else if (act.type == AT_PON || act.type == AT_DAIMINKAN || act.type == AT_CHI) {
+                } else if (act.type == AT_PON || act.type == AT_DAIMINKAN || (!sanma && act.type == AT_CHI)) {
                     if (call_claim) {
                         bool old_pon = call_claim->second.type == AT_PON || call_claim->second.type == AT_DAIMINKAN;
                         bool new_pon = act.type == AT_PON || act.type == AT_DAIMINKAN;
@@ -935,7 +996,7 @@ struct GameState {
                 }
             }
             if (!ron_claims.empty()) {
-                if (ron_claims.size() >= (size_t)(NP - 1) && rule.sanchaho_is_draw) {
+                if (!sanma && ron_claims.size() >= (size_t)(NP - 1) && rule.sanchaho_is_draw) {
                     _trigger_ryukyoku("sanchaho");
                     return;
                 }
@@ -948,7 +1009,8 @@ struct GameState {
                 bool oya_won = false, deposit_taken = false, honba_taken = false;
                 for (uint8_t w : ron_claims) {
                     PlayerState& W = players[w];
-                    bool is_chankan = pending_kan.has_value();
+                    // 3P: a pending kita is a chankan-style claim but awards no chankan yaku (state_3p/mod.rs:896-902)
+                    bool is_chankan = pending_kan.has_value() && pending_kan->second.type != AT_KITA;
                     uint32_t ron_honba = 0;
                     if (!honba_taken) {
                         honba_taken = true;
@@ -965,7 +1027,10 @@ struct GameState {
                     c.round_wind = round_wind % 4;
                     c.riichi_sticks = riichi_sticks;
                     c.honba = ron_honba;
-                    HandEvaluator he(W.hand, W.melds);
+                    c.is_sanma = sanma;
+                    c.num_players = (uint8_t)NP;
+                    if (sanma) c.kita_count = (uint8_t)W.kita_tiles.size();
+                    HandEvaluator he(W.hand, W.melds, sanma);
                     std::vector<uint8_t> ura;
                     if (W.riichi_declared) ura = _get_ura_indicators();
                     WinResult res = he.calc(win_tile, wall.dora_indicators, ura, c);
@@ -1024,7 +1089,7 @@ struct GameState {
                             std::vector<std::string> um;
                             if (W.riichi_declared)
                                 for (uint8_t t : _get_ura_indicators()) um.push_back(tid_to_mjai(t));
-                            push_event("{\"actor\":" + std::to_string(w) + ",\"deltas\":" + json_int_array(this_d, this_d + 4) +
+                            push_event("{\"actor\":" + std::to_string(w) + ",\"deltas\":" + json_int_array(this_d, this_d + NP) +
                                            ",\"target\":" + std::to_string(target_pid) + ",\"type\":\"hora\",\"ura_markers\":" +
                                            json_str_array(um) + "}",
                                        "hora", w, nullptr);
@@ -1101,7 +1166,12 @@ struct GameState {
                 if (pending_kan) {
                     auto pk = *pending_kan;
                     pending_kan.reset();
-                    _resolve_kan(pk.first, pk.second);
+                    if (pk.second.type == AT_KITA) {  // state_3p/mod.rs:1201-1209
+                        for (auto& p : players) p.ippatsu_cycle = false;
+                        resolve_kita_rinshan(pk.first);
+                    } else {
+                        _resolve_kan(pk.first, pk.second);
+                    }
                 } else {
                     _accept_riichi();
                     turn_count += 1;
@@ -1164,6 +1234,7 @@ struct GameState {
     // mod.rs:1317-1413
     void _resolve_discard(uint8_t pid, uint8_t tile, bool tsumogiri) {
         PlayerState& P = players[pid];
+        if (sanma) pending_kan.reset();  // quirk Q11 (state_3p/mod.rs:1224-1227)
         is_rinshan_flag = false;
         P.ippatsu_cycle = false;
         P.discards.push_back(tile);
@@ -1284,6 +1355,95 @@ struct GameState {
         }
     }
 
+    // state_3p/sanma.rs:9-144
+    void handle_kita(uint8_t pid, const Action& act) {
+        PlayerState& P = players[pid];
+        int tile;
+        if (act.tile >= 0 && act.tile / 4 == 30)
+            tile = act.tile;
+        else {
+            tile = -1;
+            for (uint8_t t : P.hand)
+                if (t / 4 == 30) {
+                    tile = t;
+                    break;
+                }
+            if (tile < 0) tile = act.tile >= 0 ? act.tile : (act.consume.empty() ? 0 : act.consume[0]);
+        }
+        int idx = vec_position(P.hand, (uint8_t)tile);
+        if (idx >= 0) P.hand.erase(P.hand.begin() + idx);
+        P.kita_tiles.push_back((uint8_t)tile);
+        is_first_turn = false;
+        if (!skip_mjai_logging)
+            push_event("{\"actor\":" + std::to_string(pid) + ",\"pai\":\"" + tid_to_mjai((uint8_t)tile) + "\",\"type\":\"kita\"}", "kita",
+                       pid, nullptr);
+        while (wall.pending_kan_dora_count > 0) {
+            wall.pending_kan_dora_count--;
+            _reveal_kan_dora();
+        }
+        std::vector<uint8_t> ronners;
+        for (uint8_t i = 0; i < NP; i++) {
+            if (i == pid) continue;
+            const PlayerState& Q = players[i];
+            HandEvaluator he(Q.hand, Q.melds, true);
+            bool furiten = false;
+            for (uint8_t w : he.get_waits_u8()) {
+                for (uint8_t d : Q.discards)
+                    if (d / 4 == w) furiten = true;
+                if (furiten) break;
+            }
+            if (Q.missed_agari_riichi || Q.missed_agari_doujun) furiten = true;
+            if (furiten) continue;
+            Conditions c;
+            c.tsumo = false;
+            c.riichi = Q.riichi_declared;
+            c.double_riichi = Q.double_riichi_declared;
+            c.ippatsu = Q.ippatsu_cycle;
+            c.chankan = false;
+            c.player_wind = (uint8_t)((i + NP - oya) % NP);
+            c.round_wind = round_wind % 4;
+            c.riichi_sticks = riichi_sticks;
+            c.honba = honba;
+            c.is_sanma = true;
+            c.num_players = 3;
+            c.kita_count = (uint8_t)Q.kita_tiles.size();
+            WinResult r = he.calc((uint8_t)tile, wall.dora_indicators, {}, c);
+            if (r.is_win && (r.yakuman || r.han >= 1)) {
+                ronners.push_back(i);
+                current_claims[i].push_back(Action(AT_RON, tile, {}, i));
+            }
+        }
+        if (!ronners.empty()) {
+            phase = WAIT_RESPONSE;
+            active_players = ronners;
+            last_discard = std::make_pair(pid, (uint8_t)tile);
+            pending_kan = std::make_pair(pid, act);
+        } else {
+            for (auto& p : players) p.ippatsu_cycle = false;
+            resolve_kita_rinshan(pid);
+        }
+    }
+    // state_3p/sanma.rs:171-204
+    void resolve_kita_rinshan(uint8_t pid) {
+        if (wall.drawable_count > 0) {
+            while (wall.pending_kan_dora_count > 0) {
+                wall.pending_kan_dora_count--;
+                _reveal_kan_dora();
+            }
+            if (wall.tiles.empty()) return;
+            uint8_t t = wall.tiles.front();  // draw_rinshan_tile, state_3p/wall.rs:117-124
+            wall.tiles.erase(wall.tiles.begin());
+            wall.drawable_count = wall.drawable_count > 0 ? wall.drawable_count - 1 : 0;
+            players[pid].hand.push_back(t);
+            drawn_tile = t;
+            wall.rinshan_draw_count += 1;
+            is_rinshan_flag = true;
+            ev_tsumo(pid, t);
+            phase = WAIT_ACT;
+            active_players = {pid};
+        }
+    }
+
     // mod.rs:1549-1567
     void _accept_riichi() {
         if (riichi_pending_acceptance >= 0) {
@@ -1336,9 +1496,10 @@ struct GameState {
             if (!ok) dealer_is_top = false;
         }
         bool is_last_regular = false;
+        const int32_t goal = sanma ? 40000 : 30000;  // state_3p/mod.rs:1524,1553,1561
         if (game_mode == 1 || game_mode == 4) is_last_regular = round_wind == 0 && oya == np - 1;
         if (game_mode == 2 || game_mode == 5) is_last_regular = round_wind == 1 && oya == np - 1;
-        if (oya_won && is_last_regular && dealer_is_top && dealer_score >= 30000) {
+        if (oya_won && is_last_regular && dealer_is_top && dealer_score >= goal) {
             _process_end_game();
             return;
         }
@@ -1355,18 +1516,18 @@ struct GameState {
             if (next_oya == 0) next_rw += 1;
         }
         int32_t max_score = players[0].score;
-        for (auto& p : players) max_score = std::max(max_score, p.score);
+        for (int i = 0; i < NP; i++) max_score = std::max(max_score, players[i].score);
         switch (game_mode) {
             case 1:
             case 4:
-                if (next_rw >= 1 && (max_score >= 30000 || next_rw > 1)) {
+                if (next_rw >= 1 && (max_score >= goal || next_rw > 1)) {
                     _process_end_game();
                     return;
                 }
                 break;
             case 2:
             case 5:
-                if (next_rw >= 2 && (max_score >= 30000 || next_rw > 2)) {
+                if (next_rw >= 2 && (max_score >= goal || next_rw > 2)) {
                     _process_end_game();
                     return;
                 }
@@ -1381,7 +1542,7 @@ struct GameState {
         }
         ev_type_only("end_kyoku");
         std::vector<int32_t> sc;
-        for (auto& p : players) sc.push_back(p.score);
+        for (int i = 0; i < NP; i++) sc.push_back(players[i].score);
         _initialize_round(next_oya, next_rw, next_honba, riichi_sticks, nullptr, &sc);
     }
 
@@ -1439,7 +1600,7 @@ struct GameState {
             std::string head = std::string("{\"bakaze\":\"") + winds[round_wind % 4] + "\",\"dora_marker\":\"" +
                                tid_to_mjai(wall.dora_indicators[0]) + "\",\"honba\":" + std::to_string(honba) +
                                ",\"kyoku\":" + std::to_string(oya + 1) + ",\"kyotaku\":" + std::to_string(kyotaku) +
-                               ",\"oya\":" + std::to_string(oya) + ",\"scores\":" + json_int_array(sc, sc + 4) + ",\"tehais\":[";
+                               ",\"oya\":" + std::to_string(oya) + ",\"scores\":" + json_int_array(sc, sc + NP) + ",\"tehais\":[";
             std::string tail = "],\"type\":\"start_kyoku\"}";
             std::string th[4], masked[4];
             for (int i = 0; i < NP; i++) {
@@ -1447,7 +1608,9 @@ struct GameState {
                 std::vector<std::string> q(players[i].hand.size(), "?");
                 masked[i] = json_str_array(q);
             }
-            std::string full = head + th[0] + "," + th[1] + "," + th[2] + "," + th[3] + tail;
+            std::string full = head;
+            for (int i = 0; i < NP; i++) full += (i ? "," : "") + th[i];
+            full += tail;
             std::string per[4];
             for (int pid = 0; pid < NP; pid++) {
                 std::string s = head;
@@ -1486,7 +1649,7 @@ struct GameState {
         static const std::string illegal_prefix = "Error: Illegal Action by Player ";
         if (reason == "exhaustive_draw") {
             for (int i = 0; i < np; i++) {
-                HandEvaluator he(players[i].hand, players[i].melds);
+                HandEvaluator he(players[i].hand, players[i].melds, sanma);
                 if (he.is_tenpai()) tenpai[i] = true;
             }
             for (int i = 0; i < np; i++)
@@ -1506,7 +1669,7 @@ struct GameState {
                     }
                 }
             } else {
-                int32_t pool = 3000;
+                int32_t pool = sanma ? 2000 : 3000;  // state_3p/game_mode.rs:39-41
                 int num_tp = 0;
                 for (int i = 0; i < np; i++) num_tp += tenpai[i];
                 if (num_tp > 0 && num_tp < np) {
@@ -1562,7 +1725,7 @@ struct GameState {
         if (!skip_mjai_logging) {
             int32_t d[4];
             for (int i = 0; i < np; i++) d[i] = players[i].score_delta;
-            push_event("{\"deltas\":" + json_int_array(d, d + 4) + ",\"reason\":\"" + final_reason + "\",\"type\":\"ryukyoku\"}",
+            push_event("{\"deltas\":" + json_int_array(d, d + np) + ",\"reason\":\"" + final_reason + "\",\"type\":\"ryukyoku\"}",
                        "ryukyoku", -1, nullptr);
         }
         _initialize_next_round(is_renchan, true);
@@ -1575,7 +1738,7 @@ struct GameState {
             if (p.discards.size() != 1) turns_ok = false;
             if (!p.melds.empty()) melds_empty = false;
         }
-        if (turns_ok && melds_empty && !players[0].discards.empty()) {
+        if (!sanma && turns_ok && melds_empty && !players[0].discards.empty()) {
             uint8_t first = players[0].discards[0] / 4;
             if (first >= 27 && first <= 30) {
                 bool all = true;
@@ -1603,7 +1766,7 @@ struct GameState {
         bool all_riichi = true;
         for (auto& p : players)
             if (!p.riichi_declared) all_riichi = false;
-        if (all_riichi) {
+        if (!sanma && all_riichi) {
             _trigger_ryukyoku("suucha_riichi");
             return true;
         }
@@ -1613,6 +1776,13 @@ struct GameState {
     // mod.rs:2021-2046
     void _reveal_kan_dora() {
         size_t count = wall.dora_indicators.size();
+        if (sanma) {  // state_3p/mod.rs:1894-1913: pre-extracted indicators, no bound check
+            if (count < 5) {
+                wall.dora_indicators.push_back(wall.dora_tiles[count]);
+                ev_dora(wall.dora_indicators.back());
+            }
+            return;
+        }
         if (count < 5) {
             size_t raw = 4 + 2 * count;
             size_t base = raw > wall.rinshan_draw_count ? raw - wall.rinshan_draw_count : 0;
@@ -1625,6 +1795,10 @@ struct GameState {
     // mod.rs:2048-2057
     std::vector<uint8_t> _get_ura_indicators() const {
         std::vector<uint8_t> v;
+        if (sanma) {  // state_3p/mod.rs:1925-1931
+            for (size_t i = 0; i < wall.dora_indicators.size() && i < 5; i++) v.push_back(wall.ura_tiles[i]);
+            return v;
+        }
         for (size_t i = 0; i < wall.dora_indicators.size(); i++) {
             size_t raw = 5 + 2 * i;
             size_t idx = raw > wall.rinshan_draw_count ? raw - wall.rinshan_draw_count : 0;

@@ -60,7 +60,8 @@ class PlayerView(C.Structure):
                 ("nagashi_eligible", C.c_uint8), ("ippatsu_cycle", C.c_uint8),
                 ("pao_daisangen", C.c_int8), ("pao_daisuushi", C.c_int8),
                 ("n_forbidden", C.c_uint8), ("forbidden", C.c_uint8 * 2),
-                ("riichi_sutehai", C.c_int16), ("last_tedashi", C.c_int16)]
+                ("riichi_sutehai", C.c_int16), ("last_tedashi", C.c_int16),
+                ("n_kita", C.c_uint8), ("kita", C.c_uint8 * 4)]
 
 
 class StateView(C.Structure):

@@ -13,7 +13,7 @@
 #include <vector>
 
 #include "../../include/riichi_mi355x.h"
-#include "rmj_step.hip.h"
+#include "rmj_common.hip.h"
 #include "rmj_encode.hip.h"
 
 using namespace rmj;
@@ -34,48 +34,6 @@ __device__ __forceinline__ void load_state(GState& S, const GState* src, int lan
 __device__ __forceinline__ void store_state(const GState& S, GState* dst, int lane) {
     wave_sync();
     if (lane < (int)(sizeof(GState) / 16)) reinterpret_cast<uint4*>(dst)[lane] = reinterpret_cast<const uint4*>(&S)[lane];
-}
-
-// RiichiEnv.reset defaults (env.rs:799-851) executed on device: reset() + _initialize_round(0,0,0,0,None,default scores)
-__device__ __noinline__ void ol_env_reset_default(CtxV v) {
-    CTX_FROM(v);
-    c.S.ev_count = 0;  // GameState::reset clears the logs (state/mod.rs:171-187)
-    emit_simple(c, RMJ_EV_START_GAME);
-    const int32_t sc[4] = {25000, 25000, 25000, 25000};
-    shuffle_wall(c);
-    init_round(c, 0, 0, 0, 0, sc);
-}
-
-__global__ __launch_bounds__(256, 4) void k_step(Env E, const uint64_t* __restrict__ actions, uint64_t policy_seed, uint32_t flags) {
-    __shared__ BlockShared sh;
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const uint32_t g = blockIdx.x * WPB + wave;
-    if (g >= E.n_games) return;
-    GState& S = sh.st[wave];
-    load_state(S, E.core + g, lane);
-    Ctx c{S, E, sh.x[wave], g, lane, E.wall + (size_t)g * RMJ_WALL_STRIDE, E.legal + (size_t)g * 4 * RMJ_MAX_LEGAL};
-    if (S.is_done && (flags & STEP_F_AUTORESET)) {
-        ol_env_reset_default(ctx_pack(c));
-    } else {
-        uint64_t acts[4];
-        if (flags & STEP_F_RANDOM) {
-            // RandomAgent (random_agent.py:6-15), keyed per (game, step, seat): see rmj_step_random in the header
-            uint64_t gs = sm64(policy_seed + E.game_offset + g);
-            for (int p = 0; p < 4; p++) {
-                acts[p] = RMJ_NO_ACTION;
-                int n = E.nlegal[(size_t)g * 4 + p];
-                if (((S.active_mask >> p) & 1u) && n > 0 && !S.is_done) {
-                    uint64_t ch = sm64(gs + (uint64_t)S.step_count * 4ull + (uint64_t)p) % (uint64_t)n;
-                    acts[p] = c.Lg[p * RMJ_MAX_LEGAL + ch];
-                }
-            }
-        } else {
-            for (int p = 0; p < 4; p++) acts[p] = actions[(size_t)g * 4 + p];
-        }
-        step_game(c, acts);
-    }
-    finalize_outputs(c, true);
-    store_state(S, E.core + g, lane);
 }
 
 // Device policy without stepping (rmj_random_actions)
@@ -108,64 +66,19 @@ struct ResetArgs {
     uint32_t is_ctor;
 };
 
-__global__ __launch_bounds__(256, 4) void k_reset(Env E, ResetArgs A) {
-    __shared__ BlockShared sh;
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const uint32_t g = blockIdx.x * WPB + wave;
-    if (g >= E.n_games) return;
-    if (!A.is_ctor && A.select && !A.select[g]) return;
-    GState& S = sh.st[wave];
-    if (A.is_ctor) {
-        for (int i = lane; i < (int)(sizeof(GState) / 4); i += 64) reinterpret_cast<uint32_t*>(&S)[i] = 0u;
-        wave_sync();
-    } else {
-        load_state(S, E.core + g, lane);
-    }
-    Ctx c{S, E, sh.x[wave], g, lane, E.wall + (size_t)g * RMJ_WALL_STRIDE, E.legal + (size_t)g * 4 * RMJ_MAX_LEGAL};
-    int32_t sc[4] = {25000, 25000, 25000, 25000};
-    if (A.is_ctor) {  // GameState::new, state/mod.rs:98-167
-        S.wall_seed = A.seeds ? A.seeds[g] : A.base_seed + E.game_offset + g;
-        S.hand_index = 0;
-        S.last_error_pid = 0xFF;
-        S.pending_kan_pid = 0xFF;
-        S.riichi_pending = 0xFF;
-        S.drawn_tile = 0xFF;
-        S.last_discard_pid = 0xFF;
-        for (int p = 0; p < 4; p++) S.p[p].score = 25000;
-        emit_simple(c, RMJ_EV_START_GAME);
-        shuffle_wall(c);
-        init_round(c, 0, (int)E.ctor_round_wind, 0, 0, nullptr);
-    } else {          // env.rs:799-851
-        S.ev_count = 0;
-        emit_simple(c, RMJ_EV_START_GAME);
-        if (A.scores)
-            for (int p = 0; p < 4; p++) sc[p] = A.scores[(size_t)g * 4 + p];
-        if (A.walls) {
-            for (int i = lane; i < 136; i += 64) c.X.tiles[i] = A.walls[(size_t)g * 136 + (135 - i)];  // load_wall: reverse
-            wave_sync();
-        } else {
-            shuffle_wall(c);
-        }
-        init_round(c, A.oya ? A.oya[g] : 0, A.round_wind ? A.round_wind[g] : 0, A.honba ? A.honba[g] : 0,
-                   A.kyotaku ? A.kyotaku[g] : 0u, sc);
-    }
-    finalize_outputs(c, true);
-    store_state(S, E.core + g, lane);
-}
 
-// recompute observation outputs of one game after rmj_poke_state
-__global__ __launch_bounds__(64, 4) void k_refresh(Env E, uint32_t g) {
-    __shared__ GState st;
-    __shared__ WaveScratch x;
-    const int lane = threadIdx.x & 63;
-    load_state(st, E.core + g, lane);
-    Ctx c{st, E, x, g, lane, E.wall + (size_t)g * RMJ_WALL_STRIDE, E.legal + (size_t)g * 4 * RMJ_MAX_LEGAL};
-    bool keep = st.phase == RMJ_WAIT_RESPONSE && st.pending_kan_pid != 0xFF;  // chankan claims are not reconstructible
-    if (!keep) {
-        finalize_outputs(c, false);
-        store_state(st, E.core + g, lane);
-    }
-}
+#define RMJ_NS rmj4
+#define RMJ_SANMA 0
+#include "rmj_step.hip.h"
+#include "rmj_kernels.hip.h"
+#undef RMJ_NS
+#undef RMJ_SANMA
+#define RMJ_NS rmj3
+#define RMJ_SANMA 1
+#include "rmj_step.hip.h"
+#include "rmj_kernels.hip.h"
+#undef RMJ_NS
+#undef RMJ_SANMA
 
 __global__ void k_sum_steps(const GState* core, uint32_t n, unsigned long long* out) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -445,7 +358,7 @@ int rmj_device_count(void) {
 
 int rmj_create(const RmjConfig* cfg, rmj_handle* out) {
     if (!cfg || !out || cfg->n_games == 0) return fail(RMJ_ERR_ARG, "bad config");
-    if (cfg->game_mode > 2) return fail(RMJ_ERR_ARG, "game_mode 3..5 (sanma) is not built in this round");
+    if (cfg->game_mode > 5) return fail(RMJ_ERR_ARG, "game_mode must be 0..5");
     int rc = ensure_device(cfg->device);
     if (rc) return rc;
     rmj_env* h = new rmj_env();
@@ -489,7 +402,8 @@ int rmj_create(const RmjConfig* cfg, rmj_handle* out) {
         HIPCHK(hipMemcpy(d_seeds, cfg->seeds, B * sizeof(uint64_t), hipMemcpyHostToDevice));
         A.seeds = d_seeds;
     }
-    hipLaunchKernelGGL(k_reset, game_grid(cfg->n_games), dim3(256), 0, h->stream, d, A);
+    if (cfg->game_mode >= 3) hipLaunchKernelGGL(rmj3::k_reset, game_grid(cfg->n_games), dim3(256), 0, h->stream, d, A);
+    else hipLaunchKernelGGL(rmj4::k_reset, game_grid(cfg->n_games), dim3(256), 0, h->stream, d, A);
     HIPCHK(hipGetLastError());
     HIPCHK(hipStreamSynchronize(h->stream));
     if (d_seeds) hipFree(d_seeds);
@@ -528,7 +442,8 @@ int rmj_reset(rmj_handle h, const uint8_t* select, const uint8_t* walls, const u
     ResetArgs A;
     memset(&A, 0, sizeof(A));
     A.select = d_sel; A.walls = d_walls; A.oya = d_oya; A.round_wind = d_rw; A.scores = d_sc; A.honba = d_honba; A.kyotaku = d_ky;
-    hipLaunchKernelGGL(k_reset, game_grid(h->cfg.n_games), dim3(256), 0, h->stream, h->d, A);
+    if (h->cfg.game_mode >= 3) hipLaunchKernelGGL(rmj3::k_reset, game_grid(h->cfg.n_games), dim3(256), 0, h->stream, h->d, A);
+    else hipLaunchKernelGGL(rmj4::k_reset, game_grid(h->cfg.n_games), dim3(256), 0, h->stream, h->d, A);
     HIPCHK(hipGetLastError());
     HIPCHK(hipStreamSynchronize(h->stream));
     hipFree(d_sel); hipFree(d_walls); hipFree(d_oya); hipFree(d_rw); hipFree(d_sc); hipFree(d_honba); hipFree(d_ky);
@@ -538,7 +453,8 @@ int rmj_reset(rmj_handle h, const uint8_t* select, const uint8_t* walls, const u
 int rmj_step_device(rmj_handle h, const rmj_action_t* d_actions) {
     if (!h || !d_actions) return fail(RMJ_ERR_ARG, "null argument");
     HIPCHK(hipSetDevice(h->cfg.device));
-    hipLaunchKernelGGL(k_step, game_grid(h->cfg.n_games), dim3(256), 0, h->stream, h->d, (const uint64_t*)d_actions, 0ull, 0u);
+    if (h->cfg.game_mode >= 3) hipLaunchKernelGGL(rmj3::k_step, game_grid(h->cfg.n_games), dim3(256), 0, h->stream, h->d, (const uint64_t*)d_actions, 0ull, 0u);
+    else hipLaunchKernelGGL(rmj4::k_step, game_grid(h->cfg.n_games), dim3(256), 0, h->stream, h->d, (const uint64_t*)d_actions, 0ull, 0u);
     HIPCHK(hipGetLastError());
     return RMJ_OK;
 }
@@ -553,8 +469,10 @@ int rmj_step_random(rmj_handle h, uint64_t policy_seed, uint32_t n_steps, int au
     if (!h) return fail(RMJ_ERR_ARG, "null handle");
     HIPCHK(hipSetDevice(h->cfg.device));
     uint32_t flags = STEP_F_RANDOM | (auto_reset ? STEP_F_AUTORESET : 0u);
-    for (uint32_t s = 0; s < n_steps; s++)
-        hipLaunchKernelGGL(k_step, game_grid(h->cfg.n_games), dim3(256), 0, h->stream, h->d, (const uint64_t*)nullptr, policy_seed, flags);
+    for (uint32_t s = 0; s < n_steps; s++) {
+        if (h->cfg.game_mode >= 3) hipLaunchKernelGGL(rmj3::k_step, game_grid(h->cfg.n_games), dim3(256), 0, h->stream, h->d, (const uint64_t*)nullptr, policy_seed, flags);
+        else hipLaunchKernelGGL(rmj4::k_step, game_grid(h->cfg.n_games), dim3(256), 0, h->stream, h->d, (const uint64_t*)nullptr, policy_seed, flags);
+    }
     HIPCHK(hipGetLastError());
     return RMJ_OK;
 }
@@ -636,12 +554,13 @@ int rmj_get_ranks(rmj_handle h, uint8_t* ranks) {  // env.rs:673-689
     std::vector<uint32_t> ev;
     int rc = fetch_scores(h, sc, ev);
     if (rc) return rc;
+    const int np = h->cfg.game_mode >= 3 ? 3 : 4;
     for (uint32_t g = 0; g < h->cfg.n_games; g++)
         for (int a = 0; a < 4; a++) {
             int r = 1;
-            for (int b = 0; b < 4; b++)
+            for (int b = 0; b < np; b++)
                 if (sc[g * 4 + b] > sc[g * 4 + a] || (sc[g * 4 + b] == sc[g * 4 + a] && b < a)) r++;
-            ranks[g * 4 + a] = (uint8_t)r;
+            ranks[g * 4 + a] = a < np ? (uint8_t)r : 0;
         }
     return RMJ_OK;
 }
@@ -743,6 +662,8 @@ static void to_view(const GState& S, const uint8_t* W, RmjStateView* v) {
         for (int i = 0; i < P.n_forbidden && i < 2; i++) q.forbidden[i] = P.forbidden[i];
         q.riichi_sutehai = P.riichi_sutehai == 0xFF ? -1 : (int16_t)P.riichi_sutehai;
         q.last_tedashi = P.last_tedashi == 0xFF ? -1 : (int16_t)P.last_tedashi;
+        q.n_kita = P.n_kita;
+        for (int i = 0; i < P.n_kita && i < 4; i++) q.kita[i] = P.kita[i];
     }
     v->current_player = S.current_player;
     v->is_done = S.is_done;
@@ -787,6 +708,7 @@ int rmj_poke_state(rmj_handle h, uint32_t game, const RmjStateView* v) {
     S.rinshan_count = v->rinshan_draw_count;
     int len = v->wall_len;
     if (S.rinshan_count + len > 136) return fail(RMJ_ERR_ARG, "wall too long");
+    for (int p = 0; p < 4; p++) S.stale_n[p] = 0;
     for (int i = 0; i < len; i++) W[S.rinshan_count + i] = v->wall[i];
     S.live_end = (uint8_t)(S.rinshan_count + len);
     S.n_dora = v->n_dora > 5 ? 5 : v->n_dora;
@@ -835,6 +757,8 @@ int rmj_poke_state(rmj_handle h, uint32_t game, const RmjStateView* v) {
         for (int i = 0; i < P.n_forbidden; i++) P.forbidden[i] = q.forbidden[i];
         P.riichi_sutehai = q.riichi_sutehai < 0 ? 0xFF : (uint8_t)q.riichi_sutehai;
         P.last_tedashi = q.last_tedashi < 0 ? 0xFF : (uint8_t)q.last_tedashi;
+        P.n_kita = q.n_kita > 4 ? 4 : q.n_kita;
+        for (int i = 0; i < P.n_kita; i++) P.kita[i] = q.kita[i];
     }
     S.current_player = v->current_player;
     S.is_done = v->is_done;
@@ -858,7 +782,8 @@ int rmj_poke_state(rmj_handle h, uint32_t game, const RmjStateView* v) {
     S.last_error_pid = v->last_error_pid < 0 ? 0xFF : (uint8_t)v->last_error_pid;
     HIPCHK(hipMemcpy(h->d.core + game, &S, sizeof(GState), hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(h->d.wall + (size_t)game * RMJ_WALL_STRIDE, W, RMJ_WALL_STRIDE, hipMemcpyHostToDevice));
-    hipLaunchKernelGGL(k_refresh, dim3(1), dim3(64), 0, h->stream, h->d, game);
+    if (h->cfg.game_mode >= 3) hipLaunchKernelGGL(rmj3::k_refresh, dim3(1), dim3(64), 0, h->stream, h->d, game);
+    else hipLaunchKernelGGL(rmj4::k_refresh, dim3(1), dim3(64), 0, h->stream, h->d, game);
     HIPCHK(hipGetLastError());
     HIPCHK(hipStreamSynchronize(h->stream));
     return RMJ_OK;
@@ -905,6 +830,7 @@ int rmj_format_event(const RmjEvent* ev, uint32_t n_avail, int seat, char* buf, 
     const RmjEvent& e = ev[0];
     auto A = [&](int a) { return std::to_string(a); };
     int ncons = e.flags >> 4;
+    const int np = (e.pad == 3) ? 3 : 4;  // seats, written into the pad byte by the device
     switch (e.type) {
         case RMJ_EV_START_GAME: s = "{\"type\":\"start_game\"}"; break;
         case RMJ_EV_END_KYOKU: s = "{\"type\":\"end_kyoku\"}"; break;
@@ -916,8 +842,8 @@ int rmj_format_event(const RmjEvent* ev, uint32_t n_avail, int seat, char* buf, 
             uint32_t kyotaku = e.consumed[2] | (e.consumed[3] << 8);
             s = std::string("{\"bakaze\":\"") + winds[e.consumed[0] & 3] + "\",\"dora_marker\":\"" + mjai_tile(e.tile) + "\",\"honba\":" +
                 A(e.consumed[1]) + ",\"kyoku\":" + A(e.target) + ",\"kyotaku\":" + A((int)kyotaku) + ",\"oya\":" + A(e.actor) +
-                ",\"scores\":" + jints(e.deltas, 4) + ",\"tehais\":[";
-            for (int p = 0; p < 4; p++) {
+                ",\"scores\":" + jints(e.deltas, np) + ",\"tehais\":[";
+            for (int p = 0; p < np; p++) {
                 const uint8_t* pl = reinterpret_cast<const uint8_t*>(&ev[1 + p / 2]) + 4 + 13 * (p & 1);
                 if (p) s += ",";
                 if (seat < 0 || seat == p) s += jtiles(pl, 13);
@@ -952,16 +878,19 @@ int rmj_format_event(const RmjEvent* ev, uint32_t n_avail, int seat, char* buf, 
             s = "{\"actor\":" + A(e.actor) + ",\"consumed\":" + jtiles(e.consumed, ncons) + ",\"pai\":\"" + mjai_tile(e.tile) +
                 "\",\"type\":\"" + (e.type == RMJ_EV_ANKAN ? "ankan" : "kakan") + "\"}";
             break;
+        case RMJ_EV_KITA:
+            s = "{\"actor\":" + A(e.actor) + ",\"pai\":\"" + mjai_tile(e.tile) + "\",\"type\":\"kita\"}";
+            break;
         case RMJ_EV_DORA: s = "{\"dora_marker\":\"" + mjai_tile(e.tile) + "\",\"type\":\"dora\"}"; break;
         case RMJ_EV_HORA:
-            s = "{\"actor\":" + A(e.actor) + ",\"deltas\":" + jints(e.deltas, 4) + ",\"target\":" + A(e.target) +
+            s = "{\"actor\":" + A(e.actor) + ",\"deltas\":" + jints(e.deltas, np) + ",\"target\":" + A(e.target) +
                 ((e.flags & 1) ? ",\"tsumo\":true" : "") + ",\"type\":\"hora\",\"ura_markers\":" + jtiles(e.ura, e.n_ura) + "}";
             break;
         case RMJ_EV_RYUKYOKU: {
             static const char* reasons[7] = {"exhaustive_draw", "nagashimangan", "kyushu_kyuhai", "sufuurenta", "suukansansen", "suucha_riichi",
                                              "sanchaho"};
             std::string r = e.flags < 7 ? reasons[e.flags] : ("Error: Illegal Action by Player " + A(e.actor));
-            s = "{\"deltas\":" + jints(e.deltas, 4) + ",\"reason\":\"" + r + "\",\"type\":\"ryukyoku\"}";
+            s = "{\"deltas\":" + jints(e.deltas, np) + ",\"reason\":\"" + r + "\",\"type\":\"ryukyoku\"}";
             break;
         }
         default: return RMJ_ERR_ARG;

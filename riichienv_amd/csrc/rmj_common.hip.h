@@ -1,0 +1,208 @@
+// Shared (variant-independent) device definitions of the step path: environment slabs, per-wave LDS scratch,
+// packed-action helpers (action.rs), small tile helpers.  Included once; rmj_step.hip.h is included once per variant.
+#pragma once
+#include "../../include/riichi_mi355x.h"
+#include "rmj_hand.hip.h"
+#include "rmj_shanten.hip.h"
+#include "rmj_state.h"
+
+namespace rmj {
+
+struct Env {
+    GState* core;
+    uint8_t* wall;        // [B][RMJ_WALL_STRIDE]
+    uint64_t* legal;      // [B][4][64]
+    uint8_t* nlegal;      // [B][4]
+    uint8_t* mask;        // [B][4][82]
+    uint64_t* waits;      // [B][4]
+    uint32_t* status;     // [B]  active_mask | phase<<8 | done<<16
+    RmjEvent* events;     // [B][ring]
+    uint32_t ring_mask;   // ring-1
+    uint32_t n_games;
+    uint32_t rule_bits;
+    uint32_t game_mode;
+    uint32_t skip_log;
+    uint32_t ctor_round_wind;
+    uint64_t game_offset;
+    ShantenTables sh;     // replacement-number tables (prefilter of the riichi probe)
+};
+
+struct WaveScratch {      // per-wave LDS scratch
+    uint64_t keys[136];
+    uint8_t tiles[144];
+    uint8_t maskbuf[4 * 82 + 8];
+    uint64_t legal[4][RMJ_MAX_LEGAL];  // lists produced this launch (copied to HBM by finalize_outputs)
+    uint64_t wout[4];                  // waits produced this launch
+    int nl[4];                         // list lengths produced this launch
+};
+
+__device__ __forceinline__ void wave_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+}
+__device__ __forceinline__ uint64_t lanemask_lt(int lane) { return (1ull << lane) - 1ull; }
+
+// ---------------------------------------------------------------- packed actions
+__device__ __forceinline__ uint64_t mk_action(uint32_t type, uint32_t tile, uint32_t n, uint32_t c0 = 0, uint32_t c1 = 0, uint32_t c2 = 0,
+                                              uint32_t c3 = 0) {
+    return (uint64_t)type | ((uint64_t)tile << 8) | ((uint64_t)n << 16) | ((uint64_t)c0 << 24) | ((uint64_t)c1 << 32) |
+           ((uint64_t)c2 << 40) | ((uint64_t)c3 << 48);
+}
+__device__ __forceinline__ uint32_t a_type(uint64_t a) { return (uint32_t)(a & 0xFF); }
+__device__ __forceinline__ uint32_t a_tile(uint64_t a) { return (uint32_t)((a >> 8) & 0xFF); }
+__device__ __forceinline__ uint32_t a_n(uint64_t a) { return (uint32_t)((a >> 16) & 0xFF); }
+__device__ __forceinline__ uint32_t a_c(uint64_t a, int i) { return (uint32_t)((a >> (24 + 8 * i)) & 0xFF); }
+// canonical form: consume tiles ascending (Action::new, action.rs:97-98), unused bytes zero
+__device__ inline uint64_t a_canon(uint64_t a) {
+    if (a == RMJ_NO_ACTION) return a;
+    uint32_t n = a_n(a);
+    if (n > 4) n = 4;
+    uint32_t c[4];
+#pragma unroll
+    for (int i = 0; i < 4; i++) c[i] = (uint32_t)i < n ? a_c(a, i) : 0xFFFFu;
+#pragma unroll
+    for (int i = 0; i < 4; i++)
+#pragma unroll
+        for (int j = 0; j < 3; j++)
+            if (c[j] > c[j + 1]) { uint32_t t = c[j]; c[j] = c[j + 1]; c[j + 1] = t; }
+#pragma unroll
+    for (int i = 0; i < 4; i++)
+        if ((uint32_t)i >= n) c[i] = 0;
+    return mk_action(a_type(a), a_tile(a), n, c[0], c[1], c[2], c[3]);
+}
+// action.rs:158-227
+__device__ inline int a_encode(uint64_t a) {
+    uint32_t ty = a_type(a), tile = a_tile(a);
+    switch (ty) {
+        case RMJ_DISCARD: return tile / 4;
+        case RMJ_RIICHI: return 37;
+        case RMJ_CHI: {
+            uint32_t tt = tile / 4, x = a_c(a, 0) / 4, y = a_c(a, 1) / 4;
+            uint32_t lo = min(tt, min(x, y)), hi = max(tt, max(x, y));
+            return tt == lo ? 38 : (tt == hi ? 40 : 39);
+        }
+        case RMJ_PON: return 41;
+        case RMJ_DAIMINKAN: return 42 + tile / 4;
+        case RMJ_ANKAN:
+        case RMJ_KAKAN: return 42 + a_c(a, 0) / 4;
+        case RMJ_RON:
+        case RMJ_TSUMO: return 79;
+        case RMJ_KYUSHU: return 80;
+        case RMJ_PASS: return 81;
+        default: return -1;
+    }
+}
+// action.rs:262-346 (3P compact ids, 60-wide)
+__device__ inline int a_encode_3p(uint64_t a) {
+    uint32_t ty = a_type(a), tile = a_tile(a);
+    auto compact = [](uint32_t t34) -> int { return t34 == 0 ? 0 : (t34 == 8 ? 1 : (t34 >= 9 && t34 < 34 ? (int)t34 - 7 : -1)); };
+    switch (ty) {
+        case RMJ_DISCARD: return compact(tile / 4);
+        case RMJ_RIICHI: return 27;
+        case RMJ_PON: return 28;
+        case RMJ_DAIMINKAN: { int k = compact(tile / 4); return k < 0 ? -1 : 29 + k; }
+        case RMJ_ANKAN:
+        case RMJ_KAKAN: { int k = compact(a_c(a, 0) / 4); return k < 0 ? -1 : 29 + k; }
+        case RMJ_RON:
+        case RMJ_TSUMO: return 56;
+        case RMJ_KYUSHU: return 57;
+        case RMJ_PASS: return 58;
+        case RMJ_KITA: return 59;
+        default: return -1;
+    }
+}
+// validation match, state/mod.rs:344-393 (quirk Q13)
+__device__ inline bool a_match(uint64_t l, uint64_t act) {
+    uint32_t lt = a_type(l);
+    if (lt != a_type(act)) return false;
+    bool tiles_match = a_tile(l) == a_tile(act);
+    bool cons_match = (l >> 16) == (act >> 16);
+    bool act_empty = a_n(act) == 0;
+    if (tiles_match) {
+        if (cons_match) return true;
+        if (act_empty && lt == RMJ_KAKAN) return true;
+        if (act_empty && (lt == RMJ_DISCARD || lt == RMJ_RIICHI || lt == RMJ_TSUMO || lt == RMJ_RON || lt == RMJ_PASS)) return true;
+    }
+    if (cons_match && (lt == RMJ_ANKAN || lt == RMJ_KAKAN)) return true;
+    if (a_tile(act) == RMJ_TILE_NONE) return lt == RMJ_TSUMO || lt == RMJ_RON || lt == RMJ_RIICHI || lt == RMJ_KYUSHU || lt == RMJ_KITA;
+    return false;
+}
+
+__device__ __forceinline__ uint64_t sm64(uint64_t x) {  // state/wall.rs:83-88
+    uint64_t z = x + 0x9E3779B97F4A7C15ull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+
+// ---------------------------------------------------------------- small helpers
+__device__ __forceinline__ bool is_terminal_tile136(int t) {  // types.rs:362-367
+    int tt = t / 4;
+    return tt >= 27 || (tt % 9) == 0 || (tt % 9) == 8;
+}
+__device__ __forceinline__ int next_dora34(int t, bool sanma) {  // hand_evaluator.rs:286-300 / _3p.rs:300-311
+    if (sanma) {
+        if (t == 0) return 8;
+        if (t == 8) return 0;
+        if (t < 9) return t;
+    }
+    if (t < 27) return (t % 9 == 8) ? t - 8 : t + 1;
+    if (t < 31) return t == 30 ? 27 : t + 1;
+    return t == 33 ? 31 : t + 1;
+}
+__device__ __forceinline__ bool is_aka(int t) { return t == 16 || t == 52 || t == 88; }
+
+// concealed histogram of a seat (optionally skipping hand index `skip`)
+__device__ __forceinline__ PH build_ph(const PState& P, int skip = -1) {
+    PH h = {0, 0, 0, 0};
+    int n = P.hand_len;
+    for (int j = 0; j < n; j++)
+        if (j != skip) ph_add(h, P.hand[j] >> 2);
+    return h;
+}
+__device__ inline MeldAgg build_meld_agg(const PState& P) {
+    MeldAgg m;
+    m.n = P.n_melds;
+    m.n_kan = m.n_ankan = m.n_nonchi = 0;
+    m.menzen = true;
+    m.types = 0;
+    m.fu = 0;
+    m.aka = 0;
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        m.mtypes[i] = 0;
+        m.mtype[i] = 0;
+        m.t0[i] = 0;
+        if (i < m.n) {
+            uint8_t ty = P.meld_type[i];
+            int nt = (ty >= RMJ_MELD_DAIMINKAN) ? 4 : 3;
+            uint64_t mm = 0;
+            for (int k = 0; k < nt; k++) {
+                int t = P.meld_tiles[i][k];
+                mm |= 1ull << (t >> 2);
+                m.aka += is_aka(t);
+            }
+            m.mtypes[i] = mm;
+            m.types |= mm;
+            m.mtype[i] = ty;
+            int t0 = P.meld_tiles[i][0] >> 2;  // tiles sorted by id -> lowest type first (== chi sort)
+            m.t0[i] = (uint8_t)t0;
+            bool opened = ty != RMJ_MELD_ANKAN;
+            if (opened) m.menzen = false;
+            bool kan = ty >= RMJ_MELD_DAIMINKAN;
+            m.n_kan += kan;
+            m.n_ankan += (ty == RMJ_MELD_ANKAN);
+            m.n_nonchi += (ty != RMJ_MELD_CHI);
+            if (ty != RMJ_MELD_CHI) {  // tiles[0] == tiles[1]
+                int f = opened ? 2 : 4;
+                if (t_is_terminal(t0)) f *= 2;
+                if (kan) f *= 4;
+                m.fu += f;
+            }
+        }
+    }
+    return m;
+}
+
+}  // namespace rmj

@@ -3,7 +3,7 @@
 // One wavefront per (game, seat): the tensor is assembled in LDS (lane = tile type for the per-tile channels,
 // wave-uniform scalars broadcast over the 34 columns) and streamed out as 629 coalesced 16-byte stores.
 #pragma once
-#include "rmj_step.hip.h"
+#include "rmj_common.hip.h"
 
 namespace rmj {
 

@@ -1,0 +1,109 @@
+// Variant-dependent kernels of the step path; included once per variant (see rmj_step.hip.h) inside namespace RMJ_NS.
+namespace RMJ_NS {
+
+// RiichiEnv.reset defaults (env.rs:799-851) executed on device: reset() + _initialize_round(0,0,0,0,None,default scores)
+__device__ __noinline__ void ol_env_reset_default(CtxV v) {
+    CTX_FROM(v);
+    c.S.ev_count = 0;  // GameState::reset clears the logs (state/mod.rs:171-187)
+    emit_simple(c, RMJ_EV_START_GAME);
+    const int32_t st = KSANMA ? 35000 : 25000;  // state_3p/game_mode.rs:31-33
+    const int32_t sc[4] = {st, st, st, st};
+    shuffle_wall(c);
+    init_round(c, 0, 0, 0, 0, sc);
+}
+
+__global__ __launch_bounds__(256, 4) void k_step(Env E, const uint64_t* __restrict__ actions, uint64_t policy_seed, uint32_t flags) {
+    __shared__ BlockShared sh;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const uint32_t g = blockIdx.x * WPB + wave;
+    if (g >= E.n_games) return;
+    GState& S = sh.st[wave];
+    load_state(S, E.core + g, lane);
+    Ctx c{S, E, sh.x[wave], g, lane, E.wall + (size_t)g * RMJ_WALL_STRIDE, E.legal + (size_t)g * 4 * RMJ_MAX_LEGAL};
+    if (S.is_done && (flags & STEP_F_AUTORESET)) {
+        ol_env_reset_default(ctx_pack(c));
+    } else {
+        uint64_t acts[4];
+        if (flags & STEP_F_RANDOM) {
+            // RandomAgent (random_agent.py:6-15), keyed per (game, step, seat): see rmj_step_random in the header
+            uint64_t gs = sm64(policy_seed + E.game_offset + g);
+            for (int p = 0; p < 4; p++) {
+                acts[p] = RMJ_NO_ACTION;
+                int n = E.nlegal[(size_t)g * 4 + p];
+                if (((S.active_mask >> p) & 1u) && n > 0 && !S.is_done) {
+                    uint64_t ch = sm64(gs + (uint64_t)S.step_count * 4ull + (uint64_t)p) % (uint64_t)n;
+                    acts[p] = c.Lg[p * RMJ_MAX_LEGAL + ch];
+                }
+            }
+        } else {
+            for (int p = 0; p < 4; p++) acts[p] = actions[(size_t)g * 4 + p];
+        }
+        step_game(c, acts);
+    }
+    finalize_outputs(c, true);
+    store_state(S, E.core + g, lane);
+}
+
+__global__ __launch_bounds__(256, 4) void k_reset(Env E, ResetArgs A) {
+    __shared__ BlockShared sh;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const uint32_t g = blockIdx.x * WPB + wave;
+    if (g >= E.n_games) return;
+    if (!A.is_ctor && A.select && !A.select[g]) return;
+    GState& S = sh.st[wave];
+    if (A.is_ctor) {
+        for (int i = lane; i < (int)(sizeof(GState) / 4); i += 64) reinterpret_cast<uint32_t*>(&S)[i] = 0u;
+        wave_sync();
+    } else {
+        load_state(S, E.core + g, lane);
+    }
+    Ctx c{S, E, sh.x[wave], g, lane, E.wall + (size_t)g * RMJ_WALL_STRIDE, E.legal + (size_t)g * 4 * RMJ_MAX_LEGAL};
+    const int32_t st0 = KSANMA ? 35000 : 25000;
+    int32_t sc[4] = {st0, st0, st0, st0};
+    if (A.is_ctor) {  // GameState::new, state/mod.rs:98-167
+        S.wall_seed = A.seeds ? A.seeds[g] : A.base_seed + E.game_offset + g;
+        S.hand_index = 0;
+        S.last_error_pid = 0xFF;
+        S.pending_kan_pid = 0xFF;
+        S.riichi_pending = 0xFF;
+        S.drawn_tile = 0xFF;
+        S.last_discard_pid = 0xFF;
+        for (int p = 0; p < 4; p++) S.p[p].score = st0;
+        emit_simple(c, RMJ_EV_START_GAME);
+        shuffle_wall(c);
+        init_round(c, 0, (int)E.ctor_round_wind, 0, 0, nullptr);
+    } else {          // env.rs:799-851
+        S.ev_count = 0;
+        emit_simple(c, RMJ_EV_START_GAME);
+        if (A.scores)
+            for (int p = 0; p < 4; p++) sc[p] = A.scores[(size_t)g * 4 + p];
+        if (A.walls) {
+            const int total = KSANMA ? 108 : 136;  // 3P: the first 108 entries of the [136] row
+            for (int i = lane; i < total; i += 64) c.X.tiles[i] = A.walls[(size_t)g * 136 + (total - 1 - i)];  // load_wall: reverse
+            wave_sync();
+        } else {
+            shuffle_wall(c);
+        }
+        init_round(c, A.oya ? A.oya[g] : 0, A.round_wind ? A.round_wind[g] : 0, A.honba ? A.honba[g] : 0,
+                   A.kyotaku ? A.kyotaku[g] : 0u, sc);
+    }
+    finalize_outputs(c, true);
+    store_state(S, E.core + g, lane);
+}
+
+// recompute observation outputs of one game after rmj_poke_state
+__global__ __launch_bounds__(64, 4) void k_refresh(Env E, uint32_t g) {
+    __shared__ GState st;
+    __shared__ WaveScratch x;
+    const int lane = threadIdx.x & 63;
+    load_state(st, E.core + g, lane);
+    Ctx c{st, E, x, g, lane, E.wall + (size_t)g * RMJ_WALL_STRIDE, E.legal + (size_t)g * 4 * RMJ_MAX_LEGAL};
+    bool keep = st.phase == RMJ_WAIT_RESPONSE && st.pending_kan_pid != 0xFF;  // chankan claims are not reconstructible
+    if (!keep) {
+        finalize_outputs(c, false);
+        store_state(st, E.core + g, lane);
+    }
+}
+
+
+}  // namespace RMJ_NS

@@ -50,7 +50,9 @@ struct alignas(16) PState {  // 128 bytes
     uint64_t discard_type_mask;  // derived cache: bit t set iff some discard has type t
     uint8_t discards[32];
     uint64_t waits13;            // derived cache: get_waits of the 13-tile hand (valid iff PF_WAITS_VALID)
-    uint8_t pad1[8];
+    uint8_t n_kita;              // 3P: kita_tiles (state_3p/player.rs:38)
+    uint8_t kita[4];
+    uint8_t pad1[3];
 };
 
 struct alignas(16) GState {  // 4*128 + 128 = 640 bytes
@@ -75,7 +77,11 @@ struct alignas(16) GState {  // 4*128 + 128 = 640 bytes
     uint8_t ron_offer_mask;   // seats whose stored claim list contains Ron (state/mod.rs:902-917)
     uint8_t last_error_pid;   // 0xFF none (quirk Q9)
     uint8_t wall_total;       // 136 (4P) / 108 (3P)
-    uint8_t pad[128 - 8 - 8 - 20 - 16 - 4 - 6 - 3];
+    // Number of entries of each seat's stored claim list that are still in the reference's `current_claims`
+    // (it is cleared only by _resolve_discard / all-pass / _initialize_round, so claims survive an accepted call and
+    // resurface, in front of a chankan / kita Ron offer, if the caller kans or declares kita before discarding).
+    uint8_t stale_n[4];
+    uint8_t pad[128 - 8 - 8 - 20 - 16 - 4 - 6 - 3 - 4];
 };
 
 #ifdef __cplusplus

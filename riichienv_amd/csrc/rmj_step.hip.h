@@ -12,41 +12,16 @@
 // Reference semantics: riichienv-core/src/state/mod.rs (step, _resolve_discard, _resolve_kan,
 // _accept_riichi, _deal_next, _initialize_next_round, _initialize_round, _trigger_ryukyoku,
 // check_abortive_draw, _reveal_kan_dora), state/legal_actions.rs, riichienv-python/src/env.rs.
-#pragma once
-#include "../../include/riichi_mi355x.h"
-#include "rmj_hand.hip.h"
-#include "rmj_shanten.hip.h"
-#include "rmj_state.h"
+// NOTE: this file is included ONCE PER VARIANT by rmj_api.hip with
+//   RMJ_NS    = namespace of the instantiation (rmj4 / rmj3)
+//   RMJ_SANMA = 0 (state/, 4 seats, 136 tiles) or 1 (state_3p/, 3 seats, 108 tiles, kita, no chi)
+// so that the seat count and the sanma switches are compile-time constants on each variant's hot path.
+#include "rmj_common.hip.h"
 
-namespace rmj {
-
-struct Env {
-    GState* core;
-    uint8_t* wall;        // [B][RMJ_WALL_STRIDE]
-    uint64_t* legal;      // [B][4][64]
-    uint8_t* nlegal;      // [B][4]
-    uint8_t* mask;        // [B][4][82]
-    uint64_t* waits;      // [B][4]
-    uint32_t* status;     // [B]  active_mask | phase<<8 | done<<16
-    RmjEvent* events;     // [B][ring]
-    uint32_t ring_mask;   // ring-1
-    uint32_t n_games;
-    uint32_t rule_bits;
-    uint32_t game_mode;
-    uint32_t skip_log;
-    uint32_t ctor_round_wind;
-    uint64_t game_offset;
-    ShantenTables sh;     // replacement-number tables (prefilter of the riichi probe)
-};
-
-struct WaveScratch {      // per-wave LDS scratch
-    uint64_t keys[136];
-    uint8_t tiles[144];
-    uint8_t maskbuf[4 * 82 + 8];
-    uint64_t legal[4][RMJ_MAX_LEGAL];  // lists produced this launch (copied to HBM by finalize_outputs)
-    uint64_t wout[4];                  // waits produced this launch
-    int nl[4];                         // list lengths produced this launch
-};
+namespace RMJ_NS {
+using namespace rmj;
+constexpr bool KSANMA = (RMJ_SANMA != 0);  // game_mode >= 3 (game_variant.rs:12-37)
+constexpr int KNP = KSANMA ? 3 : 4;        // seats in play; seat 3 is inert in 3P
 
 struct Ctx {
     GState& S;
@@ -70,92 +45,12 @@ struct CtxV {
     uint32_t g;
     int lane;
 };
+#undef CTX_FROM
 #define CTX_FROM(v) Ctx c{*(v).S, *(v).E, *(v).X, (v).g, (v).lane, (v).W, (v).Lg}
 __device__ __forceinline__ CtxV ctx_pack(const Ctx& c) {
     CtxV v;
     v.S = &c.S; v.X = &c.X; v.W = c.W; v.Lg = c.Lg; v.E = &c.E; v.g = c.g; v.lane = c.lane;
     return v;
-}
-
-__device__ __forceinline__ void wave_sync() {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-}
-__device__ __forceinline__ uint64_t lanemask_lt(int lane) { return (1ull << lane) - 1ull; }
-
-// ---------------------------------------------------------------- packed actions
-__device__ __forceinline__ uint64_t mk_action(uint32_t type, uint32_t tile, uint32_t n, uint32_t c0 = 0, uint32_t c1 = 0, uint32_t c2 = 0,
-                                              uint32_t c3 = 0) {
-    return (uint64_t)type | ((uint64_t)tile << 8) | ((uint64_t)n << 16) | ((uint64_t)c0 << 24) | ((uint64_t)c1 << 32) |
-           ((uint64_t)c2 << 40) | ((uint64_t)c3 << 48);
-}
-__device__ __forceinline__ uint32_t a_type(uint64_t a) { return (uint32_t)(a & 0xFF); }
-__device__ __forceinline__ uint32_t a_tile(uint64_t a) { return (uint32_t)((a >> 8) & 0xFF); }
-__device__ __forceinline__ uint32_t a_n(uint64_t a) { return (uint32_t)((a >> 16) & 0xFF); }
-__device__ __forceinline__ uint32_t a_c(uint64_t a, int i) { return (uint32_t)((a >> (24 + 8 * i)) & 0xFF); }
-// canonical form: consume tiles ascending (Action::new, action.rs:97-98), unused bytes zero
-__device__ inline uint64_t a_canon(uint64_t a) {
-    if (a == RMJ_NO_ACTION) return a;
-    uint32_t n = a_n(a);
-    if (n > 4) n = 4;
-    uint32_t c[4];
-#pragma unroll
-    for (int i = 0; i < 4; i++) c[i] = (uint32_t)i < n ? a_c(a, i) : 0xFFFFu;
-#pragma unroll
-    for (int i = 0; i < 4; i++)
-#pragma unroll
-        for (int j = 0; j < 3; j++)
-            if (c[j] > c[j + 1]) { uint32_t t = c[j]; c[j] = c[j + 1]; c[j + 1] = t; }
-#pragma unroll
-    for (int i = 0; i < 4; i++)
-        if ((uint32_t)i >= n) c[i] = 0;
-    return mk_action(a_type(a), a_tile(a), n, c[0], c[1], c[2], c[3]);
-}
-// action.rs:158-227
-__device__ inline int a_encode(uint64_t a) {
-    uint32_t ty = a_type(a), tile = a_tile(a);
-    switch (ty) {
-        case RMJ_DISCARD: return tile / 4;
-        case RMJ_RIICHI: return 37;
-        case RMJ_CHI: {
-            uint32_t tt = tile / 4, x = a_c(a, 0) / 4, y = a_c(a, 1) / 4;
-            uint32_t lo = min(tt, min(x, y)), hi = max(tt, max(x, y));
-            return tt == lo ? 38 : (tt == hi ? 40 : 39);
-        }
-        case RMJ_PON: return 41;
-        case RMJ_DAIMINKAN: return 42 + tile / 4;
-        case RMJ_ANKAN:
-        case RMJ_KAKAN: return 42 + a_c(a, 0) / 4;
-        case RMJ_RON:
-        case RMJ_TSUMO: return 79;
-        case RMJ_KYUSHU: return 80;
-        case RMJ_PASS: return 81;
-        default: return -1;
-    }
-}
-// validation match, state/mod.rs:344-393 (quirk Q13)
-__device__ inline bool a_match(uint64_t l, uint64_t act) {
-    uint32_t lt = a_type(l);
-    if (lt != a_type(act)) return false;
-    bool tiles_match = a_tile(l) == a_tile(act);
-    bool cons_match = (l >> 16) == (act >> 16);
-    bool act_empty = a_n(act) == 0;
-    if (tiles_match) {
-        if (cons_match) return true;
-        if (act_empty && lt == RMJ_KAKAN) return true;
-        if (act_empty && (lt == RMJ_DISCARD || lt == RMJ_RIICHI || lt == RMJ_TSUMO || lt == RMJ_RON || lt == RMJ_PASS)) return true;
-    }
-    if (cons_match && (lt == RMJ_ANKAN || lt == RMJ_KAKAN)) return true;
-    if (a_tile(act) == RMJ_TILE_NONE) return lt == RMJ_TSUMO || lt == RMJ_RON || lt == RMJ_RIICHI || lt == RMJ_KYUSHU || lt == RMJ_KITA;
-    return false;
-}
-
-__device__ __forceinline__ uint64_t sm64(uint64_t x) {  // state/wall.rs:83-88
-    uint64_t z = x + 0x9E3779B97F4A7C15ull;
-    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
-    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
-    return z ^ (z >> 31);
 }
 
 // ---------------------------------------------------------------- events
@@ -167,7 +62,7 @@ __device__ __forceinline__ void emit_words(Ctx& c, uint32_t w0, uint32_t w1, uin
     uint4* dst = reinterpret_cast<uint4*>(c.E.events + (size_t)c.g * (c.E.ring_mask + 1u) + idx);
     if (c.lane == 0) {
         dst[0] = make_uint4(w0, w1, w2, w3);
-        dst[1] = make_uint4(w4, w5, w6, w7);
+        dst[1] = make_uint4(w4, w5, w6, (w7 & 0x00FFFFFFu) | ((uint32_t)KNP << 24));  // pad byte = seats (formatter)
     }
     c.S.ev_count += 1;
 }
@@ -195,76 +90,7 @@ __device__ __forceinline__ void emit_meld(Ctx& c, uint8_t type, uint8_t actor, u
                (n << 4) & 0xFFu, 0);
 }
 
-// ---------------------------------------------------------------- small helpers
 __device__ __forceinline__ bool rule(const Ctx& c, uint32_t bit) { return (c.E.rule_bits & bit) != 0; }
-__device__ __forceinline__ bool is_terminal_tile136(int t) {  // types.rs:362-367
-    int tt = t / 4;
-    return tt >= 27 || (tt % 9) == 0 || (tt % 9) == 8;
-}
-__device__ __forceinline__ int next_dora34(int t, bool sanma) {  // hand_evaluator.rs:286-300 / _3p.rs:300-311
-    if (sanma) {
-        if (t == 0) return 8;
-        if (t == 8) return 0;
-        if (t < 9) return t;
-    }
-    if (t < 27) return (t % 9 == 8) ? t - 8 : t + 1;
-    if (t < 31) return t == 30 ? 27 : t + 1;
-    return t == 33 ? 31 : t + 1;
-}
-__device__ __forceinline__ bool is_aka(int t) { return t == 16 || t == 52 || t == 88; }
-
-// concealed histogram of a seat (optionally skipping hand index `skip`)
-__device__ __forceinline__ PH build_ph(const PState& P, int skip = -1) {
-    PH h = {0, 0, 0, 0};
-    int n = P.hand_len;
-    for (int j = 0; j < n; j++)
-        if (j != skip) ph_add(h, P.hand[j] >> 2);
-    return h;
-}
-__device__ inline MeldAgg build_meld_agg(const PState& P) {
-    MeldAgg m;
-    m.n = P.n_melds;
-    m.n_kan = m.n_ankan = m.n_nonchi = 0;
-    m.menzen = true;
-    m.types = 0;
-    m.fu = 0;
-    m.aka = 0;
-#pragma unroll
-    for (int i = 0; i < 4; i++) {
-        m.mtypes[i] = 0;
-        m.mtype[i] = 0;
-        m.t0[i] = 0;
-        if (i < m.n) {
-            uint8_t ty = P.meld_type[i];
-            int nt = (ty >= RMJ_MELD_DAIMINKAN) ? 4 : 3;
-            uint64_t mm = 0;
-            for (int k = 0; k < nt; k++) {
-                int t = P.meld_tiles[i][k];
-                mm |= 1ull << (t >> 2);
-                m.aka += is_aka(t);
-            }
-            m.mtypes[i] = mm;
-            m.types |= mm;
-            m.mtype[i] = ty;
-            int t0 = P.meld_tiles[i][0] >> 2;  // tiles sorted by id -> lowest type first (== chi sort)
-            m.t0[i] = (uint8_t)t0;
-            bool opened = ty != RMJ_MELD_ANKAN;
-            if (opened) m.menzen = false;
-            bool kan = ty >= RMJ_MELD_DAIMINKAN;
-            m.n_kan += kan;
-            m.n_ankan += (ty == RMJ_MELD_ANKAN);
-            m.n_nonchi += (ty != RMJ_MELD_CHI);
-            if (ty != RMJ_MELD_CHI) {  // tiles[0] == tiles[1]
-                int f = opened ? 2 : 4;
-                if (t_is_terminal(t0)) f *= 2;
-                if (kan) f *= 4;
-                m.fu += f;
-            }
-        }
-    }
-    return m;
-}
-
 // rank-sort the first n tiles of a hand (ids are unique)
 __device__ __forceinline__ void sort_hand(Ctx& c, PState& P, int n) {
     int t = 0, r = 0;
@@ -301,7 +127,8 @@ struct Cond {
     uint32_t honba;
 };
 // seat's concealed tiles = hand minus `skip_idx` (-1: none); win tile added iff total == 13
-__device__ __forceinline__ CalcOut seat_calc_impl(Ctx& c, int seat, int skip_idx, int win_tile, uint32_t cf, uint32_t honba, bool use_ura) {
+__device__ __forceinline__ CalcOut seat_calc_impl(Ctx& c, int seat, int skip_idx, int win_tile, uint32_t cf, uint32_t honba, bool use_ura,
+                                                  int kita_count) {
     GState& S = c.S;
     PState& P = S.p[seat];
     CalcIn in;
@@ -327,28 +154,41 @@ __device__ __forceinline__ CalcOut seat_calc_impl(Ctx& c, int seat, int skip_idx
         for (int k = 0; k < nt; k++) ph_add(full, P.meld_tiles[i][k] >> 2);
     }
     int dora = 0, ura = 0;
-    for (int k = 0; k < S.n_dora; k++) dora += ph_cnt(full, next_dora34(S.dora[k] >> 2, false));
+    const bool sanma = KSANMA;
+    for (int k = 0; k < S.n_dora; k++) {
+        int nt = next_dora34(S.dora[k] >> 2, sanma);
+        dora += ph_cnt(full, nt);
+        if (sanma && nt == 30) dora += kita_count;  // hand_evaluator_3p.rs:110-116
+    }
     if (use_ura)
-        for (int k = 0; k < S.n_dora; k++) {  // _get_ura_indicators, state/mod.rs:2048-2057
-            int idx = 5 + 2 * k;              // W index (rinshan shift folded into the fixed array)
-            if (idx < S.live_end) ura += ph_cnt(full, next_dora34(c.W[idx] >> 2, false));
+        for (int k = 0; k < S.n_dora; k++) {  // _get_ura_indicators, state/mod.rs:2048-2057 ; 3P: pre-extracted W[9+2k]
+            int idx = sanma ? 9 + 2 * k : 5 + 2 * k;
+            if (sanma || idx < S.live_end) {
+                int nt = next_dora34(c.W[idx] >> 2, sanma);
+                ura += ph_cnt(full, nt);
+                if (sanma && nt == 30) ura += kita_count;
+            }
         }
     in.hand14 = h;
     in.win34 = win34;
     in.cf = cf;
-    in.dora = dora; in.aka = aka; in.ura = ura; in.nuki = 0;
+    in.dora = dora & 0xFF; in.aka = aka; in.ura = ura & 0xFF; in.nuki = sanma ? kita_count : 0;
     in.round_wind34 = 27 + (S.round_wind & 3);
-    in.seat_wind34 = 27 + ((seat + 4 - S.oya) & 3);
-    in.sanma = false;
+    in.seat_wind34 = 27 + ((seat + KNP - S.oya) % KNP);
+    in.sanma = sanma;
     in.honba = honba;
     return wave_calc(in, c.lane);
 }
-__device__ __noinline__ CalcOut ol_seat_calc(CtxV v, int seat, int skip_idx, int win_tile, uint32_t cf, uint32_t honba, bool use_ura) {
+__device__ __noinline__ CalcOut ol_seat_calc(CtxV v, int seat, int skip_idx, int win_tile, uint32_t cf, uint32_t honba, bool use_ura,
+                                             int kita_count) {
     CTX_FROM(v);
-    return seat_calc_impl(c, seat, skip_idx, win_tile, cf, honba, use_ura);
+    return seat_calc_impl(c, seat, skip_idx, win_tile, cf, honba, use_ura, kita_count);
 }
-__device__ __forceinline__ CalcOut seat_calc(Ctx& c, int seat, int skip_idx, int win_tile, uint32_t cf, uint32_t honba, bool use_ura) {
-    return ol_seat_calc(ctx_pack(c), seat, skip_idx, win_tile, cf, honba, use_ura);
+// kita_count: Conditions.kita_count — the reference passes it only at settlement and in the kita ron check
+// (state_3p/mod.rs:635,926; sanma.rs:115), legality checks leave it 0.
+__device__ __forceinline__ CalcOut seat_calc(Ctx& c, int seat, int skip_idx, int win_tile, uint32_t cf, uint32_t honba, bool use_ura,
+                                             int kita_count = 0) {
+    return ol_seat_calc(ctx_pack(c), seat, skip_idx, win_tile, cf, honba, use_ura, kita_count);
 }
 __device__ inline uint32_t base_cf(const PState& P) {
     uint32_t cf = 0;
@@ -441,7 +281,7 @@ __device__ __forceinline__ bool gen_claims(Ctx& c, int i, int pid, int tile) {
         }
     }
     // Chi: lane = pattern*16 + a*4 + b
-    bool shimocha = i == ((pid + 1) & 3);
+    bool shimocha = !KSANMA && i == ((pid + 1) & 3);  // no Chi in 3P (state_3p/legal_actions.rs:386)
     if (!riichi && S.drawable_count > 0 && shimocha && hl >= 3 && tt < 27) {
         int r9 = tt % 9;
         int k = lane >> 4, a = (lane >> 2) & 3, b = lane & 3;
@@ -480,6 +320,7 @@ __device__ __forceinline__ bool gen_claims(Ctx& c, int i, int pid, int tile) {
         }
         n += __popcll(vb);
     }
+    S.stale_n[i] = (uint8_t)(n > 62 ? 62 : n);
     if (n > 0) {
         put_legal(c, i, n, mk_action(RMJ_PASS, RMJ_TILE_NONE, 0));
         c.X.nl[i] = n + 1;
@@ -497,6 +338,7 @@ __device__ __forceinline__ uint32_t tenpai_after_discard(Ctx& c, const PState& P
     PH full = build_ph(P);
     // Sound prefilter: a tenpai 13-tile subset implies replacement number <= 1 for the 14 tiles
     // (swap the discard for the winning tile), i.e. shanten(14) <= 0.  Only then run the exact probes.
+    // (4P tables; a sanma hand has no 2m-8m, for which the 4P number is a lower bound of the 3P one, so it is sound too)
     if (sh_shanten_wave(full, hl / 3, c.E.sh, c.lane) > 0) return 0;
     int prev_ty = -1;
     bool prev_res = false;
@@ -554,7 +396,8 @@ __device__ __forceinline__ void gen_act_legal(Ctx& c, int pid) {
         bool need_tp = r_stage;
         bool all_closed = true;
         for (int i = 0; i < P.n_melds; i++) all_closed = all_closed && (P.meld_type[i] == RMJ_MELD_ANKAN);
-        bool riichi_pre = !r_stage && P.score >= 1000 && S.drawable_count >= 4 && all_closed;
+        // quirk Q8: >= 4 in 4P, > 0 in 3P
+        bool riichi_pre = !r_stage && P.score >= 1000 && (KSANMA ? S.drawable_count > 0 : S.drawable_count >= 4) && all_closed;
         if (need_tp || riichi_pre) tp = tenpai_after_discard(c, P);
         bool ok = lane < hl && !forb && (!r_stage || ((tp >> lane) & 1u));
         uint64_t vb = __ballot(ok);
@@ -639,7 +482,31 @@ __device__ __forceinline__ void gen_act_legal(Ctx& c, int pid) {
         }
         if (__popcll(tm) >= 9) put_legal(c, pid, n++, mk_action(RMJ_KYUSHU, RMJ_TILE_NONE, 0));
     }
+    // 5. Kita (state_3p/sanma.rs:146-169): one action per North tile in hand, hand order
+    if (KSANMA && drawn && S.drawable_count > 0) {
+        bool hit = lane < hl && (ht >> 2) == 30;
+        uint64_t kb = __ballot(hit);
+        if (hit) {
+            int pos = n + __popcll(kb & lanemask_lt(lane));
+            if (pos < RMJ_MAX_LEGAL) c.X.legal[pid][pos] = mk_action(RMJ_KITA, ht, 0);
+        }
+        n += __popcll(kb);
+    }
     c.X.nl[pid] = n > RMJ_MAX_LEGAL ? RMJ_MAX_LEGAL : n;
+}
+
+// current_claims.entry(i).or_default().push(Ron) (state/mod.rs:524-533, 665-673; sanma.rs:121-128): the Ron offer is
+// APPENDED to whatever the seat still has in current_claims (see GState::stale_n).
+__device__ __forceinline__ void offer_ron(Ctx& c, int i, int tile) {
+    GState& S = c.S;
+    int sn = S.stale_n[i];
+    if (c.lane < sn) c.X.legal[i][c.lane] = c.Lg[i * RMJ_MAX_LEGAL + c.lane];
+    wave_sync();
+    put_legal(c, i, sn, mk_action(RMJ_RON, tile, 0));
+    put_legal(c, i, sn + 1, mk_action(RMJ_PASS, RMJ_TILE_NONE, 0));
+    c.X.nl[i] = sn + 2;
+    S.stale_n[i] = (uint8_t)(sn + 1 > 62 ? 62 : sn + 1);
+    S.ron_offer_mask |= (uint8_t)(1u << i);
 }
 
 // ---------------------------------------------------------------- transitions
@@ -653,8 +520,9 @@ __device__ __forceinline__ void reveal_kan_dora(Ctx& c) {
     GState& S = c.S;
     int count = S.n_dora;
     if (count < 5) {
-        int widx = 4 + 2 * count;  // fixed-array index; tiles[base_idx] with base_idx = widx - rinshan_count
-        if (widx < S.live_end) {
+        // 4P: tiles[4+2k-rinshan] = W[4+2k] if still inside the wall; 3P: pre-extracted W[8+2k], no bound check
+        int widx = KSANMA ? 8 + 2 * count : 4 + 2 * count;
+        if (KSANMA || widx < S.live_end) {
             uint8_t t = c.W[widx];
             S.dora[count] = t;
             S.n_dora = (uint8_t)(count + 1);
@@ -715,7 +583,7 @@ __device__ inline void shuffle_wall(Ctx& c) {
     GState& S = c.S;
     uint64_t hs = sm64(S.wall_seed + (uint64_t)S.hand_index);
     S.hand_index += 1;
-    const int N = 136;
+    const int N = KSANMA ? 108 : 136;  // 3P: ids without 2m-8m (types.rs:378-382)
     for (int i = c.lane; i < N; i += 64) c.X.keys[i] = sm64(hs + (uint64_t)i * 0x9E3779B97F4A7C15ull);
     wave_sync();
     for (int i = c.lane; i < N; i += 64) {
@@ -725,7 +593,8 @@ __device__ inline void shuffle_wall(Ctx& c) {
             uint64_t kj = c.X.keys[j];
             r += (kj < k) || (kj == k && j < i);
         }
-        c.X.tiles[N - 1 - r] = (uint8_t)i;  // w[r] = i, then reverse
+        int id = (KSANMA && i >= 4) ? i + 28 : i;  // i-th id of the tile universe
+        c.X.tiles[N - 1 - r] = (uint8_t)id;  // w[r] = id, then reverse
     }
     wave_sync();
 }
@@ -750,7 +619,8 @@ __device__ inline void init_round(Ctx& c, int oya, int round_wind, int honba, ui
         P.score_delta = 0;
         P.discard_from_hand_bits = 0; P.discard_is_riichi_bits = 0;
         P.discard_type_mask = 0;
-        if (scores) P.score = scores[p];
+        P.n_kita = 0;
+        if (scores && p < KNP) P.score = scores[p];
     }
     S.is_done = 0;
     S.pending_kan_pid = 0xFF;
@@ -765,31 +635,35 @@ __device__ inline void init_round(Ctx& c, int oya, int round_wind, int honba, ui
     S.last_discard_pid = 0xFF;
     S.last_discard_tile = 0;
     S.ron_offer_mask = 0;
+    for (int p = 0; p < 4; p++) S.stale_n[p] = 0;
     // publish the wall to HBM (W) and deal from LDS
     for (int i = lane; i < RMJ_WALL_STRIDE / 4; i += 64)
         reinterpret_cast<uint32_t*>(c.W)[i] = (i < 34) ? reinterpret_cast<const uint32_t*>(c.X.tiles)[i] : 0u;
-    S.wall_total = 136;
+    const int np = KNP;
+    const int total = KSANMA ? 108 : 136;
+    S.wall_total = (uint8_t)total;
     S.n_dora = 1;
-    S.dora[0] = c.X.tiles[4];
-    // deal: pop #n = X.tiles[135 - n]
-    if (lane < 52) {
+    S.dora[0] = c.X.tiles[KSANMA ? 8 : 4];  // state_3p/wall.rs:104-112
+    // deal: pop #n = X.tiles[total - 1 - n]; three rounds of 4 tiles per seat from the dealer, then one each
+    if (lane < 13 * np) {
         int n = lane, p, pos;
-        if (n < 48) {
-            int r = n >> 4, idx = (n & 15) >> 2, k = n & 3;
-            p = (idx + oya) & 3;
+        if (n < 12 * np) {
+            int r = n / (4 * np), rem = n - r * 4 * np;
+            int idx = rem >> 2, k = rem & 3;
+            p = (idx + oya) % np;
             pos = r * 4 + k;
         } else {
-            p = ((n - 48) + oya) & 3;
+            p = ((n - 12 * np) + oya) % np;
             pos = 12;
         }
-        S.p[p].hand[pos] = c.X.tiles[135 - n];
+        S.p[p].hand[pos] = c.X.tiles[total - 1 - n];
     }
     wave_sync();
-    for (int p = 0; p < 4; p++) {
+    for (int p = 0; p < np; p++) {
         S.p[p].hand_len = 13;
         sort_hand(c, S.p[p], 13);
     }
-    S.live_end = (uint8_t)(136 - 52);
+    S.live_end = (uint8_t)(total - 13 * np);
     S.drawable_count = (uint8_t)(S.live_end - 14);
     if (!c.E.skip_log) {
         RmjEvent e = ev_zero(RMJ_EV_START_KYOKU);
@@ -800,7 +674,7 @@ __device__ inline void init_round(Ctx& c, int oya, int round_wind, int honba, ui
         e.consumed[1] = (uint8_t)honba;
         e.consumed[2] = (uint8_t)(kyotaku & 0xFF);
         e.consumed[3] = (uint8_t)((kyotaku >> 8) & 0xFF);
-        for (int p = 0; p < 4; p++) e.deltas[p] = S.p[p].score;
+        for (int p = 0; p < 4; p++) e.deltas[p] = p < np ? S.p[p].score : 0;
         emit_raw(c, e);
         for (int half = 0; half < 2; half++) {
             RmjEvent t = ev_zero(RMJ_EV_TEHAI);
@@ -808,7 +682,7 @@ __device__ inline void init_round(Ctx& c, int oya, int round_wind, int honba, ui
             uint8_t* pl = reinterpret_cast<uint8_t*>(&t) + 4;
             for (int k = 0; k < 13; k++) {
                 pl[k] = S.p[2 * half].hand[k];
-                pl[13 + k] = S.p[2 * half + 1].hand[k];
+                pl[13 + k] = (2 * half + 1 < np) ? S.p[2 * half + 1].hand[k] : 0;
             }
             emit_raw(c, t);
         }
@@ -832,11 +706,12 @@ __device__ __noinline__ void ol_init_next_round(CtxV v, bool oya_won, bool is_dr
     CTX_FROM(v);
     GState& S = c.S;
     if (S.is_done) return;
-    const int np = 4;
-    int32_t sc[4];
+    const int np = KNP;
+    const int32_t goal = KSANMA ? 40000 : 30000;  // state_3p/mod.rs:1524,1553,1561
+    int32_t sc[4] = {0, 0, 0, 0};
     bool neg = false;
     int32_t max_score = S.p[0].score;
-    for (int p = 0; p < 4; p++) {
+    for (int p = 0; p < np; p++) {
         sc[p] = S.p[p].score;
         neg = neg || sc[p] < 0;
         max_score = max(max_score, sc[p]);
@@ -845,12 +720,12 @@ __device__ __noinline__ void ol_init_next_round(CtxV v, bool oya_won, bool is_dr
     int oya = S.oya;
     int32_t ds = sc[oya];
     bool top = true;
-    for (int seat = 0; seat < 4; seat++) top = top && (seat == oya || ds > sc[seat] || (ds == sc[seat] && oya <= seat));
+    for (int seat = 0; seat < np; seat++) top = top && (seat == oya || ds > sc[seat] || (ds == sc[seat] && oya <= seat));
     uint32_t gm = c.E.game_mode;
     bool last_regular = false;
     if (gm == 1 || gm == 4) last_regular = S.round_wind == 0 && oya == np - 1;
     if (gm == 2 || gm == 5) last_regular = S.round_wind == 1 && oya == np - 1;
-    if (oya_won && last_regular && top && ds >= 30000) { process_end_game(c); return; }
+    if (oya_won && last_regular && top && ds >= goal) { process_end_game(c); return; }
     int next_honba = S.honba, next_oya = oya, next_rw = S.round_wind;
     if (oya_won) {
         next_honba = min(next_honba + 1, 255);
@@ -860,8 +735,8 @@ __device__ __noinline__ void ol_init_next_round(CtxV v, bool oya_won, bool is_dr
         if (next_oya == 0) next_rw += 1;
     }
     bool end = false;
-    if (gm == 1 || gm == 4) end = next_rw >= 1 && (max_score >= 30000 || next_rw > 1);
-    else if (gm == 2 || gm == 5) end = next_rw >= 2 && (max_score >= 30000 || next_rw > 2);
+    if (gm == 1 || gm == 4) end = next_rw >= 1 && (max_score >= goal || next_rw > 1);
+    else if (gm == 2 || gm == 5) end = next_rw >= 2 && (max_score >= goal || next_rw > 2);
     else if (gm == 0 || gm == 3) end = true;
     else end = next_rw >= 1;
     if (end) { process_end_game(c); return; }
@@ -881,7 +756,7 @@ __device__ __noinline__ void ol_trigger_ryukyoku(CtxV v, int reason, int offende
     CTX_FROM(v);
     GState& S = c.S;
     accept_riichi(c);
-    const int np = 4;
+    const int np = KNP;
     bool tenpai[4] = {false, false, false, false};
     int final_reason = reason;
     uint32_t nagashi = 0;
@@ -905,7 +780,8 @@ __device__ __noinline__ void ol_trigger_ryukyoku(CtxV v, int reason, int offende
         } else {
             int num_tp = tenpai[0] + tenpai[1] + tenpai[2] + tenpai[3];
             if (num_tp > 0 && num_tp < np) {
-                int32_t pk = 3000 / num_tp, pn = 3000 / (np - num_tp);
+                const int32_t pool = KSANMA ? 2000 : 3000;  // state_3p/game_mode.rs:39-41
+                int32_t pk = pool / num_tp, pn = pool / (np - num_tp);
                 for (int i = 0; i < np; i++) {
                     int32_t d = tenpai[i] ? pk : -pn;
                     S.p[i].score += d;
@@ -953,7 +829,7 @@ __device__ __forceinline__ bool check_abortive_draw(Ctx& c) {
         melds_empty = melds_empty && S.p[p].n_melds == 0;
         all_riichi = all_riichi && (S.p[p].flags & PF_RIICHI_DECLARED);
     }
-    if (turns_ok && melds_empty) {
+    if (!KSANMA && turns_ok && melds_empty) {  // sufuurenta and suucha riichi are disabled in 3P (state_3p/mod.rs:1861-1888)
         int first = S.p[0].discards[0] >> 2;
         if (first >= 27 && first <= 30) {
             bool all = true;
@@ -971,7 +847,7 @@ __device__ __forceinline__ bool check_abortive_draw(Ctx& c) {
                 else same = same && (p == first_owner);
             }
     if (kans == 4 && !same) { trigger_ryukyoku(c, RMJ_RK_SUUKANSANSEN, 0); return true; }
-    if (all_riichi) { trigger_ryukyoku(c, RMJ_RK_SUUCHA_RIICHI, 0); return true; }
+    if (!KSANMA && all_riichi) { trigger_ryukyoku(c, RMJ_RK_SUUCHA_RIICHI, 0); return true; }
     return false;
 }
 
@@ -1066,6 +942,7 @@ __device__ __noinline__ void ol_resolve_kan(CtxV v, int pid, uint64_t action) {
 __device__ __forceinline__ void resolve_discard(Ctx& c, int pid, int tile, bool tsumogiri) {
     GState& S = c.S;
     PState& P = S.p[pid];
+    if (KSANMA) { S.pending_kan_pid = 0xFF; S.pending_kan_action = 0; }  // quirk Q11 (state_3p/mod.rs:1224-1227)
     S.is_rinshan = 0;
     P.flags &= ~PF_IPPATSU;
     int nd = P.n_discards;
@@ -1100,7 +977,8 @@ __device__ __forceinline__ void resolve_discard(Ctx& c, int pid, int tile, bool 
     uint32_t claim_active = 0;
     for (int i = 0; i < 4; i++) {
         c.X.nl[i] = 0;
-        if (i == pid) continue;
+        S.stale_n[i] = 0;
+        if (i == pid || i >= KNP) continue;
         if (gen_claims(c, i, pid, tile)) claim_active |= 1u << i;
     }
     if (claim_active) {
@@ -1110,9 +988,9 @@ __device__ __forceinline__ void resolve_discard(Ctx& c, int pid, int tile, bool 
         if (S.riichi_pending != 0xFF) accept_riichi(c);
         if (!check_abortive_draw(c)) {
             S.turn_count += 1;
-            S.current_player = (uint8_t)((pid + 1) & 3);
+            S.current_player = (uint8_t)((pid + 1) % KNP);
             deal_next(c);
-            if (S.turn_count >= 4) S.is_first_turn = 0;
+            if (S.turn_count >= (uint32_t)KNP) S.is_first_turn = 0;
         }
     }
 }
@@ -1135,7 +1013,7 @@ __device__ inline void cap_double(const Ctx& c, CalcOut& r, bool is_oya, bool ts
         if (cap > 0) {
             int h = r.han > cap ? r.han - cap : 0;
             r.han = h < 13 ? 13 : h;
-            ScoreOut s = calc_score((uint32_t)r.han, 0, is_oya, tsumo, honba, 4);
+            ScoreOut s = calc_score((uint32_t)r.han, 0, is_oya, tsumo, honba, (uint32_t)KNP);
             r.ron = s.ron; r.tsumo_oya = s.tsumo_oya; r.tsumo_ko = s.tsumo_ko;
         }
     }
@@ -1167,11 +1045,76 @@ __device__ inline void emit_hora(Ctx& c, int actor, int target, const int32_t* d
     int nu = 0;
     if (riichi)
         for (int k = 0; k < S.n_dora; k++) {
-            int idx = 5 + 2 * k;
-            if (idx < S.live_end && nu < 5) e.ura[nu++] = c.W[idx];
+            int idx = KSANMA ? 9 + 2 * k : 5 + 2 * k;
+            if ((KSANMA || idx < S.live_end) && nu < 5) e.ura[nu++] = c.W[idx];
         }
     e.n_ura = (uint8_t)nu;
     emit_raw(c, e);
+}
+
+// state_3p/sanma.rs:171-204
+__device__ inline void resolve_kita_rinshan(Ctx& c, int pid) {
+    GState& S = c.S;
+    if (S.drawable_count > 0) {
+        flush_pending_kan_dora(c);
+        uint8_t t = c.W[S.rinshan_count];  // draw_rinshan_tile (state_3p/wall.rs:117-124)
+        S.rinshan_count += 1;
+        S.drawable_count -= 1;
+        PState& P = S.p[pid];
+        if (P.hand_len < 14) P.hand[P.hand_len++] = t;
+        S.drawn_tile = t;
+        S.is_rinshan = 1;
+        emit_simple(c, RMJ_EV_TSUMO, (uint8_t)pid, t);  // no new dora for kita
+        S.phase = RMJ_WAIT_ACT;
+        S.active_mask = (uint8_t)(1u << pid);
+    }
+}
+// state_3p/sanma.rs:9-144
+__device__ inline void handle_kita(Ctx& c, int pid, uint64_t act) {
+    GState& S = c.S;
+    PState& P = S.p[pid];
+    const int lane = c.lane;
+    int tile;
+    if (a_tile(act) != RMJ_TILE_NONE && (a_tile(act) >> 2) == 30) tile = (int)a_tile(act);
+    else {
+        uint64_t nb = __ballot(lane < P.hand_len && (P.hand[lane] >> 2) == 30);
+        if (nb) tile = P.hand[__ffsll((long long)nb) - 1];
+        else tile = a_tile(act) != RMJ_TILE_NONE ? (int)a_tile(act) : (a_n(act) ? (int)a_c(act, 0) : 0);
+    }
+    int idx = hand_find(c, P, tile);
+    if (idx >= 0) hand_remove_at(c, P, idx);
+    waits_invalidate(P);
+    if (P.n_kita < 4) P.kita[P.n_kita++] = (uint8_t)tile;
+    S.is_first_turn = 0;
+    emit_simple(c, RMJ_EV_KITA, (uint8_t)pid, (uint8_t)tile);
+    flush_pending_kan_dora(c);
+    uint32_t ronners = 0;
+    S.ron_offer_mask = 0;
+    for (int i = 0; i < 4; i++) {
+        c.X.nl[i] = 0;
+        if (i == pid || i >= KNP) continue;
+        PState& Q = S.p[i];
+        uint64_t W = seat_waits(c, i);
+        c.X.wout[i] = W;
+        bool furiten = (W & Q.discard_type_mask) != 0ull || (Q.flags & (PF_MISSED_RIICHI | PF_MISSED_DOUJUN));
+        if (furiten || !((W >> (tile >> 2)) & 1ull)) continue;
+        CalcOut r = seat_calc(c, i, -1, tile, base_cf(Q), S.honba, false, Q.n_kita);  // chankan: false (sanma.rs:106)
+        if (r.is_win && (r.yakuman || r.han >= 1)) {
+            ronners |= 1u << i;
+            offer_ron(c, i, tile);
+        }
+    }
+    if (ronners) {
+        S.phase = RMJ_WAIT_RESPONSE;
+        S.active_mask = (uint8_t)ronners;
+        S.last_discard_pid = (uint8_t)pid;
+        S.last_discard_tile = (uint8_t)tile;
+        S.pending_kan_pid = (uint8_t)pid;
+        S.pending_kan_action = act;
+    } else {
+        for (int p = 0; p < 4; p++) S.p[p].flags &= ~PF_IPPATSU;
+        resolve_kita_rinshan(c, pid);
+    }
 }
 
 // ---------------------------------------------------------------- step (state/mod.rs:330-1315)
@@ -1222,7 +1165,8 @@ __device__ __forceinline__ void step_game(Ctx& c, const uint64_t acts_in[4]) {
         } else if (ty == RMJ_KYUSHU) {
             trigger_ryukyoku(c, RMJ_RK_KYUSHU, 0);
         } else if (ty == RMJ_RIICHI) {
-            if (P.score >= 1000 && S.drawable_count >= 4 && !(P.flags & (PF_RIICHI_DECLARED | PF_RIICHI_STAGE))) {
+            if (P.score >= 1000 && (KSANMA ? S.drawable_count > 0 : S.drawable_count >= 4) &&
+                !(P.flags & (PF_RIICHI_DECLARED | PF_RIICHI_STAGE))) {
                 P.flags |= PF_RIICHI_STAGE;
                 emit_simple(c, RMJ_EV_REACH, (uint8_t)pid);
                 if (a_tile(act) != RMJ_TILE_NONE) {  // unreachable through validation (quirk Q13), kept for parity
@@ -1242,7 +1186,7 @@ __device__ __forceinline__ void step_game(Ctx& c, const uint64_t acts_in[4]) {
                 S.ron_offer_mask = 0;
                 for (int i = 0; i < 4; i++) {
                     c.X.nl[i] = 0;
-                    if (i == pid) continue;
+                    if (i == pid || i >= KNP) continue;
                     PState& Q = S.p[i];
                     if ((Q.discard_type_mask >> (tile >> 2)) & 1ull) continue;
                     uint32_t cf = CF_CHANKAN | ((Q.flags & PF_RIICHI_DECLARED) ? CF_RIICHI : 0u);
@@ -1250,10 +1194,7 @@ __device__ __forceinline__ void step_game(Ctx& c, const uint64_t acts_in[4]) {
                     CalcOut r = seat_calc(c, i, -1, tile, cf, 0, false);
                     if (r.is_win && ((r.ym >> 42) & 1ull || (r.ym >> 49) & 1ull)) {
                         ronners |= 1u << i;
-                        put_legal(c, i, 0, mk_action(RMJ_RON, tile, 0));
-                        put_legal(c, i, 1, mk_action(RMJ_PASS, RMJ_TILE_NONE, 0));
-                        c.X.nl[i] = 2;
-                        S.ron_offer_mask |= (uint8_t)(1u << i);
+                        offer_ron(c, i, tile);
                     }
                 }
             }
@@ -1289,7 +1230,7 @@ __device__ __forceinline__ void step_game(Ctx& c, const uint64_t acts_in[4]) {
             S.ron_offer_mask = 0;
             for (int i = 0; i < 4; i++) {
                 c.X.nl[i] = 0;
-                if (i == pid) continue;
+                if (i == pid || i >= KNP) continue;
                 PState& Q = S.p[i];
                 uint64_t W = seat_waits(c, i);
                 c.X.wout[i] = W;
@@ -1299,10 +1240,7 @@ __device__ __forceinline__ void step_game(Ctx& c, const uint64_t acts_in[4]) {
                 CalcOut r = seat_calc(c, i, -1, tile, cf, S.honba, false);
                 if (r.is_win && (r.yakuman || r.han >= 1)) {
                     ronners |= 1u << i;
-                    put_legal(c, i, 0, mk_action(RMJ_RON, tile, 0));
-                    put_legal(c, i, 1, mk_action(RMJ_PASS, RMJ_TILE_NONE, 0));
-                    c.X.nl[i] = 2;
-                    S.ron_offer_mask |= (uint8_t)(1u << i);
+                    offer_ron(c, i, tile);
                 }
             }
             if (ronners) {
@@ -1323,7 +1261,7 @@ __device__ __forceinline__ void step_game(Ctx& c, const uint64_t acts_in[4]) {
             if (S.is_first_turn && no_melds) cf |= CF_FIRST_TURN;  // quirk Q5 (settlement form)
             int win_tile = S.drawn_tile != 0xFF ? S.drawn_tile : 0;
             bool riichi = P.flags & PF_RIICHI_DECLARED;
-            CalcOut res = seat_calc(c, pid, -1, win_tile, cf, S.honba, riichi);
+            CalcOut res = seat_calc(c, pid, -1, win_tile, cf, S.honba, riichi, KSANMA ? P.n_kita : 0);
             cap_double(c, res, pid == S.oya, true, S.honba);
             if (res.is_win) {
                 int32_t deltas[4] = {0, 0, 0, 0};
@@ -1331,8 +1269,10 @@ __device__ __forceinline__ void step_game(Ctx& c, const uint64_t acts_in[4]) {
                 int pao_payer = -1, pao_val = 0, total_val = 0;
                 if (res.yakuman) yakuman_totals(c, res, P, total_val, pao_val, pao_payer);
                 if (pao_val > 0) {
-                    int32_t unit = pid == S.oya ? 48000 : 32000;
-                    int32_t honba_total = (int32_t)S.honba * 3 * 100;
+                    // state_3p/mod.rs:713-721: (np-1)*16000 for the dealer, 16000+(np-2)*8000 otherwise
+                    const int np = KNP;
+                    int32_t unit = pid == S.oya ? (np - 1) * 16000 : 16000 + (np - 2) * 8000;
+                    int32_t honba_total = (int32_t)S.honba * (np - 1) * 100;
                     if (pao_payer >= 0) {
                         if (rule(c, RMJ_RULE_PAO_LIABILITY_ONLY)) {
                             int32_t pao_amt = pao_val * unit + honba_total;
@@ -1340,7 +1280,7 @@ __device__ __forceinline__ void step_game(Ctx& c, const uint64_t acts_in[4]) {
                             deltas[pao_payer] -= pao_amt;
                             total_win += pao_amt;
                             if (non > 0)
-                                for (int i = 0; i < 4; i++)
+                                for (int i = 0; i < np; i++)
                                     if (i != pid) {
                                         int32_t pay = (pid == S.oya) ? non * 16000 : (i == S.oya ? non * 16000 : non * 8000);
                                         deltas[i] -= pay;
@@ -1353,7 +1293,7 @@ __device__ __forceinline__ void step_game(Ctx& c, const uint64_t acts_in[4]) {
                         }
                     }
                 } else {
-                    for (int i = 0; i < 4; i++)
+                    for (int i = 0; i < KNP; i++)
                         if (i != pid) {
                             int32_t pay = (pid == S.oya) ? (int32_t)res.tsumo_ko : (i == S.oya ? (int32_t)res.tsumo_oya : (int32_t)res.tsumo_ko);
                             deltas[i] = -pay;
@@ -1367,9 +1307,11 @@ __device__ __forceinline__ void step_game(Ctx& c, const uint64_t acts_in[4]) {
                 emit_hora(c, pid, pid, deltas, true, riichi);
                 init_next_round(c, pid == S.oya, false);
             } else {
-                S.current_player = (uint8_t)((S.current_player + 1) & 3);
+                S.current_player = (uint8_t)((S.current_player + 1) % KNP);
                 deal_next(c);
             }
+        } else if (ty == RMJ_KITA && KSANMA) {
+            handle_kita(c, pid, act);
         }
         return;
     }
@@ -1389,7 +1331,7 @@ __device__ __forceinline__ void step_game(Ctx& c, const uint64_t acts_in[4]) {
         if (!((S.active_mask >> pid) & 1u) || acts[pid] == RMJ_NO_ACTION) continue;
         uint32_t ty = a_type(acts[pid]);
         if (ty == RMJ_RON) ron_mask |= 1u << pid;
-        else if (ty == RMJ_PON || ty == RMJ_DAIMINKAN || ty == RMJ_CHI) {
+        else if (ty == RMJ_PON || ty == RMJ_DAIMINKAN || (!KSANMA && ty == RMJ_CHI)) {
             if (claimer >= 0) {
                 bool old_pon = a_type(claim) == RMJ_PON || a_type(claim) == RMJ_DAIMINKAN;
                 bool new_pon = ty == RMJ_PON || ty == RMJ_DAIMINKAN;
@@ -1398,22 +1340,23 @@ __device__ __forceinline__ void step_game(Ctx& c, const uint64_t acts_in[4]) {
         }
     }
     if (ron_mask) {
-        if (__popc(ron_mask) >= 3 && rule(c, RMJ_RULE_SANCHAHO_DRAW)) { trigger_ryukyoku(c, RMJ_RK_SANCHAHO, 0); return; }
+        if (!KSANMA && __popc(ron_mask) >= 3 && rule(c, RMJ_RULE_SANCHAHO_DRAW)) { trigger_ryukyoku(c, RMJ_RK_SANCHAHO, 0); return; }
         int target = S.last_discard_pid != 0xFF ? S.last_discard_pid : S.current_player;
         int win_tile = S.last_discard_pid != 0xFF ? S.last_discard_tile : 0;
         int32_t total_d[4] = {0, 0, 0, 0};
         bool oya_won = false, deposit_taken = false, honba_taken = false;
-        for (int dist = 1; dist < 4; dist++) {  // winners sorted by distance from the discarder (state/mod.rs:954)
-            int w = (target + dist) & 3;
+        for (int dist = 1; dist < KNP; dist++) {  // winners sorted by distance from the discarder (state/mod.rs:954)
+            int w = (target + dist) % KNP;
             if (!((ron_mask >> w) & 1u)) continue;
             PState& Wp = S.p[w];
             uint32_t ron_honba = 0;
             if (!honba_taken) { honba_taken = true; ron_honba = S.honba; }
             uint32_t cf = base_cf(Wp);
             if (S.drawable_count == 0 && !S.is_rinshan) cf |= CF_HOUTEI;
-            if (S.pending_kan_pid != 0xFF) cf |= CF_CHANKAN;
+            // a pending kita is a chankan-style claim but awards no chankan yaku (state_3p/mod.rs:896-902)
+            if (S.pending_kan_pid != 0xFF && a_type(S.pending_kan_action) != RMJ_KITA) cf |= CF_CHANKAN;
             bool riichi = Wp.flags & PF_RIICHI_DECLARED;
-            CalcOut res = seat_calc(c, w, -1, win_tile, cf, ron_honba, riichi);
+            CalcOut res = seat_calc(c, w, -1, win_tile, cf, ron_honba, riichi, KSANMA ? Wp.n_kita : 0);
             cap_double(c, res, w == S.oya, false, ron_honba);
             if (res.is_win) {
                 int32_t score = (int32_t)res.ron;
@@ -1425,7 +1368,7 @@ __device__ __forceinline__ void step_game(Ctx& c, const uint64_t acts_in[4]) {
                     if (pp >= 0) {
                         pao_payer = pp;
                         int32_t unit = (w == S.oya) ? 48000 : 32000;
-                        int32_t honba_ron = (int32_t)ron_honba * 3 * 100;
+                        int32_t honba_ron = (int32_t)ron_honba * (KNP - 1) * 100;
                         int32_t split_base = rule(c, RMJ_RULE_PAO_LIABILITY_ONLY) ? pao_val * unit : total_val * unit;
                         pao_amt = split_base / 2 + honba_ron;
                     }
@@ -1496,18 +1439,24 @@ __device__ __forceinline__ void step_game(Ctx& c, const uint64_t acts_in[4]) {
     } else {
         S.active_mask = 0;
         S.ron_offer_mask = 0;
+        for (int p = 0; p < 4; p++) S.stale_n[p] = 0;  // current_claims.clear() (state/mod.rs:1299)
         if (S.pending_kan_pid != 0xFF) {
             int pk = S.pending_kan_pid;
             uint64_t pa = S.pending_kan_action;
             S.pending_kan_pid = 0xFF;
             S.pending_kan_action = 0;
-            resolve_kan(c, pk, pa);
+            if (a_type(pa) == RMJ_KITA) {  // state_3p/mod.rs:1201-1209
+                for (int p = 0; p < 4; p++) S.p[p].flags &= ~PF_IPPATSU;
+                resolve_kita_rinshan(c, pk);
+            } else {
+                resolve_kan(c, pk, pa);
+            }
         } else {
             accept_riichi(c);
             S.turn_count += 1;
-            S.current_player = (uint8_t)((S.current_player + 1) & 3);
+            S.current_player = (uint8_t)((S.current_player + 1) % KNP);
             deal_next(c);
-            if (S.turn_count >= 4) S.is_first_turn = 0;
+            if (S.turn_count >= (uint32_t)KNP) S.is_first_turn = 0;
         }
     }
 }
@@ -1546,8 +1495,8 @@ __device__ __forceinline__ void finalize_outputs(Ctx& c, bool claims_fresh) {
         if (lane < n) {
             uint64_t a = c.X.legal[p][lane];
             c.Lg[p * RMJ_MAX_LEGAL + lane] = a;
-            int id = a_encode(a);
-            if (id >= 0 && id < 82) c.X.maskbuf[p * 82 + id] = 1;
+            int id = KSANMA ? a_encode_3p(a) : a_encode(a);  // 60 ids in 3P (observation_3p/python.rs:100-112)
+            if (id >= 0 && id < (KSANMA ? 60 : 82)) c.X.maskbuf[p * 82 + id] = 1;
         }
     }
     wave_sync();
@@ -1570,4 +1519,4 @@ __device__ __forceinline__ void finalize_outputs(Ctx& c, bool claims_fresh) {
     if (lane == 0) c.E.status[c.g] = (uint32_t)S.active_mask | ((uint32_t)S.phase << 8) | ((uint32_t)S.is_done << 16);
 }
 
-}  // namespace rmj
+}  // namespace RMJ_NS

@@ -143,8 +143,19 @@ class VecRiichiEnv:
     # ---- RiichiEnv.reset (env.rs:799-851), batched
     def reset(self, select=None, walls=None, oya=None, round_wind=None, scores=None, honba=None, kyotaku=None):
         n = self.n
-        if scores is not None and np.asarray(scores).reshape(n, -1).shape[1] != 4:
-            raise ValueError("scores length does not match number of players 4")  # env.rs:815-823
+        seats = 3 if self.game_mode >= 3 else 4
+        if scores is not None:
+            sc = np.asarray(scores, dtype=np.int32).reshape(n, -1)
+            if sc.shape[1] != seats:
+                raise ValueError(f"scores length {sc.shape[1]} does not match number of players {seats}")  # env.rs:815-823
+            if seats == 3:
+                sc = np.concatenate([sc, np.zeros((n, 1), np.int32)], axis=1)
+            scores = sc
+        if walls is not None:
+            wl = np.asarray(walls, dtype=np.uint8).reshape(n, -1)
+            if wl.shape[1] == 108:  # 3P walls travel in the first 108 entries of the [n][136] rows
+                wl = np.concatenate([wl, np.zeros((n, 28), np.uint8)], axis=1)
+            walls = wl
         keep = []
         ptrs = []
         for arr, dt, shp in ((select, np.uint8, (n,)), (walls, np.uint8, (n, 136)), (oya, np.uint8, (n,)),

@@ -123,3 +123,36 @@ def test_encode_parity_along_rollout():
                         assert enc_act[g, s].tobytes() == ref.tobytes()
                     else:
                         assert not enc_act[g, s].any()
+
+
+@pytest.mark.parametrize("mode,rule", [(5, abi.RULE_TENHOU), (4, abi.RULE_MJSOUL)])
+def test_sanma_random_rollout_parity(mode, rule):
+    """configs[4]-style 3P games (108-tile wall, kita, no chi, 35000 start): every step compared with the oracle."""
+    from oracle import oracle
+    from riichienv_amd import vecenv
+
+    n, seed, pseed = 48, 4000, 13
+    env = vecenv.VecRiichiEnv(n, game_mode=mode, seed=seed, rule_bits=rule, event_ring=8192)
+    games = [oracle.Game(game_mode=mode, seed=seed + g, rule_bits=rule) for g in range(n)]
+    _compare(env, games, range(n), -1)
+    env.reset()
+    for o in games:
+        o.reset()
+    _compare(env, games, range(n), 0)
+    for step in range(1, 2500):
+        acts = np.array([games[g].random_actions(pseed, g) for g in range(n)], dtype=np.uint64)
+        assert (env.random_actions(pseed) == acts).all(), step
+        env.step(acts)
+        for g in range(n):
+            games[g].step([int(x) for x in acts[g]])
+        _compare(env, games, range(n), step, check_state=False)
+        _compare(env, games, [step % n, (step * 7) % n], step, check_state=True)
+        if all(o.status()[2] for o in games):
+            break
+    assert all(o.status()[2] for o in games)
+    for g in range(n):
+        _compare(env, games, [g], 99999)
+        assert env.mjai_log(g) == games[g].log(), g
+        for seat in range(3):
+            assert env.mjai_log(g, seat) == games[g].log(seat), (g, seat)
+    assert (env.ranks()[:, 3] == 0).all() and (np.sort(env.ranks()[:, :3], axis=1) == [1, 2, 3]).all()

@@ -238,6 +238,7 @@ int rmj_calculate_score(int device, const uint8_t* han, const uint8_t* fu, const
  * every seat of every game: out[n][4][74][34].  only_active != 0 -> seats that are not to act get zeros. */
 #define RMJ_ENC_CHANNELS 74
 #define RMJ_ENC_WIDTH_4P 34
+#define RMJ_ENC_WIDTH_3P 27 /* 3P: out[n][4][74][27], compact tile index (observation_3p/helpers.rs:3-15) */
 int rmj_encode(rmj_handle h, int only_active, float* out);
 int rmj_encode_device(rmj_handle h, int only_active, float* d_out); /* device pointer, asynchronous on the handle's stream */
 

@@ -175,8 +175,8 @@ class Game:
             out.append(buf.value.decode())
         return out
 
-    def encode(self, pid):
-        out = np.zeros((74, 34), np.float32)
+    def encode(self, pid, sanma=False):
+        out = np.zeros((74, 27 if sanma else 34), np.float32)
         self.L.orc_game_encode(self.h, pid, out.ctypes.data)
         return out
 

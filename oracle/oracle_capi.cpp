@@ -385,114 +385,120 @@ static uint8_t obs_get_next_tile(uint32_t tile) {
     return (uint8_t)tile;
 }
 
-// Observation.encode(): observation/python.rs:457-806 over the snapshot of state/mod.rs:189-263
-void orc_game_encode(void* gp, int pid, float* arr /*[74][34]*/) {
+// observation_3p/helpers.rs:38-47
+static uint8_t obs_get_next_tile_sanma(uint32_t tile) {
+    uint32_t t34 = tile / 4;
+    if (t34 == 0) return 32;
+    if (t34 == 8) return 0;
+    if (t34 < 8) return (uint8_t)tile;
+    return obs_get_next_tile(tile);
+}
+
+// Observation.encode(): observation/python.rs:457-806 (4P, 74x34) and observation_3p/python.rs:395-... (3P, 74x27,
+// compact column index observation_3p/helpers.rs:7-15) over the snapshot of state/mod.rs:189-263
+void orc_game_encode(void* gp, int pid, float* arr) {
     GameState* g = (GameState*)gp;
-    const int W = 34;
+    const bool sanma = g->sanma;
+    const int W = sanma ? 27 : 34, NP = g->NP;
     std::memset(arr, 0, sizeof(float) * 74 * W);
-    auto A = [&](int ch, int t) -> float& { return arr[ch * W + t]; };
+    auto col = [&](int t34) -> int { return sanma ? (t34 == 0 ? 0 : (t34 >= 8 && t34 < 34 ? t34 - 7 : -1)) : (t34 < 34 ? t34 : -1); };
+    auto set1 = [&](int ch, int t34) {
+        int c = col(t34);
+        if (c >= 0) arr[ch * W + c] = 1.0f;
+    };
+    auto bc = [&](int ch, float v) {
+        for (int k = 0; k < W; k++) arr[ch * W + k] = v;
+    };
+    auto next = [&](uint8_t di) { return sanma ? obs_get_next_tile_sanma(di) : obs_get_next_tile(di); };
     const PlayerState& P = g->players[pid];
-    int rel[4] = {pid, (pid + 1) % 4, (pid + 2) % 4, (pid + 3) % 4};
-    uint8_t counts[34] = {0};
+    std::vector<int> rel;
+    for (int i = 0; i < NP; i++) rel.push_back((pid + i) % NP);
+    std::vector<uint8_t> counts(W, 0);
     for (uint8_t t : P.hand) {
-        int idx = t / 4;
-        counts[idx]++;
-        if (t == 16 || t == 52 || t == 88) A(4, idx) = 1.0f;
-    }
-    for (int i = 0; i < 34; i++)
-        for (int k = 0; k < 4; k++)
-            if (counts[i] >= k + 1) A(k, i) = 1.0f;
-    for (size_t m = 0; m < P.melds.size() && m < 4; m++)
-        for (uint8_t t : P.melds[m].tiles) A(5 + (int)m, t / 4) = 1.0f;
-    for (uint8_t t : g->wall.dora_indicators) A(9, t / 4) = 1.0f;
-    {
-        const auto& d = P.discards;
-        for (size_t i = 0; i < 4 && i < d.size(); i++) A(10 + (int)i, d[d.size() - 1 - i] / 4) = 1.0f;
-    }
-    for (int i = 1; i < 4; i++) {
-        const auto& d = g->players[(pid + i) % 4].discards;
-        for (size_t j = 0; j < 4 && j < d.size(); j++) A(14 + (i - 1) * 4 + (int)j, d[d.size() - 1 - j] / 4) = 1.0f;
-    }
-    for (int c = 0; c < 4; c++) {
-        float v = (float)g->players[rel[c]].discards.size() / 24.0f;
-        for (int k = 0; k < W; k++) A(26 + c, k) = v;
-    }
-    int tiles_used = 0;
-    for (auto& q : g->players) {
-        tiles_used += (int)q.discards.size();
-        for (auto& m : q.melds) tiles_used += (int)m.tiles.size();
-    }
-    tiles_used += (int)P.hand.size() + (int)g->wall.dora_indicators.size();
-    float tl = (float)std::max(136 - tiles_used, 0) / 70.0f;
-    for (int k = 0; k < W; k++) A(30, k) = tl;
-    if (P.riichi_declared)
-        for (int k = 0; k < W; k++) A(31, k) = 1.0f;
-    for (int i = 1; i < 4; i++)
-        if (g->players[(pid + i) % 4].riichi_declared)
-            for (int k = 0; k < W; k++) A(32 + (i - 1), k) = 1.0f;
-    if (27 + g->round_wind < 34) A(35, 27 + g->round_wind) = 1.0f;
-    int seat = (pid + 4 - g->oya) % 4;
-    A(36, 27 + seat) = 1.0f;
-    for (int k = 0; k < W; k++) {
-        A(37, k) = (float)g->honba / 10.0f;
-        A(38, k) = (float)g->riichi_sticks / 5.0f;
-    }
-    for (int c = 0; c < 4; c++) {
-        int32_t sc = g->players[rel[c]].score;
-        float a = (float)std::min(std::max(sc, 0), 100000) / 100000.0f;
-        float b = (float)std::min(std::max(sc, 0), 30000) / 30000.0f;
-        for (int k = 0; k < W; k++) {
-            A(39 + c, k) = a;
-            A(43 + c, k) = b;
+        int c = col(t / 4);
+        if (c >= 0) {
+            counts[c]++;
+            if (t == 16 || t == 52 || t == 88) arr[4 * W + c] = 1.0f;
         }
     }
-    std::vector<uint8_t> waits = g->observation_waits(pid);
-    for (uint8_t t : waits) A(47, t) = 1.0f;
-    for (int k = 0; k < W; k++) A(48, k) = waits.empty() ? 0.0f : 1.0f;
-    int rank = 0;
-    for (auto& q : g->players)
-        if (q.score > P.score) rank++;
-    if (rank < 4)
-        for (int k = 0; k < W; k++) A(49 + rank, k) = 1.0f;
-    for (int k = 0; k < W; k++) {
-        A(53, k) = (float)g->kyoku_idx / 8.0f;
-        A(54, k) = ((float)g->round_wind * 4.0f + (float)g->kyoku_idx) / 7.0f;
+    for (int i = 0; i < W; i++)
+        for (int k = 0; k < 4; k++)
+            if (counts[i] >= k + 1) arr[k * W + i] = 1.0f;
+    for (size_t m = 0; m < P.melds.size() && m < 4; m++)
+        for (uint8_t t : P.melds[m].tiles) set1(5 + (int)m, t / 4);
+    for (uint8_t t : g->wall.dora_indicators) set1(9, t / 4);
+    {
+        const auto& d = P.discards;
+        for (size_t i = 0; i < 4 && i < d.size(); i++) set1(10 + (int)i, d[d.size() - 1 - i] / 4);
     }
+    for (int i = 1; i < NP; i++) {
+        const auto& d = g->players[(pid + i) % NP].discards;
+        for (size_t j = 0; j < 4 && j < d.size(); j++) set1(14 + (i - 1) * 4 + (int)j, d[d.size() - 1 - j] / 4);
+    }
+    for (int c = 0; c < NP; c++) bc(26 + c, (float)g->players[rel[c]].discards.size() / 24.0f);
+    int tiles_used = 0;
+    for (int q = 0; q < NP; q++) {
+        tiles_used += (int)g->players[q].discards.size();
+        for (auto& m : g->players[q].melds) tiles_used += (int)m.tiles.size();
+    }
+    tiles_used += (int)P.hand.size() + (int)g->wall.dora_indicators.size();
+    bc(30, (float)std::max((sanma ? 108 : 136) - tiles_used, 0) / 70.0f);
+    if (P.riichi_declared) bc(31, 1.0f);
+    for (int i = 1; i < NP; i++)
+        if (g->players[(pid + i) % NP].riichi_declared) bc(32 + (i - 1), 1.0f);
+    if (27 + g->round_wind < 34) set1(35, 27 + g->round_wind);
+    set1(36, 27 + (pid + NP - g->oya) % NP);
+    bc(37, (float)g->honba / 10.0f);
+    bc(38, (float)g->riichi_sticks / 5.0f);
+    for (int c = 0; c < NP; c++) {
+        int32_t sc = g->players[rel[c]].score;
+        bc(39 + c, (float)std::min(std::max(sc, 0), 100000) / 100000.0f);
+        bc(43 + c, (float)std::min(std::max(sc, 0), 30000) / 30000.0f);
+    }
+    std::vector<uint8_t> waits = g->observation_waits(pid);
+    for (uint8_t t : waits) set1(47, t);
+    bc(48, waits.empty() ? 0.0f : 1.0f);
+    int rank = 0;
+    for (int q = 0; q < NP; q++)
+        if (g->players[q].score > P.score) rank++;
+    if (rank < NP) bc(49 + rank, 1.0f);
+    bc(53, (float)g->kyoku_idx / 8.0f);
+    bc(54, ((float)g->round_wind * 4.0f + (float)g->kyoku_idx) / 7.0f);
     uint8_t dora_counts[4] = {0, 0, 0, 0};
-    for (int q = 0; q < 4; q++) {
+    for (int q = 0; q < NP; q++) {
         for (auto& m : g->players[q].melds)
             for (uint8_t tile : m.tiles)
                 for (uint8_t di : g->wall.dora_indicators)
-                    if ((tile / 4) == (obs_get_next_tile(di) / 4)) dora_counts[q]++;
+                    if ((tile / 4) == (next(di) / 4)) dora_counts[q]++;
         for (uint8_t tile : g->players[q].discards)
             for (uint8_t di : g->wall.dora_indicators)
-                if ((tile / 4) == (obs_get_next_tile(di) / 4)) dora_counts[q]++;
+                if ((tile / 4) == (next(di) / 4)) dora_counts[q]++;
     }
     for (uint8_t tile : P.hand)
         for (uint8_t di : g->wall.dora_indicators)
-            if ((tile / 4) == (obs_get_next_tile(di) / 4)) dora_counts[pid]++;
-    for (int c = 0; c < 4; c++) {
-        float v = (float)dora_counts[rel[c]] / 12.0f;
-        float mv = (float)g->players[rel[c]].melds.size() / 4.0f;
-        for (int k = 0; k < W; k++) {
-            A(55 + c, k) = v;
-            A(59 + c, k) = mv;
-        }
+            if ((tile / 4) == (next(di) / 4)) dora_counts[pid]++;
+    for (int c = 0; c < NP; c++) {
+        bc(55 + c, (float)dora_counts[rel[c]] / 12.0f);
+        bc(59 + c, (float)g->players[rel[c]].melds.size() / 4.0f);
     }
-    uint8_t seen[34] = {0};
-    for (uint8_t t : P.hand) seen[t / 4]++;
-    for (auto& q : g->players) {
-        for (auto& m : q.melds)
-            for (uint8_t t : m.tiles) seen[t / 4]++;
-        for (uint8_t t : q.discards) seen[t / 4]++;
+    std::vector<uint8_t> seen(W, 0);
+    auto see = [&](uint8_t t) {
+        int c = col(t / 4);
+        if (c >= 0) seen[c]++;
+    };
+    for (uint8_t t : P.hand) see(t);
+    for (int q = 0; q < NP; q++) {
+        for (auto& m : g->players[q].melds)
+            for (uint8_t t : m.tiles) see(t);
+        for (uint8_t t : g->players[q].discards) see(t);
     }
-    for (uint8_t t : g->wall.dora_indicators) seen[t / 4]++;
-    for (int i = 0; i < 34; i++) A(63, i) = (float)seen[i] / 4.0f;
+    for (uint8_t t : g->wall.dora_indicators) see(t);
+    for (int i = 0; i < W; i++) arr[63 * W + i] = (float)seen[i] / 4.0f;
     {
         const auto& d = P.discards;
-        for (size_t i = 0; i < 4 && 4 + i < d.size(); i++) A(64 + (int)i, d[d.size() - 1 - (4 + i)] / 4) = 1.0f;
-        const auto& e = g->players[(pid + 1) % 4].discards;
-        for (size_t i = 0; i < 2 && 4 + i < e.size(); i++) A(68 + (int)i, e[e.size() - 1 - (4 + i)] / 4) = 1.0f;
+        for (size_t i = 0; i < 4 && 4 + i < d.size(); i++) set1(64 + (int)i, d[d.size() - 1 - (4 + i)] / 4);
+        const auto& e = g->players[(pid + 1) % NP].discards;
+        for (size_t i = 0; i < 2 && 4 + i < e.size(); i++) set1(68 + (int)i, e[e.size() - 1 - (4 + i)] / 4);
     }
     // ch 70-73: tsumogiri_flags is never filled (observation/mod.rs:105) -> zeros
 }

@@ -263,23 +263,26 @@ struct EncShared {
     GState st;
     float buf[4][ENC_FLOATS];
 };
+template <bool SANMA>
 __global__ __launch_bounds__(256) void k_encode(Env E, int only_active, float* __restrict__ out) {
     __shared__ EncShared sh;
+    constexpr int FL = SANMA ? ENC_FLOATS3 : ENC_FLOATS;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const uint32_t g = blockIdx.x;
     if (threadIdx.x < sizeof(GState) / 16) reinterpret_cast<uint4*>(&sh.st)[threadIdx.x] = reinterpret_cast<const uint4*>(E.core + g)[threadIdx.x];
     __syncthreads();
     const GState& S = sh.st;
     float* buf = sh.buf[wave];
-    bool want = !only_active || (((S.active_mask >> wave) & 1u) && !S.is_done);
-    if (want) encode_seat(S, wave, buf, lane);
+    bool want = (wave < (SANMA ? 3 : 4)) && (!only_active || (((S.active_mask >> wave) & 1u) && !S.is_done));
+    if (want) encode_seat<SANMA>(S, wave, buf, lane);
     else {
-        for (int i = lane; i < ENC_FLOATS; i += 64) buf[i] = 0.0f;
+        for (int i = lane; i < FL; i += 64) buf[i] = 0.0f;
         wave_sync();
     }
-    float4* dst = reinterpret_cast<float4*>(out + ((size_t)g * 4 + wave) * ENC_FLOATS);
-    const float4* src = reinterpret_cast<const float4*>(buf);
-    for (int i = lane; i < ENC_FLOATS / 4; i += 64) dst[i] = src[i];
+    // 74*34*4 B is a multiple of 16, 74*27*4 B only of 8
+    float2* dst = reinterpret_cast<float2*>(out + ((size_t)g * 4 + wave) * FL);
+    const float2* src = reinterpret_cast<const float2*>(buf);
+    for (int i = lane; i < FL / 2; i += 64) dst[i] = src[i];
 }
 
 // shanten.rs:244-261 / :470-484 (calculate_shanten / calculate_shanten_3p over raw histograms): one thread per hand
@@ -964,14 +967,15 @@ int rmj_calculate_score(int device, const uint8_t* han, const uint8_t* fu, const
 int rmj_encode_device(rmj_handle h, int only_active, float* d_out) {
     if (!h || !d_out) return fail(RMJ_ERR_ARG, "null argument");
     HIPCHK(hipSetDevice(h->cfg.device));
-    hipLaunchKernelGGL(k_encode, dim3(h->cfg.n_games), dim3(256), 0, h->stream, h->d, only_active, d_out);
+    if (h->cfg.game_mode >= 3) hipLaunchKernelGGL(k_encode<true>, dim3(h->cfg.n_games), dim3(256), 0, h->stream, h->d, only_active, d_out);
+    else hipLaunchKernelGGL(k_encode<false>, dim3(h->cfg.n_games), dim3(256), 0, h->stream, h->d, only_active, d_out);
     HIPCHK(hipGetLastError());
     return RMJ_OK;
 }
 int rmj_encode(rmj_handle h, int only_active, float* out) {
     if (!h || !out) return fail(RMJ_ERR_ARG, "null argument");
     HIPCHK(hipSetDevice(h->cfg.device));
-    size_t bytes = (size_t)h->cfg.n_games * 4 * ENC_FLOATS * sizeof(float);
+    size_t bytes = (size_t)h->cfg.n_games * 4 * (h->cfg.game_mode >= 3 ? ENC_FLOATS3 : ENC_FLOATS) * sizeof(float);
     float* d;
     HIPCHK(hipMalloc(&d, bytes));
     int rc = rmj_encode_device(h, only_active, d);

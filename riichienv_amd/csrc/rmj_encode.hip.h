@@ -8,8 +8,16 @@
 namespace rmj {
 
 #define ENC_CH 74
-#define ENC_W 34
-#define ENC_FLOATS (ENC_CH * ENC_W)
+#define ENC_W4 34
+#define ENC_W3 27 /* observation_3p/helpers.rs:3 */
+#define ENC_FLOATS (ENC_CH * ENC_W4)
+#define ENC_FLOATS3 (ENC_CH * ENC_W3)
+// observation_3p/helpers.rs:7-15: tile34 -> compact column (2m-8m have none)
+template <bool SANMA>
+__device__ __forceinline__ int enc_col(int t34) {
+    if (!SANMA) return t34 < 34 ? t34 : -1;
+    return t34 == 0 ? 0 : ((t34 >= 8 && t34 < 34) ? t34 - 7 : -1);
+}
 
 // observation/helpers.rs:24-50 — takes a 136-id, returns a 136-id (copy 0 of the next type)
 __device__ __forceinline__ int enc_next_tile136(int tile) {
@@ -31,12 +39,28 @@ __device__ __forceinline__ uint64_t enc_waits(const PState& P, int lane) {
     return wave_waits(h, lane);
 }
 
-__device__ __forceinline__ void enc_bcast(float* buf, int ch, float v, int lane) {
-    if (lane < ENC_W) buf[ch * ENC_W + lane] = v;
+// observation_3p/helpers.rs:38-47
+__device__ __forceinline__ int enc_next_tile136_sanma(int tile) {
+    int tt = tile / 4;
+    if (tt == 0) return 32;
+    if (tt == 8) return 0;
+    if (tt < 8) return tile & 0xFF;
+    return enc_next_tile136(tile);
 }
 
+template <bool SANMA>
 __device__ inline void encode_seat(const GState& S, int pid, float* buf, int lane) {
-    for (int i = lane; i < ENC_FLOATS; i += 64) buf[i] = 0.0f;
+    constexpr int ENC_W = SANMA ? ENC_W3 : ENC_W4;
+    constexpr int NPP = SANMA ? 3 : 4;
+    auto enc_bcast = [&](float* b, int ch, float v, int l) {
+        if (l < ENC_W) b[ch * ENC_W + l] = v;
+    };
+    auto put = [&](int ch, int t34) {  // scatter one cell (skips tiles without a column)
+        int col = enc_col<SANMA>(t34);
+        if (col >= 0) buf[ch * ENC_W + col] = 1.0f;
+    };
+    const int my34 = SANMA ? (lane == 0 ? 0 : lane + 7) : lane;  // tile type of this lane's column
+    for (int i = lane; i < ENC_CH * ENC_W; i += 64) buf[i] = 0.0f;
     wave_sync();
     const PState& P = S.p[pid];
     // 1-2. hand counts + red (ch 0-4)
@@ -45,7 +69,7 @@ __device__ inline void encode_seat(const GState& S, int pid, float* buf, int lan
         bool red = false;
         for (int j = 0; j < P.hand_len; j++) {
             int t = P.hand[j];
-            if ((t >> 2) == lane) {
+            if ((t >> 2) == my34) {
                 c++;
                 red = red || is_aka(t);
             }
@@ -59,40 +83,42 @@ __device__ inline void encode_seat(const GState& S, int pid, float* buf, int lan
     // 3. own melds (ch 5-8), 4. dora indicators (ch 9)
     if (lane < 16) {
         int m = lane >> 2, k = lane & 3;
-        if (m < P.n_melds && k < ((P.meld_type[m] >= RMJ_MELD_DAIMINKAN) ? 4 : 3)) buf[(5 + m) * ENC_W + (P.meld_tiles[m][k] >> 2)] = 1.0f;
+        if (m < P.n_melds && k < ((P.meld_type[m] >= RMJ_MELD_DAIMINKAN) ? 4 : 3)) put(5 + m, P.meld_tiles[m][k] >> 2);
     }
-    if (lane < S.n_dora) buf[9 * ENC_W + (S.dora[lane] >> 2)] = 1.0f;
+    if (lane < S.n_dora) put(9, S.dora[lane] >> 2);
     // 5-6. recent discards: self ch10-13 (+64-67), opponents ch14-25 (+68-69 for the first)
     if (lane < 16) {
         int rel = lane >> 2, j = lane & 3;
-        const PState& Q = S.p[(pid + rel) & 3];
-        int n = Q.n_discards;
-        if (j < n) buf[(10 + rel * 4 + j) * ENC_W + (Q.discards[n - 1 - j] >> 2)] = 1.0f;
+        if (rel < NPP) {
+            const PState& Q = S.p[(pid + rel) % NPP];
+            int n = Q.n_discards;
+            if (j < n) put(10 + rel * 4 + j, Q.discards[n - 1 - j] >> 2);
+        }
     }
     if (lane < 4) {
         int n = P.n_discards;
-        if (4 + lane < n) buf[(64 + lane) * ENC_W + (P.discards[n - 1 - (4 + lane)] >> 2)] = 1.0f;
+        if (4 + lane < n) put(64 + lane, P.discards[n - 1 - (4 + lane)] >> 2);
     }
     if (lane < 2) {
-        const PState& Q = S.p[(pid + 1) & 3];
+        const PState& Q = S.p[(pid + 1) % NPP];
         int n = Q.n_discards;
-        if (4 + lane < n) buf[(68 + lane) * ENC_W + (Q.discards[n - 1 - (4 + lane)] >> 2)] = 1.0f;
+        if (4 + lane < n) put(68 + lane, Q.discards[n - 1 - (4 + lane)] >> 2);
     }
     // wave-uniform scalars
     int tiles_used = P.hand_len + S.n_dora;
     int32_t my_score = P.score;
     int rank = 0;
-    for (int q = 0; q < 4; q++) {
+    for (int q = 0; q < NPP; q++) {
         const PState& Q = S.p[q];
         tiles_used += Q.n_discards;
         for (int m = 0; m < Q.n_melds; m++) tiles_used += (Q.meld_type[m] >= RMJ_MELD_DAIMINKAN) ? 4 : 3;
         rank += (Q.score > my_score);
     }
-    int tiles_left = 136 - tiles_used;
+    int tiles_left = (SANMA ? 108 : 136) - tiles_used;
     if (tiles_left < 0) tiles_left = 0;
     enc_bcast(buf, 30, (float)tiles_left / 70.0f, lane);
-    for (int rel = 0; rel < 4; rel++) {
-        const PState& Q = S.p[(pid + rel) & 3];
+    for (int rel = 0; rel < NPP; rel++) {
+        const PState& Q = S.p[(pid + rel) % NPP];
         enc_bcast(buf, 26 + rel, (float)Q.n_discards / 24.0f, lane);
         if (Q.flags & PF_RIICHI_DECLARED) enc_bcast(buf, 31 + rel, 1.0f, lane);
         int32_t sc = Q.score;
@@ -106,17 +132,17 @@ __device__ inline void encode_seat(const GState& S, int pid, float* buf, int lan
     // 10. winds (ch 35-36)
     {
         int rw = S.round_wind;
-        if (lane == 0 && 27 + rw < 34) buf[35 * ENC_W + 27 + rw] = 1.0f;
-        int seat = (pid + 4 - S.oya) & 3;
-        if (lane == 0) buf[36 * ENC_W + 27 + seat] = 1.0f;
+        if (lane == 0 && 27 + rw < 34) put(35, 27 + rw);
+        int seat = (pid + NPP - S.oya) % NPP;
+        if (lane == 0) put(36, 27 + seat);
     }
     enc_bcast(buf, 37, (float)S.honba / 10.0f, lane);
     enc_bcast(buf, 38, (float)S.riichi_sticks / 5.0f, lane);
     // 14-15. waits / tenpai (ch 47-48)
     uint64_t W = enc_waits(P, lane);
-    if (lane < ENC_W && ((W >> lane) & 1ull)) buf[47 * ENC_W + lane] = 1.0f;
+    if (lane < ENC_W && ((W >> my34) & 1ull)) buf[47 * ENC_W + lane] = 1.0f;
     enc_bcast(buf, 48, W != 0ull ? 1.0f : 0.0f, lane);
-    if (rank < 4) enc_bcast(buf, 49 + rank, 1.0f, lane);
+    if (rank < NPP) enc_bcast(buf, 49 + rank, 1.0f, lane);
     enc_bcast(buf, 53, (float)S.kyoku_idx / 8.0f, lane);
     enc_bcast(buf, 54, ((float)S.round_wind * 4.0f + (float)S.kyoku_idx) / 7.0f, lane);
     // 19. dora counts (ch 55-58) and 21. tiles seen (ch 63): lane = tile type accumulates, then reduce for dora
@@ -126,33 +152,36 @@ __device__ inline void encode_seat(const GState& S, int pid, float* buf, int lan
         // dora counting is per indicator (duplicates count twice), so loop over indicators explicitly below.
         (void)dmask_lo; (void)dmask_hi;
         int dcount[4] = {0, 0, 0, 0};
-        for (int q = 0; q < 4; q++) {
+        // NOTE: the dora count is taken over tile TYPES (34-wide, also types without a column in 3P); lanes >= ENC_W
+        // cover nothing in 4P, and in 3P the types 1..7 (2m-8m) cannot occur in a sanma game.
+        for (int q = 0; q < NPP; q++) {
             const PState& Q = S.p[q];
-            int mine = 0;  // tiles of type `lane` visible for player q (melds + discards [+ own hand])
+            int mine = 0;  // tiles of this lane's type visible for player q (melds + discards [+ own hand])
             for (int m = 0; m < Q.n_melds; m++) {
                 int nt = (Q.meld_type[m] >= RMJ_MELD_DAIMINKAN) ? 4 : 3;
-                for (int k = 0; k < nt; k++) mine += ((Q.meld_tiles[m][k] >> 2) == lane);
+                for (int k = 0; k < nt; k++) mine += ((Q.meld_tiles[m][k] >> 2) == my34);
             }
-            for (int j = 0; j < Q.n_discards; j++) mine += ((Q.discards[j] >> 2) == lane);
+            for (int j = 0; j < Q.n_discards; j++) mine += ((Q.discards[j] >> 2) == my34);
             seen += mine;
             if (q == pid) {
                 int hc = 0;
-                for (int j = 0; j < P.hand_len; j++) hc += ((P.hand[j] >> 2) == lane);
+                for (int j = 0; j < P.hand_len; j++) hc += ((P.hand[j] >> 2) == my34);
                 seen += hc;
                 mine += hc;
             }
-            // contribution of this tile type to q's dora count = mine * (#indicators whose dora type == lane)
+            // contribution of this tile type to q's dora count = mine * (#indicators whose dora type is this type)
             int mult = 0;
-            for (int k = 0; k < S.n_dora; k++) mult += ((enc_next_tile136(S.dora[k]) >> 2) == lane);
+            for (int k = 0; k < S.n_dora; k++)
+                mult += (((SANMA ? enc_next_tile136_sanma(S.dora[k]) : enc_next_tile136(S.dora[k])) >> 2) == my34);
             int contrib = (lane < ENC_W) ? mine * mult : 0;
 #pragma unroll
             for (int off = 32; off >= 1; off >>= 1) contrib += __shfl_xor(contrib, off, 64);
             dcount[q] = contrib & 0xFF;  // u8 accumulator in the reference
         }
-        for (int k = 0; k < S.n_dora; k++) seen += ((S.dora[k] >> 2) == lane);
+        for (int k = 0; k < S.n_dora; k++) seen += ((S.dora[k] >> 2) == my34);
         if (lane < ENC_W) buf[63 * ENC_W + lane] = (float)(seen & 0xFF) / 4.0f;
-        for (int rel = 0; rel < 4; rel++) {
-            int q = (pid + rel) & 3;
+        for (int rel = 0; rel < NPP; rel++) {
+            int q = (pid + rel) % NPP;
             int d = q == 0 ? dcount[0] : (q == 1 ? dcount[1] : (q == 2 ? dcount[2] : dcount[3]));
             enc_bcast(buf, 55 + rel, (float)d / 12.0f, lane);
         }

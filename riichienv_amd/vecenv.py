@@ -261,7 +261,7 @@ class VecRiichiEnv:
 
     def encode(self, only_active=False):
         """Observation.encode() of every seat: float32 [n, 4, 74, 34] (observation/python.rs:457-806)."""
-        out = np.zeros((self.n, 4, 74, 34), np.float32)
+        out = np.zeros((self.n, 4, 74, 27 if self.game_mode >= 3 else 34), np.float32)
         _chk(self.L.rmj_encode(self.h, int(only_active), out.ctypes.data))
         return out
 

@@ -95,14 +95,16 @@ def test_step_random_device_policy_matches_oracle():
     assert env.total_steps() == sum(o.step_count for o in games)
 
 
-def test_encode_parity_along_rollout():
-    """Row A14: rmj_encode (74 x 34 f32 for every seat) bit-exact vs the oracle along a random rollout."""
+@pytest.mark.parametrize("mode", [2, 5])
+def test_encode_parity_along_rollout(mode):
+    """Row A14: rmj_encode (74 x 34 f32 in 4P, 74 x 27 in 3P, every seat) bit-exact vs the oracle along a rollout."""
     from oracle import oracle
     from riichienv_amd import vecenv
 
     n, seed, pseed = 24, 321, 5
-    env = vecenv.VecRiichiEnv(n, game_mode=2, seed=seed)
-    games = [oracle.Game(game_mode=2, seed=seed + g) for g in range(n)]
+    sanma = mode >= 3
+    env = vecenv.VecRiichiEnv(n, game_mode=mode, seed=seed)
+    games = [oracle.Game(game_mode=mode, seed=seed + g) for g in range(n)]
     env.reset()
     for o in games:
         o.reset()
@@ -116,8 +118,8 @@ def test_encode_parity_along_rollout():
             act, ph, dn = env.status()
             enc_act = env.encode(only_active=True)
             for g in range(n):
-                for s in range(4):
-                    ref = games[g].encode(s)
+                for s in range(3 if sanma else 4):
+                    ref = games[g].encode(s, sanma)
                     assert enc[g, s].tobytes() == ref.tobytes(), (step, g, s, np.argwhere(enc[g, s] != ref)[:5])
                     if (act[g] >> s) & 1 and not dn[g]:
                         assert enc_act[g, s].tobytes() == ref.tobytes()

@@ -44,6 +44,9 @@ class OracleEnv:
     def scores(self):
         return [p.score for p in self.g.peek().players]
 
+    def encode(self, seat):
+        return self.g.encode(seat, self.g.peek().wall_len + sum(p.hand_len for p in self.g.peek().players) <= 108)
+
 
 class GpuEnv:
     def __init__(self, game_mode=0, seed=42, rule_bits=abi.RULE_TENHOU, round_wind=0):
@@ -95,6 +98,7 @@ class DualEnv:
     """Drives the oracle and the HIP path together; every mutation is followed by a full comparison."""
 
     def __init__(self, **kw):
+        self.np = 3 if kw.get("game_mode", 0) >= 3 else 4
         self.o = OracleEnv(**kw)
         self.g = GpuEnv(**kw)
         self.check("ctor")
@@ -112,7 +116,7 @@ class DualEnv:
                 assert (np.asarray(self.g.mask(s)) == np.asarray(self.o.mask(s))).all(), (what, s, "mask")
                 assert self.g.waits(s) == self.o.waits(s), (what, s, "waits")
         assert self.g.log() == self.o.log(), what
-        for s in range(4):
+        for s in range(self.np):
             assert self.g.log(s) == self.o.log(s), (what, s)
 
     def reset(self, **kw):

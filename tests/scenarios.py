@@ -524,3 +524,134 @@ SCENARIOS = [sc_paishan_dora_indices, sc_kakan_dora_timing, sc_daiminkan_dora_ti
              sc_kuikae_deadlock, sc_sufuurenta, sc_suukansansen, sc_chankan_ron, sc_chankan_pass, sc_pao_daisangen_tsumo,
              sc_pao_mjsoul_composite_tsumo, sc_riichi_sequence, sc_kyushu_kyuhai, sc_double_ron_honba_sticks,
              sc_tobi_and_agariyame]
+
+
+# ---------------------------------------------------------------------------------------------------------
+# 3-player (sanma) KATs — riichienv-core/src/tests.rs:1042-1255, 2024-2340; tests/env/test_sanma.py
+KITA = abi.KITA
+
+
+def sc3_basics(make):
+    """tests.rs:1067-1124: 35000 start, 108 tiles without 2m-8m, dealer 14 / others 13, 3 seats in the events."""
+    env = make(game_mode=3)
+    env.reset()
+    v = env.peek()
+    assert [v.players[p].score for p in range(3)] == [35000] * 3
+    assert [v.players[p].hand_len for p in range(4)] == [14, 13, 13, 0]
+    all_tiles = list(v.wall[: v.wall_len]) + [t for p in range(3) for t in v.players[p].hand[: v.players[p].hand_len]]
+    assert len(all_tiles) == 108 and not any(1 <= t // 4 <= 7 for t in all_tiles)
+    assert v.drawable_count == 54  # 108 - 39 dealt - 14, minus the dealer's draw
+    sk = next(e for e in evs(env) if e["type"] == "start_kyoku")
+    assert sk["scores"] == [35000] * 3 and len(sk["tehais"]) == 3
+    assert [len(json.loads(s)["tehais"]) for s in env.log(1) if '"start_kyoku"' in s] == [3]
+
+
+def sc3_no_chi(make):
+    """tests.rs:1126-1156: a sequential hand is never offered Chi in sanma."""
+    env = setup(make(game_mode=5), hands=[None, [36, 40, 44, 48, 52, 56, 60, 64, 68, 72, 76, 80, 84], None, None])
+    v = env.peek()
+    t = v.players[0].hand[0]
+    env.step({0: pack_action(DISCARD, t)})
+    act, ph, dn = env.status()
+    if ph == WAIT_RESPONSE and (act >> 1) & 1:
+        assert find(env.legal(1), CHI) is None
+
+
+def sc3_kita(make):
+    """tests.rs:1166-1187 + state_3p/sanma.rs:9-204: Kita is legal with a North tile, emits kita -> tsumo (rinshan, no
+    dora), counts as nukidora, breaks the first turn; action id 59."""
+    env = setup(make(game_mode=3), hands=[[0, 36, 40, 44, 48, 52, 56, 60, 64, 68, 72, 76], None, None, None], drawn_tile=120,
+                wall=None)
+    k = find(env.legal(0), KITA)
+    assert k is not None and unpack_action(k) == (KITA, 120, [])
+    assert env.mask(0)[59] == 1
+    before = env.peek()
+    env.step({0: k})
+    v = env.peek()
+    act, ph, dn = env.status()
+    if ph == WAIT_ACT:  # nobody could ron the North tile
+        assert v.players[0].n_kita == 1 and v.players[0].kita[0] == 120 and v.is_first_turn == 0
+        assert v.rinshan_draw_count == 1 and v.is_rinshan_flag == 1 and v.n_dora == 1
+        assert v.drawable_count == before.drawable_count - 1
+        t = [e["type"] for e in evs(env)]
+        assert t[-2:] == ["kita", "tsumo"]
+        assert evs(env)[-2] == {"actor": 0, "pai": "N", "type": "kita"}
+
+
+def sc3_oyayame_needs_40000(make):
+    """tests.rs:1051-1065: last regular round, dealer top but below 40000 -> the game continues."""
+    env = make(game_mode=5)
+    hand = tiles("123456789p1134s")
+
+    def mut(v):
+        v.round_wind = 1
+        v.oya = 2
+        v.kyoku_idx = 2
+        v.current_player = 2
+        v.active_mask = 4
+        v.is_first_turn = 0
+        for p, s in enumerate([34000, 34000, 30000]):  # the win lifts the dealer to the top but below 40000
+            v.players[p].score = s
+        v.players[2].n_discards = 1
+        v.players[2].discards[0] = 108
+
+    setup(env, hands=[None, None, hand, None], current_player=2, drawn_tile=tiles("2s")[0], mutate=mut)
+    ts = find(env.legal(2), TSUMO)
+    assert ts is not None
+    env.step({2: ts})
+    assert env.status()[2] == 0  # continues: renchan in South 3
+    v = env.peek()
+    assert (v.oya, v.round_wind, v.honba) == (2, 1, 1)
+
+
+def sc3_tsumo_payments_and_nukidora(make):
+    """tests.rs:1207-1216 (3P tsumo: two payers) + hand_evaluator_3p.rs:126-147 (nukidora = kita count, yaku 34)."""
+    env = make(game_mode=5)
+    hand = tiles("234567p234567s9s")  # tanyao pinfu-shaped tenpai on 9s? keep simple: pair wait
+
+    def mut(v):
+        v.is_first_turn = 0
+        v.players[1].n_discards = 1
+        v.players[1].discards[0] = 108
+        v.players[1].n_kita = 2
+        v.players[1].kita[0] = 120
+        v.players[1].kita[1] = 121
+        v.current_player = 1
+        v.active_mask = 2
+
+    setup(env, oya=0, hands=[None, hand, None, None], current_player=1, drawn_tile=tiles("99s")[1], mutate=mut,
+          wall=None)
+    ts = find(env.legal(1), TSUMO)
+    assert ts is not None
+    env.step({1: ts})
+    hora = next(e for e in reversed(evs(env)) if e["type"] == "hora")
+    assert len(hora["deltas"]) == 3 and sum(hora["deltas"]) == 0
+    # ko tsumo: dealer pays pay_tsumo_oya, the other ko pays pay_tsumo_ko
+    assert hora["deltas"][0] < hora["deltas"][2] < 0 < hora["deltas"][1]
+
+
+def sc3_exhaustive_draw_pool_2000(make):
+    """state_3p/game_mode.rs:39-41 + state_3p/mod.rs:1791-1800: tenpai pool 2000 split over 3 seats."""
+    env = make(game_mode=5)
+    tenpai_hand = tiles("123456789p1239s")[0:13]
+
+    def mut(v):
+        v.drawable_count = 0
+        v.is_first_turn = 0
+        for p in range(3):
+            v.players[p].nagashi_eligible = 0
+
+    setup(env, hands=[tiles("19m19p19s1234567z")[0:13][:12] + [tiles("2p")[0]], tenpai_hand, tiles("147p258s369s1234z")[0:13], None],
+          drawn_tile=tiles("8s")[0], mutate=mut)
+    v = env.peek()
+    env.step({0: pack_action(DISCARD, v.drawn_tile)})
+    act, ph, dn = env.status()
+    if ph == WAIT_RESPONSE:
+        env.step({s: pack_action(PASS) for s in range(3) if (act >> s) & 1})
+    r = [e for e in evs(env) if e["type"] == "ryukyoku"][-1]
+    assert r["reason"] == "exhaustive_draw" and len(r["deltas"]) == 3
+    assert sorted(r["deltas"]) in ([-1000, -1000, 2000], [-2000, 1000, 1000], [0, 0, 0])
+
+
+SCENARIOS_3P = [sc3_basics, sc3_no_chi, sc3_kita, sc3_oyayame_needs_40000, sc3_tsumo_payments_and_nukidora,
+                sc3_exhaustive_draw_pool_2000]

@@ -2,12 +2,12 @@
 import pytest
 
 from tests.env_adapters import DualEnv, GpuEnv
-from tests.scenarios import SCENARIOS
+from tests.scenarios import SCENARIOS, SCENARIOS_3P
 
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("sc", SCENARIOS, ids=lambda f: f.__name__)
+@pytest.mark.parametrize("sc", SCENARIOS + SCENARIOS_3P, ids=lambda f: f.__name__)
 def test_gpu_scenario(sc):
     sc(lambda **kw: DualEnv(**kw))
 

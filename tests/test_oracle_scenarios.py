@@ -2,9 +2,9 @@
 import pytest
 
 from tests.env_adapters import OracleEnv
-from tests.scenarios import SCENARIOS
+from tests.scenarios import SCENARIOS, SCENARIOS_3P
 
 
-@pytest.mark.parametrize("sc", SCENARIOS, ids=lambda f: f.__name__)
+@pytest.mark.parametrize("sc", SCENARIOS + SCENARIOS_3P, ids=lambda f: f.__name__)
 def test_oracle_scenario(sc):
     sc(lambda **kw: OracleEnv(**kw))

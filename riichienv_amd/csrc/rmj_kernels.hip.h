@@ -12,7 +12,7 @@ __device__ __noinline__ void ol_env_reset_default(CtxV v) {
     init_round(c, 0, 0, 0, 0, sc);
 }
 
-__global__ __launch_bounds__(256, 4) void k_step(Env E, const uint64_t* __restrict__ actions, uint64_t policy_seed, uint32_t flags) {
+__global__ __launch_bounds__(256, 3) void k_step(Env E, const uint64_t* __restrict__ actions, uint64_t policy_seed, uint32_t flags) {
     __shared__ BlockShared sh;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const uint32_t g = blockIdx.x * WPB + wave;

@@ -380,7 +380,24 @@ __device__ __forceinline__ void gen_act_legal(Ctx& c, int pid) {
         if (S.drawable_count == 0 && !S.is_rinshan) cf |= CF_HAITEI;
         if (S.is_rinshan) cf |= CF_RINSHAN;
         if (S.is_first_turn && P.n_discards == 0) cf |= CF_FIRST_TURN;  // quirk Q5
-        if (seat_shape(c, pid, idx, tile)) {
+        // Win-shape probe.  is_agari(13 tiles + drawn) == "drawn type is a wait of the 13 tiles" (the drawn type has
+        // < 4 copies among them, so quirk Q7 cannot bite), and those waits are the seat's cached waits13: the cache
+        // describes the hand before the draw and survives a tsumogiri.  Only an invalid cache costs a probe, and that
+        // probe refills it for the claim checks that follow.
+        bool shape;
+        if (idx >= 0 && (hl - 1) + 3 * P.n_melds == 13) {
+            uint64_t W13;
+            if (P.flags & PF_WAITS_VALID) W13 = P.waits13;
+            else {
+                W13 = wave_waits(build_ph(P, idx), lane);
+                P.waits13 = W13;
+                P.flags |= PF_WAITS_VALID;
+            }
+            shape = (W13 >> (tile >> 2)) & 1ull;
+        } else {
+            shape = seat_shape(c, pid, idx, tile);
+        }
+        if (shape) {
             CalcOut r = seat_calc(c, pid, idx, tile, cf, S.honba, false);
             if (r.is_win && (r.yakuman || r.han >= 1)) put_legal(c, pid, n++, mk_action(RMJ_TSUMO, tile, 0));
         }

@@ -324,6 +324,7 @@ struct rmj_env {
     RmjConfig cfg;
     Env d;
     hipStream_t stream = nullptr;
+    Env* d_env = nullptr;  // device-resident copy of `d` (kernels take a pointer, see rmj_kernels.hip.h)
     uint64_t* d_actions = nullptr;
     unsigned long long* d_counter = nullptr;
     uint32_t ring = 0;
@@ -395,6 +396,8 @@ int rmj_create(const RmjConfig* cfg, rmj_handle* out) {
     d.ctor_round_wind = cfg->round_wind;
     d.game_offset = cfg->game_offset;
     if ((rc = shanten_tables_for(cfg->device, &d.sh))) return rc;
+    HIPCHK(hipMalloc(&h->d_env, sizeof(Env)));
+    HIPCHK(hipMemcpy(h->d_env, &d, sizeof(Env), hipMemcpyHostToDevice));
     ResetArgs A;
     memset(&A, 0, sizeof(A));
     A.is_ctor = 1;
@@ -405,8 +408,8 @@ int rmj_create(const RmjConfig* cfg, rmj_handle* out) {
         HIPCHK(hipMemcpy(d_seeds, cfg->seeds, B * sizeof(uint64_t), hipMemcpyHostToDevice));
         A.seeds = d_seeds;
     }
-    if (cfg->game_mode >= 3) hipLaunchKernelGGL(rmj3::k_reset, game_grid(cfg->n_games), dim3(256), 0, h->stream, d, A);
-    else hipLaunchKernelGGL(rmj4::k_reset, game_grid(cfg->n_games), dim3(256), 0, h->stream, d, A);
+    if (cfg->game_mode >= 3) hipLaunchKernelGGL(rmj3::k_reset, game_grid(cfg->n_games), dim3(256), 0, h->stream, (const Env*)h->d_env, A);
+    else hipLaunchKernelGGL(rmj4::k_reset, game_grid(cfg->n_games), dim3(256), 0, h->stream, (const Env*)h->d_env, A);
     HIPCHK(hipGetLastError());
     HIPCHK(hipStreamSynchronize(h->stream));
     if (d_seeds) hipFree(d_seeds);
@@ -420,7 +423,7 @@ int rmj_destroy(rmj_handle h) {
     hipSetDevice(h->cfg.device);
     hipStreamSynchronize(h->stream);
     hipFree(h->d.core); hipFree(h->d.wall); hipFree(h->d.legal); hipFree(h->d.nlegal); hipFree(h->d.mask);
-    hipFree(h->d.waits); hipFree(h->d.status); hipFree(h->d.events); hipFree(h->d_actions); hipFree(h->d_counter);
+    hipFree(h->d.waits); hipFree(h->d.status); hipFree(h->d.events); hipFree(h->d_actions); hipFree(h->d_counter); hipFree(h->d_env);
     hipStreamDestroy(h->stream);
     delete h;
     return RMJ_OK;
@@ -445,8 +448,8 @@ int rmj_reset(rmj_handle h, const uint8_t* select, const uint8_t* walls, const u
     ResetArgs A;
     memset(&A, 0, sizeof(A));
     A.select = d_sel; A.walls = d_walls; A.oya = d_oya; A.round_wind = d_rw; A.scores = d_sc; A.honba = d_honba; A.kyotaku = d_ky;
-    if (h->cfg.game_mode >= 3) hipLaunchKernelGGL(rmj3::k_reset, game_grid(h->cfg.n_games), dim3(256), 0, h->stream, h->d, A);
-    else hipLaunchKernelGGL(rmj4::k_reset, game_grid(h->cfg.n_games), dim3(256), 0, h->stream, h->d, A);
+    if (h->cfg.game_mode >= 3) hipLaunchKernelGGL(rmj3::k_reset, game_grid(h->cfg.n_games), dim3(256), 0, h->stream, (const Env*)h->d_env, A);
+    else hipLaunchKernelGGL(rmj4::k_reset, game_grid(h->cfg.n_games), dim3(256), 0, h->stream, (const Env*)h->d_env, A);
     HIPCHK(hipGetLastError());
     HIPCHK(hipStreamSynchronize(h->stream));
     hipFree(d_sel); hipFree(d_walls); hipFree(d_oya); hipFree(d_rw); hipFree(d_sc); hipFree(d_honba); hipFree(d_ky);
@@ -456,8 +459,8 @@ int rmj_reset(rmj_handle h, const uint8_t* select, const uint8_t* walls, const u
 int rmj_step_device(rmj_handle h, const rmj_action_t* d_actions) {
     if (!h || !d_actions) return fail(RMJ_ERR_ARG, "null argument");
     HIPCHK(hipSetDevice(h->cfg.device));
-    if (h->cfg.game_mode >= 3) hipLaunchKernelGGL(rmj3::k_step, game_grid(h->cfg.n_games), dim3(256), 0, h->stream, h->d, (const uint64_t*)d_actions, 0ull, 0u);
-    else hipLaunchKernelGGL(rmj4::k_step, game_grid(h->cfg.n_games), dim3(256), 0, h->stream, h->d, (const uint64_t*)d_actions, 0ull, 0u);
+    if (h->cfg.game_mode >= 3) hipLaunchKernelGGL(rmj3::k_step, game_grid(h->cfg.n_games), dim3(256), 0, h->stream, (const Env*)h->d_env, (const uint64_t*)d_actions, 0ull, 0u);
+    else hipLaunchKernelGGL(rmj4::k_step, game_grid(h->cfg.n_games), dim3(256), 0, h->stream, (const Env*)h->d_env, (const uint64_t*)d_actions, 0ull, 0u);
     HIPCHK(hipGetLastError());
     return RMJ_OK;
 }
@@ -473,8 +476,8 @@ int rmj_step_random(rmj_handle h, uint64_t policy_seed, uint32_t n_steps, int au
     HIPCHK(hipSetDevice(h->cfg.device));
     uint32_t flags = STEP_F_RANDOM | (auto_reset ? STEP_F_AUTORESET : 0u);
     for (uint32_t s = 0; s < n_steps; s++) {
-        if (h->cfg.game_mode >= 3) hipLaunchKernelGGL(rmj3::k_step, game_grid(h->cfg.n_games), dim3(256), 0, h->stream, h->d, (const uint64_t*)nullptr, policy_seed, flags);
-        else hipLaunchKernelGGL(rmj4::k_step, game_grid(h->cfg.n_games), dim3(256), 0, h->stream, h->d, (const uint64_t*)nullptr, policy_seed, flags);
+        if (h->cfg.game_mode >= 3) hipLaunchKernelGGL(rmj3::k_step, game_grid(h->cfg.n_games), dim3(256), 0, h->stream, (const Env*)h->d_env, (const uint64_t*)nullptr, policy_seed, flags);
+        else hipLaunchKernelGGL(rmj4::k_step, game_grid(h->cfg.n_games), dim3(256), 0, h->stream, (const Env*)h->d_env, (const uint64_t*)nullptr, policy_seed, flags);
     }
     HIPCHK(hipGetLastError());
     return RMJ_OK;
@@ -785,8 +788,8 @@ int rmj_poke_state(rmj_handle h, uint32_t game, const RmjStateView* v) {
     S.last_error_pid = v->last_error_pid < 0 ? 0xFF : (uint8_t)v->last_error_pid;
     HIPCHK(hipMemcpy(h->d.core + game, &S, sizeof(GState), hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(h->d.wall + (size_t)game * RMJ_WALL_STRIDE, W, RMJ_WALL_STRIDE, hipMemcpyHostToDevice));
-    if (h->cfg.game_mode >= 3) hipLaunchKernelGGL(rmj3::k_refresh, dim3(1), dim3(64), 0, h->stream, h->d, game);
-    else hipLaunchKernelGGL(rmj4::k_refresh, dim3(1), dim3(64), 0, h->stream, h->d, game);
+    if (h->cfg.game_mode >= 3) hipLaunchKernelGGL(rmj3::k_refresh, dim3(1), dim3(64), 0, h->stream, (const Env*)h->d_env, game);
+    else hipLaunchKernelGGL(rmj4::k_refresh, dim3(1), dim3(64), 0, h->stream, (const Env*)h->d_env, game);
     HIPCHK(hipGetLastError());
     HIPCHK(hipStreamSynchronize(h->stream));
     return RMJ_OK;

@@ -12,7 +12,8 @@ __device__ __noinline__ void ol_env_reset_default(CtxV v) {
     init_round(c, 0, 0, 0, 0, sc);
 }
 
-__global__ __launch_bounds__(256, 3) void k_step(Env E, const uint64_t* __restrict__ actions, uint64_t policy_seed, uint32_t flags) {
+__global__ __launch_bounds__(256, 3) void k_step(const Env* __restrict__ Ep, const uint64_t* __restrict__ actions, uint64_t policy_seed, uint32_t flags) {
+    const Env& E = *Ep;  // device-resident: its address can travel to out-of-line code without a scratch copy
     __shared__ BlockShared sh;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const uint32_t g = blockIdx.x * WPB + wave;
@@ -44,7 +45,8 @@ __global__ __launch_bounds__(256, 3) void k_step(Env E, const uint64_t* __restri
     store_state(S, E.core + g, lane);
 }
 
-__global__ __launch_bounds__(256, 4) void k_reset(Env E, ResetArgs A) {
+__global__ __launch_bounds__(256, 4) void k_reset(const Env* __restrict__ Ep, ResetArgs A) {
+    const Env& E = *Ep;
     __shared__ BlockShared sh;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const uint32_t g = blockIdx.x * WPB + wave;
@@ -92,7 +94,8 @@ __global__ __launch_bounds__(256, 4) void k_reset(Env E, ResetArgs A) {
 }
 
 // recompute observation outputs of one game after rmj_poke_state
-__global__ __launch_bounds__(64, 4) void k_refresh(Env E, uint32_t g) {
+__global__ __launch_bounds__(64, 4) void k_refresh(const Env* __restrict__ Ep, uint32_t g) {
+    const Env& E = *Ep;
     __shared__ GState st;
     __shared__ WaveScratch x;
     const int lane = threadIdx.x & 63;

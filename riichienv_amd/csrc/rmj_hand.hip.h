@@ -169,7 +169,9 @@ __device__ __forceinline__ bool is_agari(const PH& h) { return is_kokushi(h) || 
 
 // hand_evaluator.rs:196-213 : lane t < 34 tests tile t; returns the wave-uniform 34-bit wait mask.
 // `h` must be wave-uniform; caller guarantees current_total == 13.
-__device__ __forceinline__ uint64_t wave_waits(const PH& h, int lane) {
+// Out of line on purpose: the probe is ~1.5k instructions and is needed at ~10 call sites of the step kernel; one
+// shared copy keeps the hot path inside the instruction cache (arguments: 5 VGPRs, no memory).
+__device__ __noinline__ uint64_t wave_waits(PH h, int lane) {
     bool w = false;
     if (lane < 34 && ph_cnt(h, lane) < 4) {
         PH x = h;

@@ -37,6 +37,21 @@ def cpu_baseline(game_mode, rule_bits, policy_seed, target_s=15.0):
                       "oracle/ C++ restatement with MJAI logging on (Rust toolchain unavailable)"}
 
 
+def pmc_traffic(games, mode):
+    """HBM bytes per k_step launch from the committed rocprofv3 PMC passes (profiles/r01_pmc_k_step.json: FETCH_SIZE and
+    WRITE_SIZE collected in separate --pmc runs of this same command, FETCH doubled per the gfx950 note of the
+    microarch guide).  bench.py cannot run the profiler itself; null when no matching profile is committed."""
+    path = os.path.join(ROOT, "profiles", "r01_pmc_k_step.json")
+    try:
+        with open(path) as f:
+            d = json.load(f)
+        if d.get("games_per_launch") == games and mode == 2:
+            return d["hbm_traffic"]["bytes_per_launch"], "profiles/r01_pmc_k_step.json"
+    except (OSError, KeyError, ValueError):
+        pass
+    return None, None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -94,6 +109,7 @@ def main():
     if rank == 0:
         kernel_s = r.step_kernel_ms * 1e-3
         b_step = B_STEP_3P if args.mode >= 3 else B_STEP_4P
+        traffic, traffic_src = pmc_traffic(args.games, args.mode)
         achieved = b_step * args.games / kernel_s
         out = {
             "metric": "env.step()/s (whole node) at 65 536 parallel 4p games; bit-exact MJAI parity",
@@ -104,7 +120,8 @@ def main():
                                    "games per GPU, device RandomAgent, auto-reset, MJAI logging on",
                        "games_per_gpu": args.games, "sharding": "by game index, no collectives"},
             "roofline": {"bound": "hbm", "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK, "traffic": None, "kernel": "k_step",
+                         "frac": achieved / HBM_PEAK, "traffic": traffic, "traffic_unit": "bytes/launch",
+                         "traffic_source": traffic_src, "kernel": "k_step",
                          "kernel_ms": r.step_kernel_ms, "bytes_per_launch": b_step * args.games},
         }
         if world == 1 and not args.no_cpu_baseline:

@@ -64,7 +64,7 @@ def main():
 
     import torch
 
-    from riichienv_amd import abi, vecenv
+    from riichienv_amd import abi, shard, vecenv
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -80,7 +80,7 @@ def main():
 
     policy_seed = 0xC0FFEE
     env = vecenv.VecRiichiEnv(args.games, game_mode=args.mode, seed=0, rule_bits=abi.RULE_TENHOU, device=local_rank,
-                              game_offset=rank * args.games, event_ring=64)
+                              game_offset=shard.shard_offset(rank, args.games), event_ring=64)
     env.reset()
     env.step_random(policy_seed, args.warmup, auto_reset=True)
 
@@ -96,15 +96,7 @@ def main():
     t1 = time.perf_counter()
     wall = t1 - t0
     steps_local = float(r.env_steps)
-    if dist is not None:
-        t = torch.tensor([wall, steps_local], device="cuda", dtype=torch.float64)
-        tmax = t.clone()
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        dist.all_reduce(t, op=dist.ReduceOp.SUM)
-        wall = float(tmax[0])
-        steps_total = float(t[1])
-    else:
-        steps_total = steps_local
+    wall, steps_total = shard.reduce_measurement(dist, wall, steps_local, device="cuda")
 
     if rank == 0:
         kernel_s = r.step_kernel_ms * 1e-3

@@ -158,3 +158,28 @@ def test_sanma_random_rollout_parity(mode, rule):
         for seat in range(3):
             assert env.mjai_log(g, seat) == games[g].log(seat), (g, seat)
     assert (env.ranks()[:, 3] == 0).all() and (np.sort(env.ranks()[:, :3], axis=1) == [1, 2, 3]).all()
+
+
+@pytest.mark.parametrize("mode", [2, 5])
+def test_shards_equal_whole_batch(mode):
+    """Multi-GPU sharding on one device: two shard environments with game_offset 0 and B hold exactly
+    the games of one 2B environment — seeds and policy keys are functions of the global game index."""
+    from riichienv_amd import shard, vecenv
+
+    B, K = 256, 600
+    whole = vecenv.VecRiichiEnv(2 * B, game_mode=mode, seed=31, event_ring=4096)
+    parts = [vecenv.VecRiichiEnv(B, game_mode=mode, seed=31, game_offset=shard.shard_offset(r, B), event_ring=4096)
+             for r in range(2)]
+    for e in [whole] + parts:
+        e.reset()
+        e.step_random(0xFEED, K, auto_reset=True)
+    assert (np.concatenate([p.step_counts() for p in parts]) == whole.step_counts()).all()
+    assert (np.concatenate([p.scores() for p in parts]) == whole.scores()).all()
+    lw, cw = whole.legal()
+    lp = np.concatenate([p.legal()[0] for p in parts])
+    cp = np.concatenate([p.legal()[1] for p in parts])
+    assert (cw == cp).all() and (lw == lp).all()
+    assert whole.total_steps() == sum(p.total_steps() for p in parts)
+    for g in (0, B - 1, B, 2 * B - 1):
+        r, l = shard.owner_of(g, B)
+        assert whole.mjai_log(g) == parts[r].mjai_log(l)

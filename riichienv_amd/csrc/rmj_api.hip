@@ -1061,4 +1061,24 @@ int rmj_bench_rollout(rmj_handle h, uint64_t policy_seed, uint32_t warmup, uint3
     return RMJ_OK;
 }
 
+#ifdef RMJ_PROFILE
+// profiling build only (scripts/prof_sections.py): per-section wave cycles / visit counts of k_step, summed over games
+int rmj_prof_fetch(uint32_t n_games, uint64_t* cyc, uint64_t* cnt, int reset) {
+    static uint32_t* buf = nullptr;
+    HIPCHK(hipDeviceSynchronize());
+    if (!buf) {
+        HIPCHK(hipMalloc(&buf, (size_t)n_games * 32 * 4));
+        HIPCHK(hipMemset(buf, 0, (size_t)n_games * 32 * 4));
+        HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(rmj::g_prof_buf), &buf, sizeof(buf)));
+    }
+    std::vector<uint32_t> h((size_t)n_games * 32);
+    HIPCHK(hipMemcpy(h.data(), buf, h.size() * 4, hipMemcpyDeviceToHost));
+    for (int i = 0; i < 16; i++) { cyc[i] = 0; cnt[i] = 0; }
+    for (size_t g = 0; g < n_games; g++)
+        for (int i = 0; i < 16; i++) { cyc[i] += h[g * 32 + i]; cnt[i] += h[g * 32 + 16 + i]; }
+    if (reset) HIPCHK(hipMemset(buf, 0, (size_t)n_games * 32 * 4));
+    return RMJ_OK;
+}
+#endif
+
 }  // extern "C"

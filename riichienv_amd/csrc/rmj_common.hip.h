@@ -34,7 +34,32 @@ struct WaveScratch {      // per-wave LDS scratch
     uint64_t legal[4][RMJ_MAX_LEGAL];  // lists produced this launch (copied to HBM by finalize_outputs)
     uint64_t wout[4];                  // waits produced this launch
     int nl[4];                         // list lengths produced this launch
+#ifdef RMJ_PROFILE
+    uint64_t tprev;                    // section timer (profiling build only, scripts/prof_sections.py)
+    uint32_t pacc[32];
+#endif
 };
+
+// Section timing of the step kernel (profiling build only: -DRMJ_PROFILE, never the shipped library): wave cycles
+// between consecutive PROF marks are accumulated per section id by lane 0.
+#ifdef RMJ_PROFILE
+__device__ uint32_t* g_prof_buf;  // [n_games][32]: 0..15 cycles, 16..31 visit counts (each wave owns its row)
+#define PROF(X, lane, id)                                                         \
+    do {                                                                          \
+        uint64_t t__ = __builtin_readcyclecounter();                              \
+        if ((lane) == 0) {                                                        \
+            (X).pacc[id] += (uint32_t)(t__ - (X).tprev);                          \
+            (X).pacc[16 + (id)] += 1u;                                            \
+        }                                                                         \
+        (X).tprev = t__;                                                          \
+    } while (0)
+#define PROF_START(X, lane) do { if ((lane) < 32) (X).pacc[lane] = 0u; (X).tprev = __builtin_readcyclecounter(); } while (0)
+#define PROF_FLUSH(X, lane, g) do { if ((lane) < 32) rmj::g_prof_buf[(size_t)(g) * 32 + (lane)] += (X).pacc[lane]; } while (0)
+#else
+#define PROF(X, lane, id) do {} while (0)
+#define PROF_START(X, lane) do {} while (0)
+#define PROF_FLUSH(X, lane, g) do {} while (0)
+#endif
 
 __device__ __forceinline__ void wave_sync() {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
@@ -159,6 +184,23 @@ __device__ __forceinline__ PH build_ph(const PState& P, int skip = -1) {
     int n = P.hand_len;
     for (int j = 0; j < n; j++)
         if (j != skip) ph_add(h, P.hand[j] >> 2);
+    return h;
+}
+// Wave-cooperative build_ph: lane j contributes the one-hot field of hand[j]; four row sums; the result is
+// wave-uniform (scalar registers).  Must be called by all 64 lanes.
+__device__ __forceinline__ PH build_ph_wave(const PState& P, int lane, int skip = -1) {
+    const int n = P.hand_len;
+    uint32_t a = 0, b = 0, c = 0, d = 0;
+    if (lane < n && lane != skip) {
+        int t = P.hand[lane] >> 2;
+        int s = t_suit(t);
+        uint32_t one = 1u << (3 * (t - 9 * s));
+        a = s == 0 ? one : 0u; b = s == 1 ? one : 0u; c = s == 2 ? one : 0u; d = s == 3 ? one : 0u;
+    }
+    a = row_sum16(a); b = row_sum16(b); c = row_sum16(c); d = row_sum16(d);
+    PH h;
+    h.a = (uint32_t)__builtin_amdgcn_readlane((int)a, 15); h.b = (uint32_t)__builtin_amdgcn_readlane((int)b, 15);
+    h.c = (uint32_t)__builtin_amdgcn_readlane((int)c, 15); h.d = (uint32_t)__builtin_amdgcn_readlane((int)d, 15);
     return h;
 }
 __device__ inline MeldAgg build_meld_agg(const PState& P) {

@@ -30,6 +30,14 @@ struct PH {
 #define O7_2 02222222u
 #define O7_4 04444444u
 
+// Sum over each 16-lane row (DPP row_shr 1,2,4,8: no LDS traffic); the total lands in lane 15 of the row.
+__device__ __forceinline__ uint32_t row_sum16(uint32_t v) {
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, false);
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, false);
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, false);
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, false);
+    return v;
+}
 __device__ __forceinline__ int t_suit(int t) { return t >= 27 ? 3 : (t >= 18 ? 2 : (t >= 9 ? 1 : 0)); }
 __device__ __forceinline__ uint32_t ph_get(const PH& h, int s) { return s == 0 ? h.a : (s == 1 ? h.b : (s == 2 ? h.c : h.d)); }
 __device__ __forceinline__ void ph_addv(PH& h, int s, uint32_t v) {
@@ -167,18 +175,75 @@ __device__ __forceinline__ bool is_standard_agari(const PH& h) {
 // agari.rs:65-73
 __device__ __forceinline__ bool is_agari(const PH& h) { return is_kokushi(h) || is_chiitoi(h) || is_standard_agari(h); }
 
+// pair + mentsu within one numbered suit, three candidates only: with the pair at rank j and everything else in
+// mentsu, sum(rank * count) = 2j (mod 3) (a shuntsu adds 3i+3, a koutsu 3i), hence j = 2 * sum (mod 3).
+__device__ __forceinline__ int pair_residue(uint32_t x) {
+    int s1 = field_sum(x & 0070070070u), s2 = field_sum(x & 0700700700u);  // ranks 1,4,7 / 2,5,8
+    return (2 * (s1 + 2 * s2)) % 3;
+}
+
 // hand_evaluator.rs:196-213 : lane t < 34 tests tile t; returns the wave-uniform 34-bit wait mask.
 // `h` must be wave-uniform; caller guarantees current_total == 13.
-// Out of line on purpose: the probe is ~1.5k instructions and is needed at ~10 call sites of the step kernel; one
-// shared copy keeps the hot path inside the instruction cache (arguments: 5 VGPRs, no memory).
+//
+// Adding tile t changes ONE suit word, so the standard-form test factorises: lanes 0..33 judge their modified suit
+// word, lanes 34..37 judge the four unmodified words in the same instruction stream, and a candidate wins iff its own
+// word and the three unmodified others are all consistent ("mentsu only" when the word holds 0 mod 3 tiles,
+// "pair + mentsu" when it holds 2 mod 3) with exactly one pair suit (agari.rs:183-245, boolean result).
+// Out of line on purpose: one shared copy for the ~10 call sites of the step kernel (instruction-cache footprint).
 __device__ __noinline__ uint64_t wave_waits(PH h, int lane) {
-    bool w = false;
-    if (lane < 34 && ph_cnt(h, lane) < 4) {
-        PH x = h;
-        ph_add(x, lane);
-        w = is_agari(x);
+    h.a = __builtin_amdgcn_readfirstlane(h.a); h.b = __builtin_amdgcn_readfirstlane(h.b);
+    h.c = __builtin_amdgcn_readfirstlane(h.c); h.d = __builtin_amdgcn_readfirstlane(h.d);
+    const bool cand = lane < 34;
+    const int s = cand ? t_suit(lane) : ((lane - 34) & 3);
+    uint32_t w = ph_get(h, s);
+    bool live = lane < 38;
+    if (cand) {
+        int sh = 3 * (lane - 9 * s);
+        live = ((w >> sh) & 7u) < 4u;
+        w += 1u << sh;
     }
-    return __ballot(w) & 0x3FFFFFFFFull;
+    const int tot = field_sum(w) % 3;
+    bool r = false;
+    if (live && tot != 1) {
+        if (s == 3) {
+            r = tot == 0 ? honors_ok0(w) : honors_ok2(w);
+        } else {
+            // first pass serves both modes: the word itself (mentsu only) or the word minus the first pair candidate
+            int j = pair_residue(w);
+            uint32_t y = w;
+            bool go = true;
+            if (tot == 2) {
+                go = ((w >> (3 * j)) & 7u) >= 2u;
+                y = w - (2u << (3 * j));
+            }
+            r = go && mentsu_ok(y);
+            if (tot == 2 && !r) {
+#pragma unroll 1
+                for (int q = 0; q < 2 && !r; q++) {
+                    j += 3;
+                    if (((w >> (3 * j)) & 7u) >= 2u) r = mentsu_ok(w - (2u << (3 * j)));
+                }
+            }
+        }
+    }
+    const uint64_t R = __ballot(r), T2 = __ballot(tot == 2);
+    const uint32_t bR = (uint32_t)(R >> 34) & 15u, bT2 = (uint32_t)(T2 >> 34) & 15u;
+    const uint32_t others = 15u & ~(1u << s);
+    bool win = cand && live && r && (bR & others) == others && (__popc(bT2 & others) + (tot == 2 ? 1 : 0)) == 1;
+    // chiitoi needs six pairs among the 13 tiles, kokushi twelve of the thirteen terminal kinds (wave-uniform gates)
+    const int pairs = __popc(h.a & O9_2 & ~(h.a << 1)) + __popc(h.b & O9_2 & ~(h.b << 1)) + __popc(h.c & O9_2 & ~(h.c << 1)) +
+                      __popc(h.d & O7_2 & ~(h.d << 1));  // fields equal to 2 or 6
+    uint32_t pres_d = (h.d | (h.d >> 1) | (h.d >> 2)) & O7_1;
+    const int kinds = __popc(pres_d) + ((h.a & 7u) != 0u) + ((h.a >> 24) != 0u) + ((h.b & 7u) != 0u) + ((h.b >> 24) != 0u) +
+                      ((h.c & 7u) != 0u) + ((h.c >> 24) != 0u);
+    if (pairs >= 6 || kinds >= 12) {
+        if (cand && live && !win) {
+            PH x = h;
+            ph_add(x, lane);
+            win = is_kokushi(x) || is_chiitoi(x);
+        }
+    }
+    return __ballot(win) & 0x3FFFFFFFFull;
 }
 
 // ---------------------------------------------------------------- melds (wave-uniform aggregate)

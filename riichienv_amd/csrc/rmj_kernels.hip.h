@@ -19,30 +19,43 @@ __global__ __launch_bounds__(256, 3) void k_step(const Env* __restrict__ Ep, con
     const uint32_t g = blockIdx.x * WPB + wave;
     if (g >= E.n_games) return;
     GState& S = sh.st[wave];
+    PROF_START(sh.x[wave], lane);
     load_state(S, E.core + g, lane);
     Ctx c{S, E, sh.x[wave], g, lane, E.wall + (size_t)g * RMJ_WALL_STRIDE, E.legal + (size_t)g * 4 * RMJ_MAX_LEGAL};
+    PROF(c.X, lane, 0);
     if (S.is_done && (flags & STEP_F_AUTORESET)) {
         ol_env_reset_default(ctx_pack(c));
     } else {
         uint64_t acts[4];
-        if (flags & STEP_F_RANDOM) {
+        const bool device_policy = (flags & STEP_F_RANDOM) != 0;
+        // lane = seat: one gather (and one copy of the 64-bit modulo / of the canonicalisation) for all seats
+        uint64_t mine = RMJ_NO_ACTION;
+        if (device_policy) {
             // RandomAgent (random_agent.py:6-15), keyed per (game, step, seat): see rmj_step_random in the header
             uint64_t gs = sm64(policy_seed + E.game_offset + g);
-            for (int p = 0; p < 4; p++) {
-                acts[p] = RMJ_NO_ACTION;
-                int n = E.nlegal[(size_t)g * 4 + p];
-                if (((S.active_mask >> p) & 1u) && n > 0 && !S.is_done) {
-                    uint64_t ch = sm64(gs + (uint64_t)S.step_count * 4ull + (uint64_t)p) % (uint64_t)n;
-                    acts[p] = c.Lg[p * RMJ_MAX_LEGAL + ch];
+            if (lane < 4) {
+                int n = E.nlegal[(size_t)g * 4 + lane];
+                if (((S.active_mask >> lane) & 1u) && n > 0 && !S.is_done) {
+                    uint64_t ch = sm64(gs + (uint64_t)S.step_count * 4ull + (uint64_t)lane) % (uint64_t)n;
+                    mine = c.Lg[lane * RMJ_MAX_LEGAL + ch];
                 }
             }
-        } else {
-            for (int p = 0; p < 4; p++) acts[p] = actions[(size_t)g * 4 + p];
+        } else if (lane < 4) {
+            uint64_t a = actions[(size_t)g * 4 + lane];
+            mine = ((a & 0xFF) == 0xFF) ? RMJ_NO_ACTION : a_canon(a);
         }
-        step_game(c, acts);
+        const int lo = (int)(uint32_t)mine, hi = (int)(uint32_t)(mine >> 32);
+#pragma unroll
+        for (int p = 0; p < 4; p++)
+            acts[p] = (uint64_t)(uint32_t)__builtin_amdgcn_readlane(lo, p) | ((uint64_t)(uint32_t)__builtin_amdgcn_readlane(hi, p) << 32);
+        PROF(c.X, lane, 1);
+        step_game(c, acts, device_policy);  // picked from the stored lists: valid by construction
     }
+    PROF(c.X, lane, 8);
     finalize_outputs(c, true);
     store_state(S, E.core + g, lane);
+    PROF(c.X, lane, 15);
+    PROF_FLUSH(c.X, lane, g);
 }
 
 __global__ __launch_bounds__(256, 4) void k_reset(const Env* __restrict__ Ep, ResetArgs A) {

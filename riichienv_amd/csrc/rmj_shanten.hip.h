@@ -288,13 +288,38 @@ __device__ __forceinline__ int sh_shanten(const PH& h, int len_div3, bool sanma,
     return s;
 }
 
-// Wave-cooperative 4P shanten of ONE wave-uniform hand (used as a sound prefilter for the riichi probe):
-// lane = tile rank computes its term of the perfect hash in parallel, four segmented wave sums, four table loads.
+// entry (p,k) of the (min,+) merge of two packed cost vectors, for a lane-local target (p,k); x/y are given as their
+// p=0 / p=1 halves (five nibbles each).  Same capping at 15 as sh_merge.
+__device__ __forceinline__ uint32_t sh_merge_entry(uint32_t x0, uint32_t x1, uint32_t y0, uint32_t y1, int p, int k) {
+    uint32_t best = 15u;
+#pragma unroll
+    for (int p1 = 0; p1 < 2; p1++)
+#pragma unroll
+        for (int k1 = 0; k1 < 5; k1++) {
+            uint32_t vx = ((p1 ? x1 : x0) >> (4 * k1)) & 15u;
+            int pp = p - p1, kk = k - k1;
+            uint32_t vy = ((pp ? y1 : y0) >> (4 * (kk & 7))) & 15u;
+            uint32_t v = vx + vy;
+            best = (pp >= 0 && kk >= 0 && v < best) ? v : best;
+        }
+    return best;
+}
+__device__ __forceinline__ uint32_t row_min16(uint32_t v) {  // minimum over a 16-lane row, in lane 15 of the row
+    v = min(v, (uint32_t)__builtin_amdgcn_update_dpp(99, (int)v, 0x111, 0xf, 0xf, false));
+    v = min(v, (uint32_t)__builtin_amdgcn_update_dpp(99, (int)v, 0x112, 0xf, 0xf, false));
+    v = min(v, (uint32_t)__builtin_amdgcn_update_dpp(99, (int)v, 0x114, 0xf, 0xf, false));
+    v = min(v, (uint32_t)__builtin_amdgcn_update_dpp(99, (int)v, 0x118, 0xf, 0xf, false));
+    return v;
+}
+
+// Wave-cooperative 4P shanten of ONE wave-uniform hand (used as a sound prefilter for the riichi probe).
+// lane = 16*suit + rank computes its term of the perfect hash, one DPP row sum per suit, four table loads; the
+// (min,+) merges are lane-parallel too: lanes 0..9 hold merge(a,b)[idx], lanes 16..25 the entry of merge(c,d) that
+// pairs with it in the final entry (pair, m), and a row minimum finishes.
 __device__ __forceinline__ int sh_shanten_wave(const PH& h, int len_div3, const ShantenTables& T, int lane) {
+    const int q = lane >> 4, i = lane & 15;
     uint32_t val = 0;
-    int q = t_suit(lane < 34 ? lane : 0);
-    if (lane < 34) {
-        int i = lane - 9 * q;
+    if (i < (q < 3 ? 9 : 7)) {
         uint32_t x = ph_get(h, q);
         uint32_t c = (x >> (3 * i)) & 7u;
         uint32_t s = (uint32_t)field_sum(x & ((1u << (3 * i)) - 1u));
@@ -303,25 +328,31 @@ __device__ __forceinline__ int sh_shanten_wave(const PH& h, int len_div3, const 
         if (s + c > 14u) c = 14u - s;
         val = (q < 3 ? T.rank9 : T.rank7)[(i * 15 + s) * 5 + c];
     }
-    uint32_t r0 = (lane < 34 && q == 0) ? val : 0u, r1 = (lane < 34 && q == 1) ? val : 0u;
-    uint32_t r2 = (lane < 34 && q == 2) ? val : 0u, r3 = (lane < 34 && q == 3) ? val : 0u;
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) {
-        r0 += __shfl_xor(r0, off, 64);
-        r1 += __shfl_xor(r1, off, 64);
-        r2 += __shfl_xor(r2, off, 64);
-        r3 += __shfl_xor(r3, off, 64);
-    }
-    uint64_t a = T.suit[r0], b = T.suit[r1], c = T.suit[r2], d = T.honor[r3];
-    uint64_t r = sh_merge(sh_merge(a, b), sh_merge(c, d));
-    int m = len_div3 > 4 ? 4 : len_div3;
-    int sres = (int)((r >> (4 * (5 + m))) & 15u) - 1;
+    val = row_sum16(val);
+    const uint32_t r0 = (uint32_t)__builtin_amdgcn_readlane((int)val, 15), r1 = (uint32_t)__builtin_amdgcn_readlane((int)val, 31);
+    const uint32_t r2 = (uint32_t)__builtin_amdgcn_readlane((int)val, 47), r3 = (uint32_t)__builtin_amdgcn_readlane((int)val, 63);
+    const uint64_t a = T.suit[r0], b = T.suit[r1], c = T.suit[r2], d = T.honor[r3];
+    const int m = len_div3 > 4 ? 4 : len_div3;
+    const bool upper = lane >= 16;
+    const int p = i >= 5 ? 1 : 0, k = i - 5 * p;
+    const bool valid = lane < 32 && i < 10 && k <= m;
+    const uint64_t x = upper ? c : a, y = upper ? d : b;
+    uint32_t e = 15u;
+    if (valid)
+        e = sh_merge_entry((uint32_t)x & 0xFFFFFu, (uint32_t)(x >> 20) & 0xFFFFFu, (uint32_t)y & 0xFFFFFu, (uint32_t)(y >> 20) & 0xFFFFFu,
+                           upper ? 1 - p : p, upper ? m - k : k);
+    const uint32_t partner = (uint32_t)__shfl_down((int)e, 16, 64);
+    uint32_t t = (valid && !upper) ? e + partner : 99u;
+    t = row_min16(t);
+    uint32_t rep = (uint32_t)__builtin_amdgcn_readlane((int)t, 15);
+    if (rep > 15u) rep = 15u;
+    int sres = (int)rep - 1;
     if (sres <= 0 || len_div3 < 4) return sres;
     int ch = sh_chiitoi(h, false);
     sres = ch < sres ? ch : sres;
     if (sres > 0) {
-        int k = sh_kokushi(h);
-        sres = k < sres ? k : sres;
+        int kk = sh_kokushi(h);
+        sres = kk < sres ? kk : sres;
     }
     return sres;
 }

@@ -133,7 +133,7 @@ __device__ __forceinline__ CalcOut seat_calc_impl(Ctx& c, int seat, int skip_idx
     PState& P = S.p[seat];
     CalcIn in;
     in.ma = build_meld_agg(P);
-    PH h = build_ph(P, skip_idx);
+    PH h = build_ph_wave(P, c.lane, skip_idx);
     int aka = in.ma.aka;
     for (int j = 0; j < P.hand_len; j++)
         if (j != skip_idx) aka += is_aka(P.hand[j]);
@@ -203,7 +203,7 @@ __device__ __forceinline__ uint64_t seat_waits(Ctx& c, int seat) {
     PState& P = c.S.p[seat];
     if (P.hand_len + 3 * P.n_melds != 13) return 0ull;
     if (P.flags & PF_WAITS_VALID) return P.waits13;
-    PH h = build_ph(P);
+    PH h = build_ph_wave(P, c.lane);
     uint64_t W = wave_waits(h, c.lane);
     P.waits13 = W;
     P.flags |= PF_WAITS_VALID;
@@ -214,7 +214,7 @@ __device__ __forceinline__ void waits_invalidate(PState& P) { P.flags &= ~PF_WAI
 __device__ __noinline__ bool ol_is_agari(PH h) { return is_agari(h); }  // rare fallback: keep the big body out of line
 __device__ __forceinline__ bool seat_shape(Ctx& c, int seat, int skip_idx, int win_tile) {
     PState& P = c.S.p[seat];
-    PH h = build_ph(P, skip_idx);
+    PH h = build_ph_wave(P, c.lane, skip_idx);
     if (ph_total(h) + 3 * P.n_melds == 13) ph_add(h, win_tile >> 2);
     return ol_is_agari(h);
 }
@@ -336,7 +336,7 @@ __device__ __forceinline__ uint32_t tenpai_after_discard(Ctx& c, const PState& P
     uint32_t out = 0;
     int hl = P.hand_len;
     if (hl + 3 * P.n_melds != 14) return 0;
-    PH full = build_ph(P);
+    PH full = build_ph_wave(P, c.lane);
     // Sound prefilter: a tenpai 13-tile subset implies replacement number <= 1 for the 14 tiles
     // (swap the discard for the winning tile), i.e. shanten(14) <= 0.  Only then run the exact probes.
     // (4P tables; a sanma hand has no 2m-8m, for which the 4P number is a lower bound of the 3P one, so it is sound too)
@@ -390,7 +390,7 @@ __device__ __forceinline__ void gen_act_legal(Ctx& c, int pid) {
             uint64_t W13;
             if (P.flags & PF_WAITS_VALID) W13 = P.waits13;
             else {
-                W13 = wave_waits(build_ph(P, idx), lane);
+                W13 = wave_waits(build_ph_wave(P, lane, idx), lane);
                 P.waits13 = W13;
                 P.flags |= PF_WAITS_VALID;
             }
@@ -403,6 +403,7 @@ __device__ __forceinline__ void gen_act_legal(Ctx& c, int pid) {
             if (r.is_win && (r.yakuman || r.han >= 1)) put_legal(c, pid, n++, mk_action(RMJ_TSUMO, tile, 0));
         }
     }
+    PROF(c.X, lane, 9);
     // 2. Discard / Riichi
     uint8_t ht = lane < hl ? P.hand[lane] : 0xFF;
     bool forb = false;
@@ -426,6 +427,7 @@ __device__ __forceinline__ void gen_act_legal(Ctx& c, int pid) {
         n += __popcll(vb);
         if (riichi_pre && tp != 0u) put_legal(c, pid, n++, mk_action(RMJ_RIICHI, RMJ_TILE_NONE, 0));
     }
+    PROF(c.X, lane, 10);
     // 3. Kan
     if (S.drawable_count > 0 && drawn) {
         if (!r_decl && !r_stage) {
@@ -474,7 +476,7 @@ __device__ __forceinline__ void gen_act_legal(Ctx& c, int pid) {
             }
         } else if (r_decl) {
             int t = S.drawn_tile, t34 = t >> 2;
-            PH full = build_ph(P);
+            PH full = build_ph_wave(P, lane);
             if (ph_cnt(full, t34) == 4) {
                 PH pre = full;
                 ph_sub(pre, t34);
@@ -490,6 +492,7 @@ __device__ __forceinline__ void gen_act_legal(Ctx& c, int pid) {
             }
         }
     }
+    PROF(c.X, lane, 11);
     // 4. Kyushu kyuhai
     bool no_calls = (S.p[0].n_melds | S.p[1].n_melds | S.p[2].n_melds | S.p[3].n_melds) == 0;
     if (S.is_first_turn && no_calls && !r_stage) {
@@ -511,6 +514,7 @@ __device__ __forceinline__ void gen_act_legal(Ctx& c, int pid) {
         n += __popcll(kb);
     }
     c.X.nl[pid] = n > RMJ_MAX_LEGAL ? RMJ_MAX_LEGAL : n;
+    PROF(c.X, lane, 12);
 }
 
 // current_claims.entry(i).or_default().push(Ron) (state/mod.rs:524-533, 665-673; sanma.rs:121-128): the Ron offer is
@@ -841,31 +845,29 @@ __device__ __noinline__ void ol_trigger_ryukyoku(CtxV v, int reason, int offende
 // state/mod.rs:1970-2019
 __device__ __forceinline__ bool check_abortive_draw(Ctx& c) {
     GState& S = c.S;
-    bool turns_ok = true, melds_empty = true, all_riichi = true;
-    for (int p = 0; p < 4; p++) {
-        turns_ok = turns_ok && S.p[p].n_discards == 1;
-        melds_empty = melds_empty && S.p[p].n_melds == 0;
-        all_riichi = all_riichi && (S.p[p].flags & PF_RIICHI_DECLARED);
-    }
-    if (!KSANMA && turns_ok && melds_empty) {  // sufuurenta and suucha riichi are disabled in 3P (state_3p/mod.rs:1861-1888)
+    const int lane = c.lane;
+    // lane = seat*4 + meld slot (16 lanes); seat facts are taken from slot 0 of each seat
+    const int p = (lane >> 2) & 3, m = lane & 3;
+    const PState& P = S.p[p];
+    const bool in = lane < 16, seat_lane = in && m == 0;
+    const int nm = P.n_melds;
+    const uint32_t turns_ok = (uint32_t)__ballot(seat_lane && P.n_discards == 1);
+    const uint32_t has_melds = (uint32_t)__ballot(seat_lane && nm != 0);
+    const uint32_t riichi = (uint32_t)__ballot(seat_lane && (P.flags & PF_RIICHI_DECLARED));
+    const uint32_t kan = (uint32_t)__ballot(in && m < nm && P.meld_type[m] >= RMJ_MELD_DAIMINKAN);
+    const uint32_t all_seats = 0x1111u;
+    if (!KSANMA && turns_ok == all_seats && has_melds == 0u) {  // sufuurenta / suucha riichi: disabled in 3P (state_3p/mod.rs:1861-1888)
         int first = S.p[0].discards[0] >> 2;
         if (first >= 27 && first <= 30) {
-            bool all = true;
-            for (int p = 0; p < 4; p++) all = all && (S.p[p].discards[0] >> 2) == first;
-            if (all) { trigger_ryukyoku(c, RMJ_RK_SUFUURENTA, 0); return true; }
+            uint32_t same = (uint32_t)__ballot(seat_lane && (P.discards[0] >> 2) == first);
+            if (same == all_seats) { trigger_ryukyoku(c, RMJ_RK_SUFUURENTA, 0); return true; }
         }
     }
-    int kans = 0, first_owner = -1;
-    bool same = true;
-    for (int p = 0; p < 4; p++)
-        for (int m = 0; m < S.p[p].n_melds; m++)
-            if (S.p[p].meld_type[m] >= RMJ_MELD_DAIMINKAN) {
-                kans++;
-                if (first_owner < 0) first_owner = p;
-                else same = same && (p == first_owner);
-            }
-    if (kans == 4 && !same) { trigger_ryukyoku(c, RMJ_RK_SUUKANSANSEN, 0); return true; }
-    if (!KSANMA && all_riichi) { trigger_ryukyoku(c, RMJ_RK_SUUCHA_RIICHI, 0); return true; }
+    if (__popc(kan) == 4) {  // suukansansen: four kans by at least two players
+        int owner = (__ffs((int)kan) - 1) >> 2;
+        if (kan & ~(0xFu << (4 * owner))) { trigger_ryukyoku(c, RMJ_RK_SUUKANSANSEN, 0); return true; }
+    }
+    if (!KSANMA && riichi == all_seats) { trigger_ryukyoku(c, RMJ_RK_SUUCHA_RIICHI, 0); return true; }
     return false;
 }
 
@@ -993,6 +995,7 @@ __device__ __forceinline__ void resolve_discard(Ctx& c, int pid, int tile, bool 
     S.active_mask = 0;
     S.ron_offer_mask = 0;
     uint32_t claim_active = 0;
+    PROF(c.X, c.lane, 4);
     // (kept unrolled: with a compile-time seat index the claim generation is ~20 % faster than a rolled loop)
 #pragma unroll
     for (int i = 0; i < 4; i++) {
@@ -1001,6 +1004,7 @@ __device__ __forceinline__ void resolve_discard(Ctx& c, int pid, int tile, bool 
         if (i == pid || i >= KNP) continue;
         if (gen_claims(c, i, pid, tile)) claim_active |= 1u << i;
     }
+    PROF(c.X, c.lane, 5);
     if (claim_active) {
         S.phase = RMJ_WAIT_RESPONSE;
         S.active_mask = (uint8_t)claim_active;
@@ -1013,6 +1017,7 @@ __device__ __forceinline__ void resolve_discard(Ctx& c, int pid, int tile, bool 
             if (S.turn_count >= (uint32_t)KNP) S.is_first_turn = 0;
         }
     }
+    PROF(c.X, c.lane, 6);
 }
 
 __device__ inline int yakuman_val(const Ctx& c, int yid) {
@@ -1138,16 +1143,18 @@ __device__ inline void handle_kita(Ctx& c, int pid, uint64_t act) {
 }
 
 // ---------------------------------------------------------------- step (state/mod.rs:330-1315)
-__device__ __forceinline__ void step_game(Ctx& c, const uint64_t acts_in[4]) {
+// acts_in: canonical packed actions (a_canon), RMJ_NO_ACTION for a silent seat.  `trusted`: they were taken from the
+// stored legal lists by the device policy (legal by construction), so validation is skipped.
+__device__ __forceinline__ void step_game(Ctx& c, const uint64_t acts_in[4], bool trusted = false) {
     GState& S = c.S;
     const int lane = c.lane;
     if (S.is_done) return;
     S.step_count += 1;
     uint64_t acts[4];
-    for (int p = 0; p < 4; p++) acts[p] = ((acts_in[p] & 0xFF) == 0xFF) ? RMJ_NO_ACTION : a_canon(acts_in[p]);
+    for (int p = 0; p < 4; p++) acts[p] = acts_in[p];
     // ---- validation against the stored legal lists
     for (int pid = 0; pid < 4; pid++) {
-        if (acts[pid] == RMJ_NO_ACTION) continue;
+        if (trusted || acts[pid] == RMJ_NO_ACTION) continue;
         int n = c.E.nlegal[(size_t)c.g * 4 + pid];
         bool active = (S.active_mask >> pid) & 1u;
         bool valid;
@@ -1164,6 +1171,7 @@ __device__ __forceinline__ void step_game(Ctx& c, const uint64_t acts_in[4]) {
             return;
         }
     }
+    PROF(c.X, lane, 2);
     if (S.phase == RMJ_WAIT_ACT) {
         const int pid = S.current_player;
         const uint64_t act = pid == 0 ? acts[0] : (pid == 1 ? acts[1] : (pid == 2 ? acts[2] : acts[3]));
@@ -1337,10 +1345,14 @@ __device__ __forceinline__ void step_game(Ctx& c, const uint64_t acts_in[4]) {
         } else if (ty == RMJ_KITA && KSANMA) {
             handle_kita(c, pid, act);
         }
+        PROF(c.X, lane, 3);
         if (do_discard) resolve_discard(c, pid, d_tile, d_tsumogiri);
         return;
     }
     // ---- WaitResponse (state/mod.rs:900-1314)
+#ifdef RMJ_PROFILE
+    struct ProfTail { Ctx& c; __device__ ~ProfTail() { PROF(c.X, c.lane, 7); } } prof_tail{c};
+#endif
     for (int pid = 0; pid < 4; pid++)
         if ((S.ron_offer_mask >> pid) & 1u) {
             bool roned = acts[pid] != RMJ_NO_ACTION && a_type(acts[pid]) == RMJ_RON;
@@ -1511,6 +1523,7 @@ __device__ __forceinline__ void finalize_outputs(Ctx& c, bool claims_fresh) {
         }
     }
     wave_sync();
+    PROF(c.X, lane, 13);
     // masks + list publication
     for (int i = lane; i < (4 * 82 + 3) / 4; i += 64) reinterpret_cast<uint32_t*>(c.X.maskbuf)[i] = 0u;
     wave_sync();
@@ -1542,6 +1555,7 @@ __device__ __forceinline__ void finalize_outputs(Ctx& c, bool claims_fresh) {
         c.E.waits[(size_t)c.g * 4 + lane] = w;
     }
     if (lane == 0) c.E.status[c.g] = (uint32_t)S.active_mask | ((uint32_t)S.phase << 8) | ((uint32_t)S.is_done << 16);
+    PROF(c.X, lane, 14);
 }
 
 }  // namespace RMJ_NS

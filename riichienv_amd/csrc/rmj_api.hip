@@ -1067,16 +1067,16 @@ int rmj_prof_fetch(uint32_t n_games, uint64_t* cyc, uint64_t* cnt, int reset) {
     static uint32_t* buf = nullptr;
     HIPCHK(hipDeviceSynchronize());
     if (!buf) {
-        HIPCHK(hipMalloc(&buf, (size_t)n_games * 32 * 4));
-        HIPCHK(hipMemset(buf, 0, (size_t)n_games * 32 * 4));
+        HIPCHK(hipMalloc(&buf, (size_t)n_games * 64 * 4));
+        HIPCHK(hipMemset(buf, 0, (size_t)n_games * 64 * 4));
         HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(rmj::g_prof_buf), &buf, sizeof(buf)));
     }
-    std::vector<uint32_t> h((size_t)n_games * 32);
+    std::vector<uint32_t> h((size_t)n_games * 64);
     HIPCHK(hipMemcpy(h.data(), buf, h.size() * 4, hipMemcpyDeviceToHost));
-    for (int i = 0; i < 16; i++) { cyc[i] = 0; cnt[i] = 0; }
+    for (int i = 0; i < 32; i++) { cyc[i] = 0; cnt[i] = 0; }
     for (size_t g = 0; g < n_games; g++)
-        for (int i = 0; i < 16; i++) { cyc[i] += h[g * 32 + i]; cnt[i] += h[g * 32 + 16 + i]; }
-    if (reset) HIPCHK(hipMemset(buf, 0, (size_t)n_games * 32 * 4));
+        for (int i = 0; i < 32; i++) { cyc[i] += h[g * 64 + i]; cnt[i] += h[g * 64 + 32 + i]; }
+    if (reset) HIPCHK(hipMemset(buf, 0, (size_t)n_games * 64 * 4));
     return RMJ_OK;
 }
 #endif

@@ -36,25 +36,25 @@ struct WaveScratch {      // per-wave LDS scratch
     int nl[4];                         // list lengths produced this launch
 #ifdef RMJ_PROFILE
     uint64_t tprev;                    // section timer (profiling build only, scripts/prof_sections.py)
-    uint32_t pacc[32];
+    uint32_t pacc[64];
 #endif
 };
 
 // Section timing of the step kernel (profiling build only: -DRMJ_PROFILE, never the shipped library): wave cycles
 // between consecutive PROF marks are accumulated per section id by lane 0.
 #ifdef RMJ_PROFILE
-__device__ uint32_t* g_prof_buf;  // [n_games][32]: 0..15 cycles, 16..31 visit counts (each wave owns its row)
+__device__ uint32_t* g_prof_buf;  // [n_games][64]: 0..31 cycles, 32..63 visit counts (each wave owns its row)
 #define PROF(X, lane, id)                                                         \
     do {                                                                          \
         uint64_t t__ = __builtin_readcyclecounter();                              \
         if ((lane) == 0) {                                                        \
             (X).pacc[id] += (uint32_t)(t__ - (X).tprev);                          \
-            (X).pacc[16 + (id)] += 1u;                                            \
+            (X).pacc[32 + (id)] += 1u;                                            \
         }                                                                         \
         (X).tprev = t__;                                                          \
     } while (0)
-#define PROF_START(X, lane) do { if ((lane) < 32) (X).pacc[lane] = 0u; (X).tprev = __builtin_readcyclecounter(); } while (0)
-#define PROF_FLUSH(X, lane, g) do { if ((lane) < 32) rmj::g_prof_buf[(size_t)(g) * 32 + (lane)] += (X).pacc[lane]; } while (0)
+#define PROF_START(X, lane) do { (X).pacc[lane] = 0u; (X).tprev = __builtin_readcyclecounter(); } while (0)
+#define PROF_FLUSH(X, lane, g) do { rmj::g_prof_buf[(size_t)(g) * 64 + (lane)] += (X).pacc[lane]; } while (0)
 #else
 #define PROF(X, lane, id) do {} while (0)
 #define PROF_START(X, lane) do {} while (0)

@@ -12,7 +12,10 @@ __device__ __noinline__ void ol_env_reset_default(CtxV v) {
     init_round(c, 0, 0, 0, 0, sc);
 }
 
-__global__ __launch_bounds__(256, 3) void k_step(const Env* __restrict__ Ep, const uint64_t* __restrict__ actions, uint64_t policy_seed, uint32_t flags) {
+#ifndef RMJ_STEP_WAVES
+#define RMJ_STEP_WAVES 3
+#endif
+__global__ __launch_bounds__(256, RMJ_STEP_WAVES) void k_step(const Env* __restrict__ Ep, const uint64_t* __restrict__ actions, uint64_t policy_seed, uint32_t flags) {
     const Env& E = *Ep;  // device-resident: its address can travel to out-of-line code without a scratch copy
     __shared__ BlockShared sh;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -22,6 +25,8 @@ __global__ __launch_bounds__(256, 3) void k_step(const Env* __restrict__ Ep, con
     PROF_START(sh.x[wave], lane);
     load_state(S, E.core + g, lane);
     Ctx c{S, E, sh.x[wave], g, lane, E.wall + (size_t)g * RMJ_WALL_STRIDE, E.legal + (size_t)g * 4 * RMJ_MAX_LEGAL};
+    c.pf_live_end = S.live_end;
+    c.pf_draw = c.W[S.live_end > 0 ? S.live_end - 1 : 0];
     PROF(c.X, lane, 0);
     if (S.is_done && (flags & STEP_F_AUTORESET)) {
         ol_env_reset_default(ctx_pack(c));
@@ -34,7 +39,7 @@ __global__ __launch_bounds__(256, 3) void k_step(const Env* __restrict__ Ep, con
             // RandomAgent (random_agent.py:6-15), keyed per (game, step, seat): see rmj_step_random in the header
             uint64_t gs = sm64(policy_seed + E.game_offset + g);
             if (lane < 4) {
-                int n = E.nlegal[(size_t)g * 4 + lane];
+                int n = S.nlegal[lane];
                 if (((S.active_mask >> lane) & 1u) && n > 0 && !S.is_done) {
                     uint64_t ch = sm64(gs + (uint64_t)S.step_count * 4ull + (uint64_t)lane) % (uint64_t)n;
                     mine = c.Lg[lane * RMJ_MAX_LEGAL + ch];

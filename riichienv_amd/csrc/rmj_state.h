@@ -81,7 +81,8 @@ struct alignas(16) GState {  // 4*128 + 128 = 640 bytes
     // (it is cleared only by _resolve_discard / all-pass / _initialize_round, so claims survive an accepted call and
     // resurface, in front of a chankan / kita Ron offer, if the caller kans or declares kita before discarding).
     uint8_t stale_n[4];
-    uint8_t pad[128 - 8 - 8 - 20 - 16 - 4 - 6 - 3 - 4];
+    uint8_t nlegal[4];        // copy of the nlegal slab row: the policy / validation need it as soon as the record arrives
+    uint8_t pad[128 - 8 - 8 - 20 - 16 - 4 - 6 - 3 - 4 - 4];
 };
 
 #ifdef __cplusplus

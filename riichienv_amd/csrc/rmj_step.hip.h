@@ -31,6 +31,9 @@ struct Ctx {
     int lane;
     uint8_t* W;       // this game's wall (global)
     uint64_t* Lg;     // this game's legal lists [4][64] in HBM (read for validation, written by finalize)
+    // the next live-wall draw W[live_end-1], fetched as soon as the record is in LDS so that its latency is off the
+    // critical path of deal_next (valid while live_end == pf_live_end; -1: not fetched)
+    int pf_draw = -1, pf_live_end = -1;
 };
 
 // By-value view of a Ctx for out-of-line (rare-path) functions.  Passing Ctx& to a non-inlined function would
@@ -91,18 +94,19 @@ __device__ __forceinline__ void emit_meld(Ctx& c, uint8_t type, uint8_t actor, u
 }
 
 __device__ __forceinline__ bool rule(const Ctx& c, uint32_t bit) { return (c.E.rule_bits & bit) != 0; }
-// rank-sort the first n tiles of a hand (ids are unique)
-__device__ __forceinline__ void sort_hand(Ctx& c, PState& P, int n) {
-    int t = 0, r = 0;
-    if (c.lane < n) {
-        t = P.hand[c.lane];
-        for (int k = 0; k < n; k++) {  // stable rank: poked test states may repeat an id
-            int hk = P.hand[k];
-            r += (hk < t) || (hk == t && k < c.lane);
-        }
+// rank-sort the first n tiles of a hand, optionally dropping hand[drop] (hand.remove(idx); hand.sort(), state/mod.rs
+// discard path).  Tiles live in registers (lane = slot) and are compared through v_readlane: no LDS round trips.
+__device__ __forceinline__ void sort_hand(Ctx& c, PState& P, int n, int drop = -1) {
+    const bool mine = c.lane < n && c.lane != drop;
+    const int t = mine ? (int)P.hand[c.lane] : 0xFFFF;
+    int r = 0;
+#pragma unroll
+    for (int k = 0; k < 14; k++) {  // stable rank: poked test states may repeat an id
+        int tk = __builtin_amdgcn_readlane(t, k);
+        r += (tk < t) || (tk == t && k < c.lane);
     }
-    wave_sync();
-    if (c.lane < n) P.hand[r] = (uint8_t)t;
+    if (mine) P.hand[r] = (uint8_t)t;
+    if (drop >= 0 && drop < n) P.hand_len = (uint8_t)(n - 1);
     wave_sync();
 }
 // remove hand[idx] keeping order
@@ -110,10 +114,9 @@ __device__ __forceinline__ void hand_remove_at(Ctx& c, PState& P, int idx) {
     int n = P.hand_len;
     int t = 0;
     if (c.lane > idx && c.lane < n) t = P.hand[c.lane];
-    wave_sync();
     if (c.lane > idx && c.lane < n) P.hand[c.lane - 1] = (uint8_t)t;
-    wave_sync();
     P.hand_len = (uint8_t)(n - 1);
+    wave_sync();
 }
 __device__ __forceinline__ int hand_find(const Ctx& c, const PState& P, int tile) {  // position() of a 136-id, -1 if absent
     bool hit = c.lane < P.hand_len && P.hand[c.lane] == tile;
@@ -232,8 +235,10 @@ __device__ __forceinline__ bool gen_claims(Ctx& c, int i, int pid, int tile) {
     const int tt = tile >> 2;
     const int hl = P.hand_len;
     int n = 0;
+    PROF(c.X, lane, 19);
     uint64_t W = seat_waits(c, i);
     c.X.wout[i] = W;
+    PROF(c.X, lane, 16);
     bool in_discards = (P.discard_type_mask >> tt) & 1ull;
     bool in_missed = (P.flags & PF_MISSED_DOUJUN) || ((P.flags & PF_RIICHI_DECLARED) && (P.flags & PF_MISSED_RIICHI));
     if (!in_discards && !in_missed) {
@@ -250,6 +255,7 @@ __device__ __forceinline__ bool gen_claims(Ctx& c, int i, int pid, int tile) {
             }
         }
     }
+    PROF(c.X, lane, 17);
     const bool riichi = P.flags & PF_RIICHI_DECLARED;
     const bool kuikae = rule(c, RMJ_RULE_KUIKAE_FORBIDDEN);
     uint8_t ht = lane < hl ? P.hand[lane] : 0xFF;
@@ -281,6 +287,7 @@ __device__ __forceinline__ bool gen_claims(Ctx& c, int i, int pid, int tile) {
             put_legal(c, i, n++, mk_action(RMJ_DAIMINKAN, tile, 3, P.hand[i0], P.hand[i1], P.hand[i2]));
         }
     }
+    PROF(c.X, lane, 18);
     // Chi: lane = pattern*16 + a*4 + b
     bool shimocha = !KSANMA && i == ((pid + 1) & 3);  // no Chi in 3P (state_3p/legal_actions.rs:386)
     if (!riichi && S.drawable_count > 0 && shimocha && hl >= 3 && tt < 27) {
@@ -586,7 +593,9 @@ __device__ __forceinline__ void deal_next(Ctx& c) {
         return;
     }
     if (S.live_end > S.rinshan_count) {
-        uint8_t t = c.W[--S.live_end];
+        const int le = S.live_end - 1;
+        uint8_t t = (c.pf_live_end == le + 1) ? (uint8_t)c.pf_draw : c.W[le];
+        S.live_end = (uint8_t)le;
         S.drawable_count -= 1;
         int pid = S.current_player;
         PState& P = S.p[pid];
@@ -964,13 +973,16 @@ __device__ __forceinline__ void resolve_discard(Ctx& c, int pid, int tile, bool 
     PState& P = S.p[pid];
     if (KSANMA) { S.pending_kan_pid = 0xFF; S.pending_kan_action = 0; }  // quirk Q11 (state_3p/mod.rs:1224-1227)
     S.is_rinshan = 0;
-    P.flags &= ~PF_IPPATSU;
+    uint32_t fl = P.flags;  // one LDS read / one write for the whole sequence of flag updates
+    fl &= ~(uint32_t)PF_IPPATSU;
+    const bool stage = fl & PF_RIICHI_STAGE;
     int nd = P.n_discards;
     if (nd < RMJ_MAX_DISCARDS) {
         P.discards[nd] = (uint8_t)tile;
         if (!tsumogiri) P.discard_from_hand_bits |= 1u << nd;
-        if (P.flags & PF_RIICHI_STAGE) P.discard_is_riichi_bits |= 1u << nd;
-        P.n_discards = (uint8_t)(nd + 1);
+        if (stage) P.discard_is_riichi_bits |= 1u << nd;
+        nd += 1;
+        P.n_discards = (uint8_t)nd;
     }
     P.discard_type_mask |= 1ull << (tile >> 2);
     S.last_discard_pid = (uint8_t)pid;
@@ -978,20 +990,21 @@ __device__ __forceinline__ void resolve_discard(Ctx& c, int pid, int tile, bool 
     S.drawn_tile = 0xFF;
     if (!tsumogiri) {
         P.last_tedashi = (uint8_t)tile;
-        waits_invalidate(P);  // the 13-tile hand changed; a tsumogiri leaves it (and the cache) intact
+        fl &= ~(uint32_t)PF_WAITS_VALID;  // the 13-tile hand changed; a tsumogiri leaves it (and the cache) intact
     }
     S.needs_tsumo = 1;
-    if (P.flags & PF_RIICHI_STAGE) {
-        P.flags |= PF_RIICHI_DECLARED;
-        if (S.is_first_turn) P.flags |= PF_DOUBLE_RIICHI;
-        P.riichi_decl_idx = (uint8_t)(P.n_discards - 1);
-        P.flags &= ~PF_RIICHI_STAGE;
+    if (stage) {
+        fl |= PF_RIICHI_DECLARED;
+        if (S.is_first_turn) fl |= PF_DOUBLE_RIICHI;
+        P.riichi_decl_idx = (uint8_t)(nd - 1);
+        fl &= ~(uint32_t)PF_RIICHI_STAGE;
         S.riichi_pending = (uint8_t)pid;
     }
+    fl &= ~(uint32_t)PF_MISSED_DOUJUN;
+    if (!is_terminal_tile136(tile)) fl &= ~(uint32_t)PF_NAGASHI;
+    P.flags = (uint8_t)fl;
     flush_pending_kan_dora(c);
     emit_simple(c, RMJ_EV_DAHAI, (uint8_t)pid, (uint8_t)tile, tsumogiri ? 1 : 0);
-    P.flags &= ~PF_MISSED_DOUJUN;
-    if (!is_terminal_tile136(tile)) P.flags &= ~PF_NAGASHI;
     S.active_mask = 0;
     S.ron_offer_mask = 0;
     uint32_t claim_active = 0;
@@ -1010,10 +1023,13 @@ __device__ __forceinline__ void resolve_discard(Ctx& c, int pid, int tile, bool 
         S.active_mask = (uint8_t)claim_active;
     } else {
         if (S.riichi_pending != 0xFF) accept_riichi(c);
-        if (!check_abortive_draw(c)) {
+        bool abort_ = check_abortive_draw(c);
+        PROF(c.X, c.lane, 23);
+        if (!abort_) {
             S.turn_count += 1;
             S.current_player = (uint8_t)((pid + 1) % KNP);
             deal_next(c);
+            PROF(c.X, c.lane, 24);
             if (S.turn_count >= (uint32_t)KNP) S.is_first_turn = 0;
         }
     }
@@ -1155,7 +1171,7 @@ __device__ __forceinline__ void step_game(Ctx& c, const uint64_t acts_in[4], boo
     // ---- validation against the stored legal lists
     for (int pid = 0; pid < 4; pid++) {
         if (trusted || acts[pid] == RMJ_NO_ACTION) continue;
-        int n = c.E.nlegal[(size_t)c.g * 4 + pid];
+        int n = S.nlegal[pid];
         bool active = (S.active_mask >> pid) & 1u;
         bool valid;
         if (!active || n == 0) {
@@ -1187,10 +1203,12 @@ __device__ __forceinline__ void step_game(Ctx& c, const uint64_t acts_in[4], boo
             int tile = (int)a_tile(act);
             bool tsumogiri = false, valid = false;
             if (S.drawn_tile != 0xFF && S.drawn_tile == tile) { tsumogiri = true; valid = true; }
+            PROF(c.X, lane, 3);
             int idx = hand_find(c, P, tile);
+            PROF(c.X, lane, 20);
             if (idx >= 0) {
-                hand_remove_at(c, P, idx);
-                sort_hand(c, P, P.hand_len);
+                sort_hand(c, P, P.hand_len, idx);  // hand.remove(idx); hand.sort()
+                PROF(c.X, lane, 22);
                 valid = true;
             }
             do_discard = valid; d_tile = tile; d_tsumogiri = tsumogiri;
@@ -1207,7 +1225,7 @@ __device__ __forceinline__ void step_game(Ctx& c, const uint64_t acts_in[4], boo
                     P.riichi_sutehai = (uint8_t)t;
                     if (!tsumogiri) P.last_tedashi = (uint8_t)t;
                     int idx = hand_find(c, P, t);
-                    if (idx >= 0) { hand_remove_at(c, P, idx); sort_hand(c, P, P.hand_len); }
+                    if (idx >= 0) sort_hand(c, P, P.hand_len, idx);
                     do_discard = true; d_tile = t; d_tsumogiri = tsumogiri;
                 }
             }
@@ -1547,6 +1565,7 @@ __device__ __forceinline__ void finalize_outputs(Ctx& c, bool claims_fresh) {
         n = lane == 3 ? c.X.nl[3] : n;
         if (!((S.active_mask >> lane) & 1u)) n = 0;
         c.E.nlegal[(size_t)c.g * 4 + lane] = (uint8_t)n;
+        S.nlegal[lane] = (uint8_t)n;
         uint64_t w = c.X.wout[0];
         w = lane == 1 ? c.X.wout[1] : w;
         w = lane == 2 ? c.X.wout[2] : w;

@@ -476,8 +476,13 @@ int rmj_step_random(rmj_handle h, uint64_t policy_seed, uint32_t n_steps, int au
     HIPCHK(hipSetDevice(h->cfg.device));
     uint32_t flags = STEP_F_RANDOM | (auto_reset ? STEP_F_AUTORESET : 0u);
     for (uint32_t s = 0; s < n_steps; s++) {
-        if (h->cfg.game_mode >= 3) hipLaunchKernelGGL(rmj3::k_step, game_grid(h->cfg.n_games), dim3(256), 0, h->stream, (const Env*)h->d_env, (const uint64_t*)nullptr, policy_seed, flags);
-        else hipLaunchKernelGGL(rmj4::k_step, game_grid(h->cfg.n_games), dim3(256), 0, h->stream, (const Env*)h->d_env, (const uint64_t*)nullptr, policy_seed, flags);
+#ifdef RMJ_TUNE_LDS
+        static const unsigned extra_lds = getenv("RMJ_EXTRA_LDS") ? (unsigned)atoi(getenv("RMJ_EXTRA_LDS")) : 0u;  // occupancy experiments
+#else
+        const unsigned extra_lds = 0u;
+#endif
+        if (h->cfg.game_mode >= 3) hipLaunchKernelGGL(rmj3::k_step, game_grid(h->cfg.n_games), dim3(256), extra_lds, h->stream, (const Env*)h->d_env, (const uint64_t*)nullptr, policy_seed, flags);
+        else hipLaunchKernelGGL(rmj4::k_step, game_grid(h->cfg.n_games), dim3(256), extra_lds, h->stream, (const Env*)h->d_env, (const uint64_t*)nullptr, policy_seed, flags);
     }
     HIPCHK(hipGetLastError());
     return RMJ_OK;

@@ -161,6 +161,23 @@ __device__ __forceinline__ uint64_t sm64(uint64_t x) {  // state/wall.rs:83-88
     return z ^ (z >> 31);
 }
 
+// x mod n for 1 <= n <= 64, exact, without the 64-bit software division: four 16-bit digits, each step reduces a value
+// below 2^22 with an fp32 reciprocal estimate (quotient off by at most one) and one correction either way.
+__device__ __forceinline__ uint32_t mod_small(uint64_t x, uint32_t n) {
+    const float inv = __builtin_amdgcn_rcpf((float)n);
+    int r = 0;
+#pragma unroll
+    for (int d = 3; d >= 0; d--) {
+        int v = (r << 16) | (int)((x >> (16 * d)) & 0xFFFFull);
+        int q = (int)((float)v * inv);
+        int rem = v - q * (int)n;
+        rem = rem < 0 ? rem + (int)n : rem;
+        rem = rem >= (int)n ? rem - (int)n : rem;
+        r = rem;
+    }
+    return (uint32_t)r;
+}
+
 // ---------------------------------------------------------------- small helpers
 __device__ __forceinline__ bool is_terminal_tile136(int t) {  // types.rs:362-367
     int tt = t / 4;

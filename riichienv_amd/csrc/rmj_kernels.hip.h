@@ -31,7 +31,6 @@ __global__ __launch_bounds__(256, RMJ_STEP_WAVES) void k_step(const Env* __restr
     if (S.is_done && (flags & STEP_F_AUTORESET)) {
         ol_env_reset_default(ctx_pack(c));
     } else {
-        uint64_t acts[4];
         const bool device_policy = (flags & STEP_F_RANDOM) != 0;
         // lane = seat: one gather (and one copy of the 64-bit modulo / of the canonicalisation) for all seats
         uint64_t mine = RMJ_NO_ACTION;
@@ -41,7 +40,7 @@ __global__ __launch_bounds__(256, RMJ_STEP_WAVES) void k_step(const Env* __restr
             if (lane < 4) {
                 int n = S.nlegal[lane];
                 if (((S.active_mask >> lane) & 1u) && n > 0 && !S.is_done) {
-                    uint64_t ch = sm64(gs + (uint64_t)S.step_count * 4ull + (uint64_t)lane) % (uint64_t)n;
+                    uint32_t ch = mod_small(sm64(gs + (uint64_t)S.step_count * 4ull + (uint64_t)lane), (uint32_t)n);
                     mine = c.Lg[lane * RMJ_MAX_LEGAL + ch];
                 }
             }
@@ -49,12 +48,8 @@ __global__ __launch_bounds__(256, RMJ_STEP_WAVES) void k_step(const Env* __restr
             uint64_t a = actions[(size_t)g * 4 + lane];
             mine = ((a & 0xFF) == 0xFF) ? RMJ_NO_ACTION : a_canon(a);
         }
-        const int lo = (int)(uint32_t)mine, hi = (int)(uint32_t)(mine >> 32);
-#pragma unroll
-        for (int p = 0; p < 4; p++)
-            acts[p] = (uint64_t)(uint32_t)__builtin_amdgcn_readlane(lo, p) | ((uint64_t)(uint32_t)__builtin_amdgcn_readlane(hi, p) << 32);
         PROF(c.X, lane, 1);
-        step_game(c, acts, device_policy);  // picked from the stored lists: valid by construction
+        step_game(c, mine, device_policy);  // picked from the stored lists: valid by construction
     }
     PROF(c.X, lane, 8);
     finalize_outputs(c, true);

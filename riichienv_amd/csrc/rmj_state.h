@@ -52,7 +52,8 @@ struct alignas(16) PState {  // 128 bytes
     uint64_t waits13;            // derived cache: get_waits of the 13-tile hand (valid iff PF_WAITS_VALID)
     uint8_t n_kita;              // 3P: kita_tiles (state_3p/player.rs:38)
     uint8_t kita[4];
-    uint8_t pad1[3];
+    uint8_t sh13;                // derived cache: shanten number of the 13-tile hand (valid iff PF_WAITS_VALID)
+    uint8_t pad1[2];
 };
 
 struct alignas(16) GState {  // 4*128 + 128 = 640 bytes

@@ -201,16 +201,25 @@ __device__ inline uint32_t base_cf(const PState& P) {
     return cf;
 }
 
+// Fill the seat's wait cache from the histogram of its 13 tiles.  The table shanten goes first: a hand with a wait has
+// shanten 0, so shanten > 0 means "no waits" without running the probe (most hands, most of the time), and the number
+// itself is kept: one draw lowers it by at most one, which lets the riichi probe skip hands that were >= 2 away.
+// (4P tables also for a sanma hand: it has no 2m-8m, for which the 4P number is a lower bound of the 3P one.)
+__device__ __forceinline__ uint64_t fill_waits13(Ctx& c, PState& P, const PH& h13) {
+    int sh = sh_shanten_wave(h13, P.hand_len / 3, c.E.sh, c.lane);
+    uint64_t W = 0ull;
+    if (sh <= 0) W = wave_waits(h13, c.lane);
+    P.waits13 = W;
+    P.sh13 = (uint8_t)(sh < 0 ? 0 : sh);
+    P.flags |= PF_WAITS_VALID;
+    return W;
+}
 // cached get_waits of a seat's 13-tile hand (hand_evaluator.rs:196-213); 0 when the seat holds 14
 __device__ __forceinline__ uint64_t seat_waits(Ctx& c, int seat) {
     PState& P = c.S.p[seat];
     if (P.hand_len + 3 * P.n_melds != 13) return 0ull;
     if (P.flags & PF_WAITS_VALID) return P.waits13;
-    PH h = build_ph_wave(P, c.lane);
-    uint64_t W = wave_waits(h, c.lane);
-    P.waits13 = W;
-    P.flags |= PF_WAITS_VALID;
-    return W;
+    return fill_waits13(c, P, build_ph_wave(P, c.lane));
 }
 __device__ __forceinline__ void waits_invalidate(PState& P) { P.flags &= ~PF_WAITS_VALID; }
 // cheap in-line win-shape probe so that the (large, out-of-line) yaku evaluation is entered only for complete hands
@@ -339,11 +348,152 @@ __device__ __forceinline__ bool gen_claims(Ctx& c, int i, int pid, int tile) {
 }
 
 // bit j set iff HandEvaluator(hand minus hand[j]).is_tenpai()  (legal_actions.rs:77-131)
-__device__ __forceinline__ uint32_t tenpai_after_discard(Ctx& c, const PState& P) {
+// Claim generation of _resolve_discard for ALL seats at once (legal_actions.rs:254-508; same lists, same order as three
+// gen_claims calls).  The common case - nobody can claim - costs a handful of seat-parallel instructions:
+//   A  lane = seat: refill stale wait caches (rare loop), B  lane = seat: ron eligibility, yaku only for candidates,
+//   C  lane = 16*seat + hand slot: one ballot finds the pon/daiminkan material of every seat,
+//   D  chi for the next seat only, E  lane = seat: Pass / list lengths / stale counts.
+// Per-seat list positions run in LDS (X.nl), so the emission code exists once with a dynamic seat index.
+__device__ __forceinline__ uint32_t gen_claims_all(Ctx& c, int pid, int tile) {
+    GState& S = c.S;
+    const int lane = c.lane;
+    const int tt = tile >> 2;
+    if (lane < 4) c.X.nl[lane] = 0;
+    // ---- A/B (lane = seat)
+    const PState& Q = S.p[lane & 3];
+    const bool other = lane < KNP && lane != pid;
+    const uint32_t qfl = Q.flags;
+    const bool holds13 = other && (Q.hand_len + 3 * Q.n_melds == 13);
+    uint32_t need = (uint32_t)__ballot(holds13 && !(qfl & PF_WAITS_VALID)) & 0xFu;
+    while (need) {
+        int i = __ffs((int)need) - 1;
+        need &= need - 1u;
+        PState& P = S.p[i];
+        fill_waits13(c, P, build_ph_wave(P, lane));
+    }
+    wave_sync();
+    const uint64_t W = holds13 ? Q.waits13 : 0ull;
+    if (lane < 4) c.X.wout[lane] = W;
+    const uint64_t dtm = Q.discard_type_mask;
+    const bool in_discards = (dtm >> tt) & 1ull;
+    const bool in_missed = (qfl & PF_MISSED_DOUJUN) || ((qfl & PF_RIICHI_DECLARED) && (qfl & PF_MISSED_RIICHI));
+    const bool furiten = (W & dtm) != 0ull || (qfl & (PF_MISSED_RIICHI | PF_MISSED_DOUJUN));
+    uint32_t ronm = (uint32_t)__ballot(other && !in_discards && !in_missed && !furiten && ((W >> tt) & 1ull)) & 0xFu;
+    const uint32_t riichi_m = (uint32_t)__ballot(lane < 4 && (qfl & PF_RIICHI_DECLARED)) & 0xFu;
+    while (ronm) {  // rare: a seat waits on this tile and is not furiten -> yaku check
+        int i = __ffs((int)ronm) - 1;
+        ronm &= ronm - 1u;
+        PState& P = S.p[i];
+        uint32_t cf = base_cf(P);
+        if (S.drawable_count == 0 && !S.is_rinshan) cf |= CF_HOUTEI;
+        CalcOut r = seat_calc(c, i, -1, tile, cf, S.honba, false);
+        if (r.is_win) {
+            put_legal(c, i, 0, mk_action(RMJ_RON, tile, 0));
+            if (lane == 0) c.X.nl[i] = 1;
+            S.ron_offer_mask |= (uint8_t)(1u << i);
+        } else if (r.shape) {
+            P.flags |= PF_MISSED_DOUJUN;  // state/mod.rs:1386-1389
+        }
+    }
+    const bool can_call = S.drawable_count > 0;
+    const bool kuikae = rule(c, RMJ_RULE_KUIKAE_FORBIDDEN);
+    // ---- C (lane = 16*seat + slot)
+    {
+        const int k = lane >> 4, slot = lane & 15;
+        const PState& G = S.p[k];
+        const bool m = k < KNP && k != pid && slot < G.hand_len && (G.hand[slot] >> 2) == tt;
+        uint64_t mb = __ballot(m);
+        if (!can_call) mb = 0ull;
+#pragma unroll 1
+        for (int i = 0; i < KNP; i++) {
+            const uint32_t sm = (uint32_t)(mb >> (16 * i)) & 0xFFFFu;
+            const int count = __popc(sm);
+            if (count < 2 || ((riichi_m >> i) & 1u)) continue;
+            PState& P = S.p[i];
+            const int hl = P.hand_len;
+            wave_sync();
+            int n = c.X.nl[i];
+            const int i0 = __ffs((int)sm) - 1;
+            const uint32_t m1 = sm & (sm - 1u);
+            const int i1 = __ffs((int)m1) - 1;
+            if (hl >= 3 && (kuikae ? (hl - count) > 0 : (hl - 2) > 0)) {
+                put_legal(c, i, n++, mk_action(RMJ_PON, tile, 2, P.hand[i0], P.hand[i1]));
+                if (count >= 3) {
+                    const int i2 = __ffs((int)(m1 & (m1 - 1u))) - 1;
+                    put_legal(c, i, n++, mk_action(RMJ_PON, tile, 2, P.hand[i0], P.hand[i2]));
+                    put_legal(c, i, n++, mk_action(RMJ_PON, tile, 2, P.hand[i1], P.hand[i2]));
+                }
+            }
+            if (count >= 3) {
+                const int i2 = __ffs((int)(m1 & (m1 - 1u))) - 1;
+                put_legal(c, i, n++, mk_action(RMJ_DAIMINKAN, tile, 3, P.hand[i0], P.hand[i1], P.hand[i2]));
+            }
+            if (lane == 0) c.X.nl[i] = n;
+        }
+    }
+    // ---- D: Chi for the next seat (lane = pattern*16 + a*4 + b); no Chi in 3P (state_3p/legal_actions.rs:386)
+    if (!KSANMA && can_call && tt < 27) {
+        const int i = (pid + 1) & 3;
+        PState& P = S.p[i];
+        const int hl = P.hand_len;
+        if (!((riichi_m >> i) & 1u) && hl >= 3) {
+            const uint8_t ht = lane < hl ? P.hand[lane] : 0xFF;
+            const int hty = ht >> 2;
+            const int r9 = tt % 9;
+            const uint64_t m_m2 = __ballot(lane < hl && hty == tt - 2), m_m1 = __ballot(lane < hl && hty == tt - 1);
+            const uint64_t m_p1 = __ballot(lane < hl && hty == tt + 1), m_p2 = __ballot(lane < hl && hty == tt + 2);
+            // a sequence needs two of the four neighbours, adjacent around the tile (and inside the suit: pat_ok below)
+            if ((m_m2 && m_m1) || (m_m1 && m_p1) || (m_p1 && m_p2)) {
+                const uint64_t m_0 = __ballot(lane < hl && hty == tt);
+                const uint64_t m_p3 = __ballot(lane < hl && hty == tt + 3), m_m3 = __ballot(lane < hl && hty == tt - 3);
+                const int k = lane >> 4, a = (lane >> 2) & 3, b = lane & 3;
+                const bool pat_ok = k == 0 ? (r9 >= 2) : (k == 1 ? (r9 >= 1 && r9 <= 7) : (k == 2 ? (r9 <= 6) : false));
+                const uint64_t ma = k == 0 ? m_m2 : (k == 1 ? m_m1 : m_p1);
+                const uint64_t mbb = k == 0 ? m_m1 : (k == 1 ? m_p1 : m_p2);
+                // kuikae: forbidden = {tt} (+ tt+3 for pattern 2 if r9<=5, + tt-3 for pattern 0 if r9>=3)
+                int forb = __popcll(m_0);
+                if (k == 2 && r9 <= 5) forb += __popcll(m_p3);
+                if (k == 0 && r9 >= 3) forb += __popcll(m_m3);
+                const bool kk_ok = kuikae ? (hl - 2 - forb) > 0 : (hl - 2) > 0;
+                const bool valid = lane < 48 && pat_ok && a < __popcll(ma) && b < __popcll(mbb) && kk_ok;
+                uint64_t act = 0;
+                if (valid) {
+                    uint64_t x = ma;
+                    for (int q = 0; q < a; q++) x &= x - 1;
+                    uint64_t y = mbb;
+                    for (int q = 0; q < b; q++) y &= y - 1;
+                    act = mk_action(RMJ_CHI, tile, 2, P.hand[__ffsll((long long)x) - 1], P.hand[__ffsll((long long)y) - 1]);
+                }
+                const uint64_t vb = __ballot(valid);
+                wave_sync();
+                const int n = c.X.nl[i];
+                if (valid) {
+                    int pos = n + __popcll(vb & lanemask_lt(lane));
+                    if (pos < RMJ_MAX_LEGAL) c.X.legal[i][pos] = act;
+                }
+                if (lane == 0) c.X.nl[i] = n + __popcll(vb);
+            }
+        }
+    }
+    wave_sync();
+    // ---- E (lane = seat): Pass, lengths, stale counts
+    int n = lane < 4 ? c.X.nl[lane] : 0;
+    if (lane < 4) {
+        S.stale_n[lane] = (uint8_t)(n > 62 ? 62 : n);
+        if (n > 0) {
+            if (n < RMJ_MAX_LEGAL) c.X.legal[lane][n] = mk_action(RMJ_PASS, RMJ_TILE_NONE, 0);
+            c.X.nl[lane] = n + 1;
+        }
+    }
+    return (uint32_t)__ballot(lane < 4 && n > 0) & 0xFu;
+}
+
+// sh13: shanten of the 13 tiles the seat held before the draw if known (else -1): one tile lowers it by at most one
+__device__ __forceinline__ uint32_t tenpai_after_discard(Ctx& c, const PState& P, const PH& full, int sh13) {
     uint32_t out = 0;
     int hl = P.hand_len;
     if (hl + 3 * P.n_melds != 14) return 0;
-    PH full = build_ph_wave(P, c.lane);
+    if (sh13 >= 2) return 0;
     // Sound prefilter: a tenpai 13-tile subset implies replacement number <= 1 for the 14 tiles
     // (swap the discard for the winning tile), i.e. shanten(14) <= 0.  Only then run the exact probes.
     // (4P tables; a sanma hand has no 2m-8m, for which the 4P number is a lower bound of the 3P one, so it is sound too)
@@ -397,9 +547,8 @@ __device__ __forceinline__ void gen_act_legal(Ctx& c, int pid) {
             uint64_t W13;
             if (P.flags & PF_WAITS_VALID) W13 = P.waits13;
             else {
-                W13 = wave_waits(build_ph_wave(P, lane, idx), lane);
-                P.waits13 = W13;
-                P.flags |= PF_WAITS_VALID;
+                // (hand_len is 14 here; fill_waits13 wants the mentsu count of the 13 tiles: same quotient)
+                W13 = fill_waits13(c, P, build_ph_wave(P, lane, idx));
             }
             shape = (W13 >> (tile >> 2)) & 1ull;
         } else {
@@ -411,6 +560,7 @@ __device__ __forceinline__ void gen_act_legal(Ctx& c, int pid) {
         }
     }
     PROF(c.X, lane, 9);
+    const PH full = build_ph_wave(P, lane);  // shared by the riichi probe and the kan checks
     // 2. Discard / Riichi
     uint8_t ht = lane < hl ? P.hand[lane] : 0xFF;
     bool forb = false;
@@ -424,7 +574,11 @@ __device__ __forceinline__ void gen_act_legal(Ctx& c, int pid) {
         for (int i = 0; i < P.n_melds; i++) all_closed = all_closed && (P.meld_type[i] == RMJ_MELD_ANKAN);
         // quirk Q8: >= 4 in 4P, > 0 in 3P
         bool riichi_pre = !r_stage && P.score >= 1000 && (KSANMA ? S.drawable_count > 0 : S.drawable_count >= 4) && all_closed;
-        if (need_tp || riichi_pre) tp = tenpai_after_discard(c, P);
+        if (need_tp || riichi_pre) {
+            // the cache (if valid) describes the 13 tiles without the drawn one: it survives a draw and a riichi declaration
+            int sh13 = (drawn && (P.flags & PF_WAITS_VALID)) ? (int)P.sh13 : -1;
+            tp = tenpai_after_discard(c, P, full, sh13);
+        }
         bool ok = lane < hl && !forb && (!r_stage || ((tp >> lane) & 1u));
         uint64_t vb = __ballot(ok);
         if (ok) {
@@ -440,18 +594,20 @@ __device__ __forceinline__ void gen_act_legal(Ctx& c, int pid) {
         if (!r_decl && !r_stage) {
             // Ankan: types with 4 copies, ascending type.  lane = hand index, a type is reported by its first holder.
             int ty = ht >> 2;
-            uint64_t same = 0;
-            // count copies of my type: hand is sorted except the last (drawn) tile -> use ballots per lane via loop over hand
-            int cnt = 0, first = 1;
-            for (int k = 0; k < hl; k++) {
-                int tk = P.hand[k] >> 2;
-                cnt += (tk == ty);
-                if (k < lane && tk == ty) first = 0;
+            // wave-uniform gate from the histogram: some type is held four (or more) times
+            const bool any4 = (((full.a | full.b | full.c) & O9_4) | (full.d & O7_4)) != 0u;
+            uint64_t rb = 0ull;
+            bool is4 = false;
+            if (any4) {
+                int cnt = 0, first = 1;
+                for (int k = 0; k < hl; k++) {
+                    int tk = P.hand[k] >> 2;
+                    cnt += (tk == ty);
+                    if (k < lane && tk == ty) first = 0;
+                }
+                is4 = lane < hl && cnt == 4 && first;
+                rb = __ballot(is4);  // order by type: rank among reporting lanes by type value
             }
-            (void)same;
-            bool is4 = lane < hl && cnt == 4 && first;
-            // order by type: rank among reporting lanes by type value
-            uint64_t rb = __ballot(is4);
             if (rb) {
                 int rank = 0;
                 for (uint64_t q = rb; q; q &= q - 1) {
@@ -483,7 +639,6 @@ __device__ __forceinline__ void gen_act_legal(Ctx& c, int pid) {
             }
         } else if (r_decl) {
             int t = S.drawn_tile, t34 = t >> 2;
-            PH full = build_ph_wave(P, lane);
             if (ph_cnt(full, t34) == 4) {
                 PH pre = full;
                 ph_sub(pre, t34);
@@ -523,6 +678,13 @@ __device__ __forceinline__ void gen_act_legal(Ctx& c, int pid) {
     c.X.nl[pid] = n > RMJ_MAX_LEGAL ? RMJ_MAX_LEGAL : n;
     PROF(c.X, lane, 12);
 }
+
+#ifdef RMJ_OL_ACT_LEGAL
+__device__ __noinline__ void ol_gen_act_legal(CtxV v, int pid) {
+    CTX_FROM(v);
+    gen_act_legal(c, pid);
+}
+#endif
 
 // current_claims.entry(i).or_default().push(Ron) (state/mod.rs:524-533, 665-673; sanma.rs:121-128): the Ron offer is
 // APPENDED to whatever the seat still has in current_claims (see GState::stale_n).
@@ -1007,16 +1169,8 @@ __device__ __forceinline__ void resolve_discard(Ctx& c, int pid, int tile, bool 
     emit_simple(c, RMJ_EV_DAHAI, (uint8_t)pid, (uint8_t)tile, tsumogiri ? 1 : 0);
     S.active_mask = 0;
     S.ron_offer_mask = 0;
-    uint32_t claim_active = 0;
     PROF(c.X, c.lane, 4);
-    // (kept unrolled: with a compile-time seat index the claim generation is ~20 % faster than a rolled loop)
-#pragma unroll
-    for (int i = 0; i < 4; i++) {
-        c.X.nl[i] = 0;
-        S.stale_n[i] = 0;
-        if (i == pid || i >= KNP) continue;
-        if (gen_claims(c, i, pid, tile)) claim_active |= 1u << i;
-    }
+    const uint32_t claim_active = gen_claims_all(c, pid, tile);
     PROF(c.X, c.lane, 5);
     if (claim_active) {
         S.phase = RMJ_WAIT_RESPONSE;
@@ -1158,243 +1312,177 @@ __device__ inline void handle_kita(Ctx& c, int pid, uint64_t act) {
     }
 }
 
-// ---------------------------------------------------------------- step (state/mod.rs:330-1315)
-// acts_in: canonical packed actions (a_canon), RMJ_NO_ACTION for a silent seat.  `trusted`: they were taken from the
-// stored legal lists by the device policy (legal by construction), so validation is skipped.
-__device__ __forceinline__ void step_game(Ctx& c, const uint64_t acts_in[4], bool trusted = false) {
+// WaitAct actions other than Discard (Kyushu, Riichi, Ankan, Kakan, Tsumo, Kita): once per kyoku or rarer, so out of
+// line - the hot Discard path keeps its registers and its instruction-cache footprint.  Returns bit0 = "continue with
+// _resolve_discard" (Riichi declared together with a tile, unreachable through validation), bit1 = tsumogiri,
+// bits 8.. = tile.
+__device__ __noinline__ uint32_t ol_wait_act_other(CtxV v, int pid, uint64_t act) {
+    CTX_FROM(v);
     GState& S = c.S;
     const int lane = c.lane;
-    if (S.is_done) return;
-    S.step_count += 1;
-    uint64_t acts[4];
-    for (int p = 0; p < 4; p++) acts[p] = acts_in[p];
-    // ---- validation against the stored legal lists
-    for (int pid = 0; pid < 4; pid++) {
-        if (trusted || acts[pid] == RMJ_NO_ACTION) continue;
-        int n = S.nlegal[pid];
-        bool active = (S.active_mask >> pid) & 1u;
-        bool valid;
-        if (!active || n == 0) {
-            // _get_legal_actions_internal for a non-active seat: [] in WaitAct, [Pass] in WaitResponse
-            valid = S.phase == RMJ_WAIT_RESPONSE && a_match(mk_action(RMJ_PASS, RMJ_TILE_NONE, 0), acts[pid]);
-        } else {
-            bool hit = lane < n && a_match(c.Lg[pid * RMJ_MAX_LEGAL + lane], acts[pid]);
-            valid = __ballot(hit) != 0ull;
+    (void)lane;
+    PState& P = S.p[pid];
+    const uint32_t ty = a_type(act);
+    bool do_discard = false, d_tsumogiri = false;
+    int d_tile = 0;
+    if (ty == RMJ_KYUSHU) {
+        trigger_ryukyoku(c, RMJ_RK_KYUSHU, 0);
+    } else if (ty == RMJ_RIICHI) {
+        if (P.score >= 1000 && (KSANMA ? S.drawable_count > 0 : S.drawable_count >= 4) &&
+            !(P.flags & (PF_RIICHI_DECLARED | PF_RIICHI_STAGE))) {
+            P.flags |= PF_RIICHI_STAGE;
+            emit_simple(c, RMJ_EV_REACH, (uint8_t)pid);
+            if (a_tile(act) != RMJ_TILE_NONE) {  // unreachable through validation (quirk Q13), kept for parity
+                int t = (int)a_tile(act);
+                bool tsumogiri = S.drawn_tile != 0xFF && S.drawn_tile == t;
+                P.riichi_sutehai = (uint8_t)t;
+                if (!tsumogiri) P.last_tedashi = (uint8_t)t;
+                int idx = hand_find(c, P, t);
+                if (idx >= 0) sort_hand(c, P, P.hand_len, idx);
+                do_discard = true; d_tile = t; d_tsumogiri = tsumogiri;
+            }
         }
-        if (!valid) {
-            S.last_error_pid = (uint8_t)pid;
-            trigger_ryukyoku(c, RMJ_RK_ILLEGAL, pid);
-            return;
-        }
-    }
-    PROF(c.X, lane, 2);
-    if (S.phase == RMJ_WAIT_ACT) {
-        const int pid = S.current_player;
-        const uint64_t act = pid == 0 ? acts[0] : (pid == 1 ? acts[1] : (pid == 2 ? acts[2] : acts[3]));
-        if (act == RMJ_NO_ACTION) return;
-        PState& P = S.p[pid];
-        const uint32_t ty = a_type(act);
-        // The Discard branch and the (validation-unreachable) Riichi-with-tile branch both end in _resolve_discard;
-        // they share ONE inlined copy of it below (code size = instruction-cache footprint of the hot path).
-        bool do_discard = false, d_tsumogiri = false;
-        int d_tile = 0;
-        if (ty == RMJ_DISCARD) {
-            if (a_tile(act) == RMJ_TILE_NONE) return;
-            int tile = (int)a_tile(act);
-            bool tsumogiri = false, valid = false;
-            if (S.drawn_tile != 0xFF && S.drawn_tile == tile) { tsumogiri = true; valid = true; }
-            PROF(c.X, lane, 3);
-            int idx = hand_find(c, P, tile);
-            PROF(c.X, lane, 20);
-            if (idx >= 0) {
-                sort_hand(c, P, P.hand_len, idx);  // hand.remove(idx); hand.sort()
-                PROF(c.X, lane, 22);
-                valid = true;
-            }
-            do_discard = valid; d_tile = tile; d_tsumogiri = tsumogiri;
-        } else if (ty == RMJ_KYUSHU) {
-            trigger_ryukyoku(c, RMJ_RK_KYUSHU, 0);
-        } else if (ty == RMJ_RIICHI) {
-            if (P.score >= 1000 && (KSANMA ? S.drawable_count > 0 : S.drawable_count >= 4) &&
-                !(P.flags & (PF_RIICHI_DECLARED | PF_RIICHI_STAGE))) {
-                P.flags |= PF_RIICHI_STAGE;
-                emit_simple(c, RMJ_EV_REACH, (uint8_t)pid);
-                if (a_tile(act) != RMJ_TILE_NONE) {  // unreachable through validation (quirk Q13), kept for parity
-                    int t = (int)a_tile(act);
-                    bool tsumogiri = S.drawn_tile != 0xFF && S.drawn_tile == t;
-                    P.riichi_sutehai = (uint8_t)t;
-                    if (!tsumogiri) P.last_tedashi = (uint8_t)t;
-                    int idx = hand_find(c, P, t);
-                    if (idx >= 0) sort_hand(c, P, P.hand_len, idx);
-                    do_discard = true; d_tile = t; d_tsumogiri = tsumogiri;
-                }
-            }
-        } else if (ty == RMJ_ANKAN) {
-            int tile = a_tile(act) != RMJ_TILE_NONE ? (int)a_tile(act) : (a_n(act) ? (int)a_c(act, 0) : 0);
-            uint32_t ronners = 0;
-            if (rule(c, RMJ_RULE_RON_ON_ANKAN_KOKUSHI)) {
-                S.ron_offer_mask = 0;
-                for (int i = 0; i < 4; i++) {
-                    c.X.nl[i] = 0;
-                    if (i == pid || i >= KNP) continue;
-                    PState& Q = S.p[i];
-                    if ((Q.discard_type_mask >> (tile >> 2)) & 1ull) continue;
-                    uint32_t cf = CF_CHANKAN | ((Q.flags & PF_RIICHI_DECLARED) ? CF_RIICHI : 0u);
-                    if (!seat_shape(c, i, -1, tile)) continue;
-                    CalcOut r = seat_calc(c, i, -1, tile, cf, 0, false);
-                    if (r.is_win && ((r.ym >> 42) & 1ull || (r.ym >> 49) & 1ull)) {
-                        ronners |= 1u << i;
-                        offer_ron(c, i, tile);
-                    }
-                }
-            }
-            if (ronners) {
-                S.pending_kan_pid = (uint8_t)pid;
-                S.pending_kan_action = act;
-                S.phase = RMJ_WAIT_RESPONSE;
-                S.active_mask = (uint8_t)ronners;
-                S.last_discard_pid = (uint8_t)pid;
-                S.last_discard_tile = (uint8_t)tile;
-            } else {
-                resolve_kan(c, pid, act);
-            }
-        } else if (ty == RMJ_KAKAN) {
-            int tile = a_tile(act) != RMJ_TILE_NONE ? (int)a_tile(act) : (a_n(act) ? (int)a_c(act, 0) : 0);
-            int idx = hand_find(c, P, tile);
-            if (idx >= 0) hand_remove_at(c, P, idx);
-            waits_invalidate(P);
-            for (int m = 0; m < P.n_melds; m++)
-                if (P.meld_type[m] == RMJ_MELD_PON && (P.meld_tiles[m][0] >> 2) == (tile >> 2)) {
-                    P.meld_type[m] = RMJ_MELD_KAKAN;
-                    // insert keeping ascending ids
-                    uint32_t v[4] = {P.meld_tiles[m][0], P.meld_tiles[m][1], P.meld_tiles[m][2], (uint32_t)tile};
-                    for (int a = 0; a < 4; a++)
-                        for (int b = 0; b < 3; b++)
-                            if (v[b] > v[b + 1]) { uint32_t t = v[b]; v[b] = v[b + 1]; v[b + 1] = t; }
-                    for (int a = 0; a < 4; a++) P.meld_tiles[m][a] = (uint8_t)v[a];
-                    break;
-                }
-            emit_meld(c, RMJ_EV_KAKAN, (uint8_t)pid, 0, (uint8_t)tile, act);
-            flush_pending_kan_dora(c);
-            uint32_t ronners = 0;
+    } else if (ty == RMJ_ANKAN) {
+        int tile = a_tile(act) != RMJ_TILE_NONE ? (int)a_tile(act) : (a_n(act) ? (int)a_c(act, 0) : 0);
+        uint32_t ronners = 0;
+        if (rule(c, RMJ_RULE_RON_ON_ANKAN_KOKUSHI)) {
             S.ron_offer_mask = 0;
             for (int i = 0; i < 4; i++) {
                 c.X.nl[i] = 0;
                 if (i == pid || i >= KNP) continue;
                 PState& Q = S.p[i];
-                uint64_t W = seat_waits(c, i);
-                c.X.wout[i] = W;
-                bool furiten = (W & Q.discard_type_mask) != 0ull || (Q.flags & (PF_MISSED_RIICHI | PF_MISSED_DOUJUN));
-                if (furiten || !((W >> (tile >> 2)) & 1ull)) continue;
-                uint32_t cf = base_cf(Q) | CF_CHANKAN;
-                CalcOut r = seat_calc(c, i, -1, tile, cf, S.honba, false);
-                if (r.is_win && (r.yakuman || r.han >= 1)) {
+                if ((Q.discard_type_mask >> (tile >> 2)) & 1ull) continue;
+                uint32_t cf = CF_CHANKAN | ((Q.flags & PF_RIICHI_DECLARED) ? CF_RIICHI : 0u);
+                if (!seat_shape(c, i, -1, tile)) continue;
+                CalcOut r = seat_calc(c, i, -1, tile, cf, 0, false);
+                if (r.is_win && ((r.ym >> 42) & 1ull || (r.ym >> 49) & 1ull)) {
                     ronners |= 1u << i;
                     offer_ron(c, i, tile);
                 }
             }
-            if (ronners) {
-                S.pending_kan_pid = (uint8_t)pid;
-                S.pending_kan_action = act;
-                S.phase = RMJ_WAIT_RESPONSE;
-                S.active_mask = (uint8_t)ronners;
-                S.last_discard_pid = (uint8_t)pid;
-                S.last_discard_tile = (uint8_t)tile;
-            } else {
-                resolve_kan(c, pid, act);
+        }
+        if (ronners) {
+            S.pending_kan_pid = (uint8_t)pid;
+            S.pending_kan_action = act;
+            S.phase = RMJ_WAIT_RESPONSE;
+            S.active_mask = (uint8_t)ronners;
+            S.last_discard_pid = (uint8_t)pid;
+            S.last_discard_tile = (uint8_t)tile;
+        } else {
+            resolve_kan(c, pid, act);
+        }
+    } else if (ty == RMJ_KAKAN) {
+        int tile = a_tile(act) != RMJ_TILE_NONE ? (int)a_tile(act) : (a_n(act) ? (int)a_c(act, 0) : 0);
+        int idx = hand_find(c, P, tile);
+        if (idx >= 0) hand_remove_at(c, P, idx);
+        waits_invalidate(P);
+        for (int m = 0; m < P.n_melds; m++)
+            if (P.meld_type[m] == RMJ_MELD_PON && (P.meld_tiles[m][0] >> 2) == (tile >> 2)) {
+                P.meld_type[m] = RMJ_MELD_KAKAN;
+                // insert keeping ascending ids
+                uint32_t v[4] = {P.meld_tiles[m][0], P.meld_tiles[m][1], P.meld_tiles[m][2], (uint32_t)tile};
+                for (int a = 0; a < 4; a++)
+                    for (int b = 0; b < 3; b++)
+                        if (v[b] > v[b + 1]) { uint32_t t = v[b]; v[b] = v[b + 1]; v[b + 1] = t; }
+                for (int a = 0; a < 4; a++) P.meld_tiles[m][a] = (uint8_t)v[a];
+                break;
             }
-        } else if (ty == RMJ_TSUMO) {
-            uint32_t cf = base_cf(P) | CF_TSUMO;
-            if (S.drawable_count == 0 && !S.is_rinshan) cf |= CF_HAITEI;
-            if (S.is_rinshan) cf |= CF_RINSHAN;
-            bool no_melds = (S.p[0].n_melds | S.p[1].n_melds | S.p[2].n_melds | S.p[3].n_melds) == 0;
-            if (S.is_first_turn && no_melds) cf |= CF_FIRST_TURN;  // quirk Q5 (settlement form)
-            int win_tile = S.drawn_tile != 0xFF ? S.drawn_tile : 0;
-            bool riichi = P.flags & PF_RIICHI_DECLARED;
-            CalcOut res = seat_calc(c, pid, -1, win_tile, cf, S.honba, riichi, KSANMA ? P.n_kita : 0);
-            cap_double(c, res, pid == S.oya, true, S.honba);
-            if (res.is_win) {
-                int32_t deltas[4] = {0, 0, 0, 0};
-                int32_t total_win = 0;
-                int pao_payer = -1, pao_val = 0, total_val = 0;
-                if (res.yakuman) yakuman_totals(c, res, P, total_val, pao_val, pao_payer);
-                if (pao_val > 0) {
-                    // state_3p/mod.rs:713-721: (np-1)*16000 for the dealer, 16000+(np-2)*8000 otherwise
-                    const int np = KNP;
-                    int32_t unit = pid == S.oya ? (np - 1) * 16000 : 16000 + (np - 2) * 8000;
-                    int32_t honba_total = (int32_t)S.honba * (np - 1) * 100;
-                    if (pao_payer >= 0) {
-                        if (rule(c, RMJ_RULE_PAO_LIABILITY_ONLY)) {
-                            int32_t pao_amt = pao_val * unit + honba_total;
-                            int32_t non = total_val - pao_val;
-                            deltas[pao_payer] -= pao_amt;
-                            total_win += pao_amt;
-                            if (non > 0)
-                                for (int i = 0; i < np; i++)
-                                    if (i != pid) {
-                                        int32_t pay = (pid == S.oya) ? non * 16000 : (i == S.oya ? non * 16000 : non * 8000);
-                                        deltas[i] -= pay;
-                                        total_win += pay;
-                                    }
-                        } else {
-                            int32_t full = total_val * unit + honba_total;
-                            deltas[pao_payer] -= full;
-                            total_win += full;
-                        }
+        emit_meld(c, RMJ_EV_KAKAN, (uint8_t)pid, 0, (uint8_t)tile, act);
+        flush_pending_kan_dora(c);
+        uint32_t ronners = 0;
+        S.ron_offer_mask = 0;
+        for (int i = 0; i < 4; i++) {
+            c.X.nl[i] = 0;
+            if (i == pid || i >= KNP) continue;
+            PState& Q = S.p[i];
+            uint64_t W = seat_waits(c, i);
+            c.X.wout[i] = W;
+            bool furiten = (W & Q.discard_type_mask) != 0ull || (Q.flags & (PF_MISSED_RIICHI | PF_MISSED_DOUJUN));
+            if (furiten || !((W >> (tile >> 2)) & 1ull)) continue;
+            uint32_t cf = base_cf(Q) | CF_CHANKAN;
+            CalcOut r = seat_calc(c, i, -1, tile, cf, S.honba, false);
+            if (r.is_win && (r.yakuman || r.han >= 1)) {
+                ronners |= 1u << i;
+                offer_ron(c, i, tile);
+            }
+        }
+        if (ronners) {
+            S.pending_kan_pid = (uint8_t)pid;
+            S.pending_kan_action = act;
+            S.phase = RMJ_WAIT_RESPONSE;
+            S.active_mask = (uint8_t)ronners;
+            S.last_discard_pid = (uint8_t)pid;
+            S.last_discard_tile = (uint8_t)tile;
+        } else {
+            resolve_kan(c, pid, act);
+        }
+    } else if (ty == RMJ_TSUMO) {
+        uint32_t cf = base_cf(P) | CF_TSUMO;
+        if (S.drawable_count == 0 && !S.is_rinshan) cf |= CF_HAITEI;
+        if (S.is_rinshan) cf |= CF_RINSHAN;
+        bool no_melds = (S.p[0].n_melds | S.p[1].n_melds | S.p[2].n_melds | S.p[3].n_melds) == 0;
+        if (S.is_first_turn && no_melds) cf |= CF_FIRST_TURN;  // quirk Q5 (settlement form)
+        int win_tile = S.drawn_tile != 0xFF ? S.drawn_tile : 0;
+        bool riichi = P.flags & PF_RIICHI_DECLARED;
+        CalcOut res = seat_calc(c, pid, -1, win_tile, cf, S.honba, riichi, KSANMA ? P.n_kita : 0);
+        cap_double(c, res, pid == S.oya, true, S.honba);
+        if (res.is_win) {
+            int32_t deltas[4] = {0, 0, 0, 0};
+            int32_t total_win = 0;
+            int pao_payer = -1, pao_val = 0, total_val = 0;
+            if (res.yakuman) yakuman_totals(c, res, P, total_val, pao_val, pao_payer);
+            if (pao_val > 0) {
+                // state_3p/mod.rs:713-721: (np-1)*16000 for the dealer, 16000+(np-2)*8000 otherwise
+                const int np = KNP;
+                int32_t unit = pid == S.oya ? (np - 1) * 16000 : 16000 + (np - 2) * 8000;
+                int32_t honba_total = (int32_t)S.honba * (np - 1) * 100;
+                if (pao_payer >= 0) {
+                    if (rule(c, RMJ_RULE_PAO_LIABILITY_ONLY)) {
+                        int32_t pao_amt = pao_val * unit + honba_total;
+                        int32_t non = total_val - pao_val;
+                        deltas[pao_payer] -= pao_amt;
+                        total_win += pao_amt;
+                        if (non > 0)
+                            for (int i = 0; i < np; i++)
+                                if (i != pid) {
+                                    int32_t pay = (pid == S.oya) ? non * 16000 : (i == S.oya ? non * 16000 : non * 8000);
+                                    deltas[i] -= pay;
+                                    total_win += pay;
+                                }
+                    } else {
+                        int32_t full = total_val * unit + honba_total;
+                        deltas[pao_payer] -= full;
+                        total_win += full;
                     }
-                } else {
-                    for (int i = 0; i < KNP; i++)
-                        if (i != pid) {
-                            int32_t pay = (pid == S.oya) ? (int32_t)res.tsumo_ko : (i == S.oya ? (int32_t)res.tsumo_oya : (int32_t)res.tsumo_ko);
-                            deltas[i] = -pay;
-                            total_win += pay;
-                        }
                 }
-                total_win += (int32_t)(S.riichi_sticks * 1000u);
-                S.riichi_sticks = 0;
-                deltas[pid] += total_win;
-                for (int i = 0; i < 4; i++) { S.p[i].score += deltas[i]; S.p[i].score_delta = deltas[i]; }
-                emit_hora(c, pid, pid, deltas, true, riichi);
-                init_next_round(c, pid == S.oya, false);
             } else {
-                S.current_player = (uint8_t)((S.current_player + 1) % KNP);
-                deal_next(c);
+                for (int i = 0; i < KNP; i++)
+                    if (i != pid) {
+                        int32_t pay = (pid == S.oya) ? (int32_t)res.tsumo_ko : (i == S.oya ? (int32_t)res.tsumo_oya : (int32_t)res.tsumo_ko);
+                        deltas[i] = -pay;
+                        total_win += pay;
+                    }
             }
-        } else if (ty == RMJ_KITA && KSANMA) {
-            handle_kita(c, pid, act);
+            total_win += (int32_t)(S.riichi_sticks * 1000u);
+            S.riichi_sticks = 0;
+            deltas[pid] += total_win;
+            for (int i = 0; i < 4; i++) { S.p[i].score += deltas[i]; S.p[i].score_delta = deltas[i]; }
+            emit_hora(c, pid, pid, deltas, true, riichi);
+            init_next_round(c, pid == S.oya, false);
+        } else {
+            S.current_player = (uint8_t)((S.current_player + 1) % KNP);
+            deal_next(c);
         }
-        PROF(c.X, lane, 3);
-        if (do_discard) resolve_discard(c, pid, d_tile, d_tsumogiri);
-        return;
+    } else if (ty == RMJ_KITA && KSANMA) {
+        handle_kita(c, pid, act);
     }
-    // ---- WaitResponse (state/mod.rs:900-1314)
-#ifdef RMJ_PROFILE
-    struct ProfTail { Ctx& c; __device__ ~ProfTail() { PROF(c.X, c.lane, 7); } } prof_tail{c};
-#endif
-    for (int pid = 0; pid < 4; pid++)
-        if ((S.ron_offer_mask >> pid) & 1u) {
-            bool roned = acts[pid] != RMJ_NO_ACTION && a_type(acts[pid]) == RMJ_RON;
-            if (!roned) {
-                S.p[pid].flags |= PF_MISSED_DOUJUN;
-                if (S.p[pid].flags & PF_RIICHI_DECLARED) S.p[pid].flags |= PF_MISSED_RIICHI;
-            }
-        }
-    uint32_t ron_mask = 0;
-    int claimer = -1;
-    uint64_t claim = 0;
-    for (int pid = 0; pid < 4; pid++) {  // active_players is in ascending seat order (state/mod.rs:1378-1395)
-        if (!((S.active_mask >> pid) & 1u) || acts[pid] == RMJ_NO_ACTION) continue;
-        uint32_t ty = a_type(acts[pid]);
-        if (ty == RMJ_RON) ron_mask |= 1u << pid;
-        else if (ty == RMJ_PON || ty == RMJ_DAIMINKAN || (!KSANMA && ty == RMJ_CHI)) {
-            if (claimer >= 0) {
-                bool old_pon = a_type(claim) == RMJ_PON || a_type(claim) == RMJ_DAIMINKAN;
-                bool new_pon = ty == RMJ_PON || ty == RMJ_DAIMINKAN;
-                if (!old_pon && new_pon) { claimer = pid; claim = acts[pid]; }
-            } else { claimer = pid; claim = acts[pid]; }
-        }
-    }
-    if (ron_mask) {
+    return (do_discard ? 1u : 0u) | (d_tsumogiri ? 2u : 0u) | ((uint32_t)d_tile << 8);
+}
+
+// Ron settlement of a WaitResponse step (state/mod.rs:945-1142): once per kyoku at most, out of line.
+__device__ __noinline__ void ol_settle_ron(CtxV v, uint32_t ron_mask) {
+    CTX_FROM(v);
+    GState& S = c.S;
         if (!KSANMA && __popc(ron_mask) >= 3 && rule(c, RMJ_RULE_SANCHAHO_DRAW)) { trigger_ryukyoku(c, RMJ_RK_SANCHAHO, 0); return; }
         int target = S.last_discard_pid != 0xFF ? S.last_discard_pid : S.current_player;
         int win_tile = S.last_discard_pid != 0xFF ? S.last_discard_tile : 0;
@@ -1448,6 +1536,99 @@ __device__ __forceinline__ void step_game(Ctx& c, const uint64_t acts_in[4], boo
         }
         for (int i = 0; i < 4; i++) { S.p[i].score += total_d[i]; S.p[i].score_delta = total_d[i]; }
         init_next_round(c, oya_won, false);
+}
+
+// ---------------------------------------------------------------- step (state/mod.rs:330-1315)
+// acts_in: canonical packed actions (a_canon), RMJ_NO_ACTION for a silent seat.  `trusted`: they were taken from the
+// stored legal lists by the device policy (legal by construction), so validation is skipped.
+// `mine`: lane p (< 4) holds seat p's action; a seat's action is pulled out with v_readlane where it is needed instead
+// of keeping four 64-bit values in scalar registers for the whole step (SGPR pressure of the hot path).
+__device__ __forceinline__ uint64_t act_at(uint64_t mine, int p) {
+    return (uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)mine, p) |
+           ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(mine >> 32), p) << 32);
+}
+__device__ __forceinline__ void step_game(Ctx& c, const uint64_t mine, bool trusted = false) {
+    GState& S = c.S;
+    const int lane = c.lane;
+    if (S.is_done) return;
+    S.step_count += 1;
+    // ---- validation against the stored legal lists
+    for (int pid = 0; pid < 4; pid++) {
+        if (trusted) continue;
+        const uint64_t a_pid = act_at(mine, pid);
+        if (a_pid == RMJ_NO_ACTION) continue;
+        int n = S.nlegal[pid];
+        bool active = (S.active_mask >> pid) & 1u;
+        bool valid;
+        if (!active || n == 0) {
+            // _get_legal_actions_internal for a non-active seat: [] in WaitAct, [Pass] in WaitResponse
+            valid = S.phase == RMJ_WAIT_RESPONSE && a_match(mk_action(RMJ_PASS, RMJ_TILE_NONE, 0), a_pid);
+        } else {
+            bool hit = lane < n && a_match(c.Lg[pid * RMJ_MAX_LEGAL + lane], a_pid);
+            valid = __ballot(hit) != 0ull;
+        }
+        if (!valid) {
+            S.last_error_pid = (uint8_t)pid;
+            trigger_ryukyoku(c, RMJ_RK_ILLEGAL, pid);
+            return;
+        }
+    }
+    PROF(c.X, lane, 2);
+    if (S.phase == RMJ_WAIT_ACT) {
+        const int pid = S.current_player;
+        const uint64_t act = act_at(mine, pid);
+        if (act == RMJ_NO_ACTION) return;
+        PState& P = S.p[pid];
+        const uint32_t ty = a_type(act);
+        // The Discard branch and the (validation-unreachable) Riichi-with-tile branch both end in _resolve_discard;
+        // they share ONE inlined copy of it below (code size = instruction-cache footprint of the hot path).
+        bool do_discard = false, d_tsumogiri = false;
+        int d_tile = 0;
+        if (ty == RMJ_DISCARD) {
+            if (a_tile(act) == RMJ_TILE_NONE) return;
+            int tile = (int)a_tile(act);
+            bool tsumogiri = false, valid = false;
+            if (S.drawn_tile != 0xFF && S.drawn_tile == tile) { tsumogiri = true; valid = true; }
+            PROF(c.X, lane, 3);
+            int idx = hand_find(c, P, tile);
+            PROF(c.X, lane, 20);
+            if (idx >= 0) {
+                sort_hand(c, P, P.hand_len, idx);  // hand.remove(idx); hand.sort()
+                PROF(c.X, lane, 22);
+                valid = true;
+            }
+            do_discard = valid; d_tile = tile; d_tsumogiri = tsumogiri;
+        } else {
+            uint32_t r = ol_wait_act_other(ctx_pack(c), pid, act);
+            do_discard = r & 1u; d_tsumogiri = (r >> 1) & 1u; d_tile = (int)(r >> 8);
+        }
+        PROF(c.X, lane, 3);
+        if (do_discard) resolve_discard(c, pid, d_tile, d_tsumogiri);
+        return;
+    }
+    // ---- WaitResponse (state/mod.rs:900-1314)
+#ifdef RMJ_PROFILE
+    struct ProfTail { Ctx& c; __device__ ~ProfTail() { PROF(c.X, c.lane, 7); } } prof_tail{c};
+#endif
+    // lane = seat (active_players is in ascending seat order, state/mod.rs:1378-1395)
+    const bool has = lane < 4 && mine != RMJ_NO_ACTION;
+    const uint32_t my_ty = a_type(mine);
+    const uint32_t act_m = S.active_mask;
+    const bool is_act = has && ((act_m >> lane) & 1u);
+    const uint32_t roned = (uint32_t)__ballot(has && my_ty == RMJ_RON) & 0xFu;
+    if (lane < 4 && (((uint32_t)S.ron_offer_mask & ~roned) >> lane) & 1u) {  // a Ron offer that was not taken
+        uint32_t fl = S.p[lane].flags | PF_MISSED_DOUJUN;
+        if (fl & PF_RIICHI_DECLARED) fl |= PF_MISSED_RIICHI;
+        S.p[lane].flags = (uint8_t)fl;
+    }
+    const uint32_t ron_mask = roned & act_m;
+    const uint32_t pon_m = (uint32_t)__ballot(is_act && (my_ty == RMJ_PON || my_ty == RMJ_DAIMINKAN)) & 0xFu;
+    const uint32_t chi_m = KSANMA ? 0u : ((uint32_t)__ballot(is_act && my_ty == RMJ_CHI) & 0xFu);
+    // the first Pon/Daiminkan wins over a Chi; among equals the lower seat (the reference's replace-if-better scan)
+    const int claimer = pon_m ? __ffs((int)pon_m) - 1 : (chi_m ? __ffs((int)chi_m) - 1 : -1);
+    const uint64_t claim = claimer >= 0 ? act_at(mine, claimer) : 0ull;
+    if (ron_mask) {
+        ol_settle_ron(ctx_pack(c), ron_mask);
     } else if (claimer >= 0) {
         PState& C = S.p[claimer];
         accept_riichi(c);
@@ -1525,7 +1706,11 @@ __device__ __forceinline__ void finalize_outputs(Ctx& c, bool claims_fresh) {
         for (int p = 0; p < 4; p++) { c.X.nl[p] = 0; c.X.wout[p] = 0; }
     } else if (S.phase == RMJ_WAIT_ACT) {
         for (int p = 0; p < 4; p++) { c.X.nl[p] = 0; c.X.wout[p] = 0; }
+#ifdef RMJ_OL_ACT_LEGAL
+        ol_gen_act_legal(ctx_pack(c), S.current_player);
+#else
         gen_act_legal(c, S.current_player);
+#endif
     } else if (!claims_fresh) {
         // WaitResponse that was not produced in this launch (e.g. after rmj_poke_state): rebuild claims
         if (S.pending_kan_pid == 0xFF && S.last_discard_pid != 0xFF) {

@@ -12,8 +12,21 @@ __device__ __noinline__ void ol_env_reset_default(CtxV v) {
     init_round(c, 0, 0, 0, 0, sc);
 }
 
+// Full-featured step of one game, out of line: entered from k_step when the fast path met a rare transition (or the
+// game must be reset).  It starts over from the HBM record - the fast path never stores before it is sure.
+__device__ __noinline__ void ol_step_full(CtxV v, uint64_t mine, uint32_t flags) {
+    CTX_FROM(v);
+    flags = uni(flags);
+    GState& S = c.S;
+    load_state(S, c.E.core + c.g, c.lane);
+    if (S.is_done && (flags & STEP_F_AUTORESET)) ol_env_reset_default(v);
+    else step_game<false>(c, mine, (flags & STEP_F_RANDOM) != 0);
+    finalize_outputs<false>(c, true);
+    store_state(S, c.E.core + c.g, c.lane);
+}
+
 #ifndef RMJ_STEP_WAVES
-#define RMJ_STEP_WAVES 3
+#define RMJ_STEP_WAVES 8
 #endif
 __global__ __launch_bounds__(256, RMJ_STEP_WAVES) void k_step(const Env* __restrict__ Ep, const uint64_t* __restrict__ actions, uint64_t policy_seed, uint32_t flags) {
     const Env& E = *Ep;  // device-resident: its address can travel to out-of-line code without a scratch copy
@@ -28,32 +41,36 @@ __global__ __launch_bounds__(256, RMJ_STEP_WAVES) void k_step(const Env* __restr
     c.pf_live_end = S.live_end;
     c.pf_draw = c.W[S.live_end > 0 ? S.live_end - 1 : 0];
     PROF(c.X, lane, 0);
-    if (S.is_done && (flags & STEP_F_AUTORESET)) {
-        ol_env_reset_default(ctx_pack(c));
-    } else {
-        const bool device_policy = (flags & STEP_F_RANDOM) != 0;
-        // lane = seat: one gather (and one copy of the 64-bit modulo / of the canonicalisation) for all seats
-        uint64_t mine = RMJ_NO_ACTION;
-        if (device_policy) {
-            // RandomAgent (random_agent.py:6-15), keyed per (game, step, seat): see rmj_step_random in the header
-            uint64_t gs = sm64(policy_seed + E.game_offset + g);
-            if (lane < 4) {
-                int n = S.nlegal[lane];
-                if (((S.active_mask >> lane) & 1u) && n > 0 && !S.is_done) {
-                    uint32_t ch = mod_small(sm64(gs + (uint64_t)S.step_count * 4ull + (uint64_t)lane), (uint32_t)n);
-                    mine = c.Lg[lane * RMJ_MAX_LEGAL + ch];
-                }
+    const bool device_policy = (flags & STEP_F_RANDOM) != 0;
+    // lane = seat: one gather (and one copy of the modulo / of the canonicalisation) for all seats
+    uint64_t mine = RMJ_NO_ACTION;
+    if (device_policy) {
+        // RandomAgent (random_agent.py:6-15), keyed per (game, step, seat): see rmj_step_random in the header
+        uint64_t gs = sm64(policy_seed + E.game_offset + g);
+        if (lane < 4) {
+            int n = S.nlegal[lane];
+            if (((S.active_mask >> lane) & 1u) && n > 0 && !S.is_done) {
+                uint32_t ch = mod_small(sm64(gs + (uint64_t)S.step_count * 4ull + (uint64_t)lane), (uint32_t)n);
+                mine = c.Lg[lane * RMJ_MAX_LEGAL + ch];
             }
-        } else if (lane < 4) {
-            uint64_t a = actions[(size_t)g * 4 + lane];
-            mine = ((a & 0xFF) == 0xFF) ? RMJ_NO_ACTION : a_canon(a);
         }
-        PROF(c.X, lane, 1);
-        step_game(c, mine, device_policy);  // picked from the stored lists: valid by construction
+    } else if (lane < 4) {
+        uint64_t a = actions[(size_t)g * 4 + lane];
+        mine = ((a & 0xFF) == 0xFF) ? RMJ_NO_ACTION : a_canon(a);
     }
-    PROF(c.X, lane, 8);
-    finalize_outputs(c, true);
-    store_state(S, E.core + g, lane);
+    PROF(c.X, lane, 1);
+    // Fast path: the common transitions, fully inline, nothing stored until it has succeeded.
+    if (S.is_done && (flags & STEP_F_AUTORESET)) c.bail = true;
+    else {
+        step_game<true>(c, mine, device_policy);  // device policy: picked from the stored lists, valid by construction
+        PROF(c.X, lane, 8);
+        if (!c.bail) finalize_outputs<true>(c, true);
+    }
+    if (c.bail) {
+        ol_step_full(ctx_pack(c), mine, flags);
+    } else {
+        store_state(S, E.core + g, lane);
+    }
     PROF(c.X, lane, 15);
     PROF_FLUSH(c.X, lane, g);
 }
@@ -102,7 +119,7 @@ __global__ __launch_bounds__(256, 4) void k_reset(const Env* __restrict__ Ep, Re
         init_round(c, A.oya ? A.oya[g] : 0, A.round_wind ? A.round_wind[g] : 0, A.honba ? A.honba[g] : 0,
                    A.kyotaku ? A.kyotaku[g] : 0u, sc);
     }
-    finalize_outputs(c, true);
+    finalize_outputs<false>(c, true);
     store_state(S, E.core + g, lane);
 }
 
@@ -116,7 +133,7 @@ __global__ __launch_bounds__(64, 4) void k_refresh(const Env* __restrict__ Ep, u
     Ctx c{st, E, x, g, lane, E.wall + (size_t)g * RMJ_WALL_STRIDE, E.legal + (size_t)g * 4 * RMJ_MAX_LEGAL};
     bool keep = st.phase == RMJ_WAIT_RESPONSE && st.pending_kan_pid != 0xFF;  // chankan claims are not reconstructible
     if (!keep) {
-        finalize_outputs(c, false);
+        finalize_outputs<false>(c, false);
         store_state(st, E.core + g, lane);
     }
 }

@@ -34,6 +34,10 @@ struct Ctx {
     // the next live-wall draw W[live_end-1], fetched as soon as the record is in LDS so that its latency is off the
     // critical path of deal_next (valid while live_end == pf_live_end; -1: not fetched)
     int pf_draw = -1, pf_live_end = -1;
+    // Fast/slow split (k_step): the <FAST> instantiations of the transition functions cover the common transitions and
+    // set `bail` as soon as they meet anything rare (yaku evaluation, settlement, kan, ryukyoku, next round, ...); the
+    // kernel then re-runs the whole step from the untouched HBM record in the out-of-line full-featured path.
+    bool bail = false;
 };
 
 // By-value view of a Ctx for out-of-line (rare-path) functions.  Passing Ctx& to a non-inlined function would
@@ -48,8 +52,22 @@ struct CtxV {
     uint32_t g;
     int lane;
 };
+// Function arguments arrive in vector registers (the call ABI treats them as divergent); everything in a CtxV except
+// `lane` is wave-uniform, so it is moved to scalar registers on entry: the out-of-line bodies then address memory and
+// branch with scalar code like the inlined hot path does.
+template <typename T>
+__device__ __forceinline__ T* uni_ptr(T* p) {
+    uint64_t x = (uint64_t)p;
+    uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)x), hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(x >> 32));
+    return (T*)(((uint64_t)hi << 32) | lo);
+}
+__device__ __forceinline__ int uni(int x) { return __builtin_amdgcn_readfirstlane(x); }
+__device__ __forceinline__ uint32_t uni(uint32_t x) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)x); }
+__device__ __forceinline__ uint64_t uni(uint64_t x) {
+    return ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(x >> 32)) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)x);
+}
 #undef CTX_FROM
-#define CTX_FROM(v) Ctx c{*(v).S, *(v).E, *(v).X, (v).g, (v).lane, (v).W, (v).Lg}
+#define CTX_FROM(v) Ctx c{*uni_ptr((v).S), *uni_ptr((v).E), *uni_ptr((v).X), uni((v).g), (v).lane, uni_ptr((v).W), uni_ptr((v).Lg)}
 __device__ __forceinline__ CtxV ctx_pack(const Ctx& c) {
     CtxV v;
     v.S = &c.S; v.X = &c.X; v.W = c.W; v.Lg = c.Lg; v.E = &c.E; v.g = c.g; v.lane = c.lane;
@@ -185,7 +203,7 @@ __device__ __forceinline__ CalcOut seat_calc_impl(Ctx& c, int seat, int skip_idx
 __device__ __noinline__ CalcOut ol_seat_calc(CtxV v, int seat, int skip_idx, int win_tile, uint32_t cf, uint32_t honba, bool use_ura,
                                              int kita_count) {
     CTX_FROM(v);
-    return seat_calc_impl(c, seat, skip_idx, win_tile, cf, honba, use_ura, kita_count);
+    return seat_calc_impl(c, uni(seat), uni(skip_idx), uni(win_tile), uni(cf), uni(honba), use_ura, uni(kita_count));
 }
 // kita_count: Conditions.kita_count — the reference passes it only at settlement and in the kita ron check
 // (state_3p/mod.rs:635,926; sanma.rs:115), legality checks leave it 0.
@@ -354,6 +372,7 @@ __device__ __forceinline__ bool gen_claims(Ctx& c, int i, int pid, int tile) {
 //   C  lane = 16*seat + hand slot: one ballot finds the pon/daiminkan material of every seat,
 //   D  chi for the next seat only, E  lane = seat: Pass / list lengths / stale counts.
 // Per-seat list positions run in LDS (X.nl), so the emission code exists once with a dynamic seat index.
+template <bool FAST = false>
 __device__ __forceinline__ uint32_t gen_claims_all(Ctx& c, int pid, int tile) {
     GState& S = c.S;
     const int lane = c.lane;
@@ -380,6 +399,7 @@ __device__ __forceinline__ uint32_t gen_claims_all(Ctx& c, int pid, int tile) {
     const bool furiten = (W & dtm) != 0ull || (qfl & (PF_MISSED_RIICHI | PF_MISSED_DOUJUN));
     uint32_t ronm = (uint32_t)__ballot(other && !in_discards && !in_missed && !furiten && ((W >> tt) & 1ull)) & 0xFu;
     const uint32_t riichi_m = (uint32_t)__ballot(lane < 4 && (qfl & PF_RIICHI_DECLARED)) & 0xFu;
+    if (FAST && ronm) { c.bail = true; return 0u; }
     while (ronm) {  // rare: a seat waits on this tile and is not furiten -> yaku check
         int i = __ffs((int)ronm) - 1;
         ronm &= ronm - 1u;
@@ -517,6 +537,7 @@ __device__ __forceinline__ uint32_t tenpai_after_discard(Ctx& c, const PState& P
 }
 
 // legal_actions.rs:11-252 (WaitAct branch) for the current player
+template <bool FAST>
 __device__ __forceinline__ void gen_act_legal(Ctx& c, int pid) {
     GState& S = c.S;
     PState& P = S.p[pid];
@@ -552,9 +573,11 @@ __device__ __forceinline__ void gen_act_legal(Ctx& c, int pid) {
             }
             shape = (W13 >> (tile >> 2)) & 1ull;
         } else {
+            if (FAST) { c.bail = true; return; }
             shape = seat_shape(c, pid, idx, tile);
         }
         if (shape) {
+            if (FAST) { c.bail = true; return; }  // a complete hand: yaku evaluation lives in the full path
             CalcOut r = seat_calc(c, pid, idx, tile, cf, S.honba, false);
             if (r.is_win && (r.yakuman || r.han >= 1)) put_legal(c, pid, n++, mk_action(RMJ_TSUMO, tile, 0));
         }
@@ -679,12 +702,6 @@ __device__ __forceinline__ void gen_act_legal(Ctx& c, int pid) {
     PROF(c.X, lane, 12);
 }
 
-#ifdef RMJ_OL_ACT_LEGAL
-__device__ __noinline__ void ol_gen_act_legal(CtxV v, int pid) {
-    CTX_FROM(v);
-    gen_act_legal(c, pid);
-}
-#endif
 
 // current_claims.entry(i).or_default().push(Ron) (state/mod.rs:524-533, 665-673; sanma.rs:121-128): the Ron offer is
 // APPENDED to whatever the seat still has in current_claims (see GState::stale_n).
@@ -747,10 +764,12 @@ __device__ inline void process_end_game(Ctx& c) {
     emit_simple(c, RMJ_EV_END_GAME);
 }
 // state/mod.rs:1569-1593
+template <bool FAST = false>
 __device__ __forceinline__ void deal_next(Ctx& c) {
     GState& S = c.S;
     S.is_rinshan = 0;
     if (S.drawable_count == 0) {
+        if (FAST) { c.bail = true; return; }
         trigger_ryukyoku(c, RMJ_RK_EXHAUSTIVE, 0);
         return;
     }
@@ -947,6 +966,7 @@ __device__ inline bool seat_tenpai(Ctx& c, int seat) {
 // state/mod.rs:1846-1968
 __device__ __noinline__ void ol_trigger_ryukyoku(CtxV v, int reason, int offender) {
     CTX_FROM(v);
+    reason = uni(reason); offender = uni(offender);
     GState& S = c.S;
     accept_riichi(c);
     const int np = KNP;
@@ -1014,6 +1034,7 @@ __device__ __noinline__ void ol_trigger_ryukyoku(CtxV v, int reason, int offende
 }
 
 // state/mod.rs:1970-2019
+template <bool FAST = false>
 __device__ __forceinline__ bool check_abortive_draw(Ctx& c) {
     GState& S = c.S;
     const int lane = c.lane;
@@ -1031,14 +1052,26 @@ __device__ __forceinline__ bool check_abortive_draw(Ctx& c) {
         int first = S.p[0].discards[0] >> 2;
         if (first >= 27 && first <= 30) {
             uint32_t same = (uint32_t)__ballot(seat_lane && (P.discards[0] >> 2) == first);
-            if (same == all_seats) { trigger_ryukyoku(c, RMJ_RK_SUFUURENTA, 0); return true; }
+            if (same == all_seats) {
+                if (FAST) { c.bail = true; return true; }
+                trigger_ryukyoku(c, RMJ_RK_SUFUURENTA, 0);
+                return true;
+            }
         }
     }
     if (__popc(kan) == 4) {  // suukansansen: four kans by at least two players
         int owner = (__ffs((int)kan) - 1) >> 2;
-        if (kan & ~(0xFu << (4 * owner))) { trigger_ryukyoku(c, RMJ_RK_SUUKANSANSEN, 0); return true; }
+        if (kan & ~(0xFu << (4 * owner))) {
+            if (FAST) { c.bail = true; return true; }
+            trigger_ryukyoku(c, RMJ_RK_SUUKANSANSEN, 0);
+            return true;
+        }
     }
-    if (!KSANMA && riichi == all_seats) { trigger_ryukyoku(c, RMJ_RK_SUUCHA_RIICHI, 0); return true; }
+    if (!KSANMA && riichi == all_seats) {
+        if (FAST) { c.bail = true; return true; }
+        trigger_ryukyoku(c, RMJ_RK_SUUCHA_RIICHI, 0);
+        return true;
+    }
     return false;
 }
 
@@ -1092,6 +1125,7 @@ __device__ void ol_resolve_kan(CtxV v, int pid, uint64_t action);
 __device__ __forceinline__ void resolve_kan(Ctx& c, int pid, uint64_t action) { ol_resolve_kan(ctx_pack(c), pid, action); }
 __device__ __noinline__ void ol_resolve_kan(CtxV v, int pid, uint64_t action) {
     CTX_FROM(v);
+    pid = uni(pid); action = uni(action);
     GState& S = c.S;
     PState& P = S.p[pid];
     uint32_t ty = a_type(action);
@@ -1130,9 +1164,11 @@ __device__ __noinline__ void ol_resolve_kan(CtxV v, int pid, uint64_t action) {
 }
 
 // state/mod.rs:1317-1413
+template <bool FAST = false>
 __device__ __forceinline__ void resolve_discard(Ctx& c, int pid, int tile, bool tsumogiri) {
     GState& S = c.S;
     PState& P = S.p[pid];
+    if (FAST && S.pending_kan_dora > 0) { c.bail = true; return; }
     if (KSANMA) { S.pending_kan_pid = 0xFF; S.pending_kan_action = 0; }  // quirk Q11 (state_3p/mod.rs:1224-1227)
     S.is_rinshan = 0;
     uint32_t fl = P.flags;  // one LDS read / one write for the whole sequence of flag updates
@@ -1170,19 +1206,20 @@ __device__ __forceinline__ void resolve_discard(Ctx& c, int pid, int tile, bool 
     S.active_mask = 0;
     S.ron_offer_mask = 0;
     PROF(c.X, c.lane, 4);
-    const uint32_t claim_active = gen_claims_all(c, pid, tile);
+    const uint32_t claim_active = gen_claims_all<FAST>(c, pid, tile);
+    if (FAST && c.bail) return;
     PROF(c.X, c.lane, 5);
     if (claim_active) {
         S.phase = RMJ_WAIT_RESPONSE;
         S.active_mask = (uint8_t)claim_active;
     } else {
         if (S.riichi_pending != 0xFF) accept_riichi(c);
-        bool abort_ = check_abortive_draw(c);
+        bool abort_ = check_abortive_draw<FAST>(c);
         PROF(c.X, c.lane, 23);
         if (!abort_) {
             S.turn_count += 1;
             S.current_player = (uint8_t)((pid + 1) % KNP);
-            deal_next(c);
+            deal_next<FAST>(c);
             PROF(c.X, c.lane, 24);
             if (S.turn_count >= (uint32_t)KNP) S.is_first_turn = 0;
         }
@@ -1318,6 +1355,7 @@ __device__ inline void handle_kita(Ctx& c, int pid, uint64_t act) {
 // bits 8.. = tile.
 __device__ __noinline__ uint32_t ol_wait_act_other(CtxV v, int pid, uint64_t act) {
     CTX_FROM(v);
+    pid = uni(pid); act = uni(act);
     GState& S = c.S;
     const int lane = c.lane;
     (void)lane;
@@ -1482,6 +1520,7 @@ __device__ __noinline__ uint32_t ol_wait_act_other(CtxV v, int pid, uint64_t act
 // Ron settlement of a WaitResponse step (state/mod.rs:945-1142): once per kyoku at most, out of line.
 __device__ __noinline__ void ol_settle_ron(CtxV v, uint32_t ron_mask) {
     CTX_FROM(v);
+    ron_mask = uni(ron_mask);
     GState& S = c.S;
         if (!KSANMA && __popc(ron_mask) >= 3 && rule(c, RMJ_RULE_SANCHAHO_DRAW)) { trigger_ryukyoku(c, RMJ_RK_SANCHAHO, 0); return; }
         int target = S.last_discard_pid != 0xFF ? S.last_discard_pid : S.current_player;
@@ -1547,6 +1586,7 @@ __device__ __forceinline__ uint64_t act_at(uint64_t mine, int p) {
     return (uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)mine, p) |
            ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(mine >> 32), p) << 32);
 }
+template <bool FAST = false>
 __device__ __forceinline__ void step_game(Ctx& c, const uint64_t mine, bool trusted = false) {
     GState& S = c.S;
     const int lane = c.lane;
@@ -1568,6 +1608,7 @@ __device__ __forceinline__ void step_game(Ctx& c, const uint64_t mine, bool trus
             valid = __ballot(hit) != 0ull;
         }
         if (!valid) {
+            if (FAST) { c.bail = true; return; }
             S.last_error_pid = (uint8_t)pid;
             trigger_ryukyoku(c, RMJ_RK_ILLEGAL, pid);
             return;
@@ -1599,11 +1640,12 @@ __device__ __forceinline__ void step_game(Ctx& c, const uint64_t mine, bool trus
             }
             do_discard = valid; d_tile = tile; d_tsumogiri = tsumogiri;
         } else {
+            if (FAST) { c.bail = true; return; }  // Riichi, kans, Tsumo, Kyushu, Kita: full path
             uint32_t r = ol_wait_act_other(ctx_pack(c), pid, act);
             do_discard = r & 1u; d_tsumogiri = (r >> 1) & 1u; d_tile = (int)(r >> 8);
         }
         PROF(c.X, lane, 3);
-        if (do_discard) resolve_discard(c, pid, d_tile, d_tsumogiri);
+        if (do_discard) resolve_discard<FAST>(c, pid, d_tile, d_tsumogiri);
         return;
     }
     // ---- WaitResponse (state/mod.rs:900-1314)
@@ -1628,6 +1670,7 @@ __device__ __forceinline__ void step_game(Ctx& c, const uint64_t mine, bool trus
     const int claimer = pon_m ? __ffs((int)pon_m) - 1 : (chi_m ? __ffs((int)chi_m) - 1 : -1);
     const uint64_t claim = claimer >= 0 ? act_at(mine, claimer) : 0ull;
     if (ron_mask) {
+        if (FAST) { c.bail = true; return; }
         ol_settle_ron(ctx_pack(c), ron_mask);
     } else if (claimer >= 0) {
         PState& C = S.p[claimer];
@@ -1638,6 +1681,7 @@ __device__ __forceinline__ void step_game(Ctx& c, const uint64_t mine, bool trus
         if (S.last_discard_pid != 0xFF) S.p[S.last_discard_pid].flags &= ~PF_NAGASHI;
         for (int p = 0; p < 4; p++) S.p[p].flags &= ~PF_IPPATSU;
         uint32_t ty = a_type(claim);
+        if (FAST && ty == RMJ_DAIMINKAN) { c.bail = true; return; }
         if (ty == RMJ_DAIMINKAN) {
             S.current_player = (uint8_t)claimer;
             S.active_mask = (uint8_t)(1u << claimer);
@@ -1676,6 +1720,7 @@ __device__ __forceinline__ void step_game(Ctx& c, const uint64_t mine, bool trus
         S.active_mask = 0;
         S.ron_offer_mask = 0;
         for (int p = 0; p < 4; p++) S.stale_n[p] = 0;  // current_claims.clear() (state/mod.rs:1299)
+        if (FAST && S.pending_kan_pid != 0xFF) { c.bail = true; return; }
         if (S.pending_kan_pid != 0xFF) {
             int pk = S.pending_kan_pid;
             uint64_t pa = S.pending_kan_action;
@@ -1691,7 +1736,7 @@ __device__ __forceinline__ void step_game(Ctx& c, const uint64_t mine, bool trus
             accept_riichi(c);
             S.turn_count += 1;
             S.current_player = (uint8_t)((S.current_player + 1) % KNP);
-            deal_next(c);
+            deal_next<FAST>(c);
             if (S.turn_count >= (uint32_t)KNP) S.is_first_turn = 0;
         }
     }
@@ -1699,6 +1744,7 @@ __device__ __forceinline__ void step_game(Ctx& c, const uint64_t mine, bool trus
 
 // After a transition: produce the observation-side outputs for the new state
 // (get_observations(active_players), env.rs:870-871 -> state/mod.rs:189-263; mask: observation/python.rs:98-111)
+template <bool FAST = false>
 __device__ __forceinline__ void finalize_outputs(Ctx& c, bool claims_fresh) {
     GState& S = c.S;
     const int lane = c.lane;
@@ -1706,11 +1752,8 @@ __device__ __forceinline__ void finalize_outputs(Ctx& c, bool claims_fresh) {
         for (int p = 0; p < 4; p++) { c.X.nl[p] = 0; c.X.wout[p] = 0; }
     } else if (S.phase == RMJ_WAIT_ACT) {
         for (int p = 0; p < 4; p++) { c.X.nl[p] = 0; c.X.wout[p] = 0; }
-#ifdef RMJ_OL_ACT_LEGAL
-        ol_gen_act_legal(ctx_pack(c), S.current_player);
-#else
-        gen_act_legal(c, S.current_player);
-#endif
+        gen_act_legal<FAST>(c, S.current_player);
+        if (FAST && c.bail) return;
     } else if (!claims_fresh) {
         // WaitResponse that was not produced in this launch (e.g. after rmj_poke_state): rebuild claims
         if (S.pending_kan_pid == 0xFF && S.last_discard_pid != 0xFF) {

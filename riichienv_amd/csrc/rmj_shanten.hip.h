@@ -229,8 +229,9 @@ __device__ __forceinline__ int sh_normal(const PH& h, int m, const ShantenTables
 // shanten.rs:198-211 ; sanma: 2m-8m skipped (shanten.rs:437-452) — they are absent from a sanma hand anyway
 __device__ __forceinline__ int sh_chiitoi(PH h, bool sanma) {
     if (sanma) h.a &= (7u | (7u << 24));
-    uint64_t pres = ph_presence(h);
-    int kinds = __popcll(pres);
+    // kinds = number of non-empty fields (bit0|bit1|bit2 of each 3-bit field)
+    int kinds = __popc((h.a | (h.a >> 1) | (h.a >> 2)) & O9_1) + __popc((h.b | (h.b >> 1) | (h.b >> 2)) & O9_1) +
+                __popc((h.c | (h.c >> 1) | (h.c >> 2)) & O9_1) + __popc((h.d | (h.d >> 1) | (h.d >> 2)) & O7_1);
     // count >= 2  <=> bit1 or bit2 of the field
     int pairs = __popc(((h.a >> 1) | (h.a >> 2)) & O9_1) + __popc(((h.b >> 1) | (h.b >> 2)) & O9_1) +
                 __popc(((h.c >> 1) | (h.c >> 2)) & O9_1) + __popc(((h.d >> 1) | (h.d >> 2)) & O7_1);
@@ -239,22 +240,13 @@ __device__ __forceinline__ int sh_chiitoi(PH h, bool sanma) {
 }
 // shanten.rs:213-226
 __device__ __forceinline__ int sh_kokushi(const PH& h) {
-    int kinds = 0;
-    bool pair = false;
-#pragma unroll
-    for (int s = 0; s < 3; s++) {
-        uint32_t x = ph_get(h, s);
-        uint32_t c0 = x & 7u, c8 = (x >> 24) & 7u;
-        kinds += (c0 > 0u) + (c8 > 0u);
-        pair = pair || c0 >= 2u || c8 >= 2u;
-    }
-#pragma unroll
-    for (int i = 0; i < 7; i++) {
-        uint32_t c = (h.d >> (3 * i)) & 7u;
-        kinds += c > 0u;
-        pair = pair || c >= 2u;
-    }
-    return 14 - kinds - (pair ? 1 : 0) - 1;
+    const uint32_t T9 = 1u | (1u << 24);  // bit0 of the 1 and 9 fields
+    const uint32_t any_a = h.a | (h.a >> 1) | (h.a >> 2), any_b = h.b | (h.b >> 1) | (h.b >> 2);
+    const uint32_t any_c = h.c | (h.c >> 1) | (h.c >> 2), any_d = h.d | (h.d >> 1) | (h.d >> 2);
+    const int kinds = __popc(any_a & T9) + __popc(any_b & T9) + __popc(any_c & T9) + __popc(any_d & O7_1);
+    const uint32_t two = (((h.a >> 1) | (h.a >> 2)) & T9) | (((h.b >> 1) | (h.b >> 2)) & T9) | (((h.c >> 1) | (h.c >> 2)) & T9) |
+                         (((h.d >> 1) | (h.d >> 2)) & O7_1);  // a terminal kind held at least twice
+    return 14 - kinds - (two ? 1 : 0) - 1;
 }
 // shanten.rs:407-435: relocate 1m / 9m counts into empty honor slots (3P)
 __device__ __forceinline__ PH sh_relocate_3p(const PH& h) {

@@ -546,7 +546,13 @@ __device__ __forceinline__ void gen_act_legal(Ctx& c, int pid) {
     int n = 0;
     const bool r_decl = P.flags & PF_RIICHI_DECLARED, r_stage = P.flags & PF_RIICHI_STAGE;
     const bool drawn = S.drawn_tile != 0xFF;
-    c.X.wout[pid] = seat_waits(c, pid);  // non-empty only for a (poked) 13-tile holder, state/mod.rs:220-225
+    // waits of the acting seat: non-empty only for a (poked) 13-tile holder, state/mod.rs:220-225
+    if (FAST) {
+        if (P.hand_len + 3 * P.n_melds == 13) { c.bail = true; return; }
+        c.X.wout[pid] = 0ull;
+    } else {
+        c.X.wout[pid] = seat_waits(c, pid);
+    }
     // 1. Tsumo
     if (drawn && !r_stage) {
         int tile = S.drawn_tile;
@@ -663,6 +669,7 @@ __device__ __forceinline__ void gen_act_legal(Ctx& c, int pid) {
         } else if (r_decl) {
             int t = S.drawn_tile, t34 = t >> 2;
             if (ph_cnt(full, t34) == 4) {
+                if (FAST) { c.bail = true; return; }  // ankan after riichi: two wait probes, full path
                 PH pre = full;
                 ph_sub(pre, t34);
                 uint64_t wpre = 0, wpost = 0;

@@ -67,7 +67,9 @@ __global__ __launch_bounds__(256, RMJ_STEP_WAVES) void k_step(const Env* __restr
         if (!c.bail) finalize_outputs<true>(c, true);
     }
     if (c.bail) {
+        PROF(c.X, lane, 26);
         ol_step_full(ctx_pack(c), mine, flags);
+        PROF(c.X, lane, 25);
     } else {
         store_state(S, E.core + g, lane);
     }

@@ -391,6 +391,7 @@ __device__ __forceinline__ uint32_t gen_claims_all(Ctx& c, int pid, int tile) {
         fill_waits13(c, P, build_ph_wave(P, lane));
     }
     wave_sync();
+    PROF(c.X, lane, 16);
     const uint64_t W = holds13 ? Q.waits13 : 0ull;
     if (lane < 4) c.X.wout[lane] = W;
     const uint64_t dtm = Q.discard_type_mask;
@@ -417,6 +418,7 @@ __device__ __forceinline__ uint32_t gen_claims_all(Ctx& c, int pid, int tile) {
     }
     const bool can_call = S.drawable_count > 0;
     const bool kuikae = rule(c, RMJ_RULE_KUIKAE_FORBIDDEN);
+    PROF(c.X, lane, 17);
     // ---- C (lane = 16*seat + slot)
     {
         const int k = lane >> 4, slot = lane & 15;
@@ -451,6 +453,7 @@ __device__ __forceinline__ uint32_t gen_claims_all(Ctx& c, int pid, int tile) {
             if (lane == 0) c.X.nl[i] = n;
         }
     }
+    PROF(c.X, lane, 18);
     // ---- D: Chi for the next seat (lane = pattern*16 + a*4 + b); no Chi in 3P (state_3p/legal_actions.rs:386)
     if (!KSANMA && can_call && tt < 27) {
         const int i = (pid + 1) & 3;
@@ -496,6 +499,7 @@ __device__ __forceinline__ uint32_t gen_claims_all(Ctx& c, int pid, int tile) {
         }
     }
     wave_sync();
+    PROF(c.X, lane, 19);
     // ---- E (lane = seat): Pass, lengths, stale counts
     int n = lane < 4 ? c.X.nl[lane] : 0;
     if (lane < 4) {
@@ -505,6 +509,7 @@ __device__ __forceinline__ uint32_t gen_claims_all(Ctx& c, int pid, int tile) {
             c.X.nl[lane] = n + 1;
         }
     }
+    PROF(c.X, lane, 27);
     return (uint32_t)__ballot(lane < 4 && n > 0) & 0xFu;
 }
 

@@ -95,6 +95,32 @@ def test_step_random_device_policy_matches_oracle():
     assert env.total_steps() == sum(o.step_count for o in games)
 
 
+@pytest.mark.parametrize("mode,rule", [(2, abi.RULE_TENHOU), (5, abi.RULE_TENHOU), (1, abi.RULE_MJSOUL)])
+def test_device_policy_long_rollout(mode, rule):
+    """Several hanchan per game through the fused fast/full-path kernel (device policy, auto-reset): final state, legal
+    lists, masks, waits, step counts and the whole MJAI log of the last game must equal the oracle's."""
+    from oracle import oracle
+    from riichienv_amd import vecenv
+
+    n, seed, pseed, steps = 96, 900 + mode, 0xBEEF, 4000
+    env = vecenv.VecRiichiEnv(n, game_mode=mode, seed=seed, rule_bits=rule, event_ring=4096)
+    games = [oracle.Game(game_mode=mode, seed=seed + g, rule_bits=rule) for g in range(n)]
+    env.reset()
+    for o in games:
+        o.reset()
+    env.step_random(pseed, steps, auto_reset=True)
+    for g, o in enumerate(games):
+        for _ in range(steps):
+            if o.status()[2]:
+                o.reset()
+                continue
+            o.step(o.random_actions(pseed, g))
+    _compare(env, games, range(n), steps)
+    assert list(env.step_counts()) == [o.step_count for o in games]
+    for g in (0, n // 2, n - 1):
+        assert env.mjai_log(g) == games[g].log(), g
+
+
 @pytest.mark.parametrize("mode", [2, 5])
 def test_encode_parity_along_rollout(mode):
     """Row A14: rmj_encode (74 x 34 f32 in 4P, 74 x 27 in 3P, every seat) bit-exact vs the oracle along a rollout."""

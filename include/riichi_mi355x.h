@@ -246,6 +246,15 @@ int rmj_encode_device(rmj_handle h, int only_active, float* d_out); /* device po
  * (len_div3 = tile count / 3; -1 = complete hand).  Tables are generated at first use, on the host. */
 int rmj_shanten(int device, const uint8_t* counts /*[n][34]*/, uint32_t n, int sanma, int8_t* out /*[n]*/);
 
+/* shanten.rs:304-327 calculate_effective_tiles_with_discard / :525-548 _3p_with_discard: number of tile types whose
+ * draw lowers the shanten (3n+1 hand), or the best such count over the discards that do not raise it (3n+2 hand).
+ * The reference takes 136-ids and panics on a 3n hand; only types matter, a 3n hand yields 0xFFFFFFFF. */
+int rmj_effective_tiles(int device, const uint8_t* counts /*[n][34]*/, uint32_t n, int sanma, uint32_t* out /*[n]*/);
+/* shanten.rs:331-405 calculate_best_ukeire / :552-626 _3p: best, over the discards that do not raise the shanten, of the
+ * number of live tiles (4 - visible - held, saturating) whose draw lowers it. */
+int rmj_best_ukeire(int device, const uint8_t* counts /*[n][34]*/, const uint8_t* visible /*[n][34]*/, uint32_t n, int sanma,
+                    uint32_t* out /*[n]*/);
+
 /* ------------------------------------------------------------------ measurement */
 typedef struct RmjBenchResult {
     double total_ms;      /* HIP-event time over the timed region (stream of the handle) */

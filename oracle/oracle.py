@@ -55,6 +55,8 @@ def lib():
         L.orc_action_encode.argtypes = [C.c_uint64]
         L.orc_game_encode.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
         L.orc_shanten.argtypes = [C.c_void_p, C.c_uint32, C.c_int, C.c_void_p]
+        L.orc_effective_tiles.argtypes = [C.c_void_p, C.c_uint32, C.c_int, C.c_void_p]
+        L.orc_best_ukeire.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_int, C.c_void_p]
         L.orc_tid_to_mjai.argtypes = [C.c_uint8, C.c_char_p]
         L.orc_bench_rollout.restype = C.c_uint64
         L.orc_bench_rollout.argtypes = [C.c_int, C.c_uint32, C.c_int, C.c_uint32, C.c_uint64, C.c_uint64, C.c_uint32,
@@ -95,6 +97,23 @@ def shanten(counts, sanma=False):
     counts = np.ascontiguousarray(counts, dtype=np.uint8)
     out = np.zeros(counts.shape[0], np.int8)
     lib().orc_shanten(counts.ctypes.data, counts.shape[0], int(sanma), out.ctypes.data)
+    return out
+
+
+def effective_tiles(counts, sanma=False):
+    """calculate_effective_tiles(_3p)_with_discard on [n][34] type histograms (0xFFFFFFFF for a 3n hand)."""
+    counts = np.ascontiguousarray(counts, dtype=np.uint8)
+    out = np.zeros(counts.shape[0], np.uint32)
+    lib().orc_effective_tiles(counts.ctypes.data, counts.shape[0], int(sanma), out.ctypes.data)
+    return out
+
+
+def best_ukeire(counts, visible, sanma=False):
+    """calculate_best_ukeire(_3p) on [n][34] hand / visible type histograms."""
+    counts = np.ascontiguousarray(counts, dtype=np.uint8)
+    visible = np.ascontiguousarray(visible, dtype=np.uint8)
+    out = np.zeros(counts.shape[0], np.uint32)
+    lib().orc_best_ukeire(counts.ctypes.data, visible.ctypes.data, counts.shape[0], int(sanma), out.ctypes.data)
     return out
 
 

@@ -157,6 +157,16 @@ int orc_shanten(const uint8_t* counts, uint32_t n, int sanma, int8_t* out) {
     return 0;
 }
 
+// shanten.rs:304-327 / 525-548 and :331-405 / 552-626 on type histograms
+int orc_effective_tiles(const uint8_t* counts, uint32_t n, int sanma, uint32_t* out) {
+    for (uint32_t k = 0; k < n; k++) out[k] = effective_tiles_with_discard(counts + 34 * (size_t)k, sanma != 0);
+    return 0;
+}
+int orc_best_ukeire(const uint8_t* counts, const uint8_t* visible, uint32_t n, int sanma, uint32_t* out) {
+    for (uint32_t k = 0; k < n; k++) out[k] = best_ukeire(counts + 34 * (size_t)k, visible + 34 * (size_t)k, sanma != 0);
+    return 0;
+}
+
 void orc_tid_to_mjai(uint8_t tid, char* buf) { std::strcpy(buf, tid_to_mjai(tid).c_str()); }
 
 // ---------------------------------------------------------------- game

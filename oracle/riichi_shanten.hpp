@@ -8,6 +8,7 @@
 // library uses).  Pinned by the reference's KATs: tests/test_shanten.py:4-114, README.md:245-273.
 #pragma once
 #include <cstdint>
+#include <algorithm>
 #include <cstring>
 #include <map>
 #include <vector>
@@ -151,6 +152,79 @@ inline int calc_shanten_from_counts(const uint8_t* tehai, int len_div3, bool san
         if (k < s) s = k;
     }
     return s;
+}
+
+// calculate_shanten (shanten.rs:250-261 / :473-484) on a type histogram: len_div3 = number of tiles / 3
+inline int shanten_of(const uint8_t* c, bool sanma) {
+    int total = 0;
+    for (int i = 0; i < 34; i++) total += c[i];
+    return calc_shanten_from_counts(c, total / 3, sanma);
+}
+// SANMA_VALID_TILE_TYPES (shanten.rs:244-247)
+inline bool ukeire_type_ok(int t, bool sanma) { return !sanma || t == 0 || t >= 8; }
+// calculate_effective_tiles / _3p (shanten.rs:265-300, 488-521); hand must hold 3n+1 tiles
+inline uint32_t effective_tiles(const uint8_t* c, bool sanma) {
+    int cur = shanten_of(c, sanma);
+    uint32_t n = 0;
+    uint8_t t[34];
+    std::memcpy(t, c, 34);
+    for (int ty = 0; ty < 34; ty++) {
+        if (!ukeire_type_ok(ty, sanma) || c[ty] >= 4) continue;
+        t[ty]++;
+        if (shanten_of(t, sanma) < cur) n++;
+        t[ty]--;
+    }
+    return n;
+}
+// calculate_effective_tiles_with_discard / _3p_with_discard (shanten.rs:304-327, 525-548); 0xFFFFFFFF for a 3n hand
+// (the reference asserts).  The loop over hand tiles collapses to a loop over held types.
+inline uint32_t effective_tiles_with_discard(const uint8_t* c, bool sanma) {
+    int total = 0;
+    for (int i = 0; i < 34; i++) total += c[i];
+    if (total % 3 == 1) return effective_tiles(c, sanma);
+    if (total % 3 != 2) return 0xFFFFFFFFu;
+    int sh = shanten_of(c, sanma);
+    uint32_t best = 0;
+    uint8_t t[34];
+    std::memcpy(t, c, 34);
+    for (int d = 0; d < 34; d++) {
+        if (!c[d]) continue;
+        t[d]--;
+        if (shanten_of(t, sanma) <= sh) best = std::max(best, effective_tiles(t, sanma));
+        t[d]++;
+    }
+    return best;
+}
+// calculate_best_ukeire / _3p (shanten.rs:331-405, 552-626)
+inline uint32_t best_ukeire(const uint8_t* c, const uint8_t* visible, bool sanma) {
+    int cur = shanten_of(c, sanma);
+    uint32_t best = 0;
+    uint8_t t[34];
+    std::memcpy(t, c, 34);
+    for (int d = 0; d < 34; d++) {
+        if (!c[d]) continue;
+        t[d]--;
+        int nsh = shanten_of(t, sanma);
+        if (nsh <= cur) {
+            uint32_t uke = 0;
+            for (int ty = 0; ty < 34; ty++) {
+                if (!ukeire_type_ok(ty, sanma) || t[ty] >= 4) continue;
+                t[ty]++;
+                bool better = shanten_of(t, sanma) < nsh;
+                t[ty]--;
+                if (better) {
+                    int rem = 4 - (int)visible[ty];
+                    if (rem < 0) rem = 0;
+                    rem -= (int)t[ty];
+                    if (rem < 0) rem = 0;
+                    uke += (uint32_t)rem;
+                }
+            }
+            best = std::max(best, uke);
+        }
+        t[d]++;
+    }
+    return best;
 }
 
 }  // namespace orc

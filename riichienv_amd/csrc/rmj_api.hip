@@ -300,6 +300,74 @@ __global__ void k_shanten(ShantenTables T, const uint8_t* counts, uint32_t n, in
     out[i] = (int8_t)sh_shanten(h, total / 3, sanma != 0, T);
 }
 
+// shanten.rs:265-405 / :488-626 (calculate_effective_tiles(_3p)_with_discard, calculate_best_ukeire(_3p)) over raw
+// histograms: ONE WAVE PER HAND, lane = drawn tile type; the loop over discard candidates runs over held types.
+//   mode 0: effective tiles (3n+1 hand: plain; 3n+2: best over the discards that do not raise shanten; else 0xFFFFFFFF)
+//   mode 1: best ukeire against `visible`
+__global__ __launch_bounds__(256) void k_ukeire(ShantenTables T, const uint8_t* counts, const uint8_t* visible, uint32_t n, int sanma,
+                                                int mode, uint32_t* out) {
+    const int lane = threadIdx.x & 63;
+    const uint32_t i = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (i >= n) return;
+    const bool sm = sanma != 0;
+    const int t = lane;                                       // tile type of this lane
+    const bool t_ok = t < 34 && (!sm || t == 0 || t >= 8);     // SANMA_VALID_TILE_TYPES (shanten.rs:244-247)
+    const uint32_t my_cnt = t < 34 ? counts[(size_t)i * 34 + t] : 0u;
+    const uint32_t my_vis = (t < 34 && visible) ? visible[(size_t)i * 34 + t] : 0u;
+    // wave-uniform histogram: lane t contributes its field, the four words are OR-reduced over the wave
+    PH h = {0, 0, 0, 0};
+    {
+        const int s = t < 34 ? t_suit(t) : 0;
+        uint32_t f = t < 34 ? (my_cnt & 7u) << (3 * (t - 9 * s)) : 0u;
+        uint32_t w[4] = {s == 0 ? f : 0u, s == 1 ? f : 0u, s == 2 ? f : 0u, s == 3 ? f : 0u};
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+#pragma unroll
+            for (int off = 32; off >= 1; off >>= 1) w[k] |= (uint32_t)__shfl_xor((int)w[k], off, 64);
+        }
+        h.a = w[0]; h.b = w[1]; h.c = w[2]; h.d = w[3];
+    }
+    const int total = ph_total(h);
+    // number of drawn types that lower the shanten of `base` (a 3n+1 hand), weighted per lane by `weight`
+    auto improve = [&](const PH& base, int base_total, int base_sh, uint32_t weight) -> uint32_t {
+        uint32_t v = 0;
+        if (t_ok && ph_cnt(base, t) < 4) {
+            PH x = base;
+            ph_add(x, t);
+            if (sh_shanten(x, (base_total + 1) / 3, sm, T) < base_sh) v = weight;
+        }
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) v += (uint32_t)__shfl_xor((int)v, off, 64);
+        return v;
+    };
+    uint32_t res = 0;
+    const int cur = sh_shanten(h, total / 3, sm, T);
+    if (mode == 0 && total % 3 == 1) {
+        res = improve(h, total, cur, 1u);
+    } else if (mode == 0 && total % 3 != 2) {
+        res = 0xFFFFFFFFu;  // the reference asserts on a 3n hand
+    } else {
+        for (int d = 0; d < 34; d++) {
+            if (ph_cnt(h, d) == 0) continue;
+            PH sub = h;
+            ph_sub(sub, d);
+            const int nsh = sh_shanten(sub, (total - 1) / 3, sm, T);
+            if (nsh > cur) continue;
+            uint32_t weight = 1u;
+            if (mode == 1) {  // remaining = 4 - visible - held (both saturating), held counted after the discard
+                int held = (int)my_cnt - (t == d ? 1 : 0);
+                int rem = 4 - (int)my_vis;
+                rem = rem < 0 ? 0 : rem;
+                rem -= held;
+                weight = (uint32_t)(rem < 0 ? 0 : rem);
+            }
+            uint32_t v = improve(sub, total - 1, nsh, weight);
+            res = v > res ? v : res;
+        }
+    }
+    if (lane == 0) out[i] = res;
+}
+
 __global__ void k_score(const uint8_t* han, const uint8_t* fu, const uint8_t* oya, const uint8_t* tsumo, const uint32_t* honba,
                         const uint8_t* np, uint32_t n, uint32_t* out) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1036,6 +1104,38 @@ int rmj_shanten(int device, const uint8_t* counts, uint32_t n, int sanma, int8_t
     hipFree(d_c);
     hipFree(d_o);
     return RMJ_OK;
+}
+
+static int run_ukeire(int device, const uint8_t* counts, const uint8_t* visible, uint32_t n, int sanma, int mode, uint32_t* out) {
+    if (!counts || !out || (mode == 1 && !visible)) return fail(RMJ_ERR_ARG, "null argument");
+    int rc = ensure_device(device);
+    if (rc) return rc;
+    if (n == 0) return RMJ_OK;
+    ShantenTables T;
+    if ((rc = shanten_tables_for(device, &T))) return rc;
+    uint8_t *d_c = nullptr, *d_v = nullptr;
+    uint32_t* d_o = nullptr;
+    HIPCHK(hipMalloc(&d_c, (size_t)n * 34));
+    HIPCHK(hipMalloc(&d_o, (size_t)n * 4));
+    HIPCHK(hipMemcpy(d_c, counts, (size_t)n * 34, hipMemcpyHostToDevice));
+    if (mode == 1) {
+        HIPCHK(hipMalloc(&d_v, (size_t)n * 34));
+        HIPCHK(hipMemcpy(d_v, visible, (size_t)n * 34, hipMemcpyHostToDevice));
+    }
+    hipLaunchKernelGGL(k_ukeire, dim3((n + 3) / 4), dim3(256), 0, 0, T, (const uint8_t*)d_c, (const uint8_t*)d_v, n, sanma, mode, d_o);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipDeviceSynchronize());
+    HIPCHK(hipMemcpy(out, d_o, (size_t)n * 4, hipMemcpyDeviceToHost));
+    hipFree(d_c);
+    hipFree(d_o);
+    if (d_v) hipFree(d_v);
+    return RMJ_OK;
+}
+int rmj_effective_tiles(int device, const uint8_t* counts, uint32_t n, int sanma, uint32_t* out) {
+    return run_ukeire(device, counts, nullptr, n, sanma, 0, out);
+}
+int rmj_best_ukeire(int device, const uint8_t* counts, const uint8_t* visible, uint32_t n, int sanma, uint32_t* out) {
+    return run_ukeire(device, counts, visible, n, sanma, 1, out);
 }
 
 // ---- measurement -----------------------------------------------------------------------------

@@ -26,7 +26,7 @@ EXPORTS = [
     "rmj_step_device", "rmj_step_random", "rmj_random_actions", "rmj_get_status", "rmj_get_legal", "rmj_get_mask",
     "rmj_get_waits", "rmj_get_scores", "rmj_get_ranks", "rmj_get_step_counts", "rmj_total_steps", "rmj_peek_state",
     "rmj_poke_state", "rmj_get_event_counts", "rmj_get_events", "rmj_format_event", "rmj_eval_hands",
-    "rmj_agari_counts", "rmj_calculate_score", "rmj_shanten", "rmj_encode", "rmj_encode_device", "rmj_bench_rollout",
+    "rmj_agari_counts", "rmj_calculate_score", "rmj_shanten", "rmj_effective_tiles", "rmj_best_ukeire", "rmj_encode", "rmj_encode_device", "rmj_bench_rollout",
 ]
 
 
@@ -71,6 +71,8 @@ def load_lib():
     L.rmj_calculate_score.argtypes = [C.c_int] + [vp] * 6 + [C.c_uint32, vp]
     L.rmj_encode.argtypes = [vp, C.c_int, vp]
     L.rmj_encode_device.argtypes = [vp, C.c_int, vp]
+    L.rmj_effective_tiles.argtypes = [C.c_int, vp, C.c_uint32, C.c_int, vp]
+    L.rmj_best_ukeire.argtypes = [C.c_int, vp, vp, C.c_uint32, C.c_int, vp]
     L.rmj_shanten.argtypes = [C.c_int, vp, C.c_uint32, C.c_int, vp]
     L.rmj_bench_rollout.argtypes = [vp, C.c_uint64, C.c_uint32, C.c_uint32, C.POINTER(abi.BenchResult)]
     _LIB = L
@@ -310,6 +312,29 @@ def shanten(counts, sanma=False, device=0):
     n = counts.shape[0]
     out = np.zeros(n, np.int8)
     _chk(L.rmj_shanten(device, counts.ctypes.data, n, int(sanma), out.ctypes.data))
+    return out
+
+
+def effective_tiles(counts, sanma=False, device=0):
+    """calculate_effective_tiles(_3p)_with_discard on [n][34] type histograms; ValueError for a 3n hand like the
+    reference's assertion (shanten.rs:304-327, 525-548)."""
+    L = load_lib()
+    counts = np.ascontiguousarray(counts, dtype=np.uint8).reshape(-1, 34)
+    out = np.zeros(counts.shape[0], np.uint32)
+    _chk(L.rmj_effective_tiles(device, counts.ctypes.data, counts.shape[0], int(sanma), out.ctypes.data))
+    if (out == 0xFFFFFFFF).any():
+        raise ValueError("calculate_effective_tiles_with_discard requires a 3n+1 or 3n+2 hand")
+    return out
+
+
+def best_ukeire(counts, visible, sanma=False, device=0):
+    """calculate_best_ukeire(_3p) on [n][34] hand / visible type histograms (shanten.rs:331-405, 552-626)."""
+    L = load_lib()
+    counts = np.ascontiguousarray(counts, dtype=np.uint8).reshape(-1, 34)
+    visible = np.ascontiguousarray(visible, dtype=np.uint8).reshape(-1, 34)
+    assert counts.shape == visible.shape
+    out = np.zeros(counts.shape[0], np.uint32)
+    _chk(L.rmj_best_ukeire(device, counts.ctypes.data, visible.ctypes.data, counts.shape[0], int(sanma), out.ctypes.data))
     return out
 
 

@@ -31,3 +31,44 @@ def test_shanten_kats():
         assert s4[i] == e4, (h, s4[i], e4)
         if e3 is not None:
             assert s3[i] == e3, (h, s3[i], e3)
+
+
+def _types(ts):
+    c = np.zeros(34, np.uint8)
+    for t in ts:
+        c[t] += 1
+    return c
+
+
+# shanten.rs:628-785 (unit tests of calculate_effective_tiles_with_discard / calculate_best_ukeire, 4P and 3P)
+H_4P_13 = [0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 27, 27]          # 123m 456m 789m 12p 11z: tenpai on 3p
+H_4P_14 = H_4P_13 + [28]
+H_3P_14 = [9, 10, 11, 12, 13, 14, 15, 16, 17, 18, 19, 27, 27, 28]
+H_4P_SHANPON = [0, 1, 2, 3, 4, 5, 6, 7, 8, 11, 11, 29, 29, 28]  # 123m 456m 789m 33p 332z
+H_3P_SHANPON = [9, 10, 11, 12, 13, 14, 15, 16, 17, 20, 20, 29, 29, 28]
+
+
+def _vis(pairs):
+    v = np.zeros(34, np.uint8)
+    for t, n in pairs:
+        v[t] = n
+    return v
+
+
+UKEIRE_KATS = [  # (hand types, visible, sanma, expected best_ukeire)
+    (H_4P_14, [], False, 4), (H_3P_14, [], True, 4), (H_4P_SHANPON, [], False, 4), (H_4P_SHANPON, [(11, 1)], False, 3),
+    (H_4P_SHANPON, [(11, 3)], False, 2), (H_3P_SHANPON, [(20, 3)], True, 2),
+]
+
+
+def test_effective_tiles_kats():
+    assert oracle.effective_tiles([_types(H_4P_13)])[0] == 1
+    assert oracle.effective_tiles([_types(H_4P_14)])[0] >= 1
+    assert oracle.effective_tiles([_types(H_3P_14)], sanma=True)[0] >= 1
+    assert oracle.effective_tiles([_types(H_4P_13[:-1])])[0] == 0xFFFFFFFF      # 3n hand: the reference panics
+    assert oracle.effective_tiles([_types(H_3P_14[:-2])], sanma=True)[0] == 0xFFFFFFFF
+
+
+def test_best_ukeire_kats():
+    for hand, vis, sanma, want in UKEIRE_KATS:
+        assert oracle.best_ukeire([_types(hand)], [_vis(vis)], sanma=sanma)[0] == want, (hand, vis, sanma)

@@ -255,6 +255,16 @@ int rmj_effective_tiles(int device, const uint8_t* counts /*[n][34]*/, uint32_t 
 int rmj_best_ukeire(int device, const uint8_t* counts /*[n][34]*/, const uint8_t* visible /*[n][34]*/, uint32_t n, int sanma,
                     uint32_t* out /*[n]*/);
 
+/* ------------------------------------------------------------------ MJAI event ingestion
+ * RiichiEnv.apply_event (riichienv-python/src/env.rs:880-887) -> GameState::apply_mjai_event
+ * (state/event_handler.rs:18-330, state_3p/event_handler.rs:18-362) for every game at once: events[n][3] holds one MJAI
+ * event per game as binary records (a start_kyoku is START_KYOKU + two TEHAI records; type NONE = no event for that
+ * game).  Tile names are mapped to ids by the caller (parser.rs:336-385 mjai_to_tid; riichienv_amd/abi.py).  Afterwards
+ * the observation outputs (status, legal lists, masks, waits) describe the new state like after rmj_step.
+ * Scope: full-information streams (masked "?" tiles are not ingested); the caller-side mjai_log recording of
+ * env.rs:56-72 is not reproduced (start_game clears the device log, later events are not appended). */
+int rmj_apply_events(rmj_handle h, const RmjEvent* events /*[n][3]*/);
+
 /* ------------------------------------------------------------------ measurement */
 typedef struct RmjBenchResult {
     double total_ms;      /* HIP-event time over the timed region (stream of the handle) */

@@ -57,6 +57,7 @@ def lib():
         L.orc_shanten.argtypes = [C.c_void_p, C.c_uint32, C.c_int, C.c_void_p]
         L.orc_effective_tiles.argtypes = [C.c_void_p, C.c_uint32, C.c_int, C.c_void_p]
         L.orc_best_ukeire.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_int, C.c_void_p]
+        L.orc_game_apply_event.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
         L.orc_tid_to_mjai.argtypes = [C.c_uint8, C.c_char_p]
         L.orc_bench_rollout.restype = C.c_uint64
         L.orc_bench_rollout.argtypes = [C.c_int, C.c_uint32, C.c_int, C.c_uint32, C.c_uint64, C.c_uint64, C.c_uint32,
@@ -128,6 +129,7 @@ class Game:
 
     def __init__(self, game_mode=0, seed=None, rule_bits=abi.RULE_TENHOU, skip_log=False, round_wind=0):
         self.L = lib()
+        self.sanma = game_mode >= 3
         self.h = self.L.orc_game_new(game_mode, int(skip_log), seed or 0, 0 if seed is None else 1, round_wind, rule_bits)
 
     def __del__(self):
@@ -198,6 +200,11 @@ class Game:
         out = np.zeros((74, 27 if sanma else 34), np.float32)
         self.L.orc_game_encode(self.h, pid, out.ctypes.data)
         return out
+
+    def apply_event(self, ev):
+        """apply_mjai_event (state/event_handler.rs, state_3p/event_handler.rs): MJAI dict or binary records."""
+        recs = abi.event_records_from_mjai(ev, 3 if self.sanma else 4) if isinstance(ev, dict) else ev
+        self.L.orc_game_apply_event(self.h, C.byref(recs), abi.EVENT_SLOTS)
 
     def random_actions(self, policy_seed, global_game):
         arr = (C.c_uint64 * 4)()

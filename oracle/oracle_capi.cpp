@@ -167,6 +167,243 @@ int orc_best_ukeire(const uint8_t* counts, const uint8_t* visible, uint32_t n, i
     return 0;
 }
 
+// ---------------------------------------------------------------- MJAI event ingestion (row N1)
+// apply_mjai_event: state/event_handler.rs:18-330 (4P), state_3p/event_handler.rs:18-362 (3P), on the binary records
+// of include/riichi_mi355x.h (a start_kyoku is START_KYOKU + two TEHAI records, like the emitted log).  Tile strings
+// were mapped by mjai_to_tid (parser.rs:336-385) on the host.  The caller-side logging of env.rs:56-72 is not restated.
+static void erase_first(std::vector<uint8_t>& v, uint8_t t) {
+    int i = vec_position(v, t);
+    if (i >= 0) v.erase(v.begin() + i);
+}
+static void apply_claims(GameState* g, int actor, uint8_t tile, bool ron_only) {
+    g->current_claims.clear();
+    g->active_players.clear();
+    std::vector<uint8_t> claim_active;
+    for (int i = 0; i < g->NP; i++) {
+        if (i == actor) continue;
+        auto r = g->_get_claim_actions_for_player((uint8_t)i, (uint8_t)actor, tile);
+        std::vector<Action> legals;
+        for (auto& a : r.first)
+            if (!ron_only || a.type == AT_RON) legals.push_back(a);
+        if (!legals.empty()) {
+            claim_active.push_back((uint8_t)i);
+            g->current_claims[(uint8_t)i] = legals;
+        }
+    }
+    if (!claim_active.empty()) {
+        g->phase = WAIT_RESPONSE;
+        g->active_players = claim_active;
+    } else {
+        g->phase = WAIT_ACT;
+        g->active_players.clear();
+        g->current_player = 0xFF;
+    }
+}
+void orc_game_apply_event(void* gp, const RmjEvent* ev, int nrec) {
+    GameState* g = (GameState*)gp;
+    if (nrec < 1) return;
+    const RmjEvent& e = ev[0];
+    const int actor = e.actor;
+    switch (e.type) {
+        case RMJ_EV_START_GAME:  // env.rs:56-72 (reset) + event_handler.rs:20-25
+            g->reset();
+            g->mjai_log.clear();
+            for (auto& l : g->mjai_log_per_player) l.clear();
+            g->current_player = 0xFF;
+            g->active_players.clear();
+            break;
+        case RMJ_EV_START_KYOKU: {  // event_handler.rs:26-103
+            g->honba = e.consumed[1];
+            g->riichi_sticks = (uint32_t)e.consumed[2] | ((uint32_t)e.consumed[3] << 8);
+            g->round_wind = e.consumed[0] & 3;
+            g->oya = e.actor;
+            g->kyoku_idx = e.target ? (uint8_t)(e.target - 1) : 0;  // kyoku.saturating_sub(1)
+            g->current_player = 0xFF;
+            g->turn_count = 0;
+            g->is_done = false;
+            g->needs_tsumo = true;
+            g->phase = WAIT_ACT;
+            g->active_players.clear();
+            g->last_discard.reset();
+            g->current_claims.clear();
+            g->pending_kan.reset();
+            g->is_rinshan_flag = false;
+            g->is_first_turn = true;
+            g->riichi_pending_acceptance = -1;
+            g->drawn_tile = -1;
+            g->win_results.clear();
+            g->last_error.reset();
+            for (int i = 0; i < 4; i++) { g->riichi_sutehais[i] = -1; g->last_tedashis[i] = -1; }
+            g->wall.tiles.assign((size_t)((g->sanma ? 108 : 136) - 13 * g->NP), 0);
+            g->wall.dora_indicators.assign(1, e.tile);
+            g->wall.rinshan_draw_count = 0;
+            g->wall.pending_kan_dora_count = 0;
+            g->wall.drawable_count = (uint8_t)(g->wall.tiles.size() - 14);
+            for (int i = 0; i < g->NP; i++) g->players[i].reset_round();
+            for (int i = 0; i < g->NP; i++) g->players[i].score = e.deltas[i];
+            for (int half = 0; half < 2 && 1 + half < nrec; half++) {
+                const uint8_t* pl = reinterpret_cast<const uint8_t*>(&ev[1 + half]) + 4;
+                for (int q = 0; q < 2; q++) {
+                    int seat = 2 * half + q;
+                    if (seat >= g->NP) continue;
+                    std::vector<uint8_t> hand(pl + 13 * q, pl + 13 * q + 13);
+                    std::sort(hand.begin(), hand.end());
+                    g->players[seat].hand = hand;
+                }
+            }
+            break;
+        }
+        case RMJ_EV_TSUMO: {  // :104-118
+            PlayerState& P = g->players[actor];
+            g->current_player = (uint8_t)actor;
+            g->drawn_tile = e.tile;
+            P.hand.push_back(e.tile);
+            std::sort(P.hand.begin(), P.hand.end());
+            P.forbidden_discards.clear();
+            if (!g->wall.tiles.empty()) {
+                g->wall.tiles.pop_back();
+                g->wall.drawable_count = g->wall.drawable_count ? (uint8_t)(g->wall.drawable_count - 1) : 0;
+            }
+            g->phase = WAIT_ACT;
+            g->active_players.assign(1, (uint8_t)actor);
+            g->needs_tsumo = false;
+            break;
+        }
+        case RMJ_EV_DAHAI: {  // :119-156
+            PlayerState& P = g->players[actor];
+            g->current_player = (uint8_t)actor;
+            erase_first(P.hand, e.tile);
+            P.discards.push_back(e.tile);
+            g->last_discard = std::make_pair((uint8_t)actor, e.tile);
+            g->drawn_tile = -1;
+            if (P.riichi_stage) { P.riichi_declared = true; P.riichi_stage = false; }
+            apply_claims(g, actor, e.tile, false);
+            g->needs_tsumo = true;
+            break;
+        }
+        case RMJ_EV_PON:
+        case RMJ_EV_CHI: {  // :157-238 (3P: no kuikae suji for chi, state_3p/event_handler.rs:195-222)
+            PlayerState& P = g->players[actor];
+            g->current_player = (uint8_t)actor;
+            uint8_t c1 = e.consumed[0], c2 = e.consumed[1];
+            erase_first(P.hand, c1);
+            erase_first(P.hand, c2);
+            Meld m;
+            m.meld_type = e.type == RMJ_EV_PON ? MT_PON : MT_CHI;
+            m.tiles = {e.tile, c1, c2};
+            m.opened = true;
+            m.from_who = -1;
+            m.called_tile = e.tile;
+            P.melds.push_back(m);
+            g->drawn_tile = -1;
+            g->phase = WAIT_ACT;
+            g->active_players.assign(1, (uint8_t)actor);
+            g->needs_tsumo = false;
+            if (e.type == RMJ_EV_PON || !g->sanma) {
+                P.forbidden_discards.clear();
+                if (g->rule.kuikae_forbidden) {
+                    P.forbidden_discards.push_back(e.tile);
+                    if (e.type == RMJ_EV_CHI) {
+                        int t34 = e.tile / 4;
+                        int a = c1 / 4, b = c2 / 4;
+                        if (a > b) std::swap(a, b);
+                        if (a == t34 + 1 && b == t34 + 2) {
+                            if (t34 % 9 <= 5) P.forbidden_discards.push_back((uint8_t)((t34 + 3) * 4));
+                        } else if (t34 >= 2 && b == t34 - 1 && a == t34 - 2 && t34 % 9 >= 3) {
+                            P.forbidden_discards.push_back((uint8_t)((t34 - 3) * 4));
+                        }
+                    }
+                }
+            }
+            break;
+        }
+        case RMJ_EV_DAIMINKAN: {  // :239-268
+            PlayerState& P = g->players[actor];
+            g->current_player = (uint8_t)actor;
+            int n = (e.flags >> 4) & 15;
+            Meld m;
+            m.meld_type = MT_DAIMINKAN;
+            m.tiles.push_back(e.tile);
+            for (int k = 0; k < n && k < 4; k++) m.tiles.push_back(e.consumed[k]);
+            for (int k = 0; k < n && k < 4; k++) erase_first(P.hand, e.consumed[k]);
+            m.opened = true;
+            m.from_who = -1;
+            m.called_tile = e.tile;
+            P.melds.push_back(m);
+            g->phase = WAIT_ACT;
+            g->active_players.assign(1, (uint8_t)actor);
+            g->needs_tsumo = true;
+            break;
+        }
+        case RMJ_EV_ANKAN: {  // :269-289
+            PlayerState& P = g->players[actor];
+            int n = (e.flags >> 4) & 15;
+            Meld m;
+            m.meld_type = MT_ANKAN;
+            for (int k = 0; k < n && k < 4; k++) {
+                m.tiles.push_back(e.consumed[k]);
+                erase_first(P.hand, e.consumed[k]);
+            }
+            m.opened = false;
+            m.from_who = -1;
+            m.called_tile = -1;
+            P.melds.push_back(m);
+            g->current_player = (uint8_t)actor;
+            g->phase = WAIT_ACT;
+            g->active_players.assign(1, (uint8_t)actor);
+            g->needs_tsumo = true;
+            break;
+        }
+        case RMJ_EV_KAKAN: {  // :290-305
+            PlayerState& P = g->players[actor];
+            erase_first(P.hand, e.tile);
+            for (auto& m : P.melds)
+                if (m.meld_type == MT_PON && m.tiles[0] / 4 == e.tile / 4) {
+                    m.meld_type = MT_KAKAN;
+                    m.tiles.push_back(e.tile);
+                    break;
+                }
+            g->current_player = (uint8_t)actor;
+            g->phase = WAIT_ACT;
+            g->active_players.assign(1, (uint8_t)actor);
+            g->needs_tsumo = true;
+            break;
+        }
+        case RMJ_EV_REACH: g->players[actor].riichi_stage = true; break;  // :306-310
+        case RMJ_EV_REACH_ACCEPTED:                                        // :311-315
+            g->players[actor].riichi_declared = true;
+            g->riichi_sticks += 1;
+            g->players[actor].score -= 1000;
+            break;
+        case RMJ_EV_DORA: g->wall.dora_indicators.push_back(e.tile); break;  // :316-319
+        case RMJ_EV_KITA: {  // 4P: ignored (:320-322); 3P: state_3p/event_handler.rs:308-357
+            if (!g->sanma) break;
+            PlayerState& P = g->players[actor];
+            int idx = -1;
+            for (size_t i = 0; i < P.hand.size(); i++)
+                if (P.hand[i] / 4 == 30) { idx = (int)i; break; }
+            g->current_player = (uint8_t)actor;
+            g->current_claims.clear();
+            g->active_players.clear();
+            if (idx >= 0) {
+                uint8_t tile = P.hand[idx];
+                P.hand.erase(P.hand.begin() + idx);
+                P.kita_tiles.push_back(tile);
+                apply_claims(g, actor, tile, true);
+            } else {
+                g->phase = WAIT_ACT;
+                g->current_player = 0xFF;
+            }
+            g->needs_tsumo = true;
+            break;
+        }
+        case RMJ_EV_HORA:
+        case RMJ_EV_RYUKYOKU:
+        case RMJ_EV_END_KYOKU: g->is_done = true; break;  // :323-325
+        default: break;
+    }
+}
+
 void orc_tid_to_mjai(uint8_t tid, char* buf) { std::strcpy(buf, tid_to_mjai(tid).c_str()); }
 
 // ---------------------------------------------------------------- game
@@ -257,8 +494,9 @@ void orc_game_peek(void* gp, RmjStateView* v) {
         q.n_discards = (uint8_t)P.discards.size();
         for (size_t i = 0; i < P.discards.size() && i < RMJ_MAX_DISCARDS; i++) {
             q.discards[i] = P.discards[i];
-            if (P.discard_from_hand[i]) q.discard_from_hand_bits |= 1u << i;
-            if (P.discard_is_riichi[i]) q.discard_is_riichi_bits |= 1u << i;
+            // (apply_mjai_event pushes to `discards` only: the flag vectors may be shorter)
+            if (i < P.discard_from_hand.size() && P.discard_from_hand[i]) q.discard_from_hand_bits |= 1u << i;
+            if (i < P.discard_is_riichi.size() && P.discard_is_riichi[i]) q.discard_is_riichi_bits |= 1u << i;
         }
         q.riichi_declaration_index = (int8_t)P.riichi_declaration_index;
         q.score = P.score;

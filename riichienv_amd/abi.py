@@ -85,6 +85,92 @@ class Event(C.Structure):
                 ("ura", C.c_uint8 * 5), ("pad", C.c_uint8)]
 
 
+# RMJ_EV_* (include/riichi_mi355x.h)
+EV_NONE, EV_START_GAME, EV_START_KYOKU, EV_TSUMO, EV_DAHAI, EV_REACH, EV_REACH_ACCEPTED, EV_CHI, EV_PON, EV_DAIMINKAN, \
+    EV_ANKAN, EV_KAKAN, EV_DORA, EV_HORA, EV_RYUKYOKU, EV_END_KYOKU, EV_END_GAME, EV_KITA, EV_TEHAI = range(19)
+EVENT_SLOTS = 3  # records per game and call of rmj_apply_events (start_kyoku = START_KYOKU + 2 x TEHAI)
+_HONORS = ["E", "S", "W", "N", "P", "F", "C"]
+
+
+def mjai_to_tid(s: str) -> int:
+    """parser.rs:336-385 mjai_to_tid: one id per tile name (copy 0; plain 5 = copy 1, red 5 = copy 0).  The reference
+    maps an unparsable string (e.g. the masked "?") to tile 0 (parse_mjai_tile, event_handler.rs:8-10); masked streams
+    are outside this build's ingestion scope, so that case raises."""
+    if s in _HONORS:
+        return 108 + _HONORS.index(s) * 4
+    if s in ("5mr", "5pr", "5sr"):
+        return {"5mr": 16, "5pr": 52, "5sr": 88}[s]
+    if len(s) >= 2 and s[0].isdigit() and s[1] in "mpsz":
+        num, suit = int(s[0]), s[1]
+        if suit == "z":
+            if 1 <= num <= 7:
+                return 108 + (num - 1) * 4
+        else:
+            si = "mps".index(suit)
+            if num == 0:
+                return si * 36 + 16
+            if 1 <= num <= 9:
+                base = si * 36 + (num - 1) * 4
+                return base + 1 if num == 5 else base
+    raise ValueError(f"cannot map MJAI tile {s!r} (masked or malformed tiles are not supported by rmj_apply_events)")
+
+
+def event_records_from_mjai(ev: dict, num_players: int = 4):
+    """MJAI event dict (replay/mjai_replay.rs MjaiEvent) -> up to EVENT_SLOTS binary records for rmj_apply_events /
+    the oracle.  Unknown event types map to a NONE record (MjaiEvent::Other: no state change)."""
+    recs = (Event * EVENT_SLOTS)()
+    ty = ev.get("type")
+    e = recs[0]
+    actor = int(ev.get("actor", 0) or 0)
+    simple = {"start_game": EV_START_GAME, "reach": EV_REACH, "reach_accepted": EV_REACH_ACCEPTED, "hora": EV_HORA,
+              "ryukyoku": EV_RYUKYOKU, "end_kyoku": EV_END_KYOKU, "end_game": EV_END_GAME, "kita": EV_KITA}
+    if ty in simple:
+        e.type, e.actor = simple[ty], actor
+    elif ty == "start_kyoku":
+        e.type = EV_START_KYOKU
+        e.actor = int(ev["oya"])
+        e.target = int(ev["kyoku"])
+        e.tile = mjai_to_tid(ev["dora_marker"])
+        kyotaku = int(ev.get("kyoutaku", ev.get("kyotaku", 0)))
+        e.consumed[0] = "ESWN".index(ev["bakaze"]) if ev["bakaze"] in "ESWN" else 0
+        e.consumed[1] = int(ev["honba"])
+        e.consumed[2], e.consumed[3] = kyotaku & 0xFF, (kyotaku >> 8) & 0xFF
+        for i, sc in enumerate(ev["scores"][:4]):
+            e.deltas[i] = int(sc)
+        tehais = ev["tehais"]
+        for half in range(2):
+            t = recs[1 + half]
+            t.type, t.actor = EV_TEHAI, half
+            payload = []
+            for q in range(2):
+                seat = 2 * half + q
+                hand = [mjai_to_tid(x) for x in tehais[seat]] if seat < min(num_players, len(tehais)) else [0] * 13
+                if len(hand) != 13:
+                    raise ValueError("start_kyoku: every tehai must hold 13 tiles")
+                payload += hand
+            C.memmove(C.addressof(t) + 4, bytes(payload), 26)
+    elif ty in ("tsumo", "dahai", "kakan"):
+        e.type = {"tsumo": EV_TSUMO, "dahai": EV_DAHAI, "kakan": EV_KAKAN}[ty]
+        e.actor, e.tile = actor, mjai_to_tid(ev["pai"])
+        if ty == "dahai":
+            e.flags = 1 if ev.get("tsumogiri") else 0
+    elif ty in ("pon", "chi", "daiminkan", "kan", "ankan"):
+        e.type = {"pon": EV_PON, "chi": EV_CHI, "daiminkan": EV_DAIMINKAN, "kan": EV_DAIMINKAN, "ankan": EV_ANKAN}[ty]
+        e.actor = actor
+        e.target = int(ev.get("target", 0) or 0)
+        if ty != "ankan":
+            e.tile = mjai_to_tid(ev["pai"])
+        cons = [mjai_to_tid(x) for x in ev["consumed"]][:4]
+        for i, c in enumerate(cons):
+            e.consumed[i] = c
+        e.flags = (len(cons) << 4) & 0xFF
+    elif ty == "dora":
+        e.type, e.tile = EV_DORA, mjai_to_tid(ev["dora_marker"])
+    else:
+        e.type = EV_NONE
+    return recs
+
+
 class HandCase(C.Structure):
     _fields_ = [("n_tiles", C.c_uint8), ("tiles", C.c_uint8 * 14), ("n_melds", C.c_uint8), ("melds", MeldView * 4),
                 ("win_tile", C.c_uint8), ("n_dora", C.c_uint8), ("dora", C.c_uint8 * 5), ("n_ura", C.c_uint8),

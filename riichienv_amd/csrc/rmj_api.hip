@@ -1138,6 +1138,22 @@ int rmj_best_ukeire(int device, const uint8_t* counts, const uint8_t* visible, u
     return run_ukeire(device, counts, visible, n, sanma, 1, out);
 }
 
+// ---- MJAI event ingestion (row N1) --------------------------------------------------------------
+int rmj_apply_events(rmj_handle h, const RmjEvent* events) {
+    if (!h || !events) return fail(RMJ_ERR_ARG, "null argument");
+    HIPCHK(hipSetDevice(h->cfg.device));
+    const size_t bytes = (size_t)h->cfg.n_games * 3 * sizeof(RmjEvent);
+    RmjEvent* d_ev = nullptr;
+    HIPCHK(hipMalloc(&d_ev, bytes));
+    HIPCHK(hipMemcpyAsync(d_ev, events, bytes, hipMemcpyHostToDevice, h->stream));
+    if (h->cfg.game_mode >= 3) hipLaunchKernelGGL(rmj3::k_apply_event, game_grid(h->cfg.n_games), dim3(256), 0, h->stream, (const Env*)h->d_env, (const RmjEvent*)d_ev);
+    else hipLaunchKernelGGL(rmj4::k_apply_event, game_grid(h->cfg.n_games), dim3(256), 0, h->stream, (const Env*)h->d_env, (const RmjEvent*)d_ev);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(h->stream));
+    hipFree(d_ev);
+    return RMJ_OK;
+}
+
 // ---- measurement -----------------------------------------------------------------------------
 int rmj_bench_rollout(rmj_handle h, uint64_t policy_seed, uint32_t warmup, uint32_t steps, RmjBenchResult* out) {
     if (!h || !out) return fail(RMJ_ERR_ARG, "null argument");

@@ -125,6 +125,23 @@ __global__ __launch_bounds__(256, 4) void k_reset(const Env* __restrict__ Ep, Re
     store_state(S, E.core + g, lane);
 }
 
+// rmj_apply_events: one MJAI event (up to three records) per game; games whose first record is NONE are left alone
+__global__ __launch_bounds__(256, 4) void k_apply_event(const Env* __restrict__ Ep, const RmjEvent* __restrict__ ev) {
+    const Env& E = *Ep;
+    __shared__ BlockShared sh;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const uint32_t g = blockIdx.x * WPB + wave;
+    if (g >= E.n_games) return;
+    const RmjEvent* mine = ev + (size_t)g * 3;
+    if (mine[0].type == RMJ_EV_NONE || mine[0].type == RMJ_EV_END_GAME || mine[0].type == RMJ_EV_TEHAI) return;
+    GState& S = sh.st[wave];
+    load_state(S, E.core + g, lane);
+    Ctx c{S, E, sh.x[wave], g, lane, E.wall + (size_t)g * RMJ_WALL_STRIDE, E.legal + (size_t)g * 4 * RMJ_MAX_LEGAL};
+    apply_event(c, mine);
+    finalize_outputs<false>(c, true);
+    store_state(S, E.core + g, lane);
+}
+
 // recompute observation outputs of one game after rmj_poke_state
 __global__ __launch_bounds__(64, 4) void k_refresh(const Env* __restrict__ Ep, uint32_t g) {
     const Env& E = *Ep;

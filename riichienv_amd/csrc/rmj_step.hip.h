@@ -255,17 +255,15 @@ __device__ __forceinline__ void put_legal(Ctx& c, int seat, int pos, uint64_t a)
 }
 
 // legal_actions.rs:254-508.  Writes the claim list (+Pass) for seat i; returns true iff seat i has claims.
-__device__ __forceinline__ bool gen_claims(Ctx& c, int i, int pid, int tile) {
+__device__ __forceinline__ bool gen_claims(Ctx& c, int i, int pid, int tile, bool mark_missed = true) {
     GState& S = c.S;
     PState& P = S.p[i];
     const int lane = c.lane;
     const int tt = tile >> 2;
     const int hl = P.hand_len;
     int n = 0;
-    PROF(c.X, lane, 19);
     uint64_t W = seat_waits(c, i);
     c.X.wout[i] = W;
-    PROF(c.X, lane, 16);
     bool in_discards = (P.discard_type_mask >> tt) & 1ull;
     bool in_missed = (P.flags & PF_MISSED_DOUJUN) || ((P.flags & PF_RIICHI_DECLARED) && (P.flags & PF_MISSED_RIICHI));
     if (!in_discards && !in_missed) {
@@ -277,12 +275,11 @@ __device__ __forceinline__ bool gen_claims(Ctx& c, int i, int pid, int tile) {
             if (r.is_win) {
                 put_legal(c, i, n++, mk_action(RMJ_RON, tile, 0));
                 S.ron_offer_mask |= (uint8_t)(1u << i);
-            } else if (r.shape) {
+            } else if (r.shape && mark_missed) {
                 P.flags |= PF_MISSED_DOUJUN;  // state/mod.rs:1386-1389
             }
         }
     }
-    PROF(c.X, lane, 17);
     const bool riichi = P.flags & PF_RIICHI_DECLARED;
     const bool kuikae = rule(c, RMJ_RULE_KUIKAE_FORBIDDEN);
     uint8_t ht = lane < hl ? P.hand[lane] : 0xFF;
@@ -314,7 +311,6 @@ __device__ __forceinline__ bool gen_claims(Ctx& c, int i, int pid, int tile) {
             put_legal(c, i, n++, mk_action(RMJ_DAIMINKAN, tile, 3, P.hand[i0], P.hand[i1], P.hand[i2]));
         }
     }
-    PROF(c.X, lane, 18);
     // Chi: lane = pattern*16 + a*4 + b
     bool shimocha = !KSANMA && i == ((pid + 1) & 3);  // no Chi in 3P (state_3p/legal_actions.rs:386)
     if (!riichi && S.drawable_count > 0 && shimocha && hl >= 3 && tt < 27) {
@@ -1754,6 +1750,257 @@ __device__ __forceinline__ void step_game(Ctx& c, const uint64_t mine, bool trus
     }
 }
 
+// ---------------------------------------------------------------- MJAI event ingestion (row N1)
+// apply_mjai_event: state/event_handler.rs:18-330 (4P), state_3p/event_handler.rs:18-362 (3P).  `ev` = up to three
+// binary records of one game (a start_kyoku is START_KYOKU + two TEHAI records, like the emitted log).  This is the
+// reference's replay state machine, NOT step(): no validation, no wall (a zero placeholder), melds keep from_who = -1,
+// discards carry no tsumogiri/riichi flags, is_first_turn is never cleared, scoring never happens.
+// Deviation: meld tiles are stored sorted (the reference keeps [called, consumed...] order on this path).
+__device__ inline void apply_remove_first(Ctx& c, PState& P, int tile) {
+    int idx = hand_find(c, P, tile);
+    if (idx >= 0) hand_remove_at(c, P, idx);
+}
+// current_claims of a discard / kita (event_handler.rs:129-155, state_3p/event_handler.rs:320-352)
+__device__ inline void apply_claims(Ctx& c, int actor, int tile, bool ron_only) {
+    GState& S = c.S;
+    uint32_t claim_active = 0;
+    S.ron_offer_mask = 0;
+    for (int i = 0; i < 4; i++) {
+        c.X.nl[i] = 0;
+        c.X.wout[i] = 0;
+        S.stale_n[i] = 0;
+    }
+    for (int i = 0; i < KNP; i++) {
+        if (i == actor) continue;
+        bool any = gen_claims(c, i, actor, tile, false);  // the `missed` result is dropped on this path
+        if (ron_only) {  // kita: only Ron survives the filter (no Pass either)
+            wave_sync();
+            any = any && a_type(c.X.legal[i][0]) == RMJ_RON;
+            c.X.nl[i] = any ? 1 : 0;
+            S.stale_n[i] = (uint8_t)(any ? 1 : 0);
+        }
+        if (any) claim_active |= 1u << i;
+    }
+    if (claim_active) {
+        S.phase = RMJ_WAIT_RESPONSE;
+        S.active_mask = (uint8_t)claim_active;
+    } else {
+        S.phase = RMJ_WAIT_ACT;
+        S.active_mask = 0;
+        S.current_player = 0xFF;
+    }
+}
+__device__ inline void apply_event(Ctx& c, const RmjEvent* ev) {
+    GState& S = c.S;
+    const int lane = c.lane;
+    const uint32_t ty = ev[0].type;
+    const int actor = ev[0].actor & 3;
+    const int tile = ev[0].tile;
+    PState& P = S.p[actor];
+    switch (ty) {
+        case RMJ_EV_START_GAME:  // env.rs:56-72 + event_handler.rs:20-25
+            S.ev_count = 0;
+            S.current_player = 0xFF;
+            S.active_mask = 0;
+            break;
+        case RMJ_EV_START_KYOKU: {  // event_handler.rs:26-103
+            S.honba = ev[0].consumed[1];
+            S.riichi_sticks = (uint32_t)ev[0].consumed[2] | ((uint32_t)ev[0].consumed[3] << 8);
+            S.round_wind = ev[0].consumed[0] & 3;
+            S.oya = ev[0].actor;
+            S.kyoku_idx = ev[0].target ? (uint8_t)(ev[0].target - 1) : 0;
+            S.current_player = 0xFF;
+            S.turn_count = 0;
+            S.is_done = 0;
+            S.needs_tsumo = 1;
+            S.phase = RMJ_WAIT_ACT;
+            S.active_mask = 0;
+            S.last_discard_pid = 0xFF; S.last_discard_tile = 0;
+            S.ron_offer_mask = 0;
+            S.pending_kan_pid = 0xFF; S.pending_kan_action = 0;
+            S.is_rinshan = 0;
+            S.is_first_turn = 1;
+            S.riichi_pending = 0xFF;
+            S.drawn_tile = 0xFF;
+            S.last_error_pid = 0xFF;
+            const int total = KSANMA ? 108 : 136;
+            S.wall_total = (uint8_t)total;
+            S.live_end = (uint8_t)(total - 13 * KNP);
+            S.rinshan_count = 0;
+            S.pending_kan_dora = 0;
+            S.drawable_count = (uint8_t)(S.live_end - 14);
+            S.n_dora = 1;
+            S.dora[0] = (uint8_t)tile;
+            for (int i = lane; i < RMJ_WALL_STRIDE / 4; i += 64) reinterpret_cast<uint32_t*>(c.W)[i] = 0u;  // placeholder wall
+            for (int p = 0; p < 4; p++) {  // PlayerState::reset_round, state/player.rs:66-86
+                PState& Q = S.p[p];
+                Q.hand_len = 0; Q.n_melds = 0; Q.n_discards = 0;
+                Q.flags = PF_NAGASHI;
+                Q.pao37 = 0xFF; Q.pao50 = 0xFF;
+                Q.n_forbidden = 0;
+                Q.riichi_decl_idx = 0xFF; Q.riichi_sutehai = 0xFF; Q.last_tedashi = 0xFF;
+                Q.score_delta = 0;
+                Q.discard_from_hand_bits = 0; Q.discard_is_riichi_bits = 0;
+                Q.discard_type_mask = 0;
+                Q.n_kita = 0;
+                S.stale_n[p] = 0;
+                if (p < KNP) Q.score = ev[0].deltas[p];
+            }
+            wave_sync();
+            if (lane < 52) {  // lane = 13*seat + slot; records 1/2 carry seats 0,1 / 2,3 (26 payload bytes each)
+                const int seat = lane / 13, slot = lane - 13 * seat;
+                const uint8_t* pl = reinterpret_cast<const uint8_t*>(&ev[1 + (seat >> 1)]) + 4;
+                if (seat < KNP) S.p[seat].hand[slot] = pl[13 * (seat & 1) + slot];
+            }
+            wave_sync();
+            for (int p = 0; p < KNP; p++) {
+                S.p[p].hand_len = 13;
+                sort_hand(c, S.p[p], 13);
+            }
+            break;
+        }
+        case RMJ_EV_TSUMO:  // :104-118 (the whole hand is re-sorted: the drawn tile does not stay last on this path)
+            S.current_player = (uint8_t)actor;
+            S.drawn_tile = (uint8_t)tile;
+            waits_invalidate(P);
+            if (P.hand_len < 14) P.hand[P.hand_len++] = (uint8_t)tile;
+            wave_sync();
+            sort_hand(c, P, P.hand_len);
+            P.n_forbidden = 0;
+            if (S.live_end > S.rinshan_count) {
+                S.live_end -= 1;
+                if (S.drawable_count > 0) S.drawable_count -= 1;
+            }
+            S.phase = RMJ_WAIT_ACT;
+            S.active_mask = (uint8_t)(1u << actor);
+            S.needs_tsumo = 0;
+            break;
+        case RMJ_EV_DAHAI: {  // :119-156
+            S.current_player = (uint8_t)actor;
+            apply_remove_first(c, P, tile);
+            waits_invalidate(P);
+            if (P.n_discards < RMJ_MAX_DISCARDS) P.discards[P.n_discards++] = (uint8_t)tile;
+            P.discard_type_mask |= 1ull << (tile >> 2);
+            S.last_discard_pid = (uint8_t)actor;
+            S.last_discard_tile = (uint8_t)tile;
+            S.drawn_tile = 0xFF;
+            if (P.flags & PF_RIICHI_STAGE) P.flags = (uint8_t)((P.flags | PF_RIICHI_DECLARED) & ~PF_RIICHI_STAGE);
+            wave_sync();
+            apply_claims(c, actor, tile, false);
+            S.needs_tsumo = 1;
+            break;
+        }
+        case RMJ_EV_PON:
+        case RMJ_EV_CHI: {  // :157-238 ; 3P chi: no kuikae bookkeeping (state_3p/event_handler.rs:195-222)
+            S.current_player = (uint8_t)actor;
+            const int c1 = ev[0].consumed[0], c2 = ev[0].consumed[1];
+            apply_remove_first(c, P, c1);
+            apply_remove_first(c, P, c2);
+            waits_invalidate(P);
+            push_meld(P, ty == RMJ_EV_PON ? RMJ_MELD_PON : RMJ_MELD_CHI, (uint32_t)tile, (uint32_t)c1, (uint32_t)c2, 0, 3, 0xFF, tile);
+            S.drawn_tile = 0xFF;
+            S.phase = RMJ_WAIT_ACT;
+            S.active_mask = (uint8_t)(1u << actor);
+            S.needs_tsumo = 0;
+            if (ty == RMJ_EV_PON || !KSANMA) {
+                P.n_forbidden = 0;
+                if (rule(c, RMJ_RULE_KUIKAE_FORBIDDEN)) {
+                    P.forbidden[0] = (uint8_t)tile;
+                    P.n_forbidden = 1;
+                    if (ty == RMJ_EV_CHI) {
+                        int t34 = tile >> 2, a = c1 >> 2, b = c2 >> 2;
+                        int lo = min(a, b), hi = max(a, b);
+                        if (lo == t34 + 1 && hi == t34 + 2) {
+                            if (t34 % 9 <= 5) { P.forbidden[1] = (uint8_t)((t34 + 3) * 4); P.n_forbidden = 2; }
+                        } else if (t34 >= 2 && hi == t34 - 1 && lo == t34 - 2 && t34 % 9 >= 3) {
+                            P.forbidden[1] = (uint8_t)((t34 - 3) * 4);
+                            P.n_forbidden = 2;
+                        }
+                    }
+                }
+            }
+            break;
+        }
+        case RMJ_EV_DAIMINKAN: {  // :239-268
+            S.current_player = (uint8_t)actor;
+            const int n = (ev[0].flags >> 4) & 15;
+            for (int k = 0; k < n && k < 3; k++) apply_remove_first(c, P, ev[0].consumed[k]);
+            waits_invalidate(P);
+            push_meld(P, RMJ_MELD_DAIMINKAN, (uint32_t)tile, ev[0].consumed[0], ev[0].consumed[1], ev[0].consumed[2], 4, 0xFF, tile);
+            S.phase = RMJ_WAIT_ACT;
+            S.active_mask = (uint8_t)(1u << actor);
+            S.needs_tsumo = 1;
+            break;
+        }
+        case RMJ_EV_ANKAN: {  // :269-289
+            const int n = (ev[0].flags >> 4) & 15;
+            for (int k = 0; k < n && k < 4; k++) apply_remove_first(c, P, ev[0].consumed[k]);
+            waits_invalidate(P);
+            push_meld(P, RMJ_MELD_ANKAN, ev[0].consumed[0], ev[0].consumed[1], ev[0].consumed[2], ev[0].consumed[3], 4, 0xFF, 0xFF);
+            S.current_player = (uint8_t)actor;
+            S.phase = RMJ_WAIT_ACT;
+            S.active_mask = (uint8_t)(1u << actor);
+            S.needs_tsumo = 1;
+            break;
+        }
+        case RMJ_EV_KAKAN: {  // :290-305
+            apply_remove_first(c, P, tile);
+            waits_invalidate(P);
+            for (int m = 0; m < P.n_melds; m++)
+                if (P.meld_type[m] == RMJ_MELD_PON && (P.meld_tiles[m][0] >> 2) == (tile >> 2)) {
+                    P.meld_type[m] = RMJ_MELD_KAKAN;
+                    uint32_t v[4] = {P.meld_tiles[m][0], P.meld_tiles[m][1], P.meld_tiles[m][2], (uint32_t)tile};
+                    for (int a = 0; a < 4; a++)
+                        for (int b = 0; b < 3; b++)
+                            if (v[b] > v[b + 1]) { uint32_t t = v[b]; v[b] = v[b + 1]; v[b + 1] = t; }
+                    for (int a = 0; a < 4; a++) P.meld_tiles[m][a] = (uint8_t)v[a];
+                    break;
+                }
+            S.current_player = (uint8_t)actor;
+            S.phase = RMJ_WAIT_ACT;
+            S.active_mask = (uint8_t)(1u << actor);
+            S.needs_tsumo = 1;
+            break;
+        }
+        case RMJ_EV_REACH: P.flags |= PF_RIICHI_STAGE; break;  // :306-310
+        case RMJ_EV_REACH_ACCEPTED:                             // :311-315
+            P.flags |= PF_RIICHI_DECLARED;
+            S.riichi_sticks += 1;
+            P.score -= 1000;
+            break;
+        case RMJ_EV_DORA:  // :316-319
+            if (S.n_dora < 5) S.dora[S.n_dora++] = (uint8_t)tile;
+            break;
+        case RMJ_EV_KITA: {  // 4P: ignored; 3P: state_3p/event_handler.rs:308-357
+            if (!KSANMA) break;
+            uint64_t nb = __ballot(lane < P.hand_len && (P.hand[lane] >> 2) == 30);
+            S.current_player = (uint8_t)actor;
+            for (int i = 0; i < 4; i++) { c.X.nl[i] = 0; c.X.wout[i] = 0; S.stale_n[i] = 0; }
+            S.ron_offer_mask = 0;
+            S.active_mask = 0;
+            if (nb) {
+                int idx = __ffsll((long long)nb) - 1;
+                int kt = P.hand[idx];
+                hand_remove_at(c, P, idx);
+                waits_invalidate(P);
+                if (P.n_kita < 4) P.kita[P.n_kita++] = (uint8_t)kt;
+                wave_sync();
+                apply_claims(c, actor, kt, true);
+            } else {
+                S.phase = RMJ_WAIT_ACT;
+                S.current_player = 0xFF;
+            }
+            S.needs_tsumo = 1;
+            break;
+        }
+        case RMJ_EV_HORA:
+        case RMJ_EV_RYUKYOKU:
+        case RMJ_EV_END_KYOKU: S.is_done = 1; break;  // :323-325
+        default: break;
+    }
+    wave_sync();
+}
+
 // After a transition: produce the observation-side outputs for the new state
 // (get_observations(active_players), env.rs:870-871 -> state/mod.rs:189-263; mask: observation/python.rs:98-111)
 template <bool FAST = false>
@@ -1761,6 +2008,9 @@ __device__ __forceinline__ void finalize_outputs(Ctx& c, bool claims_fresh) {
     GState& S = c.S;
     const int lane = c.lane;
     if (S.is_done) {
+        for (int p = 0; p < 4; p++) { c.X.nl[p] = 0; c.X.wout[p] = 0; }
+    } else if (!FAST && S.active_mask == 0) {
+        // nobody to act (only reachable through rmj_apply_events: between a discard nobody can claim and the next tsumo)
         for (int p = 0; p < 4; p++) { c.X.nl[p] = 0; c.X.wout[p] = 0; }
     } else if (S.phase == RMJ_WAIT_ACT) {
         for (int p = 0; p < 4; p++) { c.X.nl[p] = 0; c.X.wout[p] = 0; }

@@ -26,7 +26,7 @@ EXPORTS = [
     "rmj_step_device", "rmj_step_random", "rmj_random_actions", "rmj_get_status", "rmj_get_legal", "rmj_get_mask",
     "rmj_get_waits", "rmj_get_scores", "rmj_get_ranks", "rmj_get_step_counts", "rmj_total_steps", "rmj_peek_state",
     "rmj_poke_state", "rmj_get_event_counts", "rmj_get_events", "rmj_format_event", "rmj_eval_hands",
-    "rmj_agari_counts", "rmj_calculate_score", "rmj_shanten", "rmj_effective_tiles", "rmj_best_ukeire", "rmj_encode", "rmj_encode_device", "rmj_bench_rollout",
+    "rmj_agari_counts", "rmj_calculate_score", "rmj_shanten", "rmj_effective_tiles", "rmj_best_ukeire", "rmj_apply_events", "rmj_encode", "rmj_encode_device", "rmj_bench_rollout",
 ]
 
 
@@ -73,6 +73,7 @@ def load_lib():
     L.rmj_encode_device.argtypes = [vp, C.c_int, vp]
     L.rmj_effective_tiles.argtypes = [C.c_int, vp, C.c_uint32, C.c_int, vp]
     L.rmj_best_ukeire.argtypes = [C.c_int, vp, vp, C.c_uint32, C.c_int, vp]
+    L.rmj_apply_events.argtypes = [vp, vp]
     L.rmj_shanten.argtypes = [C.c_int, vp, C.c_uint32, C.c_int, vp]
     L.rmj_bench_rollout.argtypes = [vp, C.c_uint64, C.c_uint32, C.c_uint32, C.POINTER(abi.BenchResult)]
     _LIB = L
@@ -172,6 +173,19 @@ class VecRiichiEnv:
     def step(self, actions):
         a = np.ascontiguousarray(actions, dtype=np.uint64).reshape(self.n, 4)
         _chk(self.L.rmj_step(self.h, a.ctypes.data))
+
+    def apply_events(self, events):
+        """RiichiEnv.apply_event (env.rs:880-887) for every game: `events[g]` is an MJAI dict, pre-built records
+        (abi.event_records_from_mjai) or None (no event for game g)."""
+        buf = (abi.Event * (abi.EVENT_SLOTS * self.n))()
+        np_ = 3 if self.game_mode >= 3 else 4
+        for g, ev in enumerate(events):
+            if ev is None:
+                continue
+            recs = abi.event_records_from_mjai(ev, np_) if isinstance(ev, dict) else ev
+            C.memmove(C.addressof(buf) + g * abi.EVENT_SLOTS * C.sizeof(abi.Event), C.addressof(recs),
+                      abi.EVENT_SLOTS * C.sizeof(abi.Event))
+        _chk(self.L.rmj_apply_events(self.h, C.addressof(buf)))
 
     def step_random(self, policy_seed, n_steps=1, auto_reset=False):
         _chk(self.L.rmj_step_random(self.h, policy_seed, n_steps, int(auto_reset)))

@@ -242,6 +242,14 @@ int rmj_calculate_score(int device, const uint8_t* han, const uint8_t* fu, const
 int rmj_encode(rmj_handle h, int only_active, float* out);
 int rmj_encode_device(rmj_handle h, int only_active, float* d_out); /* device pointer, asynchronous on the handle's stream */
 
+/* Observation.encode_extended (observation/python.rs:1271-1296): 215 channels = encode() + discard decay (4), shanten
+ * efficiency (16), ankan (4), fuuro (80), action availability (11), discard candidates (5), pass context (3), last
+ * tedashis (9), riichi sutehais (9); observation/encode.rs:293-585, observation_3p/encode.rs:315-615.
+ * out[n][4][215][34] (3P: [n][4][215][27], seat 3 zero). */
+#define RMJ_ENC_EXT_CHANNELS 215
+int rmj_encode_extended(rmj_handle h, int only_active, float* out);
+int rmj_encode_extended_device(rmj_handle h, int only_active, float* d_out); /* device pointer, asynchronous on the handle's stream */
+
 /* shanten.rs:244-261 calculate_shanten / :470-484 calculate_shanten_3p over raw 34-histograms
  * (len_div3 = tile count / 3; -1 = complete hand).  Tables are generated at first use, on the host. */
 int rmj_shanten(int device, const uint8_t* counts /*[n][34]*/, uint32_t n, int sanma, int8_t* out /*[n]*/);

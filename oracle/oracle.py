@@ -54,6 +54,7 @@ def lib():
         L.orc_find_divisions.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
         L.orc_action_encode.argtypes = [C.c_uint64]
         L.orc_game_encode.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
+        L.orc_game_encode_extended.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
         L.orc_shanten.argtypes = [C.c_void_p, C.c_uint32, C.c_int, C.c_void_p]
         L.orc_effective_tiles.argtypes = [C.c_void_p, C.c_uint32, C.c_int, C.c_void_p]
         L.orc_best_ukeire.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_int, C.c_void_p]
@@ -199,6 +200,11 @@ class Game:
     def encode(self, pid, sanma=False):
         out = np.zeros((74, 27 if sanma else 34), np.float32)
         self.L.orc_game_encode(self.h, pid, out.ctypes.data)
+        return out
+
+    def encode_extended(self, pid):
+        out = np.zeros((215, 27 if self.sanma else 34), np.float32)
+        self.L.orc_game_encode_extended(self.h, pid, out.ctypes.data)
         return out
 
     def apply_event(self, ev):

@@ -3,6 +3,8 @@
 // riichi_state.hpp.  Uses the POD views of include/riichi_mi355x.h so tests can
 // compare the oracle and the HIP path byte for byte.
 #include <chrono>
+#include <cmath>
+#include <algorithm>
 #include <cstdio>
 #include <cstring>
 #include <thread>
@@ -749,6 +751,152 @@ void orc_game_encode(void* gp, int pid, float* arr) {
         for (size_t i = 0; i < 2 && 4 + i < e.size(); i++) set1(68 + (int)i, e[e.size() - 1 - (4 + i)] / 4);
     }
     // ch 70-73: tsumogiri_flags is never filled (observation/mod.rs:105) -> zeros
+}
+
+// Observation.encode_extended(): 215 channels = encode() + the nine blocks of observation/encode.rs:293-585 (4P, 34
+// columns) / observation_3p/encode.rs:315-615 (3P, 27 compact columns), python.rs:1271-1296.
+// Snapshot quirks restated: Observation.last_discard receives the DISCARDER'S SEAT, not the tile
+// (state/mod.rs:252 destructures (pid, tile) as (tile, _pid)); dora membership compares full 136-ids with the copy-0
+// id of the next tile; riichi_sutehais is only written on an unreachable branch (state/mod.rs:466).
+void orc_game_encode_extended(void* gp, int pid, float* arr) {
+    GameState* g = (GameState*)gp;
+    const bool sanma = g->sanma;
+    const int W = sanma ? 27 : 34, NP = g->NP;
+    std::memset(arr, 0, sizeof(float) * 215 * W);
+    orc_game_encode(gp, pid, arr);
+    auto col = [&](int t34) -> int { return sanma ? (t34 == 0 ? 0 : (t34 >= 8 && t34 < 34 ? t34 - 7 : -1)) : (t34 < 34 ? t34 : -1); };
+    auto bc = [&](int ch, float v) {
+        for (int k = 0; k < W; k++) arr[ch * W + k] = v;
+    };
+    auto next = [&](uint8_t di) { return sanma ? obs_get_next_tile_sanma(di) : obs_get_next_tile(di); };
+    const PlayerState& P = g->players[pid];
+    std::vector<int> rel;
+    for (int i = 0; i < NP; i++) rel.push_back((pid + i) % NP);
+    // 74..77 discard history decay (encode.rs:295-313)
+    for (int c = 0; c < NP; c++) {
+        const auto& d = g->players[rel[c]].discards;
+        for (size_t turn = 0; turn < d.size(); turn++) {
+            int k = col(d[turn] / 4);
+            if (k < 0) continue;
+            float age = (float)(d.size() - 1 - turn);
+            arr[(74 + c) * W + k] += std::exp(-0.2f * age);
+        }
+    }
+    // 78..93 shanten efficiency (encode.rs:317-350)
+    uint8_t hc[34] = {0}, vis[34] = {0};
+    for (uint8_t t : P.hand) hc[t / 4]++;
+    auto see = [&](uint8_t t) { if (t / 4 < 34 && vis[t / 4] < 255) vis[t / 4]++; };
+    for (int q = 0; q < NP; q++) {
+        for (uint8_t t : g->players[q].discards) see(t);
+        for (auto& m : g->players[q].melds)
+            for (uint8_t t : m.tiles) see(t);
+    }
+    for (uint8_t t : g->wall.dora_indicators) see(t);
+    const int cur_sh = shanten_of(hc, sanma);
+    for (int c = 0; c < NP; c++) {
+        int base = 78 + c * 4;
+        if (rel[c] == pid) {
+            uint32_t eff = effective_tiles_with_discard(hc, sanma);  // (a 3n hand would panic in the reference)
+            uint32_t uke = best_ukeire(hc, vis, sanma);
+            bc(base, std::max((float)cur_sh, 0.0f) / 8.0f);
+            bc(base + 1, (float)eff / (sanma ? 27.0f : 34.0f));
+            bc(base + 2, (float)uke / 80.0f);
+        } else {
+            bc(base, 0.5f); bc(base + 1, 0.5f); bc(base + 2, 0.5f);
+        }
+        bc(base + 3, std::min((float)g->players[rel[c]].discards.size() / 18.0f, 1.0f));
+    }
+    // 94..97 ankan overview (encode.rs:354-368), 98..177 fuuro overview (:372-396)
+    for (int c = 0; c < NP; c++) {
+        const auto& ms = g->players[rel[c]].melds;
+        for (size_t mi = 0; mi < ms.size(); mi++) {
+            const Meld& m = ms[mi];
+            if (m.meld_type == MT_ANKAN && !m.tiles.empty()) {
+                int k = col(m.tiles[0] / 4);
+                if (k >= 0) arr[(94 + c) * W + k] = 1.0f;
+            }
+            if (mi >= 4) continue;
+            for (size_t sl = 0; sl < m.tiles.size() && sl < 4; sl++) {
+                uint8_t t = m.tiles[sl];
+                int k = col(t / 4);
+                if (k >= 0) arr[(98 + c * 20 + (int)mi * 5 + (int)sl) * W + k] = 1.0f;
+                if ((t == 16 || t == 52 || t == 88) && k >= 0) arr[(98 + c * 20 + (int)mi * 5 + 4) * W + k] = 1.0f;
+            }
+        }
+    }
+    // 178..188 action availability (encode.rs:399-429) over the observation's legal actions (state/mod.rs:199-208)
+    std::vector<Action> legal;
+    if (!g->is_done) {
+        bool in_act = false;
+        for (uint8_t a : g->active_players) in_act = in_act || a == pid;
+        if ((g->phase == WAIT_ACT && g->current_player == pid) || (g->phase == WAIT_RESPONSE && in_act))
+            legal = g->_get_legal_actions_internal((uint8_t)pid);
+    }
+    for (const Action& a : legal) {
+        switch (a.type) {
+            case AT_RIICHI: bc(178, 1.0f); break;
+            case AT_CHI:
+                if (a.consume.size() == 2) {
+                    int t0 = a.consume[0] / 4, t1 = a.consume[1] / 4, diff = std::abs(t1 - t0);
+                    if (diff == 1) bc(t0 < t1 ? 179 : 181, 1.0f);
+                    else if (diff == 2) bc(180, 1.0f);
+                }
+                break;
+            case AT_PON: bc(182, 1.0f); break;
+            case AT_DAIMINKAN: bc(183, 1.0f); break;
+            case AT_ANKAN: bc(184, 1.0f); break;
+            case AT_KAKAN: bc(185, 1.0f); break;
+            case AT_TSUMO:
+            case AT_RON: bc(186, 1.0f); break;
+            case AT_KYUSHU: bc(187, 1.0f); break;
+            case AT_PASS: bc(188, 1.0f); break;
+            default: break;
+        }
+    }
+    // 189..193 discard candidates (encode.rs:433-475)
+    {
+        const size_t n = P.hand.size();
+        bc(189, (float)n / 34.0f);
+        int keep = 0, inc = 0;
+        uint8_t t[34];
+        std::memcpy(t, hc, 34);
+        for (uint8_t tile : P.hand) {
+            t[tile / 4]--;
+            int ns = shanten_of(t, sanma);
+            t[tile / 4]++;
+            if (ns == cur_sh) keep++;
+            else if (ns > cur_sh) inc++;
+        }
+        if (n) {
+            bc(190, (float)keep / (float)n);
+            bc(191, (float)inc / (float)n);
+        }
+        bc(192, cur_sh == -1 ? 1.0f : 0.0f);
+        bc(193, P.riichi_declared ? 1.0f : 0.0f);
+    }
+    // 194..196 pass context (:479-509), 197..205 last tedashis (:513-546), 206..214 riichi sutehais (:550-585)
+    std::vector<uint8_t> dora_tiles;
+    for (uint8_t di : g->wall.dora_indicators) dora_tiles.push_back(next(di));
+    auto is_dora = [&](uint8_t tile) { return std::find(dora_tiles.begin(), dora_tiles.end(), tile) != dora_tiles.end(); };
+    auto tile_feats = [&](int ch, int tile) {
+        int t34 = tile / 4;
+        if (sanma) {
+            int k = col(t34);
+            if (k >= 0) bc(ch, (float)k / 26.0f);
+        } else {
+            bc(ch, (float)t34 / 33.0f);
+        }
+        bc(ch + 1, (tile == 16 || tile == 52 || tile == 88) ? 1.0f : 0.0f);
+        bc(ch + 2, is_dora((uint8_t)tile) ? 1.0f : 0.0f);
+    };
+    if (g->last_discard) tile_feats(194, g->last_discard->first);  // the seat number, see the header comment
+    int opp = 0;
+    for (int q = 0; q < NP; q++) {
+        if (q == pid) continue;
+        if (g->last_tedashis[q] >= 0) tile_feats(197 + opp * 3, g->last_tedashis[q]);
+        if (g->riichi_sutehais[q] >= 0) tile_feats(206 + opp * 3, g->riichi_sutehais[q]);
+        opp++;
+    }
 }
 
 uint32_t orc_game_log_len(void* gp, int seat) {

@@ -285,6 +285,36 @@ __global__ __launch_bounds__(256) void k_encode(Env E, int only_active, float* _
     for (int i = lane; i < FL / 2; i += 64) dst[i] = src[i];
 }
 
+// Observation.encode_extended (215 channels): one wave (= one block) per (game, seat); see encode_ext_seat
+template <bool SANMA>
+__global__ __launch_bounds__(64) void k_encode_ext(Env E, int only_active, const float* __restrict__ decay, float* __restrict__ out) {
+    constexpr int W = SANMA ? ENC_W3 : ENC_W4;
+    constexpr int FL = ENC_EXT_CH * W;
+    __shared__ GState st;
+    __shared__ float buf[FL];
+    const int lane = threadIdx.x & 63;
+    const uint32_t g = blockIdx.x >> 2;
+    const int seat = blockIdx.x & 3;
+    if (lane < (int)(sizeof(GState) / 16)) reinterpret_cast<uint4*>(&st)[lane] = reinterpret_cast<const uint4*>(E.core + g)[lane];
+    wave_sync();
+    const GState& S = st;
+    const bool want = (seat < (SANMA ? 3 : 4)) && (!only_active || (((S.active_mask >> seat) & 1u) && !S.is_done));
+    if (want) {
+        encode_seat<SANMA>(S, seat, buf, lane);
+        const int n_legal = (((S.active_mask >> seat) & 1u) && !S.is_done) ? (int)E.nlegal[(size_t)g * 4 + seat] : 0;
+        encode_ext_seat<SANMA>(S, seat, buf, lane, E.sh, decay, E.legal + ((size_t)g * 4 + seat) * RMJ_MAX_LEGAL, n_legal);
+    } else {
+        for (int i = lane; i < FL; i += 64) buf[i] = 0.0f;
+        wave_sync();
+    }
+    float* dst = out + ((size_t)g * 4 + seat) * FL;
+    if (FL % 2 == 0) {
+        for (int i = lane; i < FL / 2; i += 64) reinterpret_cast<float2*>(dst)[i] = reinterpret_cast<const float2*>(buf)[i];
+    } else {  // 215 x 27 is odd: rows of consecutive seats are only 4-byte aligned
+        for (int i = lane; i < FL; i += 64) dst[i] = buf[i];
+    }
+}
+
 // shanten.rs:244-261 / :470-484 (calculate_shanten / calculate_shanten_3p over raw histograms): one thread per hand
 __global__ void k_shanten(ShantenTables T, const uint8_t* counts, uint32_t n, int sanma, int8_t* out) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -311,7 +341,6 @@ __global__ __launch_bounds__(256) void k_ukeire(ShantenTables T, const uint8_t* 
     if (i >= n) return;
     const bool sm = sanma != 0;
     const int t = lane;                                       // tile type of this lane
-    const bool t_ok = t < 34 && (!sm || t == 0 || t >= 8);     // SANMA_VALID_TILE_TYPES (shanten.rs:244-247)
     const uint32_t my_cnt = t < 34 ? counts[(size_t)i * 34 + t] : 0u;
     const uint32_t my_vis = (t < 34 && visible) ? visible[(size_t)i * 34 + t] : 0u;
     // wave-uniform histogram: lane t contributes its field, the four words are OR-reduced over the wave
@@ -327,44 +356,7 @@ __global__ __launch_bounds__(256) void k_ukeire(ShantenTables T, const uint8_t* 
         }
         h.a = w[0]; h.b = w[1]; h.c = w[2]; h.d = w[3];
     }
-    const int total = ph_total(h);
-    // number of drawn types that lower the shanten of `base` (a 3n+1 hand), weighted per lane by `weight`
-    auto improve = [&](const PH& base, int base_total, int base_sh, uint32_t weight) -> uint32_t {
-        uint32_t v = 0;
-        if (t_ok && ph_cnt(base, t) < 4) {
-            PH x = base;
-            ph_add(x, t);
-            if (sh_shanten(x, (base_total + 1) / 3, sm, T) < base_sh) v = weight;
-        }
-#pragma unroll
-        for (int off = 32; off >= 1; off >>= 1) v += (uint32_t)__shfl_xor((int)v, off, 64);
-        return v;
-    };
-    uint32_t res = 0;
-    const int cur = sh_shanten(h, total / 3, sm, T);
-    if (mode == 0 && total % 3 == 1) {
-        res = improve(h, total, cur, 1u);
-    } else if (mode == 0 && total % 3 != 2) {
-        res = 0xFFFFFFFFu;  // the reference asserts on a 3n hand
-    } else {
-        for (int d = 0; d < 34; d++) {
-            if (ph_cnt(h, d) == 0) continue;
-            PH sub = h;
-            ph_sub(sub, d);
-            const int nsh = sh_shanten(sub, (total - 1) / 3, sm, T);
-            if (nsh > cur) continue;
-            uint32_t weight = 1u;
-            if (mode == 1) {  // remaining = 4 - visible - held (both saturating), held counted after the discard
-                int held = (int)my_cnt - (t == d ? 1 : 0);
-                int rem = 4 - (int)my_vis;
-                rem = rem < 0 ? 0 : rem;
-                rem -= held;
-                weight = (uint32_t)(rem < 0 ? 0 : rem);
-            }
-            uint32_t v = improve(sub, total - 1, nsh, weight);
-            res = v > res ? v : res;
-        }
-    }
+    const uint32_t res = sh_ukeire_wave(T, h, my_cnt, my_vis, sm, mode, lane);
     if (lane == 0) out[i] = res;
 }
 
@@ -396,6 +388,7 @@ struct rmj_env {
     uint64_t* d_actions = nullptr;
     unsigned long long* d_counter = nullptr;
     uint32_t ring = 0;
+    float* d_decay = nullptr;  // expf(-0.2f * age), age 0..31, computed on the host (encode_extended)
 };
 
 static int ensure_device(int device) {
@@ -466,6 +459,12 @@ int rmj_create(const RmjConfig* cfg, rmj_handle* out) {
     if ((rc = shanten_tables_for(cfg->device, &d.sh))) return rc;
     HIPCHK(hipMalloc(&h->d_env, sizeof(Env)));
     HIPCHK(hipMemcpy(h->d_env, &d, sizeof(Env), hipMemcpyHostToDevice));
+    {
+        float decay[RMJ_MAX_DISCARDS];
+        for (int a = 0; a < RMJ_MAX_DISCARDS; a++) decay[a] = expf(-0.2f * (float)a);  // same call as the reference's f32::exp
+        HIPCHK(hipMalloc(&h->d_decay, sizeof(decay)));
+        HIPCHK(hipMemcpy(h->d_decay, decay, sizeof(decay), hipMemcpyHostToDevice));
+    }
     ResetArgs A;
     memset(&A, 0, sizeof(A));
     A.is_ctor = 1;
@@ -490,7 +489,7 @@ int rmj_destroy(rmj_handle h) {
     if (!h) return RMJ_OK;
     hipSetDevice(h->cfg.device);
     hipStreamSynchronize(h->stream);
-    hipFree(h->d.core); hipFree(h->d.wall); hipFree(h->d.legal); hipFree(h->d.nlegal); hipFree(h->d.mask);
+    hipFree(h->d.core); hipFree(h->d.wall); hipFree(h->d.legal); hipFree(h->d.nlegal); hipFree(h->d_decay); hipFree(h->d.mask);
     hipFree(h->d.waits); hipFree(h->d.status); hipFree(h->d.events); hipFree(h->d_actions); hipFree(h->d_counter); hipFree(h->d_env);
     hipStreamDestroy(h->stream);
     delete h;
@@ -1055,6 +1054,28 @@ int rmj_encode(rmj_handle h, int only_active, float* out) {
     float* d;
     HIPCHK(hipMalloc(&d, bytes));
     int rc = rmj_encode_device(h, only_active, d);
+    if (rc) return rc;
+    HIPCHK(hipStreamSynchronize(h->stream));
+    HIPCHK(hipMemcpy(out, d, bytes, hipMemcpyDeviceToHost));
+    hipFree(d);
+    return RMJ_OK;
+}
+
+int rmj_encode_extended_device(rmj_handle h, int only_active, float* d_out) {
+    if (!h || !d_out) return fail(RMJ_ERR_ARG, "null argument");
+    HIPCHK(hipSetDevice(h->cfg.device));
+    if (h->cfg.game_mode >= 3) hipLaunchKernelGGL(k_encode_ext<true>, dim3(h->cfg.n_games * 4), dim3(64), 0, h->stream, h->d, only_active, (const float*)h->d_decay, d_out);
+    else hipLaunchKernelGGL(k_encode_ext<false>, dim3(h->cfg.n_games * 4), dim3(64), 0, h->stream, h->d, only_active, (const float*)h->d_decay, d_out);
+    HIPCHK(hipGetLastError());
+    return RMJ_OK;
+}
+int rmj_encode_extended(rmj_handle h, int only_active, float* out) {
+    if (!h || !out) return fail(RMJ_ERR_ARG, "null argument");
+    HIPCHK(hipSetDevice(h->cfg.device));
+    size_t bytes = (size_t)h->cfg.n_games * 4 * ENC_EXT_CH * (h->cfg.game_mode >= 3 ? ENC_W3 : ENC_W4) * sizeof(float);
+    float* d;
+    HIPCHK(hipMalloc(&d, bytes));
+    int rc = rmj_encode_extended_device(h, only_active, d);
     if (rc) return rc;
     HIPCHK(hipStreamSynchronize(h->stream));
     HIPCHK(hipMemcpy(out, d, bytes, hipMemcpyDeviceToHost));

@@ -190,4 +190,176 @@ __device__ inline void encode_seat(const GState& S, int pid, float* buf, int lan
     wave_sync();
 }
 
+// ---------------------------------------------------------------- encode_extended
+// Channels 74..214 of Observation.encode_extended (python.rs:1271-1296): observation/encode.rs:293-585 (4P) /
+// observation_3p/encode.rs:315-615 (3P).  `buf` holds all 215 x W floats; channels 0..73 were written by encode_seat.
+// `decay[a]` = expf(-0.2f * a) computed on the HOST (the reference's f32::exp is the platform expf; a device exp could
+// differ in the last bit), added in turn order like the reference's accumulation.
+// Snapshot quirks kept: Observation.last_discard is the DISCARDER'S SEAT (state/mod.rs:252), dora membership compares the
+// full 136-id with the copy-0 id of the next tile, riichi_sutehais is never set on a reachable path.
+#define ENC_EXT_CH 215
+template <bool SANMA>
+__device__ inline void encode_ext_seat(const GState& S, int pid, float* buf, int lane, const ShantenTables& T, const float* decay,
+                                       const uint64_t* legal, int n_legal) {
+    constexpr int ENC_W = SANMA ? ENC_W3 : ENC_W4;
+    constexpr int NPP = SANMA ? 3 : 4;
+    const PState& P = S.p[pid];
+    const int my34 = SANMA ? (lane == 0 ? 0 : lane + 7) : lane;  // tile type of this lane's column
+    auto bc = [&](int ch, float v) {
+        if (lane < ENC_W) buf[ch * ENC_W + lane] = v;
+    };
+    for (int i = ENC_CH * ENC_W + lane; i < ENC_EXT_CH * ENC_W; i += 64) buf[i] = 0.0f;
+    wave_sync();
+    // 74..77 discard history decay: lane = column, discards visited in turn order
+    for (int c = 0; c < NPP; c++) {
+        const PState& Q = S.p[(pid + c) % NPP];
+        const int n = Q.n_discards;
+        if (lane < ENC_W) {
+            float acc = 0.0f;
+            for (int turn = 0; turn < n; turn++)
+                if ((Q.discards[turn] >> 2) == my34) acc += decay[n - 1 - turn];
+            buf[(74 + c) * ENC_W + lane] = acc;
+        }
+    }
+    // hand / visible histograms: lane = tile type (34 lanes, also in 3P)
+    uint32_t my_cnt = 0, my_vis = 0;
+    if (lane < 34) {
+        for (int j = 0; j < P.hand_len; j++) my_cnt += (P.hand[j] >> 2) == lane;
+        for (int q = 0; q < NPP; q++) {
+            const PState& Q = S.p[q];
+            for (int j = 0; j < Q.n_discards; j++) my_vis += (Q.discards[j] >> 2) == lane;
+            for (int m = 0; m < Q.n_melds; m++) {
+                int nt = (Q.meld_type[m] >= RMJ_MELD_DAIMINKAN) ? 4 : 3;
+                for (int k = 0; k < nt; k++) my_vis += (Q.meld_tiles[m][k] >> 2) == lane;
+            }
+        }
+        for (int k = 0; k < S.n_dora; k++) my_vis += (S.dora[k] >> 2) == lane;
+    }
+    PH h = {0, 0, 0, 0};
+    {
+        const int s = lane < 34 ? t_suit(lane) : 0;
+        uint32_t f = lane < 34 ? (my_cnt & 7u) << (3 * (lane - 9 * s)) : 0u;
+        uint32_t w[4] = {s == 0 ? f : 0u, s == 1 ? f : 0u, s == 2 ? f : 0u, s == 3 ? f : 0u};
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+#pragma unroll
+            for (int off = 32; off >= 1; off >>= 1) w[k] |= (uint32_t)__shfl_xor((int)w[k], off, 64);
+        }
+        h.a = w[0]; h.b = w[1]; h.c = w[2]; h.d = w[3];
+    }
+    const int total = ph_total(h);
+    const int cur_sh = sh_shanten(h, total / 3, SANMA, T);
+    // 78..93 shanten efficiency
+    {
+        const uint32_t eff = sh_ukeire_wave(T, h, my_cnt, my_vis, SANMA, 0, lane);
+        const uint32_t uke = sh_ukeire_wave(T, h, my_cnt, my_vis, SANMA, 1, lane);
+        for (int c = 0; c < NPP; c++) {
+            const int base = 78 + c * 4;
+            if (c == 0) {
+                bc(base, fmaxf((float)cur_sh, 0.0f) / 8.0f);
+                bc(base + 1, (float)eff / (SANMA ? 27.0f : 34.0f));
+                bc(base + 2, (float)uke / 80.0f);
+            } else {
+                bc(base, 0.5f); bc(base + 1, 0.5f); bc(base + 2, 0.5f);
+            }
+            bc(base + 3, fminf((float)S.p[(pid + c) % NPP].n_discards / 18.0f, 1.0f));
+        }
+    }
+    wave_sync();
+    // 94..97 ankan overview, 98..177 fuuro overview: lane = 16*rel + 4*meld + slot
+    {
+        const int c = lane >> 4, mi = (lane >> 2) & 3, sl = lane & 3;
+        if (c < NPP) {
+            const PState& Q = S.p[(pid + c) % NPP];
+            if (mi < Q.n_melds) {
+                const int nt = (Q.meld_type[mi] >= RMJ_MELD_DAIMINKAN) ? 4 : 3;
+                if (sl < nt) {
+                    const int tile = Q.meld_tiles[mi][sl];
+                    const int col = enc_col<SANMA>(tile >> 2);
+                    if (col >= 0) {
+                        buf[(98 + c * 20 + mi * 5 + sl) * ENC_W + col] = 1.0f;
+                        if (is_aka(tile)) buf[(98 + c * 20 + mi * 5 + 4) * ENC_W + col] = 1.0f;
+                        if (sl == 0 && Q.meld_type[mi] == RMJ_MELD_ANKAN) buf[(94 + c) * ENC_W + col] = 1.0f;
+                    }
+                }
+            }
+        }
+    }
+    // 178..188 action availability over the seat's legal list
+    {
+        uint32_t kind = 0xFFu;
+        if (lane < n_legal) {
+            const uint64_t a = legal[lane];
+            switch (a_type(a)) {
+                case RMJ_RIICHI: kind = 0; break;
+                case RMJ_CHI:
+                    if (a_n(a) == 2) {
+                        int t0 = (int)(a_c(a, 0) >> 2), t1 = (int)(a_c(a, 1) >> 2);
+                        int diff = t1 > t0 ? t1 - t0 : t0 - t1;
+                        if (diff == 1) kind = t0 < t1 ? 1 : 3;
+                        else if (diff == 2) kind = 2;
+                    }
+                    break;
+                case RMJ_PON: kind = 4; break;
+                case RMJ_DAIMINKAN: kind = 5; break;
+                case RMJ_ANKAN: kind = 6; break;
+                case RMJ_KAKAN: kind = 7; break;
+                case RMJ_TSUMO:
+                case RMJ_RON: kind = 8; break;
+                case RMJ_KYUSHU: kind = 9; break;
+                case RMJ_PASS: kind = 10; break;
+                default: break;
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < 11; k++)
+            if (__ballot(kind == (uint32_t)k)) bc(178 + k, 1.0f);
+    }
+    // 189..193 discard candidates: lane = hand slot
+    {
+        const int n = P.hand_len;
+        int ns = 99;
+        if (lane < n) {
+            PH x = h;
+            ph_sub(x, P.hand[lane] >> 2);
+            ns = sh_shanten(x, (total - 1) / 3, SANMA, T);
+        }
+        const int keep = __popcll(__ballot(lane < n && ns == cur_sh));
+        const int inc = __popcll(__ballot(lane < n && ns > cur_sh));
+        bc(189, (float)n / 34.0f);
+        if (n) {
+            bc(190, (float)keep / (float)n);
+            bc(191, (float)inc / (float)n);
+        }
+        bc(192, cur_sh == -1 ? 1.0f : 0.0f);
+        bc(193, (P.flags & PF_RIICHI_DECLARED) ? 1.0f : 0.0f);
+    }
+    // 194..196 pass context, 197..205 last tedashis, 206..214 riichi sutehais
+    {
+        auto tile_feats = [&](int ch, int tile) {
+            const int t34 = tile >> 2;
+            if (SANMA) {
+                const int k = enc_col<true>(t34);
+                if (k >= 0) bc(ch, (float)k / 26.0f);
+            } else {
+                bc(ch, (float)t34 / 33.0f);
+            }
+            bc(ch + 1, is_aka(tile) ? 1.0f : 0.0f);
+            bool dora = false;
+            for (int k = 0; k < S.n_dora; k++)
+                dora = dora || (SANMA ? enc_next_tile136_sanma(S.dora[k]) : enc_next_tile136(S.dora[k])) == tile;
+            bc(ch + 2, dora ? 1.0f : 0.0f);
+        };
+        if (S.last_discard_pid != 0xFF) tile_feats(194, S.last_discard_pid);
+        int opp = 0;
+        for (int q = 0; q < NPP; q++) {
+            if (q == pid) continue;
+            if (S.p[q].last_tedashi != 0xFF) tile_feats(197 + opp * 3, S.p[q].last_tedashi);
+            if (S.p[q].riichi_sutehai != 0xFF) tile_feats(206 + opp * 3, S.p[q].riichi_sutehai);
+            opp++;
+        }
+    }
+    wave_sync();
+}
+
 }  // namespace rmj

@@ -349,4 +349,51 @@ __device__ __forceinline__ int sh_shanten_wave(const PH& h, int len_div3, const 
     return sres;
 }
 
+// calculate_effective_tiles(_3p)_with_discard (mode 0) / calculate_best_ukeire(_3p) (mode 1), shanten.rs:265-405 /
+// :488-626, for ONE wave-uniform hand: lane = drawn tile type (my_cnt / my_vis = this lane's held / visible count), the
+// loop over discard candidates runs over held types.  mode 0 on a 3n hand yields 0xFFFFFFFF (the reference asserts).
+__device__ inline uint32_t sh_ukeire_wave(const ShantenTables& T, const PH& h, uint32_t my_cnt, uint32_t my_vis, bool sm, int mode, int lane) {
+    const int t = lane;
+    const bool t_ok = t < 34 && (!sm || t == 0 || t >= 8);  // SANMA_VALID_TILE_TYPES (shanten.rs:244-247)
+    const int total = ph_total(h);
+    // number of drawn types that lower the shanten of `base` (a 3n+1 hand), weighted per lane by `weight`
+    auto improve = [&](const PH& base, int base_total, int base_sh, uint32_t weight) -> uint32_t {
+        uint32_t v = 0;
+        if (t_ok && ph_cnt(base, t) < 4) {
+            PH x = base;
+            ph_add(x, t);
+            if (sh_shanten(x, (base_total + 1) / 3, sm, T) < base_sh) v = weight;
+        }
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) v += (uint32_t)__shfl_xor((int)v, off, 64);
+        return v;
+    };
+    uint32_t res = 0;
+    const int cur = sh_shanten(h, total / 3, sm, T);
+    if (mode == 0 && total % 3 == 1) {
+        res = improve(h, total, cur, 1u);
+    } else if (mode == 0 && total % 3 != 2) {
+        res = 0xFFFFFFFFu;
+    } else {
+        for (int d = 0; d < 34; d++) {
+            if (ph_cnt(h, d) == 0) continue;
+            PH sub = h;
+            ph_sub(sub, d);
+            const int nsh = sh_shanten(sub, (total - 1) / 3, sm, T);
+            if (nsh > cur) continue;
+            uint32_t weight = 1u;
+            if (mode == 1) {  // remaining = 4 - visible - held (both saturating), held counted after the discard
+                int held = (int)my_cnt - (t == d ? 1 : 0);
+                int rem = 4 - (int)my_vis;
+                rem = rem < 0 ? 0 : rem;
+                rem -= held;
+                weight = (uint32_t)(rem < 0 ? 0 : rem);
+            }
+            uint32_t v = improve(sub, total - 1, nsh, weight);
+            res = v > res ? v : res;
+        }
+    }
+    return res;
+}
+
 }  // namespace rmj

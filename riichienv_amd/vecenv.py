@@ -26,7 +26,7 @@ EXPORTS = [
     "rmj_step_device", "rmj_step_random", "rmj_random_actions", "rmj_get_status", "rmj_get_legal", "rmj_get_mask",
     "rmj_get_waits", "rmj_get_scores", "rmj_get_ranks", "rmj_get_step_counts", "rmj_total_steps", "rmj_peek_state",
     "rmj_poke_state", "rmj_get_event_counts", "rmj_get_events", "rmj_format_event", "rmj_eval_hands",
-    "rmj_agari_counts", "rmj_calculate_score", "rmj_shanten", "rmj_effective_tiles", "rmj_best_ukeire", "rmj_apply_events", "rmj_encode", "rmj_encode_device", "rmj_bench_rollout",
+    "rmj_agari_counts", "rmj_calculate_score", "rmj_shanten", "rmj_effective_tiles", "rmj_best_ukeire", "rmj_apply_events", "rmj_encode", "rmj_encode_device", "rmj_encode_extended", "rmj_encode_extended_device", "rmj_bench_rollout",
 ]
 
 
@@ -71,6 +71,8 @@ def load_lib():
     L.rmj_calculate_score.argtypes = [C.c_int] + [vp] * 6 + [C.c_uint32, vp]
     L.rmj_encode.argtypes = [vp, C.c_int, vp]
     L.rmj_encode_device.argtypes = [vp, C.c_int, vp]
+    L.rmj_encode_extended.argtypes = [vp, C.c_int, vp]
+    L.rmj_encode_extended_device.argtypes = [vp, C.c_int, vp]
     L.rmj_effective_tiles.argtypes = [C.c_int, vp, C.c_uint32, C.c_int, vp]
     L.rmj_best_ukeire.argtypes = [C.c_int, vp, vp, C.c_uint32, C.c_int, vp]
     L.rmj_apply_events.argtypes = [vp, vp]
@@ -279,6 +281,13 @@ class VecRiichiEnv:
         """Observation.encode() of every seat: float32 [n, 4, 74, 34] (observation/python.rs:457-806)."""
         out = np.zeros((self.n, 4, 74, 27 if self.game_mode >= 3 else 34), np.float32)
         _chk(self.L.rmj_encode(self.h, int(only_active), out.ctypes.data))
+        return out
+
+    def encode_extended(self, only_active=False):
+        """Observation.encode_extended() of every (game, seat): [n][4][215][34] f32 (3P: [n][4][215][27])."""
+        w = 27 if self.game_mode >= 3 else 34
+        out = np.zeros((self.n, 4, 215, w), np.float32)
+        _chk(self.L.rmj_encode_extended(self.h, int(only_active), out.ctypes.data))
         return out
 
     def bench_rollout(self, policy_seed, warmup, steps) -> abi.BenchResult:

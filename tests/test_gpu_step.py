@@ -153,6 +153,35 @@ def test_encode_parity_along_rollout(mode):
                         assert not enc_act[g, s].any()
 
 
+@pytest.mark.parametrize("mode", [2, 5])
+def test_encode_extended_parity_along_rollout(mode):
+    """Row N3: rmj_encode_extended (215 x 34 / 215 x 27 f32, every seat) bit-exact vs the oracle along a rollout
+    (oracle shanten = enumeration, so fewer samples than the base encoder test)."""
+    from oracle import oracle
+    from riichienv_amd import vecenv
+
+    n, seed, pseed = 8, 4321, 9
+    sanma = mode >= 3
+    env = vecenv.VecRiichiEnv(n, game_mode=mode, seed=seed)
+    games = [oracle.Game(game_mode=mode, seed=seed + g) for g in range(n)]
+    env.reset()
+    for o in games:
+        o.reset()
+    for step in range(330):
+        acts = np.array([games[g].random_actions(pseed, g) for g in range(n)], dtype=np.uint64)
+        env.step(acts)
+        for g in range(n):
+            games[g].step([int(x) for x in acts[g]])
+        if step % 82 == 0 or step == 329:
+            enc = env.encode_extended()
+            for g in range(n):
+                for s in range(3 if sanma else 4):
+                    ref = games[g].encode_extended(s)
+                    bad = np.argwhere(enc[g, s] != ref)
+                    assert enc[g, s].tobytes() == ref.tobytes(), (step, g, s, bad[:6], enc[g, s][tuple(bad[0])], ref[tuple(bad[0])])
+                assert not enc[g, 3].any() or not sanma
+
+
 @pytest.mark.parametrize("mode,rule", [(5, abi.RULE_TENHOU), (4, abi.RULE_MJSOUL)])
 def test_sanma_random_rollout_parity(mode, rule):
     """configs[4]-style 3P games (108-tile wall, kita, no chi, 35000 start): every step compared with the oracle."""

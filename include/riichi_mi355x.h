@@ -263,6 +263,27 @@ int rmj_effective_tiles(int device, const uint8_t* counts /*[n][34]*/, uint32_t 
 int rmj_best_ukeire(int device, const uint8_t* counts /*[n][34]*/, const uint8_t* visible /*[n][34]*/, uint32_t n, int sanma,
                     uint32_t* out /*[n]*/);
 
+/* ------------------------------------------------------------------ trainer-side device interface
+ * Zero-copy views of the observation outputs for a policy that runs on the same GPU (riichienv-ml's PPO worker loop,
+ * trainers/_ppo_worker.py:113-466, reads obs.mask() / obs.encode() per game on the host).  The pointers stay valid until
+ * rmj_destroy; their contents are rewritten by every step / reset / apply call, in order, on `stream`. */
+typedef struct RmjDeviceViews {
+    uint32_t n_games, reserved;
+    const uint32_t* status;   /* [n]        active_mask | phase << 8 | is_done << 16 */
+    const uint8_t* nlegal;    /* [n][4]     */
+    const uint64_t* legal;    /* [n][4][64] packed actions */
+    const uint8_t* mask;      /* [n][4][82] action-id mask (first 60 ids in 3P) */
+    const uint64_t* waits;    /* [n][4]     34-bit wait masks */
+    void* stream;             /* hipStream_t of the handle */
+} RmjDeviceViews;
+int rmj_device_views(rmj_handle h, RmjDeviceViews* out);
+/* step with the policy's action ids ([n][4] int32 on the device, -1 = no action): Observation.find_action
+ * (observation/python.rs:119-122) + RiichiEnv.step; auto_reset != 0 restarts finished games like rmj_step_random */
+int rmj_step_ids_device(rmj_handle h, const int32_t* d_action_ids, int auto_reset);
+/* scores() (env.rs:401-404) into a device buffer [n][4]; d_event_counts [n] may be NULL */
+int rmj_scores_device(rmj_handle h, int32_t* d_scores, uint32_t* d_event_counts);
+int rmj_sync(rmj_handle h); /* wait for the handle's stream */
+
 /* ------------------------------------------------------------------ MJAI event ingestion
  * RiichiEnv.apply_event (riichienv-python/src/env.rs:880-887) -> GameState::apply_mjai_event
  * (state/event_handler.rs:18-330, state_3p/event_handler.rs:18-362) for every game at once: events[n][3] holds one MJAI

@@ -53,6 +53,7 @@ def lib():
         L.orc_calculate_score.argtypes = [C.c_void_p] * 6 + [C.c_uint32, C.c_void_p]
         L.orc_find_divisions.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
         L.orc_action_encode.argtypes = [C.c_uint64]
+        L.orc_action_encode_3p.argtypes = [C.c_uint64]
         L.orc_game_encode.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
         L.orc_game_encode_extended.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
         L.orc_shanten.argtypes = [C.c_void_p, C.c_uint32, C.c_int, C.c_void_p]

@@ -455,6 +455,7 @@ int orc_game_mask(void* gp, int pid, uint8_t* mask82) {
     return 0;
 }
 int orc_action_encode(rmj_action_t a) { return unpack_action(a, -1).encode(); }
+int orc_action_encode_3p(rmj_action_t a) { return unpack_action(a, -1).encode_3p(); }
 
 uint64_t orc_game_waits(void* gp, int pid) {
     GameState* g = (GameState*)gp;

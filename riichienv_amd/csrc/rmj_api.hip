@@ -21,6 +21,7 @@ using namespace rmj;
 #define WPB 4
 #define STEP_F_RANDOM 1u
 #define STEP_F_AUTORESET 2u
+#define STEP_F_IDS 4u /* `actions` holds int32 action ids [n][4] (Observation.find_action semantics) */
 
 struct BlockShared {
     GState st[WPB];
@@ -95,7 +96,7 @@ __global__ void k_gather_scores(const GState* core, uint32_t n, int32_t* out, ui
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) {
         for (int p = 0; p < 4; p++) out[(size_t)i * 4 + p] = core[i].p[p].score;
-        evc[i] = core[i].ev_count;
+        if (evc) evc[i] = core[i].ev_count;
     }
 }
 
@@ -529,6 +530,43 @@ int rmj_step_device(rmj_handle h, const rmj_action_t* d_actions) {
     if (h->cfg.game_mode >= 3) hipLaunchKernelGGL(rmj3::k_step, game_grid(h->cfg.n_games), dim3(256), 0, h->stream, (const Env*)h->d_env, (const uint64_t*)d_actions, 0ull, 0u);
     else hipLaunchKernelGGL(rmj4::k_step, game_grid(h->cfg.n_games), dim3(256), 0, h->stream, (const Env*)h->d_env, (const uint64_t*)d_actions, 0ull, 0u);
     HIPCHK(hipGetLastError());
+    return RMJ_OK;
+}
+// Trainer-side entry (row N4): the policy's categorical outputs (action ids of the 82- / 60-way space, -1 = no action),
+// resident on the device, are mapped to the first legal action with that id (Observation.find_action,
+// observation/python.rs:119-122) inside the step kernel.  An id without a legal action is an illegal action (chombo).
+int rmj_step_ids_device(rmj_handle h, const int32_t* d_action_ids, int auto_reset) {
+    if (!h || !d_action_ids) return fail(RMJ_ERR_ARG, "null argument");
+    HIPCHK(hipSetDevice(h->cfg.device));
+    const uint32_t flags = STEP_F_IDS | (auto_reset ? STEP_F_AUTORESET : 0u);
+    if (h->cfg.game_mode >= 3) hipLaunchKernelGGL(rmj3::k_step, game_grid(h->cfg.n_games), dim3(256), 0, h->stream, (const Env*)h->d_env, reinterpret_cast<const uint64_t*>(d_action_ids), 0ull, flags);
+    else hipLaunchKernelGGL(rmj4::k_step, game_grid(h->cfg.n_games), dim3(256), 0, h->stream, (const Env*)h->d_env, reinterpret_cast<const uint64_t*>(d_action_ids), 0ull, flags);
+    HIPCHK(hipGetLastError());
+    return RMJ_OK;
+}
+int rmj_device_views(rmj_handle h, RmjDeviceViews* out) {
+    if (!h || !out) return fail(RMJ_ERR_ARG, "null argument");
+    out->n_games = h->cfg.n_games;
+    out->status = h->d.status;
+    out->nlegal = h->d.nlegal;
+    out->legal = h->d.legal;
+    out->mask = h->d.mask;
+    out->waits = h->d.waits;
+    out->stream = (void*)h->stream;
+    return RMJ_OK;
+}
+int rmj_scores_device(rmj_handle h, int32_t* d_scores, uint32_t* d_event_counts) {
+    if (!h || !d_scores) return fail(RMJ_ERR_ARG, "null argument");
+    HIPCHK(hipSetDevice(h->cfg.device));
+    const uint32_t n = h->cfg.n_games;
+    hipLaunchKernelGGL(k_gather_scores, dim3((n + 255) / 256), dim3(256), 0, h->stream, h->d.core, n, d_scores, d_event_counts);
+    HIPCHK(hipGetLastError());
+    return RMJ_OK;
+}
+int rmj_sync(rmj_handle h) {
+    if (!h) return fail(RMJ_ERR_ARG, "null handle");
+    HIPCHK(hipSetDevice(h->cfg.device));
+    HIPCHK(hipStreamSynchronize(h->stream));
     return RMJ_OK;
 }
 int rmj_step(rmj_handle h, const rmj_action_t* actions) {

@@ -54,6 +54,24 @@ __global__ __launch_bounds__(256, RMJ_STEP_WAVES) void k_step(const Env* __restr
                 mine = c.Lg[lane * RMJ_MAX_LEGAL + ch];
             }
         }
+    } else if (flags & STEP_F_IDS) {
+        // Observation.find_action (observation/python.rs:119-122): the first legal action of the seat whose encoded id
+        // equals the policy's id; lane = list entry.  No match = an action that fails validation (illegal action).
+        const int32_t* ids = reinterpret_cast<const int32_t*>(actions);
+        for (int p = 0; p < 4; p++) {
+            const int id = ids[(size_t)g * 4 + p];
+            const int n = S.nlegal[p];
+            if (id < 0 || !((S.active_mask >> p) & 1u) || n == 0 || S.is_done) continue;
+            uint64_t a = 0;
+            bool hit = false;
+            if (lane < n) {
+                a = c.Lg[p * RMJ_MAX_LEGAL + lane];
+                hit = (KSANMA ? a_encode_3p(a) : a_encode(a)) == id;
+            }
+            const uint64_t b = __ballot(hit);
+            const uint64_t chosen = b ? act_at(a, __ffsll((long long)b) - 1) : mk_action(0x7F, RMJ_TILE_NONE, 0);
+            if (lane == p) mine = chosen;
+        }
     } else if (lane < 4) {
         uint64_t a = actions[(size_t)g * 4 + lane];
         mine = ((a & 0xFF) == 0xFF) ? RMJ_NO_ACTION : a_canon(a);

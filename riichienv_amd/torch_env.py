@@ -1,0 +1,122 @@
+"""Trainer-side batched environment: a Gym-style loop over all games of a shard with the policy
+on the same GPU.  Observations are encoded straight into torch tensors (rmj_encode_device / rmj_encode_extended_device),
+masks / legal lists / status are zero-copy views of the library's device slabs, actions are the policy's categorical
+ids (rmj_step_ids_device = Observation.find_action + RiichiEnv.step), rewards come from scores()/ranks()
+(riichienv-python/src/env.rs:401-404, 673-727).  Replaces the per-game Python loop of
+riichienv-ml trainers/_ppo_worker.py:113-466.
+
+torch is used for device memory and streams only; all game logic runs in the HIP library."""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import abi, vecenv
+
+
+class DeviceViews(C.Structure):
+    _fields_ = [("n_games", C.c_uint32), ("reserved", C.c_uint32), ("status", C.c_void_p), ("nlegal", C.c_void_p),
+                ("legal", C.c_void_p), ("mask", C.c_void_p), ("waits", C.c_void_p), ("stream", C.c_void_p)]
+
+
+class _CudaArray:
+    """Minimal __cuda_array_interface__ carrier so that torch.as_tensor wraps library-owned device memory in place."""
+
+    def __init__(self, ptr, shape, typestr, owner):
+        self.__cuda_array_interface__ = {"shape": tuple(shape), "typestr": typestr, "data": (int(ptr), False), "version": 3,
+                                         "strides": None}
+        self._owner = owner   # keeps the environment (and with it the allocation) alive
+
+
+class TorchVecEnv:
+    """`n_games` games on one GPU driven by a torch policy.
+
+    obs(), mask, status … describe the state AFTER the last step; step(action_ids) takes an int32 tensor [n, 4] on the
+    same device (-1 for seats that do not act)."""
+
+    def __init__(self, n_games, game_mode=2, seed=0, device=0, extended=False, skip_mjai_logging=True, **kw):
+        import torch
+
+        self.torch = torch
+        self.device = torch.device("cuda", device)
+        self.env = vecenv.VecRiichiEnv(n_games, game_mode=game_mode, seed=seed, device=device,
+                                       skip_mjai_logging=skip_mjai_logging, **kw)
+        L = self.env.L
+        L.rmj_device_views.argtypes = [C.c_void_p, C.POINTER(DeviceViews)]
+        L.rmj_step_ids_device.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
+        L.rmj_scores_device.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        L.rmj_sync.argtypes = [C.c_void_p]
+        self.n = int(n_games)
+        self.sanma = self.env.game_mode >= 3
+        self.extended = bool(extended)
+        self.channels = 215 if extended else 74
+        self.width = 27 if self.sanma else 34
+        v = DeviceViews()
+        vecenv._chk(L.rmj_device_views(self.env.h, C.byref(v)))
+        wrap = lambda ptr, shape, ts: torch.as_tensor(_CudaArray(ptr, shape, ts, self), device=self.device)  # noqa: E731
+        self.status_raw = wrap(v.status, (self.n,), "<u4") if hasattr(torch, "uint32") else wrap(v.status, (self.n,), "<i4")
+        self.nlegal = wrap(v.nlegal, (self.n, 4), "|u1")
+        self.mask = wrap(v.mask, (self.n, 4, abi.ACTION_SPACE_4P), "|u1")      # zero-copy, rewritten by every step
+        self.legal = wrap(v.legal, (self.n, 4, abi.MAX_LEGAL), "<i8")          # packed actions (bit pattern of the u64)
+        self.waits = wrap(v.waits, (self.n, 4), "<i8")
+        self._obs = torch.zeros((self.n, 4, self.channels, self.width), dtype=torch.float32, device=self.device)
+        self._scores = torch.zeros((self.n, 4), dtype=torch.int32, device=self.device)
+        self.env.reset()
+
+    # ---- status helpers (views, no copies beyond the arithmetic)
+    def _status(self):
+        s = self.status_raw.to(self.torch.int64) & 0xFFFFFFFF
+        return s & 0xFF, (s >> 8) & 0xFF, ((s >> 16) & 0xFF).bool()
+
+    def active(self):
+        """bool [n, 4]: seats that must act now"""
+        a, _, done = self._status()
+        seats = self.torch.arange(4, device=self.device)
+        return (((a[:, None] >> seats[None, :]) & 1) == 1) & ~done[:, None]
+
+    def done(self):
+        return self._status()[2]
+
+    def obs(self, only_active=True):
+        """encode() / encode_extended() of every (game, seat) into a resident tensor [n, 4, C, W]"""
+        L = self.env.L
+        fn = L.rmj_encode_extended_device if self.extended else L.rmj_encode_device
+        vecenv._chk(fn(self.env.h, int(only_active), C.c_void_p(self._obs.data_ptr())))
+        self.sync()
+        return self._obs
+
+    def scores(self):
+        vecenv._chk(self.env.L.rmj_scores_device(self.env.h, C.c_void_p(self._scores.data_ptr()), None))
+        self.sync()
+        return self._scores
+
+    def ranks(self):
+        """ranks() of env.rs:673-689 (1 = first; ties broken by seat) computed on the device from scores()"""
+        sc = self.scores().to(self.torch.int64)
+        np_ = 3 if self.sanma else 4
+        key = sc[:, :np_] * 8 - self.torch.arange(np_, device=self.device)[None, :]
+        r = (key[:, None, :] > key[:, :, None]).sum(-1) + 1
+        out = self.torch.zeros((self.n, 4), dtype=self.torch.int64, device=self.device)
+        out[:, :np_] = r
+        return out
+
+    def step(self, action_ids, auto_reset=True):
+        t = self.torch
+        ids = action_ids.to(device=self.device, dtype=t.int32).contiguous()
+        assert ids.shape == (self.n, 4)
+        t.cuda.current_stream(self.device).synchronize()      # the ids were produced on torch's stream
+        vecenv._chk(self.env.L.rmj_step_ids_device(self.env.h, C.c_void_p(ids.data_ptr()), int(auto_reset)))
+        self.sync()
+
+    def sync(self):
+        vecenv._chk(self.env.L.rmj_sync(self.env.h))
+
+    def sample_random_ids(self, generator=None):
+        """uniform choice among the legal ids of every acting seat (a masked categorical policy's baseline)"""
+        t = self.torch
+        m = self.mask.to(t.float32) * self.active()[:, :, None]
+        has = m.sum(-1) > 0
+        probs = t.where(has[:, :, None], m, t.ones_like(m))
+        ids = t.multinomial(probs.view(-1, m.shape[-1]), 1, generator=generator).view(self.n, 4)
+        return t.where(has, ids, t.full_like(ids, -1)).to(t.int32)

@@ -1,0 +1,47 @@
+#!/usr/bin/env python3
+"""Trainer-side loop throughput (row N4): encode observations + masked uniform policy in torch + id-based step, all on
+one GPU.  Prints env.step/s of the whole loop and of its parts."""
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch  # noqa: E402
+
+from riichienv_amd.torch_env import TorchVecEnv  # noqa: E402
+
+
+def main():
+    n = int(sys.argv[1]) if len(sys.argv) > 1 else 65536
+    ext = len(sys.argv) > 2 and sys.argv[2] == "ext"
+    env = TorchVecEnv(n, game_mode=2, seed=0, extended=ext)
+    gen = torch.Generator(device=env.device)
+    gen.manual_seed(0)
+    for _ in range(20):
+        env.step(env.sample_random_ids(gen))
+    torch.cuda.synchronize()
+    t_obs = t_pol = t_step = 0.0
+    steps0 = env.env.total_steps()
+    K = 100
+    t0 = time.perf_counter()
+    for _ in range(K):
+        a = time.perf_counter()
+        env.obs(only_active=True)
+        b = time.perf_counter()
+        ids = env.sample_random_ids(gen)
+        torch.cuda.synchronize()
+        c = time.perf_counter()
+        env.step(ids)
+        d = time.perf_counter()
+        t_obs += b - a
+        t_pol += c - b
+        t_step += d - c
+    t1 = time.perf_counter()
+    steps = env.env.total_steps() - steps0
+    print(f"games {n} channels {env.channels}: loop {steps / (t1 - t0) / 1e6:.1f} M env.step/s "
+          f"(obs {t_obs / K * 1e3:.2f} ms, torch policy {t_pol / K * 1e3:.2f} ms, step {t_step / K * 1e3:.2f} ms per iteration)")
+
+
+if __name__ == "__main__":
+    main()

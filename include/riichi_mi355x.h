@@ -239,6 +239,8 @@ int rmj_calculate_score(int device, const uint8_t* han, const uint8_t* fu, const
 #define RMJ_ENC_CHANNELS 74
 #define RMJ_ENC_WIDTH_4P 34
 #define RMJ_ENC_WIDTH_3P 27 /* 3P: out[n][4][74][27], compact tile index (observation_3p/helpers.rs:3-15) */
+/* only_active: 0 = every seat, 1 = acting seats (rows of the others are zeroed), 2 = acting seats, rows of the others
+ * are left untouched (no HBM traffic for them; meant for resident device buffers) */
 int rmj_encode(rmj_handle h, int only_active, float* out);
 int rmj_encode_device(rmj_handle h, int only_active, float* d_out); /* device pointer, asynchronous on the handle's stream */
 

@@ -259,60 +259,56 @@ __global__ __launch_bounds__(256) void k_agari_counts(const uint8_t* counts, uin
     }
 }
 
-// Observation.encode() for every (game, seat): out[g][seat][74][34] f32 (zeros for skipped seats)
-struct EncShared {
-    GState st;
-    float buf[4][ENC_FLOATS];
-};
-template <bool SANMA>
-__global__ __launch_bounds__(256) void k_encode(Env E, int only_active, float* __restrict__ out) {
-    __shared__ EncShared sh;
-    constexpr int FL = SANMA ? ENC_FLOATS3 : ENC_FLOATS;
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const uint32_t g = blockIdx.x;
-    if (threadIdx.x < sizeof(GState) / 16) reinterpret_cast<uint4*>(&sh.st)[threadIdx.x] = reinterpret_cast<const uint4*>(E.core + g)[threadIdx.x];
-    __syncthreads();
-    const GState& S = sh.st;
-    float* buf = sh.buf[wave];
-    bool want = (wave < (SANMA ? 3 : 4)) && (!only_active || (((S.active_mask >> wave) & 1u) && !S.is_done));
-    if (want) encode_seat<SANMA>(S, wave, buf, lane);
-    else {
-        for (int i = lane; i < FL; i += 64) buf[i] = 0.0f;
-        wave_sync();
+// Observation.encode() / encode_extended() for every (game, seat): one wave (= one block) per (game, seat).
+// out[g][seat][C][W] f32, C = 74 or 215.  The tensor is assembled in an 84-channel LDS staging buffer (11 KB: 13 blocks per
+// CU) and streamed out group by group: base channels, then the two extended groups (rmj_encode.hip.h).
+// only_active: 0 = every seat, 1 = acting seats (other rows zeroed), 2 = acting seats (other rows untouched).
+template <int W>
+__device__ __forceinline__ void enc_stream_out(float* dst, const float* buf, int n_floats, int lane) {
+    // both even: 16-byte rows are not guaranteed (215 x 27 is odd), 8-byte pairs are when the offset and count are even
+    if ((n_floats & 1) == 0 && ((reinterpret_cast<uintptr_t>(dst) & 7u) == 0)) {
+        for (int i = lane; i < n_floats / 2; i += 64) reinterpret_cast<float2*>(dst)[i] = reinterpret_cast<const float2*>(buf)[i];
+    } else {
+        for (int i = lane; i < n_floats; i += 64) dst[i] = buf[i];
     }
-    // 74*34*4 B is a multiple of 16, 74*27*4 B only of 8
-    float2* dst = reinterpret_cast<float2*>(out + ((size_t)g * 4 + wave) * FL);
-    const float2* src = reinterpret_cast<const float2*>(buf);
-    for (int i = lane; i < FL / 2; i += 64) dst[i] = src[i];
 }
-
-// Observation.encode_extended (215 channels): one wave (= one block) per (game, seat); see encode_ext_seat
-template <bool SANMA>
-__global__ __launch_bounds__(64) void k_encode_ext(Env E, int only_active, const float* __restrict__ decay, float* __restrict__ out) {
+template <bool SANMA, bool EXT>
+__global__ __launch_bounds__(64) void k_encode(Env E, int only_active, const float* __restrict__ decay, float* __restrict__ out) {
     constexpr int W = SANMA ? ENC_W3 : ENC_W4;
-    constexpr int FL = ENC_EXT_CH * W;
+    constexpr int CH = EXT ? ENC_EXT_CH : ENC_CH;
     __shared__ GState st;
-    __shared__ float buf[FL];
+    __shared__ float buf[ENC_EXT_C_SLOTS * W];
     const int lane = threadIdx.x & 63;
     const uint32_t g = blockIdx.x >> 2;
     const int seat = blockIdx.x & 3;
+    float* dst = out + ((size_t)g * 4 + seat) * CH * W;
+    if (only_active) {  // cheap early-out from the 4-byte status word, before the record is fetched
+        const uint32_t stw = E.status[g];
+        const bool acts = ((stw >> seat) & 1u) && !((stw >> 16) & 0xFFu);
+        if (!acts || seat >= (SANMA ? 3 : 4)) {
+            if (only_active == 1)
+                for (int i = lane; i < CH * W; i += 64) dst[i] = 0.0f;
+            return;
+        }
+    }
     if (lane < (int)(sizeof(GState) / 16)) reinterpret_cast<uint4*>(&st)[lane] = reinterpret_cast<const uint4*>(E.core + g)[lane];
     wave_sync();
     const GState& S = st;
-    const bool want = (seat < (SANMA ? 3 : 4)) && (!only_active || (((S.active_mask >> seat) & 1u) && !S.is_done));
-    if (want) {
-        encode_seat<SANMA>(S, seat, buf, lane);
-        const int n_legal = (((S.active_mask >> seat) & 1u) && !S.is_done) ? (int)E.nlegal[(size_t)g * 4 + seat] : 0;
-        encode_ext_seat<SANMA>(S, seat, buf, lane, E.sh, decay, E.legal + ((size_t)g * 4 + seat) * RMJ_MAX_LEGAL, n_legal);
-    } else {
-        for (int i = lane; i < FL; i += 64) buf[i] = 0.0f;
-        wave_sync();
+    if (seat >= (SANMA ? 3 : 4)) {
+        for (int i = lane; i < CH * W; i += 64) dst[i] = 0.0f;
+        return;
     }
-    float* dst = out + ((size_t)g * 4 + seat) * FL;
-    if (FL % 2 == 0) {
-        for (int i = lane; i < FL / 2; i += 64) reinterpret_cast<float2*>(dst)[i] = reinterpret_cast<const float2*>(buf)[i];
-    } else {  // 215 x 27 is odd: rows of consecutive seats are only 4-byte aligned
-        for (int i = lane; i < FL; i += 64) dst[i] = buf[i];
+    encode_seat<SANMA>(S, seat, buf, lane);
+    enc_stream_out<W>(dst, buf, ENC_CH * W, lane);
+    if (EXT) {
+        wave_sync();
+        const int n_legal = (((S.active_mask >> seat) & 1u) && !S.is_done) ? (int)E.nlegal[(size_t)g * 4 + seat] : 0;
+        encode_ext_scalars<SANMA>(S, seat, buf, lane, E.sh, decay, E.legal + ((size_t)g * 4 + seat) * RMJ_MAX_LEGAL, n_legal);
+        enc_stream_out<W>(dst + 74 * W, buf, 20 * W, lane);
+        enc_stream_out<W>(dst + 178 * W, buf + 20 * W, 37 * W, lane);
+        wave_sync();
+        encode_ext_melds<SANMA>(S, seat, buf, lane);
+        enc_stream_out<W>(dst + 94 * W, buf, ENC_EXT_C_SLOTS * W, lane);
     }
 }
 
@@ -1077,14 +1073,20 @@ int rmj_calculate_score(int device, const uint8_t* han, const uint8_t* fu, const
 }
 
 // ---- feature encoder (row A14) --------------------------------------------------------------------
-int rmj_encode_device(rmj_handle h, int only_active, float* d_out) {
+static int launch_encode(rmj_handle h, int only_active, float* d_out, bool ext) {
     if (!h || !d_out) return fail(RMJ_ERR_ARG, "null argument");
     HIPCHK(hipSetDevice(h->cfg.device));
-    if (h->cfg.game_mode >= 3) hipLaunchKernelGGL(k_encode<true>, dim3(h->cfg.n_games), dim3(256), 0, h->stream, h->d, only_active, d_out);
-    else hipLaunchKernelGGL(k_encode<false>, dim3(h->cfg.n_games), dim3(256), 0, h->stream, h->d, only_active, d_out);
+    const dim3 grid(h->cfg.n_games * 4), block(64);
+    const float* decay = h->d_decay;
+    const bool sanma = h->cfg.game_mode >= 3;
+    if (sanma && ext) hipLaunchKernelGGL((k_encode<true, true>), grid, block, 0, h->stream, h->d, only_active, decay, d_out);
+    else if (sanma) hipLaunchKernelGGL((k_encode<true, false>), grid, block, 0, h->stream, h->d, only_active, decay, d_out);
+    else if (ext) hipLaunchKernelGGL((k_encode<false, true>), grid, block, 0, h->stream, h->d, only_active, decay, d_out);
+    else hipLaunchKernelGGL((k_encode<false, false>), grid, block, 0, h->stream, h->d, only_active, decay, d_out);
     HIPCHK(hipGetLastError());
     return RMJ_OK;
 }
+int rmj_encode_device(rmj_handle h, int only_active, float* d_out) { return launch_encode(h, only_active, d_out, false); }
 int rmj_encode(rmj_handle h, int only_active, float* out) {
     if (!h || !out) return fail(RMJ_ERR_ARG, "null argument");
     HIPCHK(hipSetDevice(h->cfg.device));
@@ -1099,14 +1101,7 @@ int rmj_encode(rmj_handle h, int only_active, float* out) {
     return RMJ_OK;
 }
 
-int rmj_encode_extended_device(rmj_handle h, int only_active, float* d_out) {
-    if (!h || !d_out) return fail(RMJ_ERR_ARG, "null argument");
-    HIPCHK(hipSetDevice(h->cfg.device));
-    if (h->cfg.game_mode >= 3) hipLaunchKernelGGL(k_encode_ext<true>, dim3(h->cfg.n_games * 4), dim3(64), 0, h->stream, h->d, only_active, (const float*)h->d_decay, d_out);
-    else hipLaunchKernelGGL(k_encode_ext<false>, dim3(h->cfg.n_games * 4), dim3(64), 0, h->stream, h->d, only_active, (const float*)h->d_decay, d_out);
-    HIPCHK(hipGetLastError());
-    return RMJ_OK;
-}
+int rmj_encode_extended_device(rmj_handle h, int only_active, float* d_out) { return launch_encode(h, only_active, d_out, true); }
 int rmj_encode_extended(rmj_handle h, int only_active, float* out) {
     if (!h || !out) return fail(RMJ_ERR_ARG, "null argument");
     HIPCHK(hipSetDevice(h->cfg.device));

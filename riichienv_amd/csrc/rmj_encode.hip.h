@@ -198,17 +198,23 @@ __device__ inline void encode_seat(const GState& S, int pid, float* buf, int lan
 // Snapshot quirks kept: Observation.last_discard is the DISCARDER'S SEAT (state/mod.rs:252), dora membership compares the
 // full 136-id with the copy-0 id of the next tile, riichi_sutehais is never set on a reachable path.
 #define ENC_EXT_CH 215
+// The 141 extended channels are produced in two LDS-sized groups (one 84-channel staging buffer per block):
+//   group B ("scalars"): 74..93 (decay, shanten) -> slots 0..19 and 178..214 (availability, candidates, contexts) -> slots 20..56
+//   group C ("melds")  : 94..177 (ankan, fuuro overview) -> slots 0..83
+#define ENC_EXT_B_SLOTS 57
+#define ENC_EXT_C_SLOTS 84
+__device__ __forceinline__ int enc_ext_b_slot(int ch) { return ch < 94 ? ch - 74 : ch - 178 + 20; }
 template <bool SANMA>
-__device__ inline void encode_ext_seat(const GState& S, int pid, float* buf, int lane, const ShantenTables& T, const float* decay,
-                                       const uint64_t* legal, int n_legal) {
+__device__ inline void encode_ext_scalars(const GState& S, int pid, float* buf, int lane, const ShantenTables& T, const float* decay,
+                                          const uint64_t* legal, int n_legal) {
     constexpr int ENC_W = SANMA ? ENC_W3 : ENC_W4;
     constexpr int NPP = SANMA ? 3 : 4;
     const PState& P = S.p[pid];
     const int my34 = SANMA ? (lane == 0 ? 0 : lane + 7) : lane;  // tile type of this lane's column
     auto bc = [&](int ch, float v) {
-        if (lane < ENC_W) buf[ch * ENC_W + lane] = v;
+        if (lane < ENC_W) buf[enc_ext_b_slot(ch) * ENC_W + lane] = v;
     };
-    for (int i = ENC_CH * ENC_W + lane; i < ENC_EXT_CH * ENC_W; i += 64) buf[i] = 0.0f;
+    for (int i = lane; i < ENC_EXT_B_SLOTS * ENC_W; i += 64) buf[i] = 0.0f;
     wave_sync();
     // 74..77 discard history decay: lane = column, discards visited in turn order
     for (int c = 0; c < NPP; c++) {
@@ -218,7 +224,7 @@ __device__ inline void encode_ext_seat(const GState& S, int pid, float* buf, int
             float acc = 0.0f;
             for (int turn = 0; turn < n; turn++)
                 if ((Q.discards[turn] >> 2) == my34) acc += decay[n - 1 - turn];
-            buf[(74 + c) * ENC_W + lane] = acc;
+            buf[enc_ext_b_slot(74 + c) * ENC_W + lane] = acc;
         }
     }
     // hand / visible histograms: lane = tile type (34 lanes, also in 3P)
@@ -266,25 +272,6 @@ __device__ inline void encode_ext_seat(const GState& S, int pid, float* buf, int
         }
     }
     wave_sync();
-    // 94..97 ankan overview, 98..177 fuuro overview: lane = 16*rel + 4*meld + slot
-    {
-        const int c = lane >> 4, mi = (lane >> 2) & 3, sl = lane & 3;
-        if (c < NPP) {
-            const PState& Q = S.p[(pid + c) % NPP];
-            if (mi < Q.n_melds) {
-                const int nt = (Q.meld_type[mi] >= RMJ_MELD_DAIMINKAN) ? 4 : 3;
-                if (sl < nt) {
-                    const int tile = Q.meld_tiles[mi][sl];
-                    const int col = enc_col<SANMA>(tile >> 2);
-                    if (col >= 0) {
-                        buf[(98 + c * 20 + mi * 5 + sl) * ENC_W + col] = 1.0f;
-                        if (is_aka(tile)) buf[(98 + c * 20 + mi * 5 + 4) * ENC_W + col] = 1.0f;
-                        if (sl == 0 && Q.meld_type[mi] == RMJ_MELD_ANKAN) buf[(94 + c) * ENC_W + col] = 1.0f;
-                    }
-                }
-            }
-        }
-    }
     // 178..188 action availability over the seat's legal list
     {
         uint32_t kind = 0xFFu;
@@ -357,6 +344,34 @@ __device__ inline void encode_ext_seat(const GState& S, int pid, float* buf, int
             if (S.p[q].last_tedashi != 0xFF) tile_feats(197 + opp * 3, S.p[q].last_tedashi);
             if (S.p[q].riichi_sutehai != 0xFF) tile_feats(206 + opp * 3, S.p[q].riichi_sutehai);
             opp++;
+        }
+    }
+    wave_sync();
+}
+
+template <bool SANMA>
+__device__ inline void encode_ext_melds(const GState& S, int pid, float* buf, int lane) {
+    constexpr int ENC_W = SANMA ? ENC_W3 : ENC_W4;
+    constexpr int NPP = SANMA ? 3 : 4;
+    for (int i = lane; i < ENC_EXT_C_SLOTS * ENC_W; i += 64) buf[i] = 0.0f;
+    wave_sync();
+    // 94..97 ankan overview, 98..177 fuuro overview: lane = 16*rel + 4*meld + slot
+    {
+        const int c = lane >> 4, mi = (lane >> 2) & 3, sl = lane & 3;
+        if (c < NPP) {
+            const PState& Q = S.p[(pid + c) % NPP];
+            if (mi < Q.n_melds) {
+                const int nt = (Q.meld_type[mi] >= RMJ_MELD_DAIMINKAN) ? 4 : 3;
+                if (sl < nt) {
+                    const int tile = Q.meld_tiles[mi][sl];
+                    const int col = enc_col<SANMA>(tile >> 2);
+                    if (col >= 0) {
+                        buf[(4 + c * 20 + mi * 5 + sl) * ENC_W + col] = 1.0f;
+                        if (is_aka(tile)) buf[(4 + c * 20 + mi * 5 + 4) * ENC_W + col] = 1.0f;
+                        if (sl == 0 && Q.meld_type[mi] == RMJ_MELD_ANKAN) buf[c * ENC_W + col] = 1.0f;
+                    }
+                }
+            }
         }
     }
     wave_sync();

@@ -79,10 +79,11 @@ class TorchVecEnv:
         return self._status()[2]
 
     def obs(self, only_active=True):
-        """encode() / encode_extended() of every (game, seat) into a resident tensor [n, 4, C, W]"""
+        """encode() / encode_extended() into a resident tensor [n, 4, C, W].  only_active=True refreshes only the rows
+        of the seats that must act (rows of the other seats keep their previous contents: mask them with active())."""
         L = self.env.L
         fn = L.rmj_encode_extended_device if self.extended else L.rmj_encode_device
-        vecenv._chk(fn(self.env.h, int(only_active), C.c_void_p(self._obs.data_ptr())))
+        vecenv._chk(fn(self.env.h, 2 if only_active else 0, C.c_void_p(self._obs.data_ptr())))
         self.sync()
         return self._obs
 

@@ -20,7 +20,7 @@ import random
 
 import numpy as np
 
-from . import abi, vecenv
+from . import abi, mjai, vecenv
 
 
 class ActionType(enum.IntEnum):  # action.rs:55-68 (pyclass rename_all = SCREAMING_SNAKE_CASE)
@@ -119,6 +119,41 @@ class Action:
             return 81
         raise ValueError("Kita action is not valid in 4-player mode")
 
+    def encode_3p(self) -> int:  # action.rs:262-346 (60-way space, compact tile index action.rs:14-22)
+        def compact(tile):
+            t34 = tile // 4
+            c = 0 if t34 == 0 else (t34 - 7 if 8 <= t34 < 34 else None)
+            if c is None:
+                raise ValueError(f"Tile type {t34} (manzu 2-8) is not valid in 3P mode")
+            return c
+
+        t = self.action_type
+        if t == ActionType.DISCARD:
+            if self.tile is None:
+                raise ValueError("Discard action requires a tile")
+            return compact(self.tile)
+        if t == ActionType.RIICHI:
+            return 27
+        if t == ActionType.CHI:
+            raise ValueError("Chi is not allowed in 3P mode")
+        if t == ActionType.PON:
+            return 28
+        if t == ActionType.DAIMINKAN:
+            if self.tile is None:
+                raise ValueError("Daiminkan action requires a tile")
+            return 29 + compact(self.tile)
+        if t in (ActionType.ANKAN, ActionType.KAKAN):
+            if not self.consume_tiles:
+                raise ValueError("Ankan/Kakan action requires consumed tiles")
+            return 29 + compact(self.consume_tiles[0])
+        if t in (ActionType.RON, ActionType.TSUMO):
+            return 56
+        if t == ActionType.KYUSHU_KYUHAI:
+            return 57
+        if t == ActionType.PASS:
+            return 58
+        return 59  # Kita
+
     def to_mjai(self) -> str:  # action.rs:107-149 (serde_json BTreeMap -> alphabetical keys)
         names = {ActionType.DISCARD: "dahai", ActionType.CHI: "chi", ActionType.PON: "pon", ActionType.DAIMINKAN: "daiminkan",
                  ActionType.ANKAN: "ankan", ActionType.KAKAN: "kakan", ActionType.RIICHI: "reach", ActionType.TSUMO: "hora",
@@ -181,17 +216,19 @@ class GameRule:  # rule.rs:10-57
 class Observation:
     """Per-seat snapshot (observation/mod.rs:24-56; state/mod.rs:189-263)."""
 
-    def __init__(self, player_id, view, legal, mask, waits, new_events, events, encoder):
+    def __init__(self, player_id, view, legal, mask, waits, new_events, events, encoder, num_players=4, ext_encoder=None):
         pid = player_id
         self.player_id = pid
-        self.hands = [list(p.hand[: p.hand_len]) if i == pid else [] for i, p in enumerate(view.players)]
+        self.num_players = num_players            # 3: Observation3P (observation_3p/mod.rs)
+        players = list(view.players)[:num_players]
+        self.hands = [list(p.hand[: p.hand_len]) if i == pid else [] for i, p in enumerate(players)]
         self.hand = self.hands[pid]
         self.melds = [[Meld(m.meld_type, list(m.tiles[: m.n_tiles]), bool(m.opened), m.from_who,
-                            None if m.called_tile < 0 else m.called_tile) for m in p.melds[: p.n_melds]] for p in view.players]
-        self.discards = [list(p.discards[: p.n_discards]) for p in view.players]
+                            None if m.called_tile < 0 else m.called_tile) for m in p.melds[: p.n_melds]] for p in players]
+        self.discards = [list(p.discards[: p.n_discards]) for p in players]
         self.dora_indicators = list(view.dora[: view.n_dora])
-        self.scores = [p.score for p in view.players]
-        self.riichi_declared = [bool(p.riichi_declared) for p in view.players]
+        self.scores = [p.score for p in players]
+        self.riichi_declared = [bool(p.riichi_declared) for p in players]
         self.honba = view.honba
         self.riichi_sticks = view.riichi_sticks
         self.round_wind = view.round_wind
@@ -199,15 +236,28 @@ class Observation:
         self.kyoku_index = view.kyoku_idx
         self.waits = [t for t in range(34) if (waits >> t) & 1]
         self.is_tenpai = bool(self.waits)
-        self.riichi_sutehais = [None if p.riichi_sutehai < 0 else p.riichi_sutehai for p in view.players]
-        self.last_tedashis = [None if p.last_tedashi < 0 else p.last_tedashi for p in view.players]
-        self.last_discard = None if view.last_discard_pid < 0 else view.last_discard_tile
+        self.riichi_sutehais = [None if p.riichi_sutehai < 0 else p.riichi_sutehai for p in players]
+        self.last_tedashis = [None if p.last_tedashi < 0 else p.last_tedashi for p in players]
+        # the reference hands the DISCARDER'S SEAT over here (state/mod.rs:252 destructures (pid, tile) as (tile, _pid))
+        self.last_discard = None if view.last_discard_pid < 0 else view.last_discard_pid
         self.drawn_tile = None if view.drawn_tile < 0 else view.drawn_tile
         self._legal_actions = legal
         self._mask = mask
         self._new_events = new_events
         self.events = events
         self._encoder = encoder
+        self._ext_encoder = ext_encoder
+
+    def action_space_size(self):  # observation/python.rs:114-117
+        return 60 if self.num_players == 3 else 82
+
+    def select_action_from_mjai(self, mjai_data):  # observation/mjai_select.rs:88-194
+        packed = mjai.select_action_from_mjai([a._pack() for a in self._legal_actions], mjai_data, self.drawn_tile,
+                                              self.num_players == 3)
+        return None if packed is None else Action._from_packed(packed, self.player_id)
+
+    def encode_extended(self) -> bytes:  # observation/python.rs:1271-1296 -> 215 x 34 (3P: 215 x 27) f32
+        return self._ext_encoder(self.player_id).tobytes()
 
     def legal_actions(self):  # observation/python.rs:93-96
         return list(self._legal_actions)
@@ -221,7 +271,7 @@ class Observation:
     def find_action(self, action_id):  # observation/mod.rs:117-129
         for a in self._legal_actions:
             try:
-                if a.encode() == action_id:
+                if (a.encode_3p() if self.num_players == 3 else a.encode()) == action_id:
                     return a
             except ValueError:
                 pass
@@ -242,11 +292,29 @@ class RiichiEnv:
                                       skip_mjai_logging=skip_mjai_logging, round_wind=round_wind or 0, device=device,
                                       event_ring=8192)
         self._cursor = [0, 0, 0, 0]  # player_event_counts (state/mod.rs:211-218)
+        self._np = 3 if self._mode >= 3 else 4
+
+    @property
+    def num_players(self):
+        return self._np
+
+    # ---- MJAI event ingestion (env.rs:880-948; full-information streams, see rmj_apply_events) -------------
+    def apply_event(self, event):
+        self._v.apply_events([event])
+        if event.get("type") == "start_game":
+            self._cursor = [0, 0, 0, 0]
+
+    def observe_event(self, event, player_id):
+        self.apply_event(event)
+        if event.get("type") in ("start_game", "start_kyoku", "reach_accepted", "dora", "hora", "ryukyoku", "end_kyoku", "end_game"):
+            return None
+        obs = self.get_observation(player_id)
+        return obs if obs.legal_actions() else None
 
     # ---- core loop -----------------------------------------------------------------------------------
     def reset(self, oya=None, wall=None, round_wind=None, scores=None, honba=None, kyotaku=None, seed=None):
-        if scores is not None and len(scores) != 4:
-            raise ValueError(f"scores length {len(scores)} does not match number of players 4")  # env.rs:815-823
+        if scores is not None and len(scores) != self._np:
+            raise ValueError(f"scores length {len(scores)} does not match number of players {self._np}")  # env.rs:815-823
         self._v.reset(walls=None if wall is None else np.array(wall, np.uint8)[None], oya=None if oya is None else [oya],
                       round_wind=None if round_wind is None else [round_wind],
                       scores=None if scores is None else np.array(scores, np.int32)[None],
@@ -264,7 +332,7 @@ class RiichiEnv:
         return self.get_observations(self.active_players)
 
     def get_observations(self, players=None):
-        pids = list(range(4)) if players is None else list(players)
+        pids = list(range(self._np)) if players is None else list(players)
         view = self._v.peek(0)
         legal, cnt = self._v.legal()
         mask = self._v.mask()
@@ -277,6 +345,12 @@ class RiichiEnv:
                 enc["a"] = self._v.encode()
             return enc["a"][0, pid]
 
+        def ext_encoder(pid):
+            if "x" not in enc:
+                enc["x"] = self._v.encode_extended()
+            return enc["x"][0, pid]
+
+        nmask = 60 if self._np == 3 else 82
         out = {}
         for pid in pids:
             active = bool((act >> pid) & 1) and not view.is_done and (
@@ -286,7 +360,8 @@ class RiichiEnv:
             log = self._v.mjai_log(0, pid)
             new = log[self._cursor[pid]:]
             self._cursor[pid] = len(log)
-            out[pid] = Observation(pid, view, la, mask[0, pid] if active else np.zeros(82, np.uint8), w, new, log, encoder)
+            out[pid] = Observation(pid, view, la, mask[0, pid][:nmask] if active else np.zeros(nmask, np.uint8), w, new, log,
+                                   encoder, self._np, ext_encoder)
         return out
 
     def get_observation(self, player_id):
@@ -313,16 +388,19 @@ class RiichiEnv:
         return bool(self._v.done()[0])
 
     def scores(self):
-        return [int(x) for x in self._v.scores()[0]]
+        return [int(x) for x in self._v.scores()[0]][: self._np]
 
     def ranks(self):  # env.rs:673-689
-        return [int(x) for x in self._v.ranks()[0]]
+        return [int(x) for x in self._v.ranks()[0]][: self._np]
 
     def points(self, rule_name="basic"):  # env.rs:691-727
-        presets = {"basic": (1.0, 25000.0, [50.0, 10.0, -10.0, -50.0]), "ouza-tyoujyo": (0.0, 25000.0, [100.0, 40.0, -40.0, -100.0]),
-                   "ouza-normal": (0.0, 25000.0, [50.0, 20.0, -20.0, -50.0])}
+        if self._np == 3:
+            presets = {"basic": (1.0, 35000.0, [40.0, 0.0, -40.0])}
+        else:
+            presets = {"basic": (1.0, 25000.0, [50.0, 10.0, -10.0, -50.0]), "ouza-tyoujyo": (0.0, 25000.0, [100.0, 40.0, -40.0, -100.0]),
+                       "ouza-normal": (0.0, 25000.0, [50.0, 20.0, -20.0, -50.0])}
         if rule_name not in presets:
-            raise ValueError(f"Unknown preset rule: {rule_name}")
+            raise ValueError(f"Unknown preset rule{' for 3P' if self._np == 3 else ''}: {rule_name}")
         w, base, uma = presets[rule_name]
         return [(s - base) / 1000.0 * w + uma[r - 1] for s, r in zip(self.scores(), self.ranks())]
 

@@ -82,3 +82,52 @@ def test_claim_priority_like_reference():
     env.step({1: Action(ActionType.CHI, tile=57, consume_tiles=[62, 65]), 2: Action(ActionType.PON, tile=57, consume_tiles=[56, 58])})
     assert env.phase == Phase.WaitAct and env.active_players == [2]
     assert env.mjai_log[-1]["type"] == "pon"
+
+
+def test_sanma_readme_loop_and_surface():
+    """3-player mode through the reference-named API: Observation3P surface (60-way space, 74 x 27 features) + loop."""
+    from riichienv_amd.compat import ActionType, RandomAgent, RiichiEnv
+
+    agent = RandomAgent(seed=3)
+    env = RiichiEnv(game_mode="3p-red-half", seed=11)
+    obs_dict = env.reset()
+    o = obs_dict[0]
+    assert env.num_players == 3 and len(o.hands) == 3 and len(o.mask()) == 60 and o.action_space_size() == 60
+    assert len(o.encode()) == 74 * 27 * 4 and len(o.encode_extended()) == 215 * 27 * 4
+    a = o.legal_actions()[0]
+    assert o.find_action(a.encode_3p()) is not None
+    steps = 0
+    seen_kita = False
+    while not env.done():
+        actions = {pid: agent.act(ob) for pid, ob in obs_dict.items()}
+        seen_kita = seen_kita or any(x.action_type == ActionType.KITA for x in actions.values())
+        obs_dict = env.step(actions)
+        steps += 1
+        assert steps < 6000
+    assert len(env.scores()) == 3 and sorted(env.ranks()) == [1, 2, 3] and len(env.points("basic")) == 3
+    assert sum(env.scores()) + 1000 * env.riichi_sticks == 105000
+    with pytest.raises(ValueError):
+        env.points("ouza-normal")
+    with pytest.raises(ValueError):
+        env.reset(scores=[1, 2, 3, 4])
+
+
+def test_observe_event_flow_like_reference():
+    """tests/env/test_apply_event.py (full-information variants) through compat.observe_event + select_action_from_mjai."""
+    from riichienv_amd.compat import ActionType, RiichiEnv
+    from tests.apply_events_util import TEHAIS_4P, start_kyoku
+
+    env = RiichiEnv(game_mode=0)
+    assert env.observe_event({"type": "start_game"}, 1) is None
+    assert env.observe_event(start_kyoku(TEHAIS_4P), 1) is None
+    assert env.observe_event({"type": "tsumo", "actor": 0, "pai": "4p"}, 1) is None      # another seat's draw
+    obs = env.observe_event({"type": "dahai", "actor": 0, "pai": "1m", "tsumogiri": False}, 1)
+    assert obs is not None and {ActionType.PON, ActionType.PASS} <= {a.action_type for a in obs.legal_actions()}
+    sel = obs.select_action_from_mjai({"type": "pon", "actor": 1, "target": 0, "pai": "1m", "consumed": ["1m", "1m"]})
+    assert sel is not None and sel.action_type == ActionType.PON
+    assert obs.select_action_from_mjai({"type": "none"}).action_type == ActionType.PASS
+    obs = env.observe_event({"type": "pon", "actor": 1, "target": 0, "pai": "1m", "consumed": ["1m", "1m"]}, 1)
+    assert obs is not None and any(a.action_type == ActionType.DISCARD for a in obs.legal_actions())
+    d = obs.select_action_from_mjai({"type": "dahai", "pai": "5s", "tsumogiri": False})
+    assert d is not None and d.tile // 4 == 22
+    assert env.observe_event({"type": "hora", "actor": 0, "target": 0}, 1) is None

@@ -292,7 +292,9 @@ int rmj_sync(rmj_handle h); /* wait for the handle's stream */
  * event per game as binary records (a start_kyoku is START_KYOKU + two TEHAI records; type NONE = no event for that
  * game).  Tile names are mapped to ids by the caller (parser.rs:336-385 mjai_to_tid; riichienv_amd/abi.py).  Afterwards
  * the observation outputs (status, legal lists, masks, waits) describe the new state like after rmj_step.
- * Scope: full-information streams (masked "?" tiles are not ingested); the caller-side mjai_log recording of
+ * Bit-exact parity is claimed for full-information streams; a masked "?" tile is mapped to tile 0 by the host mapper on
+ * request, like parse_mjai_tile (event_handler.rs:8-10), which leaves the masked seats in a garbage state in both
+ * implementations (only the observing seat's outputs are meaningful).  The caller-side mjai_log recording of
  * env.rs:56-72 is not reproduced (start_game clears the device log, later events are not appended). */
 int rmj_apply_events(rmj_handle h, const RmjEvent* events /*[n][3]*/);
 

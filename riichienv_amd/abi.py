@@ -92,10 +92,11 @@ EVENT_SLOTS = 3  # records per game and call of rmj_apply_events (start_kyoku = 
 _HONORS = ["E", "S", "W", "N", "P", "F", "C"]
 
 
-def mjai_to_tid(s: str) -> int:
+def mjai_to_tid(s: str, masked_ok: bool = False) -> int:
     """parser.rs:336-385 mjai_to_tid: one id per tile name (copy 0; plain 5 = copy 1, red 5 = copy 0).  The reference
-    maps an unparsable string (e.g. the masked "?") to tile 0 (parse_mjai_tile, event_handler.rs:8-10); masked streams
-    are outside this build's ingestion scope, so that case raises."""
+    maps an unparsable string (e.g. the masked "?") to tile 0 (parse_mjai_tile, event_handler.rs:8-10); with
+    masked_ok the same happens here (bot-side streams: the state of the masked seats is then garbage, as in the
+    reference, and only the observing seat's outputs are meaningful), otherwise it raises."""
     if s in _HONORS:
         return 108 + _HONORS.index(s) * 4
     if s in ("5mr", "5pr", "5sr"):
@@ -112,10 +113,12 @@ def mjai_to_tid(s: str) -> int:
             if 1 <= num <= 9:
                 base = si * 36 + (num - 1) * 4
                 return base + 1 if num == 5 else base
-    raise ValueError(f"cannot map MJAI tile {s!r} (masked or malformed tiles are not supported by rmj_apply_events)")
+    if masked_ok:
+        return 0
+    raise ValueError(f"cannot map MJAI tile {s!r} (pass masked_ok=True to ingest masked streams like the reference)")
 
 
-def event_records_from_mjai(ev: dict, num_players: int = 4):
+def event_records_from_mjai(ev: dict, num_players: int = 4, masked_ok: bool = False):
     """MJAI event dict (replay/mjai_replay.rs MjaiEvent) -> up to EVENT_SLOTS binary records for rmj_apply_events /
     the oracle.  Unknown event types map to a NONE record (MjaiEvent::Other: no state change)."""
     recs = (Event * EVENT_SLOTS)()
@@ -130,7 +133,7 @@ def event_records_from_mjai(ev: dict, num_players: int = 4):
         e.type = EV_START_KYOKU
         e.actor = int(ev["oya"])
         e.target = int(ev["kyoku"])
-        e.tile = mjai_to_tid(ev["dora_marker"])
+        e.tile = mjai_to_tid(ev["dora_marker"], masked_ok)
         kyotaku = int(ev.get("kyoutaku", ev.get("kyotaku", 0)))
         e.consumed[0] = "ESWN".index(ev["bakaze"]) if ev["bakaze"] in "ESWN" else 0
         e.consumed[1] = int(ev["honba"])
@@ -144,14 +147,14 @@ def event_records_from_mjai(ev: dict, num_players: int = 4):
             payload = []
             for q in range(2):
                 seat = 2 * half + q
-                hand = [mjai_to_tid(x) for x in tehais[seat]] if seat < min(num_players, len(tehais)) else [0] * 13
+                hand = [mjai_to_tid(x, masked_ok) for x in tehais[seat]] if seat < min(num_players, len(tehais)) else [0] * 13
                 if len(hand) != 13:
                     raise ValueError("start_kyoku: every tehai must hold 13 tiles")
                 payload += hand
             C.memmove(C.addressof(t) + 4, bytes(payload), 26)
     elif ty in ("tsumo", "dahai", "kakan"):
         e.type = {"tsumo": EV_TSUMO, "dahai": EV_DAHAI, "kakan": EV_KAKAN}[ty]
-        e.actor, e.tile = actor, mjai_to_tid(ev["pai"])
+        e.actor, e.tile = actor, mjai_to_tid(ev["pai"], masked_ok)
         if ty == "dahai":
             e.flags = 1 if ev.get("tsumogiri") else 0
     elif ty in ("pon", "chi", "daiminkan", "kan", "ankan"):
@@ -159,13 +162,13 @@ def event_records_from_mjai(ev: dict, num_players: int = 4):
         e.actor = actor
         e.target = int(ev.get("target", 0) or 0)
         if ty != "ankan":
-            e.tile = mjai_to_tid(ev["pai"])
-        cons = [mjai_to_tid(x) for x in ev["consumed"]][:4]
+            e.tile = mjai_to_tid(ev["pai"], masked_ok)
+        cons = [mjai_to_tid(x, masked_ok) for x in ev["consumed"]][:4]
         for i, c in enumerate(cons):
             e.consumed[i] = c
         e.flags = (len(cons) << 4) & 0xFF
     elif ty == "dora":
-        e.type, e.tile = EV_DORA, mjai_to_tid(ev["dora_marker"])
+        e.type, e.tile = EV_DORA, mjai_to_tid(ev["dora_marker"], masked_ok)
     else:
         e.type = EV_NONE
     return recs

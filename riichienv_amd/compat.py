@@ -300,7 +300,7 @@ class RiichiEnv:
 
     # ---- MJAI event ingestion (env.rs:880-948; full-information streams, see rmj_apply_events) -------------
     def apply_event(self, event):
-        self._v.apply_events([event])
+        self._v.apply_events([event], masked_ok=True)  # "?" -> tile 0 like parse_mjai_tile (event_handler.rs:8-10)
         if event.get("type") == "start_game":
             self._cursor = [0, 0, 0, 0]
 

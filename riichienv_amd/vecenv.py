@@ -177,7 +177,7 @@ class VecRiichiEnv:
         a = np.ascontiguousarray(actions, dtype=np.uint64).reshape(self.n, 4)
         _chk(self.L.rmj_step(self.h, a.ctypes.data))
 
-    def apply_events(self, events):
+    def apply_events(self, events, masked_ok=False):
         """RiichiEnv.apply_event (env.rs:880-887) for every game: `events[g]` is an MJAI dict, pre-built records
         (abi.event_records_from_mjai) or None (no event for game g)."""
         buf = (abi.Event * (abi.EVENT_SLOTS * self.n))()
@@ -185,7 +185,7 @@ class VecRiichiEnv:
         for g, ev in enumerate(events):
             if ev is None:
                 continue
-            recs = abi.event_records_from_mjai(ev, np_) if isinstance(ev, dict) else ev
+            recs = abi.event_records_from_mjai(ev, np_, masked_ok) if isinstance(ev, dict) else ev
             C.memmove(C.addressof(buf) + g * abi.EVENT_SLOTS * C.sizeof(abi.Event), C.addressof(recs),
                       abi.EVENT_SLOTS * C.sizeof(abi.Event))
         _chk(self.L.rmj_apply_events(self.h, C.addressof(buf)))

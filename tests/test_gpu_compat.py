@@ -131,3 +131,40 @@ def test_observe_event_flow_like_reference():
     d = obs.select_action_from_mjai({"type": "dahai", "pai": "5s", "tsumogiri": False})
     assert d is not None and d.tile // 4 == 22
     assert env.observe_event({"type": "hora", "actor": 0, "target": 0}, 1) is None
+
+
+def _masked(tehais, my_seat):
+    return [h if i == my_seat else ["?"] * 13 for i, h in enumerate(tehais)]
+
+
+def test_observe_event_masked_stream_like_reference():
+    """tests/env/test_apply_event.py:104-233 with the other seats' hands masked ("?"), the way a bot sees the stream."""
+    from riichienv_amd.compat import ActionType, RiichiEnv
+    from tests.apply_events_util import TEHAIS_3P, TEHAIS_4P, start_kyoku
+
+    env = RiichiEnv(game_mode=0)
+    env.observe_event({"type": "start_game"}, 1)
+    assert env.observe_event(start_kyoku(_masked(TEHAIS_4P, 1)), 1) is None
+    assert env.observe_event({"type": "tsumo", "actor": 0, "pai": "?"}, 1) is None
+    obs = env.observe_event({"type": "dahai", "actor": 0, "pai": "1m", "tsumogiri": True}, 1)
+    assert obs is not None and {ActionType.PON, ActionType.PASS} <= {a.action_type for a in obs.legal_actions()}
+    obs = env.observe_event({"type": "tsumo", "actor": 1, "pai": "6s"}, 1)      # after everybody passed
+    assert obs is not None and any(a.action_type == ActionType.DISCARD for a in obs.legal_actions())
+    assert len(obs.hand) == 14
+
+    env = RiichiEnv(game_mode=0)
+    env.observe_event({"type": "start_game"}, 0)
+    env.observe_event(start_kyoku(_masked(TEHAIS_4P, 0)), 0)
+    obs = env.observe_event({"type": "tsumo", "actor": 0, "pai": "4p"}, 0)
+    assert obs is not None
+    assert env.observe_event({"type": "dahai", "actor": 0, "pai": "4p", "tsumogiri": True}, 0) is None
+    assert env.observe_event({"type": "tsumo", "actor": 1, "pai": "?"}, 0) is None
+    obs = env.observe_event({"type": "dahai", "actor": 1, "pai": "4s", "tsumogiri": True}, 0)
+    assert obs is None or obs.legal_actions()
+
+    env = RiichiEnv(game_mode="3p-red-half")
+    env.observe_event({"type": "start_game"}, 1)
+    env.observe_event(start_kyoku(_masked(TEHAIS_3P, 1)), 1)
+    env.observe_event({"type": "tsumo", "actor": 0, "pai": "?"}, 1)
+    obs = env.observe_event({"type": "dahai", "actor": 0, "pai": "1p", "tsumogiri": False}, 1)
+    assert obs is not None and ActionType.PON in {a.action_type for a in obs.legal_actions()}

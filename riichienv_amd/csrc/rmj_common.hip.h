@@ -27,6 +27,17 @@ struct Env {
     ShantenTables sh;     // replacement-number tables (prefilter of the riichi probe)
 };
 
+// The Env record is immutable while a kernel runs.  Reading it through the CONSTANT address space tells the compiler so:
+// its fields are fetched with scalar loads (s_load, cached, no vmcnt stall) even after the kernel has stored to global
+// memory - through a generic `const Env&` every field access after a store was a vector global_load followed by
+// s_waitcnt vmcnt(0), i.e. a full memory round trip (and a wait for all outstanding stores) at every event emission.
+typedef const __attribute__((address_space(4))) Env CEnv;
+__device__ __forceinline__ ShantenTables sh_tables_of(CEnv& E) {
+    ShantenTables T;
+    T.rank9 = E.sh.rank9; T.rank7 = E.sh.rank7; T.suit = E.sh.suit; T.honor = E.sh.honor;
+    return T;
+}
+
 struct WaveScratch {      // per-wave LDS scratch
     uint64_t keys[136];
     uint8_t tiles[144];

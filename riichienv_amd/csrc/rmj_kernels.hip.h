@@ -29,7 +29,7 @@ __device__ __noinline__ void ol_step_full(CtxV v, uint64_t mine, uint32_t flags)
 #define RMJ_STEP_WAVES 8
 #endif
 __global__ __launch_bounds__(256, RMJ_STEP_WAVES) void k_step(const Env* __restrict__ Ep, const uint64_t* __restrict__ actions, uint64_t policy_seed, uint32_t flags) {
-    const Env& E = *Ep;  // device-resident: its address can travel to out-of-line code without a scratch copy
+    CEnv& E = *(CEnv*)Ep;  // device-resident record, read through the constant address space (see CEnv)
     __shared__ BlockShared sh;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const uint32_t g = blockIdx.x * WPB + wave;
@@ -96,7 +96,7 @@ __global__ __launch_bounds__(256, RMJ_STEP_WAVES) void k_step(const Env* __restr
 }
 
 __global__ __launch_bounds__(256, 4) void k_reset(const Env* __restrict__ Ep, ResetArgs A) {
-    const Env& E = *Ep;
+    CEnv& E = *(CEnv*)Ep;
     __shared__ BlockShared sh;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const uint32_t g = blockIdx.x * WPB + wave;
@@ -145,7 +145,7 @@ __global__ __launch_bounds__(256, 4) void k_reset(const Env* __restrict__ Ep, Re
 
 // rmj_apply_events: one MJAI event (up to three records) per game; games whose first record is NONE are left alone
 __global__ __launch_bounds__(256, 4) void k_apply_event(const Env* __restrict__ Ep, const RmjEvent* __restrict__ ev) {
-    const Env& E = *Ep;
+    CEnv& E = *(CEnv*)Ep;
     __shared__ BlockShared sh;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const uint32_t g = blockIdx.x * WPB + wave;
@@ -162,7 +162,7 @@ __global__ __launch_bounds__(256, 4) void k_apply_event(const Env* __restrict__ 
 
 // recompute observation outputs of one game after rmj_poke_state
 __global__ __launch_bounds__(64, 4) void k_refresh(const Env* __restrict__ Ep, uint32_t g) {
-    const Env& E = *Ep;
+    CEnv& E = *(CEnv*)Ep;
     __shared__ GState st;
     __shared__ WaveScratch x;
     const int lane = threadIdx.x & 63;

@@ -25,7 +25,7 @@ constexpr int KNP = KSANMA ? 3 : 4;        // seats in play; seat 3 is inert in 
 
 struct Ctx {
     GState& S;
-    const Env& E;
+    CEnv& E;
     WaveScratch& X;
     uint32_t g;
     int lane;
@@ -67,10 +67,10 @@ __device__ __forceinline__ uint64_t uni(uint64_t x) {
     return ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(x >> 32)) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)x);
 }
 #undef CTX_FROM
-#define CTX_FROM(v) Ctx c{*uni_ptr((v).S), *uni_ptr((v).E), *uni_ptr((v).X), uni((v).g), (v).lane, uni_ptr((v).W), uni_ptr((v).Lg)}
+#define CTX_FROM(v) Ctx c{*uni_ptr((v).S), *(CEnv*)uni_ptr((v).E), *uni_ptr((v).X), uni((v).g), (v).lane, uni_ptr((v).W), uni_ptr((v).Lg)}
 __device__ __forceinline__ CtxV ctx_pack(const Ctx& c) {
     CtxV v;
-    v.S = &c.S; v.X = &c.X; v.W = c.W; v.Lg = c.Lg; v.E = &c.E; v.g = c.g; v.lane = c.lane;
+    v.S = &c.S; v.X = &c.X; v.W = c.W; v.Lg = c.Lg; v.E = (const Env*)&c.E; v.g = c.g; v.lane = c.lane;
     return v;
 }
 
@@ -224,7 +224,7 @@ __device__ inline uint32_t base_cf(const PState& P) {
 // itself is kept: one draw lowers it by at most one, which lets the riichi probe skip hands that were >= 2 away.
 // (4P tables also for a sanma hand: it has no 2m-8m, for which the 4P number is a lower bound of the 3P one.)
 __device__ __forceinline__ uint64_t fill_waits13(Ctx& c, PState& P, const PH& h13) {
-    int sh = sh_shanten_wave(h13, P.hand_len / 3, c.E.sh, c.lane);
+    int sh = sh_shanten_wave(h13, P.hand_len / 3, sh_tables_of(c.E), c.lane);
     uint64_t W = 0ull;
     if (sh <= 0) W = wave_waits(h13, c.lane);
     P.waits13 = W;
@@ -518,7 +518,7 @@ __device__ __forceinline__ uint32_t tenpai_after_discard(Ctx& c, const PState& P
     // Sound prefilter: a tenpai 13-tile subset implies replacement number <= 1 for the 14 tiles
     // (swap the discard for the winning tile), i.e. shanten(14) <= 0.  Only then run the exact probes.
     // (4P tables; a sanma hand has no 2m-8m, for which the 4P number is a lower bound of the 3P one, so it is sound too)
-    if (sh_shanten_wave(full, hl / 3, c.E.sh, c.lane) > 0) return 0;
+    if (sh_shanten_wave(full, hl / 3, sh_tables_of(c.E), c.lane) > 0) return 0;
     int prev_ty = -1;
     bool prev_res = false;
     for (int j = 0; j < hl; j++) {

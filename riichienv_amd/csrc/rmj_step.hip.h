@@ -79,13 +79,14 @@ __device__ __forceinline__ CtxV ctx_pack(const Ctx& c) {
 __device__ __forceinline__ void emit_words(Ctx& c, uint32_t w0, uint32_t w1, uint32_t w2, uint32_t w3, uint32_t w4, uint32_t w5,
                                            uint32_t w6, uint32_t w7) {
     if (c.E.skip_log) return;
-    uint32_t idx = c.S.ev_count & c.E.ring_mask;
+    const uint32_t evc = (uint32_t)__builtin_amdgcn_readfirstlane((int)c.S.ev_count);  // wave-uniform: scalar address math
+    const uint32_t idx = evc & c.E.ring_mask;
     uint4* dst = reinterpret_cast<uint4*>(c.E.events + (size_t)c.g * (c.E.ring_mask + 1u) + idx);
     if (c.lane == 0) {
         dst[0] = make_uint4(w0, w1, w2, w3);
         dst[1] = make_uint4(w4, w5, w6, (w7 & 0x00FFFFFFu) | ((uint32_t)KNP << 24));  // pad byte = seats (formatter)
     }
-    c.S.ev_count += 1;
+    c.S.ev_count = evc + 1;
 }
 __device__ __forceinline__ void emit_raw(Ctx& c, const RmjEvent& ev) {  // rare paths (struct built on the stack)
     uint32_t p[8];
@@ -125,6 +126,26 @@ __device__ __forceinline__ void sort_hand(Ctx& c, PState& P, int n, int drop = -
     }
     if (mine) P.hand[r] = (uint8_t)t;
     if (drop >= 0 && drop < n) P.hand_len = (uint8_t)(n - 1);
+    wave_sync();
+}
+// hand.remove(drop); hand.sort() of the discard path when the hand is "n-1 sorted tiles + the drawn tile last" (always,
+// unless a test poked an unsorted hand: checked, general sort then): every tile knows its new slot from the position of
+// the removed tile and one comparison with the drawn tile; the drawn tile's slot is one ballot.  Same stable order as
+// sort_hand (equal ids keep their relative order).
+__device__ __forceinline__ void discard_sort(Ctx& c, PState& P, int n, int drop) {
+    const int lane = c.lane;
+    const int t = lane < n ? (int)P.hand[lane] : 0xFFFF;
+    const int nxt = __builtin_amdgcn_update_dpp(0xFFFF, t, 0x101 /* row_shl:1 */, 0xf, 0xf, false);
+    if (__ballot(lane < n - 2 && t > nxt)) {  // prefix not sorted
+        sort_hand(c, P, n, drop);
+        return;
+    }
+    const int d = __builtin_amdgcn_readlane(t, n - 1);
+    const int before_d = __popcll(__ballot(lane < n - 1 && lane != drop && t <= d));
+    int r = lane - (drop < lane ? 1 : 0) + ((drop != n - 1 && d < t) ? 1 : 0);
+    if (lane == n - 1) r = before_d;
+    if (lane < n && lane != drop) P.hand[r] = (uint8_t)t;
+    P.hand_len = (uint8_t)(n - 1);
     wave_sync();
 }
 // remove hand[idx] keeping order
@@ -1642,7 +1663,7 @@ __device__ __forceinline__ void step_game(Ctx& c, const uint64_t mine, bool trus
             int idx = hand_find(c, P, tile);
             PROF(c.X, lane, 20);
             if (idx >= 0) {
-                sort_hand(c, P, P.hand_len, idx);  // hand.remove(idx); hand.sort()
+                discard_sort(c, P, P.hand_len, idx);  // hand.remove(idx); hand.sort()
                 PROF(c.X, lane, 22);
                 valid = true;
             }
@@ -2032,12 +2053,13 @@ __device__ __forceinline__ void finalize_outputs(Ctx& c, bool claims_fresh) {
     }
     wave_sync();
     PROF(c.X, lane, 13);
-    // masks + list publication
+    // masks + list publication (only the seats that act have a list; a step usually has one)
+    const uint32_t am = (uint32_t)__builtin_amdgcn_readfirstlane((int)S.active_mask);
     for (int i = lane; i < (4 * 82 + 3) / 4; i += 64) reinterpret_cast<uint32_t*>(c.X.maskbuf)[i] = 0u;
     wave_sync();
-    for (int p = 0; p < 4; p++) {
-        int n = c.X.nl[p];
-        if (!((S.active_mask >> p) & 1u)) n = 0;
+    for (uint32_t m = am; m; m &= m - 1u) {
+        const int p = __ffs((int)m) - 1;
+        const int n = c.X.nl[p];
         if (lane < n) {
             uint64_t a = c.X.legal[p][lane];
             c.Lg[p * RMJ_MAX_LEGAL + lane] = a;
@@ -2049,19 +2071,11 @@ __device__ __forceinline__ void finalize_outputs(Ctx& c, bool claims_fresh) {
     uint32_t* mout = reinterpret_cast<uint32_t*>(c.E.mask + (size_t)c.g * 328);
     for (int i = lane; i < 82; i += 64) mout[i] = reinterpret_cast<const uint32_t*>(c.X.maskbuf)[i];
     if (lane < 4) {
-        int n = c.X.nl[0];
-        n = lane == 1 ? c.X.nl[1] : n;
-        n = lane == 2 ? c.X.nl[2] : n;
-        n = lane == 3 ? c.X.nl[3] : n;
-        if (!((S.active_mask >> lane) & 1u)) n = 0;
+        const bool acts = (am >> lane) & 1u;
+        const int n = acts ? c.X.nl[lane] : 0;
         c.E.nlegal[(size_t)c.g * 4 + lane] = (uint8_t)n;
         S.nlegal[lane] = (uint8_t)n;
-        uint64_t w = c.X.wout[0];
-        w = lane == 1 ? c.X.wout[1] : w;
-        w = lane == 2 ? c.X.wout[2] : w;
-        w = lane == 3 ? c.X.wout[3] : w;
-        if (!((S.active_mask >> lane) & 1u)) w = 0;
-        c.E.waits[(size_t)c.g * 4 + lane] = w;
+        c.E.waits[(size_t)c.g * 4 + lane] = acts ? c.X.wout[lane] : 0ull;
     }
     if (lane == 0) c.E.status[c.g] = (uint32_t)S.active_mask | ((uint32_t)S.phase << 8) | ((uint32_t)S.is_done << 16);
     PROF(c.X, lane, 14);

@@ -333,7 +333,7 @@ __device__ __forceinline__ int sh_shanten_wave(const PH& h, int len_div3, const 
     if (valid)
         e = sh_merge_entry((uint32_t)x & 0xFFFFFu, (uint32_t)(x >> 20) & 0xFFFFFu, (uint32_t)y & 0xFFFFFu, (uint32_t)(y >> 20) & 0xFFFFFu,
                            upper ? 1 - p : p, upper ? m - k : k);
-    const uint32_t partner = (uint32_t)__shfl_down((int)e, 16, 64);
+    const uint32_t partner = (uint32_t)__builtin_amdgcn_ds_bpermute(((lane + 16) & 63) << 2, (int)e);  // value of lane + 16
     uint32_t t = (valid && !upper) ? e + partner : 99u;
     t = row_min16(t);
     uint32_t rep = (uint32_t)__builtin_amdgcn_readlane((int)t, 15);

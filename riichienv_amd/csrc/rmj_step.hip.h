@@ -614,15 +614,14 @@ __device__ __forceinline__ void gen_act_legal(Ctx& c, int pid) {
     const PH full = build_ph_wave(P, lane);  // shared by the riichi probe and the kan checks
     // 2. Discard / Riichi
     uint8_t ht = lane < hl ? P.hand[lane] : 0xFF;
-    bool forb = false;
-    for (int f = 0; f < P.n_forbidden; f++) forb = forb || ((P.forbidden[f] >> 2) == (ht >> 2));
+    const int nforb = P.n_forbidden;  // at most two entries (kuikae)
+    const bool forb = (nforb > 0 && (P.forbidden[0] >> 2) == (ht >> 2)) || (nforb > 1 && (P.forbidden[1] >> 2) == (ht >> 2));
     if (r_decl) {
         if (drawn) put_legal(c, pid, n++, mk_action(RMJ_DISCARD, S.drawn_tile, 0));
     } else {
         uint32_t tp = 0;
         bool need_tp = r_stage;
-        bool all_closed = true;
-        for (int i = 0; i < P.n_melds; i++) all_closed = all_closed && (P.meld_type[i] == RMJ_MELD_ANKAN);
+        const bool all_closed = __ballot(lane < P.n_melds && P.meld_type[lane & 3] != RMJ_MELD_ANKAN) == 0ull;
         // quirk Q8: >= 4 in 4P, > 0 in 3P
         bool riichi_pre = !r_stage && P.score >= 1000 && (KSANMA ? S.drawable_count > 0 : S.drawable_count >= 4) && all_closed;
         if (need_tp || riichi_pre) {

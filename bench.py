@@ -60,6 +60,9 @@ def main():
     ap.add_argument("--games", type=int, default=65536, help="games per GPU")
     ap.add_argument("--mode", type=int, default=2, help="0/1/2 = 4p-red-single/east/half, 3/4/5 = 3p-red-single/east/half")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--encode", action="store_true",
+                    help="also produce the feature tensor of the acting seats every step (BASELINE configs[4]: sanma with "
+                         "feature-encoding tensor output); reported in config, the step kernel's roofline is unchanged")
     args = ap.parse_args()
 
     import torch
@@ -91,7 +94,21 @@ def main():
 
     barrier()
     t0 = time.perf_counter()
-    r = env.bench_rollout(policy_seed, 0, args.steps)   # exactly K launches, HIP events on the kernel's stream
+    if args.encode:
+        import ctypes as C
+
+        w = 27 if args.mode >= 3 else 34
+        obs = torch.zeros((args.games, 4, 74, w), dtype=torch.float32, device=f"cuda:{local_rank}")
+        before = env.total_steps()
+        r = None
+        for _ in range(args.steps):   # one step launch + one encode launch per step, same stream, no host sync in between
+            rr = env.bench_rollout(policy_seed, 0, 1)
+            r = rr if r is None else r
+            vecenv._chk(env.L.rmj_encode_device(env.h, 2, C.c_void_p(obs.data_ptr())))
+        env.total_steps()
+        r.env_steps = env.total_steps() - before
+    else:
+        r = env.bench_rollout(policy_seed, 0, args.steps)   # exactly K launches, HIP events on the kernel's stream
     barrier()
     t1 = time.perf_counter()
     wall = t1 - t0
@@ -110,7 +127,8 @@ def main():
             "scaling": "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
             "config": {"workload": f"{args.games} parallel {['4p-red-single','4p-red-east','4p-red-half','3p-red-single','3p-red-east','3p-red-half'][args.mode]} "
                                    "games per GPU, device RandomAgent, auto-reset, MJAI logging on",
-                       "games_per_gpu": args.games, "sharding": "by game index, no collectives"},
+                       "games_per_gpu": args.games, "sharding": "by game index, no collectives",
+                       "feature_tensor_output": bool(args.encode)},
             "roofline": {"bound": "hbm", "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK, "traffic": traffic, "traffic_unit": "bytes/launch",
                          "traffic_source": traffic_src, "kernel": "k_step",

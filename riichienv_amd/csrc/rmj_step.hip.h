@@ -240,14 +240,35 @@ __device__ inline uint32_t base_cf(const PState& P) {
     return cf;
 }
 
+// Number of ISOLATED tiles of a wave-uniform hand: a kind held exactly once with nothing within two ranks in its suit
+// (honors: held exactly once).  Such a tile belongs to no set, pair or taatsu.  lane = tile type.
+__device__ __forceinline__ int isolated_tiles(const PH& h, int lane) {
+    const int s = lane < 34 ? t_suit(lane) : 3, r = lane - 9 * s;
+    const uint32_t x = ph_get(h, s);
+    const uint32_t nz = (x | (x >> 1) | (x >> 2)) & O9_1;        // bit 3j set iff rank j is held
+    const uint32_t win = (nz << 6) >> (3 * r);                    // rank r-2 -> bit 0, r-1 -> 3, r -> 6, r+1 -> 9, r+2 -> 12
+    const bool alone = s == 3 || (win & 0x1209u) == 0u;
+    return __popcll(__ballot(lane < 34 && ((x >> (3 * r)) & 7u) == 1u && alone));
+}
 // Fill the seat's wait cache from the histogram of its 13 tiles.  The table shanten goes first: a hand with a wait has
 // shanten 0, so shanten > 0 means "no waits" without running the probe (most hands, most of the time), and the number
 // itself is kept: one draw lowers it by at most one, which lets the riichi probe skip hands that were >= 2 away.
+// In front of the tables sits a pure-ALU bound: four isolated tiles leave at most nine tiles for blocks, i.e. standard
+// shanten >= 8 - 2*3 = 2, chiitoi shanten >= 6 - 4 = 2 (at most four pairs), and kokushi is excluded by its kind count -
+// most hands of a random rollout stop there, without any table access.
 // (4P tables also for a sanma hand: it has no 2m-8m, for which the 4P number is a lower bound of the 3P one.)
 __device__ __forceinline__ uint64_t fill_waits13(Ctx& c, PState& P, const PH& h13) {
-    int sh = sh_shanten_wave(h13, P.hand_len / 3, sh_tables_of(c.E), c.lane);
+    int sh;
     uint64_t W = 0ull;
-    if (sh <= 0) W = wave_waits(h13, c.lane);
+    const uint32_t T9 = 1u | (1u << 24);
+    const int yaochu_kinds = __popc((h13.a | (h13.a >> 1) | (h13.a >> 2)) & T9) + __popc((h13.b | (h13.b >> 1) | (h13.b >> 2)) & T9) +
+                             __popc((h13.c | (h13.c >> 1) | (h13.c >> 2)) & T9) + __popc((h13.d | (h13.d >> 1) | (h13.d >> 2)) & O7_1);
+    if (isolated_tiles(h13, c.lane) >= 4 && yaochu_kinds < 11) {
+        sh = 2;  // a lower bound is all the users of sh13 need
+    } else {
+        sh = sh_shanten_wave(h13, P.hand_len / 3, sh_tables_of(c.E), c.lane);
+        if (sh <= 0) W = wave_waits(h13, c.lane);
+    }
     P.waits13 = W;
     P.sh13 = (uint8_t)(sh < 0 ? 0 : sh);
     P.flags |= PF_WAITS_VALID;

@@ -23,10 +23,16 @@ using namespace rmj;
 #define STEP_F_AUTORESET 2u
 #define STEP_F_IDS 4u /* `actions` holds int32 action ids [n][4] (Observation.find_action semantics) */
 
-struct BlockShared {
-    GState st[WPB];
-    WaveScratch x[WPB];
+template <int N>
+struct BlockSharedT {
+    GState st[N];
+    WaveScratch x[N];
 };
+typedef BlockSharedT<WPB> BlockShared;
+#ifndef RMJ_STEP_WPB
+#define RMJ_STEP_WPB 1 /* games (= waves) per block of the step kernel: single-wave blocks release their LDS as soon as the game is done (a block of four waited for its slowest game) */
+#endif
+static inline dim3 step_grid(uint32_t n) { return dim3((n + RMJ_STEP_WPB - 1) / RMJ_STEP_WPB); }
 
 __device__ __forceinline__ void load_state(GState& S, const GState* src, int lane) {
     if (lane < (int)(sizeof(GState) / 16)) reinterpret_cast<uint4*>(&S)[lane] = reinterpret_cast<const uint4*>(src)[lane];
@@ -523,8 +529,8 @@ int rmj_reset(rmj_handle h, const uint8_t* select, const uint8_t* walls, const u
 int rmj_step_device(rmj_handle h, const rmj_action_t* d_actions) {
     if (!h || !d_actions) return fail(RMJ_ERR_ARG, "null argument");
     HIPCHK(hipSetDevice(h->cfg.device));
-    if (h->cfg.game_mode >= 3) hipLaunchKernelGGL(rmj3::k_step, game_grid(h->cfg.n_games), dim3(256), 0, h->stream, (const Env*)h->d_env, (const uint64_t*)d_actions, 0ull, 0u);
-    else hipLaunchKernelGGL(rmj4::k_step, game_grid(h->cfg.n_games), dim3(256), 0, h->stream, (const Env*)h->d_env, (const uint64_t*)d_actions, 0ull, 0u);
+    if (h->cfg.game_mode >= 3) hipLaunchKernelGGL(rmj3::k_step, step_grid(h->cfg.n_games), dim3(64 * RMJ_STEP_WPB), 0, h->stream, (const Env*)h->d_env, (const uint64_t*)d_actions, 0ull, 0u);
+    else hipLaunchKernelGGL(rmj4::k_step, step_grid(h->cfg.n_games), dim3(64 * RMJ_STEP_WPB), 0, h->stream, (const Env*)h->d_env, (const uint64_t*)d_actions, 0ull, 0u);
     HIPCHK(hipGetLastError());
     return RMJ_OK;
 }
@@ -535,8 +541,8 @@ int rmj_step_ids_device(rmj_handle h, const int32_t* d_action_ids, int auto_rese
     if (!h || !d_action_ids) return fail(RMJ_ERR_ARG, "null argument");
     HIPCHK(hipSetDevice(h->cfg.device));
     const uint32_t flags = STEP_F_IDS | (auto_reset ? STEP_F_AUTORESET : 0u);
-    if (h->cfg.game_mode >= 3) hipLaunchKernelGGL(rmj3::k_step, game_grid(h->cfg.n_games), dim3(256), 0, h->stream, (const Env*)h->d_env, reinterpret_cast<const uint64_t*>(d_action_ids), 0ull, flags);
-    else hipLaunchKernelGGL(rmj4::k_step, game_grid(h->cfg.n_games), dim3(256), 0, h->stream, (const Env*)h->d_env, reinterpret_cast<const uint64_t*>(d_action_ids), 0ull, flags);
+    if (h->cfg.game_mode >= 3) hipLaunchKernelGGL(rmj3::k_step, step_grid(h->cfg.n_games), dim3(64 * RMJ_STEP_WPB), 0, h->stream, (const Env*)h->d_env, reinterpret_cast<const uint64_t*>(d_action_ids), 0ull, flags);
+    else hipLaunchKernelGGL(rmj4::k_step, step_grid(h->cfg.n_games), dim3(64 * RMJ_STEP_WPB), 0, h->stream, (const Env*)h->d_env, reinterpret_cast<const uint64_t*>(d_action_ids), 0ull, flags);
     HIPCHK(hipGetLastError());
     return RMJ_OK;
 }
@@ -582,8 +588,8 @@ int rmj_step_random(rmj_handle h, uint64_t policy_seed, uint32_t n_steps, int au
 #else
         const unsigned extra_lds = 0u;
 #endif
-        if (h->cfg.game_mode >= 3) hipLaunchKernelGGL(rmj3::k_step, game_grid(h->cfg.n_games), dim3(256), extra_lds, h->stream, (const Env*)h->d_env, (const uint64_t*)nullptr, policy_seed, flags);
-        else hipLaunchKernelGGL(rmj4::k_step, game_grid(h->cfg.n_games), dim3(256), extra_lds, h->stream, (const Env*)h->d_env, (const uint64_t*)nullptr, policy_seed, flags);
+        if (h->cfg.game_mode >= 3) hipLaunchKernelGGL(rmj3::k_step, step_grid(h->cfg.n_games), dim3(64 * RMJ_STEP_WPB), extra_lds, h->stream, (const Env*)h->d_env, (const uint64_t*)nullptr, policy_seed, flags);
+        else hipLaunchKernelGGL(rmj4::k_step, step_grid(h->cfg.n_games), dim3(64 * RMJ_STEP_WPB), extra_lds, h->stream, (const Env*)h->d_env, (const uint64_t*)nullptr, policy_seed, flags);
     }
     HIPCHK(hipGetLastError());
     return RMJ_OK;

@@ -28,11 +28,11 @@ __device__ __noinline__ void ol_step_full(CtxV v, uint64_t mine, uint32_t flags)
 #ifndef RMJ_STEP_WAVES
 #define RMJ_STEP_WAVES 8
 #endif
-__global__ __launch_bounds__(256, RMJ_STEP_WAVES) void k_step(const Env* __restrict__ Ep, const uint64_t* __restrict__ actions, uint64_t policy_seed, uint32_t flags) {
+__global__ __launch_bounds__(64 * RMJ_STEP_WPB, RMJ_STEP_WAVES) void k_step(const Env* __restrict__ Ep, const uint64_t* __restrict__ actions, uint64_t policy_seed, uint32_t flags) {
     CEnv& E = *(CEnv*)Ep;  // device-resident record, read through the constant address space (see CEnv)
-    __shared__ BlockShared sh;
+    __shared__ BlockSharedT<RMJ_STEP_WPB> sh;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const uint32_t g = blockIdx.x * WPB + wave;
+    const uint32_t g = blockIdx.x * RMJ_STEP_WPB + wave;
     if (g >= E.n_games) return;
     GState& S = sh.st[wave];
     PROF_START(sh.x[wave], lane);

@@ -86,8 +86,14 @@ __global__ __launch_bounds__(64 * RMJ_STEP_WPB, RMJ_STEP_WAVES) void k_step(cons
     }
     if (c.bail) {
         PROF(c.X, lane, 26);
+#ifdef RMJ_PROFILE
+        const uint64_t t_full = __builtin_readcyclecounter();
+#endif
         ol_step_full(ctx_pack(c), mine, flags);
         PROF(c.X, lane, 25);
+#ifdef RMJ_PROFILE
+        if (lane == 0) { c.X.pacc[28] += (uint32_t)(__builtin_readcyclecounter() - t_full); c.X.pacc[32 + 28] += 1u; }
+#endif
     } else {
         store_state(S, E.core + g, lane);
     }

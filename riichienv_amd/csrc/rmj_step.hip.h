@@ -839,23 +839,78 @@ __device__ __forceinline__ void deal_next(Ctx& c) {
     }
 }
 
-// the build's seed -> wall definition (oracle/riichi_state.hpp build_wall); writes W[0..135] (already reversed)
+// the build's seed -> wall definition (oracle/riichi_state.hpp build_wall); writes W[0..135] (already reversed):
+// ids sorted by (key, id), key_i = splitmix64(hs + i * phi).  The rank of a tile is found with a 128-bucket counting
+// pass on the top 7 key bits (LDS atomics + one wave scan) and an exact (key, id) comparison inside its own bucket
+// (about one member on average) instead of 136 comparisons per tile: the round restart is the longest thing a wave
+// ever does, and its tail sets the duration of the launch.
 __device__ inline void shuffle_wall(Ctx& c) {
     GState& S = c.S;
+    const int lane = c.lane;
     uint64_t hs = sm64(S.wall_seed + (uint64_t)S.hand_index);
     S.hand_index += 1;
     const int N = KSANMA ? 108 : 136;  // 3P: ids without 2m-8m (types.rs:378-382)
-    for (int i = c.lane; i < N; i += 64) c.X.keys[i] = sm64(hs + (uint64_t)i * 0x9E3779B97F4A7C15ull);
+    // scratch (free until finalize): grouped keys in X.legal[0..135], bucket counters behind them, source index in maskbuf
+    uint64_t* gk = &c.X.legal[0][0];
+    uint32_t* cnt = reinterpret_cast<uint32_t*>(&c.X.legal[0][0] + 144);  // 129 counters (+1 sentinel)
+    uint8_t* gi = c.X.maskbuf;
+    for (int q = lane; q < 130; q += 64) cnt[q] = 0u;
+    uint64_t key[3];
+    uint32_t pos[3];
+#pragma unroll
+    for (int q = 0; q < 3; q++) {
+        const int i = lane + 64 * q;
+        key[q] = sm64(hs + (uint64_t)i * 0x9E3779B97F4A7C15ull);
+    }
     wave_sync();
-    for (int i = c.lane; i < N; i += 64) {
-        uint64_t k = c.X.keys[i];
-        int r = 0;
-        for (int j = 0; j < N; j++) {
-            uint64_t kj = c.X.keys[j];
-            r += (kj < k) || (kj == k && j < i);
+#pragma unroll
+    for (int q = 0; q < 3; q++) {
+        const int i = lane + 64 * q;
+        pos[q] = i < N ? atomicAdd(&cnt[(uint32_t)(key[q] >> 57)], 1u) : 0u;
+    }
+    wave_sync();
+    {   // exclusive prefix sum over the 128 buckets (two per lane), written back in place; cnt[128] = N
+        const uint32_t v0 = cnt[2 * lane], v1 = cnt[2 * lane + 1];
+        uint32_t incl = v0 + v1;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            uint32_t up = (uint32_t)__shfl_up((int)incl, off, 64);
+            if (lane >= off) incl += up;
         }
-        int id = (KSANMA && i >= 4) ? i + 28 : i;  // i-th id of the tile universe
-        c.X.tiles[N - 1 - r] = (uint8_t)id;  // w[r] = id, then reverse
+        const uint32_t excl = incl - (v0 + v1);
+        wave_sync();
+        cnt[2 * lane] = excl;
+        cnt[2 * lane + 1] = excl + v0;
+        if (lane == 63) cnt[128] = incl;
+    }
+    wave_sync();
+#pragma unroll
+    for (int q = 0; q < 3; q++) {
+        const int i = lane + 64 * q;
+        if (i < N) {
+            const uint32_t slot = cnt[(uint32_t)(key[q] >> 57)] + pos[q];
+            gk[slot] = key[q];
+            gi[slot] = (uint8_t)i;
+        }
+    }
+    wave_sync();
+#pragma unroll
+    for (int q = 0; q < 3; q++) {
+        const int sl = lane + 64 * q;
+        if (sl < N) {
+            const uint64_t k = gk[sl];
+            const int i = gi[sl];
+            const uint32_t bkt = (uint32_t)(k >> 57);
+            const int lo = (int)cnt[bkt], hi = (int)cnt[bkt + 1];
+            int r = lo;
+            for (int t = lo; t < hi; t++) {
+                const uint64_t kt = gk[t];
+                const int it = gi[t];
+                r += (kt < k) || (kt == k && it < i);
+            }
+            const int id = (KSANMA && i >= 4) ? i + 28 : i;  // i-th id of the tile universe
+            c.X.tiles[N - 1 - r] = (uint8_t)id;               // w[r] = id, then reverse
+        }
     }
     wave_sync();
 }

@@ -17,7 +17,7 @@ NAMES = {0: "load_state", 1: "policy pick", 2: "validate", 3: "WaitAct pre (find
          8: "(gap) step->finalize", 9: "act_legal: waits+tsumo", 10: "act_legal: discard/riichi probe",
          11: "act_legal: kan", 12: "act_legal: kyushu/kita", 13: "finalize: pre-publication", 14: "finalize: mask/list/status",
          15: "store_state",          20: "pre: hand_find", 21: "pre: remove_at", 22: "pre: sort", 23: "deal: accept/abortive", 24: "deal: deal_next", 25: "FULL PATH (ol_step_full)", 26: "fast-path tail before bail",
-         16: "claims A: cache refill", 17: "claims B: ron eligibility", 18: "claims C: pon/kan", 19: "claims D: chi", 27: "claims E: tail"}
+         16: "claims A: cache refill", 17: "claims B: ron eligibility", 18: "claims C: pon/kan", 19: "claims D: chi", 27: "claims E: tail", 28: "FULL PATH total (overlaps inner sections)"}
 
 
 def main():

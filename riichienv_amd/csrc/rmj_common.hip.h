@@ -39,7 +39,6 @@ __device__ __forceinline__ ShantenTables sh_tables_of(CEnv& E) {
 }
 
 struct WaveScratch {      // per-wave LDS scratch
-    uint64_t keys[136];
     uint8_t tiles[144];
     uint8_t maskbuf[4 * 82 + 8];
     uint64_t legal[4][RMJ_MAX_LEGAL];  // lists produced this launch (copied to HBM by finalize_outputs)

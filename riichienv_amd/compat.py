@@ -259,6 +259,42 @@ class Observation:
     def encode_extended(self) -> bytes:  # observation/python.rs:1271-1296 -> 215 x 34 (3P: 215 x 27) f32
         return self._ext_encoder(self.player_id).tobytes()
 
+    # ---- the separately exposed feature blocks of the reference = slices of the extended tensor
+    #      (observation/python.rs:183-236, 808-875, 927-1268 restate the blocks of observation/encode.rs:293-585)
+    def _ext(self):
+        w = 27 if self.num_players == 3 else 34
+        return np.frombuffer(self.encode_extended(), dtype=np.float32).reshape(215, w)
+
+    def encode_discard_history_decay(self, decay_rate=None) -> bytes:  # (np, W)
+        if decay_rate is not None and abs(decay_rate - 0.2) > 1e-12:
+            raise NotImplementedError("the device table holds exp(-0.2 * age); other decay rates are not built")
+        return self._ext()[74:74 + self.num_players].tobytes()
+
+    def encode_shanten_efficiency(self) -> bytes:  # (np, 4): shanten, effective tiles, best ukeire, turn
+        e = self._ext()
+        return np.ascontiguousarray(e[78:78 + 4 * self.num_players, 0].reshape(self.num_players, 4)).tobytes()
+
+    def encode_ankan_overview(self) -> bytes:  # (np, W)
+        return self._ext()[94:94 + self.num_players].tobytes()
+
+    def encode_fuuro_overview(self) -> bytes:  # (np, 4, 5, W)
+        return self._ext()[98:98 + 20 * self.num_players].tobytes()
+
+    def encode_action_availability(self) -> bytes:  # (11,)
+        return np.ascontiguousarray(self._ext()[178:189, 0]).tobytes()
+
+    def encode_discard_candidates(self) -> bytes:  # (5,)
+        return np.ascontiguousarray(self._ext()[189:194, 0]).tobytes()
+
+    def encode_pass_context(self) -> bytes:  # (3,)
+        return np.ascontiguousarray(self._ext()[194:197, 0]).tobytes()
+
+    def encode_last_tedashis(self) -> bytes:  # (np - 1, 3)
+        return np.ascontiguousarray(self._ext()[197:197 + 3 * (self.num_players - 1), 0]).tobytes()
+
+    def encode_riichi_sutehais(self) -> bytes:  # (np - 1, 3)
+        return np.ascontiguousarray(self._ext()[206:206 + 3 * (self.num_players - 1), 0]).tobytes()
+
     def legal_actions(self):  # observation/python.rs:93-96
         return list(self._legal_actions)
 

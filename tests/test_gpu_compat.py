@@ -168,3 +168,22 @@ def test_observe_event_masked_stream_like_reference():
     env.observe_event({"type": "tsumo", "actor": 0, "pai": "?"}, 1)
     obs = env.observe_event({"type": "dahai", "actor": 0, "pai": "1p", "tsumogiri": False}, 1)
     assert obs is not None and ActionType.PON in {a.action_type for a in obs.legal_actions()}
+
+
+def test_feature_block_accessors_match_reference_shapes():
+    """tests/env/test_apply_event.py:test_encode_shanten_efficiency_handles_quad_draw (len 64 / 48) and the block layout."""
+    import numpy as np
+
+    from riichienv_amd.compat import RiichiEnv
+
+    for mode, npl, w in ((0, 4, 34), ("3p-red-half", 3, 27)):
+        env = RiichiEnv(game_mode=mode, seed=5)
+        o = env.reset()[0]
+        assert len(o.encode_shanten_efficiency()) == 4 * 4 * npl        # 64 (4P) / 48 (3P) bytes
+        eff = np.frombuffer(o.encode_shanten_efficiency(), np.float32).reshape(npl, 4)
+        assert (eff[1:, :3] == 0.5).all() and 0 <= eff[0, 0] <= 1
+        assert len(o.encode_discard_history_decay()) == npl * w * 4 and len(o.encode_fuuro_overview()) == npl * 20 * w * 4
+        assert len(o.encode_action_availability()) == 44 and len(o.encode_discard_candidates()) == 20
+        assert len(o.encode_last_tedashis()) == (npl - 1) * 12 and len(o.encode_pass_context()) == 12
+        cand = np.frombuffer(o.encode_discard_candidates(), np.float32)
+        assert abs(cand[0] - 14 / 34.0) < 1e-7

@@ -519,11 +519,106 @@ def sc_tobi_and_agariyame(make):
     assert [e["type"] for e in evs(env)][-2:] == ["end_kyoku", "end_game"]
 
 
+
+# -- transcribed from tests/env/rule_validation/test_furiten_rules.py, test_temporary_furiten.py, test_valid_ankan.py,
+#    tests/env/test_riichi_no_claims.py, tests/env/test_honba_reset.py --------------------------------------
+_SAFE1 = tiles("147m258p369s2345z")[0:13]   # hands that cannot claim anything used below
+_SAFE2 = tiles("147m258p369s4567z")[0:13]
+
+
+def sc_furiten_ron(make):
+    """test_furiten_rules.py:4-90 / :93-127: a wait tile among the own discards kills Ron on ANY wait; without it Ron is offered."""
+    hand0 = [4, 8, 52, 53, 60, 61, 62, 92, 93, 94, 108, 109, 110]           # 23m 55p 666p 888s 111z: waits 1m / 4m
+    for own_discards, expect_ron in (([0], False), ([], True)):
+        env = setup(make(game_mode=2), hands=[hand0, _SAFE1, _SAFE2, tiles("19m19p19s1236677z")[0:13]],
+                    current_player=1, active_players=[1], drawn_tile=12, discards=[own_discards, [], [], []], wall=list(range(136)))
+        env.step({1: pack_action(DISCARD, 12)})                            # 4m
+        act, ph, dn = env.status()
+        if expect_ron:
+            assert ph == WAIT_RESPONSE and (act & 1) and find(env.legal(0), RON) is not None
+        else:
+            assert not (act & 1)                                           # no Ron, and nothing else to claim
+
+
+def sc_temporary_furiten(make):
+    """test_temporary_furiten.py:11-66: passing an offered Ron sets missed_agari_doujun; the same tile from the next
+    player is not offered again (same go-around)."""
+    h3 = [4, 8, 12, 40, 44, 48, 76, 80, 84, 92, 93, 94, 96]                 # 234m 234p 234s 66s 67s: waits 5s / 8s
+    h1 = _SAFE1[:12] + [88]
+    h2 = _SAFE2[:12] + [89]
+    env = setup(make(game_mode=2), hands=[tiles("19m19p19s1234567z")[0:13], h1, h2, h3], current_player=1,
+                active_players=[1], drawn_tile=135, wall=list(range(136)), mutate=lambda v: setattr(v, "is_first_turn", 0))
+    env.step({1: pack_action(DISCARD, 88)})                                 # 5s (red)
+    act, ph, dn = env.status()
+    assert ph == WAIT_RESPONSE and (act >> 3) & 1 and find(env.legal(3), RON) is not None
+    env.step({s: pack_action(PASS) for s in range(4) if (act >> s) & 1})
+    v = env.peek()
+    assert v.players[3].missed_agari_doujun == 1
+    assert v.current_player == 2 and v.phase == WAIT_ACT                    # seat 2 drew
+    env.step({2: pack_action(DISCARD, 89)})                                 # 5s again, same go-around
+    act, ph, dn = env.status()
+    assert not ((act >> 3) & 1) or find(env.legal(3), RON) is None
+
+
+def sc_valid_ankan_after_riichi(make):
+    """test_valid_ankan.py:7-28: after riichi an ankan that keeps the waits is legal (hand 2m2m 9p9p9p(+1) 1s1s1s 5s5s5s 7s7s)."""
+    h2 = [4, 5, 68, 69, 71, 73, 74, 75, 88, 89, 90, 97, 98]
+    env = setup(make(game_mode=2), hands=[_SAFE1, _SAFE2, h2, tiles("19m19p19s1236677z")[0:13]], current_player=2,
+                active_players=[2], drawn_tile=70, riichi_declared=[False, False, True, False], wall=list(range(136)))
+    ank = [a for a in env.legal(2) if unpack_action(a)[0] == ANKAN]
+    assert len(ank) == 1 and sorted(unpack_action(ank[0])[2]) == [68, 69, 70, 71]
+
+
+def sc_no_claims_during_riichi(make):
+    """test_riichi_no_claims.py:6-88: a riichi player is offered neither Chi nor Pon; without riichi Chi is offered."""
+    for tile, h2, riichi, want in ((72, [76, 80, 4, 8, 12, 16, 20, 24, 28, 32, 36, 40, 44], True, None),
+                                   (72, [76, 80, 4, 8, 12, 16, 20, 24, 28, 32, 36, 40, 44], False, CHI),
+                                   (78, [76, 77, 4, 8, 12, 16, 20, 24, 28, 32, 36, 40, 44], True, None)):
+        h = [list(range(13)) for _ in range(4)]
+        h[1] = [tile] + list(range(12))
+        h[2] = h2
+        env = setup(make(game_mode=2), hands=h, current_player=1, active_players=[1], drawn_tile=tile,
+                    riichi_declared=[False, False, riichi, False], wall=list(range(136)))
+        env.step({1: pack_action(DISCARD, tile)})
+        act, ph, dn = env.status()
+        kinds = {unpack_action(a)[0] for a in env.legal(2)} if (act >> 2) & 1 else set()
+        if want is None:
+            assert CHI not in kinds and PON not in kinds
+            assert ph == WAIT_ACT and act == 0b0100                        # seat 2 simply drew
+        else:
+            assert ph == WAIT_RESPONSE and want in kinds
+
+
+def sc_honba_reset_and_increment(make):
+    """test_honba_reset.py:4-73: a non-dealer win resets honba and rotates the dealer; a dealer win adds one."""
+    h1 = [0, 1, 4, 5, 8, 9, 12, 13, 16, 17, 20, 21, 24]                      # chiitoi tanki 7m
+    h0 = [2, 3, 6, 7, 10, 11, 14, 15, 18, 19, 22, 23, 26]
+    env = setup(make(game_mode=2), hands=[h0, h1, _SAFE1, _SAFE2], drawn_tile=25, points=[60000, 25000, 25000, 25000],
+                wall=list(range(136)), reset_kw={"oya": 0, "honba": 5})
+    assert env.peek().honba == 5
+    env.step({0: pack_action(DISCARD, 25)})
+    act, ph, dn = env.status()
+    assert ph == WAIT_RESPONSE and env.peek().last_discard_pid == 0 and env.peek().last_discard_tile == 25
+    acts = {s: pack_action(PASS) for s in range(4) if (act >> s) & 1}
+    acts[1] = find(env.legal(1), RON)
+    env.step(acts)
+    v = env.peek()
+    assert v.honba == 0 and v.oya == 1
+    env = setup(make(game_mode=2), hands=[h1, _SAFE1, _SAFE2, tiles("19m19p19s1236677z")[0:13]], drawn_tile=25,
+                wall=list(range(136)), reset_kw={"oya": 0, "honba": 5})
+    ts = find(env.legal(0), TSUMO)
+    assert ts is not None
+    env.step({0: ts})
+    v = env.peek()
+    assert v.honba == 6 and v.oya == 0
+
 SCENARIOS = [sc_paishan_dora_indices, sc_kakan_dora_timing, sc_daiminkan_dora_timing, sc_south_round_tsumo,
              sc_illegal_discard_penalty, sc_illegal_out_of_turn, sc_claim_priority_pon_over_chi, sc_kuikae_suji,
              sc_kuikae_deadlock, sc_sufuurenta, sc_suukansansen, sc_chankan_ron, sc_chankan_pass, sc_pao_daisangen_tsumo,
              sc_pao_mjsoul_composite_tsumo, sc_riichi_sequence, sc_kyushu_kyuhai, sc_double_ron_honba_sticks,
-             sc_tobi_and_agariyame]
+             sc_tobi_and_agariyame,
+             sc_furiten_ron, sc_temporary_furiten, sc_valid_ankan_after_riichi, sc_no_claims_during_riichi,
+             sc_honba_reset_and_increment]
 
 
 # ---------------------------------------------------------------------------------------------------------

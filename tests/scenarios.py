@@ -612,13 +612,45 @@ def sc_honba_reset_and_increment(make):
     v = env.peek()
     assert v.honba == 6 and v.oya == 0
 
+def sc_pao_ron_honba(make):
+    """tests/env/agari/test_pao_honba.py:6-77: daisangen pao, Ron from a third party with 2 honba: the discarder pays half,
+    the liable seat half plus the whole honba (32600 = 16000 + 16600)."""
+    env = setup(make(game_mode=2), hands=[_SAFE1, _SAFE2, tiles("19m19p19s1236677z")[0:13], [0, 1, 2, 4, 99, 132, 133]],
+                melds=[[], [], [], [(PON_M, [124, 125, 126], True, 0, -1), (PON_M, [128, 129, 130], True, 0, -1)]],
+                current_player=0, phase=WAIT_RESPONSE, active_players=[3], wall=list(range(136)), reset_kw={"oya": 0, "honba": 2},
+                mutate=lambda v: (setattr(v, "last_discard_pid", 0), setattr(v, "last_discard_tile", 134), setattr(v, "is_first_turn", 0)))
+    pon = find(env.legal(3), PON, 134)
+    assert pon is not None
+    env.step({3: pon})
+    assert env.peek().players[3].pao_daisangen == 0              # seat 0 is liable for the daisangen
+    env.step({3: pack_action(DISCARD, 99)})
+    act, ph, dn = env.status()
+    if ph == WAIT_RESPONSE:
+        env.step({s: pack_action(PASS) for s in range(4) if (act >> s) & 1})
+    v = env.peek()                                               # now: seat 2 discards 2m (id 6) -> WaitResponse for seat 3
+    for p in range(4):
+        if v.players[p].hand_len + 3 * v.players[p].n_melds == 14:
+            v.players[p].hand_len -= 1                           # undo the draw the engine dealt after the pass
+    v.drawn_tile = -1
+    v.current_player = 2
+    v.phase = WAIT_RESPONSE
+    v.active_mask = 0b1000
+    v.last_discard_pid, v.last_discard_tile = 2, 6
+    env.poke(v)
+    ron = find(env.legal(3), RON, 6)
+    assert ron is not None
+    env.step({3: ron})
+    hora = next(e for e in reversed(evs(env)) if e["type"] == "hora")
+    assert hora["deltas"] == [-16600, 0, -16000, 32600]
+
+
 SCENARIOS = [sc_paishan_dora_indices, sc_kakan_dora_timing, sc_daiminkan_dora_timing, sc_south_round_tsumo,
              sc_illegal_discard_penalty, sc_illegal_out_of_turn, sc_claim_priority_pon_over_chi, sc_kuikae_suji,
              sc_kuikae_deadlock, sc_sufuurenta, sc_suukansansen, sc_chankan_ron, sc_chankan_pass, sc_pao_daisangen_tsumo,
              sc_pao_mjsoul_composite_tsumo, sc_riichi_sequence, sc_kyushu_kyuhai, sc_double_ron_honba_sticks,
              sc_tobi_and_agariyame,
              sc_furiten_ron, sc_temporary_furiten, sc_valid_ankan_after_riichi, sc_no_claims_during_riichi,
-             sc_honba_reset_and_increment]
+             sc_honba_reset_and_increment, sc_pao_ron_honba]
 
 
 # ---------------------------------------------------------------------------------------------------------

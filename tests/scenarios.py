@@ -644,13 +644,48 @@ def sc_pao_ron_honba(make):
     assert hora["deltas"] == [-16600, 0, -16000, 32600]
 
 
+def sc_doujun_cleared_by_call(make):
+    """tests/env/test_m263_ron_mismatch.py:4-77: temporary furiten (missed_agari_doujun) ends with the seat's own call and
+    discard; the next winning discard is offered as Ron again."""
+    h1 = _SAFE1[:12] + [36]
+    h2 = _SAFE2[:12] + [93]
+    env = setup(make(game_mode=2), hands=[tiles("19m19p19s1236677z")[0:13], h1, h2, [37, 38, 40, 92]],
+                melds=[[], [], [], [(PON_M, [124, 125, 126], True, 0, -1), (CHI_M, [24, 28, 32], True, 2, -1), (CHI_M, [60, 64, 68], True, 2, -1)]],
+                current_player=1, active_players=[1], drawn_tile=135, wall=list(range(136)),
+                mutate=lambda v: (setattr(v.players[3], "missed_agari_doujun", 1), setattr(v, "is_first_turn", 0)))
+    env.step({1: pack_action(DISCARD, 36)})                               # 1p
+    pon = find(env.legal(3), PON, 36)
+    assert pon is not None
+    act = env.status()[0]
+    acts = {s: pack_action(PASS) for s in range(4) if (act >> s) & 1}
+    acts[3] = pon
+    env.step(acts)
+    env.step({3: pack_action(DISCARD, 40)})                               # 2p; hand is now the single 7s
+    act, ph, dn = env.status()
+    if ph == WAIT_RESPONSE:
+        env.step({s: pack_action(PASS) for s in range(4) if (act >> s) & 1})
+    v = env.peek()
+    assert v.players[3].missed_agari_doujun == 0
+    assert v.current_player == 0 and v.phase == WAIT_ACT                  # seat 0 drew; let it tsumogiri, then seat 1, then seat 2
+    for seat in (0, 1):
+        v = env.peek()
+        env.step({seat: pack_action(DISCARD, v.drawn_tile)})
+        act, ph, dn = env.status()
+        if ph == WAIT_RESPONSE:
+            env.step({s: pack_action(PASS) for s in range(4) if (act >> s) & 1})
+    assert env.peek().current_player == 2
+    env.step({2: pack_action(DISCARD, 93)})                               # 7s
+    act, ph, dn = env.status()
+    assert ph == WAIT_RESPONSE and (act >> 3) & 1 and find(env.legal(3), RON, 93) is not None
+
+
 SCENARIOS = [sc_paishan_dora_indices, sc_kakan_dora_timing, sc_daiminkan_dora_timing, sc_south_round_tsumo,
              sc_illegal_discard_penalty, sc_illegal_out_of_turn, sc_claim_priority_pon_over_chi, sc_kuikae_suji,
              sc_kuikae_deadlock, sc_sufuurenta, sc_suukansansen, sc_chankan_ron, sc_chankan_pass, sc_pao_daisangen_tsumo,
              sc_pao_mjsoul_composite_tsumo, sc_riichi_sequence, sc_kyushu_kyuhai, sc_double_ron_honba_sticks,
              sc_tobi_and_agariyame,
              sc_furiten_ron, sc_temporary_furiten, sc_valid_ankan_after_riichi, sc_no_claims_during_riichi,
-             sc_honba_reset_and_increment, sc_pao_ron_honba]
+             sc_honba_reset_and_increment, sc_pao_ron_honba, sc_doujun_cleared_by_call]
 
 
 # ---------------------------------------------------------------------------------------------------------

@@ -679,13 +679,51 @@ def sc_doujun_cleared_by_call(make):
     assert ph == WAIT_RESPONSE and (act >> 3) & 1 and find(env.legal(3), RON, 93) is not None
 
 
+def _exhaust(env, scores):
+    """Put the game one discard before an exhaustive draw with everybody noten and no nagashi; returns after the draw."""
+    v = env.peek()
+    hands = [tiles("19m19p19s1236677z")[0:13], _SAFE1, _SAFE2, tiles("258m369p147s1234z")[0:13]]
+    cur = v.current_player
+    for p in range(4):
+        h = sorted(hands[p] + ([135] if p == cur else []))
+        v.players[p].hand_len = len(h)
+        for i, t in enumerate(h):
+            v.players[p].hand[i] = t
+        v.players[p].n_melds = 0
+        v.players[p].nagashi_eligible = 0
+        v.players[p].score = scores[p]
+        v.players[p].riichi_declared = 0
+    v.drawn_tile = 135
+    v.phase = WAIT_ACT
+    v.active_mask = 1 << cur
+    v.drawable_count = 0
+    v.is_first_turn = 0
+    env.poke(v)
+    env.step({cur: pack_action(DISCARD, 135)})
+
+
+def sc_sudden_death_west_round(make):
+    """src/tests.rs:172-231: South 4 ends below 30000 -> the hanchan enters West 1; once somebody holds >= 30000 after a
+    West hand the game ends (end_game is the last event)."""
+    env = setup(make(game_mode=2), wall=list(range(136)), current_player=3, active_players=[3],
+                mutate=lambda v: (setattr(v, "round_wind", 1), setattr(v, "kyoku_idx", 3), setattr(v, "oya", 3)))
+    _exhaust(env, [25000] * 4)
+    v = env.peek()
+    assert not v.is_done and v.round_wind == 2 and v.kyoku_idx == 0 and v.oya == 0
+    _exhaust(env, [31000, 25000, 24000, 20000])
+    assert env.status()[2] == 1
+    t = [e["type"] for e in evs(env)]
+    assert t[-1] == "end_game" and "ryukyoku" in t
+
+
 SCENARIOS = [sc_paishan_dora_indices, sc_kakan_dora_timing, sc_daiminkan_dora_timing, sc_south_round_tsumo,
              sc_illegal_discard_penalty, sc_illegal_out_of_turn, sc_claim_priority_pon_over_chi, sc_kuikae_suji,
              sc_kuikae_deadlock, sc_sufuurenta, sc_suukansansen, sc_chankan_ron, sc_chankan_pass, sc_pao_daisangen_tsumo,
              sc_pao_mjsoul_composite_tsumo, sc_riichi_sequence, sc_kyushu_kyuhai, sc_double_ron_honba_sticks,
              sc_tobi_and_agariyame,
              sc_furiten_ron, sc_temporary_furiten, sc_valid_ankan_after_riichi, sc_no_claims_during_riichi,
-             sc_honba_reset_and_increment, sc_pao_ron_honba, sc_doujun_cleared_by_call]
+             sc_honba_reset_and_increment, sc_pao_ron_honba, sc_doujun_cleared_by_call,
+             sc_sudden_death_west_round]
 
 
 # ---------------------------------------------------------------------------------------------------------

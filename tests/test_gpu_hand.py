@@ -164,3 +164,18 @@ def test_effective_tiles_and_ukeire_parity(sanma):
         assert vecenv.effective_tiles([_types(H_4P_13)])[0] == 1
     with pytest.raises(ValueError):
         vecenv.effective_tiles([_types(H_4P_13[:-1])], sanma=sanma)
+
+
+def test_hand_kats_from_reference_unit_tests_gpu():
+    """The tests.rs KATs of tests/hand_kats.py through rmj_eval_hands, and identical to the oracle's full result."""
+    from oracle import oracle
+    from riichienv_amd import vecenv
+    from tests.hand_kats import HAND_KATS, check
+
+    cases = [abi.hand_case_from_fixture(c) for _, c, _ in HAND_KATS]
+    res = vecenv.eval_hands(cases)
+    ref = oracle.eval_hands(cases)
+    for (name, _, want), r, o in zip(HAND_KATS, res, ref):
+        check(name, r, want)
+        assert (r.is_win, r.han, r.fu, list(r.yaku[: r.n_yaku]), r.ron_agari, r.tsumo_agari_oya, r.tsumo_agari_ko) == \
+               (o.is_win, o.han, o.fu, list(o.yaku[: o.n_yaku]), o.ron_agari, o.tsumo_agari_oya, o.tsumo_agari_ko), name

@@ -74,3 +74,12 @@ def test_tid_to_mjai():
     assert oracle.tid_to_mjai(0) == "1m" and oracle.tid_to_mjai(17) == "5m" and oracle.tid_to_mjai(35) == "9m"
     assert oracle.tid_to_mjai(36) == "1p" and oracle.tid_to_mjai(107) == "9s"
     assert [oracle.tid_to_mjai(108 + 4 * i) for i in range(7)] == list("ESWNPFC")
+
+
+def test_hand_kats_from_reference_unit_tests():
+    """riichienv-core/src/tests.rs:93-148, 312-372, 1510-1592 (yakuman ids, win shape without yaku, kazoe cap)."""
+    from tests.hand_kats import HAND_KATS, check
+
+    res = oracle.eval_hands([abi.hand_case_from_fixture(c) for _, c, _ in HAND_KATS])
+    for (name, _, want), r in zip(HAND_KATS, res):
+        check(name, r, want)

@@ -392,7 +392,22 @@ struct rmj_env {
     unsigned long long* d_counter = nullptr;
     uint32_t ring = 0;
     float* d_decay = nullptr;  // expf(-0.2f * age), age 0..31, computed on the host (encode_extended)
+    void* d_scratch = nullptr; // staging buffer of the host-copy entry points (grown on demand, never per call)
+    size_t scratch_bytes = 0;
 };
+// device staging memory of at least `bytes` bytes, owned by the handle
+static int scratch_for(rmj_env* h, size_t bytes, void** out) {
+    if (bytes > h->scratch_bytes) {
+        HIPCHK(hipStreamSynchronize(h->stream));
+        if (h->d_scratch) hipFree(h->d_scratch);
+        h->d_scratch = nullptr;
+        h->scratch_bytes = 0;
+        HIPCHK(hipMalloc(&h->d_scratch, bytes));
+        h->scratch_bytes = bytes;
+    }
+    *out = h->d_scratch;
+    return RMJ_OK;
+}
 
 static int ensure_device(int device) {
     int n = 0;
@@ -492,7 +507,7 @@ int rmj_destroy(rmj_handle h) {
     if (!h) return RMJ_OK;
     hipSetDevice(h->cfg.device);
     hipStreamSynchronize(h->stream);
-    hipFree(h->d.core); hipFree(h->d.wall); hipFree(h->d.legal); hipFree(h->d.nlegal); hipFree(h->d_decay); hipFree(h->d.mask);
+    hipFree(h->d.core); hipFree(h->d.wall); hipFree(h->d.legal); hipFree(h->d.nlegal); hipFree(h->d_decay); if (h->d_scratch) hipFree(h->d_scratch); hipFree(h->d.mask);
     hipFree(h->d.waits); hipFree(h->d.status); hipFree(h->d.events); hipFree(h->d_actions); hipFree(h->d_counter); hipFree(h->d_env);
     hipStreamDestroy(h->stream);
     delete h;
@@ -645,16 +660,17 @@ static int fetch_scores(rmj_handle h, std::vector<int32_t>& sc, std::vector<uint
     int32_t* d_sc;
     uint32_t* d_ev;
     HIPCHK(hipSetDevice(h->cfg.device));
-    HIPCHK(hipMalloc(&d_sc, (size_t)n * 16));
-    HIPCHK(hipMalloc(&d_ev, (size_t)n * 4));
+    void* sp;
+    int rcs = scratch_for(h, (size_t)n * 20, &sp);
+    if (rcs) return rcs;
+    d_sc = (int32_t*)sp;
+    d_ev = (uint32_t*)((char*)sp + (size_t)n * 16);
     hipLaunchKernelGGL(k_gather_scores, dim3((n + 255) / 256), dim3(256), 0, h->stream, h->d.core, n, d_sc, d_ev);
     sc.resize((size_t)n * 4);
     evc.resize(n);
     HIPCHK(hipStreamSynchronize(h->stream));
     HIPCHK(hipMemcpy(sc.data(), d_sc, (size_t)n * 16, hipMemcpyDeviceToHost));
     HIPCHK(hipMemcpy(evc.data(), d_ev, (size_t)n * 4, hipMemcpyDeviceToHost));
-    hipFree(d_sc);
-    hipFree(d_ev);
     return RMJ_OK;
 }
 int rmj_get_scores(rmj_handle h, int32_t* scores) {
@@ -696,11 +712,13 @@ int rmj_get_step_counts(rmj_handle h, uint64_t* steps) {
     uint32_t n = h->cfg.n_games;
     uint64_t* d;
     HIPCHK(hipSetDevice(h->cfg.device));
-    HIPCHK(hipMalloc(&d, (size_t)n * 8));
+    void* sp;
+    int rcs = scratch_for(h, (size_t)n * 8, &sp);
+    if (rcs) return rcs;
+    d = (uint64_t*)sp;
     hipLaunchKernelGGL(k_gather_steps, dim3((n + 255) / 256), dim3(256), 0, h->stream, h->d.core, n, d);
     HIPCHK(hipStreamSynchronize(h->stream));
     HIPCHK(hipMemcpy(steps, d, (size_t)n * 8, hipMemcpyDeviceToHost));
-    hipFree(d);
     return RMJ_OK;
 }
 int rmj_total_steps(rmj_handle h, uint64_t* total) {
@@ -1097,13 +1115,13 @@ int rmj_encode(rmj_handle h, int only_active, float* out) {
     if (!h || !out) return fail(RMJ_ERR_ARG, "null argument");
     HIPCHK(hipSetDevice(h->cfg.device));
     size_t bytes = (size_t)h->cfg.n_games * 4 * (h->cfg.game_mode >= 3 ? ENC_FLOATS3 : ENC_FLOATS) * sizeof(float);
-    float* d;
-    HIPCHK(hipMalloc(&d, bytes));
-    int rc = rmj_encode_device(h, only_active, d);
+    void* sp;
+    int rc = scratch_for(h, bytes, &sp);
     if (rc) return rc;
+    float* d = (float*)sp;
+    if ((rc = rmj_encode_device(h, only_active, d))) return rc;
     HIPCHK(hipStreamSynchronize(h->stream));
     HIPCHK(hipMemcpy(out, d, bytes, hipMemcpyDeviceToHost));
-    hipFree(d);
     return RMJ_OK;
 }
 
@@ -1112,13 +1130,13 @@ int rmj_encode_extended(rmj_handle h, int only_active, float* out) {
     if (!h || !out) return fail(RMJ_ERR_ARG, "null argument");
     HIPCHK(hipSetDevice(h->cfg.device));
     size_t bytes = (size_t)h->cfg.n_games * 4 * ENC_EXT_CH * (h->cfg.game_mode >= 3 ? ENC_W3 : ENC_W4) * sizeof(float);
-    float* d;
-    HIPCHK(hipMalloc(&d, bytes));
-    int rc = rmj_encode_extended_device(h, only_active, d);
+    void* sp;
+    int rc = scratch_for(h, bytes, &sp);
     if (rc) return rc;
+    float* d = (float*)sp;
+    if ((rc = rmj_encode_extended_device(h, only_active, d))) return rc;
     HIPCHK(hipStreamSynchronize(h->stream));
     HIPCHK(hipMemcpy(out, d, bytes, hipMemcpyDeviceToHost));
-    hipFree(d);
     return RMJ_OK;
 }
 
@@ -1203,14 +1221,15 @@ int rmj_apply_events(rmj_handle h, const RmjEvent* events) {
     if (!h || !events) return fail(RMJ_ERR_ARG, "null argument");
     HIPCHK(hipSetDevice(h->cfg.device));
     const size_t bytes = (size_t)h->cfg.n_games * 3 * sizeof(RmjEvent);
-    RmjEvent* d_ev = nullptr;
-    HIPCHK(hipMalloc(&d_ev, bytes));
+    void* sp;
+    int rcs = scratch_for(h, bytes, &sp);
+    if (rcs) return rcs;
+    RmjEvent* d_ev = (RmjEvent*)sp;
     HIPCHK(hipMemcpyAsync(d_ev, events, bytes, hipMemcpyHostToDevice, h->stream));
     if (h->cfg.game_mode >= 3) hipLaunchKernelGGL(rmj3::k_apply_event, game_grid(h->cfg.n_games), dim3(256), 0, h->stream, (const Env*)h->d_env, (const RmjEvent*)d_ev);
     else hipLaunchKernelGGL(rmj4::k_apply_event, game_grid(h->cfg.n_games), dim3(256), 0, h->stream, (const Env*)h->d_env, (const RmjEvent*)d_ev);
     HIPCHK(hipGetLastError());
     HIPCHK(hipStreamSynchronize(h->stream));
-    hipFree(d_ev);
     return RMJ_OK;
 }
 

@@ -284,6 +284,7 @@ __global__ __launch_bounds__(64) void k_encode(Env E, int only_active, const flo
     constexpr int CH = EXT ? ENC_EXT_CH : ENC_CH;
     __shared__ GState st;
     __shared__ float buf[ENC_EXT_C_SLOTS * W];
+    __shared__ uint32_t hist[ENC_HIST_WORDS];
     const int lane = threadIdx.x & 63;
     const uint32_t g = blockIdx.x >> 2;
     const int seat = blockIdx.x & 3;
@@ -304,7 +305,7 @@ __global__ __launch_bounds__(64) void k_encode(Env E, int only_active, const flo
         for (int i = lane; i < CH * W; i += 64) dst[i] = 0.0f;
         return;
     }
-    encode_seat<SANMA>(S, seat, buf, lane);
+    encode_seat<SANMA>(S, seat, buf, lane, hist);
     enc_stream_out<W>(dst, buf, ENC_CH * W, lane);
     if (EXT) {
         wave_sync();

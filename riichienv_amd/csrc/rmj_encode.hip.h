@@ -48,8 +48,10 @@ __device__ __forceinline__ int enc_next_tile136_sanma(int tile) {
     return enc_next_tile136(tile);
 }
 
+// `hist`: 5 x 36 u32 of LDS scratch (type histograms of the four seats' visible tiles and of the own hand)
+#define ENC_HIST_WORDS (5 * 36)
 template <bool SANMA>
-__device__ inline void encode_seat(const GState& S, int pid, float* buf, int lane) {
+__device__ inline void encode_seat(const GState& S, int pid, float* buf, int lane, uint32_t* hist) {
     constexpr int ENC_W = SANMA ? ENC_W3 : ENC_W4;
     constexpr int NPP = SANMA ? 3 : 4;
     auto enc_bcast = [&](float* b, int ch, float v, int l) {
@@ -61,24 +63,31 @@ __device__ inline void encode_seat(const GState& S, int pid, float* buf, int lan
     };
     const int my34 = SANMA ? (lane == 0 ? 0 : lane + 7) : lane;  // tile type of this lane's column
     for (int i = lane; i < ENC_CH * ENC_W; i += 64) buf[i] = 0.0f;
+    for (int i = lane; i < ENC_HIST_WORDS; i += 64) hist[i] = 0u;
     wave_sync();
     const PState& P = S.p[pid];
-    // 1-2. hand counts + red (ch 0-4)
-    if (lane < ENC_W) {
-        int c = 0;
-        bool red = false;
-        for (int j = 0; j < P.hand_len; j++) {
-            int t = P.hand[j];
-            if ((t >> 2) == my34) {
-                c++;
-                red = red || is_aka(t);
-            }
+    // type histograms by LDS atomics, lane = tile slot: hist[q] = melds + discards of seat q, hist[4] = own hand
+    for (int q = 0; q < NPP; q++) {
+        const PState& Q = S.p[q];
+        if (lane < Q.n_discards) atomicAdd(&hist[q * 36 + (Q.discards[lane] >> 2)], 1u);
+        if (lane < 16) {
+            const int m = lane >> 2, k = lane & 3;
+            if (m < Q.n_melds && k < ((Q.meld_type[m] >= RMJ_MELD_DAIMINKAN) ? 4 : 3)) atomicAdd(&hist[q * 36 + (Q.meld_tiles[m][k] >> 2)], 1u);
         }
+    }
+    if (lane < P.hand_len) {
+        const int t = P.hand[lane];
+        atomicAdd(&hist[4 * 36 + (t >> 2)], 1u);
+        if (is_aka(t)) put(4, t >> 2);   // red five in hand (ch 4)
+    }
+    wave_sync();
+    // 1-2. hand counts (ch 0-3)
+    if (lane < ENC_W) {
+        const int c = (int)hist[4 * 36 + my34];
         if (c >= 1) buf[0 * ENC_W + lane] = 1.0f;
         if (c >= 2) buf[1 * ENC_W + lane] = 1.0f;
         if (c >= 3) buf[2 * ENC_W + lane] = 1.0f;
         if (c >= 4) buf[3 * ENC_W + lane] = 1.0f;
-        if (red) buf[4 * ENC_W + lane] = 1.0f;
     }
     // 3. own melds (ch 5-8), 4. dora indicators (ch 9)
     if (lane < 16) {
@@ -145,45 +154,28 @@ __device__ inline void encode_seat(const GState& S, int pid, float* buf, int lan
     if (rank < NPP) enc_bcast(buf, 49 + rank, 1.0f, lane);
     enc_bcast(buf, 53, (float)S.kyoku_idx / 8.0f, lane);
     enc_bcast(buf, 54, ((float)S.round_wind * 4.0f + (float)S.kyoku_idx) / 7.0f, lane);
-    // 19. dora counts (ch 55-58) and 21. tiles seen (ch 63): lane = tile type accumulates, then reduce for dora
+    // 19. dora counts (ch 55-58): per seat, the number of visible tiles (own hand included for the observer) whose type is
+    //     the dora of an indicator, counted per indicator (u8 accumulator in the reference); 21. tiles seen (ch 63)
     {
-        int seen = 0;
-        uint32_t dmask_lo = 0, dmask_hi = 0;  // multiset of dora types as counts per type would need 34 counters:
-        // dora counting is per indicator (duplicates count twice), so loop over indicators explicitly below.
-        (void)dmask_lo; (void)dmask_hi;
         int dcount[4] = {0, 0, 0, 0};
-        // NOTE: the dora count is taken over tile TYPES (34-wide, also types without a column in 3P); lanes >= ENC_W
-        // cover nothing in 4P, and in 3P the types 1..7 (2m-8m) cannot occur in a sanma game.
-        for (int q = 0; q < NPP; q++) {
-            const PState& Q = S.p[q];
-            int mine = 0;  // tiles of this lane's type visible for player q (melds + discards [+ own hand])
-            for (int m = 0; m < Q.n_melds; m++) {
-                int nt = (Q.meld_type[m] >= RMJ_MELD_DAIMINKAN) ? 4 : 3;
-                for (int k = 0; k < nt; k++) mine += ((Q.meld_tiles[m][k] >> 2) == my34);
-            }
-            for (int j = 0; j < Q.n_discards; j++) mine += ((Q.discards[j] >> 2) == my34);
-            seen += mine;
-            if (q == pid) {
-                int hc = 0;
-                for (int j = 0; j < P.hand_len; j++) hc += ((P.hand[j] >> 2) == my34);
-                seen += hc;
-                mine += hc;
-            }
-            // contribution of this tile type to q's dora count = mine * (#indicators whose dora type is this type)
-            int mult = 0;
-            for (int k = 0; k < S.n_dora; k++)
-                mult += (((SANMA ? enc_next_tile136_sanma(S.dora[k]) : enc_next_tile136(S.dora[k])) >> 2) == my34);
-            int contrib = (lane < ENC_W) ? mine * mult : 0;
+        for (int k = 0; k < S.n_dora; k++) {
+            const int dt = (SANMA ? enc_next_tile136_sanma(S.dora[k]) : enc_next_tile136(S.dora[k])) >> 2;
+            if (dt < 34) {
 #pragma unroll
-            for (int off = 32; off >= 1; off >>= 1) contrib += __shfl_xor(contrib, off, 64);
-            dcount[q] = contrib & 0xFF;  // u8 accumulator in the reference
+                for (int q = 0; q < 4; q++)
+                    if (q < NPP) dcount[q] += (int)hist[q * 36 + dt] + (q == pid ? (int)hist[4 * 36 + dt] : 0);
+            }
         }
-        for (int k = 0; k < S.n_dora; k++) seen += ((S.dora[k] >> 2) == my34);
-        if (lane < ENC_W) buf[63 * ENC_W + lane] = (float)(seen & 0xFF) / 4.0f;
+        if (lane < ENC_W) {
+            int seen = (int)hist[4 * 36 + my34];
+            for (int q = 0; q < NPP; q++) seen += (int)hist[q * 36 + my34];
+            for (int k = 0; k < S.n_dora; k++) seen += ((S.dora[k] >> 2) == my34);
+            buf[63 * ENC_W + lane] = (float)(seen & 0xFF) / 4.0f;
+        }
         for (int rel = 0; rel < NPP; rel++) {
             int q = (pid + rel) % NPP;
             int d = q == 0 ? dcount[0] : (q == 1 ? dcount[1] : (q == 2 ? dcount[2] : dcount[3]));
-            enc_bcast(buf, 55 + rel, (float)d / 12.0f, lane);
+            enc_bcast(buf, 55 + rel, (float)(d & 0xFF) / 12.0f, lane);
         }
     }
     // ch 70-73 stay 0: tsumogiri_flags is never filled (observation/mod.rs:105)

@@ -35,6 +35,30 @@ class RmjError(RuntimeError):
     pass
 
 
+def _share_torch_hip_runtime():
+    """One HIP runtime per process.  PyTorch-ROCm ships its own libamdhip64.so.7 (+ HSA runtime); the system one under
+    /opt/rocm has the same soname, so whichever is loaded first serves both, and torch fails with "No HIP GPUs are
+    available" when it finds the system copy already in the process.  When torch is installed but not imported yet,
+    load its copy first, so that a later `import torch` (TorchVecEnv, a trainer) works whatever the import order.
+    RMJ_HIP_RUNTIME=system keeps the system runtime."""
+    import importlib.util
+    import sys
+    if "torch" in sys.modules or os.environ.get("RMJ_HIP_RUNTIME") == "system":
+        return
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        spec = None
+    if spec is None or not spec.origin:
+        return
+    cand = os.path.join(os.path.dirname(spec.origin), "lib", "libamdhip64.so")
+    if os.path.exists(cand):
+        try:
+            C.CDLL(cand, mode=C.RTLD_GLOBAL)
+        except OSError:
+            pass
+
+
 def load_lib():
     """Load the HIP library; raises (never falls back) if it has not been built."""
     global _LIB
@@ -43,6 +67,7 @@ def load_lib():
     if not os.path.exists(LIB_PATH):
         raise RmjError(f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
                        "(hipcc --offload-arch=gfx950). There is no CPU fallback.")
+    _share_torch_hip_runtime()
     L = C.CDLL(LIB_PATH)
     L.rmj_version.restype = C.c_char_p
     L.rmj_last_error.restype = C.c_char_p

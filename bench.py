@@ -45,7 +45,7 @@ def pmc_traffic(games, mode):
     try:
         with open(path) as f:
             d = json.load(f)
-        if d.get("games_per_launch") == games and mode == 2:
+        if d.get("games_per_launch") == games and mode == 2:  # games = games of ONE launch
             return d["hbm_traffic"]["bytes_per_launch"], "profiles/r01_pmc_k_step.json"
     except (OSError, KeyError, ValueError):
         pass
@@ -108,7 +108,7 @@ def main():
         env.total_steps()
         r.env_steps = env.total_steps() - before
     else:
-        r = env.bench_rollout(policy_seed, 0, args.steps)   # exactly K launches, HIP events on the kernel's stream
+        r = env.bench_rollout(policy_seed, 0, args.steps)   # exactly K steps of every game, HIP events on the handle's stream
     barrier()
     t1 = time.perf_counter()
     wall = t1 - t0
@@ -118,8 +118,12 @@ def main():
     if rank == 0:
         kernel_s = r.step_kernel_ms * 1e-3
         b_step = B_STEP_3P if args.mode >= 3 else B_STEP_4P
-        traffic, traffic_src = pmc_traffic(args.games, args.mode)
-        achieved = b_step * args.games / kernel_s
+        # a device rollout runs as `in_flight` concurrent launches (halves of the batch on two streams, rmj_step_random):
+        # bytes and duration are per launch, the bandwidth the chip delivers is in_flight launches' worth
+        in_flight = max(1, int(r.launches_in_flight))
+        games_per_launch = args.games // in_flight
+        traffic, traffic_src = pmc_traffic(games_per_launch, args.mode)
+        achieved = in_flight * b_step * games_per_launch / kernel_s
         out = {
             "metric": "env.step()/s (whole node) at 65 536 parallel 4p games; bit-exact MJAI parity",
             "value": steps_total / wall, "unit": "env.step/s", "n_gpus": world, "steps": args.steps,
@@ -132,7 +136,8 @@ def main():
             "roofline": {"bound": "hbm", "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK, "traffic": traffic, "traffic_unit": "bytes/launch",
                          "traffic_source": traffic_src, "kernel": "k_step",
-                         "kernel_ms": r.step_kernel_ms, "bytes_per_launch": b_step * args.games},
+                         "kernel_ms": r.step_kernel_ms, "bytes_per_launch": b_step * games_per_launch,
+                         "games_per_launch": games_per_launch, "launches_in_flight": in_flight},
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.mode, abi.RULE_TENHOU, policy_seed)

@@ -33,6 +33,8 @@ typedef BlockSharedT<WPB> BlockShared;
 #define RMJ_STEP_WPB 1 /* games (= waves) per block of the step kernel: single-wave blocks release their LDS as soon as the game is done (a block of four waited for its slowest game) */
 #endif
 static inline dim3 step_grid(uint32_t n) { return dim3((n + RMJ_STEP_WPB - 1) / RMJ_STEP_WPB); }
+// smallest batch that a multi-step device rollout splits over the two streams of a handle (launch_step_range)
+#define RMJ_SPLIT_MIN_GAMES 16384u
 
 __device__ __forceinline__ void load_state(GState& S, const GState* src, int lane) {
     if (lane < (int)(sizeof(GState) / 16)) reinterpret_cast<uint4*>(&S)[lane] = reinterpret_cast<const uint4*>(src)[lane];
@@ -388,6 +390,11 @@ struct rmj_env {
     RmjConfig cfg;
     Env d;
     hipStream_t stream = nullptr;
+    // second stream of multi-step device rollouts (rmj_step_random): the games are stepped as two halves, one per
+    // stream, so that the draining tail of one half's launch overlaps the body of the other's.  Forked from and joined
+    // back into `stream` inside the call: every other entry point sees one ordered stream.
+    hipStream_t stream2 = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     Env* d_env = nullptr;  // device-resident copy of `d` (kernels take a pointer, see rmj_kernels.hip.h)
     uint64_t* d_actions = nullptr;
     unsigned long long* d_counter = nullptr;
@@ -455,6 +462,9 @@ int rmj_create(const RmjConfig* cfg, rmj_handle* out) {
     Env& d = h->d;
     memset(&d, 0, sizeof(d));
     HIPCHK(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
+    HIPCHK(hipStreamCreateWithFlags(&h->stream2, hipStreamNonBlocking));
+    HIPCHK(hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming));
+    HIPCHK(hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming));
     HIPCHK(hipMalloc(&d.core, B * sizeof(GState)));
     HIPCHK(hipMalloc(&d.wall, B * RMJ_WALL_STRIDE));
     HIPCHK(hipMalloc(&d.legal, B * 4 * RMJ_MAX_LEGAL * sizeof(uint64_t)));
@@ -511,6 +521,9 @@ int rmj_destroy(rmj_handle h) {
     hipFree(h->d.core); hipFree(h->d.wall); hipFree(h->d.legal); hipFree(h->d.nlegal); hipFree(h->d_decay); if (h->d_scratch) hipFree(h->d_scratch); hipFree(h->d.mask);
     hipFree(h->d.waits); hipFree(h->d.status); hipFree(h->d.events); hipFree(h->d_actions); hipFree(h->d_counter); hipFree(h->d_env);
     hipStreamDestroy(h->stream);
+    if (h->stream2) { hipStreamSynchronize(h->stream2); hipStreamDestroy(h->stream2); }
+    if (h->ev_fork) hipEventDestroy(h->ev_fork);
+    if (h->ev_join) hipEventDestroy(h->ev_join);
     delete h;
     return RMJ_OK;
 }
@@ -542,11 +555,21 @@ int rmj_reset(rmj_handle h, const uint8_t* select, const uint8_t* walls, const u
     return RMJ_OK;
 }
 
+// one k_step launch over games [g0, g1) of the handle
+static inline void launch_step_range(rmj_env* h, hipStream_t st, const uint64_t* d_actions, uint64_t policy_seed, uint32_t flags,
+                                     uint32_t g0, uint32_t g1) {
+#ifdef RMJ_TUNE_LDS
+    static const unsigned extra_lds = getenv("RMJ_EXTRA_LDS") ? (unsigned)atoi(getenv("RMJ_EXTRA_LDS")) : 0u;  // occupancy experiments
+#else
+    const unsigned extra_lds = 0u;
+#endif
+    if (h->cfg.game_mode >= 3) hipLaunchKernelGGL(rmj3::k_step, step_grid(g1 - g0), dim3(64 * RMJ_STEP_WPB), extra_lds, st, (const Env*)h->d_env, d_actions, policy_seed, flags, g0, g1);
+    else hipLaunchKernelGGL(rmj4::k_step, step_grid(g1 - g0), dim3(64 * RMJ_STEP_WPB), extra_lds, st, (const Env*)h->d_env, d_actions, policy_seed, flags, g0, g1);
+}
 int rmj_step_device(rmj_handle h, const rmj_action_t* d_actions) {
     if (!h || !d_actions) return fail(RMJ_ERR_ARG, "null argument");
     HIPCHK(hipSetDevice(h->cfg.device));
-    if (h->cfg.game_mode >= 3) hipLaunchKernelGGL(rmj3::k_step, step_grid(h->cfg.n_games), dim3(64 * RMJ_STEP_WPB), 0, h->stream, (const Env*)h->d_env, (const uint64_t*)d_actions, 0ull, 0u);
-    else hipLaunchKernelGGL(rmj4::k_step, step_grid(h->cfg.n_games), dim3(64 * RMJ_STEP_WPB), 0, h->stream, (const Env*)h->d_env, (const uint64_t*)d_actions, 0ull, 0u);
+    launch_step_range(h, h->stream, (const uint64_t*)d_actions, 0ull, 0u, 0u, h->cfg.n_games);
     HIPCHK(hipGetLastError());
     return RMJ_OK;
 }
@@ -557,8 +580,7 @@ int rmj_step_ids_device(rmj_handle h, const int32_t* d_action_ids, int auto_rese
     if (!h || !d_action_ids) return fail(RMJ_ERR_ARG, "null argument");
     HIPCHK(hipSetDevice(h->cfg.device));
     const uint32_t flags = STEP_F_IDS | (auto_reset ? STEP_F_AUTORESET : 0u);
-    if (h->cfg.game_mode >= 3) hipLaunchKernelGGL(rmj3::k_step, step_grid(h->cfg.n_games), dim3(64 * RMJ_STEP_WPB), 0, h->stream, (const Env*)h->d_env, reinterpret_cast<const uint64_t*>(d_action_ids), 0ull, flags);
-    else hipLaunchKernelGGL(rmj4::k_step, step_grid(h->cfg.n_games), dim3(64 * RMJ_STEP_WPB), 0, h->stream, (const Env*)h->d_env, reinterpret_cast<const uint64_t*>(d_action_ids), 0ull, flags);
+    launch_step_range(h, h->stream, reinterpret_cast<const uint64_t*>(d_action_ids), 0ull, flags, 0u, h->cfg.n_games);
     HIPCHK(hipGetLastError());
     return RMJ_OK;
 }
@@ -594,18 +616,29 @@ int rmj_step(rmj_handle h, const rmj_action_t* actions) {
     HIPCHK(hipMemcpy(h->d_actions, actions, (size_t)h->cfg.n_games * 4 * sizeof(uint64_t), hipMemcpyHostToDevice));
     return rmj_step_device(h, h->d_actions);
 }
+// streams a device rollout of n_steps steps uses (RMJ_STEP_STREAMS=1 keeps everything on one stream)
+static int rollout_streams(const rmj_env* h, uint32_t n_steps) {
+    static const int want = getenv("RMJ_STEP_STREAMS") ? atoi(getenv("RMJ_STEP_STREAMS")) : 2;
+    return (want >= 2 && n_steps >= 2 && h->cfg.n_games >= RMJ_SPLIT_MIN_GAMES) ? 2 : 1;
+}
 int rmj_step_random(rmj_handle h, uint64_t policy_seed, uint32_t n_steps, int auto_reset) {
     if (!h) return fail(RMJ_ERR_ARG, "null handle");
     HIPCHK(hipSetDevice(h->cfg.device));
     uint32_t flags = STEP_F_RANDOM | (auto_reset ? STEP_F_AUTORESET : 0u);
-    for (uint32_t s = 0; s < n_steps; s++) {
-#ifdef RMJ_TUNE_LDS
-        static const unsigned extra_lds = getenv("RMJ_EXTRA_LDS") ? (unsigned)atoi(getenv("RMJ_EXTRA_LDS")) : 0u;  // occupancy experiments
-#else
-        const unsigned extra_lds = 0u;
-#endif
-        if (h->cfg.game_mode >= 3) hipLaunchKernelGGL(rmj3::k_step, step_grid(h->cfg.n_games), dim3(64 * RMJ_STEP_WPB), extra_lds, h->stream, (const Env*)h->d_env, (const uint64_t*)nullptr, policy_seed, flags);
-        else hipLaunchKernelGGL(rmj4::k_step, step_grid(h->cfg.n_games), dim3(64 * RMJ_STEP_WPB), extra_lds, h->stream, (const Env*)h->d_env, (const uint64_t*)nullptr, policy_seed, flags);
+    const uint32_t n = h->cfg.n_games;
+    if (rollout_streams(h, n_steps) == 2) {
+        // games are independent: each half advances n_steps steps on its own stream (header: rmj_step_random)
+        const uint32_t half = n / 2;
+        HIPCHK(hipEventRecord(h->ev_fork, h->stream));
+        HIPCHK(hipStreamWaitEvent(h->stream2, h->ev_fork, 0));
+        for (uint32_t s = 0; s < n_steps; s++) {
+            launch_step_range(h, h->stream, nullptr, policy_seed, flags, 0u, half);
+            launch_step_range(h, h->stream2, nullptr, policy_seed, flags, half, n);
+        }
+        HIPCHK(hipEventRecord(h->ev_join, h->stream2));
+        HIPCHK(hipStreamWaitEvent(h->stream, h->ev_join, 0));
+    } else {
+        for (uint32_t s = 0; s < n_steps; s++) launch_step_range(h, h->stream, nullptr, policy_seed, flags, 0u, n);
     }
     HIPCHK(hipGetLastError());
     return RMJ_OK;
@@ -1255,10 +1288,11 @@ int rmj_bench_rollout(rmj_handle h, uint64_t policy_seed, uint32_t warmup, uint3
     hipEventDestroy(e0);
     hipEventDestroy(e1);
     out->total_ms = ms;
-    out->launches = steps;
-    out->step_kernel_ms = steps ? ms / steps : 0.0;
+    const uint32_t fl = (uint32_t)rollout_streams(h, steps);
+    out->launches = steps * fl;
+    out->step_kernel_ms = steps ? ms / steps : 0.0;  // each stream runs `steps` launches back to back during `ms`
     out->env_steps = after - before;
-    out->reserved = 0;
+    out->launches_in_flight = fl;
     return RMJ_OK;
 }
 

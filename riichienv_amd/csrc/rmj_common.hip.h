@@ -38,12 +38,17 @@ __device__ __forceinline__ ShantenTables sh_tables_of(CEnv& E) {
     return T;
 }
 
+#define RMJ_EV_STAGE 4
 struct WaveScratch {      // per-wave LDS scratch
     uint8_t tiles[144];
     uint8_t maskbuf[4 * 82 + 8];
     uint64_t legal[4][RMJ_MAX_LEGAL];  // lists produced this launch (copied to HBM by finalize_outputs)
     uint64_t wout[4];                  // waits produced this launch
     int nl[4];                         // list lengths produced this launch
+    // events of the fast path, staged until the step has succeeded (k_step): a store in flight would make every later
+    // s_waitcnt vmcnt(0) of the step - table lookups, the wall draw - wait for its acknowledgement as well
+    alignas(16) uint32_t evbuf[RMJ_EV_STAGE][8];
+    uint32_t evidx[RMJ_EV_STAGE];      // ring slot of each staged event
 #ifdef RMJ_PROFILE
     uint64_t tprev;                    // section timer (profiling build only, scripts/prof_sections.py)
     uint32_t pacc[64];

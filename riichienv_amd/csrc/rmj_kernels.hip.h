@@ -28,32 +28,44 @@ __device__ __noinline__ void ol_step_full(CtxV v, uint64_t mine, uint32_t flags)
 #ifndef RMJ_STEP_WAVES
 #define RMJ_STEP_WAVES 8
 #endif
-__global__ __launch_bounds__(64 * RMJ_STEP_WPB, RMJ_STEP_WAVES) void k_step(const Env* __restrict__ Ep, const uint64_t* __restrict__ actions, uint64_t policy_seed, uint32_t flags) {
+__global__ __launch_bounds__(64 * RMJ_STEP_WPB, RMJ_STEP_WAVES) void k_step(const Env* __restrict__ Ep, const uint64_t* __restrict__ actions, uint64_t policy_seed, uint32_t flags,
+                                                                                uint32_t g_base, uint32_t g_end) {
     CEnv& E = *(CEnv*)Ep;  // device-resident record, read through the constant address space (see CEnv)
     __shared__ BlockSharedT<RMJ_STEP_WPB> sh;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const uint32_t g = blockIdx.x * RMJ_STEP_WPB + wave;
-    if (g >= E.n_games) return;
+    const uint32_t g = g_base + blockIdx.x * RMJ_STEP_WPB + wave;  // the launch covers games [g_base, g_end)
+    if (g >= g_end) return;
     GState& S = sh.st[wave];
     PROF_START(sh.x[wave], lane);
+    const bool device_policy = (flags & STEP_F_RANDOM) != 0;
+    // Device policy: the first 16 entries of every seat's stored list (lane = 16 * seat + entry) are requested together
+    // with the record, so that the pick below does not cost a second, dependent trip to HBM (the choice needs nlegal
+    // and step_count of the record); longer lists fall back to the dependent load.
+    uint64_t* const Lg0 = E.legal + (size_t)g * 4 * RMJ_MAX_LEGAL;
+    uint64_t spec = 0;
+    if (device_policy) spec = Lg0[(lane >> 4) * RMJ_MAX_LEGAL + (lane & 15)];
     load_state(S, E.core + g, lane);
-    Ctx c{S, E, sh.x[wave], g, lane, E.wall + (size_t)g * RMJ_WALL_STRIDE, E.legal + (size_t)g * 4 * RMJ_MAX_LEGAL};
+    Ctx c{S, E, sh.x[wave], g, lane, E.wall + (size_t)g * RMJ_WALL_STRIDE, Lg0};
     c.pf_live_end = S.live_end;
     c.pf_draw = c.W[S.live_end > 0 ? S.live_end - 1 : 0];
     PROF(c.X, lane, 0);
-    const bool device_policy = (flags & STEP_F_RANDOM) != 0;
     // lane = seat: one gather (and one copy of the modulo / of the canonicalisation) for all seats
     uint64_t mine = RMJ_NO_ACTION;
     if (device_policy) {
         // RandomAgent (random_agent.py:6-15), keyed per (game, step, seat): see rmj_step_random in the header
         uint64_t gs = sm64(policy_seed + E.game_offset + g);
+        bool pick = false;
+        uint32_t ch = 0;
         if (lane < 4) {
             int n = S.nlegal[lane];
             if (((S.active_mask >> lane) & 1u) && n > 0 && !S.is_done) {
-                uint32_t ch = mod_small(sm64(gs + (uint64_t)S.step_count * 4ull + (uint64_t)lane), (uint32_t)n);
-                mine = c.Lg[lane * RMJ_MAX_LEGAL + ch];
+                ch = mod_small(sm64(gs + (uint64_t)S.step_count * 4ull + (uint64_t)lane), (uint32_t)n);
+                pick = true;
             }
         }
+        const int src = (lane & 3) * 16 + (int)(ch & 15u);
+        const uint64_t got = (uint64_t)__shfl((unsigned long long)spec, src, 64);
+        if (pick) mine = ch < 16u ? got : c.Lg[lane * RMJ_MAX_LEGAL + ch];
     } else if (flags & STEP_F_IDS) {
         // Observation.find_action (observation/python.rs:119-122): the first legal action of the seat whose encoded id
         // equals the policy's id; lane = list entry.  No match = an action that fails validation (illegal action).
@@ -80,6 +92,7 @@ __global__ __launch_bounds__(64 * RMJ_STEP_WPB, RMJ_STEP_WAVES) void k_step(cons
     // Fast path: the common transitions, fully inline, nothing stored until it has succeeded.
     if (S.is_done && (flags & STEP_F_AUTORESET)) c.bail = true;
     else {
+        c.ev_stage = 0;
         step_game<true>(c, mine, device_policy);  // device policy: picked from the stored lists, valid by construction
         PROF(c.X, lane, 8);
         if (!c.bail) finalize_outputs<true>(c, true);
@@ -95,6 +108,7 @@ __global__ __launch_bounds__(64 * RMJ_STEP_WPB, RMJ_STEP_WAVES) void k_step(cons
         if (lane == 0) { c.X.pacc[28] += (uint32_t)(__builtin_readcyclecounter() - t_full); c.X.pacc[32 + 28] += 1u; }
 #endif
     } else {
+        flush_events(c);
         store_state(S, E.core + g, lane);
     }
     PROF(c.X, lane, 15);

@@ -38,6 +38,9 @@ struct Ctx {
     // set `bail` as soon as they meet anything rare (yaku evaluation, settlement, kan, ryukyoku, next round, ...); the
     // kernel then re-runs the whole step from the untouched HBM record in the out-of-line full-featured path.
     bool bail = false;
+    // >= 0: events are staged in X.evbuf (count so far), flushed by k_step once the fast path has succeeded; -1: every
+    // event is stored to the ring at once (all other kernels, the full path, out-of-line bodies)
+    int ev_stage = -1;
 };
 
 // By-value view of a Ctx for out-of-line (rare-path) functions.  Passing Ctx& to a non-inlined function would
@@ -81,12 +84,32 @@ __device__ __forceinline__ void emit_words(Ctx& c, uint32_t w0, uint32_t w1, uin
     if (c.E.skip_log) return;
     const uint32_t evc = (uint32_t)__builtin_amdgcn_readfirstlane((int)c.S.ev_count);  // wave-uniform: scalar address math
     const uint32_t idx = evc & c.E.ring_mask;
+    c.S.ev_count = evc + 1;
+    w7 = (w7 & 0x00FFFFFFu) | ((uint32_t)KNP << 24);  // pad byte = seats (formatter)
+    if (c.ev_stage >= 0 && c.ev_stage < RMJ_EV_STAGE) {
+        if (c.lane == 0) {
+            uint4* b = reinterpret_cast<uint4*>(c.X.evbuf[c.ev_stage]);
+            b[0] = make_uint4(w0, w1, w2, w3);
+            b[1] = make_uint4(w4, w5, w6, w7);
+            c.X.evidx[c.ev_stage] = idx;
+        }
+        c.ev_stage += 1;
+        return;
+    }
     uint4* dst = reinterpret_cast<uint4*>(c.E.events + (size_t)c.g * (c.E.ring_mask + 1u) + idx);
     if (c.lane == 0) {
         dst[0] = make_uint4(w0, w1, w2, w3);
-        dst[1] = make_uint4(w4, w5, w6, (w7 & 0x00FFFFFFu) | ((uint32_t)KNP << 24));  // pad byte = seats (formatter)
+        dst[1] = make_uint4(w4, w5, w6, w7);
     }
-    c.S.ev_count = evc + 1;
+}
+// staged events -> ring: lane = 2 * event + half, one 16-byte store per lane
+__device__ __forceinline__ void flush_events(Ctx& c) {
+    const int n = c.ev_stage;
+    if (n > 0 && c.lane < 2 * n) {
+        const int e = c.lane >> 1, h = c.lane & 1;
+        uint4* dst = reinterpret_cast<uint4*>(c.E.events + (size_t)c.g * (c.E.ring_mask + 1u) + c.X.evidx[e]);
+        dst[h] = reinterpret_cast<const uint4*>(c.X.evbuf[e])[h];
+    }
 }
 __device__ __forceinline__ void emit_raw(Ctx& c, const RmjEvent& ev) {  // rare paths (struct built on the stack)
     uint32_t p[8];
@@ -837,7 +860,8 @@ __device__ __forceinline__ void deal_next(Ctx& c) {
     }
     if (S.live_end > S.rinshan_count) {
         const int le = S.live_end - 1;
-        uint8_t t = (c.pf_live_end == le + 1) ? (uint8_t)c.pf_draw : c.W[le];
+        // FAST: nothing before this point moves live_end (kans bail), the prefetched tile is the draw
+        uint8_t t = (FAST || c.pf_live_end == le + 1) ? (uint8_t)c.pf_draw : c.W[le];
         S.live_end = (uint8_t)le;
         S.drawable_count -= 1;
         int pid = S.current_player;

@@ -238,3 +238,31 @@ def test_shards_equal_whole_batch(mode):
     for g in (0, B - 1, B, 2 * B - 1):
         r, l = shard.owner_of(g, B)
         assert whole.mjai_log(g) == parts[r].mjai_log(l)
+
+
+@pytest.mark.parametrize("mode", [2, 5])
+def test_two_stream_rollout_equals_single_stream(mode):
+    """rmj_step_random issues a multi-step rollout of >= 16 384 games as two halves on two HIP streams (header); the
+    result must be the one of stepping launch by launch on the handle's stream (n_steps = 1 never splits)."""
+    from riichienv_amd import vecenv
+
+    B, K = 16384, 400
+    a = vecenv.VecRiichiEnv(B, game_mode=mode, seed=5, event_ring=1024)
+    b = vecenv.VecRiichiEnv(B, game_mode=mode, seed=5, event_ring=1024)
+    a.reset()
+    b.reset()
+    a.step_random(0xBEEF, K, auto_reset=True)          # split
+    for _ in range(K):
+        b.step_random(0xBEEF, 1, auto_reset=True)      # one stream
+    assert a.total_steps() == b.total_steps()
+    assert (a.step_counts() == b.step_counts()).all()
+    assert (a.scores() == b.scores()).all()
+    assert (a.status()[0] == b.status()[0]).all()
+    la, ca = a.legal()
+    lb, cb = b.legal()
+    assert (ca == cb).all() and (la == lb).all()
+    assert (a.mask() == b.mask()).all()
+    for g in (0, B // 2 - 1, B // 2, B - 1):
+        assert a.mjai_log(g) == b.mjai_log(g)
+    r = a.bench_rollout(0xBEEF, 0, 10)
+    assert r.launches == 20 and r.launches_in_flight == 2

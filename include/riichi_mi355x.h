@@ -184,10 +184,11 @@ int rmj_step_device(rmj_handle h, const rmj_action_t* d_actions);
  * keyed per (game, step, seat) — SURVEY §8(c)): choice = mix(policy_seed, global_game, step_no, seat) % n_legal
  * over the ordered legal list.  Runs n_steps batched steps; with auto_reset != 0 a finished game is
  * re-`reset()` (defaults) at the start of the next step instead of stepping.
- * Games are independent, so a rollout of >= 2 steps over >= 16 384 games is issued as two halves of the batch on two
- * HIP streams (each half gets its n_steps launches in order; the draining tail of one half's launch overlaps the body
- * of the other's), forked from and joined back into the handle's stream inside the call.  Every game is stepped exactly
- * n_steps times either way, and the results do not depend on it.  RMJ_STEP_STREAMS=1 in the environment keeps one stream. */
+ * Games are independent, so a rollout of >= 2 steps over >= 16 384 games is issued as up to four parts of the batch
+ * (>= 8 192 games each) on as many HIP streams: each part gets its n_steps launches in order, and the draining tail of
+ * one part's launch overlaps the bodies of the others'.  The streams are forked from and joined back into the handle's
+ * stream inside the call.  Every game is stepped exactly n_steps times either way, and the results do not depend on
+ * it.  RMJ_STEP_STREAMS=<k> in the environment sets the number of parts (1 = one stream). */
 int rmj_step_random(rmj_handle h, uint64_t policy_seed, uint32_t n_steps, int auto_reset);
 /* Fill actions[n][4] with what the device policy would choose for the CURRENT state (no step). */
 int rmj_random_actions(rmj_handle h, uint64_t policy_seed, rmj_action_t* actions);
@@ -309,7 +310,7 @@ typedef struct RmjBenchResult {
                              the launches of one stream run back to back over the timed region */
     uint64_t env_steps;   /* sum over games of step calls that advanced the game */
     uint32_t launches;    /* step-kernel launches in the timed region */
-    uint32_t launches_in_flight; /* 1, or 2 when the rollout ran as two halves on two streams (rmj_step_random) */
+    uint32_t launches_in_flight; /* streams the rollout ran on (parts of the batch, rmj_step_random); 1 = one stream */
 } RmjBenchResult;
 int rmj_bench_rollout(rmj_handle h, uint64_t policy_seed, uint32_t warmup, uint32_t steps, RmjBenchResult* out);
 

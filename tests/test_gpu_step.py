@@ -242,11 +242,12 @@ def test_shards_equal_whole_batch(mode):
 
 @pytest.mark.parametrize("mode", [2, 5])
 def test_two_stream_rollout_equals_single_stream(mode):
-    """rmj_step_random issues a multi-step rollout of >= 16 384 games as two halves on two HIP streams (header); the
-    result must be the one of stepping launch by launch on the handle's stream (n_steps = 1 never splits)."""
+    """rmj_step_random issues a multi-step rollout of >= 16 384 games as up to four parts on as many HIP streams
+    (header); the result must be the one of stepping launch by launch on the handle's stream (n_steps = 1 never
+    splits)."""
     from riichienv_amd import vecenv
 
-    B, K = 16384, 400
+    B, K = 32768, 400
     a = vecenv.VecRiichiEnv(B, game_mode=mode, seed=5, event_ring=1024)
     b = vecenv.VecRiichiEnv(B, game_mode=mode, seed=5, event_ring=1024)
     a.reset()
@@ -262,7 +263,7 @@ def test_two_stream_rollout_equals_single_stream(mode):
     lb, cb = b.legal()
     assert (ca == cb).all() and (la == lb).all()
     assert (a.mask() == b.mask()).all()
-    for g in (0, B // 2 - 1, B // 2, B - 1):
+    for g in (0, B // 4 - 1, B // 4, B // 2, 3 * B // 4 - 1, B - 1):
         assert a.mjai_log(g) == b.mjai_log(g)
     r = a.bench_rollout(0xBEEF, 0, 10)
-    assert r.launches == 20 and r.launches_in_flight == 2
+    assert r.launches == 40 and r.launches_in_flight == 4

@@ -38,14 +38,8 @@ __global__ __launch_bounds__(64 * RMJ_STEP_WPB, RMJ_STEP_WAVES) void k_step(cons
     GState& S = sh.st[wave];
     PROF_START(sh.x[wave], lane);
     const bool device_policy = (flags & STEP_F_RANDOM) != 0;
-    // Device policy: the first 16 entries of every seat's stored list (lane = 16 * seat + entry) are requested together
-    // with the record, so that the pick below does not cost a second, dependent trip to HBM (the choice needs nlegal
-    // and step_count of the record); longer lists fall back to the dependent load.
-    uint64_t* const Lg0 = E.legal + (size_t)g * 4 * RMJ_MAX_LEGAL;
-    uint64_t spec = 0;
-    if (device_policy) spec = Lg0[(lane >> 4) * RMJ_MAX_LEGAL + (lane & 15)];
     load_state(S, E.core + g, lane);
-    Ctx c{S, E, sh.x[wave], g, lane, E.wall + (size_t)g * RMJ_WALL_STRIDE, Lg0};
+    Ctx c{S, E, sh.x[wave], g, lane, E.wall + (size_t)g * RMJ_WALL_STRIDE, E.legal + (size_t)g * 4 * RMJ_MAX_LEGAL};
     c.pf_live_end = S.live_end;
     c.pf_draw = c.W[S.live_end > 0 ? S.live_end - 1 : 0];
     PROF(c.X, lane, 0);
@@ -54,18 +48,15 @@ __global__ __launch_bounds__(64 * RMJ_STEP_WPB, RMJ_STEP_WAVES) void k_step(cons
     if (device_policy) {
         // RandomAgent (random_agent.py:6-15), keyed per (game, step, seat): see rmj_step_random in the header
         uint64_t gs = sm64(policy_seed + E.game_offset + g);
-        bool pick = false;
-        uint32_t ch = 0;
+        // (requesting the list heads together with the record, to spare the dependent trip to HBM, was measured
+        // slower: the step is bound by VALU issue, not by latency, and the extra shuffle and traffic cost more)
         if (lane < 4) {
             int n = S.nlegal[lane];
             if (((S.active_mask >> lane) & 1u) && n > 0 && !S.is_done) {
-                ch = mod_small(sm64(gs + (uint64_t)S.step_count * 4ull + (uint64_t)lane), (uint32_t)n);
-                pick = true;
+                uint32_t ch = mod_small(sm64(gs + (uint64_t)S.step_count * 4ull + (uint64_t)lane), (uint32_t)n);
+                mine = c.Lg[lane * RMJ_MAX_LEGAL + ch];
             }
         }
-        const int src = (lane & 3) * 16 + (int)(ch & 15u);
-        const uint64_t got = (uint64_t)__shfl((unsigned long long)spec, src, 64);
-        if (pick) mine = ch < 16u ? got : c.Lg[lane * RMJ_MAX_LEGAL + ch];
     } else if (flags & STEP_F_IDS) {
         // Observation.find_action (observation/python.rs:119-122): the first legal action of the seat whose encoded id
         // equals the policy's id; lane = list entry.  No match = an action that fails validation (illegal action).

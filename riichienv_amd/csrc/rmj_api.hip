@@ -1308,6 +1308,17 @@ int rmj_bench_rollout(rmj_handle h, uint64_t policy_seed, uint32_t warmup, uint3
     return RMJ_OK;
 }
 
+#ifdef RMJ_CUTS
+// instruction accounting build only (scripts/valu_sections.py): waves end at PROF mark `cut` (-1: run to the end)
+extern "C" int rmj_prof_set_cut(int cut, int cut2, int cut3) {
+    HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(rmj::g_cut3), &cut3, sizeof(cut3)));
+    HIPCHK(hipDeviceSynchronize());
+    HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(rmj::g_cut), &cut, sizeof(cut)));
+    HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(rmj::g_cut2), &cut2, sizeof(cut2)));
+    return RMJ_OK;
+}
+#endif
+
 #ifdef RMJ_PROFILE
 // profiling build only (scripts/prof_sections.py): per-section wave cycles / visit counts of k_step, summed over games
 int rmj_prof_fetch(uint32_t n_games, uint64_t* cyc, uint64_t* cnt, int reset) {

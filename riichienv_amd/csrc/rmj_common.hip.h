@@ -70,6 +70,14 @@ __device__ uint32_t* g_prof_buf;  // [n_games][64]: 0..31 cycles, 32..63 visit c
     } while (0)
 #define PROF_START(X, lane) do { (X).pacc[lane] = 0u; (X).tprev = __builtin_readcyclecounter(); } while (0)
 #define PROF_FLUSH(X, lane, g) do { rmj::g_prof_buf[(size_t)(g) * 64 + (lane)] += (X).pacc[lane]; } while (0)
+#elif defined(RMJ_CUTS)
+// Instruction accounting build (scripts/valu_sections.py, never the shipped library): a wave that reaches mark `g_cut`
+// ends there, before anything is stored.  The difference of the launch's PMC instruction counters between two cuts is
+// the number of instructions executed between the two marks.
+__device__ int g_cut = -1, g_cut2 = -1, g_cut3 = -1;
+#define PROF(X, lane, id) do { if (rmj::g_cut == (id) || rmj::g_cut2 == (id) || rmj::g_cut3 == (id)) __builtin_amdgcn_endpgm(); } while (0)
+#define PROF_START(X, lane) do {} while (0)
+#define PROF_FLUSH(X, lane, g) do {} while (0)
 #else
 #define PROF(X, lane, id) do {} while (0)
 #define PROF_START(X, lane) do {} while (0)
@@ -191,6 +199,29 @@ __device__ __forceinline__ uint32_t mod_small(uint64_t x, uint32_t n) {
         r = rem;
     }
     return (uint32_t)r;
+}
+
+// The same for wave-uniform operands, on the scalar unit only (the step is bound by VALU issue): with a_i = 2^(16 i) mod n
+// the digit sum d0 + d1 a1 + d2 a2 + d3 a3 is below 2^24 and congruent to x, and for v < 2^24, n <= 64 the quotient is
+// exactly mulhi(v, ceil(2^32 / n)) (error term v * (M n - 2^32) < 2^24 * 64 < 2^32).  Both tables are compile-time data
+// in the constant address space: scalar loads.
+struct ModTab { uint32_t pw[65]; uint32_t inv[65]; };
+constexpr ModTab make_modtab() {
+    ModTab t{};
+    for (uint32_t n = 1; n <= 64; n++) {
+        const uint64_t a1 = 65536ull % n, a2 = (a1 * 65536ull) % n, a3 = (a2 * 65536ull) % n;
+        t.pw[n] = (uint32_t)(a1 | (a2 << 8) | (a3 << 16));
+        t.inv[n] = n == 1 ? 0u : (uint32_t)((0x100000000ull + n - 1) / n);
+    }
+    return t;
+}
+__constant__ const ModTab g_modtab = make_modtab();
+__device__ __forceinline__ uint32_t mod_small_uniform(uint64_t x, uint32_t n) {  // x, n in SGPRs; 1 <= n <= 64
+    const uint32_t pw = g_modtab.pw[n], inv = g_modtab.inv[n];
+    const uint32_t lo = (uint32_t)x, hi = (uint32_t)(x >> 32);
+    const uint32_t v = (lo & 0xFFFFu) + (lo >> 16) * (pw & 0xFFu) + (hi & 0xFFFFu) * ((pw >> 8) & 0xFFu) + (hi >> 16) * (pw >> 16);
+    const uint32_t q = (uint32_t)(((uint64_t)v * inv) >> 32);
+    return n == 1 ? 0u : v - q * n;
 }
 
 // ---------------------------------------------------------------- small helpers

@@ -47,15 +47,21 @@ __global__ __launch_bounds__(64 * RMJ_STEP_WPB, RMJ_STEP_WAVES) void k_step(cons
     uint64_t mine = RMJ_NO_ACTION;
     if (device_policy) {
         // RandomAgent (random_agent.py:6-15), keyed per (game, step, seat): see rmj_step_random in the header
-        uint64_t gs = sm64(policy_seed + E.game_offset + g);
-        // (requesting the list heads together with the record, to spare the dependent trip to HBM, was measured
-        // slower: the step is bound by VALU issue, not by latency, and the extra shuffle and traffic cost more)
-        if (lane < 4) {
-            int n = S.nlegal[lane];
-            if (((S.active_mask >> lane) & 1u) && n > 0 && !S.is_done) {
-                uint32_t ch = mod_small(sm64(gs + (uint64_t)S.step_count * 4ull + (uint64_t)lane), (uint32_t)n);
-                mine = c.Lg[lane * RMJ_MAX_LEGAL + ch];
-            }
+        // Scalar unit throughout (the step is bound by VALU issue; this pick used to cost 120 VALU instructions): a
+        // loop over the acting seats, hash and modulo on SGPRs, one vector load of the chosen entry by lane = seat.
+        // (Requesting the list heads together with the record, to spare the dependent trip to HBM, was measured
+        // slower: latency is hidden by the other waves, the extra shuffle and traffic are not.)
+        const uint64_t gs = sm64(policy_seed + E.game_offset + uni(g));
+        const uint64_t sk = gs + (uint64_t)uni((uint32_t)S.step_count) * 4ull;
+        uint32_t am = S.is_done ? 0u : (uint32_t)S.active_mask;
+        am = uni(am) & 0xFu;
+        while (am) {
+            const int p = __builtin_ctz(am);
+            am &= am - 1u;
+            const uint32_t n = uni((uint32_t)S.nlegal[p]);
+            if (n == 0u) continue;
+            const uint32_t ch = mod_small_uniform(sm64(sk + (uint64_t)p), n > 64u ? 64u : n);
+            if (lane == p) mine = c.Lg[p * RMJ_MAX_LEGAL + ch];
         }
     } else if (flags & STEP_F_IDS) {
         // Observation.find_action (observation/python.rs:119-122): the first legal action of the seat whose encoded id

@@ -286,8 +286,22 @@ __device__ __forceinline__ uint64_t fill_waits13(Ctx& c, PState& P, const PH& h1
     const uint32_t T9 = 1u | (1u << 24);
     const int yaochu_kinds = __popc((h13.a | (h13.a >> 1) | (h13.a >> 2)) & T9) + __popc((h13.b | (h13.b >> 1) | (h13.b >> 2)) & T9) +
                              __popc((h13.c | (h13.c >> 1) | (h13.c >> 2)) & T9) + __popc((h13.d | (h13.d >> 1) | (h13.d >> 2)) & O7_1);
-    if (isolated_tiles(h13, c.lane) >= 4 && yaochu_kinds < 11) {
-        sh = 2;  // a lower bound is all the users of sh13 need
+    // iso isolated tiles leave r = tiles - iso for blocks: 2 * mentsu + taatsu <= {6, 5, 4} for iso = {4, 5, >= 6} whatever
+    // the number of melds, i.e. standard shanten >= {2, 3, 4}; a closed hand also has the exact chiitoi number (6 - pairs
+    // + missing kinds) and a kokushi bound (13 - kinds - 1).  The bound is worth keeping as large as it is: every later
+    // tedashi lowers it by one instead of recomputing (resolve_discard).
+    const int iso = isolated_tiles(h13, c.lane);
+    int lb = iso >= 6 ? 4 : (iso == 5 ? 3 : (iso == 4 ? 2 : 0));
+    if (P.hand_len / 3 == 4) {
+        const int koku = 12 - yaochu_kinds;
+        lb = koku < lb ? koku : lb;
+        if (lb > 2) {
+            const int chi = sh_chiitoi(h13, false);
+            lb = chi < lb ? chi : lb;
+        }
+    }
+    if (lb >= 2) {
+        sh = lb;  // a lower bound is all the users of sh13 need
     } else {
         sh = sh_shanten_wave(h13, P.hand_len / 3, sh_tables_of(c.E), c.lane);
         if (sh <= 0) W = wave_waits(h13, c.lane);
@@ -1329,7 +1343,13 @@ __device__ __forceinline__ void resolve_discard(Ctx& c, int pid, int tile, bool 
     S.drawn_tile = 0xFF;
     if (!tsumogiri) {
         P.last_tedashi = (uint8_t)tile;
-        fl &= ~(uint32_t)PF_WAITS_VALID;  // the 13-tile hand changed; a tsumogiri leaves it (and the cache) intact
+        // The 13-tile hand changed by one tile (a tsumogiri leaves it, and the cache, intact): its shanten moved by at
+        // most one.  A cached lower bound >= 3 therefore stays a bound >= 2 after losing one: still "no waits" (waits13
+        // is 0 for every sh13 >= 1) and still "no Riichi after the next draw" (tenpai_after_discard).  A bound of 2 is
+        // recomputed instead of kept as 1: measured, the riichi probe it would no longer spare costs more than the refill.
+        const int lb = P.sh13;
+        if ((fl & PF_WAITS_VALID) && lb >= 3) P.sh13 = (uint8_t)(lb - 1);
+        else fl &= ~(uint32_t)PF_WAITS_VALID;
     }
     S.needs_tsumo = 1;
     if (stage) {
@@ -1790,7 +1810,7 @@ __device__ __forceinline__ void step_game(Ctx& c, const uint64_t mine, bool trus
         return;
     }
     // ---- WaitResponse (state/mod.rs:900-1314)
-#ifdef RMJ_PROFILE
+#if defined(RMJ_PROFILE) || defined(RMJ_CUTS)
     struct ProfTail { Ctx& c; __device__ ~ProfTail() { PROF(c.X, c.lane, 7); } } prof_tail{c};
 #endif
     // lane = seat (active_players is in ascending seat order, state/mod.rs:1378-1395)

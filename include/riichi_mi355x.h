@@ -303,6 +303,19 @@ int rmj_sync(rmj_handle h); /* wait for the handle's stream */
  * env.rs:56-72 is not reproduced (start_game clears the device log, later events are not appended). */
 int rmj_apply_events(rmj_handle h, const RmjEvent* events /*[n][3]*/);
 
+/* Auxiliary feature blocks of an Observation that are not part of encode() / encode_extended(); absolute seat order,
+ * public information only, so one block per game serves every observing seat (NP = 4, W = 34; 3P: NP = 3, W = 27):
+ *   RMJ_AUX_KAWA_OVERVIEW     out[n][NP][7][W]   Observation.encode_kawa_overview (observation/python.rs:881-925,
+ *                                                observation_3p/python.rs:759-810), incl. its red-five id / column quirks
+ *   RMJ_AUX_YAKU_POSSIBILITY  out[n][NP][21][2]  Observation.encode_yaku_possibility (observation/python.rs:327-455,
+ *                                                observation_3p/python.rs:275-400) over yaku_checker.rs:27-412
+ *   RMJ_AUX_FURITEN_RON       out[n][NP][21]     Observation.encode_furiten_ron_possibility (observation/python.rs:251-293);
+ *                                                all ones: the reference never fills tsumogiri_flags (observation/mod.rs:105)
+ * `out` is a host pointer (rmj_encode_aux) or a device pointer written on the handle's stream (rmj_encode_aux_device). */
+enum { RMJ_AUX_KAWA_OVERVIEW = 0, RMJ_AUX_YAKU_POSSIBILITY = 1, RMJ_AUX_FURITEN_RON = 2 };
+int rmj_encode_aux(rmj_handle h, int which, float* out);
+int rmj_encode_aux_device(rmj_handle h, int which, float* d_out);
+
 /* ------------------------------------------------------------------ measurement */
 typedef struct RmjBenchResult {
     double total_ms;      /* HIP-event time over the timed region (stream of the handle) */

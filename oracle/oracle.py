@@ -56,6 +56,8 @@ def lib():
         L.orc_action_encode_3p.argtypes = [C.c_uint64]
         L.orc_game_encode.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
         L.orc_game_encode_extended.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
+        for f in (L.orc_game_encode_kawa_overview, L.orc_game_encode_yaku_possibility, L.orc_game_encode_furiten_ron):
+            f.argtypes = [C.c_void_p, C.c_void_p]
         L.orc_shanten.argtypes = [C.c_void_p, C.c_uint32, C.c_int, C.c_void_p]
         L.orc_effective_tiles.argtypes = [C.c_void_p, C.c_uint32, C.c_int, C.c_void_p]
         L.orc_best_ukeire.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_int, C.c_void_p]
@@ -206,6 +208,22 @@ class Game:
     def encode_extended(self, pid):
         out = np.zeros((215, 27 if self.sanma else 34), np.float32)
         self.L.orc_game_encode_extended(self.h, pid, out.ctypes.data)
+        return out
+
+    def encode_kawa_overview(self):
+        np_ = 3 if self.sanma else 4
+        out = np.zeros((np_, 7, 27 if self.sanma else 34), np.float32)
+        self.L.orc_game_encode_kawa_overview(self.h, out.ctypes.data)
+        return out
+
+    def encode_yaku_possibility(self):
+        out = np.zeros((3 if self.sanma else 4, 21, 2), np.float32)
+        self.L.orc_game_encode_yaku_possibility(self.h, out.ctypes.data)
+        return out
+
+    def encode_furiten_ron_possibility(self):
+        out = np.zeros((3 if self.sanma else 4, 21), np.float32)
+        self.L.orc_game_encode_furiten_ron(self.h, out.ctypes.data)
         return out
 
     def apply_event(self, ev):

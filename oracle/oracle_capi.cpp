@@ -759,6 +759,138 @@ void orc_game_encode(void* gp, int pid, float* arr) {
 // Snapshot quirks restated: Observation.last_discard receives the DISCARDER'S SEAT, not the tile
 // (state/mod.rs:252 destructures (pid, tile) as (tile, _pid)); dora membership compares full 136-ids with the copy-0
 // id of the next tile; riichi_sutehais is only written on an unreachable branch (state/mod.rs:466).
+// ---- auxiliary encoders (absolute seat order, public information only: the same for every observing seat) ----
+// Observation.encode_kawa_overview (observation/python.rs:881-925, observation_3p/python.rs:759-810): out [NP][7][W].
+// Channels 0..3: "at least k+1 discards of this type"; channels 4..6: red-five flags.  Quirks reproduced: the reference
+// tests the ids 20 / 24 / 28 (not 16 / 52 / 88) and, in 4P, marks column 5 + 9 i (6m / 6p / 6s); 3P marks channel 5
+// column 6 and channel 6 column 15, and never channel 4.
+void orc_game_encode_kawa_overview(void* gp, float* out) {
+    GameState* g = (GameState*)gp;
+    const bool sanma = g->sanma;
+    const int W = sanma ? 27 : 34, NP = g->NP;
+    std::memset(out, 0, sizeof(float) * NP * 7 * W);
+    auto col = [&](int t34) -> int { return sanma ? (t34 == 0 ? 0 : (t34 >= 8 && t34 < 34 ? t34 - 7 : -1)) : (t34 < 34 ? t34 : -1); };
+    for (int p = 0; p < NP; p++) {
+        float* a = out + (size_t)p * 7 * W;
+        int cnt[34] = {0};
+        bool aka[3] = {false, false, false};
+        for (uint8_t t : g->players[p].discards) {
+            const int c = col(t / 4);
+            if (c >= 0) {
+                const int k = cnt[c] < 3 ? cnt[c] : 3;
+                a[k * W + c] = 1.0f;
+                if (cnt[c] < 255) cnt[c]++;
+            }
+            if (t == 20) aka[0] = true;
+            if (t == 24) aka[1] = true;
+            if (t == 28) aka[2] = true;
+        }
+        if (!sanma) {
+            for (int i = 0; i < 3; i++)
+                if (aka[i]) a[(4 + i) * W + 5 + i * 9] = 1.0f;
+        } else {
+            if (aka[1]) a[5 * W + col(13)] = 1.0f;
+            if (aka[2]) a[6 * W + col(22)] = 1.0f;
+        }
+    }
+}
+// Observation.encode_yaku_possibility (observation/python.rs:327-455, observation_3p/python.rs:275-400) over
+// yaku_checker.rs:27-412: out [NP][21][2], 0.0 = "impossible given melds / discards / dora indicators", else 1.0
+// (Possible and Unknown both encode as 1.0, yaku_checker.rs:18-25); tsumo and ron columns are equal.
+void orc_game_encode_yaku_possibility(void* gp, float* out) {
+    GameState* g = (GameState*)gp;
+    const int NP = g->NP;
+    auto yaochu = [](int tt) { return tt % 9 == 0 || tt % 9 == 8 || tt >= 27; };
+    for (int p = 0; p < NP; p++) {
+        const PlayerState& P = g->players[p];
+        const auto& melds = P.melds;
+        bool imp[21];
+        for (bool& b : imp) b = false;
+        auto visible = [&](int tt) {  // yaku_checker.rs:42-58: own discards + dora indicators
+            int n = 0;
+            for (uint8_t t : P.discards) n += (t / 4 == tt);
+            for (uint8_t t : g->wall.dora_indicators) n += (t / 4 == tt);
+            return n;
+        };
+        auto has_set = [&](int tt) {  // yaku_checker.rs:68-75
+            for (const Meld& m : melds)
+                if (!m.tiles.empty() && m.tiles[0] / 4 == tt && m.tiles.size() >= 3) return true;
+            return false;
+        };
+        auto yakuhai_imp = [&](int tt) { return !has_set(tt) && visible(tt) >= 3; };
+        // 0 tanyao (:28-39)
+        for (const Meld& m : melds)
+            for (uint8_t t : m.tiles)
+                if (yaochu(t / 4)) imp[0] = true;
+        // 1..3 dragons, 4 round wind, 5 seat wind (:61-84; python.rs:347-372)
+        for (int k = 0; k < 3; k++) imp[1 + k] = yakuhai_imp(31 + k);
+        imp[4] = yakuhai_imp(27 + g->round_wind);
+        imp[5] = yakuhai_imp(27 + (p + NP - g->oya) % NP);
+        // 6 honitsu, 7 chinitsu (:87-138)
+        if (!melds.empty()) {
+            bool suit[3] = {false, false, false}, honor = false;
+            for (const Meld& m : melds)
+                for (uint8_t t : m.tiles) {
+                    if (t / 4 < 27) suit[t / 4 / 9] = true;
+                    else honor = true;
+                }
+            const int ns = (int)suit[0] + suit[1] + suit[2];
+            imp[6] = ns >= 2;
+            imp[7] = ns >= 2 || (ns == 1 && honor);
+        }
+        // 8 toitoi (:141-166): a meld of three consecutive types
+        for (const Meld& m : melds)
+            if (m.tiles.size() == 3) {
+                const int t0 = m.tiles[0] / 4, t1 = m.tiles[1] / 4, t2 = m.tiles[2] / 4;
+                if (t0 + 1 == t1 && t1 + 1 == t2 && t0 < 27) imp[8] = true;
+            }
+        // 9 chiitoitsu (:169-175), 19 iipeikou (:385-392): any meld
+        imp[9] = imp[19] = !melds.empty();
+        // 10 shousangen (:178-201): some dragon fully visible
+        for (int k = 0; k < 3; k++)
+            if (visible(31 + k) >= 4) imp[10] = true;
+        // 11 daisangen (:204-235): a dragon without a set and two or more visible
+        for (int k = 0; k < 3; k++)
+            if (!has_set(31 + k) && visible(31 + k) >= 2) imp[11] = true;
+        // 12 tsuuiisou (:238-249), 13 chinroutou (:252-263), 14 honroutou (:266-278)
+        for (const Meld& m : melds)
+            for (uint8_t t : m.tiles) {
+                const int tt = t / 4;
+                if (tt < 27) imp[12] = true;
+                if (tt >= 27 || (tt % 9 != 0 && tt % 9 != 8)) imp[13] = true;
+                if (!yaochu(tt)) imp[14] = true;
+            }
+        // 15 kokushi (:281-300)
+        if (!melds.empty()) imp[15] = true;
+        else {
+            static const int req[13] = {0, 8, 9, 17, 18, 26, 27, 28, 29, 30, 31, 32, 33};
+            for (int tt : req)
+                if (visible(tt) >= 4) imp[15] = true;
+        }
+        // 16 chanta (:303-328), 17 junchan (:331-359)
+        for (const Meld& m : melds) {
+            if (m.tiles.empty()) continue;
+            bool any_yaochu = false, any_terminal = false, any_honor = false;
+            for (uint8_t t : m.tiles) {
+                const int tt = t / 4;
+                if (yaochu(tt)) any_yaochu = true;
+                if (tt >= 27) any_honor = true;
+                else if (tt % 9 == 0 || tt % 9 == 8) any_terminal = true;
+            }
+            if (!any_yaochu) imp[16] = true;
+            if (any_honor || !any_terminal) imp[17] = true;
+        }
+        // 18 sanshoku, 20 ittsu: never impossible (:363-382, :395-412)
+        for (int y = 0; y < 21; y++) out[((size_t)p * 21 + y) * 2] = out[((size_t)p * 21 + y) * 2 + 1] = imp[y] ? 0.0f : 1.0f;
+    }
+}
+// Observation.encode_furiten_ron_possibility (observation/python.rs:251-293): out [NP][21].  It zeroes a seat's row after
+// three consecutive tsumogiri in `tsumogiri_flags`, which the reference never fills (observation/mod.rs:105): all ones.
+void orc_game_encode_furiten_ron(void* gp, float* out) {
+    GameState* g = (GameState*)gp;
+    for (int i = 0; i < g->NP * 21; i++) out[i] = 1.0f;
+}
+
 void orc_game_encode_extended(void* gp, int pid, float* arr) {
     GameState* g = (GameState*)gp;
     const bool sanma = g->sanma;

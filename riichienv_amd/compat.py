@@ -216,7 +216,8 @@ class GameRule:  # rule.rs:10-57
 class Observation:
     """Per-seat snapshot (observation/mod.rs:24-56; state/mod.rs:189-263)."""
 
-    def __init__(self, player_id, view, legal, mask, waits, new_events, events, encoder, num_players=4, ext_encoder=None):
+    def __init__(self, player_id, view, legal, mask, waits, new_events, events, encoder, num_players=4, ext_encoder=None,
+                 aux_encoder=None):
         pid = player_id
         self.player_id = pid
         self.num_players = num_players            # 3: Observation3P (observation_3p/mod.rs)
@@ -247,6 +248,7 @@ class Observation:
         self.events = events
         self._encoder = encoder
         self._ext_encoder = ext_encoder
+        self._aux_encoder = aux_encoder
 
     def action_space_size(self):  # observation/python.rs:114-117
         return 60 if self.num_players == 3 else 82
@@ -294,6 +296,16 @@ class Observation:
 
     def encode_riichi_sutehais(self) -> bytes:  # (np - 1, 3)
         return np.ascontiguousarray(self._ext()[206:206 + 3 * (self.num_players - 1), 0]).tobytes()
+
+    # ---- blocks outside the extended tensor: one device launch per block (rmj_encode_aux)
+    def encode_kawa_overview(self) -> bytes:  # observation/python.rs:881-925 -> (np, 7, W)
+        return self._aux_encoder("encode_kawa_overview").tobytes()
+
+    def encode_yaku_possibility(self) -> bytes:  # observation/python.rs:327-455 -> (np, 21, 2)
+        return self._aux_encoder("encode_yaku_possibility").tobytes()
+
+    def encode_furiten_ron_possibility(self) -> bytes:  # observation/python.rs:251-293 -> (np, 21)
+        return self._aux_encoder("encode_furiten_ron_possibility").tobytes()
 
     def legal_actions(self):  # observation/python.rs:93-96
         return list(self._legal_actions)
@@ -386,6 +398,11 @@ class RiichiEnv:
                 enc["x"] = self._v.encode_extended()
             return enc["x"][0, pid]
 
+        def aux_encoder(name):
+            if name not in enc:
+                enc[name] = getattr(self._v, name)()
+            return enc[name][0]
+
         nmask = 60 if self._np == 3 else 82
         out = {}
         for pid in pids:
@@ -397,7 +414,7 @@ class RiichiEnv:
             new = log[self._cursor[pid]:]
             self._cursor[pid] = len(log)
             out[pid] = Observation(pid, view, la, mask[0, pid][:nmask] if active else np.zeros(nmask, np.uint8), w, new, log,
-                                   encoder, self._np, ext_encoder)
+                                   encoder, self._np, ext_encoder, aux_encoder)
         return out
 
     def get_observation(self, player_id):

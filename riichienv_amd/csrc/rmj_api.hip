@@ -323,6 +323,124 @@ __global__ __launch_bounds__(64) void k_encode(Env E, int only_active, const flo
     }
 }
 
+// ---- auxiliary encoders (row N3): kawa overview, yaku possibility, furiten-ron possibility ----------------------
+// One wave per game; absolute seat order, public information only (the same for every observing seat).
+//   which 0  Observation.encode_kawa_overview           (observation/python.rs:881-925, observation_3p/python.rs:759-810)
+//   which 1  Observation.encode_yaku_possibility        (observation/python.rs:327-455 over yaku_checker.rs:27-412)
+//   which 2  Observation.encode_furiten_ron_possibility (observation/python.rs:251-293)
+template <bool SANMA>
+__global__ __launch_bounds__(64) void k_encode_aux(Env E, int which, float* __restrict__ out) {
+    constexpr int W = SANMA ? ENC_W3 : ENC_W4, NP = SANMA ? 3 : 4;
+    __shared__ GState st;
+    const int lane = threadIdx.x & 63;
+    const uint32_t g = blockIdx.x;
+    if (which == 2) {  // tsumogiri_flags is never filled by the reference (observation/mod.rs:105): every row stays 1.0
+        for (int i = lane; i < NP * 21; i += 64) out[(size_t)g * NP * 21 + i] = 1.0f;
+        return;
+    }
+    if (lane < (int)(sizeof(GState) / 16)) reinterpret_cast<uint4*>(&st)[lane] = reinterpret_cast<const uint4*>(E.core + g)[lane];
+    wave_sync();
+    const GState& S = st;
+    if (which == 0) {
+        // lane = tile column.  Channel k (< 4) is set iff the seat has discarded more than k tiles of the type; channels 4..6 are
+        // the red-five flags with the reference's ids and columns (20 / 24 / 28; 4P column 5 + 9 i, 3P (5, 6) and (6, 15))
+        float* dst = out + (size_t)g * NP * 7 * W;
+        for (int p = 0; p < NP; p++) {
+            const PState& P = S.p[p];
+            int cnt = 0;
+            bool aka0 = false, aka1 = false, aka2 = false;
+            for (int k = 0; k < P.n_discards; k++) {
+                const int t = P.discards[k];
+                cnt += (lane < W && enc_col<SANMA>(t >> 2) == lane);
+                aka0 |= t == 20;
+                aka1 |= t == 24;
+                aka2 |= t == 28;
+            }
+            if (lane < W) {
+                for (int k = 0; k < 4; k++) dst[(p * 7 + k) * W + lane] = cnt > k ? 1.0f : 0.0f;
+                if (!SANMA) {
+                    dst[(p * 7 + 4) * W + lane] = (aka0 && lane == 5) ? 1.0f : 0.0f;
+                    dst[(p * 7 + 5) * W + lane] = (aka1 && lane == 14) ? 1.0f : 0.0f;
+                    dst[(p * 7 + 6) * W + lane] = (aka2 && lane == 23) ? 1.0f : 0.0f;
+                } else {
+                    dst[(p * 7 + 4) * W + lane] = 0.0f;
+                    dst[(p * 7 + 5) * W + lane] = (aka1 && lane == 6) ? 1.0f : 0.0f;
+                    dst[(p * 7 + 6) * W + lane] = (aka2 && lane == 15) ? 1.0f : 0.0f;
+                }
+            }
+        }
+        return;
+    }
+    // which == 1.  lane = tile type: visible[type] = own discards + dora indicators (yaku_checker.rs:42-58); the meld facts
+    // are wave-uniform loops over <= 4 melds x <= 4 tiles.
+    float* dst = out + (size_t)g * NP * 21 * 2;
+    for (int p = 0; p < NP; p++) {
+        const PState& P = S.p[p];
+        int vis = 0;
+        for (int k = 0; k < P.n_discards; k++) vis += (P.discards[k] >> 2) == lane;
+        for (int k = 0; k < S.n_dora; k++) vis += (S.dora[k] >> 2) == lane;
+        const uint64_t vis2 = __ballot(lane < 34 && vis >= 2), vis3 = __ballot(lane < 34 && vis >= 3), vis4 = __ballot(lane < 34 && vis >= 4);
+        uint64_t set_types = 0;  // types with a meld of >= 3 tiles starting with that type (yaku_checker.rs:68-75)
+        bool any_yaochu = false, simple_tile = false, any_number = false, any_honor = false, any_non_terminal = false;
+        bool suit0 = false, suit1 = false, suit2 = false, has_run = false, no_yaochu_meld = false, junchan_bad = false;
+        const int nm = P.n_melds;
+        for (int m = 0; m < nm; m++) {
+            const int len = (P.meld_type[m] == RMJ_MELD_CHI || P.meld_type[m] == RMJ_MELD_PON) ? 3 : 4;
+            const int t0 = P.meld_tiles[m][0] >> 2, t1 = P.meld_tiles[m][1] >> 2, t2 = P.meld_tiles[m][2] >> 2;
+            set_types |= 1ull << t0;
+            if (len == 3 && t0 + 1 == t1 && t1 + 1 == t2 && t0 < 27) has_run = true;
+            bool m_yaochu = false, m_terminal = false, m_honor = false;
+            for (int k = 0; k < len; k++) {
+                const int tt = P.meld_tiles[m][k] >> 2;
+                const bool honor = tt >= 27, terminal = !honor && (tt % 9 == 0 || tt % 9 == 8);
+                m_yaochu |= honor || terminal;
+                m_terminal |= terminal;
+                m_honor |= honor;
+                any_number |= !honor;
+                any_non_terminal |= !terminal;
+                simple_tile |= !honor && !terminal;
+                if (!honor) { suit0 |= tt < 9; suit1 |= tt >= 9 && tt < 18; suit2 |= tt >= 18; }
+            }
+            any_yaochu |= m_yaochu;
+            any_honor |= m_honor;
+            if (!m_yaochu) no_yaochu_meld = true;
+            if (m_honor || !m_terminal) junchan_bad = true;
+        }
+        const int ns = (int)suit0 + (int)suit1 + (int)suit2;
+        const int round_t = 27 + S.round_wind, seat_t = 27 + (p + NP - S.oya) % NP;
+        auto yakuhai_imp = [&](int tt) { return !((set_types >> tt) & 1ull) && ((vis3 >> tt) & 1ull); };
+        const uint64_t koku_req = 0x101ull | (0x101ull << 9) | (0x101ull << 18) | (0x7Full << 27);
+        bool imp = false;
+        switch (lane) {
+            case 0: imp = any_yaochu; break;
+            case 1: imp = yakuhai_imp(31); break;
+            case 2: imp = yakuhai_imp(32); break;
+            case 3: imp = yakuhai_imp(33); break;
+            case 4: imp = yakuhai_imp(round_t); break;
+            case 5: imp = yakuhai_imp(seat_t); break;
+            case 6: imp = nm > 0 && ns >= 2; break;
+            case 7: imp = nm > 0 && (ns >= 2 || (ns == 1 && any_honor)); break;
+            case 8: imp = has_run; break;
+            case 9: imp = nm > 0; break;
+            case 10: imp = ((vis4 >> 31) & 7ull) != 0ull; break;
+            case 11: imp = (((vis2 & ~set_types) >> 31) & 7ull) != 0ull; break;
+            case 12: imp = any_number; break;
+            case 13: imp = any_non_terminal; break;
+            case 14: imp = simple_tile; break;
+            case 15: imp = nm > 0 || (vis4 & koku_req) != 0ull; break;
+            case 16: imp = no_yaochu_meld; break;
+            case 17: imp = junchan_bad; break;
+            case 19: imp = nm > 0; break;
+            default: break;  // 18 sanshoku, 20 ittsu: never impossible
+        }
+        if (lane < 21) {
+            const float v = imp ? 0.0f : 1.0f;
+            reinterpret_cast<float2*>(dst)[p * 21 + lane] = make_float2(v, v);
+        }
+    }
+}
+
+
 // shanten.rs:244-261 / :470-484 (calculate_shanten / calculate_shanten_3p over raw histograms): one thread per hand
 __global__ void k_shanten(ShantenTables T, const uint8_t* counts, uint32_t n, int sanma, int8_t* out) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1168,6 +1286,33 @@ int rmj_encode(rmj_handle h, int only_active, float* out) {
     if ((rc = rmj_encode_device(h, only_active, d))) return rc;
     HIPCHK(hipStreamSynchronize(h->stream));
     HIPCHK(hipMemcpy(out, d, bytes, hipMemcpyDeviceToHost));
+    return RMJ_OK;
+}
+
+static size_t aux_floats(const rmj_env* h, int which) {
+    const size_t np = h->cfg.game_mode >= 3 ? 3 : 4, w = h->cfg.game_mode >= 3 ? ENC_W3 : ENC_W4;
+    return which == 0 ? np * 7 * w : (which == 1 ? np * 21 * 2 : np * 21);
+}
+int rmj_encode_aux_device(rmj_handle h, int which, float* d_out) {
+    if (!h || !d_out) return fail(RMJ_ERR_ARG, "null argument");
+    if (which < 0 || which > 2) return fail(RMJ_ERR_ARG, "unknown auxiliary encoder");
+    HIPCHK(hipSetDevice(h->cfg.device));
+    if (h->cfg.game_mode >= 3) hipLaunchKernelGGL((k_encode_aux<true>), dim3(h->cfg.n_games), dim3(64), 0, h->stream, h->d, which, d_out);
+    else hipLaunchKernelGGL((k_encode_aux<false>), dim3(h->cfg.n_games), dim3(64), 0, h->stream, h->d, which, d_out);
+    HIPCHK(hipGetLastError());
+    return RMJ_OK;
+}
+int rmj_encode_aux(rmj_handle h, int which, float* out) {
+    if (!h || !out) return fail(RMJ_ERR_ARG, "null argument");
+    if (which < 0 || which > 2) return fail(RMJ_ERR_ARG, "unknown auxiliary encoder");
+    HIPCHK(hipSetDevice(h->cfg.device));
+    const size_t bytes = (size_t)h->cfg.n_games * aux_floats(h, which) * sizeof(float);
+    void* sp;
+    int rc = scratch_for(h, bytes, &sp);
+    if (rc) return rc;
+    if ((rc = rmj_encode_aux_device(h, which, (float*)sp))) return rc;
+    HIPCHK(hipStreamSynchronize(h->stream));
+    HIPCHK(hipMemcpy(out, sp, bytes, hipMemcpyDeviceToHost));
     return RMJ_OK;
 }
 

@@ -27,7 +27,7 @@ EXPORTS = [
     "rmj_get_waits", "rmj_get_scores", "rmj_get_ranks", "rmj_get_step_counts", "rmj_total_steps", "rmj_peek_state",
     "rmj_poke_state", "rmj_get_event_counts", "rmj_get_events", "rmj_format_event", "rmj_eval_hands",
     "rmj_agari_counts", "rmj_calculate_score", "rmj_shanten", "rmj_effective_tiles", "rmj_best_ukeire", "rmj_apply_events", "rmj_device_views", "rmj_step_ids_device",
-    "rmj_scores_device", "rmj_sync", "rmj_encode", "rmj_encode_device", "rmj_encode_extended", "rmj_encode_extended_device", "rmj_bench_rollout",
+    "rmj_scores_device", "rmj_sync", "rmj_encode", "rmj_encode_device", "rmj_encode_extended", "rmj_encode_extended_device", "rmj_encode_aux", "rmj_encode_aux_device", "rmj_bench_rollout",
 ]
 
 
@@ -99,6 +99,8 @@ def load_lib():
     L.rmj_encode_device.argtypes = [vp, C.c_int, vp]
     L.rmj_encode_extended.argtypes = [vp, C.c_int, vp]
     L.rmj_encode_extended_device.argtypes = [vp, C.c_int, vp]
+    L.rmj_encode_aux.argtypes = [vp, C.c_int, vp]
+    L.rmj_encode_aux_device.argtypes = [vp, C.c_int, vp]
     L.rmj_effective_tiles.argtypes = [C.c_int, vp, C.c_uint32, C.c_int, vp]
     L.rmj_best_ukeire.argtypes = [C.c_int, vp, vp, C.c_uint32, C.c_int, vp]
     L.rmj_apply_events.argtypes = [vp, vp]
@@ -315,6 +317,23 @@ class VecRiichiEnv:
         out = np.zeros((self.n, 4, 215, w), np.float32)
         _chk(self.L.rmj_encode_extended(self.h, int(only_active), out.ctypes.data))
         return out
+
+    def _encode_aux(self, which, shape):
+        out = np.zeros((self.n,) + shape, np.float32)
+        _chk(self.L.rmj_encode_aux(self.h, which, out.ctypes.data))
+        return out
+
+    def encode_kawa_overview(self):
+        """Observation.encode_kawa_overview() of every game: [n][NP][7][W] f32 (absolute seats; header RMJ_AUX_*)."""
+        return self._encode_aux(0, (3, 7, 27) if self.game_mode >= 3 else (4, 7, 34))
+
+    def encode_yaku_possibility(self):
+        """Observation.encode_yaku_possibility() of every game: [n][NP][21][2] f32."""
+        return self._encode_aux(1, (3, 21, 2) if self.game_mode >= 3 else (4, 21, 2))
+
+    def encode_furiten_ron_possibility(self):
+        """Observation.encode_furiten_ron_possibility() of every game: [n][NP][21] f32."""
+        return self._encode_aux(2, (3, 21) if self.game_mode >= 3 else (4, 21))
 
     def bench_rollout(self, policy_seed, warmup, steps) -> abi.BenchResult:
         r = abi.BenchResult()

@@ -316,6 +316,33 @@ enum { RMJ_AUX_KAWA_OVERVIEW = 0, RMJ_AUX_YAKU_POSSIBILITY = 1, RMJ_AUX_FURITEN_
 int rmj_encode_aux(rmj_handle h, int which, float* out);
 int rmj_encode_aux_device(rmj_handle h, int which, float* d_out);
 
+/* Sequence (transformer) features, observation/sequence_features.rs (4-player games only, like the reference; spec
+ * docs/SEQUENCE_FEATURE_ENCODING.md), for every (game, seat): Observation.encode_seq_sparse(game_style) (:331-378),
+ * encode_seq_numeric (:447-471), encode_seq_candidates (:697-813) and, per game, encode_seq_progression (:503-671).
+ * Arrays are padded to fixed lengths with the reference's padding values (441; (4,276,2,2,4); (279,2,2,3)), the real
+ * lengths are returned beside them.  The reference derives these features from the MJAI strings an Observation
+ * carries (`events`, the seat's log since its previous observation); the device defines them over the events of the
+ * CURRENT ROUND, read from the binary event ring: the progression is GameState::round_seq_progression (the snapshot
+ * the reference attaches with enable_seq_caching, state/mod.rs:257-260, 2150-2161), the drawn tile, the last
+ * discarder and the round-start honba / deposits / scores are those of the round.  The ring must still hold the
+ * round's start_kyoku (create the handle with event_ring >= 256): otherwise n_progression[g] = 0xFFFF and the
+ * round-start numbers fall back to the current ones (sequence_features.rs:490).  Seats that are not to act get no
+ * candidates. */
+#define RMJ_SEQ_SPARSE 25
+#define RMJ_SEQ_PROG 256
+#define RMJ_SEQ_CAND 64
+typedef struct RmjSeqBuffers {
+    uint16_t* sparse;        /* [n][4][25]     token ids, padded with 441 */
+    uint8_t* n_sparse;       /* [n][4]         */
+    float* numeric;          /* [n][4][12]     */
+    uint16_t* progression;   /* [n][256][5]    (actor, type, moqie, liqi, from), padded with (4,276,2,2,4) */
+    uint16_t* n_progression; /* [n]            */
+    uint16_t* candidates;    /* [n][4][64][4]  (type, moqie, liqi, from) in legal-list order, padded with (279,2,2,3) */
+    uint8_t* n_candidates;   /* [n][4]         */
+} RmjSeqBuffers;
+int rmj_encode_seq(rmj_handle h, int game_style, const RmjSeqBuffers* out);          /* host arrays */
+int rmj_encode_seq_device(rmj_handle h, int game_style, const RmjSeqBuffers* d_out); /* device arrays, handle's stream */
+
 /* ------------------------------------------------------------------ measurement */
 typedef struct RmjBenchResult {
     double total_ms;      /* HIP-event time over the timed region (stream of the handle) */

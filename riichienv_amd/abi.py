@@ -198,6 +198,14 @@ class Config(C.Structure):
                 ("seeds", C.POINTER(C.c_uint64)), ("event_ring", C.c_uint32), ("reserved1", C.c_uint32)]
 
 
+class SeqBuffers(C.Structure):
+    _fields_ = [("sparse", C.c_void_p), ("n_sparse", C.c_void_p), ("numeric", C.c_void_p), ("progression", C.c_void_p),
+                ("n_progression", C.c_void_p), ("candidates", C.c_void_p), ("n_candidates", C.c_void_p)]
+
+
+SEQ_SPARSE, SEQ_PROG, SEQ_CAND = 25, 256, 64
+
+
 class BenchResult(C.Structure):
     _fields_ = [("total_ms", C.c_double), ("step_kernel_ms", C.c_double), ("env_steps", C.c_uint64),
                 ("launches", C.c_uint32), ("launches_in_flight", C.c_uint32)]

@@ -217,7 +217,7 @@ class Observation:
     """Per-seat snapshot (observation/mod.rs:24-56; state/mod.rs:189-263)."""
 
     def __init__(self, player_id, view, legal, mask, waits, new_events, events, encoder, num_players=4, ext_encoder=None,
-                 aux_encoder=None):
+                 aux_encoder=None, seq_encoder=None):
         pid = player_id
         self.player_id = pid
         self.num_players = num_players            # 3: Observation3P (observation_3p/mod.rs)
@@ -249,6 +249,7 @@ class Observation:
         self._encoder = encoder
         self._ext_encoder = ext_encoder
         self._aux_encoder = aux_encoder
+        self._seq_encoder = seq_encoder
 
     def action_space_size(self):  # observation/python.rs:114-117
         return 60 if self.num_players == 3 else 82
@@ -306,6 +307,32 @@ class Observation:
 
     def encode_furiten_ron_possibility(self) -> bytes:  # observation/python.rs:251-293 -> (np, 21)
         return self._aux_encoder("encode_furiten_ron_possibility").tobytes()
+
+    # ---- sequence (transformer) features, observation/sequence_features.rs: variable-length arrays like the reference's,
+    #      computed by rmj_encode_seq over the events of the current round (header: the reference uses the Observation's
+    #      own `events`, i.e. the log since the seat's previous observation)
+    def _seq(self, game_style=1):
+        if self.num_players == 3:
+            raise AttributeError("sequence features exist for 4-player observations only (observation/sequence_features.rs)")
+        return self._seq_encoder(int(game_style))
+
+    def encode_seq_sparse(self, game_style=1) -> bytes:  # python.rs:1302-1317 -> u16[5..25]
+        o = self._seq(game_style)
+        return o["sparse"][0, self.player_id, : o["n_sparse"][0, self.player_id]].tobytes()
+
+    def encode_seq_numeric(self) -> bytes:  # python.rs:1319-1333 -> f32[12]
+        return self._seq()["numeric"][0, self.player_id].tobytes()
+
+    def encode_seq_progression(self) -> bytes:  # python.rs:1335-1350 -> u16[n][5]
+        o = self._seq()
+        n = int(o["n_progression"][0])
+        if n == 0xFFFF:
+            raise RuntimeError("the event ring no longer holds the round's start_kyoku: create the env with a larger event ring")
+        return o["progression"][0, :n].tobytes()
+
+    def encode_seq_candidates(self) -> bytes:  # python.rs:1352-1362 -> u16[n][4]
+        o = self._seq()
+        return o["candidates"][0, self.player_id, : o["n_candidates"][0, self.player_id]].tobytes()
 
     def legal_actions(self):  # observation/python.rs:93-96
         return list(self._legal_actions)
@@ -403,6 +430,11 @@ class RiichiEnv:
                 enc[name] = getattr(self._v, name)()
             return enc[name][0]
 
+        def seq_encoder(game_style):
+            if ("seq", game_style) not in enc:
+                enc[("seq", game_style)] = self._v.encode_seq(game_style)
+            return enc[("seq", game_style)]
+
         nmask = 60 if self._np == 3 else 82
         out = {}
         for pid in pids:
@@ -414,7 +446,7 @@ class RiichiEnv:
             new = log[self._cursor[pid]:]
             self._cursor[pid] = len(log)
             out[pid] = Observation(pid, view, la, mask[0, pid][:nmask] if active else np.zeros(nmask, np.uint8), w, new, log,
-                                   encoder, self._np, ext_encoder, aux_encoder)
+                                   encoder, self._np, ext_encoder, aux_encoder, seq_encoder)
         return out
 
     def get_observation(self, player_id):

@@ -27,7 +27,7 @@ EXPORTS = [
     "rmj_get_waits", "rmj_get_scores", "rmj_get_ranks", "rmj_get_step_counts", "rmj_total_steps", "rmj_peek_state",
     "rmj_poke_state", "rmj_get_event_counts", "rmj_get_events", "rmj_format_event", "rmj_eval_hands",
     "rmj_agari_counts", "rmj_calculate_score", "rmj_shanten", "rmj_effective_tiles", "rmj_best_ukeire", "rmj_apply_events", "rmj_device_views", "rmj_step_ids_device",
-    "rmj_scores_device", "rmj_sync", "rmj_encode", "rmj_encode_device", "rmj_encode_extended", "rmj_encode_extended_device", "rmj_encode_aux", "rmj_encode_aux_device", "rmj_bench_rollout",
+    "rmj_scores_device", "rmj_sync", "rmj_encode", "rmj_encode_device", "rmj_encode_extended", "rmj_encode_extended_device", "rmj_encode_aux", "rmj_encode_aux_device", "rmj_encode_seq", "rmj_encode_seq_device", "rmj_bench_rollout",
 ]
 
 
@@ -101,6 +101,8 @@ def load_lib():
     L.rmj_encode_extended_device.argtypes = [vp, C.c_int, vp]
     L.rmj_encode_aux.argtypes = [vp, C.c_int, vp]
     L.rmj_encode_aux_device.argtypes = [vp, C.c_int, vp]
+    L.rmj_encode_seq.argtypes = [vp, C.c_int, C.POINTER(abi.SeqBuffers)]
+    L.rmj_encode_seq_device.argtypes = [vp, C.c_int, C.POINTER(abi.SeqBuffers)]
     L.rmj_effective_tiles.argtypes = [C.c_int, vp, C.c_uint32, C.c_int, vp]
     L.rmj_best_ukeire.argtypes = [C.c_int, vp, vp, C.c_uint32, C.c_int, vp]
     L.rmj_apply_events.argtypes = [vp, vp]
@@ -334,6 +336,19 @@ class VecRiichiEnv:
     def encode_furiten_ron_possibility(self):
         """Observation.encode_furiten_ron_possibility() of every game: [n][NP][21] f32."""
         return self._encode_aux(2, (3, 21) if self.game_mode >= 3 else (4, 21))
+
+    def encode_seq(self, game_style=1):
+        """Sequence (transformer) features of every (game, seat), 4P only (header: rmj_encode_seq): dict of padded arrays
+        sparse [n,4,25] u16, numeric [n,4,12] f32, progression [n,256,5] u16, candidates [n,4,64,4] u16 and their lengths."""
+        n = self.n
+        out = dict(sparse=np.zeros((n, 4, abi.SEQ_SPARSE), np.uint16), n_sparse=np.zeros((n, 4), np.uint8),
+                   numeric=np.zeros((n, 4, 12), np.float32), progression=np.zeros((n, abi.SEQ_PROG, 5), np.uint16),
+                   n_progression=np.zeros(n, np.uint16), candidates=np.zeros((n, 4, abi.SEQ_CAND, 4), np.uint16),
+                   n_candidates=np.zeros((n, 4), np.uint8))
+        b = abi.SeqBuffers(*[out[k].ctypes.data for k in ("sparse", "n_sparse", "numeric", "progression", "n_progression",
+                                                            "candidates", "n_candidates")])
+        _chk(self.L.rmj_encode_seq(self.h, int(game_style), C.byref(b)))
+        return out
 
     def bench_rollout(self, policy_seed, warmup, steps) -> abi.BenchResult:
         r = abi.BenchResult()

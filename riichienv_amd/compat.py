@@ -245,7 +245,7 @@ class Observation:
         self._legal_actions = legal
         self._mask = mask
         self._new_events = new_events
-        self.events = events
+        self._log = events  # the seat's whole log (not a reference field)
         self._encoder = encoder
         self._ext_encoder = ext_encoder
         self._aux_encoder = aux_encoder
@@ -342,6 +342,10 @@ class Observation:
 
     def new_events(self):
         return list(self._new_events)
+
+    @property
+    def events(self):  # observation/python.rs:81-91: the Observation's events ARE the new events (observation/mod.rs:138-140), as dicts
+        return [json.loads(s) for s in self._new_events]
 
     def find_action(self, action_id):  # observation/mod.rs:117-129
         for a in self._legal_actions:

@@ -187,3 +187,22 @@ def test_feature_block_accessors_match_reference_shapes():
         assert len(o.encode_last_tedashis()) == (npl - 1) * 12 and len(o.encode_pass_context()) == 12
         cand = np.frombuffer(o.encode_discard_candidates(), np.float32)
         assert abs(cand[0] - 14 / 34.0) < 1e-7
+
+
+def test_observation_events_are_the_delta_like_reference():
+    """tests/test_observation_serialization.py:85-120, tests/env/test_riichienv.py:42-45: Observation.events holds the
+    seat's NEW events since its previous observation (dicts), not the whole log."""
+    from riichienv_amd.compat import Action, ActionType, Phase, RiichiEnv
+
+    env = RiichiEnv(seed=9)
+    obs = env.reset()
+    dealer = obs[0]
+    assert [e["type"] for e in dealer.events] == ["start_game", "start_kyoku", "tsumo"]
+    obs = env.step({0: Action(ActionType.DISCARD, tile=dealer.hand[0])})
+    for pid in (1, 2, 3):
+        while env.phase == Phase.WaitResponse:
+            obs = env.step({p: Action(ActionType.PASS) for p in env.active_players})
+        obs = env.step({pid: Action(ActionType.DISCARD, tile=obs[pid].hand[-1])})   # tsumogiri: nobody's hand changes shape
+    while env.phase == Phase.WaitResponse:
+        obs = env.step({p: Action(ActionType.PASS) for p in env.active_players})
+    assert [e["type"] for e in obs[0].events] == ["dahai", "tsumo"] * 4

@@ -371,6 +371,7 @@ class RiichiEnv:
                                       skip_mjai_logging=skip_mjai_logging, round_wind=round_wind or 0, device=device,
                                       event_ring=8192)
         self._cursor = [0, 0, 0, 0]  # player_event_counts (state/mod.rs:211-218)
+        self._applied = None         # host-side logs of apply_event / observe_event (see apply_event)
         self._np = 3 if self._mode >= 3 else 4
 
     @property
@@ -380,8 +381,24 @@ class RiichiEnv:
     # ---- MJAI event ingestion (env.rs:880-948; full-information streams, see rmj_apply_events) -------------
     def apply_event(self, event):
         self._v.apply_events([event], masked_ok=True)  # "?" -> tile 0 like parse_mjai_tile (event_handler.rs:8-10)
-        if event.get("type") == "start_game":
-            self._cursor = [0, 0, 0, 0]
+        # apply_and_log (env.rs:52-72): the caller's event is pushed into mjai_log and, masked per seat like
+        # _push_mjai_event (state/mod.rs:2094-2148), into the seats' logs; start_game restarts them.  The device does not
+        # append applied events to its ring, so the binding keeps these logs on the host from the first apply_event on.
+        if event.get("type") == "start_game" or self._applied is None:
+            fresh = event.get("type") == "start_game"
+            self._applied = [] if fresh else list(self._v.mjai_log(0))
+            self._applied_seat = [[] if fresh else list(self._v.mjai_log(0, p)) for p in range(self._np)]
+            if fresh:
+                self._cursor = [0, 0, 0, 0]
+        dumps = lambda e: json.dumps(e, sort_keys=True, separators=(",", ":"), ensure_ascii=False)  # serde_json::Value order
+        self._applied.append(dumps(event))
+        for p in range(self._np):
+            ev = event
+            if event.get("type") == "start_kyoku" and isinstance(event.get("tehais"), list):
+                ev = dict(event, tehais=[h if i == p else ["?"] * len(h) for i, h in enumerate(event["tehais"])])
+            elif event.get("type") == "tsumo" and event.get("actor") != p:
+                ev = dict(event, pai="?")
+            self._applied_seat[p].append(dumps(ev))
 
     def observe_event(self, event, player_id):
         self.apply_event(event)
@@ -399,6 +416,7 @@ class RiichiEnv:
                       scores=None if scores is None else np.array(scores, np.int32)[None],
                       honba=None if honba is None else [honba], kyotaku=None if kyotaku is None else [kyotaku])
         self._cursor = [0, 0, 0, 0]
+        self._applied = None
         return self.get_observations(self.active_players)
 
     def step(self, actions):
@@ -446,7 +464,7 @@ class RiichiEnv:
                 (view.phase == Phase.WaitAct and view.current_player == pid) or view.phase == Phase.WaitResponse)
             la = [Action._from_packed(x, pid) for x in legal[0, pid, : cnt[0, pid]]] if active else []
             w = int(waits[0, pid]) if active else self._waits_of(view, pid)
-            log = self._v.mjai_log(0, pid)
+            log = self._v.mjai_log(0, pid) if self._applied is None else self._applied_seat[pid]
             new = log[self._cursor[pid]:]
             self._cursor[pid] = len(log)
             out[pid] = Observation(pid, view, la, mask[0, pid][:nmask] if active else np.zeros(nmask, np.uint8), w, new, log,
@@ -495,7 +513,7 @@ class RiichiEnv:
 
     @property
     def mjai_log(self):  # env.rs:729-739
-        return [json.loads(s) for s in self._v.mjai_log(0)]
+        return [json.loads(s) for s in (self._v.mjai_log(0) if self._applied is None else self._applied)]
 
     # ---- state getters (env.rs:134-622) ----------------------------------------------------------------
     def _view(self):

@@ -249,8 +249,8 @@ __device__ inline void encode_ext_scalars(const GState& S, int pid, float* buf, 
     const int cur_sh = sh_shanten(h, total / 3, SANMA, T);
     // 78..93 shanten efficiency
     {
-        const uint32_t eff = sh_ukeire_wave(T, h, my_cnt, my_vis, SANMA, 0, lane);
-        const uint32_t uke = sh_ukeire_wave(T, h, my_cnt, my_vis, SANMA, 1, lane);
+        uint32_t eff, uke;
+        sh_ukeire_both(T, h, my_cnt, my_vis, SANMA, lane, true, true, eff, uke);
         for (int c = 0; c < NPP; c++) {
             const int base = 78 + c * 4;
             if (c == 0) {

@@ -349,51 +349,68 @@ __device__ __forceinline__ int sh_shanten_wave(const PH& h, int len_div3, const 
     return sres;
 }
 
-// calculate_effective_tiles(_3p)_with_discard (mode 0) / calculate_best_ukeire(_3p) (mode 1), shanten.rs:265-405 /
+// calculate_effective_tiles(_3p)_with_discard ("eff") and calculate_best_ukeire(_3p) ("uke"), shanten.rs:265-405 /
 // :488-626, for ONE wave-uniform hand: lane = drawn tile type (my_cnt / my_vis = this lane's held / visible count), the
-// loop over discard candidates runs over held types.  mode 0 on a 3n hand yields 0xFFFFFFFF (the reference asserts).
-__device__ inline uint32_t sh_ukeire_wave(const ShantenTables& T, const PH& h, uint32_t my_cnt, uint32_t my_vis, bool sm, int mode, int lane) {
+// loop over discard candidates runs over held types.  eff on a 3n hand yields 0xFFFFFFFF (the reference asserts).
+// Both quantities judge the same (discard d, draw t) pairs - "does t lower the shanten of the hand without d" - so one
+// pass serves both, and the shanten after each discard is evaluated for all d at once (lane = d): 2 + #held-types
+// per-lane table evaluations instead of 2 + 4 x #held-types for the two separate walks.
+__device__ inline void sh_ukeire_both(const ShantenTables& T, const PH& h, uint32_t my_cnt, uint32_t my_vis, bool sm, int lane,
+                                      bool want_eff, bool want_uke, uint32_t& eff, uint32_t& uke) {
     const int t = lane;
     const bool t_ok = t < 34 && (!sm || t == 0 || t >= 8);  // SANMA_VALID_TILE_TYPES (shanten.rs:244-247)
     const int total = ph_total(h);
-    // number of drawn types that lower the shanten of `base` (a 3n+1 hand), weighted per lane by `weight`
-    auto improve = [&](const PH& base, int base_total, int base_sh, uint32_t weight) -> uint32_t {
-        uint32_t v = 0;
-        if (t_ok && ph_cnt(base, t) < 4) {
-            PH x = base;
-            ph_add(x, t);
-            if (sh_shanten(x, (base_total + 1) / 3, sm, T) < base_sh) v = weight;
-        }
-#pragma unroll
-        for (int off = 32; off >= 1; off >>= 1) v += (uint32_t)__shfl_xor((int)v, off, 64);
-        return v;
-    };
-    uint32_t res = 0;
     const int cur = sh_shanten(h, total / 3, sm, T);
-    if (mode == 0 && total % 3 == 1) {
-        res = improve(h, total, cur, 1u);
-    } else if (mode == 0 && total % 3 != 2) {
-        res = 0xFFFFFFFFu;
-    } else {
-        for (int d = 0; d < 34; d++) {
-            if (ph_cnt(h, d) == 0) continue;
-            PH sub = h;
-            ph_sub(sub, d);
-            const int nsh = sh_shanten(sub, (total - 1) / 3, sm, T);
-            if (nsh > cur) continue;
-            uint32_t weight = 1u;
-            if (mode == 1) {  // remaining = 4 - visible - held (both saturating), held counted after the discard
-                int held = (int)my_cnt - (t == d ? 1 : 0);
-                int rem = 4 - (int)my_vis;
-                rem = rem < 0 ? 0 : rem;
-                rem -= held;
-                weight = (uint32_t)(rem < 0 ? 0 : rem);
-            }
-            uint32_t v = improve(sub, total - 1, nsh, weight);
-            res = v > res ? v : res;
+    // does drawing this lane's type lower the shanten of `base` (a 3n+1 hand)?
+    auto improves = [&](const PH& base, int base_total, int base_sh) -> bool {
+        if (!(t_ok && ph_cnt(base, t) < 4)) return false;
+        PH x = base;
+        ph_add(x, t);
+        return sh_shanten(x, (base_total + 1) / 3, sm, T) < base_sh;
+    };
+    eff = 0;
+    uke = 0;
+    if (want_eff && total % 3 == 1) eff = (uint32_t)__popcll(__ballot(improves(h, total, cur)));
+    if (want_eff && total % 3 == 0) eff = 0xFFFFFFFFu;
+    const bool eff_loop = want_eff && total % 3 == 2;
+    if (!eff_loop && !want_uke) return;
+    // shanten after discarding this lane's type (127: not held)
+    int nsh_l = 127;
+    if (lane < 34 && ph_cnt(h, lane) > 0) {
+        PH sub = h;
+        ph_sub(sub, lane);
+        nsh_l = sh_shanten(sub, (total - 1) / 3, sm, T);
+    }
+    uint64_t cand = __ballot(nsh_l <= cur);
+    while (cand) {
+        const int d = __ffsll((long long)cand) - 1;
+        cand &= cand - 1ull;
+        const int nsh = __builtin_amdgcn_readlane(nsh_l, d);
+        PH sub = h;
+        ph_sub(sub, d);
+        const bool f = improves(sub, total - 1, nsh);
+        const uint64_t fb = __ballot(f);
+        if (eff_loop) {
+            const uint32_t e = (uint32_t)__popcll(fb);
+            eff = e > eff ? e : eff;
+        }
+        if (want_uke) {  // remaining = 4 - visible - held (both saturating), held counted after the discard
+            int held = (int)my_cnt - (t == d ? 1 : 0);
+            int rem = 4 - (int)my_vis;
+            rem = rem < 0 ? 0 : rem;
+            rem -= held;
+            const uint32_t w = f ? (uint32_t)(rem < 0 ? 0 : rem) : 0u;   // 0..4
+            const uint32_t u = (uint32_t)__popcll(__ballot(w & 1u)) + 2u * (uint32_t)__popcll(__ballot(w & 2u)) +
+                               4u * (uint32_t)__popcll(__ballot(w & 4u));
+            uke = u > uke ? u : uke;
         }
     }
-    return res;
+}
+// one of the two (rmj_effective_tiles: mode 0, rmj_best_ukeire: mode 1)
+__device__ inline uint32_t sh_ukeire_wave(const ShantenTables& T, const PH& h, uint32_t my_cnt, uint32_t my_vis, bool sm, int mode, int lane) {
+    uint32_t eff, uke;
+    sh_ukeire_both(T, h, my_cnt, my_vis, sm, lane, mode == 0, mode == 1, eff, uke);
+    return mode == 0 ? eff : uke;
 }
 
 }  // namespace rmj

@@ -206,3 +206,33 @@ def test_observation_events_are_the_delta_like_reference():
     while env.phase == Phase.WaitResponse:
         obs = env.step({p: Action(ActionType.PASS) for p in env.active_players})
     assert [e["type"] for e in obs[0].events] == ["dahai", "tsumo"] * 4
+
+
+def test_apply_event_records_the_callers_log():
+    """apply_and_log (riichienv-python/src/env.rs:52-72): applied events are pushed into mjai_log (the caller's event, extra
+    fields included) and, masked per seat, into the seats' logs that Observation.events / new_events draw from."""
+    import os
+
+    from riichienv_amd.compat import RiichiEnv
+    from riichienv_amd.replay import load_mjai_jsonl
+
+    log = load_mjai_jsonl(os.path.join(os.path.dirname(__file__), "golden", "126_204_0_mjai.jsonl"))
+    env = RiichiEnv(game_mode="4p-red-half", seed=1)
+    env.reset()                                   # leaves reset's own events in the device log: start_game restarts the logs
+    cut = next(i for i, e in enumerate(log) if e["type"] == "dahai") + 1
+    for e in log[:cut]:
+        env.apply_event(e)
+    assert env.mjai_log == log[:cut]
+    first = log[cut - 1]
+    assert first["type"] == "dahai"
+    # seat 1 sees the dealer's first discard: its events since the start hold the masked start_kyoku and tsumo
+    ev = env.get_observation(1).events
+    assert [x["type"] for x in ev][:2] == ["start_game", "start_kyoku"] and ev[-1] == first
+    sk = ev[1]
+    assert sk["tehais"][1] == log[1]["tehais"][1] and all(h == ["?"] * 13 for i, h in enumerate(sk["tehais"]) if i != 1)
+    ts = [x for x in ev if x["type"] == "tsumo"]
+    assert ts and all(x["pai"] == "?" for x in ts if x["actor"] != 1)
+    assert env.get_observation(1).events == []    # the cursor moved (state/mod.rs:211-218)
+    o = env.observe_event(log[cut], 2)            # observe_event = apply + get_observation (env.rs:895-948): cursor of seat 2
+    assert env.mjai_log == log[: cut + 1]
+    assert env.get_observation(2).events == [] and (o is None or o.events[-1]["type"] == log[cut]["type"])

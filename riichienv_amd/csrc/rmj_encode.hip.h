@@ -247,10 +247,11 @@ __device__ inline void encode_ext_scalars(const GState& S, int pid, float* buf, 
     }
     const int total = ph_total(h);
     const int cur_sh = sh_shanten(h, total / 3, SANMA, T);
+    int nsh_type = 127;  // lane = tile type: shanten after discarding one tile of the type (filled by the ukeire walk)
     // 78..93 shanten efficiency
     {
         uint32_t eff, uke;
-        sh_ukeire_both(T, h, my_cnt, my_vis, SANMA, lane, true, true, eff, uke);
+        sh_ukeire_both(T, h, my_cnt, my_vis, SANMA, lane, true, true, eff, uke, cur_sh, &nsh_type);
         for (int c = 0; c < NPP; c++) {
             const int base = 78 + c * 4;
             if (c == 0) {
@@ -297,12 +298,10 @@ __device__ inline void encode_ext_scalars(const GState& S, int pid, float* buf, 
     // 189..193 discard candidates: lane = hand slot
     {
         const int n = P.hand_len;
-        int ns = 99;
-        if (lane < n) {
-            PH x = h;
-            ph_sub(x, P.hand[lane] >> 2);
-            ns = sh_shanten(x, (total - 1) / 3, SANMA, T);
-        }
+        // the shanten after discarding slot `lane` = the per-type number the ukeire walk has computed already
+        const int ty = lane < n ? (P.hand[lane] >> 2) : 0;
+        const int got = __shfl(nsh_type, ty, 64);
+        const int ns = lane < n ? got : 99;
         const int keep = __popcll(__ballot(lane < n && ns == cur_sh));
         const int inc = __popcll(__ballot(lane < n && ns > cur_sh));
         bc(189, (float)n / 34.0f);

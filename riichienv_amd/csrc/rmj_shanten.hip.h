@@ -356,11 +356,11 @@ __device__ __forceinline__ int sh_shanten_wave(const PH& h, int len_div3, const 
 // pass serves both, and the shanten after each discard is evaluated for all d at once (lane = d): 2 + #held-types
 // per-lane table evaluations instead of 2 + 4 x #held-types for the two separate walks.
 __device__ inline void sh_ukeire_both(const ShantenTables& T, const PH& h, uint32_t my_cnt, uint32_t my_vis, bool sm, int lane,
-                                      bool want_eff, bool want_uke, uint32_t& eff, uint32_t& uke) {
+                                      bool want_eff, bool want_uke, uint32_t& eff, uint32_t& uke, int cur_in = -99, int* nsh_out = nullptr) {
     const int t = lane;
     const bool t_ok = t < 34 && (!sm || t == 0 || t >= 8);  // SANMA_VALID_TILE_TYPES (shanten.rs:244-247)
     const int total = ph_total(h);
-    const int cur = sh_shanten(h, total / 3, sm, T);
+    const int cur = cur_in != -99 ? cur_in : sh_shanten(h, total / 3, sm, T);  // the caller may know it already
     // does drawing this lane's type lower the shanten of `base` (a 3n+1 hand)?
     auto improves = [&](const PH& base, int base_total, int base_sh) -> bool {
         if (!(t_ok && ph_cnt(base, t) < 4)) return false;
@@ -381,6 +381,7 @@ __device__ inline void sh_ukeire_both(const ShantenTables& T, const PH& h, uint3
         ph_sub(sub, lane);
         nsh_l = sh_shanten(sub, (total - 1) / 3, sm, T);
     }
+    if (nsh_out) *nsh_out = nsh_l;  // lane = type: shanten after discarding one tile of it (127: not held)
     uint64_t cand = __ballot(nsh_l <= cur);
     while (cand) {
         const int d = __ffsll((long long)cand) - 1;

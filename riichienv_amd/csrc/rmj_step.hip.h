@@ -69,6 +69,11 @@ __device__ __forceinline__ uint32_t uni(uint32_t x) { return (uint32_t)__builtin
 __device__ __forceinline__ uint64_t uni(uint64_t x) {
     return ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(x >> 32)) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)x);
 }
+// U(x): a value every lane of the wave holds alike (anything read from the record in LDS), moved to a scalar register.  The
+// compiler cannot prove LDS loads uniform and would lower a branch on them with exec-mask save / restore instructions;
+// a branch on U(x) is a plain scalar compare-and-branch (the step is bound by VALU + SALU issue).
+template <typename T>
+__device__ __forceinline__ T U(T x) { return (T)__builtin_amdgcn_readfirstlane((int)x); }
 #undef CTX_FROM
 #define CTX_FROM(v) Ctx c{*uni_ptr((v).S), *(CEnv*)uni_ptr((v).E), *uni_ptr((v).X), uni((v).g), (v).lane, uni_ptr((v).W), uni_ptr((v).Lg)}
 __device__ __forceinline__ CtxV ctx_pack(const Ctx& c) {
@@ -451,6 +456,7 @@ template <bool FAST = false>
 __device__ __forceinline__ uint32_t gen_claims_all(Ctx& c, int pid, int tile) {
     GState& S = c.S;
     const int lane = c.lane;
+    pid = U(pid); tile = U(tile);
     const int tt = tile >> 2;
     if (lane < 4) c.X.nl[lane] = 0;
     // ---- A/B (lane = seat)
@@ -491,7 +497,7 @@ __device__ __forceinline__ uint32_t gen_claims_all(Ctx& c, int pid, int tile) {
             P.flags |= PF_MISSED_DOUJUN;  // state/mod.rs:1386-1389
         }
     }
-    const bool can_call = S.drawable_count > 0;
+    const bool can_call = U((int)S.drawable_count) > 0;
     const bool kuikae = rule(c, RMJ_RULE_KUIKAE_FORBIDDEN);
     PROF(c.X, lane, 17);
     // ---- C (lane = 16*seat + slot)
@@ -507,9 +513,9 @@ __device__ __forceinline__ uint32_t gen_claims_all(Ctx& c, int pid, int tile) {
             const int count = __popc(sm);
             if (count < 2 || ((riichi_m >> i) & 1u)) continue;
             PState& P = S.p[i];
-            const int hl = P.hand_len;
+            const int hl = U((int)P.hand_len);
             wave_sync();
-            int n = c.X.nl[i];
+            int n = U(c.X.nl[i]);
             const int i0 = __ffs((int)sm) - 1;
             const uint32_t m1 = sm & (sm - 1u);
             const int i1 = __ffs((int)m1) - 1;
@@ -533,7 +539,7 @@ __device__ __forceinline__ uint32_t gen_claims_all(Ctx& c, int pid, int tile) {
     if (!KSANMA && can_call && tt < 27) {
         const int i = (pid + 1) & 3;
         PState& P = S.p[i];
-        const int hl = P.hand_len;
+        const int hl = U((int)P.hand_len);
         if (!((riichi_m >> i) & 1u) && hl >= 3) {
             const uint8_t ht = lane < hl ? P.hand[lane] : 0xFF;
             const int hty = ht >> 2;
@@ -564,7 +570,7 @@ __device__ __forceinline__ uint32_t gen_claims_all(Ctx& c, int pid, int tile) {
                 }
                 const uint64_t vb = __ballot(valid);
                 wave_sync();
-                const int n = c.X.nl[i];
+                const int n = U(c.X.nl[i]);
                 if (valid) {
                     int pos = n + __popcll(vb & lanemask_lt(lane));
                     if (pos < RMJ_MAX_LEGAL) c.X.legal[i][pos] = act;
@@ -633,39 +639,46 @@ __device__ __forceinline__ uint32_t tenpai_after_discard(Ctx& c, const PState& P
 template <bool FAST>
 __device__ __forceinline__ void gen_act_legal(Ctx& c, int pid) {
     GState& S = c.S;
+    pid = U(pid);
     PState& P = S.p[pid];
     const int lane = c.lane;
-    const int hl = P.hand_len;
+    const int hl = U((int)P.hand_len);
+    const int nmelds = U((int)P.n_melds);
     int n = 0;
-    const bool r_decl = P.flags & PF_RIICHI_DECLARED, r_stage = P.flags & PF_RIICHI_STAGE;
-    const bool drawn = S.drawn_tile != 0xFF;
+    const uint32_t pflags = U((uint32_t)P.flags);
+    const bool r_decl = pflags & PF_RIICHI_DECLARED, r_stage = pflags & PF_RIICHI_STAGE;
+    const int drawn_tile = U((int)S.drawn_tile);
+    const bool drawn = drawn_tile != 0xFF;
+    const int drawable = U((int)S.drawable_count);
+    const bool first_turn = U((int)S.is_first_turn) != 0;
+    const bool rinshan = U((int)S.is_rinshan) != 0;
     // waits of the acting seat: non-empty only for a (poked) 13-tile holder, state/mod.rs:220-225
     if (FAST) {
-        if (P.hand_len + 3 * P.n_melds == 13) { c.bail = true; return; }
+        if (hl + 3 * nmelds == 13) { c.bail = true; return; }
         c.X.wout[pid] = 0ull;
     } else {
         c.X.wout[pid] = seat_waits(c, pid);
     }
     // 1. Tsumo
     if (drawn && !r_stage) {
-        int tile = S.drawn_tile;
+        int tile = drawn_tile;
         int idx = -1;  // rposition
         {
             uint64_t b = __ballot(lane < hl && P.hand[lane] == tile);
             if (b) idx = 63 - __clzll((long long)b);
         }
         uint32_t cf = base_cf(P) | CF_TSUMO;
-        if (S.drawable_count == 0 && !S.is_rinshan) cf |= CF_HAITEI;
-        if (S.is_rinshan) cf |= CF_RINSHAN;
-        if (S.is_first_turn && P.n_discards == 0) cf |= CF_FIRST_TURN;  // quirk Q5
+        if (drawable == 0 && !rinshan) cf |= CF_HAITEI;
+        if (rinshan) cf |= CF_RINSHAN;
+        if (first_turn && U((int)P.n_discards) == 0) cf |= CF_FIRST_TURN;  // quirk Q5
         // Win-shape probe.  is_agari(13 tiles + drawn) == "drawn type is a wait of the 13 tiles" (the drawn type has
         // < 4 copies among them, so quirk Q7 cannot bite), and those waits are the seat's cached waits13: the cache
         // describes the hand before the draw and survives a tsumogiri.  Only an invalid cache costs a probe, and that
         // probe refills it for the claim checks that follow.
         bool shape;
-        if (idx >= 0 && (hl - 1) + 3 * P.n_melds == 13) {
+        if (idx >= 0 && (hl - 1) + 3 * nmelds == 13) {
             uint64_t W13;
-            if (P.flags & PF_WAITS_VALID) W13 = P.waits13;
+            if (pflags & PF_WAITS_VALID) W13 = P.waits13;
             else {
                 // (hand_len is 14 here; fill_waits13 wants the mentsu count of the 13 tiles: same quotient)
                 W13 = fill_waits13(c, P, build_ph_wave(P, lane, idx));
@@ -685,19 +698,19 @@ __device__ __forceinline__ void gen_act_legal(Ctx& c, int pid) {
     const PH full = build_ph_wave(P, lane);  // shared by the riichi probe and the kan checks
     // 2. Discard / Riichi
     uint8_t ht = lane < hl ? P.hand[lane] : 0xFF;
-    const int nforb = P.n_forbidden;  // at most two entries (kuikae)
+    const int nforb = U((int)P.n_forbidden);  // at most two entries (kuikae)
     const bool forb = (nforb > 0 && (P.forbidden[0] >> 2) == (ht >> 2)) || (nforb > 1 && (P.forbidden[1] >> 2) == (ht >> 2));
     if (r_decl) {
-        if (drawn) put_legal(c, pid, n++, mk_action(RMJ_DISCARD, S.drawn_tile, 0));
+        if (drawn) put_legal(c, pid, n++, mk_action(RMJ_DISCARD, drawn_tile, 0));
     } else {
         uint32_t tp = 0;
         bool need_tp = r_stage;
-        const bool all_closed = __ballot(lane < P.n_melds && P.meld_type[lane & 3] != RMJ_MELD_ANKAN) == 0ull;
+        const bool all_closed = __ballot(lane < nmelds && P.meld_type[lane & 3] != RMJ_MELD_ANKAN) == 0ull;
         // quirk Q8: >= 4 in 4P, > 0 in 3P
-        bool riichi_pre = !r_stage && P.score >= 1000 && (KSANMA ? S.drawable_count > 0 : S.drawable_count >= 4) && all_closed;
+        bool riichi_pre = !r_stage && U(P.score) >= 1000 && (KSANMA ? drawable > 0 : drawable >= 4) && all_closed;
         if (need_tp || riichi_pre) {
             // the cache (if valid) describes the 13 tiles without the drawn one: it survives a draw and a riichi declaration
-            int sh13 = (drawn && (P.flags & PF_WAITS_VALID)) ? (int)P.sh13 : -1;
+            int sh13 = (drawn && (U((uint32_t)P.flags) & PF_WAITS_VALID)) ? U((int)P.sh13) : -1;
             tp = tenpai_after_discard(c, P, full, sh13);
         }
         bool ok = lane < hl && !forb && (!r_stage || ((tp >> lane) & 1u));
@@ -711,7 +724,7 @@ __device__ __forceinline__ void gen_act_legal(Ctx& c, int pid) {
     }
     PROF(c.X, lane, 10);
     // 3. Kan
-    if (S.drawable_count > 0 && drawn) {
+    if (drawable > 0 && drawn) {
         if (!r_decl && !r_stage) {
             // Ankan: types with 4 copies, ascending type.  lane = hand index, a type is reported by its first holder.
             int ty = ht >> 2;
@@ -744,8 +757,8 @@ __device__ __forceinline__ void gen_act_legal(Ctx& c, int pid) {
                 n += __popcll(rb);
             }
             // Kakan: meld order, then hand order
-            for (int m = 0; m < P.n_melds; m++) {
-                if (P.meld_type[m] == RMJ_MELD_PON) {
+            for (int m = 0; m < nmelds; m++) {
+                if (U((int)P.meld_type[m]) == RMJ_MELD_PON) {
                     int target = P.meld_tiles[m][0] >> 2;
                     bool hit = lane < hl && (ht >> 2) == target;
                     uint64_t kb = __ballot(hit);
@@ -759,7 +772,7 @@ __device__ __forceinline__ void gen_act_legal(Ctx& c, int pid) {
                 }
             }
         } else if (r_decl) {
-            int t = S.drawn_tile, t34 = t >> 2;
+            int t = drawn_tile, t34 = t >> 2;
             if (ph_cnt(full, t34) == 4) {
                 if (FAST) { c.bail = true; return; }  // ankan after riichi: two wait probes, full path
                 PH pre = full;
@@ -778,8 +791,7 @@ __device__ __forceinline__ void gen_act_legal(Ctx& c, int pid) {
     }
     PROF(c.X, lane, 11);
     // 4. Kyushu kyuhai
-    bool no_calls = (S.p[0].n_melds | S.p[1].n_melds | S.p[2].n_melds | S.p[3].n_melds) == 0;
-    if (S.is_first_turn && no_calls && !r_stage) {
+    if (first_turn && !r_stage && U((int)(S.p[0].n_melds | S.p[1].n_melds | S.p[2].n_melds | S.p[3].n_melds)) == 0) {
         uint64_t tm = 0;
         for (int k = 0; k < hl; k++) {
             int t = P.hand[k];
@@ -788,7 +800,7 @@ __device__ __forceinline__ void gen_act_legal(Ctx& c, int pid) {
         if (__popcll(tm) >= 9) put_legal(c, pid, n++, mk_action(RMJ_KYUSHU, RMJ_TILE_NONE, 0));
     }
     // 5. Kita (state_3p/sanma.rs:146-169): one action per North tile in hand, hand order
-    if (KSANMA && drawn && S.drawable_count > 0) {
+    if (KSANMA && drawn && drawable > 0) {
         bool hit = lane < hl && (ht >> 2) == 30;
         uint64_t kb = __ballot(hit);
         if (hit) {
@@ -838,16 +850,16 @@ __device__ __forceinline__ void reveal_kan_dora(Ctx& c) {
     }
 }
 __device__ __forceinline__ void flush_pending_kan_dora(Ctx& c) {
-    while (c.S.pending_kan_dora > 0) {
-        c.S.pending_kan_dora -= 1;
+    for (int n = U((int)c.S.pending_kan_dora); n > 0; n--) {
+        c.S.pending_kan_dora = (uint8_t)(n - 1);
         reveal_kan_dora(c);
     }
 }
 // state/mod.rs:1549-1567
 __device__ __forceinline__ void accept_riichi(Ctx& c) {
     GState& S = c.S;
-    if (S.riichi_pending != 0xFF) {
-        int p = S.riichi_pending;
+    const int p = U((int)S.riichi_pending);
+    if (p != 0xFF) {
         S.p[p].score -= 1000;
         S.p[p].score_delta -= 1000;
         S.riichi_sticks += 1;
@@ -867,20 +879,23 @@ template <bool FAST = false>
 __device__ __forceinline__ void deal_next(Ctx& c) {
     GState& S = c.S;
     S.is_rinshan = 0;
-    if (S.drawable_count == 0) {
+    const int drawable = U((int)S.drawable_count);
+    if (drawable == 0) {
         if (FAST) { c.bail = true; return; }
         trigger_ryukyoku(c, RMJ_RK_EXHAUSTIVE, 0);
         return;
     }
-    if (S.live_end > S.rinshan_count) {
-        const int le = S.live_end - 1;
+    const int live_end = U((int)S.live_end);
+    if (live_end > U((int)S.rinshan_count)) {
+        const int le = live_end - 1;
         // FAST: nothing before this point moves live_end (kans bail), the prefetched tile is the draw
         uint8_t t = (FAST || c.pf_live_end == le + 1) ? (uint8_t)c.pf_draw : c.W[le];
         S.live_end = (uint8_t)le;
-        S.drawable_count -= 1;
-        int pid = S.current_player;
+        S.drawable_count = (uint8_t)(drawable - 1);
+        const int pid = U((int)S.current_player);
         PState& P = S.p[pid];
-        if (P.hand_len < 14) P.hand[P.hand_len++] = t;
+        const int hl = U((int)P.hand_len);
+        if (hl < 14) { P.hand[hl] = t; P.hand_len = (uint8_t)(hl + 1); }
         S.drawn_tile = t;
         S.needs_tsumo = 0;
         S.phase = RMJ_WAIT_ACT;
@@ -1204,7 +1219,7 @@ __device__ __forceinline__ bool check_abortive_draw(Ctx& c) {
     const uint32_t kan = (uint32_t)__ballot(in && m < nm && P.meld_type[m] >= RMJ_MELD_DAIMINKAN);
     const uint32_t all_seats = 0x1111u;
     if (!KSANMA && turns_ok == all_seats && has_melds == 0u) {  // sufuurenta / suucha riichi: disabled in 3P (state_3p/mod.rs:1861-1888)
-        int first = S.p[0].discards[0] >> 2;
+        const int first = U((int)S.p[0].discards[0]) >> 2;
         if (first >= 27 && first <= 30) {
             uint32_t same = (uint32_t)__ballot(seat_lane && (P.discards[0] >> 2) == first);
             if (same == all_seats) {
@@ -1322,14 +1337,15 @@ __device__ __noinline__ void ol_resolve_kan(CtxV v, int pid, uint64_t action) {
 template <bool FAST = false>
 __device__ __forceinline__ void resolve_discard(Ctx& c, int pid, int tile, bool tsumogiri) {
     GState& S = c.S;
+    pid = U(pid); tile = U(tile); tsumogiri = U((int)tsumogiri) != 0;
     PState& P = S.p[pid];
-    if (FAST && S.pending_kan_dora > 0) { c.bail = true; return; }
+    if (FAST && U((int)S.pending_kan_dora) > 0) { c.bail = true; return; }
     if (KSANMA) { S.pending_kan_pid = 0xFF; S.pending_kan_action = 0; }  // quirk Q11 (state_3p/mod.rs:1224-1227)
     S.is_rinshan = 0;
-    uint32_t fl = P.flags;  // one LDS read / one write for the whole sequence of flag updates
+    uint32_t fl = U((uint32_t)P.flags);  // one LDS read / one write for the whole sequence of flag updates
     fl &= ~(uint32_t)PF_IPPATSU;
     const bool stage = fl & PF_RIICHI_STAGE;
-    int nd = P.n_discards;
+    int nd = U((int)P.n_discards);
     if (nd < RMJ_MAX_DISCARDS) {
         P.discards[nd] = (uint8_t)tile;
         if (!tsumogiri) P.discard_from_hand_bits |= 1u << nd;
@@ -1347,14 +1363,14 @@ __device__ __forceinline__ void resolve_discard(Ctx& c, int pid, int tile, bool 
         // most one.  A cached lower bound >= 3 therefore stays a bound >= 2 after losing one: still "no waits" (waits13
         // is 0 for every sh13 >= 1) and still "no Riichi after the next draw" (tenpai_after_discard).  A bound of 2 is
         // recomputed instead of kept as 1: measured, the riichi probe it would no longer spare costs more than the refill.
-        const int lb = P.sh13;
+        const int lb = U((int)P.sh13);
         if ((fl & PF_WAITS_VALID) && lb >= 3) P.sh13 = (uint8_t)(lb - 1);
         else fl &= ~(uint32_t)PF_WAITS_VALID;
     }
     S.needs_tsumo = 1;
     if (stage) {
         fl |= PF_RIICHI_DECLARED;
-        if (S.is_first_turn) fl |= PF_DOUBLE_RIICHI;
+        if (U((int)S.is_first_turn)) fl |= PF_DOUBLE_RIICHI;
         P.riichi_decl_idx = (uint8_t)(nd - 1);
         fl &= ~(uint32_t)PF_RIICHI_STAGE;
         S.riichi_pending = (uint8_t)pid;
@@ -1374,15 +1390,15 @@ __device__ __forceinline__ void resolve_discard(Ctx& c, int pid, int tile, bool 
         S.phase = RMJ_WAIT_RESPONSE;
         S.active_mask = (uint8_t)claim_active;
     } else {
-        if (S.riichi_pending != 0xFF) accept_riichi(c);
+        if (U((int)S.riichi_pending) != 0xFF) accept_riichi(c);
         bool abort_ = check_abortive_draw<FAST>(c);
         PROF(c.X, c.lane, 23);
         if (!abort_) {
-            S.turn_count += 1;
-            S.current_player = (uint8_t)((pid + 1) % KNP);
+            S.turn_count = U(S.turn_count) + 1u;
+            S.current_player = (uint8_t)(pid + 1 == KNP ? 0 : pid + 1);
             deal_next<FAST>(c);
             PROF(c.X, c.lane, 24);
-            if (S.turn_count >= (uint32_t)KNP) S.is_first_turn = 0;
+            if (U(S.turn_count) >= (uint32_t)KNP) S.is_first_turn = 0;  // re-read: deal_next may have started a new round
         }
     }
     PROF(c.X, c.lane, 6);
@@ -1751,19 +1767,20 @@ template <bool FAST = false>
 __device__ __forceinline__ void step_game(Ctx& c, const uint64_t mine, bool trusted = false) {
     GState& S = c.S;
     const int lane = c.lane;
-    if (S.is_done) return;
+    if (U((int)S.is_done)) return;
     S.step_count += 1;
+    const int phase = U((int)S.phase);
     // ---- validation against the stored legal lists
     for (int pid = 0; pid < 4; pid++) {
         if (trusted) continue;
         const uint64_t a_pid = act_at(mine, pid);
         if (a_pid == RMJ_NO_ACTION) continue;
-        int n = S.nlegal[pid];
-        bool active = (S.active_mask >> pid) & 1u;
+        int n = U((int)S.nlegal[pid]);
+        bool active = (U((uint32_t)S.active_mask) >> pid) & 1u;
         bool valid;
         if (!active || n == 0) {
             // _get_legal_actions_internal for a non-active seat: [] in WaitAct, [Pass] in WaitResponse
-            valid = S.phase == RMJ_WAIT_RESPONSE && a_match(mk_action(RMJ_PASS, RMJ_TILE_NONE, 0), a_pid);
+            valid = phase == RMJ_WAIT_RESPONSE && a_match(mk_action(RMJ_PASS, RMJ_TILE_NONE, 0), a_pid);
         } else {
             bool hit = lane < n && a_match(c.Lg[pid * RMJ_MAX_LEGAL + lane], a_pid);
             valid = __ballot(hit) != 0ull;
@@ -1776,8 +1793,8 @@ __device__ __forceinline__ void step_game(Ctx& c, const uint64_t mine, bool trus
         }
     }
     PROF(c.X, lane, 2);
-    if (S.phase == RMJ_WAIT_ACT) {
-        const int pid = S.current_player;
+    if (phase == RMJ_WAIT_ACT) {
+        const int pid = U((int)S.current_player);
         const uint64_t act = act_at(mine, pid);
         if (act == RMJ_NO_ACTION) return;
         PState& P = S.p[pid];
@@ -1790,12 +1807,13 @@ __device__ __forceinline__ void step_game(Ctx& c, const uint64_t mine, bool trus
             if (a_tile(act) == RMJ_TILE_NONE) return;
             int tile = (int)a_tile(act);
             bool tsumogiri = false, valid = false;
-            if (S.drawn_tile != 0xFF && S.drawn_tile == tile) { tsumogiri = true; valid = true; }
+            const int drawn = U((int)S.drawn_tile);
+            if (drawn != 0xFF && drawn == tile) { tsumogiri = true; valid = true; }
             PROF(c.X, lane, 3);
             int idx = hand_find(c, P, tile);
             PROF(c.X, lane, 20);
             if (idx >= 0) {
-                discard_sort(c, P, P.hand_len, idx);  // hand.remove(idx); hand.sort()
+                discard_sort(c, P, U((int)P.hand_len), idx);  // hand.remove(idx); hand.sort()
                 PROF(c.X, lane, 22);
                 valid = true;
             }
@@ -2160,14 +2178,15 @@ template <bool FAST = false>
 __device__ __forceinline__ void finalize_outputs(Ctx& c, bool claims_fresh) {
     GState& S = c.S;
     const int lane = c.lane;
-    if (S.is_done) {
+    const int phase = U((int)S.phase);
+    if (U((int)S.is_done)) {
         for (int p = 0; p < 4; p++) { c.X.nl[p] = 0; c.X.wout[p] = 0; }
-    } else if (!FAST && S.active_mask == 0) {
+    } else if (!FAST && U((int)S.active_mask) == 0) {
         // nobody to act (only reachable through rmj_apply_events: between a discard nobody can claim and the next tsumo)
         for (int p = 0; p < 4; p++) { c.X.nl[p] = 0; c.X.wout[p] = 0; }
-    } else if (S.phase == RMJ_WAIT_ACT) {
+    } else if (phase == RMJ_WAIT_ACT) {
         for (int p = 0; p < 4; p++) { c.X.nl[p] = 0; c.X.wout[p] = 0; }
-        gen_act_legal<FAST>(c, S.current_player);
+        gen_act_legal<FAST>(c, U((int)S.current_player));
         if (FAST && c.bail) return;
     } else if (!claims_fresh) {
         // WaitResponse that was not produced in this launch (e.g. after rmj_poke_state): rebuild claims
@@ -2191,7 +2210,7 @@ __device__ __forceinline__ void finalize_outputs(Ctx& c, bool claims_fresh) {
     wave_sync();
     for (uint32_t m = am; m; m &= m - 1u) {
         const int p = __ffs((int)m) - 1;
-        const int n = c.X.nl[p];
+        const int n = U(c.X.nl[p]);
         if (lane < n) {
             uint64_t a = c.X.legal[p][lane];
             c.Lg[p * RMJ_MAX_LEGAL + lane] = a;

@@ -68,9 +68,9 @@ __global__ __launch_bounds__(64 * RMJ_STEP_WPB, RMJ_STEP_WAVES) void k_step(cons
         // equals the policy's id; lane = list entry.  No match = an action that fails validation (illegal action).
         const int32_t* ids = reinterpret_cast<const int32_t*>(actions);
         for (int p = 0; p < 4; p++) {
-            const int id = ids[(size_t)g * 4 + p];
-            const int n = S.nlegal[p];
-            if (id < 0 || !((S.active_mask >> p) & 1u) || n == 0 || S.is_done) continue;
+            const int id = U(ids[(size_t)g * 4 + p]);
+            const int n = U((int)S.nlegal[p]);
+            if (id < 0 || !((U((uint32_t)S.active_mask) >> p) & 1u) || n == 0 || U((int)S.is_done)) continue;
             uint64_t a = 0;
             bool hit = false;
             if (lane < n) {
@@ -87,7 +87,7 @@ __global__ __launch_bounds__(64 * RMJ_STEP_WPB, RMJ_STEP_WAVES) void k_step(cons
     }
     PROF(c.X, lane, 1);
     // Fast path: the common transitions, fully inline, nothing stored until it has succeeded.
-    if (S.is_done && (flags & STEP_F_AUTORESET)) c.bail = true;
+    if (U((int)S.is_done) && (flags & STEP_F_AUTORESET)) c.bail = true;
     else {
         c.ev_stage = 0;
         step_game<true>(c, mine, device_policy);  // device policy: picked from the stored lists, valid by construction

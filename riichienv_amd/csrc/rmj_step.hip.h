@@ -186,7 +186,7 @@ __device__ __forceinline__ void hand_remove_at(Ctx& c, PState& P, int idx) {
     wave_sync();
 }
 __device__ __forceinline__ int hand_find(const Ctx& c, const PState& P, int tile) {  // position() of a 136-id, -1 if absent
-    bool hit = c.lane < P.hand_len && P.hand[c.lane] == tile;
+    bool hit = c.lane < U((int)P.hand_len) && P.hand[c.lane] == tile;
     uint64_t b = __ballot(hit);
     return b ? (__ffsll((long long)b) - 1) : -1;
 }
@@ -289,15 +289,17 @@ __device__ __forceinline__ uint64_t fill_waits13(Ctx& c, PState& P, const PH& h1
     int sh;
     uint64_t W = 0ull;
     const uint32_t T9 = 1u | (1u << 24);
-    const int yaochu_kinds = __popc((h13.a | (h13.a >> 1) | (h13.a >> 2)) & T9) + __popc((h13.b | (h13.b >> 1) | (h13.b >> 2)) & T9) +
-                             __popc((h13.c | (h13.c >> 1) | (h13.c >> 2)) & T9) + __popc((h13.d | (h13.d >> 1) | (h13.d >> 2)) & O7_1);
+    const uint32_t ha = U(h13.a), hb = U(h13.b), hc = U(h13.c), hd = U(h13.d);  // wave-uniform histogram words
+    const int yaochu_kinds = __popc((ha | (ha >> 1) | (ha >> 2)) & T9) + __popc((hb | (hb >> 1) | (hb >> 2)) & T9) +
+                             __popc((hc | (hc >> 1) | (hc >> 2)) & T9) + __popc((hd | (hd >> 1) | (hd >> 2)) & O7_1);
     // iso isolated tiles leave r = tiles - iso for blocks: 2 * mentsu + taatsu <= {6, 5, 4} for iso = {4, 5, >= 6} whatever
     // the number of melds, i.e. standard shanten >= {2, 3, 4}; a closed hand also has the exact chiitoi number (6 - pairs
     // + missing kinds) and a kokushi bound (13 - kinds - 1).  The bound is worth keeping as large as it is: every later
     // tedashi lowers it by one instead of recomputing (resolve_discard).
     const int iso = isolated_tiles(h13, c.lane);
     int lb = iso >= 6 ? 4 : (iso == 5 ? 3 : (iso == 4 ? 2 : 0));
-    if (P.hand_len / 3 == 4) {
+    const int len3 = U((int)P.hand_len) / 3;
+    if (len3 == 4) {
         const int koku = 12 - yaochu_kinds;
         lb = koku < lb ? koku : lb;
         if (lb > 2) {
@@ -308,7 +310,7 @@ __device__ __forceinline__ uint64_t fill_waits13(Ctx& c, PState& P, const PH& h1
     if (lb >= 2) {
         sh = lb;  // a lower bound is all the users of sh13 need
     } else {
-        sh = sh_shanten_wave(h13, P.hand_len / 3, sh_tables_of(c.E), c.lane);
+        sh = sh_shanten_wave(h13, len3, sh_tables_of(c.E), c.lane);
         if (sh <= 0) W = wave_waits(h13, c.lane);
     }
     P.waits13 = W;
@@ -1857,7 +1859,8 @@ __device__ __forceinline__ void step_game(Ctx& c, const uint64_t mine, bool trus
         S.is_rinshan = 0;
         S.is_first_turn = 0;
         C.flags &= ~PF_MISSED_DOUJUN;
-        if (S.last_discard_pid != 0xFF) S.p[S.last_discard_pid].flags &= ~PF_NAGASHI;
+        const int ldp = U((int)S.last_discard_pid);
+        if (ldp != 0xFF) S.p[ldp].flags &= ~PF_NAGASHI;
         for (int p = 0; p < 4; p++) S.p[p].flags &= ~PF_IPPATSU;
         uint32_t ty = a_type(claim);
         if (FAST && ty == RMJ_DAIMINKAN) { c.bail = true; return; }
@@ -1869,7 +1872,7 @@ __device__ __forceinline__ void step_game(Ctx& c, const uint64_t mine, bool trus
             return;
         }
         hand_remove_tiles(c, C, claim);
-        int discarder = S.last_discard_pid, tile = S.last_discard_tile;
+        int discarder = U((int)S.last_discard_pid), tile = U((int)S.last_discard_tile);
         push_meld(C, ty == RMJ_PON ? RMJ_MELD_PON : RMJ_MELD_CHI, a_c(claim, 0), a_c(claim, 1), (uint32_t)tile, 0, 3, discarder, tile);
         emit_meld(c, ty == RMJ_PON ? RMJ_EV_PON : RMJ_EV_CHI, (uint8_t)claimer, (uint8_t)discarder, (uint8_t)tile, claim);
         if (ty == RMJ_PON) pao_check(c, claimer, discarder, tile);

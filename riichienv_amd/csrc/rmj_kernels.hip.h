@@ -47,11 +47,16 @@ __global__ __launch_bounds__(64 * RMJ_STEP_WPB, RMJ_STEP_WAVES) void k_step(cons
     uint64_t mine = RMJ_NO_ACTION;
     if (device_policy) {
         // RandomAgent (random_agent.py:6-15), keyed per (game, step, seat): see rmj_step_random in the header
-        // Scalar unit throughout (the step is bound by VALU issue; this pick used to cost 120 VALU instructions): a
-        // loop over the acting seats, hash and modulo on SGPRs, one vector load of the chosen entry by lane = seat.
+        // A loop over the acting seats; the modulo runs on the scalar unit (exact, by table), the chosen entry is loaded by
+        // lane = seat.  The two hashes are pure arithmetic on wave-uniform values that the compiler would place on the
+        // scalar unit; they are kept on the VECTOR unit on purpose (an opaque zero in a VGPR joins the sum): the step is
+        // bound by the busier of the two issue ports, after the scalar branches of this round that is the scalar one
+        // (642 SALU vs 539 VALU per step), and a 64-bit multiply costs 8 scalar but 5 vector instructions.
         // (Requesting the list heads together with the record, to spare the dependent trip to HBM, was measured
         // slower: latency is hidden by the other waves, the extra shuffle and traffic are not.)
-        const uint64_t gs = sm64(policy_seed + E.game_offset + uni(g));
+        uint32_t vz;
+        asm volatile("v_mov_b32 %0, 0" : "=v"(vz));
+        const uint64_t gs = sm64(policy_seed + E.game_offset + uni(g) + (uint64_t)vz);
         const uint64_t sk = gs + (uint64_t)uni((uint32_t)S.step_count) * 4ull;
         uint32_t am = S.is_done ? 0u : (uint32_t)S.active_mask;
         am = uni(am) & 0xFu;
@@ -60,7 +65,7 @@ __global__ __launch_bounds__(64 * RMJ_STEP_WPB, RMJ_STEP_WAVES) void k_step(cons
             am &= am - 1u;
             const uint32_t n = uni((uint32_t)S.nlegal[p]);
             if (n == 0u) continue;
-            const uint32_t ch = mod_small_uniform(sm64(sk + (uint64_t)p), n > 64u ? 64u : n);
+            const uint32_t ch = mod_small_uniform(uni(sm64(sk + (uint64_t)p)), n > 64u ? 64u : n);
             if (lane == p) mine = c.Lg[p * RMJ_MAX_LEGAL + ch];
         }
     } else if (flags & STEP_F_IDS) {

@@ -715,6 +715,116 @@ def sc_sudden_death_west_round(make):
     t = [e["type"] for e in evs(env)]
     assert t[-1] == "end_game" and "ryukyoku" in t
 
+def sc_ron_after_call_clears_doujun(make):
+    """test_m263_ron_mismatch.py:4-77: a seat in temporary furiten calls Pon and discards; the furiten is gone and the next
+    discard of its wait is offered as Ron."""
+    melds3 = [(abi.MELD_PON, [124, 125, 126], True, 0, 124), (abi.MELD_CHI, [24, 28, 32], True, 2, 24), (abi.MELD_CHI, [60, 64, 68], True, 2, 60)]
+    h1 = [36] + _SAFE1[1:13]
+
+    def mut(v):
+        v.players[3].missed_agari_doujun = 1
+        v.is_first_turn = 0
+
+    env = setup(make(game_mode=2), hands=[_SAFE2, h1[:12], tiles("2378m2378p23s567z")[0:13][:12] + [93], [92, 37, 38, 40]],
+                melds=[None, None, None, melds3], current_player=1, active_players=[1], drawn_tile=36 if 36 not in h1[:12] else None,
+                wall=list(range(136)), mutate=mut)
+    env.step({1: pack_action(DISCARD, 36)})                                 # 1p
+    act, ph, dn = env.status()
+    assert ph == WAIT_RESPONSE and (act >> 3) & 1 and find(env.legal(3), PON) is not None
+    env.step({3: pack_action(PON, 36, [37, 38])})
+    assert env.peek().players[3].missed_agari_doujun == 0                   # cleared by the call (state/mod.rs:1196)
+    env.step({3: pack_action(DISCARD, 40)})
+    while env.status()[1] == WAIT_RESPONSE:                                 # nobody needs the 2p
+        a = env.status()[0]
+        env.step({s: pack_action(PASS) for s in range(4) if (a >> s) & 1})
+    v = env.peek()
+    assert v.phase == WAIT_ACT and v.current_player == 0                    # seat 0 drew; force seat 2's turn with the 7s
+    v.current_player, v.active_mask = 2, 1 << 2
+    env.poke(v)
+    env.step({2: pack_action(DISCARD, 93)})                                 # 7s
+    act, ph, dn = env.status()
+    assert ph == WAIT_RESPONSE and (act >> 3) & 1 and find(env.legal(3), RON) is not None
+
+
+def sc_discard_type_tracking(make):
+    """test_discard_type.py:5-61: discard_from_hand is False for a tsumogiri and True for a tedashi."""
+    env = setup(make(game_mode=2), hands=[_SAFE1, _SAFE2, tiles("258m369p147s1234z")[0:13], tiles("369m147p258s4567z")[0:13]],
+                drawn_tile=10, wall=list(range(136)))
+    env.step({0: pack_action(DISCARD, 10)})
+    p = env.peek().players[0]
+    assert p.n_discards == 1 and p.discards[0] == 10 and (p.discard_from_hand_bits & 1) == 0
+    while env.status()[1] == WAIT_RESPONSE:
+        a = env.status()[0]
+        env.step({s: pack_action(PASS) for s in range(4) if (a >> s) & 1})
+    v = env.peek()
+    cur = v.current_player
+    tile = v.players[cur].hand[0]
+    assert tile != v.drawn_tile
+    env.step({cur: pack_action(DISCARD, tile)})
+    q = env.peek().players[cur]
+    assert q.discards[q.n_discards - 1] == tile and (q.discard_from_hand_bits >> (q.n_discards - 1)) & 1 == 1
+
+
+def sc_riichi_markers(make):
+    """test_riichi_markers.py:5-113: riichi_stage after the declaration; the declaring discard sets discard_is_riichi,
+    riichi_declared and riichi_declaration_index; other seats stay None; reset() clears everything."""
+    hand0 = [0, 1, 2, 12, 13, 14, 24, 25, 26, 40, 41, 42, 108]
+    env = setup(make(game_mode=2), hands=[hand0, _SAFE1, _SAFE2, None], drawn_tile=109, wall=list(range(136)))
+    r = find(env.legal(0), RIICHI)
+    assert r is not None
+    env.step({0: r})
+    v = env.peek()
+    assert v.players[0].riichi_stage == 1 and v.players[0].riichi_declared == 0
+    discards = [a for a in env.legal(0) if unpack_action(a)[0] == DISCARD]
+    assert discards and len(discards) == len(env.legal(0))                  # riichi stage: nothing but (tenpai-keeping) discards
+    env.step({0: discards[0]})
+    v = env.peek()
+    p = v.players[0]
+    assert p.n_discards == 1 and p.discards[0] == unpack_action(discards[0])[1]
+    assert (p.discard_is_riichi_bits & 1) == 1 and p.riichi_stage == 0 and p.riichi_declared == 1
+    assert p.riichi_declaration_index == 0 and v.players[1].riichi_declaration_index == -1
+    env.reset()
+    v = env.peek()
+    assert v.players[0].riichi_declaration_index == -1 and v.players[0].n_discards == 0 and v.players[0].discard_is_riichi_bits == 0
+
+
+def sc_daiminkan_rinshan_draw(make):
+    """actions/test_daiminkan_rinshan_draw.py:8-53: an accepted Daiminkan makes the caller the current player in WaitAct
+    with a rinshan tile drawn from the wall and a tsumo event logged."""
+    h1 = [72, 73, 74] + [1, 5, 9, 13, 37, 41, 45, 49, 110, 114]
+    env = setup(make(game_mode=2), hands=[tiles("19m19p19s1234567z")[0:13][:12] + [3], h1, _SAFE1, _SAFE2], drawn_tile=75,
+                wall=list(range(136)))
+    env.step({0: pack_action(DISCARD, 75)})
+    act, ph, dn = env.status()
+    assert ph == WAIT_RESPONSE and (act >> 1) & 1
+    kan = find(env.legal(1), DAIMINKAN)
+    assert kan is not None
+    before = env.peek()
+    env.step({1: kan})
+    v = env.peek()
+    assert v.current_player == 1 and v.phase == WAIT_ACT and v.drawn_tile >= 0
+    assert v.rinshan_draw_count == before.rinshan_draw_count + 1
+    last = evs(env)[-1]
+    assert last["type"] == "tsumo" and last["actor"] == 1 and last["pai"] == abi_mjai(v.drawn_tile)
+
+
+def sc_chi_needs_the_exact_copies(make):
+    """actions/test_relaxed_red5.py:7-81: a Chi must name tiles the caller really holds - the red five by its own id, a plain
+    five by the held copy; naming another copy is an illegal action (penalty ryukyoku, no meld)."""
+    filler = [108, 109, 110, 112, 113, 114, 116, 117, 118, 120, 121]
+    for five, named, ok in ((16, 16, True), (16, 20, False), (17, 18, False), (17, 17, True)):
+        env = setup(make(game_mode=2), hands=[[five, 12] + filler, _SAFE1, _SAFE2, tiles("19m19p19s1234567z")[0:13][:12] + [1]],
+                    current_player=3, active_players=[3], drawn_tile=8, wall=list(range(136)))
+        env.step({3: pack_action(DISCARD, 8)})                              # 3m from kamicha
+        act, ph, dn = env.status()
+        assert ph == WAIT_RESPONSE and act & 1
+        env.step({0: pack_action(CHI, 8, [named, 12])})
+        p0 = env.peek().players[0]
+        if ok:
+            assert p0.n_melds == 1 and p0.melds[0].meld_type == abi.MELD_CHI and five in list(p0.melds[0].tiles[:3])
+        else:
+            assert p0.n_melds == 0
+
 
 SCENARIOS = [sc_paishan_dora_indices, sc_kakan_dora_timing, sc_daiminkan_dora_timing, sc_south_round_tsumo,
              sc_illegal_discard_penalty, sc_illegal_out_of_turn, sc_claim_priority_pon_over_chi, sc_kuikae_suji,
@@ -723,7 +833,8 @@ SCENARIOS = [sc_paishan_dora_indices, sc_kakan_dora_timing, sc_daiminkan_dora_ti
              sc_tobi_and_agariyame,
              sc_furiten_ron, sc_temporary_furiten, sc_valid_ankan_after_riichi, sc_no_claims_during_riichi,
              sc_honba_reset_and_increment, sc_pao_ron_honba, sc_doujun_cleared_by_call,
-             sc_sudden_death_west_round]
+             sc_sudden_death_west_round, sc_ron_after_call_clears_doujun, sc_discard_type_tracking, sc_riichi_markers,
+             sc_daiminkan_rinshan_draw, sc_chi_needs_the_exact_copies]
 
 
 # ---------------------------------------------------------------------------------------------------------

@@ -665,20 +665,24 @@ __device__ __forceinline__ void gen_act_legal(Ctx& c, int pid) {
     if (drawn && !r_stage) {
         int tile = drawn_tile;
         int idx = -1;  // rposition
+        int same_type;  // tiles of the drawn type in the 14
         {
-            uint64_t b = __ballot(lane < hl && P.hand[lane] == tile);
+            const int ht0 = lane < hl ? (int)P.hand[lane] : -1;
+            uint64_t b = __ballot(ht0 == tile);
             if (b) idx = 63 - __clzll((long long)b);
+            same_type = __popcll(__ballot(ht0 >= 0 && (ht0 >> 2) == (tile >> 2)));
         }
         uint32_t cf = base_cf(P) | CF_TSUMO;
         if (drawable == 0 && !rinshan) cf |= CF_HAITEI;
         if (rinshan) cf |= CF_RINSHAN;
         if (first_turn && U((int)P.n_discards) == 0) cf |= CF_FIRST_TURN;  // quirk Q5
-        // Win-shape probe.  is_agari(13 tiles + drawn) == "drawn type is a wait of the 13 tiles" (the drawn type has
-        // < 4 copies among them, so quirk Q7 cannot bite), and those waits are the seat's cached waits13: the cache
-        // describes the hand before the draw and survives a tsumogiri.  Only an invalid cache costs a probe, and that
-        // probe refills it for the claim checks that follow.
+        // Win-shape probe.  is_agari(13 tiles + drawn) == "drawn type is a wait of the 13 tiles" as long as the drawn type
+        // has < 4 copies among them (quirk Q7: get_waits skips a type already held four times - only a poked state with a
+        // repeated id, like the reference's own actions/test_riichi_pass.py, holds five; it takes the direct probe), and
+        // those waits are the seat's cached waits13: the cache describes the hand before the draw and survives a
+        // tsumogiri.  Only an invalid cache costs a probe, and that probe refills it for the claim checks that follow.
         bool shape;
-        if (idx >= 0 && (hl - 1) + 3 * nmelds == 13) {
+        if (idx >= 0 && same_type <= 4 && (hl - 1) + 3 * nmelds == 13) {
             uint64_t W13;
             if (pflags & PF_WAITS_VALID) W13 = P.waits13;
             else {

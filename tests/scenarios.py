@@ -825,6 +825,42 @@ def sc_chi_needs_the_exact_copies(make):
         else:
             assert p0.n_melds == 0
 
+def sc_kakan_from_tsumo_and_from_hand(make):
+    """actions/test_kakan.py:7-84: with a Pon of 1m, Kakan is offered for the 4th copy whether it was just drawn (a duplicate id
+    in the reference's test: relaxed check) or sits in the hand; executing it turns the Pon into a Kakan of [0,1,2,3], removes
+    the tile from the hand and logs a kakan event."""
+    pon = [(abi.MELD_PON, [0, 1, 2], True, 1, 0)]
+    env = setup(make(game_mode=2), hands=[[4, 5, 6, 7, 8, 9, 10, 11, 12, 60], _SAFE1, _SAFE2, None], melds=[pon, None, None, None],
+                drawn_tile=2, wall=list(range(136)))
+    assert find(env.legal(0), KAKAN) is not None
+    env = setup(make(game_mode=2), hands=[[3, 4, 5, 6, 7, 8, 9, 10, 11, 12], _SAFE1, _SAFE2, None], melds=[pon, None, None, None],
+                drawn_tile=13, wall=list(range(136)))
+    k = [a for a in env.legal(0) if unpack_action(a)[0] == KAKAN]
+    assert len(k) == 1 and unpack_action(k[0])[1] == 3 and sorted(unpack_action(k[0])[2]) == [0, 1, 2]
+    env.step({0: k[0]})
+    while env.status()[1] == WAIT_RESPONSE:                                  # nobody can rob it
+        a = env.status()[0]
+        env.step({q: pack_action(PASS) for q in range(4) if (a >> q) & 1})
+    p = env.peek().players[0]
+    assert p.n_melds == 1 and p.melds[0].meld_type == abi.MELD_KAKAN and sorted(p.melds[0].tiles[:4]) == [0, 1, 2, 3]
+    assert 3 not in list(p.hand[: p.hand_len])
+    assert any(e["type"] == "kakan" for e in evs(env))
+
+
+def sc_riichi_player_tsumogiri(make):
+    """actions/test_riichi_pass.py:11-54: a riichi player in WaitAct may discard the drawn tile or win, never Pass; the discard is
+    logged as a tsumogiri and play moves on."""
+    env = setup(make(game_mode=2), hands=[list(range(13)), _SAFE1, _SAFE2, tiles("258m369p147s1234z")[0:13]], drawn_tile=10,
+                riichi_declared=[True, False, False, False], wall=list(range(136)))
+    kinds = [unpack_action(a)[0] for a in env.legal(0)]
+    assert DISCARD in kinds and PASS not in kinds and TSUMO in kinds
+    assert [unpack_action(a)[1] for a in env.legal(0) if unpack_action(a)[0] == DISCARD] == [10]
+    env.step({0: pack_action(DISCARD, 10)})
+    v = env.peek()
+    assert v.phase == WAIT_ACT and v.current_player == 1 and (v.last_discard_pid, v.last_discard_tile) == (0, 10)
+    e = evs(env)
+    assert e[-2]["type"] == "dahai" and e[-2]["actor"] == 0 and e[-2]["tsumogiri"] is True and e[-1]["type"] == "tsumo"
+
 
 SCENARIOS = [sc_paishan_dora_indices, sc_kakan_dora_timing, sc_daiminkan_dora_timing, sc_south_round_tsumo,
              sc_illegal_discard_penalty, sc_illegal_out_of_turn, sc_claim_priority_pon_over_chi, sc_kuikae_suji,
@@ -834,7 +870,8 @@ SCENARIOS = [sc_paishan_dora_indices, sc_kakan_dora_timing, sc_daiminkan_dora_ti
              sc_furiten_ron, sc_temporary_furiten, sc_valid_ankan_after_riichi, sc_no_claims_during_riichi,
              sc_honba_reset_and_increment, sc_pao_ron_honba, sc_doujun_cleared_by_call,
              sc_sudden_death_west_round, sc_ron_after_call_clears_doujun, sc_discard_type_tracking, sc_riichi_markers,
-             sc_daiminkan_rinshan_draw, sc_chi_needs_the_exact_copies]
+             sc_daiminkan_rinshan_draw, sc_chi_needs_the_exact_copies, sc_kakan_from_tsumo_and_from_hand,
+             sc_riichi_player_tsumogiri]
 
 
 # ---------------------------------------------------------------------------------------------------------

@@ -26,7 +26,13 @@ _dais = t34([27] * 3 + [28] * 3 + [29] * 3 + [30] * 3 + [0, 0])
 _m84 = [0, 1, 2, 60, 64, 72, 73, 74, 76, 80, 96, 100, 104]           # 111m 78p 11123s 789s (tests.rs:312-372)
 _kazoe = [0, 1, 4, 5, 8, 9, 12, 16, 20, 24, 28, 32, 17]               # 112233 4 5r 6789 m + 5m (tests.rs:1510-1592)
 
+_south = [0, 1, 2, 4, 5, 6, 8, 9, 10, 32]                              # 111m 222m 333m 9m + pon of South (test_riichienv_hora.py:63-100)
+
 HAND_KATS = [
+    # tests/env/test_riichienv_hora.py:63-100: North seat in a South round rons 9m: round wind, toitoi, sanankou, honitsu
+    ("south_round_toitoi", case(_south, 33, player_wind=3, round_wind=1,
+                                melds=[{"meld_type": "pon", "tiles": [112, 113, 114], "opened": True, "from_who": 0}]),
+     {"is_win": 1, "yaku": [11, 21, 22, 27]}),
     # tests.rs:93-108 tsuuiisou (id 39; also daisuushii 50 -> >= 13 han)
     ("tsuuiisou", case(_tsuu[:-1], _tsuu[-1]), {"is_win": 1, "yakuman": 1, "has": [39], "min_han": 13}),
     # tests.rs:110-130 ryuuiisou (id 40)
@@ -45,7 +51,9 @@ HAND_KATS = [
 def check(name, r, want):
     ids = list(r.yaku[: r.n_yaku])
     for k, v in want.items():
-        if k == "has":
+        if k == "yaku":
+            assert ids == v, (name, ids)
+        elif k == "has":
             assert all(y in ids for y in v), (name, ids)
         elif k == "min_han":
             assert r.han >= v, (name, r.han)

@@ -861,6 +861,26 @@ def sc_riichi_player_tsumogiri(make):
     e = evs(env)
     assert e[-2]["type"] == "dahai" and e[-2]["actor"] == 0 and e[-2]["tsumogiri"] is True and e[-1]["type"] == "tsumo"
 
+def sc_melds_with_red_fives(make):
+    """actions/test_meld_aka.py:12-232: Chi in all three positions and Pon with a plain or a red 5m as the called tile, incl.
+    a Chi that names the second copy of a tile (ids as riichienv.parse_hand assigns them; the two hands of the reference's
+    test share ids, and the discarder holds the discarded id twice)."""
+    h0 = [0, 4, 8, 12, 17, 20, 24, 28, 32, 36, 40, 44, 48]                    # 123456789m1234p
+    pins = [36, 40, 44, 48, 53, 56, 60, 64, 68, 80]                          # 123456789p3s
+    cases = [([8, 12, 13], 17, CHI, [8, 12]), ([8, 12, 13], 16, CHI, [8, 12]), ([12, 13, 20], 17, CHI, [12, 20]),
+             ([12, 13, 20], 16, CHI, [12, 20]), ([24, 25, 20], 17, CHI, [20, 24]), ([24, 25, 20], 16, CHI, [20, 24]),
+             ([24, 25, 20], 16, CHI, [20, 25]), ([17, 18, 20], 16, PON, [17, 18]), ([17, 18, 20], 19, PON, [17, 18])]
+    for man, drawn, kind, consume in cases:
+        env = setup(make(game_mode=2), hands=[h0, man + pins, _SAFE1, _SAFE2], drawn_tile=drawn, wall=list(range(136)))
+        env.step({0: pack_action(DISCARD, drawn)})
+        act, ph, dn = env.status()
+        assert ph == WAIT_RESPONSE and act == 0b0010
+        assert pack_action(kind, drawn, consume) in env.legal(1)
+        env.step({1: pack_action(kind, drawn, consume)})
+        act, ph, dn = env.status()
+        assert ph == WAIT_ACT and act == 0b0010
+        assert evs(env)[-1]["type"] == ("chi" if kind == CHI else "pon")
+
 
 SCENARIOS = [sc_paishan_dora_indices, sc_kakan_dora_timing, sc_daiminkan_dora_timing, sc_south_round_tsumo,
              sc_illegal_discard_penalty, sc_illegal_out_of_turn, sc_claim_priority_pon_over_chi, sc_kuikae_suji,
@@ -871,7 +891,7 @@ SCENARIOS = [sc_paishan_dora_indices, sc_kakan_dora_timing, sc_daiminkan_dora_ti
              sc_honba_reset_and_increment, sc_pao_ron_honba, sc_doujun_cleared_by_call,
              sc_sudden_death_west_round, sc_ron_after_call_clears_doujun, sc_discard_type_tracking, sc_riichi_markers,
              sc_daiminkan_rinshan_draw, sc_chi_needs_the_exact_copies, sc_kakan_from_tsumo_and_from_hand,
-             sc_riichi_player_tsumogiri]
+             sc_riichi_player_tsumogiri, sc_melds_with_red_fives]
 
 
 # ---------------------------------------------------------------------------------------------------------

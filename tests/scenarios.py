@@ -881,6 +881,27 @@ def sc_melds_with_red_fives(make):
         assert ph == WAIT_ACT and act == 0b0010
         assert evs(env)[-1]["type"] == ("chi" if kind == CHI else "pon")
 
+def sc_game_mode_round_transitions(make):
+    """test_game_rules.py:11-100: after a kyushu kyuhai draw a single-round game is over; an east-only game goes on with the
+    same dealer and one honba, announced by a start_kyoku event."""
+    h = [0, 4, 8, 12, 36, 40, 44, 48, 72, 76, 80, 108, 112]
+    for mode, expect_done in ((0, True), (1, False)):
+        env = setup(make(game_mode=mode), hands=[h, tiles("19m19p19s1234567z")[0:13], list(h), list(h)], drawn_tile=1,
+                    wall=list(range(136)))
+        v = env.peek()
+        assert v.oya == 0 and v.round_wind == 0 and v.honba == 0
+        env.step({0: pack_action(DISCARD, 80)})
+        act, ph, dn = env.status()
+        assert (act >> 1) & 1 and find(env.legal(1), KYUSHU) is not None
+        env.step({1: pack_action(KYUSHU)})
+        act, ph, dn = env.status()
+        assert bool(dn) == expect_done
+        if not expect_done:
+            v = env.peek()
+            assert act & 1 and v.oya == 0 and v.round_wind == 0 and v.honba == 1
+            e = evs(env)
+            assert e[-2]["type"] == "start_kyoku" and e[-2]["oya"] == 0 and e[-2]["honba"] == 1
+
 
 SCENARIOS = [sc_paishan_dora_indices, sc_kakan_dora_timing, sc_daiminkan_dora_timing, sc_south_round_tsumo,
              sc_illegal_discard_penalty, sc_illegal_out_of_turn, sc_claim_priority_pon_over_chi, sc_kuikae_suji,
@@ -891,7 +912,7 @@ SCENARIOS = [sc_paishan_dora_indices, sc_kakan_dora_timing, sc_daiminkan_dora_ti
              sc_honba_reset_and_increment, sc_pao_ron_honba, sc_doujun_cleared_by_call,
              sc_sudden_death_west_round, sc_ron_after_call_clears_doujun, sc_discard_type_tracking, sc_riichi_markers,
              sc_daiminkan_rinshan_draw, sc_chi_needs_the_exact_copies, sc_kakan_from_tsumo_and_from_hand,
-             sc_riichi_player_tsumogiri, sc_melds_with_red_fives]
+             sc_riichi_player_tsumogiri, sc_melds_with_red_fives, sc_game_mode_round_transitions]
 
 
 # ---------------------------------------------------------------------------------------------------------

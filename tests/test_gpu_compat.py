@@ -236,3 +236,29 @@ def test_apply_event_records_the_callers_log():
     o = env.observe_event(log[cut], 2)            # observe_event = apply + get_observation (env.rs:895-948): cursor of seat 2
     assert env.mjai_log == log[: cut + 1]
     assert env.get_observation(2).events == [] and (o is None or o.events[-1]["type"] == log[cut]["type"])
+
+
+def test_reset_starts_a_fresh_game_like_reference():
+    """tests/env/test_reset_game.py:9-53: reset() without arguments restores scores, round wind, dealer, honba and deposits;
+    a scores list of the wrong length is a ValueError."""
+    from riichienv_amd.compat import RiichiEnv
+
+    env = RiichiEnv(seed=42)
+    env.reset(scores=[30000, 20000, 40000, 10000])
+    assert env.scores() == [30000, 20000, 40000, 10000]
+    env.reset()
+    assert env.scores() == [25000] * 4
+    env.reset(round_wind=1, oya=2, honba=3, kyotaku=5)
+    assert (env.round_wind, env.oya, env.honba, env.riichi_sticks) == (1, 2, 3, 5)
+    env.reset()
+    assert (env.round_wind, env.oya, env.honba, env.riichi_sticks) == (0, 0, 0, 0)
+    for bad in ([25000] * 3, []):
+        with pytest.raises(ValueError, match="does not match"):
+            env.reset(scores=bad)
+    e3 = RiichiEnv(seed=42, game_mode="3p-red-east")
+    e3.reset(scores=[40000, 30000, 35000])
+    assert e3.scores() == [40000, 30000, 35000]
+    e3.reset()
+    assert e3.scores() == [35000] * 3
+    with pytest.raises(ValueError, match="does not match"):
+        e3.reset(scores=[35000] * 4)

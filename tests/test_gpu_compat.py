@@ -262,3 +262,28 @@ def test_reset_starts_a_fresh_game_like_reference():
     assert e3.scores() == [35000] * 3
     with pytest.raises(ValueError, match="does not match"):
         e3.reset(scores=[35000] * 4)
+
+
+def test_apply_and_observe_event_log_like_reference():
+    """tests/env/test_apply_event_mjai_log.py (issue #184): start_game through apply_event / observe_event clears the
+    constructor's log, later events accumulate in order with their fields (also the caller's extra ones), 4P and 3P."""
+    from riichienv_amd.compat import RiichiEnv
+    from tests.apply_events_util import TEHAIS_3P, TEHAIS_4P, start_kyoku
+
+    for mode, tehais in (("4p-red-half", TEHAIS_4P), ("3p-red-half", TEHAIS_3P)):
+        for feed in ("apply", "observe"):
+            env = RiichiEnv(game_mode=mode)
+            assert len(env.mjai_log) > 0                                   # the constructor's own round
+            push = env.apply_event if feed == "apply" else (lambda e: env.observe_event(e, 0))
+            push({"type": "start_game", "names": ["A", "B", "C", "D"][: len(tehais)]})
+            assert len(env.mjai_log) == 1 and env.mjai_log[0]["names"][0] == "A"
+            sk = start_kyoku(tehais)
+            events = [sk, {"type": "tsumo", "actor": 0, "pai": "5p"}, {"type": "dahai", "actor": 0, "pai": "5p", "tsumogiri": True}]
+            for e in events:
+                push(e)
+            log = env.mjai_log
+            assert [e["type"] for e in log] == ["start_game", "start_kyoku", "tsumo", "dahai"]
+            assert log[2] == {"type": "tsumo", "actor": 0, "pai": "5p"} and log[3]["tsumogiri"] is True
+            assert len(log[1]["tehais"]) == len(tehais)
+            push({"type": "start_game"})                                   # a second start_game resets the log again
+            assert len(env.mjai_log) == 1 and env.mjai_log[0]["type"] == "start_game"

@@ -287,3 +287,21 @@ def test_apply_and_observe_event_log_like_reference():
             assert len(log[1]["tehais"]) == len(tehais)
             push({"type": "start_game"})                                   # a second start_game resets the log again
             assert len(env.mjai_log) == 1 and env.mjai_log[0]["type"] == "start_game"
+
+
+def test_ranks_and_points_kats():
+    """tests/env/test_env_ranks_points.py:7-60: ranks (ties by seat) and the preset point rules."""
+    from riichienv_amd.compat import RiichiEnv
+
+    env = RiichiEnv(seed=42)
+    env.reset(scores=[30000, 20000, 40000, 10000])
+    assert env.ranks() == [2, 3, 1, 4]
+    for oya, sc in ((0, [25000] * 4), (1, [25000] * 4), (0, [30000, 30000, 20000, 20000])):
+        env.reset(oya=oya, scores=sc)
+        assert env.ranks() == [1, 2, 3, 4]
+    env.reset(oya=0, scores=[35000, 25000, 25000, 15000])
+    assert env.points("basic") == [60, 10, -10, -60]
+    env.reset(oya=0, scores=[40000, 30000, 20000, 10000])
+    assert env.points("ouza-tyoujyo") == [100, 40, -40, -100] and env.points("ouza-normal") == [50, 20, -20, -50]
+    with pytest.raises(ValueError, match="Unknown preset rule: nonexistent"):
+        env.points("nonexistent")

@@ -902,6 +902,32 @@ def sc_game_mode_round_transitions(make):
             e = evs(env)
             assert e[-2]["type"] == "start_kyoku" and e[-2]["oya"] == 0 and e[-2]["honba"] == 1
 
+def sc_oyayame_needs_the_sole_or_seat_first_top(make):
+    """_initialize_next_round (state/mod.rs:1606-1620; tests/test_oyayame_tiebreak.py:6-78): a dealer win in the last regular
+    round ends the game only if the dealer is top with >= 30000, ties going to the LOWER seat - dealer seat 3 tied with seat
+    0 plays on (renchan), one point more for the dealer ends it."""
+    h3 = [4, 8, 12, 13, 17, 20, 56, 60, 64, 80, 81, 84, 92]                 # 234m 456m 678p 33s 46s: kanchan 5s, tanyao only
+    h1 = _SAFE1[:12]
+    for s0, expect_done in ((30000, False), (29900, True)):
+        def mut(v):
+            v.n_dora = 1
+            v.dora[0] = 132
+            v.is_first_turn = 0
+        env = setup(make(game_mode=2), hands=[tiles("19m19p19s1234567z")[0:13], h1, _SAFE2, h3], current_player=1, active_players=[1],
+                    drawn_tile=89, points=[s0, 22000, 20000, 28000], round_wind=1, wall=list(range(136)), mutate=mut,
+                    reset_kw={"oya": 3, "round_wind": 1})
+        env.step({1: pack_action(DISCARD, 89)})
+        act, ph, dn = env.status()
+        assert ph == WAIT_RESPONSE and (act >> 3) & 1 and find(env.legal(3), RON) is not None
+        env.step({3: pack_action(RON, 89)})
+        hora = [e for e in evs(env) if e["type"] == "hora"][-1]
+        assert hora["deltas"] == [0, -2000, 0, 2000]                        # dealer 1 han 40 fu
+        act, ph, dn = env.status()
+        v = env.peek()
+        assert bool(dn) == expect_done
+        if not expect_done:
+            assert v.oya == 3 and v.honba == 1 and v.round_wind == 1 and [p.score for p in v.players] == [30000, 20000, 20000, 30000]
+
 
 SCENARIOS = [sc_paishan_dora_indices, sc_kakan_dora_timing, sc_daiminkan_dora_timing, sc_south_round_tsumo,
              sc_illegal_discard_penalty, sc_illegal_out_of_turn, sc_claim_priority_pon_over_chi, sc_kuikae_suji,
@@ -912,7 +938,8 @@ SCENARIOS = [sc_paishan_dora_indices, sc_kakan_dora_timing, sc_daiminkan_dora_ti
              sc_honba_reset_and_increment, sc_pao_ron_honba, sc_doujun_cleared_by_call,
              sc_sudden_death_west_round, sc_ron_after_call_clears_doujun, sc_discard_type_tracking, sc_riichi_markers,
              sc_daiminkan_rinshan_draw, sc_chi_needs_the_exact_copies, sc_kakan_from_tsumo_and_from_hand,
-             sc_riichi_player_tsumogiri, sc_melds_with_red_fives, sc_game_mode_round_transitions]
+             sc_riichi_player_tsumogiri, sc_melds_with_red_fives, sc_game_mode_round_transitions,
+             sc_oyayame_needs_the_sole_or_seat_first_top]
 
 
 # ---------------------------------------------------------------------------------------------------------

@@ -43,7 +43,7 @@ __global__ __launch_bounds__(64 * RMJ_STEP_WPB, RMJ_STEP_WAVES) void k_step(cons
     c.pf_live_end = S.live_end;
     c.pf_draw = c.W[S.live_end > 0 ? S.live_end - 1 : 0];
     PROF(c.X, lane, 0);
-    // lane = seat: one gather (and one copy of the modulo / of the canonicalisation) for all seats
+    // the seats' actions of this step: lane p (< 4) holds seat p's packed action (act_at reads them back)
     uint64_t mine = RMJ_NO_ACTION;
     if (device_policy) {
         // RandomAgent (random_agent.py:6-15), keyed per (game, step, seat): see rmj_step_random in the header

@@ -290,6 +290,11 @@ int rmj_step_ids_device(rmj_handle h, const int32_t* d_action_ids, int auto_rese
 /* scores() (env.rs:401-404) into a device buffer [n][4]; d_event_counts [n] may be NULL */
 int rmj_scores_device(rmj_handle h, int32_t* d_scores, uint32_t* d_event_counts);
 int rmj_sync(rmj_handle h); /* wait for the handle's stream */
+/* Issue all further work of the handle on the caller's HIP stream (e.g. the stream of the policy's framework), so that
+ * kernels of the library and of the policy are ordered by the stream itself and no host synchronisation is needed
+ * between them (NULL = the device's default stream, which is what frameworks use unless told otherwise); own != 0 returns
+ * to the handle's own stream.  Work already issued is waited for first. */
+int rmj_set_stream(rmj_handle h, void* hip_stream, int own);
 
 /* ------------------------------------------------------------------ MJAI event ingestion
  * RiichiEnv.apply_event (riichienv-python/src/env.rs:880-887) -> GameState::apply_mjai_event

@@ -510,7 +510,8 @@ static int fail(int code, const std::string& msg) {
 struct rmj_env {
     RmjConfig cfg;
     Env d;
-    hipStream_t stream = nullptr;
+    hipStream_t stream = nullptr;      // the stream every entry point works on: own_stream, or the caller's (rmj_set_stream)
+    hipStream_t own_stream = nullptr;
     // extra streams of multi-step device rollouts (rmj_step_random): the games are stepped as k parts, one per stream,
     // so that the draining tail of one part's launch overlaps the bodies of the others'.  Forked from and joined back
     // into `stream` inside the call: every other entry point sees one ordered stream.  Measured at 65 536 games:
@@ -583,7 +584,8 @@ int rmj_create(const RmjConfig* cfg, rmj_handle* out) {
     const size_t B = cfg->n_games;
     Env& d = h->d;
     memset(&d, 0, sizeof(d));
-    HIPCHK(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
+    HIPCHK(hipStreamCreateWithFlags(&h->own_stream, hipStreamNonBlocking));
+    h->stream = h->own_stream;
     HIPCHK(hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming));
     for (int i = 0; i < RMJ_MAX_ROLLOUT_STREAMS - 1; i++) {
         HIPCHK(hipStreamCreateWithFlags(&h->xstream[i], hipStreamNonBlocking));
@@ -644,7 +646,7 @@ int rmj_destroy(rmj_handle h) {
     hipStreamSynchronize(h->stream);
     hipFree(h->d.core); hipFree(h->d.wall); hipFree(h->d.legal); hipFree(h->d.nlegal); hipFree(h->d_decay); if (h->d_scratch) hipFree(h->d_scratch); hipFree(h->d.mask);
     hipFree(h->d.waits); hipFree(h->d.status); hipFree(h->d.events); hipFree(h->d_actions); hipFree(h->d_counter); hipFree(h->d_env);
-    hipStreamDestroy(h->stream);
+    hipStreamDestroy(h->own_stream);
     for (int i = 0; i < RMJ_MAX_ROLLOUT_STREAMS - 1; i++) {
         if (h->xstream[i]) { hipStreamSynchronize(h->xstream[i]); hipStreamDestroy(h->xstream[i]); }
         if (h->ev_join[i]) hipEventDestroy(h->ev_join[i]);
@@ -727,6 +729,13 @@ int rmj_scores_device(rmj_handle h, int32_t* d_scores, uint32_t* d_event_counts)
     const uint32_t n = h->cfg.n_games;
     hipLaunchKernelGGL(k_gather_scores, dim3((n + 255) / 256), dim3(256), 0, h->stream, h->d.core, n, d_scores, d_event_counts);
     HIPCHK(hipGetLastError());
+    return RMJ_OK;
+}
+int rmj_set_stream(rmj_handle h, void* stream, int own) {
+    if (!h) return fail(RMJ_ERR_ARG, "null handle");
+    HIPCHK(hipSetDevice(h->cfg.device));
+    HIPCHK(hipStreamSynchronize(h->stream));  // everything issued so far is complete before the order changes hands
+    h->stream = own ? h->own_stream : (hipStream_t)stream;  // (a NULL stream is the device's default stream)
     return RMJ_OK;
 }
 int rmj_sync(rmj_handle h) {

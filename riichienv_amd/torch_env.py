@@ -35,7 +35,10 @@ class TorchVecEnv:
     obs(), mask, status … describe the state AFTER the last step; step(action_ids) takes an int32 tensor [n, 4] on the
     same device (-1 for seats that do not act)."""
 
-    def __init__(self, n_games, game_mode=2, seed=0, device=0, extended=False, skip_mjai_logging=True, **kw):
+    def __init__(self, n_games, game_mode=2, seed=0, device=0, extended=False, skip_mjai_logging=True, share_stream=True, **kw):
+        """share_stream: issue the library's kernels on torch's current stream of `device` (rmj_set_stream): policy and
+        environment are then ordered by the stream, without host synchronisation between them.  With False the library keeps
+        its own stream and every call synchronises."""
         import torch
 
         self.torch = torch
@@ -62,6 +65,9 @@ class TorchVecEnv:
         self.waits = wrap(v.waits, (self.n, 4), "<i8")
         self._obs = torch.zeros((self.n, 4, self.channels, self.width), dtype=torch.float32, device=self.device)
         self._scores = torch.zeros((self.n, 4), dtype=torch.int32, device=self.device)
+        self.shared = bool(share_stream)
+        if self.shared:
+            vecenv._chk(L.rmj_set_stream(self.env.h, C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream), 0))
         self.env.reset()
 
     # ---- status helpers (views, no copies beyond the arithmetic)
@@ -106,12 +112,15 @@ class TorchVecEnv:
         t = self.torch
         ids = action_ids.to(device=self.device, dtype=t.int32).contiguous()
         assert ids.shape == (self.n, 4)
-        t.cuda.current_stream(self.device).synchronize()      # the ids were produced on torch's stream
+        if not self.shared:
+            t.cuda.current_stream(self.device).synchronize()  # the ids were produced on torch's stream
         vecenv._chk(self.env.L.rmj_step_ids_device(self.env.h, C.c_void_p(ids.data_ptr()), int(auto_reset)))
         self.sync()
 
     def sync(self):
-        vecenv._chk(self.env.L.rmj_sync(self.env.h))
+        """own stream: wait for the library's work; shared stream: nothing to do, torch's stream orders it"""
+        if not self.shared:
+            vecenv._chk(self.env.L.rmj_sync(self.env.h))
 
     def sample_random_ids(self, generator=None):
         """uniform choice among the legal ids of every acting seat (a masked categorical policy's baseline)"""

@@ -27,7 +27,7 @@ EXPORTS = [
     "rmj_get_waits", "rmj_get_scores", "rmj_get_ranks", "rmj_get_step_counts", "rmj_total_steps", "rmj_peek_state",
     "rmj_poke_state", "rmj_get_event_counts", "rmj_get_events", "rmj_format_event", "rmj_eval_hands",
     "rmj_agari_counts", "rmj_calculate_score", "rmj_shanten", "rmj_effective_tiles", "rmj_best_ukeire", "rmj_apply_events", "rmj_device_views", "rmj_step_ids_device",
-    "rmj_scores_device", "rmj_sync", "rmj_encode", "rmj_encode_device", "rmj_encode_extended", "rmj_encode_extended_device", "rmj_encode_aux", "rmj_encode_aux_device", "rmj_encode_seq", "rmj_encode_seq_device", "rmj_bench_rollout",
+    "rmj_scores_device", "rmj_sync", "rmj_set_stream", "rmj_encode", "rmj_encode_device", "rmj_encode_extended", "rmj_encode_extended_device", "rmj_encode_aux", "rmj_encode_aux_device", "rmj_encode_seq", "rmj_encode_seq_device", "rmj_bench_rollout",
 ]
 
 
@@ -99,6 +99,7 @@ def load_lib():
     L.rmj_encode_device.argtypes = [vp, C.c_int, vp]
     L.rmj_encode_extended.argtypes = [vp, C.c_int, vp]
     L.rmj_encode_extended_device.argtypes = [vp, C.c_int, vp]
+    L.rmj_set_stream.argtypes = [vp, vp, C.c_int]
     L.rmj_encode_aux.argtypes = [vp, C.c_int, vp]
     L.rmj_encode_aux_device.argtypes = [vp, C.c_int, vp]
     L.rmj_encode_seq.argtypes = [vp, C.c_int, C.POINTER(abi.SeqBuffers)]

@@ -12,10 +12,8 @@ import torch  # noqa: E402
 from riichienv_amd.torch_env import TorchVecEnv  # noqa: E402
 
 
-def main():
-    n = int(sys.argv[1]) if len(sys.argv) > 1 else 65536
-    ext = len(sys.argv) > 2 and sys.argv[2] == "ext"
-    env = TorchVecEnv(n, game_mode=2, seed=0, extended=ext)
+def run(n, ext, shared):
+    env = TorchVecEnv(n, game_mode=2, seed=0, extended=ext, share_stream=shared)
     gen = torch.Generator(device=env.device)
     gen.manual_seed(0)
     for _ in range(20):
@@ -30,17 +28,27 @@ def main():
         env.obs(only_active=True)
         b = time.perf_counter()
         ids = env.sample_random_ids(gen)
-        torch.cuda.synchronize()
+        if not shared:
+            torch.cuda.synchronize()      # own stream: the parts are timed one by one
         c = time.perf_counter()
         env.step(ids)
         d = time.perf_counter()
         t_obs += b - a
         t_pol += c - b
         t_step += d - c
+    torch.cuda.synchronize()
     t1 = time.perf_counter()
     steps = env.env.total_steps() - steps0
-    print(f"games {n} channels {env.channels}: loop {steps / (t1 - t0) / 1e6:.1f} M env.step/s "
-          f"(obs {t_obs / K * 1e3:.2f} ms, torch policy {t_pol / K * 1e3:.2f} ms, step {t_step / K * 1e3:.2f} ms per iteration)")
+    parts = "" if shared else f" (obs {t_obs / K * 1e3:.2f} ms, torch policy {t_pol / K * 1e3:.2f} ms, step {t_step / K * 1e3:.2f} ms per iteration)"
+    print(f"games {n} channels {env.channels} {'shared stream, no host sync' if shared else 'own stream, synchronised parts'}: "
+          f"loop {steps / (t1 - t0) / 1e6:.1f} M env.step/s, {(t1 - t0) / K * 1e3:.2f} ms per iteration{parts}")
+
+
+def main():
+    n = int(sys.argv[1]) if len(sys.argv) > 1 else 65536
+    ext = len(sys.argv) > 2 and sys.argv[2] == "ext"
+    run(n, ext, False)
+    run(n, ext, True)
 
 
 if __name__ == "__main__":

@@ -8,15 +8,15 @@ from riichienv_amd import abi
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("mode", [2, 5])
-def test_torch_env_matches_oracle(mode):
+@pytest.mark.parametrize("mode,shared", [(2, True), (5, True), (2, False)])
+def test_torch_env_matches_oracle(mode, shared):
     torch = pytest.importorskip("torch")
     from oracle import oracle
     from riichienv_amd.torch_env import TorchVecEnv
 
     n, seed = 48, 700 + mode
     sanma = mode >= 3
-    env = TorchVecEnv(n, game_mode=mode, seed=seed, extended=False, skip_mjai_logging=False)
+    env = TorchVecEnv(n, game_mode=mode, seed=seed, extended=False, skip_mjai_logging=False, share_stream=shared)
     games = [oracle.Game(game_mode=mode, seed=seed + g) for g in range(n)]
     for o in games:
         o.reset()

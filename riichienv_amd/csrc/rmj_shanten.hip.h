@@ -349,6 +349,46 @@ __device__ __forceinline__ int sh_shanten_wave(const PH& h, int len_div3, const 
     return sres;
 }
 
+// ---- shanten of a hand that differs from a known hand in ONE suit (4P): the three other suit vectors and their pair
+// merge are reused, only the changed suit is looked up and merged again (1 rank + 1 merge + 1 entry instead of 4 + 3).
+struct ShBase {
+    uint64_t v[4];   // packed cost vectors of man / pin / sou / honors
+    uint64_t ab, cd; // merge(v0, v1), merge(v2, v3)
+};
+__device__ __forceinline__ uint64_t sh_vec(uint32_t word, int q, const ShantenTables& T) {
+    return q < 3 ? T.suit[sh_rank(word, 9, T.rank9)] : T.honor[sh_rank(word, 7, T.rank7)];
+}
+// wave-uniform hand -> base; lanes 0..3 look one suit up each, the vectors are broadcast
+__device__ __forceinline__ ShBase sh_base_wave(const PH& h, const ShantenTables& T, int lane) {
+    const int q = lane & 3;
+    const uint64_t mine = sh_vec(ph_get(h, q), q, T);
+    ShBase B;
+#pragma unroll
+    for (int k = 0; k < 4; k++)
+        B.v[k] = (uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)mine, k) |
+                 ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(mine >> 32), k) << 32);
+    B.ab = sh_merge(B.v[0], B.v[1]);
+    B.cd = sh_merge(B.v[2], B.v[3]);
+    return B;
+}
+// shanten (shanten.rs:228-241, 4P) of the hand x = base hand with suit q replaced by the vector nv
+__device__ __forceinline__ int sh_shanten_mod(const ShBase& B, int q, uint64_t nv, const PH& x, int len_div3) {
+    const uint64_t other = q == 0 ? B.v[1] : (q == 1 ? B.v[0] : (q == 2 ? B.v[3] : B.v[2]));
+    const uint64_t side = q < 2 ? B.cd : B.ab;
+    const uint64_t X = sh_merge(nv, other);
+    const int m = len_div3 > 4 ? 4 : len_div3;
+    int s = (int)sh_merge_entry((uint32_t)X & 0xFFFFFu, (uint32_t)(X >> 20) & 0xFFFFFu, (uint32_t)side & 0xFFFFFu,
+                                (uint32_t)(side >> 20) & 0xFFFFFu, 1, m) - 1;
+    if (s <= 0 || len_div3 < 4) return s;
+    const int c = sh_chiitoi(x, false);
+    s = c < s ? c : s;
+    if (s > 0) {
+        const int k = sh_kokushi(x);
+        s = k < s ? k : s;
+    }
+    return s;
+}
+
 // calculate_effective_tiles(_3p)_with_discard ("eff") and calculate_best_ukeire(_3p) ("uke"), shanten.rs:265-405 /
 // :488-626, for ONE wave-uniform hand: lane = drawn tile type (my_cnt / my_vis = this lane's held / visible count), the
 // loop over discard candidates runs over held types.  eff on a 3n hand yields 0xFFFFFFFF (the reference asserts).
@@ -360,6 +400,84 @@ __device__ inline void sh_ukeire_both(const ShantenTables& T, const PH& h, uint3
     const int t = lane;
     const bool t_ok = t < 34 && (!sm || t == 0 || t >= 8);  // SANMA_VALID_TILE_TYPES (shanten.rs:244-247)
     const int total = ph_total(h);
+    if (!sm) {
+        // 4P: every hand judged here is the hand h with one tile removed and / or one added, i.e. it differs from a known
+        // hand in one suit: sh_shanten_mod on a base of h, resp. of h minus the discard
+        const int q = t < 34 ? t_suit(t) : 0, r = t < 34 ? t - 9 * q : 0;
+        const uint32_t one = 1u << (3 * r);
+        const ShBase Bh = sh_base_wave(h, T, lane);
+        const int m_h = total / 3 > 4 ? 4 : total / 3;
+        const int cur = cur_in != -99 ? cur_in : ([&] {
+            int s0 = (int)sh_merge_entry((uint32_t)Bh.ab & 0xFFFFFu, (uint32_t)(Bh.ab >> 20) & 0xFFFFFu, (uint32_t)Bh.cd & 0xFFFFFu,
+                                         (uint32_t)(Bh.cd >> 20) & 0xFFFFFu, 1, m_h) - 1;
+            if (s0 <= 0 || total / 3 < 4) return s0;
+            const int c = sh_chiitoi(h, false);
+            s0 = c < s0 ? c : s0;
+            if (s0 > 0) { const int k = sh_kokushi(h); s0 = k < s0 ? k : s0; }
+            return s0;
+        })();
+        eff = 0;
+        uke = 0;
+        if (want_eff && total % 3 == 1) {
+            bool f = false;
+            if (t < 34 && ph_cnt(h, t) < 4) {
+                PH x = h;
+                ph_add(x, t);
+                f = sh_shanten_mod(Bh, q, sh_vec(ph_get(h, q) + one, q, T), x, (total + 1) / 3) < cur;
+            }
+            eff = (uint32_t)__popcll(__ballot(f));
+        }
+        if (want_eff && total % 3 == 0) eff = 0xFFFFFFFFu;
+        const bool eff_loop = want_eff && total % 3 == 2;
+        if (!eff_loop && !want_uke) return;
+        int nsh_l = 127;
+        uint64_t nv_d = 0;
+        if (t < 34 && ph_cnt(h, t) > 0) {
+            PH sub = h;
+            ph_sub(sub, t);
+            nv_d = sh_vec(ph_get(h, q) - one, q, T);
+            nsh_l = sh_shanten_mod(Bh, q, nv_d, sub, (total - 1) / 3);
+        }
+        if (nsh_out) *nsh_out = nsh_l;
+        uint64_t cand = __ballot(nsh_l <= cur);
+        while (cand) {
+            const int d = __ffsll((long long)cand) - 1;
+            cand &= cand - 1ull;
+            const int nsh = __builtin_amdgcn_readlane(nsh_l, d);
+            const int qd = t_suit(d);
+            PH sub = h;
+            ph_sub(sub, d);
+            ShBase Bs = Bh;  // base of h minus d: the discarder's suit vector comes from lane d
+            const uint64_t V = (uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)nv_d, d) |
+                               ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(nv_d >> 32), d) << 32);
+            if (qd == 0) { Bs.v[0] = V; Bs.ab = sh_merge(V, Bh.v[1]); }
+            else if (qd == 1) { Bs.v[1] = V; Bs.ab = sh_merge(Bh.v[0], V); }
+            else if (qd == 2) { Bs.v[2] = V; Bs.cd = sh_merge(V, Bh.v[3]); }
+            else { Bs.v[3] = V; Bs.cd = sh_merge(Bh.v[2], V); }
+            bool f = false;
+            if (t < 34 && ph_cnt(sub, t) < 4) {
+                PH x = sub;
+                ph_add(x, t);
+                f = sh_shanten_mod(Bs, q, sh_vec(ph_get(sub, q) + one, q, T), x, total / 3) < nsh;
+            }
+            const uint64_t fb = __ballot(f);
+            if (eff_loop) {
+                const uint32_t e = (uint32_t)__popcll(fb);
+                eff = e > eff ? e : eff;
+            }
+            if (want_uke) {
+                int held = (int)my_cnt - (t == d ? 1 : 0);
+                int rem = 4 - (int)my_vis;
+                rem = rem < 0 ? 0 : rem;
+                rem -= held;
+                const uint32_t w = f ? (uint32_t)(rem < 0 ? 0 : rem) : 0u;
+                const uint32_t u = (uint32_t)__popcll(__ballot(w & 1u)) + 2u * (uint32_t)__popcll(__ballot(w & 2u)) +
+                                   4u * (uint32_t)__popcll(__ballot(w & 4u));
+                uke = u > uke ? u : uke;
+            }
+        }
+        return;
+    }
     const int cur = cur_in != -99 ? cur_in : sh_shanten(h, total / 3, sm, T);  // the caller may know it already
     // does drawing this lane's type lower the shanten of `base` (a 3n+1 hand)?
     auto improves = [&](const PH& base, int base_total, int base_sh) -> bool {

@@ -1069,5 +1069,51 @@ def sc3_exhaustive_draw_pool_2000(make):
     assert sorted(r["deltas"]) in ([-1000, -1000, 2000], [-2000, 1000, 1000], [0, 0, 0])
 
 
+def sc3_pon_and_rotation(make):
+    """tests/env/test_sanma.py:119-207: turns rotate 0 -> 1 -> 2 -> 0, Chi never appears, Pon works and makes the caller the
+    current player."""
+    h0 = [36, 40, 44, 48, 52, 56, 60, 64, 68, 72, 76, 80, 84]
+    h1 = sorted([37, 38, 49, 53, 57, 61, 65, 69, 73, 77, 81, 85, 89])
+    env = setup(make(game_mode=5), hands=[h0, h1, tiles("19m19p19s1234567z")[0:13], None], drawn_tile=88)
+    env.step({0: pack_action(DISCARD, 36)})                                 # 1p: seat 1 holds a pair
+    act, ph, dn = env.status()
+    assert ph == WAIT_RESPONSE and (act >> 1) & 1
+    kinds = {unpack_action(a)[0] for q in range(3) if (act >> q) & 1 for a in env.legal(q)}
+    assert PON in kinds and CHI not in kinds
+    env.step({1: find(env.legal(1), PON)})
+    v = env.peek()
+    assert v.current_player == 1 and v.phase == WAIT_ACT and v.players[1].n_melds == 1
+    # rotation from a fresh round: discard the drawn tile, pass every claim
+    env = make(game_mode=5)
+    env.reset()
+    order = []
+    for _ in range(4):
+        v = env.peek()
+        order.append(v.current_player)
+        assert all(unpack_action(a)[0] != CHI for a in env.legal(v.current_player))
+        env.step({v.current_player: pack_action(DISCARD, v.drawn_tile)})
+        while env.status()[1] == WAIT_RESPONSE:
+            a = env.status()[0]
+            assert all(unpack_action(x)[0] != CHI for q in range(3) if (a >> q) & 1 for x in env.legal(q))
+            env.step({q: pack_action(PASS) for q in range(3) if (a >> q) & 1})
+    assert order == [0, 1, 2, 0]
+
+
+def sc3_ron_deltas(make):
+    """tests/env/test_sanma.py:434-466: a Ron in 3P moves points between winner and discarder only; the third seat is untouched."""
+    p1 = sorted([36, 37, 38, 40, 41, 42, 44, 45, 46, 32, 33, 34, 0])       # 111p 222p 333p 999m 1m: tanki 1m
+    h0 = sorted([48, 52, 56, 60, 64, 68, 72, 76, 80, 84, 88, 92, 96])
+    env = setup(make(game_mode=5), hands=[h0, p1, tiles("19m19p19s1234567z")[0:13], None], drawn_tile=1,
+                mutate=lambda v: setattr(v, "is_first_turn", 0))
+    env.step({0: pack_action(DISCARD, 1)})
+    act, ph, dn = env.status()
+    assert ph == WAIT_RESPONSE and (act >> 1) & 1
+    rons = [a for a in env.legal(1) if unpack_action(a)[0] == RON]
+    assert len(rons) == 1
+    env.step({1: rons[0]})
+    d = [e for e in evs(env) if e["type"] == "hora"][-1]["deltas"]
+    assert len(d) == 3 and d[1] > 0 and d[0] < 0 and d[2] == 0 and sum(d) == 0
+
+
 SCENARIOS_3P = [sc3_basics, sc3_no_chi, sc3_kita, sc3_oyayame_needs_40000, sc3_tsumo_payments_and_nukidora,
-                sc3_exhaustive_draw_pool_2000]
+                sc3_exhaustive_draw_pool_2000, sc3_pon_and_rotation, sc3_ron_deltas]

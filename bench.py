@@ -32,9 +32,14 @@ def cpu_baseline(game_mode, rule_bits, policy_seed, target_s=15.0):
     rate = steps / max(secs, 1e-9)
     per_game = int(max(200, min(200000, rate * target_s / n_games)))
     steps, secs = oracle.bench_rollout(game_mode, rule_bits, False, n_games, 0, policy_seed, per_game, threads)
+    # one thread, a few seconds: the per-core rate beside the all-cores one
+    s1, t1 = oracle.bench_rollout(game_mode, rule_bits, False, 8, 0, policy_seed, 200, 1)
+    per1 = int(max(200, min(200000, (s1 / max(t1, 1e-9)) * 3.0 / 8)))
+    s1, t1 = oracle.bench_rollout(game_mode, rule_bits, False, 8, 0, policy_seed, per1, 1)
     return {"value": steps / secs, "unit": "env.step/s", "cores": threads, "kind": "port",
             "sample": f"{n_games} games x {per_game} steps, {threads} threads, {secs:.1f}s, "
-                      "oracle/ C++ restatement with MJAI logging on (Rust toolchain unavailable)"}
+                      "oracle/ C++ restatement with MJAI logging on (Rust toolchain unavailable)",
+            "single_thread": {"value": s1 / t1, "sample": f"8 games x {per1} steps, {t1:.1f}s"}}
 
 
 def pmc_traffic(games, mode):

@@ -1484,11 +1484,14 @@ __device__ inline void resolve_kita_rinshan(Ctx& c, int pid) {
         S.active_mask = (uint8_t)(1u << pid);
     }
 }
-// state_3p/sanma.rs:9-144
-__device__ inline void handle_kita(Ctx& c, int pid, uint64_t act) {
+// state_3p/sanma.rs:9-144.  <FAST>: part of the fast path of k_step (a Kita is a common action of 3P games: 3 % of the steps
+// of a random rollout); it hands over to the full path when a seat could rob the tile (yaku evaluation).
+template <bool FAST = false>
+__device__ __forceinline__ void handle_kita(Ctx& c, int pid, uint64_t act) {
     GState& S = c.S;
     PState& P = S.p[pid];
     const int lane = c.lane;
+    if (FAST && U((int)S.pending_kan_dora) > 0) { c.bail = true; return; }
     int tile;
     if (a_tile(act) != RMJ_TILE_NONE && (a_tile(act) >> 2) == 30) tile = (int)a_tile(act);
     else {
@@ -1513,6 +1516,7 @@ __device__ inline void handle_kita(Ctx& c, int pid, uint64_t act) {
         c.X.wout[i] = W;
         bool furiten = (W & Q.discard_type_mask) != 0ull || (Q.flags & (PF_MISSED_RIICHI | PF_MISSED_DOUJUN));
         if (furiten || !((W >> (tile >> 2)) & 1ull)) continue;
+        if (FAST) { c.bail = true; return; }
         CalcOut r = seat_calc(c, i, -1, tile, base_cf(Q), S.honba, false, Q.n_kita);  // chankan: false (sanma.rs:106)
         if (r.is_win && (r.yakuman || r.han >= 1)) {
             ronners |= 1u << i;
@@ -1824,8 +1828,11 @@ __device__ __forceinline__ void step_game(Ctx& c, const uint64_t mine, bool trus
                 valid = true;
             }
             do_discard = valid; d_tile = tile; d_tsumogiri = tsumogiri;
+        } else if (FAST && KSANMA && ty == RMJ_KITA) {
+            handle_kita<true>(c, pid, act);
+            return;
         } else {
-            if (FAST) { c.bail = true; return; }  // Riichi, kans, Tsumo, Kyushu, Kita: full path
+            if (FAST) { c.bail = true; return; }  // Riichi, kans, Tsumo, Kyushu: full path
             uint32_t r = ol_wait_act_other(ctx_pack(c), pid, act);
             do_discard = r & 1u; d_tsumogiri = (r >> 1) & 1u; d_tile = (int)(r >> 8);
         }

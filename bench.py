@@ -2,14 +2,19 @@
 """bench.py — env.step()/s of the MI355X-native batched Riichi step path.
 
 One "step" = one batched env.step over every game of the shard (device-side RandomAgent policy,
-auto-reset of finished games), i.e. one launch of the step kernel.  Workload at N=1:
+auto-reset of finished games), i.e. one launch of the step kernel per part of the batch.  Workload at N=1:
 BASELINE.json configs[2] — 65 536 parallel 4p-red-half games, RandomAgent, MJAI logging on.
-N>1: one process per GPU (torch.distributed.run), games sharded by global index, no collective
-on the data path (weak scaling: 65 536 games per GPU).
+N>1: one process per GPU, games sharded by global index, no collective on the data path (weak scaling: 65 536 games
+per GPU).  `python bench.py --gpus N` without a torchrun environment starts the N rank processes itself
+(torch.distributed.run as a child process, before this process has imported torch or touched HIP) and relays rank 0's
+JSON line; under `python -m torch.distributed.run ... bench.py --gpus N` it is one of the ranks.
 """
 import argparse
+import glob
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -18,7 +23,71 @@ sys.path.insert(0, ROOT)
 
 B_STEP_4P = 1688          # algorithmic bytes per env.step per 4P game
 B_STEP_3P = 1280          # 3P: 2*512 + 12 + 180 + 64
+B_OBS_4P = 74 * 34 * 4    # Observation.encode(): 10 064 B per acting seat (docs/FEATURE_ENCODING.md:8-82)
+B_OBS_3P = 74 * 27 * 4    # 7 992 B
 HBM_PEAK = 8.0e12         # B/s, /opt/skills/guides/MI355X_MICROARCH.md (HBM3E peak, spec)
+MODES = ['4p-red-single', '4p-red-east', '4p-red-half', '3p-red-single', '3p-red-east', '3p-red-half']
+STEADY_MIN = 200          # steady-state window of >= 200 batched steps after the warm-up has reached round ends
+
+
+def parse_args(argv=None):
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=2000)
+    ap.add_argument("--warmup", type=int, default=200)
+    ap.add_argument("--games", type=int, default=65536, help="games per GPU")
+    ap.add_argument("--mode", type=int, default=2, help="0/1/2 = 4p-red-single/east/half, 3/4/5 = 3p-red-single/east/half")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip the single-stream / validated-actions side measurements")
+    ap.add_argument("--encode", action="store_true",
+                    help="also produce the feature tensor of the acting seats every step (BASELINE configs[4]: sanma with "
+                         "feature-encoding tensor output): one step launch + one encode launch per step")
+    return ap.parse_args(argv)
+
+
+def free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def launcher_command(args, port, script=None):
+    """Command + environment that start `args.gpus` rank processes of this script on one node (one process per GPU).
+    Pure function of its arguments: tests/test_bench_contract.py checks it without a GPU."""
+    script = script or os.path.abspath(__file__)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), script,
+           "--gpus", str(args.gpus), "--steps", str(args.steps), "--warmup", str(args.warmup),
+           "--games", str(args.games), "--mode", str(args.mode)]
+    if args.no_cpu_baseline:
+        cmd.append("--no-cpu-baseline")
+    if args.no_extras:
+        cmd.append("--no-extras")
+    if args.encode:
+        cmd.append("--encode")
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC only on this pool (RCCL barrier between the ranks)
+    env["MASTER_ADDR"] = "127.0.0.1"
+    return cmd, env
+
+
+def launch_ranks(args):
+    """--gpus N > 1 outside torchrun: start the ranks as children (this process never initialises the GPU, and nothing is
+    exec'ed over a process that has), relay rank 0's JSON line, exit with the launcher's code."""
+    cmd, env = launcher_command(args, free_port())
+    p = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    line = None
+    for ln in p.stdout.splitlines():
+        s = ln.strip()
+        if s.startswith("{") and '"metric"' in s:
+            line = s
+        elif s:
+            print(s, file=sys.stderr)
+    if p.returncode != 0 or line is None:
+        print(f"bench.py: the {args.gpus}-rank launch failed (exit code {p.returncode})", file=sys.stderr)
+        return p.returncode or 1
+    print(line)
+    return 0
 
 
 def cpu_baseline(game_mode, rule_bits, policy_seed, target_s=15.0):
@@ -42,51 +111,71 @@ def cpu_baseline(game_mode, rule_bits, policy_seed, target_s=15.0):
             "single_thread": {"value": s1 / t1, "sample": f"8 games x {per1} steps, {t1:.1f}s"}}
 
 
-def pmc_traffic(games, mode):
-    """HBM bytes per k_step launch from the committed rocprofv3 PMC passes (profiles/r01_pmc_k_step.json: FETCH_SIZE and
-    WRITE_SIZE collected in separate --pmc runs of this same command, FETCH doubled per the gfx950 note of the
-    microarch guide).  bench.py cannot run the profiler itself; null when no matching profile is committed."""
-    path = os.path.join(ROOT, "profiles", "r01_pmc_k_step.json")
-    try:
-        with open(path) as f:
-            d = json.load(f)
-        if d.get("games_per_launch") == games and mode == 2:  # games = games of ONE launch
-            return d["hbm_traffic"]["bytes_per_launch"], "profiles/r01_pmc_k_step.json"
-    except (OSError, KeyError, ValueError):
-        pass
+def pmc_traffic(kernel, games_per_launch, mode):
+    """HBM bytes per launch of `kernel` from the newest committed rocprofv3 PMC summary that matches the launch shape
+    (profiles/r*_pmc_<kernel>*.json: FETCH_SIZE and WRITE_SIZE collected in separate --pmc runs of this same command,
+    FETCH doubled per the gfx950 note of the microarch guide).  bench.py cannot run the profiler itself; null when no
+    matching profile is committed."""
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", f"r*_pmc_{kernel}*.json")), reverse=True):
+        try:
+            with open(path) as f:
+                d = json.load(f)
+            if d.get("games_per_launch") == games_per_launch and d.get("mode", 2) == mode:
+                return d["hbm_traffic"]["bytes_per_launch"], os.path.relpath(path, ROOT)
+        except (OSError, KeyError, ValueError):
+            continue
     return None, None
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=2000)
-    ap.add_argument("--warmup", type=int, default=200)
-    ap.add_argument("--games", type=int, default=65536, help="games per GPU")
-    ap.add_argument("--mode", type=int, default=2, help="0/1/2 = 4p-red-single/east/half, 3/4/5 = 3p-red-single/east/half")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--encode", action="store_true",
-                    help="also produce the feature tensor of the acting seats every step (BASELINE configs[4]: sanma with "
-                         "feature-encoding tensor output); reported in config, the step kernel's roofline is unchanged")
-    args = ap.parse_args()
+def workload_name(args):
+    s = f"{args.games} parallel {MODES[args.mode]} games per GPU, device RandomAgent, auto-reset, MJAI logging on"
+    if args.encode:
+        s += ", Observation.encode() of every acting seat written to a resident tensor after every step"
+    return s
+
+
+def metric_name(args):
+    """BASELINE.json's metric for the configuration it is quoted on; a descriptive one for every other workload."""
+    if args.mode < 3 and args.games == 65536 and not args.encode:
+        return "env.step()/s (whole node) at 65 536 parallel 4p games; bit-exact MJAI parity"
+    seats = "3p" if args.mode >= 3 else "4p"
+    extra = " with feature-encoding tensor output" if args.encode else ""
+    return f"env.step()/s (whole node) at {args.games} parallel {seats} games per GPU{extra}; bit-exact MJAI parity"
+
+
+def main(argv=None):
+    args = parse_args(argv)
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        return launch_ranks(args)
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: start it as `python bench.py --gpus {args.gpus}` or under "
+              f"torch.distributed.run with --nproc-per-node {args.gpus}", file=sys.stderr)
+        return 2
 
     import torch
 
     from riichienv_amd import abi, shard, vecenv
 
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
+    have = vecenv.load_lib().rmj_device_count() if torch.cuda.device_count() > 0 else 0
+    if have < world:
+        print(f"bench.py: {world} ranks need {world} GPUs on this node, {have} visible (the product path has no CPU fallback)",
+              file=sys.stderr)
+        return 3
     dist = None
     if world > 1:
         import torch.distributed as dist
 
         torch.cuda.set_device(local_rank)
         dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs a GPU: the product path has no CPU fallback")
 
     policy_seed = 0xC0FFEE
+    sanma = args.mode >= 3
     env = vecenv.VecRiichiEnv(args.games, game_mode=args.mode, seed=0, rule_bits=abi.RULE_TENHOU, device=local_rank,
                               game_offset=shard.shard_offset(rank, args.games), event_ring=64)
     env.reset()
@@ -97,65 +186,100 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    r_enc = None
-    if args.encode:
-        # k_step duration for the roofline object: single launches over all games (a policy that needs the features is a
-        # barrier between steps, so this mode cannot keep several launches in flight); extra warm-up, outside the timed region
-        rs = [env.bench_rollout(policy_seed, 0, 1) for _ in range(20)]
-        r_enc = rs[0]
-        r_enc.step_kernel_ms = sum(x.step_kernel_ms for x in rs) / len(rs)
-        obs = torch.zeros((args.games, 4, 74, 27 if args.mode >= 3 else 34), dtype=torch.float32, device=f"cuda:{local_rank}")
-    barrier()
-    t0 = time.perf_counter()
+    obs = None
     if args.encode:
         import ctypes as C
 
+        obs = torch.zeros((args.games, 4, 74, 27 if sanma else 34), dtype=torch.float32, device=f"cuda:{local_rank}")
+    full0 = env.total_full_path()
+    barrier()
+    t0 = time.perf_counter()
+    if args.encode:
         before = env.total_steps()
         for _ in range(args.steps):   # one step launch + one encode launch per step, same stream, no host sync in between
             env.step_random(policy_seed, 1, auto_reset=True)
             vecenv._chk(env.L.rmj_encode_device(env.h, 2, C.c_void_p(obs.data_ptr())))
-        r = r_enc
-        r.env_steps = env.total_steps() - before   # synchronises the stream
-        r.launches_in_flight = 1
+        steps_local = float(env.total_steps() - before)   # synchronises the stream
+        r = None
     else:
         r = env.bench_rollout(policy_seed, 0, args.steps)   # exactly K steps of every game, HIP events on the handle's stream
+        steps_local = float(r.env_steps)
     barrier()
     t1 = time.perf_counter()
-    wall = t1 - t0
-    steps_local = float(r.env_steps)
-    wall, steps_total = shard.reduce_measurement(dist, wall, steps_local, device="cuda")
+    full_steps = env.total_full_path() - full0
+    wall, steps_total = shard.reduce_measurement(dist, t1 - t0, steps_local, device="cuda")
+
+    # ---- side measurements, outside the timed region (rank 0 of a 1-GPU run only)
+    extras = {}
+    r_enc_step = None
+    if args.encode:
+        # k_step / k_encode launch durations for the roofline objects: single launches over all games (a policy that needs
+        # the features is a barrier between steps, so this mode cannot keep several launches in flight)
+        rs = [env.bench_rollout(policy_seed, 0, 1) for _ in range(20)]
+        r_enc_step = sum(x.step_kernel_ms for x in rs) / len(rs)
+        act, _, dn = env.status()
+        acting = int(sum(bin(int(a)).count("1") for a, d in zip(act, dn) if not d))
+        enc_ms = env.bench_encode(obs.data_ptr(), 50, extended=False, only_active=2)
+        extras["encode"] = (acting, enc_ms)
+    if rank == 0 and world == 1 and not args.no_extras and not args.encode:
+        k = min(args.steps, 300)
+        env.set_rollout_streams(1)
+        r1 = env.bench_rollout(policy_seed, 0, k)
+        extras["single_stream"] = {"value": r1.env_steps / (r1.total_ms * 1e-3), "ms_per_step": r1.total_ms / k, "steps": k,
+                                   "what": "the same rollout as one launch over all games per step on one stream (what a policy "
+                                           "that is a barrier between steps gets)"}
+        rv = env.bench_rollout_validated(policy_seed, 0, k)
+        extras["validated_actions"] = {"value": rv.env_steps / (rv.total_ms * 1e-3), "ms_per_step": rv.total_ms / k, "steps": k,
+                                       "what": "one policy launch writing packed actions + one step launch that validates them "
+                                               "against the stored legal lists (state/mod.rs:339-402), one stream"}
+        env.set_rollout_streams(4)
 
     if rank == 0:
-        kernel_s = r.step_kernel_ms * 1e-3
-        b_step = B_STEP_3P if args.mode >= 3 else B_STEP_4P
-        # a device rollout runs as `in_flight` concurrent launches (halves of the batch on two streams, rmj_step_random):
-        # bytes and duration are per launch, the bandwidth the chip delivers is in_flight launches' worth
-        in_flight = max(1, int(r.launches_in_flight))
+        b_step = B_STEP_3P if sanma else B_STEP_4P
+        if args.encode:
+            in_flight, kernel_ms = 1, r_enc_step
+        else:
+            # a device rollout runs as `in_flight` concurrent launches (parts of the batch on as many streams,
+            # rmj_step_random): bytes and duration are per launch, the bandwidth the chip delivers is in_flight launches' worth
+            in_flight, kernel_ms = max(1, int(r.launches_in_flight)), r.step_kernel_ms
         games_per_launch = args.games // in_flight
-        traffic, traffic_src = pmc_traffic(games_per_launch, args.mode)
-        achieved = in_flight * b_step * games_per_launch / kernel_s
+        traffic, traffic_src = pmc_traffic("k_step", games_per_launch, args.mode)
+        achieved = in_flight * b_step * games_per_launch / (kernel_ms * 1e-3)
         out = {
-            "metric": "env.step()/s (whole node) at 65 536 parallel 4p games; bit-exact MJAI parity",
+            "metric": metric_name(args),
             "value": steps_total / wall, "unit": "env.step/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": wall * 1e3 / args.steps, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
-            "config": {"workload": f"{args.games} parallel {['4p-red-single','4p-red-east','4p-red-half','3p-red-single','3p-red-east','3p-red-half'][args.mode]} "
-                                   "games per GPU, device RandomAgent, auto-reset, MJAI logging on",
-                       "games_per_gpu": args.games, "sharding": "by game index, no collectives",
-                       "feature_tensor_output": bool(args.encode)},
+            "config": {"workload": workload_name(args), "games_per_gpu": args.games,
+                       "sharding": "by game index, no collectives", "feature_tensor_output": bool(args.encode),
+                       "parity": "bit-exact vs the oracle on identical walls; seed -> wall is the build's own shuffle (DESIGN.md §6)"},
+            # short runs (the first ~60 steps of a game cannot end a round) are not the steady state the metric is defined on
+            "steady_state": bool(args.warmup >= STEADY_MIN and args.steps >= STEADY_MIN),
+            "full_path_frac": full_steps / max(steps_local, 1.0),
             "roofline": {"bound": "hbm", "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK, "traffic": traffic, "traffic_unit": "bytes/launch",
                          "traffic_source": traffic_src, "kernel": "k_step",
-                         "kernel_ms": r.step_kernel_ms, "bytes_per_launch": b_step * games_per_launch,
+                         "kernel_ms": kernel_ms, "bytes_per_launch": b_step * games_per_launch,
                          "games_per_launch": games_per_launch, "launches_in_flight": in_flight},
         }
+        if "encode" in extras:
+            acting, enc_ms = extras.pop("encode")
+            b_obs = B_OBS_3P if sanma else B_OBS_4P
+            tr, tr_src = pmc_traffic("k_encode", args.games, args.mode)
+            out["roofline_encode"] = {"bound": "hbm", "achieved": b_obs * acting / (enc_ms * 1e-3) / 1e9, "peak": HBM_PEAK / 1e9,
+                                      "unit": "GB/s", "frac": b_obs * acting / (enc_ms * 1e-3) / HBM_PEAK, "traffic": tr,
+                                      "traffic_unit": "bytes/launch", "traffic_source": tr_src, "kernel": "k_encode",
+                                      "kernel_ms": enc_ms, "bytes_per_launch": b_obs * acting, "acting_seats": acting,
+                                      "bytes_per_observation": b_obs}
+        out.update(extras)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.mode, abi.RULE_TENHOU, policy_seed)
         print(json.dumps(out))
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+    return 0
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main())

@@ -151,7 +151,8 @@ typedef struct RmjConfig {
     uint8_t reserved0;
     uint32_t rule_bits;   /* RMJ_RULE_* */
     int32_t device;       /* HIP device ordinal */
-    uint64_t base_seed;   /* episode seed of game g = base_seed + game_offset + g unless `seeds` given */
+    uint64_t base_seed;   /* episode seed of game g = splitmix64(base_seed + game_offset + g) unless `seeds` given (consecutive
+                             seeds would make game g's k-th hand deal game g+k's first wall, state/wall.rs:38) */
     uint64_t game_offset; /* global index of this shard's first game (multi-GPU sharding by index) */
     const uint64_t* seeds;/* optional [n_games] explicit episode seeds (RiichiEnv(seed=...)) */
     uint32_t event_ring;  /* per-game MJAI event ring capacity (power of two, >= 64) */
@@ -192,6 +193,8 @@ int rmj_step_device(rmj_handle h, const rmj_action_t* d_actions);
 int rmj_step_random(rmj_handle h, uint64_t policy_seed, uint32_t n_steps, int auto_reset);
 /* Fill actions[n][4] with what the device policy would choose for the CURRENT state (no step). */
 int rmj_random_actions(rmj_handle h, uint64_t policy_seed, rmj_action_t* actions);
+/* Same into a device buffer [n][4], asynchronous on the handle's stream (feeds rmj_step_device without a host trip). */
+int rmj_random_actions_device(rmj_handle h, uint64_t policy_seed, rmj_action_t* d_actions);
 
 /* ------------------------------------------------------------------ observations */
 int rmj_get_status(rmj_handle h, uint8_t* active_mask, uint8_t* phase, uint8_t* done); /* each [n] */
@@ -203,6 +206,10 @@ int rmj_get_ranks(rmj_handle h, uint8_t* ranks /*[n][4], 1-based, ties by seat (
 int rmj_get_step_counts(rmj_handle h, uint64_t* steps /*[n]*/);
 int rmj_total_steps(rmj_handle h, uint64_t* total);
 int rmj_peek_state(rmj_handle h, uint32_t game, RmjStateView* out);
+/* The observation outputs of ONE game (get_observations of its acting seats, env.rs:741-765): legal [4][64] + counts [4],
+ * mask [4][82], waits [4], status = active_mask | phase << 8 | is_done << 16.  For sampled checks of large batches. */
+int rmj_peek_outputs(rmj_handle h, uint32_t game, rmj_action_t* legal, uint8_t* counts, uint8_t* mask, uint64_t* waits,
+                     uint32_t* status);
 int rmj_poke_state(rmj_handle h, uint32_t game, const RmjStateView* in); /* recomputes legal actions */
 
 /* MJAI events: total number emitted so far per game, and a window of records. */
@@ -356,8 +363,22 @@ typedef struct RmjBenchResult {
     uint64_t env_steps;   /* sum over games of step calls that advanced the game */
     uint32_t launches;    /* step-kernel launches in the timed region */
     uint32_t launches_in_flight; /* streams the rollout ran on (parts of the batch, rmj_step_random); 1 = one stream */
+    uint64_t full_path_steps; /* game-steps of the timed region that left the fast path of the step kernel (round ends,
+                                 yaku evaluation, kans, riichi, restarts of finished games) */
 } RmjBenchResult;
 int rmj_bench_rollout(rmj_handle h, uint64_t policy_seed, uint32_t warmup, uint32_t steps, RmjBenchResult* out);
+/* The unfused counterpart: per step one policy launch (packed actions into a device buffer) and one step launch that
+ * validates them against the stored legal lists like GameState::step does for an external agent (state/mod.rs:339-402);
+ * finished games restart; one stream, the whole batch per launch.  step_kernel_ms = policy + step launch. */
+int rmj_bench_rollout_validated(rmj_handle h, uint64_t policy_seed, uint32_t warmup, uint32_t steps, RmjBenchResult* out);
+/* Average duration (ms) of one encoder launch over `reps` back-to-back launches, HIP events on the handle's stream;
+ * extended = 0: rmj_encode_device, 1: rmj_encode_extended_device (same d_out / only_active meaning). */
+int rmj_bench_encode(rmj_handle h, int extended, int only_active, float* d_out, uint32_t reps, double* avg_ms);
+/* Parts (HIP streams) a multi-step device rollout of this handle is cut into, 1..8 (default 4, or RMJ_STEP_STREAMS in
+ * the environment when the handle is created); see rmj_step_random. */
+int rmj_set_rollout_streams(rmj_handle h, int k);
+/* Sum over games of the steps that took the full path of the step kernel since the handle was created. */
+int rmj_total_full_path(rmj_handle h, uint64_t* total);
 
 #ifdef __cplusplus
 }

@@ -1067,7 +1067,7 @@ uint64_t orc_bench_rollout(int game_mode, uint32_t rule_bits, int skip_log, uint
     auto work = [&](int tid) {
         uint64_t total = 0;
         for (uint32_t gi = tid; gi < n_games; gi += threads) {
-            GameState g((uint8_t)game_mode, skip_log != 0, base_seed + gi, 0, GameRule::from_bits(rule_bits));
+            GameState g((uint8_t)game_mode, skip_log != 0, splitmix64(base_seed + gi), 0, GameRule::from_bits(rule_bits));  // shard.game_seed
             g.env_reset(-1, nullptr, -1, nullptr, -1, -1);
             for (uint32_t s = 0; s < steps_per_game; s++) {
                 if (g.is_done) {

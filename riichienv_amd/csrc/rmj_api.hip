@@ -99,6 +99,13 @@ __global__ void k_sum_steps(const GState* core, uint32_t n, unsigned long long* 
     for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
     if ((threadIdx.x & 63) == 0 && v) atomicAdd(out, v);
 }
+__global__ void k_sum_full(const GState* core, uint32_t n, unsigned long long* out) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    unsigned long long v = 0;
+    for (; i < n; i += gridDim.x * blockDim.x) v += core[i].full_count;
+    for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
+    if ((threadIdx.x & 63) == 0 && v) atomicAdd(out, v);
+}
 __global__ void k_gather_steps(const GState* core, uint32_t n, uint64_t* out) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) out[i] = core[i].step_count;
@@ -525,6 +532,7 @@ struct rmj_env {
     float* d_decay = nullptr;  // expf(-0.2f * age), age 0..31, computed on the host (encode_extended)
     void* d_scratch = nullptr; // staging buffer of the host-copy entry points (grown on demand, never per call)
     size_t scratch_bytes = 0;
+    int want_streams = 4;      // parts a multi-step device rollout is cut into (rmj_set_rollout_streams; RMJ_STEP_STREAMS at create)
 };
 // device staging memory of at least `bytes` bytes, owned by the handle
 static int scratch_for(rmj_env* h, size_t bytes, void** out) {
@@ -549,14 +557,36 @@ static int ensure_device(int device) {
 }
 static inline dim3 game_grid(uint32_t n) { return dim3((n + WPB - 1) / WPB); }
 
-template <typename T>
-static int upload(const T* src, size_t count, T** dst) {
-    *dst = nullptr;
-    if (!src) return RMJ_OK;
-    HIPCHK(hipMalloc(dst, count * sizeof(T)));
-    HIPCHK(hipMemcpy(*dst, src, count * sizeof(T), hipMemcpyHostToDevice));
-    return RMJ_OK;
-}
+// Temporary device buffers (and timing events) of one entry point: released on EVERY return path, so that an error
+// in the middle of a call (HIPCHK returns at once) strands nothing on the device.
+struct DevTmp {
+    std::vector<void*> bufs;
+    std::vector<hipEvent_t> events;
+    ~DevTmp() {
+        for (void* q : bufs) if (q) hipFree(q);
+        for (hipEvent_t e : events) if (e) hipEventDestroy(e);
+    }
+    template <typename T>
+    hipError_t alloc(T** dst, size_t bytes) {
+        *dst = nullptr;
+        hipError_t e = hipMalloc((void**)dst, bytes);
+        if (e == hipSuccess) bufs.push_back((void*)*dst);
+        return e;
+    }
+    template <typename T>
+    int upload(const T* src, size_t count, T** dst) {  // NULL source = optional array not given
+        *dst = nullptr;
+        if (!src) return RMJ_OK;
+        HIPCHK(alloc(dst, count * sizeof(T)));
+        HIPCHK(hipMemcpy(*dst, src, count * sizeof(T), hipMemcpyHostToDevice));
+        return RMJ_OK;
+    }
+    hipError_t event(hipEvent_t* e) {
+        hipError_t r = hipEventCreate(e);
+        if (r == hipSuccess) events.push_back(*e);
+        return r;
+    }
+};
 
 static int shanten_tables_for(int device, ShantenTables* out);
 
@@ -570,20 +600,15 @@ int rmj_device_count(void) {
     return n;
 }
 
-int rmj_create(const RmjConfig* cfg, rmj_handle* out) {
-    if (!cfg || !out || cfg->n_games == 0) return fail(RMJ_ERR_ARG, "bad config");
-    if (cfg->game_mode > 5) return fail(RMJ_ERR_ARG, "game_mode must be 0..5");
-    int rc = ensure_device(cfg->device);
-    if (rc) return rc;
-    rmj_env* h = new rmj_env();
-    h->cfg = *cfg;
+// body of rmj_create; on any failure the caller destroys the partially built handle (rmj_destroy tolerates null members)
+static int create_impl(rmj_env* h, const RmjConfig* cfg, uint64_t** d_seeds_out) {
     uint32_t ring = cfg->event_ring ? cfg->event_ring : 64;
     uint32_t r2 = 64;
     while (r2 < ring) r2 <<= 1;
     h->ring = r2;
+    if (const char* e = getenv("RMJ_STEP_STREAMS")) h->want_streams = atoi(e);
     const size_t B = cfg->n_games;
     Env& d = h->d;
-    memset(&d, 0, sizeof(d));
     HIPCHK(hipStreamCreateWithFlags(&h->own_stream, hipStreamNonBlocking));
     h->stream = h->own_stream;
     HIPCHK(hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming));
@@ -603,6 +628,7 @@ int rmj_create(const RmjConfig* cfg, rmj_handle* out) {
     HIPCHK(hipMalloc(&h->d_counter, sizeof(unsigned long long)));
     HIPCHK(hipMemsetAsync(d.legal, 0, B * 4 * RMJ_MAX_LEGAL * sizeof(uint64_t), h->stream));
     HIPCHK(hipMemsetAsync(d.nlegal, 0, B * 4, h->stream));
+    HIPCHK(hipMemsetAsync(d.mask, 0, B * 4 * 82, h->stream));
     HIPCHK(hipMemsetAsync(d.events, 0, B * (size_t)r2 * sizeof(RmjEvent), h->stream));
     d.ring_mask = r2 - 1;
     d.n_games = cfg->n_games;
@@ -611,6 +637,7 @@ int rmj_create(const RmjConfig* cfg, rmj_handle* out) {
     d.skip_log = cfg->skip_mjai_logging;
     d.ctor_round_wind = cfg->round_wind;
     d.game_offset = cfg->game_offset;
+    int rc;
     if ((rc = shanten_tables_for(cfg->device, &d.sh))) return rc;
     HIPCHK(hipMalloc(&h->d_env, sizeof(Env)));
     HIPCHK(hipMemcpy(h->d_env, &d, sizeof(Env), hipMemcpyHostToDevice));
@@ -624,18 +651,35 @@ int rmj_create(const RmjConfig* cfg, rmj_handle* out) {
     memset(&A, 0, sizeof(A));
     A.is_ctor = 1;
     A.base_seed = cfg->base_seed;
-    uint64_t* d_seeds = nullptr;
     if (cfg->seeds) {
-        HIPCHK(hipMalloc(&d_seeds, B * sizeof(uint64_t)));
-        HIPCHK(hipMemcpy(d_seeds, cfg->seeds, B * sizeof(uint64_t), hipMemcpyHostToDevice));
-        A.seeds = d_seeds;
+        HIPCHK(hipMalloc(d_seeds_out, B * sizeof(uint64_t)));
+        HIPCHK(hipMemcpy(*d_seeds_out, cfg->seeds, B * sizeof(uint64_t), hipMemcpyHostToDevice));
+        A.seeds = *d_seeds_out;
     }
     if (cfg->game_mode >= 3) hipLaunchKernelGGL(rmj3::k_reset, game_grid(cfg->n_games), dim3(256), 0, h->stream, (const Env*)h->d_env, A);
     else hipLaunchKernelGGL(rmj4::k_reset, game_grid(cfg->n_games), dim3(256), 0, h->stream, (const Env*)h->d_env, A);
     HIPCHK(hipGetLastError());
     HIPCHK(hipStreamSynchronize(h->stream));
+    return RMJ_OK;
+}
+int rmj_create(const RmjConfig* cfg, rmj_handle* out) {
+    if (!cfg || !out || cfg->n_games == 0) return fail(RMJ_ERR_ARG, "bad config");
+    if (cfg->game_mode > 5) return fail(RMJ_ERR_ARG, "game_mode must be 0..5");
+    int rc = ensure_device(cfg->device);
+    if (rc) return rc;
+    rmj_env* h = new rmj_env();
+    h->cfg = *cfg;
+    memset(&h->d, 0, sizeof(h->d));
+    uint64_t* d_seeds = nullptr;
+    rc = create_impl(h, cfg, &d_seeds);
     if (d_seeds) hipFree(d_seeds);
     h->cfg.seeds = nullptr;
+    if (rc) {  // nothing allocated so far outlives a failed constructor (an OOM at 524 288 games would strand GBs)
+        const std::string keep = g_err;
+        rmj_destroy(h);
+        g_err = keep;
+        return rc;
+    }
     *out = h;
     return RMJ_OK;
 }
@@ -643,10 +687,10 @@ int rmj_create(const RmjConfig* cfg, rmj_handle* out) {
 int rmj_destroy(rmj_handle h) {
     if (!h) return RMJ_OK;
     hipSetDevice(h->cfg.device);
-    hipStreamSynchronize(h->stream);
+    if (h->stream) hipStreamSynchronize(h->stream);
     hipFree(h->d.core); hipFree(h->d.wall); hipFree(h->d.legal); hipFree(h->d.nlegal); hipFree(h->d_decay); if (h->d_scratch) hipFree(h->d_scratch); hipFree(h->d.mask);
     hipFree(h->d.waits); hipFree(h->d.status); hipFree(h->d.events); hipFree(h->d_actions); hipFree(h->d_counter); hipFree(h->d_env);
-    hipStreamDestroy(h->own_stream);
+    if (h->own_stream) hipStreamDestroy(h->own_stream);
     for (int i = 0; i < RMJ_MAX_ROLLOUT_STREAMS - 1; i++) {
         if (h->xstream[i]) { hipStreamSynchronize(h->xstream[i]); hipStreamDestroy(h->xstream[i]); }
         if (h->ev_join[i]) hipEventDestroy(h->ev_join[i]);
@@ -658,6 +702,7 @@ int rmj_destroy(rmj_handle h) {
 
 int rmj_reset(rmj_handle h, const uint8_t* select, const uint8_t* walls, const uint8_t* oya, const uint8_t* round_wind,
               const int32_t* scores, const uint8_t* honba, const uint32_t* kyotaku) {
+    DevTmp tmp;
     if (!h) return fail(RMJ_ERR_ARG, "null handle");
     HIPCHK(hipSetDevice(h->cfg.device));
     const size_t B = h->cfg.n_games;
@@ -665,13 +710,13 @@ int rmj_reset(rmj_handle h, const uint8_t* select, const uint8_t* walls, const u
     int32_t* d_sc;
     uint32_t* d_ky;
     int rc;
-    if ((rc = upload(select, B, &d_sel))) return rc;
-    if ((rc = upload(walls, B * 136, &d_walls))) return rc;
-    if ((rc = upload(oya, B, &d_oya))) return rc;
-    if ((rc = upload(round_wind, B, &d_rw))) return rc;
-    if ((rc = upload(scores, B * 4, &d_sc))) return rc;
-    if ((rc = upload(honba, B, &d_honba))) return rc;
-    if ((rc = upload(kyotaku, B, &d_ky))) return rc;
+    if ((rc = tmp.upload(select, B, &d_sel))) return rc;
+    if ((rc = tmp.upload(walls, B * 136, &d_walls))) return rc;
+    if ((rc = tmp.upload(oya, B, &d_oya))) return rc;
+    if ((rc = tmp.upload(round_wind, B, &d_rw))) return rc;
+    if ((rc = tmp.upload(scores, B * 4, &d_sc))) return rc;
+    if ((rc = tmp.upload(honba, B, &d_honba))) return rc;
+    if ((rc = tmp.upload(kyotaku, B, &d_ky))) return rc;
     ResetArgs A;
     memset(&A, 0, sizeof(A));
     A.select = d_sel; A.walls = d_walls; A.oya = d_oya; A.round_wind = d_rw; A.scores = d_sc; A.honba = d_honba; A.kyotaku = d_ky;
@@ -679,7 +724,6 @@ int rmj_reset(rmj_handle h, const uint8_t* select, const uint8_t* walls, const u
     else hipLaunchKernelGGL(rmj4::k_reset, game_grid(h->cfg.n_games), dim3(256), 0, h->stream, (const Env*)h->d_env, A);
     HIPCHK(hipGetLastError());
     HIPCHK(hipStreamSynchronize(h->stream));
-    hipFree(d_sel); hipFree(d_walls); hipFree(d_oya); hipFree(d_rw); hipFree(d_sc); hipFree(d_honba); hipFree(d_ky);
     return RMJ_OK;
 }
 
@@ -753,7 +797,7 @@ int rmj_step(rmj_handle h, const rmj_action_t* actions) {
 }
 // streams a device rollout of n_steps steps uses (RMJ_STEP_STREAMS=1 keeps everything on one stream)
 static int rollout_streams(const rmj_env* h, uint32_t n_steps) {
-    static const int want = getenv("RMJ_STEP_STREAMS") ? atoi(getenv("RMJ_STEP_STREAMS")) : 4;
+    const int want = h->want_streams;
     if (want < 2 || n_steps < 2 || h->cfg.n_games < RMJ_SPLIT_MIN_GAMES) return 1;
     int k = want > RMJ_MAX_ROLLOUT_STREAMS ? RMJ_MAX_ROLLOUT_STREAMS : want;
     const int fit = (int)(h->cfg.n_games / RMJ_SPLIT_MIN_PART);
@@ -1212,34 +1256,34 @@ int rmj_format_event(const RmjEvent* ev, uint32_t n_avail, int seat, char* buf, 
 
 // ---- batched hand math ---------------------------------------------------------------------
 int rmj_eval_hands(int device, const RmjHandCase* cases, uint32_t n, RmjHandResult* out) {
+    DevTmp tmp;
     if (!cases || !out) return fail(RMJ_ERR_ARG, "null argument");
     int rc = ensure_device(device);
     if (rc) return rc;
     if (n == 0) return RMJ_OK;
     RmjHandCase* d_in;
     RmjHandResult* d_out;
-    HIPCHK(hipMalloc(&d_in, (size_t)n * sizeof(RmjHandCase)));
-    HIPCHK(hipMalloc(&d_out, (size_t)n * sizeof(RmjHandResult)));
+    HIPCHK(tmp.alloc(&d_in, (size_t)n * sizeof(RmjHandCase)));
+    HIPCHK(tmp.alloc(&d_out, (size_t)n * sizeof(RmjHandResult)));
     HIPCHK(hipMemcpy(d_in, cases, (size_t)n * sizeof(RmjHandCase), hipMemcpyHostToDevice));
     hipLaunchKernelGGL(k_eval_hands, game_grid(n), dim3(256), 0, 0, d_in, n, d_out);
     HIPCHK(hipGetLastError());
     HIPCHK(hipDeviceSynchronize());
     HIPCHK(hipMemcpy(out, d_out, (size_t)n * sizeof(RmjHandResult), hipMemcpyDeviceToHost));
-    hipFree(d_in);
-    hipFree(d_out);
     return RMJ_OK;
 }
 int rmj_agari_counts(int device, const uint8_t* counts, uint32_t n, uint8_t* is_agari_out, uint8_t* is_tenpai, uint64_t* waits) {
+    DevTmp tmp;
     if (!counts || !is_agari_out || !is_tenpai || !waits) return fail(RMJ_ERR_ARG, "null argument");
     int rc = ensure_device(device);
     if (rc) return rc;
     if (n == 0) return RMJ_OK;
     uint8_t *d_c, *d_a, *d_t;
     uint64_t* d_w;
-    HIPCHK(hipMalloc(&d_c, (size_t)n * 34));
-    HIPCHK(hipMalloc(&d_a, n));
-    HIPCHK(hipMalloc(&d_t, n));
-    HIPCHK(hipMalloc(&d_w, (size_t)n * 8));
+    HIPCHK(tmp.alloc(&d_c, (size_t)n * 34));
+    HIPCHK(tmp.alloc(&d_a, n));
+    HIPCHK(tmp.alloc(&d_t, n));
+    HIPCHK(tmp.alloc(&d_w, (size_t)n * 8));
     HIPCHK(hipMemcpy(d_c, counts, (size_t)n * 34, hipMemcpyHostToDevice));
     hipLaunchKernelGGL(k_agari_counts, game_grid(n), dim3(256), 0, 0, d_c, n, d_a, d_t, d_w);
     HIPCHK(hipGetLastError());
@@ -1247,26 +1291,25 @@ int rmj_agari_counts(int device, const uint8_t* counts, uint32_t n, uint8_t* is_
     HIPCHK(hipMemcpy(is_agari_out, d_a, n, hipMemcpyDeviceToHost));
     HIPCHK(hipMemcpy(is_tenpai, d_t, n, hipMemcpyDeviceToHost));
     HIPCHK(hipMemcpy(waits, d_w, (size_t)n * 8, hipMemcpyDeviceToHost));
-    hipFree(d_c); hipFree(d_a); hipFree(d_t); hipFree(d_w);
     return RMJ_OK;
 }
 int rmj_calculate_score(int device, const uint8_t* han, const uint8_t* fu, const uint8_t* is_oya, const uint8_t* is_tsumo,
                         const uint32_t* honba, const uint8_t* num_players, uint32_t n, uint32_t* out) {
+    DevTmp tmp;
     if (!han || !fu || !is_oya || !is_tsumo || !honba || !num_players || !out) return fail(RMJ_ERR_ARG, "null argument");
     int rc = ensure_device(device);
     if (rc) return rc;
     if (n == 0) return RMJ_OK;
     uint8_t *d_h, *d_f, *d_o, *d_t, *d_n;
     uint32_t *d_hb, *d_out;
-    if ((rc = upload(han, n, &d_h)) || (rc = upload(fu, n, &d_f)) || (rc = upload(is_oya, n, &d_o)) || (rc = upload(is_tsumo, n, &d_t)) ||
-        (rc = upload(num_players, n, &d_n)) || (rc = upload(honba, n, &d_hb)))
+    if ((rc = tmp.upload(han, n, &d_h)) || (rc = tmp.upload(fu, n, &d_f)) || (rc = tmp.upload(is_oya, n, &d_o)) || (rc = tmp.upload(is_tsumo, n, &d_t)) ||
+        (rc = tmp.upload(num_players, n, &d_n)) || (rc = tmp.upload(honba, n, &d_hb)))
         return rc;
-    HIPCHK(hipMalloc(&d_out, (size_t)n * 16));
+    HIPCHK(tmp.alloc(&d_out, (size_t)n * 16));
     hipLaunchKernelGGL(k_score, dim3((n + 255) / 256), dim3(256), 0, 0, d_h, d_f, d_o, d_t, d_hb, d_n, n, d_out);
     HIPCHK(hipGetLastError());
     HIPCHK(hipDeviceSynchronize());
     HIPCHK(hipMemcpy(out, d_out, (size_t)n * 16, hipMemcpyDeviceToHost));
-    hipFree(d_h); hipFree(d_f); hipFree(d_o); hipFree(d_t); hipFree(d_n); hipFree(d_hb); hipFree(d_out);
     return RMJ_OK;
 }
 
@@ -1399,6 +1442,7 @@ static int shanten_tables_for(int device, ShantenTables* out) {
     return RMJ_OK;
 }
 int rmj_shanten(int device, const uint8_t* counts, uint32_t n, int sanma, int8_t* out) {
+    DevTmp tmp;
     if (!counts || !out) return fail(RMJ_ERR_ARG, "null argument");
     int rc = ensure_device(device);
     if (rc) return rc;
@@ -1407,19 +1451,18 @@ int rmj_shanten(int device, const uint8_t* counts, uint32_t n, int sanma, int8_t
     if ((rc = shanten_tables_for(device, &T))) return rc;
     uint8_t* d_c;
     int8_t* d_o;
-    HIPCHK(hipMalloc(&d_c, (size_t)n * 34));
-    HIPCHK(hipMalloc(&d_o, n));
+    HIPCHK(tmp.alloc(&d_c, (size_t)n * 34));
+    HIPCHK(tmp.alloc(&d_o, n));
     HIPCHK(hipMemcpy(d_c, counts, (size_t)n * 34, hipMemcpyHostToDevice));
     hipLaunchKernelGGL(k_shanten, dim3((n + 255) / 256), dim3(256), 0, 0, T, d_c, n, sanma, d_o);
     HIPCHK(hipGetLastError());
     HIPCHK(hipDeviceSynchronize());
     HIPCHK(hipMemcpy(out, d_o, n, hipMemcpyDeviceToHost));
-    hipFree(d_c);
-    hipFree(d_o);
     return RMJ_OK;
 }
 
 static int run_ukeire(int device, const uint8_t* counts, const uint8_t* visible, uint32_t n, int sanma, int mode, uint32_t* out) {
+    DevTmp tmp;
     if (!counts || !out || (mode == 1 && !visible)) return fail(RMJ_ERR_ARG, "null argument");
     int rc = ensure_device(device);
     if (rc) return rc;
@@ -1428,20 +1471,17 @@ static int run_ukeire(int device, const uint8_t* counts, const uint8_t* visible,
     if ((rc = shanten_tables_for(device, &T))) return rc;
     uint8_t *d_c = nullptr, *d_v = nullptr;
     uint32_t* d_o = nullptr;
-    HIPCHK(hipMalloc(&d_c, (size_t)n * 34));
-    HIPCHK(hipMalloc(&d_o, (size_t)n * 4));
+    HIPCHK(tmp.alloc(&d_c, (size_t)n * 34));
+    HIPCHK(tmp.alloc(&d_o, (size_t)n * 4));
     HIPCHK(hipMemcpy(d_c, counts, (size_t)n * 34, hipMemcpyHostToDevice));
     if (mode == 1) {
-        HIPCHK(hipMalloc(&d_v, (size_t)n * 34));
+        HIPCHK(tmp.alloc(&d_v, (size_t)n * 34));
         HIPCHK(hipMemcpy(d_v, visible, (size_t)n * 34, hipMemcpyHostToDevice));
     }
     hipLaunchKernelGGL(k_ukeire, dim3((n + 3) / 4), dim3(256), 0, 0, T, (const uint8_t*)d_c, (const uint8_t*)d_v, n, sanma, mode, d_o);
     HIPCHK(hipGetLastError());
     HIPCHK(hipDeviceSynchronize());
     HIPCHK(hipMemcpy(out, d_o, (size_t)n * 4, hipMemcpyDeviceToHost));
-    hipFree(d_c);
-    hipFree(d_o);
-    if (d_v) hipFree(d_v);
     return RMJ_OK;
 }
 int rmj_effective_tiles(int device, const uint8_t* counts, uint32_t n, int sanma, uint32_t* out) {
@@ -1470,30 +1510,125 @@ int rmj_apply_events(rmj_handle h, const RmjEvent* events) {
 
 // ---- measurement -----------------------------------------------------------------------------
 int rmj_bench_rollout(rmj_handle h, uint64_t policy_seed, uint32_t warmup, uint32_t steps, RmjBenchResult* out) {
+    DevTmp tmp;  // owns the two timing events on every return path
     if (!h || !out) return fail(RMJ_ERR_ARG, "null argument");
     HIPCHK(hipSetDevice(h->cfg.device));
     int rc = rmj_step_random(h, policy_seed, warmup, 1);
     if (rc) return rc;
-    uint64_t before = 0, after = 0;
-    if ((rc = rmj_total_steps(h, &before))) return rc;
+    uint64_t before = 0, after = 0, full0 = 0, full1 = 0;
+    if ((rc = rmj_total_steps(h, &before)) || (rc = rmj_total_full_path(h, &full0))) return rc;
     hipEvent_t e0, e1;
-    HIPCHK(hipEventCreate(&e0));
-    HIPCHK(hipEventCreate(&e1));
+    HIPCHK(tmp.event(&e0));
+    HIPCHK(tmp.event(&e1));
     HIPCHK(hipEventRecord(e0, h->stream));
     if ((rc = rmj_step_random(h, policy_seed, steps, 1))) return rc;
     HIPCHK(hipEventRecord(e1, h->stream));
     HIPCHK(hipEventSynchronize(e1));
     float ms = 0.f;
     HIPCHK(hipEventElapsedTime(&ms, e0, e1));
-    if ((rc = rmj_total_steps(h, &after))) return rc;
-    hipEventDestroy(e0);
-    hipEventDestroy(e1);
+    if ((rc = rmj_total_steps(h, &after)) || (rc = rmj_total_full_path(h, &full1))) return rc;
     out->total_ms = ms;
     const uint32_t fl = (uint32_t)rollout_streams(h, steps);
     out->launches = steps * fl;
     out->step_kernel_ms = steps ? ms / steps : 0.0;  // each stream runs `steps` launches back to back during `ms`
     out->env_steps = after - before;
     out->launches_in_flight = fl;
+    out->full_path_steps = full1 - full0;
+    return RMJ_OK;
+}
+int rmj_set_rollout_streams(rmj_handle h, int k) {
+    if (!h || k < 1 || k > RMJ_MAX_ROLLOUT_STREAMS) return fail(RMJ_ERR_ARG, "rollout streams must be 1..8");
+    h->want_streams = k;
+    return RMJ_OK;
+}
+int rmj_total_full_path(rmj_handle h, uint64_t* total) {
+    if (!h || !total) return fail(RMJ_ERR_ARG, "null argument");
+    HIPCHK(hipSetDevice(h->cfg.device));
+    HIPCHK(hipMemsetAsync(h->d_counter, 0, 8, h->stream));
+    hipLaunchKernelGGL(k_sum_full, dim3(256), dim3(256), 0, h->stream, h->d.core, h->cfg.n_games, h->d_counter);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(h->stream));
+    unsigned long long v = 0;
+    HIPCHK(hipMemcpy(&v, h->d_counter, 8, hipMemcpyDeviceToHost));
+    *total = v;
+    return RMJ_OK;
+}
+int rmj_random_actions_device(rmj_handle h, uint64_t policy_seed, rmj_action_t* d_actions) {
+    if (!h || !d_actions) return fail(RMJ_ERR_ARG, "null argument");
+    HIPCHK(hipSetDevice(h->cfg.device));
+    const uint32_t n = h->cfg.n_games;
+    hipLaunchKernelGGL(k_random_actions, dim3((n + 255) / 256), dim3(256), 0, h->stream, h->d, policy_seed, (uint64_t*)d_actions);
+    HIPCHK(hipGetLastError());
+    return RMJ_OK;
+}
+// The unfused counterpart of rmj_bench_rollout: every step is one policy launch (k_random_actions writes packed actions
+// to a device buffer) followed by one step launch that VALIDATES those actions against the stored legal lists like
+// GameState::step does for an external agent (state/mod.rs:339-402); finished games restart.  One stream, whole batch.
+int rmj_bench_rollout_validated(rmj_handle h, uint64_t policy_seed, uint32_t warmup, uint32_t steps, RmjBenchResult* out) {
+    DevTmp tmp;
+    if (!h || !out) return fail(RMJ_ERR_ARG, "null argument");
+    HIPCHK(hipSetDevice(h->cfg.device));
+    const uint32_t n = h->cfg.n_games;
+    uint64_t before = 0, after = 0, full0 = 0, full1 = 0;
+    hipEvent_t e0, e1;
+    HIPCHK(tmp.event(&e0));
+    HIPCHK(tmp.event(&e1));
+    int rc;
+    for (uint32_t s = 0; s < warmup + steps; s++) {
+        if (s == warmup) {
+            if ((rc = rmj_total_steps(h, &before)) || (rc = rmj_total_full_path(h, &full0))) return rc;
+            HIPCHK(hipEventRecord(e0, h->stream));
+        }
+        hipLaunchKernelGGL(k_random_actions, dim3((n + 255) / 256), dim3(256), 0, h->stream, h->d, policy_seed, h->d_actions);
+        launch_step_range(h, h->stream, h->d_actions, 0ull, STEP_F_AUTORESET, 0u, n);
+    }
+    HIPCHK(hipEventRecord(e1, h->stream));
+    HIPCHK(hipEventSynchronize(e1));
+    HIPCHK(hipGetLastError());
+    float ms = 0.f;
+    HIPCHK(hipEventElapsedTime(&ms, e0, e1));
+    if ((rc = rmj_total_steps(h, &after)) || (rc = rmj_total_full_path(h, &full1))) return rc;
+    out->total_ms = ms;
+    out->launches = steps;
+    out->step_kernel_ms = steps ? ms / steps : 0.0;  // policy launch + step launch
+    out->env_steps = after - before;
+    out->launches_in_flight = 1;
+    out->full_path_steps = full1 - full0;
+    return RMJ_OK;
+}
+// Average duration of one encoder launch over `reps` back-to-back launches (HIP events on the handle's stream): the
+// roofline figure of BASELINE's feature-output configuration.  d_out like rmj_encode_device / rmj_encode_extended_device.
+int rmj_bench_encode(rmj_handle h, int extended, int only_active, float* d_out, uint32_t reps, double* avg_ms) {
+    DevTmp tmp;
+    if (!h || !d_out || !avg_ms || reps == 0) return fail(RMJ_ERR_ARG, "bad argument");
+    HIPCHK(hipSetDevice(h->cfg.device));
+    hipEvent_t e0, e1;
+    HIPCHK(tmp.event(&e0));
+    HIPCHK(tmp.event(&e1));
+    int rc;
+    if ((rc = launch_encode(h, only_active, d_out, extended != 0))) return rc;  // warm-up
+    HIPCHK(hipEventRecord(e0, h->stream));
+    for (uint32_t i = 0; i < reps; i++)
+        if ((rc = launch_encode(h, only_active, d_out, extended != 0))) return rc;
+    HIPCHK(hipEventRecord(e1, h->stream));
+    HIPCHK(hipEventSynchronize(e1));
+    float ms = 0.f;
+    HIPCHK(hipEventElapsedTime(&ms, e0, e1));
+    *avg_ms = (double)ms / reps;
+    return RMJ_OK;
+}
+// Observation outputs of ONE game (sampled parity checks at batch sizes where fetching every game's lists is wasteful)
+int rmj_peek_outputs(rmj_handle h, uint32_t game, rmj_action_t* legal /*[4][64]*/, uint8_t* counts /*[4]*/, uint8_t* mask /*[4][82]*/,
+                     uint64_t* waits /*[4]*/, uint32_t* status) {
+    if (!h || !legal || !counts || !mask || !waits || !status) return fail(RMJ_ERR_ARG, "null argument");
+    if (game >= h->cfg.n_games) return fail(RMJ_ERR_RANGE, "game index out of range");
+    HIPCHK(hipSetDevice(h->cfg.device));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    HIPCHK(hipMemcpy(legal, h->d.legal + (size_t)game * 4 * RMJ_MAX_LEGAL, 4 * RMJ_MAX_LEGAL * sizeof(uint64_t), hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(counts, h->d.nlegal + (size_t)game * 4, 4, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(mask, h->d.mask + (size_t)game * 4 * 82, 4 * 82, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(waits, h->d.waits + (size_t)game * 4, 4 * sizeof(uint64_t), hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(status, h->d.status + game, 4, hipMemcpyDeviceToHost));
     return RMJ_OK;
 }
 

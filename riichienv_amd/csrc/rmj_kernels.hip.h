@@ -19,6 +19,7 @@ __device__ __noinline__ void ol_step_full(CtxV v, uint64_t mine, uint32_t flags)
     flags = uni(flags);
     GState& S = c.S;
     load_state(S, c.E.core + c.g, c.lane);
+    S.full_count += 1;
     if (S.is_done && (flags & STEP_F_AUTORESET)) ol_env_reset_default(v);
     else step_game<false>(c, mine, (flags & STEP_F_RANDOM) != 0);
     finalize_outputs<false>(c, true);
@@ -135,7 +136,7 @@ __global__ __launch_bounds__(256, 4) void k_reset(const Env* __restrict__ Ep, Re
     const int32_t st0 = KSANMA ? 35000 : 25000;
     int32_t sc[4] = {st0, st0, st0, st0};
     if (A.is_ctor) {  // GameState::new, state/mod.rs:98-167
-        S.wall_seed = A.seeds ? A.seeds[g] : A.base_seed + E.game_offset + g;
+        S.wall_seed = A.seeds ? A.seeds[g] : sm64(A.base_seed + E.game_offset + g);  // shard.game_seed: decorrelated default seeds
         S.hand_index = 0;
         S.last_error_pid = 0xFF;
         S.pending_kan_pid = 0xFF;

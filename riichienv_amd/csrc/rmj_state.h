@@ -83,7 +83,9 @@ struct alignas(16) GState {  // 4*128 + 128 = 640 bytes
     // resurface, in front of a chankan / kita Ron offer, if the caller kans or declares kita before discarding).
     uint8_t stale_n[4];
     uint8_t nlegal[4];        // copy of the nlegal slab row: the policy / validation need it as soon as the record arrives
-    uint8_t pad[128 - 8 - 8 - 20 - 16 - 4 - 6 - 3 - 4 - 4];
+    uint8_t pad0_[3];
+    uint32_t full_count;      // measurement only: steps of this game that took the full path of k_step (bench.py)
+    uint8_t pad[128 - 8 - 8 - 20 - 16 - 4 - 6 - 3 - 4 - 4 - 3 - 4];
 };
 
 #ifdef __cplusplus

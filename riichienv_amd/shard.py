@@ -18,9 +18,22 @@ def shard_offset(rank: int, games_per_rank: int) -> int:
     return rank * games_per_rank
 
 
+def splitmix64(x: int) -> int:
+    """state/wall.rs:83-88."""
+    z = (int(x) + 0x9E3779B97F4A7C15) & MASK64
+    z = ((z ^ (z >> 30)) * 0xBF58476D1CE4E5B9) & MASK64
+    z = ((z ^ (z >> 27)) * 0x94D049BB133111EB) & MASK64
+    return z ^ (z >> 31)
+
+
 def game_seed(base_seed: int, global_game: int) -> int:
-    """Seed of global game g when no per-game seed array is given (rmj_create: base_seed + game_offset + local)."""
-    return (int(base_seed) + int(global_game)) & MASK64
+    """Episode seed of global game g when no per-game seed array is given (rmj_create): splitmix64(base_seed + g).
+
+    The reference keys the wall of a game's k-th hand by splitmix64(seed + k) (state/wall.rs:38): with CONSECUTIVE
+    episode seeds game g's k-th hand would deal the wall of game g+k's first hand, so the default seeds of a batch are
+    decorrelated first (the reference's own default is OS entropy per env, env.rs:107-110).  Explicit per-game seeds
+    (`seeds=`) are used as given, like RiichiEnv(seed=...)."""
+    return splitmix64((int(base_seed) + int(global_game)) & MASK64)
 
 
 def owner_of(global_game: int, games_per_rank: int) -> tuple[int, int]:

@@ -28,6 +28,8 @@ EXPORTS = [
     "rmj_poke_state", "rmj_get_event_counts", "rmj_get_events", "rmj_format_event", "rmj_eval_hands",
     "rmj_agari_counts", "rmj_calculate_score", "rmj_shanten", "rmj_effective_tiles", "rmj_best_ukeire", "rmj_apply_events", "rmj_device_views", "rmj_step_ids_device",
     "rmj_scores_device", "rmj_sync", "rmj_set_stream", "rmj_encode", "rmj_encode_device", "rmj_encode_extended", "rmj_encode_extended_device", "rmj_encode_aux", "rmj_encode_aux_device", "rmj_encode_seq", "rmj_encode_seq_device", "rmj_bench_rollout",
+    "rmj_bench_rollout_validated", "rmj_bench_encode", "rmj_set_rollout_streams", "rmj_total_full_path",
+    "rmj_random_actions_device", "rmj_peek_outputs",
 ]
 
 
@@ -109,6 +111,12 @@ def load_lib():
     L.rmj_apply_events.argtypes = [vp, vp]
     L.rmj_shanten.argtypes = [C.c_int, vp, C.c_uint32, C.c_int, vp]
     L.rmj_bench_rollout.argtypes = [vp, C.c_uint64, C.c_uint32, C.c_uint32, C.POINTER(abi.BenchResult)]
+    L.rmj_bench_rollout_validated.argtypes = [vp, C.c_uint64, C.c_uint32, C.c_uint32, C.POINTER(abi.BenchResult)]
+    L.rmj_bench_encode.argtypes = [vp, C.c_int, C.c_int, vp, C.c_uint32, C.POINTER(C.c_double)]
+    L.rmj_set_rollout_streams.argtypes = [vp, C.c_int]
+    L.rmj_total_full_path.argtypes = [vp, C.POINTER(C.c_uint64)]
+    L.rmj_random_actions_device.argtypes = [vp, C.c_uint64, vp]
+    L.rmj_peek_outputs.argtypes = [vp, C.c_uint32, vp, vp, vp, vp, C.POINTER(C.c_uint32)]
     _LIB = L
     return L
 
@@ -355,6 +363,37 @@ class VecRiichiEnv:
         r = abi.BenchResult()
         _chk(self.L.rmj_bench_rollout(self.h, policy_seed, warmup, steps, C.byref(r)))
         return r
+
+    def bench_rollout_validated(self, policy_seed, warmup, steps) -> abi.BenchResult:
+        """One policy launch + one validating step launch per step (header: rmj_bench_rollout_validated)."""
+        r = abi.BenchResult()
+        _chk(self.L.rmj_bench_rollout_validated(self.h, policy_seed, warmup, steps, C.byref(r)))
+        return r
+
+    def bench_encode(self, d_out_ptr, reps, extended=False, only_active=2) -> float:
+        """Average ms of one encoder launch into the device buffer at `d_out_ptr` (header: rmj_bench_encode)."""
+        ms = C.c_double()
+        _chk(self.L.rmj_bench_encode(self.h, int(extended), int(only_active), C.c_void_p(d_out_ptr), reps, C.byref(ms)))
+        return ms.value
+
+    def set_rollout_streams(self, k):
+        _chk(self.L.rmj_set_rollout_streams(self.h, int(k)))
+
+    def total_full_path(self):
+        t = C.c_uint64()
+        _chk(self.L.rmj_total_full_path(self.h, C.byref(t)))
+        return t.value
+
+    def peek_outputs(self, g):
+        """(legal [4][64] u64, counts [4], mask [4][82], waits [4], active_mask, phase, done) of one game."""
+        legal = np.zeros((4, abi.MAX_LEGAL), np.uint64)
+        cnt = np.zeros(4, np.uint8)
+        mask = np.zeros((4, 82), np.uint8)
+        waits = np.zeros(4, np.uint64)
+        st = C.c_uint32()
+        _chk(self.L.rmj_peek_outputs(self.h, int(g), legal.ctypes.data, cnt.ctypes.data, mask.ctypes.data, waits.ctypes.data,
+                                     C.byref(st)))
+        return legal, cnt, mask, waits, st.value & 0xFF, (st.value >> 8) & 0xFF, (st.value >> 16) & 0xFF
 
 
 # ---- batched hand math (kernel gate) -----------------------------------------------------

@@ -2,6 +2,7 @@
 """Parity soak (not part of the test suite): long device-policy rollouts of every game mode under both rule sets and
 several seeds, compared with the oracle game by game - final state, legal lists, masks, waits, step counts and the whole
 MJAI log of every game.  usage: python scripts/soak_parity.py [games] [steps] [seeds]"""
+from riichienv_amd.shard import game_seed
 import os
 import sys
 import time
@@ -22,7 +23,7 @@ for mode in range(6):
         for k in range(seeds):
             seed, pseed = 7000 + 131 * k + mode, 0xA5A5 + 977 * k
             env = vecenv.VecRiichiEnv(n, game_mode=mode, seed=seed, rule_bits=rule, event_ring=8192)
-            games = [oracle.Game(game_mode=mode, seed=seed + g, rule_bits=rule) for g in range(n)]
+            games = [oracle.Game(game_mode=mode, seed=game_seed(seed, g), rule_bits=rule) for g in range(n)]
             env.reset()
             for o in games:
                 o.reset()

@@ -1,5 +1,6 @@
 """GPU parity of the auxiliary encoders (rmj_encode_aux: kawa overview / yaku possibility / furiten-ron possibility)
 against the oracle: the hand-built cases of tests/aux_cases.py and every game of random rollouts, 4P and 3P."""
+from riichienv_amd.shard import game_seed
 import numpy as np
 import pytest
 
@@ -32,7 +33,7 @@ def test_aux_encoders_along_rollout(mode):
 
     n, seed, pseed = 24, 777, 3
     env = vecenv.VecRiichiEnv(n, game_mode=mode, seed=seed)
-    games = [oracle.Game(game_mode=mode, seed=seed + g) for g in range(n)]
+    games = [oracle.Game(game_mode=mode, seed=game_seed(seed, g)) for g in range(n)]
     env.reset()
     for o in games:
         o.reset()

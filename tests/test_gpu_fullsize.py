@@ -1,0 +1,168 @@
+"""Parity at the batch sizes BASELINE.json names (configs[1..4]): the batch runs through rmj_step_random exactly like
+bench.py drives it (device policy, auto-reset, the default split into four range launches on four HIP streams), then
+~256 sampled games - game 0, both sides of every part boundary, the last game, and a seeded random rest - are compared
+with the oracle driven by the same policy key: full state, ordered legal lists, masks, waits, status, step counts and
+the tail of the MJAI log that the event ring still holds (and, for the sanma feature configuration, the 74 x 27 tensors
+that rmj_encode_device wrote).  Games are independent (state/mod.rs:330-1315 touches one GameState), so the oracle only
+has to replay the sampled ones."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from riichienv_amd import abi
+from riichienv_amd.shard import game_seed
+from tests.parity_util import diff_dict, fmt_action, normalize_view
+
+pytestmark = pytest.mark.gpu
+
+SEED, PSEED = 20261002, 0xC0FFEE
+
+
+def sample_games(n, k=256, parts=4):
+    idx = {0, 1, n - 2, n - 1}
+    for i in range(1, parts):
+        b = n * i // parts
+        idx |= {b - 1, b, b + 1}
+    for i in range(1, 8):       # boundaries of an eight-way split as well (rollouts of other stream counts, 8-GPU shards)
+        b = n * i // 8
+        idx |= {b - 1, b}
+    rng = np.random.default_rng(n)
+    idx |= set(int(x) for x in rng.integers(0, n, size=k))
+    return sorted(i for i in idx if 0 <= i < n)[: k + 40]
+
+
+def oracle_replay(mode, rule, g_global, steps):
+    from oracle import oracle
+
+    o = oracle.Game(game_mode=mode, seed=game_seed(SEED, g_global), rule_bits=rule)
+    o.reset()
+    for _ in range(steps):
+        if o.status()[2]:
+            o.reset()
+            continue
+        o.step(o.random_actions(PSEED, g_global))
+    return o
+
+
+def device_log_tail(env, g, ring):
+    """Formatted MJAI strings of the events of game g that are still in the ring (a start_kyoku whose first record has
+    been overwritten is dropped together with its continuation records)."""
+    total = int(env.event_counts()[g])
+    first = max(0, total - ring)
+    buf, n = env.events(g, first)
+    i = 0
+    while i < n and buf[i].type == abi.EV_TEHAI:
+        i += 1
+    out = []
+    s = C.create_string_buffer(2048)
+    while i < n:
+        used = env.L.rmj_format_event(C.cast(C.byref(buf, i * C.sizeof(abi.Event)), C.POINTER(abi.Event)), n - i, -1, s, 2048)
+        assert used > 0, (g, i, buf[i].type)
+        out.append(s.value.decode())
+        i += used
+    return out
+
+
+def compare_game(env, g, o, ring, tag):
+    legal, cnt, mask, waits, act, ph, dn = env.peek_outputs(g)
+    oa, op, od = o.status()
+    assert (act, ph, dn) == (oa, op, od), (tag, g, "status", (act, ph, dn), (oa, op, od))
+    d = diff_dict(normalize_view(env.peek(g)), normalize_view(o.peek()))
+    assert not d, (tag, g, d[:10])
+    for s in range(4):
+        if (oa >> s) & 1 and not od:
+            ol = o.legal(s)
+            gl = [int(x) for x in legal[s, : cnt[s]]]
+            assert gl == ol, (tag, g, s, [fmt_action(a) for a in gl], [fmt_action(a) for a in ol])
+            assert (mask[s] == o.mask(s)).all(), (tag, g, s, "mask")
+            assert int(waits[s]) == o.waits(s), (tag, g, s, "waits")
+        else:
+            assert cnt[s] == 0 and mask[s].sum() == 0, (tag, g, s, "inactive seat has outputs")
+    tail = device_log_tail(env, g, ring)
+    olog = o.log()
+    assert len(tail) >= min(len(olog), ring // 3 - 2), (tag, g, len(tail), len(olog))
+    assert tail == olog[len(olog) - len(tail):], (tag, g, "mjai log tail")
+
+
+def run_config(mode, rule, n, steps, offset=0, ring=256):
+    from riichienv_amd import vecenv
+
+    env = vecenv.VecRiichiEnv(n, game_mode=mode, seed=SEED, rule_bits=rule, game_offset=offset, event_ring=ring)
+    env.reset()
+    env.step_random(PSEED, steps, auto_reset=True)   # >= 16 384 games: four range launches per step on four streams
+    counts = env.step_counts()
+    sample = sample_games(n)
+    total = 0
+    for g in sample:
+        o = oracle_replay(mode, rule, offset + g, steps)
+        compare_game(env, g, o, ring, (mode, n, offset))
+        assert int(counts[g]) == o.step_count, (g, int(counts[g]), o.step_count)
+        total += o.step_count
+    assert total > 0
+    return env, sample
+
+
+def test_4096_games_4p_red_single():
+    """configs[1]: 4 096 parallel 4p-red-single games (one launch per step: below the split threshold); single-kyoku
+    games end after ~100 steps, so every sampled game has been restarted several times."""
+    env, sample = run_config(0, abi.RULE_TENHOU, 4096, 700)
+    assert env.bench_rollout(PSEED, 0, 4).launches_in_flight == 1
+
+
+@pytest.mark.parametrize("offset", [0, 7 * 65536])
+def test_65536_games_4p_red_half(offset):
+    """configs[2] (the headline workload), and the last of the eight shards of configs[3] (global games 458 752 ...)."""
+    env, sample = run_config(2, abi.RULE_TENHOU, 65536, 700, offset=offset)
+    assert env.bench_rollout(PSEED, 0, 4).launches_in_flight == 4
+
+
+def test_65536_games_4p_mjsoul_rules_single_stream_equals_split():
+    """The same batch stepped on ONE stream must end in the same sampled states as the four-stream split (different rule
+    set for breadth: Mahjong Soul yakuman / pao options)."""
+    from riichienv_amd import vecenv
+
+    n, steps = 65536, 400
+    env = vecenv.VecRiichiEnv(n, game_mode=1, seed=SEED, rule_bits=abi.RULE_MJSOUL, event_ring=256)
+    env.set_rollout_streams(1)
+    env.reset()
+    env.step_random(PSEED, steps, auto_reset=True)
+    for g in sample_games(n, k=96):
+        compare_game(env, g, oracle_replay(1, abi.RULE_MJSOUL, g, steps), 256, "1-stream")
+
+
+def test_524288_games_4p_red_half():
+    """configs[3] as ONE shard on one GPU: 524 288 games, four range launches of 131 072 games per step."""
+    run_config(2, abi.RULE_TENHOU, 524288, 600, ring=64)
+
+
+def test_65536_games_3p_with_feature_tensor():
+    """configs[4]: 65 536 sanma games, every step followed by rmj_encode_device(only_active=2) into a resident
+    [B, 4, 74, 27] tensor (bench.py --mode 5 --encode); the acting seats' rows of the sampled games must be the oracle's
+    Observation.encode() of the final state, byte for byte."""
+    import torch
+
+    from riichienv_amd import vecenv
+
+    n, steps, ring, mode = 65536, 500, 256, 5
+    env = vecenv.VecRiichiEnv(n, game_mode=mode, seed=SEED, event_ring=ring)
+    env.reset()
+    obs = torch.zeros((n, 4, 74, 27), dtype=torch.float32, device="cuda:0")
+    env.step_random(PSEED, steps - 50, auto_reset=True)           # split rollout
+    for _ in range(50):                                            # then the bench's step + encode cadence
+        env.step_random(PSEED, 1, auto_reset=True)
+        vecenv._chk(env.L.rmj_encode_device(env.h, 2, C.c_void_p(obs.data_ptr())))
+    env.L.rmj_sync(env.h)
+    sample = sample_games(n)
+    rows = obs[torch.tensor(sample, device="cuda:0")].cpu().numpy()
+    checked = 0
+    for k, g in enumerate(sample):
+        o = oracle_replay(mode, abi.RULE_TENHOU, g, steps)
+        compare_game(env, g, o, ring, "3p+encode")
+        oa, _, od = o.status()
+        for s in range(3):
+            if (oa >> s) & 1 and not od:
+                ref = o.encode(s, True)
+                assert rows[k, s].tobytes() == ref.tobytes(), (g, s, np.argwhere(rows[k, s] != ref)[:5])
+                checked += 1
+    assert checked >= len(sample) // 2

@@ -1,5 +1,6 @@
 """GPU parity of the sequence features (rmj_encode_seq) against the Python restatement of observation/sequence_features.rs
 (oracle/seq_features.py) fed with the oracle game's state and its seat log of the current round."""
+from riichienv_amd.shard import game_seed
 import numpy as np
 import pytest
 
@@ -42,7 +43,7 @@ def test_seq_features_along_rollout(mode, seed):
 
     n, pseed = 12, 5
     env = vecenv.VecRiichiEnv(n, game_mode=mode, seed=seed, event_ring=1024)
-    games = [oracle.Game(game_mode=mode, seed=seed + g) for g in range(n)]
+    games = [oracle.Game(game_mode=mode, seed=game_seed(seed, g)) for g in range(n)]
     env.reset()
     for o in games:
         o.reset()

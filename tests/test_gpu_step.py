@@ -1,5 +1,6 @@
 """GPU parity (the hot path): VecRiichiEnv through the C-ABI vs the oracle, game by game and
 step by step — full state, ordered legal lists, masks, waits, MJAI event strings, scores."""
+from riichienv_amd.shard import game_seed
 import numpy as np
 import pytest
 
@@ -44,7 +45,7 @@ def test_random_rollout_parity(mode, rule):
 
     n, seed, pseed = 48, 1000, 77
     env = vecenv.VecRiichiEnv(n, game_mode=mode, seed=seed, rule_bits=rule, event_ring=8192)
-    games = [oracle.Game(game_mode=mode, seed=seed + g, rule_bits=rule) for g in range(n)]
+    games = [oracle.Game(game_mode=mode, seed=game_seed(seed, g), rule_bits=rule) for g in range(n)]
     _compare(env, games, range(n), -1)  # constructor state (shuffle #0)
     env.reset()
     for o in games:
@@ -79,7 +80,7 @@ def test_step_random_device_policy_matches_oracle():
 
     n, seed, pseed, steps = 32, 5, 4242, 1500
     env = vecenv.VecRiichiEnv(n, game_mode=0, seed=seed, event_ring=64)
-    games = [oracle.Game(game_mode=0, seed=seed + g) for g in range(n)]
+    games = [oracle.Game(game_mode=0, seed=game_seed(seed, g)) for g in range(n)]
     env.reset()
     for o in games:
         o.reset()
@@ -104,7 +105,7 @@ def test_device_policy_long_rollout(mode, rule):
 
     n, seed, pseed, steps = 96, 900 + mode, 0xBEEF, 4000
     env = vecenv.VecRiichiEnv(n, game_mode=mode, seed=seed, rule_bits=rule, event_ring=4096)
-    games = [oracle.Game(game_mode=mode, seed=seed + g, rule_bits=rule) for g in range(n)]
+    games = [oracle.Game(game_mode=mode, seed=game_seed(seed, g), rule_bits=rule) for g in range(n)]
     env.reset()
     for o in games:
         o.reset()
@@ -130,7 +131,7 @@ def test_encode_parity_along_rollout(mode):
     n, seed, pseed = 24, 321, 5
     sanma = mode >= 3
     env = vecenv.VecRiichiEnv(n, game_mode=mode, seed=seed)
-    games = [oracle.Game(game_mode=mode, seed=seed + g) for g in range(n)]
+    games = [oracle.Game(game_mode=mode, seed=game_seed(seed, g)) for g in range(n)]
     env.reset()
     for o in games:
         o.reset()
@@ -163,7 +164,7 @@ def test_encode_extended_parity_along_rollout(mode):
     n, seed, pseed = 8, 4321, 9
     sanma = mode >= 3
     env = vecenv.VecRiichiEnv(n, game_mode=mode, seed=seed)
-    games = [oracle.Game(game_mode=mode, seed=seed + g) for g in range(n)]
+    games = [oracle.Game(game_mode=mode, seed=game_seed(seed, g)) for g in range(n)]
     env.reset()
     for o in games:
         o.reset()
@@ -190,7 +191,7 @@ def test_sanma_random_rollout_parity(mode, rule):
 
     n, seed, pseed = 48, 4000, 13
     env = vecenv.VecRiichiEnv(n, game_mode=mode, seed=seed, rule_bits=rule, event_ring=8192)
-    games = [oracle.Game(game_mode=mode, seed=seed + g, rule_bits=rule) for g in range(n)]
+    games = [oracle.Game(game_mode=mode, seed=game_seed(seed, g), rule_bits=rule) for g in range(n)]
     _compare(env, games, range(n), -1)
     env.reset()
     for o in games:

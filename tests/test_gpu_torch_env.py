@@ -1,5 +1,6 @@
 """Row N4: the trainer-side loop (torch tensors on the GPU, zero-copy masks, id-based stepping) against the oracle
 driven with the same action ids through find_action semantics."""
+from riichienv_amd.shard import game_seed
 import numpy as np
 import pytest
 
@@ -17,7 +18,7 @@ def test_torch_env_matches_oracle(mode, shared):
     n, seed = 48, 700 + mode
     sanma = mode >= 3
     env = TorchVecEnv(n, game_mode=mode, seed=seed, extended=False, skip_mjai_logging=False, share_stream=shared)
-    games = [oracle.Game(game_mode=mode, seed=seed + g) for g in range(n)]
+    games = [oracle.Game(game_mode=mode, seed=game_seed(seed, g)) for g in range(n)]
     for o in games:
         o.reset()
     gen = torch.Generator(device=env.device)

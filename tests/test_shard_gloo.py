@@ -87,7 +87,11 @@ def test_two_rank_shards_equal_one_rank(mode):
 
 def test_shard_helpers():
     assert shard.shard_offset(0, 65536) == 0 and shard.shard_offset(7, 65536) == 7 * 65536
-    assert shard.game_seed(2**64 - 1, 2) == 1
+    assert shard.game_seed(2**64 - 1, 2) == shard.splitmix64(1)          # wraps like the device's uint64 sum
+    assert shard.splitmix64(0) == 0xE220A8397B1DCDAF                      # splitmix64 known answer (first output of seed 0)
+    # decorrelated default seeds: no two (game, hand) pairs of a batch share a wall key seed + hand_index
+    keys = {(shard.game_seed(77, g) + k) & shard.MASK64 for g in range(4096) for k in range(32)}
+    assert len(keys) == 4096 * 32
     assert shard.owner_of(65536 * 3 + 5, 65536) == (3, 5)
     with pytest.raises(ValueError):
         shard.shard_offset(-1, 4)

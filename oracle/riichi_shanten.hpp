@@ -11,6 +11,7 @@
 #include <algorithm>
 #include <cstring>
 #include <map>
+#include <unordered_map>
 #include <vector>
 
 namespace orc {
@@ -76,10 +77,22 @@ inline SuitCost suit_cost_enum(const uint8_t* cnt, int n /*9 or 7*/, bool sequen
     return out;
 }
 
+// The enumeration of one suit vector is memoised per thread (the ukeire walks and the golden-vector tests evaluate
+// hundreds of hands that differ in one suit): same numbers, computed once per distinct vector.
+inline const SuitCost& suit_cost_memo(const uint8_t* cnt, int n, bool sequences) {
+    thread_local std::unordered_map<uint32_t, SuitCost> memo;
+    uint32_t key = sequences ? 0u : 1u << 31;
+    for (int i = 0; i < n; i++) key |= (uint32_t)(cnt[i] & 7u) << (3 * i);
+    auto it = memo.find(key);
+    if (it != memo.end()) return it->second;
+    if (memo.size() > 400000) memo.clear();
+    return memo.emplace(key, suit_cost_enum(cnt, n, sequences)).first->second;
+}
+
 inline int calc_normal_enum(const uint8_t* tiles34, int m) {
     SuitCost s[4];
-    for (int q = 0; q < 3; q++) s[q] = suit_cost_enum(tiles34 + 9 * q, 9, true);
-    s[3] = suit_cost_enum(tiles34 + 27, 7, false);
+    for (int q = 0; q < 3; q++) s[q] = suit_cost_memo(tiles34 + 9 * q, 9, true);
+    s[3] = suit_cost_memo(tiles34 + 27, 7, false);
     if (m > 4) m = 4;
     int best = 99;
     for (int k0 = 0; k0 <= m; k0++)

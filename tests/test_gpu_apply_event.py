@@ -1,5 +1,6 @@
 """Row N1 on the GPU: rmj_apply_events against the oracle's apply_mjai_event.  Event streams = the reference-test flows
 and whole MJAI logs of finished random rollouts (each game is fed its own log, one event per launch)."""
+from riichienv_amd.shard import game_seed
 import json
 
 import numpy as np
@@ -47,7 +48,7 @@ def _run_streams(mode, streams):
 
     n = len(streams)
     env = vecenv.VecRiichiEnv(n, game_mode=mode, seed=1)
-    games = [oracle.Game(game_mode=mode, seed=1 + g) for g in range(n)]
+    games = [oracle.Game(game_mode=mode, seed=game_seed(1, g)) for g in range(n)]
     env.reset()
     for o in games:
         o.reset()

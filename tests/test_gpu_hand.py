@@ -92,6 +92,38 @@ def test_agari_counts_random(golden_dir, size):
     assert (w == ow).all()
 
 
+def _million_hands(seed, n, size):
+    """n hands of `size` tiles, vectorised: the `size` smallest of 136 random keys; two thirds of the hands draw from one
+    suit + honors or from two suits only, so that tenpai and complete shapes are frequent."""
+    rng = np.random.default_rng(seed)
+    keys = rng.random((n, 136), dtype=np.float32)
+    style = rng.integers(0, 3, size=n)
+    suit = rng.integers(0, 3, size=n)
+    tile_suit = np.minimum(np.arange(136) // 36, 3)
+    drop1 = (style == 1)[:, None] & (tile_suit[None, :] != suit[:, None]) & (tile_suit[None, :] != 3)   # one suit + honors
+    drop2 = (style == 2)[:, None] & ((tile_suit[None, :] == suit[:, None]) | (tile_suit[None, :] == 3))  # the two other suits
+    keys[drop1 | drop2] = 2.0
+    idx = np.argpartition(keys, size, axis=1)[:, :size] // 4
+    return (idx[:, :, None] == np.arange(34, dtype=idx.dtype)[None, None, :]).sum(axis=1).astype(np.uint8)
+
+
+def test_agari_counts_million_hands():
+    """is_agari / is_tenpai / waits of 10^6 random hands (13 and 14 tiles), bit-exact vs the oracle."""
+    from oracle import oracle
+    from riichienv_amd import vecenv
+
+    seen_tenpai = seen_agari = 0
+    for chunk in range(10):
+        counts = _million_hands(1000 + chunk, 100000, 13 + (chunk & 1))
+        assert counts.max() <= 4 and (counts.sum(axis=1) == 13 + (chunk & 1)).all()
+        ag, tp, w = vecenv.agari_counts(counts)
+        oag, otp, ow = oracle.agari_counts(counts)
+        assert (ag == oag).all() and (tp == otp).all() and (w == ow).all(), chunk
+        seen_tenpai += int(otp.sum())
+        seen_agari += int(oag.sum())
+    assert seen_tenpai > 2000 and seen_agari > 100, (seen_tenpai, seen_agari)
+
+
 def test_score_table():
     from oracle import oracle
     from riichienv_amd import vecenv
@@ -179,3 +211,26 @@ def test_hand_kats_from_reference_unit_tests_gpu():
         check(name, r, want)
         assert (r.is_win, r.han, r.fu, list(r.yaku[: r.n_yaku]), r.ron_agari, r.tsumo_agari_oya, r.tsumo_agari_ko) == \
                (o.is_win, o.han, o.fu, list(o.yaku[: o.n_yaku]), o.ron_agari, o.tsumo_agari_oya, o.tsumo_agari_ko), name
+
+
+def test_shanten_and_ukeire_equal_the_reference_tables():
+    """rmj_shanten / rmj_effective_tiles / rmj_best_ukeire against the answers of the REFERENCE's nyanten lookup
+    (tests/golden/shanten_vectors.json, scripts/gen_shanten_vectors.py): 10^5 sampled hands per variant, every len/3 class."""
+    from tests.shanten_sampler import sample_hand, sample_hands, sample_visible
+    from tests.test_oracle_shanten_golden import GOLD, expected_shanten
+
+    for tag, sanma in (("4p", False), ("3p", True)):
+        hands = sample_hands(GOLD["seed"], GOLD["n_shanten"], sanma)
+        got = vecenv.shanten(hands, sanma=sanma)
+        exp = expected_shanten(tag)
+        bad = np.nonzero(got != exp)[0]
+        assert bad.size == 0, (tag, bad[:5], hands[bad[:1]], got[bad[:5]], exp[bad[:5]])
+        n = GOLD["n_ukeire"]
+        hands = np.array([sample_hand(GOLD["seed"] + 1, i, sanma) for i in range(n)], dtype=np.uint8)
+        vis = np.array([sample_visible(GOLD["seed"] + 1, i, hands[i]) for i in range(n)], dtype=np.uint8)
+        eff_exp = np.array(GOLD[f"effective_tiles_{tag}"])
+        uke_exp = np.array(GOLD[f"best_ukeire_{tag}"])
+        k = eff_exp >= 0
+        assert (vecenv.effective_tiles(hands[k], sanma=sanma) == eff_exp[k]).all(), tag
+        k = uke_exp >= 0
+        assert (vecenv.best_ukeire(hands[k], vis[k], sanma=sanma) == uke_exp[k]).all(), tag

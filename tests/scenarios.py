@@ -1115,5 +1115,305 @@ def sc3_ron_deltas(make):
     assert len(d) == 3 and d[1] > 0 and d[0] < 0 and d[2] == 0 and sum(d) == 0
 
 
+def _poke3(env, fn):
+    v = env.peek()
+    fn(v)
+    env.poke(v)
+    return env.peek()
+
+
+def _set_hand(pl, hand):
+    pl.hand_len = len(hand)
+    for i, t in enumerate(hand):
+        pl.hand[i] = t
+
+
+def _kita_state(make, seat, hand13, north, riichi=False):
+    """The fixture of the kita-interaction tests (tests.rs:2024-2340): a fresh 3p-red-half round, the wall replaced by
+    1p..5p (ids 36..55, rinshan draw = 36) with drawable_count = len - 14, `seat` to act holding `hand13` + the North tile
+    it has just drawn."""
+    env = make(game_mode=5)
+    env.reset()
+
+    def mut(v):
+        v.wall_len = 20
+        for i, t in enumerate(range(36, 56)):
+            v.wall[i] = t
+        v.drawable_count = 6
+        pl = v.players[seat]
+        _set_hand(pl, list(hand13) + ([north] if north is not None else []))
+        if seat != 0:  # the dealer's first draw goes back: every seat holds what the reference test gives it
+            _set_hand(v.players[0], list(v.players[0].hand[: 13]))
+        if riichi:
+            pl.riichi_declared = 1
+            pl.riichi_declaration_index = 0
+            pl.n_discards = 1
+            pl.discards[0] = 131
+            pl.discard_from_hand_bits = 1
+            pl.discard_is_riichi_bits = 1
+        v.drawn_tile = north if north is not None else -1
+        v.current_player = seat
+        v.phase = WAIT_ACT
+        v.active_mask = 1 << seat
+        v.needs_tsumo = 0
+
+    _poke3(env, mut)
+    return env
+
+
+def _redraw(env, seat, tile):
+    """`hand.push(tile); drawn_tile = Some(tile); current_player = seat; WaitAct` of the reference tests."""
+    def mut(v):
+        pl = v.players[seat]
+        h = list(pl.hand[: pl.hand_len]) + [tile]
+        _set_hand(pl, h)
+        v.drawn_tile = tile
+        v.current_player = seat
+        v.phase = WAIT_ACT
+        v.active_mask = 1 << seat
+        v.needs_tsumo = 0
+        for q in range(3):   # nobody else is in the middle of a turn
+            if q != seat and v.players[q].hand_len + 3 * v.players[q].n_melds == 14:
+                v.players[q].hand_len -= 1
+
+    return _poke3(env, mut)
+
+
+def sc3_kita_tile_none_removes_north(make):
+    """tests.rs:2024-2080 (issue #179): a Kita action WITHOUT a tile removes the North tile from the hand (not tile 0),
+    files it under kita_tiles, and the rinshan draw restores the hand size."""
+    env = _kita_state(make, 0, [36, 40, 44, 48, 52, 56, 60, 64, 68, 72, 76, 80], 120)
+    before = env.peek()
+    assert any(t // 4 == 30 for t in before.players[0].hand[: before.players[0].hand_len])
+    assert find(env.legal(0), KITA) is not None
+    env.step({0: pack_action(KITA)})                       # tile = None (quirk Q13: validation accepts it)
+    v = env.peek()
+    hand = list(v.players[0].hand[: v.players[0].hand_len])
+    assert not any(t // 4 == 30 for t in hand)
+    assert v.players[0].n_kita == 1 and v.players[0].kita[0] // 4 == 30
+    assert len(hand) == before.players[0].hand_len
+    assert v.drawn_tile == 36 and evs(env)[-2:] == [{"actor": 0, "pai": "N", "type": "kita"},
+                                                      {"actor": 0, "pai": "1p", "type": "tsumo"}]
+
+
+def sc3_kita_with_correct_tile(make):
+    """tests.rs:2192-2222: the same with tile = Some(120)."""
+    env = _kita_state(make, 0, [36, 40, 44, 48, 52, 56, 60, 64, 68, 72, 76, 80], 120)
+    env.step({0: pack_action(KITA, 120)})
+    v = env.peek()
+    hand = list(v.players[0].hand[: v.players[0].hand_len])
+    assert 120 not in hand and list(v.players[0].kita[: v.players[0].n_kita]) == [120] and len(hand) == 13
+
+
+def sc3_ankan_available_after_kita_in_riichi(make):
+    """tests.rs:2084-2190: riichi seat draws North, declares Kita without a tile, discards the rinshan tile; when it later
+    draws the fourth 4p, Ankan is offered (waits unchanged) and Kita is not (no North left)."""
+    env = _kita_state(make, 1, [40, 41, 48, 49, 50, 52, 56, 60, 72, 73, 74, 100, 104], 121, riichi=True)
+    env.step({1: pack_action(KITA)})
+    v = env.peek()
+    hand = list(v.players[1].hand[: v.players[1].hand_len])
+    assert not any(t // 4 == 30 for t in hand) and len(hand) == 14
+    env.step({1: pack_action(DISCARD, v.drawn_tile)})      # tsumogiri of the rinshan tile
+    assert env.peek().players[1].hand_len == 13
+    _redraw(env, 1, 51)
+    v = env.peek()
+    assert sum(1 for t in v.players[1].hand[: v.players[1].hand_len] if t // 4 == 12) == 4
+    kinds = [unpack_action(a)[0] for a in env.legal(1)]
+    assert ANKAN in kinds and KITA not in kinds
+
+
+def sc3_reach_available_after_kita(make):
+    """tests.rs:2224-2285: Riichi stays available after a tile-less Kita (tenpai hand, drawable_count > 0: quirk Q8)."""
+    env = _kita_state(make, 1, [40, 44, 48, 52, 56, 60, 76, 80, 84, 88, 92, 96, 100], 122)
+    env.step({1: pack_action(KITA)})
+    env.step({1: pack_action(DISCARD, env.peek().drawn_tile)})
+    _redraw(env, 1, 68)
+    assert RIICHI in [unpack_action(a)[0] for a in env.legal(1)]
+
+
+def sc3_tsumo_available_after_kita(make):
+    """tests.rs:2287-2344: after a tile-less Kita the seat still wins by Tsumo on its pair wait."""
+    env = _kita_state(make, 2, [40, 44, 48, 52, 56, 60, 76, 80, 84, 88, 92, 96, 108], 123)
+    env.step({2: pack_action(KITA)})
+    v = env.peek()
+    assert v.players[2].hand_len == 14
+    rinshan = v.drawn_tile
+
+    def mut(v):   # hand.remove(rinshan); discards.push(rinshan); drawn_tile = None; then draw E (109)
+        pl = v.players[2]
+        h = [t for t in pl.hand[: pl.hand_len] if t != rinshan]
+        _set_hand(pl, h + [109])
+        pl.discards[pl.n_discards] = rinshan
+        pl.n_discards += 1
+        v.drawn_tile = 109
+        v.current_player = 2
+        v.phase = WAIT_ACT
+        v.active_mask = 4
+
+    _poke3(env, mut)
+    assert TSUMO in [unpack_action(a)[0] for a in env.legal(2)]
+
+
+def sc3_ryukyoku_deltas_are_reset_each_round(make):
+    """tests.rs:1228-1256: score deltas of an earlier settlement do not leak into the ryukyoku event of the next round
+    (suukansansen is kept in 3P, state_3p/mod.rs:1861-1888)."""
+    env = make(game_mode=5)
+    env.reset()
+
+    def stale(v):
+        for p, d in enumerate([2300, -2300, 0]):
+            v.players[p].score_delta = d
+
+    _poke3(env, stale)
+    env.reset()                                            # _initialize_round resets the deltas
+    scattered = [0, 32, 36, 40, 44, 72, 76, 80, 112, 116, 120, 124, 128]
+    setup(env, hands=[scattered[:7], scattered[:7], scattered[:], None],
+          melds=[[(ANKAN_M, [48, 49, 50, 51], False), (ANKAN_M, [52, 53, 54, 55], False)],
+                 [(ANKAN_M, [56, 57, 58, 59], False), (ANKAN_M, [60, 61, 62, 63], False)], [], []],
+          current_player=1, drawn_tile=108, reset_kw={})
+    env.step({1: pack_action(DISCARD, 108)})
+    r = [e for e in evs(env) if e["type"] == "ryukyoku"][-1]
+    assert r["reason"] == "suukansansen" and r["deltas"] == [0, 0, 0]
+
+
+def sc3_dora_wraps_between_1m_and_9m(make):
+    """tests.rs:1192-1205 through the state machine: the indicator 1m makes 9m the dora (and 9m makes 1m), so a concealed
+    999m / 111m triplet is worth three han at settlement: menzen tsumo + dora 3, 40 fu = mangan, ko win 4000 + 2000."""
+    for ind, trip in ((0, "999m"), (32, "111m")):
+        env = make(game_mode=5)
+        hand = tiles(trip + "234567p234s9s")
+
+        def mut(v, ind=ind):
+            v.is_first_turn = 0
+            v.n_dora = 1
+            v.dora[0] = ind
+            v.players[1].n_discards = 1
+            v.players[1].discards[0] = 128
+            v.current_player = 1
+            v.active_mask = 2
+
+        setup(env, oya=0, hands=[None, hand, None, None], current_player=1, drawn_tile=tiles("99s")[1], mutate=mut)
+        env.step({1: find(env.legal(1), TSUMO)})
+        hora = next(e for e in reversed(evs(env)) if e["type"] == "hora")
+        assert hora["deltas"] == [-4000, 6000, -2000], (ind, hora)
+
+
+def sc3_ankan_dora_before_rinshan(make):
+    """tests/env/test_kan_dora_timing_events.py:210-256: ankan -> dora -> tsumo in 3P."""
+    env = make(game_mode=3)
+    env.reset()
+
+    def mut(v):
+        _set_hand(v.players[0], [36, 37, 38, 39, 40, 41, 42, 43, 44, 45, 46, 47, 48])
+        v.active_mask = 1
+        v.current_player = 0
+        v.phase = WAIT_ACT
+        v.needs_tsumo = 0
+        v.drawn_tile = 39
+
+    _poke3(env, mut)
+    a = find(env.legal(0), ANKAN)
+    assert a is not None
+    env.step({0: a})
+    t = [e["type"] for e in evs(env)]
+    k = t.index("ankan")
+    assert t[k + 1: k + 3] == ["dora", "tsumo"]
+
+
+def sc3_kakan_dora_before_discard(make):
+    """tests/env/test_kan_dora_timing_events.py:258-320: kakan -> tsumo -> dora -> dahai in 3P."""
+    env = make(game_mode=3)
+    env.reset()
+
+    def mut(v):
+        _set_hand(v.players[0], [39, 40, 41, 42, 43, 44, 45, 46, 47, 48, 49])
+        v.players[0].n_melds = 1
+        set_meld(v.players[0].melds[0], PON_M, [36, 37, 38], True)
+        v.active_mask = 1
+        v.current_player = 0
+        v.phase = WAIT_ACT
+        v.needs_tsumo = 0
+        v.drawn_tile = 39
+
+    _poke3(env, mut)
+    a = find(env.legal(0), KAKAN)
+    assert a is not None
+    env.step({0: a})
+    if env.status()[1] == WAIT_RESPONSE:   # a chankan offer: everybody passes
+        env.step({s: pack_action(PASS) for s in range(3) if (env.status()[0] >> s) & 1})
+    d = find(env.legal(0), DISCARD)
+    assert d is not None
+    env.step({0: d})
+    t = [e["type"] for e in evs(env)]
+    k = t.index("kakan")
+    rest = t[k + 1:]
+    assert rest.index("tsumo") < rest.index("dora") < rest.index("dahai")
+
+
+def sc3_initialization(make):
+    """tests/env/test_sanma.py:49-117: dealer 14 tiles, others 13, 68 tiles left, no 2m-8m anywhere, the log opens with
+    start_game / start_kyoku / tsumo; every sanma game mode."""
+    for mode in (3, 4, 5):
+        env = make(game_mode=mode)
+        env.reset()
+        v = env.peek()
+        assert [v.players[p].hand_len for p in range(3)] == [14, 13, 13] and v.players[3].hand_len == 0
+        assert v.wall_len == 68 and v.phase == WAIT_ACT and v.current_player == 0 and env.status()[0] == 1
+        seen = set(v.wall[: v.wall_len]) | set(v.dora[: v.n_dora])
+        for p in range(3):
+            seen |= set(v.players[p].hand[: v.players[p].hand_len])
+        assert len(seen) == 108 and not any(1 <= t // 4 <= 7 for t in seen)
+        assert [e["type"] for e in evs(env)[:3]] == ["start_game", "start_kyoku", "tsumo"]
+        assert env.scores()[:3] == [35000] * 3
+
+
+def sc3_tsumo_deltas(make):
+    """tests/env/test_sanma.py:403-432: a Tsumo in 3P is paid by the two other seats, deltas sum to zero."""
+    env = make(game_mode=5)
+    env.reset()
+
+    def mut(v):
+        _set_hand(v.players[0], sorted([36, 37, 38, 40, 41, 42, 44, 45, 46, 32, 33, 34, 0]) + [1])
+        v.drawn_tile = 1
+        v.current_player = 0
+        v.is_first_turn = 0
+        v.players[0].discards[v.players[0].n_discards] = 100
+        v.players[0].n_discards += 1
+
+    _poke3(env, mut)
+    assert find(env.legal(0), TSUMO) is not None
+    env.step({0: pack_action(TSUMO)})
+    hora = next(e for e in reversed(evs(env)) if e["type"] == "hora")
+    d = hora["deltas"]
+    assert hora["tsumo"] is True and len(d) == 3 and d[0] > 0 and d[1] < 0 and d[2] < 0 and sum(d) == 0
+
+
+def sc3_play_full_round(make):
+    """tests/env/test_sanma.py:480-499 (+514-530): Tsumo when offered, otherwise discard the last tile, pass every claim,
+    until the single-round game is over; the seats' masked logs carry three tehais."""
+    env = make(game_mode=3, seed=7)
+    env.reset()
+    turns = 0
+    while not env.status()[2] and turns < 200:
+        v = env.peek()
+        pid = v.current_player
+        ts = find(env.legal(pid), TSUMO)
+        if ts is not None:
+            env.step({pid: ts})
+        else:
+            env.step({pid: pack_action(DISCARD, v.players[pid].hand[v.players[pid].hand_len - 1])})
+        while env.status()[1] == WAIT_RESPONSE and not env.status()[2]:
+            env.step({s: pack_action(PASS) for s in range(3) if (env.status()[0] >> s) & 1})
+        turns += 1
+    assert env.status()[2] == 1
+    sk = [json.loads(x) for x in env.log(1) if '"start_kyoku"' in x][0]
+    assert len(sk["tehais"]) == 3 and sk["tehais"][0] == ["?"] * 13 and sk["tehais"][1] != ["?"] * 13
+    assert evs(env)[-1]["type"] == "end_game"
+
+
 SCENARIOS_3P = [sc3_basics, sc3_no_chi, sc3_kita, sc3_oyayame_needs_40000, sc3_tsumo_payments_and_nukidora,
-                sc3_exhaustive_draw_pool_2000, sc3_pon_and_rotation, sc3_ron_deltas]
+                sc3_exhaustive_draw_pool_2000, sc3_pon_and_rotation, sc3_ron_deltas, sc3_kita_tile_none_removes_north,
+                sc3_kita_with_correct_tile, sc3_ankan_available_after_kita_in_riichi, sc3_reach_available_after_kita,
+                sc3_tsumo_available_after_kita, sc3_ryukyoku_deltas_are_reset_each_round, sc3_dora_wraps_between_1m_and_9m,
+                sc3_ankan_dora_before_rinshan, sc3_kakan_dora_before_discard, sc3_initialization, sc3_tsumo_deltas,
+                sc3_play_full_round]

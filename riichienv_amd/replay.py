@@ -108,7 +108,20 @@ class Kyoku:
                     # the first hora of a batch starts from the round's scores minus the ACCEPTED riichi deposits; further
                     # hora events (double / triple ron) add their deltas (mjai_replay.rs:581-599)
                     self.end_scores[i] = (self.scores[i] + d - (1000 if self._accepted[i] else 0)) if first else self.end_scores[i] + d
-            self._pending_hule.append({"seat": a, "zimo": a == ev.get("target"), "hu_tile": ev.get("pai")})
+            # the winning tile: the event's `pai`, else the tile of the last action (mjai_replay.rs:541-559)
+            if ev.get("pai") is not None:
+                hu = abi.mjai_to_tid(ev["pai"], True)
+            else:
+                last = self.actions[-1] if self.actions else None
+                hu = 0
+                if last is not None and last["name"] in ("DealTile", "DiscardTile"):
+                    hu = abi.mjai_to_tid(last["tile"], True)
+                elif last is not None and last["name"] == "AnGangAddGang":
+                    hu = abi.mjai_to_tid(last["tiles"][0], True)
+            ur = ev.get("uradora_markers") if ev.get("uradora_markers") is not None else ev.get("ura_markers")
+            self._pending_hule.append({"seat": a, "zimo": a == ev.get("target"), "hu_tile": hu, "count": ev.get("han") or 0,
+                                       "fu": ev.get("fu") or 0,
+                                       "li_doras": None if ur is None else [abi.mjai_to_tid(t, True) for t in ur]})
         elif ty == "kita":
             self.actions.append({"name": "BaBei", "seat": a})
         elif ty == "ryukyoku":
@@ -127,11 +140,237 @@ class Kyoku:
                                                   **{f"tiles{i}": list(h) for i, h in enumerate(self.hands)})}
         return [head] + [{"name": a["name"], "data": {k: v for k, v in a.items() if k != "name"}} for a in self.actions]
 
+    def take_win_result_contexts(self, ankan_from_consumed=True):
+        """LogKyoku.take_win_result_contexts (replay/mod.rs:1089-1091)"""
+        return WinResultContextIterator(self, ankan_from_consumed)
+
     def grp_features(self):
         """LogKyoku.grp_features (replay/mod.rs:1502-1522)"""
         return dict(chang=self.chang, ju=self.ju, ben=self.ben, liqibang=self.liqibang, scores=list(self.scores),
                     end_scores=list(self.end_scores), wliqi=list(self.wliqi),
                     delta_scores=[e - s for s, e in zip(self.scores, self.end_scores)] if len(self.scores) == len(self.end_scores) else [])
+
+
+class WinResultContext:
+    """WinResultContext (replay/mod.rs:2096-2180): the evaluator inputs of one win as the replay reconstructs them, the
+    log's own expectation (MJAI logs carry none: han / fu 0, no yaku) and `actual` = HandEvaluator.calc of those inputs
+    (filled in batch by evaluate_win_contexts)."""
+
+    __slots__ = ("seat", "tiles", "melds", "agari_tile", "dora_indicators", "ura_indicators", "conditions", "expected_yaku",
+                 "expected_han", "expected_fu", "actual", "sanma")
+
+    def __init__(self, **kw):
+        for k in self.__slots__:
+            setattr(self, k, kw.get(k))
+
+    def hand_case(self) -> abi.HandCase:
+        hc = abi.HandCase()
+        hc.n_tiles = len(self.tiles)
+        for i, t in enumerate(self.tiles[:14]):
+            hc.tiles[i] = t
+        hc.n_melds = len(self.melds)
+        for i, m in enumerate(self.melds[:4]):
+            mv = hc.melds[i]
+            mv.meld_type = m["meld_type"]
+            mv.n_tiles = len(m["tiles"])
+            for j, t in enumerate(m["tiles"][:4]):
+                mv.tiles[j] = t
+            mv.opened = 1 if m["opened"] else 0
+            mv.from_who = m["from_who"]
+            mv.called_tile = -1 if m["called_tile"] is None else m["called_tile"]
+        hc.win_tile = self.agari_tile
+        hc.n_dora = min(len(self.dora_indicators), 5)
+        for i, t in enumerate(self.dora_indicators[:5]):
+            hc.dora[i] = t
+        hc.n_ura = min(len(self.ura_indicators), 5)
+        for i, t in enumerate(self.ura_indicators[:5]):
+            hc.ura[i] = t
+        c = self.conditions
+        for k in ("tsumo", "riichi", "double_riichi", "ippatsu", "haitei", "houtei", "rinshan", "chankan", "tsumo_first_turn"):
+            setattr(hc, k, 1 if c[k] else 0)
+        hc.player_wind, hc.round_wind, hc.honba = c["player_wind"], c["round_wind"], c["honba"]
+        hc.kita_count = c["kita_count"]
+        hc.is_sanma = 1 if self.sanma else 0
+        return hc
+
+
+_MELD_ID = {"Chi": abi.MELD_CHI, "Pon": abi.MELD_PON, "Daiminkan": abi.MELD_DAIMINKAN, "Ankan": abi.MELD_ANKAN,
+            "Kakan": abi.MELD_KAKAN}
+
+
+def _match_and_remove(hand, target):
+    """TileConverter::match_and_remove_u8 (replay/mod.rs:2243-2255): the exact id, else any copy of the type."""
+    if target in hand:
+        hand.remove(target)
+        return True
+    for k, x in enumerate(hand):
+        if x // 4 == target // 4:
+            del hand[k]
+            return True
+    return False
+
+
+class WinResultContextIterator:
+    """WinResultContextIterator (replay/mod.rs:1593-2094) over one Kyoku built from an MJAI log: walks the round's actions,
+    keeps the seats' hands / melds / riichi, ippatsu, rinshan and first-turn flags, the dora indicators and the tile
+    count, and yields one WinResultContext per `hora`.  An MJAI log carries no wall (`paishan`), so the wall-dependent
+    branches (_recalc_doras, _get_ura_indicators) are the reference's no-wall paths: indicators come from the `dora`
+    events, ura indicators from the hora event.  `actual` is left None; evaluate_win_contexts fills it for many
+    contexts at once on the GPU.
+    Reference quirk: MjaiReplay builds every Ankan with tile_raw_id = 0 (mjai_replay.rs:507-514), and the iterator
+    removes "four tiles of type tile_raw_id" (replay/mod.rs:1912-1935), i.e. it treats every MJAI ankan as 1m.
+    `ankan_from_consumed=False` reproduces that; the default uses the type of the consumed tiles."""
+
+    def __init__(self, kyoku: Kyoku, ankan_from_consumed=True):
+        n = len(kyoku.scores)
+        self.k = kyoku
+        self.n = n
+        self.idx = 0
+        self.pending = []
+        self.melds = [[] for _ in range(4)]
+        self.hands = [[abi.mjai_to_tid(t, True) for t in h] for h in kyoku.hands] + [[] for _ in range(4 - n)]
+        self.liqi, self.wliqi, self.ippatsu, self.rinshan = [False] * 4, [False] * 4, [False] * 4, [False] * 4
+        self.first = [True] * 4
+        self.was_kakan, self.kakan_tile, self.was_babei = False, None, False
+        self.ippatsu_before_babei = [False] * 4
+        self.doras = [abi.mjai_to_tid(kyoku.doras[0], True)]     # kyoku.doras grows with the dora events: start from the header's
+        self.left = 55 if n == 3 else 70
+        self.kita = [0] * 4
+        self.ankan_from_consumed = ankan_from_consumed
+
+    def __iter__(self):
+        return self
+
+    def _after_kakan_reset(self):
+        if self.was_kakan:
+            self.ippatsu = [False] * 4
+            self.first = [False] * 4
+            self.was_kakan = self.was_babei = False
+            self.kakan_tile = None
+
+    def __next__(self):
+        if self.pending:
+            return self.pending.pop(0)
+        acts = self.k.actions
+        while self.idx < len(acts):
+            a = acts[self.idx]
+            self.idx += 1
+            name = a["name"]
+            if name != "Hule":
+                self.rinshan = [False] * 4
+                if name != "BaBei":
+                    self.was_babei = False
+            if name == "DiscardTile":
+                seat = a["seat"]
+                self._after_kakan_reset()
+                if a["is_wliqi"]:
+                    self.wliqi[seat] = self.ippatsu[seat] = True
+                if a["is_liqi"]:
+                    self.liqi[seat] = self.ippatsu[seat] = True
+                else:
+                    self.ippatsu[seat] = False
+                self.first[seat] = False
+                _match_and_remove(self.hands[seat], abi.mjai_to_tid(a["tile"], True))
+            elif name == "DealTile":
+                seat = a["seat"]
+                self._after_kakan_reset()
+                self.hands[seat].append(abi.mjai_to_tid(a["tile"], True))
+                if self.left > 0:
+                    self.left -= 1
+            elif name == "ChiPengGang":
+                seat = a["seat"]
+                self.rinshan = [False] * 4
+                self.ippatsu = [False] * 4
+                self.first = [False] * 4
+                self.was_kakan = self.was_babei = False
+                self.kakan_tile = None
+                tl = [abi.mjai_to_tid(t, True) for t in a["tiles"]]
+                for t, f in zip(tl, a["froms"]):
+                    if f == seat:
+                        _match_and_remove(self.hands[seat], t)
+                frm = next((f for f in a["froms"] if f != seat), -1)
+                called = next((t for t, f in zip(tl, a["froms"]) if f != seat), None)
+                self.melds[seat].append(dict(meld_type=_MELD_ID[a["meld_type"]], tiles=tl, opened=True, from_who=frm,
+                                             called_tile=called))
+                if a["meld_type"] == "Daiminkan":
+                    self.rinshan[seat] = True
+            elif name == "Dora":
+                self.doras.append(abi.mjai_to_tid(a["dora_marker"], True))     # no wall: replay/mod.rs:1869-1871
+            elif name == "AnGangAddGang":
+                seat = a["seat"]
+                self.rinshan = [False] * 4
+                tl = [abi.mjai_to_tid(t, True) for t in a["tiles"]]
+                if a["meld_type"] == "Ankan":
+                    self.ippatsu = [False] * 4
+                    self.first = [False] * 4
+                    self.was_kakan = self.was_babei = False
+                    self.kakan_tile = None
+                    t34 = tl[0] // 4 if (self.ankan_from_consumed and tl) else 0
+                    for _ in range(4):
+                        for k, x in enumerate(self.hands[seat]):
+                            if x // 4 == t34:
+                                del self.hands[seat][k]
+                                break
+                    self.melds[seat].append(dict(meld_type=abi.MELD_ANKAN, tiles=[t34 * 4 + i for i in range(4)], opened=False,
+                                                 from_who=-1, called_tile=None))
+                    self.rinshan[seat] = True
+                else:
+                    self.was_kakan, self.kakan_tile = True, tl[0]
+                    self.rinshan[seat] = True
+                    for m in self.melds[seat]:
+                        if m["meld_type"] == abi.MELD_PON and m["tiles"][0] // 4 == tl[0] // 4:
+                            m["meld_type"] = abi.MELD_KAKAN
+                            m["tiles"] = m["tiles"] + [tl[0]]
+                            break
+                    else:
+                        self.melds[seat].append(dict(meld_type=abi.MELD_KAKAN, tiles=tl, opened=True, from_who=-1, called_tile=None))
+                    _match_and_remove(self.hands[seat], tl[0])
+            elif name == "BaBei":
+                seat = a["seat"]
+                self.ippatsu_before_babei = list(self.ippatsu)
+                self.ippatsu = [False] * 4
+                self.first = [False] * 4
+                self.was_babei = True
+                for k, x in enumerate(self.hands[seat]):
+                    if x // 4 == 30:
+                        del self.hands[seat][k]
+                        break
+                self.kita[seat] += 1
+                self.rinshan[seat] = True
+            elif name == "Hule":
+                for h in a["hules"]:
+                    seat, zimo = h["seat"], h["zimo"]
+                    win = h["hu_tile"]
+                    chankan = (not zimo) and self.was_kakan and self.kakan_tile is not None and self.kakan_tile // 4 == win // 4
+                    ipp = self.ippatsu_before_babei[seat] if (not zimo and self.was_babei) else self.ippatsu[seat]
+                    hand = list(self.hands[seat])
+                    cond = dict(tsumo=zimo, riichi=self.liqi[seat], double_riichi=self.wliqi[seat], ippatsu=ipp,
+                                haitei=self.left == 0 and zimo and not self.rinshan[seat],
+                                houtei=self.left == 0 and not zimo and not self.rinshan[seat], rinshan=self.rinshan[seat],
+                                chankan=chankan, tsumo_first_turn=self.first[seat] and zimo,
+                                player_wind=(seat + self.n - self.k.ju) % self.n, round_wind=self.k.chang, honba=0,
+                                kita_count=self.kita[seat])
+                    if not zimo:
+                        hand.append(win)
+                    ura = list(h["li_doras"]) if (self.liqi[seat] and h.get("li_doras") is not None) else \
+                        ([abi.mjai_to_tid(t, True) for t in self.k.ura_doras] if self.liqi[seat] else [])
+                    self.pending.append(WinResultContext(seat=seat, tiles=hand, melds=[dict(m) for m in self.melds[seat]],
+                                                         agari_tile=win, dora_indicators=list(self.doras), ura_indicators=ura,
+                                                         conditions=cond, expected_yaku=[], expected_han=h.get("count", 0),
+                                                         expected_fu=h.get("fu", 0), actual=None, sanma=self.n == 3))
+                if self.pending:
+                    return self.pending.pop(0)
+        raise StopIteration
+
+
+def evaluate_win_contexts(contexts, device=0):
+    """`actual` of many WinResultContexts in ONE batch on the GPU: rmj_eval_hands = HandEvaluator(tiles, melds).calc(agari
+    tile, dora, ura, conditions) (replay/mod.rs:2060-2068).  Returns the contexts."""
+    contexts = list(contexts)
+    if contexts:
+        for c, r in zip(contexts, vecenv.eval_hands([c.hand_case() for c in contexts], device=device)):
+            c.actual = r
+    return contexts
 
 
 class MjaiReplay:

@@ -48,6 +48,13 @@ __device__ __forceinline__ void store_state(const GState& S, GState* dst, int la
     if (lane < (int)(sizeof(GState) / 16)) reinterpret_cast<uint4*>(dst)[lane] = reinterpret_cast<const uint4*>(&S)[lane];
 }
 
+// fast path of k_step: the 128 B of globals and the PState quarters named by `dirty` (bit = seat)
+__device__ __forceinline__ void store_state_partial(const GState& S, GState* dst, int lane, uint32_t dirty) {
+    wave_sync();
+    if (lane < (int)(sizeof(GState) / 16) && (lane >= 32 || ((dirty >> (lane >> 3)) & 1u)))
+        reinterpret_cast<uint4*>(dst)[lane] = reinterpret_cast<const uint4*>(&S)[lane];
+}
+
 // Device policy without stepping (rmj_random_actions)
 __global__ void k_random_actions(Env E, uint64_t policy_seed, uint64_t* out) {
     uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;

@@ -112,7 +112,7 @@ __global__ __launch_bounds__(64 * RMJ_STEP_WPB, RMJ_STEP_WAVES) void k_step(cons
 #endif
     } else {
         flush_events(c);
-        store_state(S, E.core + g, lane);
+        store_state_partial(S, E.core + g, lane, U(c.dirty));
     }
     PROF(c.X, lane, 15);
     PROF_FLUSH(c.X, lane, g);

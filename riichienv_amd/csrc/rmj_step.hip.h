@@ -41,6 +41,9 @@ struct Ctx {
     // >= 0: events are staged in X.evbuf (count so far), flushed by k_step once the fast path has succeeded; -1: every
     // event is stored to the ring at once (all other kernels, the full path, out-of-line bodies)
     int ev_stage = -1;
+    // PState quarters of the record that this step may have modified (bit = seat; the 128 B of globals always are): the
+    // fast path of k_step stores only those back.  0xF everywhere it is not tracked.
+    uint32_t dirty = 0xFu;
 };
 
 // By-value view of a Ctx for out-of-line (rare-path) functions.  Passing Ctx& to a non-inlined function would
@@ -467,6 +470,7 @@ __device__ __forceinline__ uint32_t gen_claims_all(Ctx& c, int pid, int tile) {
     const uint32_t qfl = Q.flags;
     const bool holds13 = other && (Q.hand_len + 3 * Q.n_melds == 13);
     uint32_t need = (uint32_t)__ballot(holds13 && !(qfl & PF_WAITS_VALID)) & 0xFu;
+    c.dirty |= need;
     while (need) {
         int i = __ffs((int)need) - 1;
         need &= need - 1u;
@@ -866,6 +870,7 @@ __device__ __forceinline__ void accept_riichi(Ctx& c) {
     GState& S = c.S;
     const int p = U((int)S.riichi_pending);
     if (p != 0xFF) {
+        c.dirty |= 1u << p;
         S.p[p].score -= 1000;
         S.p[p].score_delta -= 1000;
         S.riichi_sticks += 1;
@@ -899,6 +904,7 @@ __device__ __forceinline__ void deal_next(Ctx& c) {
         S.live_end = (uint8_t)le;
         S.drawable_count = (uint8_t)(drawable - 1);
         const int pid = U((int)S.current_player);
+        c.dirty |= 1u << pid;
         PState& P = S.p[pid];
         const int hl = U((int)P.hand_len);
         if (hl < 14) { P.hand[hl] = t; P.hand_len = (uint8_t)(hl + 1); }
@@ -1491,6 +1497,7 @@ __device__ __forceinline__ void handle_kita(Ctx& c, int pid, uint64_t act) {
     GState& S = c.S;
     PState& P = S.p[pid];
     const int lane = c.lane;
+    c.dirty = 0xFu;
     if (FAST && U((int)S.pending_kan_dora) > 0) { c.bail = true; return; }
     int tile;
     if (a_tile(act) != RMJ_TILE_NONE && (a_tile(act) >> 2) == 30) tile = (int)a_tile(act);
@@ -1815,6 +1822,7 @@ __device__ __forceinline__ void step_game(Ctx& c, const uint64_t mine, bool trus
         int d_tile = 0;
         if (ty == RMJ_DISCARD) {
             if (a_tile(act) == RMJ_TILE_NONE) return;
+            if (FAST) c.dirty = 1u << pid;  // the discard path tracks the seats it touches (resolve_discard, claims, next draw)
             int tile = (int)a_tile(act);
             bool tsumogiri = false, valid = false;
             const int drawn = U((int)S.drawn_tile);
@@ -2218,8 +2226,11 @@ __device__ __forceinline__ void finalize_outputs(Ctx& c, bool claims_fresh) {
     }
     wave_sync();
     PROF(c.X, lane, 13);
-    // masks + list publication (only the seats that act have a list; a step usually has one)
+    // masks + list publication (only the seats that act have a list; a step usually has one).  Mask rows of seats that
+    // are not to act are all zero and stay so: only the rows of the seats that had a list before this step (S.nlegal
+    // still holds the previous publication) or have one now are rewritten - 82 B per row in 16-bit units.
     const uint32_t am = (uint32_t)__builtin_amdgcn_readfirstlane((int)S.active_mask);
+    const uint32_t rows = (((uint32_t)__ballot(lane < 4 && S.nlegal[lane & 3] != 0)) | am) & 0xFu;
     for (int i = lane; i < (4 * 82 + 3) / 4; i += 64) reinterpret_cast<uint32_t*>(c.X.maskbuf)[i] = 0u;
     wave_sync();
     for (uint32_t m = am; m; m &= m - 1u) {
@@ -2233,8 +2244,11 @@ __device__ __forceinline__ void finalize_outputs(Ctx& c, bool claims_fresh) {
         }
     }
     wave_sync();
-    uint32_t* mout = reinterpret_cast<uint32_t*>(c.E.mask + (size_t)c.g * 328);
-    for (int i = lane; i < 82; i += 64) mout[i] = reinterpret_cast<const uint32_t*>(c.X.maskbuf)[i];
+    uint16_t* mout = reinterpret_cast<uint16_t*>(c.E.mask + (size_t)c.g * 328);
+    for (uint32_t m = rows; m; m &= m - 1u) {
+        const int p = __ffs((int)m) - 1;
+        if (lane < 41) mout[41 * p + lane] = reinterpret_cast<const uint16_t*>(c.X.maskbuf)[41 * p + lane];
+    }
     if (lane < 4) {
         const bool acts = (am >> lane) & 1u;
         const int n = acts ? c.X.nl[lane] : 0;

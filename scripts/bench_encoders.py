@@ -1,0 +1,33 @@
+#!/usr/bin/env python3
+"""Encoder kernels in isolation (for rocprofv3): after a device rollout that brought 65 536 games into mid-game states,
+time rmj_encode_device / rmj_encode_extended_device (only_active = 2: the acting seats' rows) with HIP events on the handle's
+stream, 4P and 3P.  Prints one JSON object with the average launch duration, the acting seats and the algorithmic bytes
+(74 x W x 4 resp. 215 x W x 4 per acting seat, docs/FEATURE_ENCODING.md:8-82)."""
+import json
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch  # noqa: E402
+
+from riichienv_amd import vecenv  # noqa: E402
+
+out = {}
+for mode in (2, 5):
+    w = 27 if mode >= 3 else 34
+    env = vecenv.VecRiichiEnv(65536, game_mode=mode, seed=0, event_ring=64)
+    env.reset()
+    env.step_random(0xC0FFEE, 400, auto_reset=True)
+    act, _, dn = env.status()
+    acting = int(sum(bin(int(a)).count("1") for a, d in zip(act, dn) if not d))
+    for ext in (False, True):
+        ch = 215 if ext else 74
+        buf = torch.zeros((65536, 4, ch, w), dtype=torch.float32, device="cuda:0")
+        ms = env.bench_encode(buf.data_ptr(), 40, extended=ext, only_active=2)
+        b = ch * w * 4 * acting
+        out[f"{'k_encode_ext' if ext else 'k_encode'}_{'3p' if mode >= 3 else '4p'}"] = {
+            "kernel_ms": ms, "acting_seats": acting, "bytes_per_launch": b, "achieved_GBps": b / (ms * 1e-3) / 1e9,
+            "frac_of_8TBps": b / (ms * 1e-3) / 8e12}
+        del buf
+    env.close()
+print(json.dumps(out))

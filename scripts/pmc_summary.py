@@ -7,6 +7,7 @@ import os
 import sys
 
 root, tag, kern = sys.argv[1], sys.argv[2], sys.argv[3]
+mode = int(sys.argv[4]) if len(sys.argv) > 4 else 2
 out = {}
 for f in glob.glob(os.path.join(root, tag + "_p*", "**", "*counter_collection.csv"), recursive=True):
     acc = {}
@@ -21,8 +22,8 @@ for f in glob.glob(os.path.join(root, tag + "_p*", "**", "*counter_collection.cs
         per.setdefault(name, []).append(v)
     for name, vals in per.items():
         out[name] = {"mean_per_launch": sum(vals) / len(vals), "launches": len(vals)}
-doc = {"command": "rocprofv3 --pmc <group> -- python3 bench.py --steps 50 --warmup 20 --no-cpu-baseline (one pass per counter "
-                  "group, scripts/pmc_collect.sh)", "kernel": kern, "counters": out}
+doc = {"command": "rocprofv3 --pmc <group> -- python3 <bench command> (one pass per counter group, scripts/r02_profiles.sh / "
+                  "scripts/pmc_collect.sh)", "kernel": kern, "mode": mode, "counters": out}
 waves = out.get("SQ_WAVES", {}).get("mean_per_launch")
 if waves:
     doc["games_per_launch"] = int(round(waves))  # one wave per game

@@ -1,0 +1,43 @@
+#!/bin/bash
+# Round-2 profile artifacts on the GPU box (outputs under gpurun_out/<tag>_*; the summaries are copied to profiles/ by hand):
+#   bench lines (headline, 3P + feature tensor), rocprofv3 kernel stats of both commands, FETCH/WRITE + instruction PMC
+#   passes for k_step, k_encode and k_encode_ext.
+TAG=${1:-r02}
+export TMPDIR=/tmp
+R=${GRAFT_REPO_ROOT:-$(pwd)}
+cd $R
+python3 bench.py > gpurun_out/${TAG}_bench_n1.json 2> gpurun_out/${TAG}_bench_n1.err
+python3 bench.py --mode 5 --encode --steps 400 --warmup 300 --no-cpu-baseline > gpurun_out/${TAG}_bench_3p_encode.json 2>> gpurun_out/${TAG}_bench_n1.err
+python3 bench.py --mode 5 --no-cpu-baseline > gpurun_out/${TAG}_bench_3p_mode5.json 2>> gpurun_out/${TAG}_bench_n1.err
+# kernel stats: the headline command and the feature-output command
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/${TAG}_stats -- python3 bench.py --steps 500 --warmup 200 --no-cpu-baseline --no-extras > gpurun_out/${TAG}_stats.log 2>&1
+find gpurun_out/${TAG}_stats -name "*kernel_stats.csv" -exec cp {} gpurun_out/${TAG}_kernel_stats.csv \;
+rm -rf gpurun_out/${TAG}_stats
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/${TAG}_stats_enc -- python3 bench.py --mode 5 --encode --steps 300 --warmup 300 --no-cpu-baseline > gpurun_out/${TAG}_stats_enc.log 2>&1
+find gpurun_out/${TAG}_stats_enc -name "*kernel_stats.csv" -exec cp {} gpurun_out/${TAG}_kernel_stats_3p_encode.csv \;
+rm -rf gpurun_out/${TAG}_stats_enc
+# extended encoder: scripts/bench_torch_env.py drives encode_extended; kernel stats of that loop
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/${TAG}_stats_ext -- python3 scripts/bench_encoders.py > gpurun_out/${TAG}_bench_encoders.json 2> gpurun_out/${TAG}_stats_ext.log
+find gpurun_out/${TAG}_stats_ext -name "*kernel_stats.csv" -exec cp {} gpurun_out/${TAG}_kernel_stats_encoders.csv \;
+rm -rf gpurun_out/${TAG}_stats_ext
+# PMC passes (one group per run, no tracing flags)
+i=0
+for grp in "FETCH_SIZE" "WRITE_SIZE" "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVES" "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_ACTIVE_INST_ANY" \
+           "SQ_INSTS_SMEM SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_BRANCH" "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_LDS SQ_THREAD_CYCLES_VALU"; do
+  i=$((i+1))
+  timeout 300 rocprofv3 --pmc $grp --output-format csv -d $R/gpurun_out/${TAG}_pmc_p$i -- python3 bench.py --steps 50 --warmup 300 --no-cpu-baseline --no-extras > $R/gpurun_out/${TAG}_pmc_p$i.log 2>&1
+  echo "k_step pass $i ($grp) rc=$?"
+done
+python3 scripts/pmc_summary.py $R/gpurun_out ${TAG}_pmc k_step 2 > $R/gpurun_out/${TAG}_pmc_k_step.json
+i=0
+for grp in "FETCH_SIZE" "WRITE_SIZE" "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVES" "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_ACTIVE_INST_ANY"; do
+  i=$((i+1))
+  timeout 300 rocprofv3 --pmc $grp --output-format csv -d $R/gpurun_out/${TAG}_pmcenc_p$i -- python3 scripts/bench_encoders.py > $R/gpurun_out/${TAG}_pmcenc_p$i.log 2>&1
+  echo "encoders pass $i ($grp) rc=$?"
+done
+python3 scripts/pmc_summary.py $R/gpurun_out ${TAG}_pmcenc "k_encode<false, false>" 2 > $R/gpurun_out/${TAG}_pmc_k_encode_4p.json
+python3 scripts/pmc_summary.py $R/gpurun_out ${TAG}_pmcenc "k_encode<true, false>" 5 > $R/gpurun_out/${TAG}_pmc_k_encode_3p.json
+python3 scripts/pmc_summary.py $R/gpurun_out ${TAG}_pmcenc "k_encode<false, true>" 2 > $R/gpurun_out/${TAG}_pmc_k_encode_ext_4p.json
+python3 scripts/pmc_summary.py $R/gpurun_out ${TAG}_pmcenc "k_encode<true, true>" 5 > $R/gpurun_out/${TAG}_pmc_k_encode_ext_3p.json
+rm -rf gpurun_out/${TAG}_pmc_p* gpurun_out/${TAG}_pmcenc_p*/
+cat gpurun_out/${TAG}_bench_n1.json; head -6 gpurun_out/${TAG}_kernel_stats.csv; head -6 gpurun_out/${TAG}_kernel_stats_3p_encode.csv; cat gpurun_out/${TAG}_bench_encoders.json

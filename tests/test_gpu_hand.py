@@ -216,6 +216,7 @@ def test_hand_kats_from_reference_unit_tests_gpu():
 def test_shanten_and_ukeire_equal_the_reference_tables():
     """rmj_shanten / rmj_effective_tiles / rmj_best_ukeire against the answers of the REFERENCE's nyanten lookup
     (tests/golden/shanten_vectors.json, scripts/gen_shanten_vectors.py): 10^5 sampled hands per variant, every len/3 class."""
+    from riichienv_amd import vecenv
     from tests.shanten_sampler import sample_hand, sample_hands, sample_visible
     from tests.test_oracle_shanten_golden import GOLD, expected_shanten
 

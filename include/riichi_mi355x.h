@@ -294,6 +294,13 @@ int rmj_device_views(rmj_handle h, RmjDeviceViews* out);
 /* step with the policy's action ids ([n][4] int32 on the device, -1 = no action): Observation.find_action
  * (observation/python.rs:119-122) + RiichiEnv.step; auto_reset != 0 restarts finished games like rmj_step_random */
 int rmj_step_ids_device(rmj_handle h, const int32_t* d_action_ids, int auto_reset);
+/* Masked categorical sampling for a policy on the same GPU (what riichienv-ml's PPO worker does per game on the host with
+ * obs.mask(), trainers/_ppo_worker.py:164-239): for every seat that is to act, one action id drawn from
+ * softmax(logits) restricted to the seat's legal ids (Gumbel-max on the resident mask slab); d_logits [n][4][stride] f32 on
+ * the device (stride >= 82 / 60; masked entries are never read as candidates), NULL = uniform over the legal ids.
+ * d_ids [n][4] int32, -1 for seats that do not act: the input of rmj_step_ids_device.  Counter-based noise: the same
+ * (seed, state) gives the same ids.  Asynchronous on the handle's stream. */
+int rmj_sample_ids_device(rmj_handle h, const float* d_logits, uint32_t stride, uint64_t seed, int32_t* d_ids);
 /* scores() (env.rs:401-404) into a device buffer [n][4]; d_event_counts [n] may be NULL */
 int rmj_scores_device(rmj_handle h, int32_t* d_scores, uint32_t* d_event_counts);
 int rmj_sync(rmj_handle h); /* wait for the handle's stream */

@@ -72,6 +72,48 @@ __global__ void k_random_actions(Env E, uint64_t policy_seed, uint64_t* out) {
     }
 }
 
+// Trainer-side masked categorical sampler (rmj_sample_ids_device): one wave per game; for every seat that is to act the
+// lanes hold ids lane and lane + 64 of the seat's mask row, add Gumbel noise to the policy's logits (Gumbel-max = a draw
+// from softmax(logits) restricted to the legal ids; no logits = uniform over the legal ids) and a wave arg-max picks the id.
+// The noise is counter-based: splitmix64(seed, global game, the game's step count, seat, id).
+__global__ __launch_bounds__(256) void k_sample_ids(Env E, const float* __restrict__ logits, uint32_t stride, uint64_t seed,
+                                                    int32_t* __restrict__ out) {
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const uint32_t g = blockIdx.x * 4 + wave;
+    if (g >= E.n_games) return;
+    const uint32_t st = E.status[g];
+    const uint32_t am = (st >> 16) & 0xFFu ? 0u : (st & 0xFu);   // done games have nobody to act
+    const int A = E.game_mode >= 3 ? RMJ_ACTION_SPACE_3P : RMJ_ACTION_SPACE_4P;
+    const uint64_t base = sm64(seed ^ sm64(E.game_offset + g)) + ((uint64_t)E.core[g].step_count << 10);
+    int32_t res = -1;   // lane p ends up with seat p's id
+    for (int p = 0; p < 4; p++) {
+        if (!((am >> p) & 1u) || E.nlegal[(size_t)g * 4 + p] == 0) continue;   // wave-uniform
+        const uint8_t* m = E.mask + ((size_t)g * 4 + p) * 82;
+        const float* lg = logits ? logits + ((size_t)g * 4 + p) * stride : nullptr;
+        float best = -INFINITY;
+        int bid = -1;
+#pragma unroll
+        for (int k = 0; k < 2; k++) {
+            const int id = lane + 64 * k;
+            if (id < A && m[id]) {
+                const uint64_t h = sm64(base + ((uint64_t)p << 8) + (uint64_t)id);
+                const float u = ((float)(uint32_t)(h >> 40) + 0.5f) * (1.0f / 16777216.0f);   // (0, 1), 24 bits
+                const float key = (lg ? lg[id] : 0.0f) - __logf(-__logf(u));
+                if (key > best || bid < 0) { best = key; bid = id; }
+            }
+        }
+        // wave arg-max (ties to the lower id)
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) {
+            const float ob = __shfl_xor(best, off, 64);
+            const int oi = __shfl_xor(bid, off, 64);
+            if (oi >= 0 && (bid < 0 || ob > best || (ob == best && oi < bid))) { best = ob; bid = oi; }
+        }
+        if (lane == p) res = bid;
+    }
+    if (lane < 4) out[(size_t)g * 4 + lane] = res;
+}
+
 struct ResetArgs {
     const uint8_t* select;
     const uint8_t* walls;       // [n][136] reference orientation (draw order)
@@ -760,6 +802,16 @@ int rmj_step_ids_device(rmj_handle h, const int32_t* d_action_ids, int auto_rese
     HIPCHK(hipSetDevice(h->cfg.device));
     const uint32_t flags = STEP_F_IDS | (auto_reset ? STEP_F_AUTORESET : 0u);
     launch_step_range(h, h->stream, reinterpret_cast<const uint64_t*>(d_action_ids), 0ull, flags, 0u, h->cfg.n_games);
+    HIPCHK(hipGetLastError());
+    return RMJ_OK;
+}
+int rmj_sample_ids_device(rmj_handle h, const float* d_logits, uint32_t stride, uint64_t seed, int32_t* d_ids) {
+    if (!h || !d_ids) return fail(RMJ_ERR_ARG, "null argument");
+    const uint32_t A = h->cfg.game_mode >= 3 ? RMJ_ACTION_SPACE_3P : RMJ_ACTION_SPACE_4P;
+    if (d_logits && stride < A) return fail(RMJ_ERR_ARG, "logits row shorter than the action space");
+    HIPCHK(hipSetDevice(h->cfg.device));
+    const uint32_t n = h->cfg.n_games;
+    hipLaunchKernelGGL(k_sample_ids, dim3((n + 3) / 4), dim3(256), 0, h->stream, h->d, d_logits, stride, seed, d_ids);
     HIPCHK(hipGetLastError());
     return RMJ_OK;
 }

@@ -122,6 +122,24 @@ class TorchVecEnv:
         if not self.shared:
             vecenv._chk(self.env.L.rmj_sync(self.env.h))
 
+    def sample_ids(self, logits=None, seed=0):
+        """One id per acting seat drawn from softmax(logits) over the seat's legal ids, -1 elsewhere, by ONE kernel of the
+        library (rmj_sample_ids_device: Gumbel-max on the resident mask slab) - no torch indexing / multinomial in the loop.
+        logits: float32 [n, 4, A'] with A' >= 82 (60 in 3P) on this device, or None for the uniform policy."""
+        t = self.torch
+        if not hasattr(self, "_ids"):
+            self._ids = t.full((self.n, 4), -1, dtype=t.int32, device=self.device)
+        ptr, stride = None, 0
+        if logits is not None:
+            assert logits.dtype == t.float32 and logits.is_contiguous() and tuple(logits.shape[:2]) == (self.n, 4)
+            ptr, stride = C.c_void_p(logits.data_ptr()), int(logits.shape[2])
+            if not self.shared:
+                t.cuda.current_stream(self.device).synchronize()   # the logits were produced on torch's stream
+        vecenv._chk(self.env.L.rmj_sample_ids_device(self.env.h, ptr, stride, int(seed) & 0xFFFFFFFFFFFFFFFF,
+                                                     C.c_void_p(self._ids.data_ptr())))
+        self.sync()
+        return self._ids
+
     def sample_random_ids(self, generator=None):
         """uniform choice among the legal ids of every acting seat (a masked categorical policy's baseline)"""
         t = self.torch

@@ -29,7 +29,7 @@ EXPORTS = [
     "rmj_agari_counts", "rmj_calculate_score", "rmj_shanten", "rmj_effective_tiles", "rmj_best_ukeire", "rmj_apply_events", "rmj_device_views", "rmj_step_ids_device",
     "rmj_scores_device", "rmj_sync", "rmj_set_stream", "rmj_encode", "rmj_encode_device", "rmj_encode_extended", "rmj_encode_extended_device", "rmj_encode_aux", "rmj_encode_aux_device", "rmj_encode_seq", "rmj_encode_seq_device", "rmj_bench_rollout",
     "rmj_bench_rollout_validated", "rmj_bench_encode", "rmj_set_rollout_streams", "rmj_total_full_path",
-    "rmj_random_actions_device", "rmj_peek_outputs",
+    "rmj_random_actions_device", "rmj_peek_outputs", "rmj_sample_ids_device",
 ]
 
 
@@ -117,6 +117,7 @@ def load_lib():
     L.rmj_total_full_path.argtypes = [vp, C.POINTER(C.c_uint64)]
     L.rmj_random_actions_device.argtypes = [vp, C.c_uint64, vp]
     L.rmj_peek_outputs.argtypes = [vp, C.c_uint32, vp, vp, vp, vp, C.POINTER(C.c_uint32)]
+    L.rmj_sample_ids_device.argtypes = [vp, vp, C.c_uint32, C.c_uint64, vp]
     _LIB = L
     return L
 

@@ -12,12 +12,18 @@ import torch  # noqa: E402
 from riichienv_amd.torch_env import TorchVecEnv  # noqa: E402
 
 
-def run(n, ext, shared):
+def run(n, ext, shared, fused=False):
     env = TorchVecEnv(n, game_mode=2, seed=0, extended=ext, share_stream=shared)
     gen = torch.Generator(device=env.device)
     gen.manual_seed(0)
+    it = [0]
+
+    def policy():
+        it[0] += 1
+        return env.sample_ids(seed=it[0]) if fused else env.sample_random_ids(gen)
+
     for _ in range(20):
-        env.step(env.sample_random_ids(gen))
+        env.step(policy())
     torch.cuda.synchronize()
     t_obs = t_pol = t_step = 0.0
     steps0 = env.env.total_steps()
@@ -27,7 +33,7 @@ def run(n, ext, shared):
         a = time.perf_counter()
         env.obs(only_active=True)
         b = time.perf_counter()
-        ids = env.sample_random_ids(gen)
+        ids = policy()
         if not shared:
             torch.cuda.synchronize()      # own stream: the parts are timed one by one
         c = time.perf_counter()
@@ -40,7 +46,8 @@ def run(n, ext, shared):
     t1 = time.perf_counter()
     steps = env.env.total_steps() - steps0
     parts = "" if shared else f" (obs {t_obs / K * 1e3:.2f} ms, torch policy {t_pol / K * 1e3:.2f} ms, step {t_step / K * 1e3:.2f} ms per iteration)"
-    print(f"games {n} channels {env.channels} {'shared stream, no host sync' if shared else 'own stream, synchronised parts'}: "
+    print(f"games {n} channels {env.channels} {'fused masked sampler (rmj_sample_ids_device)' if fused else 'torch masked multinomial'}, "
+          f"{'shared stream, no host sync' if shared else 'own stream, synchronised parts'}: "
           f"loop {steps / (t1 - t0) / 1e6:.1f} M env.step/s, {(t1 - t0) / K * 1e3:.2f} ms per iteration{parts}")
 
 
@@ -49,6 +56,8 @@ def main():
     ext = len(sys.argv) > 2 and sys.argv[2] == "ext"
     run(n, ext, False)
     run(n, ext, True)
+    run(n, ext, False, fused=True)
+    run(n, ext, True, fused=True)
 
 
 if __name__ == "__main__":

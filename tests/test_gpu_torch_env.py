@@ -56,3 +56,39 @@ def test_torch_env_matches_oracle(mode, shared):
         v = o.peek()
         assert list(sc[g]) == [v.players[p].score for p in range(4)]
     assert (rk == env.env.ranks()).all()
+
+
+@pytest.mark.parametrize("mode", [2, 5])
+def test_fused_masked_sampler(mode):
+    """rmj_sample_ids_device: ids are legal (mask bit set) exactly for the acting seats, deterministic in (seed, state),
+    follow the logits (a dominant logit always wins, a masked id never does), and are uniform over the legal ids without."""
+    torch = pytest.importorskip("torch")
+    from riichienv_amd.torch_env import TorchVecEnv
+
+    n = 4096
+    A = 60 if mode >= 3 else 82
+    env = TorchVecEnv(n, game_mode=mode, seed=77, share_stream=True)
+    for k in range(60):
+        env.step(env.sample_ids(seed=k))
+    act = env.active()
+    mask = env.mask.to(torch.bool)
+    ids = env.sample_ids(seed=123).clone()
+    assert ((ids >= 0) == act).all()
+    g, s = torch.nonzero(act, as_tuple=True)
+    assert mask[g, s, ids[g, s].long()].all() and (ids[g, s] < A).all()
+    assert (env.sample_ids(seed=123) == ids).all() and not (env.sample_ids(seed=124) == ids).all()
+    # logits: the largest legal id gets +50 -> always chosen; an illegal id with +1000 is never chosen
+    legal_ids = torch.where(mask, torch.arange(82, device=env.device)[None, None, :], torch.full((1,), -1, device=env.device))
+    top = legal_ids.max(-1).values
+    logits = torch.zeros((n, 4, 82), dtype=torch.float32, device=env.device)
+    logits[g, s, top[g, s]] = 50.0
+    logits[~mask] = 1000.0
+    got = env.sample_ids(logits, seed=5)
+    assert (got[g, s].long() == top[g, s]).all()
+    # uniformity: over many seeds, the discard ids of one acting seat with >= 10 legal ids are all drawn, none dominates
+    cnt = mask.sum(-1)
+    k = int(torch.nonzero(act & (cnt >= 10))[0, 0]), int(torch.nonzero(act & (cnt >= 10))[0, 1])
+    draws = torch.stack([env.sample_ids(seed=1000 + i)[k[0], k[1]].clone() for i in range(600)]).long()
+    hist = torch.bincount(draws, minlength=82)[mask[k[0], k[1]]]
+    c = int(cnt[k[0], k[1]])
+    assert (hist > 0).all() and hist.max() < 3.0 * 600 / c and hist.min() > 600 / c / 3.5, (hist, c)

@@ -359,6 +359,26 @@ typedef struct RmjSeqBuffers {
     uint16_t* candidates;    /* [n][4][64][4]  (type, moqie, liqi, from) in legal-list order, padded with (279,2,2,3) */
     uint8_t* n_candidates;   /* [n][4]         */
 } RmjSeqBuffers;
+/* The same features over the events of ONE OBSERVATION, as the reference's live environment computes them
+ * (Observation.events = the seat's log since its previous observation, state/mod.rs:211-218; enable_seq_caching is off
+ * outside the replay path): the progression holds only that delta (per seat), the drawn-tile token exists only while the
+ * delta still contains the seat's tsumo, the round-start numbers come from a start_kyoku inside the delta (else the current
+ * ones, sequence_features.rs:490), the last discarder is searched in the delta.  The library keeps the seats' event
+ * cursors in the record: every publication of observations for an acting seat (reset, step) advances that seat's cursor
+ * like get_observation does.  Seats that are not to act get empty outputs; n_progression = 0xFFFF if the ring no longer
+ * holds the delta. */
+#define RMJ_SEQ_DELTA_PROG 64
+typedef struct RmjSeqDeltaBuffers {
+    uint16_t* sparse;        /* [n][4][25]     */
+    uint8_t* n_sparse;       /* [n][4]         */
+    float* numeric;          /* [n][4][12]     */
+    uint16_t* progression;   /* [n][4][64][5]  per seat: the delta's entries, padded with (4,276,2,2,4) */
+    uint16_t* n_progression; /* [n][4]         */
+    uint16_t* candidates;    /* [n][4][64][4]  */
+    uint8_t* n_candidates;   /* [n][4]         */
+} RmjSeqDeltaBuffers;
+int rmj_encode_seq_delta(rmj_handle h, int game_style, const RmjSeqDeltaBuffers* out);          /* host arrays */
+int rmj_encode_seq_delta_device(rmj_handle h, int game_style, const RmjSeqDeltaBuffers* d_out); /* device arrays, handle's stream */
 int rmj_encode_seq(rmj_handle h, int game_style, const RmjSeqBuffers* out);          /* host arrays */
 int rmj_encode_seq_device(rmj_handle h, int game_style, const RmjSeqBuffers* d_out); /* device arrays, handle's stream */
 

@@ -203,7 +203,7 @@ class SeqBuffers(C.Structure):
                 ("n_progression", C.c_void_p), ("candidates", C.c_void_p), ("n_candidates", C.c_void_p)]
 
 
-SEQ_SPARSE, SEQ_PROG, SEQ_CAND = 25, 256, 64
+SEQ_SPARSE, SEQ_PROG, SEQ_CAND, SEQ_DELTA_PROG = 25, 256, 64, 64
 
 
 class BenchResult(C.Structure):

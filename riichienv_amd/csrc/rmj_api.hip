@@ -1462,6 +1462,40 @@ int rmj_encode_seq(rmj_handle h, int game_style, const RmjSeqBuffers* out) {
     return RMJ_OK;
 }
 
+int rmj_encode_seq_delta_device(rmj_handle h, int game_style, const RmjSeqDeltaBuffers* d) {
+    if (!h || !d || !d->sparse || !d->n_sparse || !d->numeric || !d->progression || !d->n_progression || !d->candidates || !d->n_candidates)
+        return fail(RMJ_ERR_ARG, "null argument");
+    if (h->cfg.game_mode >= 3) return fail(RMJ_ERR_ARG, "sequence features exist for 4-player games only (observation/sequence_features.rs)");
+    if (h->cfg.skip_mjai_logging) return fail(RMJ_ERR_ARG, "sequence features read the event log: create the handle with logging on");
+    HIPCHK(hipSetDevice(h->cfg.device));
+    hipLaunchKernelGGL(k_encode_seq_delta, dim3(h->cfg.n_games), dim3(64), 0, h->stream, h->d, game_style, *d);
+    HIPCHK(hipGetLastError());
+    return RMJ_OK;
+}
+int rmj_encode_seq_delta(rmj_handle h, int game_style, const RmjSeqDeltaBuffers* out) {
+    if (!h || !out) return fail(RMJ_ERR_ARG, "null argument");
+    HIPCHK(hipSetDevice(h->cfg.device));
+    const size_t n = h->cfg.n_games;
+    const size_t sz[7] = {n * 4 * RMJ_SEQ_SPARSE * 2, n * 4, n * 4 * 12 * 4, n * 4 * RMJ_SEQ_DELTA_PROG * 5 * 2, n * 4 * 2,
+                          n * 4 * RMJ_SEQ_CAND * 4 * 2, n * 4};
+    size_t off[8] = {0};
+    for (int i = 0; i < 7; i++) off[i + 1] = off[i] + ((sz[i] + 255) & ~(size_t)255);
+    void* sp;
+    int rc = scratch_for(h, off[7], &sp);
+    if (rc) return rc;
+    char* b = (char*)sp;
+    RmjSeqDeltaBuffers d{(uint16_t*)(b + off[0]), (uint8_t*)(b + off[1]), (float*)(b + off[2]), (uint16_t*)(b + off[3]), (uint16_t*)(b + off[4]),
+                         (uint16_t*)(b + off[5]), (uint8_t*)(b + off[6])};
+    if ((rc = rmj_encode_seq_delta_device(h, game_style, &d))) return rc;
+    HIPCHK(hipStreamSynchronize(h->stream));
+    void* dst[7] = {out->sparse, out->n_sparse, out->numeric, out->progression, out->n_progression, out->candidates, out->n_candidates};
+    for (int i = 0; i < 7; i++) {
+        if (!dst[i]) return fail(RMJ_ERR_ARG, "null output array");
+        HIPCHK(hipMemcpy(dst[i], b + off[i], sz[i], hipMemcpyDeviceToHost));
+    }
+    return RMJ_OK;
+}
+
 int rmj_encode_extended_device(rmj_handle h, int only_active, float* d_out) { return launch_encode(h, only_active, d_out, true); }
 int rmj_encode_extended(rmj_handle h, int only_active, float* out) {
     if (!h || !out) return fail(RMJ_ERR_ARG, "null argument");

@@ -5,6 +5,7 @@ namespace RMJ_NS {
 __device__ __noinline__ void ol_env_reset_default(CtxV v) {
     CTX_FROM(v);
     c.S.ev_count = 0;  // GameState::reset clears the logs (state/mod.rs:171-187)
+    if (c.lane < 4) { c.S.obs_from[c.lane] = 0; c.S.obs_upto[c.lane] = 0; }
     emit_simple(c, RMJ_EV_START_GAME);
     const int32_t st = KSANMA ? 35000 : 25000;  // state_3p/game_mode.rs:31-33
     const int32_t sc[4] = {st, st, st, st};
@@ -149,6 +150,7 @@ __global__ __launch_bounds__(256, 4) void k_reset(const Env* __restrict__ Ep, Re
         init_round(c, 0, (int)E.ctor_round_wind, 0, 0, nullptr);
     } else {          // env.rs:799-851
         S.ev_count = 0;
+        if (lane < 4) { S.obs_from[lane] = 0; S.obs_upto[lane] = 0; }
         emit_simple(c, RMJ_EV_START_GAME);
         if (A.scores)
             for (int p = 0; p < 4; p++) sc[p] = A.scores[(size_t)g * 4 + p];
@@ -179,7 +181,7 @@ __global__ __launch_bounds__(256, 4) void k_apply_event(const Env* __restrict__ 
     load_state(S, E.core + g, lane);
     Ctx c{S, E, sh.x[wave], g, lane, E.wall + (size_t)g * RMJ_WALL_STRIDE, E.legal + (size_t)g * 4 * RMJ_MAX_LEGAL};
     apply_event(c, mine);
-    finalize_outputs<false>(c, true);
+    finalize_outputs<false>(c, true, false);  // apply_event hands out no observation (env.rs:880-887)
     store_state(S, E.core + g, lane);
 }
 
@@ -193,7 +195,7 @@ __global__ __launch_bounds__(64, 4) void k_refresh(const Env* __restrict__ Ep, u
     Ctx c{st, E, x, g, lane, E.wall + (size_t)g * RMJ_WALL_STRIDE, E.legal + (size_t)g * 4 * RMJ_MAX_LEGAL};
     bool keep = st.phase == RMJ_WAIT_RESPONSE && st.pending_kan_pid != 0xFF;  // chankan claims are not reconstructible
     if (!keep) {
-        finalize_outputs<false>(c, false);
+        finalize_outputs<false>(c, false, false);
         store_state(st, E.core + g, lane);
     }
 }

@@ -85,7 +85,10 @@ struct alignas(16) GState {  // 4*128 + 128 = 640 bytes
     uint8_t nlegal[4];        // copy of the nlegal slab row: the policy / validation need it as soon as the record arrives
     uint8_t pad0_[3];
     uint32_t full_count;      // measurement only: steps of this game that took the full path of k_step (bench.py)
-    uint8_t pad[128 - 8 - 8 - 20 - 16 - 4 - 6 - 3 - 4 - 4 - 3 - 4];
+    // player_event_counts of the reference (state/mod.rs:65, 211-218): the events [obs_from[p], obs_upto[p]) are the delta
+    // (Observation.events) of seat p's latest observation; advanced whenever observations are published for an acting seat
+    uint32_t obs_from[4], obs_upto[4];
+    uint8_t pad[128 - 8 - 8 - 20 - 16 - 4 - 6 - 3 - 4 - 4 - 3 - 4 - 32];
 };
 
 #ifdef __cplusplus

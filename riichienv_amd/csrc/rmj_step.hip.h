@@ -2197,7 +2197,7 @@ __device__ inline void apply_event(Ctx& c, const RmjEvent* ev) {
 // After a transition: produce the observation-side outputs for the new state
 // (get_observations(active_players), env.rs:870-871 -> state/mod.rs:189-263; mask: observation/python.rs:98-111)
 template <bool FAST = false>
-__device__ __forceinline__ void finalize_outputs(Ctx& c, bool claims_fresh) {
+__device__ __forceinline__ void finalize_outputs(Ctx& c, bool claims_fresh, bool observe = true) {
     GState& S = c.S;
     const int lane = c.lane;
     const int phase = U((int)S.phase);
@@ -2255,6 +2255,10 @@ __device__ __forceinline__ void finalize_outputs(Ctx& c, bool claims_fresh) {
         c.E.nlegal[(size_t)c.g * 4 + lane] = (uint8_t)n;
         S.nlegal[lane] = (uint8_t)n;
         c.E.waits[(size_t)c.g * 4 + lane] = acts ? c.X.wout[lane] : 0ull;
+        if (observe && acts && !S.is_done) {  // get_observation advances the seat's event cursor (state/mod.rs:211-218)
+            S.obs_from[lane] = S.obs_upto[lane];
+            S.obs_upto[lane] = S.ev_count;
+        }
     }
     if (lane == 0) c.E.status[c.g] = (uint32_t)S.active_mask | ((uint32_t)S.phase << 8) | ((uint32_t)S.is_done << 16);
     PROF(c.X, lane, 14);

@@ -30,6 +30,7 @@ EXPORTS = [
     "rmj_scores_device", "rmj_sync", "rmj_set_stream", "rmj_encode", "rmj_encode_device", "rmj_encode_extended", "rmj_encode_extended_device", "rmj_encode_aux", "rmj_encode_aux_device", "rmj_encode_seq", "rmj_encode_seq_device", "rmj_bench_rollout",
     "rmj_bench_rollout_validated", "rmj_bench_encode", "rmj_set_rollout_streams", "rmj_total_full_path",
     "rmj_random_actions_device", "rmj_peek_outputs", "rmj_sample_ids_device",
+    "rmj_encode_seq_delta", "rmj_encode_seq_delta_device",
 ]
 
 
@@ -118,6 +119,8 @@ def load_lib():
     L.rmj_random_actions_device.argtypes = [vp, C.c_uint64, vp]
     L.rmj_peek_outputs.argtypes = [vp, C.c_uint32, vp, vp, vp, vp, C.POINTER(C.c_uint32)]
     L.rmj_sample_ids_device.argtypes = [vp, vp, C.c_uint32, C.c_uint64, vp]
+    L.rmj_encode_seq_delta.argtypes = [vp, C.c_int, C.POINTER(abi.SeqBuffers)]          # same field layout as RmjSeqBuffers
+    L.rmj_encode_seq_delta_device.argtypes = [vp, C.c_int, C.POINTER(abi.SeqBuffers)]
     _LIB = L
     return L
 
@@ -358,6 +361,19 @@ class VecRiichiEnv:
         b = abi.SeqBuffers(*[out[k].ctypes.data for k in ("sparse", "n_sparse", "numeric", "progression", "n_progression",
                                                             "candidates", "n_candidates")])
         _chk(self.L.rmj_encode_seq(self.h, int(game_style), C.byref(b)))
+        return out
+
+    def encode_seq_delta(self, game_style=1):
+        """The sequence features over the events of the seats' latest observation, like the reference's live environment
+        (header: rmj_encode_seq_delta): progression is per seat [n,4,64,5]; seats that are not to act get empty outputs."""
+        n = self.n
+        out = dict(sparse=np.zeros((n, 4, abi.SEQ_SPARSE), np.uint16), n_sparse=np.zeros((n, 4), np.uint8),
+                   numeric=np.zeros((n, 4, 12), np.float32), progression=np.zeros((n, 4, abi.SEQ_DELTA_PROG, 5), np.uint16),
+                   n_progression=np.zeros((n, 4), np.uint16), candidates=np.zeros((n, 4, abi.SEQ_CAND, 4), np.uint16),
+                   n_candidates=np.zeros((n, 4), np.uint8))
+        b = abi.SeqBuffers(*[out[k].ctypes.data for k in ("sparse", "n_sparse", "numeric", "progression", "n_progression",
+                                                            "candidates", "n_candidates")])
+        _chk(self.L.rmj_encode_seq_delta(self.h, int(game_style), C.byref(b)))
         return out
 
     def bench_rollout(self, policy_seed, warmup, steps) -> abi.BenchResult:

@@ -98,3 +98,74 @@ def test_compat_observation_seq_features():
     o3 = next(iter(env3.reset().values()))
     with pytest.raises(AttributeError):
         o3.encode_seq_numeric()
+
+
+@pytest.mark.parametrize("mode,seed", [(2, 21), (0, 100)])
+def test_seq_features_per_observation_delta(mode, seed):
+    """rmj_encode_seq_delta: the features over Observation.events as the reference's LIVE environment hands them out - the
+    seat's log since its previous observation (state/mod.rs:211-218).  The harness keeps the oracle seats' cursors exactly
+    like get_observation does (advanced for every acting seat after reset and after every step) and feeds the Python
+    restatement of sequence_features.rs with that delta."""
+    from oracle import oracle
+    from oracle import seq_features as sf
+    from riichienv_amd import vecenv
+
+    n, pseed = 12, 5
+    env = vecenv.VecRiichiEnv(n, game_mode=mode, seed=seed, event_ring=256)
+    games = [oracle.Game(game_mode=mode, seed=game_seed(seed, g)) for g in range(n)]
+    env.reset()
+    cursor = [[0] * 4 for _ in range(n)]
+    delta = [[[] for _ in range(4)] for _ in range(n)]
+
+    def observe(g):
+        a, _, dn = games[g].status()
+        for p in range(4):
+            if (a >> p) & 1 and not dn:
+                log = games[g].log(p)
+                delta[g][p] = log[cursor[g][p]:]
+                cursor[g][p] = len(log)
+
+    for g, o in enumerate(games):
+        o.reset()
+        observe(g)
+    seen_reach_without_draw = seen_start = 0
+    for step in range(700):
+        # every fifth step, and whenever some acting seat's delta is just its own reach (the live-environment special case)
+        after_reach = any(len(delta[g][p]) == 1 and '"reach"' in delta[g][p][0] and (games[g].status()[0] >> p) & 1
+                          for g in range(n) for p in range(4))
+        if step % 5 == 0 or after_reach:
+            out = env.encode_seq_delta(1)
+            for g, o in enumerate(games):
+                a, _, dn = o.status()
+                for p in range(4):
+                    acts = bool((a >> p) & 1) and not dn
+                    npg = int(out["n_progression"][g, p])
+                    if not acts:
+                        assert npg == 0 and int(out["n_candidates"][g, p]) == 0
+                        continue
+                    ev = delta[g][p]
+                    want = sf.progression(ev, cap=64)
+                    got = [tuple(int(x) for x in r) for r in out["progression"][g, p, :npg]]
+                    assert got == want, (step, g, p, got, want)
+                    assert (out["progression"][g, p, npg:] == np.array(sf.PROG_PAD, np.uint16)).all()
+                    obs = sf.observation_of(o, p)
+                    tok = sf.sparse(obs, ev, 1)
+                    ns = int(out["n_sparse"][g, p])
+                    assert [int(x) for x in out["sparse"][g, p, :ns]] == tok, (step, g, p)
+                    assert [float(x) for x in out["numeric"][g, p]] == sf.numeric(obs, ev), (step, g, p)
+                    cand = sf.candidates(obs, ev, o.legal(p))
+                    nc = int(out["n_candidates"][g, p])
+                    assert [tuple(int(x) for x in r) for r in out["candidates"][g, p, :nc]] == cand, (step, g, p)
+                    # the live-environment effects the round-based variant cannot show
+                    v = o.peek()
+                    if v.drawn_tile >= 0 and v.current_player == p and sf.get_drawn_tile(ev, p) is None:
+                        seen_reach_without_draw += 1
+                    seen_start += any('"start_kyoku"' in s for s in ev)
+        acts = np.array([games[g].random_actions(pseed, g) for g in range(n)], dtype=np.uint64)
+        env.step(acts)
+        for g in range(n):
+            games[g].step([int(x) for x in acts[g]])
+            observe(g)
+    assert seen_start > 0
+    if mode == 2:
+        assert seen_reach_without_draw > 0   # after its own reach the seat's delta no longer holds the tsumo

@@ -70,7 +70,9 @@ def test_fused_masked_sampler(mode):
     env = TorchVecEnv(n, game_mode=mode, seed=77, share_stream=True)
     for k in range(60):
         env.step(env.sample_ids(seed=k))
-    act = env.active()
+    # a seat that is to act but has NO legal action gets -1: the reference can deadlock a 3P seat that declared Riichi and
+    # then Kita (legal in the riichi stage, state_3p/legal_actions.rs:241-243) when no tenpai-keeping discard is left
+    act = env.active() & (env.nlegal > 0)
     mask = env.mask.to(torch.bool)
     ids = env.sample_ids(seed=123).clone()
     assert ((ids >= 0) == act).all()

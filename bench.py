@@ -188,17 +188,15 @@ def main(argv=None):
 
     obs = None
     if args.encode:
-        import ctypes as C
-
         obs = torch.zeros((args.games, 4, 74, 27 if sanma else 34), dtype=torch.float32, device=f"cuda:{local_rank}")
     full0 = env.total_full_path()
     barrier()
     t0 = time.perf_counter()
     if args.encode:
         before = env.total_steps()
-        for _ in range(args.steps):   # one step launch + one encode launch per step, same stream, no host sync in between
-            env.step_random(policy_seed, 1, auto_reset=True)
-            vecenv._chk(env.L.rmj_encode_device(env.h, 2, C.c_void_p(obs.data_ptr())))
+        # every step of every game is followed by encode() of its acting seats into the resident tensor; like the plain
+        # rollout, the batch runs as four parts on four streams (step, encode, step, encode ... per part)
+        env.step_random_encode(policy_seed, args.steps, obs.data_ptr(), auto_reset=True, only_active=2)
         steps_local = float(env.total_steps() - before)   # synchronises the stream
         r = None
     else:

@@ -255,6 +255,11 @@ int rmj_calculate_score(int device, const uint8_t* han, const uint8_t* fu, const
  * are left untouched (no HBM traffic for them; meant for resident device buffers) */
 int rmj_encode(rmj_handle h, int only_active, float* out);
 int rmj_encode_device(rmj_handle h, int only_active, float* d_out); /* device pointer, asynchronous on the handle's stream */
+/* Device-policy rollout WITH feature output (BASELINE configs[4]): n_steps x (one step of every game, then encode() of the
+ * seats that are to act into the resident tensor d_out).  Same results as calling rmj_step_random(h, seed, 1, auto_reset)
+ * and rmj_encode_device(h, only_active, d_out) n_steps times; issued like rmj_step_random as up to four parts of the batch on
+ * as many HIP streams, each part running step, encode, step, encode ... in order. */
+int rmj_step_random_encode(rmj_handle h, uint64_t policy_seed, uint32_t n_steps, int auto_reset, int only_active, float* d_out);
 
 /* Observation.encode_extended (observation/python.rs:1271-1296): 215 channels = encode() + discard decay (4), shanten
  * efficiency (16), ankan (4), fuuro (80), action availability (11), discard candidates (5), pass context (3), last

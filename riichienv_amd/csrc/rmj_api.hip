@@ -339,12 +339,75 @@ __device__ __forceinline__ void enc_stream_out(float* dst, const float* buf, int
         for (int i = lane; i < n_floats; i += 64) dst[i] = buf[i];
     }
 }
+// n_floats floats from LDS to global memory in 16-byte stores: `dst` is 8-byte aligned (every row of the tensors is an even
+// number of floats from a 16-byte aligned base), so at most two floats precede the first 16-byte boundary and at most
+// three follow the last; the body goes out as dwordx4 (the epilogue of a wave is store-issue bound: half the instructions
+// of the 8-byte version).  The LDS side is read as two 8-byte halves (its offset is only 8-byte aligned after the head).
+__device__ __forceinline__ void enc_stream_out16(float* dst, const float* buf, int n_floats, int lane) {
+    const int head = (int)(((16u - (uint32_t)(reinterpret_cast<uintptr_t>(dst) & 15u)) & 15u) >> 2);  // 0 or 2
+    const int body = (n_floats - head) >> 2, tail0 = head + 4 * body;
+    if (lane < head) dst[lane] = buf[lane];
+    float4* d4 = reinterpret_cast<float4*>(dst + head);
+    for (int i = lane; i < body; i += 64) {
+        const float2 lo = *reinterpret_cast<const float2*>(buf + head + 4 * i), hi = *reinterpret_cast<const float2*>(buf + head + 4 * i + 2);
+        d4[i] = make_float4(lo.x, lo.y, hi.x, hi.y);
+    }
+    if (lane < n_floats - tail0) dst[tail0 + lane] = buf[tail0 + lane];
+}
+__device__ __forceinline__ void enc_zero16(float* dst, int n_floats, int lane) {
+    const int head = (int)(((16u - (uint32_t)(reinterpret_cast<uintptr_t>(dst) & 15u)) & 15u) >> 2);
+    const int body = (n_floats - head) >> 2, tail0 = head + 4 * body;
+    if (lane < head) dst[lane] = 0.0f;
+    float4* d4 = reinterpret_cast<float4*>(dst + head);
+    for (int i = lane; i < body; i += 64) d4[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (lane < n_floats - tail0) dst[tail0 + lane] = 0.0f;
+}
+// Observation.encode() of the games [g0, g0 + gridDim.x): ONE block (= one wave) per game, which walks the seats it has to
+// encode - with only_active that is the acting seat (one, rarely two or three), so the launch has a quarter of the blocks of
+// a (game, seat) grid and no early-exit blocks.  The 74 channels of a seat are produced in windows of 16 into a 2 KB LDS
+// buffer and streamed out window by window (16 x W x 4 B: a multiple of 16 bytes for W = 34 and W = 27).
+template <bool SANMA, int ENC_WINDOW>
+__global__ __launch_bounds__(64) void k_encode_base(Env E, int only_active, float* __restrict__ out, uint32_t g0) {
+    constexpr int W = SANMA ? ENC_W3 : ENC_W4, NPP = SANMA ? 3 : 4;
+    __shared__ GState st;
+    __shared__ __attribute__((aligned(16))) float buf[ENC_WINDOW * W];
+    __shared__ uint32_t hist[ENC_HIST_WORDS];
+    const int lane = threadIdx.x & 63;
+    const uint32_t g = g0 + blockIdx.x;
+    // the record is requested together with the status word (nearly every game has a seat to act): one memory round trip
+    uint4 rec = make_uint4(0u, 0u, 0u, 0u);
+    if (lane < (int)(sizeof(GState) / 16)) rec = reinterpret_cast<const uint4*>(E.core + g)[lane];
+    const uint32_t stw = E.status[g];
+    const uint32_t am = ((stw >> 16) & 0xFFu) ? 0u : (stw & 0xFu);
+    float* base = out + (size_t)g * 4 * ENC_CH * W;
+    if (only_active && am == 0u) {
+        if (only_active == 1) enc_zero16(base, 4 * ENC_CH * W, lane);
+        return;
+    }
+    if (lane < (int)(sizeof(GState) / 16)) reinterpret_cast<uint4*>(&st)[lane] = rec;
+    wave_sync();
+    const GState& S = st;
+    for (int seat = 0; seat < 4; seat++) {
+        float* dst = base + (size_t)seat * ENC_CH * W;
+        const bool acts = (am >> seat) & 1u;
+        if (seat >= NPP || (only_active && !acts)) {
+            if (only_active != 2) enc_zero16(dst, ENC_CH * W, lane);
+            continue;
+        }
+        for (int c0 = 0; c0 < ENC_CH; c0 += ENC_WINDOW) {
+            const int n = ENC_CH - c0 < ENC_WINDOW ? ENC_CH - c0 : ENC_WINDOW;
+            encode_seat<SANMA>(S, seat, buf, lane, hist, c0, n, c0 == 0);
+            enc_stream_out16(dst + c0 * W, buf, n * W, lane);
+            wave_sync();
+        }
+    }
+}
 template <bool SANMA, bool EXT>
 __global__ __launch_bounds__(64) void k_encode(Env E, int only_active, const float* __restrict__ decay, float* __restrict__ out) {
     constexpr int W = SANMA ? ENC_W3 : ENC_W4;
     constexpr int CH = EXT ? ENC_EXT_CH : ENC_CH;
     __shared__ GState st;
-    __shared__ float buf[ENC_EXT_C_SLOTS * W];
+    __shared__ __attribute__((aligned(16))) float buf[ENC_EXT_C_SLOTS * W];
     __shared__ uint32_t hist[ENC_HIST_WORDS];
     const int lane = threadIdx.x & 63;
     const uint32_t g = blockIdx.x >> 2;
@@ -638,6 +701,7 @@ struct DevTmp {
 };
 
 static int shanten_tables_for(int device, ShantenTables* out);
+static void launch_encode_base_range(rmj_env* h, hipStream_t st, int only_active, float* d_out, uint32_t g0, uint32_t g1);
 
 extern "C" {
 
@@ -882,6 +946,39 @@ int rmj_step_random(rmj_handle h, uint64_t policy_seed, uint32_t n_steps, int au
         }
     } else {
         for (uint32_t s = 0; s < n_steps; s++) launch_step_range(h, h->stream, nullptr, policy_seed, flags, 0u, n);
+    }
+    HIPCHK(hipGetLastError());
+    return RMJ_OK;
+}
+// The feature-output rollout of BASELINE configs[4]: every step of the device-policy rollout is followed by Observation.encode()
+// of the seats that are to act, written into the resident tensor d_out [n][4][74][W] (only_active as in rmj_encode_device).
+// Same results as n_steps x (rmj_step_random(h, seed, 1, auto_reset); rmj_encode_device(h, only_active, d_out)); issued like
+// rmj_step_random as up to four parts of the batch on as many streams, each part running step, encode, step, encode ...
+int rmj_step_random_encode(rmj_handle h, uint64_t policy_seed, uint32_t n_steps, int auto_reset, int only_active, float* d_out) {
+    if (!h || !d_out) return fail(RMJ_ERR_ARG, "null argument");
+    HIPCHK(hipSetDevice(h->cfg.device));
+    const uint32_t flags = STEP_F_RANDOM | (auto_reset ? STEP_F_AUTORESET : 0u);
+    const uint32_t n = h->cfg.n_games;
+    const int k = rollout_streams(h, n_steps);
+    if (k >= 2) {
+        HIPCHK(hipEventRecord(h->ev_fork, h->stream));
+        for (int i = 1; i < k; i++) HIPCHK(hipStreamWaitEvent(h->xstream[i - 1], h->ev_fork, 0));
+        for (uint32_t s = 0; s < n_steps; s++)
+            for (int i = 0; i < k; i++) {
+                hipStream_t st = i ? h->xstream[i - 1] : h->stream;
+                const uint32_t g0 = (uint32_t)((uint64_t)n * i / k), g1 = (uint32_t)((uint64_t)n * (i + 1) / k);
+                launch_step_range(h, st, nullptr, policy_seed, flags, g0, g1);
+                launch_encode_base_range(h, st, only_active, d_out, g0, g1);
+            }
+        for (int i = 1; i < k; i++) {
+            HIPCHK(hipEventRecord(h->ev_join[i - 1], h->xstream[i - 1]));
+            HIPCHK(hipStreamWaitEvent(h->stream, h->ev_join[i - 1], 0));
+        }
+    } else {
+        for (uint32_t s = 0; s < n_steps; s++) {
+            launch_step_range(h, h->stream, nullptr, policy_seed, flags, 0u, n);
+            launch_encode_base_range(h, h->stream, only_active, d_out, 0u, n);
+        }
     }
     HIPCHK(hipGetLastError());
     return RMJ_OK;
@@ -1373,6 +1470,14 @@ int rmj_calculate_score(int device, const uint8_t* han, const uint8_t* fu, const
 }
 
 // ---- feature encoder (row A14) --------------------------------------------------------------------
+// Observation.encode() of the games [g0, g1) on stream `st`.  The whole 74-channel tensor of a seat is staged at once: windows
+// of 37 / 16 channels (more resident waves, the seat's work repeated per window) measured 0.195 / 0.35 ms against 0.19 ms
+// for 65 536 4P games - the kernel is bound by its own instruction stream and the store epilogue, not by occupancy.
+static void launch_encode_base_range(rmj_env* h, hipStream_t st, int only_active, float* d_out, uint32_t g0, uint32_t g1) {
+    const dim3 grid(g1 - g0), block(64);
+    if (h->cfg.game_mode >= 3) hipLaunchKernelGGL((k_encode_base<true, ENC_CH>), grid, block, 0, st, h->d, only_active, d_out, g0);
+    else hipLaunchKernelGGL((k_encode_base<false, ENC_CH>), grid, block, 0, st, h->d, only_active, d_out, g0);
+}
 static int launch_encode(rmj_handle h, int only_active, float* d_out, bool ext) {
     if (!h || !d_out) return fail(RMJ_ERR_ARG, "null argument");
     HIPCHK(hipSetDevice(h->cfg.device));
@@ -1380,9 +1485,8 @@ static int launch_encode(rmj_handle h, int only_active, float* d_out, bool ext) 
     const float* decay = h->d_decay;
     const bool sanma = h->cfg.game_mode >= 3;
     if (sanma && ext) hipLaunchKernelGGL((k_encode<true, true>), grid, block, 0, h->stream, h->d, only_active, decay, d_out);
-    else if (sanma) hipLaunchKernelGGL((k_encode<true, false>), grid, block, 0, h->stream, h->d, only_active, decay, d_out);
     else if (ext) hipLaunchKernelGGL((k_encode<false, true>), grid, block, 0, h->stream, h->d, only_active, decay, d_out);
-    else hipLaunchKernelGGL((k_encode<false, false>), grid, block, 0, h->stream, h->d, only_active, decay, d_out);
+    else launch_encode_base_range(h, h->stream, only_active, d_out, 0u, h->cfg.n_games);
     HIPCHK(hipGetLastError());
     return RMJ_OK;
 }

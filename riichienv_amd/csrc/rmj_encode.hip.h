@@ -51,43 +51,62 @@ __device__ __forceinline__ int enc_next_tile136_sanma(int tile) {
 // `hist`: 5 x 36 u32 of LDS scratch (type histograms of the four seats' visible tiles and of the own hand)
 #define ENC_HIST_WORDS (5 * 36)
 template <bool SANMA>
-__device__ inline void encode_seat(const GState& S, int pid, float* buf, int lane, uint32_t* hist) {
+// The channels [ch_lo, ch_lo + ch_n) are produced into buf[0 .. ch_n * W): the whole tensor (0, 74) for the extended
+// encoder, windows of 16 channels for the base encoder (a 2 KB staging buffer keeps eight waves per SIMD resident where
+// the whole 10 KB tensor allowed three: the kernel is bound by the latency of its dependent loads and of the store
+// stream, not by instruction issue).  `first` = build the type histograms (they serve every window of the seat).
+__device__ inline void encode_seat(const GState& S, int pid, float* buf, int lane, uint32_t* hist, int ch_lo = 0, int ch_n = ENC_CH,
+                                   bool first = true) {
     constexpr int ENC_W = SANMA ? ENC_W3 : ENC_W4;
     constexpr int NPP = SANMA ? 3 : 4;
+    auto slot = [&](int ch) { const int k = ch - ch_lo; return (k >= 0 && k < ch_n) ? k : -1; };
     auto enc_bcast = [&](float* b, int ch, float v, int l) {
-        if (l < ENC_W) b[ch * ENC_W + l] = v;
+        const int k = slot(ch);
+        if (k >= 0 && l < ENC_W) b[k * ENC_W + l] = v;
     };
     auto put = [&](int ch, int t34) {  // scatter one cell (skips tiles without a column)
         int col = enc_col<SANMA>(t34);
-        if (col >= 0) buf[ch * ENC_W + col] = 1.0f;
+        const int k = slot(ch);
+        if (k >= 0 && col >= 0) buf[k * ENC_W + col] = 1.0f;
+    };
+    auto cell = [&](int ch, float v) {   // this lane's column of channel ch
+        const int k = slot(ch);
+        if (k >= 0 && lane < ENC_W) buf[k * ENC_W + lane] = v;
     };
     const int my34 = SANMA ? (lane == 0 ? 0 : lane + 7) : lane;  // tile type of this lane's column
-    for (int i = lane; i < ENC_CH * ENC_W; i += 64) buf[i] = 0.0f;
-    for (int i = lane; i < ENC_HIST_WORDS; i += 64) hist[i] = 0u;
+    {   // zero the window: 16-byte LDS stores (buf is 16-byte aligned), then the odd floats
+        const int n4 = (ch_n * ENC_W) >> 2;
+        for (int i = lane; i < n4; i += 64) reinterpret_cast<float4*>(buf)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (lane < ((ch_n * ENC_W) & 3)) buf[4 * n4 + lane] = 0.0f;
+    }
+    if (first)
+        for (int i = lane; i < ENC_HIST_WORDS; i += 64) hist[i] = 0u;
     wave_sync();
     const PState& P = S.p[pid];
     // type histograms by LDS atomics, lane = tile slot: hist[q] = melds + discards of seat q, hist[4] = own hand
-    for (int q = 0; q < NPP; q++) {
-        const PState& Q = S.p[q];
-        if (lane < Q.n_discards) atomicAdd(&hist[q * 36 + (Q.discards[lane] >> 2)], 1u);
-        if (lane < 16) {
-            const int m = lane >> 2, k = lane & 3;
-            if (m < Q.n_melds && k < ((Q.meld_type[m] >= RMJ_MELD_DAIMINKAN) ? 4 : 3)) atomicAdd(&hist[q * 36 + (Q.meld_tiles[m][k] >> 2)], 1u);
+    if (first) {
+        for (int q = 0; q < NPP; q++) {
+            const PState& Q = S.p[q];
+            if (lane < Q.n_discards) atomicAdd(&hist[q * 36 + (Q.discards[lane] >> 2)], 1u);
+            if (lane < 16) {
+                const int m = lane >> 2, k = lane & 3;
+                if (m < Q.n_melds && k < ((Q.meld_type[m] >= RMJ_MELD_DAIMINKAN) ? 4 : 3)) atomicAdd(&hist[q * 36 + (Q.meld_tiles[m][k] >> 2)], 1u);
+            }
         }
+        if (lane < P.hand_len) atomicAdd(&hist[4 * 36 + (P.hand[lane] >> 2)], 1u);
     }
     if (lane < P.hand_len) {
         const int t = P.hand[lane];
-        atomicAdd(&hist[4 * 36 + (t >> 2)], 1u);
         if (is_aka(t)) put(4, t >> 2);   // red five in hand (ch 4)
     }
     wave_sync();
     // 1-2. hand counts (ch 0-3)
     if (lane < ENC_W) {
         const int c = (int)hist[4 * 36 + my34];
-        if (c >= 1) buf[0 * ENC_W + lane] = 1.0f;
-        if (c >= 2) buf[1 * ENC_W + lane] = 1.0f;
-        if (c >= 3) buf[2 * ENC_W + lane] = 1.0f;
-        if (c >= 4) buf[3 * ENC_W + lane] = 1.0f;
+        if (c >= 1) cell(0, 1.0f);
+        if (c >= 2) cell(1, 1.0f);
+        if (c >= 3) cell(2, 1.0f);
+        if (c >= 4) cell(3, 1.0f);
     }
     // 3. own melds (ch 5-8), 4. dora indicators (ch 9)
     if (lane < 16) {
@@ -148,9 +167,11 @@ __device__ inline void encode_seat(const GState& S, int pid, float* buf, int lan
     enc_bcast(buf, 37, (float)S.honba / 10.0f, lane);
     enc_bcast(buf, 38, (float)S.riichi_sticks / 5.0f, lane);
     // 14-15. waits / tenpai (ch 47-48)
-    uint64_t W = enc_waits(P, lane);
-    if (lane < ENC_W && ((W >> my34) & 1ull)) buf[47 * ENC_W + lane] = 1.0f;
-    enc_bcast(buf, 48, W != 0ull ? 1.0f : 0.0f, lane);
+    if (slot(47) >= 0 || slot(48) >= 0) {   // (wave-uniform) only the window that holds the wait channels pays for the probe
+        uint64_t W = enc_waits(P, lane);
+        if (lane < ENC_W && ((W >> my34) & 1ull)) cell(47, 1.0f);
+        enc_bcast(buf, 48, W != 0ull ? 1.0f : 0.0f, lane);
+    }
     if (rank < NPP) enc_bcast(buf, 49 + rank, 1.0f, lane);
     enc_bcast(buf, 53, (float)S.kyoku_idx / 8.0f, lane);
     enc_bcast(buf, 54, ((float)S.round_wind * 4.0f + (float)S.kyoku_idx) / 7.0f, lane);
@@ -170,7 +191,7 @@ __device__ inline void encode_seat(const GState& S, int pid, float* buf, int lan
             int seen = (int)hist[4 * 36 + my34];
             for (int q = 0; q < NPP; q++) seen += (int)hist[q * 36 + my34];
             for (int k = 0; k < S.n_dora; k++) seen += ((S.dora[k] >> 2) == my34);
-            buf[63 * ENC_W + lane] = (float)(seen & 0xFF) / 4.0f;
+            cell(63, (float)(seen & 0xFF) / 4.0f);
         }
         for (int rel = 0; rel < NPP; rel++) {
             int q = (pid + rel) % NPP;

@@ -30,7 +30,7 @@ EXPORTS = [
     "rmj_scores_device", "rmj_sync", "rmj_set_stream", "rmj_encode", "rmj_encode_device", "rmj_encode_extended", "rmj_encode_extended_device", "rmj_encode_aux", "rmj_encode_aux_device", "rmj_encode_seq", "rmj_encode_seq_device", "rmj_bench_rollout",
     "rmj_bench_rollout_validated", "rmj_bench_encode", "rmj_set_rollout_streams", "rmj_total_full_path",
     "rmj_random_actions_device", "rmj_peek_outputs", "rmj_sample_ids_device",
-    "rmj_encode_seq_delta", "rmj_encode_seq_delta_device",
+    "rmj_encode_seq_delta", "rmj_encode_seq_delta_device", "rmj_step_random_encode",
 ]
 
 
@@ -119,6 +119,7 @@ def load_lib():
     L.rmj_random_actions_device.argtypes = [vp, C.c_uint64, vp]
     L.rmj_peek_outputs.argtypes = [vp, C.c_uint32, vp, vp, vp, vp, C.POINTER(C.c_uint32)]
     L.rmj_sample_ids_device.argtypes = [vp, vp, C.c_uint32, C.c_uint64, vp]
+    L.rmj_step_random_encode.argtypes = [vp, C.c_uint64, C.c_uint32, C.c_int, C.c_int, vp]
     L.rmj_encode_seq_delta.argtypes = [vp, C.c_int, C.POINTER(abi.SeqBuffers)]          # same field layout as RmjSeqBuffers
     L.rmj_encode_seq_delta_device.argtypes = [vp, C.c_int, C.POINTER(abi.SeqBuffers)]
     _LIB = L
@@ -234,6 +235,11 @@ class VecRiichiEnv:
 
     def step_random(self, policy_seed, n_steps=1, auto_reset=False):
         _chk(self.L.rmj_step_random(self.h, policy_seed, n_steps, int(auto_reset)))
+
+    def step_random_encode(self, policy_seed, n_steps, d_out_ptr, auto_reset=True, only_active=2):
+        """n_steps x (step of every game + encode() of the acting seats into the device tensor at d_out_ptr): header
+        rmj_step_random_encode (BASELINE configs[4])."""
+        _chk(self.L.rmj_step_random_encode(self.h, policy_seed, n_steps, int(auto_reset), int(only_active), C.c_void_p(d_out_ptr)))
 
     def random_actions(self, policy_seed):
         a = np.zeros((self.n, 4), np.uint64)

@@ -166,3 +166,28 @@ def test_65536_games_3p_with_feature_tensor():
                 assert rows[k, s].tobytes() == ref.tobytes(), (g, s, np.argwhere(rows[k, s] != ref)[:5])
                 checked += 1
     assert checked >= len(sample) // 2
+
+
+def test_fused_feature_rollout_equals_step_then_encode():
+    """rmj_step_random_encode (four parts on four streams, step + encode per part and step) must leave exactly the tensor
+    and the states of the unfused loop rmj_step_random(1) + rmj_encode_device per step."""
+    import torch
+
+    from riichienv_amd import vecenv
+
+    n, steps, mode = 32768, 120, 5
+    a = vecenv.VecRiichiEnv(n, game_mode=mode, seed=SEED, event_ring=64)
+    b = vecenv.VecRiichiEnv(n, game_mode=mode, seed=SEED, event_ring=64)
+    a.reset()
+    b.reset()
+    oa = torch.zeros((n, 4, 74, 27), dtype=torch.float32, device="cuda:0")
+    ob = torch.zeros((n, 4, 74, 27), dtype=torch.float32, device="cuda:0")
+    a.step_random_encode(PSEED, steps, oa.data_ptr(), auto_reset=True, only_active=2)
+    for _ in range(steps):
+        b.step_random(PSEED, 1, auto_reset=True)
+        vecenv._chk(b.L.rmj_encode_device(b.h, 2, C.c_void_p(ob.data_ptr())))
+    a.L.rmj_sync(a.h)
+    b.L.rmj_sync(b.h)
+    assert torch.equal(oa, ob)
+    assert (a.step_counts() == b.step_counts()).all() and (a.scores() == b.scores()).all()
+    assert float(oa.abs().sum()) > 0

@@ -100,7 +100,7 @@ def test_compat_observation_seq_features():
         o3.encode_seq_numeric()
 
 
-@pytest.mark.parametrize("mode,seed", [(2, 21), (0, 100)])
+@pytest.mark.parametrize("mode,seed", [(2, 29), (0, 100)])
 def test_seq_features_per_observation_delta(mode, seed):
     """rmj_encode_seq_delta: the features over Observation.events as the reference's LIVE environment hands them out - the
     seat's log since its previous observation (state/mod.rs:211-218).  The harness keeps the oracle seats' cursors exactly

@@ -212,6 +212,19 @@ int rmj_peek_outputs(rmj_handle h, uint32_t game, rmj_action_t* legal, uint8_t* 
                      uint32_t* status);
 int rmj_poke_state(rmj_handle h, uint32_t game, const RmjStateView* in); /* recomputes legal actions */
 
+/* RiichiEnv.win_results (env.rs:606-607; state/mod.rs:60, 863, 1107, 1729): the WinResult of every seat that won the
+ * current round, with its pao payer.  The reference clears the map whenever a round is initialised, so it is non-empty
+ * only while the game is over (the round that ended it was won).  out[4] is indexed by seat; *seat_mask tells which
+ * entries are set. */
+typedef struct RmjWinResult { /* WinResult, types.rs:282-293 */
+    uint8_t is_win, yakuman, has_win_shape, n_yaku;
+    uint8_t yaku[20];
+    uint32_t han, fu, ron_agari, tsumo_agari_oya, tsumo_agari_ko;
+    int8_t pao_payer; /* -1 = None */
+    uint8_t pad[3];
+} RmjWinResult;
+int rmj_get_win_results(rmj_handle h, uint32_t game, RmjWinResult* out /*[4]*/, uint8_t* seat_mask);
+
 /* MJAI events: total number emitted so far per game, and a window of records. */
 int rmj_get_event_counts(rmj_handle h, uint32_t* counts /*[n]*/);
 int rmj_get_events(rmj_handle h, uint32_t game, uint32_t first, uint32_t max_events, RmjEvent* out, uint32_t* n_out);

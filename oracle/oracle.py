@@ -63,6 +63,7 @@ def lib():
         L.orc_best_ukeire.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_int, C.c_void_p]
         L.orc_game_apply_event.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
         L.orc_tid_to_mjai.argtypes = [C.c_uint8, C.c_char_p]
+        L.orc_game_win_results.argtypes = [C.c_void_p, C.POINTER(abi.WinResult)]
         L.orc_bench_rollout.restype = C.c_uint64
         L.orc_bench_rollout.argtypes = [C.c_int, C.c_uint32, C.c_int, C.c_uint32, C.c_uint64, C.c_uint64, C.c_uint32,
                                         C.c_int, C.POINTER(C.c_double)]
@@ -224,6 +225,19 @@ class Game:
     def encode_furiten_ron_possibility(self):
         out = np.zeros((3 if self.sanma else 4, 21), np.float32)
         self.L.orc_game_encode_furiten_ron(self.h, out.ctypes.data)
+        return out
+
+    def win_results(self):
+        arr = (abi.WinResult * 4)()
+        m = self.L.orc_game_win_results(self.h, arr)
+        out = {}
+        for p in range(4):
+            if (m >> p) & 1:
+                w = arr[p]
+                out[p] = dict(is_win=bool(w.is_win), yakuman=bool(w.yakuman), has_win_shape=bool(w.has_win_shape),
+                              yaku=list(w.yaku[: w.n_yaku]), han=w.han, fu=w.fu, ron_agari=w.ron_agari,
+                              tsumo_agari_oya=w.tsumo_agari_oya, tsumo_agari_ko=w.tsumo_agari_ko,
+                              pao_payer=None if w.pao_payer < 0 else int(w.pao_payer))
         return out
 
     def apply_event(self, ev):

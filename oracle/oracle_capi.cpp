@@ -1057,6 +1057,24 @@ void orc_game_random_actions(void* gp, uint64_t policy_seed, uint64_t global_gam
     }
 }
 
+// RiichiEnv.win_results (env.rs:606-607): out[4] by seat, returns the seat mask
+int orc_game_win_results(void* h, RmjWinResult* out) {
+    auto* g = (GameState*)h;
+    int mask = 0;
+    std::memset(out, 0, 4 * sizeof(RmjWinResult));
+    for (auto& kv : g->win_results) {
+        const WinResult& w = kv.second;
+        RmjWinResult& r = out[kv.first & 3];
+        r.is_win = w.is_win; r.yakuman = w.yakuman; r.has_win_shape = w.has_win_shape;
+        r.n_yaku = (uint8_t)std::min<size_t>(w.yaku.size(), 20);
+        for (int i = 0; i < r.n_yaku; i++) r.yaku[i] = (uint8_t)w.yaku[i];
+        r.han = w.han; r.fu = w.fu; r.ron_agari = w.ron_agari; r.tsumo_agari_oya = w.tsumo_agari_oya; r.tsumo_agari_ko = w.tsumo_agari_ko;
+        r.pao_payer = (int8_t)w.pao_payer;
+        mask |= 1 << (kv.first & 3);
+    }
+    return mask;
+}
+
 // ---------------------------------------------------------------- CPU baseline (bench.py cpu_baseline leg)
 // Runs `n_games` independent random-agent games (sharded over `threads`) for at least `min_steps_per_game`
 // env.step calls each with auto-reset, returns total env steps; seconds via *secs.

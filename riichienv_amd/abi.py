@@ -191,6 +191,12 @@ class HandResult(C.Structure):
                 ("is_tenpai", C.c_uint8), ("is_agari", C.c_uint8), ("pad", C.c_uint8 * 6)]
 
 
+class WinResult(C.Structure):
+    _fields_ = [("is_win", C.c_uint8), ("yakuman", C.c_uint8), ("has_win_shape", C.c_uint8), ("n_yaku", C.c_uint8),
+                ("yaku", C.c_uint8 * 20), ("han", C.c_uint32), ("fu", C.c_uint32), ("ron_agari", C.c_uint32),
+                ("tsumo_agari_oya", C.c_uint32), ("tsumo_agari_ko", C.c_uint32), ("pao_payer", C.c_int8), ("pad", C.c_uint8 * 3)]
+
+
 class Config(C.Structure):
     _fields_ = [("n_games", C.c_uint32), ("game_mode", C.c_uint8), ("skip_mjai_logging", C.c_uint8),
                 ("round_wind", C.c_uint8), ("reserved0", C.c_uint8), ("rule_bits", C.c_uint32),

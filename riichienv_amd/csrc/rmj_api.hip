@@ -737,6 +737,8 @@ static int create_impl(rmj_env* h, const RmjConfig* cfg, uint64_t** d_seeds_out)
     HIPCHK(hipMalloc(&d.waits, B * 4 * sizeof(uint64_t)));
     HIPCHK(hipMalloc(&d.status, B * sizeof(uint32_t)));
     HIPCHK(hipMalloc(&d.events, B * (size_t)r2 * sizeof(RmjEvent)));
+    HIPCHK(hipMalloc(&d.win, B * 4 * sizeof(RmjWinResult)));
+    HIPCHK(hipMemsetAsync(d.win, 0, B * 4 * sizeof(RmjWinResult), h->stream));
     HIPCHK(hipMalloc(&h->d_actions, B * 4 * sizeof(uint64_t)));
     HIPCHK(hipMalloc(&h->d_counter, sizeof(unsigned long long)));
     HIPCHK(hipMemsetAsync(d.legal, 0, B * 4 * RMJ_MAX_LEGAL * sizeof(uint64_t), h->stream));
@@ -802,7 +804,7 @@ int rmj_destroy(rmj_handle h) {
     hipSetDevice(h->cfg.device);
     if (h->stream) hipStreamSynchronize(h->stream);
     hipFree(h->d.core); hipFree(h->d.wall); hipFree(h->d.legal); hipFree(h->d.nlegal); hipFree(h->d_decay); if (h->d_scratch) hipFree(h->d_scratch); hipFree(h->d.mask);
-    hipFree(h->d.waits); hipFree(h->d.status); hipFree(h->d.events); hipFree(h->d_actions); hipFree(h->d_counter); hipFree(h->d_env);
+    hipFree(h->d.waits); hipFree(h->d.status); hipFree(h->d.events); hipFree(h->d.win); hipFree(h->d_actions); hipFree(h->d_counter); hipFree(h->d_env);
     if (h->own_stream) hipStreamDestroy(h->own_stream);
     for (int i = 0; i < RMJ_MAX_ROLLOUT_STREAMS - 1; i++) {
         if (h->xstream[i]) { hipStreamSynchronize(h->xstream[i]); hipStreamDestroy(h->xstream[i]); }
@@ -1107,6 +1109,17 @@ int rmj_total_steps(rmj_handle h, uint64_t* total) {
     return RMJ_OK;
 }
 
+int rmj_get_win_results(rmj_handle h, uint32_t game, RmjWinResult* out, uint8_t* seat_mask) {
+    if (!h || !out || !seat_mask) return fail(RMJ_ERR_ARG, "null argument");
+    if (game >= h->cfg.n_games) return fail(RMJ_ERR_RANGE, "game index out of range");
+    GState st;
+    SYNC_FETCH(&st, h->d.core + game, sizeof(GState));
+    HIPCHK(hipMemcpy(out, h->d.win + (size_t)game * 4, 4 * sizeof(RmjWinResult), hipMemcpyDeviceToHost));
+    *seat_mask = st.win_mask;
+    for (int p = 0; p < 4; p++)
+        if (!((st.win_mask >> p) & 1u)) memset(&out[p], 0, sizeof(RmjWinResult));
+    return RMJ_OK;
+}
 int rmj_get_events(rmj_handle h, uint32_t game, uint32_t first, uint32_t max_events, RmjEvent* out, uint32_t* n_out) {
     if (!h || !out || !n_out) return fail(RMJ_ERR_ARG, "null argument");
     if (game >= h->cfg.n_games) return fail(RMJ_ERR_RANGE, "game index out of range");

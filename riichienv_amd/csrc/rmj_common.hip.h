@@ -17,6 +17,7 @@ struct Env {
     uint64_t* waits;      // [B][4]
     uint32_t* status;     // [B]  active_mask | phase<<8 | done<<16
     RmjEvent* events;     // [B][ring]
+    RmjWinResult* win;    // [B][4]  win_results of the round that ended the game (rare path only)
     uint32_t ring_mask;   // ring-1
     uint32_t n_games;
     uint32_t rule_bits;

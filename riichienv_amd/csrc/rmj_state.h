@@ -88,7 +88,8 @@ struct alignas(16) GState {  // 4*128 + 128 = 640 bytes
     // player_event_counts of the reference (state/mod.rs:65, 211-218): the events [obs_from[p], obs_upto[p]) are the delta
     // (Observation.events) of seat p's latest observation; advanced whenever observations are published for an acting seat
     uint32_t obs_from[4], obs_upto[4];
-    uint8_t pad[128 - 8 - 8 - 20 - 16 - 4 - 6 - 3 - 4 - 4 - 3 - 4 - 32];
+    uint8_t win_mask;         // seats with an entry in the win-result slab (win_results of the reference; cleared per round)
+    uint8_t pad[128 - 8 - 8 - 20 - 16 - 4 - 6 - 3 - 4 - 4 - 3 - 4 - 32 - 1];
 };
 
 #ifdef __cplusplus

@@ -1029,6 +1029,7 @@ __device__ inline void init_round(Ctx& c, int oya, int round_wind, int honba, ui
     S.last_discard_pid = 0xFF;
     S.last_discard_tile = 0;
     S.ron_offer_mask = 0;
+    S.win_mask = 0;  // win_results.clear() (state/mod.rs:1729)
     for (int p = 0; p < 4; p++) S.stale_n[p] = 0;
     // publish the wall to HBM (W) and deal from LDS
     for (int i = lane; i < RMJ_WALL_STRIDE / 4; i += 64)
@@ -1455,6 +1456,25 @@ __device__ inline void yakuman_totals(const Ctx& c, const CalcOut& r, const PSta
     }
 }
 
+// win_results.insert(seat, val) (state/mod.rs:855-863, 1100-1107): the capped result with its ordered yaku list and the pao payer
+__device__ inline void record_win(Ctx& c, int seat, const CalcOut& r) {
+    GState& S = c.S;
+    const PState& P = S.p[seat];
+    if (c.lane == 0) {
+        RmjWinResult w;
+        __builtin_memset(&w, 0, sizeof(w));
+        w.is_win = r.is_win; w.yakuman = r.yakuman; w.has_win_shape = r.shape;
+        w.n_yaku = (uint8_t)yaku_list(r.kind, r.ym, w.yaku, 20);
+        w.han = (uint32_t)r.han; w.fu = (uint32_t)r.fu;
+        w.ron_agari = r.ron; w.tsumo_agari_oya = r.tsumo_oya; w.tsumo_agari_ko = r.tsumo_ko;
+        w.pao_payer = -1;
+        if (((r.ym >> 37) & 1ull) && P.pao37 != 0xFF) w.pao_payer = (int8_t)P.pao37;
+        else if (((r.ym >> 50) & 1ull) && P.pao50 != 0xFF) w.pao_payer = (int8_t)P.pao50;
+        c.E.win[(size_t)c.g * 4 + seat] = w;
+    }
+    S.win_mask |= (uint8_t)(1u << seat);
+}
+
 __device__ inline void emit_hora(Ctx& c, int actor, int target, const int32_t* deltas, bool tsumo, bool riichi) {
     if (c.E.skip_log) return;
     GState& S = c.S;
@@ -1699,6 +1719,7 @@ __device__ __noinline__ uint32_t ol_wait_act_other(CtxV v, int pid, uint64_t act
             S.riichi_sticks = 0;
             deltas[pid] += total_win;
             for (int i = 0; i < 4; i++) { S.p[i].score += deltas[i]; S.p[i].score_delta = deltas[i]; }
+            record_win(c, pid, res);
             emit_hora(c, pid, pid, deltas, true, riichi);
             init_next_round(c, pid == S.oya, false);
         } else {
@@ -1764,6 +1785,7 @@ __device__ __noinline__ void ol_settle_ron(CtxV v, uint32_t ron_mask) {
                     deposit_taken = true;
                 }
                 if (w == S.oya) oya_won = true;
+                record_win(c, w, res);
                 emit_hora(c, w, target, this_d, false, riichi);
             }
         }
@@ -2024,6 +2046,7 @@ __device__ inline void apply_event(Ctx& c, const RmjEvent* ev) {
             S.drawable_count = (uint8_t)(S.live_end - 14);
             S.n_dora = 1;
             S.dora[0] = (uint8_t)tile;
+            S.win_mask = 0;
             for (int i = lane; i < RMJ_WALL_STRIDE / 4; i += 64) reinterpret_cast<uint32_t*>(c.W)[i] = 0u;  // placeholder wall
             for (int p = 0; p < 4; p++) {  // PlayerState::reset_round, state/player.rs:66-86
                 PState& Q = S.p[p];

@@ -31,6 +31,7 @@ EXPORTS = [
     "rmj_bench_rollout_validated", "rmj_bench_encode", "rmj_set_rollout_streams", "rmj_total_full_path",
     "rmj_random_actions_device", "rmj_peek_outputs", "rmj_sample_ids_device",
     "rmj_encode_seq_delta", "rmj_encode_seq_delta_device", "rmj_step_random_encode",
+    "rmj_get_win_results",
 ]
 
 
@@ -120,6 +121,7 @@ def load_lib():
     L.rmj_peek_outputs.argtypes = [vp, C.c_uint32, vp, vp, vp, vp, C.POINTER(C.c_uint32)]
     L.rmj_sample_ids_device.argtypes = [vp, vp, C.c_uint32, C.c_uint64, vp]
     L.rmj_step_random_encode.argtypes = [vp, C.c_uint64, C.c_uint32, C.c_int, C.c_int, vp]
+    L.rmj_get_win_results.argtypes = [vp, C.c_uint32, C.POINTER(abi.WinResult), C.POINTER(C.c_uint8)]
     L.rmj_encode_seq_delta.argtypes = [vp, C.c_int, C.POINTER(abi.SeqBuffers)]          # same field layout as RmjSeqBuffers
     L.rmj_encode_seq_delta_device.argtypes = [vp, C.c_int, C.POINTER(abi.SeqBuffers)]
     _LIB = L
@@ -298,6 +300,21 @@ class VecRiichiEnv:
 
     def poke(self, g, v: abi.StateView):
         _chk(self.L.rmj_poke_state(self.h, g, C.byref(v)))
+
+    def win_results(self, g):
+        """RiichiEnv.win_results of game g (env.rs:606-607): {seat: dict} of the round that ended the game."""
+        arr = (abi.WinResult * 4)()
+        m = C.c_uint8()
+        _chk(self.L.rmj_get_win_results(self.h, int(g), arr, C.byref(m)))
+        out = {}
+        for p in range(4):
+            if (m.value >> p) & 1:
+                w = arr[p]
+                out[p] = dict(is_win=bool(w.is_win), yakuman=bool(w.yakuman), has_win_shape=bool(w.has_win_shape),
+                              yaku=list(w.yaku[: w.n_yaku]), han=w.han, fu=w.fu, ron_agari=w.ron_agari,
+                              tsumo_agari_oya=w.tsumo_agari_oya, tsumo_agari_ko=w.tsumo_agari_ko,
+                              pao_payer=None if w.pao_payer < 0 else int(w.pao_payer))
+        return out
 
     def event_counts(self):
         c = np.zeros(self.n, np.uint32)

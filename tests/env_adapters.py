@@ -44,6 +44,9 @@ class OracleEnv:
     def scores(self):
         return [p.score for p in self.g.peek().players]
 
+    def win_results(self):
+        return self.g.win_results()
+
     def encode(self, seat):
         return self.g.encode(seat, self.g.peek().wall_len + sum(p.hand_len for p in self.g.peek().players) <= 108)
 
@@ -93,6 +96,9 @@ class GpuEnv:
     def scores(self):
         return [int(x) for x in self.e.scores()[0]]
 
+    def win_results(self):
+        return self.e.win_results(0)
+
 
 class DualEnv:
     """Drives the oracle and the HIP path together; every mutation is followed by a full comparison."""
@@ -116,6 +122,7 @@ class DualEnv:
                 assert (np.asarray(self.g.mask(s)) == np.asarray(self.o.mask(s))).all(), (what, s, "mask")
                 assert self.g.waits(s) == self.o.waits(s), (what, s, "waits")
         assert self.g.log() == self.o.log(), what
+        assert self.g.win_results() == self.o.win_results(), (what, "win_results", self.g.win_results(), self.o.win_results())
         for s in range(self.np):
             assert self.g.log(s) == self.o.log(s), (what, s)
 
@@ -154,6 +161,9 @@ class DualEnv:
 
     def scores(self):
         return self.o.scores()
+
+    def win_results(self):
+        return self.o.win_results()
 
 
 def events(env, seat=-1):

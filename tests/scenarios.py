@@ -929,7 +929,51 @@ def sc_oyayame_needs_the_sole_or_seat_first_top(make):
             assert v.oya == 3 and v.honba == 1 and v.round_wind == 1 and [p.score for p in v.players] == [30000, 20000, 20000, 30000]
 
 
-SCENARIOS = [sc_paishan_dora_indices, sc_kakan_dora_timing, sc_daiminkan_dora_timing, sc_south_round_tsumo,
+def sc_win_results_of_the_final_round(make):
+    """tests/env/test_riichienv_hora.py:5-100 (+ env.rs:606-607): win_results holds the winner's WinResult after the round
+    that ended the game - chankan as the only yaku ([3]), then South-round yakuhai + toitoi + sanankou + honitsu
+    ([11, 21, 22, 27], emission order); a new round clears it (state/mod.rs:1729)."""
+    env = make(game_mode=0, seed=42)
+    env.reset()
+    assert env.win_results() == {}
+    p1 = [0, 4, 8, 40, 44, 48, 56, 64, 72, 76, 80, 104, 105]
+
+    def mut(v):
+        v.players[0].n_melds = 1
+        set_meld(v.players[0].melds[0], PON_M, [60, 61, 62], True)
+        v.n_dora = 1
+        v.dora[0] = 135
+
+    setup(env, hands=[list(range(120, 132)), p1, None, None], current_player=0, drawn_tile=63, mutate=mut)
+    env.step({0: pack_action(KAKAN, 63)})
+    act, ph, dn = env.status()
+    assert ph == WAIT_RESPONSE and (act >> 1) & 1
+    ron = [a for a in env.legal(1) if unpack_action(a)[0] == RON]
+    assert len(ron) == 1
+    env.step({1: ron[0]})
+    assert env.status()[2] == 1 and "hora" in [e["type"] for e in evs(env)[-3:]]
+    w = env.win_results()
+    assert list(w) == [1] and w[1]["yaku"] == [3] and w[1]["is_win"] and not w[1]["yakuman"] and w[1]["pao_payer"] is None
+    # South 1: seat 3 (North seat) wins on 9m with a South pon: yakuhai of the round wind, toitoi, sanankou, honitsu
+    env.reset(round_wind=1, oya=0, honba=0, kyotaku=0)
+    assert env.win_results() == {}
+
+    def mut2(v):
+        v.players[3].n_melds = 1
+        set_meld(v.players[3].melds[0], PON_M, [112, 113, 114], True)
+        v.drawn_tile = -1
+        v.n_dora = 1
+        v.dora[0] = 135   # the reference's seed gives this round no dora in the winner's hand; keep the yaku list free of it
+
+    setup(env, hands=[None, None, [33] + list(range(40, 52)), [0, 1, 2, 4, 5, 6, 8, 9, 10, 32]], current_player=2, mutate=mut2,
+          reset_kw=dict(round_wind=1, oya=0, honba=0, kyotaku=0))
+    env.step({2: pack_action(DISCARD, 33)})
+    assert (env.status()[0] >> 3) & 1 and find(env.legal(3), RON) is not None
+    env.step({3: pack_action(RON, 33)})
+    assert env.win_results()[3]["yaku"] == [11, 21, 22, 27]
+
+
+SCENARIOS = [sc_win_results_of_the_final_round, sc_paishan_dora_indices, sc_kakan_dora_timing, sc_daiminkan_dora_timing, sc_south_round_tsumo,
              sc_illegal_discard_penalty, sc_illegal_out_of_turn, sc_claim_priority_pon_over_chi, sc_kuikae_suji,
              sc_kuikae_deadlock, sc_sufuurenta, sc_suukansansen, sc_chankan_ron, sc_chankan_pass, sc_pao_daisangen_tsumo,
              sc_pao_mjsoul_composite_tsumo, sc_riichi_sequence, sc_kyushu_kyuhai, sc_double_ron_honba_sticks,

@@ -132,12 +132,14 @@ struct ResetArgs {
 #define RMJ_SANMA 0
 #include "rmj_step.hip.h"
 #include "rmj_kernels.hip.h"
+#include "rmj_step4.hip.h"
 #undef RMJ_NS
 #undef RMJ_SANMA
 #define RMJ_NS rmj3
 #define RMJ_SANMA 1
 #include "rmj_step.hip.h"
 #include "rmj_kernels.hip.h"
+#include "rmj_step4.hip.h"
 #undef RMJ_NS
 #undef RMJ_SANMA
 
@@ -645,6 +647,7 @@ struct rmj_env {
     void* d_scratch = nullptr; // staging buffer of the host-copy entry points (grown on demand, never per call)
     size_t scratch_bytes = 0;
     int want_streams = 4;      // parts a multi-step device rollout is cut into (rmj_set_rollout_streams; RMJ_STEP_STREAMS at create)
+    int quad = 0;              // device-policy steps run four games per wave (k_step4); RMJ_STEP4 at create
 };
 // device staging memory of at least `bytes` bytes, owned by the handle
 static int scratch_for(rmj_env* h, size_t bytes, void** out) {
@@ -720,6 +723,7 @@ static int create_impl(rmj_env* h, const RmjConfig* cfg, uint64_t** d_seeds_out)
     while (r2 < ring) r2 <<= 1;
     h->ring = r2;
     if (const char* e = getenv("RMJ_STEP_STREAMS")) h->want_streams = atoi(e);
+    if (const char* e = getenv("RMJ_STEP4")) h->quad = atoi(e);
     const size_t B = cfg->n_games;
     Env& d = h->d;
     HIPCHK(hipStreamCreateWithFlags(&h->own_stream, hipStreamNonBlocking));
@@ -850,6 +854,12 @@ static inline void launch_step_range(rmj_env* h, hipStream_t st, const uint64_t*
 #else
     const unsigned extra_lds = 0u;
 #endif
+    if (h->quad && (flags & STEP_F_RANDOM)) {   // device policy: four games per wave
+        const dim3 grid((g1 - g0 + 3u) / 4u);
+        if (h->cfg.game_mode >= 3) hipLaunchKernelGGL(rmj3::k_step4, grid, dim3(64), 0, st, (const Env*)h->d_env, policy_seed, flags, g0, g1);
+        else hipLaunchKernelGGL(rmj4::k_step4, grid, dim3(64), 0, st, (const Env*)h->d_env, policy_seed, flags, g0, g1);
+        return;
+    }
     if (h->cfg.game_mode >= 3) hipLaunchKernelGGL(rmj3::k_step, step_grid(g1 - g0), dim3(64 * RMJ_STEP_WPB), extra_lds, st, (const Env*)h->d_env, d_actions, policy_seed, flags, g0, g1);
     else hipLaunchKernelGGL(rmj4::k_step, step_grid(g1 - g0), dim3(64 * RMJ_STEP_WPB), extra_lds, st, (const Env*)h->d_env, d_actions, policy_seed, flags, g0, g1);
 }

@@ -1,0 +1,837 @@
+// Four games per wavefront: the fast path of the step kernel re-expressed with ONE 16-LANE DPP ROW PER GAME.
+//
+// Why (profiles/r02_pmc_k_step.json): with one game per wave the step is bound by instruction ISSUE on the
+// vector and the scalar port together (~620 VALU + ~640 SALU wave-instructions per game-step, both ports ~85 % busy at
+// eight waves per SIMD), and the vector instructions use at most 16 of their 64 lanes for real work - everything else is
+// wave-uniform bookkeeping.  Here the four rows of a wave hold four different games: lane r of a row is hand slot r
+// (0..13), seat r (0..3), meld slot r ... exactly the 16-lane sub-layouts the one-game code already used; the per-game
+// "scalar" bookkeeping runs once per wave on the vector unit for four games at a time, and the scalar unit is left with
+// loop control and addresses.  Cross-lane traffic stays inside a row: DPP row shifts / sums, ballots sliced per row,
+// ds_bpermute for "read lane k of my row".
+//
+// Coverage: every common transition - discard (incl. the riichi discard), claim generation (Pon / Daiminkan / Chi lists,
+// ordered like the reference), Pass / Pon / Chi responses, the next draw, the drawer's legal list, wait-cache refills by
+// the isolated-tile bound and the table shanten, 3P Kita.  Anything that needs a yaku evaluation, a wait probe, a kan, a
+// riichi declaration, a round end or a restart makes ITS ROW bail; the wave finishes the other rows, stores them, and then
+// runs the bailed games one by one through the complete state machine (ol_step_full) from their untouched HBM records.
+// Results are identical to k_step by construction of the parity suite (every GPU test runs on this kernel).
+//
+// Included once per variant inside namespace RMJ_NS, after rmj_kernels.hip.h.
+namespace RMJ_NS {
+
+#define R4_LIST 16 /* staged list entries per (game, seat); a longer list makes the row bail */
+struct Quad4Tier0 {
+    alignas(16) uint32_t ev[4][RMJ_EV_STAGE][8];  // staged MJAI records per game
+    uint32_t evidx[4][RMJ_EV_STAGE];
+    uint64_t lst[4][4][R4_LIST];                   // staged legal lists per (game, seat)
+    uint32_t mk[4][4][4];                          // 82-bit action-id masks per (game, seat), built with LDS atomics
+};
+struct Quad4Shared {
+    GState st[4];
+    union {
+        WaveScratch x;   // scratch of the full path (bailed games, after the tier-0 rows have been stored)
+        Quad4Tier0 t;
+    } u;
+};
+
+__device__ __forceinline__ uint32_t rballot(bool p, int rb) { return (uint32_t)(__ballot(p) >> rb) & 0xFFFFu; }
+__device__ __forceinline__ int rbc(int v, int src_lane) { return __builtin_amdgcn_ds_bpermute(src_lane << 2, v); }
+__device__ __forceinline__ uint64_t rbc64(uint64_t v, int src_lane) {
+    return (uint64_t)(uint32_t)rbc((int)(uint32_t)v, src_lane) | ((uint64_t)(uint32_t)rbc((int)(uint32_t)(v >> 32), src_lane) << 32);
+}
+__device__ __forceinline__ uint32_t row_or16(uint32_t v) {  // OR over a 16-lane row, result in lane 15 of the row
+    v |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, false);
+    v |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, false);
+    v |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, false);
+    v |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, false);
+    return v;
+}
+
+// Per-row context: everything is a per-lane value that is uniform within the row.
+struct R4 {
+    GState* G;
+    Quad4Tier0* T;
+    CEnv* E;
+    int lane, r, rb, row;
+    uint32_t g;
+    bool live;        // the row still runs in tier 0
+    bool bail;        // the row goes to the full path
+    int evn;          // staged events
+    uint32_t dirty;
+};
+
+__device__ __forceinline__ void r4_emit(R4& q, uint32_t w0, uint32_t w1, uint32_t w6) {
+    if (q.E->skip_log) return;
+    const uint32_t evc = q.G->ev_count;
+    if (q.evn >= RMJ_EV_STAGE) { q.bail = true; return; }
+    if (q.r == 0) {
+        uint4* b = reinterpret_cast<uint4*>(q.T->ev[q.row][q.evn]);
+        b[0] = make_uint4(w0, w1, 0u, 0u);
+        b[1] = make_uint4(0u, 0u, w6, (uint32_t)KNP << 24);
+        q.T->evidx[q.row][q.evn] = evc & q.E->ring_mask;
+        q.G->ev_count = evc + 1;
+    }
+    q.evn += 1;
+    wave_sync();
+}
+__device__ __forceinline__ void r4_emit_simple(R4& q, uint32_t type, uint32_t actor, uint32_t tile, uint32_t fl = 0) {
+    r4_emit(q, type | (actor << 8) | (tile << 24), 0u, fl);
+}
+
+// concealed histogram of a seat's hand (optionally without slot `skip`): lane r contributes hand[r]; uniform in the row
+__device__ __forceinline__ PH r4_hist(const R4& q, const PState* P, int skip) {
+    const int n = P->hand_len;
+    uint32_t a = 0, b = 0, c = 0, d = 0;
+    if (q.r < n && q.r != skip) {
+        const int t = P->hand[q.r] >> 2, s = t_suit(t);
+        const uint32_t one = 1u << (3 * (t - 9 * s));
+        a = s == 0 ? one : 0u; b = s == 1 ? one : 0u; c = s == 2 ? one : 0u; d = s == 3 ? one : 0u;
+    }
+    a = row_sum16(a); b = row_sum16(b); c = row_sum16(c); d = row_sum16(d);
+    const int l15 = q.rb + 15;
+    PH h;
+    h.a = (uint32_t)rbc((int)a, l15); h.b = (uint32_t)rbc((int)b, l15); h.c = (uint32_t)rbc((int)c, l15); h.d = (uint32_t)rbc((int)d, l15);
+    return h;
+}
+// isolated tiles of a histogram, bitwise (same number as isolated_tiles(): held exactly once, nothing within two ranks)
+__device__ __forceinline__ int r4_isolated(const PH& h) {
+    int iso = 0;
+#pragma unroll
+    for (int s = 0; s < 3; s++) {
+        const uint32_t x = ph_get(h, s);
+        const uint32_t nz = (x | (x >> 1) | (x >> 2)) & O9_1;
+        const uint32_t one = x & ~(x >> 1) & ~(x >> 2) & O9_1;                                  // fields equal to 1
+        const uint32_t nb = ((nz << 3) | (nz << 6) | (nz >> 3) | (nz >> 6)) & O9_1;             // a held rank within two
+        iso += __popc(one & ~nb);
+    }
+    const uint32_t x = h.d;
+    iso += __popc(x & ~(x >> 1) & ~(x >> 2) & O7_1);
+    return iso;
+}
+// table shanten (4P tables) of one histogram per row: lane i (< 9) computes its term of the perfect hash suit by suit
+__device__ __forceinline__ int r4_shanten(const R4& q, const PH& h, int len_div3) {
+    const ShantenTables T = sh_tables_of(*q.E);
+    const int i = q.r, l15 = q.rb + 15;
+    uint64_t vec[4];
+#pragma unroll
+    for (int s = 0; s < 4; s++) {
+        uint32_t val = 0;
+        if (i < (s < 3 ? 9 : 7)) {
+            const uint32_t x = ph_get(h, s);
+            uint32_t c = (x >> (3 * i)) & 7u;
+            uint32_t sm = (uint32_t)field_sum(x & ((1u << (3 * i)) - 1u));
+            if (c > 4u) c = 4u;
+            if (sm > 14u) sm = 14u;
+            if (sm + c > 14u) c = 14u - sm;
+            val = (s < 3 ? T.rank9 : T.rank7)[(i * 15 + sm) * 5 + c];
+        }
+        val = row_sum16(val);
+        const uint32_t idx = (uint32_t)rbc((int)val, l15);
+        vec[s] = s < 3 ? T.suit[idx] : T.honor[idx];
+    }
+    const int m = len_div3 > 4 ? 4 : len_div3;
+    // lanes 0..9: entry idx of merge(a, b) and the entry of merge(c, d) that pairs with it in the final entry (pair = 1, m)
+    const int p = i >= 5 ? 1 : 0, k = i - 5 * p;
+    uint32_t t = 99u;
+    if (i < 10 && k <= m) {
+        const uint32_t e1 = sh_merge_entry((uint32_t)vec[0] & 0xFFFFFu, (uint32_t)(vec[0] >> 20) & 0xFFFFFu, (uint32_t)vec[1] & 0xFFFFFu,
+                                           (uint32_t)(vec[1] >> 20) & 0xFFFFFu, p, k);
+        const uint32_t e2 = sh_merge_entry((uint32_t)vec[2] & 0xFFFFFu, (uint32_t)(vec[2] >> 20) & 0xFFFFFu, (uint32_t)vec[3] & 0xFFFFFu,
+                                           (uint32_t)(vec[3] >> 20) & 0xFFFFFu, 1 - p, m - k);
+        t = e1 + e2;
+    }
+    t = row_min16(t);
+    uint32_t rep = (uint32_t)rbc((int)t, l15);
+    if (rep > 15u) rep = 15u;
+    int sres = (int)rep - 1;
+    if (sres <= 0 || len_div3 < 4) return sres;
+    const int ch = sh_chiitoi(h, false);
+    sres = ch < sres ? ch : sres;
+    if (sres > 0) {
+        const int kk = sh_kokushi(h);
+        sres = kk < sres ? kk : sres;
+    }
+    return sres;
+}
+// fill_waits13 of tier 0: the isolated-tile bound, else the table shanten; a hand with a possible wait (shanten <= 0)
+// needs the probe -> the row bails.  Writes the cache like fill_waits13 (waits13 = 0 for every shanten >= 1).
+__device__ __forceinline__ void r4_fill_waits13(R4& q, PState* P, const PH& h13) {
+    const uint32_t T9 = 1u | (1u << 24);
+    const int yaochu = __popc((h13.a | (h13.a >> 1) | (h13.a >> 2)) & T9) + __popc((h13.b | (h13.b >> 1) | (h13.b >> 2)) & T9) +
+                       __popc((h13.c | (h13.c >> 1) | (h13.c >> 2)) & T9) + __popc((h13.d | (h13.d >> 1) | (h13.d >> 2)) & O7_1);
+    const int iso = r4_isolated(h13);
+    int lb = iso >= 6 ? 4 : (iso == 5 ? 3 : (iso == 4 ? 2 : 0));
+    const int len3 = P->hand_len / 3;
+    if (len3 == 4) {
+        const int koku = 12 - yaochu;
+        lb = koku < lb ? koku : lb;
+        if (lb > 2) {
+            const int chi = sh_chiitoi(h13, false);
+            lb = chi < lb ? chi : lb;
+        }
+    }
+    int sh = lb;
+    if (lb < 2) {
+        sh = r4_shanten(q, h13, len3);
+        if (sh <= 0) { q.bail = true; return; }
+    }
+    if (q.r == 0) {
+        P->waits13 = 0ull;
+        P->sh13 = (uint8_t)sh;
+        P->flags |= PF_WAITS_VALID;
+    }
+    wave_sync();
+}
+
+// accept_riichi (state/mod.rs:1549-1567)
+__device__ __forceinline__ void r4_accept_riichi(R4& q) {
+    GState* G = q.G;
+    const int p = G->riichi_pending;
+    if (p != 0xFF) {
+        q.dirty |= 1u << p;
+        if (q.r == 0) {
+            G->p[p].score -= 1000;
+            G->p[p].score_delta -= 1000;
+            G->riichi_sticks += 1;
+            G->p[p].flags |= PF_RIICHI_DECLARED | PF_IPPATSU;
+            G->riichi_pending = 0xFF;
+        }
+        wave_sync();
+        r4_emit_simple(q, RMJ_EV_REACH_ACCEPTED, (uint32_t)p, 0);
+    }
+}
+// check_abortive_draw (state/mod.rs:1970-2019): any abortive draw makes the row bail; lane = seat * 4 + meld slot
+__device__ __forceinline__ void r4_check_abortive(R4& q) {
+    GState* G = q.G;
+    const int p = (q.r >> 2) & 3, m = q.r & 3;
+    const PState& P = G->p[p];
+    const bool seat_lane = m == 0;
+    const int nm = P.n_melds;
+    const uint32_t turns_ok = rballot(seat_lane && P.n_discards == 1, q.rb);
+    const uint32_t has_melds = rballot(seat_lane && nm != 0, q.rb);
+    const uint32_t riichi = rballot(seat_lane && (P.flags & PF_RIICHI_DECLARED), q.rb);
+    const uint32_t kan = rballot(m < nm && P.meld_type[m] >= RMJ_MELD_DAIMINKAN, q.rb);
+    const uint32_t all_seats = 0x1111u;
+    if (!KSANMA && turns_ok == all_seats && has_melds == 0u) {
+        const int first = G->p[0].discards[0] >> 2;
+        if (first >= 27 && first <= 30) {
+            const uint32_t same = rballot(seat_lane && (P.discards[0] >> 2) == first, q.rb);
+            if (same == all_seats) q.bail = true;
+        }
+    }
+    if (__popc(kan) == 4) {
+        const int owner = (__ffs((int)kan) - 1) >> 2;
+        if (kan & ~(0xFu << (4 * owner))) q.bail = true;
+    }
+    if (!KSANMA && riichi == all_seats) q.bail = true;
+}
+// deal_next (state/mod.rs:1569-1593); pf = the prefetched live-wall tile W[live_end - 1]
+__device__ __forceinline__ void r4_deal_next(R4& q, int pf) {
+    GState* G = q.G;
+    const int drawable = G->drawable_count;
+    if (drawable == 0) { q.bail = true; return; }   // exhaustive draw
+    const int live_end = G->live_end;
+    const int pid = G->current_player;
+    PState* P = &G->p[pid];
+    const int hl = P->hand_len;
+    if (live_end > G->rinshan_count) {
+        q.dirty |= 1u << pid;
+        if (q.r == 0) {
+            G->is_rinshan = 0;
+            G->live_end = (uint8_t)(live_end - 1);
+            G->drawable_count = (uint8_t)(drawable - 1);
+            if (hl < 14) { P->hand[hl] = (uint8_t)pf; P->hand_len = (uint8_t)(hl + 1); }
+            G->drawn_tile = (uint8_t)pf;
+            G->needs_tsumo = 0;
+            G->phase = RMJ_WAIT_ACT;
+            G->active_mask = (uint8_t)(1u << pid);
+            P->n_forbidden = 0;
+        }
+        wave_sync();
+        r4_emit_simple(q, RMJ_EV_TSUMO, (uint32_t)pid, (uint32_t)pf);
+    } else if (q.r == 0) {
+        G->is_rinshan = 0;
+    }
+}
+
+// stage one list entry / finish a seat's list
+__device__ __forceinline__ void r4_put(R4& q, int seat, int pos, uint64_t a) {
+    if (pos < R4_LIST) q.T->lst[q.row][seat][pos] = a;
+}
+
+// _resolve_discard (state/mod.rs:1317-1413) incl. claim generation (legal_actions.rs:254-508) for the row's game.
+// nl[] = list length of seat r (lanes r < 4) after the call; returns through G->phase / active_mask like the reference.
+__device__ __forceinline__ void r4_resolve_discard(R4& q, int pid, int tile, bool tsumogiri, int pf, int& nl_mine, uint64_t& w_mine) {
+    GState* G = q.G;
+    PState* P = &G->p[pid];
+    const int r = q.r, rb = q.rb;
+    if (G->pending_kan_dora > 0) { q.bail = true; return; }
+    const int tt = tile >> 2;
+    {
+        uint32_t fl = P->flags;
+        const bool stage = fl & PF_RIICHI_STAGE;
+        int nd = P->n_discards;
+        if (r == 0) {
+            if (KSANMA) { G->pending_kan_pid = 0xFF; G->pending_kan_action = 0; }
+            G->is_rinshan = 0;
+            fl &= ~(uint32_t)PF_IPPATSU;
+            if (nd < RMJ_MAX_DISCARDS) {
+                P->discards[nd] = (uint8_t)tile;
+                if (!tsumogiri) P->discard_from_hand_bits |= 1u << nd;
+                if (stage) P->discard_is_riichi_bits |= 1u << nd;
+                nd += 1;
+                P->n_discards = (uint8_t)nd;
+            }
+            P->discard_type_mask |= 1ull << tt;
+            G->last_discard_pid = (uint8_t)pid;
+            G->last_discard_tile = (uint8_t)tile;
+            G->drawn_tile = 0xFF;
+            if (!tsumogiri) {
+                P->last_tedashi = (uint8_t)tile;
+                const int lb = P->sh13;
+                if ((fl & PF_WAITS_VALID) && lb >= 3) P->sh13 = (uint8_t)(lb - 1);
+                else fl &= ~(uint32_t)PF_WAITS_VALID;
+            }
+            G->needs_tsumo = 1;
+            if (stage) {
+                fl |= PF_RIICHI_DECLARED;
+                if (G->is_first_turn) fl |= PF_DOUBLE_RIICHI;
+                P->riichi_decl_idx = (uint8_t)(nd - 1);
+                fl &= ~(uint32_t)PF_RIICHI_STAGE;
+                G->riichi_pending = (uint8_t)pid;
+            }
+            fl &= ~(uint32_t)PF_MISSED_DOUJUN;
+            if (!is_terminal_tile136(tile)) fl &= ~(uint32_t)PF_NAGASHI;
+            P->flags = (uint8_t)fl;
+            G->active_mask = 0;
+            G->ron_offer_mask = 0;
+        }
+    }
+    wave_sync();
+    r4_emit_simple(q, RMJ_EV_DAHAI, (uint32_t)pid, (uint32_t)tile, tsumogiri ? 1u : 0u);
+    if (q.bail) return;
+    // ---- A: refill stale wait caches of the other seats that hold 13 tiles (loop over seats, uniform per row)
+    for (int i = 0; i < KNP; i++) {
+        PState* Q = &G->p[i];
+        const bool need = i != pid && (Q->hand_len + 3 * Q->n_melds == 13) && !(Q->flags & PF_WAITS_VALID);
+        if (__ballot(need)) {
+            if (need) {
+                q.dirty |= 1u << i;
+                const PH h = r4_hist(q, Q, -1);
+                r4_fill_waits13(q, Q, h);
+            }
+        }
+    }
+    if (q.bail) return;
+    // ---- B (lane = seat): Ron eligibility: a seat that waits on the tile and is not furiten needs the yaku check -> bail
+    const PState& S4 = G->p[r & 3];
+    const bool other = r < KNP && r != pid;
+    const uint32_t qfl = S4.flags;
+    const bool holds13 = other && (S4.hand_len + 3 * S4.n_melds == 13);
+    const uint64_t W = holds13 ? S4.waits13 : 0ull;
+    const uint64_t dtm = S4.discard_type_mask;
+    const bool in_discards = (dtm >> tt) & 1ull;
+    const bool in_missed = (qfl & PF_MISSED_DOUJUN) || ((qfl & PF_RIICHI_DECLARED) && (qfl & PF_MISSED_RIICHI));
+    const bool furiten = (W & dtm) != 0ull || (qfl & (PF_MISSED_RIICHI | PF_MISSED_DOUJUN));
+    if (rballot(other && !in_discards && !in_missed && !furiten && ((W >> tt) & 1ull), rb)) { q.bail = true; return; }
+    const uint32_t riichi_m = rballot(r < 4 && (qfl & PF_RIICHI_DECLARED), rb) & 0xFu;
+    w_mine = r < 4 ? W : 0ull;
+    const bool can_call = G->drawable_count > 0;
+    const bool kuikae = (q.E->rule_bits & RMJ_RULE_KUIKAE_FORBIDDEN) != 0;
+    int nl0 = 0, nl1 = 0, nl2 = 0, nl3 = 0;   // list length of each seat so far (row-uniform; no indexed array: no scratch)
+    auto nl_get = [&](int i) { return i == 0 ? nl0 : (i == 1 ? nl1 : (i == 2 ? nl2 : nl3)); };
+    auto nl_set = [&](int i, int v) {
+        nl0 = i == 0 ? v : nl0; nl1 = i == 1 ? v : nl1; nl2 = i == 2 ? v : nl2; nl3 = i == 3 ? v : nl3;
+    };
+    // ---- C: Pon / Daiminkan material, seat by seat (lane = hand slot)
+#pragma unroll
+    for (int i = 0; i < KNP; i++) {
+        if (i == pid) continue;
+        const PState* Q = &G->p[i];
+        const int hl = Q->hand_len;
+        const int ht = r < hl ? (int)Q->hand[r] : 0xFF;
+        const uint32_t sm = can_call ? rballot(r < hl && (ht >> 2) == tt, rb) : 0u;
+        const int count = __popc(sm);
+        if (count < 2 || ((riichi_m >> i) & 1u)) continue;
+        const int i0 = __ffs((int)sm) - 1;
+        const uint32_t m1 = sm & (sm - 1u);
+        const int i1 = __ffs((int)m1) - 1;
+        const int i2 = count >= 3 ? __ffs((int)(m1 & (m1 - 1u))) - 1 : 0;
+        const uint32_t h0 = (uint32_t)rbc(ht, rb + i0), h1 = (uint32_t)rbc(ht, rb + i1), h2 = (uint32_t)rbc(ht, rb + i2);
+        int n = nl_get(i);
+        if (r == 0) {
+            if (hl >= 3 && (kuikae ? (hl - count) > 0 : (hl - 2) > 0)) {
+                r4_put(q, i, n, mk_action(RMJ_PON, tile, 2, h0, h1));
+                if (count >= 3) {
+                    r4_put(q, i, n + 1, mk_action(RMJ_PON, tile, 2, h0, h2));
+                    r4_put(q, i, n + 2, mk_action(RMJ_PON, tile, 2, h1, h2));
+                }
+            }
+        }
+        if (hl >= 3 && (kuikae ? (hl - count) > 0 : (hl - 2) > 0)) n += count >= 3 ? 3 : 1;
+        if (count >= 3) {
+            if (r == 0) r4_put(q, i, n, mk_action(RMJ_DAIMINKAN, tile, 3, h0, h1, h2));
+            n += 1;
+        }
+        nl_set(i, n);
+    }
+    // ---- D: Chi for the next seat (lane = a * 4 + b, pattern by pattern); no Chi in 3P
+    if (!KSANMA && can_call && tt < 27) {
+        const int i = (pid + 1) & 3;
+        const PState* Q = &G->p[i];
+        const int hl = Q->hand_len;
+        if (!((riichi_m >> i) & 1u) && hl >= 3) {
+            const int ht = r < hl ? (int)Q->hand[r] : 0xFF;
+            const int hty = ht >> 2;
+            const int r9 = tt % 9;
+            const uint32_t m_m2 = rballot(r < hl && hty == tt - 2, rb), m_m1 = rballot(r < hl && hty == tt - 1, rb);
+            const uint32_t m_p1 = rballot(r < hl && hty == tt + 1, rb), m_p2 = rballot(r < hl && hty == tt + 2, rb);
+            if ((m_m2 && m_m1) || (m_m1 && m_p1) || (m_p1 && m_p2)) {
+                const uint32_t m_0 = rballot(r < hl && hty == tt, rb);
+                const uint32_t m_p3 = rballot(r < hl && hty == tt + 3, rb), m_m3 = rballot(r < hl && hty == tt - 3, rb);
+                const int a = (r >> 2) & 3, b = r & 3;
+                int n = nl_get(i);
+#pragma unroll
+                for (int k = 0; k < 3; k++) {
+                    const bool pat_ok = k == 0 ? (r9 >= 2) : (k == 1 ? (r9 >= 1 && r9 <= 7) : (r9 <= 6));
+                    const uint32_t ma = k == 0 ? m_m2 : (k == 1 ? m_m1 : m_p1);
+                    const uint32_t mbb = k == 0 ? m_m1 : (k == 1 ? m_p1 : m_p2);
+                    int forb = __popc(m_0);
+                    if (k == 2 && r9 <= 5) forb += __popc(m_p3);
+                    if (k == 0 && r9 >= 3) forb += __popc(m_m3);
+                    const bool kk_ok = kuikae ? (hl - 2 - forb) > 0 : (hl - 2) > 0;
+                    const bool valid = pat_ok && a < __popc(ma) && b < __popc(mbb) && kk_ok;
+                    uint32_t x = ma, y = mbb;
+                    for (int s = 0; s < a; s++) x &= x - 1u;
+                    for (int s = 0; s < b; s++) y &= y - 1u;
+                    const int ia = valid ? __ffs((int)x) - 1 : 0, ib = valid ? __ffs((int)y) - 1 : 0;
+                    const uint32_t ta = (uint32_t)rbc(ht, rb + ia), tb = (uint32_t)rbc(ht, rb + ib);
+                    const uint32_t vb = rballot(valid, rb);
+                    if (valid) r4_put(q, i, n + __popc(vb & ((1u << r) - 1u)), mk_action(RMJ_CHI, tile, 2, ta, tb));
+                    n += __popc(vb);
+                }
+                nl_set(i, n);
+            }
+        }
+    }
+    // ---- E: Pass, lengths, stale counts (lane = seat)
+    int n_me = r < 4 ? nl_get(r) : 0;
+    if (rballot(r < 4 && n_me + 1 > R4_LIST, rb)) { q.bail = true; return; }
+    if (r < 4) {
+        G->stale_n[r] = (uint8_t)(n_me > 62 ? 62 : n_me);
+        if (n_me > 0) {
+            q.T->lst[q.row][r][n_me] = mk_action(RMJ_PASS, RMJ_TILE_NONE, 0);
+            n_me += 1;
+        }
+    }
+    nl_mine = r < 4 ? n_me : 0;
+    const uint32_t claim_active = rballot(r < 4 && n_me > 0, rb) & 0xFu;
+    wave_sync();
+    if (claim_active) {
+        if (r == 0) {
+            G->phase = RMJ_WAIT_RESPONSE;
+            G->active_mask = (uint8_t)claim_active;
+        }
+        wave_sync();
+    } else {
+        r4_accept_riichi(q);
+        r4_check_abortive(q);
+        if (q.bail) return;
+        const uint32_t tc = G->turn_count + 1u;
+        if (r == 0) {
+            G->turn_count = tc;
+            G->current_player = (uint8_t)(pid + 1 == KNP ? 0 : pid + 1);
+        }
+        wave_sync();
+        r4_deal_next(q, pf);
+        if (q.bail) return;
+        if (r == 0 && tc >= (uint32_t)KNP) G->is_first_turn = 0;
+        wave_sync();
+    }
+}
+
+// _get_legal_actions_internal, WaitAct branch (legal_actions.rs:11-252), for the row's current player.  Everything that
+// needs a yaku evaluation or a wait probe (a complete hand, a possible Riichi, a kan in riichi) makes the row bail.
+__device__ __forceinline__ void r4_gen_act_legal(R4& q, int& nl_mine) {
+    GState* G = q.G;
+    const int r = q.r, rb = q.rb;
+    const int pid = G->current_player;
+    PState* P = &G->p[pid];
+    const int hl = P->hand_len, nmelds = P->n_melds;
+    const uint32_t pflags = P->flags;
+    const bool r_decl = pflags & PF_RIICHI_DECLARED, r_stage = pflags & PF_RIICHI_STAGE;
+    const int drawn_tile = G->drawn_tile;
+    const bool drawn = drawn_tile != 0xFF;
+    const int drawable = G->drawable_count;
+    if (hl + 3 * nmelds == 13 || r_stage) { q.bail = true; return; }
+    const int ht = r < hl ? (int)P->hand[r] : 0xFF;
+    const int hty = ht >> 2;
+    int n = 0;
+    // 1. Tsumo: is the drawn type a wait of the 13 other tiles?  (cache, else the cheap refill; a complete hand bails)
+    if (drawn) {
+        const uint32_t b = rballot(r < hl && ht == drawn_tile, rb);
+        const int idx = b ? 31 - __clz((int)b) : -1;
+        const int same_type = __popc(rballot(r < hl && hty == (drawn_tile >> 2), rb));
+        if (!(idx >= 0 && same_type <= 4 && (hl - 1) + 3 * nmelds == 13)) { q.bail = true; return; }
+        if (!(pflags & PF_WAITS_VALID)) {
+            const PH h13 = r4_hist(q, P, idx);
+            r4_fill_waits13(q, P, h13);
+            if (q.bail) return;
+        }
+        if ((P->waits13 >> (drawn_tile >> 2)) & 1ull) { q.bail = true; return; }
+    }
+    // 2. Discards (+ Riichi -> bail)
+    const int nforb = P->n_forbidden;
+    const bool forb = (nforb > 0 && (P->forbidden[0] >> 2) == hty) || (nforb > 1 && (P->forbidden[1] >> 2) == hty);
+    const PH full = r4_hist(q, P, -1);
+    if (r_decl) {
+        if (drawn) {
+            if (r == 0) r4_put(q, pid, n, mk_action(RMJ_DISCARD, drawn_tile, 0));
+            n += 1;
+        }
+    } else {
+        const bool all_closed = rballot(r < nmelds && P->meld_type[r & 3] != RMJ_MELD_ANKAN, rb) == 0u;
+        const bool riichi_pre = P->score >= 1000 && (KSANMA ? drawable > 0 : drawable >= 4) && all_closed;
+        if (riichi_pre) {
+            const int sh13 = (drawn && (P->flags & PF_WAITS_VALID)) ? (int)P->sh13 : -1;
+            if (sh13 < 2) {
+                // tenpai_after_discard: only a 14-tile shanten <= 0 can keep a tenpai 13; those hands take the probes
+                if (r4_shanten(q, full, hl / 3) <= 0) { q.bail = true; return; }
+            }
+        }
+        const bool ok = r < hl && !forb;
+        const uint32_t vb = rballot(ok, rb);
+        if (ok) r4_put(q, pid, n + __popc(vb & ((1u << r) - 1u)), mk_action(RMJ_DISCARD, ht, 0));
+        n += __popc(vb);
+    }
+    // 3. Kan
+    if (drawable > 0 && drawn) {
+        if (!r_decl) {
+            const bool any4 = (((full.a | full.b | full.c) & O9_4) | (full.d & O7_4)) != 0u;
+            if (any4) { q.bail = true; return; }          // Ankan available: full path builds the list
+            const uint32_t pon_lane = rballot(r < nmelds && P->meld_type[r & 3] == RMJ_MELD_PON, rb);
+            if (pon_lane) {                               // Kakan: meld order, then hand order
+                for (int m = 0; m < nmelds; m++) {
+                    if (P->meld_type[m] != RMJ_MELD_PON) continue;
+                    const int target = P->meld_tiles[m][0] >> 2;
+                    const bool hit = r < hl && hty == target;
+                    const uint32_t kb = rballot(hit, rb);
+                    if (hit)
+                        r4_put(q, pid, n + __popc(kb & ((1u << r) - 1u)),
+                               mk_action(RMJ_KAKAN, ht, 3, P->meld_tiles[m][0], P->meld_tiles[m][1], P->meld_tiles[m][2]));
+                    n += __popc(kb);
+                }
+            }
+        } else {
+            if (ph_cnt(full, drawn_tile >> 2) == 4) { q.bail = true; return; }   // ankan after riichi: wait probes
+        }
+    }
+    // 4. Kyushu kyuhai: first turn, no calls, nine kinds of terminals and honors (the type set is OR-ed over the row)
+    if (G->is_first_turn && (G->p[0].n_melds | G->p[1].n_melds | G->p[2].n_melds | G->p[3].n_melds) == 0) {
+        const bool term = r < hl && is_terminal_tile136(ht);
+        const uint32_t lo = row_or16(term && hty < 32 ? 1u << hty : 0u), hi = row_or16(term && hty >= 32 ? 1u << (hty - 32) : 0u);
+        const int kinds = __popc((uint32_t)rbc((int)lo, rb + 15)) + __popc((uint32_t)rbc((int)hi, rb + 15));
+        if (kinds >= 9) {
+            if (r == 0) r4_put(q, pid, n, mk_action(RMJ_KYUSHU, RMJ_TILE_NONE, 0));
+            n += 1;
+        }
+    }
+    // 5. Kita (state_3p/sanma.rs:146-169)
+    if (KSANMA && drawn && drawable > 0) {
+        const bool hit = r < hl && hty == 30;
+        const uint32_t kb = rballot(hit, rb);
+        if (hit) r4_put(q, pid, n + __popc(kb & ((1u << r) - 1u)), mk_action(RMJ_KITA, ht, 0));
+        n += __popc(kb);
+    }
+    if (n > R4_LIST) { q.bail = true; return; }
+    nl_mine = r == pid ? n : 0;
+    wave_sync();
+}
+
+// One step of four consecutive games per wave; device policy only (rmj_step_random / rmj_bench_rollout).
+#ifndef RMJ_STEP4_WAVES
+#define RMJ_STEP4_WAVES 6
+#endif
+__global__ __launch_bounds__(64, RMJ_STEP4_WAVES) void k_step4(const Env* __restrict__ Ep, uint64_t policy_seed, uint32_t flags, uint32_t g_base,
+                                                                   uint32_t g_end) {
+    CEnv& E = *(CEnv*)Ep;
+    __shared__ Quad4Shared sh;
+    const int lane = threadIdx.x & 63;
+    const int row = lane >> 4, r = lane & 15, rb = lane & 48;
+    const uint32_t g0 = g_base + blockIdx.x * 4u;
+    const uint32_t g = g0 + (uint32_t)row;
+    const uint32_t n_here = g_end - g0 < 4u ? g_end - g0 : 4u;   // games of this wave
+    // ---- records: 4 x 640 B contiguous in HBM -> LDS
+    for (int c = lane; c < (int)(n_here * (sizeof(GState) / 16)); c += 64)
+        reinterpret_cast<uint4*>(&sh.st[0])[c] = reinterpret_cast<const uint4*>(E.core + g0)[c];
+    wave_sync();
+    R4 q;
+    q.G = &sh.st[row]; q.T = &sh.u.t; q.E = &E; q.lane = lane; q.r = r; q.rb = rb; q.row = row; q.g = g;
+    q.live = (uint32_t)row < n_here;
+    q.bail = false; q.evn = 0; q.dirty = 0xFu;
+    GState* G = q.G;
+    const uint64_t* Lg = E.legal + (size_t)g * 4 * RMJ_MAX_LEGAL;
+    // the next live-wall draw (valid while nothing moves live_end: kans bail)
+    int pf = 0;
+    if (q.live) {
+        const int le = G->live_end;
+        pf = (E.wall + (size_t)g * RMJ_WALL_STRIDE)[le > 0 ? le - 1 : 0];
+    }
+    // ---- policy (lane = seat): RandomAgent keyed per (game, step, seat), see k_step
+    uint64_t mine = RMJ_NO_ACTION;
+    if (q.live) {
+        if (G->is_done) {
+            q.bail = true;   // finished game: restart (auto-reset) or nothing to do - both handled by the full path
+        } else if (r < 4) {
+            const uint32_t n = G->nlegal[r];
+            if (((G->active_mask >> r) & 1u) && n != 0u) {
+                const uint64_t gs = sm64(policy_seed + E.game_offset + (uint64_t)g);
+                const uint64_t key = sm64(gs + (uint64_t)G->step_count * 4ull + (uint64_t)r);
+                const uint32_t ch = mod_small(key, n > 64u ? 64u : n);
+                mine = Lg[r * RMJ_MAX_LEGAL + ch];
+            }
+        }
+    }
+    int nl_mine = 0;          // lane = seat: length of the seat's list produced by this step
+    uint64_t w_mine = 0ull;   // lane = seat: waits published for the seat
+    const bool t0 = q.live && !q.bail;
+    if (t0) {
+        if (r == 0) G->step_count += 1;
+        const int phase = G->phase;
+        if (phase == RMJ_WAIT_ACT) {
+            const int pid = G->current_player;
+            const uint64_t act = rbc64(mine, rb + pid);
+            const uint32_t ty = a_type(act);
+            PState* P = &G->p[pid];
+            if (act == RMJ_NO_ACTION || a_tile(act) == RMJ_TILE_NONE) {
+                q.bail = true;
+            } else if (ty == RMJ_DISCARD) {
+                q.dirty = 1u << pid;
+                const int tile = (int)a_tile(act);
+                const int hl = P->hand_len;
+                const int t = r < hl ? (int)P->hand[r] : 0xFFFF;
+                const int drawn = G->drawn_tile;
+                const bool tsumogiri = drawn != 0xFF && drawn == tile;
+                const uint32_t fm = rballot(r < hl && t == tile, rb);
+                const int idx = fm ? __ffs((int)fm) - 1 : -1;
+                // hand.remove(idx); hand.sort(): the hand is 13 sorted tiles + the drawn one (else: poked state -> bail)
+                const int nxt = __builtin_amdgcn_update_dpp(0xFFFF, t, 0x101 /* row_shl:1 */, 0xf, 0xf, false);
+                if (idx < 0 || rballot(r < hl - 2 && t > nxt, rb)) {
+                    q.bail = true;
+                } else {
+                    const int d = rbc(t, rb + hl - 1);
+                    const int before_d = __popc(rballot(r < hl - 1 && r != idx && t <= d, rb));
+                    int np = r - (idx < r ? 1 : 0) + ((idx != hl - 1 && d < t) ? 1 : 0);
+                    if (r == hl - 1) np = before_d;
+                    wave_sync();
+                    if (r < hl && r != idx) P->hand[np] = (uint8_t)t;
+                    if (r == 0) P->hand_len = (uint8_t)(hl - 1);
+                    wave_sync();
+                    r4_resolve_discard(q, pid, tile, tsumogiri, pf, nl_mine, w_mine);
+                }
+            } else {
+                q.bail = true;   // Riichi, kans, Tsumo, Kyushu, Kita: full path
+            }
+        } else {
+            // ---- WaitResponse (state/mod.rs:900-1314), lane = seat
+            q.dirty = 0xFu;
+            const bool has = r < 4 && mine != RMJ_NO_ACTION;
+            const uint32_t my_ty = a_type(mine);
+            const uint32_t act_m = G->active_mask;
+            const bool is_act = has && ((act_m >> r) & 1u);
+            const uint32_t roned = rballot(has && my_ty == RMJ_RON, rb) & 0xFu;
+            const uint32_t offer = G->ron_offer_mask;
+            if (roned & act_m) {
+                q.bail = true;                                    // Ron settlement
+            } else {
+                if (r < 4 && ((offer & ~roned) >> r) & 1u) {      // a Ron offer that was not taken
+                    uint32_t fl = G->p[r].flags | PF_MISSED_DOUJUN;
+                    if (fl & PF_RIICHI_DECLARED) fl |= PF_MISSED_RIICHI;
+                    G->p[r].flags = (uint8_t)fl;
+                }
+                const uint32_t pon_m = rballot(is_act && (my_ty == RMJ_PON || my_ty == RMJ_DAIMINKAN), rb) & 0xFu;
+                const uint32_t chi_m = KSANMA ? 0u : (rballot(is_act && my_ty == RMJ_CHI, rb) & 0xFu);
+                const int claimer = pon_m ? __ffs((int)pon_m) - 1 : (chi_m ? __ffs((int)chi_m) - 1 : -1);
+                wave_sync();
+                if (claimer >= 0) {
+                    const uint64_t claim = rbc64(mine, rb + claimer);
+                    const uint32_t ty = a_type(claim);
+                    if (ty == RMJ_DAIMINKAN) {
+                        q.bail = true;
+                    } else {
+                        PState* C = &G->p[claimer];
+                        r4_accept_riichi(q);
+                        const int ldp = G->last_discard_pid, tile = G->last_discard_tile;
+                        if (r < 4) {
+                            uint32_t fl = G->p[r].flags & ~(uint32_t)PF_IPPATSU;
+                            if (r == claimer) fl &= ~(uint32_t)PF_MISSED_DOUJUN;
+                            if (r == ldp) fl &= ~(uint32_t)PF_NAGASHI;
+                            if (r == claimer) fl &= ~(uint32_t)PF_WAITS_VALID;   // hand_remove_tiles
+                            G->p[r].flags = (uint8_t)fl;
+                        }
+                        // hand_remove_tiles: both consumed ids leave the hand, order preserved
+                        const int hl = C->hand_len;
+                        const int hc = r < hl ? (int)C->hand[r] : 0xFFFF;
+                        const uint32_t c0 = a_c(claim, 0), c1 = a_c(claim, 1);
+                        const uint32_t f0 = rballot(r < hl && (uint32_t)hc == c0, rb), f1 = rballot(r < hl && (uint32_t)hc == c1, rb);
+                        const uint32_t rm = (f0 ? (f0 & (0u - f0)) : 0u) | (f1 ? (f1 & (0u - f1)) : 0u);
+                        wave_sync();
+                        if (r < hl && !((rm >> r) & 1u)) C->hand[r - __popc(rm & ((1u << r) - 1u))] = (uint8_t)hc;
+                        if (r == 0) {
+                            C->hand_len = (uint8_t)(hl - __popc(rm));
+                            G->is_rinshan = 0;
+                            G->is_first_turn = 0;
+                            push_meld(*C, ty == RMJ_PON ? RMJ_MELD_PON : RMJ_MELD_CHI, c0, c1, (uint32_t)tile, 0, 3, ldp, tile);
+                        }
+                        wave_sync();
+                        {   // emit_meld
+                            const uint32_t cons = c0 | (c1 << 8);
+                            r4_emit(q, (uint32_t)(ty == RMJ_PON ? RMJ_EV_PON : RMJ_EV_CHI) | ((uint32_t)claimer << 8) | ((uint32_t)ldp << 16) |
+                                           ((uint32_t)tile << 24), cons, (2u << 4) & 0xFFu);
+                        }
+                        if (r == 0) {
+                            if (ty == RMJ_PON) {   // pao_check (state/mod.rs:1228-1259)
+                                int nd = 0, nw = 0;
+                                for (int m = 0; m < C->n_melds; m++) {
+                                    const int tm = C->meld_tiles[m][0] >> 2;
+                                    if (C->meld_type[m] != RMJ_MELD_CHI) { nd += (tm >= 31 && tm <= 33); nw += (tm >= 27 && tm <= 30); }
+                                }
+                                const int tv = tile >> 2;
+                                if (tv >= 31 && tv <= 33) { if (nd == 3) C->pao37 = (uint8_t)ldp; }
+                                else if (tv >= 27 && tv <= 30) { if (nw == 4) C->pao50 = (uint8_t)ldp; }
+                            }
+                            G->current_player = (uint8_t)claimer;
+                            G->phase = RMJ_WAIT_ACT;
+                            G->active_mask = (uint8_t)(1u << claimer);
+                            C->forbidden[0] = (uint8_t)tile;
+                            C->n_forbidden = 1;
+                            if (ty != RMJ_PON) {
+                                const int t34 = tile >> 2;
+                                const int x = (int)c0 >> 2, y = (int)c1 >> 2;
+                                const int lo = min(x, y), hi = max(x, y);
+                                if (lo == t34 + 1 && hi == t34 + 2) {
+                                    if (t34 % 9 <= 5) { C->forbidden[1] = (uint8_t)((t34 + 3) * 4); C->n_forbidden = 2; }
+                                } else if (t34 >= 2 && hi == t34 - 1 && lo == t34 - 2 && t34 % 9 >= 3) {
+                                    C->forbidden[1] = (uint8_t)((t34 - 3) * 4);
+                                    C->n_forbidden = 2;
+                                }
+                            }
+                            G->needs_tsumo = 0;
+                            G->drawn_tile = 0xFF;
+                        }
+                        wave_sync();
+                    }
+                } else {
+                    if (G->pending_kan_pid != 0xFF) {
+                        q.bail = true;     // a chankan / kita offer was passed: the kan resolves in the full path
+                    } else {
+                        if (r == 0) {
+                            G->active_mask = 0;
+                            G->ron_offer_mask = 0;
+                        }
+                        if (r < 4) G->stale_n[r] = 0;   // current_claims.clear() (state/mod.rs:1299)
+                        wave_sync();
+                        r4_accept_riichi(q);
+                        const uint32_t tc = G->turn_count + 1u;
+                        const int np_ = (G->current_player + 1) % KNP;
+                        if (r == 0) {
+                            G->turn_count = tc;
+                            G->current_player = (uint8_t)np_;
+                        }
+                        wave_sync();
+                        r4_deal_next(q, pf);
+                        if (!q.bail) {
+                            if (r == 0 && tc >= (uint32_t)KNP) G->is_first_turn = 0;
+                            wave_sync();
+                        }
+                    }
+                }
+            }
+        }
+        // ---- the next observation: a WaitAct state needs the acting seat's list
+        if (!q.bail && G->phase == RMJ_WAIT_ACT) {
+            nl_mine = 0;
+            w_mine = 0ull;
+            r4_gen_act_legal(q, nl_mine);
+        }
+    }
+    // ---- publication of the rows that completed in tier 0
+    const bool done0 = q.live && t0 && !q.bail;
+    if (done0) {
+        const uint32_t am = G->active_mask;
+        const bool acts = r < 4 && ((am >> r) & 1u);
+        const int n_me = acts ? nl_mine : 0;
+        // masks: 82-bit id sets per seat by LDS atomics, rows of seats that had or have a list are rewritten
+        const uint32_t rows = (rballot(r < 4 && G->nlegal[r & 3] != 0, rb) | am) & 0xFu;
+        q.T->mk[row][r >> 2][r & 3] = 0u;
+        wave_sync();
+        for (uint32_t m = am; m; m &= m - 1u) {
+            const int p = __ffs((int)m) - 1;
+            const int n = rbc(n_me, rb + p);
+            if (r < n) {
+                const uint64_t a = q.T->lst[row][p][r];
+                (E.legal + (size_t)g * 4 * RMJ_MAX_LEGAL)[p * RMJ_MAX_LEGAL + r] = a;
+                const int id = KSANMA ? a_encode_3p(a) : a_encode(a);
+                if (id >= 0 && id < (KSANMA ? 60 : 82)) atomicOr(&q.T->mk[row][p][id >> 5], 1u << (id & 31));
+            }
+        }
+        wave_sync();
+        uint16_t* mout = reinterpret_cast<uint16_t*>(E.mask + (size_t)g * 328);
+        for (uint32_t m = rows; m; m &= m - 1u) {
+            const int p = __ffs((int)m) - 1;
+#pragma unroll
+            for (int k = 0; k < 3; k++) {
+                const int j = r + 16 * k;   // 16-bit unit = ids 2j, 2j + 1
+                if (j < 41) {
+                    const uint32_t w = q.T->mk[row][p][(2 * j) >> 5];
+                    const uint32_t b0 = (w >> ((2 * j) & 31)) & 1u, b1 = (w >> ((2 * j + 1) & 31)) & 1u;
+                    mout[41 * p + j] = (uint16_t)(b0 | (b1 << 8));
+                }
+            }
+        }
+        if (r < 4) {
+            E.nlegal[(size_t)g * 4 + r] = (uint8_t)n_me;
+            G->nlegal[r] = (uint8_t)n_me;
+            E.waits[(size_t)g * 4 + r] = acts ? w_mine : 0ull;
+            if (acts && !G->is_done) {
+                G->obs_from[r] = G->obs_upto[r];
+                G->obs_upto[r] = G->ev_count;
+            }
+        }
+        if (r == 0) E.status[g] = (uint32_t)G->active_mask | ((uint32_t)G->phase << 8) | ((uint32_t)G->is_done << 16);
+        // staged events -> ring
+        if (r < 2 * q.evn) {
+            const int e = r >> 1, hh = r & 1;
+            uint4* dst = reinterpret_cast<uint4*>(E.events + (size_t)g * (E.ring_mask + 1u) + q.T->evidx[row][e]);
+            dst[hh] = reinterpret_cast<const uint4*>(q.T->ev[row][e])[hh];
+        }
+    }
+    wave_sync();
+    // ---- records of the completed rows back to HBM (globals + touched PState quarters)
+    {
+        const uint64_t okm = __ballot(done0 && r == 0);                     // bit 16 * row
+        const uint32_t d0 = (uint32_t)rbc((int)q.dirty, 0), d1 = (uint32_t)rbc((int)q.dirty, 16), d2 = (uint32_t)rbc((int)q.dirty, 32),
+                       d3 = (uint32_t)rbc((int)q.dirty, 48);
+        for (int c = lane; c < (int)(n_here * (sizeof(GState) / 16)); c += 64) {
+            const int gm = c / 40, off = c - 40 * gm;
+            const uint32_t dm = gm == 0 ? d0 : (gm == 1 ? d1 : (gm == 2 ? d2 : d3));
+            if (((okm >> (16 * gm)) & 1u) && (off >= 32 || ((dm >> (off >> 3)) & 1u)))
+                reinterpret_cast<uint4*>(E.core + g0)[c] = reinterpret_cast<const uint4*>(&sh.st[0])[c];
+        }
+    }
+    wave_sync();
+    // ---- bailed games: the complete state machine, one game at a time, from the untouched HBM record
+    uint64_t bm = __ballot(q.live && q.bail && r == 0);
+    while (bm) {
+        const int br = (__ffsll((long long)bm) - 1) >> 4;
+        bm &= bm - 1ull;
+        const uint32_t gg = g0 + (uint32_t)br;
+        // the seats' actions of that game move to lanes 0..3
+        const uint64_t m_full = rbc64(mine, 16 * br + (lane & 3));
+        Ctx c{sh.st[br], E, sh.u.x, gg, lane, E.wall + (size_t)gg * RMJ_WALL_STRIDE, E.legal + (size_t)gg * 4 * RMJ_MAX_LEGAL};
+        ol_step_full(ctx_pack(c), lane < 4 ? m_full : RMJ_NO_ACTION, flags);
+        wave_sync();
+    }
+}
+
+}  // namespace RMJ_NS

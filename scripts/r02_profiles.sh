@@ -35,8 +35,8 @@ for grp in "FETCH_SIZE" "WRITE_SIZE" "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS S
   timeout 300 rocprofv3 --pmc $grp --output-format csv -d $R/gpurun_out/${TAG}_pmcenc_p$i -- python3 scripts/bench_encoders.py > $R/gpurun_out/${TAG}_pmcenc_p$i.log 2>&1
   echo "encoders pass $i ($grp) rc=$?"
 done
-python3 scripts/pmc_summary.py $R/gpurun_out ${TAG}_pmcenc "k_encode<false, false>" 2 > $R/gpurun_out/${TAG}_pmc_k_encode_4p.json
-python3 scripts/pmc_summary.py $R/gpurun_out ${TAG}_pmcenc "k_encode<true, false>" 5 > $R/gpurun_out/${TAG}_pmc_k_encode_3p.json
+python3 scripts/pmc_summary.py $R/gpurun_out ${TAG}_pmcenc "k_encode_base<false" 2 > $R/gpurun_out/${TAG}_pmc_k_encode_4p.json
+python3 scripts/pmc_summary.py $R/gpurun_out ${TAG}_pmcenc "k_encode_base<true" 5 > $R/gpurun_out/${TAG}_pmc_k_encode_3p.json
 python3 scripts/pmc_summary.py $R/gpurun_out ${TAG}_pmcenc "k_encode<false, true>" 2 > $R/gpurun_out/${TAG}_pmc_k_encode_ext_4p.json
 python3 scripts/pmc_summary.py $R/gpurun_out ${TAG}_pmcenc "k_encode<true, true>" 5 > $R/gpurun_out/${TAG}_pmc_k_encode_ext_3p.json
 rm -rf gpurun_out/${TAG}_pmc_p* gpurun_out/${TAG}_pmcenc_p*/

@@ -224,8 +224,8 @@ def main(argv=None):
         env.set_rollout_streams(1)
         r1 = env.bench_rollout(policy_seed, 0, k)
         extras["single_stream"] = {"value": r1.env_steps / (r1.total_ms * 1e-3), "ms_per_step": r1.total_ms / k, "steps": k,
-                                   "what": "the same rollout as one launch over all games per step on one stream (what a policy "
-                                           "that is a barrier between steps gets)"}
+                                   "what": "the same rollout with every step as its own launch over all games on one stream "
+                                           "(what a policy that is a barrier between steps gets)"}
         rv = env.bench_rollout_validated(policy_seed, 0, k)
         extras["validated_actions"] = {"value": rv.env_steps / (rv.total_ms * 1e-3), "ms_per_step": rv.total_ms / k, "steps": k,
                                        "what": "one policy launch writing packed actions + one step launch that validates them "
@@ -234,15 +234,23 @@ def main(argv=None):
 
     if rank == 0:
         b_step = B_STEP_3P if sanma else B_STEP_4P
+        steps_per_launch = 1
         if args.encode:
             in_flight, kernel_ms = 1, r_enc_step
+        elif int(r.launches) == 1 and args.steps > 1:
+            # the rollout is ONE launch in which every wave steps its four games `steps` times: the launch processes
+            # steps x games game-steps; its duration comes from HIP events around it on the handle's stream
+            in_flight, kernel_ms, steps_per_launch = 1, r.total_ms, args.steps
         else:
-            # a device rollout runs as `in_flight` concurrent launches (parts of the batch on as many streams,
-            # rmj_step_random): bytes and duration are per launch, the bandwidth the chip delivers is in_flight launches' worth
+            # per-step launches on `in_flight` streams (parts of the batch): bytes and duration are per launch, the
+            # bandwidth the chip delivers is in_flight launches' worth
             in_flight, kernel_ms = max(1, int(r.launches_in_flight)), r.step_kernel_ms
         games_per_launch = args.games // in_flight
-        traffic, traffic_src = pmc_traffic("k_step", games_per_launch, args.mode)
-        achieved = in_flight * b_step * games_per_launch / (kernel_ms * 1e-3)
+        traffic, traffic_src = pmc_traffic("k_step4", games_per_launch, args.mode)
+        if traffic is not None:
+            traffic *= steps_per_launch            # the committed summary is per step of all games
+        bytes_per_launch = b_step * games_per_launch * steps_per_launch
+        achieved = in_flight * bytes_per_launch / (kernel_ms * 1e-3)
         out = {
             "metric": metric_name(args),
             "value": steps_total / wall, "unit": "env.step/s", "n_gpus": world, "steps": args.steps,
@@ -256,9 +264,10 @@ def main(argv=None):
             "full_path_frac": full_steps / max(steps_local, 1.0),
             "roofline": {"bound": "hbm", "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK, "traffic": traffic, "traffic_unit": "bytes/launch",
-                         "traffic_source": traffic_src, "kernel": "k_step",
-                         "kernel_ms": kernel_ms, "bytes_per_launch": b_step * games_per_launch,
-                         "games_per_launch": games_per_launch, "launches_in_flight": in_flight},
+                         "traffic_source": traffic_src, "kernel": "k_step4" if not args.encode else "k_step",
+                         "kernel_ms": kernel_ms, "bytes_per_launch": bytes_per_launch, "bytes_per_game_step": b_step,
+                         "games_per_launch": games_per_launch, "steps_per_launch": steps_per_launch,
+                         "launches_in_flight": in_flight},
         }
         if "encode" in extras:
             acting, enc_ms = extras.pop("encode")

@@ -185,11 +185,13 @@ int rmj_step_device(rmj_handle h, const rmj_action_t* d_actions);
  * keyed per (game, step, seat) — SURVEY §8(c)): choice = mix(policy_seed, global_game, step_no, seat) % n_legal
  * over the ordered legal list.  Runs n_steps batched steps; with auto_reset != 0 a finished game is
  * re-`reset()` (defaults) at the start of the next step instead of stepping.
- * Games are independent, so a rollout of >= 2 steps over >= 16 384 games is issued as up to four parts of the batch
- * (>= 8 192 games each) on as many HIP streams: each part gets its n_steps launches in order, and the draining tail of
- * one part's launch overlaps the bodies of the others'.  The streams are forked from and joined back into the handle's
- * stream inside the call.  Every game is stepped exactly n_steps times either way, and the results do not depend on
- * it.  RMJ_STEP_STREAMS=<k> in the environment sets the number of parts (1 = one stream). */
+ * Games are independent, so a rollout of >= 2 steps needs no synchronisation between the steps of different games: it
+ * is issued as ONE launch in which every wavefront keeps its four games' records in LDS and steps them n_steps times,
+ * publishing every step's outputs (lists, masks, status, events, record) exactly like n_steps launches would (kernel
+ * k_step4<true>, four games per wavefront).  Every game is stepped exactly n_steps times and the results do not depend on
+ * it.  rmj_set_rollout_streams(h, 1) (or RMJ_STEP_STREAMS=1) makes every step its own launch on the handle's stream - what
+ * a policy that is a barrier between steps gets; RMJ_STEP4=1 / 0 in the environment at create selects the earlier
+ * schedules (one launch per step and part on up to four streams; one game per wavefront). */
 int rmj_step_random(rmj_handle h, uint64_t policy_seed, uint32_t n_steps, int auto_reset);
 /* Fill actions[n][4] with what the device policy would choose for the CURRENT state (no step). */
 int rmj_random_actions(rmj_handle h, uint64_t policy_seed, rmj_action_t* actions);
@@ -403,10 +405,11 @@ int rmj_encode_seq_device(rmj_handle h, int game_style, const RmjSeqBuffers* d_o
 /* ------------------------------------------------------------------ measurement */
 typedef struct RmjBenchResult {
     double total_ms;      /* HIP-event time over the timed region (stream of the handle) */
-    double step_kernel_ms;/* average duration of one step-kernel launch: total_ms / (launches / launches_in_flight) -
-                             the launches of one stream run back to back over the timed region */
+    double step_kernel_ms;/* average duration of one step of all games: total_ms / steps (a fused rollout is one launch of
+                             `steps` steps; with per-step launches on several streams, the launches of one stream run back
+                             to back over the timed region) */
     uint64_t env_steps;   /* sum over games of step calls that advanced the game */
-    uint32_t launches;    /* step-kernel launches in the timed region */
+    uint32_t launches;    /* step-kernel launches in the timed region (1 for a fused rollout) */
     uint32_t launches_in_flight; /* streams the rollout ran on (parts of the batch, rmj_step_random); 1 = one stream */
     uint64_t full_path_steps; /* game-steps of the timed region that left the fast path of the step kernel (round ends,
                                  yaku evaluation, kans, riichi, restarts of finished games) */

@@ -647,7 +647,8 @@ struct rmj_env {
     void* d_scratch = nullptr; // staging buffer of the host-copy entry points (grown on demand, never per call)
     size_t scratch_bytes = 0;
     int want_streams = 4;      // parts a multi-step device rollout is cut into (rmj_set_rollout_streams; RMJ_STEP_STREAMS at create)
-    int quad = 0;              // device-policy steps run four games per wave (k_step4); RMJ_STEP4 at create
+    int quad = 2;              // device-policy steps: 0 = one game per wave (k_step), 1 = four games per wave (k_step4), 2 = and a
+                               // rollout of >= 2 steps is ONE launch in which every wave steps its own games (k_step4<true>); RMJ_STEP4 at create
 };
 // device staging memory of at least `bytes` bytes, owned by the handle
 static int scratch_for(rmj_env* h, size_t bytes, void** out) {
@@ -856,8 +857,8 @@ static inline void launch_step_range(rmj_env* h, hipStream_t st, const uint64_t*
 #endif
     if (h->quad && (flags & STEP_F_RANDOM)) {   // device policy: four games per wave
         const dim3 grid((g1 - g0 + 3u) / 4u);
-        if (h->cfg.game_mode >= 3) hipLaunchKernelGGL(rmj3::k_step4, grid, dim3(64), 0, st, (const Env*)h->d_env, policy_seed, flags, g0, g1);
-        else hipLaunchKernelGGL(rmj4::k_step4, grid, dim3(64), 0, st, (const Env*)h->d_env, policy_seed, flags, g0, g1);
+        if (h->cfg.game_mode >= 3) hipLaunchKernelGGL(rmj3::k_step4<false>, grid, dim3(64), 0, st, (const Env*)h->d_env, policy_seed, flags, g0, g1, 1u);
+        else hipLaunchKernelGGL(rmj4::k_step4<false>, grid, dim3(64), 0, st, (const Env*)h->d_env, policy_seed, flags, g0, g1, 1u);
         return;
     }
     if (h->cfg.game_mode >= 3) hipLaunchKernelGGL(rmj3::k_step, step_grid(g1 - g0), dim3(64 * RMJ_STEP_WPB), extra_lds, st, (const Env*)h->d_env, d_actions, policy_seed, flags, g0, g1);
@@ -933,6 +934,7 @@ int rmj_step(rmj_handle h, const rmj_action_t* actions) {
 // streams a device rollout of n_steps steps uses (RMJ_STEP_STREAMS=1 keeps everything on one stream)
 static int rollout_streams(const rmj_env* h, uint32_t n_steps) {
     const int want = h->want_streams;
+    if (h->quad >= 2 && n_steps >= 2 && want >= 2) return 1;   // the fused rollout: one launch, no parts
     if (want < 2 || n_steps < 2 || h->cfg.n_games < RMJ_SPLIT_MIN_GAMES) return 1;
     int k = want > RMJ_MAX_ROLLOUT_STREAMS ? RMJ_MAX_ROLLOUT_STREAMS : want;
     const int fit = (int)(h->cfg.n_games / RMJ_SPLIT_MIN_PART);
@@ -943,6 +945,14 @@ int rmj_step_random(rmj_handle h, uint64_t policy_seed, uint32_t n_steps, int au
     HIPCHK(hipSetDevice(h->cfg.device));
     uint32_t flags = STEP_F_RANDOM | (auto_reset ? STEP_F_AUTORESET : 0u);
     const uint32_t n = h->cfg.n_games;
+    if (h->quad >= 2 && n_steps >= 2 && h->want_streams >= 2) {   // (rmj_set_rollout_streams(h, 1): one launch per step, one stream)
+        // four games per wave, the whole rollout in ONE launch: every wave steps its own games n_steps times (k_step4<true>)
+        const dim3 grid((n + 3u) / 4u);
+        if (h->cfg.game_mode >= 3) hipLaunchKernelGGL(rmj3::k_step4<true>, grid, dim3(64), 0, h->stream, (const Env*)h->d_env, policy_seed, flags, 0u, n, n_steps);
+        else hipLaunchKernelGGL(rmj4::k_step4<true>, grid, dim3(64), 0, h->stream, (const Env*)h->d_env, policy_seed, flags, 0u, n, n_steps);
+        HIPCHK(hipGetLastError());
+        return RMJ_OK;
+    }
     const int k = rollout_streams(h, n_steps);
     if (k >= 2) {
         // games are independent: each part advances n_steps steps on its own stream (header: rmj_step_random)
@@ -1749,7 +1759,8 @@ int rmj_bench_rollout(rmj_handle h, uint64_t policy_seed, uint32_t warmup, uint3
     if ((rc = rmj_total_steps(h, &after)) || (rc = rmj_total_full_path(h, &full1))) return rc;
     out->total_ms = ms;
     const uint32_t fl = (uint32_t)rollout_streams(h, steps);
-    out->launches = steps * fl;
+    const bool fused = h->quad >= 2 && steps >= 2 && h->want_streams >= 2;
+    out->launches = fused ? 1u : steps * fl;
     out->step_kernel_ms = steps ? ms / steps : 0.0;  // each stream runs `steps` launches back to back during `ms`
     out->env_steps = after - before;
     out->launches_in_flight = fl;

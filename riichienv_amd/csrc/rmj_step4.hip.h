@@ -548,34 +548,40 @@ __device__ __forceinline__ void r4_gen_act_legal(R4& q, int& nl_mine) {
     wave_sync();
 }
 
-// One step of four consecutive games per wave; device policy only (rmj_step_random / rmj_bench_rollout).
-#ifndef RMJ_STEP4_WAVES
-#define RMJ_STEP4_WAVES 6
-#endif
-__global__ __launch_bounds__(64, RMJ_STEP4_WAVES) void k_step4(const Env* __restrict__ Ep, uint64_t policy_seed, uint32_t flags, uint32_t g_base,
-                                                                   uint32_t g_end) {
+// One step of four consecutive games per wave (device policy only: rmj_step_random / rmj_bench_rollout); `load`: fetch the records from HBM first (the rollout loop keeps them in LDS)
+template <bool LOOP>
+__device__ __forceinline__ void step4_body(const Env* Ep, Quad4Shared& sh, uint64_t policy_seed, uint32_t flags, uint32_t g_base, uint32_t g_end,
+                                           bool load) {
     CEnv& E = *(CEnv*)Ep;
-    __shared__ Quad4Shared sh;
     const int lane = threadIdx.x & 63;
     const int row = lane >> 4, r = lane & 15, rb = lane & 48;
     const uint32_t g0 = g_base + blockIdx.x * 4u;
     const uint32_t g = g0 + (uint32_t)row;
     const uint32_t n_here = g_end - g0 < 4u ? g_end - g0 : 4u;   // games of this wave
-    // ---- records: 4 x 640 B contiguous in HBM -> LDS
-    for (int c = lane; c < (int)(n_here * (sizeof(GState) / 16)); c += 64)
-        reinterpret_cast<uint4*>(&sh.st[0])[c] = reinterpret_cast<const uint4*>(E.core + g0)[c];
-    wave_sync();
+    if (load) {   // ---- records: 4 x 640 B contiguous in HBM -> LDS
+        for (int c = lane; c < (int)(n_here * (sizeof(GState) / 16)); c += 64)
+            reinterpret_cast<uint4*>(&sh.st[0])[c] = reinterpret_cast<const uint4*>(E.core + g0)[c];
+        wave_sync();
+    }
+    {
     R4 q;
     q.G = &sh.st[row]; q.T = &sh.u.t; q.E = &E; q.lane = lane; q.r = r; q.rb = rb; q.row = row; q.g = g;
     q.live = (uint32_t)row < n_here;
-    q.bail = false; q.evn = 0; q.dirty = 0xFu;
     GState* G = q.G;
     const uint64_t* Lg = E.legal + (size_t)g * 4 * RMJ_MAX_LEGAL;
+    q.bail = false; q.evn = 0; q.dirty = 0xFu;
     // the next live-wall draw (valid while nothing moves live_end: kans bail)
     int pf = 0;
     if (q.live) {
         const int le = G->live_end;
-        pf = (E.wall + (size_t)g * RMJ_WALL_STRIDE)[le > 0 ? le - 1 : 0];
+        const int wi = le > 0 ? le - 1 : 0;
+        const uint8_t* Wg = E.wall + (size_t)g * RMJ_WALL_STRIDE;
+        if (LOOP) {
+            const uint32_t w = __hip_atomic_load(reinterpret_cast<const uint32_t*>(Wg) + (wi >> 2), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            pf = (int)((w >> (8 * (wi & 3))) & 0xFFu);
+        } else {
+            pf = Wg[wi];
+        }
     }
     // ---- policy (lane = seat): RandomAgent keyed per (game, step, seat), see k_step
     uint64_t mine = RMJ_NO_ACTION;
@@ -588,7 +594,8 @@ __global__ __launch_bounds__(64, RMJ_STEP4_WAVES) void k_step4(const Env* __rest
                 const uint64_t gs = sm64(policy_seed + E.game_offset + (uint64_t)g);
                 const uint64_t key = sm64(gs + (uint64_t)G->step_count * 4ull + (uint64_t)r);
                 const uint32_t ch = mod_small(key, n > 64u ? 64u : n);
-                mine = Lg[r * RMJ_MAX_LEGAL + ch];
+                const uint64_t* src = Lg + r * RMJ_MAX_LEGAL + ch;
+                mine = LOOP ? __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : *src;
             }
         }
     }
@@ -831,6 +838,40 @@ __global__ __launch_bounds__(64, RMJ_STEP4_WAVES) void k_step4(const Env* __rest
         Ctx c{sh.st[br], E, sh.u.x, gg, lane, E.wall + (size_t)gg * RMJ_WALL_STRIDE, E.legal + (size_t)gg * 4 * RMJ_MAX_LEGAL};
         ol_step_full(ctx_pack(c), lane < 4 ? m_full : RMJ_NO_ACTION, flags);
         wave_sync();
+    }
+    if (LOOP) {
+        // The next step reads back this step's lists / wall tile with agent-scope loads (served by the XCD's L2, past the
+        // vector L1); the stores are this wave's own, to the same addresses and through the same L2 channel, so no cache
+        // write-back is needed - an agent-scope release fence would write the whole L2 back (buffer_wbl2: 6x slower).
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        wave_sync();
+    }
+    }
+}
+// The step as an out-of-line function with its own static LDS: the rollout loop calls it once per step, so nothing of a
+// step is hoisted out of the loop or kept live across it (the loop inlined: 48 VGPR + 37 SGPR spills).
+template <bool LOOP>
+__device__ __noinline__ void step4_call(const Env* Ep, uint64_t policy_seed, uint32_t flags, uint32_t g_base, uint32_t g_end, uint32_t load) {
+    __shared__ Quad4Shared sh;
+    step4_body<LOOP>(uni_ptr(Ep), sh, uni(policy_seed), uni(flags), uni(g_base), uni(g_end), uni(load) != 0u);
+}
+#ifndef RMJ_STEP4_WAVES
+#define RMJ_STEP4_WAVES 6
+#endif
+// LOOP = false: one step per launch.  LOOP = true: games are independent, so a device-policy rollout needs no
+// synchronisation between the steps of DIFFERENT games: the wave keeps its four records in LDS and steps its own games
+// n_steps times (publishing every step's outputs exactly like n_steps launches would).  A launch per step ends with the
+// slowest wave (the one that restarts a round), and at 65 536 games (16 384 waves = two generations of resident waves)
+// that tail costs as much as the work; the loop pays it once per rollout.
+template <bool LOOP>
+__global__ __launch_bounds__(64, RMJ_STEP4_WAVES) void k_step4(const Env* __restrict__ Ep, uint64_t policy_seed, uint32_t flags, uint32_t g_base,
+                                                                   uint32_t g_end, uint32_t n_steps) {
+    if (LOOP) {
+#pragma unroll 1
+        for (uint32_t it = 0; it < n_steps; it++) step4_call<true>(Ep, policy_seed, flags, g_base, g_end, it == 0 ? 1u : 0u);
+    } else {
+        __shared__ Quad4Shared sh;
+        step4_body<false>(Ep, sh, policy_seed, flags, g_base, g_end, true);
     }
 }
 

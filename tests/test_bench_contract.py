@@ -29,7 +29,7 @@ def test_committed_bench_line_has_the_contract_fields():
     assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9
     # achieved = launches in flight x algorithmic bytes per launch / average launch duration
     assert abs(r["achieved"] - r["launches_in_flight"] * r["bytes_per_launch"] / (r["kernel_ms"] * 1e-3) / 1e9) < 1e-6 * r["achieved"]
-    assert r["bytes_per_launch"] == 1688 * r["games_per_launch"]
+    assert r["bytes_per_launch"] == 1688 * r["games_per_launch"] * r.get("steps_per_launch", 1)
     assert r["traffic"] is None or r["traffic"] > 0
     c = line["cpu_baseline"]
     assert c["kind"] == "port" and c["unit"] == "env.step/s" and c["cores"] >= 1 and c["value"] > 0 and "sample" in c

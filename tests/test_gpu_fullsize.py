@@ -107,14 +107,14 @@ def test_4096_games_4p_red_single():
     """configs[1]: 4 096 parallel 4p-red-single games (one launch per step: below the split threshold); single-kyoku
     games end after ~100 steps, so every sampled game has been restarted several times."""
     env, sample = run_config(0, abi.RULE_TENHOU, 4096, 700)
-    assert env.bench_rollout(PSEED, 0, 4).launches_in_flight == 1
+    assert env.bench_rollout(PSEED, 0, 4).launches == 1
 
 
 @pytest.mark.parametrize("offset", [0, 7 * 65536])
 def test_65536_games_4p_red_half(offset):
     """configs[2] (the headline workload), and the last of the eight shards of configs[3] (global games 458 752 ...)."""
     env, sample = run_config(2, abi.RULE_TENHOU, 65536, 700, offset=offset)
-    assert env.bench_rollout(PSEED, 0, 4).launches_in_flight == 4
+    assert env.bench_rollout(PSEED, 0, 4).launches == 1     # the fused rollout
 
 
 def test_65536_games_4p_mjsoul_rules_single_stream_equals_split():

@@ -243,9 +243,9 @@ def test_shards_equal_whole_batch(mode):
 
 @pytest.mark.parametrize("mode", [2, 5])
 def test_two_stream_rollout_equals_single_stream(mode):
-    """rmj_step_random issues a multi-step rollout of >= 16 384 games as up to four parts on as many HIP streams
-    (header); the result must be the one of stepping launch by launch on the handle's stream (n_steps = 1 never
-    splits)."""
+    """rmj_step_random issues a multi-step rollout as ONE launch in which every wave steps its four games n_steps times
+    (header); the result must be the one of stepping launch by launch on the handle's stream (n_steps = 1 is always a
+    launch of its own)."""
     from riichienv_amd import vecenv
 
     B, K = 32768, 400
@@ -267,4 +267,4 @@ def test_two_stream_rollout_equals_single_stream(mode):
     for g in (0, B // 4 - 1, B // 4, B // 2, 3 * B // 4 - 1, B - 1):
         assert a.mjai_log(g) == b.mjai_log(g)
     r = a.bench_rollout(0xBEEF, 0, 10)
-    assert r.launches == 40 and r.launches_in_flight == 4
+    assert r.launches == 1 and r.launches_in_flight == 1      # the fused rollout: one launch, every wave loops over the steps

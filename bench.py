@@ -121,7 +121,8 @@ def pmc_traffic(kernel, games_per_launch, mode):
             with open(path) as f:
                 d = json.load(f)
             if d.get("games_per_launch") == games_per_launch and d.get("mode", 2) == mode:
-                return d["hbm_traffic"]["bytes_per_launch"], os.path.relpath(path, ROOT)
+                t = d["hbm_traffic"]
+                return t.get("bytes_per_step", t["bytes_per_launch"]), os.path.relpath(path, ROOT)
         except (OSError, KeyError, ValueError):
             continue
     return None, None

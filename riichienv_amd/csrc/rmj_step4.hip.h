@@ -636,8 +636,73 @@ __device__ __forceinline__ void step4_body(const Env* Ep, Quad4Shared& sh, uint6
                     wave_sync();
                     r4_resolve_discard(q, pid, tile, tsumogiri, pf, nl_mine, w_mine);
                 }
+            } else if (KSANMA && ty == RMJ_KITA) {
+                // ---- handle_kita (state_3p/sanma.rs:9-144): a common action of 3P games; a seat that could rob the tile bails
+                q.dirty = 0xFu;
+                const int tile = (int)a_tile(act);
+                const int hl = P->hand_len;
+                const int t = r < hl ? (int)P->hand[r] : 0xFFFF;
+                const uint32_t fm = rballot(r < hl && t == tile, rb);
+                if (G->pending_kan_dora > 0 || !fm || (tile >> 2) != 30 || G->drawable_count == 0) {
+                    q.bail = true;
+                } else {
+                    const int idx = __ffs((int)fm) - 1;
+                    wave_sync();
+                    if (r > idx && r < hl) P->hand[r - 1] = (uint8_t)t;     // hand.remove(idx), order kept
+                    if (r == 0) {
+                        P->hand_len = (uint8_t)(hl - 1);
+                        P->flags &= ~PF_WAITS_VALID;
+                        if (P->n_kita < 4) P->kita[P->n_kita++] = (uint8_t)tile;
+                        G->is_first_turn = 0;
+                        G->ron_offer_mask = 0;
+                    }
+                    wave_sync();
+                    r4_emit_simple(q, RMJ_EV_KITA, (uint32_t)pid, (uint32_t)tile);
+                    // the other seats: refill stale wait caches, then "waits on North and not furiten" needs the yaku check
+                    for (int i = 0; i < KNP; i++) {
+                        PState* Q = &G->p[i];
+                        const bool need = i != pid && (Q->hand_len + 3 * Q->n_melds == 13) && !(Q->flags & PF_WAITS_VALID);
+                        if (__ballot(need)) {
+                            if (need) r4_fill_waits13(q, Q, r4_hist(q, Q, -1));
+                        }
+                    }
+                    if (!q.bail) {
+                        const PState& S4 = G->p[r & 3];
+                        const bool other = r < KNP && r != pid;
+                        const bool holds13 = other && (S4.hand_len + 3 * S4.n_melds == 13);
+                        const uint64_t W = holds13 ? S4.waits13 : 0ull;
+                        const bool furiten = (W & S4.discard_type_mask) != 0ull || (S4.flags & (PF_MISSED_RIICHI | PF_MISSED_DOUJUN));
+                        if (rballot(other && !furiten && ((W >> 30) & 1ull), rb)) q.bail = true;
+                    }
+                    if (!q.bail) {
+                        // resolve_kita_rinshan (state_3p/sanma.rs:171-204): replacement draw from the dead wall, no new dora
+                        const int rc = G->rinshan_count;
+                        const uint8_t* Wg = E.wall + (size_t)g * RMJ_WALL_STRIDE;
+                        int rt;
+                        if (LOOP) {
+                            const uint32_t w = __hip_atomic_load(reinterpret_cast<const uint32_t*>(Wg) + (rc >> 2), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            rt = (int)((w >> (8 * (rc & 3))) & 0xFFu);
+                        } else {
+                            rt = Wg[rc];
+                        }
+                        if (r < 4) G->p[r].flags &= ~PF_IPPATSU;
+                        wave_sync();
+                        if (r == 0) {
+                            G->rinshan_count = (uint8_t)(rc + 1);
+                            G->drawable_count -= 1;
+                            const int h2 = P->hand_len;
+                            if (h2 < 14) { P->hand[h2] = (uint8_t)rt; P->hand_len = (uint8_t)(h2 + 1); }
+                            G->drawn_tile = (uint8_t)rt;
+                            G->is_rinshan = 1;
+                            G->phase = RMJ_WAIT_ACT;
+                            G->active_mask = (uint8_t)(1u << pid);
+                        }
+                        wave_sync();
+                        r4_emit_simple(q, RMJ_EV_TSUMO, (uint32_t)pid, (uint32_t)rt);
+                    }
+                }
             } else {
-                q.bail = true;   // Riichi, kans, Tsumo, Kyushu, Kita: full path
+                q.bail = true;   // Riichi, kans, Tsumo, Kyushu: full path
             }
         } else {
             // ---- WaitResponse (state/mod.rs:900-1314), lane = seat

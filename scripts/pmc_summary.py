@@ -8,6 +8,8 @@ import sys
 
 root, tag, kern = sys.argv[1], sys.argv[2], sys.argv[3]
 mode = int(sys.argv[4]) if len(sys.argv) > 4 else 2
+steps_per_launch = int(sys.argv[5]) if len(sys.argv) > 5 else 1     # fused rollouts: one launch = that many steps of every game
+games_per_wave = int(sys.argv[6]) if len(sys.argv) > 6 else 1
 out = {}
 for f in glob.glob(os.path.join(root, tag + "_p*", "**", "*counter_collection.csv"), recursive=True):
     acc = {}
@@ -26,12 +28,16 @@ doc = {"command": "rocprofv3 --pmc <group> -- python3 <bench command> (one pass 
                   "scripts/pmc_collect.sh)", "kernel": kern, "mode": mode, "counters": out}
 waves = out.get("SQ_WAVES", {}).get("mean_per_launch")
 if waves:
-    doc["games_per_launch"] = int(round(waves))  # one wave per game
-    doc["per_wave"] = {k: v["mean_per_launch"] / waves for k, v in out.items()}
+    doc["games_per_launch"] = int(round(waves)) * games_per_wave
+    doc["games_per_wave"] = games_per_wave
+    doc["steps_per_launch"] = steps_per_launch
+    # per wave AND per step: a wave of a fused rollout lives for steps_per_launch steps
+    doc["per_wave"] = {k: v["mean_per_launch"] / waves / steps_per_launch for k, v in out.items()}
 if "FETCH_SIZE" in out and "WRITE_SIZE" in out:
     f, w = out["FETCH_SIZE"]["mean_per_launch"], out["WRITE_SIZE"]["mean_per_launch"]
     doc["hbm_traffic"] = {"fetch_kb": f, "write_kb": w,
                           "note": "FETCH_SIZE is reported in 64 B units on gfx950 but scaled as 32 B by the tool: doubled per "
                                   "MI355X_MICROARCH.md; WRITE_SIZE as is",
-                          "bytes_per_launch": (2.0 * f + w) * 1024.0}
+                          "bytes_per_launch": (2.0 * f + w) * 1024.0,
+                          "bytes_per_step": (2.0 * f + w) * 1024.0 / steps_per_launch}
 print(json.dumps(doc, indent=1))

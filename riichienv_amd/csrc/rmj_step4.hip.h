@@ -113,9 +113,10 @@ __device__ __forceinline__ int r4_shanten(const R4& q, const PH& h, int len_div3
     const ShantenTables T = sh_tables_of(*q.E);
     const int i = q.r, l15 = q.rb + 15;
     uint64_t vec[4];
+    uint32_t val[4];
 #pragma unroll
-    for (int s = 0; s < 4; s++) {
-        uint32_t val = 0;
+    for (int s = 0; s < 4; s++) {   // the four rank-table loads are in flight together, then the four vector loads
+        val[s] = 0;
         if (i < (s < 3 ? 9 : 7)) {
             const uint32_t x = ph_get(h, s);
             uint32_t c = (x >> (3 * i)) & 7u;
@@ -123,12 +124,13 @@ __device__ __forceinline__ int r4_shanten(const R4& q, const PH& h, int len_div3
             if (c > 4u) c = 4u;
             if (sm > 14u) sm = 14u;
             if (sm + c > 14u) c = 14u - sm;
-            val = (s < 3 ? T.rank9 : T.rank7)[(i * 15 + sm) * 5 + c];
+            val[s] = (s < 3 ? T.rank9 : T.rank7)[(i * 15 + sm) * 5 + c];
         }
-        val = row_sum16(val);
-        const uint32_t idx = (uint32_t)rbc((int)val, l15);
-        vec[s] = s < 3 ? T.suit[idx] : T.honor[idx];
     }
+#pragma unroll
+    for (int s = 0; s < 4; s++) val[s] = (uint32_t)rbc((int)row_sum16(val[s]), l15);
+#pragma unroll
+    for (int s = 0; s < 4; s++) vec[s] = s < 3 ? T.suit[val[s]] : T.honor[val[s]];
     const int m = len_div3 > 4 ? 4 : len_div3;
     // lanes 0..9: entry idx of merge(a, b) and the entry of merge(c, d) that pairs with it in the final entry (pair = 1, m)
     const int p = i >= 5 ? 1 : 0, k = i - 5 * p;
@@ -172,8 +174,16 @@ __device__ __forceinline__ void r4_fill_waits13(R4& q, PState* P, const PH& h13)
     }
     int sh = lb;
     if (lb < 2) {
-        sh = r4_shanten(q, h13, len3);
-        if (sh <= 0) { q.bail = true; return; }
+        // A tenpai 13-tile hand has at most ONE isolated tile (a tanki wait; chiitoi tenpai: its single), and a kokushi
+        // tenpai holds twelve kinds of terminals and honors: two isolated tiles and fewer than twelve such kinds mean
+        // shanten >= 1 - no waits, which is all the cache must know; sh13 = 1 is then a lower bound (its users only ever
+        // skip work on ">= 2").  Only the remaining ~5 % of the hands take the table shanten.
+        if (iso >= 2 && yaochu < 12) {
+            sh = 1;
+        } else {
+            sh = r4_shanten(q, h13, len3);
+            if (sh <= 0) { q.bail = true; return; }
+        }
     }
     if (q.r == 0) {
         P->waits13 = 0ull;
@@ -495,8 +505,15 @@ __device__ __forceinline__ void r4_gen_act_legal(R4& q, int& nl_mine) {
         if (riichi_pre) {
             const int sh13 = (drawn && (P->flags & PF_WAITS_VALID)) ? (int)P->sh13 : -1;
             if (sh13 < 2) {
-                // tenpai_after_discard: only a 14-tile shanten <= 0 can keep a tenpai 13; those hands take the probes
-                if (r4_shanten(q, full, hl / 3) <= 0) { q.bail = true; return; }
+                // tenpai_after_discard: only a 14-tile shanten <= 0 can keep a tenpai 13 (those hands take the probes).  Such a
+                // hand has at most TWO isolated tiles (the discard and a tanki) and, as a kokushi shape, thirteen kinds with
+                // at most one missing: three isolated tiles and < 12 kinds of terminals / honors rule Riichi out without tables.
+                const uint32_t T9 = 1u | (1u << 24);
+                const int yk = __popc((full.a | (full.a >> 1) | (full.a >> 2)) & T9) + __popc((full.b | (full.b >> 1) | (full.b >> 2)) & T9) +
+                               __popc((full.c | (full.c >> 1) | (full.c >> 2)) & T9) + __popc((full.d | (full.d >> 1) | (full.d >> 2)) & O7_1);
+                if (!(r4_isolated(full) >= 3 && yk < 12)) {
+                    if (r4_shanten(q, full, hl / 3) <= 0) { q.bail = true; return; }
+                }
             }
         }
         const bool ok = r < hl && !forb;

@@ -20,6 +20,11 @@
 namespace RMJ_NS {
 
 #define R4_LIST 16 /* staged list entries per (game, seat); a longer list makes the row bail */
+#ifdef RMJ_CUTS   /* instruction accounting build (scripts/valu_sections4.py): the wave ends at mark g_cut */
+#define R4M(id) do { if (rmj::g_cut == (id)) __builtin_amdgcn_endpgm(); } while (0)
+#else
+#define R4M(id) do {} while (0)
+#endif
 struct Quad4Tier0 {
     alignas(16) uint32_t ev[4][RMJ_EV_STAGE][8];  // staged MJAI records per game
     uint32_t evidx[4][RMJ_EV_STAGE];
@@ -319,19 +324,26 @@ __device__ __forceinline__ void r4_resolve_discard(R4& q, int pid, int tile, boo
     }
     wave_sync();
     r4_emit_simple(q, RMJ_EV_DAHAI, (uint32_t)pid, (uint32_t)tile, tsumogiri ? 1u : 0u);
+    R4M(50);
     if (q.bail) return;
-    // ---- A: refill stale wait caches of the other seats that hold 13 tiles (loop over seats, uniform per row)
-    for (int i = 0; i < KNP; i++) {
-        PState* Q = &G->p[i];
-        const bool need = i != pid && (Q->hand_len + 3 * Q->n_melds == 13) && !(Q->flags & PF_WAITS_VALID);
-        if (__ballot(need)) {
-            if (need) {
-                q.dirty |= 1u << i;
+    // ---- A: refill stale wait caches of the other seats that hold 13 tiles: every row walks ITS OWN stale seats (usually
+    //      one - the previous discarder), so the loop runs once or twice per wave, not once per seat index
+    {
+        const PState& S0 = G->p[r & 3];
+        uint32_t need_m = rballot(r < KNP && r != pid && (S0.hand_len + 3 * S0.n_melds == 13) && !(S0.flags & PF_WAITS_VALID), rb) & 0xFu;
+        q.dirty |= need_m;
+        while (__ballot(need_m != 0u)) {
+            if (need_m) {
+                const int i = __ffs((int)need_m) - 1;
+                need_m &= need_m - 1u;
+                PState* Q = &G->p[i];
                 const PH h = r4_hist(q, Q, -1);
                 r4_fill_waits13(q, Q, h);
+                if (q.bail) need_m = 0u;
             }
         }
     }
+    R4M(51);
     if (q.bail) return;
     // ---- B (lane = seat): Ron eligibility: a seat that waits on the tile and is not furiten needs the yaku check -> bail
     const PState& S4 = G->p[r & 3];
@@ -348,6 +360,7 @@ __device__ __forceinline__ void r4_resolve_discard(R4& q, int pid, int tile, boo
     w_mine = r < 4 ? W : 0ull;
     const bool can_call = G->drawable_count > 0;
     const bool kuikae = (q.E->rule_bits & RMJ_RULE_KUIKAE_FORBIDDEN) != 0;
+    R4M(52);
     int nl0 = 0, nl1 = 0, nl2 = 0, nl3 = 0;   // list length of each seat so far (row-uniform; no indexed array: no scratch)
     auto nl_get = [&](int i) { return i == 0 ? nl0 : (i == 1 ? nl1 : (i == 2 ? nl2 : nl3)); };
     auto nl_set = [&](int i, int v) {
@@ -385,6 +398,7 @@ __device__ __forceinline__ void r4_resolve_discard(R4& q, int pid, int tile, boo
         }
         nl_set(i, n);
     }
+    R4M(53);
     // ---- D: Chi for the next seat (lane = a * 4 + b, pattern by pattern); no Chi in 3P
     if (!KSANMA && can_call && tt < 27) {
         const int i = (pid + 1) & 3;
@@ -424,6 +438,7 @@ __device__ __forceinline__ void r4_resolve_discard(R4& q, int pid, int tile, boo
             }
         }
     }
+    R4M(54);
     // ---- E: Pass, lengths, stale counts (lane = seat)
     int n_me = r < 4 ? nl_get(r) : 0;
     if (rballot(r < 4 && n_me + 1 > R4_LIST, rb)) { q.bail = true; return; }
@@ -437,6 +452,7 @@ __device__ __forceinline__ void r4_resolve_discard(R4& q, int pid, int tile, boo
     nl_mine = r < 4 ? n_me : 0;
     const uint32_t claim_active = rballot(r < 4 && n_me > 0, rb) & 0xFu;
     wave_sync();
+    R4M(55);
     if (claim_active) {
         if (r == 0) {
             G->phase = RMJ_WAIT_RESPONSE;
@@ -490,6 +506,7 @@ __device__ __forceinline__ void r4_gen_act_legal(R4& q, int& nl_mine) {
         }
         if ((P->waits13 >> (drawn_tile >> 2)) & 1ull) { q.bail = true; return; }
     }
+    R4M(60);
     // 2. Discards (+ Riichi -> bail)
     const int nforb = P->n_forbidden;
     const bool forb = (nforb > 0 && (P->forbidden[0] >> 2) == hty) || (nforb > 1 && (P->forbidden[1] >> 2) == hty);
@@ -521,6 +538,7 @@ __device__ __forceinline__ void r4_gen_act_legal(R4& q, int& nl_mine) {
         if (ok) r4_put(q, pid, n + __popc(vb & ((1u << r) - 1u)), mk_action(RMJ_DISCARD, ht, 0));
         n += __popc(vb);
     }
+    R4M(61);
     // 3. Kan
     if (drawable > 0 && drawn) {
         if (!r_decl) {
@@ -568,18 +586,24 @@ __device__ __forceinline__ void r4_gen_act_legal(R4& q, int& nl_mine) {
 // One step of four consecutive games per wave (device policy only: rmj_step_random / rmj_bench_rollout); `load`: fetch the records from HBM first (the rollout loop keeps them in LDS)
 template <bool LOOP>
 __device__ __forceinline__ void step4_body(const Env* Ep, Quad4Shared& sh, uint64_t policy_seed, uint32_t flags, uint32_t g_base, uint32_t g_end,
-                                           bool load) {
+                                           bool load, uint64_t gs_row) {
     CEnv& E = *(CEnv*)Ep;
     const int lane = threadIdx.x & 63;
     const int row = lane >> 4, r = lane & 15, rb = lane & 48;
     const uint32_t g0 = g_base + blockIdx.x * 4u;
     const uint32_t g = g0 + (uint32_t)row;
     const uint32_t n_here = g_end - g0 < 4u ? g_end - g0 : 4u;   // games of this wave
-    if (load) {   // ---- records: 4 x 640 B contiguous in HBM -> LDS
-        for (int c = lane; c < (int)(n_here * (sizeof(GState) / 16)); c += 64)
-            reinterpret_cast<uint4*>(&sh.st[0])[c] = reinterpret_cast<const uint4*>(E.core + g0)[c];
+    if (load) {   // ---- records: every row fetches its own 640 B (40 chunks of 16 B, three per lane)
+        if ((uint32_t)row < n_here) {
+#pragma unroll
+            for (int k = 0; k < 3; k++) {
+                const int off = r + 16 * k;
+                if (off < (int)(sizeof(GState) / 16)) reinterpret_cast<uint4*>(&sh.st[row])[off] = reinterpret_cast<const uint4*>(E.core + g)[off];
+            }
+        }
         wave_sync();
     }
+    R4M(40);
     {
     R4 q;
     q.G = &sh.st[row]; q.T = &sh.u.t; q.E = &E; q.lane = lane; q.r = r; q.rb = rb; q.row = row; q.g = g;
@@ -608,7 +632,7 @@ __device__ __forceinline__ void step4_body(const Env* Ep, Quad4Shared& sh, uint6
         } else if (r < 4) {
             const uint32_t n = G->nlegal[r];
             if (((G->active_mask >> r) & 1u) && n != 0u) {
-                const uint64_t gs = sm64(policy_seed + E.game_offset + (uint64_t)g);
+                const uint64_t gs = LOOP ? gs_row : sm64(policy_seed + E.game_offset + (uint64_t)g);   // (the loop hashes the game once)
                 const uint64_t key = sm64(gs + (uint64_t)G->step_count * 4ull + (uint64_t)r);
                 const uint32_t ch = mod_small(key, n > 64u ? 64u : n);
                 const uint64_t* src = Lg + r * RMJ_MAX_LEGAL + ch;
@@ -616,6 +640,7 @@ __device__ __forceinline__ void step4_body(const Env* Ep, Quad4Shared& sh, uint6
             }
         }
     }
+    R4M(41);
     int nl_mine = 0;          // lane = seat: length of the seat's list produced by this step
     uint64_t w_mine = 0ull;   // lane = seat: waits published for the seat
     const bool t0 = q.live && !q.bail;
@@ -651,7 +676,9 @@ __device__ __forceinline__ void step4_body(const Env* Ep, Quad4Shared& sh, uint6
                     if (r < hl && r != idx) P->hand[np] = (uint8_t)t;
                     if (r == 0) P->hand_len = (uint8_t)(hl - 1);
                     wave_sync();
+                    R4M(42);
                     r4_resolve_discard(q, pid, tile, tsumogiri, pf, nl_mine, w_mine);
+                    R4M(56);
                 }
             } else if (KSANMA && ty == RMJ_KITA) {
                 // ---- handle_kita (state_3p/sanma.rs:9-144): a common action of 3P games; a seat that could rob the tile bails
@@ -676,11 +703,17 @@ __device__ __forceinline__ void step4_body(const Env* Ep, Quad4Shared& sh, uint6
                     wave_sync();
                     r4_emit_simple(q, RMJ_EV_KITA, (uint32_t)pid, (uint32_t)tile);
                     // the other seats: refill stale wait caches, then "waits on North and not furiten" needs the yaku check
-                    for (int i = 0; i < KNP; i++) {
-                        PState* Q = &G->p[i];
-                        const bool need = i != pid && (Q->hand_len + 3 * Q->n_melds == 13) && !(Q->flags & PF_WAITS_VALID);
-                        if (__ballot(need)) {
-                            if (need) r4_fill_waits13(q, Q, r4_hist(q, Q, -1));
+                    {
+                        const PState& S0 = G->p[r & 3];
+                        uint32_t need_m = rballot(r < KNP && r != pid && (S0.hand_len + 3 * S0.n_melds == 13) && !(S0.flags & PF_WAITS_VALID), rb) & 0xFu;
+                        while (__ballot(need_m != 0u)) {
+                            if (need_m) {
+                                const int i = __ffs((int)need_m) - 1;
+                                need_m &= need_m - 1u;
+                                PState* Q = &G->p[i];
+                                r4_fill_waits13(q, Q, r4_hist(q, Q, -1));
+                                if (q.bail) need_m = 0u;
+                            }
                         }
                     }
                     if (!q.bail) {
@@ -837,6 +870,7 @@ __device__ __forceinline__ void step4_body(const Env* Ep, Quad4Shared& sh, uint6
                 }
             }
         }
+        R4M(43);
         // ---- the next observation: a WaitAct state needs the acting seat's list
         if (!q.bail && G->phase == RMJ_WAIT_ACT) {
             nl_mine = 0;
@@ -844,6 +878,7 @@ __device__ __forceinline__ void step4_body(const Env* Ep, Quad4Shared& sh, uint6
             r4_gen_act_legal(q, nl_mine);
         }
     }
+    R4M(45);
     // ---- publication of the rows that completed in tier 0
     const bool done0 = q.live && t0 && !q.bail;
     if (done0) {
@@ -896,19 +931,18 @@ __device__ __forceinline__ void step4_body(const Env* Ep, Quad4Shared& sh, uint6
         }
     }
     wave_sync();
+    R4M(46);
     // ---- records of the completed rows back to HBM (globals + touched PState quarters)
-    {
-        const uint64_t okm = __ballot(done0 && r == 0);                     // bit 16 * row
-        const uint32_t d0 = (uint32_t)rbc((int)q.dirty, 0), d1 = (uint32_t)rbc((int)q.dirty, 16), d2 = (uint32_t)rbc((int)q.dirty, 32),
-                       d3 = (uint32_t)rbc((int)q.dirty, 48);
-        for (int c = lane; c < (int)(n_here * (sizeof(GState) / 16)); c += 64) {
-            const int gm = c / 40, off = c - 40 * gm;
-            const uint32_t dm = gm == 0 ? d0 : (gm == 1 ? d1 : (gm == 2 ? d2 : d3));
-            if (((okm >> (16 * gm)) & 1u) && (off >= 32 || ((dm >> (off >> 3)) & 1u)))
-                reinterpret_cast<uint4*>(E.core + g0)[c] = reinterpret_cast<const uint4*>(&sh.st[0])[c];
+    if (done0) {
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+            const int off = r + 16 * k;
+            if (off < (int)(sizeof(GState) / 16) && (off >= 32 || ((q.dirty >> (off >> 3)) & 1u)))
+                reinterpret_cast<uint4*>(E.core + g)[off] = reinterpret_cast<const uint4*>(&sh.st[row])[off];
         }
     }
     wave_sync();
+    R4M(47);
     // ---- bailed games: the complete state machine, one game at a time, from the untouched HBM record
     uint64_t bm = __ballot(q.live && q.bail && r == 0);
     while (bm) {
@@ -933,9 +967,10 @@ __device__ __forceinline__ void step4_body(const Env* Ep, Quad4Shared& sh, uint6
 // The step as an out-of-line function with its own static LDS: the rollout loop calls it once per step, so nothing of a
 // step is hoisted out of the loop or kept live across it (the loop inlined: 48 VGPR + 37 SGPR spills).
 template <bool LOOP>
-__device__ __noinline__ void step4_call(const Env* Ep, uint64_t policy_seed, uint32_t flags, uint32_t g_base, uint32_t g_end, uint32_t load) {
+__device__ __noinline__ void step4_call(const Env* Ep, uint64_t policy_seed, uint32_t flags, uint32_t g_base, uint32_t g_end, uint32_t load,
+                                        uint64_t gs_row) {
     __shared__ Quad4Shared sh;
-    step4_body<LOOP>(uni_ptr(Ep), sh, uni(policy_seed), uni(flags), uni(g_base), uni(g_end), uni(load) != 0u);
+    step4_body<LOOP>(uni_ptr(Ep), sh, uni(policy_seed), uni(flags), uni(g_base), uni(g_end), uni(load) != 0u, gs_row);
 }
 #ifndef RMJ_STEP4_WAVES
 #define RMJ_STEP4_WAVES 6
@@ -949,11 +984,13 @@ template <bool LOOP>
 __global__ __launch_bounds__(64, RMJ_STEP4_WAVES) void k_step4(const Env* __restrict__ Ep, uint64_t policy_seed, uint32_t flags, uint32_t g_base,
                                                                    uint32_t g_end, uint32_t n_steps) {
     if (LOOP) {
+        const uint32_t g = g_base + blockIdx.x * 4u + ((threadIdx.x & 63u) >> 4);
+        const uint64_t gs_row = sm64(policy_seed + ((CEnv*)Ep)->game_offset + (uint64_t)g);   // policy key of the row's game
 #pragma unroll 1
-        for (uint32_t it = 0; it < n_steps; it++) step4_call<true>(Ep, policy_seed, flags, g_base, g_end, it == 0 ? 1u : 0u);
+        for (uint32_t it = 0; it < n_steps; it++) step4_call<true>(Ep, policy_seed, flags, g_base, g_end, it == 0 ? 1u : 0u, gs_row);
     } else {
         __shared__ Quad4Shared sh;
-        step4_body<false>(Ep, sh, policy_seed, flags, g_base, g_end, true);
+        step4_body<false>(Ep, sh, policy_seed, flags, g_base, g_end, true, 0ull);
     }
 }
 

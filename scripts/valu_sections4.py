@@ -1,0 +1,74 @@
+#!/usr/bin/env python3
+"""Instruction accounting of k_step4 (four games per wave) by section, accounting build -DRMJ_CUTS (scripts/build_cuts.sh).
+
+run (GPU box):   rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS --output-format csv -d gpurun_out/cuts4 -- \
+                     python3 scripts/valu_sections4.py run
+then:            python3 scripts/valu_sections4.py report gpurun_out/cuts4
+
+The marks end the WAVE (all four rows) where the first row reaches them: marks inside the WaitAct branch (42, 50..56) give
+the cost of the discard path up to there for a wave whose rows are in that branch, marks at the convergence points (40,
+41, 43, 45, 46, 47) the cost of everything before them.  Nothing is stored by a cut launch: every launch sees the same
+game states (the rollout is warmed up with the uncut kernel)."""
+import csv
+import ctypes as C
+import glob
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+CUTS = [40, 41, 42, 50, 51, 52, 53, 54, 55, 56, 43, 60, 61, 45, 46, 47]
+NAMES = {40: "records loaded", 41: "policy pick", 42: "discard: find + sort", 50: "discard: bookkeeping + dahai event", 51: "claims A: wait-cache refill",
+         52: "claims B: ron eligibility", 53: "claims C: pon / kan lists", 54: "claims D: chi lists", 55: "claims E: pass / lengths",
+         56: "no claims: riichi accept, abortive check, next draw", 43: "both phase branches done (incl. WaitResponse)",
+         60: "act list: tsumo check", 61: "act list: discards + riichi bound", 45: "act list: kan / kyushu / kita", 46: "publication: lists, masks, status, events",
+         47: "records stored"}
+GAMES = 65536
+
+
+def run():
+    os.environ["RMJ_STEP_STREAMS"] = "1"
+    os.environ["RMJ_STEP4"] = "1"
+    from riichienv_amd import vecenv
+    vecenv.LIB_PATH = os.path.join(ROOT, "riichienv_amd", "libriichi_mi355x_cuts.so")
+    L = vecenv.load_lib()
+    L.rmj_prof_set_cut.argtypes = [C.c_int, C.c_int, C.c_int]
+    env = vecenv.VecRiichiEnv(GAMES, game_mode=int(os.environ.get("RMJ_MODE", "2")), seed=0)
+    env.reset()
+    L.rmj_prof_set_cut(-1, -1, -1)
+    env.step_random(0xC0FFEE, 500, auto_reset=True)
+    env.total_steps()
+    for cut in CUTS:
+        L.rmj_prof_set_cut(cut, -1, -1)
+        env.step_random(0xC0FFEE, 1, auto_reset=True)
+        env.total_steps()
+    L.rmj_prof_set_cut(-1, -1, -1)
+    env.step_random(0xC0FFEE, 1, auto_reset=True)      # reference launch, same states: everything, stores and bails included
+    env.total_steps()
+
+
+def report(root):
+    rows = {}
+    for f in glob.glob(os.path.join(root, "**", "*counter_collection.csv"), recursive=True):
+        with open(f) as fh:
+            for r in csv.DictReader(fh):
+                if "k_step4" not in r.get("Kernel_Name", ""):
+                    continue
+                d = int(r["Dispatch_Id"])
+                rows.setdefault(d, {})
+                rows[d][r["Counter_Name"]] = rows[d].get(r["Counter_Name"], 0.0) + float(r["Counter_Value"])
+    ids = sorted(rows)[-(len(CUTS) + 1):]
+    W = GAMES // 4
+    full = rows[ids[-1]]
+    out = {"games": GAMES, "waves": W, "whole_step_per_wave": {k: v / W for k, v in full.items()}, "reach_mark": {}}
+    print("whole step (tier 0 + bailed games, publication and stores), per wave of four games:", {k: round(v / W, 1) for k, v in full.items()})
+    for cut, d in zip(CUTS, ids[:-1]):
+        per = {k: v / W for k, v in rows[d].items()}
+        out["reach_mark"][str(cut)] = {"name": NAMES[cut], **per}
+        print(f"{cut:3d} {NAMES[cut]:52s} VALU {per.get('SQ_INSTS_VALU', 0):7.1f}  SALU {per.get('SQ_INSTS_SALU', 0):7.1f}  LDS {per.get('SQ_INSTS_LDS', 0):6.1f}")
+    json.dump(out, open(os.path.join(root, "valu_sections4.json"), "w"), indent=1)
+
+
+if __name__ == "__main__":
+    run() if sys.argv[1] == "run" else report(sys.argv[2])

@@ -269,9 +269,13 @@ __device__ __forceinline__ void r4_deal_next(R4& q, int pf) {
     }
 }
 
-// stage one list entry / finish a seat's list
-__device__ __forceinline__ void r4_put(R4& q, int seat, int pos, uint64_t a) {
-    if (pos < R4_LIST) q.T->lst[q.row][seat][pos] = a;
+// stage one list entry together with its action id (Action::encode / encode_3p, action.rs:158-346) in the free top byte:
+// where an entry is generated its kind is known, so the id is a constant or one shift - the publication does not decode
+__device__ __forceinline__ int r4_tile_id(int t34) {   // discard id of a tile type: the type, 3P: the compact index
+    return KSANMA ? (t34 == 0 ? 0 : (t34 == 8 ? 1 : t34 - 7)) : t34;
+}
+__device__ __forceinline__ void r4_put(R4& q, int seat, int pos, uint64_t a, int id) {
+    if (pos < R4_LIST) q.T->lst[q.row][seat][pos] = a | ((uint64_t)(uint32_t)id << 56);
 }
 
 // _resolve_discard (state/mod.rs:1317-1413) incl. claim generation (legal_actions.rs:254-508) for the row's game.
@@ -384,16 +388,16 @@ __device__ __forceinline__ void r4_resolve_discard(R4& q, int pid, int tile, boo
         int n = nl_get(i);
         if (r == 0) {
             if (hl >= 3 && (kuikae ? (hl - count) > 0 : (hl - 2) > 0)) {
-                r4_put(q, i, n, mk_action(RMJ_PON, tile, 2, h0, h1));
+                r4_put(q, i, n, mk_action(RMJ_PON, tile, 2, h0, h1), KSANMA ? 28 : 41);
                 if (count >= 3) {
-                    r4_put(q, i, n + 1, mk_action(RMJ_PON, tile, 2, h0, h2));
-                    r4_put(q, i, n + 2, mk_action(RMJ_PON, tile, 2, h1, h2));
+                    r4_put(q, i, n + 1, mk_action(RMJ_PON, tile, 2, h0, h2), KSANMA ? 28 : 41);
+                    r4_put(q, i, n + 2, mk_action(RMJ_PON, tile, 2, h1, h2), KSANMA ? 28 : 41);
                 }
             }
         }
         if (hl >= 3 && (kuikae ? (hl - count) > 0 : (hl - 2) > 0)) n += count >= 3 ? 3 : 1;
         if (count >= 3) {
-            if (r == 0) r4_put(q, i, n, mk_action(RMJ_DAIMINKAN, tile, 3, h0, h1, h2));
+            if (r == 0) r4_put(q, i, n, mk_action(RMJ_DAIMINKAN, tile, 3, h0, h1, h2), (KSANMA ? 29 : 42) + r4_tile_id(tt));
             n += 1;
         }
         nl_set(i, n);
@@ -431,7 +435,7 @@ __device__ __forceinline__ void r4_resolve_discard(R4& q, int pid, int tile, boo
                     const int ia = valid ? __ffs((int)x) - 1 : 0, ib = valid ? __ffs((int)y) - 1 : 0;
                     const uint32_t ta = (uint32_t)rbc(ht, rb + ia), tb = (uint32_t)rbc(ht, rb + ib);
                     const uint32_t vb = rballot(valid, rb);
-                    if (valid) r4_put(q, i, n + __popc(vb & ((1u << r) - 1u)), mk_action(RMJ_CHI, tile, 2, ta, tb));
+                    if (valid) r4_put(q, i, n + __popc(vb & ((1u << r) - 1u)), mk_action(RMJ_CHI, tile, 2, ta, tb), 40 - k);
                     n += __popc(vb);
                 }
                 nl_set(i, n);
@@ -445,7 +449,7 @@ __device__ __forceinline__ void r4_resolve_discard(R4& q, int pid, int tile, boo
     if (r < 4) {
         G->stale_n[r] = (uint8_t)(n_me > 62 ? 62 : n_me);
         if (n_me > 0) {
-            q.T->lst[q.row][r][n_me] = mk_action(RMJ_PASS, RMJ_TILE_NONE, 0);
+            q.T->lst[q.row][r][n_me] = mk_action(RMJ_PASS, RMJ_TILE_NONE, 0) | ((uint64_t)(KSANMA ? 58 : 81) << 56);
             n_me += 1;
         }
     }
@@ -513,7 +517,7 @@ __device__ __forceinline__ void r4_gen_act_legal(R4& q, int& nl_mine) {
     const PH full = r4_hist(q, P, -1);
     if (r_decl) {
         if (drawn) {
-            if (r == 0) r4_put(q, pid, n, mk_action(RMJ_DISCARD, drawn_tile, 0));
+            if (r == 0) r4_put(q, pid, n, mk_action(RMJ_DISCARD, drawn_tile, 0), r4_tile_id(drawn_tile >> 2));
             n += 1;
         }
     } else {
@@ -535,7 +539,7 @@ __device__ __forceinline__ void r4_gen_act_legal(R4& q, int& nl_mine) {
         }
         const bool ok = r < hl && !forb;
         const uint32_t vb = rballot(ok, rb);
-        if (ok) r4_put(q, pid, n + __popc(vb & ((1u << r) - 1u)), mk_action(RMJ_DISCARD, ht, 0));
+        if (ok) r4_put(q, pid, n + __popc(vb & ((1u << r) - 1u)), mk_action(RMJ_DISCARD, ht, 0), r4_tile_id(hty));
         n += __popc(vb);
     }
     R4M(61);
@@ -553,7 +557,8 @@ __device__ __forceinline__ void r4_gen_act_legal(R4& q, int& nl_mine) {
                     const uint32_t kb = rballot(hit, rb);
                     if (hit)
                         r4_put(q, pid, n + __popc(kb & ((1u << r) - 1u)),
-                               mk_action(RMJ_KAKAN, ht, 3, P->meld_tiles[m][0], P->meld_tiles[m][1], P->meld_tiles[m][2]));
+                               mk_action(RMJ_KAKAN, ht, 3, P->meld_tiles[m][0], P->meld_tiles[m][1], P->meld_tiles[m][2]),
+                               (KSANMA ? 29 : 42) + r4_tile_id(target));
                     n += __popc(kb);
                 }
             }
@@ -567,7 +572,7 @@ __device__ __forceinline__ void r4_gen_act_legal(R4& q, int& nl_mine) {
         const uint32_t lo = row_or16(term && hty < 32 ? 1u << hty : 0u), hi = row_or16(term && hty >= 32 ? 1u << (hty - 32) : 0u);
         const int kinds = __popc((uint32_t)rbc((int)lo, rb + 15)) + __popc((uint32_t)rbc((int)hi, rb + 15));
         if (kinds >= 9) {
-            if (r == 0) r4_put(q, pid, n, mk_action(RMJ_KYUSHU, RMJ_TILE_NONE, 0));
+            if (r == 0) r4_put(q, pid, n, mk_action(RMJ_KYUSHU, RMJ_TILE_NONE, 0), KSANMA ? 57 : 80);
             n += 1;
         }
     }
@@ -575,7 +580,7 @@ __device__ __forceinline__ void r4_gen_act_legal(R4& q, int& nl_mine) {
     if (KSANMA && drawn && drawable > 0) {
         const bool hit = r < hl && hty == 30;
         const uint32_t kb = rballot(hit, rb);
-        if (hit) r4_put(q, pid, n + __popc(kb & ((1u << r) - 1u)), mk_action(RMJ_KITA, ht, 0));
+        if (hit) r4_put(q, pid, n + __popc(kb & ((1u << r) - 1u)), mk_action(RMJ_KITA, ht, 0), 59);
         n += __popc(kb);
     }
     if (n > R4_LIST) { q.bail = true; return; }
@@ -649,14 +654,14 @@ __device__ __forceinline__ void step4_body(const Env* Ep, Quad4Shared& sh, uint6
         const int phase = G->phase;
         if (phase == RMJ_WAIT_ACT) {
             const int pid = G->current_player;
-            const uint64_t act = rbc64(mine, rb + pid);
-            const uint32_t ty = a_type(act);
+            const uint32_t act = (uint32_t)rbc((int)(uint32_t)mine, rb + pid);   // type and tile live in the low dword
+            const uint32_t ty = act & 0xFFu;
             PState* P = &G->p[pid];
-            if (act == RMJ_NO_ACTION || a_tile(act) == RMJ_TILE_NONE) {
+            if (act == 0xFFFFFFFFu || ((act >> 8) & 0xFFu) == RMJ_TILE_NONE) {
                 q.bail = true;
             } else if (ty == RMJ_DISCARD) {
                 q.dirty = 1u << pid;
-                const int tile = (int)a_tile(act);
+                const int tile = (int)((act >> 8) & 0xFFu);
                 const int hl = P->hand_len;
                 const int t = r < hl ? (int)P->hand[r] : 0xFFFF;
                 const int drawn = G->drawn_tile;
@@ -683,7 +688,7 @@ __device__ __forceinline__ void step4_body(const Env* Ep, Quad4Shared& sh, uint6
             } else if (KSANMA && ty == RMJ_KITA) {
                 // ---- handle_kita (state_3p/sanma.rs:9-144): a common action of 3P games; a seat that could rob the tile bails
                 q.dirty = 0xFu;
-                const int tile = (int)a_tile(act);
+                const int tile = (int)((act >> 8) & 0xFFu);
                 const int hl = P->hand_len;
                 const int t = r < hl ? (int)P->hand[r] : 0xFFFF;
                 const uint32_t fm = rballot(r < hl && t == tile, rb);
@@ -893,10 +898,10 @@ __device__ __forceinline__ void step4_body(const Env* Ep, Quad4Shared& sh, uint6
             const int p = __ffs((int)m) - 1;
             const int n = rbc(n_me, rb + p);
             if (r < n) {
-                const uint64_t a = q.T->lst[row][p][r];
-                (E.legal + (size_t)g * 4 * RMJ_MAX_LEGAL)[p * RMJ_MAX_LEGAL + r] = a;
-                const int id = KSANMA ? a_encode_3p(a) : a_encode(a);
-                if (id >= 0 && id < (KSANMA ? 60 : 82)) atomicOr(&q.T->mk[row][p][id >> 5], 1u << (id & 31));
+                const uint64_t e = q.T->lst[row][p][r];
+                (E.legal + (size_t)g * 4 * RMJ_MAX_LEGAL)[p * RMJ_MAX_LEGAL + r] = e & 0x00FFFFFFFFFFFFFFull;
+                const int id = (int)(e >> 56);     // the id travels with the staged entry (r4_put)
+                atomicOr(&q.T->mk[row][p][id >> 5], 1u << (id & 31));
             }
         }
         wave_sync();

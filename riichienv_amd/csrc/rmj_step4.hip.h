@@ -39,7 +39,13 @@ struct Quad4Shared {
     } u;
 };
 
-__device__ __forceinline__ uint32_t rballot(bool p, int rb) { return (uint32_t)(__ballot(p) >> rb) & 0xFFFFu; }
+// ballot of the lane's own row: pick the half of the 64-bit mask (one select on the lane-constant "upper half" predicate),
+// then a 16-bit field extract at bit 0 / 16 - three vector instructions instead of a 64-bit shift by a lane-varying amount
+__device__ __forceinline__ uint32_t rballot(bool p, int rb) {
+    const uint64_t b = __ballot(p);
+    const uint32_t w = (rb & 32) ? (uint32_t)(b >> 32) : (uint32_t)b;
+    return __builtin_amdgcn_ubfe(w, (uint32_t)(rb & 16), 16u);
+}
 __device__ __forceinline__ int rbc(int v, int src_lane) { return __builtin_amdgcn_ds_bpermute(src_lane << 2, v); }
 __device__ __forceinline__ uint64_t rbc64(uint64_t v, int src_lane) {
     return (uint64_t)(uint32_t)rbc((int)(uint32_t)v, src_lane) | ((uint64_t)(uint32_t)rbc((int)(uint32_t)(v >> 32), src_lane) << 32);
@@ -160,15 +166,99 @@ __device__ __forceinline__ int r4_shanten(const R4& q, const PH& h, int len_div3
     }
     return sres;
 }
-// fill_waits13 of tier 0: the isolated-tile bound, else the table shanten; a hand with a possible wait (shanten <= 0)
-// needs the probe -> the row bails.  Writes the cache like fill_waits13 (waits13 = 0 for every shanten >= 1).
-__device__ __forceinline__ void r4_fill_waits13(R4& q, PState* P, const PH& h13) {
+// "Spread" key of a tile type: ranks of one suit stay adjacent, suits are 16 apart, honors 3 apart - two tiles can belong to
+// one set, pair or taatsu iff their keys differ by at most 2 (honors: iff equal).
+__device__ __forceinline__ int r4_key(int t34) {
+    return t34 < 27 ? t34 + 7 * ((t34 >= 9) + (t34 >= 18)) : 48 + 3 * (t34 - 27);
+}
+// Shape numbers of a SORTED run of `n` tiles of P's hand (13-tile hands are kept sorted; a 14th, drawn tile sits behind
+// them) plus an optional extra tile type `ex` (-1: none), without building a histogram: lane r looks at its two sorted
+// neighbours (DPP row shifts) and at the extra tile.
+struct R4Shape {
+    int iso;      // tiles held exactly once with nothing within two ranks (isolated_tiles())
+    int yaochu;   // kinds of terminals and honors
+    int kinds;    // distinct tile types
+    int pairs;    // types held at least twice
+};
+__device__ __forceinline__ R4Shape r4_shape_sorted(const R4& q, const PState* P, int n, int ex) {
+    const int r = q.r, rb = q.rb;
+    const bool in = r < n;
+    const int t = in ? (int)(P->hand[r] >> 2) : 99;
+    const int k = in ? r4_key(t) : 1000;
+    const int kp = __builtin_amdgcn_update_dpp(-1000, k, 0x111 /* row_shr:1 */, 0xf, 0xf, false);   // lane r - 1 (row start: -1000)
+    int kn = __builtin_amdgcn_update_dpp(1000, k, 0x101 /* row_shl:1 */, 0xf, 0xf, false);           // lane r + 1 (row end: 1000)
+    const int ke = ex >= 0 ? r4_key(ex) : -2000;
+    const bool term = t >= 27 || t == 0 || t == 8 || t == 9 || t == 17 || t == 18 || t == 26;
+    const bool first = in && k != kp, last_of_kind = in && k != kn;
+    const uint32_t ex_close = rballot(in && (k - ke <= 2 && ke - k <= 2), rb);     // some held tile within two of the extra one
+    const uint32_t ex_same = rballot(in && k == ke, rb);
+    const uint32_t ex_single = rballot(in && k == ke && first && last_of_kind, rb);   // the extra tile makes a pair of a single
+    R4Shape o;
+    o.iso = __popc(rballot(in && k - kp > 2 && kn - k > 2 && (k - ke > 2 || ke - k > 2), rb)) + ((ex >= 0 && !ex_close) ? 1 : 0);
+    const bool ex_term = ex >= 27 || ex == 0 || ex == 8 || ex == 9 || ex == 17 || ex == 18 || ex == 26;
+    o.yaochu = __popc(rballot(first && term, rb)) + ((ex >= 0 && ex_term && !ex_same) ? 1 : 0);
+    o.kinds = __popc(rballot(first, rb)) + ((ex >= 0 && !ex_same) ? 1 : 0);
+    o.pairs = __popc(rballot(first && !last_of_kind, rb)) + (ex_single ? 1 : 0);
+    return o;
+}
+// fill_waits13 of tier 0 for the sorted 13-tile hand P->hand[0 .. n): the isolated-tile bound, else the table shanten (the
+// only user of a histogram); a hand with a possible wait (shanten <= 0) needs the probe -> the row bails.  Writes the cache
+// like fill_waits13 (waits13 = 0 for every shanten >= 1).
+__device__ __forceinline__ void r4_fill_waits13(R4& q, PState* P, int n) {
+    const R4Shape sp = r4_shape_sorted(q, P, n, -1);
+    const int iso = sp.iso, yaochu = sp.yaochu;
+    int lb = iso >= 6 ? 4 : (iso == 5 ? 3 : (iso == 4 ? 2 : 0));
+    const int len3 = n / 3;
+    if (len3 == 4) {
+        const int koku = 12 - yaochu;
+        lb = koku < lb ? koku : lb;
+        if (lb > 2) {
+            const int chi = 6 - sp.pairs + (sp.kinds < 7 ? 7 - sp.kinds : 0);   // sh_chiitoi
+            lb = chi < lb ? chi : lb;
+        }
+    }
+    int sh = lb;
+    if (lb < 2) {
+        // A tenpai 13-tile hand has at most ONE isolated tile (a tanki wait; chiitoi tenpai: its single), and a kokushi
+        // tenpai holds twelve kinds of terminals and honors: two isolated tiles and fewer than twelve such kinds mean
+        // shanten >= 1 - no waits, which is all the cache must know; sh13 = 1 is then a lower bound (its users only ever
+        // skip work on ">= 2").  Only the remaining ~5 % of the hands take the table shanten.
+        if (iso >= 2 && yaochu < 12) {
+            sh = 1;
+        } else {
+            PH h13 = {0, 0, 0, 0};
+            {   // histogram of the n sorted tiles
+                uint32_t a = 0, b = 0, c = 0, d = 0;
+                if (q.r < n) {
+                    const int t = P->hand[q.r] >> 2, su = t_suit(t);
+                    const uint32_t one = 1u << (3 * (t - 9 * su));
+                    a = su == 0 ? one : 0u; b = su == 1 ? one : 0u; c = su == 2 ? one : 0u; d = su == 3 ? one : 0u;
+                }
+                a = row_sum16(a); b = row_sum16(b); c = row_sum16(c); d = row_sum16(d);
+                const int l15 = q.rb + 15;
+                h13.a = (uint32_t)rbc((int)a, l15); h13.b = (uint32_t)rbc((int)b, l15); h13.c = (uint32_t)rbc((int)c, l15); h13.d = (uint32_t)rbc((int)d, l15);
+            }
+            sh = r4_shanten(q, h13, len3);
+            if (sh <= 0) { q.bail = true; return; }
+        }
+    }
+    if (q.r == 0) {
+        P->waits13 = 0ull;
+        P->sh13 = (uint8_t)sh;
+        P->flags |= PF_WAITS_VALID;
+    }
+    wave_sync();
+}
+
+// The same from a histogram, for a hand whose 13 tiles are not one sorted run (right after a Kita the previous drawn tile
+// sits behind the twelve sorted ones).
+__device__ __forceinline__ void r4_fill_waits13_h(R4& q, PState* P, const PH& h13) {
     const uint32_t T9 = 1u | (1u << 24);
     const int yaochu = __popc((h13.a | (h13.a >> 1) | (h13.a >> 2)) & T9) + __popc((h13.b | (h13.b >> 1) | (h13.b >> 2)) & T9) +
                        __popc((h13.c | (h13.c >> 1) | (h13.c >> 2)) & T9) + __popc((h13.d | (h13.d >> 1) | (h13.d >> 2)) & O7_1);
     const int iso = r4_isolated(h13);
     int lb = iso >= 6 ? 4 : (iso == 5 ? 3 : (iso == 4 ? 2 : 0));
-    const int len3 = P->hand_len / 3;
+    const int len3 = ph_total(h13) / 3;
     if (len3 == 4) {
         const int koku = 12 - yaochu;
         lb = koku < lb ? koku : lb;
@@ -179,10 +269,6 @@ __device__ __forceinline__ void r4_fill_waits13(R4& q, PState* P, const PH& h13)
     }
     int sh = lb;
     if (lb < 2) {
-        // A tenpai 13-tile hand has at most ONE isolated tile (a tanki wait; chiitoi tenpai: its single), and a kokushi
-        // tenpai holds twelve kinds of terminals and honors: two isolated tiles and fewer than twelve such kinds mean
-        // shanten >= 1 - no waits, which is all the cache must know; sh13 = 1 is then a lower bound (its users only ever
-        // skip work on ">= 2").  Only the remaining ~5 % of the hands take the table shanten.
         if (iso >= 2 && yaochu < 12) {
             sh = 1;
         } else {
@@ -341,8 +427,7 @@ __device__ __forceinline__ void r4_resolve_discard(R4& q, int pid, int tile, boo
                 const int i = __ffs((int)need_m) - 1;
                 need_m &= need_m - 1u;
                 PState* Q = &G->p[i];
-                const PH h = r4_hist(q, Q, -1);
-                r4_fill_waits13(q, Q, h);
+                r4_fill_waits13(q, Q, Q->hand_len);
                 if (q.bail) need_m = 0u;
             }
         }
@@ -504,8 +589,10 @@ __device__ __forceinline__ void r4_gen_act_legal(R4& q, int& nl_mine) {
         const int same_type = __popc(rballot(r < hl && hty == (drawn_tile >> 2), rb));
         if (!(idx >= 0 && same_type <= 4 && (hl - 1) + 3 * nmelds == 13)) { q.bail = true; return; }
         if (!(pflags & PF_WAITS_VALID)) {
-            const PH h13 = r4_hist(q, P, idx);
-            r4_fill_waits13(q, P, h13);
+            // the drawn tile is the last one and the 13 others are normally one sorted run; after a Kita they are not
+            const int nx = __builtin_amdgcn_update_dpp(0xFFFF, ht, 0x101 /* row_shl:1 */, 0xf, 0xf, false);
+            if (idx != hl - 1 || rballot(r < hl - 2 && ht > nx, rb)) r4_fill_waits13_h(q, P, r4_hist(q, P, idx));
+            else r4_fill_waits13(q, P, hl - 1);
             if (q.bail) return;
         }
         if ((P->waits13 >> (drawn_tile >> 2)) & 1ull) { q.bail = true; return; }
@@ -670,13 +757,30 @@ __device__ __forceinline__ void step4_body(const Env* Ep, Quad4Shared& sh, uint6
                 const int idx = fm ? __ffs((int)fm) - 1 : -1;
                 // hand.remove(idx); hand.sort(): the hand is 13 sorted tiles + the drawn one (else: poked state -> bail)
                 const int nxt = __builtin_amdgcn_update_dpp(0xFFFF, t, 0x101 /* row_shl:1 */, 0xf, 0xf, false);
-                if (idx < 0 || rballot(r < hl - 2 && t > nxt, rb)) {
+                const uint32_t uns = rballot(r < hl - 2 && t > nxt, rb);
+                // 3P: right after a Kita the tile drawn before it sits behind the sorted run, in front of the replacement draw
+                const bool two_loose = KSANMA && hl >= 3 && uns == (1u << (hl - 3));
+                if (idx < 0 || (uns && !two_loose)) {
                     q.bail = true;
                 } else {
-                    const int d = rbc(t, rb + hl - 1);
-                    const int before_d = __popc(rballot(r < hl - 1 && r != idx && t <= d, rb));
-                    int np = r - (idx < r ? 1 : 0) + ((idx != hl - 1 && d < t) ? 1 : 0);
-                    if (r == hl - 1) np = before_d;
+                    int np;
+                    if (!uns) {
+                        const int d = rbc(t, rb + hl - 1);
+                        const int before_d = __popc(rballot(r < hl - 1 && r != idx && t <= d, rb));
+                        np = r - (idx < r ? 1 : 0) + ((idx != hl - 1 && d < t) ? 1 : 0);
+                        if (r == hl - 1) np = before_d;
+                    } else {
+                        // sorted run of m = hl - 2 tiles + two loose ones (A, B): the new slot of a tile = the number of remaining
+                        // tiles with a smaller id (ids are unique)
+                        const int m = hl - 2;
+                        const int A = rbc(t, rb + m), B = rbc(t, rb + m + 1);
+                        const bool remA = idx != m, remB = idx != m + 1;
+                        const bool in_run = r < m && r != idx;
+                        const int lessA = __popc(rballot(in_run && t < A, rb)), lessB = __popc(rballot(in_run && t < B, rb));
+                        np = r - (idx < r ? 1 : 0) + ((remA && A < t) ? 1 : 0) + ((remB && B < t) ? 1 : 0);
+                        if (r == m) np = lessA + ((remB && B < A) ? 1 : 0);
+                        if (r == m + 1) np = lessB + ((remA && A < B) ? 1 : 0);
+                    }
                     wave_sync();
                     if (r < hl && r != idx) P->hand[np] = (uint8_t)t;
                     if (r == 0) P->hand_len = (uint8_t)(hl - 1);
@@ -716,7 +820,7 @@ __device__ __forceinline__ void step4_body(const Env* Ep, Quad4Shared& sh, uint6
                                 const int i = __ffs((int)need_m) - 1;
                                 need_m &= need_m - 1u;
                                 PState* Q = &G->p[i];
-                                r4_fill_waits13(q, Q, r4_hist(q, Q, -1));
+                                r4_fill_waits13(q, Q, Q->hand_len);
                                 if (q.bail) need_m = 0u;
                             }
                         }

@@ -855,10 +855,10 @@ static inline void launch_step_range(rmj_env* h, hipStream_t st, const uint64_t*
 #else
     const unsigned extra_lds = 0u;
 #endif
-    if (h->quad && allow_quad && (flags & STEP_F_RANDOM)) {   // device policy: four games per wave
+    if (h->quad && allow_quad) {   // four games per wave (device policy, packed actions or action ids)
         const dim3 grid((g1 - g0 + 3u) / 4u);
-        if (h->cfg.game_mode >= 3) hipLaunchKernelGGL(rmj3::k_step4<false>, grid, dim3(64), 0, st, (const Env*)h->d_env, policy_seed, flags, g0, g1, 1u);
-        else hipLaunchKernelGGL(rmj4::k_step4<false>, grid, dim3(64), 0, st, (const Env*)h->d_env, policy_seed, flags, g0, g1, 1u);
+        if (h->cfg.game_mode >= 3) hipLaunchKernelGGL(rmj3::k_step4<false>, grid, dim3(64), 0, st, (const Env*)h->d_env, policy_seed, flags, g0, g1, 1u, d_actions);
+        else hipLaunchKernelGGL(rmj4::k_step4<false>, grid, dim3(64), 0, st, (const Env*)h->d_env, policy_seed, flags, g0, g1, 1u, d_actions);
         return;
     }
     if (h->cfg.game_mode >= 3) hipLaunchKernelGGL(rmj3::k_step, step_grid(g1 - g0), dim3(64 * RMJ_STEP_WPB), extra_lds, st, (const Env*)h->d_env, d_actions, policy_seed, flags, g0, g1);
@@ -948,8 +948,8 @@ int rmj_step_random(rmj_handle h, uint64_t policy_seed, uint32_t n_steps, int au
     if (h->quad >= 2 && n_steps >= 2 && h->want_streams >= 2) {   // (rmj_set_rollout_streams(h, 1): one launch per step, one stream)
         // four games per wave, the whole rollout in ONE launch: every wave steps its own games n_steps times (k_step4<true>)
         const dim3 grid((n + 3u) / 4u);
-        if (h->cfg.game_mode >= 3) hipLaunchKernelGGL(rmj3::k_step4<true>, grid, dim3(64), 0, h->stream, (const Env*)h->d_env, policy_seed, flags, 0u, n, n_steps);
-        else hipLaunchKernelGGL(rmj4::k_step4<true>, grid, dim3(64), 0, h->stream, (const Env*)h->d_env, policy_seed, flags, 0u, n, n_steps);
+        if (h->cfg.game_mode >= 3) hipLaunchKernelGGL(rmj3::k_step4<true>, grid, dim3(64), 0, h->stream, (const Env*)h->d_env, policy_seed, flags, 0u, n, n_steps, (const uint64_t*)nullptr);
+        else hipLaunchKernelGGL(rmj4::k_step4<true>, grid, dim3(64), 0, h->stream, (const Env*)h->d_env, policy_seed, flags, 0u, n, n_steps, (const uint64_t*)nullptr);
         HIPCHK(hipGetLastError());
         return RMJ_OK;
     }
@@ -1872,6 +1872,18 @@ extern "C" int rmj_prof_set_cut(int cut, int cut2, int cut3) {
     HIPCHK(hipDeviceSynchronize());
     HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(rmj::g_cut), &cut, sizeof(cut)));
     HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(rmj::g_cut2), &cut2, sizeof(cut2)));
+    return RMJ_OK;
+}
+#endif
+
+#ifdef RMJ_CUTS
+extern "C" int rmj_prof_bail_census(uint32_t* out32, int reset) {
+    HIPCHK(hipDeviceSynchronize());
+    HIPCHK(hipMemcpyFromSymbol(out32, HIP_SYMBOL(rmj::g_bail_reason), 32 * sizeof(uint32_t)));
+    if (reset) {
+        uint32_t z[32] = {0};
+        HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(rmj::g_bail_reason), z, sizeof(z)));
+    }
     return RMJ_OK;
 }
 #endif

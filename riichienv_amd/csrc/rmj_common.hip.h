@@ -76,6 +76,7 @@ __device__ uint32_t* g_prof_buf;  // [n_games][64]: 0..31 cycles, 32..63 visit c
 // ends there, before anything is stored.  The difference of the launch's PMC instruction counters between two cuts is
 // the number of instructions executed between the two marks.
 __device__ int g_cut = -1, g_cut2 = -1, g_cut3 = -1;
+__device__ uint32_t g_bail_reason[32];  // bail census of k_step4 (R4BAIL sites)
 #define PROF(X, lane, id) do { if (rmj::g_cut == (id) || rmj::g_cut2 == (id) || rmj::g_cut3 == (id)) __builtin_amdgcn_endpgm(); } while (0)
 #define PROF_START(X, lane) do {} while (0)
 #define PROF_FLUSH(X, lane, g) do {} while (0)

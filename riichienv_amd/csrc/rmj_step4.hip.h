@@ -20,10 +20,12 @@
 namespace RMJ_NS {
 
 #define R4_LIST 16 /* staged list entries per (game, seat); a longer list makes the row bail */
-#ifdef RMJ_CUTS   /* instruction accounting build (scripts/valu_sections4.py): the wave ends at mark g_cut */
-#define R4M(id) do { if (rmj::g_cut == (id)) __builtin_amdgcn_endpgm(); } while (0)
+#ifdef RMJ_CUTS   /* instruction accounting build (scripts/valu_sections4.py, scripts/bail_census.py) */
+#define R4M(id) do { if (rmj::g_cut == (id)) __builtin_amdgcn_endpgm(); } while (0)   /* the wave ends at mark g_cut */
+#define R4BAIL(q, id) do { (q).bail = true; if ((q).r == 0) atomicAdd(&rmj::g_bail_reason[id], 1u); } while (0)   /* bail census */
 #else
 #define R4M(id) do {} while (0)
+#define R4BAIL(q, id) do { (q).bail = true; } while (0)
 #endif
 struct Quad4Tier0 {
     alignas(16) uint32_t ev[4][RMJ_EV_STAGE][8];  // staged MJAI records per game
@@ -74,7 +76,7 @@ struct R4 {
 __device__ __forceinline__ void r4_emit(R4& q, uint32_t w0, uint32_t w1, uint32_t w6) {
     if (q.E->skip_log) return;
     const uint32_t evc = q.G->ev_count;
-    if (q.evn >= RMJ_EV_STAGE) { q.bail = true; return; }
+    if (q.evn >= RMJ_EV_STAGE) { R4BAIL(q, 1); return; }
     if (q.r == 0) {
         uint4* b = reinterpret_cast<uint4*>(q.T->ev[q.row][q.evn]);
         b[0] = make_uint4(w0, w1, 0u, 0u);
@@ -239,7 +241,7 @@ __device__ __forceinline__ void r4_fill_waits13(R4& q, PState* P, int n) {
                 h13.a = (uint32_t)rbc((int)a, l15); h13.b = (uint32_t)rbc((int)b, l15); h13.c = (uint32_t)rbc((int)c, l15); h13.d = (uint32_t)rbc((int)d, l15);
             }
             sh = r4_shanten(q, h13, len3);
-            if (sh <= 0) { q.bail = true; return; }
+            if (sh <= 0) { R4BAIL(q, 2); return; }
         }
     }
     if (q.r == 0) {
@@ -273,7 +275,7 @@ __device__ __forceinline__ void r4_fill_waits13_h(R4& q, PState* P, const PH& h1
             sh = 1;
         } else {
             sh = r4_shanten(q, h13, len3);
-            if (sh <= 0) { q.bail = true; return; }
+            if (sh <= 0) { R4BAIL(q, 3); return; }
         }
     }
     if (q.r == 0) {
@@ -317,20 +319,20 @@ __device__ __forceinline__ void r4_check_abortive(R4& q) {
         const int first = G->p[0].discards[0] >> 2;
         if (first >= 27 && first <= 30) {
             const uint32_t same = rballot(seat_lane && (P.discards[0] >> 2) == first, q.rb);
-            if (same == all_seats) q.bail = true;
+            if (same == all_seats) R4BAIL(q, 4);
         }
     }
     if (__popc(kan) == 4) {
         const int owner = (__ffs((int)kan) - 1) >> 2;
-        if (kan & ~(0xFu << (4 * owner))) q.bail = true;
+        if (kan & ~(0xFu << (4 * owner))) R4BAIL(q, 5);
     }
-    if (!KSANMA && riichi == all_seats) q.bail = true;
+    if (!KSANMA && riichi == all_seats) R4BAIL(q, 6);
 }
 // deal_next (state/mod.rs:1569-1593); pf = the prefetched live-wall tile W[live_end - 1]
 __device__ __forceinline__ void r4_deal_next(R4& q, int pf) {
     GState* G = q.G;
     const int drawable = G->drawable_count;
-    if (drawable == 0) { q.bail = true; return; }   // exhaustive draw
+    if (drawable == 0) { R4BAIL(q, 7); return; }   // exhaustive draw
     const int live_end = G->live_end;
     const int pid = G->current_player;
     PState* P = &G->p[pid];
@@ -370,7 +372,7 @@ __device__ __forceinline__ void r4_resolve_discard(R4& q, int pid, int tile, boo
     GState* G = q.G;
     PState* P = &G->p[pid];
     const int r = q.r, rb = q.rb;
-    if (G->pending_kan_dora > 0) { q.bail = true; return; }
+    if (G->pending_kan_dora > 0) { R4BAIL(q, 8); return; }
     const int tt = tile >> 2;
     {
         uint32_t fl = P->flags;
@@ -444,7 +446,7 @@ __device__ __forceinline__ void r4_resolve_discard(R4& q, int pid, int tile, boo
     const bool in_discards = (dtm >> tt) & 1ull;
     const bool in_missed = (qfl & PF_MISSED_DOUJUN) || ((qfl & PF_RIICHI_DECLARED) && (qfl & PF_MISSED_RIICHI));
     const bool furiten = (W & dtm) != 0ull || (qfl & (PF_MISSED_RIICHI | PF_MISSED_DOUJUN));
-    if (rballot(other && !in_discards && !in_missed && !furiten && ((W >> tt) & 1ull), rb)) { q.bail = true; return; }
+    if (rballot(other && !in_discards && !in_missed && !furiten && ((W >> tt) & 1ull), rb)) { R4BAIL(q, 9); return; }
     const uint32_t riichi_m = rballot(r < 4 && (qfl & PF_RIICHI_DECLARED), rb) & 0xFu;
     w_mine = r < 4 ? W : 0ull;
     const bool can_call = G->drawable_count > 0;
@@ -530,7 +532,7 @@ __device__ __forceinline__ void r4_resolve_discard(R4& q, int pid, int tile, boo
     R4M(54);
     // ---- E: Pass, lengths, stale counts (lane = seat)
     int n_me = r < 4 ? nl_get(r) : 0;
-    if (rballot(r < 4 && n_me + 1 > R4_LIST, rb)) { q.bail = true; return; }
+    if (rballot(r < 4 && n_me + 1 > R4_LIST, rb)) { R4BAIL(q, 10); return; }
     if (r < 4) {
         G->stale_n[r] = (uint8_t)(n_me > 62 ? 62 : n_me);
         if (n_me > 0) {
@@ -578,7 +580,7 @@ __device__ __forceinline__ void r4_gen_act_legal(R4& q, int& nl_mine) {
     const int drawn_tile = G->drawn_tile;
     const bool drawn = drawn_tile != 0xFF;
     const int drawable = G->drawable_count;
-    if (hl + 3 * nmelds == 13 || r_stage) { q.bail = true; return; }
+    if (hl + 3 * nmelds == 13 || r_stage) { R4BAIL(q, 11); return; }
     const int ht = r < hl ? (int)P->hand[r] : 0xFF;
     const int hty = ht >> 2;
     int n = 0;
@@ -587,7 +589,7 @@ __device__ __forceinline__ void r4_gen_act_legal(R4& q, int& nl_mine) {
         const uint32_t b = rballot(r < hl && ht == drawn_tile, rb);
         const int idx = b ? 31 - __clz((int)b) : -1;
         const int same_type = __popc(rballot(r < hl && hty == (drawn_tile >> 2), rb));
-        if (!(idx >= 0 && same_type <= 4 && (hl - 1) + 3 * nmelds == 13)) { q.bail = true; return; }
+        if (!(idx >= 0 && same_type <= 4 && (hl - 1) + 3 * nmelds == 13)) { R4BAIL(q, 12); return; }
         if (!(pflags & PF_WAITS_VALID)) {
             // the drawn tile is the last one and the 13 others are normally one sorted run; after a Kita they are not
             const int nx = __builtin_amdgcn_update_dpp(0xFFFF, ht, 0x101 /* row_shl:1 */, 0xf, 0xf, false);
@@ -595,7 +597,7 @@ __device__ __forceinline__ void r4_gen_act_legal(R4& q, int& nl_mine) {
             else r4_fill_waits13(q, P, hl - 1);
             if (q.bail) return;
         }
-        if ((P->waits13 >> (drawn_tile >> 2)) & 1ull) { q.bail = true; return; }
+        if ((P->waits13 >> (drawn_tile >> 2)) & 1ull) { R4BAIL(q, 13); return; }
     }
     R4M(60);
     // 2. Discards (+ Riichi -> bail)
@@ -620,7 +622,7 @@ __device__ __forceinline__ void r4_gen_act_legal(R4& q, int& nl_mine) {
                 const int yk = __popc((full.a | (full.a >> 1) | (full.a >> 2)) & T9) + __popc((full.b | (full.b >> 1) | (full.b >> 2)) & T9) +
                                __popc((full.c | (full.c >> 1) | (full.c >> 2)) & T9) + __popc((full.d | (full.d >> 1) | (full.d >> 2)) & O7_1);
                 if (!(r4_isolated(full) >= 3 && yk < 12)) {
-                    if (r4_shanten(q, full, hl / 3) <= 0) { q.bail = true; return; }
+                    if (r4_shanten(q, full, hl / 3) <= 0) { R4BAIL(q, 14); return; }
                 }
             }
         }
@@ -634,7 +636,7 @@ __device__ __forceinline__ void r4_gen_act_legal(R4& q, int& nl_mine) {
     if (drawable > 0 && drawn) {
         if (!r_decl) {
             const bool any4 = (((full.a | full.b | full.c) & O9_4) | (full.d & O7_4)) != 0u;
-            if (any4) { q.bail = true; return; }          // Ankan available: full path builds the list
+            if (any4) { R4BAIL(q, 15); return; }          // Ankan available: full path builds the list
             const uint32_t pon_lane = rballot(r < nmelds && P->meld_type[r & 3] == RMJ_MELD_PON, rb);
             if (pon_lane) {                               // Kakan: meld order, then hand order
                 for (int m = 0; m < nmelds; m++) {
@@ -650,7 +652,7 @@ __device__ __forceinline__ void r4_gen_act_legal(R4& q, int& nl_mine) {
                 }
             }
         } else {
-            if (ph_cnt(full, drawn_tile >> 2) == 4) { q.bail = true; return; }   // ankan after riichi: wait probes
+            if (ph_cnt(full, drawn_tile >> 2) == 4) { R4BAIL(q, 16); return; }   // ankan after riichi: wait probes
         }
     }
     // 4. Kyushu kyuhai: first turn, no calls, nine kinds of terminals and honors (the type set is OR-ed over the row)
@@ -670,7 +672,7 @@ __device__ __forceinline__ void r4_gen_act_legal(R4& q, int& nl_mine) {
         if (hit) r4_put(q, pid, n + __popc(kb & ((1u << r) - 1u)), mk_action(RMJ_KITA, ht, 0), 59);
         n += __popc(kb);
     }
-    if (n > R4_LIST) { q.bail = true; return; }
+    if (n > R4_LIST) { R4BAIL(q, 17); return; }
     nl_mine = r == pid ? n : 0;
     wave_sync();
 }
@@ -678,7 +680,7 @@ __device__ __forceinline__ void r4_gen_act_legal(R4& q, int& nl_mine) {
 // One step of four consecutive games per wave (device policy only: rmj_step_random / rmj_bench_rollout); `load`: fetch the records from HBM first (the rollout loop keeps them in LDS)
 template <bool LOOP>
 __device__ __forceinline__ void step4_body(const Env* Ep, Quad4Shared& sh, uint64_t policy_seed, uint32_t flags, uint32_t g_base, uint32_t g_end,
-                                           bool load, uint64_t gs_row) {
+                                           bool load, uint64_t gs_row, const uint64_t* __restrict__ actions = nullptr) {
     CEnv& E = *(CEnv*)Ep;
     const int lane = threadIdx.x & 63;
     const int row = lane >> 4, r = lane & 15, rb = lane & 48;
@@ -720,15 +722,65 @@ __device__ __forceinline__ void step4_body(const Env* Ep, Quad4Shared& sh, uint6
     uint64_t mine = RMJ_NO_ACTION;
     if (q.live) {
         if (G->is_done) {
-            q.bail = true;   // finished game: restart (auto-reset) or nothing to do - both handled by the full path
-        } else if (r < 4) {
-            const uint32_t n = G->nlegal[r];
-            if (((G->active_mask >> r) & 1u) && n != 0u) {
-                const uint64_t gs = LOOP ? gs_row : sm64(policy_seed + E.game_offset + (uint64_t)g);   // (the loop hashes the game once)
-                const uint64_t key = sm64(gs + (uint64_t)G->step_count * 4ull + (uint64_t)r);
-                const uint32_t ch = mod_small(key, n > 64u ? 64u : n);
-                const uint64_t* src = Lg + r * RMJ_MAX_LEGAL + ch;
-                mine = LOOP ? __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : *src;
+            R4BAIL(q, 18);   // finished game: restart (auto-reset) or nothing to do - both handled by the full path
+        } else if (flags & STEP_F_RANDOM) {
+            if (r < 4) {
+                const uint32_t n = G->nlegal[r];
+                if (((G->active_mask >> r) & 1u) && n != 0u) {
+                    const uint64_t gs = LOOP ? gs_row : sm64(policy_seed + E.game_offset + (uint64_t)g);   // (the loop hashes the game once)
+                    const uint64_t key = sm64(gs + (uint64_t)G->step_count * 4ull + (uint64_t)r);
+                    const uint32_t ch = mod_small(key, n > 64u ? 64u : n);
+                    const uint64_t* src = Lg + r * RMJ_MAX_LEGAL + ch;
+                    mine = LOOP ? __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : *src;
+                }
+            }
+        } else if (!LOOP) {
+            // ---- the caller's actions (lane = seat): packed actions, validated against the stored lists like GameState::step
+            // does (state/mod.rs:339-402), or action ids mapped to the first legal action with that id (Observation.find_action,
+            // observation/python.rs:119-122).  Anything the lists do not confirm goes to the full path (illegal action penalty).
+            const bool by_id = (flags & STEP_F_IDS) != 0u;
+            int want = -1;
+            uint64_t given = RMJ_NO_ACTION;
+            bool has = false;
+            const uint32_t am = G->active_mask;
+            if (r < 4) {
+                if (by_id) {   // ids of seats that are not to act are ignored (k_step does the same)
+                    want = reinterpret_cast<const int32_t*>(actions)[(size_t)g * 4 + r];
+                    has = want >= 0 && ((am >> r) & 1u) && G->nlegal[r] != 0;
+                } else {
+                    const uint64_t a = actions[(size_t)g * 4 + r];
+                    has = (a & 0xFFull) != 0xFFull;
+                    given = has ? a_canon(a) : RMJ_NO_ACTION;
+                    mine = given;   // (a bailed row hands the caller's actions to the full path as they are)
+                }
+            }
+            if (!by_id && rballot(r < 4 && has && (!((am >> r) & 1u) || G->nlegal[r & 3] == 0), rb)) {
+                R4BAIL(q, 27);       // a seat that is not to act sent something: the reference's validation decides
+            } else {
+                uint32_t todo = rballot(r < 4 && has, rb) & 0xFu;
+                while (__ballot(todo != 0u)) {
+                    if (todo) {
+                        const int p = __ffs((int)todo) - 1;
+                        todo &= todo - 1u;
+                        const int n = G->nlegal[p];
+                        const int want_p = rbc(want, rb + p);
+                        const uint64_t given_p = rbc64(given, rb + p);
+                        bool found = false;
+                        uint64_t chosen = 0ull;
+                        for (int base = 0; base < n; base += 16) {   // 16 stored entries per pass
+                            const bool in = base + r < n;
+                            const uint64_t e = in ? Lg[p * RMJ_MAX_LEGAL + base + r] : 0ull;
+                            const bool hit = in && (by_id ? (KSANMA ? a_encode_3p(e) : a_encode(e)) == want_p : a_match(e, given_p));
+                            const uint32_t hb = rballot(hit, rb);
+                            if (hb && !found) {
+                                found = true;
+                                chosen = rbc64(e, rb + __ffs((int)hb) - 1);
+                            }
+                        }
+                        if (by_id && r == p) mine = found ? chosen : mk_action(0x7F, RMJ_TILE_NONE, 0);   // no legal action with that id
+                        if (!found) { R4BAIL(q, 28); todo = 0u; }   // illegal action: penalty in the full path
+                    }
+                }
             }
         }
     }
@@ -745,7 +797,7 @@ __device__ __forceinline__ void step4_body(const Env* Ep, Quad4Shared& sh, uint6
             const uint32_t ty = act & 0xFFu;
             PState* P = &G->p[pid];
             if (act == 0xFFFFFFFFu || ((act >> 8) & 0xFFu) == RMJ_TILE_NONE) {
-                q.bail = true;
+                R4BAIL(q, 19);
             } else if (ty == RMJ_DISCARD) {
                 q.dirty = 1u << pid;
                 const int tile = (int)((act >> 8) & 0xFFu);
@@ -761,7 +813,7 @@ __device__ __forceinline__ void step4_body(const Env* Ep, Quad4Shared& sh, uint6
                 // 3P: right after a Kita the tile drawn before it sits behind the sorted run, in front of the replacement draw
                 const bool two_loose = KSANMA && hl >= 3 && uns == (1u << (hl - 3));
                 if (idx < 0 || (uns && !two_loose)) {
-                    q.bail = true;
+                    R4BAIL(q, 20);
                 } else {
                     int np;
                     if (!uns) {
@@ -797,7 +849,7 @@ __device__ __forceinline__ void step4_body(const Env* Ep, Quad4Shared& sh, uint6
                 const int t = r < hl ? (int)P->hand[r] : 0xFFFF;
                 const uint32_t fm = rballot(r < hl && t == tile, rb);
                 if (G->pending_kan_dora > 0 || !fm || (tile >> 2) != 30 || G->drawable_count == 0) {
-                    q.bail = true;
+                    R4BAIL(q, 21);
                 } else {
                     const int idx = __ffs((int)fm) - 1;
                     wave_sync();
@@ -831,7 +883,7 @@ __device__ __forceinline__ void step4_body(const Env* Ep, Quad4Shared& sh, uint6
                         const bool holds13 = other && (S4.hand_len + 3 * S4.n_melds == 13);
                         const uint64_t W = holds13 ? S4.waits13 : 0ull;
                         const bool furiten = (W & S4.discard_type_mask) != 0ull || (S4.flags & (PF_MISSED_RIICHI | PF_MISSED_DOUJUN));
-                        if (rballot(other && !furiten && ((W >> 30) & 1ull), rb)) q.bail = true;
+                        if (rballot(other && !furiten && ((W >> 30) & 1ull), rb)) R4BAIL(q, 22);
                     }
                     if (!q.bail) {
                         // resolve_kita_rinshan (state_3p/sanma.rs:171-204): replacement draw from the dead wall, no new dora
@@ -861,7 +913,7 @@ __device__ __forceinline__ void step4_body(const Env* Ep, Quad4Shared& sh, uint6
                     }
                 }
             } else {
-                q.bail = true;   // Riichi, kans, Tsumo, Kyushu: full path
+                R4BAIL(q, 23);   // Riichi, kans, Tsumo, Kyushu: full path
             }
         } else {
             // ---- WaitResponse (state/mod.rs:900-1314), lane = seat
@@ -873,7 +925,7 @@ __device__ __forceinline__ void step4_body(const Env* Ep, Quad4Shared& sh, uint6
             const uint32_t roned = rballot(has && my_ty == RMJ_RON, rb) & 0xFu;
             const uint32_t offer = G->ron_offer_mask;
             if (roned & act_m) {
-                q.bail = true;                                    // Ron settlement
+                R4BAIL(q, 24);                                    // Ron settlement
             } else {
                 if (r < 4 && ((offer & ~roned) >> r) & 1u) {      // a Ron offer that was not taken
                     uint32_t fl = G->p[r].flags | PF_MISSED_DOUJUN;
@@ -888,7 +940,7 @@ __device__ __forceinline__ void step4_body(const Env* Ep, Quad4Shared& sh, uint6
                     const uint64_t claim = rbc64(mine, rb + claimer);
                     const uint32_t ty = a_type(claim);
                     if (ty == RMJ_DAIMINKAN) {
-                        q.bail = true;
+                        R4BAIL(q, 25);
                     } else {
                         PState* C = &G->p[claimer];
                         r4_accept_riichi(q);
@@ -954,7 +1006,7 @@ __device__ __forceinline__ void step4_body(const Env* Ep, Quad4Shared& sh, uint6
                     }
                 } else {
                     if (G->pending_kan_pid != 0xFF) {
-                        q.bail = true;     // a chankan / kita offer was passed: the kan resolves in the full path
+                        R4BAIL(q, 26);     // a chankan / kita offer was passed: the kan resolves in the full path
                     } else {
                         if (r == 0) {
                             G->active_mask = 0;
@@ -1091,7 +1143,7 @@ __device__ __noinline__ void step4_call(const Env* Ep, uint64_t policy_seed, uin
 // that tail costs as much as the work; the loop pays it once per rollout.
 template <bool LOOP>
 __global__ __launch_bounds__(64, RMJ_STEP4_WAVES) void k_step4(const Env* __restrict__ Ep, uint64_t policy_seed, uint32_t flags, uint32_t g_base,
-                                                                   uint32_t g_end, uint32_t n_steps) {
+                                                                   uint32_t g_end, uint32_t n_steps, const uint64_t* __restrict__ actions) {
     if (LOOP) {
         const uint32_t g = g_base + blockIdx.x * 4u + ((threadIdx.x & 63u) >> 4);
         const uint64_t gs_row = sm64(policy_seed + ((CEnv*)Ep)->game_offset + (uint64_t)g);   // policy key of the row's game
@@ -1099,7 +1151,7 @@ __global__ __launch_bounds__(64, RMJ_STEP4_WAVES) void k_step4(const Env* __rest
         for (uint32_t it = 0; it < n_steps; it++) step4_call<true>(Ep, policy_seed, flags, g_base, g_end, it == 0 ? 1u : 0u, gs_row);
     } else {
         __shared__ Quad4Shared sh;
-        step4_body<false>(Ep, sh, policy_seed, flags, g_base, g_end, true, 0ull);
+        step4_body<false>(Ep, sh, policy_seed, flags, g_base, g_end, true, 0ull, actions);
     }
 }
 

@@ -12,7 +12,7 @@ for grp in "FETCH_SIZE" "WRITE_SIZE" "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS S
   timeout 300 rocprofv3 --pmc $grp --output-format csv -d $R/gpurun_out/${TAG}_pmc_p$i -- python3 bench.py --mode $MODE --steps $N --warmup $N --no-cpu-baseline --no-extras > $R/gpurun_out/${TAG}_pmc_p$i.log 2>&1
   echo "pass $i ($grp) rc=$?"
 done
-python3 scripts/pmc_summary.py $R/gpurun_out ${TAG}_pmc "k_step4<true>" $MODE $N 4 > $R/gpurun_out/${TAG}_pmc_k_step4.json
+python3 scripts/pmc_summary.py $R/gpurun_out ${TAG}_pmc "k_step4<true>" $MODE $N 4 65536 > $R/gpurun_out/${TAG}_pmc_k_step4.json
 rm -rf gpurun_out/${TAG}_pmc_p*/
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/${TAG}_stats -- python3 bench.py --mode $MODE --steps 1000 --warmup 1000 --no-cpu-baseline --no-extras > gpurun_out/${TAG}_stats.log 2>&1
 find gpurun_out/${TAG}_stats -name "*kernel_stats.csv" -exec cp {} gpurun_out/${TAG}_kernel_stats.csv \;

@@ -10,6 +10,7 @@ root, tag, kern = sys.argv[1], sys.argv[2], sys.argv[3]
 mode = int(sys.argv[4]) if len(sys.argv) > 4 else 2
 steps_per_launch = int(sys.argv[5]) if len(sys.argv) > 5 else 1     # fused rollouts: one launch = that many steps of every game
 games_per_wave = int(sys.argv[6]) if len(sys.argv) > 6 else 1
+games_known = int(sys.argv[7]) if len(sys.argv) > 7 else 0            # games of a launch when known (SQ_WAVES over-counts fused rollouts)
 out = {}
 for f in glob.glob(os.path.join(root, tag + "_p*", "**", "*counter_collection.csv"), recursive=True):
     acc = {}
@@ -27,6 +28,9 @@ for f in glob.glob(os.path.join(root, tag + "_p*", "**", "*counter_collection.cs
 doc = {"command": "rocprofv3 --pmc <group> -- python3 <bench command> (one pass per counter group, scripts/r02_profiles.sh / "
                   "scripts/pmc_collect.sh)", "kernel": kern, "mode": mode, "counters": out}
 waves = out.get("SQ_WAVES", {}).get("mean_per_launch")
+if games_known:
+    doc["sq_waves_counter"] = waves
+    waves = games_known / games_per_wave
 if waves:
     doc["games_per_launch"] = int(round(waves)) * games_per_wave
     doc["games_per_wave"] = games_per_wave

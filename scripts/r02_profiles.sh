@@ -31,7 +31,7 @@ for grp in "FETCH_SIZE" "WRITE_SIZE" "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS S
   timeout 300 rocprofv3 --pmc $grp --output-format csv -d $R/gpurun_out/${TAG}_pmc_p$i -- python3 bench.py --steps 300 --warmup 300 --no-cpu-baseline --no-extras > $R/gpurun_out/${TAG}_pmc_p$i.log 2>&1
   echo "k_step4 pass $i ($grp) rc=$?"
 done
-python3 scripts/pmc_summary.py $R/gpurun_out ${TAG}_pmc "k_step4<true>" 2 300 4 > $R/gpurun_out/${TAG}_pmc_k_step4.json
+python3 scripts/pmc_summary.py $R/gpurun_out ${TAG}_pmc "k_step4<true>" 2 300 4 65536 > $R/gpurun_out/${TAG}_pmc_k_step4.json
 i=0
 for grp in "FETCH_SIZE" "WRITE_SIZE" "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVES" "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_ACTIVE_INST_ANY"; do
   i=$((i+1))

@@ -203,6 +203,9 @@ __device__ __forceinline__ uint32_t mod_small(uint64_t x, uint32_t n) {
     return (uint32_t)r;
 }
 
+// Per-lane variant by magic multiplication: digits of 16 bits keep every intermediate below 2^22, where
+// floor(v / n) = mulhi(v, ceil(2^32 / n)) exactly (error term v * (M n - 2^32) < 2^22 * 64 < 2^32); M from the table.
+__device__ __forceinline__ uint32_t mod_small_magic(uint64_t x, uint32_t n);
 // The same for wave-uniform operands, on the scalar unit only (the step is bound by VALU issue): with a_i = 2^(16 i) mod n
 // the digit sum d0 + d1 a1 + d2 a2 + d3 a3 is below 2^24 and congruent to x, and for v < 2^24, n <= 64 the quotient is
 // exactly mulhi(v, ceil(2^32 / n)) (error term v * (M n - 2^32) < 2^24 * 64 < 2^32).  Both tables are compile-time data
@@ -218,6 +221,17 @@ constexpr ModTab make_modtab() {
     return t;
 }
 __constant__ const ModTab g_modtab = make_modtab();
+__device__ __forceinline__ uint32_t mod_small_magic(uint64_t x, uint32_t n) {  // 1 <= n <= 64, per lane
+    const uint32_t inv = g_modtab.inv[n];
+    uint32_t r = 0;
+#pragma unroll
+    for (int d = 3; d >= 0; d--) {
+        const uint32_t v = (r << 16) | (uint32_t)((x >> (16 * d)) & 0xFFFFull);
+        const uint32_t qd = __umulhi(v, inv);
+        r = v - qd * n;
+    }
+    return n == 1u ? 0u : r;
+}
 __device__ __forceinline__ uint32_t mod_small_uniform(uint64_t x, uint32_t n) {  // x, n in SGPRs; 1 <= n <= 64
     const uint32_t pw = g_modtab.pw[n], inv = g_modtab.inv[n];
     const uint32_t lo = (uint32_t)x, hi = (uint32_t)(x >> 32);

@@ -729,7 +729,7 @@ __device__ __forceinline__ void step4_body(const Env* Ep, Quad4Shared& sh, uint6
                 if (((G->active_mask >> r) & 1u) && n != 0u) {
                     const uint64_t gs = LOOP ? gs_row : sm64(policy_seed + E.game_offset + (uint64_t)g);   // (the loop hashes the game once)
                     const uint64_t key = sm64(gs + (uint64_t)G->step_count * 4ull + (uint64_t)r);
-                    const uint32_t ch = mod_small(key, n > 64u ? 64u : n);
+                    const uint32_t ch = mod_small_magic(key, n > 64u ? 64u : n);
                     const uint64_t* src = Lg + r * RMJ_MAX_LEGAL + ch;
                     mine = LOOP ? __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : *src;
                 }

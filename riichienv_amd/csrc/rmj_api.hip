@@ -366,13 +366,24 @@ __device__ __forceinline__ void enc_zero16(float* dst, int n_floats, int lane) {
 }
 // Observation.encode() of the games [g0, g0 + gridDim.x): ONE block (= one wave) per game, which walks the seats it has to
 // encode - with only_active that is the acting seat (one, rarely two or three), so the launch has a quarter of the blocks of
-// a (game, seat) grid and no early-exit blocks.  The 74 channels of a seat are produced in windows of 16 into a 2 KB LDS
-// buffer and streamed out window by window (16 x W x 4 B: a multiple of 16 bytes for W = 34 and W = 27).
-template <bool SANMA, int ENC_WINDOW>
-__global__ __launch_bounds__(64) void k_encode_base(Env E, int only_active, float* __restrict__ out, uint32_t g0) {
+// a (game, seat) grid and no early-exit blocks.  The 74 channels are staged as column bit masks + broadcast values
+// (EncBitSink: 1 KB of LDS, 2.4 KB per block with the record and the histograms, so the CU holds its 32 waves) and
+// expanded to floats in the 16-byte stores.
+#ifndef RMJ_ENC_WAVES
+#define RMJ_ENC_WAVES 8
+#endif
+#if RMJ_ENC_WAVES > 0
+#define RMJ_ENC_OCC __attribute__((amdgpu_waves_per_eu(RMJ_ENC_WAVES, RMJ_ENC_WAVES)))
+#else
+#define RMJ_ENC_OCC
+#endif
+template <bool SANMA>
+__global__ __launch_bounds__(64) RMJ_ENC_OCC void k_encode_base(Env E, int only_active, float* __restrict__ out, uint32_t g0) {
     constexpr int W = SANMA ? ENC_W3 : ENC_W4, NPP = SANMA ? 3 : 4;
     __shared__ GState st;
-    __shared__ __attribute__((aligned(16))) float buf[ENC_WINDOW * W];
+    __shared__ uint64_t bits[ENC_CH];
+    __shared__ float scal[ENC_CH];
+    __shared__ float col63[36];
     __shared__ uint32_t hist[ENC_HIST_WORDS];
     const int lane = threadIdx.x & 63;
     const uint32_t g = g0 + blockIdx.x;
@@ -396,12 +407,10 @@ __global__ __launch_bounds__(64) void k_encode_base(Env E, int only_active, floa
             if (only_active != 2) enc_zero16(dst, ENC_CH * W, lane);
             continue;
         }
-        for (int c0 = 0; c0 < ENC_CH; c0 += ENC_WINDOW) {
-            const int n = ENC_CH - c0 < ENC_WINDOW ? ENC_CH - c0 : ENC_WINDOW;
-            encode_seat<SANMA>(S, seat, buf, lane, hist, c0, n, c0 == 0);
-            enc_stream_out16(dst + c0 * W, buf, n * W, lane);
-            wave_sync();
-        }
+        EncBitSink<W> o{bits, scal, col63, lane, -1.0f};
+        encode_seat_to<SANMA>(S, seat, lane, hist, o, true);
+        enc_emit_bits<W>(dst, bits, scal, col63, lane);
+        wave_sync();
     }
 }
 template <bool SANMA, bool EXT>
@@ -1510,8 +1519,8 @@ int rmj_calculate_score(int device, const uint8_t* han, const uint8_t* fu, const
 // for 65 536 4P games - the kernel is bound by its own instruction stream and the store epilogue, not by occupancy.
 static void launch_encode_base_range(rmj_env* h, hipStream_t st, int only_active, float* d_out, uint32_t g0, uint32_t g1) {
     const dim3 grid(g1 - g0), block(64);
-    if (h->cfg.game_mode >= 3) hipLaunchKernelGGL((k_encode_base<true, ENC_CH>), grid, block, 0, st, h->d, only_active, d_out, g0);
-    else hipLaunchKernelGGL((k_encode_base<false, ENC_CH>), grid, block, 0, st, h->d, only_active, d_out, g0);
+    if (h->cfg.game_mode >= 3) hipLaunchKernelGGL((k_encode_base<true>), grid, block, 0, st, h->d, only_active, d_out, g0);
+    else hipLaunchKernelGGL((k_encode_base<false>), grid, block, 0, st, h->d, only_active, d_out, g0);
 }
 static int launch_encode(rmj_handle h, int only_active, float* d_out, bool ext) {
     if (!h || !d_out) return fail(RMJ_ERR_ARG, "null argument");

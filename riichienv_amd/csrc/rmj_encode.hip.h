@@ -50,35 +50,115 @@ __device__ __forceinline__ int enc_next_tile136_sanma(int tile) {
 
 // `hist`: 5 x 36 u32 of LDS scratch (type histograms of the four seats' visible tiles and of the own hand)
 #define ENC_HIST_WORDS (5 * 36)
-template <bool SANMA>
-// The channels [ch_lo, ch_lo + ch_n) are produced into buf[0 .. ch_n * W): the whole tensor (0, 74) for the extended
-// encoder, windows of 16 channels for the base encoder (a 2 KB staging buffer keeps eight waves per SIMD resident where
-// the whole 10 KB tensor allowed three: the kernel is bound by the latency of its dependent loads and of the store
-// stream, not by instruction issue).  `first` = build the type histograms (they serve every window of the seat).
-__device__ inline void encode_seat(const GState& S, int pid, float* buf, int lane, uint32_t* hist, int ch_lo = 0, int ch_n = ENC_CH,
-                                   bool first = true) {
+// ---- output sinks of encode_seat: ONE body produces the 74 channels, the sink decides how they are staged.
+// EncFloatSink: the channels [ch_lo, ch_lo + ch_n) as floats in buf[0 .. ch_n * W) (the extended encoder stages the whole
+// tensor; windows exist for experiments).  EncBitSink: every channel of Observation.encode() is either a 0/1 pattern over
+// the tile columns (hand counts, melds, discards, dora, waits, winds), one value broadcast over all columns (counts, scores,
+// flags), or - channel 63 only - a per-column number: 74 column bit masks + 74 broadcast values + 34 floats = 1 KB of LDS
+// instead of 10 KB, expanded to floats on the way out (enc_emit_bits).
+template <int W>
+struct EncFloatSink {
+    float* buf;
+    int ch_lo, ch_n, lane;
+    __device__ __forceinline__ int slot(int ch) const { const int k = ch - ch_lo; return (k >= 0 && k < ch_n) ? k : -1; }
+    __device__ __forceinline__ bool wants(int ch) const { return slot(ch) >= 0; }
+    __device__ __forceinline__ void zero() const {   // 16-byte LDS stores (buf is 16-byte aligned), then the odd floats
+        const int n4 = (ch_n * W) >> 2;
+        for (int i = lane; i < n4; i += 64) reinterpret_cast<float4*>(buf)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (lane < ((ch_n * W) & 3)) buf[4 * n4 + lane] = 0.0f;
+    }
+    __device__ __forceinline__ void put(int ch, int col) const {   // one cell = 1
+        const int k = slot(ch);
+        if (k >= 0 && col >= 0) buf[k * W + col] = 1.0f;
+    }
+    __device__ __forceinline__ void bcast(int ch, float v) const {   // every column = v
+        const int k = slot(ch);
+        if (k >= 0 && lane < W) buf[k * W + lane] = v;
+    }
+    __device__ __forceinline__ void cell(int ch, float v) const {   // this lane's column = v (1.0 except for channel 63)
+        const int k = slot(ch);
+        if (k >= 0 && lane < W) buf[k * W + lane] = v;
+    }
+    __device__ __forceinline__ void flush() const {}
+};
+template <int W>
+struct EncBitSink {
+    uint64_t* bits;   // [74] column masks (broadcast channels: all W columns)
+    float* scal;      // [74] the value of the set columns (1.0 unless the channel is a broadcast one)
+    float* col63;     // [36] channel 63
+    int lane;
+    float acc;        // lane i < 37 collects the broadcast value of channel 26 + i (-1 = none): no LDS traffic per broadcast
+    __device__ __forceinline__ bool wants(int) const { return true; }
+    __device__ __forceinline__ void zero() {
+        for (int i = lane; i < ENC_CH; i += 64) { bits[i] = 0ull; scal[i] = 1.0f; }
+        if (lane < 36) col63[lane] = 0.0f;
+        acc = -1.0f;
+    }
+    __device__ __forceinline__ void put(int ch, int col) const {
+        if (col >= 0) atomicOr(reinterpret_cast<unsigned long long*>(&bits[ch]), 1ull << col);
+    }
+    __device__ __forceinline__ void bcast(int ch, float v) {   // wave-uniform calls; every broadcast channel lies in 26..62
+        if (lane == ch - 26) acc = v;
+    }
+    __device__ __forceinline__ void cell(int ch, float v) const {
+        if (lane < W) {
+            if (ch == 63) col63[lane] = v;
+            else atomicOr(reinterpret_cast<unsigned long long*>(&bits[ch]), 1ull << lane);
+        }
+    }
+    __device__ __forceinline__ void flush() const {
+        if (lane < 37 && acc >= 0.0f) {
+            scal[26 + lane] = acc;
+            bits[26 + lane] = (1ull << W) - 1ull;
+        }
+    }
+};
+// 74 x W floats of one seat from the bit-staged form, in 16-byte stores (`dst` is 8-byte aligned like in enc_stream_out16).
+// A float4 spans at most two channels: the column bits of both are merged into one word, bit k = element k.
+template <int W>
+__device__ __forceinline__ void enc_emit_bits(float* dst, const uint64_t* bits, const float* scal, const float* col63, int lane) {
+    constexpr int N = ENC_CH * W;
+    const int head = (int)(((16u - (uint32_t)(reinterpret_cast<uintptr_t>(dst) & 15u)) & 15u) >> 2);  // 0 or 2
+    const int body = (N - head) >> 2, tail0 = head + 4 * body;
+    auto one = [&](int e) -> float {
+        const int ch = e / W, col = e - ch * W;
+        if (ch == 63) return col63[col];
+        return ((bits[ch] >> col) & 1ull) ? scal[ch] : 0.0f;
+    };
+    if (lane < head) dst[lane] = one(lane);
+    float4* d4 = reinterpret_cast<float4*>(dst + head);
+    for (int i = lane; i < body; i += 64) {
+        const int e0 = head + 4 * i;
+        const int ch0 = e0 / W, col0 = e0 - ch0 * W;
+        const int ch1 = ch0 + 1 < ENC_CH ? ch0 + 1 : ch0;
+        const int n0 = W - col0;   // elements k < n0 belong to ch0 (n0 >= 1)
+        float4 v;
+        if (ch0 == 63 || (ch1 == 63 && n0 < 4)) {
+            v = make_float4(one(e0), one(e0 + 1), one(e0 + 2), one(e0 + 3));
+        } else {
+            const uint32_t c = (uint32_t)((bits[ch0] >> col0) | (bits[ch1] << n0));
+            const float s0 = scal[ch0], s1 = scal[ch1];
+            v.x = (c & 1u) ? s0 : 0.0f;
+            v.y = (c & 2u) ? (n0 > 1 ? s0 : s1) : 0.0f;
+            v.z = (c & 4u) ? (n0 > 2 ? s0 : s1) : 0.0f;
+            v.w = (c & 8u) ? (n0 > 3 ? s0 : s1) : 0.0f;
+        }
+        d4[i] = v;
+    }
+    if (lane < N - tail0) dst[tail0 + lane] = one(tail0 + lane);
+}
+template <bool SANMA, class SINK>
+__device__ inline void encode_seat_to(const GState& S, int pid, int lane, uint32_t* hist, SINK& o, bool first) {
     constexpr int ENC_W = SANMA ? ENC_W3 : ENC_W4;
     constexpr int NPP = SANMA ? 3 : 4;
-    auto slot = [&](int ch) { const int k = ch - ch_lo; return (k >= 0 && k < ch_n) ? k : -1; };
-    auto enc_bcast = [&](float* b, int ch, float v, int l) {
-        const int k = slot(ch);
-        if (k >= 0 && l < ENC_W) b[k * ENC_W + l] = v;
-    };
-    auto put = [&](int ch, int t34) {  // scatter one cell (skips tiles without a column)
-        int col = enc_col<SANMA>(t34);
-        const int k = slot(ch);
-        if (k >= 0 && col >= 0) buf[k * ENC_W + col] = 1.0f;
-    };
-    auto cell = [&](int ch, float v) {   // this lane's column of channel ch
-        const int k = slot(ch);
-        if (k >= 0 && lane < ENC_W) buf[k * ENC_W + lane] = v;
-    };
+    auto enc_bcast = [&](float*, int ch, float v, int) { o.bcast(ch, v); };
+    auto put = [&](int ch, int t34) { o.put(ch, enc_col<SANMA>(t34)); };   // scatter one cell (skips tiles without a column)
+    auto cell = [&](int ch, float v) { o.cell(ch, v); };
+    auto slot = [&](int ch) { return o.wants(ch) ? 0 : -1; };
+    float* const buf = nullptr;
+    (void)buf;
     const int my34 = SANMA ? (lane == 0 ? 0 : lane + 7) : lane;  // tile type of this lane's column
-    {   // zero the window: 16-byte LDS stores (buf is 16-byte aligned), then the odd floats
-        const int n4 = (ch_n * ENC_W) >> 2;
-        for (int i = lane; i < n4; i += 64) reinterpret_cast<float4*>(buf)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (lane < ((ch_n * ENC_W) & 3)) buf[4 * n4 + lane] = 0.0f;
-    }
+    o.zero();
     if (first)
         for (int i = lane; i < ENC_HIST_WORDS; i += 64) hist[i] = 0u;
     wave_sync();
@@ -200,7 +280,16 @@ __device__ inline void encode_seat(const GState& S, int pid, float* buf, int lan
         }
     }
     // ch 70-73 stay 0: tsumogiri_flags is never filled (observation/mod.rs:105)
+    o.flush();
     wave_sync();
+}
+
+// the float-staged form (extended encoder: whole tensor; ch_lo / ch_n select a window)
+template <bool SANMA>
+__device__ inline void encode_seat(const GState& S, int pid, float* buf, int lane, uint32_t* hist, int ch_lo = 0, int ch_n = ENC_CH,
+                                   bool first = true) {
+    EncFloatSink<SANMA ? ENC_W3 : ENC_W4> o{buf, ch_lo, ch_n, lane};
+    encode_seat_to<SANMA>(S, pid, lane, hist, o, first);
 }
 
 // ---------------------------------------------------------------- encode_extended

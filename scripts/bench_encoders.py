@@ -12,6 +12,8 @@ import torch  # noqa: E402
 
 from riichienv_amd import vecenv  # noqa: E402
 
+if len(sys.argv) > 1:   # a variant build: riichienv_amd/libriichi_mi355x_<suffix>.so
+    vecenv.LIB_PATH = vecenv.LIB_PATH.replace(".so", "_" + sys.argv[1] + ".so")
 out = {}
 for mode in (2, 5):
     w = 27 if mode >= 3 else 34

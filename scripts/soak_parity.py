@@ -2,7 +2,6 @@
 """Parity soak (not part of the test suite): long device-policy rollouts of every game mode under both rule sets and
 several seeds, compared with the oracle game by game - final state, legal lists, masks, waits, step counts and the whole
 MJAI log of every game.  usage: python scripts/soak_parity.py [games] [steps] [seeds]"""
-from riichienv_amd.shard import game_seed
 import os
 import sys
 import time
@@ -11,6 +10,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from oracle import oracle  # noqa: E402
 from riichienv_amd import abi, vecenv  # noqa: E402
+from riichienv_amd.shard import game_seed  # noqa: E402
 from tests.test_gpu_step import _compare  # noqa: E402
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 128

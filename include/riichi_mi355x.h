@@ -275,6 +275,16 @@ int rmj_encode_device(rmj_handle h, int only_active, float* d_out); /* device po
  * and rmj_encode_device(h, only_active, d_out) n_steps times; issued like rmj_step_random as up to four parts of the batch on
  * as many HIP streams, each part running step, encode, step, encode ... in order. */
 int rmj_step_random_encode(rmj_handle h, uint64_t policy_seed, uint32_t n_steps, int auto_reset, int only_active, float* d_out);
+/* The batch a trainer stacks from the reference's `{pid: obs.encode() for pid, obs in env.step(...).items()}`
+ * (riichienv-python/src/env.rs:857-872, observation/python.rs encode): the Observation.encode() tensors of the ACTING seats
+ * only, one after the other in (game, seat) order.  d_out: [capacity][74][34 | 27] f32, d_index: [capacity] i32 = game * 4 + seat
+ * of every row, *d_count (device u32): the number of observations of this state (finished games have none); when it exceeds
+ * `capacity` only the first `capacity` rows were written.  Dense rows instead of 1 row in 4 of the [n_games][4] tensor:
+ * the same bytes leave at 1.6x the rate.  Asynchronous on the handle's stream. */
+int rmj_encode_compact_device(rmj_handle h, float* d_out, int32_t* d_index, uint32_t capacity, uint32_t* d_count);
+/* rmj_step_random(h, seed, 1, auto_reset) + rmj_encode_compact_device n_steps times (one stream): BASELINE configs[4]. */
+int rmj_step_random_encode_compact(rmj_handle h, uint64_t policy_seed, uint32_t n_steps, int auto_reset, float* d_out, int32_t* d_index,
+                                   uint32_t capacity, uint32_t* d_count);
 
 /* Observation.encode_extended (observation/python.rs:1271-1296): 215 channels = encode() + discard decay (4), shanten
  * efficiency (16), ankan (4), fuuro (80), action availability (11), discard candidates (5), pass context (3), last
@@ -422,6 +432,8 @@ int rmj_bench_rollout_validated(rmj_handle h, uint64_t policy_seed, uint32_t war
 /* Average duration (ms) of one encoder launch over `reps` back-to-back launches, HIP events on the handle's stream;
  * extended = 0: rmj_encode_device, 1: rmj_encode_extended_device (same d_out / only_active meaning). */
 int rmj_bench_encode(rmj_handle h, int extended, int only_active, float* d_out, uint32_t reps, double* avg_ms);
+/* the same for rmj_encode_compact_device (slot scan + encoder launch) */
+int rmj_bench_encode_compact(rmj_handle h, float* d_out, int32_t* d_index, uint32_t capacity, uint32_t* d_count, uint32_t reps, double* avg_ms);
 /* Parts (HIP streams) a multi-step device rollout of this handle is cut into, 1..8 (default 4, or RMJ_STEP_STREAMS in
  * the environment when the handle is created); see rmj_step_random. */
 int rmj_set_rollout_streams(rmj_handle h, int k);

@@ -364,26 +364,62 @@ __device__ __forceinline__ void enc_zero16(float* dst, int n_floats, int lane) {
     for (int i = lane; i < body; i += 64) d4[i] = make_float4(0.f, 0.f, 0.f, 0.f);
     if (lane < n_floats - tail0) dst[tail0 + lane] = 0.0f;
 }
+// Slots of the compact observation batch, level one: a block of 1024 threads scans the acting-seat counts of its 1024 games
+// (finished games have none): offs[g] = acting seats in the block's games before g, totals[block] = the block's sum.  The
+// encoder adds the totals of the blocks before its game's block (at most 512 numbers, one wave reduction).
+#define OBS_SCAN_BLOCK 1024
+__global__ __launch_bounds__(OBS_SCAN_BLOCK) void k_obs_offsets(const uint32_t* __restrict__ status, uint32_t n, uint32_t* __restrict__ offs,
+                                                               uint32_t* __restrict__ totals) {
+    __shared__ uint32_t wsum[OBS_SCAN_BLOCK / 64];
+    const uint32_t t = threadIdx.x, g = blockIdx.x * OBS_SCAN_BLOCK + t, lane = t & 63u, wv = t >> 6;
+    uint32_t c = 0u;
+    if (g < n) {
+        const uint32_t w = status[g];
+        c = ((w >> 16) & 0xFFu) ? 0u : (uint32_t)__popc(w & 0xFu);
+    }
+    uint32_t inc = c;   // inclusive scan inside the wave
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t v = (uint32_t)__shfl_up((int)inc, d, 64);
+        if ((int)lane >= d) inc += v;
+    }
+    if (lane == 63u) wsum[wv] = inc;
+    __syncthreads();
+    uint32_t before = 0u;
+    for (uint32_t k = 0; k < wv; k++) before += wsum[k];
+    if (g < n) offs[g] = before + inc - c;
+    if (t == OBS_SCAN_BLOCK - 1) totals[blockIdx.x] = before + inc;
+}
+// sum of totals[0 .. nb) by one wave (nb <= 512 for 524 288 games)
+__device__ __forceinline__ uint32_t obs_block_prefix(const uint32_t* __restrict__ totals, uint32_t nb, int lane) {
+    uint32_t s = 0u;
+    for (uint32_t k = (uint32_t)lane; k < nb; k += 64u) s += totals[k];
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) s += (uint32_t)__shfl_xor((int)s, d, 64);
+    return s;
+}
 // Observation.encode() of the games [g0, g0 + gridDim.x): ONE block (= one wave) per game, which walks the seats it has to
 // encode - with only_active that is the acting seat (one, rarely two or three), so the launch has a quarter of the blocks of
-// a (game, seat) grid and no early-exit blocks.  The 74 channels are staged as column bit masks + broadcast values
-// (EncBitSink: 1 KB of LDS, 2.4 KB per block with the record and the histograms, so the CU holds its 32 waves) and
-// expanded to floats in the 16-byte stores.
+// a (game, seat) grid and no early-exit blocks.  The tensor of a seat is staged as one byte per cell (EncByteSink: 2.5 KB,
+// 4.9 KB of LDS per block with the record, the histograms and the value table) and leaves as a stream of 16-byte stores.
 #ifndef RMJ_ENC_WAVES
-#define RMJ_ENC_WAVES 8
+#define RMJ_ENC_WAVES 0
 #endif
 #if RMJ_ENC_WAVES > 0
 #define RMJ_ENC_OCC __attribute__((amdgpu_waves_per_eu(RMJ_ENC_WAVES, RMJ_ENC_WAVES)))
 #else
 #define RMJ_ENC_OCC
 #endif
-template <bool SANMA>
-__global__ __launch_bounds__(64) RMJ_ENC_OCC void k_encode_base(Env E, int only_active, float* __restrict__ out, uint32_t g0) {
+// `offs` != nullptr: compact output (rmj_encode_compact_device) - the observations of the acting seats, one after the other in
+// (game, seat) order: observation offs[g] + j is the j-th acting seat of game g, `index` receives game * 4 + seat.
+template <bool SANMA, bool COMPACT>
+__global__ __launch_bounds__(64) RMJ_ENC_OCC void k_encode_base(Env E, int only_active, float* __restrict__ out, uint32_t g0,
+                                                               const uint32_t* __restrict__ offs, int32_t* __restrict__ index, uint32_t capacity,
+                                                               const uint32_t* __restrict__ totals, uint32_t* __restrict__ count) {
     constexpr int W = SANMA ? ENC_W3 : ENC_W4, NPP = SANMA ? 3 : 4;
     __shared__ GState st;
-    __shared__ uint64_t bits[ENC_CH];
-    __shared__ float scal[ENC_CH];
-    __shared__ float col63[36];
+    __shared__ __attribute__((aligned(16))) uint8_t raw[(ENC_CH * W + 4 + 15) / 16 * 16];
+    __shared__ float lut[ENC_LUT];
     __shared__ uint32_t hist[ENC_HIST_WORDS];
     const int lane = threadIdx.x & 63;
     const uint32_t g = g0 + blockIdx.x;
@@ -393,23 +429,44 @@ __global__ __launch_bounds__(64) RMJ_ENC_OCC void k_encode_base(Env E, int only_
     const uint32_t stw = E.status[g];
     const uint32_t am = ((stw >> 16) & 0xFFu) ? 0u : (stw & 0xFu);
     float* base = out + (size_t)g * 4 * ENC_CH * W;
-    if (only_active && am == 0u) {
+    uint32_t slot = 0u;
+    if (COMPACT) {
+        if (blockIdx.x == 0) {   // the size of the batch: all block totals
+            const uint32_t all = obs_block_prefix(totals, (E.n_games + OBS_SCAN_BLOCK - 1) / OBS_SCAN_BLOCK, lane);
+            if (lane == 0) *count = all;
+        }
+        if (am == 0u) return;
+        slot = offs[g] + obs_block_prefix(totals, g / OBS_SCAN_BLOCK, lane);
+    } else if (only_active && am == 0u) {
         if (only_active == 1) enc_zero16(base, 4 * ENC_CH * W, lane);
         return;
     }
+    enc_lut_init(lut, lane);
     if (lane < (int)(sizeof(GState) / 16)) reinterpret_cast<uint4*>(&st)[lane] = rec;
     wave_sync();
     const GState& S = st;
     for (int seat = 0; seat < 4; seat++) {
         float* dst = base + (size_t)seat * ENC_CH * W;
         const bool acts = (am >> seat) & 1u;
-        if (seat >= NPP || (only_active && !acts)) {
+        if (COMPACT) {
+            if (seat >= NPP || !acts) continue;
+            if (slot >= capacity) return;                  // (the count tells the caller that the buffer was too small)
+            dst = out + (size_t)slot * ENC_CH * W;
+            if (lane == 0) index[slot] = (int32_t)(g * 4u + (uint32_t)seat);
+            slot += 1u;
+        } else if (seat >= NPP || (only_active && !acts)) {
             if (only_active != 2) enc_zero16(dst, ENC_CH * W, lane);
             continue;
         }
-        EncBitSink<W> o{bits, scal, col63, lane, -1.0f};
+        const int head = (int)(((16u - (uint32_t)(reinterpret_cast<uintptr_t>(dst) & 15u)) & 15u) >> 2);  // 0 or 2 floats
+        EncByteSink<W> o{raw + ((4 - head) & 3), lut, lane, -1.0f};
+#ifdef RMJ_ENC_NOCOMPUTE   /* experiment: the memory side alone (record in, 74 x W floats out) */
+        o.zero();
+        wave_sync();
+#else
         encode_seat_to<SANMA>(S, seat, lane, hist, o, true);
-        enc_emit_bits<W>(dst, bits, scal, col63, lane);
+#endif
+        enc_emit_bytes<W>(dst, o.cells, lut, lane, head);
         wave_sync();
     }
 }
@@ -651,6 +708,7 @@ struct rmj_env {
     Env* d_env = nullptr;  // device-resident copy of `d` (kernels take a pointer, see rmj_kernels.hip.h)
     uint64_t* d_actions = nullptr;
     unsigned long long* d_counter = nullptr;
+    uint32_t* d_obs_offs = nullptr;    // [n_games] + [blocks] slots of the compact observation batch (rmj_encode_compact_device)
     uint32_t ring = 0;
     float* d_decay = nullptr;  // expf(-0.2f * age), age 0..31, computed on the host (encode_extended)
     void* d_scratch = nullptr; // staging buffer of the host-copy entry points (grown on demand, never per call)
@@ -755,6 +813,7 @@ static int create_impl(rmj_env* h, const RmjConfig* cfg, uint64_t** d_seeds_out)
     HIPCHK(hipMemsetAsync(d.win, 0, B * 4 * sizeof(RmjWinResult), h->stream));
     HIPCHK(hipMalloc(&h->d_actions, B * 4 * sizeof(uint64_t)));
     HIPCHK(hipMalloc(&h->d_counter, sizeof(unsigned long long)));
+    HIPCHK(hipMalloc(&h->d_obs_offs, (B + (B + 1023) / 1024) * sizeof(uint32_t)));   // per game + per scan block
     HIPCHK(hipMemsetAsync(d.legal, 0, B * 4 * RMJ_MAX_LEGAL * sizeof(uint64_t), h->stream));
     HIPCHK(hipMemsetAsync(d.nlegal, 0, B * 4, h->stream));
     HIPCHK(hipMemsetAsync(d.mask, 0, B * 4 * 82, h->stream));
@@ -818,7 +877,7 @@ int rmj_destroy(rmj_handle h) {
     hipSetDevice(h->cfg.device);
     if (h->stream) hipStreamSynchronize(h->stream);
     hipFree(h->d.core); hipFree(h->d.wall); hipFree(h->d.legal); hipFree(h->d.nlegal); hipFree(h->d_decay); if (h->d_scratch) hipFree(h->d_scratch); hipFree(h->d.mask);
-    hipFree(h->d.waits); hipFree(h->d.status); hipFree(h->d.events); hipFree(h->d.win); hipFree(h->d_actions); hipFree(h->d_counter); hipFree(h->d_env);
+    hipFree(h->d.waits); hipFree(h->d.status); hipFree(h->d.events); hipFree(h->d.win); hipFree(h->d_actions); hipFree(h->d_counter); hipFree(h->d_obs_offs); hipFree(h->d_env);
     if (h->own_stream) hipStreamDestroy(h->own_stream);
     for (int i = 0; i < RMJ_MAX_ROLLOUT_STREAMS - 1; i++) {
         if (h->xstream[i]) { hipStreamSynchronize(h->xstream[i]); hipStreamDestroy(h->xstream[i]); }
@@ -1519,8 +1578,8 @@ int rmj_calculate_score(int device, const uint8_t* han, const uint8_t* fu, const
 // for 65 536 4P games - the kernel is bound by its own instruction stream and the store epilogue, not by occupancy.
 static void launch_encode_base_range(rmj_env* h, hipStream_t st, int only_active, float* d_out, uint32_t g0, uint32_t g1) {
     const dim3 grid(g1 - g0), block(64);
-    if (h->cfg.game_mode >= 3) hipLaunchKernelGGL((k_encode_base<true>), grid, block, 0, st, h->d, only_active, d_out, g0);
-    else hipLaunchKernelGGL((k_encode_base<false>), grid, block, 0, st, h->d, only_active, d_out, g0);
+    if (h->cfg.game_mode >= 3) hipLaunchKernelGGL((k_encode_base<true, false>), grid, block, 0, st, h->d, only_active, d_out, g0, (const uint32_t*)nullptr, (int32_t*)nullptr, 0u, (const uint32_t*)nullptr, (uint32_t*)nullptr);
+    else hipLaunchKernelGGL((k_encode_base<false, false>), grid, block, 0, st, h->d, only_active, d_out, g0, (const uint32_t*)nullptr, (int32_t*)nullptr, 0u, (const uint32_t*)nullptr, (uint32_t*)nullptr);
 }
 static int launch_encode(rmj_handle h, int only_active, float* d_out, bool ext) {
     if (!h || !d_out) return fail(RMJ_ERR_ARG, "null argument");
@@ -1535,6 +1594,50 @@ static int launch_encode(rmj_handle h, int only_active, float* d_out, bool ext) 
     return RMJ_OK;
 }
 int rmj_encode_device(rmj_handle h, int only_active, float* d_out) { return launch_encode(h, only_active, d_out, false); }
+static void launch_encode_compact(rmj_env* h, float* d_out, int32_t* d_index, uint32_t capacity, uint32_t* d_count) {
+    const uint32_t n = h->cfg.n_games, nb = (n + OBS_SCAN_BLOCK - 1) / OBS_SCAN_BLOCK;
+    uint32_t* totals = h->d_obs_offs + n;
+    hipLaunchKernelGGL(k_obs_offsets, dim3(nb), dim3(OBS_SCAN_BLOCK), 0, h->stream, (const uint32_t*)h->d.status, n, h->d_obs_offs, totals);
+    if (h->cfg.game_mode >= 3) hipLaunchKernelGGL((k_encode_base<true, true>), dim3(n), dim3(64), 0, h->stream, h->d, 2, d_out, 0u, (const uint32_t*)h->d_obs_offs, d_index, capacity, (const uint32_t*)totals, d_count);
+    else hipLaunchKernelGGL((k_encode_base<false, true>), dim3(n), dim3(64), 0, h->stream, h->d, 2, d_out, 0u, (const uint32_t*)h->d_obs_offs, d_index, capacity, (const uint32_t*)totals, d_count);
+}
+int rmj_encode_compact_device(rmj_handle h, float* d_out, int32_t* d_index, uint32_t capacity, uint32_t* d_count) {
+    if (!h || !d_out || !d_index || !d_count) return fail(RMJ_ERR_ARG, "null argument");
+    HIPCHK(hipSetDevice(h->cfg.device));
+    launch_encode_compact(h, d_out, d_index, capacity, d_count);
+    HIPCHK(hipGetLastError());
+    return RMJ_OK;
+}
+int rmj_step_random_encode_compact(rmj_handle h, uint64_t policy_seed, uint32_t n_steps, int auto_reset, float* d_out, int32_t* d_index,
+                                   uint32_t capacity, uint32_t* d_count) {
+    if (!h || !d_out || !d_index || !d_count) return fail(RMJ_ERR_ARG, "null argument");
+    HIPCHK(hipSetDevice(h->cfg.device));
+    const uint32_t flags = STEP_F_RANDOM | (auto_reset ? STEP_F_AUTORESET : 0u);
+    for (uint32_t s = 0; s < n_steps; s++) {
+        launch_step_range(h, h->stream, nullptr, policy_seed, flags, 0u, h->cfg.n_games);
+        launch_encode_compact(h, d_out, d_index, capacity, d_count);
+    }
+    HIPCHK(hipGetLastError());
+    return RMJ_OK;
+}
+int rmj_bench_encode_compact(rmj_handle h, float* d_out, int32_t* d_index, uint32_t capacity, uint32_t* d_count, uint32_t reps, double* avg_ms) {
+    DevTmp tmp;
+    if (!h || !d_out || !d_index || !d_count || !avg_ms || reps == 0) return fail(RMJ_ERR_ARG, "bad argument");
+    HIPCHK(hipSetDevice(h->cfg.device));
+    hipEvent_t e0, e1;
+    HIPCHK(tmp.event(&e0));
+    HIPCHK(tmp.event(&e1));
+    launch_encode_compact(h, d_out, d_index, capacity, d_count);  // warm-up
+    HIPCHK(hipEventRecord(e0, h->stream));
+    for (uint32_t i = 0; i < reps; i++) launch_encode_compact(h, d_out, d_index, capacity, d_count);
+    HIPCHK(hipEventRecord(e1, h->stream));
+    HIPCHK(hipEventSynchronize(e1));
+    HIPCHK(hipGetLastError());
+    float ms = 0.f;
+    HIPCHK(hipEventElapsedTime(&ms, e0, e1));
+    *avg_ms = (double)ms / reps;
+    return RMJ_OK;
+}
 int rmj_encode(rmj_handle h, int only_active, float* out) {
     if (!h || !out) return fail(RMJ_ERR_ARG, "null argument");
     HIPCHK(hipSetDevice(h->cfg.device));
@@ -1893,6 +1996,26 @@ extern "C" int rmj_prof_bail_census(uint32_t* out32, int reset) {
         uint32_t z[32] = {0};
         HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(rmj::g_bail_reason), z, sizeof(z)));
     }
+    return RMJ_OK;
+}
+#endif
+
+#ifdef RMJ_TL4
+// timeline build only (scripts/timeline4.py): rows of the waves of the last launch of k_step4<false> (allocates on first call)
+int rmj_tl4_fetch(uint64_t* out, uint32_t n_waves) {
+    static unsigned long long* buf = nullptr;
+    static uint32_t cap = 0;
+    HIPCHK(hipDeviceSynchronize());
+    if (!buf) {
+        cap = n_waves;
+        HIPCHK(hipMalloc(&buf, (size_t)cap * 16 * 8));
+        HIPCHK(hipMemset(buf, 0, (size_t)cap * 16 * 8));
+        HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(rmj::g_tl4), &buf, sizeof(buf)));
+        return RMJ_OK;
+    }
+    HIPCHK(hipMemcpy(out, buf, (size_t)(n_waves < cap ? n_waves : cap) * 16 * 8, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemset(buf, 0, (size_t)cap * 16 * 8));   // blocks that leave at once (heavy-first order) write nothing
+    HIPCHK(hipDeviceSynchronize());
     return RMJ_OK;
 }
 #endif

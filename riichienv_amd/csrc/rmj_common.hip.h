@@ -56,6 +56,11 @@ struct WaveScratch {      // per-wave LDS scratch
 #endif
 };
 
+// Timeline build of k_step4 (-DRMJ_TL4, scripts/timeline4.py, never the shipped library): every wave of a launch owns a row of
+// 16 u64: core cycles between the outer marks of the step [0..6], start / end on the 100 MHz clock [8], [9]
+#ifdef RMJ_TL4
+__device__ unsigned long long* g_tl4;
+#endif
 // Section timing of the step kernel (profiling build only: -DRMJ_PROFILE, never the shipped library): wave cycles
 // between consecutive PROF marks are accumulated per section id by lane 0.
 #ifdef RMJ_PROFILE

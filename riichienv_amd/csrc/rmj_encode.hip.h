@@ -52,10 +52,9 @@ __device__ __forceinline__ int enc_next_tile136_sanma(int tile) {
 #define ENC_HIST_WORDS (5 * 36)
 // ---- output sinks of encode_seat: ONE body produces the 74 channels, the sink decides how they are staged.
 // EncFloatSink: the channels [ch_lo, ch_lo + ch_n) as floats in buf[0 .. ch_n * W) (the extended encoder stages the whole
-// tensor; windows exist for experiments).  EncBitSink: every channel of Observation.encode() is either a 0/1 pattern over
-// the tile columns (hand counts, melds, discards, dora, waits, winds), one value broadcast over all columns (counts, scores,
-// flags), or - channel 63 only - a per-column number: 74 column bit masks + 74 broadcast values + 34 floats = 1 KB of LDS
-// instead of 10 KB, expanded to floats on the way out (enc_emit_bits).
+// tensor; windows exist for experiments).  Every channel of Observation.encode() is either a 0/1 pattern over the tile
+// columns (hand counts, melds, discards, dora, waits, winds), one value broadcast over all columns (counts, scores, flags),
+// or - channel 63 only - a per-column count / 4: EncByteSink stages a one-byte code per cell.
 template <int W>
 struct EncFloatSink {
     float* buf;
@@ -79,73 +78,65 @@ struct EncFloatSink {
         const int k = slot(ch);
         if (k >= 0 && lane < W) buf[k * W + lane] = v;
     }
+    __device__ __forceinline__ void cell_quarters(int ch, int c) const { cell(ch, (float)c / 4.0f); }
     __device__ __forceinline__ void flush() const {}
 };
+// EncByteSink: one byte per cell of the 74 x W tensor, a code into a table of floats: 0 -> 0.0, 1 -> 1.0, 2 + k -> the value
+// broadcast over channel 26 + k (k < 37), 40 + c -> c / 4 (channel 63, c <= 203 even in a poked state).  2.5 KB instead of
+// 10 KB per observation, and the way out stays a plain stream of 16-byte stores (enc_emit_bytes).
+#define ENC_LUT 256
 template <int W>
-struct EncBitSink {
-    uint64_t* bits;   // [74] column masks (broadcast channels: all W columns)
-    float* scal;      // [74] the value of the set columns (1.0 unless the channel is a broadcast one)
-    float* col63;     // [36] channel 63
+struct EncByteSink {
+    uint8_t* cells;   // cell e of the tensor at cells[e]; cells + head is 4-byte aligned (head: see enc_emit_bytes)
+    float* lut;       // [ENC_LUT]; entries 0, 1 and 40.. are filled once per block (enc_lut_init)
     int lane;
-    float acc;        // lane i < 37 collects the broadcast value of channel 26 + i (-1 = none): no LDS traffic per broadcast
+    float acc;        // lane k < 37 collects the value broadcast over channel 26 + k (-1 = none)
     __device__ __forceinline__ bool wants(int) const { return true; }
     __device__ __forceinline__ void zero() {
-        for (int i = lane; i < ENC_CH; i += 64) { bits[i] = 0ull; scal[i] = 1.0f; }
-        if (lane < 36) col63[lane] = 0.0f;
+        uint4* z = reinterpret_cast<uint4*>(reinterpret_cast<uintptr_t>(cells) & ~(uintptr_t)15);   // the 16-byte aligned raw buffer
+        for (int i = lane; i < (ENC_CH * W + 4 + 15) / 16; i += 64) z[i] = make_uint4(0u, 0u, 0u, 0u);
         acc = -1.0f;
     }
     __device__ __forceinline__ void put(int ch, int col) const {
-        if (col >= 0) atomicOr(reinterpret_cast<unsigned long long*>(&bits[ch]), 1ull << col);
+        if (col >= 0) cells[ch * W + col] = 1;
     }
     __device__ __forceinline__ void bcast(int ch, float v) {   // wave-uniform calls; every broadcast channel lies in 26..62
         if (lane == ch - 26) acc = v;
+        if (lane < W) cells[ch * W + lane] = (uint8_t)(2 + ch - 26);
     }
-    __device__ __forceinline__ void cell(int ch, float v) const {
-        if (lane < W) {
-            if (ch == 63) col63[lane] = v;
-            else atomicOr(reinterpret_cast<unsigned long long*>(&bits[ch]), 1ull << lane);
-        }
+    __device__ __forceinline__ void cell(int ch, float) const {   // this lane's column = 1
+        if (lane < W) cells[ch * W + lane] = 1;
+    }
+    __device__ __forceinline__ void cell_quarters(int ch, int c) const {   // this lane's column = c / 4
+        if (lane < W) cells[ch * W + lane] = (uint8_t)(40 + c);
     }
     __device__ __forceinline__ void flush() const {
-        if (lane < 37 && acc >= 0.0f) {
-            scal[26 + lane] = acc;
-            bits[26 + lane] = (1ull << W) - 1ull;
-        }
+        if (lane < 37 && acc >= 0.0f) lut[2 + lane] = acc;
     }
 };
-// 74 x W floats of one seat from the bit-staged form, in 16-byte stores (`dst` is 8-byte aligned like in enc_stream_out16).
-// A float4 spans at most two channels: the column bits of both are merged into one word, bit k = element k.
+__device__ __forceinline__ void enc_lut_init(float* lut, int lane) {
+    for (int i = lane; i < ENC_LUT; i += 64) lut[i] = i < 2 ? (float)i : (i >= 40 ? (float)(i - 40) * 0.25f : 0.0f);
+}
+// 74 x W floats of one seat from the byte-staged form, in 16-byte stores (`dst` is 8-byte aligned like in enc_stream_out16:
+// `head` = 0 or 2 floats precede the first 16-byte boundary; the cells are laid out so that cells + head is dword aligned)
 template <int W>
-__device__ __forceinline__ void enc_emit_bits(float* dst, const uint64_t* bits, const float* scal, const float* col63, int lane) {
+__device__ __forceinline__ void enc_emit_bytes(float* dst, const uint8_t* cells, const float* lut, int lane, int head) {
     constexpr int N = ENC_CH * W;
-    const int head = (int)(((16u - (uint32_t)(reinterpret_cast<uintptr_t>(dst) & 15u)) & 15u) >> 2);  // 0 or 2
     const int body = (N - head) >> 2, tail0 = head + 4 * body;
-    auto one = [&](int e) -> float {
-        const int ch = e / W, col = e - ch * W;
-        if (ch == 63) return col63[col];
-        return ((bits[ch] >> col) & 1ull) ? scal[ch] : 0.0f;
-    };
-    if (lane < head) dst[lane] = one(lane);
+    if (lane < head) dst[lane] = lut[cells[lane]];
     float4* d4 = reinterpret_cast<float4*>(dst + head);
+    const uint32_t* c4 = reinterpret_cast<const uint32_t*>(cells + head);
     for (int i = lane; i < body; i += 64) {
-        const int e0 = head + 4 * i;
-        const int ch0 = e0 / W, col0 = e0 - ch0 * W;
-        const int ch1 = ch0 + 1 < ENC_CH ? ch0 + 1 : ch0;
-        const int n0 = W - col0;   // elements k < n0 belong to ch0 (n0 >= 1)
-        float4 v;
-        if (ch0 == 63 || (ch1 == 63 && n0 < 4)) {
-            v = make_float4(one(e0), one(e0 + 1), one(e0 + 2), one(e0 + 3));
-        } else {
-            const uint32_t c = (uint32_t)((bits[ch0] >> col0) | (bits[ch1] << n0));
-            const float s0 = scal[ch0], s1 = scal[ch1];
-            v.x = (c & 1u) ? s0 : 0.0f;
-            v.y = (c & 2u) ? (n0 > 1 ? s0 : s1) : 0.0f;
-            v.z = (c & 4u) ? (n0 > 2 ? s0 : s1) : 0.0f;
-            v.w = (c & 8u) ? (n0 > 3 ? s0 : s1) : 0.0f;
-        }
-        d4[i] = v;
+        const uint32_t w = c4[i];
+#ifdef RMJ_ENC_NT
+        const float4 v4 = make_float4(lut[w & 255u], lut[(w >> 8) & 255u], lut[(w >> 16) & 255u], lut[w >> 24]);
+        __builtin_nontemporal_store(v4.x, &d4[i].x); __builtin_nontemporal_store(v4.y, &d4[i].y);
+        __builtin_nontemporal_store(v4.z, &d4[i].z); __builtin_nontemporal_store(v4.w, &d4[i].w);
+#else
+        d4[i] = make_float4(lut[w & 255u], lut[(w >> 8) & 255u], lut[(w >> 16) & 255u], lut[w >> 24]);
+#endif
     }
-    if (lane < N - tail0) dst[tail0 + lane] = one(tail0 + lane);
+    if (lane < N - tail0) dst[tail0 + lane] = lut[cells[tail0 + lane]];
 }
 template <bool SANMA, class SINK>
 __device__ inline void encode_seat_to(const GState& S, int pid, int lane, uint32_t* hist, SINK& o, bool first) {
@@ -271,7 +262,7 @@ __device__ inline void encode_seat_to(const GState& S, int pid, int lane, uint32
             int seen = (int)hist[4 * 36 + my34];
             for (int q = 0; q < NPP; q++) seen += (int)hist[q * 36 + my34];
             for (int k = 0; k < S.n_dora; k++) seen += ((S.dora[k] >> 2) == my34);
-            cell(63, (float)(seen & 0xFF) / 4.0f);
+            o.cell_quarters(63, seen & 0xFF);
         }
         for (int rel = 0; rel < NPP; rel++) {
             int q = (pid + rel) % NPP;

@@ -25,7 +25,17 @@ namespace RMJ_NS {
 #define R4BAIL(q, id) do { (q).bail = true; if ((q).r == 0) atomicAdd(&rmj::g_bail_reason[id], 1u); } while (0)   /* bail census */
 #else
 #define R4M(id) do {} while (0)
+#ifdef RMJ_TL4
+#define R4BAIL(q, id) do { (q).bail = true; if ((q).r == 0) rmj::g_tl4[(size_t)blockIdx.x * 16 + 10 + (q).row] = (unsigned long long)(id) + 1ull; } while (0)
+#else
 #define R4BAIL(q, id) do { (q).bail = true; } while (0)
+#endif
+#endif
+#ifdef RMJ_TL4   /* timeline build (scripts/timeline4.py): core cycles between the outer marks of step4_body, summed over the waves */
+#define R4T(k) do { const uint64_t t__ = __builtin_readcyclecounter(); \
+        if ((threadIdx.x & 63) == 0) rmj::g_tl4[(size_t)blockIdx.x * 16 + (k)] = (unsigned long long)(t__ - tl_prev); tl_prev = t__; } while (0)
+#else
+#define R4T(k) do {} while (0)
 #endif
 struct Quad4Tier0 {
     alignas(16) uint32_t ev[4][RMJ_EV_STAGE][8];  // staged MJAI records per game
@@ -682,6 +692,9 @@ template <bool LOOP>
 __device__ __forceinline__ void step4_body(const Env* Ep, Quad4Shared& sh, uint64_t policy_seed, uint32_t flags, uint32_t g_base, uint32_t g_end,
                                            bool load, uint64_t gs_row, const uint64_t* __restrict__ actions = nullptr) {
     CEnv& E = *(CEnv*)Ep;
+#ifdef RMJ_TL4
+    uint64_t tl_prev = __builtin_readcyclecounter();
+#endif
     const int lane = threadIdx.x & 63;
     const int row = lane >> 4, r = lane & 15, rb = lane & 48;
     const uint32_t g0 = g_base + blockIdx.x * 4u;
@@ -698,6 +711,7 @@ __device__ __forceinline__ void step4_body(const Env* Ep, Quad4Shared& sh, uint6
         wave_sync();
     }
     R4M(40);
+    R4T(0);
     {
     R4 q;
     q.G = &sh.st[row]; q.T = &sh.u.t; q.E = &E; q.lane = lane; q.r = r; q.rb = rb; q.row = row; q.g = g;
@@ -785,6 +799,7 @@ __device__ __forceinline__ void step4_body(const Env* Ep, Quad4Shared& sh, uint6
         }
     }
     R4M(41);
+    R4T(1);
     int nl_mine = 0;          // lane = seat: length of the seat's list produced by this step
     uint64_t w_mine = 0ull;   // lane = seat: waits published for the seat
     const bool t0 = q.live && !q.bail;
@@ -1032,6 +1047,7 @@ __device__ __forceinline__ void step4_body(const Env* Ep, Quad4Shared& sh, uint6
             }
         }
         R4M(43);
+    R4T(2);
         // ---- the next observation: a WaitAct state needs the acting seat's list
         if (!q.bail && G->phase == RMJ_WAIT_ACT) {
             nl_mine = 0;
@@ -1040,6 +1056,7 @@ __device__ __forceinline__ void step4_body(const Env* Ep, Quad4Shared& sh, uint6
         }
     }
     R4M(45);
+    R4T(3);
     // ---- publication of the rows that completed in tier 0
     const bool done0 = q.live && t0 && !q.bail;
     if (done0) {
@@ -1093,6 +1110,7 @@ __device__ __forceinline__ void step4_body(const Env* Ep, Quad4Shared& sh, uint6
     }
     wave_sync();
     R4M(46);
+    R4T(4);
     // ---- records of the completed rows back to HBM (globals + touched PState quarters)
     if (done0) {
 #pragma unroll
@@ -1104,8 +1122,12 @@ __device__ __forceinline__ void step4_body(const Env* Ep, Quad4Shared& sh, uint6
     }
     wave_sync();
     R4M(47);
+    R4T(5);
     // ---- bailed games: the complete state machine, one game at a time, from the untouched HBM record
     uint64_t bm = __ballot(q.live && q.bail && r == 0);
+#ifdef RMJ_TL4
+    if (!LOOP && lane == 0) rmj::g_tl4[(size_t)blockIdx.x * 16 + 7] = (unsigned long long)__popcll(bm);
+#endif
     while (bm) {
         const int br = (__ffsll((long long)bm) - 1) >> 4;
         bm &= bm - 1ull;
@@ -1116,6 +1138,7 @@ __device__ __forceinline__ void step4_body(const Env* Ep, Quad4Shared& sh, uint6
         ol_step_full(ctx_pack(c), lane < 4 ? m_full : RMJ_NO_ACTION, flags);
         wave_sync();
     }
+    R4T(6);
     if (LOOP) {
         // The next step reads back this step's lists / wall tile with agent-scope loads (served by the XCD's L2, past the
         // vector L1); the stores are this wave's own, to the same addresses and through the same L2 channel, so no cache
@@ -1151,7 +1174,17 @@ __global__ __launch_bounds__(64, RMJ_STEP4_WAVES) void k_step4(const Env* __rest
         for (uint32_t it = 0; it < n_steps; it++) step4_call<true>(Ep, policy_seed, flags, g_base, g_end, it == 0 ? 1u : 0u, gs_row);
     } else {
         __shared__ Quad4Shared sh;
+#ifdef RMJ_TL4
+        const unsigned long long rt0 = __builtin_amdgcn_s_memrealtime();
+#endif
         step4_body<false>(Ep, sh, policy_seed, flags, g_base, g_end, true, 0ull, actions);
+#ifdef RMJ_TL4
+        const unsigned long long rt1 = __builtin_amdgcn_s_memrealtime();
+        if ((threadIdx.x & 63) == 0) {
+            rmj::g_tl4[(size_t)blockIdx.x * 16 + 8] = rt0;
+            rmj::g_tl4[(size_t)blockIdx.x * 16 + 9] = rt1;
+        }
+#endif
     }
 }
 

@@ -31,6 +31,7 @@ EXPORTS = [
     "rmj_bench_rollout_validated", "rmj_bench_encode", "rmj_set_rollout_streams", "rmj_total_full_path",
     "rmj_random_actions_device", "rmj_peek_outputs", "rmj_sample_ids_device",
     "rmj_encode_seq_delta", "rmj_encode_seq_delta_device", "rmj_step_random_encode",
+    "rmj_encode_compact_device", "rmj_step_random_encode_compact", "rmj_bench_encode_compact",
     "rmj_get_win_results",
 ]
 
@@ -121,6 +122,9 @@ def load_lib():
     L.rmj_peek_outputs.argtypes = [vp, C.c_uint32, vp, vp, vp, vp, C.POINTER(C.c_uint32)]
     L.rmj_sample_ids_device.argtypes = [vp, vp, C.c_uint32, C.c_uint64, vp]
     L.rmj_step_random_encode.argtypes = [vp, C.c_uint64, C.c_uint32, C.c_int, C.c_int, vp]
+    L.rmj_encode_compact_device.argtypes = [vp, vp, vp, C.c_uint32, vp]
+    L.rmj_step_random_encode_compact.argtypes = [vp, C.c_uint64, C.c_uint32, C.c_int, vp, vp, C.c_uint32, vp]
+    L.rmj_bench_encode_compact.argtypes = [vp, vp, vp, C.c_uint32, vp, C.c_uint32, C.POINTER(C.c_double)]
     L.rmj_get_win_results.argtypes = [vp, C.c_uint32, C.POINTER(abi.WinResult), C.POINTER(C.c_uint8)]
     L.rmj_encode_seq_delta.argtypes = [vp, C.c_int, C.POINTER(abi.SeqBuffers)]          # same field layout as RmjSeqBuffers
     L.rmj_encode_seq_delta_device.argtypes = [vp, C.c_int, C.POINTER(abi.SeqBuffers)]
@@ -242,6 +246,21 @@ class VecRiichiEnv:
         """n_steps x (step of every game + encode() of the acting seats into the device tensor at d_out_ptr): header
         rmj_step_random_encode (BASELINE configs[4])."""
         _chk(self.L.rmj_step_random_encode(self.h, policy_seed, n_steps, int(auto_reset), int(only_active), C.c_void_p(d_out_ptr)))
+
+    def encode_compact_device(self, d_out_ptr, d_index_ptr, capacity, d_count_ptr):
+        """Observation.encode() of the acting seats as one dense batch in (game, seat) order (header: rmj_encode_compact_device);
+        all three pointers are device pointers, asynchronous on the handle's stream."""
+        _chk(self.L.rmj_encode_compact_device(self.h, C.c_void_p(d_out_ptr), C.c_void_p(d_index_ptr), capacity, C.c_void_p(d_count_ptr)))
+
+    def step_random_encode_compact(self, policy_seed, n_steps, d_out_ptr, d_index_ptr, capacity, d_count_ptr, auto_reset=True):
+        _chk(self.L.rmj_step_random_encode_compact(self.h, policy_seed, n_steps, int(auto_reset), C.c_void_p(d_out_ptr),
+                                                   C.c_void_p(d_index_ptr), capacity, C.c_void_p(d_count_ptr)))
+
+    def bench_encode_compact(self, d_out_ptr, d_index_ptr, capacity, d_count_ptr, reps=20):
+        ms = C.c_double()
+        _chk(self.L.rmj_bench_encode_compact(self.h, C.c_void_p(d_out_ptr), C.c_void_p(d_index_ptr), capacity, C.c_void_p(d_count_ptr),
+                                             reps, C.byref(ms)))
+        return ms.value
 
     def random_actions(self, policy_seed):
         a = np.zeros((self.n, 4), np.uint64)

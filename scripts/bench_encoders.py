@@ -31,5 +31,17 @@ for mode in (2, 5):
             "kernel_ms": ms, "acting_seats": acting, "bytes_per_launch": b, "achieved_GBps": b / (ms * 1e-3) / 1e9,
             "frac_of_8TBps": b / (ms * 1e-3) / 8e12}
         del buf
+    # the same observations as one dense batch (rmj_encode_compact_device: slot scan + encoder)
+    cap = acting + 64
+    buf = torch.zeros((cap, 74, w), dtype=torch.float32, device="cuda:0")
+    index = torch.zeros((cap,), dtype=torch.int32, device="cuda:0")
+    count = torch.zeros((1,), dtype=torch.int32, device="cuda:0")
+    ms = env.bench_encode_compact(buf.data_ptr(), index.data_ptr(), cap, count.data_ptr(), 40)
+    assert int(count.item()) == acting
+    b = 74 * w * 4 * acting
+    out[f"k_encode_compact_{'3p' if mode >= 3 else '4p'}"] = {
+        "kernel_ms": ms, "acting_seats": acting, "bytes_per_launch": b, "achieved_GBps": b / (ms * 1e-3) / 1e9,
+        "frac_of_8TBps": b / (ms * 1e-3) / 8e12, "note": "k_obs_offsets + k_encode_base per repetition"}
+    del buf
     env.close()
 print(json.dumps(out))

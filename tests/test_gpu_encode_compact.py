@@ -1,0 +1,85 @@
+"""rmj_encode_compact_device: the Observation.encode() tensors of the acting seats as one dense batch in (game, seat) order
+(what a trainer stacks from the reference's `{pid: obs.encode()}` of env.step, env.rs:857-872).  Every row must be byte-equal
+to the acting seat's row of the [n_games][4] tensor of rmj_encode_device and - on sampled games - to the oracle's encode();
+the index must list exactly the acting seats of the unfinished games in order."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from riichienv_amd.shard import game_seed
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("mode,n", [(2, 3001), (5, 4099), (0, 257)])
+def test_compact_rows_equal_the_full_tensor_and_the_oracle(mode, n):
+    import torch
+
+    from oracle import oracle
+    from riichienv_amd import vecenv
+
+    w = 27 if mode >= 3 else 34
+    seed, pseed = 77, 0xBEEF
+    env = vecenv.VecRiichiEnv(n, game_mode=mode, seed=seed, event_ring=64)
+    env.reset()
+    games = [oracle.Game(game_mode=mode, seed=game_seed(seed, g)) for g in range(8)]
+    for o in games:
+        o.reset()
+    full = torch.zeros((n, 4, 74, w), dtype=torch.float32, device="cuda:0")
+    cap = n + n // 2
+    out = torch.full((cap, 74, w), -7.0, dtype=torch.float32, device="cuda:0")
+    index = torch.full((cap,), -1, dtype=torch.int32, device="cuda:0")
+    count = torch.zeros((1,), dtype=torch.int32, device="cuda:0")
+    multi = 0
+    for step in range(160):      # no auto-reset: finished games must drop out of the batch (mode 0 games end inside the loop)
+        if step % 3 == 0:
+            full.zero_()
+            out.fill_(-7.0)
+            torch.cuda.synchronize()      # torch's stream is not the handle's stream
+            vecenv._chk(env.L.rmj_encode_device(env.h, 2, C.c_void_p(full.data_ptr())))
+            env.encode_compact_device(out.data_ptr(), index.data_ptr(), cap, count.data_ptr())
+            env.L.rmj_sync(env.h)
+            act, _, done = env.status()
+            want = [g * 4 + s for g in range(n) if not done[g] for s in range(4) if (int(act[g]) >> s) & 1]
+            k = int(count.item())
+            assert k == len(want) and k <= cap, (step, k, len(want))
+            idx = index[:k].cpu().numpy()
+            assert idx.tolist() == want
+            rows = out[:k]
+            ref = full.view(n * 4, 74, w)[torch.from_numpy(idx.astype(np.int64)).to("cuda:0")]
+            bad = (rows != ref).flatten(1).any(dim=1).nonzero().flatten().tolist()
+            assert not bad, (step, len(bad), bad[:5], (rows[bad[0]] != ref[bad[0]]).nonzero()[:6].tolist(), idx[bad[0]])
+            assert float(out[k:].max().item()) == -7.0 and float(out[k:].min().item()) == -7.0     # nothing behind the batch is touched
+            multi += int((np.bincount(idx >> 2, minlength=n) > 1).sum())
+            host = rows.cpu().numpy()
+            for j, gi in enumerate(idx):
+                g, s = int(gi) >> 2, int(gi) & 3
+                if g < len(games):
+                    assert host[j].tobytes() == games[g].encode(s, mode >= 3).tobytes(), (step, g, s)
+        for g, o in enumerate(games):
+            if not o.status()[2]:
+                o.step(o.random_actions(pseed, g))
+        env.step_random(pseed, 1, auto_reset=False)
+    assert multi > 0 or mode != 2, multi   # 4P half games: states with several claimants (pon + chi of one discard) were part of it
+
+
+def test_capacity_smaller_than_the_batch_writes_only_capacity_rows():
+    import torch
+
+    from riichienv_amd import vecenv
+
+    n = 512
+    env = vecenv.VecRiichiEnv(n, game_mode=2, seed=5, event_ring=64)
+    env.reset()
+    env.step_random(1, 30, auto_reset=True)
+    cap = 100
+    out = torch.full((cap + 8, 74, 34), -7.0, dtype=torch.float32, device="cuda:0")
+    index = torch.full((cap + 8,), -1, dtype=torch.int32, device="cuda:0")
+    count = torch.zeros((1,), dtype=torch.int32, device="cuda:0")
+    torch.cuda.synchronize()
+    env.encode_compact_device(out.data_ptr(), index.data_ptr(), cap, count.data_ptr())
+    env.L.rmj_sync(env.h)
+    assert int(count.item()) >= n          # the count reports the whole batch
+    assert (index[:cap] >= 0).all() and (index[cap:] == -1).all()
+    assert float(out[cap:].max().item()) == -7.0 and float(out[:cap].min().item()) >= 0.0

@@ -50,6 +50,19 @@ __device__ __forceinline__ int enc_next_tile136_sanma(int tile) {
 
 // `hist`: 5 x 36 u32 of LDS scratch (type histograms of the four seats' visible tiles and of the own hand)
 #define ENC_HIST_WORDS (5 * 36)
+// x / C for a non-negative integer x <= XMAX, bit-equal to the IEEE division the reference performs ((x as f32) / C): the
+// product with the rounded reciprocal, corrected once with the exact remainder (two FMAs instead of the ~12 instructions of
+// a division, and the encoder divides ~35 times per observation).  The identity holds for every integer of the stated range:
+// checked exhaustively with exact rational arithmetic by tests/test_exact_division.py; larger x take the division.
+template <int C, int XMAX>
+__device__ __forceinline__ float enc_div(int x) {
+    constexpr float c = (float)C, rc = 1.0f / (float)C;
+    const float xf = (float)x;
+    if (x > XMAX) return xf / c;   // (wave-uniform operands: a poked state, never a played one)
+    const float q = __fmul_rn(xf, rc);
+    const float r = __builtin_fmaf(-q, c, xf);
+    return __builtin_fmaf(r, rc, q);
+}
 // ---- output sinks of encode_seat: ONE body produces the 74 channels, the sink decides how they are staged.
 // EncFloatSink: the channels [ch_lo, ch_lo + ch_n) as floats in buf[0 .. ch_n * W) (the extended encoder stages the whole
 // tensor; windows exist for experiments).  Every channel of Observation.encode() is either a 0/1 pattern over the tile
@@ -128,12 +141,13 @@ __device__ __forceinline__ void enc_emit_bytes(float* dst, const uint8_t* cells,
     const uint32_t* c4 = reinterpret_cast<const uint32_t*>(cells + head);
     for (int i = lane; i < body; i += 64) {
         const uint32_t w = c4[i];
-#ifdef RMJ_ENC_NT
-        const float4 v4 = make_float4(lut[w & 255u], lut[(w >> 8) & 255u], lut[(w >> 16) & 255u], lut[w >> 24]);
-        __builtin_nontemporal_store(v4.x, &d4[i].x); __builtin_nontemporal_store(v4.y, &d4[i].y);
-        __builtin_nontemporal_store(v4.z, &d4[i].z); __builtin_nontemporal_store(v4.w, &d4[i].w);
+        // streaming (non-temporal) 16-byte stores: the tensor is written once and read by another kernel much later
+        typedef float enc_v4f __attribute__((ext_vector_type(4)));
+        const enc_v4f v4 = {lut[w & 255u], lut[(w >> 8) & 255u], lut[(w >> 16) & 255u], lut[w >> 24]};
+#ifdef RMJ_ENC_NO_NT
+        *reinterpret_cast<enc_v4f*>(&d4[i]) = v4;
 #else
-        d4[i] = make_float4(lut[w & 255u], lut[(w >> 8) & 255u], lut[(w >> 16) & 255u], lut[w >> 24]);
+        __builtin_nontemporal_store(v4, reinterpret_cast<enc_v4f*>(&d4[i]));
 #endif
     }
     if (lane < N - tail0) dst[tail0 + lane] = lut[cells[tail0 + lane]];
@@ -215,16 +229,16 @@ __device__ inline void encode_seat_to(const GState& S, int pid, int lane, uint32
     }
     int tiles_left = (SANMA ? 108 : 136) - tiles_used;
     if (tiles_left < 0) tiles_left = 0;
-    enc_bcast(buf, 30, (float)tiles_left / 70.0f, lane);
+    enc_bcast(buf, 30, enc_div<70, 255>(tiles_left), lane);
     for (int rel = 0; rel < NPP; rel++) {
         const PState& Q = S.p[(pid + rel) % NPP];
-        enc_bcast(buf, 26 + rel, (float)Q.n_discards / 24.0f, lane);
+        enc_bcast(buf, 26 + rel, enc_div<24, 255>((int)Q.n_discards), lane);
         if (Q.flags & PF_RIICHI_DECLARED) enc_bcast(buf, 31 + rel, 1.0f, lane);
         int32_t sc = Q.score;
         int32_t s1 = sc < 0 ? 0 : (sc > 100000 ? 100000 : sc);
         int32_t s2 = sc < 0 ? 0 : (sc > 30000 ? 30000 : sc);
-        enc_bcast(buf, 39 + rel, (float)s1 / 100000.0f, lane);
-        enc_bcast(buf, 43 + rel, (float)s2 / 30000.0f, lane);
+        enc_bcast(buf, 39 + rel, enc_div<100000, 100000>(s1), lane);
+        enc_bcast(buf, 43 + rel, enc_div<30000, 30000>(s2), lane);
         enc_bcast(buf, 59 + rel, (float)Q.n_melds / 4.0f, lane);
     }
     wave_sync();
@@ -235,8 +249,8 @@ __device__ inline void encode_seat_to(const GState& S, int pid, int lane, uint32
         int seat = (pid + NPP - S.oya) % NPP;
         if (lane == 0) put(36, 27 + seat);
     }
-    enc_bcast(buf, 37, (float)S.honba / 10.0f, lane);
-    enc_bcast(buf, 38, (float)S.riichi_sticks / 5.0f, lane);
+    enc_bcast(buf, 37, enc_div<10, 255>((int)S.honba), lane);
+    enc_bcast(buf, 38, enc_div<5, 4096>((int)(S.riichi_sticks > 0x7FFFFFFFu ? 0x7FFFFFFFu : S.riichi_sticks)), lane);
     // 14-15. waits / tenpai (ch 47-48)
     if (slot(47) >= 0 || slot(48) >= 0) {   // (wave-uniform) only the window that holds the wait channels pays for the probe
         uint64_t W = enc_waits(P, lane);
@@ -245,7 +259,7 @@ __device__ inline void encode_seat_to(const GState& S, int pid, int lane, uint32
     }
     if (rank < NPP) enc_bcast(buf, 49 + rank, 1.0f, lane);
     enc_bcast(buf, 53, (float)S.kyoku_idx / 8.0f, lane);
-    enc_bcast(buf, 54, ((float)S.round_wind * 4.0f + (float)S.kyoku_idx) / 7.0f, lane);
+    enc_bcast(buf, 54, enc_div<7, 1275>((int)S.round_wind * 4 + (int)S.kyoku_idx), lane);
     // 19. dora counts (ch 55-58): per seat, the number of visible tiles (own hand included for the observer) whose type is
     //     the dora of an indicator, counted per indicator (u8 accumulator in the reference); 21. tiles seen (ch 63)
     {
@@ -267,7 +281,7 @@ __device__ inline void encode_seat_to(const GState& S, int pid, int lane, uint32
         for (int rel = 0; rel < NPP; rel++) {
             int q = (pid + rel) % NPP;
             int d = q == 0 ? dcount[0] : (q == 1 ? dcount[1] : (q == 2 ? dcount[2] : dcount[3]));
-            enc_bcast(buf, 55 + rel, (float)(d & 0xFF) / 12.0f, lane);
+            enc_bcast(buf, 55 + rel, enc_div<12, 255>(d & 0xFF), lane);
         }
     }
     // ch 70-73 stay 0: tsumogiri_flags is never filled (observation/mod.rs:105)

@@ -38,8 +38,10 @@ for grp in "FETCH_SIZE" "WRITE_SIZE" "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS S
   timeout 300 rocprofv3 --pmc $grp --output-format csv -d $R/gpurun_out/${TAG}_pmcenc_p$i -- python3 scripts/bench_encoders.py > $R/gpurun_out/${TAG}_pmcenc_p$i.log 2>&1
   echo "encoders pass $i ($grp) rc=$?"
 done
-python3 scripts/pmc_summary.py $R/gpurun_out ${TAG}_pmcenc "k_encode_base<false" 2 > $R/gpurun_out/${TAG}_pmc_k_encode_4p.json
-python3 scripts/pmc_summary.py $R/gpurun_out ${TAG}_pmcenc "k_encode_base<true" 5 > $R/gpurun_out/${TAG}_pmc_k_encode_3p.json
+python3 scripts/pmc_summary.py $R/gpurun_out ${TAG}_pmcenc "k_encode_base<false, false>" 2 > $R/gpurun_out/${TAG}_pmc_k_encode_4p.json
+python3 scripts/pmc_summary.py $R/gpurun_out ${TAG}_pmcenc "k_encode_base<true, false>" 5 > $R/gpurun_out/${TAG}_pmc_k_encode_3p.json
+python3 scripts/pmc_summary.py $R/gpurun_out ${TAG}_pmcenc "k_encode_base<false, true>" 2 > $R/gpurun_out/${TAG}_pmc_k_encode_compact_4p.json
+python3 scripts/pmc_summary.py $R/gpurun_out ${TAG}_pmcenc "k_encode_base<true, true>" 5 > $R/gpurun_out/${TAG}_pmc_k_encode_compact_3p.json
 python3 scripts/pmc_summary.py $R/gpurun_out ${TAG}_pmcenc "k_encode<false, true>" 2 > $R/gpurun_out/${TAG}_pmc_k_encode_ext_4p.json
 python3 scripts/pmc_summary.py $R/gpurun_out ${TAG}_pmcenc "k_encode<true, true>" 5 > $R/gpurun_out/${TAG}_pmc_k_encode_ext_3p.json
 rm -rf gpurun_out/${TAG}_pmc_p* gpurun_out/${TAG}_pmcenc_p*
@@ -51,6 +53,10 @@ if [ -f riichienv_amd/libriichi_mi355x_cuts.so ]; then
   rm -rf gpurun_out/${TAG}_cuts4
   python3 scripts/bail_census.py 2 2>/dev/null > gpurun_out/${TAG}_bail_census.txt
   python3 scripts/bail_census.py 5 2>/dev/null >> gpurun_out/${TAG}_bail_census.txt
+fi
+# timeline build: what a launch per step spends its time on
+if [ -f riichienv_amd/libriichi_mi355x_tl4.so ]; then
+  python3 scripts/timeline4.py 65536 2 2>/dev/null > gpurun_out/${TAG}_k_step4_launch_timeline.json
 fi
 python3 scripts/bench_torch_env.py 2>&1 | grep -v amdgpu > gpurun_out/${TAG}_torch_loop.txt
 python3 scripts/bench_torch_env.py 65536 ext 2>&1 | grep -v amdgpu >> gpurun_out/${TAG}_torch_loop.txt

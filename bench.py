@@ -159,6 +159,12 @@ def main(argv=None):
               f"torch.distributed.run with --nproc-per-node {args.gpus}", file=sys.stderr)
         return 2
 
+    # stdout carries exactly ONE line, the JSON of rank 0: everything libraries print on file descriptor 1 meanwhile (RCCL
+    # announces its library path there) goes to stderr; the descriptor comes back for the line itself
+    sys.stdout.flush()
+    saved_stdout = os.dup(1)
+    os.dup2(2, 1)
+
     import torch
 
     from riichienv_amd import abi, shard, vecenv
@@ -169,7 +175,7 @@ def main(argv=None):
               file=sys.stderr)
         return 3
     dist = None
-    if world > 1:
+    if world > 1 or os.environ.get("RMJ_BENCH_FORCE_DIST"):   # (the variable: exercise the RCCL path with one rank on a 1-GPU box)
         import torch.distributed as dist
 
         torch.cuda.set_device(local_rank)
@@ -282,7 +288,10 @@ def main(argv=None):
         out.update(extras)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.mode, abi.RULE_TENHOU, policy_seed)
-        print(json.dumps(out))
+        sys.stdout.flush()
+        os.dup2(saved_stdout, 1)
+        print(json.dumps(out), flush=True)
+        os.dup2(2, 1)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

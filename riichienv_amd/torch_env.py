@@ -93,6 +93,32 @@ class TorchVecEnv:
         self.sync()
         return self._obs
 
+    def obs_compact(self, capacity=None, sync_count=True):
+        """The batch a policy consumes: encode() of the acting seats only, dense, in (game, seat) order
+        (rmj_encode_compact_device).  Returns (obs [k, 74, W], index [k] int32 = game * 4 + seat); with sync_count=False the
+        full-capacity buffers and the device count tensor are returned instead (no host round trip: rows behind the count
+        hold old data).  capacity defaults to n + n // 2 rows and grows on demand."""
+        t = self.torch
+        if self.extended:
+            raise vecenv.RmjError("obs_compact() covers Observation.encode(); use obs() for encode_extended()")
+        cap = int(capacity or getattr(self, "_cap", 0) or (self.n + self.n // 2 + 1))
+        if getattr(self, "_cobs", None) is None or self._cobs.shape[0] < cap:
+            self._cobs = t.zeros((cap, 74, self.width), dtype=t.float32, device=self.device)
+            self._cidx = t.zeros((cap,), dtype=t.int32, device=self.device)
+            self._ccnt = t.zeros((1,), dtype=t.int32, device=self.device)
+            self._cap = cap
+            if not self.shared:
+                t.cuda.current_stream(self.device).synchronize()   # the buffers were zeroed on torch's stream
+        self.env.encode_compact_device(self._cobs.data_ptr(), self._cidx.data_ptr(), self._cap, self._ccnt.data_ptr())
+        self.sync()
+        if not sync_count:
+            return self._cobs, self._cidx, self._ccnt
+        k = int(self._ccnt.item())
+        if k > self._cap:                                          # more claimants than rows: grow once and encode again
+            self._cobs = None
+            return self.obs_compact(capacity=k + k // 8, sync_count=True)
+        return self._cobs[:k], self._cidx[:k]
+
     def scores(self):
         vecenv._chk(self.env.L.rmj_scores_device(self.env.h, C.c_void_p(self._scores.data_ptr()), None))
         self.sync()

@@ -50,6 +50,13 @@ def test_torch_env_matches_oracle(mode, shared):
             for g in (0, n - 1):
                 for s in range(3 if sanma else 4):
                     assert obs[g, s].tobytes() == games[g].encode(s, sanma).tobytes(), (step, g, s)
+            # the dense batch of the acting seats: same rows, (game, seat) order
+            cobs, cidx = env.obs_compact()
+            a2 = env.active().cpu().numpy()
+            assert cidx.cpu().numpy().tolist() == [g * 4 + s for g in range(n) for s in range(4) if a2[g, s]]
+            ch = cobs.cpu().numpy()
+            for j, gi in enumerate(cidx.cpu().numpy()):
+                assert ch[j].tobytes() == obs[int(gi) >> 2, int(gi) & 3].tobytes(), (step, int(gi))
     sc = env.scores().cpu().numpy()
     rk = env.ranks().cpu().numpy()
     for g, o in enumerate(games):

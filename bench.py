@@ -113,10 +113,10 @@ def cpu_baseline(game_mode, rule_bits, policy_seed, target_s=15.0):
 
 def pmc_traffic(kernel, games_per_launch, mode):
     """HBM bytes per launch of `kernel` from the newest committed rocprofv3 PMC summary that matches the launch shape
-    (profiles/r*_pmc_<kernel>*.json: FETCH_SIZE and WRITE_SIZE collected in separate --pmc runs of this same command,
+    (profiles/r*_pmc_<kernel>.json: FETCH_SIZE and WRITE_SIZE collected in separate --pmc runs of this same command,
     FETCH doubled per the gfx950 note of the microarch guide).  bench.py cannot run the profiler itself; null when no
     matching profile is committed."""
-    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", f"r*_pmc_{kernel}*.json")), reverse=True):
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", f"r*_pmc_{kernel}.json")), reverse=True):
         try:
             with open(path) as f:
                 d = json.load(f)
@@ -253,9 +253,11 @@ def main(argv=None):
             # bandwidth the chip delivers is in_flight launches' worth
             in_flight, kernel_ms = max(1, int(r.launches_in_flight)), r.step_kernel_ms
         games_per_launch = args.games // in_flight
-        traffic, traffic_src = pmc_traffic("k_step4", games_per_launch, args.mode)
+        # (the committed counter summary is of the fused rollout kernel, per step of all games; the per-step launches of the
+        #  feature rollout have no counter profile of their own)
+        traffic, traffic_src = (None, None) if args.encode else pmc_traffic("k_step4", games_per_launch, args.mode)
         if traffic is not None:
-            traffic *= steps_per_launch            # the committed summary is per step of all games
+            traffic *= steps_per_launch
         bytes_per_launch = b_step * games_per_launch * steps_per_launch
         achieved = in_flight * bytes_per_launch / (kernel_ms * 1e-3)
         out = {
@@ -271,7 +273,7 @@ def main(argv=None):
             "full_path_frac": full_steps / max(steps_local, 1.0),
             "roofline": {"bound": "hbm", "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK, "traffic": traffic, "traffic_unit": "bytes/launch",
-                         "traffic_source": traffic_src, "kernel": "k_step4" if not args.encode else "k_step",
+                         "traffic_source": traffic_src, "kernel": "k_step4<true>" if steps_per_launch > 1 else "k_step4<false>",
                          "kernel_ms": kernel_ms, "bytes_per_launch": bytes_per_launch, "bytes_per_game_step": b_step,
                          "games_per_launch": games_per_launch, "steps_per_launch": steps_per_launch,
                          "launches_in_flight": in_flight},
@@ -279,10 +281,10 @@ def main(argv=None):
         if "encode" in extras:
             acting, enc_ms = extras.pop("encode")
             b_obs = B_OBS_3P if sanma else B_OBS_4P
-            tr, tr_src = pmc_traffic("k_encode", args.games, args.mode)
+            tr, tr_src = pmc_traffic("k_encode_3p" if sanma else "k_encode_4p", args.games, args.mode)
             out["roofline_encode"] = {"bound": "hbm", "achieved": b_obs * acting / (enc_ms * 1e-3) / 1e9, "peak": HBM_PEAK / 1e9,
                                       "unit": "GB/s", "frac": b_obs * acting / (enc_ms * 1e-3) / HBM_PEAK, "traffic": tr,
-                                      "traffic_unit": "bytes/launch", "traffic_source": tr_src, "kernel": "k_encode",
+                                      "traffic_unit": "bytes/launch", "traffic_source": tr_src, "kernel": "k_encode_base",
                                       "kernel_ms": enc_ms, "bytes_per_launch": b_obs * acting, "acting_seats": acting,
                                       "bytes_per_observation": b_obs}
         out.update(extras)

@@ -51,6 +51,43 @@ def run(n, ext, shared, fused=False):
           f"loop {steps / (t1 - t0) / 1e6:.1f} M env.step/s, {(t1 - t0) / K * 1e3:.2f} ms per iteration{parts}")
 
 
+def run_parts(n, parts, compact=False):
+    """The same loop with the batch cut into `parts` environments (shards by game index) on `parts` torch streams: the store-bound
+    encoder of one part runs under the issue-bound step of another (what rmj_step_random_encode does inside the library)."""
+    per = n // parts
+    streams = [torch.cuda.Stream() for _ in range(parts)]
+    envs = []
+    for i, st in enumerate(streams):
+        with torch.cuda.stream(st):
+            envs.append(TorchVecEnv(per, game_mode=2, seed=0, share_stream=True, game_offset=i * per))
+    it = 0
+
+    def one_round():
+        nonlocal it
+        it += 1
+        for e, st in zip(envs, streams):
+            with torch.cuda.stream(st):
+                if compact:
+                    e.obs_compact(sync_count=False)
+                else:
+                    e.obs(only_active=True)
+                e.step(e.sample_ids(seed=it))
+
+    for _ in range(20):
+        one_round()
+    torch.cuda.synchronize()
+    steps0 = sum(e.env.total_steps() for e in envs)
+    K = 100
+    t0 = time.perf_counter()
+    for _ in range(K):
+        one_round()
+    torch.cuda.synchronize()
+    t1 = time.perf_counter()
+    steps = sum(e.env.total_steps() for e in envs) - steps0
+    print(f"games {n} as {parts} parts on {parts} streams, {'compact batch' if compact else '[n, 4] tensor'}, fused masked sampler: "
+          f"loop {steps / (t1 - t0) / 1e6:.1f} M env.step/s, {(t1 - t0) / K * 1e3:.2f} ms per iteration")
+
+
 def main():
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 65536
     ext = len(sys.argv) > 2 and sys.argv[2] == "ext"
@@ -58,6 +95,10 @@ def main():
     run(n, ext, True)
     run(n, ext, False, fused=True)
     run(n, ext, True, fused=True)
+    if not ext:
+        for parts in (2, 4):
+            run_parts(n, parts)
+        run_parts(n, 4, compact=True)
 
 
 if __name__ == "__main__":

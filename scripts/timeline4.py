@@ -31,10 +31,11 @@ def main():
     env.reset()
     env.step_random(0xC0FFEE, 600, auto_reset=True)
     env.step_random(0xC0FFEE, 1, auto_reset=True)
+    L.rmj_tl4_fetch(buf.ctypes.data_as(C.c_void_p), waves)       # (clears the rows the warm-up rollout wrote)
     n = 40
     sec = np.zeros(7)
     acc = {k: 0.0 for k in ("last_start", "last_end", "last_end_no_bail", "life", "life_bail_p50", "life_bail_p90", "life_bail_max",
-                            "life_other_p50", "life_other_max", "bail_waves", "multi_bail_waves")}
+                            "life_other_p50", "life_other_max", "bail_waves", "multi_bail_waves", "bail_rows")}
     alive = np.zeros(12)
     sites = {}
     for _ in range(n):
@@ -55,6 +56,7 @@ def main():
         acc["life_other_p50"] += p[0]; acc["life_other_max"] += p[1]
         acc["bail_waves"] += int(b.sum())
         acc["multi_bail_waves"] += int((buf[:, 7] > 1).sum())
+        acc["bail_rows"] += int(buf[:, 7].sum())
         edges = np.linspace(z, t1.max(), 13)
         for k in range(12):
             mid = 0.5 * (edges[k] + edges[k + 1])
@@ -64,8 +66,8 @@ def main():
             sites[int(s_)] = sites.get(int(s_), 0) + int(c_)
     out = {"waves_per_launch": waves, "launches": n,
            "sections_core_cycles_per_wave": {name: sec[k] / n for k, name in enumerate(NAMES)},
-           "us": {k: v / n for k, v in acc.items() if k not in ("bail_waves", "multi_bail_waves")},
-           "waves_with_a_full_path_game_per_launch": acc["bail_waves"] / n, "of_those_with_two_or_more": acc["multi_bail_waves"] / n,
+           "us": {k: v / n for k, v in acc.items() if k not in ("bail_waves", "multi_bail_waves", "bail_rows")},
+           "full_path_games_per_launch": acc["bail_rows"] / n, "waves_with_a_full_path_game_per_launch": acc["bail_waves"] / n, "of_those_with_two_or_more": acc["multi_bail_waves"] / n,
            "waves_alive_in_twelfths_of_the_launch": [h / n for h in alive],
            "full_path_games_per_launch_by_tier0_exit": {str(k): v / n for k, v in sorted(sites.items())}}
     r = env.bench_rollout(0xC0FFEE, 0, 200)

@@ -52,39 +52,30 @@ def run(n, ext, shared, fused=False):
 
 
 def run_parts(n, parts, compact=False):
-    """The same loop with the batch cut into `parts` environments (shards by game index) on `parts` torch streams: the store-bound
-    encoder of one part runs under the issue-bound step of another (what rmj_step_random_encode does inside the library)."""
-    per = n // parts
-    streams = [torch.cuda.Stream() for _ in range(parts)]
-    envs = []
-    for i, st in enumerate(streams):
-        with torch.cuda.stream(st):
-            envs.append(TorchVecEnv(per, game_mode=2, seed=0, share_stream=True, game_offset=i * per))
+    """The same loop on ShardedTorchVecEnv: the batch as `parts` shards (by game index) on `parts` torch streams - the store-bound
+    encoder of one shard runs under the issue-bound step of another (what rmj_step_random_encode does inside the library)."""
+    from riichienv_amd.torch_env import ShardedTorchVecEnv
+
+    env = ShardedTorchVecEnv(n, parts=parts, game_mode=2, seed=0)
     it = 0
 
     def one_round():
         nonlocal it
         it += 1
-        for e, st in zip(envs, streams):
-            with torch.cuda.stream(st):
-                if compact:
-                    e.obs_compact(sync_count=False)
-                else:
-                    e.obs(only_active=True)
-                e.step(e.sample_ids(seed=it))
+        env.step_policy(lambda e, *obs: e.sample_ids(seed=it), compact=compact)
 
     for _ in range(20):
         one_round()
     torch.cuda.synchronize()
-    steps0 = sum(e.env.total_steps() for e in envs)
+    steps0 = int(env.step_counts().sum())
     K = 100
     t0 = time.perf_counter()
     for _ in range(K):
         one_round()
     torch.cuda.synchronize()
     t1 = time.perf_counter()
-    steps = sum(e.env.total_steps() for e in envs) - steps0
-    print(f"games {n} as {parts} parts on {parts} streams, {'compact batch' if compact else '[n, 4] tensor'}, fused masked sampler: "
+    steps = int(env.step_counts().sum()) - steps0
+    print(f"games {n} as {parts} shards on {parts} streams, {'compact batch' if compact else '[n, 4] tensor'}, fused masked sampler: "
           f"loop {steps / (t1 - t0) / 1e6:.1f} M env.step/s, {(t1 - t0) / K * 1e3:.2f} ms per iteration")
 
 

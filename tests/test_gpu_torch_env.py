@@ -101,3 +101,24 @@ def test_fused_masked_sampler(mode):
     hist = torch.bincount(draws, minlength=82)[mask[k[0], k[1]]]
     c = int(cnt[k[0], k[1]])
     assert (hist > 0).all() and hist.max() < 3.0 * 600 / c and hist.min() > 600 / c / 3.5, (hist, c)
+
+
+def test_sharded_env_equals_one_env():
+    """Four shards on four torch streams end in the same games as one environment (seeds, walls and the sampler's noise are
+    keyed by the global game index)."""
+    torch = pytest.importorskip("torch")
+    from riichienv_amd.torch_env import ShardedTorchVecEnv, TorchVecEnv
+
+    n, seed, steps = 512, 4321, 300
+    one = TorchVecEnv(n, game_mode=2, seed=seed)
+    sh = ShardedTorchVecEnv(n, parts=4, game_mode=2, seed=seed)
+    for k in range(steps):
+        one.step(one.sample_ids(seed=k + 1))
+        sh.step_policy(lambda e, obs, index, count: e.sample_ids(seed=k + 1))
+    torch.cuda.synchronize()
+    assert (one.env.step_counts() == sh.step_counts()).all()
+    assert torch.equal(one.scores().cpu(), sh.scores().cpu())
+    assert int(one.env.step_counts().sum()) > n * steps // 2
+    # the dense batch of a shard indexes the shard's own games
+    obs, idx = sh.shards[1].obs_compact()
+    assert obs.shape[0] == idx.shape[0] and int(idx.max()) < sh.per * 4

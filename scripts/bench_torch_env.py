@@ -67,14 +67,15 @@ def run_parts(n, parts, compact=False):
     for _ in range(20):
         one_round()
     torch.cuda.synchronize()
-    steps0 = int(env.step_counts().sum())
+    env.synchronize()
+    steps0 = sum(e.env.total_steps() for e in env.shards)
     K = 100
     t0 = time.perf_counter()
     for _ in range(K):
         one_round()
     torch.cuda.synchronize()
     t1 = time.perf_counter()
-    steps = int(env.step_counts().sum()) - steps0
+    steps = sum(e.env.total_steps() for e in env.shards) - steps0
     print(f"games {n} as {parts} shards on {parts} streams, {'compact batch' if compact else '[n, 4] tensor'}, fused masked sampler: "
           f"loop {steps / (t1 - t0) / 1e6:.1f} M env.step/s, {(t1 - t0) / K * 1e3:.2f} ms per iteration")
 

@@ -268,3 +268,56 @@ def test_two_stream_rollout_equals_single_stream(mode):
         assert a.mjai_log(g) == b.mjai_log(g)
     r = a.bench_rollout(0xBEEF, 0, 10)
     assert r.launches == 1 and r.launches_in_flight == 1      # the fused rollout: one launch, every wave loops over the steps
+
+
+@pytest.mark.parametrize("mode", [2, 5])
+def test_noisy_host_actions_parity(mode):
+    """GameState::step validates what it is given (state/mod.rs:339-402): a seeded fraction of the host's actions is replaced
+    by actions the reference rejects or ignores - a discard of a tile the seat does not hold, another seat's legal action, a
+    Pass outside WaitResponse, an action from a seat that is not to act, a missing action - and every step (illegal-action
+    penalty rounds included) must leave device and oracle in the same state."""
+    from oracle import oracle
+    from riichienv_amd import vecenv
+
+    n, seed, pseed = 64, 31337 + mode, 99
+    npl = 3 if mode >= 3 else 4
+    env = vecenv.VecRiichiEnv(n, game_mode=mode, seed=seed, event_ring=8192)
+    games = [oracle.Game(game_mode=mode, seed=game_seed(seed, g)) for g in range(n)]
+    env.reset()
+    for o in games:
+        o.reset()
+    rng = np.random.default_rng(seed)
+    noisy = 0
+    for step in range(1, 900):
+        acts = np.array([games[g].random_actions(pseed, g) for g in range(n)], dtype=np.uint64)
+        for g in range(n):
+            oa, _, od = games[g].status()
+            if od or rng.random() > 0.02:
+                continue
+            s = int(rng.integers(npl))
+            kind = int(rng.integers(5))
+            if kind == 0:
+                acts[g, s] = abi.pack_action(abi.DISCARD, int(rng.integers(136)))
+            elif kind == 1:
+                other = [a for p in range(npl) if p != s for a in games[g].legal(p)]
+                if other:
+                    acts[g, s] = other[int(rng.integers(len(other)))]
+            elif kind == 2:
+                acts[g, s] = abi.pack_action(abi.PASS)
+            elif kind == 3:
+                acts[g, s] = abi.NO_ACTION
+            else:
+                acts[g, s] = abi.pack_action(abi.RIICHI, int(rng.integers(136)))
+            noisy += 1
+        env.step(acts)
+        for g in range(n):
+            if not games[g].status()[2]:
+                games[g].step([int(x) for x in acts[g]])
+        _compare(env, games, range(n), step, check_state=False)
+        _compare(env, games, [step % n, (step * 5) % n, (step * 11) % n], step, check_state=True)
+        if all(o.status()[2] for o in games):
+            break
+    assert noisy > 100
+    for g in range(n):
+        _compare(env, games, [g], 99999)
+        assert env.mjai_log(g) == games[g].log(), g

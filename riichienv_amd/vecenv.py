@@ -17,7 +17,7 @@ import numpy as np
 from . import abi
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libriichi_mi355x.so")
+LIB_PATH = os.environ.get("RMJ_LIB_PATH") or os.path.join(_HERE, "libriichi_mi355x.so")   # (the variable: experiment builds)
 _LIB = None
 
 # every symbol include/riichi_mi355x.h declares

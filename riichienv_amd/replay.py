@@ -6,7 +6,8 @@ log is applied with rmj_apply_events (= RiichiEnv.apply_event), and whenever the
 decision the acting seat's legal list, mask, feature tensor and the action it took (select_action_from_mjai,
 observation/mjai_select.rs:88-194, encoded as the 82- / 60-way id) are emitted - the (obs, action) pairs of
 behaviour-cloning / offline-RL datasets.  This is the event-stream semantics of apply_event (tile names map to one id
-per name, no wall); it is not a restatement of the reference's MjSoul-style replay pipeline (LogAction / grp_features).
+per name, no wall).  The host-side kyoku API of both log formats lives here as well: MjaiReplay / MjSoulReplay -> Kyoku
+(events, grp_features) -> WinResultContextIterator -> evaluate_win_contexts (all wins in one rmj_eval_hands launch).
 """
 from __future__ import annotations
 
@@ -134,7 +135,7 @@ class Kyoku:
 
     def events(self):
         """LogKyoku.events (replay/mod.rs:1294-1500): NewRound followed by one entry per action"""
-        head = {"name": "NewRound", "data": dict(scores=list(self.scores), doras=list(self.doras), dora_marker=self.doras[0],
+        head = {"name": "NewRound", "data": dict(scores=list(self.scores), doras=list(self.doras), dora_marker=self.doras[0] if self.doras else None,
                                                   chang=self.chang, ju=self.ju, ben=self.ben, liqibang=self.liqibang,
                                                   left_tile_count=self.left_tile_count,
                                                   **{f"tiles{i}": list(h) for i, h in enumerate(self.hands)})}
@@ -210,6 +211,30 @@ def _match_and_remove(hand, target):
     return False
 
 
+_MS_HONORS = "ESWNPFC"
+
+
+def mjsoul_tile_to_mjai(t):
+    """MjSoul tile string -> MJAI name, by TileConverter::parse_tile (replay/mod.rs:2184-2202): digit + suit, 0 = red five,
+    z1..z7 = E S W N P F C; malformed strings fall back to the reference's defaults (number 0 -> red five, suit -> 1m)."""
+    if not t:
+        return "1m"
+    d, su = t[0], t[1:]
+    num = int(d) if d.isdigit() else 0
+    red = num == 0
+    num = 5 if red else num
+    if su == "z":
+        return _MS_HONORS[num - 1] if 1 <= num <= 7 else "1m"
+    if su not in ("m", "p", "s"):
+        return "1m"
+    return f"{num}{su}" + ("r" if red else "")
+
+
+def _parse_paishan(s):
+    """parse_paishan (replay/mod.rs:1627-1637): two characters per tile, draw order"""
+    return [abi.mjai_to_tid(mjsoul_tile_to_mjai(s[i:i + 2]), True) for i in range(0, len(s) - 1, 2)]
+
+
 class WinResultContextIterator:
     """WinResultContextIterator (replay/mod.rs:1593-2094) over one Kyoku built from an MJAI log: walks the round's actions,
     keeps the seats' hands / melds / riichi, ippatsu, rinshan and first-turn flags, the dora indicators and the tile
@@ -233,13 +258,45 @@ class WinResultContextIterator:
         self.first = [True] * 4
         self.was_kakan, self.kakan_tile, self.was_babei = False, None, False
         self.ippatsu_before_babei = [False] * 4
-        self.doras = [abi.mjai_to_tid(kyoku.doras[0], True)]     # kyoku.doras grows with the dora events: start from the header's
-        self.left = 55 if n == 3 else 70
+        if getattr(kyoku, "source", "mjai") == "mjsoul":
+            self.doras = [abi.mjai_to_tid(t, True) for t in kyoku.doras]          # current_doras = kyoku.doras (replay/mod.rs:1663)
+            self.left = kyoku.left_tile_count                                       # the header's count (default 70, :443)
+        else:
+            self.doras = [abi.mjai_to_tid(kyoku.doras[0], True)]  # an MJAI kyoku's doras grow with its dora events: start from the header's
+            self.left = 55 if n == 3 else 70
         self.kita = [0] * 4
         self.ankan_from_consumed = ankan_from_consumed
+        # wall-dependent bookkeeping (replay/mod.rs:1634-1724): MjSoul records may carry the wall (`paishan`)
+        self.wall = _parse_paishan(kyoku.paishan) if getattr(kyoku, "paishan", None) else []
+        self.dora_count = 1
+        self.pending_minkan_doras = 0
 
     def __iter__(self):
         return self
+
+    def _recalc_doras(self):      # replay/mod.rs:1673-1690: indicator i of the wall sits at len - 5 - 2i
+        if not self.wall:
+            return
+        n = len(self.wall)
+        self.doras = [self.wall[n - 5 - 2 * i] for i in range(self.dora_count) if n >= 5 + 2 * i]
+
+    def _sync_doras_with_wall(self):   # replay/mod.rs:1692-1708
+        if not self.wall:
+            return
+        if len(self.doras) > self.dora_count:      # the log shows more indicators: trust it
+            self.dora_count = len(self.doras)
+            self.pending_minkan_doras = 0
+        elif self.dora_count > len(self.doras):
+            self._recalc_doras()
+
+    def _ura_from_wall(self):          # replay/mod.rs:1710-1724
+        n = len(self.wall)
+        return [self.wall[n - 6 - 2 * i] for i in range(self.dora_count) if n >= 6 + 2 * i]
+
+    def _flush_pending_doras(self):
+        if self.pending_minkan_doras > 0:
+            self.dora_count += self.pending_minkan_doras
+            self.pending_minkan_doras = 0
 
     def _after_kakan_reset(self):
         if self.was_kakan:
@@ -271,12 +328,22 @@ class WinResultContextIterator:
                     self.ippatsu[seat] = False
                 self.first[seat] = False
                 _match_and_remove(self.hands[seat], abi.mjai_to_tid(a["tile"], True))
+                if a.get("doras") is not None:
+                    self.doras = [abi.mjai_to_tid(t, True) for t in a["doras"]]
+                self._flush_pending_doras()          # a discard reveals the pending kan indicators
+                self._sync_doras_with_wall()
             elif name == "DealTile":
                 seat = a["seat"]
                 self._after_kakan_reset()
                 self.hands[seat].append(abi.mjai_to_tid(a["tile"], True))
-                if self.left > 0:
+                if a.get("left_tile_count") is not None:
+                    self.left = a["left_tile_count"]
+                elif self.left > 0:
                     self.left -= 1
+                if a.get("doras") is not None:       # a draw that shows indicators is a replacement draw
+                    self.doras = [abi.mjai_to_tid(t, True) for t in a["doras"]]
+                    self.rinshan[seat] = True
+                self._sync_doras_with_wall()
             elif name == "ChiPengGang":
                 seat = a["seat"]
                 self.rinshan = [False] * 4
@@ -294,12 +361,21 @@ class WinResultContextIterator:
                                              called_tile=called))
                 if a["meld_type"] == "Daiminkan":
                     self.rinshan[seat] = True
+                    self._flush_pending_doras()
+                    self.pending_minkan_doras += 1
             elif name == "Dora":
-                self.doras.append(abi.mjai_to_tid(a["dora_marker"], True))     # no wall: replay/mod.rs:1869-1871
+                if not self.wall:
+                    self.doras.append(abi.mjai_to_tid(a["dora_marker"], True))     # no wall: replay/mod.rs:1869-1871
+                else:
+                    self.dora_count += 1
+                    if self.pending_minkan_doras > 0:
+                        self.pending_minkan_doras -= 1
+                    self._sync_doras_with_wall()
             elif name == "AnGangAddGang":
                 seat = a["seat"]
                 self.rinshan = [False] * 4
                 tl = [abi.mjai_to_tid(t, True) for t in a["tiles"]]
+                self._flush_pending_doras()          # a new kan flushes the indicators pending from an earlier open kan
                 if a["meld_type"] == "Ankan":
                     self.ippatsu = [False] * 4
                     self.first = [False] * 4
@@ -314,7 +390,10 @@ class WinResultContextIterator:
                     self.melds[seat].append(dict(meld_type=abi.MELD_ANKAN, tiles=[t34 * 4 + i for i in range(4)], opened=False,
                                                  from_who=-1, called_tile=None))
                     self.rinshan[seat] = True
+                    if self.wall:
+                        self.dora_count += 1         # a concealed kan shows its indicator at once
                 else:
+                    self.pending_minkan_doras += 1   # an added kan shows it after the discard
                     self.was_kakan, self.kakan_tile = True, tl[0]
                     self.rinshan[seat] = True
                     for m in self.melds[seat]:
@@ -325,6 +404,7 @@ class WinResultContextIterator:
                     else:
                         self.melds[seat].append(dict(meld_type=abi.MELD_KAKAN, tiles=tl, opened=True, from_who=-1, called_tile=None))
                     _match_and_remove(self.hands[seat], tl[0])
+                self._sync_doras_with_wall()
             elif name == "BaBei":
                 seat = a["seat"]
                 self.ippatsu_before_babei = list(self.ippatsu)
@@ -352,11 +432,17 @@ class WinResultContextIterator:
                                 kita_count=self.kita[seat])
                     if not zimo:
                         hand.append(win)
-                    ura = list(h["li_doras"]) if (self.liqi[seat] and h.get("li_doras") is not None) else \
-                        ([abi.mjai_to_tid(t, True) for t in self.k.ura_doras] if self.liqi[seat] else [])
+                    if not self.liqi[seat]:
+                        ura = []
+                    elif h.get("li_doras") is not None:
+                        ura = list(h["li_doras"])
+                    elif self.wall:
+                        ura = self._ura_from_wall()
+                    else:
+                        ura = [abi.mjai_to_tid(t, True) for t in self.k.ura_doras]
                     self.pending.append(WinResultContext(seat=seat, tiles=hand, melds=[dict(m) for m in self.melds[seat]],
                                                          agari_tile=win, dora_indicators=list(self.doras), ura_indicators=ura,
-                                                         conditions=cond, expected_yaku=[], expected_han=h.get("count", 0),
+                                                         conditions=cond, expected_yaku=list(h.get("fans", [])), expected_han=h.get("count", 0),
                                                          expected_fu=h.get("fu", 0), actual=None, sanma=self.n == 3))
                 if self.pending:
                     return self.pending.pop(0)
@@ -493,3 +579,158 @@ class ReplayBatch:
                        "action_id": np.array([self._encode_id(d[2]) for d in dec], dtype=np.int64),
                        "mask": mask[gs, ss][:, :nmask].copy(), "obs": enc[gs, ss].copy()}
             self.env.apply_events([l[k] if k < len(l) else None for l in self.logs], masked_ok=self.masked_ok)
+
+
+class MjSoulReplay:
+    """MjSoulReplay (replay/mjsoul_replay.rs:20-688): Mahjong Soul records - per round a list of `{"name": ..., "data": ...}`
+    actions starting with NewRound - as the same Kyoku objects MjaiReplay yields (tile names are translated to MJAI names, the
+    action vocabulary is the reference's own, replay/mod.rs:35-80).  The reference ships no MjSoul record; the reader follows
+    the serde schema of mjsoul_replay.rs (field aliases, defaults, `#[serde(other)]`) and is tested on records converted from
+    games the oracle played (tests/test_mjsoul_replay.py).  Not built: from_dict's game_end_scores, which the reference gets
+    by replaying the last round through GameState.apply_log_action."""
+
+    _MELD = {0: "Chi", 1: "Pon", 2: "Daiminkan", 3: "Ankan"}
+
+    def __init__(self, rounds):
+        self.rounds = rounds
+
+    @classmethod
+    def from_json(cls, path):
+        """mjsoul_replay.rs:168-194: a gzip file holding {"rounds": [[action, ...], ...]} (plain JSON is accepted as well)"""
+        try:
+            with open(path, "rb") as f:
+                raw = f.read()
+        except OSError as e:
+            raise ValueError(f"Failed to open file: {e}")
+        if raw[:2] == b"\x1f\x8b":
+            raw = gzip.decompress(raw)
+        try:
+            log = json.loads(raw)
+        except ValueError as e:
+            raise ValueError(f"Failed to parse JSON: {e}")
+        return cls._from_rounds(log["rounds"])
+
+    @classmethod
+    def from_dict(cls, paifu):
+        """mjsoul_replay.rs:196-240: a paifu dict {"data": rounds, ...} or the list of rounds itself"""
+        if isinstance(paifu, dict):
+            if "data" not in paifu:
+                raise ValueError("Invalid dict format: missing 'data'")
+            return cls._from_rounds(paifu["data"])
+        if isinstance(paifu, list):
+            return cls._from_rounds(paifu)
+        raise ValueError("Invalid input format: expected dict or list")
+
+    @classmethod
+    def _from_rounds(cls, rounds_raw):
+        rounds = [cls._kyoku_from_raw_actions(r) for r in rounds_raw]
+        for i in range(len(rounds) - 1):           # the next round's start scores (mjsoul_replay.rs:189-191)
+            rounds[i].end_scores = list(rounds[i + 1].scores)
+        return cls(rounds)
+
+    @classmethod
+    def _kyoku_from_raw_actions(cls, raw):        # mjsoul_replay.rs:440-561
+        k = Kyoku.__new__(Kyoku)
+        k.source = "mjsoul"
+        k.mjai_events = []
+        k.scores, k.doras, k.ura_doras, k.hands = [], [], [], [[] for _ in range(4)]
+        k.chang = k.ju = k.ben = k.liqibang = 0
+        k.left_tile_count, k.paishan = 70, None
+        head = raw[0] if raw else None
+        if head is not None and head.get("name") == "NewRound":
+            d = head.get("data", {})
+            k.scores = list(d["scores"])
+            da = d.get("dora_indicators") if d.get("dora_indicators") is not None else d.get("doras")
+            if da is not None:
+                k.doras = [mjsoul_tile_to_mjai(t) for t in da]
+            elif d.get("dora_marker") is not None:
+                k.doras = [mjsoul_tile_to_mjai(d["dora_marker"])]
+            k.hands = [[mjsoul_tile_to_mjai(t) for t in d[f"tiles{i}"]] for i in range(4)]
+            k.chang, k.ju = int(d["chang"]), int(d["ju"])
+            k.ben = int(d["ben"] if d.get("ben") is not None else (d.get("honba") or 0))
+            k.liqibang = int(d["liqibang"])
+            k.left_tile_count = int(d["left_tile_count"]) if d.get("left_tile_count") is not None else 70
+            if d.get("ura_doras") is not None:
+                k.ura_doras = [mjsoul_tile_to_mjai(t) for t in d["ura_doras"]]
+            k.paishan = d.get("paishan")
+        # (the reference keeps four hand vectors whatever the player count; Kyoku keeps one per score like MjaiReplay)
+        k.hands = k.hands[: len(k.scores)] if k.scores else k.hands
+        k.end_scores = list(k.scores)
+        k.actions = [a for a in (cls._parse_raw_action(x) for x in raw) if a is not None]
+        k.wliqi = [False] * max(len(k.scores), 0)
+        for a in k.actions:
+            if a["name"] == "DiscardTile" and a["is_wliqi"] and a["seat"] < len(k.wliqi):
+                k.wliqi[a["seat"]] = True
+        k._pending_hule = []
+        return k
+
+    @classmethod
+    def _parse_raw_action(cls, x):                # mjsoul_replay.rs:563-687
+        name, d = x.get("name"), x.get("data", {}) or {}
+        tiles = lambda v: [mjsoul_tile_to_mjai(t) for t in v]   # noqa: E731
+        if name == "NewRound":
+            return {"name": "Other"}
+        if name == "DiscardTile":
+            return {"name": "DiscardTile", "seat": d["seat"], "tile": mjsoul_tile_to_mjai(d["tile"]), "is_liqi": bool(d.get("is_liqi", False)),
+                    "is_wliqi": bool(d.get("is_wliqi", False)), "doras": tiles(d["doras"]) if d.get("doras") else None}
+        if name == "DealTile":
+            doras = tiles(d["doras"]) if d.get("doras") else None
+            if doras is None and d.get("dora_marker") is not None:
+                doras = [mjsoul_tile_to_mjai(d["dora_marker"])]
+            return {"name": "DealTile", "seat": d["seat"], "tile": mjsoul_tile_to_mjai(d["tile"]), "doras": doras,
+                    "left_tile_count": d.get("left_tile_count")}
+        if name == "ChiPengGang":
+            return {"name": "ChiPengGang", "seat": d["seat"], "meld_type": cls._MELD.get(d["type"], "Chi"), "tiles": tiles(d["tiles"]),
+                    "froms": list(d["froms"])}
+        if name == "AnGangAddGang":
+            return {"name": "AnGangAddGang", "seat": d["seat"], "meld_type": "Ankan" if d["type"] == 3 else "Kakan",
+                    "tiles": [mjsoul_tile_to_mjai(d["tiles"])]}
+        if name == "Hule":
+            hs = []
+            for h in d["hules"]:
+                li = h.get("ura_dora_indicators") if h.get("ura_dora_indicators") is not None else h.get("li_doras")
+                hs.append({"seat": h["seat"], "hu_tile": abi.mjai_to_tid(mjsoul_tile_to_mjai(h["hu_tile"]), True), "zimo": bool(h["zimo"]),
+                           "count": h["count"], "fu": h["fu"], "fans": [f["id"] for f in h["fans"] if f.get("val", 0) > 0],
+                           "li_doras": None if li is None else [abi.mjai_to_tid(mjsoul_tile_to_mjai(t), True) for t in li],
+                           "yiman": bool(h["yiman"]), "point_rong": h["point_rong"], "point_zimo_qin": h["point_zimo_qin"],
+                           "point_zimo_xian": h["point_zimo_xian"]})
+            return {"name": "Hule", "hules": hs}
+        if name == "dora":
+            return {"name": "Dora", "dora_marker": mjsoul_tile_to_mjai(d["dora_marker"])}
+        if name == "NoTile":
+            return {"name": "NoTile"}
+        if name == "BaBei":
+            return {"name": "BaBei", "seat": d["seat"], "moqie": bool(d.get("moqie", False))}
+        if name == "LiuJu":
+            return {"name": "LiuJu", "lj_type": d.get("type", 0), "seat": d.get("seat", 0), "tiles": tiles(d.get("tiles", []))}
+        return {"name": "Other"}
+
+    def num_rounds(self):
+        return len(self.rounds)
+
+    def take_kyokus(self):
+        return iter(self.rounds)
+
+    def verify(self, evaluate=None):
+        """mjsoul_replay.rs:255-436: evaluate every win of every round and compare with what the record expects - the yaku
+        sets without the dora kinds (31, 32, 33), han (yakuman counts normalised) and fu.  `evaluate` maps a list of
+        WinResultContexts to evaluated contexts (default: one rmj_eval_hands launch).  Returns (wins, mismatches)."""
+        ctxs = [c for k in self.rounds for c in k.take_win_result_contexts()]
+        ctxs = (evaluate or evaluate_win_contexts)(ctxs)
+        ignored, yakuman_ids = {31, 32, 33}, set(range(35, 51))
+        bad = 0
+        for c in ctxs:
+            sim = list(c.actual.yaku[: c.actual.n_yaku])
+            exp = list(c.expected_yaku)
+            exp_han = c.expected_han * 13 if (any(y in yakuman_ids for y in exp) and c.expected_han < 13) else c.expected_han
+            mismatch = sorted(y for y in sim if y not in ignored) != sorted(y for y in exp if y not in ignored)
+            if not mismatch:
+                sim_ign, exp_ign = sum(y in ignored for y in sim), sum(y in ignored for y in exp)
+                if exp_han < 13 and c.actual.han != exp_han - exp_ign + sim_ign:
+                    mismatch = c.actual.han != exp_han
+                elif (c.actual.han >= 13) != (exp_han >= 13):
+                    mismatch = True
+                if not mismatch and exp_han < 13 and c.actual.fu != c.expected_fu:
+                    mismatch = True
+            bad += mismatch
+        return len(ctxs), bad

@@ -85,3 +85,23 @@ def test_win_contexts_of_the_real_log_evaluated_in_one_gpu_batch(tmp_path):
     (k,) = list(MjaiReplay.from_jsonl(str(p)).take_kyokus())
     (c,) = evaluate_win_contexts(k.take_win_result_contexts())
     assert c.actual.is_win and 3 in list(c.actual.yaku[: c.actual.n_yaku])   # chankan
+
+
+def test_mjsoul_records_verified_in_one_gpu_batch():
+    """MjSoulReplay.verify with its default evaluator (all wins of all rounds in ONE rmj_eval_hands launch): records converted
+    from two oracle-played games carry the oracle's han / fu / yaku as expectations; the GPU must confirm every one."""
+    from oracle import oracle
+    from riichienv_amd.replay import MjSoulReplay
+    from tests.mjsoul_util import play_logged_game, to_mjsoul_rounds
+
+    total = 0
+    for mode, seed in ((2, 1), (5, 3)):
+        events, walls = play_logged_game(mode, seed)
+        plain = MjSoulReplay.from_dict(to_mjsoul_rounds(events, walls))
+        ctxs = [c for k in plain.take_kyokus() for c in k.take_win_result_contexts()]
+        res = oracle.eval_hands([c.hand_case() for c in ctxs])
+        exp = {i: dict(count=r.han, fu=r.fu, fans=list(r.yaku[: r.n_yaku])) for i, r in enumerate(res)}
+        n, bad = MjSoulReplay.from_dict(to_mjsoul_rounds(events, walls, expectations=exp)).verify()
+        assert n == len(ctxs) and bad == 0, (mode, seed, n, bad)
+        total += n
+    assert total >= 4

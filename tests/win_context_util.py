@@ -35,8 +35,9 @@ def check_points(k, c, hora, actual):
             assert -d[i] == pay + 100 * k.ben, (k.chang, k.ju, i, d, pay)
     else:
         tgt = hora["target"]
-        assert -d[tgt] == actual.ron_agari + 300 * k.ben, (k.chang, k.ju, d, actual.ron_agari)
-        assert d[c.seat] >= actual.ron_agari + 300 * k.ben     # + riichi deposits
+        hb = 100 * (len(d) - 1) * k.ben          # 300 per honba with four players, 200 with three
+        assert -d[tgt] == actual.ron_agari + hb, (k.chang, k.ju, d, actual.ron_agari)
+        assert d[c.seat] >= actual.ron_agari + hb     # + riichi deposits
     assert bool(hora.get("ura_markers")) == bool(c.ura_indicators) or not c.conditions["riichi"]
 
 

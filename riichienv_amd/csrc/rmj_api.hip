@@ -470,12 +470,42 @@ __global__ __launch_bounds__(64) RMJ_ENC_OCC void k_encode_base(Env E, int only_
         wave_sync();
     }
 }
-template <bool SANMA, bool EXT>
-__global__ __launch_bounds__(64) void k_encode(Env E, int only_active, const float* __restrict__ decay, float* __restrict__ out) {
+// n floats computed per element into 16-byte stores (4-byte aligned dst: up to three floats before the first boundary)
+template <class F>
+__device__ __forceinline__ void enc_emit_fn(float* dst, int n_floats, int lane, F f) {
+    int head = (int)(((16u - (uint32_t)(reinterpret_cast<uintptr_t>(dst) & 15u)) & 15u) >> 2);
+    if (head > n_floats) head = n_floats;
+    const int body = (n_floats - head) >> 2, tail0 = head + 4 * body;
+    if (lane < head) dst[lane] = f(lane);
+    float4* d4 = reinterpret_cast<float4*>(dst + head);
+    for (int i = lane; i < body; i += 64) {
+        const int e = head + 4 * i;
+        d4[i] = make_float4(f(e), f(e + 1), f(e + 2), f(e + 3));
+    }
+    if (lane < n_floats - tail0) dst[tail0 + lane] = f(tail0 + lane);
+}
+// encode_extended() of every (game, seat): one wave per seat.  The 215 x W tensor leaves in three groups that share one
+// staging area of bytes: the 74 base channels (EncByteSink), the extended scalars (four per-column channels as floats and a
+// table of the 53 channels that are one value per row) and the 84 meld-overview channels (a 0/1 pattern).  6 KB of LDS per
+// block instead of 12 KB: the kernel waits on table lookups (the ukeire walk), and its duration is inversely proportional to
+// the resident waves (measured by capping them: 13 / 8 / 5 / 3 blocks per CU -> 1.05 / 1.63 / 2.24 / 3.67 ms).
+#ifndef RMJ_ENCX_WAVES
+#define RMJ_ENCX_WAVES 0
+#endif
+#if RMJ_ENCX_WAVES > 0
+#define RMJ_ENCX_OCC __attribute__((amdgpu_waves_per_eu(RMJ_ENCX_WAVES, RMJ_ENCX_WAVES)))
+#else
+#define RMJ_ENCX_OCC
+#endif
+template <bool SANMA>
+__global__ __launch_bounds__(64) RMJ_ENCX_OCC void k_encode_ext(Env E, int only_active, const float* __restrict__ decay, float* __restrict__ out) {
     constexpr int W = SANMA ? ENC_W3 : ENC_W4;
-    constexpr int CH = EXT ? ENC_EXT_CH : ENC_CH;
+    constexpr int CH = ENC_EXT_CH;
     __shared__ GState st;
-    __shared__ __attribute__((aligned(16))) float buf[ENC_EXT_C_SLOTS * W];
+    __shared__ __attribute__((aligned(16))) uint8_t raw[(ENC_EXT_C_SLOTS * W + 4 + 15) / 16 * 16];
+    __shared__ float lut[ENC_LUT];
+    __shared__ float tab[ENC_EXT_B_SLOTS];
+    __shared__ float col4[4 * W];
     __shared__ uint32_t hist[ENC_HIST_WORDS];
     const int lane = threadIdx.x & 63;
     const uint32_t g = blockIdx.x >> 2;
@@ -491,23 +521,36 @@ __global__ __launch_bounds__(64) void k_encode(Env E, int only_active, const flo
         }
     }
     if (lane < (int)(sizeof(GState) / 16)) reinterpret_cast<uint4*>(&st)[lane] = reinterpret_cast<const uint4*>(E.core + g)[lane];
+    enc_lut_init(lut, lane);
     wave_sync();
     const GState& S = st;
     if (seat >= (SANMA ? 3 : 4)) {
         for (int i = lane; i < CH * W; i += 64) dst[i] = 0.0f;
         return;
     }
-    encode_seat<SANMA>(S, seat, buf, lane, hist);
-    enc_stream_out<W>(dst, buf, ENC_CH * W, lane);
-    if (EXT) {
+    auto head_of = [](const float* p) { return (int)(((16u - (uint32_t)(reinterpret_cast<uintptr_t>(p) & 15u)) & 15u) >> 2); };
+    {   // channels 0..73
+        const int head = head_of(dst);
+        EncByteSink<W> o{raw + ((4 - head) & 3), lut, lane, -1.0f};
+        encode_seat_to<SANMA>(S, seat, lane, hist, o, true);
+        enc_emit_bytes<W>(dst, o.cells, lut, lane, head);
         wave_sync();
+    }
+    {   // channels 74..93 and 178..214
         const int n_legal = (((S.active_mask >> seat) & 1u) && !S.is_done) ? (int)E.nlegal[(size_t)g * 4 + seat] : 0;
-        encode_ext_scalars<SANMA>(S, seat, buf, lane, E.sh, decay, E.legal + ((size_t)g * 4 + seat) * RMJ_MAX_LEGAL, n_legal);
-        enc_stream_out<W>(dst + 74 * W, buf, 20 * W, lane);
-        enc_stream_out<W>(dst + 178 * W, buf + 20 * W, 37 * W, lane);
+        encode_ext_scalars<SANMA>(S, seat, tab, col4, lane, E.sh, decay, E.legal + ((size_t)g * 4 + seat) * RMJ_MAX_LEGAL, n_legal);
+        enc_emit_fn(dst + 74 * W, 20 * W, lane, [&](int e) { return e < 4 * W ? col4[e] : tab[e / W]; });
+        enc_emit_fn(dst + 178 * W, 37 * W, lane, [&](int e) { return tab[20 + e / W]; });
         wave_sync();
-        encode_ext_melds<SANMA>(S, seat, buf, lane);
-        enc_stream_out<W>(dst + 94 * W, buf, ENC_EXT_C_SLOTS * W, lane);
+    }
+    {   // channels 94..177
+        float* d = dst + 94 * W;
+        const int head = head_of(d);
+        uint8_t* cells = raw + ((4 - head) & 3);
+        for (int i = lane; i < (int)sizeof(raw) / 16; i += 64) reinterpret_cast<uint4*>(raw)[i] = make_uint4(0u, 0u, 0u, 0u);
+        wave_sync();
+        encode_ext_melds<SANMA>(S, seat, cells, lane);
+        enc_emit_bytes<W, ENC_EXT_C_SLOTS>(d, cells, lut, lane, head);
     }
 }
 
@@ -1594,8 +1637,8 @@ static int launch_encode(rmj_handle h, int only_active, float* d_out, bool ext) 
     const dim3 grid(h->cfg.n_games * 4), block(64);
     const float* decay = h->d_decay;
     const bool sanma = h->cfg.game_mode >= 3;
-    if (sanma && ext) hipLaunchKernelGGL((k_encode<true, true>), grid, block, 0, h->stream, h->d, only_active, decay, d_out);
-    else if (ext) hipLaunchKernelGGL((k_encode<false, true>), grid, block, 0, h->stream, h->d, only_active, decay, d_out);
+    if (sanma && ext) hipLaunchKernelGGL((k_encode_ext<true>), grid, block, 0, h->stream, h->d, only_active, decay, d_out);
+    else if (ext) hipLaunchKernelGGL((k_encode_ext<false>), grid, block, 0, h->stream, h->d, only_active, decay, d_out);
     else launch_encode_base_range(h, h->stream, only_active, d_out, 0u, h->cfg.n_games);
     HIPCHK(hipGetLastError());
     return RMJ_OK;

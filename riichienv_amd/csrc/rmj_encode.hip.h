@@ -130,11 +130,11 @@ struct EncByteSink {
 __device__ __forceinline__ void enc_lut_init(float* lut, int lane) {
     for (int i = lane; i < ENC_LUT; i += 64) lut[i] = i < 2 ? (float)i : (i >= 40 ? (float)(i - 40) * 0.25f : 0.0f);
 }
-// 74 x W floats of one seat from the byte-staged form, in 16-byte stores (`dst` is 8-byte aligned like in enc_stream_out16:
-// `head` = 0 or 2 floats precede the first 16-byte boundary; the cells are laid out so that cells + head is dword aligned)
-template <int W>
+// NCH x W floats from the byte-staged form, in 16-byte stores: `head` = 0..3 floats precede the first 16-byte boundary of the
+// (4-byte aligned) `dst`; the cells are laid out so that cells + head is dword aligned
+template <int W, int NCH = ENC_CH>
 __device__ __forceinline__ void enc_emit_bytes(float* dst, const uint8_t* cells, const float* lut, int lane, int head) {
-    constexpr int N = ENC_CH * W;
+    constexpr int N = NCH * W;
     const int body = (N - head) >> 2, tail0 = head + 4 * body;
     if (lane < head) dst[lane] = lut[cells[lane]];
     float4* d4 = reinterpret_cast<float4*>(dst + head);
@@ -312,16 +312,19 @@ __device__ inline void encode_seat(const GState& S, int pid, float* buf, int lan
 #define ENC_EXT_C_SLOTS 84
 __device__ __forceinline__ int enc_ext_b_slot(int ch) { return ch < 94 ? ch - 74 : ch - 178 + 20; }
 template <bool SANMA>
-__device__ inline void encode_ext_scalars(const GState& S, int pid, float* buf, int lane, const ShantenTables& T, const float* decay,
+__device__ inline void encode_ext_scalars(const GState& S, int pid, float* tab, float* col4, int lane, const ShantenTables& T, const float* decay,
                                           const uint64_t* legal, int n_legal) {
     constexpr int ENC_W = SANMA ? ENC_W3 : ENC_W4;
     constexpr int NPP = SANMA ? 3 : 4;
     const PState& P = S.p[pid];
     const int my34 = SANMA ? (lane == 0 ? 0 : lane + 7) : lane;  // tile type of this lane's column
+    // group B is four per-column channels (74..77 -> col4[4][W]) and 53 channels that hold one value in every column
+    // (-> tab[slot], wave-uniform calls): 0.8 KB instead of 57 x W floats
     auto bc = [&](int ch, float v) {
-        if (lane < ENC_W) buf[enc_ext_b_slot(ch) * ENC_W + lane] = v;
+        if (lane == 0) tab[enc_ext_b_slot(ch)] = v;
     };
-    for (int i = lane; i < ENC_EXT_B_SLOTS * ENC_W; i += 64) buf[i] = 0.0f;
+    if (lane < ENC_EXT_B_SLOTS) tab[lane] = 0.0f;
+    for (int i = lane; i < 4 * ENC_W; i += 64) col4[i] = 0.0f;
     wave_sync();
     // 74..77 discard history decay: lane = column, discards visited in turn order
     for (int c = 0; c < NPP; c++) {
@@ -331,7 +334,7 @@ __device__ inline void encode_ext_scalars(const GState& S, int pid, float* buf, 
             float acc = 0.0f;
             for (int turn = 0; turn < n; turn++)
                 if ((Q.discards[turn] >> 2) == my34) acc += decay[n - 1 - turn];
-            buf[enc_ext_b_slot(74 + c) * ENC_W + lane] = acc;
+            col4[c * ENC_W + lane] = acc;
         }
     }
     // hand / visible histograms: lane = tile type (34 lanes, also in 3P)
@@ -456,11 +459,10 @@ __device__ inline void encode_ext_scalars(const GState& S, int pid, float* buf, 
 }
 
 template <bool SANMA>
-__device__ inline void encode_ext_melds(const GState& S, int pid, float* buf, int lane) {
+__device__ inline void encode_ext_melds(const GState& S, int pid, uint8_t* cells, int lane) {
+    // group C (94..177) is a 0/1 pattern: one byte per cell (cell e of the group at cells[e]; the caller zeroed them)
     constexpr int ENC_W = SANMA ? ENC_W3 : ENC_W4;
     constexpr int NPP = SANMA ? 3 : 4;
-    for (int i = lane; i < ENC_EXT_C_SLOTS * ENC_W; i += 64) buf[i] = 0.0f;
-    wave_sync();
     // 94..97 ankan overview, 98..177 fuuro overview: lane = 16*rel + 4*meld + slot
     {
         const int c = lane >> 4, mi = (lane >> 2) & 3, sl = lane & 3;
@@ -472,9 +474,9 @@ __device__ inline void encode_ext_melds(const GState& S, int pid, float* buf, in
                     const int tile = Q.meld_tiles[mi][sl];
                     const int col = enc_col<SANMA>(tile >> 2);
                     if (col >= 0) {
-                        buf[(4 + c * 20 + mi * 5 + sl) * ENC_W + col] = 1.0f;
-                        if (is_aka(tile)) buf[(4 + c * 20 + mi * 5 + 4) * ENC_W + col] = 1.0f;
-                        if (sl == 0 && Q.meld_type[mi] == RMJ_MELD_ANKAN) buf[c * ENC_W + col] = 1.0f;
+                        cells[(4 + c * 20 + mi * 5 + sl) * ENC_W + col] = 1;
+                        if (is_aka(tile)) cells[(4 + c * 20 + mi * 5 + 4) * ENC_W + col] = 1;
+                        if (sl == 0 && Q.meld_type[mi] == RMJ_MELD_ANKAN) cells[c * ENC_W + col] = 1;
                     }
                 }
             }

@@ -42,8 +42,8 @@ python3 scripts/pmc_summary.py $R/gpurun_out ${TAG}_pmcenc "k_encode_base<false,
 python3 scripts/pmc_summary.py $R/gpurun_out ${TAG}_pmcenc "k_encode_base<true, false>" 5 > $R/gpurun_out/${TAG}_pmc_k_encode_3p.json
 python3 scripts/pmc_summary.py $R/gpurun_out ${TAG}_pmcenc "k_encode_base<false, true>" 2 > $R/gpurun_out/${TAG}_pmc_k_encode_compact_4p.json
 python3 scripts/pmc_summary.py $R/gpurun_out ${TAG}_pmcenc "k_encode_base<true, true>" 5 > $R/gpurun_out/${TAG}_pmc_k_encode_compact_3p.json
-python3 scripts/pmc_summary.py $R/gpurun_out ${TAG}_pmcenc "k_encode<false, true>" 2 > $R/gpurun_out/${TAG}_pmc_k_encode_ext_4p.json
-python3 scripts/pmc_summary.py $R/gpurun_out ${TAG}_pmcenc "k_encode<true, true>" 5 > $R/gpurun_out/${TAG}_pmc_k_encode_ext_3p.json
+python3 scripts/pmc_summary.py $R/gpurun_out ${TAG}_pmcenc "k_encode_ext<false>" 2 > $R/gpurun_out/${TAG}_pmc_k_encode_ext_4p.json
+python3 scripts/pmc_summary.py $R/gpurun_out ${TAG}_pmcenc "k_encode_ext<true>" 5 > $R/gpurun_out/${TAG}_pmc_k_encode_ext_3p.json
 rm -rf gpurun_out/${TAG}_pmc_p* gpurun_out/${TAG}_pmcenc_p*
 # accounting build: sections of one step (per-step launches of k_step4<false>) and the bail census
 if [ -f riichienv_amd/libriichi_mi355x_cuts.so ]; then

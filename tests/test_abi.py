@@ -64,3 +64,38 @@ def test_no_cpu_fallback():
         vecenv.eval_hands([abi.HandCase()])
     src = open(os.path.join(ROOT, "riichienv_amd", "vecenv.py")).read()
     assert "oracle" not in src.replace("oracle/oracle.py", "")
+
+
+def _build_c_example(tmp_path):
+    import subprocess
+
+    exe = tmp_path / "rollout"
+    lib_dir = os.path.join(ROOT, "riichienv_amd")
+    cmd = ["gcc", "-O2", "-Wall", "-Werror", "-I" + os.path.join(ROOT, "include"), os.path.join(ROOT, "examples", "rollout.c"), "-o", str(exe),
+           "-L" + lib_dir, "-l:libriichi_mi355x.so", "-Wl,-rpath," + lib_dir]
+    subprocess.check_call(cmd)
+    return str(exe)
+
+
+def test_plain_c_program_links_against_the_boundary_and_fails_loudly_without_a_gpu(tmp_path):
+    """examples/rollout.c sees nothing but include/riichi_mi355x.h (C, not C++): it must compile warning-free with gcc, link
+    against the shared library, and - in this container, without a GPU - stop at rmj_create with the library's error text
+    instead of computing anything on the CPU."""
+    import subprocess
+
+    import torch
+
+    exe = _build_c_example(tmp_path)
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present: covered by the gpu test")
+    p = subprocess.run([exe], capture_output=True, text=True)
+    assert p.returncode == 1 and "no HIP device" in p.stderr and "0 device(s)" in p.stdout
+
+
+@pytest.mark.gpu
+def test_plain_c_program_runs_a_rollout(tmp_path):
+    import subprocess
+
+    p = subprocess.run([_build_c_example(tmp_path)], capture_output=True, text=True)
+    assert p.returncode == 0, p.stderr
+    assert "env.step calls advanced a game" in p.stdout and '"type"' in p.stdout

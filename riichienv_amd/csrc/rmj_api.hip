@@ -2058,13 +2058,13 @@ int rmj_tl4_fetch(uint64_t* out, uint32_t n_waves) {
     HIPCHK(hipDeviceSynchronize());
     if (!buf) {
         cap = n_waves;
-        HIPCHK(hipMalloc(&buf, (size_t)cap * 16 * 8));
-        HIPCHK(hipMemset(buf, 0, (size_t)cap * 16 * 8));
+        HIPCHK(hipMalloc(&buf, (size_t)cap * RMJ_TL4_ROW * 8));
+        HIPCHK(hipMemset(buf, 0, (size_t)cap * RMJ_TL4_ROW * 8));
         HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(rmj::g_tl4), &buf, sizeof(buf)));
         return RMJ_OK;
     }
-    HIPCHK(hipMemcpy(out, buf, (size_t)(n_waves < cap ? n_waves : cap) * 16 * 8, hipMemcpyDeviceToHost));
-    HIPCHK(hipMemset(buf, 0, (size_t)cap * 16 * 8));   // blocks that leave at once (heavy-first order) write nothing
+    HIPCHK(hipMemcpy(out, buf, (size_t)(n_waves < cap ? n_waves : cap) * RMJ_TL4_ROW * 8, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemset(buf, 0, (size_t)cap * RMJ_TL4_ROW * 8));   // blocks that leave at once (heavy-first order) write nothing
     HIPCHK(hipDeviceSynchronize());
     return RMJ_OK;
 }

@@ -54,12 +54,21 @@ struct WaveScratch {      // per-wave LDS scratch
     uint64_t tprev;                    // section timer (profiling build only, scripts/prof_sections.py)
     uint32_t pacc[64];
 #endif
+#ifdef RMJ_TL4
+    uint64_t tl_prev;                  // timeline build: cycles between the marks of the full path (TLF), per wave
+    uint32_t tl_acc[16];
+#endif
 };
 
 // Timeline build of k_step4 (-DRMJ_TL4, scripts/timeline4.py, never the shipped library): every wave of a launch owns a row of
-// 16 u64: core cycles between the outer marks of the step [0..6], start / end on the 100 MHz clock [8], [9]
+// 32 u64: core cycles between the outer marks of the step [0..6], start / end on the 100 MHz clock [8], [9]
 #ifdef RMJ_TL4
 __device__ unsigned long long* g_tl4;
+#define RMJ_TL4_ROW 32   /* u64 per wave: [0..15] as above, [16..31] cycles between the marks of the full path (TLF) */
+#define TLF(c, k) do { const uint64_t t__ = __builtin_readcyclecounter(); \
+        if ((c).lane == 0) { (c).X.tl_acc[k] += (uint32_t)(t__ - (c).X.tl_prev); (c).X.tl_prev = t__; } } while (0)
+#else
+#define TLF(c, k) do {} while (0)
 #endif
 // Section timing of the step kernel (profiling build only: -DRMJ_PROFILE, never the shipped library): wave cycles
 // between consecutive PROF marks are accumulated per section id by lane 0.

@@ -705,6 +705,7 @@ __device__ __forceinline__ void gen_act_legal(Ctx& c, int pid) {
         }
     }
     PROF(c.X, lane, 9);
+    TLF(c, 8);
     const PH full = build_ph_wave(P, lane);  // shared by the riichi probe and the kan checks
     // 2. Discard / Riichi
     uint8_t ht = lane < hl ? P.hand[lane] : 0xFF;
@@ -733,6 +734,7 @@ __device__ __forceinline__ void gen_act_legal(Ctx& c, int pid) {
         if (riichi_pre && tp != 0u) put_legal(c, pid, n++, mk_action(RMJ_RIICHI, RMJ_TILE_NONE, 0));
     }
     PROF(c.X, lane, 10);
+    TLF(c, 14);
     // 3. Kan
     if (drawable > 0 && drawn) {
         if (!r_decl && !r_stage) {
@@ -800,6 +802,7 @@ __device__ __forceinline__ void gen_act_legal(Ctx& c, int pid) {
         }
     }
     PROF(c.X, lane, 11);
+    TLF(c, 15);
     // 4. Kyushu kyuhai
     if (first_turn && !r_stage && U((int)(S.p[0].n_melds | S.p[1].n_melds | S.p[2].n_melds | S.p[3].n_melds)) == 0) {
         uint64_t tm = 0;
@@ -893,6 +896,7 @@ __device__ __forceinline__ void deal_next(Ctx& c) {
     const int drawable = U((int)S.drawable_count);
     if (drawable == 0) {
         if (FAST) { c.bail = true; return; }
+        TLF(c, 1);     // everything of the step before the exhaustive draw (discard, claims)
         trigger_ryukyoku(c, RMJ_RK_EXHAUSTIVE, 0);
         return;
     }
@@ -1060,6 +1064,7 @@ __device__ inline void init_round(Ctx& c, int oya, int round_wind, int honba, ui
     }
     S.live_end = (uint8_t)(total - 13 * np);
     S.drawable_count = (uint8_t)(S.live_end - 14);
+    TLF(c, 6);         // record reset, wall to HBM, deal, four sorts
     if (!c.E.skip_log) {
         RmjEvent e = ev_zero(RMJ_EV_START_KYOKU);
         e.actor = (uint8_t)oya;
@@ -1082,6 +1087,7 @@ __device__ inline void init_round(Ctx& c, int oya, int round_wind, int honba, ui
             emit_raw(c, t);
         }
     }
+    TLF(c, 7);         // start_kyoku + tehai events
     S.current_player = (uint8_t)oya;
     S.phase = RMJ_WAIT_ACT;
     S.active_mask = (uint8_t)(1u << oya);
@@ -1137,8 +1143,11 @@ __device__ __noinline__ void ol_init_next_round(CtxV v, bool oya_won, bool is_dr
     if (end) { process_end_game(c); return; }
     emit_simple(c, RMJ_EV_END_KYOKU);
     uint32_t sticks = S.riichi_sticks;
+    TLF(c, 4);         // next-round decision + end_kyoku
     shuffle_wall(c);
+    TLF(c, 5);
     init_round(c, next_oya, next_rw, next_honba, sticks, sc);
+    TLF(c, 9);
 }
 
 // tenpai of a seat at exhaustive draw: HandEvaluator::is_tenpai (hand_evaluator.rs:178-194)
@@ -1158,6 +1167,7 @@ __device__ __noinline__ void ol_trigger_ryukyoku(CtxV v, int reason, int offende
     uint32_t nagashi = 0;
     if (reason == RMJ_RK_EXHAUSTIVE) {
         for (int i = 0; i < np; i++) tenpai[i] = seat_tenpai(c, i);
+        TLF(c, 2);     // accept_riichi + the seats' tenpai
         for (int i = 0; i < np; i++)
             if (S.p[i].flags & PF_NAGASHI) nagashi |= 1u << i;
         if (nagashi) {
@@ -1213,6 +1223,7 @@ __device__ __noinline__ void ol_trigger_ryukyoku(CtxV v, int reason, int offende
         for (int i = 0; i < np; i++) e.deltas[i] = S.p[i].score_delta;
         emit_raw(c, e);
     }
+    TLF(c, 3);         // payments + ryukyoku event
     init_next_round(c, renchan, true);
 }
 
@@ -2249,6 +2260,7 @@ __device__ __forceinline__ void finalize_outputs(Ctx& c, bool claims_fresh, bool
     }
     wave_sync();
     PROF(c.X, lane, 13);
+    TLF(c, 10);        // (finalize) the acting seat's list
     // masks + list publication (only the seats that act have a list; a step usually has one).  Mask rows of seats that
     // are not to act are all zero and stay so: only the rows of the seats that had a list before this step (S.nlegal
     // still holds the previous publication) or have one now are rewritten - 82 B per row in 16-bit units.

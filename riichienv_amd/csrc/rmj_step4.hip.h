@@ -26,14 +26,14 @@ namespace RMJ_NS {
 #else
 #define R4M(id) do {} while (0)
 #ifdef RMJ_TL4
-#define R4BAIL(q, id) do { (q).bail = true; if ((q).r == 0) rmj::g_tl4[(size_t)blockIdx.x * 16 + 10 + (q).row] = (unsigned long long)(id) + 1ull; } while (0)
+#define R4BAIL(q, id) do { (q).bail = true; if ((q).r == 0) rmj::g_tl4[(size_t)blockIdx.x * RMJ_TL4_ROW + 10 + (q).row] = (unsigned long long)(id) + 1ull; } while (0)
 #else
 #define R4BAIL(q, id) do { (q).bail = true; } while (0)
 #endif
 #endif
 #ifdef RMJ_TL4   /* timeline build (scripts/timeline4.py): core cycles between the outer marks of step4_body, summed over the waves */
 #define R4T(k) do { const uint64_t t__ = __builtin_readcyclecounter(); \
-        if ((threadIdx.x & 63) == 0) rmj::g_tl4[(size_t)blockIdx.x * 16 + (k)] = (unsigned long long)(t__ - tl_prev); tl_prev = t__; } while (0)
+        if ((threadIdx.x & 63) == 0) rmj::g_tl4[(size_t)blockIdx.x * RMJ_TL4_ROW + (k)] = (unsigned long long)(t__ - tl_prev); tl_prev = t__; } while (0)
 #else
 #define R4T(k) do {} while (0)
 #endif
@@ -1143,7 +1143,7 @@ __device__ __forceinline__ void step4_body(const Env* Ep, Quad4Shared& sh, uint6
     // ---- bailed games: the complete state machine, one game at a time, from the untouched HBM record
     uint64_t bm = __ballot(q.live && q.bail && r == 0);
 #ifdef RMJ_TL4
-    if (!LOOP && lane == 0) rmj::g_tl4[(size_t)blockIdx.x * 16 + 7] = (unsigned long long)__popcll(bm);
+    if (!LOOP && lane == 0) rmj::g_tl4[(size_t)blockIdx.x * RMJ_TL4_ROW + 7] = (unsigned long long)__popcll(bm);
 #endif
     while (bm) {
         const int br = (__ffsll((long long)bm) - 1) >> 4;
@@ -1152,8 +1152,17 @@ __device__ __forceinline__ void step4_body(const Env* Ep, Quad4Shared& sh, uint6
         // the seats' actions of that game move to lanes 0..3
         const uint64_t m_full = rbc64(mine, 16 * br + (lane & 3));
         Ctx c{sh.st[br], E, sh.u.x, gg, lane, E.wall + (size_t)gg * RMJ_WALL_STRIDE, E.legal + (size_t)gg * 4 * RMJ_MAX_LEGAL};
+#ifdef RMJ_TL4
+        if (lane < 16) sh.u.x.tl_acc[lane] = 0u;
+        if (lane == 0) sh.u.x.tl_prev = __builtin_readcyclecounter();
+        wave_sync();
+#endif
         ol_step_full(ctx_pack(c), lane < 4 ? m_full : RMJ_NO_ACTION, flags);
         wave_sync();
+#ifdef RMJ_TL4
+        if (!LOOP && lane < 16) rmj::g_tl4[(size_t)blockIdx.x * RMJ_TL4_ROW + 16 + lane] += (unsigned long long)sh.u.x.tl_acc[lane];
+        wave_sync();
+#endif
     }
     R4T(6);
     if (LOOP) {
@@ -1198,8 +1207,8 @@ __global__ __launch_bounds__(64, RMJ_STEP4_WAVES) void k_step4(const Env* __rest
 #ifdef RMJ_TL4
         const unsigned long long rt1 = __builtin_amdgcn_s_memrealtime();
         if ((threadIdx.x & 63) == 0) {
-            rmj::g_tl4[(size_t)blockIdx.x * 16 + 8] = rt0;
-            rmj::g_tl4[(size_t)blockIdx.x * 16 + 9] = rt1;
+            rmj::g_tl4[(size_t)blockIdx.x * RMJ_TL4_ROW + 8] = rt0;
+            rmj::g_tl4[(size_t)blockIdx.x * RMJ_TL4_ROW + 9] = rt1;
         }
 #endif
     }

@@ -15,6 +15,9 @@ sys.path.insert(0, ROOT)
 from riichienv_amd import vecenv  # noqa: E402
 
 vecenv.LIB_PATH = os.path.join(ROOT, "riichienv_amd", "libriichi_mi355x_tl4.so")
+FULL = ["load record", "step up to the exhaustive draw (discard, claims)", "accept_riichi + tenpai of the seats", "payments + ryukyoku event",
+        "next-round decision + end_kyoku", "wall shuffle", "round reset, wall to HBM, deal, four sorts", "start_kyoku + tehai events", "list: waits + tsumo check",
+        "first draw", "list: kyushu / kita + rest", "(step_game returns)", "masks, lists, status", "record store", "list: discards + riichi probe", "list: kans"]
 NAMES = ["load records", "policy", "apply + claims", "drawer's list", "publication", "record store", "bailed games (full path)"]
 
 
@@ -25,7 +28,7 @@ def main():
     os.environ["RMJ_STEP_STREAMS"] = "1"
     L = vecenv.load_lib()
     waves = (games + 3) // 4
-    buf = np.zeros((waves, 16), dtype=np.uint64)
+    buf = np.zeros((waves, 32), dtype=np.uint64)
     L.rmj_tl4_fetch(buf.ctypes.data_as(C.c_void_p), waves)       # allocates the rows before any kernel runs
     env = vecenv.VecRiichiEnv(games, game_mode=mode, seed=0)
     env.reset()
@@ -38,6 +41,8 @@ def main():
                             "life_other_p50", "life_other_max", "bail_waves", "multi_bail_waves", "bail_rows")}
     alive = np.zeros(12)
     sites = {}
+    fsec = np.zeros(16)
+    fgames = 0
     for _ in range(n):
         env.step_random(0xC0FFEE, 1, auto_reset=True)
         L.rmj_tl4_fetch(buf.ctypes.data_as(C.c_void_p), waves)
@@ -61,6 +66,9 @@ def main():
         for k in range(12):
             mid = 0.5 * (edges[k] + edges[k + 1])
             alive[k] += ((t0 <= mid) & (t1 > mid)).sum()
+        ex = (buf[:, 10:14] == 8).any(axis=1) & (buf[:, 7] == 1)      # waves whose ONE full-path game was an exhaustive draw (site 7)
+        fsec += buf[ex, 16:32].astype(np.float64).sum(axis=0)
+        fgames += int(ex.sum())
         why = buf[:, 10:14].astype(np.int64).ravel()
         for s_, c_ in zip(*np.unique(why[why > 0] - 1, return_counts=True)):
             sites[int(s_)] = sites.get(int(s_), 0) + int(c_)
@@ -69,7 +77,9 @@ def main():
            "us": {k: v / n for k, v in acc.items() if k not in ("bail_waves", "multi_bail_waves", "bail_rows")},
            "full_path_games_per_launch": acc["bail_rows"] / n, "waves_with_a_full_path_game_per_launch": acc["bail_waves"] / n, "of_those_with_two_or_more": acc["multi_bail_waves"] / n,
            "waves_alive_in_twelfths_of_the_launch": [h / n for h in alive],
-           "full_path_games_per_launch_by_tier0_exit": {str(k): v / n for k, v in sorted(sites.items())}}
+           "full_path_games_per_launch_by_tier0_exit": {str(k): v / n for k, v in sorted(sites.items())},
+           "full_path_of_an_exhaustive_draw_core_cycles": {name: fsec[k] / max(fgames, 1) for k, name in enumerate(FULL)},
+           "exhaustive_draw_games_sampled": fgames}
     r = env.bench_rollout(0xC0FFEE, 0, 200)
     out["instrumented_kernel_ms"] = r.step_kernel_ms
     print(json.dumps(out, indent=1))

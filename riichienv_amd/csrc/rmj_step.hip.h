@@ -1621,6 +1621,7 @@ __device__ __noinline__ uint32_t ol_wait_act_other(CtxV v, int pid, uint64_t act
                 if (r.is_win && ((r.ym >> 42) & 1ull || (r.ym >> 49) & 1ull)) {
                     ronners |= 1u << i;
                     offer_ron(c, i, tile);
+                    c.X.wout[i] = seat_waits(c, i);   // the observation of the offered seat carries its waits (like the kakan branch)
                 }
             }
         }
@@ -2244,6 +2245,13 @@ __device__ __forceinline__ void finalize_outputs(Ctx& c, bool claims_fresh, bool
         for (int p = 0; p < 4; p++) { c.X.nl[p] = 0; c.X.wout[p] = 0; }
         gen_act_legal<FAST>(c, U((int)S.current_player));
         if (FAST && c.bail) return;
+        if (!FAST) {
+            // a poked state may list seats as active that are not the current player (tests/test_riichi_autoplay.py sets
+            // current_player without active_players): their observation has no actions but still carries their waits
+            const uint32_t others = U((uint32_t)S.active_mask) & ~(1u << U((int)S.current_player)) & 0xFu;
+            for (int p = 0; p < 4; p++)
+                if ((others >> p) & 1u) c.X.wout[p] = seat_waits(c, p);
+        }
     } else if (!claims_fresh) {
         // WaitResponse that was not produced in this launch (e.g. after rmj_poke_state): rebuild claims
         if (S.pending_kan_pid == 0xFF && S.last_discard_pid != 0xFF) {

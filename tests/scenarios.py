@@ -427,6 +427,259 @@ def sc_pao_mjsoul_composite_tsumo(make):
     assert hora["deltas"] == [64000, -16000, -8000, -40000]
 
 
+def _poke_pao_case(make, hands, melds, pao, current_player, drawn_tile, riichi_sticks=0):
+    """The state the tests of tests/env/test_majsoul_pao_scoring.py build with the reference's setters after
+    RiichiEnv(seed=1, rule=default_mjsoul, game_mode="4p-red-single").reset(): oya 0, 25000 each, hands / melds / pao of the
+    named seats replaced as given (hands stay in the given order, the drawn tile is NOT added to the hand), WaitAct for
+    `current_player`.  pao: {winner: (field, liable seat)} with field "pao_daisangen" (yaku 37) or "pao_daisuushi" (yaku 50)."""
+    env = make(game_mode=0, seed=1, rule_bits=abi.RULE_MJSOUL)
+    env.reset()
+    v = env.peek()
+    v.oya = 0
+    for p in range(4):
+        v.players[p].score = 25000
+    for p, h in hands.items():
+        v.players[p].hand_len = len(h)
+        for i, t in enumerate(h):
+            v.players[p].hand[i] = t
+    for p, ms in melds.items():
+        v.players[p].n_melds = len(ms)
+        for i, (mt, mtiles, frm) in enumerate(ms):
+            set_meld(v.players[p].melds[i], mt, mtiles, True, frm, -1)
+    for p, (field, liable) in pao.items():
+        setattr(v.players[p], field, liable)
+    v.riichi_sticks = riichi_sticks
+    v.current_player = current_player
+    v.active_mask = 1 << current_player
+    v.drawn_tile = drawn_tile
+    v.needs_tsumo = 0
+    v.phase = WAIT_ACT
+    env.poke(v)
+    return env
+
+
+def _deltas(env):
+    v = env.peek()
+    return [v.players[p].score_delta for p in range(4)]
+
+
+def sc_mjsoul_pao_tsumo_composite(make):
+    """tests/env/test_majsoul_pao_scoring.py:5-83: dealer tsumo daisangen (pao by seat 2) + tsuuiisou under MjSoul rules: the
+    liable seat pays the daisangen unit (48000) plus its normal share of the other yakuman (16000)."""
+    env = _poke_pao_case(make, {0: [128, 129, 130, 132, 133, 134, 108, 109, 110, 112]}, {0: [(PON_M, [124, 125, 126], 1)]},
+                         {0: ("pao_daisangen", 2)}, 0, 113)
+    env.step({0: pack_action(TSUMO)})
+    assert env.win_results()[0]["yakuman"]
+    assert _deltas(env) == [96000, -16000, -64000, -16000]
+
+
+def sc_mjsoul_pao_ron_composite(make):
+    """tests/env/test_majsoul_pao_scoring.py:85-169: daisuushi (double, pao by seat 2) + tsuuiisou, Ron from seat 1: only the
+    pao portion (96000) is split, the discarder pays 144000 - 48000."""
+    melds0 = [(PON_M, [108, 109, 110], 1), (PON_M, [112, 113, 114], 1), (PON_M, [116, 117, 118], 1)]
+    env = _poke_pao_case(make, {0: [120, 121, 124, 124], 1: [122, 1, 2, 3, 5, 6, 7, 8, 9, 10, 11, 12, 13]}, {0: melds0},
+                         {0: ("pao_daisuushi", 2)}, 1, 122)
+    env.step({1: pack_action(DISCARD, 122)})
+    assert env.status()[1] == WAIT_RESPONSE
+    env.step({0: pack_action(RON, 122)})
+    assert _deltas(env) == [144000, -96000, -48000, 0]
+
+
+def sc_mjsoul_pao_ron_single(make):
+    """tests/env/test_majsoul_pao_scoring.py:171-241: a single yakuman with pao, Ron: split 50/50 like Tenhou."""
+    melds0 = [(PON_M, [128, 129, 130], 1), (PON_M, [132, 133, 134], 1), (PON_M, [124, 125, 126], 1)]
+    env = _poke_pao_case(make, {0: [0, 1, 4, 4], 1: [4, 1, 2, 3, 5, 6, 7, 8, 9, 10, 11, 12, 13]}, {0: melds0},
+                         {0: ("pao_daisangen", 2)}, 1, 4)
+    env.step({1: pack_action(DISCARD, 4)})
+    assert env.status()[1] == WAIT_RESPONSE
+    env.step({0: pack_action(RON, 4)})
+    assert _deltas(env) == [48000, -24000, -24000, 0]
+
+
+def _mjsoul_real_record(make, sticks):
+    melds2 = [(PON_M, [124, 125, 126], 3), (PON_M, [116, 117, 118], 1), (PON_M, [128, 129, 130], 1), (PON_M, [132, 133, 134], 3)]
+    env = _poke_pao_case(make, {2: [112], 0: [113, 1, 2, 3, 5, 6, 7, 8, 9, 10, 11, 12, 13]}, {2: melds2}, {2: ("pao_daisangen", 3)}, 0, 113,
+                         riichi_sticks=sticks)
+    env.step({0: pack_action(DISCARD, 113)})
+    assert env.status()[1] == WAIT_RESPONSE
+    env.step({2: pack_action(RON, 113)})
+    return env
+
+
+def sc_mjsoul_pao_ron_real_record(make):
+    """tests/env/test_majsoul_pao_scoring.py:243-315 (MjSoul game 251122-9051f1e9, round 11): ko Ron, daisangen (pao by seat 3) +
+    tsuuiisou = 64000: the pao portion 32000 is halved, the discarder pays 48000."""
+    assert _deltas(_mjsoul_real_record(make, 0)) == [-48000, 0, 64000, -16000]
+
+
+def sc_mjsoul_pao_ron_real_record_with_riichi_stick(make):
+    """tests/env/test_majsoul_pao_scoring.py:317-372: the same with one riichi stick on the table: the winner collects it."""
+    assert _deltas(_mjsoul_real_record(make, 1)) == [-48000, 0, 65000, -16000]
+
+
+def _kokushi_ankan_state(make, rule_bits):
+    """setup_kokushi_scenario (tests/env/test_rules_chankan.py:4-45): on the constructor's first round (no reset), seat 0 holds
+    four 9p (the fourth just drawn) + ten low tiles, seat 1 a kokushi tenpai waiting on 9p, seats 2 and 3 empty hands."""
+    env = make(rule_bits=rule_bits)
+    v = env.peek()
+    _set_hand(v.players[0], sorted([68, 69, 70] + list(range(10)) + [71]))
+    _set_hand(v.players[1], sorted(t * 4 for t in [0, 8, 9, 18, 26, 27, 28, 29, 30, 31, 32, 33] + [0]))
+    _set_hand(v.players[2], [])
+    _set_hand(v.players[3], [])
+    v.current_player = 0
+    v.active_mask = 1
+    v.drawn_tile = 71
+    v.phase = WAIT_ACT
+    v.needs_tsumo = 0
+    env.poke(v)
+    return env
+
+
+def sc_rules_chankan_kokushi_tenhou(make):
+    """tests/env/test_rules_chankan.py:48-66: Tenhou rules: an Ankan cannot be robbed, not even by kokushi: the game goes on with
+    seat 0's replacement draw.  (The action names another copy of the quad than the generated one: accepted, quirk Q13.)"""
+    env = _kokushi_ankan_state(make, abi.RULE_TENHOU)
+    env.step({0: pack_action(ANKAN, 71, [68, 69, 70, 71])})
+    v = env.peek()
+    assert v.current_player == 0 and v.phase == WAIT_ACT and v.drawn_tile >= 0
+
+
+def sc_rules_chankan_kokushi_mjsoul(make):
+    """tests/env/test_rules_chankan.py:69-90: MjSoul rules: kokushi may rob the Ankan: WaitResponse, seat 1 is offered Ron on 71."""
+    env = _kokushi_ankan_state(make, abi.RULE_MJSOUL)
+    env.step({0: pack_action(ANKAN, 71, [68, 69, 70, 71])})
+    act, ph, _ = env.status()
+    assert ph == WAIT_RESPONSE and (act >> 1) & 1
+    ron = [a for a in env.legal(1) if unpack_action(a)[0] == RON]
+    assert ron and unpack_action(ron[0])[1] == 71
+
+
+def sc_rules_standard_chankan_kakan(make):
+    """tests/env/test_rules_chankan.py:93-170: the ordinary chankan (Ron on an added kan) works under Tenhou rules as well."""
+    env = make(rule_bits=abi.RULE_TENHOU)
+    v = env.peek()
+    _set_hand(v.players[0], sorted(list(range(10)) + [71]))
+    v.players[0].n_melds = 1
+    set_meld(v.players[0].melds[0], PON_M, [68, 69, 70], True, -1, -1)
+    p1 = []
+    for t in (0, 4, 8):
+        p1 += [t * 4, t * 4 + 1, t * 4 + 2]
+    _set_hand(v.players[1], sorted(p1 + [48, 49, 60, 64]))
+    _set_hand(v.players[2], [])
+    _set_hand(v.players[3], [])
+    v.current_player = 0
+    v.active_mask = 1
+    v.drawn_tile = 71
+    v.phase = WAIT_ACT
+    v.needs_tsumo = 0
+    env.poke(v)
+    env.step({0: pack_action(KAKAN, 71, [68, 69, 70])})
+    act, ph, _ = env.status()
+    assert ph == WAIT_RESPONSE and (act >> 1) & 1
+    ron = [a for a in env.legal(1) if unpack_action(a)[0] == RON]
+    assert ron and unpack_action(ron[0])[1] == 71
+
+
+def sc_game_modes_initialization_params(make):
+    """tests/env/test_game_modes.py:9-32: reset(scores, kyotaku, honba) of a 4p-red-single game shows in the state and in the
+    start_kyoku event."""
+    env = make(game_mode=0, round_wind=0)
+    env.reset(scores=[30000] * 4, kyotaku=1, honba=2)
+    v = env.peek()
+    assert [v.players[p].score for p in range(4)] == [30000] * 4 and v.riichi_sticks == 1
+    sk = evs(env)[1]
+    assert sk["type"] == "start_kyoku" and sk["bakaze"] == "E" and sk["honba"] == 2 and sk["kyotaku"] == 1
+
+
+def sc_game_modes_south_round_wind(make):
+    """tests/env/test_game_modes.py:34-43: round_wind=1 -> bakaze S"""
+    env = make(game_mode=0, round_wind=1)
+    env.reset(round_wind=1)
+    assert evs(env)[1]["bakaze"] == "S"
+
+
+def sc_riichi_setup_leaves_only_discards(make):
+    """tests/env/actions/test_riichi_autoplay_pass.py:14-44: after the Riichi declaration the seat's list holds discards only,
+    among them the drawn 5p and the 1z (every discard is listed, also those of a false riichi)."""
+    env = setup(make(seed=42), hands=[tiles("111222333444m1z"), tiles("111222333444p2z"), tiles("111222333444s3z"), tiles("555666777888m4z")],
+                current_player=0, drawn_tile=tiles("5p")[0])
+    env.step({0: pack_action(RIICHI)})
+    legal = [unpack_action(a) for a in env.legal(0)]
+    assert legal and all(t == DISCARD for t, _, _ in legal)
+    assert {tiles("5p")[0], tiles("1z")[0]} <= {tl for _, tl, _ in legal}
+
+
+_NO_CLAIM_HANDS = [[0, 1, 4, 5, 8, 20, 20, 20, 20, 20, 20, 20, 20], [23, 35, 38, 61, 69, 70, 79, 83, 98, 123, 127, 128, 130],
+                   [1, 4, 5, 8, 12, 17, 56, 59, 81, 94, 101, 106, 122]]
+
+
+def sc_riichi_no_pon_claim(make):
+    """tests/env/actions/test_riichi_no_claim.py:15-32: a seat in riichi is not offered Pon: the turn passes to it."""
+    env = setup(make(seed=42), hands=_NO_CLAIM_HANDS + [[0] * 12 + [2]], current_player=3, active_players=[3],
+                riichi_declared=[True, False, False, False], drawn_tile=2)
+    env.step({3: pack_action(DISCARD, 2)})
+    act, ph, _ = env.status()
+    assert ph == WAIT_ACT and act == 1
+
+
+def sc_riichi_no_chi_claim(make):
+    """tests/env/actions/test_riichi_no_claim.py:34-54: a seat in riichi is offered Ron but not Chi."""
+    env = setup(make(seed=42), hands=_NO_CLAIM_HANDS + [[0] * 12 + [11]], current_player=3, active_players=[3],
+                riichi_declared=[True, False, False, False], drawn_tile=11)
+    env.step({3: pack_action(DISCARD, 11)})
+    act, ph, _ = env.status()
+    assert ph == WAIT_RESPONSE and act == 1
+    kinds = [unpack_action(a)[0] for a in env.legal(0)]
+    assert CHI not in kinds and RON in kinds
+
+
+def _riichi_autoplay(make, others, consistent=False):
+    env = make(seed=42)
+    env.reset()
+    v = env.peek()
+    v.players[0].riichi_declared = 1
+    v.current_player = 3
+    if consistent:
+        v.active_mask = 1 << 3
+    _set_hand(v.players[0], [1, 5, 9, 13, 17, 21, 25, 29, 33, 37, 41, 45, 49])
+    _set_hand(v.players[1], others[0])
+    _set_hand(v.players[2], others[1])
+    _set_hand(v.players[3], others[2] + [100])
+    v.wall_len = 40
+    for i, t in enumerate([101, 102, 103, 104] * 10):
+        v.wall[i] = t
+    v.drawn_tile = -1
+    env.poke(v)
+    env.step({3: pack_action(DISCARD, 100)})
+    v = env.peek()
+    assert v.current_player == 0
+    dt = v.drawn_tile
+    assert dt >= 0
+    env.step({0: pack_action(DISCARD, dt)})
+    act, ph, _ = env.status()
+    assert act == 2 and env.peek().current_player == 1
+    e = evs(env)
+    assert (e[-1]["type"], e[-1]["actor"]) == ("tsumo", 1)
+    assert (e[-2]["type"], e[-2]["actor"], e[-2]["tsumogiri"]) == ("dahai", 0, True)
+    assert (e[-3]["type"], e[-3]["actor"]) == ("tsumo", 0)
+
+
+def sc_riichi_autoplay_waits_for_the_discard(make):
+    """tests/test_riichi_autoplay.py:4-95: a seat in riichi that draws a dead tile is still asked for its discard (no auto-play);
+    the discard is logged as tsumogiri and the next seat draws.  State as the test pokes it: seat 0 in riichi with a garbage
+    hand, the wall replaced by 40 tiles, seat 3 (not the acting seat of the reset state) discards 100; the other seats hold
+    thirteen copies of tile 0 (oracle only, see SCENARIOS_ORACLE_ONLY)."""
+    _riichi_autoplay(make, [[0] * 13, [0] * 13, [0] * 12])
+
+
+def sc_riichi_autoplay_waits_for_the_discard_possible_hands(make):
+    """The same flow with hands a game can hold (other copies of 1m..4p for the seats that only watch) and with the discarder
+    also named in active_players: runs on the GPU too.  (The reference test leaves active_players = [0] while seat 3 acts; the
+    reference regenerates the legal actions of whoever sends an action, the HIP path validates against the lists it published
+    for the active seats - DESIGN.md section 6, Q17.)"""
+    _riichi_autoplay(make, [list(range(2, 54, 4)), list(range(3, 55, 4)), list(range(0, 48, 4))], consistent=True)
+
+
 def sc_riichi_sequence(make):
     """docs/RULES.md:64-78, tests/env/rule_validation/test_riichi_sequence.py: reach -> dahai -> reach_accepted
     -> tsumo; riichi discard restricted to tenpai-keeping tiles; stick paid on acceptance; ippatsu tsumo."""
@@ -976,7 +1229,11 @@ def sc_win_results_of_the_final_round(make):
 SCENARIOS = [sc_win_results_of_the_final_round, sc_paishan_dora_indices, sc_kakan_dora_timing, sc_daiminkan_dora_timing, sc_south_round_tsumo,
              sc_illegal_discard_penalty, sc_illegal_out_of_turn, sc_claim_priority_pon_over_chi, sc_kuikae_suji,
              sc_kuikae_deadlock, sc_sufuurenta, sc_suukansansen, sc_chankan_ron, sc_chankan_pass, sc_pao_daisangen_tsumo,
-             sc_pao_mjsoul_composite_tsumo, sc_riichi_sequence, sc_kyushu_kyuhai, sc_double_ron_honba_sticks,
+             sc_pao_mjsoul_composite_tsumo, sc_mjsoul_pao_tsumo_composite, sc_mjsoul_pao_ron_composite, sc_mjsoul_pao_ron_single,
+             sc_mjsoul_pao_ron_real_record, sc_mjsoul_pao_ron_real_record_with_riichi_stick, sc_rules_chankan_kokushi_tenhou,
+             sc_rules_chankan_kokushi_mjsoul, sc_rules_standard_chankan_kakan, sc_game_modes_initialization_params,
+             sc_game_modes_south_round_wind, sc_riichi_setup_leaves_only_discards,
+             sc_riichi_autoplay_waits_for_the_discard_possible_hands, sc_riichi_sequence, sc_kyushu_kyuhai, sc_double_ron_honba_sticks,
              sc_tobi_and_agariyame,
              sc_furiten_ron, sc_temporary_furiten, sc_valid_ankan_after_riichi, sc_no_claims_during_riichi,
              sc_honba_reset_and_increment, sc_pao_ron_honba, sc_doujun_cleared_by_call,
@@ -1454,6 +1711,11 @@ def sc3_play_full_round(make):
     assert len(sk["tehais"]) == 3 and sk["tehais"][0] == ["?"] * 13 and sk["tehais"][1] != ["?"] * 13
     assert evs(env)[-1]["type"] == "end_game"
 
+
+# Reference tests whose fixture is a hand no game can reach - twelve or thirteen copies of ONE tile id (tests/env/actions/
+# test_riichi_no_claim.py and tests/test_riichi_autoplay.py fill hands with [0] * 12 / [0] * 13): the oracle follows the reference there (fourteen 1m are a complete hand), the HIP path
+# keeps type counts in 3-bit fields and is not run on them.
+SCENARIOS_ORACLE_ONLY = [sc_riichi_no_pon_claim, sc_riichi_no_chi_claim, sc_riichi_autoplay_waits_for_the_discard]
 
 SCENARIOS_3P = [sc3_basics, sc3_no_chi, sc3_kita, sc3_oyayame_needs_40000, sc3_tsumo_payments_and_nukidora,
                 sc3_exhaustive_draw_pool_2000, sc3_pon_and_rotation, sc3_ron_deltas, sc3_kita_tile_none_removes_north,

@@ -680,6 +680,170 @@ def sc_riichi_autoplay_waits_for_the_discard_possible_hands(make):
     _riichi_autoplay(make, [list(range(2, 54, 4)), list(range(3, 55, 4)), list(range(0, 48, 4))], consistent=True)
 
 
+_KOKUSHI_WAIT_E = sorted([0, 32, 36, 68, 72, 104, 112, 116, 120, 124, 128, 132] + [1])   # thirteen kinds but East, 1m paired
+
+
+def _ankan_east_state(make, game_mode, rule_bits, seat1_hand, seat1_melds=None):
+    """tests/env/agari/test_chankan.py:101-219: after reset(), seat 0 holds EEE + ten low tiles and has drawn the fourth East (111),
+    seat 1 the given hand; the other seats keep what the wall dealt."""
+    env = make(seed=42, game_mode=game_mode, rule_bits=rule_bits)
+    env.reset()
+    v = env.peek()
+    _set_hand(v.players[0], [108, 109, 110] + [4, 8, 12, 16, 20, 24, 28, 32, 36, 40, 111])
+    v.drawn_tile = 111
+    _set_hand(v.players[1], seat1_hand)
+    if seat1_melds:
+        v.players[1].n_melds = len(seat1_melds)
+        for i, m in enumerate(seat1_melds):
+            set_meld(v.players[1].melds[i], *m)
+    v.current_player = 0
+    v.phase = WAIT_ACT
+    v.active_mask = 1
+    env.poke(v)
+    return env
+
+
+def sc_kokushi_ankan_ron(make):
+    """tests/env/agari/test_chankan.py:101-147: MjSoul rules: kokushi robs the Ankan of East and wins (yaku 42), the game ends."""
+    env = _ankan_east_state(make, 0, abi.RULE_MJSOUL, _KOKUSHI_WAIT_E)
+    env.step({0: pack_action(ANKAN, 111, [108, 109, 110, 111])})
+    act, ph, _ = env.status()
+    assert ph == WAIT_RESPONSE and (act >> 1) & 1
+    ron = [a for a in env.legal(1) if unpack_action(a)[0] == RON]
+    assert ron and unpack_action(ron[0])[1] == 111
+    env.step({1: ron[0]})
+    assert env.status()[2]
+    w = env.win_results()
+    assert w[1]["is_win"] and 42 in w[1]["yaku"]
+
+
+def sc_kokushi_ankan_ron_tenhou(make):
+    """tests/env/agari/test_chankan.py:149-183: Tenhou rules: no Ron on an Ankan, seat 0 goes on."""
+    env = _ankan_east_state(make, 1, abi.RULE_TENHOU, _KOKUSHI_WAIT_E)
+    env.step({0: pack_action(ANKAN, 111, [108, 109, 110, 111])})
+    act, ph, _ = env.status()
+    assert ph == WAIT_ACT and act == 1
+
+
+def sc_non_kokushi_ankan_no_ron(make):
+    """tests/env/agari/test_chankan.py:185-219: an ordinary hand waiting on the tile cannot rob an Ankan: the kan resolves at once."""
+    env = _ankan_east_state(make, 1, abi.RULE_TENHOU, [112, 113, 116, 116, 120, 120, 124, 124, 128, 128],
+                            [(PON_M, [132, 133, 134], True, -1, -1)])
+    env.step({0: pack_action(ANKAN, 111, [108, 109, 110, 111])})
+    v = env.peek()
+    assert v.phase == WAIT_ACT and v.current_player == 0 and v.players[0].n_melds == 1
+    assert v.players[0].melds[0].meld_type == ANKAN_M and v.drawn_tile >= 0
+
+
+def _four_1m_state(make, riichi):
+    env = make(seed=42)
+    env.reset()
+    v = env.peek()
+    _set_hand(v.players[0], [0, 1, 2, 3] + list(range(12, 22)))
+    v.drawn_tile = 3
+    v.active_mask = 1
+    v.current_player = 0
+    v.phase = WAIT_ACT
+    if riichi:
+        v.players[0].riichi_declared = 1
+    env.poke(v)
+    return env
+
+
+def sc_ankan_generation(make):
+    """tests/env/agari/test_chankan.py:221-243: four 1m in hand: the list offers the Ankan with all four tiles."""
+    env = _four_1m_state(make, False)
+    ankan = [unpack_action(a) for a in env.legal(0) if unpack_action(a)[0] == ANKAN]
+    assert ankan and ankan[0][1] in (0, 1, 2, 3) and sorted(ankan[0][2]) == [0, 1, 2, 3]
+
+
+def sc_ankan_generation_riichi(make):
+    """tests/env/agari/test_chankan.py:245-268: the same after a riichi declaration (the kan of the drawn type that keeps the waits)."""
+    env = _four_1m_state(make, True)
+    ankan = [unpack_action(a) for a in env.legal(0) if unpack_action(a)[0] == ANKAN]
+    assert ankan and ankan[0][1] == 0 and sorted(ankan[0][2]) == [0, 1, 2, 3]
+
+
+def sc_chankan_stale_claims_repro(make):
+    """tests/env/agari/test_chankan.py:270-330 (match 27, step 267): seat 0 passes a Pon offer, then seat 3 adds 6p to its Pon: seat 0,
+    waiting on 3p-6p, must be offered Ron - its observation holds the stale Pon entry plus the Ron (stale current_claims, section 6)."""
+    env = setup(make(seed=42), hands=[[4, 5, 6, 8, 9, 10, 12, 13, 14, 61, 62, 49, 53], [], [63, 64, 65, 66, 67, 68, 69, 70, 71, 72, 73, 74, 75], []],
+                melds=[[], [], [], [(PON_M, [56, 57, 58], True, -1, -1)]], discards=[[60], [], [], []], current_player=2)
+    env.step({2: pack_action(DISCARD, 63)})
+    act, ph, _ = env.status()
+    assert (act >> 0) & 1
+    env.step({s: pack_action(PASS) for s in range(4) if (act >> s) & 1})
+    v = env.peek()
+    assert v.current_player == 3
+    v.drawn_tile = 59
+    _set_hand(v.players[3], [59])
+    env.poke(v)
+    env.step({3: pack_action(KAKAN, 59, [56, 57, 58])})
+    act, ph, _ = env.status()
+    assert (act >> 0) & 1, (act, ph)
+    assert RON in [unpack_action(a)[0] for a in env.legal(0)]
+
+
+def sc_env_scoring_ron_deltas(make):
+    """tests/test_env_scoring.py:6-47: Ron on the discarded haku: zero-sum deltas in the hora event, scores updated."""
+    env = make(seed=42)
+    env.reset()
+    v = env.peek()
+    _set_hand(v.players[0], sorted([124, 125] + [0, 4, 8, 5, 9, 12, 16, 20, 24, 14, 15]))
+    v.current_player = 1
+    v.phase = WAIT_ACT
+    v.active_mask = 2
+    h1 = list(v.players[1].hand[: v.players[1].hand_len]) + [126]
+    _set_hand(v.players[1], h1)
+    if v.players[0].hand_len == 14:
+        pass
+    env.poke(v)
+    env.step({1: pack_action(DISCARD, 126)})
+    act, ph, _ = env.status()
+    assert (act >> 0) & 1 and find(env.legal(0), RON) is not None
+    env.step({0: pack_action(RON, 126)})
+    hora = next(e for e in reversed(evs(env)) if e["type"] == "hora")
+    d = hora["deltas"]
+    assert d[1] < 0 < d[0] and sum(d) == 0
+    v = env.peek()
+    assert v.players[0].score == 25000 + d[0] and v.players[1].score == 25000 + d[1]
+
+
+def sc_env_scoring_tsumo_deltas(make):
+    """tests/test_env_scoring.py:49-85: a tsumo (haku triplet) outside the first turn: the event is flagged tsumo, everybody pays."""
+    env = make(seed=42)
+    env.reset()
+    v = env.peek()
+    _set_hand(v.players[0], sorted([124, 125, 126, 0, 4, 8, 5, 9, 13, 16, 20, 24, 12]))
+    v.drawn_tile = 14
+    v.current_player = 0
+    v.is_first_turn = 0
+    v.players[0].discards[v.players[0].n_discards] = 0
+    v.players[0].n_discards += 1
+    env.poke(v)
+    assert find(env.legal(0), TSUMO) is not None
+    env.step({0: pack_action(TSUMO)})
+    hora = next(e for e in reversed(evs(env)) if e["type"] == "hora")
+    d = hora["deltas"]
+    assert hora["tsumo"] is True and d[0] > 0 and all(x < 0 for x in d[1:]) and sum(d) == 0
+    assert env.peek().players[0].score == 25000 + d[0]
+
+
+def sc_env_scoring_ura_markers(make):
+    """tests/test_env_scoring.py:87-107: a tsumo in riichi shows the ura markers in the hora event."""
+    env = make(seed=42)
+    env.reset()
+    v = env.peek()
+    v.players[0].riichi_declared = 1
+    _set_hand(v.players[0], sorted([124, 125, 126, 0, 1, 2, 4, 5, 6, 8, 9, 10, 12]))
+    v.drawn_tile = 13
+    v.current_player = 0
+    env.poke(v)
+    env.step({0: pack_action(TSUMO)})
+    hora = next(e for e in reversed(evs(env)) if e["type"] == "hora")
+    assert len(hora["ura_markers"]) > 0
+
+
 def sc_riichi_sequence(make):
     """docs/RULES.md:64-78, tests/env/rule_validation/test_riichi_sequence.py: reach -> dahai -> reach_accepted
     -> tsumo; riichi discard restricted to tenpai-keeping tiles; stick paid on acceptance; ippatsu tsumo."""
@@ -1233,7 +1397,9 @@ SCENARIOS = [sc_win_results_of_the_final_round, sc_paishan_dora_indices, sc_kaka
              sc_mjsoul_pao_ron_real_record, sc_mjsoul_pao_ron_real_record_with_riichi_stick, sc_rules_chankan_kokushi_tenhou,
              sc_rules_chankan_kokushi_mjsoul, sc_rules_standard_chankan_kakan, sc_game_modes_initialization_params,
              sc_game_modes_south_round_wind, sc_riichi_setup_leaves_only_discards,
-             sc_riichi_autoplay_waits_for_the_discard_possible_hands, sc_riichi_sequence, sc_kyushu_kyuhai, sc_double_ron_honba_sticks,
+             sc_riichi_autoplay_waits_for_the_discard_possible_hands, sc_kokushi_ankan_ron, sc_kokushi_ankan_ron_tenhou,
+             sc_non_kokushi_ankan_no_ron, sc_ankan_generation, sc_ankan_generation_riichi, sc_chankan_stale_claims_repro,
+             sc_env_scoring_ron_deltas, sc_env_scoring_tsumo_deltas, sc_env_scoring_ura_markers, sc_riichi_sequence, sc_kyushu_kyuhai, sc_double_ron_honba_sticks,
              sc_tobi_and_agariyame,
              sc_furiten_ron, sc_temporary_furiten, sc_valid_ankan_after_riichi, sc_no_claims_during_riichi,
              sc_honba_reset_and_increment, sc_pao_ron_honba, sc_doujun_cleared_by_call,

@@ -844,6 +844,192 @@ def sc_env_scoring_ura_markers(make):
     assert len(hora["ura_markers"]) > 0
 
 
+def _poked_round(make, hands, current_player=0, drawn_tile=None, mutate=None, game_mode=0):
+    """The fixture of tests/env/test_riichienv.py:197-650: RiichiEnv(seed=42).reset(), then hands replaced through the setter (given
+    order kept sorted like the tests do), active_players = [current_player], drawn_tile set WITHOUT touching the hand.  Seats the
+    reference test leaves to the wall get hands that cannot call anything here (the walls differ, section 6): honours and
+    terminals of other suits, stated per scenario."""
+    env = make(seed=42, game_mode=game_mode)
+    env.reset()
+    v = env.peek()
+    for p, h in hands.items():
+        _set_hand(v.players[p], h)
+    v.current_player = current_player
+    v.active_mask = 1 << current_player
+    v.phase = WAIT_ACT
+    if drawn_tile is not None:
+        v.drawn_tile = drawn_tile
+    if mutate:
+        mutate(v)
+    env.poke(v)
+    return env
+
+
+_IDLE2 = [73, 77, 81, 85, 89, 93, 97, 101, 105, 109, 113, 117, 121]      # sou / honours: no 1m-5m, no pairs
+_IDLE3 = [74, 78, 82, 86, 90, 94, 98, 102, 106, 110, 114, 118, 122]
+
+
+def sc_env_initialization(make):
+    """tests/env/test_riichienv.py:8-64: after reset(): 83 wall tiles (69 live + 14 dead), 14 / 13 / 13 / 13 tiles, nothing melded
+    or discarded, the dealer acts in WaitAct with fourteen discards to choose from, its log so far is start_game, start_kyoku, tsumo."""
+    env = make(seed=42)
+    v = env.peek()
+    assert v.wall_len > 0
+    env.reset()
+    v = env.peek()
+    assert v.wall_len == 83
+    assert [v.players[p].hand_len for p in range(4)] == [14, 13, 13, 13]
+    assert all(v.players[p].n_melds == 0 and v.players[p].n_discards == 0 for p in range(4))
+    assert (v.current_player, v.turn_count, v.is_done, v.needs_tsumo) == (0, 0, 0, 0)
+    act, ph, dn = env.status()
+    assert (act, ph, dn) == (1, WAIT_ACT, 0)
+    assert [e["type"] for e in evs(env, 0)] == ["start_game", "start_kyoku", "tsumo"]
+    legal = [unpack_action(a) for a in env.legal(0)]
+    assert len(legal) == 14 and legal[0][0] == DISCARD and 0 <= legal[0][1] < 136 and legal[0][2] == []
+
+
+def sc_env_basic_step_processing(make):
+    """tests/env/test_riichienv.py:66-127: discard, pass whatever is offered, the next seat draws; its own log masks the others' hands
+    and draws, the environment's log does not."""
+    env = make(seed=42)
+    env.reset()
+    v = env.peek()
+    env.step({0: pack_action(DISCARD, v.players[0].hand[v.players[0].hand_len - 1])})
+    passed = 0
+    while env.status()[1] == WAIT_RESPONSE:
+        act = env.status()[0]
+        env.step({s: pack_action(PASS) for s in range(4) if (act >> s) & 1})
+        passed += 1
+    act, ph, dn = env.status()
+    v = env.peek()
+    assert (ph, v.current_player, act, dn) == (WAIT_ACT, 1, 2, 0) and v.players[1].hand_len == 14 and v.drawn_tile >= 0
+    e1 = evs(env, 1)
+    assert [e["type"] for e in e1[:3]] == ["start_game", "start_kyoku", "tsumo"]
+    th = e1[1]["tehais"]
+    assert th[0][0] == "?" and th[1][0] != "?" and th[2][0] == "?" and th[3][0] == "?"
+    assert e1[2]["actor"] == 0 and e1[2]["pai"] == "?"
+    full = evs(env)
+    assert [e["type"] for e in full] == ["start_game", "start_kyoku", "tsumo", "dahai", "tsumo"]
+    assert [(e["actor"], e["pai"] != "?") for e in full[2:]] == [(0, True), (0, True), (1, True)]
+
+
+def sc_env_pon_claim(make):
+    """tests/env/test_riichienv.py:197-239: seat 2 holds two 1m: Pon of seat 0's 1m, then it is seat 2's turn; the pon event."""
+    env = _poked_round(make, {0: [0, 4, 8, 12, 16, 20, 24, 28, 32, 36, 40, 44, 48], 1: [13, 15, 17, 19, 21, 22, 23, 25, 26, 27, 29, 30, 31],
+                              2: sorted([1, 2, 57, 61, 65, 69, 73, 77, 81, 85, 89, 93, 97]),
+                              3: [101, 105, 109, 113, 117, 121, 125, 129, 133, 6, 10, 14, 18]}, drawn_tile=52)
+    env.step({0: pack_action(DISCARD, 0)})
+    act, ph, _ = env.status()
+    assert ph == WAIT_RESPONSE and act == 4
+    assert find(env.legal(2), PON) is not None
+    env.step({2: pack_action(PON, 0, [1, 2])})
+    v = env.peek()
+    assert v.current_player == 2 and v.phase == WAIT_ACT
+    last = evs(env)[-1]
+    assert (last["type"], last["actor"], last["target"], last["pai"]) == ("pon", 2, 0, "1m")
+
+
+def sc_env_pon_red_dora_claim(make):
+    """tests/env/test_riichienv.py:241-280: Pon of the discarded red 5m with two plain 5m (seat 1 empty; seat 3 made harmless)."""
+    env = _poked_round(make, {0: [0, 4, 8, 12, 16, 20, 24, 28, 32, 36, 40, 44, 48], 1: [],
+                              2: sorted([17, 18, 21, 25, 29, 33, 37, 41, 45, 49, 53, 57, 61]), 3: _IDLE3}, drawn_tile=16)
+    env.step({0: pack_action(DISCARD, 16)})
+    act, ph, _ = env.status()
+    assert ph == WAIT_RESPONSE and act == 4
+    pon = find(env.legal(2), PON)
+    assert pon is not None
+    env.step({2: pon})
+    v = env.peek()
+    assert v.current_player == 2 and v.phase == WAIT_ACT
+    last = evs(env)[-1]
+    assert (last["type"], last["actor"], last["target"], last["pai"]) == ("pon", 2, 0, "5mr")
+
+
+def _chi_state(make, h1):
+    return _poked_round(make, {0: [8] + list(range(40, 52)), 1: sorted(h1), 2: _IDLE2, 3: _IDLE3}, drawn_tile=100)
+
+
+def sc_env_chi_claim(make):
+    """tests/env/test_riichienv.py:282-327: the next seat holds 4m 5m: Chi of the discarded 3m."""
+    env = _chi_state(make, [12, 16] + list(range(60, 71)))
+    env.step({0: pack_action(DISCARD, 8)})
+    act, ph, _ = env.status()
+    assert ph == WAIT_RESPONSE and (act >> 1) & 1
+    assert find(env.legal(1), CHI) is not None
+    env.step({1: pack_action(CHI, 8, [12, 16])})
+    v = env.peek()
+    assert v.current_player == 1 and v.phase == WAIT_ACT and evs(env)[-1]["type"] == "chi"
+
+
+def sc_env_chi_claim_with_red_dora(make):
+    """tests/env/test_riichienv.py:329-421: with 4m, 5m and 5mr in hand two Chi are offered and the seat chooses the five it uses."""
+    for five, name in ((17, "5m"), (16, "5mr")):
+        env = _chi_state(make, [12, 16, 17] + list(range(60, 71)))
+        env.step({0: pack_action(DISCARD, 8)})
+        act, ph, _ = env.status()
+        assert ph == WAIT_RESPONSE and (act >> 1) & 1
+        assert sum(unpack_action(a)[0] == CHI for a in env.legal(1)) == 2
+        env.step({1: pack_action(CHI, 8, [12, five])})
+        v = env.peek()
+        assert v.current_player == 1 and v.phase == WAIT_ACT
+        last = evs(env)[-1]
+        assert (last["type"], last["pai"], last["consumed"]) == ("chi", "3m", ["4m", name])
+
+
+def _illegal_ryukyoku(env):
+    r = next(e for e in reversed(evs(env)) if e["type"] == "ryukyoku")
+    assert "Error: Illegal Action" in r["reason"]
+
+
+def sc_env_chi_claim_with_invalid_tile(make):
+    """tests/env/test_riichienv.py:423-480: a Chi that names a tile the seat does not hold is an illegal action (penalty ryukyoku)."""
+    env = _chi_state(make, [12, 16, 17] + list(range(60, 71)))
+    env.step({0: pack_action(DISCARD, 8)})
+    assert sum(unpack_action(a)[0] == CHI for a in env.legal(1)) == 2
+    env.step({1: pack_action(CHI, 8, [12, 10])})
+    _illegal_ryukyoku(env)
+
+
+def sc_env_chi_claim_with_invalid_combo(make):
+    """tests/env/test_riichienv.py:482-512: tiles in hand that form no sequence with the discard: illegal action."""
+    env = _poked_round(make, {0: [8] + list(range(40, 52)), 1: sorted([12, 60] + list(range(61, 72))), 2: _IDLE2, 3: _IDLE3})
+    env.step({0: pack_action(DISCARD, 8)})
+    env.step({1: pack_action(CHI, 8, [12, 60])})
+    _illegal_ryukyoku(env)
+
+
+def sc_env_chi_multiple_patterns(make):
+    """tests/env/test_riichienv.py:514-555: 123456789m + 5mr against a discarded 4m: five Chi (23, 35, 3-5r, 56, 5r-6)."""
+    env = _poked_round(make, {0: [13] + list(range(40, 52)), 1: sorted([0, 4, 8, 12, 16, 17, 20, 24, 28, 32] + [100, 104, 108]),
+                              2: _IDLE2, 3: _IDLE3}, drawn_tile=100)
+    env.step({0: pack_action(DISCARD, 13)})
+    chis = [set(unpack_action(a)[2]) for a in env.legal(1) if unpack_action(a)[0] == CHI]
+    assert len(chis) == 5
+    for want in ({4, 8}, {8, 17}, {8, 16}, {17, 20}, {16, 20}):
+        assert want in chis
+
+
+def sc_env_ron_claim(make):
+    """tests/env/test_riichienv.py:557-597: 111222333444m + 5m waits on 5m: one Ron action, a hora event follows."""
+    env = _poked_round(make, {1: [0, 1, 2, 4, 5, 6, 8, 9, 10, 12, 13, 14, 16], 0: sorted([17] + list(range(40, 53))), 2: _IDLE2, 3: _IDLE3})
+    env.step({0: pack_action(DISCARD, 17)})
+    act, ph, _ = env.status()
+    assert ph == WAIT_RESPONSE and act == 2
+    ron = [a for a in env.legal(1) if unpack_action(a)[0] == RON]
+    assert len(ron) == 1
+    env.step({1: ron[0]})
+    assert "hora" in [e["type"] for e in evs(env)[-3:]]
+
+
+def sc_env_ankan_riichi_legality(make):
+    """tests/env/test_riichienv.py:599-640: in riichi with 1s 1s 1s (+ drawn 1s) 2s 3s the Ankan would change the waits: not offered."""
+    def riichi3(v):
+        v.players[3].riichi_declared = 1
+
+    env = _poked_round(make, {3: sorted([4, 5, 36, 60, 64, 68, 72, 73, 74, 75, 76, 80, 88, 92])}, current_player=3, drawn_tile=72, mutate=riichi3)
+    assert not [a for a in env.legal(3) if unpack_action(a)[0] == ANKAN]
+
+
 def sc_riichi_sequence(make):
     """docs/RULES.md:64-78, tests/env/rule_validation/test_riichi_sequence.py: reach -> dahai -> reach_accepted
     -> tsumo; riichi discard restricted to tenpai-keeping tiles; stick paid on acceptance; ippatsu tsumo."""
@@ -1399,7 +1585,10 @@ SCENARIOS = [sc_win_results_of_the_final_round, sc_paishan_dora_indices, sc_kaka
              sc_game_modes_south_round_wind, sc_riichi_setup_leaves_only_discards,
              sc_riichi_autoplay_waits_for_the_discard_possible_hands, sc_kokushi_ankan_ron, sc_kokushi_ankan_ron_tenhou,
              sc_non_kokushi_ankan_no_ron, sc_ankan_generation, sc_ankan_generation_riichi, sc_chankan_stale_claims_repro,
-             sc_env_scoring_ron_deltas, sc_env_scoring_tsumo_deltas, sc_env_scoring_ura_markers, sc_riichi_sequence, sc_kyushu_kyuhai, sc_double_ron_honba_sticks,
+             sc_env_scoring_ron_deltas, sc_env_scoring_tsumo_deltas, sc_env_scoring_ura_markers, sc_env_initialization,
+             sc_env_basic_step_processing, sc_env_pon_claim, sc_env_pon_red_dora_claim, sc_env_chi_claim, sc_env_chi_claim_with_red_dora,
+             sc_env_chi_claim_with_invalid_tile, sc_env_chi_claim_with_invalid_combo, sc_env_chi_multiple_patterns, sc_env_ron_claim,
+             sc_env_ankan_riichi_legality, sc_riichi_sequence, sc_kyushu_kyuhai, sc_double_ron_honba_sticks,
              sc_tobi_and_agariyame,
              sc_furiten_ron, sc_temporary_furiten, sc_valid_ankan_after_riichi, sc_no_claims_during_riichi,
              sc_honba_reset_and_increment, sc_pao_ron_honba, sc_doujun_cleared_by_call,

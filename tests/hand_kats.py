@@ -48,6 +48,69 @@ HAND_KATS = [
 ]
 
 
+# ---- the reference's Python evaluator tests (hand strings written out as ids: parse_hand hands out copies in order and skips
+# the red copy of a five unless the digit is 0, parser.rs:43-97)
+def _ids(s):
+    out, digits, used = [], [], {}
+    for ch in s:
+        if ch.isdigit():
+            digits.append(int(ch))
+            continue
+        su = "mpsz".index(ch)
+        for d in digits:
+            if d == 0:
+                out.append(su * 36 + 16)
+                continue
+            t = su * 9 + d - 1
+            k = used.get(t, 1 if (su < 3 and d == 5) else 0)
+            out.append(4 * t + k)
+            used[t] = k + 1
+        digits = []
+    return out
+
+
+def _pon(ids):
+    return {"meld_type": "pon", "tiles": ids, "opened": True, "from_who": 0}
+
+
+def _chi(ids):
+    return {"meld_type": "chi", "tiles": ids, "opened": True, "from_who": 0}
+
+
+_akas = [8, 12, 16, 48, 52, 56, 80, 84, 88]                             # 345m 456p 345s with the three red fives
+_text = _ids("123m456p789s111z2z")                                       # test_agari_calculator.py:41-98
+
+HAND_KATS += [
+    # tests/test_core.py:46-111 (yaku ids by scenario; the win tile is a further copy of its type)
+    ("core_tanyao", case(_ids("234m234p234s66m88s"), 22), {"is_win": 1, "has": [12], "min_han": 1}),
+    ("core_pinfu", case(_ids("123m456p789s23p99m"), 37), {"is_win": 1, "has": [14], "min_han": 1}),
+    ("core_yakuhai_white", case(_ids("123m456p78s88m"), 104, melds=[_pon([124, 125, 126])]), {"is_win": 1, "has": [7], "min_han": 1}),
+    ("core_honitsu", case(_ids("123m567m111m33z22z"), 114), {"is_win": 1, "has": [27], "min_han": 3}),
+    ("core_red_dora_pinfu", case(_ids("234m067p678s34m22z"), 17), {"is_win": 1, "has": [14], "min_han": 2}),
+    ("core_no_honroutou", case(_ids("11s22z"), 74, melds=[_pon([124, 125, 126]), _chi([84, 88, 92]), _chi([24, 28, 32])]),
+     {"is_win": 1, "has": [7], "lacks": [24, 31]}),
+    # tests/test_core.py:114-148: three red fives + tanyao = 4 han, the aka id once
+    ("core_three_aka", case(_akas + [92, 93, 94, 64], 65), {"is_win": 1, "yakuman": 0, "has": [32, 12], "once": [32], "han": 4}),
+    # tests/test_core.py:151-187: red fives alone are no yaku
+    ("core_only_aka_fails", case(_akas + [104, 105, 106, 108], 109, player_wind=1, round_wind=1), {"is_win": 0}),
+    # tests/test_agari_calculator.py:4-38: a riichi hand whose wait is not two-sided has no pinfu
+    ("calc_no_pinfu", case([12, 17, 21, 68, 68, 80, 80, 83, 96, 104, 120, 120, 122], 100, riichi=True, player_wind=3, round_wind=0),
+     {"lacks": [14]}),
+    # tests/test_agari_calculator.py:41-98: 123m456p789s EEE S, win on S, by seat wind and win type
+    ("calc_text_oya_ron", case(_text, 113), {"is_win": 1, "han": 2, "fu": 40, "ron_agari": 3900, "tsumo_agari_oya": 0, "tsumo_agari_ko": 0}),
+    ("calc_text_south_tsumo", case(_text, 113, tsumo=True, player_wind=1),
+     {"is_win": 1, "han": 2, "fu": 40, "ron_agari": 0, "tsumo_agari_oya": 1300, "tsumo_agari_ko": 700}),
+    ("calc_text_east_tsumo", case(_text, 113, tsumo=True, player_wind=0),
+     {"is_win": 1, "han": 3, "fu": 40, "ron_agari": 0, "tsumo_agari_oya": 0, "tsumo_agari_ko": 2600}),
+    ("calc_text_west_tsumo", case(_text, 113, tsumo=True, player_wind=2),
+     {"is_win": 1, "han": 2, "fu": 40, "ron_agari": 0, "tsumo_agari_oya": 1300, "tsumo_agari_ko": 700}),
+    ("calc_text_north_tsumo", case(_text, 113, tsumo=True, player_wind=3),
+     {"is_win": 1, "han": 2, "fu": 40, "ron_agari": 0, "tsumo_agari_oya": 1300, "tsumo_agari_ko": 700}),
+    # tests/test_agari_calculator.py:100-141: an open hand whose only han is a red five is no win (yaku shibari)
+    ("calc_yaku_shibari", case([4, 8, 52, 56, 60, 76, 77, 92, 96, 100], 0, melds=[_chi([16, 20, 24])]), {"is_win": 0}),
+]
+
+
 def check(name, r, want):
     ids = list(r.yaku[: r.n_yaku])
     for k, v in want.items():
@@ -55,6 +118,10 @@ def check(name, r, want):
             assert ids == v, (name, ids)
         elif k == "has":
             assert all(y in ids for y in v), (name, ids)
+        elif k == "lacks":
+            assert not any(y in ids for y in v), (name, ids)
+        elif k == "once":
+            assert all(ids.count(y) == 1 for y in v), (name, ids)
         elif k == "min_han":
             assert r.han >= v, (name, r.han)
         elif k == "shape":

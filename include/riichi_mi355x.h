@@ -349,7 +349,12 @@ int rmj_set_stream(rmj_handle h, void* hip_stream, int own);
  * Bit-exact parity is claimed for full-information streams; a masked "?" tile is mapped to tile 0 by the host mapper on
  * request, like parse_mjai_tile (event_handler.rs:8-10), which leaves the masked seats in a garbage state in both
  * implementations (only the observing seat's outputs are meaningful).  The caller-side mjai_log recording of
- * env.rs:56-72 is not reproduced (start_game clears the device log, later events are not appended). */
+ * env.rs:56-72 is not reproduced (start_game clears the device log, later events are not appended).
+ * RMJ_EVF_REPLAY_PASS in the first record's `pad`: the bookkeeping of the reference's log walker on top of the event
+ * (KyokuStepIterator, replay/mod.rs:129-177; apply_log_action, state/event_handler.rs:391-392): a seat that was offered Ron on
+ * the last discard and does not win with this event has passed (same-turn furiten, permanent in riichi), and a discard ends
+ * the discarder's same-turn furiten - what (observation, action) datasets built from logs need. */
+#define RMJ_EVF_REPLAY_PASS 1u
 int rmj_apply_events(rmj_handle h, const RmjEvent* events /*[n][3]*/);
 
 /* Auxiliary feature blocks of an Observation that are not part of encode() / encode_extended(); absolute seat order,

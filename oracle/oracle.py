@@ -240,9 +240,12 @@ class Game:
                               pao_payer=None if w.pao_payer < 0 else int(w.pao_payer))
         return out
 
-    def apply_event(self, ev):
-        """apply_mjai_event (state/event_handler.rs, state_3p/event_handler.rs): MJAI dict or binary records."""
+    def apply_event(self, ev, replay=False):
+        """apply_mjai_event (state/event_handler.rs, state_3p/event_handler.rs): MJAI dict or binary records.  replay=True: plus
+        the missed-Ron bookkeeping of KyokuStepIterator (replay/mod.rs:129-177)."""
         recs = abi.event_records_from_mjai(ev, 3 if self.sanma else 4) if isinstance(ev, dict) else ev
+        if replay:
+            recs[0].pad |= 1
         self.L.orc_game_apply_event(self.h, C.byref(recs), abi.EVENT_SLOTS)
 
     def random_actions(self, policy_seed, global_game):

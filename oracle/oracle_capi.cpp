@@ -206,6 +206,22 @@ void orc_game_apply_event(void* gp, const RmjEvent* ev, int nrec) {
     if (nrec < 1) return;
     const RmjEvent& e = ev[0];
     const int actor = e.actor;
+    // Replay semantics (pad bit 0; KyokuStepIterator::_collect_pass_observations, replay/mod.rs:129-177): a seat that was offered
+    // Ron on the last discard and does not win with this event has passed - same-turn furiten, permanent in riichi.
+    if ((e.pad & 1) && g->phase == WAIT_RESPONSE && !g->pending_kan.has_value()) {
+        for (auto& kv : g->current_claims) {
+            if (std::find(g->active_players.begin(), g->active_players.end(), kv.first) == g->active_players.end()) continue;
+            if (e.type == RMJ_EV_HORA && kv.first == (uint8_t)actor) continue;
+            bool ron = false;
+            for (auto& a : kv.second) ron = ron || a.type == AT_RON;
+            if (!ron) continue;
+            PlayerState& Q = g->players[kv.first];
+            Q.missed_agari_doujun = true;
+            if (Q.riichi_declared) Q.missed_agari_riichi = true;
+        }
+    }
+    // ... and the walker's discard (apply_log_action, state/event_handler.rs:391-392) ends the discarder's same-turn furiten
+    if ((e.pad & 1) && e.type == RMJ_EV_DAHAI && actor < g->NP) g->players[actor].missed_agari_doujun = false;
     switch (e.type) {
         case RMJ_EV_START_GAME:  // env.rs:56-72 (reset) + event_handler.rs:20-25
             g->reset();

@@ -2024,6 +2024,20 @@ __device__ inline void apply_event(Ctx& c, const RmjEvent* ev) {
     const int actor = ev[0].actor & 3;
     const int tile = ev[0].tile;
     PState& P = S.p[actor];
+    // Replay semantics (RMJ_EVF_REPLAY_PASS in `pad`; KyokuStepIterator::_collect_pass_observations, replay/mod.rs:129-177): a
+    // seat that was offered Ron on the last discard and does not win with this event has passed - same-turn furiten,
+    // permanent in riichi.
+    if ((ev[0].pad & 1u) && S.phase == RMJ_WAIT_RESPONSE && S.pending_kan_pid == 0xFF) {
+        uint32_t m = (uint32_t)S.ron_offer_mask & (uint32_t)S.active_mask & 0xFu;
+        if (ty == RMJ_EV_HORA) m &= ~(1u << actor);
+        for (int i = 0; i < KNP; i++)
+            if ((m >> i) & 1u) {
+                PState& Q = S.p[i];
+                Q.flags |= PF_MISSED_DOUJUN | ((Q.flags & PF_RIICHI_DECLARED) ? PF_MISSED_RIICHI : 0);
+            }
+    }
+    // ... and the walker's discard (apply_log_action, state/event_handler.rs:391-392) ends the discarder's same-turn furiten
+    if ((ev[0].pad & 1u) && ty == RMJ_EV_DAHAI) P.flags &= ~PF_MISSED_DOUJUN;
     switch (ty) {
         case RMJ_EV_START_GAME:  // env.rs:56-72 + event_handler.rs:20-25
             S.ev_count = 0;

@@ -578,7 +578,7 @@ class ReplayBatch:
                 yield {"index": k, "game": gs, "seat": ss, "action": np.array([d[2] for d in dec], dtype=np.uint64),
                        "action_id": np.array([self._encode_id(d[2]) for d in dec], dtype=np.int64),
                        "mask": mask[gs, ss][:, :nmask].copy(), "obs": enc[gs, ss].copy()}
-            self.env.apply_events([l[k] if k < len(l) else None for l in self.logs], masked_ok=self.masked_ok)
+            self.env.apply_events([l[k] if k < len(l) else None for l in self.logs], masked_ok=self.masked_ok, replay=True)
 
 
 class MjSoulReplay:

@@ -226,15 +226,19 @@ class VecRiichiEnv:
         a = np.ascontiguousarray(actions, dtype=np.uint64).reshape(self.n, 4)
         _chk(self.L.rmj_step(self.h, a.ctypes.data))
 
-    def apply_events(self, events, masked_ok=False):
+    def apply_events(self, events, masked_ok=False, replay=False):
         """RiichiEnv.apply_event (env.rs:880-887) for every game: `events[g]` is an MJAI dict, pre-built records
-        (abi.event_records_from_mjai) or None (no event for game g)."""
+        (abi.event_records_from_mjai) or None (no event for game g).  replay=True adds the bookkeeping of the reference's log
+        walker (KyokuStepIterator, replay/mod.rs:129-177): a seat that was offered Ron on the last discard and does not win with
+        this event has passed - same-turn furiten, permanent in riichi (record flag RMJ_EVF_REPLAY_PASS in `pad`)."""
         buf = (abi.Event * (abi.EVENT_SLOTS * self.n))()
         np_ = 3 if self.game_mode >= 3 else 4
         for g, ev in enumerate(events):
             if ev is None:
                 continue
             recs = abi.event_records_from_mjai(ev, np_, masked_ok) if isinstance(ev, dict) else ev
+            if replay:
+                recs[0].pad |= 1
             C.memmove(C.addressof(buf) + g * abi.EVENT_SLOTS * C.sizeof(abi.Event), C.addressof(recs),
                       abi.EVENT_SLOTS * C.sizeof(abi.Event))
         _chk(self.L.rmj_apply_events(self.h, C.addressof(buf)))

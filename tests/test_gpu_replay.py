@@ -30,7 +30,7 @@ def test_real_log_yields_every_decision():
     for smp in rb.samples():
         # bring the oracle to the same event index, then compare game 0's samples
         while k_prev < smp["index"]:
-            o.apply_event(events[k_prev])
+            o.apply_event(events[k_prev], replay=True)
             k_prev += 1
         for j in np.where(smp["game"] == 0)[0]:
             s = int(smp["seat"][j])
@@ -105,3 +105,18 @@ def test_mjsoul_records_verified_in_one_gpu_batch():
         assert n == len(ctxs) and bad == 0, (mode, seed, n, bad)
         total += n
     assert total >= 4
+
+
+def test_pass_samples_carry_the_missed_ron_furiten():
+    """tests/env/test_apply_event.py:535-632 (TestReplayFuriten) on ReplayBatch: a seat that lets a Ron go is in same-turn furiten
+    until its own discard (the second 3m is offered again), in riichi for good (the second 3m yields no sample at all)."""
+    from riichienv_amd import replay
+    from tests.apply_events_util import furiten_log
+
+    rb = replay.ReplayBatch([furiten_log(False), furiten_log(True)], game_mode=0, include_pass=True)
+    got = {0: [], 1: []}
+    for smp in rb.samples():
+        for j in range(len(smp["game"])):
+            if int(smp["seat"][j]) == 1 and abi.unpack_action(int(smp["action"][j]))[0] == abi.PASS:
+                got[int(smp["game"][j])].append(bool(smp["mask"][j][79]))      # id 79 = Ron / Tsumo
+    assert got == {0: [True, True], 1: [True]}

@@ -59,7 +59,7 @@ def test_sanma_log_replays_into_the_policy_decisions(seed):
     got = []
     for smp in rb.samples():
         while k_prev < smp["index"]:
-            o.apply_event(events[k_prev])
+            o.apply_event(events[k_prev], replay=True)
             k_prev += 1
         ev = events[smp["index"]]
         for j in range(len(smp["game"])):

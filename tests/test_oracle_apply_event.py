@@ -96,3 +96,32 @@ def test_3p_pon_and_kita():
     feed(g2, [{"type": "start_game"}, start_kyoku(hands), {"type": "tsumo", "actor": 0, "pai": "3z"}, {"type": "kita", "actor": 0}])
     v = g2.peek()
     assert v.players[0].n_kita == 1 and v.players[0].kita[0] // 4 == 30 and v.current_player == 0xFF
+
+
+def _pass_observations_of_seat1(events):
+    """Walk a log through apply_event(replay=True); whenever seat 1 is offered a claim and the log goes on without it taking one (its implicit
+    Pass), record whether Ron was among the offers - what KyokuStepIterator yields as the seat's Pass steps."""
+    g = oracle.Game(game_mode=0)
+    out = []
+    for ev in events:
+        act, ph, _ = g.status()
+        claims = ev.get("type") in ("hora", "pon", "chi", "daiminkan") and ev.get("actor") == 1
+        if ph == abi.WAIT_RESPONSE and (act >> 1) & 1 and not claims:
+            out.append(abi.RON in types_of(g, 1))
+        g.apply_event(ev, replay=True)
+    return out
+
+
+def test_doujun_furiten_resets_after_own_discard():
+    """tests/env/test_apply_event.py:535-574: seat 1 passes the Ron on seat 0's 3m, draws and discards: the same-turn furiten is gone
+    and seat 2's 3m is offered again."""
+    from tests.apply_events_util import furiten_log
+
+    assert _pass_observations_of_seat1(furiten_log(False)) == [True, True]
+
+
+def test_riichi_furiten_persists_after_own_discard():
+    """tests/env/test_apply_event.py:576-632: in riichi the missed Ron is permanent: the second 3m produces no offer at all."""
+    from tests.apply_events_util import furiten_log
+
+    assert _pass_observations_of_seat1(furiten_log(True)) == [True]

@@ -427,17 +427,17 @@ def sc_pao_mjsoul_composite_tsumo(make):
     assert hora["deltas"] == [64000, -16000, -8000, -40000]
 
 
-def _poke_pao_case(make, hands, melds, pao, current_player, drawn_tile, riichi_sticks=0):
+def _poke_pao_case(make, hands, melds, pao, current_player, drawn_tile, riichi_sticks=0, rule_bits=abi.RULE_MJSOUL, game_mode=0, oya=0):
     """The state the tests of tests/env/test_majsoul_pao_scoring.py build with the reference's setters after
     RiichiEnv(seed=1, rule=default_mjsoul, game_mode="4p-red-single").reset(): oya 0, 25000 each, hands / melds / pao of the
     named seats replaced as given (hands stay in the given order, the drawn tile is NOT added to the hand), WaitAct for
     `current_player`.  pao: {winner: (field, liable seat)} with field "pao_daisangen" (yaku 37) or "pao_daisuushi" (yaku 50)."""
-    env = make(game_mode=0, seed=1, rule_bits=abi.RULE_MJSOUL)
+    env = make(game_mode=game_mode, seed=1, rule_bits=rule_bits)
     env.reset()
     v = env.peek()
-    v.oya = 0
+    v.oya = oya
     for p in range(4):
-        v.players[p].score = 25000
+        v.players[p].score = 25000 if game_mode < 3 else 35000
     for p, h in hands.items():
         v.players[p].hand_len = len(h)
         for i, t in enumerate(h):
@@ -1030,6 +1030,84 @@ def sc_env_ankan_riichi_legality(make):
     assert not [a for a in env.legal(3) if unpack_action(a)[0] == ANKAN]
 
 
+def _daiminkan_state(make, melds0, discarder, tile, consumed):
+    """riichienv-core/src/tests.rs:1594-1743: seat 0 holds open Pon melds and the three further copies of `tile`; `discarder` has
+    just discarded `tile` and seat 0 is offered the Daiminkan (the Rust tests call _resolve_kan directly)."""
+    env = make(game_mode=2, seed=1)
+    env.reset()
+    v = env.peek()
+    n = 13 - 3 * len(melds0) - 3
+    _set_hand(v.players[0], sorted(consumed + [t for t in (0, 5, 10, 40, 45, 50, 80)][:n]))
+    v.players[0].n_melds = len(melds0)
+    for i, (mt, frm) in enumerate(melds0):
+        set_meld(v.players[0].melds[i], PON_M, mt, True, frm, mt[0])
+    for p in range(1, 4):
+        if v.players[p].hand_len == 14:
+            v.players[p].hand_len = 13
+    v.drawn_tile = -1
+    v.phase = WAIT_RESPONSE
+    v.active_mask = 1
+    v.current_player = discarder
+    v.last_discard_pid = discarder
+    v.last_discard_tile = tile
+    env.poke(v)
+    kan = find(env.legal(0), DAIMINKAN)
+    assert kan is not None
+    env.step({0: pack_action(DAIMINKAN, tile, consumed)})
+    return env.peek().players[0]
+
+
+def sc_daiminkan_pao_daisangen(make):
+    """tests.rs:1594-1644: the third dragon set completed by a Daiminkan makes the discarder liable (yaku 37)."""
+    p0 = _daiminkan_state(make, [([124, 125, 126], 1), ([128, 129, 130], 2)], 3, 132, [133, 134, 135])
+    assert p0.pao_daisangen == 3 and p0.pao_daisuushi == -1
+
+
+def sc_daiminkan_pao_daisuushii(make):
+    """tests.rs:1646-1701: the fourth wind set by Daiminkan: liable for daisuushii (yaku 50)."""
+    p0 = _daiminkan_state(make, [([108, 109, 110], 1), ([112, 113, 114], 2), ([116, 117, 118], 3)], 2, 120, [121, 122, 123])
+    assert p0.pao_daisuushi == 2 and p0.pao_daisangen == -1
+
+
+def sc_daiminkan_no_pao_insufficient_melds(make):
+    """tests.rs:1703-1742: only the second dragon set: nobody is liable."""
+    p0 = _daiminkan_state(make, [([124, 125, 126], 1)], 1, 128, [129, 130, 131])
+    assert p0.pao_daisangen == -1 and p0.pao_daisuushi == -1
+
+
+def sc_tenhou_tsumo_pao_composite(make):
+    """tests.rs:1886-1917 on the state machine: Tenhou rules, ko tsumo of daisangen (pao by seat 3) + tsuuiisou: the liable seat
+    pays both yakuman (64000), nobody else pays."""
+    env = _poke_pao_case(make, {0: [128, 129, 130, 132, 133, 134, 108, 109, 110, 112]}, {0: [(PON_M, [124, 125, 126], 1)]},
+                         {0: ("pao_daisangen", 3)}, 0, 113, rule_bits=abi.RULE_TENHOU, oya=1)
+    env.step({0: pack_action(TSUMO)})
+    assert _deltas(env) == [64000, 0, 0, -64000]
+
+
+def sc_tenhou_ron_pao_composite(make):
+    """tests.rs:1919-1950 (Tenhou: the WHOLE yakuman total is split in halves) on the state machine: dealer Ron of daisuushii (pao
+    by seat 1) + tsuuiisou from seat 2.  Tenhou counts daisuushii once (no double yakuman, rule.rs), so the total is 2 x 48000."""
+    melds0 = [(PON_M, [108, 109, 110], 1), (PON_M, [112, 113, 114], 1), (PON_M, [116, 117, 118], 1)]
+    env = _poke_pao_case(make, {0: [120, 121, 124, 124], 2: [122, 1, 2, 3, 5, 6, 7, 8, 9, 10, 11, 12, 13]}, {0: melds0},
+                         {0: ("pao_daisuushi", 1)}, 2, 122, rule_bits=abi.RULE_TENHOU)
+    env.step({2: pack_action(DISCARD, 122)})
+    assert env.status()[1] == WAIT_RESPONSE
+    env.step({0: pack_action(RON, 122)})
+    assert _deltas(env) == [96000, -48000, -48000, 0]
+
+
+def sc_mjsoul_3p_ron_pao_composite(make):
+    """tests.rs:1951-1986 on the state machine: sanma, MjSoul rules, dealer Ron of daisangen (pao by seat 1) + tsuuiisou from seat
+    2: only the daisangen unit is halved: 24000 / 72000."""
+    melds0 = [(PON_M, [124, 125, 126], 1), (PON_M, [128, 129, 130], 1), (PON_M, [132, 133, 134], 1)]
+    env = _poke_pao_case(make, {0: [108, 109, 112, 113], 2: [114, 36, 37, 40, 41, 44, 45, 48, 49, 53, 54, 56, 57]}, {0: melds0},
+                         {0: ("pao_daisangen", 1)}, 2, 114, game_mode=3)
+    env.step({2: pack_action(DISCARD, 114)})
+    assert env.status()[1] == WAIT_RESPONSE
+    env.step({0: pack_action(RON, 114)})
+    assert _deltas(env)[:3] == [96000, -24000, -72000]
+
+
 def sc_riichi_sequence(make):
     """docs/RULES.md:64-78, tests/env/rule_validation/test_riichi_sequence.py: reach -> dahai -> reach_accepted
     -> tsumo; riichi discard restricted to tenpai-keeping tiles; stick paid on acceptance; ippatsu tsumo."""
@@ -1588,7 +1666,8 @@ SCENARIOS = [sc_win_results_of_the_final_round, sc_paishan_dora_indices, sc_kaka
              sc_env_scoring_ron_deltas, sc_env_scoring_tsumo_deltas, sc_env_scoring_ura_markers, sc_env_initialization,
              sc_env_basic_step_processing, sc_env_pon_claim, sc_env_pon_red_dora_claim, sc_env_chi_claim, sc_env_chi_claim_with_red_dora,
              sc_env_chi_claim_with_invalid_tile, sc_env_chi_claim_with_invalid_combo, sc_env_chi_multiple_patterns, sc_env_ron_claim,
-             sc_env_ankan_riichi_legality, sc_riichi_sequence, sc_kyushu_kyuhai, sc_double_ron_honba_sticks,
+             sc_env_ankan_riichi_legality, sc_daiminkan_pao_daisangen, sc_daiminkan_pao_daisuushii, sc_daiminkan_no_pao_insufficient_melds,
+             sc_tenhou_tsumo_pao_composite, sc_tenhou_ron_pao_composite, sc_riichi_sequence, sc_kyushu_kyuhai, sc_double_ron_honba_sticks,
              sc_tobi_and_agariyame,
              sc_furiten_ron, sc_temporary_furiten, sc_valid_ankan_after_riichi, sc_no_claims_during_riichi,
              sc_honba_reset_and_increment, sc_pao_ron_honba, sc_doujun_cleared_by_call,
@@ -2072,7 +2151,7 @@ def sc3_play_full_round(make):
 # keeps type counts in 3-bit fields and is not run on them.
 SCENARIOS_ORACLE_ONLY = [sc_riichi_no_pon_claim, sc_riichi_no_chi_claim, sc_riichi_autoplay_waits_for_the_discard]
 
-SCENARIOS_3P = [sc3_basics, sc3_no_chi, sc3_kita, sc3_oyayame_needs_40000, sc3_tsumo_payments_and_nukidora,
+SCENARIOS_3P = [sc_mjsoul_3p_ron_pao_composite, sc3_basics, sc3_no_chi, sc3_kita, sc3_oyayame_needs_40000, sc3_tsumo_payments_and_nukidora,
                 sc3_exhaustive_draw_pool_2000, sc3_pon_and_rotation, sc3_ron_deltas, sc3_kita_tile_none_removes_north,
                 sc3_kita_with_correct_tile, sc3_ankan_available_after_kita_in_riichi, sc3_reach_available_after_kita,
                 sc3_tsumo_available_after_kita, sc3_ryukyoku_deltas_are_reset_each_round, sc3_dora_wraps_between_1m_and_9m,

@@ -106,6 +106,8 @@ HAND_KATS += [
      {"is_win": 1, "han": 2, "fu": 40, "ron_agari": 0, "tsumo_agari_oya": 1300, "tsumo_agari_ko": 700}),
     ("calc_text_north_tsumo", case(_text, 113, tsumo=True, player_wind=3),
      {"is_win": 1, "han": 2, "fu": 40, "ron_agari": 0, "tsumo_agari_oya": 1300, "tsumo_agari_ko": 700}),
+    # riichienv-core/src/tests.rs:263-272: 111222333m 444p 1s is tenpai on 1s (waits bit 18)
+    ("rs_is_tenpai", case([0, 1, 2, 4, 5, 6, 8, 9, 10, 12, 13, 14, 72], 73), {"is_tenpai": 1, "waits_has": [18]}),
     # tests/test_agari_calculator.py:100-141: an open hand whose only han is a red five is no win (yaku shibari)
     ("calc_yaku_shibari", case([4, 8, 52, 56, 60, 76, 77, 92, 96, 100], 0, melds=[_chi([16, 20, 24])]), {"is_win": 0}),
 ]
@@ -118,6 +120,8 @@ def check(name, r, want):
             assert ids == v, (name, ids)
         elif k == "has":
             assert all(y in ids for y in v), (name, ids)
+        elif k == "waits_has":
+            assert all((int(r.waits) >> t) & 1 for t in v), (name, hex(int(r.waits)))
         elif k == "lacks":
             assert not any(y in ids for y in v), (name, ids)
         elif k == "once":

@@ -1108,6 +1108,72 @@ def sc_mjsoul_3p_ron_pao_composite(make):
     assert _deltas(env)[:3] == [96000, -24000, -72000]
 
 
+def sc_ryukyoku_deltas_are_reset_each_round_4p(make):
+    """tests.rs:234-261: score deltas of an earlier settlement do not leak into the ryukyoku event of the next round (four East
+    discards on the first turn: sufuurenta)."""
+    env = make()
+    env.reset()
+    v = env.peek()
+    for p, d in enumerate([2300, -2300, 0, 0]):
+        v.players[p].score_delta = d
+    env.poke(v)
+    scattered = [0, 4, 8, 36, 40, 44, 72, 76, 80, 112, 116, 120, 124]
+    setup(env, hands=[scattered[:] for _ in range(4)], wall=list(range(136)))      # reset() = _initialize_round: deltas cleared
+    for i, w in enumerate([108, 109, 110, 111]):
+        v = env.peek()
+        p = v.current_player
+        pl = v.players[p]
+        pl.hand[0] = w
+        v.drawn_tile = w
+        env.poke(v)
+        env.step({p: pack_action(DISCARD, w)})
+    r = [e for e in evs(env) if e["type"] == "ryukyoku"][-1]
+    assert r["reason"] == "sufuurenta" and r["deltas"] == [0, 0, 0, 0]
+
+
+def sc_riichi_stage_only_tenpai_maintaining_discards(make):
+    """tests.rs:936-1005: after the Riichi declaration (tile = None, MJAI style) the seat is in the riichi stage, not yet declared;
+    its list holds only discards that keep 123456789m 12p 11s tenpai (the drawn 5sr among them) and no second Riichi."""
+    env = make(game_mode=2)
+    env.reset()
+    v = env.peek()
+    pid = v.current_player
+    _set_hand(v.players[pid], sorted([0, 4, 8, 12, 16, 20, 24, 28, 32, 36, 40, 72, 73, 88]))
+    v.players[pid].score = 25000
+    v.drawn_tile = 88
+    v.phase = WAIT_ACT
+    v.active_mask = 1 << pid
+    env.poke(v)
+    env.step({pid: pack_action(RIICHI)})
+    pl = env.peek().players[pid]
+    assert pl.riichi_stage == 1 and pl.riichi_declared == 0
+    legal = [unpack_action(a) for a in env.legal(pid)]
+    discards = [tl for t, tl, _ in legal if t == DISCARD]
+    assert discards and 88 in discards and RIICHI not in [t for t, _, _ in legal]
+    from oracle import oracle
+
+    hand = list(pl.hand[: pl.hand_len])
+    for tl in discards:              # HandEvaluator(hand - tile).is_tenpai(): shanten 0 of the remaining thirteen
+        rest = list(hand)
+        rest.remove(tl)
+        cnt = [[0] * 34]
+        for t in rest:
+            cnt[0][t // 4] += 1
+        assert int(oracle.shanten(cnt)[0]) == 0, tl
+
+
+def sc_no_tobi_with_positive_scores(make):
+    """tests.rs:1007-1040 (+ 270-311 for the bust case elsewhere): a hanchan goes on after a round when nobody is below zero."""
+    env = make(game_mode=2)
+    env.reset()
+    v = env.peek()
+    hand = list(v.players[0].hand[: v.players[0].hand_len])
+    bad = next(t for t in range(136) if t not in hand)
+    env.step({0: pack_action(DISCARD, bad)})                   # a penalty round end: 13000 / 29000 x 3, all positive
+    v = env.peek()
+    assert not v.is_done and all(v.players[p].score > 0 for p in range(4))
+
+
 def sc_riichi_sequence(make):
     """docs/RULES.md:64-78, tests/env/rule_validation/test_riichi_sequence.py: reach -> dahai -> reach_accepted
     -> tsumo; riichi discard restricted to tenpai-keeping tiles; stick paid on acceptance; ippatsu tsumo."""
@@ -1667,7 +1733,8 @@ SCENARIOS = [sc_win_results_of_the_final_round, sc_paishan_dora_indices, sc_kaka
              sc_env_basic_step_processing, sc_env_pon_claim, sc_env_pon_red_dora_claim, sc_env_chi_claim, sc_env_chi_claim_with_red_dora,
              sc_env_chi_claim_with_invalid_tile, sc_env_chi_claim_with_invalid_combo, sc_env_chi_multiple_patterns, sc_env_ron_claim,
              sc_env_ankan_riichi_legality, sc_daiminkan_pao_daisangen, sc_daiminkan_pao_daisuushii, sc_daiminkan_no_pao_insufficient_melds,
-             sc_tenhou_tsumo_pao_composite, sc_tenhou_ron_pao_composite, sc_riichi_sequence, sc_kyushu_kyuhai, sc_double_ron_honba_sticks,
+             sc_tenhou_tsumo_pao_composite, sc_tenhou_ron_pao_composite, sc_ryukyoku_deltas_are_reset_each_round_4p,
+             sc_riichi_stage_only_tenpai_maintaining_discards, sc_no_tobi_with_positive_scores, sc_riichi_sequence, sc_kyushu_kyuhai, sc_double_ron_honba_sticks,
              sc_tobi_and_agariyame,
              sc_furiten_ron, sc_temporary_furiten, sc_valid_ankan_after_riichi, sc_no_claims_during_riichi,
              sc_honba_reset_and_increment, sc_pao_ron_honba, sc_doujun_cleared_by_call,

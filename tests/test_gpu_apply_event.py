@@ -42,7 +42,7 @@ def _compare(env, games, step_no):
                 assert cnt[g, s] == 0
 
 
-def _run_streams(mode, streams):
+def _run_streams(mode, streams, prepare=None):
     from oracle import oracle
     from riichienv_amd import vecenv
 
@@ -52,6 +52,12 @@ def _run_streams(mode, streams):
     env.reset()
     for o in games:
         o.reset()
+    if prepare:
+        for g, o in enumerate(games):
+            v = o.peek()
+            prepare(v)
+            o.poke(v)
+            env.poke(g, v)
     for k in range(max(len(s) for s in streams)):
         evs = [s[k] if k < len(s) else None for s in streams]
         env.apply_events(evs)
@@ -103,3 +109,24 @@ def test_replay_own_logs(mode):
             o.step(o.random_actions(77, g))
         streams.append([json.loads(x) for x in o.log()])
     _run_streams(mode, streams)
+
+
+@pytest.mark.parametrize("mode,npl", [(2, 4), (5, 3)])
+def test_start_kyoku_after_a_depleted_round(mode, npl):
+    """riichienv-core/src/tests.rs:576-834 on the device: start_kyoku rewinds the wall and resets drawable_count (left at 1 by the
+    poke), the first tsumo takes one tile, a reach-eligible tenpai is offered Riichi (issue #198); every event compared with the
+    oracle."""
+    def deplete(v):
+        v.drawable_count = 1
+
+    score = [25000] * 4 if npl == 4 else [35000] * 3
+    # (the Rust tests deal thirteen copies of one tile to a seat; the device counts types in 3-bit fields, so playable hands here)
+    plain = [["1p", "4p", "7p", "1s", "4s", "7s", "E", "S", "W", "N", "P", "F", "C"], ["2p", "5p", "8p", "2s", "5s", "8s", "E", "S", "W", "N", "P", "F", "C"],
+             ["3p", "6p", "9p", "3s", "6s", "9s", "E", "S", "W", "N", "P", "F", "C"], ["1p", "5p", "9p", "1s", "5s", "9s", "E", "S", "W", "N", "P", "F", "9m"]]
+    sk1 = start_kyoku(plain[:npl], oya=1, scores=score)
+    sk1["kyoku"], sk1["dora_marker"] = 2, "1p"
+    tehai = (["1m", "2m", "3m", "4m", "5m", "6m", "7m", "8m", "9m", "1p", "2p", "3p", "1s"] if npl == 4 else
+             ["1p", "2p", "3p", "4p", "5p", "6p", "7p", "8p", "9p", "1s", "2s", "3s", "9m"])
+    sk2 = start_kyoku([tehai] + [["1z"] * 13 for _ in range(npl - 1)], oya=0, scores=score)
+    sk2["kyoku"], sk2["dora_marker"] = 2, "9s"
+    _run_streams(mode, [[sk1, {"type": "tsumo", "actor": 1, "pai": "5p"}], [sk2, {"type": "tsumo", "actor": 0, "pai": "E"}]], prepare=deplete)

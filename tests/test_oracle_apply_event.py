@@ -125,3 +125,41 @@ def test_riichi_furiten_persists_after_own_discard():
     from tests.apply_events_util import furiten_log
 
     assert _pass_observations_of_seat1(furiten_log(True)) == [True]
+
+
+_REACH_TEHAI = ["1m", "2m", "3m", "4m", "5m", "6m", "7m", "8m", "9m", "1p", "2p", "3p", "1s"]
+
+
+@pytest.mark.parametrize("mode,npl,wall,live", [(2, 4, 84, 70), (5, 3, 69, 55)])
+def test_start_kyoku_rewinds_the_wall_and_the_tile_count(mode, npl, wall, live):
+    """riichienv-core/src/tests.rs:576-668 (4P), 707-795 (3P): start_kyoku rewinds the wall to before the dealer's draw and resets
+    drawable_count whatever an earlier round left; the first tsumo takes one tile."""
+    g = oracle.Game(game_mode=mode)
+    assert g.peek().wall_len == wall - 1                      # the constructor's round has drawn already
+    v = g.peek()
+    v.drawable_count = 1                                       # a depleted earlier round
+    g.poke(v)
+    tehais = [[f"{1 + p}p"] * 13 for p in range(npl)]
+    sk = start_kyoku(tehais, oya=1, scores=[25000] * npl if npl == 4 else [35000] * npl)
+    sk["kyoku"], sk["dora_marker"] = 2, "1p"
+    feed(g, [sk])
+    v = g.peek()
+    assert (v.wall_len, v.drawable_count, v.needs_tsumo, v.drawn_tile) == (wall, live, 1, -1)
+    g.apply_event({"type": "tsumo", "actor": 1, "pai": "5p"})
+    v = g.peek()
+    assert (v.wall_len, v.drawable_count) == (wall - 1, live - 1)
+
+
+@pytest.mark.parametrize("mode,npl", [(2, 4), (5, 3)])
+def test_replay_start_kyoku_offers_reach(mode, npl):
+    """tests.rs:669-706 (4P), 796-834 (3P), issue #198: a reach-eligible tenpai right after a replayed start_kyoku is offered Riichi
+    although the earlier round ended with drawable_count = 1.  (3P: the manzu 2-8 of the 4P fixture are replaced by pinzu / souzu.)"""
+    g = oracle.Game(game_mode=mode)
+    v = g.peek()
+    v.drawable_count = 1
+    g.poke(v)
+    tehai = _REACH_TEHAI if npl == 4 else ["1p", "2p", "3p", "4p", "5p", "6p", "7p", "8p", "9p", "1s", "2s", "3s", "9m"]
+    sk = start_kyoku([tehai] + [["1z"] * 13 for _ in range(npl - 1)], oya=0, scores=[25000] * npl if npl == 4 else [35000] * npl)
+    sk["kyoku"], sk["dora_marker"] = 2, "9s"
+    feed(g, [sk, {"type": "tsumo", "actor": 0, "pai": "E"}])
+    assert abi.RIICHI in types_of(g, 0)

@@ -1162,6 +1162,29 @@ def sc_riichi_stage_only_tenpai_maintaining_discards(make):
         assert int(oracle.shanten(cnt)[0]) == 0, tl
 
 
+def sc_reach_accepted_event_includes_actor(make):
+    """tests.rs:857-934: Riichi (tile = None), the 5sr discard, everybody passes: the log holds a reach_accepted event with the
+    declarer as actor and the pending acceptance is cleared."""
+    env = make(game_mode=2)
+    env.reset()
+    v = env.peek()
+    pid = v.current_player
+    _set_hand(v.players[pid], sorted([0, 4, 8, 12, 16, 20, 24, 28, 32, 36, 40, 72, 73, 88]))
+    v.players[pid].score = 25000
+    v.drawn_tile = 88
+    v.phase = WAIT_ACT
+    v.active_mask = 1 << pid
+    env.poke(v)
+    env.step({pid: pack_action(RIICHI)})
+    env.step({pid: pack_action(DISCARD, 88)})
+    act, ph, _ = env.status()
+    if ph == WAIT_RESPONSE:
+        env.step({s: pack_action(PASS) for s in range(4) if (act >> s) & 1})
+    ra = [e for e in evs(env) if e["type"] == "reach_accepted"]
+    assert ra and ra[0]["actor"] == pid
+    assert env.peek().riichi_pending_acceptance == -1
+
+
 def sc_no_tobi_with_positive_scores(make):
     """tests.rs:1007-1040 (+ 270-311 for the bust case elsewhere): a hanchan goes on after a round when nobody is below zero."""
     env = make(game_mode=2)
@@ -1734,7 +1757,7 @@ SCENARIOS = [sc_win_results_of_the_final_round, sc_paishan_dora_indices, sc_kaka
              sc_env_chi_claim_with_invalid_tile, sc_env_chi_claim_with_invalid_combo, sc_env_chi_multiple_patterns, sc_env_ron_claim,
              sc_env_ankan_riichi_legality, sc_daiminkan_pao_daisangen, sc_daiminkan_pao_daisuushii, sc_daiminkan_no_pao_insufficient_melds,
              sc_tenhou_tsumo_pao_composite, sc_tenhou_ron_pao_composite, sc_ryukyoku_deltas_are_reset_each_round_4p,
-             sc_riichi_stage_only_tenpai_maintaining_discards, sc_no_tobi_with_positive_scores, sc_riichi_sequence, sc_kyushu_kyuhai, sc_double_ron_honba_sticks,
+             sc_riichi_stage_only_tenpai_maintaining_discards, sc_reach_accepted_event_includes_actor, sc_no_tobi_with_positive_scores, sc_riichi_sequence, sc_kyushu_kyuhai, sc_double_ron_honba_sticks,
              sc_tobi_and_agariyame,
              sc_furiten_ron, sc_temporary_furiten, sc_valid_ankan_after_riichi, sc_no_claims_during_riichi,
              sc_honba_reset_and_increment, sc_pao_ron_honba, sc_doujun_cleared_by_call,

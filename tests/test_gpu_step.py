@@ -1,6 +1,7 @@
 """GPU parity (the hot path): VecRiichiEnv through the C-ABI vs the oracle, game by game and
 step by step — full state, ordered legal lists, masks, waits, MJAI event strings, scores."""
 from riichienv_amd.shard import game_seed
+import os
 import numpy as np
 import pytest
 
@@ -267,7 +268,8 @@ def test_two_stream_rollout_equals_single_stream(mode):
     for g in (0, B // 4 - 1, B // 4, B // 2, 3 * B // 4 - 1, B - 1):
         assert a.mjai_log(g) == b.mjai_log(g)
     r = a.bench_rollout(0xBEEF, 0, 10)
-    assert r.launches == 1 and r.launches_in_flight == 1      # the fused rollout: one launch, every wave loops over the steps
+    if os.environ.get("RMJ_STEP4", "2") == "2":                   # the default: the fused rollout, one launch, every wave loops
+        assert r.launches == 1 and r.launches_in_flight == 1
 
 
 @pytest.mark.parametrize("mode", [2, 5])

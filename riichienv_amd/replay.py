@@ -145,6 +145,31 @@ class Kyoku:
         """LogKyoku.take_win_result_contexts (replay/mod.rs:1089-1091)"""
         return WinResultContextIterator(self, ankan_from_consumed)
 
+    game_end_scores = None        # set by MjSoulReplay.from_dict (None for MJAI logs, mjai_replay.rs:266)
+
+    @staticmethod
+    def _ranks(scores):
+        """get_ranks (replay/mod.rs:1542-1552): 0 = top; equal scores rank by seat index"""
+        order = sorted(range(len(scores)), key=lambda i: (-scores[i], i))
+        ranks = [0] * len(scores)
+        for r, seat in enumerate(order):
+            ranks[seat] = r
+        return ranks
+
+    def take_grp_features(self):
+        """LogKyoku.take_grp_features (replay/mod.rs:1524-1589): the round's scores / ranks before and after, the final ranks of
+        the game (from game_end_scores when the reader computed them, else the round's own end ranks) and the dealt hands as ids"""
+        ini = list(self.scores)
+        end = list(self.end_scores) if self.end_scores else ini
+        ri, re_ = self._ranks(ini), self._ranks(end)
+        out = dict(chang=self.chang, ju=self.ju, ben=self.ben, liqibang=self.liqibang,
+                   round_initial_scores=ini, round_end_scores=end, round_delta_scores=[e - s_ for s_, e in zip(ini, end)],
+                   round_initial_ranks=ri, round_end_ranks=re_, round_delta_ranks=[e - s_ for s_, e in zip(ri, re_)],
+                   final_ranks=self._ranks(self.game_end_scores) if self.game_end_scores is not None else list(re_))
+        for i, h in enumerate(self.hands):
+            out[f"player{i}_initial_hand_tids"] = [abi.mjai_to_tid(t, True) for t in h]
+        return out
+
     def grp_features(self):
         """LogKyoku.grp_features (replay/mod.rs:1502-1522)"""
         return dict(chang=self.chang, ju=self.ju, ben=self.ben, liqibang=self.liqibang, scores=list(self.scores),
@@ -459,6 +484,253 @@ def evaluate_win_contexts(contexts, device=0):
     return contexts
 
 
+def _gpu_tenpai(cases, device=0):
+    """HandEvaluator(hand, melds).is_tenpai() of many hands in one rmj_eval_hands launch"""
+    from .vecenv import eval_hands
+
+    return [bool(r.is_tenpai) for r in eval_hands(cases, device=device)] if cases else []
+
+
+class LogRoundWalker:
+    """GameState / GameState3P::apply_log_action (state/event_handler.rs:332-891, state_3p/event_handler.rs:365-840) reduced to
+    what decides the scores: the record's actions move tiles between hands, melds and rivers, riichi deposits are taken when the
+    next draw / call / draw-end confirms them (a Ron on the riichi discard voids the deposit), a Hule pays the points the RECORD
+    carries (point_rong / point_zimo_qin / point_zimo_xian, honba added here, pao split from the melds the walker saw), an
+    exhaustive draw pays nagashi mangan or the tenpai / noten payments.  The one piece of hand math - is_tenpai of the hands at
+    NoTile - is left to the caller (`pending_cases` -> `finish`), so many records resolve it in one GPU launch."""
+
+    _NO_COND = dict(tsumo=False, riichi=False, double_riichi=False, ippatsu=False, haitei=False, houtei=False, rinshan=False,
+                    chankan=False, tsumo_first_turn=False, player_wind=0, round_wind=0, honba=0, kita_count=0)
+
+    def __init__(self, k: Kyoku):
+        n = self.n = len(k.scores)
+        if n not in (3, 4):              # try_into().unwrap_or(...) of mjsoul_replay.rs:266, :299
+            n = self.n = 4
+            self.scores = [25000] * 4
+        else:
+            self.scores = list(k.scores)
+        self.oya = k.ju % n
+        self.honba, self.sticks = k.ben, k.liqibang
+        self.hands = [sorted(abi.mjai_to_tid(t, True) for t in (k.hands[i] if i < len(k.hands) else [])) for i in range(n)]
+        self.melds = [[] for _ in range(n)]
+        self.pao = [dict() for _ in range(n)]
+        self.nagashi = [True] * n
+        self.declared = [False] * n
+        self.pending_riichi = None
+        self.last_discard = None
+        self.current = self.oya
+        self.actions = list(k.actions)
+        self.pos = 0
+        self.pending_cases = None
+
+    def _take_deposit(self):
+        if self.pending_riichi is not None:
+            self.scores[self.pending_riichi] -= 1000
+            self.sticks += 1
+            self.pending_riichi = None
+
+    @staticmethod
+    def _remove(hand, t):
+        if t in hand:
+            hand.remove(t)
+
+    def run(self):
+        """Applies actions until the end, or until a NoTile needs the tenpai flags (then pending_cases holds one HandCase per
+        seat and finish() resumes).  Returns True when the round is complete."""
+        while self.pos < len(self.actions):
+            a = self.actions[self.pos]
+            self.pos += 1
+            name = a["name"]
+            n = self.n
+            if name == "DiscardTile":
+                s, t = a["seat"], abi.mjai_to_tid(a["tile"], True)
+                self._remove(self.hands[s], t)
+                self.nagashi[s] = self.nagashi[s] and (t // 4 >= 27 or (t // 4) % 9 in (0, 8))
+                if a["is_liqi"] or a["is_wliqi"]:
+                    if n == 3 or not self.declared[s]:
+                        self.pending_riichi = s
+                    self.declared[s] = True
+                self.last_discard = (s, t)
+                self.current = (s + 1) % n
+            elif name == "DealTile":
+                self._take_deposit()
+                self.hands[a["seat"]].append(abi.mjai_to_tid(a["tile"], True))
+                self.current = a["seat"]
+            elif name == "ChiPengGang":
+                self._take_deposit()
+                s = a["seat"]
+                if self.last_discard is not None:
+                    self.nagashi[self.last_discard[0]] = False
+                tiles = [abi.mjai_to_tid(t, True) for t in a["tiles"]]
+                froms = list(a["froms"])
+                for i, t in enumerate(tiles):
+                    if i < len(froms) and froms[i] == s:
+                        self._remove(self.hands[s], t)
+                other = [(t, f) for t, f in zip(tiles, froms) if f != s]
+                from_who = other[0][1] if other else -1
+                ct = other[0][0] if other else None
+                kind = a["meld_type"]
+                self.melds[s].append(dict(meld_type=_MELD_ID[kind], tiles=tiles, opened=True, from_who=from_who, called_tile=ct))
+                if kind in ("Pon", "Daiminkan") and ct is not None:
+                    groups = [m["tiles"][0] // 4 for m in self.melds[s] if m["meld_type"] != abi.MELD_CHI]
+                    if 31 <= ct // 4 <= 33 and sum(31 <= g <= 33 for g in groups) == 3:
+                        self.pao[s][37] = max(from_who, 0)
+                    elif 27 <= ct // 4 <= 30 and sum(27 <= g <= 30 for g in groups) == 4:
+                        self.pao[s][50] = max(from_who, 0)
+                self.current = s
+            elif name == "AnGangAddGang":
+                s, t = a["seat"], abi.mjai_to_tid(a["tiles"][0], True)
+                if a["meld_type"] == "Ankan":
+                    for _ in range(4):
+                        for i, x in enumerate(self.hands[s]):
+                            if x // 4 == t // 4:
+                                del self.hands[s][i]
+                                break
+                    b = t // 4 * 4
+                    self.melds[s].append(dict(meld_type=abi.MELD_ANKAN, tiles=[b, b + 1, b + 2, b + 3], opened=False, from_who=-1,
+                                              called_tile=None))
+                else:
+                    self._remove(self.hands[s], t)
+                    for m in self.melds[s]:
+                        if m["meld_type"] == abi.MELD_PON and m["tiles"][0] // 4 == t // 4:
+                            m["meld_type"] = abi.MELD_KAKAN
+                            m["tiles"] = sorted(m["tiles"] + [t])
+                            break
+                self.last_discard = (s, t)
+                self.current = s
+            elif name == "BaBei" and n == 3:
+                self._take_deposit()
+                s = a["seat"]
+                for i, x in enumerate(self.hands[s]):
+                    if x // 4 == 30:
+                        self.last_discard = (s, x)
+                        del self.hands[s][i]
+                        break
+                self.current = s
+            elif name == "Hule":
+                self._hule(a["hules"])
+            elif name == "NoTile":
+                self._take_deposit()
+                winners = [i for i in range(n) if self.nagashi[i]]
+                if winners:
+                    for w in winners:          # mangan tsumo without honba: calculate_score(5, 30, is_oya, true, 0, np)
+                        for i in range(n):
+                            if i != w:
+                                pay = 4000 if (w == self.oya or i == self.oya) else 2000
+                                self.scores[i] -= pay
+                                self.scores[w] += pay
+                else:
+                    self.pending_cases = [WinResultContext(seat=i, tiles=list(self.hands[i]), melds=[dict(m) for m in self.melds[i]],
+                                                           agari_tile=0, dora_indicators=[], ura_indicators=[],
+                                                           conditions=self._NO_COND, sanma=n == 3).hand_case() for i in range(n)]
+                    return False
+            elif name == "LiuJu":
+                if n == 4:                     # (the 3P handler leaves a pending deposit alone, state_3p/event_handler.rs:834-837)
+                    self._take_deposit()
+        return True
+
+    def finish(self, tenpai):
+        """the tenpai flags of pending_cases -> the noten payments (3000 shared among four, 2000 among three), then the rest"""
+        n = self.n
+        self.pending_cases = None
+        num = sum(bool(t) for t in tenpai)
+        if 0 < num < n:
+            pot = 3000 if n == 4 else 2000
+            for i, tp in enumerate(tenpai):
+                self.scores[i] += pot // num if tp else -(pot // (n - num))
+        return self.run()
+
+    def _hule(self, hules):
+        n, oya = self.n, self.oya
+        tsumo = lambda h: h["zimo"] and (n == 4 or h["seat"] == self.current)   # noqa: E731  (3P: a zimo flag on another seat's turn is a Ron)
+        if hules and not tsumo(hules[0]):
+            self.pending_riichi = None
+        honba, sticks, honba_taken = self.honba, self.sticks, False
+        for h in hules:
+            w = h["seat"]
+            total = pao_val = 0
+            payer = None
+            if h.get("yiman"):
+                for y in h.get("fans", []):
+                    val = 2 if y in (47, 48, 49, 50) else 1
+                    total += val
+                    if y in self.pao[w]:
+                        pao_val += val
+                        payer = self.pao[w][y]
+            qin, xian, rong = int(h.get("point_zimo_qin", 0)), int(h.get("point_zimo_xian", 0)), int(h.get("point_rong", 0))
+
+            def move(src, amount):
+                self.scores[src] -= amount
+                self.scores[w] += amount
+
+            if tsumo(h):
+                is_oya = w == oya
+                if pao_val > 0 and n == 4:
+                    unit = 48000 if is_oya else 32000
+                    move(payer, pao_val * unit)
+                    rest = (total - pao_val) * unit
+                    if rest > 0:
+                        for i in range(4):
+                            if i != w:
+                                move(i, rest // 3 if is_oya else (rest // 2 if i == oya else rest // 4))
+                    move(payer, honba * 300)
+                elif pao_val > 0:
+                    whole = xian * 2 if is_oya else qin + xian
+                    pao_amt = whole * pao_val // total
+                    rest = whole - pao_amt
+                    move(payer, pao_amt)
+                    if rest > 0:
+                        for i in range(3):
+                            if i != w:
+                                move(i, rest // 2 if is_oya else ((qin if i == oya else xian) * rest // whole))
+                    move(payer, honba * 200)
+                else:
+                    for i in range(n):
+                        if i != w:
+                            move(i, (xian if (is_oya or i != oya) else qin) + honba * 100)
+            elif self.last_discard is not None:
+                target = self.last_discard[0]
+                hb = 0 if honba_taken else honba * 100 * (n - 1)
+                honba_taken = True
+                if n == 4:
+                    # (the 4P handler takes the first pao entry among the fans, whatever the yakuman count)
+                    p4 = next((self.pao[w][y] for y in h.get("fans", []) if h.get("yiman") and y in self.pao[w]), None)
+                    if p4 is not None:           # the liable seat and the discarder pay half each; the winner receives point_rong
+                        self.scores[p4] -= rong // 2 + hb
+                        self.scores[target] -= rong // 2
+                        self.scores[w] += rong + hb
+                    else:
+                        move(target, rong + hb)
+                elif pao_val > 0:
+                    pao_amt = rong * pao_val // total
+                    move(payer if payer is not None else target, pao_amt // 2 + hb)
+                    move(target, rong - pao_amt // 2)
+                else:
+                    move(target, rong + hb)
+        if hules:
+            self.scores[hules[0]["seat"]] += sticks * 1000
+            self.sticks = 0
+
+
+def game_end_scores(kyokus, tenpai=None, device=0):
+    """The end scores of many rounds (the last round of each record: mjsoul_replay.rs:259-339) - every walker runs on the host,
+    the is_tenpai checks of all exhaustive draws go out as ONE rmj_eval_hands batch.  `tenpai` maps a list of HandCases to
+    flags (default: the GPU)."""
+    walkers = [LogRoundWalker(k) for k in kyokus]
+    waiting = [w for w in walkers if not w.run()]
+    while waiting:
+        cases = [c for w in waiting for c in w.pending_cases]
+        flags = (tenpai or (lambda cs: _gpu_tenpai(cs, device)))(cases)
+        nxt, at = [], 0
+        for w in waiting:
+            k = len(w.pending_cases)
+            if not w.finish(flags[at: at + k]):
+                nxt.append(w)
+            at += k
+        waiting = nxt
+    return [list(w.scores) for w in walkers]
+
+
 class MjaiReplay:
     """MjaiReplay (replay/mjai_replay.rs:270-384): an MJAI log split into rounds.  `steps` of the reference's kyoku objects
     (observation, action) is ReplayBatch.samples() here (many logs in lock-step on the GPU)."""
@@ -586,8 +858,8 @@ class MjSoulReplay:
     actions starting with NewRound - as the same Kyoku objects MjaiReplay yields (tile names are translated to MJAI names, the
     action vocabulary is the reference's own, replay/mod.rs:35-80).  The reference ships no MjSoul record; the reader follows
     the serde schema of mjsoul_replay.rs (field aliases, defaults, `#[serde(other)]`) and is tested on records converted from
-    games the oracle played (tests/test_mjsoul_replay.py).  Not built: from_dict's game_end_scores, which the reference gets
-    by replaying the last round through GameState.apply_log_action."""
+    games the oracle played (tests/test_mjsoul_replay.py).  from_dict also yields game_end_scores (the last round replayed by
+    LogRoundWalker, the reference's GameState.apply_log_action; from_json does not, as in the reference)."""
 
     _MELD = {0: "Chi", 1: "Pon", 2: "Daiminkan", 3: "Ankan"}
 
@@ -611,15 +883,31 @@ class MjSoulReplay:
         return cls._from_rounds(log["rounds"])
 
     @classmethod
-    def from_dict(cls, paifu):
-        """mjsoul_replay.rs:196-240: a paifu dict {"data": rounds, ...} or the list of rounds itself"""
-        if isinstance(paifu, dict):
-            if "data" not in paifu:
-                raise ValueError("Invalid dict format: missing 'data'")
-            return cls._from_rounds(paifu["data"])
-        if isinstance(paifu, list):
-            return cls._from_rounds(paifu)
-        raise ValueError("Invalid input format: expected dict or list")
+    def from_dict(cls, paifu, tenpai=None, device=0):
+        """mjsoul_replay.rs:196-342: a paifu dict {"data": rounds, ...} or the list of rounds itself.  Like the reference this
+        entry also replays the last round through the log walker (LogRoundWalker = apply_log_action): its result is the last
+        round's end_scores and every round's game_end_scores (take_grp_features' final_ranks).  `tenpai`: see game_end_scores."""
+        return cls.from_dicts([paifu], tenpai=tenpai, device=device)[0]
+
+    @classmethod
+    def from_dicts(cls, paifus, tenpai=None, device=0):
+        """from_dict of many records; the tenpai checks of all their final exhaustive draws share one GPU launch"""
+        out = []
+        for paifu in paifus:
+            if isinstance(paifu, dict):
+                if "data" not in paifu:
+                    raise ValueError("Invalid dict format: missing 'data'")
+                out.append(cls._from_rounds(paifu["data"]))
+            elif isinstance(paifu, list):
+                out.append(cls._from_rounds(paifu))
+            else:
+                raise ValueError("Invalid input format: expected dict or list")
+        with_rounds = [r for r in out if r.rounds]
+        for r, ges in zip(with_rounds, game_end_scores([r.rounds[-1] for r in with_rounds], tenpai=tenpai, device=device)):
+            r.rounds[-1].end_scores = list(ges)
+            for k in r.rounds:
+                k.game_end_scores = list(ges)
+        return out
 
     @classmethod
     def _from_rounds(cls, rounds_raw):

@@ -29,8 +29,9 @@ def tid_to_mjsoul(t):
     return f"{t34 % 9 + 1}{'mpsz'[t34 // 9]}"
 
 
-def play_logged_game(mode, seed, rule=abi.RULE_MJSOUL, max_steps=8000):
-    """(MJAI events, walls): walls[i] = the 136-ids of round i's wall in draw order (= MjSoul's paishan)"""
+def play_logged_game(mode, seed, rule=abi.RULE_MJSOUL, max_steps=8000, with_scores=False):
+    """(MJAI events, walls): walls[i] = the 136-ids of round i's wall in draw order (= MjSoul's paishan); with_scores adds the
+    scores the oracle's game ended with"""
     from oracle import oracle
 
     sanma = mode >= 3
@@ -91,6 +92,9 @@ def play_logged_game(mode, seed, rule=abi.RULE_MJSOUL, max_steps=8000):
     events = [json.loads(s) for s in o.log()]
     n_rounds = sum(e["type"] == "start_kyoku" for e in events)
     assert len(walls) >= n_rounds
+    if with_scores:
+        v = o.peek()
+        return events, walls[:n_rounds], [int(v.players[i].score) for i in range(npl)]
     return events, walls[:n_rounds]
 
 
@@ -181,8 +185,9 @@ def to_mjsoul_rounds(events, walls, with_paishan=True, expectations=None):
             else:
                 hu = last["data"]["tile"]
             h = dict(seat=a, hu_tile=hu, zimo=zimo, count=exp.get("count", 0), fu=exp.get("fu", 0),
-                     fans=[{"id": y, "val": 1} for y in exp.get("fans", [])] + [{"id": 99, "val": 0}], hand=[], yiman=False,
-                     point_rong=0, point_zimo_qin=0, point_zimo_xian=0)
+                     fans=[{"id": y, "val": 1} for y in exp.get("fans", [])] + [{"id": 99, "val": 0}], hand=[], yiman=bool(exp.get("yiman", False)),
+                     point_rong=exp.get("point_rong", 0), point_zimo_qin=exp.get("point_zimo_qin", 0),
+                     point_zimo_xian=exp.get("point_zimo_xian", 0))
             if "paishan" not in cur[0]["data"] and ev.get("ura_markers"):
                 h["li_doras"] = [mjai_to_mjsoul(t) for t in ev["ura_markers"]]
             st["hules"] = (st["hules"] or []) + [h]

@@ -107,6 +107,34 @@ def test_mjsoul_records_verified_in_one_gpu_batch():
     assert total >= 4
 
 
+def test_mjsoul_game_end_scores_with_the_gpu_tenpai_batch():
+    """MjSoulReplay.from_dict / from_dicts with their default is_tenpai evaluator (rmj_eval_hands, one launch for all the
+    exhaustive draws): every round of two oracle-played games, each as the last round of its own record, ends with the scores
+    the next round starts with; the whole record ends with the scores of the oracle's game (mjsoul_replay.rs:259-339)."""
+    from oracle import oracle
+    from riichienv_amd.replay import MjSoulReplay
+    from tests.mjsoul_util import play_logged_game, to_mjsoul_rounds
+
+    draws = 0
+    for mode, seed in ((2, 2), (5, 2)):
+        events, walls, final = play_logged_game(mode, seed, with_scores=True)
+        plain = MjSoulReplay.from_dict(to_mjsoul_rounds(events, walls))
+        ctxs = [c for k in plain.take_kyokus() for c in k.take_win_result_contexts()]
+        res = oracle.eval_hands([c.hand_case() for c in ctxs])
+        exp = {i: dict(count=r.han, fu=r.fu, fans=list(r.yaku[: r.n_yaku]), yiman=bool(r.yakuman), point_rong=r.ron_agari,
+                       point_zimo_qin=r.tsumo_agari_oya, point_zimo_xian=r.tsumo_agari_ko) for i, r in enumerate(res)}
+        rounds = to_mjsoul_rounds(events, walls, expectations=exp)
+        whole = MjSoulReplay.from_dict({"data": rounds})
+        ks = list(whole.take_kyokus())
+        assert ks[0].game_end_scores == final and ks[-1].end_scores == final
+        singles = MjSoulReplay.from_dicts([[r] for r in rounds])
+        for i, x in enumerate(singles):
+            want = ks[i + 1].scores if i + 1 < len(ks) else final
+            assert x.rounds[0].game_end_scores == want, (mode, seed, i)
+            draws += ks[i].actions[-1]["name"] == "NoTile"
+    assert draws >= 4
+
+
 def test_pass_samples_carry_the_missed_ron_furiten():
     """tests/env/test_apply_event.py:535-632 (TestReplayFuriten) on ReplayBatch: a seat that lets a Ron go is in same-turn furiten
     until its own discard (the second 3m is offered again), in riichi for good (the second 3m yields no sample at all)."""

@@ -26,6 +26,12 @@ def _oracle_eval(ctxs):
     return ctxs
 
 
+def _oracle_tenpai(cases):
+    from oracle import oracle
+
+    return [bool(r.is_tenpai) for r in oracle.eval_hands(list(cases))] if cases else []
+
+
 def _replacement_draw_wins(events):
     """per hora event: was it a tsumo on the replacement draw of a kan / kita"""
     out, hist = [], []
@@ -122,16 +128,135 @@ def test_records_of_played_games_reconstruct_every_win(mode, seed, tmp_path):
 
 def test_verify_counts_mismatches():
     events, walls = play_logged_game(2, 1)
-    plain = MjSoulReplay.from_dict(to_mjsoul_rounds(events, walls))
+    plain = MjSoulReplay.from_dict(to_mjsoul_rounds(events, walls), tenpai=_oracle_tenpai)
     ctxs = _oracle_eval([c for k in plain.take_kyokus() for c in k.take_win_result_contexts()])
     exp = {i: dict(count=c.actual.han, fu=c.actual.fu, fans=list(c.actual.yaku[: c.actual.n_yaku])) for i, c in enumerate(ctxs)}
     n = len(ctxs)
     assert n >= 3
     # the same games without the wall (indicators from the records' own `doras` lists, ura indicators from li_doras)
     for with_wall in (True, False):
-        r = MjSoulReplay.from_dict(to_mjsoul_rounds(events, walls, with_paishan=with_wall, expectations=exp))
+        r = MjSoulReplay.from_dict(to_mjsoul_rounds(events, walls, with_paishan=with_wall, expectations=exp), tenpai=_oracle_tenpai)
         got = r.verify(evaluate=_oracle_eval)
         assert got == (n, 0), (with_wall, got)
     exp[0]["fu"] += 10
     exp[1]["fans"] = exp[1]["fans"] + [1] if 1 not in exp[1]["fans"] else [y for y in exp[1]["fans"] if y != 1]
-    assert MjSoulReplay.from_dict(to_mjsoul_rounds(events, walls, expectations=exp)).verify(evaluate=_oracle_eval)[1] >= 1
+    assert MjSoulReplay.from_dict(to_mjsoul_rounds(events, walls, expectations=exp), tenpai=_oracle_tenpai).verify(evaluate=_oracle_eval)[1] >= 1
+
+
+def _records_with_points(events, walls):
+    """the records of a played game whose Hule entries carry what Mahjong Soul writes: yaku ids, the yakuman flag and the
+    points without honba (evaluated by the oracle from the reconstructed contexts)"""
+    plain = MjSoulReplay.from_dict(to_mjsoul_rounds(events, walls), tenpai=_oracle_tenpai)
+    ctxs = _oracle_eval([c for k in plain.take_kyokus() for c in k.take_win_result_contexts()])
+    exp = {i: dict(count=c.actual.han, fu=c.actual.fu, fans=list(c.actual.yaku[: c.actual.n_yaku]), yiman=bool(c.actual.yakuman),
+                   point_rong=c.actual.ron_agari, point_zimo_qin=c.actual.tsumo_agari_oya, point_zimo_xian=c.actual.tsumo_agari_ko)
+           for i, c in enumerate(ctxs)}
+    return to_mjsoul_rounds(events, walls, expectations=exp)
+
+
+def _per_round_records(rounds):
+    """every round as the last round of its own one-round record: the walker is checked on all rounds, not only the final one"""
+    return [[r] for r in rounds]
+
+
+@pytest.mark.parametrize("mode,seed", [(2, 1), (2, 2), (2, 5), (2, 7), (5, 2), (5, 3), (5, 4)])
+def test_game_end_scores_of_played_games(mode, seed):
+    """from_dict's game_end_scores (mjsoul_replay.rs:259-339: the last round replayed through apply_log_action): the scores the
+    walker ends with are the scores the oracle's game ended with; and, round by round, the start scores of the next round."""
+    events, walls, final = play_logged_game(mode, seed, with_scores=True)
+    rounds = _records_with_points(events, walls)
+    r = MjSoulReplay.from_dict({"data": rounds}, tenpai=_oracle_tenpai)
+    ks = list(r.take_kyokus())
+    assert ks[-1].game_end_scores == final and ks[0].game_end_scores == final and ks[-1].end_scores == final
+    f = ks[0].take_grp_features()
+    order = sorted(range(len(final)), key=lambda i: (-final[i], i))
+    assert [f["final_ranks"][s] for s in order] == list(range(len(final)))
+    assert f["round_initial_scores"] == ks[0].scores and f["round_end_scores"] == ks[1].scores
+    assert f["round_delta_scores"] == [b - a for a, b in zip(ks[0].scores, ks[1].scores)]
+    assert [len(f[f"player{i}_initial_hand_tids"]) for i in range(len(final))] == [14 if i == ks[0].ju else 13 for i in range(len(final))]
+    # each round alone: one batch over all of them (from_dicts), end of round i = start of round i + 1
+    singles = MjSoulReplay.from_dicts(_per_round_records(rounds), tenpai=_oracle_tenpai)
+    ends = [x.rounds[0].game_end_scores for x in singles]
+    kinds = set()
+    for i in range(len(ks) - 1):
+        assert ends[i] == ks[i + 1].scores, (i, ends[i], ks[i + 1].scores, [a["name"] for a in ks[i].actions][-2:])
+        kinds.add(ks[i].actions[-1]["name"])
+    assert ends[-1] == final
+    assert "Hule" in kinds
+
+
+def test_grp_features_of_an_mjai_kyoku_have_no_game_end_scores(tmp_path):
+    """mjai_replay.rs:266: MJAI rounds carry no game_end_scores - final_ranks falls back to the round's own end ranks"""
+    events, walls = play_logged_game(2, 1)
+    p = tmp_path / "g.jsonl"
+    write_jsonl(p, events)
+    k = next(iter(MjaiReplay.from_jsonl(str(p)).take_kyokus()))
+    f = k.take_grp_features()
+    assert k.game_end_scores is None and f["final_ranks"] == f["round_end_ranks"]
+    assert f["round_delta_ranks"] == [e - s for s, e in zip(f["round_initial_ranks"], f["round_end_ranks"])]
+
+
+def _round(scores, actions, oya=0, ben=0, liqibang=0, hands=None):
+    n = len(scores)
+    t13 = ["1m", "4m", "7m", "1p", "4p", "7p", "1s", "4s", "7s", "1z", "2z", "3z", "4z"]          # far from tenpai
+    d = dict(scores=list(scores), dora_marker="1s", chang=0, ju=oya, ben=ben, liqibang=liqibang)
+    for i in range(4):
+        d[f"tiles{i}"] = list((hands or {}).get(i, t13 + ["1m"] * (i == oya))) if i < n else []
+    return [{"name": "NewRound", "data": d}] + actions
+
+
+def _hule(seat, zimo, **kw):
+    h = dict(seat=seat, hu_tile="1m", zimo=zimo, count=1, fu=30, fans=[{"id": y, "val": 1} for y in kw.pop("fans", [1])], hand=[],
+             yiman=False, point_rong=0, point_zimo_qin=0, point_zimo_xian=0)
+    h.update(kw)
+    return h
+
+
+def _end(actions, **kw):
+    r = MjSoulReplay.from_dict([_round(kw.pop("scores", [25000] * 4), actions, **kw)], tenpai=_oracle_tenpai)
+    return r.rounds[0].game_end_scores
+
+
+def test_log_walker_rules_read_from_the_reference():
+    """apply_log_action's rules that the played games do not reach, as hand-made records (state/event_handler.rs:332-891,
+    state_3p/event_handler.rs:365-840)"""
+    D = lambda s, t, **kw: {"name": "DiscardTile", "data": dict(seat=s, tile=t, **kw)}        # noqa: E731
+    T = lambda s, t: {"name": "DealTile", "data": dict(seat=s, tile=t)}                        # noqa: E731
+    P = lambda s, t, frm: {"name": "ChiPengGang", "data": dict(seat=s, type=1, tiles=[t, t, t], froms=[s, s, frm])}   # noqa: E731
+    H = lambda *hs: {"name": "Hule", "data": {"hules": list(hs)}}                              # noqa: E731
+    # a Ron on the riichi discard voids the deposit; of a double Ron only the first winner takes honba and the sticks
+    got = _end([D(0, "1m", is_liqi=True), H(_hule(1, False, point_rong=2000), _hule(2, False, point_rong=3900))], ben=2, liqibang=1)
+    assert got == [25000 - 2000 - 600 - 3900, 25000 + 2000 + 600 + 1000, 25000 + 3900, 25000]
+    # the deposit stands once the next draw confirms it; a tsumo pays qin / xian + 100 per honba each
+    got = _end([D(0, "1m", is_liqi=True), T(1, "9s"), H(_hule(1, True, point_zimo_qin=2000, point_zimo_xian=1000))], ben=1)
+    assert got == [25000 - 1000 - 2100, 25000 + 2100 + 1100 + 1100 + 1000, 25000 - 1100, 25000 - 1100]
+    # a second riichi flag of the same seat does not cost another deposit (4P: `if !riichi_declared`)
+    got = _end([D(0, "1m", is_liqi=True), T(1, "9s"), D(1, "9s"), T(0, "2s"), D(0, "2s", is_liqi=True), T(1, "3s"), {"name": "LiuJu", "data": {}}])
+    assert got == [24000, 25000, 25000, 25000]
+    # abortive draw: the pending deposit is taken with four players, left alone with three
+    assert _end([D(0, "1m", is_liqi=True), {"name": "LiuJu", "data": {}}]) == [24000, 25000, 25000, 25000]
+    assert _end([D(0, "1m", is_liqi=True), {"name": "LiuJu", "data": {}}], scores=[35000] * 3) == [35000] * 3
+    # pao: the third dragon pon makes the discarder liable - a yakuman tsumo is paid by that seat alone (+ all the honba)
+    dragons = [D(0, "5z"), P(1, "5z", 0), D(1, "9s"), T(2, "6z"), D(2, "6z"), P(1, "6z", 2), D(1, "8s"), T(2, "7z"), D(2, "7z"), P(1, "7z", 2), D(1, "7s"), T(2, "1s"),
+               D(2, "1s"), T(3, "2s"), D(3, "2s"), T(0, "3s"), D(0, "3s"), T(1, "1m")]
+    tsumo = H(_hule(1, True, yiman=True, fans=[37], point_zimo_qin=16000, point_zimo_xian=8000))
+    assert _end(dragons + [tsumo], ben=1) == [25000, 25000 + 32000 + 300, 25000 - 32000 - 300, 25000]
+    # ... with a second, unrelated yakuman the other half is split as a normal tsumo (oya half, the others a quarter each)
+    two = H(_hule(1, True, yiman=True, fans=[37, 39], point_zimo_qin=32000, point_zimo_xian=16000))
+    assert _end(dragons + [two]) == [25000 - 16000, 25000 + 64000, 25000 - 32000 - 8000, 25000 - 8000]
+    # ... and a Ron is shared by the liable seat and the discarder, honba on the liable seat
+    ron = dragons[:-1] + [T(1, "4s"), D(1, "4s"), T(2, "5s"), D(2, "5s"), T(3, "1m"), D(3, "1m"), H(_hule(1, False, yiman=True, fans=[37], point_rong=32000))]
+    assert _end(ron, ben=2) == [25000, 25000 + 32000 + 600, 25000 - 16000 - 600, 25000 - 16000]
+    # nagashi mangan: only terminal / honor discards and none of them called; every eligible seat is paid a mangan tsumo
+    base = [D(0, "1m"), T(1, "5s"), D(1, "5s"), T(2, "5p"), D(2, "5p"), T(3, "4s"), D(3, "4s"), {"name": "NoTile", "data": {}}]
+    assert _end(base) == [25000 + 12000, 21000, 21000, 21000]
+    called = [D(0, "1m"), P(1, "1m", 0), D(1, "5s"), T(2, "5p"), D(2, "5p"), T(3, "4s"), D(3, "4s"), {"name": "NoTile", "data": {}}]
+    hands = {1: ["1m", "1m", "2p", "3p", "4p", "5s", "6s", "7s", "5s", "2s", "3s", "4s", "9p"]}
+    got = _end(called, hands=hands)           # nobody is eligible: seat 1 (1m pon + three runs + 9p) is the only tenpai hand
+    assert got == [24000, 28000, 24000, 24000]
+    # three players: a Hule flagged zimo on another seat's turn is a Ron on the last discard (state_3p/event_handler.rs:598-611)
+    got = _end([D(0, "1p"), H(_hule(2, True, point_rong=8000, point_zimo_qin=4000, point_zimo_xian=2000))], scores=[35000] * 3, ben=1)
+    assert got == [35000 - 8000 - 200, 35000, 35000 + 8000 + 200]
+    got = _end([D(0, "1p"), {"name": "DealTile", "data": dict(seat=1, tile="9s")}, H(_hule(1, True, point_zimo_qin=4000, point_zimo_xian=2000))],
+               scores=[35000] * 3, ben=1)
+    assert got == [35000 - 4100, 35000 + 4100 + 2100, 35000 - 2100]

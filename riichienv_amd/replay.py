@@ -141,6 +141,145 @@ class Kyoku:
                                                   **{f"tiles{i}": list(h) for i, h in enumerate(self.hands)})}
         return [head] + [{"name": a["name"], "data": {k: v for k, v in a.items() if k != "name"}} for a in self.actions]
 
+    def to_mjai_events(self, reveal_listed_doras=True):
+        """The round as MJAI events (start_kyoku ... end_kyoku), whatever its source: what ReplayBatch / rmj_apply_events
+        consume.  For a Mahjong Soul round this is where the reference's LogKyoku.steps sets its state up (replay/mod.rs:
+        1094-1290): a 14-tile hand marks the dealer, whose drawn tile is the tile of the first action if that is the dealer's
+        own discard / tsumo / kan, else the last tile of the list; the deposit of a riichi is confirmed (reach_accepted) by the
+        next draw / call / draw-end and dropped by a Ron (apply_log_action, state/event_handler.rs:396-423, :683-688); new
+        indicators listed by a draw are revealed before it, those listed by a discard after it; tsumogiri = the discard is the
+        drawn tile (event_handler.rs:343-347).  reveal_listed_doras=False keeps the reference's step iterator as it is:
+        apply_log_action ignores the `doras` lists of DealTile / DiscardTile, so its observations of a Mahjong Soul record
+        never show a kan dora (only explicit `dora` actions do); the default reveals them."""
+        if getattr(self, "source", None) != "mjsoul":
+            return list(self.mjai_events)
+        from .mjai import tid_to_mjai
+
+        n = len(self.scores)
+        kind = lambda t: t[:2] if t[0].isdigit() else t      # noqa: E731  ("5mr" and "5m" are one type)
+        hands = [list(h) for h in self.hands[:n]]
+        oya = next((i for i, h in enumerate(hands) if len(h) == 14), self.ju % max(n, 1))
+        drawn = [None] * n
+        ev = []
+        first_draw = None
+        if len(hands[oya]) == 14:
+            first_draw = hands[oya][-1]
+            a0 = self.actions[0] if self.actions else {"name": "Other"}
+            if a0["name"] == "Hule":
+                first_draw = next((tid_to_mjai(h["hu_tile"]) for h in a0["hules"] if h["seat"] == oya and h["zimo"]), first_draw)
+            elif a0["name"] == "DiscardTile" and a0["seat"] == oya:
+                first_draw = a0["tile"]
+            elif a0["name"] == "AnGangAddGang" and a0["seat"] == oya:
+                first_draw = a0["tiles"][0]
+            if first_draw not in hands[oya]:
+                first_draw = next((t for t in hands[oya] if kind(t) == kind(first_draw)), hands[oya][-1])
+            hands[oya].remove(first_draw)
+        ev.append({"type": "start_kyoku", "bakaze": "ESWN"[self.chang] if 0 <= self.chang < 4 else "E", "kyoku": self.ju + 1, "honba": self.ben,
+                   "kyotaku": self.liqibang, "oya": oya, "scores": list(self.scores), "dora_marker": self.doras[0] if self.doras else "?",
+                   "tehais": [list(h) for h in hands]})
+        if first_draw is not None:
+            ev.append({"type": "tsumo", "actor": oya, "pai": first_draw})
+            hands[oya].append(first_draw)
+            drawn[oya] = first_draw
+        known = max(len(self.doras), 1)
+        melds = [[] for _ in range(n)]
+        pending_reach = None
+        last_discard = None
+
+        def accept():
+            nonlocal pending_reach
+            if pending_reach is not None:
+                ev.append({"type": "reach_accepted", "actor": pending_reach})
+                pending_reach = None
+
+        def reveal(listed):
+            nonlocal known
+            for t in ((listed or []) if reveal_listed_doras else [])[known:]:
+                ev.append({"type": "dora", "dora_marker": t})
+                known += 1
+
+        def take(seat, t):
+            h = hands[seat]
+            if t in h:
+                h.remove(t)
+            else:
+                k = next((x for x in h if kind(x) == kind(t)), None)
+                if k is not None:
+                    h.remove(k)
+
+        for a in self.actions:
+            name = a["name"]
+            if name == "DealTile":
+                accept()
+                reveal(a.get("doras"))
+                s = a["seat"]
+                ev.append({"type": "tsumo", "actor": s, "pai": a["tile"]})
+                hands[s].append(a["tile"])
+                drawn[s] = a["tile"]
+            elif name == "DiscardTile":
+                s = a["seat"]
+                riichi = a["is_liqi"] or a["is_wliqi"]
+                if riichi:
+                    ev.append({"type": "reach", "actor": s})
+                ev.append({"type": "dahai", "actor": s, "pai": a["tile"], "tsumogiri": drawn[s] == a["tile"]})
+                take(s, a["tile"])
+                drawn[s] = None
+                last_discard = s
+                if riichi:
+                    pending_reach = s
+                reveal(a.get("doras"))
+            elif name == "ChiPengGang":
+                accept()
+                s = a["seat"]
+                own = [t for t, f in zip(a["tiles"], a["froms"]) if f == s]
+                other = [(t, f) for t, f in zip(a["tiles"], a["froms"]) if f != s]
+                pai, target = other[0] if other else (a["tiles"][0], last_discard if last_discard is not None else 0)
+                ty = {"Chi": "chi", "Pon": "pon", "Daiminkan": "daiminkan"}.get(a["meld_type"], "chi")
+                ev.append({"type": ty, "actor": s, "target": target, "pai": pai, "consumed": own})
+                for t in own:
+                    take(s, t)
+                melds[s].append((ty, pai, own))
+                drawn[s] = None
+            elif name == "AnGangAddGang":
+                s, t = a["seat"], a["tiles"][0]
+                if a["meld_type"] == "Ankan":
+                    own = [x for x in hands[s] if kind(x) == kind(t)][:4]
+                    own += [kind(t)] * (4 - len(own))
+                    ev.append({"type": "ankan", "actor": s, "consumed": own})
+                    for x in own:
+                        take(s, x)
+                else:
+                    pon = next((m for m in melds[s] if m[0] == "pon" and kind(m[1]) == kind(t)), None)
+                    ev.append({"type": "kakan", "actor": s, "pai": t, "consumed": ([pon[1]] + list(pon[2])) if pon else [kind(t)] * 3})
+                    take(s, t)
+                last_discard = s
+                drawn[s] = None
+            elif name == "BaBei":
+                accept()
+                s = a["seat"]
+                ev.append({"type": "kita", "actor": s, "pai": "N"})
+                take(s, "N")
+                last_discard = s
+                drawn[s] = None
+            elif name == "Dora":
+                ev.append({"type": "dora", "dora_marker": a["dora_marker"]})
+                known += 1
+            elif name == "Hule":
+                if a["hules"] and not a["hules"][0]["zimo"]:
+                    pending_reach = None
+                for h in a["hules"]:
+                    ev.append({"type": "hora", "actor": h["seat"], "target": h["seat"] if h["zimo"] else (last_discard if last_discard is not None else 0),
+                               "pai": tid_to_mjai(h["hu_tile"])})
+            elif name == "NoTile":
+                accept()
+                ev.append({"type": "ryukyoku"})
+            elif name == "LiuJu":
+                if n == 4:
+                    accept()
+                ev.append({"type": "ryukyoku", "reason": "abortive"})
+        ev.append({"type": "end_kyoku"})
+        return ev
+
     def take_win_result_contexts(self, ankan_from_consumed=True):
         """LogKyoku.take_win_result_contexts (replay/mod.rs:1089-1091)"""
         return WinResultContextIterator(self, ankan_from_consumed)
@@ -998,6 +1137,15 @@ class MjSoulReplay:
 
     def take_kyokus(self):
         return iter(self.rounds)
+
+    def to_mjai(self, reveal_listed_doras=True):
+        """The record as one MJAI event list (start_game, the rounds' Kyoku.to_mjai_events, end_game): the input of ReplayBatch,
+        which turns it into (observation, mask, action) samples on the GPU - this framework's form of LogKyoku.steps for
+        Mahjong Soul records (replay/mod.rs:1094-1290 + KyokuStepIterator)."""
+        out = [{"type": "start_game"}]
+        for k in self.rounds:
+            out += k.to_mjai_events(reveal_listed_doras)
+        return out + [{"type": "end_game"}]
 
     def verify(self, evaluate=None):
         """mjsoul_replay.rs:255-436: evaluate every win of every round and compare with what the record expects - the yaku

@@ -135,6 +135,40 @@ def test_mjsoul_game_end_scores_with_the_gpu_tenpai_batch():
     assert draws >= 4
 
 
+@pytest.mark.parametrize("mode,seed", [(2, 5), (5, 4)])
+def test_mjsoul_records_replay_into_the_same_samples_as_their_mjai_log(mode, seed):
+    """Per-step observations of Mahjong Soul records (the reference's LogKyoku.steps over a record, replay/mod.rs:1094-1290):
+    MjSoulReplay.to_mjai feeds ReplayBatch.  A record written from an oracle-played game and the game's own MJAI log, replayed
+    side by side in ONE batch, must give the same decisions - seat, action id, mask - and the same feature tensors, except at
+    the discard after an open kan, where the record reveals the new indicator with the discard and the log just before it."""
+    from riichienv_amd import replay
+    from tests.mjsoul_util import play_logged_game, to_mjsoul_rounds
+
+    events, walls = play_logged_game(mode, seed)
+    oracle_tenpai = None      # (the GPU default: rmj_eval_hands)
+    rec = replay.MjSoulReplay.from_dict(to_mjsoul_rounds(events, walls), tenpai=oracle_tenpai).to_mjai()
+    moved = 0
+    strip = [e for e in events if e["type"] != "dora"]
+    assert len(rec) == len(events)
+    for a, b in zip(events, rec):
+        moved += (a["type"] == "dora") != (b["type"] == "dora")
+    assert len(strip) < len(events)
+    rb = replay.ReplayBatch([events, rec], game_mode=mode, include_pass=True)
+    n = differ = 0
+    for smp in rb.samples():
+        g = smp["game"]
+        i0, i1 = np.where(g == 0)[0], np.where(g == 1)[0]
+        if moved and len(i0) != len(i1):
+            continue                                         # an index where one stream holds the dora event, the other the discard
+        assert len(i0) == len(i1), smp["index"]
+        for x, y in zip(i0, i1):
+            assert (int(smp["seat"][x]), int(smp["action_id"][x])) == (int(smp["seat"][y]), int(smp["action_id"][y])), smp["index"]
+            assert (smp["mask"][x] == smp["mask"][y]).all()
+            differ += smp["obs"][x].tobytes() != smp["obs"][y].tobytes()
+            n += 1
+    assert n > 100 and differ <= moved, (n, differ, moved)
+
+
 def test_pass_samples_carry_the_missed_ron_furiten():
     """tests/env/test_apply_event.py:535-632 (TestReplayFuriten) on ReplayBatch: a seat that lets a Ron go is in same-turn furiten
     until its own discard (the second 3m is offered again), in riichi for good (the second 3m yields no sample at all)."""

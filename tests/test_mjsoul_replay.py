@@ -260,3 +260,59 @@ def test_log_walker_rules_read_from_the_reference():
     got = _end([D(0, "1p"), {"name": "DealTile", "data": dict(seat=1, tile="9s")}, H(_hule(1, True, point_zimo_qin=4000, point_zimo_xian=2000))],
                scores=[35000] * 3, ben=1)
     assert got == [35000 - 4100, 35000 + 4100 + 2100, 35000 - 2100]
+
+
+_MJAI_KEYS = {"start_kyoku": ["bakaze", "kyoku", "honba", "kyotaku", "oya", "scores", "dora_marker", "tehais"], "tsumo": ["actor", "pai"],
+              "dahai": ["actor", "pai", "tsumogiri"], "reach": ["actor"], "reach_accepted": ["actor"], "chi": ["actor", "target", "pai", "consumed"],
+              "pon": ["actor", "target", "pai", "consumed"], "daiminkan": ["actor", "target", "pai", "consumed"], "ankan": ["actor", "consumed"],
+              "kakan": ["actor", "pai", "consumed"], "kita": ["actor"], "dora": ["dora_marker"], "hora": ["actor", "target"]}
+
+
+def _norm_mjai(events):
+    """the fields a record can carry; a discard of a tile with the drawn tile's NAME counts as tsumogiri (records hold names)"""
+    out, drawn = [], {}
+    for e in events:
+        d = {k: e.get(k) for k in _MJAI_KEYS.get(e["type"], [])}
+        d["type"] = e["type"]
+        if "consumed" in d:
+            d["consumed"] = sorted(d["consumed"])
+        if e["type"] == "start_kyoku":
+            d["tehais"] = [sorted(h) for h in e["tehais"][: len(e["scores"])]]
+        if e["type"] == "tsumo":
+            drawn[e["actor"]] = e["pai"]
+        elif e["type"] == "dahai":
+            d["tsumogiri"] = drawn.get(e["actor"]) == e["pai"]
+            drawn[e["actor"]] = None
+        elif e["type"] in ("chi", "pon", "daiminkan", "ankan", "kakan", "kita"):
+            drawn[e["actor"]] = None
+        out.append(d)
+    return out
+
+
+@pytest.mark.parametrize("mode,seed", [(2, 1), (2, 5), (2, 7), (5, 2), (5, 4)])
+def test_records_convert_back_to_the_mjai_log_they_came_from(mode, seed):
+    """MjSoulReplay.to_mjai (the input of ReplayBatch for Mahjong Soul records): the MJAI log of an oracle-played game, written
+    as a record and read back, is the same event stream - deals, draws, discards with their tsumogiri flag, calls with their
+    exact tiles (red fives), riichi declaration / acceptance (none after a Ron on the riichi discard), wins with their targets.
+    Indicators of open kans: the record lists them on the discard, so they follow it (the log reveals them just before)."""
+    events, walls = play_logged_game(mode, seed)
+    r = MjSoulReplay.from_dict(to_mjsoul_rounds(events, walls), tenpai=_oracle_tenpai)
+    a, b = _norm_mjai(events), _norm_mjai(r.to_mjai())
+    strip = lambda xs: [x for x in xs if x["type"] != "dora"]      # noqa: E731
+    assert strip(a) == strip(b)
+
+    def dora_positions(xs):
+        pos, k = [], 0
+        for x in xs:
+            if x["type"] == "dora":
+                pos.append((x["dora_marker"], k))
+            else:
+                k += 1
+        return pos
+
+    pa, pb = dora_positions(a), dora_positions(b)
+    assert [m for m, _ in pa] == [m for m, _ in pb] and len(pa) >= 1
+    assert all(kb - ka in (0, 1) for (_, ka), (_, kb) in zip(pa, pb))
+    # the reference's own step iterator never reveals the listed indicators
+    quiet = r.to_mjai(reveal_listed_doras=False)
+    assert not any(e["type"] == "dora" for e in quiet) and len(quiet) == len(strip(b))

@@ -280,6 +280,37 @@ class Kyoku:
         ev.append({"type": "end_kyoku"})
         return ev
 
+    rule = "tenhou"
+
+    def steps(self, seat=None, rule=None, skip_single_action=True, device=0, extended=False):
+        """LogKyoku.steps (replay/mod.rs:1094-1290, KyokuStepIterator :199-560): the decisions of this round, one by one, as
+        `(obs, action)` for one seat or `(seat, obs, action)` for all - obs a StepObservation (feature tensor, mask, legal
+        actions of the deciding seat), action the compat.Action the log took.  A riichi is two decisions (Riichi, then the
+        discard with Riichi no longer offered); seats that let a claim go yield Pass decisions, delivered before the decision of
+        the seat that did claim, highest seat first (the iterator pops its queue from the back, :211); skip_single_action drops
+        decisions with at most one legal action.  The round runs as a one-game ReplayBatch on the GPU - datasets over many
+        logs should use ReplayBatch directly, which replays them in lock-step."""
+        from .compat import Action, ActionType
+
+        n = len(self.scores)
+        bits = abi.RULE_MJSOUL if (rule or self.rule) == "mjsoul" else abi.RULE_TENHOU
+        env = vecenv.VecRiichiEnv(1, game_mode=5 if n == 3 else 2, seed=0, rule_bits=bits, device=device, skip_mjai_logging=True)
+        rb = ReplayBatch([[{"type": "start_game"}] + self.to_mjai_events()], extended=extended, include_pass=True, env=env)
+        for smp in rb.samples():
+            order = list(range(len(smp["seat"])))
+            is_pass = [abi.unpack_action(int(a))[0] == abi.PASS for a in smp["action"]]
+            order = sorted((j for j in order if is_pass[j]), key=lambda j: -int(smp["seat"][j])) + [j for j in order if not is_pass[j]]
+            for j in order:
+                s = int(smp["seat"][j])
+                legal = [int(a) for a in smp["legal"][j]]
+                if seat is not None and s != seat:
+                    continue
+                if skip_single_action and len(legal) <= 1:
+                    continue
+                obs = StepObservation(s, n, smp["obs"][j], smp["mask"][j], legal)
+                act = Action._from_packed(int(smp["action"][j]), actor=s if is_pass[j] else None)
+                yield (obs, act) if seat is not None else (s, obs, act)
+
     def take_win_result_contexts(self, ankan_from_consumed=True):
         """LogKyoku.take_win_result_contexts (replay/mod.rs:1089-1091)"""
         return WinResultContextIterator(self, ankan_from_consumed)
@@ -314,6 +345,30 @@ class Kyoku:
         return dict(chang=self.chang, ju=self.ju, ben=self.ben, liqibang=self.liqibang, scores=list(self.scores),
                     end_scores=list(self.end_scores), wliqi=list(self.wliqi),
                     delta_scores=[e - s for s, e in zip(self.scores, self.end_scores)] if len(self.scores) == len(self.end_scores) else [])
+
+
+class StepObservation:
+    """What a decision of Kyoku.steps carries of the reference's Observation: the seat, its feature tensor (encode() = the
+    74 x 34 / 74 x 27 block, or the 215-channel one with extended=True), the action mask and the legal actions."""
+
+    __slots__ = ("player_id", "num_players", "tensor", "_mask", "_legal")
+
+    def __init__(self, player_id, num_players, tensor, mask, legal):
+        self.player_id, self.num_players, self.tensor, self._mask, self._legal = player_id, num_players, tensor, mask, legal
+
+    def action_space_size(self):
+        return 60 if self.num_players == 3 else 82
+
+    def legal_actions(self):
+        from .compat import Action
+
+        return [Action._from_packed(a) for a in self._legal]
+
+    def mask(self) -> bytes:
+        return bytes(bytearray(int(x) for x in self._mask))
+
+    def encode(self) -> bytes:
+        return self.tensor.tobytes()
 
 
 class WinResultContext:
@@ -906,6 +961,8 @@ class MjaiReplay:
             rounds.append(cur)
         for i in range(len(rounds) - 1):          # the next round's start scores are authoritative (mjai_replay.rs:363-367)
             rounds[i].end_scores = list(rounds[i + 1].scores)
+        for k in rounds:
+            k.rule = rule or "tenhou"
         return cls(rounds, events)
 
     def num_rounds(self):
@@ -988,7 +1045,8 @@ class ReplayBatch:
                 ss = np.array([d[1] for d in dec])
                 yield {"index": k, "game": gs, "seat": ss, "action": np.array([d[2] for d in dec], dtype=np.uint64),
                        "action_id": np.array([self._encode_id(d[2]) for d in dec], dtype=np.int64),
-                       "mask": mask[gs, ss][:, :nmask].copy(), "obs": enc[gs, ss].copy()}
+                       "mask": mask[gs, ss][:, :nmask].copy(), "obs": enc[gs, ss].copy(),
+                       "legal": [legal[g, s, : cnt[g, s]].copy() for g, s in zip(gs, ss)]}
             self.env.apply_events([l[k] if k < len(l) else None for l in self.logs], masked_ok=self.masked_ok, replay=True)
 
 
@@ -1059,6 +1117,7 @@ class MjSoulReplay:
     def _kyoku_from_raw_actions(cls, raw):        # mjsoul_replay.rs:440-561
         k = Kyoku.__new__(Kyoku)
         k.source = "mjsoul"
+        k.rule = "mjsoul"                         # mjsoul_replay.rs:541
         k.mjai_events = []
         k.scores, k.doras, k.ura_doras, k.hands = [], [], [], [[] for _ in range(4)]
         k.chang = k.ju = k.ben = k.liqibang = 0

@@ -169,6 +169,66 @@ def test_mjsoul_records_replay_into_the_same_samples_as_their_mjai_log(mode, see
     assert n > 100 and differ <= moved, (n, differ, moved)
 
 
+_REACH_TEHAIS = [["1p", "1p", "2p", "2p", "2p", "3p", "3p", "3p", "4p", "4p", "4p", "5z", "5z"],
+                 ["1s", "1s", "1s", "2s", "2s", "2s", "3s", "3s", "3s", "4s", "4s", "4s", "6z"],
+                 ["1z", "1z", "2z", "2z", "3z", "3z", "4z", "4z", "5z", "5z", "6z", "6z", "7z"],
+                 ["5m", "5m", "6m", "6m", "7m", "7m", "8m", "8m", "9m", "9m", "1m", "1m", "2m"]]
+
+
+@pytest.mark.parametrize("n", [3, 4])
+def test_steps_reach_discard_observation_is_not_duplicated_state(n, tmp_path):
+    """tests/test_mjai_replay.py:103-150 (3P, rule="mjsoul") and :208-257 (4P): Kyoku.steps replays reach + dahai as two decisions -
+    Riichi is legal at the first, no longer at the second"""
+    from riichienv_amd.compat import ActionType
+    from riichienv_amd.replay import MjaiReplay
+    from tests.win_context_util import write_jsonl
+
+    data = [{"type": "start_game", "names": ["A", "B", "C", "D"][:n], "id": "test_reach"},
+            {"type": "start_kyoku", "bakaze": "E", "kyoku": 1, "honba": 0, "kyoutaku": 0, "oya": 0, "scores": [35000 if n == 3 else 25000] * n,
+             "dora_marker": "1p", "tehais": _REACH_TEHAIS[:n]},
+            {"type": "tsumo", "actor": 0, "pai": "1p"}, {"type": "reach", "actor": 0}, {"type": "dahai", "actor": 0, "pai": "1p", "tsumogiri": True},
+            {"type": "ryukyoku", "reason": "test"}, {"type": "end_kyoku"}, {"type": "end_game"}]
+    p = tmp_path / "reach.jsonl"
+    write_jsonl(p, data)
+    kyoku = list(MjaiReplay.from_jsonl(str(p), rule="mjsoul" if n == 3 else None).take_kyokus())[0]
+    steps = list(kyoku.steps(0, skip_single_action=False))
+    assert len(steps) >= 2
+    (riichi_obs, riichi_act), (discard_obs, discard_act) = steps[0], steps[1]
+    assert riichi_act.action_type == ActionType.RIICHI and discard_act.action_type == ActionType.DISCARD
+    assert ActionType.RIICHI in [a.action_type for a in riichi_obs.legal_actions()]
+    assert ActionType.RIICHI not in [a.action_type for a in discard_obs.legal_actions()]
+    # the dataset loop of riichienv_ml/datasets/mjai_logs.py:105-113: the action id is legal in the observation's mask
+    for obs, act in steps:
+        aid = act.encode_3p() if n == 3 else act.encode()
+        mask = np.frombuffer(obs.mask(), dtype=np.uint8)
+        assert mask.shape[0] == obs.action_space_size() and mask[aid] == 1
+        assert len(obs.encode()) == 74 * (27 if n == 3 else 34) * 4
+
+
+def test_steps_of_a_real_round_order_and_filters():
+    """Kyoku.steps on the first round of the reference's real hanchan log: all seats = the union of the per-seat iterators;
+    Pass decisions come before the claim they lost to; skip_single_action drops the forced decisions only."""
+    from riichienv_amd.compat import ActionType
+    from riichienv_amd.replay import MjaiReplay
+
+    k = next(iter(MjaiReplay.from_jsonl(LOG).take_kyokus()))
+    every = list(k.steps(skip_single_action=False))
+    assert len(every) > 60 and all(len(x) == 3 for x in every)
+    for seat in range(4):
+        mine = list(k.steps(seat, skip_single_action=False))
+        ref = [(o, a) for s, o, a in every if s == seat]
+        assert [(a.action_type, a.tile) for _, a in mine] == [(a.action_type, a.tile) for _, a in ref]
+        assert all(o1.encode() == o2.encode() for (o1, _), (o2, _) in zip(mine, ref))
+    kept = list(k.steps(skip_single_action=True))
+    assert 0 < len(kept) <= len(every) and all(len(o.legal_actions()) > 1 for _, o, _ in kept)
+    assert len(kept) == sum(len(o.legal_actions()) > 1 for _, o, _ in every)
+    kinds = [a.action_type for _, _, a in every]
+    assert ActionType.DISCARD in kinds and ActionType.PASS in kinds
+    # every decision's action is one of the observation's legal actions
+    for s, o, a in every:
+        assert any(a.action_type == l.action_type and a.tile == l.tile and a.consume_tiles == l.consume_tiles for l in o.legal_actions())
+
+
 def test_pass_samples_carry_the_missed_ron_furiten():
     """tests/env/test_apply_event.py:535-632 (TestReplayFuriten) on ReplayBatch: a seat that lets a Ron go is in same-turn furiten
     until its own discard (the second 3m is offered again), in riichi for good (the second 3m yields no sample at all)."""

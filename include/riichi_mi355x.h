@@ -202,7 +202,7 @@ int rmj_random_actions_device(rmj_handle h, uint64_t policy_seed, rmj_action_t* 
 int rmj_get_status(rmj_handle h, uint8_t* active_mask, uint8_t* phase, uint8_t* done); /* each [n] */
 int rmj_get_legal(rmj_handle h, rmj_action_t* legal /*[n][4][64]*/, uint8_t* counts /*[n][4]*/);
 int rmj_get_mask(rmj_handle h, uint8_t* mask /*[n][4][82]*/);
-int rmj_get_waits(rmj_handle h, uint64_t* waits /*[n][4] bit t = tile type t*/);
+int rmj_get_waits(rmj_handle h, uint64_t* waits /*[n][4] bit t = tile type t; 0 for seats without an observation (not active, env.rs:870-871) */);
 int rmj_get_scores(rmj_handle h, int32_t* scores /*[n][4]*/);
 int rmj_get_ranks(rmj_handle h, uint8_t* ranks /*[n][4], 1-based, ties by seat (env.rs:673-689)*/);
 int rmj_get_step_counts(rmj_handle h, uint64_t* steps /*[n]*/);

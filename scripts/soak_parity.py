@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Parity soak (not part of the test suite): long device-policy rollouts of every game mode under both rule sets and
 several seeds, compared with the oracle game by game - final state, legal lists, masks, waits, step counts and the whole
-MJAI log of every game.  usage: python scripts/soak_parity.py [games] [steps] [seeds]"""
+MJAI log of every game.  usage: python scripts/soak_parity.py [games] [steps] [seeds] [first seed index]"""
 import os
 import sys
 import time
@@ -16,11 +16,12 @@ from tests.test_gpu_step import _compare  # noqa: E402
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 128
 steps = int(sys.argv[2]) if len(sys.argv) > 2 else 5000
 seeds = int(sys.argv[3]) if len(sys.argv) > 3 else 2
+first = int(sys.argv[4]) if len(sys.argv) > 4 else 0
 total = 0
 t0 = time.time()
 for mode in range(6):
     for rule, rname in ((abi.RULE_TENHOU, "tenhou"), (abi.RULE_MJSOUL, "mjsoul")):
-        for k in range(seeds):
+        for k in range(first, first + seeds):
             seed, pseed = 7000 + 131 * k + mode, 0xA5A5 + 977 * k
             env = vecenv.VecRiichiEnv(n, game_mode=mode, seed=seed, rule_bits=rule, event_ring=8192)
             games = [oracle.Game(game_mode=mode, seed=game_seed(seed, g), rule_bits=rule) for g in range(n)]

@@ -29,6 +29,49 @@ def tid_to_mjsoul(t):
     return f"{t34 % 9 + 1}{'mpsz'[t34 // 9]}"
 
 
+def greedy_actions(o, rng, sanma, call_rate=0.25):
+    """The policy of the played games: every win / riichi / kan / kita that is offered, a pon or chi a quarter of the time, a
+    discard that keeps the shanten of the rest lowest (ties by `rng`), else pass.  Returns the four packed actions."""
+    from oracle import oracle
+
+    npl = 3 if sanma else 4
+    act = o.status()[0]
+    acts = [abi.NO_ACTION] * 4
+    v = o.peek()
+    for s in range(npl):
+        if not (act >> s) & 1:
+            continue
+        legal = o.legal(s)
+        if not legal:
+            continue
+        kinds = {}
+        for a in legal:
+            kinds.setdefault(abi.unpack_action(a)[0], []).append(a)
+        pick = None
+        for ty in (abi.TSUMO, abi.RON, abi.RIICHI, abi.ANKAN, abi.KAKAN, abi.DAIMINKAN, abi.KITA):
+            if ty in kinds:
+                pick = kinds[ty][0]
+                break
+        if pick is None and (abi.PON in kinds or abi.CHI in kinds) and rng.random() < call_rate:
+            pick = (kinds.get(abi.PON) or kinds.get(abi.CHI))[0]
+        if pick is None and abi.DISCARD in kinds:
+            hand = list(v.players[s].hand[: v.players[s].hand_len])
+            cands = kinds[abi.DISCARD]
+            cnt = np.zeros((len(cands), 34), dtype=np.uint8)
+            for i, a in enumerate(cands):
+                rest = list(hand)
+                rest.remove(abi.unpack_action(a)[1])
+                for t in rest:
+                    cnt[i, t // 4] += 1
+            sh = np.asarray(oracle.shanten(cnt, sanma))
+            best = np.flatnonzero(sh == sh.min())
+            pick = cands[int(best[int(rng.integers(len(best)))])]
+        if pick is None:
+            pick = kinds.get(abi.PASS, legal)[0]
+        acts[s] = pick
+    return acts
+
+
 def play_logged_game(mode, seed, rule=abi.RULE_MJSOUL, max_steps=8000, with_scores=False):
     """(MJAI events, walls): walls[i] = the 136-ids of round i's wall in draw order (= MjSoul's paishan); with_scores adds the
     scores the oracle's game ended with"""
@@ -50,42 +93,9 @@ def play_logged_game(mode, seed, rule=abi.RULE_MJSOUL, max_steps=8000, with_scor
 
     note_wall()
     for _ in range(max_steps):
-        act, _, done = o.status()
-        if done:
+        if o.status()[2]:
             break
-        acts = [abi.NO_ACTION] * 4
-        v = o.peek()
-        for s in range(npl):
-            if not (act >> s) & 1:
-                continue
-            legal = o.legal(s)
-            if not legal:
-                continue
-            kinds = {}
-            for a in legal:
-                kinds.setdefault(abi.unpack_action(a)[0], []).append(a)
-            pick = None
-            for ty in (abi.TSUMO, abi.RON, abi.RIICHI, abi.ANKAN, abi.KAKAN, abi.DAIMINKAN, abi.KITA):
-                if ty in kinds:
-                    pick = kinds[ty][0]
-                    break
-            if pick is None and (abi.PON in kinds or abi.CHI in kinds) and rng.random() < 0.25:
-                pick = (kinds.get(abi.PON) or kinds.get(abi.CHI))[0]
-            if pick is None and abi.DISCARD in kinds:
-                hand = list(v.players[s].hand[: v.players[s].hand_len])
-                cands = kinds[abi.DISCARD]
-                cnt = np.zeros((len(cands), 34), dtype=np.uint8)
-                for i, a in enumerate(cands):
-                    rest = list(hand)
-                    rest.remove(abi.unpack_action(a)[1])
-                    for t in rest:
-                        cnt[i, t // 4] += 1
-                sh = np.asarray(oracle.shanten(cnt, sanma))
-                best = np.flatnonzero(sh == sh.min())
-                pick = cands[int(best[int(rng.integers(len(best)))])]
-            if pick is None:
-                pick = kinds.get(abi.PASS, legal)[0]
-            acts[s] = pick
+        acts = greedy_actions(o, rng, sanma)
         o.step(acts)
         note_wall()
     assert o.status()[2], "the game did not end"

@@ -323,3 +323,44 @@ def test_noisy_host_actions_parity(mode):
     for g in range(n):
         _compare(env, games, [g], 99999)
         assert env.mjai_log(g) == games[g].log(), g
+
+
+@pytest.mark.parametrize("mode,rule", [(2, abi.RULE_TENHOU), (5, abi.RULE_MJSOUL)])
+def test_greedy_play_parity(mode, rule):
+    """Parity where rounds END IN WINS: the oracle plays with the tenpai-seeking policy of tests/mjsoul_util (every win /
+    riichi / kan / kita taken, shanten-greedy discards), the same actions go through rmj_step, and every step must leave device
+    and oracle with the same status, legal lists, masks and waits (full state on a rotating sample and at the end, whole MJAI
+    logs at the end).  The uniform RandomAgent wins about once in 250 rounds; here most rounds end with a Ron or a Tsumo."""
+    import json
+
+    from oracle import oracle
+    from riichienv_amd import vecenv
+    from tests.mjsoul_util import greedy_actions
+
+    n, seed = 24, 4711 + mode
+    sanma = mode >= 3
+    env = vecenv.VecRiichiEnv(n, game_mode=mode, seed=seed, rule_bits=rule, event_ring=16384)
+    games = [oracle.Game(game_mode=mode, seed=game_seed(seed, g), rule_bits=rule) for g in range(n)]
+    env.reset()
+    for o in games:
+        o.reset()
+    rng = np.random.default_rng(seed)
+    for step in range(1, 700):
+        acts = np.full((n, 4), abi.NO_ACTION, dtype=np.uint64)
+        for g, o in enumerate(games):
+            if not o.status()[2]:
+                a = greedy_actions(o, rng, sanma)
+                acts[g] = a
+                o.step(a)
+        env.step(acts)
+        _compare(env, games, range(n), step, check_state=False)
+        _compare(env, games, [step % n], step, check_state=True)
+    _compare(env, games, range(n), -1, check_state=True)
+    kinds = {}
+    for g, o in enumerate(games):
+        log = o.log()
+        assert env.mjai_log(g) == log, g
+        for s in log:
+            t = json.loads(s)["type"]
+            kinds[t] = kinds.get(t, 0) + 1
+    assert kinds.get("hora", 0) >= 40 and kinds.get("reach_accepted", 0) >= 30, kinds

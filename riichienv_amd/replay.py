@@ -290,7 +290,7 @@ class Kyoku:
         the seat that did claim, highest seat first (the iterator pops its queue from the back, :211); skip_single_action drops
         decisions with at most one legal action.  The round runs as a one-game ReplayBatch on the GPU - datasets over many
         logs should use ReplayBatch directly, which replays them in lock-step."""
-        from .compat import Action, ActionType
+        from .compat import Action
 
         n = len(self.scores)
         bits = abi.RULE_MJSOUL if (rule or self.rule) == "mjsoul" else abi.RULE_TENHOU

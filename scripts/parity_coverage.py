@@ -66,6 +66,8 @@ def census_logs(logs, label=""):
                     # the reader's double-riichi flag (mjai_replay.rs:415, :606-611) ...
                     if c.conditions["double_riichi"]:
                         reach_at = next(j for j, e in enumerate(k.mjai_events) if e.get("type") == "reach" and e.get("actor") == c.seat)
+                        # (up to the riichi DISCARD: a seat may declare, take a kita and only then discard)
+                        reach_at = next(j for j, e in enumerate(k.mjai_events) if j > reach_at and e.get("type") == "dahai" and e.get("actor") == c.seat)
                         if any(e.get("type") == "kita" for e in k.mjai_events[:reach_at]):
                             c.conditions["double_riichi"] = False
                             wins["riichi after a kita (reader says double)"] += 1
@@ -78,6 +80,18 @@ def census_logs(logs, label=""):
                             c.tiles = list(c.tiles[:-1]) + [north]
                             c.agari_tile = north
                             wins["ron on a kita"] += 1
+                    # ... nor does a Ron on a kakan whose kan flushed the pending indicator of an earlier open kan: the `dora` event
+                    # sits between the kakan and the hora, the reader's last action is Dora (tile 0, and no chankan)
+                    if h["actor"] != h["target"] and h.get("pai") is None:
+                        full = [e for e in k.mjai_events if e.get("type") not in ("reach", "reach_accepted")]
+                        at_f = next(j for j, e in enumerate(full) if e is h)
+                        before = [e for e in full[:at_f] if e["type"] != "hora"]
+                        if len(before) >= 2 and before[-1]["type"] == "dora" and before[-2]["type"] == "kakan":
+                            t = abi.mjai_to_tid(before[-2]["pai"])
+                            c.tiles = list(c.tiles[:-1]) + [t]
+                            c.agari_tile = t
+                            c.conditions["chankan"] = True
+                            wins["chankan behind a dora event"] += 1
                     ctx_all.append(c)
                     expect.append((k, h, i))
     evaluate_win_contexts(ctx_all)

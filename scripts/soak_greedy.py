@@ -5,7 +5,7 @@ actions go to rmj_step, and device and oracle are compared after every step (sta
 state of a rotating sample) and at the end (every state, every whole MJAI log).  The uniform RandomAgent of soak_parity.py wins
 once in ~250 rounds; this policy ends most rounds with a win, so riichi / ippatsu / ura, Ron with several claimants, chankan,
 rinshan, pao and the yaku checks of the step kernel's claim code run thousands of times.
-usage: python scripts/soak_greedy.py [games] [max steps] [seed]"""
+usage: python scripts/soak_greedy.py [games] [max steps] [seed] [call rate, default 0.25]"""
 import collections
 import json
 import os
@@ -23,7 +23,7 @@ from tests.mjsoul_util import greedy_actions  # noqa: E402
 from tests.test_gpu_step import _compare  # noqa: E402
 
 
-def run(mode, rule, n, max_steps, seed):
+def run(mode, rule, n, max_steps, seed, call_rate=0.25):
     sanma = mode >= 3
     env = vecenv.VecRiichiEnv(n, game_mode=mode, seed=seed, rule_bits=rule, event_ring=16384)
     games = [oracle.Game(game_mode=mode, seed=game_seed(seed, g), rule_bits=rule) for g in range(n)]
@@ -39,7 +39,7 @@ def run(mode, rule, n, max_steps, seed):
             if o.status()[2]:
                 continue
             live += 1
-            a = greedy_actions(o, rng, sanma)
+            a = greedy_actions(o, rng, sanma, call_rate)
             acts[g] = a
             o.step(a)
         if not live:
@@ -71,12 +71,13 @@ def main():
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 64
     max_steps = int(sys.argv[2]) if len(sys.argv) > 2 else 4000
     seed = int(sys.argv[3]) if len(sys.argv) > 3 else 555
+    call_rate = float(sys.argv[4]) if len(sys.argv) > 4 else 0.25
     t0 = time.time()
     total = 0
     for k, (mode, rule, name) in enumerate(((2, abi.RULE_TENHOU, "4p-red-half tenhou"), (2, abi.RULE_MJSOUL, "4p-red-half mjsoul"),
                                             (5, abi.RULE_MJSOUL, "3p-red-half mjsoul"), (5, abi.RULE_TENHOU, "3p-red-half tenhou"),
                                             (0, abi.RULE_TENHOU, "4p-red-single tenhou"), (4, abi.RULE_MJSOUL, "3p-red-east mjsoul"))):
-        steps, tally, cen = run(mode, rule, n, max_steps, seed + 17 * k)
+        steps, tally, cen = run(mode, rule, n, max_steps, seed + 17 * k, call_rate)
         total += steps
         keep = {k: v for k, v in sorted(tally.items()) if k in ("hora", "reach", "reach_accepted", "ankan", "kakan", "daiminkan", "kita", "pon", "chi", "start_kyoku")
                 or k.startswith("ryukyoku")}

@@ -66,6 +66,57 @@ def test_torch_env_matches_oracle(mode, shared):
 
 
 @pytest.mark.parametrize("mode", [2, 5])
+def test_greedy_ids_parity(mode):
+    """The id path (rmj_step_ids_device = Observation.find_action + step) where rounds end in wins: the oracle's tenpai-seeking
+    policy (tests/mjsoul_util.greedy_actions) picks an action, its id goes to the device, and the oracle takes the FIRST legal
+    action with that id like find_action does (observation/mod.rs:117-129: ids do not tell a red five from a plain one).  Status,
+    lists, masks, waits after every step; whole MJAI logs at the end."""
+    torch = pytest.importorskip("torch")
+    import json
+
+    from oracle import oracle
+    from riichienv_amd.torch_env import TorchVecEnv
+    from tests.mjsoul_util import greedy_actions
+    from tests.test_gpu_step import _compare
+
+    n, seed = 24, 8100 + mode
+    sanma = mode >= 3
+    env = TorchVecEnv(n, game_mode=mode, seed=seed, skip_mjai_logging=False, share_stream=True, event_ring=16384)
+    games = [oracle.Game(game_mode=mode, seed=game_seed(seed, g)) for g in range(n)]
+    for o in games:
+        o.reset()
+    enc_fn = games[0].L.orc_action_encode_3p if sanma else games[0].L.orc_action_encode
+    rng = np.random.default_rng(seed)
+    swapped = 0
+    for step in range(1, 650):
+        ids = np.full((n, 4), -1, dtype=np.int32)
+        for g, o in enumerate(games):
+            if o.status()[2]:
+                continue
+            picks = greedy_actions(o, rng, sanma)
+            acts = [abi.NO_ACTION] * 4
+            for s, a in enumerate(picks):
+                if a == abi.NO_ACTION:
+                    continue
+                ids[g, s] = enc_fn(a)
+                acts[s] = next(x for x in o.legal(s) if enc_fn(x) == ids[g, s])
+                swapped += acts[s] != a
+            o.step(acts)
+        env.step(torch.from_numpy(ids).to(env.device), auto_reset=False)
+        torch.cuda.synchronize()
+        _compare(env.env, games, range(n), step, check_state=False)
+        _compare(env.env, games, [step % n], step, check_state=True)
+    kinds = {}
+    for g, o in enumerate(games):
+        log = o.log()
+        assert env.env.mjai_log(g) == log, g
+        for x in log:
+            t = json.loads(x)["type"]
+            kinds[t] = kinds.get(t, 0) + 1
+    assert kinds.get("hora", 0) >= 30 and swapped > 0, (kinds, swapped)
+
+
+@pytest.mark.parametrize("mode", [2, 5])
 def test_fused_masked_sampler(mode):
     """rmj_sample_ids_device: ids are legal (mask bit set) exactly for the acting seats, deterministic in (seed, state),
     follow the logits (a dominant logit always wins, a masked id never does), and are uniform over the legal ids without."""

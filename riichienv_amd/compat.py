@@ -38,6 +38,20 @@ class ActionType(enum.IntEnum):  # action.rs:55-68 (pyclass rename_all = SCREAMI
     KITA = 11
 
 
+# PascalCase aliases of the reference's Python layer (src/riichienv/action.py:5-17, deprecated there, still exported)
+for _n in list(ActionType):
+    setattr(ActionType, "".join(w.capitalize() for w in _n.name.split("_")), _n)
+
+
+class GameType(enum.IntEnum):  # src/riichienv/game_mode.py
+    YON_IKKYOKU = 0
+    YON_TONPUSEN = 1
+    YON_HANCHAN = 2
+    SAN_IKKYOKU = 3
+    SAN_TONPUSEN = 4
+    SAN_HANCHAN = 5
+
+
 class Phase(enum.IntEnum):  # action.rs:29-33
     WaitAct = 0
     WaitResponse = 1

@@ -63,5 +63,9 @@ def test_the_package_answers_to_the_reference_names():
                  "parse_hand", "parse_tile", "MjaiReplay", "MjSoulReplay", "Kyoku", "WinResultContext", "convert"):
         assert getattr(rv, name) is not None, name
     assert rv.convert.tid_to_mjai(16) == "5mr" and rv.parse_tile("0p") == 52 and int(rv.Wind.North) == 3
+    # src/riichienv/action.py:5-17 (PascalCase aliases), game_mode.py, consts.py
+    assert rv.ActionType.Discard is rv.ActionType.DISCARD and rv.ActionType.KyushuKyuhai is rv.ActionType.KYUSHU_KYUHAI
+    assert len(list(rv.ActionType)) == 12 and int(rv.GameType.SAN_HANCHAN) == 5
+    assert (rv.consts.N_TILE_TYPES_4P, rv.consts.N_TILE_TYPES_3P, rv.consts.N_TILES_4P, rv.consts.N_TILES_3P) == (34, 27, 136, 108)
     with pytest.raises(AttributeError):
         rv.no_such_name

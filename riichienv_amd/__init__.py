@@ -4,7 +4,8 @@
 package (`import riichienv as rv`: src/riichienv/__init__.py) resolve lazily to their counterparts here - RiichiEnv, Action,
 ActionType, Observation, Meld, MeldType, Phase, GameRule, GameType, RandomAgent (riichienv_amd.compat); Conditions, HandEvaluator,
 HandEvaluator3P, Wind, WinResult, Score, calculate_score, calculate_shanten, calculate_shanten_3p, check_riichi_candidates,
-parse_hand, parse_tile (riichienv_amd.hand); MjaiReplay, MjSoulReplay, Kyoku, WinResultContext (riichienv_amd.replay); the
+parse_hand, parse_tile (riichienv_amd.hand); MjaiReplay, MjSoulReplay, Kyoku, WinResultContext (riichienv_amd.replay); Yaku, get_yaku_by_id, get_all_yaku
+(riichienv_amd.yaku_table); the
 `convert` and `consts` modules.
 """
 from .vecenv import VecRiichiEnv, RmjError, load_lib  # noqa: F401
@@ -14,6 +15,7 @@ _LAZY = {
     "hand": ("Conditions", "HandEvaluator", "HandEvaluator3P", "Wind", "WinResult", "Score", "calculate_score", "calculate_shanten",
              "calculate_shanten_3p", "check_riichi_candidates", "parse_hand", "parse_tile"),
     "replay": ("MjaiReplay", "MjSoulReplay", "Kyoku", "WinResultContext"),
+    "yaku_table": ("Yaku", "get_yaku_by_id", "get_all_yaku"),
 }
 __all__ = ["VecRiichiEnv", "RmjError", "load_lib", "convert", "consts"] + [n for names in _LAZY.values() for n in names]
 

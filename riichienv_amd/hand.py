@@ -55,6 +55,12 @@ class WinResult:  # types.rs:282-293
         self.han, self.fu = int(r.han), int(r.fu)
         self.pao_payer = None
 
+    def yaku_list(self):
+        """the Yaku entries of the ids in `yaku` (ids without an entry are skipped)"""
+        from .yaku_table import get_yaku_by_id
+
+        return [y for y in (get_yaku_by_id(i) for i in self.yaku) if y is not None]
+
     def __repr__(self):
         return f"WinResult(is_win={self.is_win}, han={self.han}, fu={self.fu}, yaku={self.yaku}, ron_agari={self.ron_agari})"
 

@@ -69,3 +69,30 @@ def test_the_package_answers_to_the_reference_names():
     assert (rv.consts.N_TILE_TYPES_4P, rv.consts.N_TILE_TYPES_3P, rv.consts.N_TILES_4P, rv.consts.N_TILES_3P) == (34, 27, 136, 108)
     with pytest.raises(AttributeError):
         rv.no_such_name
+
+
+def test_yaku_table():
+    """yaku.rs:35-127: one entry per yaku id the evaluator can emit; id = Mahjong Soul's id; Tenhou's indices"""
+    import json
+    import os
+
+    import riichienv_amd as rv
+
+    allk = rv.get_all_yaku()
+    assert len(allk) == 49 and len({y.id for y in allk}) == 49 and all(y.id == y.mjsoul_id for y in allk)
+    assert [y.id for y in allk] == sorted(y.id for y in allk) and rv.get_yaku_by_id(46) is None and rv.get_yaku_by_id(0) is None
+    for i, en, tenhou in ((1, "Menzen Tsumo", 0), (2, "Riichi", 1), (30, "Ippatsu", 2), (14, "Pinfu", 7), (12, "Tanyao", 8), (25, "Chiitoitsu", 22),
+                          (31, "Dora", 52), (33, "Ura Dora", 53), (32, "Aka Dora", 54), (42, "Kokushi Musou", 47), (50, "Dai Suusi", 49)):
+        y = rv.get_yaku_by_id(i)
+        assert (y.name_en, y.tenhou_id) == (en, tenhou), i
+    assert rv.get_yaku_by_id(2).name == "立直" and "Riichi" in repr(rv.get_yaku_by_id(2))
+    # every id in the reference's golden agari cases has an entry
+    gold = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    seen = set()
+    for f in ("agari_4p.json", "agari_3p.json"):
+        with open(os.path.join(gold, f)) as fh:
+            data = json.load(fh)
+        for case in (data if isinstance(data, list) else data.get("cases", [])):
+            exp = case.get("expected", case)
+            seen.update(int(y) for y in exp.get("yaku", []))
+    assert seen and all(rv.get_yaku_by_id(i) is not None for i in seen), sorted(seen)

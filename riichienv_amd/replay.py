@@ -383,6 +383,25 @@ class WinResultContext:
         for k in self.__slots__:
             setattr(self, k, kw.get(k))
 
+    def create_calculator(self):
+        """replay/mod.rs:2160-2163: a HandEvaluator (3P: HandEvaluator3P) over this context's tiles and melds"""
+        from .compat import Meld
+        from .hand import HandEvaluator, HandEvaluator3P
+
+        melds = [Meld(m["meld_type"], list(m["tiles"]), m["opened"], m["from_who"], m["called_tile"]) for m in self.melds]
+        return (HandEvaluator3P if self.sanma else HandEvaluator)(list(self.tiles), melds)
+
+    def calculate(self, calculator, conditions=None):
+        """replay/mod.rs:2165-2179: calculator.calc(agari tile, indicators, ura indicators, conditions or the context's own)"""
+        from .hand import Conditions
+
+        cond = conditions
+        if cond is None:
+            c = self.conditions
+            cond = Conditions(**{k: c[k] for k in ("tsumo", "riichi", "double_riichi", "ippatsu", "haitei", "houtei", "rinshan", "chankan",
+                                                    "tsumo_first_turn", "player_wind", "round_wind", "honba", "kita_count")})
+        return calculator.calc(self.agari_tile, list(self.dora_indicators), cond, list(self.ura_indicators))
+
     def hand_case(self) -> abi.HandCase:
         hc = abi.HandCase()
         hc.n_tiles = len(self.tiles)

@@ -89,3 +89,23 @@ def test_waits_tenpai_and_riichi_candidates():
     # 3P: the evaluator of the sanma variant scores with two payers
     r3 = HandEvaluator3P.hand_from_text("111m456p789s111z2z").calc(parse_tile("2z"), conditions=Conditions(tsumo=True, player_wind=Wind.South))
     assert r3.is_win and r3.tsumo_agari_oya > 0 and r3.ron_agari == 0
+
+
+def test_win_context_create_calculator_and_calculate():
+    """replay/mod.rs:2160-2179 on the reference's real log: WinResultContext.create_calculator() + calculate() give what the batch
+    evaluation of the same contexts gives (and the payments of the log, tests/win_context_util.check_points)"""
+    from riichienv_amd.replay import evaluate_win_contexts
+    from tests.win_context_util import check_points, contexts_with_deltas
+
+    rows = contexts_with_deltas()
+    evaluate_win_contexts([c for _, c, _ in rows])
+    for k, c, h in rows:
+        r = c.calculate(c.create_calculator())
+        a = c.actual
+        assert (r.is_win, r.han, r.fu, r.yaku, r.ron_agari, r.tsumo_agari_oya, r.tsumo_agari_ko) == (
+            bool(a.is_win), a.han, a.fu, list(a.yaku[: a.n_yaku]), a.ron_agari, a.tsumo_agari_oya, a.tsumo_agari_ko)
+        check_points(k, c, h, r)
+        assert [y.id for y in r.yaku_list()] == r.yaku
+    k, c, _ = rows[0]
+    no_riichi = c.calculate(c.create_calculator(), Conditions(tsumo=c.conditions["tsumo"], player_wind=c.conditions["player_wind"], round_wind=c.conditions["round_wind"]))
+    assert 2 not in no_riichi.yaku

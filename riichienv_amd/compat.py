@@ -384,6 +384,7 @@ class RiichiEnv:
         self._v = vecenv.VecRiichiEnv(1, game_mode=self._mode, seeds=np.array([s], np.uint64), rule_bits=self._rule.bits(),
                                       skip_mjai_logging=skip_mjai_logging, round_wind=round_wind or 0, device=device,
                                       event_ring=8192)
+        self._seed, self._skip_log = (None if seed is None else int(seed)), bool(skip_mjai_logging)
         self._cursor = [0, 0, 0, 0]  # player_event_counts (state/mod.rs:211-218)
         self._applied = None         # host-side logs of apply_event / observe_event (see apply_event)
         self._np = 3 if self._mode >= 3 else 4
@@ -670,6 +671,109 @@ class RiichiEnv:
                 d[50] = p.pao_daisuushi
             out.append(d)
         return out
+
+    # per-seat flags (env.rs:300-470): list getters, list setters
+    def _seat_flag(name, cast=bool):   # noqa: N805
+        def get(self):
+            return [cast(getattr(p, name)) for p in list(self._view().players)[: self._np]]
+
+        def put(self, values):
+            def f(v):
+                for p, x in enumerate(values):
+                    setattr(v.players[p], name, int(x))
+            self._poke(f)
+        return property(get, put)
+
+    riichi_stage = _seat_flag("riichi_stage")
+    double_riichi_declared = _seat_flag("double_riichi_declared")
+    missed_agari_riichi = _seat_flag("missed_agari_riichi")
+    missed_agari_doujun = _seat_flag("missed_agari_doujun")
+    nagashi_eligible = _seat_flag("nagashi_eligible")
+    ippatsu_cycle = _seat_flag("ippatsu_cycle")
+    score_deltas = _seat_flag("score_delta", int)
+    del _seat_flag
+
+    @property
+    def forbidden_discards(self):
+        return [list(p.forbidden[: p.n_forbidden]) for p in list(self._view().players)[: self._np]]
+
+    @forbidden_discards.setter
+    def forbidden_discards(self, lists):
+        def f(v):
+            for p, lst in enumerate(lists):
+                v.players[p].n_forbidden = min(len(lst), 2)
+                for i, t in enumerate(list(lst)[:2]):
+                    v.players[p].forbidden[i] = t
+        self._poke(f)
+
+    @property
+    def is_done(self):
+        return bool(self._view().is_done)
+
+    @property
+    def is_rinshan_flag(self):
+        return bool(self._view().is_rinshan_flag)
+
+    @is_rinshan_flag.setter
+    def is_rinshan_flag(self, b):
+        self._poke(lambda v: setattr(v, "is_rinshan_flag", int(bool(b))))
+
+    @property
+    def riichi_pending_acceptance(self):
+        x = self._view().riichi_pending_acceptance
+        return None if x < 0 else int(x)
+
+    @riichi_pending_acceptance.setter
+    def riichi_pending_acceptance(self, x):
+        self._poke(lambda v: setattr(v, "riichi_pending_acceptance", -1 if x is None else int(x)))
+
+    @property
+    def pending_kan_dora_count(self):
+        return int(self._view().pending_kan_dora_count)
+
+    @pending_kan_dora_count.setter
+    def pending_kan_dora_count(self, n):
+        self._poke(lambda v: setattr(v, "pending_kan_dora_count", int(n)))
+
+    @property
+    def pending_kan(self):
+        """(seat, Action) of a kan waiting for the chankan answers, else None (state/mod.rs:61)"""
+        v = self._view()
+        return None if v.pending_kan_pid < 0 else (int(v.pending_kan_pid), Action._from_packed(v.pending_kan_action, int(v.pending_kan_pid)))
+
+    @property
+    def last_discard(self):
+        v = self._view()
+        return None if v.last_discard_pid < 0 else (int(v.last_discard_pid), int(v.last_discard_tile))
+
+    @last_discard.setter
+    def last_discard(self, x):
+        def f(v):
+            v.last_discard_pid, v.last_discard_tile = (-1, -1) if x is None else (int(x[0]), int(x[1]))
+        self._poke(f)
+
+    @property
+    def current_claims(self):
+        """{seat: legal claim actions} while the round waits for answers (state/mod.rs:60)"""
+        v = self._view()
+        if v.phase != Phase.WaitResponse:
+            return {}
+        return {p: self._get_legal_actions(p) for p in range(self._np) if (v.active_mask >> p) & 1}
+
+    @property
+    def agari_results(self):
+        """{seat: WinResult fields} of the round that ended the game (env.rs:606-607)"""
+        return self._v.win_results(0)
+
+    last_agari_results = agari_results
+
+    def game_mode(self):
+        return self._mode
+
+    game_type = property(lambda self: GameType(self._mode))
+    seed = property(lambda self: self._seed)
+    skip_mjai_logging = property(lambda self: self._skip_log)
+    player_event_counts = property(lambda self: list(self._cursor[: self._np]))
 
     oya = property(lambda self: self._view().oya)
     honba = property(lambda self: self._view().honba)

@@ -305,3 +305,46 @@ def test_ranks_and_points_kats():
     assert env.points("ouza-tyoujyo") == [100, 40, -40, -100] and env.points("ouza-normal") == [50, 20, -20, -50]
     with pytest.raises(ValueError, match="Unknown preset rule: nonexistent"):
         env.points("nonexistent")
+
+
+def test_state_attributes_of_the_reference_env():
+    """The state getters / setters the reference's tests reach for (riichienv-python/src/env.rs:134-622; _riichienv.pyi:762-863):
+    per-seat flags as lists, last_discard, current_claims, pending_kan, agari_results, game_mode / game_type / seed."""
+    from riichienv_amd.compat import ActionType, GameType, Phase, RandomAgent, RiichiEnv
+
+    env = RiichiEnv(game_mode="4p-red-half", seed=11, skip_mjai_logging=True)
+    obs = env.reset()
+    assert not env.is_done and env.game_mode() == 2 and env.game_type == GameType.YON_HANCHAN and env.seed == 11 and env.skip_mjai_logging
+    for name in ("riichi_stage", "double_riichi_declared", "missed_agari_riichi", "missed_agari_doujun", "ippatsu_cycle"):
+        assert getattr(env, name) == [False] * 4, name
+    assert env.nagashi_eligible == [True] * 4 and env.score_deltas == [0] * 4 and env.forbidden_discards == [[], [], [], []]
+    assert env.last_discard is None and env.pending_kan is None and env.current_claims == {} and env.riichi_pending_acceptance is None
+    assert env.pending_kan_dora_count == 0 and not env.is_rinshan_flag and env.agari_results == {}
+    # setters write through to the device record
+    env.missed_agari_doujun = [False, True, False, False]
+    env.forbidden_discards = [[], [], [4, 8], []]
+    env.riichi_pending_acceptance = 2
+    env.pending_kan_dora_count = 1
+    assert env.missed_agari_doujun == [False, True, False, False] and env.forbidden_discards[2] == [4, 8]
+    assert env.riichi_pending_acceptance == 2 and env.pending_kan_dora_count == 1
+    env.riichi_pending_acceptance = None
+    env.pending_kan_dora_count = 0
+    env.missed_agari_doujun = [False] * 4
+    env.forbidden_discards = [[], [], [], []]
+    # play until somebody is offered a claim: current_claims = the published lists of the answering seats
+    agent = RandomAgent(seed=3)
+    seen = False
+    for _ in range(400):
+        if env.done():
+            break
+        if env.phase == Phase.WaitResponse:
+            cl = env.current_claims
+            assert set(cl) == set(env.active_players) == set(obs) and env.last_discard is not None
+            for p, acts in cl.items():
+                assert [(a.action_type, a.tile) for a in acts] == [(a.action_type, a.tile) for a in obs[p].legal_actions()]
+                assert any(a.action_type == ActionType.PASS for a in acts)
+            seen = True
+            break
+        obs = env.step({p: agent.act(o) for p, o in obs.items()})
+    assert seen
+    assert env.player_event_counts == [0, 0, 0, 0] or all(c >= 0 for c in env.player_event_counts)

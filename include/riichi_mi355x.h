@@ -178,6 +178,14 @@ int rmj_reset(rmj_handle h, const uint8_t* select, const uint8_t* walls, const u
 
 /* RiichiEnv.step (env.rs:857-872): actions[n][4] packed, RMJ_NO_ACTION for seats that do not act.
  * Games that are done are left untouched (state/mod.rs:331-333). */
+/* RiichiEnv.clone / __copy__ / __deepcopy__ (riichienv-python/src/env.rs:358-372) for the whole batch: a new handle on the same
+ * device with the same configuration whose games are in exactly the state of `h`'s - records, walls, published lists / masks /
+ * waits / status, event rings, win results (device-to-device copies of the slabs; SURVEY section 5, checkpoint / resume). */
+int rmj_clone(rmj_handle h, rmj_handle* out);
+/* The complete state of game src_idx[i] of `src` copied into game dst_idx[i] of `dst` (same device, player count and event ring
+ * size; dst may be src when the destination games are not among the source games; destination indices distinct): forks for a
+ * tree search, a pool of saved positions, refilling slots.  Host index arrays. */
+int rmj_copy_games(rmj_handle dst, const uint32_t* dst_idx, rmj_handle src, const uint32_t* src_idx, uint32_t n);
 int rmj_step(rmj_handle h, const rmj_action_t* actions);
 /* Same, `actions` is a device pointer (zero-copy from a GPU policy). */
 int rmj_step_device(rmj_handle h, const rmj_action_t* d_actions);

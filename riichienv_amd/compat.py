@@ -393,6 +393,25 @@ class RiichiEnv:
     def num_players(self):
         return self._np
 
+    def clone(self):
+        """RiichiEnv.clone / __copy__ / __deepcopy__ (env.rs:358-372): an independent environment in the same state"""
+        import copy
+
+        out = object.__new__(RiichiEnv)
+        out.__dict__.update({k: v for k, v in self.__dict__.items() if k != "_v"})
+        out._v = self._v.clone()
+        out._cursor = list(self._cursor)
+        out._applied = copy.deepcopy(self._applied)
+        if hasattr(self, "_applied_seat"):
+            out._applied_seat = copy.deepcopy(self._applied_seat)
+        return out
+
+    def __copy__(self):
+        return self.clone()
+
+    def __deepcopy__(self, memo):
+        return self.clone()
+
     # ---- MJAI event ingestion (env.rs:880-948; full-information streams, see rmj_apply_events) -------------
     def apply_event(self, event):
         self._v.apply_events([event], masked_ok=True)  # "?" -> tile 0 like parse_mjai_tile (event_handler.rs:8-10)

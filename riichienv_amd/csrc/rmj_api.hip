@@ -931,6 +931,55 @@ int rmj_destroy(rmj_handle h) {
     return RMJ_OK;
 }
 
+int rmj_clone(rmj_handle h, rmj_handle* out) {
+    if (!h || !out) return fail(RMJ_ERR_ARG, "null argument");
+    HIPCHK(hipSetDevice(h->cfg.device));
+    RmjConfig cfg = h->cfg;
+    cfg.seeds = nullptr;
+    cfg.event_ring = h->d.ring_mask + 1u;
+    rmj_handle c = nullptr;
+    int rc = rmj_create(&cfg, &c);
+    if (rc) return rc;
+    c->want_streams = h->want_streams;
+    c->quad = h->quad;
+    HIPCHK(hipStreamSynchronize(h->stream));
+    const size_t B = h->cfg.n_games, ring = (size_t)h->d.ring_mask + 1u;
+    const struct { void* dst; const void* src; size_t bytes; } slabs[] = {
+        {c->d.core, h->d.core, B * sizeof(GState)}, {c->d.wall, h->d.wall, B * RMJ_WALL_STRIDE},
+        {c->d.legal, h->d.legal, B * 4 * RMJ_MAX_LEGAL * sizeof(uint64_t)}, {c->d.nlegal, h->d.nlegal, B * 4}, {c->d.mask, h->d.mask, B * 4 * 82},
+        {c->d.waits, h->d.waits, B * 4 * sizeof(uint64_t)}, {c->d.status, h->d.status, B * sizeof(uint32_t)},
+        {c->d.events, h->d.events, B * ring * sizeof(RmjEvent)}, {c->d.win, h->d.win, B * 4 * sizeof(RmjWinResult)}};
+    for (const auto& s : slabs) {
+        if (hipMemcpyAsync(s.dst, s.src, s.bytes, hipMemcpyDeviceToDevice, c->stream) != hipSuccess) {
+            rmj_destroy(c);
+            return fail(RMJ_ERR_HIP, "rmj_clone: device copy failed");
+        }
+    }
+    HIPCHK(hipStreamSynchronize(c->stream));
+    *out = c;
+    return RMJ_OK;
+}
+
+int rmj_copy_games(rmj_handle dst, const uint32_t* dst_idx, rmj_handle src, const uint32_t* src_idx, uint32_t n) {
+    DevTmp tmp;
+    if (!dst || !src || (n && (!dst_idx || !src_idx))) return fail(RMJ_ERR_ARG, "null argument");
+    if (dst->cfg.device != src->cfg.device || (dst->cfg.game_mode >= 3) != (src->cfg.game_mode >= 3) || dst->d.ring_mask != src->d.ring_mask)
+        return fail(RMJ_ERR_ARG, "rmj_copy_games: the handles must share device, player count and event ring size");
+    if (n == 0) return RMJ_OK;
+    for (uint32_t i = 0; i < n; i++)
+        if (dst_idx[i] >= dst->cfg.n_games || src_idx[i] >= src->cfg.n_games) return fail(RMJ_ERR_ARG, "rmj_copy_games: game index out of range");
+    HIPCHK(hipSetDevice(dst->cfg.device));
+    uint32_t *d_a, *d_b;
+    int rc;
+    if ((rc = tmp.upload(dst_idx, n, &d_a)) || (rc = tmp.upload(src_idx, n, &d_b))) return rc;
+    if (src != dst) HIPCHK(hipStreamSynchronize(src->stream));
+    if (dst->cfg.game_mode >= 3) hipLaunchKernelGGL(rmj3::k_copy_games, dim3(n), dim3(64), 0, dst->stream, (const Env*)dst->d_env, (const Env*)src->d_env, d_a, d_b, n);
+    else hipLaunchKernelGGL(rmj4::k_copy_games, dim3(n), dim3(64), 0, dst->stream, (const Env*)dst->d_env, (const Env*)src->d_env, d_a, d_b, n);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(dst->stream));
+    return RMJ_OK;
+}
+
 int rmj_reset(rmj_handle h, const uint8_t* select, const uint8_t* walls, const uint8_t* oya, const uint8_t* round_wind,
               const int32_t* scores, const uint8_t* honba, const uint32_t* kyotaku) {
     DevTmp tmp;

@@ -204,5 +204,31 @@ __global__ __launch_bounds__(64, 4) void k_refresh(const Env* __restrict__ Ep, u
     }
 }
 
+// rmj_copy_games: the complete per-game state (record, wall, published lists / masks / waits / status, event ring, win results) of
+// game src_idx[i] of `Sp` into game dst_idx[i] of `Dp`; one wave per pair, 4-byte words (every slab stride is a multiple of 4).
+__device__ __forceinline__ void copy_words(void* dst, const void* src, size_t bytes, int lane) {
+    uint32_t* d = reinterpret_cast<uint32_t*>(dst);
+    const uint32_t* s = reinterpret_cast<const uint32_t*>(src);
+    for (size_t i = lane; i < bytes / 4; i += 64) d[i] = s[i];
+}
+__global__ __launch_bounds__(64) void k_copy_games(const Env* __restrict__ Dp, const Env* __restrict__ Sp, const uint32_t* __restrict__ dst_idx,
+                                                   const uint32_t* __restrict__ src_idx, uint32_t n) {
+    const uint32_t i = blockIdx.x;
+    if (i >= n) return;
+    CEnv& D = *(CEnv*)Dp;
+    CEnv& S = *(CEnv*)Sp;
+    const size_t a = dst_idx[i], b = src_idx[i];
+    const int lane = threadIdx.x & 63;
+    const size_t ring = (size_t)S.ring_mask + 1u;
+    copy_words(D.core + a, S.core + b, sizeof(GState), lane);
+    copy_words(D.wall + a * RMJ_WALL_STRIDE, S.wall + b * RMJ_WALL_STRIDE, RMJ_WALL_STRIDE, lane);
+    copy_words(D.legal + a * 4 * RMJ_MAX_LEGAL, S.legal + b * 4 * RMJ_MAX_LEGAL, 4 * RMJ_MAX_LEGAL * sizeof(uint64_t), lane);
+    copy_words(D.nlegal + a * 4, S.nlegal + b * 4, 4, lane);
+    copy_words(D.mask + a * 328, S.mask + b * 328, 328, lane);
+    copy_words(D.waits + a * 4, S.waits + b * 4, 4 * sizeof(uint64_t), lane);
+    copy_words(D.status + a, S.status + b, sizeof(uint32_t), lane);
+    copy_words(D.events + a * ring, S.events + b * ring, ring * sizeof(RmjEvent), lane);
+    copy_words(D.win + a * 4, S.win + b * 4, 4 * sizeof(RmjWinResult), lane);
+}
 
 }  // namespace RMJ_NS

@@ -348,3 +348,22 @@ def test_state_attributes_of_the_reference_env():
         obs = env.step({p: agent.act(o) for p, o in obs.items()})
     assert seen
     assert env.player_event_counts == [0, 0, 0, 0] or all(c >= 0 for c in env.player_event_counts)
+
+
+def test_quickstart_example_runs():
+    """examples/quickstart.py: the four ways in (reference loop, batched rollout, policy loop on the GPU, hand math + logs)"""
+    import importlib.util
+    import os
+
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "examples", "quickstart.py")
+    spec = importlib.util.spec_from_file_location("quickstart", path)
+    q = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(q)
+    scores, ranks = q.reference_loop()
+    assert len(scores) == 4 and sorted(ranks) == [1, 2, 3, 4]
+    total, _ = q.batched_rollout(1024, 100)
+    assert total == 1024 * 100
+    shape, steps = q.policy_loop(512, 10)
+    assert shape == (74, 34) and steps > 0
+    hand, n_dec, first = q.hands_and_logs()
+    assert hand[:4] == (2, 40, 1300, 700) and n_dec > 20 and len(first) == 3

@@ -364,3 +364,48 @@ def test_greedy_play_parity(mode, rule):
             t = json.loads(s)["type"]
             kinds[t] = kinds.get(t, 0) + 1
     assert kinds.get("hora", 0) >= 40 and kinds.get("reach_accepted", 0) >= 30, kinds
+
+
+@pytest.mark.parametrize("n", [1, 2, 3, 5, 7, 9])
+def test_ragged_batch_sizes(n):
+    """Batches that do not fill their last wave (four games per wave): the fused rollout, single device-policy steps, host actions
+    and the encoders all handle 1 .. 3 live rows in a quad; every game still equals its oracle."""
+    from oracle import oracle
+    from riichienv_amd import vecenv
+
+    seed, pseed = 900 + n, 5
+    for mode in (2, 5):
+        env = vecenv.VecRiichiEnv(n, game_mode=mode, seed=seed, event_ring=8192)
+        games = [oracle.Game(game_mode=mode, seed=game_seed(seed, g)) for g in range(n)]
+        env.reset()
+        for o in games:
+            o.reset()
+        def advance(k):
+            for g, o in enumerate(games):
+                for _ in range(k):
+                    if o.status()[2]:
+                        o.reset()
+                    else:
+                        o.step(o.random_actions(pseed, g))
+        env.step_random(pseed, 200, auto_reset=True)          # one launch, every wave loops
+        advance(200)
+        _compare(env, games, range(n), 200)
+        for _ in range(50):                                   # a launch per step
+            env.step_random(pseed, 1, auto_reset=True)
+        advance(50)
+        _compare(env, games, range(n), 250)
+        for step in range(40):                                # host actions
+            acts = np.array([games[g].random_actions(pseed, g) for g in range(n)], dtype=np.uint64)
+            env.step(acts)
+            for g, o in enumerate(games):
+                if not o.status()[2]:
+                    o.step([int(x) for x in acts[g]])
+        _compare(env, games, range(n), 290)
+        enc = env.encode()
+        for g, o in enumerate(games):
+            act = o.status()[0]
+            for s in range(3 if mode >= 3 else 4):
+                if (act >> s) & 1:
+                    assert enc[g, s].tobytes() == o.encode(s, mode >= 3).tobytes(), (n, mode, g, s)
+            assert env.mjai_log(g) == o.log(), (n, mode, g)
+        env.close()

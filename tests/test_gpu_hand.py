@@ -235,3 +235,16 @@ def test_shanten_and_ukeire_equal_the_reference_tables():
         assert (vecenv.effective_tiles(hands[k], sanma=sanma) == eff_exp[k]).all(), tag
         k = uke_exp >= 0
         assert (vecenv.best_ukeire(hands[k], vis[k], sanma=sanma) == uke_exp[k]).all(), tag
+
+
+def test_empty_batches():
+    """n = 0 is a valid batch for every batched hand entry point (nothing launched, RMJ_OK)"""
+    from riichienv_amd import vecenv
+
+    assert vecenv.eval_hands([]) == []
+    z = np.zeros((0, 34), np.uint8)
+    ag, tp, w = vecenv.agari_counts(z)
+    assert ag.shape == (0,) and tp.shape == (0,) and w.shape == (0,)
+    assert vecenv.shanten(z).shape == (0,) and vecenv.shanten(z, True).shape == (0,)
+    e = np.zeros(0, np.uint8)
+    assert vecenv.calculate_score(e, e, e, e, np.zeros(0, np.uint32), e).shape[0] == 0

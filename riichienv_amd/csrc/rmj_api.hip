@@ -934,6 +934,7 @@ int rmj_destroy(rmj_handle h) {
 int rmj_clone(rmj_handle h, rmj_handle* out) {
     if (!h || !out) return fail(RMJ_ERR_ARG, "null argument");
     HIPCHK(hipSetDevice(h->cfg.device));
+    HIPCHK(hipStreamSynchronize(h->stream));   // (before anything is allocated: an early return below must not strand the copy)
     RmjConfig cfg = h->cfg;
     cfg.seeds = nullptr;
     cfg.event_ring = h->d.ring_mask + 1u;
@@ -942,7 +943,6 @@ int rmj_clone(rmj_handle h, rmj_handle* out) {
     if (rc) return rc;
     c->want_streams = h->want_streams;
     c->quad = h->quad;
-    HIPCHK(hipStreamSynchronize(h->stream));
     const size_t B = h->cfg.n_games, ring = (size_t)h->d.ring_mask + 1u;
     const struct { void* dst; const void* src; size_t bytes; } slabs[] = {
         {c->d.core, h->d.core, B * sizeof(GState)}, {c->d.wall, h->d.wall, B * RMJ_WALL_STRIDE},
@@ -955,7 +955,10 @@ int rmj_clone(rmj_handle h, rmj_handle* out) {
             return fail(RMJ_ERR_HIP, "rmj_clone: device copy failed");
         }
     }
-    HIPCHK(hipStreamSynchronize(c->stream));
+    if (hipStreamSynchronize(c->stream) != hipSuccess) {
+        rmj_destroy(c);
+        return fail(RMJ_ERR_HIP, "rmj_clone: device copy failed");
+    }
     *out = c;
     return RMJ_OK;
 }

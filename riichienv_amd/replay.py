@@ -290,11 +290,20 @@ class Kyoku:
         the seat that did claim, highest seat first (the iterator pops its queue from the back, :211); skip_single_action drops
         decisions with at most one legal action.  The round runs as a one-game ReplayBatch on the GPU - datasets over many
         logs should use ReplayBatch directly, which replays them in lock-step."""
+        n = len(self.scores)
+        bits = abi.RULE_MJSOUL if (rule or self.rule) == "mjsoul" else abi.RULE_TENHOU
+        key = (5 if n == 3 else 2, bits, device)
+        pool = _STEP_ENVS.setdefault(key, [])       # one-game environments are reused: a start_kyoku event rewrites the round
+        env = pool.pop() if pool else vecenv.VecRiichiEnv(1, game_mode=key[0], seed=0, rule_bits=bits, device=device, skip_mjai_logging=True)
+        try:
+            yield from self._steps_on(env, seat, skip_single_action, extended)
+        finally:
+            pool.append(env)
+
+    def _steps_on(self, env, seat, skip_single_action, extended):
         from .compat import Action
 
         n = len(self.scores)
-        bits = abi.RULE_MJSOUL if (rule or self.rule) == "mjsoul" else abi.RULE_TENHOU
-        env = vecenv.VecRiichiEnv(1, game_mode=5 if n == 3 else 2, seed=0, rule_bits=bits, device=device, skip_mjai_logging=True)
         rb = ReplayBatch([[{"type": "start_game"}] + self.to_mjai_events()], extended=extended, include_pass=True, env=env)
         for smp in rb.samples():
             order = list(range(len(smp["seat"])))
@@ -345,6 +354,9 @@ class Kyoku:
         return dict(chang=self.chang, ju=self.ju, ben=self.ben, liqibang=self.liqibang, scores=list(self.scores),
                     end_scores=list(self.end_scores), wliqi=list(self.wliqi),
                     delta_scores=[e - s for s, e in zip(self.scores, self.end_scores)] if len(self.scores) == len(self.end_scores) else [])
+
+
+_STEP_ENVS = {}   # (game mode, rule bits, device) -> idle one-game environments of Kyoku.steps
 
 
 class StepObservation:

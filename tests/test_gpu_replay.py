@@ -229,6 +229,29 @@ def test_steps_of_a_real_round_order_and_filters():
         assert any(a.action_type == l.action_type and a.tile == l.tile and a.consume_tiles == l.consume_tiles for l in o.legal_actions())
 
 
+def test_steps_reuses_its_environment_without_leaking_state():
+    """Kyoku.steps keeps a pool of one-game environments; walking all twelve rounds of the real log (the dataset loop of
+    riichienv_ml/datasets/mjai_logs.py:100-113: every round, every seat) on reused environments gives the decisions a fresh
+    environment gives, and two interleaved iterators do not share one"""
+    from riichienv_amd import replay
+    from riichienv_amd.replay import MjaiReplay
+
+    ks = list(MjaiReplay.from_jsonl(LOG).take_kyokus())
+    first = [[(s, a.action_type, a.tile, o.encode()) for s, o, a in k.steps(skip_single_action=False)] for k in ks]
+    replay._STEP_ENVS.clear()
+    fresh = []
+    for k in ks:
+        fresh.append([(s, a.action_type, a.tile, o.encode()) for s, o, a in k.steps(skip_single_action=False)])
+        replay._STEP_ENVS.clear()                  # a new environment for every round
+    assert first == fresh and sum(len(x) for x in first) > 700
+    per_seat = sum(len(list(k.steps(seat))) for k in ks for seat in range(4))
+    assert per_seat == sum(len(list(k.steps())) for k in ks)
+    a, b = ks[0].steps(skip_single_action=False), ks[1].steps(skip_single_action=False)
+    mixed = [x for pair in zip(a, b) for x in pair]
+    want = [x for pair in zip(first[0], first[1]) for x in pair]
+    assert [(s, act.action_type, act.tile) for s, _, act in mixed] == [(s, t, tile) for s, t, tile, _ in want]
+
+
 def test_pass_samples_carry_the_missed_ron_furiten():
     """tests/env/test_apply_event.py:535-632 (TestReplayFuriten) on ReplayBatch: a seat that lets a Ron go is in same-turn furiten
     until its own discard (the second 3m is offered again), in riichi for good (the second 3m yields no sample at all)."""

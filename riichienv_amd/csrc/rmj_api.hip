@@ -759,6 +759,12 @@ struct rmj_env {
     int want_streams = 4;      // parts a multi-step device rollout is cut into (rmj_set_rollout_streams; RMJ_STEP_STREAMS at create)
     int quad = 2;              // device-policy steps: 0 = one game per wave (k_step), 1 = four games per wave (k_step4), 2 = and a
                                // rollout of >= 2 steps is ONE launch in which every wave steps its own games (k_step4<true>); RMJ_STEP4 at create
+    // long fused rollouts hand the work out in (quad, chunk) tickets to a grid that fits the chip once (k_step4_queue)
+    int queue_chunk = 64;      // steps per ticket; RMJ_QUEUE_CHUNK at create, 0 = off (every wave keeps one quad for the rollout)
+    uint32_t* d_qheads = nullptr;   // [8][RMJ_Q_STRIDE] ticket counters, one line per XCD
+    uint32_t* d_qdone = nullptr;    // [quads] chunks finished
+    uint32_t q_slots = 0;           // waves of k_step4_queue the device holds at once
+    uint32_t queue_skip_xcds = 0;   // test hook: XCDs whose waves leave the queue kernel at once (RMJ_QUEUE_TEST_SKIP_XCDS at create)
 };
 // device staging memory of at least `bytes` bytes, owned by the handle
 static int scratch_for(rmj_env* h, size_t bytes, void** out) {
@@ -835,6 +841,8 @@ static int create_impl(rmj_env* h, const RmjConfig* cfg, uint64_t** d_seeds_out)
     h->ring = r2;
     if (const char* e = getenv("RMJ_STEP_STREAMS")) h->want_streams = atoi(e);
     if (const char* e = getenv("RMJ_STEP4")) h->quad = atoi(e);
+    if (const char* e = getenv("RMJ_QUEUE_CHUNK")) h->queue_chunk = atoi(e);
+    if (const char* e = getenv("RMJ_QUEUE_TEST_SKIP_XCDS")) h->queue_skip_xcds = (uint32_t)strtoul(e, nullptr, 0) & 0xFFu;
     const size_t B = cfg->n_games;
     Env& d = h->d;
     HIPCHK(hipStreamCreateWithFlags(&h->own_stream, hipStreamNonBlocking));
@@ -920,7 +928,7 @@ int rmj_destroy(rmj_handle h) {
     hipSetDevice(h->cfg.device);
     if (h->stream) hipStreamSynchronize(h->stream);
     hipFree(h->d.core); hipFree(h->d.wall); hipFree(h->d.legal); hipFree(h->d.nlegal); hipFree(h->d_decay); if (h->d_scratch) hipFree(h->d_scratch); hipFree(h->d.mask);
-    hipFree(h->d.waits); hipFree(h->d.status); hipFree(h->d.events); hipFree(h->d.win); hipFree(h->d_actions); hipFree(h->d_counter); hipFree(h->d_obs_offs); hipFree(h->d_env);
+    hipFree(h->d.waits); hipFree(h->d.status); hipFree(h->d.events); hipFree(h->d.win); hipFree(h->d_actions); hipFree(h->d_counter); hipFree(h->d_obs_offs); hipFree(h->d_env); hipFree(h->d_qheads); hipFree(h->d_qdone);
     if (h->own_stream) hipStreamDestroy(h->own_stream);
     for (int i = 0; i < RMJ_MAX_ROLLOUT_STREAMS - 1; i++) {
         if (h->xstream[i]) { hipStreamSynchronize(h->xstream[i]); hipStreamDestroy(h->xstream[i]); }
@@ -943,6 +951,7 @@ int rmj_clone(rmj_handle h, rmj_handle* out) {
     if (rc) return rc;
     c->want_streams = h->want_streams;
     c->quad = h->quad;
+    c->queue_chunk = h->queue_chunk;
     const size_t B = h->cfg.n_games, ring = (size_t)h->d.ring_mask + 1u;
     const struct { void* dst; const void* src; size_t bytes; } slabs[] = {
         {c->d.core, h->d.core, B * sizeof(GState)}, {c->d.wall, h->d.wall, B * RMJ_WALL_STRIDE},
@@ -1111,6 +1120,32 @@ int rmj_step_random(rmj_handle h, uint64_t policy_seed, uint32_t n_steps, int au
     if (h->quad >= 2 && n_steps >= 2 && h->want_streams >= 2) {   // (rmj_set_rollout_streams(h, 1): one launch per step, one stream)
         // four games per wave, the whole rollout in ONE launch: every wave steps its own games n_steps times (k_step4<true>)
         const dim3 grid((n + 3u) / 4u);
+        if (h->queue_chunk > 0 && grid.x >= 64u && n_steps >= 2u * (uint32_t)h->queue_chunk) {
+            // ... or, for a long rollout of a batch that does not fill the chip a whole number of times, in (quad, chunk) tickets
+            if (!h->d_qheads) {
+                HIPCHK(hipMalloc(&h->d_qheads, 8 * RMJ_Q_STRIDE * sizeof(uint32_t)));
+                HIPCHK(hipMalloc(&h->d_qdone, (size_t)grid.x * sizeof(uint32_t)));
+                int per_cu = 0, cus = 0;
+                const bool sanma = h->cfg.game_mode >= 3;
+                HIPCHK(sanma ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, rmj3::k_step4_queue, 64, 0)
+                             : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, rmj4::k_step4_queue, 64, 0));
+                HIPCHK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, h->cfg.device));
+                h->q_slots = (uint32_t)(per_cu > 0 ? per_cu : 1) * (uint32_t)(cus > 0 ? cus : 1);
+            }
+            HIPCHK(hipMemsetAsync(h->d_qheads, 0, 8 * RMJ_Q_STRIDE * sizeof(uint32_t), h->stream));
+            HIPCHK(hipMemsetAsync(h->d_qdone, 0, (size_t)grid.x * sizeof(uint32_t), h->stream));
+            const dim3 gq(grid.x < h->q_slots ? grid.x : h->q_slots);
+            const uint32_t chunk = (uint32_t)h->queue_chunk;
+            if (h->cfg.game_mode >= 3) {
+                hipLaunchKernelGGL(rmj3::k_step4_queue, gq, dim3(64), 0, h->stream, (const Env*)h->d_env, policy_seed, flags, n, n_steps, chunk, h->d_qheads, h->d_qdone, h->queue_skip_xcds);
+                hipLaunchKernelGGL(rmj3::k_step4_fixup, grid, dim3(64), 0, h->stream, (const Env*)h->d_env, policy_seed, flags, n, n_steps, (const uint32_t*)h->d_qdone);
+            } else {
+                hipLaunchKernelGGL(rmj4::k_step4_queue, gq, dim3(64), 0, h->stream, (const Env*)h->d_env, policy_seed, flags, n, n_steps, chunk, h->d_qheads, h->d_qdone, h->queue_skip_xcds);
+                hipLaunchKernelGGL(rmj4::k_step4_fixup, grid, dim3(64), 0, h->stream, (const Env*)h->d_env, policy_seed, flags, n, n_steps, (const uint32_t*)h->d_qdone);
+            }
+            HIPCHK(hipGetLastError());
+            return RMJ_OK;
+        }
         if (h->cfg.game_mode >= 3) hipLaunchKernelGGL(rmj3::k_step4<true>, grid, dim3(64), 0, h->stream, (const Env*)h->d_env, policy_seed, flags, 0u, n, n_steps, (const uint64_t*)nullptr);
         else hipLaunchKernelGGL(rmj4::k_step4<true>, grid, dim3(64), 0, h->stream, (const Env*)h->d_env, policy_seed, flags, 0u, n, n_steps, (const uint64_t*)nullptr);
         HIPCHK(hipGetLastError());

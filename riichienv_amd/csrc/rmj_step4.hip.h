@@ -707,14 +707,14 @@ __device__ __forceinline__ void r4_gen_act_legal(R4& q, int& nl_mine) {
 // One step of four consecutive games per wave (device policy only: rmj_step_random / rmj_bench_rollout); `load`: fetch the records from HBM first (the rollout loop keeps them in LDS)
 template <bool LOOP>
 __device__ __forceinline__ void step4_body(const Env* Ep, Quad4Shared& sh, uint64_t policy_seed, uint32_t flags, uint32_t g_base, uint32_t g_end,
-                                           bool load, uint64_t gs_row, const uint64_t* __restrict__ actions = nullptr) {
+                                           bool load, uint64_t gs_row, const uint64_t* __restrict__ actions = nullptr, uint32_t quad = 0xFFFFFFFFu) {
     CEnv& E = *(CEnv*)Ep;
 #ifdef RMJ_TL4
     uint64_t tl_prev = __builtin_readcyclecounter();
 #endif
     const int lane = threadIdx.x & 63;
     const int row = lane >> 4, r = lane & 15, rb = lane & 48;
-    const uint32_t g0 = g_base + blockIdx.x * 4u;
+    const uint32_t g0 = g_base + (quad == 0xFFFFFFFFu ? blockIdx.x : quad) * 4u;   // (k_step4_queue names the quad, the others own quad = block)
     const uint32_t g = g0 + (uint32_t)row;
     const uint32_t n_here = g_end - g0 < 4u ? g_end - g0 : 4u;   // games of this wave
     if (load) {   // ---- records: every row fetches its own 640 B (40 chunks of 16 B, three per lane)
@@ -1178,9 +1178,9 @@ __device__ __forceinline__ void step4_body(const Env* Ep, Quad4Shared& sh, uint6
 // step is hoisted out of the loop or kept live across it (the loop inlined: 48 VGPR + 37 SGPR spills).
 template <bool LOOP>
 __device__ __noinline__ void step4_call(const Env* Ep, uint64_t policy_seed, uint32_t flags, uint32_t g_base, uint32_t g_end, uint32_t load,
-                                        uint64_t gs_row) {
+                                        uint64_t gs_row, uint32_t quad = 0xFFFFFFFFu) {
     __shared__ Quad4Shared sh;
-    step4_body<LOOP>(uni_ptr(Ep), sh, uni(policy_seed), uni(flags), uni(g_base), uni(g_end), uni(load) != 0u, gs_row);
+    step4_body<LOOP>(uni_ptr(Ep), sh, uni(policy_seed), uni(flags), uni(g_base), uni(g_end), uni(load) != 0u, gs_row, nullptr, uni(quad));
 }
 #ifndef RMJ_STEP4_WAVES
 #define RMJ_STEP4_WAVES 6
@@ -1212,6 +1212,68 @@ __global__ __launch_bounds__(64, RMJ_STEP4_WAVES) void k_step4(const Env* __rest
         }
 #endif
     }
+}
+
+// The fused rollout with the work handed out in pieces.  k_step4<true> gives every wave one quad for the whole rollout; at 65 536
+// games that is 16 384 waves for ~7 168 wave slots, and the last 2 000 of them run on a chip that is three quarters empty
+// (524 288 games, where that tail does not matter, step 10 % faster).  Here a grid that fits the chip once pulls (quad, chunk)
+// tickets: chunk c of a quad = its steps [c * chunk, (c + 1) * chunk), in ticket order chunk-major, so chunk c - 1 of the same quad
+// was handed out a full round earlier.  A quad's chunks stay on ONE XCD (queue per XCD, quads dealt by quad % 8; the XCD is read
+// from the hardware register, not guessed from the block index): the per-XCD L2 is then the single point through which one
+// wave's record / lists / wall reach the next - stores are write-through to it, the hand-over is "drain stores, publish the chunk
+// count with an agent-scope atomic", the pick-up "poll it, invalidate this CU's L1 (acquire), load".  No cross-XCD traffic, no
+// L2 write-back.  Results are those of k_step4<true>: every game steps n_steps times with the same policy keys.
+#define RMJ_Q_STRIDE 32u   /* u32 words per XCD queue head (its own 128-byte line) */
+// (out of line: inlined into the ticket loop, the one-lane branches below were restructured into a loop nest that re-used a stale
+// ticket - the kernel then ran quads twice at once)
+__device__ __noinline__ uint32_t q_take_ticket(uint32_t* head) {
+    uint32_t t = 0u;
+    if ((threadIdx.x & 63u) == 0u) t = __hip_atomic_fetch_add(head, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return (uint32_t)__builtin_amdgcn_readfirstlane((int)t);
+}
+__device__ __noinline__ void q_wait_for(const uint32_t* slot, uint32_t want) {
+    if ((threadIdx.x & 63u) == 0u)
+        while (__hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < want) __builtin_amdgcn_s_sleep(8);
+    wave_sync();
+}
+__global__ __launch_bounds__(64, RMJ_STEP4_WAVES) void k_step4_queue(const Env* __restrict__ Ep, uint64_t policy_seed, uint32_t flags, uint32_t n_games,
+                                                                         uint32_t n_steps, uint32_t chunk, uint32_t* __restrict__ heads, uint32_t* __restrict__ done,
+                                                                         uint32_t skip_xcds) {
+    const uint32_t xcd = (uint32_t)__builtin_amdgcn_s_getreg((3 << 11) | 20) & 7u;   // HW_REG_XCC_ID[3:0]
+    if ((skip_xcds >> xcd) & 1u) return;   // test hook (RMJ_QUEUE_TEST_SKIP_XCDS): pretend these XCDs received no block -> k_step4_fixup
+    const uint32_t n_quads = (n_games + 3u) / 4u;
+    const uint32_t mine = n_quads > xcd ? (n_quads - xcd + 7u) / 8u : 0u;             // quads xcd, xcd + 8, ...
+    const uint32_t n_chunks = (n_steps + chunk - 1u) / chunk;
+    const uint32_t lane = threadIdx.x & 63u;
+    if (mine == 0u) return;
+#pragma unroll 1
+    for (;;) {
+        const uint32_t t = q_take_ticket(heads + xcd * RMJ_Q_STRIDE);
+        if (t >= mine * n_chunks) break;
+        const uint32_t c = t / mine, quad = (t - c * mine) * 8u + xcd;
+        if (c > 0u) q_wait_for(done + quad, c);   // the quad's previous chunk (handed out `mine` tickets ago) must have ended
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        const uint32_t steps = n_steps - c * chunk < chunk ? n_steps - c * chunk : chunk;
+        const uint32_t g = quad * 4u + (lane >> 4);
+        const uint64_t gs_row = sm64(policy_seed + ((CEnv*)Ep)->game_offset + (uint64_t)g);
+#pragma unroll 1
+        for (uint32_t it = 0; it < steps; it++) step4_call<true>(Ep, policy_seed, flags, 0u, n_games, it == 0 ? 1u : 0u, gs_row, quad);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this chunk's stores are in the XCD's L2
+        wave_sync();
+        if (lane == 0u) __hip_atomic_store(done + quad, c + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+
+// Safety net of k_step4_queue: where blocks run is not ours to decide - a quad whose XCD received no block at all (a partitioned
+// device, a dispatcher that skips an XCD) has done[quad] == 0 and is stepped here, by one wave for the whole rollout like
+// k_step4<true> (nothing of it has run yet, so no other cache holds newer data).  Every other wave exits at once.
+__global__ __launch_bounds__(64, RMJ_STEP4_WAVES) void k_step4_fixup(const Env* __restrict__ Ep, uint64_t policy_seed, uint32_t flags, uint32_t n_games,
+                                                                         uint32_t n_steps, const uint32_t* __restrict__ done) {
+    if (uni(__hip_atomic_load(done + blockIdx.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) != 0u) return;
+    const uint32_t g = blockIdx.x * 4u + ((threadIdx.x & 63u) >> 4);
+    const uint64_t gs_row = sm64(policy_seed + ((CEnv*)Ep)->game_offset + (uint64_t)g);
+#pragma unroll 1
+    for (uint32_t it = 0; it < n_steps; it++) step4_call<true>(Ep, policy_seed, flags, 0u, n_games, it == 0 ? 1u : 0u, gs_row);
 }
 
 }  // namespace RMJ_NS

@@ -195,3 +195,60 @@ def test_fused_feature_rollout_equals_step_then_encode():
     assert torch.equal(oa, ob)
     assert (a.step_counts() == b.step_counts()).all() and (a.scores() == b.scores()).all()
     assert float(oa.abs().sum()) > 0
+
+
+def _rollout_with(env_vars, mode, n, steps, seed=4242, pseed=PSEED):
+    """a device-policy rollout in an environment created under `env_vars` (the library reads its knobs at rmj_create)"""
+    from riichienv_amd import vecenv
+
+    old = {k: os.environ.get(k) for k in env_vars}
+    os.environ.update(env_vars)
+    try:
+        env = vecenv.VecRiichiEnv(n, game_mode=mode, seed=seed, event_ring=64)
+    finally:
+        for k, v in old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+    env.reset()
+    env.step_random(pseed, steps, auto_reset=True)
+    return env
+
+
+def _same_batch(a, b, n):
+    assert (a.step_counts() == b.step_counts()).all() and (a.scores() == b.scores()).all()
+    la, ca = a.legal()
+    lb, cb = b.legal()
+    assert (ca == cb).all() and (la == lb).all() and (a.mask() == b.mask()).all() and (a.waits() == b.waits()).all()
+    assert all((x == y).all() for x, y in zip(a.status(), b.status())) and (a.event_counts() == b.event_counts()).all()
+    for g in list(range(0, n, max(1, n // 64))) + [n - 1]:
+        assert not diff_dict(normalize_view(a.peek(g)), normalize_view(b.peek(g))), g
+        first = max(0, int(a.event_counts()[g]) - 60)            # the last 60 event records still in the ring, byte for byte
+        (ea, na), (eb, nb) = a.events(g, first, 60), b.events(g, first, 60)
+        assert na == nb and bytes(ea)[: na * C.sizeof(abi.Event)] == bytes(eb)[: nb * C.sizeof(abi.Event)], g
+
+
+@pytest.mark.parametrize("mode,n", [(2, 16384), (5, 16384), (2, 4099), (0, 1001)])
+def test_queued_rollout_equals_the_one_quad_per_wave_rollout(mode, n):
+    """k_step4_queue (the rollout handed out as (quad, chunk) tickets to a grid that fits the chip once, per-XCD queues) against
+    k_step4<true> (every wave keeps its quad for the whole rollout): same outputs for EVERY game, same records and log tails on a
+    sample; batches with a ragged last quad; several chunk lengths incl. one that does not divide the rollout."""
+    plain = _rollout_with({"RMJ_QUEUE_CHUNK": "0"}, mode, n, 333)
+    for chunk in ("64", "50", "166"):
+        queued = _rollout_with({"RMJ_QUEUE_CHUNK": chunk}, mode, n, 333)
+        _same_batch(plain, queued, n)
+        queued.close()
+    plain.close()
+
+
+def test_queued_rollout_survives_xcds_without_blocks():
+    """Where blocks run is the dispatcher's business: XCDs that receive no block of the queue kernel (simulated: their waves leave at
+    once) have their quads stepped by k_step4_fixup.  Same results with two, and with all but one, of the eight XCDs missing."""
+    n = 8192
+    plain = _rollout_with({"RMJ_QUEUE_CHUNK": "0"}, 2, n, 200)
+    for skip in ("0x24", "0xFE"):
+        q = _rollout_with({"RMJ_QUEUE_CHUNK": "64", "RMJ_QUEUE_TEST_SKIP_XCDS": skip}, 2, n, 200)
+        _same_batch(plain, q, n)
+        q.close()
+    plain.close()

@@ -128,6 +128,13 @@ def pmc_traffic(kernel, games_per_launch, mode):
     return None, None
 
 
+def fused_kernel_name(r):
+    """the kernel a multi-step device rollout ran as (rmj_step_random): long rollouts of batches between one and eight chip-fulls of
+    waves are handed out as (quad, chunk) tickets to a chip-sized grid (k_step4_queue); otherwise every wave keeps its quad for the
+    rollout (k_step4<true>).  The library reports which (RmjBenchResult.queued)."""
+    return "k_step4_queue" if int(r.queued) else "k_step4<true>"
+
+
 def workload_name(args):
     s = f"{args.games} parallel {MODES[args.mode]} games per GPU, device RandomAgent, auto-reset, MJAI logging on"
     if args.encode:
@@ -273,7 +280,7 @@ def main(argv=None):
             "full_path_frac": full_steps / max(steps_local, 1.0),
             "roofline": {"bound": "hbm", "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK, "traffic": traffic, "traffic_unit": "bytes/launch",
-                         "traffic_source": traffic_src, "kernel": "k_step4<true>" if steps_per_launch > 1 else "k_step4<false>",
+                         "traffic_source": traffic_src, "kernel": fused_kernel_name(r) if steps_per_launch > 1 else "k_step4<false>",
                          "kernel_ms": kernel_ms, "bytes_per_launch": bytes_per_launch, "bytes_per_game_step": b_step,
                          "games_per_launch": games_per_launch, "steps_per_launch": steps_per_launch,
                          "launches_in_flight": in_flight},

@@ -214,7 +214,8 @@ SEQ_SPARSE, SEQ_PROG, SEQ_CAND, SEQ_DELTA_PROG = 25, 256, 64, 64
 
 class BenchResult(C.Structure):
     _fields_ = [("total_ms", C.c_double), ("step_kernel_ms", C.c_double), ("env_steps", C.c_uint64),
-                ("launches", C.c_uint32), ("launches_in_flight", C.c_uint32), ("full_path_steps", C.c_uint64)]
+                ("launches", C.c_uint32), ("launches_in_flight", C.c_uint32), ("full_path_steps", C.c_uint64),
+                ("queued", C.c_uint32), ("reserved", C.c_uint32)]
 
 
 def hand_case_from_fixture(case: dict) -> HandCase:

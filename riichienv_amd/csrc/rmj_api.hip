@@ -764,6 +764,7 @@ struct rmj_env {
     uint32_t* d_qheads = nullptr;   // [8][RMJ_Q_STRIDE] ticket counters, one line per XCD
     uint32_t* d_qdone = nullptr;    // [quads] chunks finished
     uint32_t q_slots = 0;           // waves of k_step4_queue the device holds at once
+    int queue_force = 0;            // RMJ_QUEUE_FORCE at create (tests): tickets for every batch of >= 64 quads
     uint32_t queue_skip_xcds = 0;   // test hook: XCDs whose waves leave the queue kernel at once (RMJ_QUEUE_TEST_SKIP_XCDS at create)
 };
 // device staging memory of at least `bytes` bytes, owned by the handle
@@ -842,6 +843,7 @@ static int create_impl(rmj_env* h, const RmjConfig* cfg, uint64_t** d_seeds_out)
     if (const char* e = getenv("RMJ_STEP_STREAMS")) h->want_streams = atoi(e);
     if (const char* e = getenv("RMJ_STEP4")) h->quad = atoi(e);
     if (const char* e = getenv("RMJ_QUEUE_CHUNK")) h->queue_chunk = atoi(e);
+    if (const char* e = getenv("RMJ_QUEUE_FORCE")) h->queue_force = atoi(e);
     if (const char* e = getenv("RMJ_QUEUE_TEST_SKIP_XCDS")) h->queue_skip_xcds = (uint32_t)strtoul(e, nullptr, 0) & 0xFFu;
     const size_t B = cfg->n_games;
     Env& d = h->d;
@@ -952,6 +954,7 @@ int rmj_clone(rmj_handle h, rmj_handle* out) {
     c->want_streams = h->want_streams;
     c->quad = h->quad;
     c->queue_chunk = h->queue_chunk;
+    c->queue_force = h->queue_force;
     const size_t B = h->cfg.n_games, ring = (size_t)h->d.ring_mask + 1u;
     const struct { void* dst; const void* src; size_t bytes; } slabs[] = {
         {c->d.core, h->d.core, B * sizeof(GState)}, {c->d.wall, h->d.wall, B * RMJ_WALL_STRIDE},
@@ -1112,6 +1115,24 @@ static int rollout_streams(const rmj_env* h, uint32_t n_steps) {
     const int fit = (int)(h->cfg.n_games / RMJ_SPLIT_MIN_PART);
     return k > fit ? fit : k;
 }
+// Does a fused rollout of n_steps run as tickets (k_step4_queue)?  Worth it when the batch is more than one and fewer than eight
+// chip-fulls of waves: below, every quad is resident at once and there is no tail; far above, the tail is a small share and the
+// chunk hand-overs cost more than it (524 288 games: -2 %).
+static bool rollout_queued(rmj_env* h, uint32_t n_steps) {
+    const uint32_t quads = (h->cfg.n_games + 3u) / 4u;
+    if (!(h->quad >= 2 && n_steps >= 2 && h->want_streams >= 2) || h->queue_chunk <= 0 || n_steps < 2u * (uint32_t)h->queue_chunk) return false;
+    if (h->q_slots == 0) {
+        int per_cu = 0, cus = 0;
+        const bool sanma = h->cfg.game_mode >= 3;
+        if ((sanma ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, rmj3::k_step4_queue, 64, 0)
+                   : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, rmj4::k_step4_queue, 64, 0)) != hipSuccess ||
+            hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, h->cfg.device) != hipSuccess)
+            return false;
+        h->q_slots = (uint32_t)(per_cu > 0 ? per_cu : 1) * (uint32_t)(cus > 0 ? cus : 1);
+    }
+    if (h->queue_force) return quads >= 64u;   // RMJ_QUEUE_FORCE=1 (tests): any batch with a quad per XCD queue to spare
+    return quads > h->q_slots && quads < 8u * h->q_slots;
+}
 int rmj_step_random(rmj_handle h, uint64_t policy_seed, uint32_t n_steps, int auto_reset) {
     if (!h) return fail(RMJ_ERR_ARG, "null handle");
     HIPCHK(hipSetDevice(h->cfg.device));
@@ -1120,17 +1141,11 @@ int rmj_step_random(rmj_handle h, uint64_t policy_seed, uint32_t n_steps, int au
     if (h->quad >= 2 && n_steps >= 2 && h->want_streams >= 2) {   // (rmj_set_rollout_streams(h, 1): one launch per step, one stream)
         // four games per wave, the whole rollout in ONE launch: every wave steps its own games n_steps times (k_step4<true>)
         const dim3 grid((n + 3u) / 4u);
-        if (h->queue_chunk > 0 && grid.x >= 64u && n_steps >= 2u * (uint32_t)h->queue_chunk) {
+        if (rollout_queued(h, n_steps)) {
             // ... or, for a long rollout of a batch that does not fill the chip a whole number of times, in (quad, chunk) tickets
             if (!h->d_qheads) {
                 HIPCHK(hipMalloc(&h->d_qheads, 8 * RMJ_Q_STRIDE * sizeof(uint32_t)));
                 HIPCHK(hipMalloc(&h->d_qdone, (size_t)grid.x * sizeof(uint32_t)));
-                int per_cu = 0, cus = 0;
-                const bool sanma = h->cfg.game_mode >= 3;
-                HIPCHK(sanma ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, rmj3::k_step4_queue, 64, 0)
-                             : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, rmj4::k_step4_queue, 64, 0));
-                HIPCHK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, h->cfg.device));
-                h->q_slots = (uint32_t)(per_cu > 0 ? per_cu : 1) * (uint32_t)(cus > 0 ? cus : 1);
             }
             HIPCHK(hipMemsetAsync(h->d_qheads, 0, 8 * RMJ_Q_STRIDE * sizeof(uint32_t), h->stream));
             HIPCHK(hipMemsetAsync(h->d_qdone, 0, (size_t)grid.x * sizeof(uint32_t), h->stream));
@@ -2016,6 +2031,8 @@ int rmj_bench_rollout(rmj_handle h, uint64_t policy_seed, uint32_t warmup, uint3
     out->env_steps = after - before;
     out->launches_in_flight = fl;
     out->full_path_steps = full1 - full0;
+    out->queued = rollout_queued(h, steps) ? 1u : 0u;
+    out->reserved = 0u;
     return RMJ_OK;
 }
 int rmj_set_rollout_streams(rmj_handle h, int k) {

@@ -12,7 +12,7 @@ python3 bench.py --mode 5 --encode --steps 400 --warmup 300 --no-cpu-baseline > 
 python3 bench.py --mode 5 --no-cpu-baseline > gpurun_out/${TAG}_bench_3p_mode5.json 2>> gpurun_out/${TAG}_bench_n1.err
 python3 bench.py --games 524288 --steps 500 --warmup 300 --no-cpu-baseline --no-extras > gpurun_out/${TAG}_bench_524288.json 2>> gpurun_out/${TAG}_bench_n1.err
 python3 bench.py --games 4096 --mode 0 --no-cpu-baseline --no-extras > gpurun_out/${TAG}_bench_4096_mode0.json 2>> gpurun_out/${TAG}_bench_n1.err
-# kernel stats: the headline command (warmup == steps: every k_step4<true> launch is a rollout of exactly 1000 steps) ...
+# kernel stats: the headline command (warmup == steps: every k_step4_queue launch is a rollout of exactly 1000 steps) ...
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/${TAG}_stats -- python3 bench.py --steps 1000 --warmup 1000 --no-cpu-baseline --no-extras > gpurun_out/${TAG}_stats.log 2>&1
 find gpurun_out/${TAG}_stats -name "*kernel_stats.csv" -exec cp {} gpurun_out/${TAG}_kernel_stats.csv \;
 rm -rf gpurun_out/${TAG}_stats
@@ -23,7 +23,7 @@ rm -rf gpurun_out/${TAG}_stats_enc
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/${TAG}_stats_ext -- python3 scripts/bench_encoders.py > gpurun_out/${TAG}_bench_encoders.json 2> gpurun_out/${TAG}_stats_ext.log
 find gpurun_out/${TAG}_stats_ext -name "*kernel_stats.csv" -exec cp {} gpurun_out/${TAG}_kernel_stats_encoders.csv \;
 rm -rf gpurun_out/${TAG}_stats_ext
-# PMC: the fused rollout kernel (one group per run, no tracing flags; warmup == steps = 300)
+# PMC: the fused rollout kernel k_step4_queue (one group per run, no tracing flags; warmup == steps = 300)
 i=0
 for grp in "FETCH_SIZE" "WRITE_SIZE" "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVES" "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_ACTIVE_INST_ANY" \
            "SQ_INSTS_SMEM SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_BRANCH" "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_LDS SQ_THREAD_CYCLES_VALU"; do
@@ -31,7 +31,7 @@ for grp in "FETCH_SIZE" "WRITE_SIZE" "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS S
   timeout 300 rocprofv3 --pmc $grp --output-format csv -d $R/gpurun_out/${TAG}_pmc_p$i -- python3 bench.py --steps 300 --warmup 300 --no-cpu-baseline --no-extras > $R/gpurun_out/${TAG}_pmc_p$i.log 2>&1
   echo "k_step4 pass $i ($grp) rc=$?"
 done
-python3 scripts/pmc_summary.py $R/gpurun_out ${TAG}_pmc "k_step4<true>" 2 300 4 65536 > $R/gpurun_out/${TAG}_pmc_k_step4.json
+python3 scripts/pmc_summary.py $R/gpurun_out ${TAG}_pmc "k_step4_queue" 2 300 4 65536 > $R/gpurun_out/${TAG}_pmc_k_step4.json
 i=0
 for grp in "FETCH_SIZE" "WRITE_SIZE" "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVES" "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_ACTIVE_INST_ANY"; do
   i=$((i+1))

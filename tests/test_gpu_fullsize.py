@@ -236,7 +236,7 @@ def test_queued_rollout_equals_the_one_quad_per_wave_rollout(mode, n):
     sample; batches with a ragged last quad; several chunk lengths incl. one that does not divide the rollout."""
     plain = _rollout_with({"RMJ_QUEUE_CHUNK": "0"}, mode, n, 333)
     for chunk in ("64", "50", "166"):
-        queued = _rollout_with({"RMJ_QUEUE_CHUNK": chunk}, mode, n, 333)
+        queued = _rollout_with({"RMJ_QUEUE_CHUNK": chunk, "RMJ_QUEUE_FORCE": "1"}, mode, n, 333)
         _same_batch(plain, queued, n)
         queued.close()
     plain.close()
@@ -248,7 +248,7 @@ def test_queued_rollout_survives_xcds_without_blocks():
     n = 8192
     plain = _rollout_with({"RMJ_QUEUE_CHUNK": "0"}, 2, n, 200)
     for skip in ("0x24", "0xFE"):
-        q = _rollout_with({"RMJ_QUEUE_CHUNK": "64", "RMJ_QUEUE_TEST_SKIP_XCDS": skip}, 2, n, 200)
+        q = _rollout_with({"RMJ_QUEUE_CHUNK": "64", "RMJ_QUEUE_FORCE": "1", "RMJ_QUEUE_TEST_SKIP_XCDS": skip}, 2, n, 200)
         _same_batch(plain, q, n)
         q.close()
     plain.close()

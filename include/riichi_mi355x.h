@@ -197,8 +197,8 @@ int rmj_step_device(rmj_handle h, const rmj_action_t* d_actions);
  * is issued as ONE launch in which every wavefront keeps its four games' records in LDS and steps them n_steps times,
  * publishing every step's outputs (lists, masks, status, events, record) exactly like n_steps launches would (kernel
  * k_step4<true>, four games per wavefront).  Every game is stepped exactly n_steps times and the results do not depend on
- * it.  A long rollout (>= 2 x 64 steps) of a batch of >= 64 quads is handed out in pieces instead: a grid that fits the chip
- * once pulls (quad, 64-step chunk) tickets from per-XCD queues (kernel k_step4_queue; a quad's chunks stay on one XCD, whose L2
+ * it.  A rollout of >= 32 steps of a batch between one and eight chip-fulls of wavefronts is handed out in pieces instead: a grid
+ * that fits the chip once pulls (quad, chunk of up to 64 steps) tickets from per-XCD queues (kernel k_step4_queue; a quad's chunks stay on one XCD, whose L2
  * carries the record from one wavefront to the next), so a batch that is not a whole multiple of the chip's wave slots leaves no
  * half-empty tail (65 536 games: +10 %); RMJ_QUEUE_CHUNK at create sets the chunk length, 0 switches the tickets off.  rmj_set_rollout_streams(h, 1) (or RMJ_STEP_STREAMS=1) makes every step its own launch on the handle's stream - what
  * a policy that is a barrier between steps gets; RMJ_STEP4=1 / 0 in the environment at create selects the earlier

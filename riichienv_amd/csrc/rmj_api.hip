@@ -1118,9 +1118,14 @@ static int rollout_streams(const rmj_env* h, uint32_t n_steps) {
 // Does a fused rollout of n_steps run as tickets (k_step4_queue)?  Worth it when the batch is more than one and fewer than eight
 // chip-fulls of waves: below, every quad is resident at once and there is no tail; far above, the tail is a small share and the
 // chunk hand-overs cost more than it (524 288 games: -2 %).
+// steps per ticket: the configured chunk, shorter for a short rollout (its tail is one chunk long: at least 16 chunks per quad)
+static uint32_t rollout_chunk(const rmj_env* h, uint32_t n_steps) {
+    const uint32_t cap = (uint32_t)h->queue_chunk, fine = n_steps / 16u < 16u ? 16u : n_steps / 16u;
+    return fine < cap ? fine : cap;
+}
 static bool rollout_queued(rmj_env* h, uint32_t n_steps) {
     const uint32_t quads = (h->cfg.n_games + 3u) / 4u;
-    if (!(h->quad >= 2 && n_steps >= 2 && h->want_streams >= 2) || h->queue_chunk <= 0 || n_steps < 2u * (uint32_t)h->queue_chunk) return false;
+    if (!(h->quad >= 2 && n_steps >= 2 && h->want_streams >= 2) || h->queue_chunk <= 0 || n_steps < 2u * rollout_chunk(h, n_steps)) return false;
     if (h->q_slots == 0) {
         int per_cu = 0, cus = 0;
         const bool sanma = h->cfg.game_mode >= 3;
@@ -1150,7 +1155,7 @@ int rmj_step_random(rmj_handle h, uint64_t policy_seed, uint32_t n_steps, int au
             HIPCHK(hipMemsetAsync(h->d_qheads, 0, 8 * RMJ_Q_STRIDE * sizeof(uint32_t), h->stream));
             HIPCHK(hipMemsetAsync(h->d_qdone, 0, (size_t)grid.x * sizeof(uint32_t), h->stream));
             const dim3 gq(grid.x < h->q_slots ? grid.x : h->q_slots);
-            const uint32_t chunk = (uint32_t)h->queue_chunk;
+            const uint32_t chunk = rollout_chunk(h, n_steps);
             if (h->cfg.game_mode >= 3) {
                 hipLaunchKernelGGL(rmj3::k_step4_queue, gq, dim3(64), 0, h->stream, (const Env*)h->d_env, policy_seed, flags, n, n_steps, chunk, h->d_qheads, h->d_qdone, h->queue_skip_xcds);
                 hipLaunchKernelGGL(rmj3::k_step4_fixup, grid, dim3(64), 0, h->stream, (const Env*)h->d_env, policy_seed, flags, n, n_steps, (const uint32_t*)h->d_qdone);

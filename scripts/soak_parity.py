@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Parity soak (not part of the test suite): long device-policy rollouts of every game mode under both rule sets and
 several seeds, compared with the oracle game by game - final state, legal lists, masks, waits, step counts and the whole
-MJAI log of every game.  usage: python scripts/soak_parity.py [games] [steps] [seeds] [first seed index]"""
+MJAI log of every game.  usage: python scripts/soak_parity.py [games] [steps] [seeds] [first seed index]
+(RMJ_QUEUE_FORCE=1 with >= 256 games runs the rollouts as (quad, chunk) tickets, kernel k_step4_queue, instead of one quad per wave)"""
 import os
 import sys
 import time

@@ -186,6 +186,9 @@ int rmj_clone(rmj_handle h, rmj_handle* out);
  * size; dst may be src when the destination games are not among the source games; destination indices distinct): forks for a
  * tree search, a pool of saved positions, refilling slots.  Host index arrays. */
 int rmj_copy_games(rmj_handle dst, const uint32_t* dst_idx, rmj_handle src, const uint32_t* src_idx, uint32_t n);
+/* Same with the index arrays on the device (a tree search that lives on the GPU): asynchronous on dst's stream; pairs with an index
+ * out of range are skipped. */
+int rmj_copy_games_device(rmj_handle dst, const uint32_t* d_dst_idx, rmj_handle src, const uint32_t* d_src_idx, uint32_t n);
 int rmj_step(rmj_handle h, const rmj_action_t* actions);
 /* Same, `actions` is a device pointer (zero-copy from a GPU policy). */
 int rmj_step_device(rmj_handle h, const rmj_action_t* d_actions);

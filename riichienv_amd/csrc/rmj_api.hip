@@ -995,6 +995,19 @@ int rmj_copy_games(rmj_handle dst, const uint32_t* dst_idx, rmj_handle src, cons
     return RMJ_OK;
 }
 
+int rmj_copy_games_device(rmj_handle dst, const uint32_t* d_dst_idx, rmj_handle src, const uint32_t* d_src_idx, uint32_t n) {
+    if (!dst || !src || (n && (!d_dst_idx || !d_src_idx))) return fail(RMJ_ERR_ARG, "null argument");
+    if (dst->cfg.device != src->cfg.device || (dst->cfg.game_mode >= 3) != (src->cfg.game_mode >= 3) || dst->d.ring_mask != src->d.ring_mask)
+        return fail(RMJ_ERR_ARG, "rmj_copy_games_device: the handles must share device, player count and event ring size");
+    if (n == 0) return RMJ_OK;
+    HIPCHK(hipSetDevice(dst->cfg.device));
+    if (src != dst && src->stream != dst->stream) HIPCHK(hipStreamSynchronize(src->stream));
+    if (dst->cfg.game_mode >= 3) hipLaunchKernelGGL(rmj3::k_copy_games, dim3(n), dim3(64), 0, dst->stream, (const Env*)dst->d_env, (const Env*)src->d_env, d_dst_idx, d_src_idx, n);
+    else hipLaunchKernelGGL(rmj4::k_copy_games, dim3(n), dim3(64), 0, dst->stream, (const Env*)dst->d_env, (const Env*)src->d_env, d_dst_idx, d_src_idx, n);
+    HIPCHK(hipGetLastError());
+    return RMJ_OK;
+}
+
 int rmj_reset(rmj_handle h, const uint8_t* select, const uint8_t* walls, const uint8_t* oya, const uint8_t* round_wind,
               const int32_t* scores, const uint8_t* honba, const uint32_t* kyotaku) {
     DevTmp tmp;

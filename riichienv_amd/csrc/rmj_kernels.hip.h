@@ -218,6 +218,7 @@ __global__ __launch_bounds__(64) void k_copy_games(const Env* __restrict__ Dp, c
     CEnv& D = *(CEnv*)Dp;
     CEnv& S = *(CEnv*)Sp;
     const size_t a = dst_idx[i], b = src_idx[i];
+    if (a >= D.n_games || b >= S.n_games) return;   // (device index arrays are not checked on the host)
     const int lane = threadIdx.x & 63;
     const size_t ring = (size_t)S.ring_mask + 1u;
     copy_words(D.core + a, S.core + b, sizeof(GState), lane);

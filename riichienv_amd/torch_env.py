@@ -148,6 +148,19 @@ class TorchVecEnv:
         if not self.shared:
             vecenv._chk(self.env.L.rmj_sync(self.env.h))
 
+    def copy_games(self, dst_idx, src_env, src_idx):
+        """rmj_copy_games_device: the complete state of src_env's games `src_idx` into this environment's games `dst_idx` (int32 /
+        int64 tensors on this device; src_env may be self when the two index sets are disjoint) - forks for a tree search that
+        lives on the GPU, saved positions, refilling slots.  Asynchronous on this environment's stream."""
+        t = self.torch
+        a = dst_idx.to(device=self.device, dtype=t.int32).contiguous()
+        b = src_idx.to(device=self.device, dtype=t.int32).contiguous()
+        assert a.numel() == b.numel()
+        if not self.shared:
+            t.cuda.current_stream(self.device).synchronize()
+        L = self.env.L
+        vecenv._chk(L.rmj_copy_games_device(self.env.h, C.c_void_p(a.data_ptr()), src_env.env.h, C.c_void_p(b.data_ptr()), int(a.numel())))
+
     def sample_ids(self, logits=None, seed=0):
         """One id per acting seat drawn from softmax(logits) over the seat's legal ids, -1 elsewhere, by ONE kernel of the
         library (rmj_sample_ids_device: Gumbel-max on the resident mask slab) - no torch indexing / multinomial in the loop.

@@ -26,7 +26,7 @@ EXPORTS = [
     "rmj_step_device", "rmj_step_random", "rmj_random_actions", "rmj_get_status", "rmj_get_legal", "rmj_get_mask",
     "rmj_get_waits", "rmj_get_scores", "rmj_get_ranks", "rmj_get_step_counts", "rmj_total_steps", "rmj_peek_state",
     "rmj_poke_state", "rmj_get_event_counts", "rmj_get_events", "rmj_format_event", "rmj_eval_hands",
-    "rmj_agari_counts", "rmj_calculate_score", "rmj_shanten", "rmj_effective_tiles", "rmj_best_ukeire", "rmj_apply_events", "rmj_device_views", "rmj_step_ids_device", "rmj_clone", "rmj_copy_games",
+    "rmj_agari_counts", "rmj_calculate_score", "rmj_shanten", "rmj_effective_tiles", "rmj_best_ukeire", "rmj_apply_events", "rmj_device_views", "rmj_step_ids_device", "rmj_clone", "rmj_copy_games", "rmj_copy_games_device",
     "rmj_scores_device", "rmj_sync", "rmj_set_stream", "rmj_encode", "rmj_encode_device", "rmj_encode_extended", "rmj_encode_extended_device", "rmj_encode_aux", "rmj_encode_aux_device", "rmj_encode_seq", "rmj_encode_seq_device", "rmj_bench_rollout",
     "rmj_bench_rollout_validated", "rmj_bench_encode", "rmj_set_rollout_streams", "rmj_total_full_path",
     "rmj_random_actions_device", "rmj_peek_outputs", "rmj_sample_ids_device",
@@ -83,6 +83,7 @@ def load_lib():
     L.rmj_step.argtypes = [vp, vp]
     L.rmj_clone.argtypes = [vp, C.POINTER(vp)]
     L.rmj_copy_games.argtypes = [vp, vp, vp, vp, C.c_uint32]
+    L.rmj_copy_games_device.argtypes = [vp, vp, vp, vp, C.c_uint32]
     L.rmj_step_device.argtypes = [vp, vp]
     L.rmj_step_random.argtypes = [vp, C.c_uint64, C.c_uint32, C.c_int]
     L.rmj_random_actions.argtypes = [vp, C.c_uint64, vp]

@@ -111,3 +111,32 @@ def test_scalar_env_clone_copy_deepcopy():
         n_log = len(env.mjai_log)
         twin.step({p: o.legal_actions()[0] for p, o in o2.items() if o.legal_actions()})
         assert len(env.mjai_log) == n_log and len(twin.mjai_log) >= n_log
+
+
+def test_torch_env_forks_on_the_device():
+    """TorchVecEnv.copy_games (rmj_copy_games_device, index tensors on the GPU, the environment's own stream): fork the first
+    quarter of a batch into the other three quarters, step all with the same per-slot policy seeds -> the quarters stay identical;
+    out-of-range pairs are skipped"""
+    torch = pytest.importorskip("torch")
+    from riichienv_amd.torch_env import TorchVecEnv
+
+    n, q = 256, 64
+    env = TorchVecEnv(n, game_mode=2, seed=9, skip_mjai_logging=False, event_ring=4096)
+    for k in range(80):
+        env.step(env.sample_ids(seed=k))
+    src = torch.arange(q, device=env.device).repeat(3)
+    dst = torch.arange(q, n, device=env.device)
+    env.copy_games(dst, env, src)
+    env.copy_games(torch.tensor([n + 5], device=env.device), env, torch.tensor([0], device=env.device))     # skipped
+    torch.cuda.synchronize()
+    for g in (0, 17, 63):
+        for k in (1, 2, 3):
+            _same(env.env, g, env.env, g + k * q)
+    for k in range(40):
+        ids = env.sample_ids(seed=1000 + k)
+        ids[q:] = ids[:q].repeat(3, 1)                      # the forks take their original's actions
+        env.step(ids, auto_reset=False)
+    torch.cuda.synchronize()
+    for g in (0, 17, 63):
+        for k in (1, 2, 3):
+            _same(env.env, g, env.env, g + k * q)

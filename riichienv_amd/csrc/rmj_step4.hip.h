@@ -1237,7 +1237,8 @@ __device__ __noinline__ void q_wait_for(const uint32_t* slot, uint32_t want) {
     wave_sync();
 }
 // (74 VGPRs: 6 waves per SIMD = 6 144 slots.  Compiled for 7 - 71 VGPRs, four scratch accesses in the ticket loop - it is not faster:
-//  1 617 / 1 504 M env.step/s against 1 642 / 1 529 M in 4P / 3P; the seventh wave was worth its 10 % mostly because it shortened the tail)
+//  1 617 / 1 504 M env.step/s against 1 642 / 1 529 M in 4P / 3P; the seventh wave was worth its 10 % mostly because it shortened the tail.
+//  Launch bounds for 4 / 5 / 8 waves: 1 532 / 1 279, 1 530 / 1 454, 1 426 / 1 382 - 6 is the optimum)
 __global__ __launch_bounds__(64, RMJ_STEP4_WAVES) void k_step4_queue(const Env* __restrict__ Ep, uint64_t policy_seed, uint32_t flags, uint32_t n_games,
                                                                          uint32_t n_steps, uint32_t chunk, uint32_t* __restrict__ heads, uint32_t* __restrict__ done,
                                                                          uint32_t skip_xcds) {

@@ -28,6 +28,11 @@ B_OBS_3P = 74 * 27 * 4    # 7 992 B
 HBM_PEAK = 8.0e12         # B/s, /opt/skills/guides/MI355X_MICROARCH.md (HBM3E peak, spec)
 MODES = ['4p-red-single', '4p-red-east', '4p-red-half', '3p-red-single', '3p-red-east', '3p-red-half']
 STEADY_MIN = 200          # steady-state window of >= 200 batched steps after the warm-up has reached round ends
+PREROLL = 2000            # untimed steps of every game BEFORE the warm-up, whatever --warmup says: the first ~60 steps of a game
+                          # cannot end a round and games started together end their first rounds in bursts (after 600 steps a
+                          # 20-step window still saw 4 % of the game-steps in the full path, the long-run share is 1.7 %); after
+                          # 2 000 steps (~17 rounds of RandomAgent play, 80 ms at 65 536 games) round ends, settlements and
+                          # restarts are spread like in the steady state the metric is defined on.  Reported as "preroll_steps".
 
 
 def parse_args(argv=None):
@@ -39,6 +44,8 @@ def parse_args(argv=None):
     ap.add_argument("--mode", type=int, default=2, help="0/1/2 = 4p-red-single/east/half, 3/4/5 = 3p-red-single/east/half")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the single-stream / validated-actions side measurements")
+    ap.add_argument("--preroll", type=int, default=PREROLL,
+                    help="untimed steps before the warm-up that bring every game to steady state (0: time the opening phase)")
     ap.add_argument("--encode", action="store_true",
                     help="also produce the feature tensor of the acting seats every step (BASELINE configs[4]: sanma with "
                          "feature-encoding tensor output): one step launch + one encode launch per step")
@@ -59,6 +66,8 @@ def launcher_command(args, port, script=None):
            "--master-addr", "127.0.0.1", "--master-port", str(port), script,
            "--gpus", str(args.gpus), "--steps", str(args.steps), "--warmup", str(args.warmup),
            "--games", str(args.games), "--mode", str(args.mode)]
+    if args.preroll != PREROLL:
+        cmd += ["--preroll", str(args.preroll)]
     if args.no_cpu_baseline:
         cmd.append("--no-cpu-baseline")
     if args.no_extras:
@@ -111,15 +120,17 @@ def cpu_baseline(game_mode, rule_bits, policy_seed, target_s=15.0):
             "single_thread": {"value": s1 / t1, "sample": f"8 games x {per1} steps, {t1:.1f}s"}}
 
 
-def pmc_traffic(kernel, games_per_launch, mode):
+def pmc_traffic(kernel, games_per_launch, mode, ran_as=None):
     """HBM bytes per launch of `kernel` from the newest committed rocprofv3 PMC summary that matches the launch shape
     (profiles/r*_pmc_<kernel>.json: FETCH_SIZE and WRITE_SIZE collected in separate --pmc runs of this same command,
-    FETCH doubled per the gfx950 note of the microarch guide).  bench.py cannot run the profiler itself; null when no
-    matching profile is committed."""
+    FETCH doubled per the gfx950 note of the microarch guide) and, with `ran_as`, the kernel the timed launch ran as (the
+    summary's "kernel" field).  bench.py cannot run the profiler itself; null when no matching profile is committed."""
     for path in sorted(glob.glob(os.path.join(ROOT, "profiles", f"r*_pmc_{kernel}.json")), reverse=True):
         try:
             with open(path) as f:
                 d = json.load(f)
+            if ran_as is not None and ran_as not in str(d.get("kernel", "")):
+                continue
             if d.get("games_per_launch") == games_per_launch and d.get("mode", 2) == mode:
                 t = d["hbm_traffic"]
                 return t.get("bytes_per_step", t["bytes_per_launch"]), os.path.relpath(path, ROOT)
@@ -193,6 +204,8 @@ def main(argv=None):
     env = vecenv.VecRiichiEnv(args.games, game_mode=args.mode, seed=0, rule_bits=abi.RULE_TENHOU, device=local_rank,
                               game_offset=shard.shard_offset(rank, args.games), event_ring=64)
     env.reset()
+    if args.preroll > 0:
+        env.step_random(policy_seed, args.preroll, auto_reset=True)   # to steady state (see PREROLL), untimed
     env.step_random(policy_seed, args.warmup, auto_reset=True)
 
     def barrier():
@@ -204,20 +217,22 @@ def main(argv=None):
     if args.encode:
         obs = torch.zeros((args.games, 4, 74, 27 if sanma else 34), dtype=torch.float32, device=f"cuda:{local_rank}")
     full0 = env.total_full_path()
+    before = env.total_steps()
     barrier()
     t0 = time.perf_counter()
     if args.encode:
-        before = env.total_steps()
         # every step of every game is followed by encode() of its acting seats into the resident tensor; like the plain
         # rollout, the batch runs as four parts on four streams (step, encode, step, encode ... per part)
         env.step_random_encode(policy_seed, args.steps, obs.data_ptr(), auto_reset=True, only_active=2)
-        steps_local = float(env.total_steps() - before)   # synchronises the stream
+        env.sync()
         r = None
     else:
-        r = env.bench_rollout(policy_seed, 0, args.steps)   # exactly K steps of every game, HIP events on the handle's stream
-        steps_local = float(r.env_steps)
+        # exactly K steps of every game and nothing else inside the region: HIP events on the handle's stream around the rollout
+        # (returns when the second event has completed); the step counters are read outside
+        r = env.time_rollout(policy_seed, args.steps)
     barrier()
     t1 = time.perf_counter()
+    steps_local = float(env.total_steps() - before)
     full_steps = env.total_full_path() - full0
     wall, steps_total = shard.reduce_measurement(dist, t1 - t0, steps_local, device="cuda")
 
@@ -245,6 +260,13 @@ def main(argv=None):
                                        "what": "one policy launch writing packed actions + one step launch that validates them "
                                                "against the stored legal lists (state/mod.rs:339-402), one stream"}
         env.set_rollout_streams(4)
+        if args.steps < 1000:
+            kl = 1000
+            rl = env.bench_rollout(policy_seed, 0, kl)
+            extras["long_rollout"] = {"value": rl.env_steps / (rl.total_ms * 1e-3), "ms_per_step": rl.total_ms / kl, "steps": kl,
+                                      "kernel": fused_kernel_name(rl),
+                                      "what": "the same rollout over 1 000 steps as one launch (a short timed region pays the launch's "
+                                              "ramp-up and tail, ~0.1 ms, once per K steps)"}
 
     if rank == 0:
         b_step = B_STEP_3P if sanma else B_STEP_4P
@@ -262,7 +284,8 @@ def main(argv=None):
         games_per_launch = args.games // in_flight
         # (the committed counter summary is of the fused rollout kernel, per step of all games; the per-step launches of the
         #  feature rollout have no counter profile of their own)
-        traffic, traffic_src = (None, None) if args.encode else pmc_traffic("k_step4", games_per_launch, args.mode)
+        kernel_name = fused_kernel_name(r) if steps_per_launch > 1 else "k_step4<false>"
+        traffic, traffic_src = (None, None) if args.encode else pmc_traffic("k_step4", games_per_launch, args.mode, ran_as=kernel_name)
         if traffic is not None:
             traffic *= steps_per_launch
         bytes_per_launch = b_step * games_per_launch * steps_per_launch
@@ -276,11 +299,13 @@ def main(argv=None):
                        "sharding": "by game index, no collectives", "feature_tensor_output": bool(args.encode),
                        "parity": "bit-exact vs the oracle on identical walls; seed -> wall is the build's own shuffle (DESIGN.md §6)"},
             # short runs (the first ~60 steps of a game cannot end a round) are not the steady state the metric is defined on
-            "steady_state": bool(args.warmup >= STEADY_MIN and args.steps >= STEADY_MIN),
+            # steady state = every game has played through several round ends before the timed region (pre-roll + warm-up)
+            "steady_state": bool(args.preroll + args.warmup >= 300),
+            "preroll_steps": args.preroll,
             "full_path_frac": full_steps / max(steps_local, 1.0),
             "roofline": {"bound": "hbm", "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK, "traffic": traffic, "traffic_unit": "bytes/launch",
-                         "traffic_source": traffic_src, "kernel": fused_kernel_name(r) if steps_per_launch > 1 else "k_step4<false>",
+                         "traffic_source": traffic_src, "kernel": kernel_name,
                          "kernel_ms": kernel_ms, "bytes_per_launch": bytes_per_launch, "bytes_per_game_step": b_step,
                          "games_per_launch": games_per_launch, "steps_per_launch": steps_per_launch,
                          "launches_in_flight": in_flight},

@@ -446,6 +446,10 @@ typedef struct RmjBenchResult {
     uint32_t reserved;
 } RmjBenchResult;
 int rmj_bench_rollout(rmj_handle h, uint64_t policy_seed, uint32_t warmup, uint32_t steps, RmjBenchResult* out);
+/* The timed region alone: HIP events around rmj_step_random(h, policy_seed, steps, 1) on the handle's stream and nothing else
+ * (no counter launches, no host round trips besides the final event wait); env_steps / full_path_steps stay 0 - read
+ * rmj_total_steps / rmj_total_full_path before and after.  What bench.py times. */
+int rmj_time_rollout(rmj_handle h, uint64_t policy_seed, uint32_t steps, RmjBenchResult* out);
 /* The unfused counterpart: per step one policy launch (packed actions into a device buffer) and one step launch that
  * validates them against the stored legal lists like GameState::step does for an external agent (state/mod.rs:339-402);
  * finished games restart; one stream, the whole batch per launch.  step_kernel_ms = policy + step launch. */

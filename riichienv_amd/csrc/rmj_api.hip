@@ -143,6 +143,11 @@ struct ResetArgs {
 #undef RMJ_NS
 #undef RMJ_SANMA
 
+// largest raw HW_REG_XCC_ID[3:0] over the waves of the launch (rmj_create: is the per-XCD queue assumption of k_step4_queue valid?)
+__global__ void k_probe_xcc(unsigned long long* out) {
+    const unsigned long long id = (unsigned long long)((uint32_t)__builtin_amdgcn_s_getreg((3 << 11) | 20) & 15u);
+    if ((threadIdx.x & 63u) == 0u) atomicMax(out, id);
+}
 __global__ void k_sum_steps(const GState* core, uint32_t n, unsigned long long* out) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     unsigned long long v = 0;
@@ -766,6 +771,10 @@ struct rmj_env {
     uint32_t q_slots = 0;           // waves of k_step4_queue the device holds at once
     int queue_force = 0;            // RMJ_QUEUE_FORCE at create (tests): tickets for every batch of >= 64 quads
     uint32_t queue_skip_xcds = 0;   // test hook: XCDs whose waves leave the queue kernel at once (RMJ_QUEUE_TEST_SKIP_XCDS at create)
+    int queue_min_chunk = 8;        // shortest ticket (steps): a rollout of >= 2 tickets per quad runs as tickets; RMJ_QUEUE_MIN_CHUNK at create
+    uint32_t max_xcc_id = 0;        // largest HW_REG_XCC_ID seen by a probe launch at create: the ticket rollout assumes ids 0..7 (one L2 per queue)
+    int enc_streams = 0;            // RMJ_ENC_STREAMS at create (0: want_streams): parts of the step + encode rollout
+    int enc_parts_quad = -1;        // RMJ_ENC_PARTS_QUAD at create (-1: follow `quad`)
 };
 // device staging memory of at least `bytes` bytes, owned by the handle
 static int scratch_for(rmj_env* h, size_t bytes, void** out) {
@@ -845,6 +854,9 @@ static int create_impl(rmj_env* h, const RmjConfig* cfg, uint64_t** d_seeds_out)
     if (const char* e = getenv("RMJ_QUEUE_CHUNK")) h->queue_chunk = atoi(e);
     if (const char* e = getenv("RMJ_QUEUE_FORCE")) h->queue_force = atoi(e);
     if (const char* e = getenv("RMJ_QUEUE_TEST_SKIP_XCDS")) h->queue_skip_xcds = (uint32_t)strtoul(e, nullptr, 0) & 0xFFu;
+    if (const char* e = getenv("RMJ_QUEUE_MIN_CHUNK")) h->queue_min_chunk = atoi(e) > 0 ? atoi(e) : 1;
+    if (const char* e = getenv("RMJ_ENC_STREAMS")) h->enc_streams = atoi(e);
+    if (const char* e = getenv("RMJ_ENC_PARTS_QUAD")) h->enc_parts_quad = atoi(e) != 0;
     const size_t B = cfg->n_games;
     Env& d = h->d;
     HIPCHK(hipStreamCreateWithFlags(&h->own_stream, hipStreamNonBlocking));
@@ -866,6 +878,18 @@ static int create_impl(rmj_env* h, const RmjConfig* cfg, uint64_t** d_seeds_out)
     HIPCHK(hipMemsetAsync(d.win, 0, B * 4 * sizeof(RmjWinResult), h->stream));
     HIPCHK(hipMalloc(&h->d_actions, B * 4 * sizeof(uint64_t)));
     HIPCHK(hipMalloc(&h->d_counter, sizeof(unsigned long long)));
+    {   // The ticket rollout (k_step4_queue) hands a quad from wave to wave through ONE XCD's L2 and keys its eight queues by
+        // HW_REG_XCC_ID & 7: on a part or partition mode that reports ids >= 8 two XCDs would share a queue and the hand-over
+        // would cross L2s without a write-back.  A probe launch (more blocks than any dispatcher keeps on one XCD) records the
+        // largest id; tickets are used only when it is <= 7 (rollout_queued), k_step4<true> otherwise.
+        HIPCHK(hipMemsetAsync(h->d_counter, 0, sizeof(unsigned long long), h->stream));
+        hipLaunchKernelGGL(k_probe_xcc, dim3(4096), dim3(64), 0, h->stream, h->d_counter);
+        HIPCHK(hipGetLastError());
+        unsigned long long m = 0;
+        HIPCHK(hipMemcpyAsync(&m, h->d_counter, sizeof(m), hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(hipStreamSynchronize(h->stream));
+        h->max_xcc_id = (uint32_t)m;
+    }
     HIPCHK(hipMalloc(&h->d_obs_offs, (B + (B + 1023) / 1024) * sizeof(uint32_t)));   // per game + per scan block
     HIPCHK(hipMemsetAsync(d.legal, 0, B * 4 * RMJ_MAX_LEGAL * sizeof(uint64_t), h->stream));
     HIPCHK(hipMemsetAsync(d.nlegal, 0, B * 4, h->stream));
@@ -955,6 +979,9 @@ int rmj_clone(rmj_handle h, rmj_handle* out) {
     c->quad = h->quad;
     c->queue_chunk = h->queue_chunk;
     c->queue_force = h->queue_force;
+    c->queue_min_chunk = h->queue_min_chunk;
+    c->enc_streams = h->enc_streams;
+    c->enc_parts_quad = h->enc_parts_quad;
     const size_t B = h->cfg.n_games, ring = (size_t)h->d.ring_mask + 1u;
     const struct { void* dst; const void* src; size_t bytes; } slabs[] = {
         {c->d.core, h->d.core, B * sizeof(GState)}, {c->d.wall, h->d.wall, B * RMJ_WALL_STRIDE},
@@ -1133,12 +1160,13 @@ static int rollout_streams(const rmj_env* h, uint32_t n_steps) {
 // chunk hand-overs cost more than it (524 288 games: -2 %).
 // steps per ticket: the configured chunk, shorter for a short rollout (its tail is one chunk long: at least 16 chunks per quad)
 static uint32_t rollout_chunk(const rmj_env* h, uint32_t n_steps) {
-    const uint32_t cap = (uint32_t)h->queue_chunk, fine = n_steps / 16u < 16u ? 16u : n_steps / 16u;
+    const uint32_t cap = (uint32_t)h->queue_chunk, lo = (uint32_t)h->queue_min_chunk, fine = n_steps / 16u < lo ? lo : n_steps / 16u;
     return fine < cap ? fine : cap;
 }
 static bool rollout_queued(rmj_env* h, uint32_t n_steps) {
     const uint32_t quads = (h->cfg.n_games + 3u) / 4u;
     if (!(h->quad >= 2 && n_steps >= 2 && h->want_streams >= 2) || h->queue_chunk <= 0 || n_steps < 2u * rollout_chunk(h, n_steps)) return false;
+    if (h->max_xcc_id > 7u) return false;   // more XCC ids than queues: no single L2 per queue (see rmj_create)
     if (h->q_slots == 0) {
         int per_cu = 0, cus = 0;
         const bool sanma = h->cfg.game_mode >= 3;
@@ -1215,10 +1243,8 @@ int rmj_step_random_encode(rmj_handle h, uint64_t policy_seed, uint32_t n_steps,
     // The encoder is bound by its stores, the step by instruction issue: parts of the batch on k streams put the step of one
     // part under the encoder of another (measured, 65 536 3P games: one stream 283 M env.step/s, four parts 383 M with the
     // four-game kernel and 323 M with the one-game kernel).  RMJ_ENC_STREAMS / RMJ_ENC_PARTS_QUAD: experiment knobs.
-    int k = h->want_streams;
-    bool parts_quad = h->quad != 0;
-    if (const char* e = getenv("RMJ_ENC_STREAMS")) k = atoi(e);
-    if (const char* q = getenv("RMJ_ENC_PARTS_QUAD")) parts_quad = atoi(q) != 0;
+    int k = h->enc_streams > 0 ? h->enc_streams : h->want_streams;
+    const bool parts_quad = h->enc_parts_quad >= 0 ? h->enc_parts_quad != 0 : h->quad != 0;
     if (k > RMJ_MAX_ROLLOUT_STREAMS) k = RMJ_MAX_ROLLOUT_STREAMS;
     if ((int)(n / RMJ_SPLIT_MIN_PART) < k) k = (int)(n / RMJ_SPLIT_MIN_PART);
     if (n_steps < 2 || n < RMJ_SPLIT_MIN_GAMES || k < 2) k = 1;
@@ -2023,14 +2049,14 @@ int rmj_apply_events(rmj_handle h, const RmjEvent* events) {
 }
 
 // ---- measurement -----------------------------------------------------------------------------
-int rmj_bench_rollout(rmj_handle h, uint64_t policy_seed, uint32_t warmup, uint32_t steps, RmjBenchResult* out) {
+static int bench_rollout_impl(rmj_handle h, uint64_t policy_seed, uint32_t warmup, uint32_t steps, RmjBenchResult* out, bool count) {
     DevTmp tmp;  // owns the two timing events on every return path
     if (!h || !out) return fail(RMJ_ERR_ARG, "null argument");
     HIPCHK(hipSetDevice(h->cfg.device));
-    int rc = rmj_step_random(h, policy_seed, warmup, 1);
+    int rc = warmup ? rmj_step_random(h, policy_seed, warmup, 1) : RMJ_OK;
     if (rc) return rc;
     uint64_t before = 0, after = 0, full0 = 0, full1 = 0;
-    if ((rc = rmj_total_steps(h, &before)) || (rc = rmj_total_full_path(h, &full0))) return rc;
+    if (count && ((rc = rmj_total_steps(h, &before)) || (rc = rmj_total_full_path(h, &full0)))) return rc;
     hipEvent_t e0, e1;
     HIPCHK(tmp.event(&e0));
     HIPCHK(tmp.event(&e1));
@@ -2040,7 +2066,7 @@ int rmj_bench_rollout(rmj_handle h, uint64_t policy_seed, uint32_t warmup, uint3
     HIPCHK(hipEventSynchronize(e1));
     float ms = 0.f;
     HIPCHK(hipEventElapsedTime(&ms, e0, e1));
-    if ((rc = rmj_total_steps(h, &after)) || (rc = rmj_total_full_path(h, &full1))) return rc;
+    if (count && ((rc = rmj_total_steps(h, &after)) || (rc = rmj_total_full_path(h, &full1)))) return rc;
     out->total_ms = ms;
     const uint32_t fl = (uint32_t)rollout_streams(h, steps);
     const bool fused = h->quad >= 2 && steps >= 2 && h->want_streams >= 2;
@@ -2052,6 +2078,16 @@ int rmj_bench_rollout(rmj_handle h, uint64_t policy_seed, uint32_t warmup, uint3
     out->queued = rollout_queued(h, steps) ? 1u : 0u;
     out->reserved = 0u;
     return RMJ_OK;
+}
+int rmj_bench_rollout(rmj_handle h, uint64_t policy_seed, uint32_t warmup, uint32_t steps, RmjBenchResult* out) {
+    return bench_rollout_impl(h, policy_seed, warmup, steps, out, true);
+}
+// The timed region alone: HIP events on the handle's stream around rmj_step_random(h, policy_seed, steps, auto_reset = 1), nothing
+// else issued or synchronised (the step / full-path counters of rmj_bench_rollout cost four small launches and four host round
+// trips - a fifth of a 20-step rollout).  env_steps / full_path_steps are left 0: read rmj_total_steps / rmj_total_full_path
+// outside the region.
+int rmj_time_rollout(rmj_handle h, uint64_t policy_seed, uint32_t steps, RmjBenchResult* out) {
+    return bench_rollout_impl(h, policy_seed, 0u, steps, out, false);
 }
 int rmj_set_rollout_streams(rmj_handle h, int k) {
     if (!h || k < 1 || k > RMJ_MAX_ROLLOUT_STREAMS) return fail(RMJ_ERR_ARG, "rollout streams must be 1..8");
@@ -2111,6 +2147,8 @@ int rmj_bench_rollout_validated(rmj_handle h, uint64_t policy_seed, uint32_t war
     out->env_steps = after - before;
     out->launches_in_flight = 1;
     out->full_path_steps = full1 - full0;
+    out->queued = 0u;
+    out->reserved = 0u;
     return RMJ_OK;
 }
 // Average duration of one encoder launch over `reps` back-to-back launches (HIP events on the handle's stream): the

@@ -151,7 +151,8 @@ class TorchVecEnv:
     def copy_games(self, dst_idx, src_env, src_idx):
         """rmj_copy_games_device: the complete state of src_env's games `src_idx` into this environment's games `dst_idx` (int32 /
         int64 tensors on this device; src_env may be self when the two index sets are disjoint) - forks for a tree search that
-        lives on the GPU, saved positions, refilling slots.  Asynchronous on this environment's stream."""
+        lives on the GPU, saved positions, refilling slots.  Asynchronous on a shared stream; with the library's own stream the call
+        returns when the copy is done (the index tensors are temporaries of torch's allocator)."""
         t = self.torch
         a = dst_idx.to(device=self.device, dtype=t.int32).contiguous()
         b = src_idx.to(device=self.device, dtype=t.int32).contiguous()
@@ -160,14 +161,27 @@ class TorchVecEnv:
             t.cuda.current_stream(self.device).synchronize()
         L = self.env.L
         vecenv._chk(L.rmj_copy_games_device(self.env.h, C.c_void_p(a.data_ptr()), src_env.env.h, C.c_void_p(b.data_ptr()), int(a.numel())))
+        # own stream: torch's caching allocator orders the reuse of `a` / `b` by torch's stream, not by the library's, so the
+        # kernel must have read them before they are released (shared stream: torch's stream orders it)
+        self.sync()
 
-    def sample_ids(self, logits=None, seed=0):
+    def sample_ids(self, logits=None, seed=0, index=None):
         """One id per acting seat drawn from softmax(logits) over the seat's legal ids, -1 elsewhere, by ONE kernel of the
         library (rmj_sample_ids_device: Gumbel-max on the resident mask slab) - no torch indexing / multinomial in the loop.
-        logits: float32 [n, 4, A'] with A' >= 82 (60 in 3P) on this device, or None for the uniform policy."""
+        logits: float32 [n, 4, A'] with A' >= 82 (60 in 3P) on this device, or None for the uniform policy; with `index`
+        (the second result of obs_compact(): game * 4 + seat per row) logits are the compact rows [k, A'] a policy computed
+        from the compact observation batch, scattered here into the [n, 4, A'] layout (rows of seats that do not act are never
+        read by the sampler)."""
         t = self.torch
         if not hasattr(self, "_ids"):
             self._ids = t.full((self.n, 4), -1, dtype=t.int32, device=self.device)
+        if logits is not None and index is not None:
+            a = int(logits.shape[-1])
+            if getattr(self, "_full_logits", None) is None or self._full_logits.shape[-1] != a:
+                self._full_logits = t.zeros((self.n * 4, a), dtype=t.float32, device=self.device)
+            k = int(index.shape[0])
+            self._full_logits[index.to(t.int64)] = logits.reshape(-1, a)[:k].to(t.float32)
+            logits = self._full_logits.view(self.n, 4, a)
         ptr, stride = None, 0
         if logits is not None:
             assert logits.dtype == t.float32 and logits.is_contiguous() and tuple(logits.shape[:2]) == (self.n, 4)

@@ -27,7 +27,7 @@ EXPORTS = [
     "rmj_get_waits", "rmj_get_scores", "rmj_get_ranks", "rmj_get_step_counts", "rmj_total_steps", "rmj_peek_state",
     "rmj_poke_state", "rmj_get_event_counts", "rmj_get_events", "rmj_format_event", "rmj_eval_hands",
     "rmj_agari_counts", "rmj_calculate_score", "rmj_shanten", "rmj_effective_tiles", "rmj_best_ukeire", "rmj_apply_events", "rmj_device_views", "rmj_step_ids_device", "rmj_clone", "rmj_copy_games", "rmj_copy_games_device",
-    "rmj_scores_device", "rmj_sync", "rmj_set_stream", "rmj_encode", "rmj_encode_device", "rmj_encode_extended", "rmj_encode_extended_device", "rmj_encode_aux", "rmj_encode_aux_device", "rmj_encode_seq", "rmj_encode_seq_device", "rmj_bench_rollout",
+    "rmj_scores_device", "rmj_sync", "rmj_set_stream", "rmj_encode", "rmj_encode_device", "rmj_encode_extended", "rmj_encode_extended_device", "rmj_encode_aux", "rmj_encode_aux_device", "rmj_encode_seq", "rmj_encode_seq_device", "rmj_bench_rollout", "rmj_time_rollout",
     "rmj_bench_rollout_validated", "rmj_bench_encode", "rmj_set_rollout_streams", "rmj_total_full_path",
     "rmj_random_actions_device", "rmj_peek_outputs", "rmj_sample_ids_device",
     "rmj_encode_seq_delta", "rmj_encode_seq_delta_device", "rmj_step_random_encode",
@@ -118,6 +118,7 @@ def load_lib():
     L.rmj_shanten.argtypes = [C.c_int, vp, C.c_uint32, C.c_int, vp]
     L.rmj_bench_rollout.argtypes = [vp, C.c_uint64, C.c_uint32, C.c_uint32, C.POINTER(abi.BenchResult)]
     L.rmj_bench_rollout_validated.argtypes = [vp, C.c_uint64, C.c_uint32, C.c_uint32, C.POINTER(abi.BenchResult)]
+    L.rmj_time_rollout.argtypes = [vp, C.c_uint64, C.c_uint32, C.POINTER(abi.BenchResult)]
     L.rmj_bench_encode.argtypes = [vp, C.c_int, C.c_int, vp, C.c_uint32, C.POINTER(C.c_double)]
     L.rmj_set_rollout_streams.argtypes = [vp, C.c_int]
     L.rmj_total_full_path.argtypes = [vp, C.POINTER(C.c_uint64)]
@@ -257,11 +258,15 @@ class VecRiichiEnv:
             if ev is None:
                 continue
             recs = abi.event_records_from_mjai(ev, np_, masked_ok) if isinstance(ev, dict) else ev
-            if replay:
-                recs[0].pad |= 1
             C.memmove(C.addressof(buf) + g * abi.EVENT_SLOTS * C.sizeof(abi.Event), C.addressof(recs),
                       abi.EVENT_SLOTS * C.sizeof(abi.Event))
+            if replay:
+                buf[g * abi.EVENT_SLOTS].pad |= 1   # on the staged copy: the caller's records stay as they were
         _chk(self.L.rmj_apply_events(self.h, C.addressof(buf)))
+
+    def sync(self):
+        """wait for everything issued on the handle's stream (rmj_sync)"""
+        _chk(self.L.rmj_sync(self.h))
 
     def step_random(self, policy_seed, n_steps=1, auto_reset=False):
         _chk(self.L.rmj_step_random(self.h, policy_seed, n_steps, int(auto_reset)))
@@ -445,6 +450,12 @@ class VecRiichiEnv:
     def bench_rollout(self, policy_seed, warmup, steps) -> abi.BenchResult:
         r = abi.BenchResult()
         _chk(self.L.rmj_bench_rollout(self.h, policy_seed, warmup, steps, C.byref(r)))
+        return r
+
+    def time_rollout(self, policy_seed, steps) -> abi.BenchResult:
+        """HIP-event time of rmj_step_random(seed, steps, auto_reset) alone (header: rmj_time_rollout); counters stay 0."""
+        r = abi.BenchResult()
+        _chk(self.L.rmj_time_rollout(self.h, policy_seed, steps, C.byref(r)))
         return r
 
     def bench_rollout_validated(self, policy_seed, warmup, steps) -> abi.BenchResult:

@@ -173,3 +173,28 @@ def test_sharded_env_equals_one_env():
     # the dense batch of a shard indexes the shard's own games
     obs, idx = sh.shards[1].obs_compact()
     assert obs.shape[0] == idx.shape[0] and int(idx.max()) < sh.per * 4
+
+
+@pytest.mark.parametrize("shared", [True, False])
+def test_readme_loop_compact_logits(shared):
+    """The quick-start loop of README.md: a policy over the compact observation batch returns compact logits [k, 82];
+    sample_ids(logits, index=index) scatters them to the acting seats.  A dominant logit on the largest legal id of every row
+    must be the id that is played."""
+    torch = pytest.importorskip("torch")
+    from riichienv_amd.torch_env import TorchVecEnv
+
+    n = 1024
+    env = TorchVecEnv(n, game_mode=2, seed=31, share_stream=shared)
+    for k in range(40):
+        obs, index = env.obs_compact()
+        assert obs.shape[1:] == (74, 34) and obs.shape[0] == index.shape[0]
+        g, s = (index // 4).long(), (index % 4).long()
+        mask = env.mask[g, s].to(torch.bool)                               # [k, 82]
+        top = torch.where(mask, torch.arange(82, device=env.device)[None, :], torch.full((1,), -1, device=env.device)).max(-1).values
+        logits = torch.zeros((obs.shape[0], 82), dtype=torch.float32, device=env.device)
+        has = top >= 0
+        logits[has, top[has]] = 60.0
+        ids = env.sample_ids(logits=logits, seed=k, index=index)
+        assert (ids[g[has], s[has]].long() == top[has]).all()
+        assert int((ids >= 0).sum()) == int(has.sum())
+        env.step(ids)

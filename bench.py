@@ -44,6 +44,10 @@ def parse_args(argv=None):
     ap.add_argument("--mode", type=int, default=2, help="0/1/2 = 4p-red-single/east/half, 3/4/5 = 3p-red-single/east/half")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the single-stream / validated-actions side measurements")
+    ap.add_argument("--policy", choices=["random", "greedy"], default="random",
+                    help="device policy of the rollout: the RandomAgent of BASELINE's configs, or the greedy policy that plays to win "
+                         "(rmj_step_greedy: shanten-greedy discards, every win / riichi / kan / kita taken, calls at --call-rate)")
+    ap.add_argument("--call-rate", type=int, default=64, help="greedy policy: pon / chi taken with probability call_rate / 256")
     ap.add_argument("--preroll", type=int, default=PREROLL,
                     help="untimed steps before the warm-up that bring every game to steady state (0: time the opening phase)")
     ap.add_argument("--encode", action="store_true",
@@ -68,6 +72,8 @@ def launcher_command(args, port, script=None):
            "--games", str(args.games), "--mode", str(args.mode)]
     if args.preroll != PREROLL:
         cmd += ["--preroll", str(args.preroll)]
+    if args.policy != "random":
+        cmd += ["--policy", args.policy, "--call-rate", str(args.call_rate)]
     if args.no_cpu_baseline:
         cmd.append("--no-cpu-baseline")
     if args.no_extras:
@@ -99,25 +105,52 @@ def launch_ranks(args):
     return 0
 
 
+_WORKER = """
+import sys
+sys.path.insert(0, sys.argv[1])
+from oracle import oracle
+mode, rule, pseed, first, games, per = (int(x) for x in sys.argv[2:8])
+s, t = oracle.bench_rollout(mode, rule, False, games, first, pseed, per, 1)
+print(s, t)
+"""
+
+
 def cpu_baseline(game_mode, rule_bits, policy_seed, target_s=15.0):
-    """Oracle (CPU restatement of riichienv-core, kind="port") on the host cores: bounded sample."""
+    """Oracle (CPU restatement of riichienv-core, kind="port") on the host cores: bounded sample.  Must run BEFORE this process
+    touches the GPU: the all-cores figure comes from one single-threaded worker PROCESS per hardware thread (children of this
+    process), because the oracle allocates std::map / vector / string per step and 256 threads of one process spend their time in
+    the allocator (round 2: 9.5x one thread on 256 threads).  Reported beside it: the same workload as threads of one process
+    (`threads_value`) and parallel_efficiency = value / (cores x single-thread rate)."""
     from oracle import oracle
 
-    threads = os.cpu_count() or 1
-    n_games = threads * 8
-    # calibrate with a short run, then size the sample for ~target_s seconds
-    steps, secs = oracle.bench_rollout(game_mode, rule_bits, False, n_games, 0, policy_seed, 200, threads)
-    rate = steps / max(secs, 1e-9)
-    per_game = int(max(200, min(200000, rate * target_s / n_games)))
-    steps, secs = oracle.bench_rollout(game_mode, rule_bits, False, n_games, 0, policy_seed, per_game, threads)
-    # one thread, a few seconds: the per-core rate beside the all-cores one (SURVEY.md §8(d))
+    cores = os.cpu_count() or 1
+    # one thread, ~3 s: the per-core rate (SURVEY.md §8(d))
     s1, t1 = oracle.bench_rollout(game_mode, rule_bits, False, 8, 0, policy_seed, 200, 1)
     per1 = int(max(200, min(200000, (s1 / max(t1, 1e-9)) * 3.0 / 8)))
     s1, t1 = oracle.bench_rollout(game_mode, rule_bits, False, 8, 0, policy_seed, per1, 1)
-    return {"value": steps / secs, "unit": "env.step/s", "cores": threads, "kind": "port",
-            "sample": f"{n_games} games x {per_game} steps, {threads} threads, {secs:.1f}s, "
-                      "oracle/ C++ restatement with MJAI logging on (Rust toolchain unavailable)",
-            "single_thread": {"value": s1 / t1, "sample": f"8 games x {per1} steps, {t1:.1f}s"}}
+    rate1 = s1 / t1
+    # all cores: `cores` processes x 8 games, sized for ~target_s seconds at HALF the single-thread rate (SMT siblings share a core)
+    per_game = int(max(200, min(200000, 0.5 * rate1 * target_s / 8)))
+    t0 = time.perf_counter()
+    procs = [subprocess.Popen([sys.executable, "-c", _WORKER, ROOT, str(game_mode), str(rule_bits), str(policy_seed), str(8 * i), "8",
+                               str(per_game)], stdout=subprocess.PIPE, text=True) for i in range(cores)]
+    outs = [p.communicate()[0].split() for p in procs]
+    wall = time.perf_counter() - t0
+    if any(p.returncode != 0 or len(o) != 2 for p, o in zip(procs, outs)):
+        raise RuntimeError("cpu_baseline: an oracle worker process failed")
+    steps = sum(int(o[0]) for o in outs)
+    secs = max(float(o[1]) for o in outs)
+    # the same as threads of ONE process, ~5 s (what round 2 reported as the baseline)
+    th_games = cores * 8
+    per_th = max(100, per_game // 32)
+    st, tt = oracle.bench_rollout(game_mode, rule_bits, False, th_games, 0, policy_seed, per_th, cores)
+    return {"value": steps / secs, "unit": "env.step/s", "cores": cores, "kind": "port",
+            "sample": f"{cores} worker processes x 8 games x {per_game} steps (one thread each), slowest worker {secs:.1f}s "
+                      f"({wall:.1f}s with process start), oracle/ C++ restatement with MJAI logging on (Rust toolchain unavailable)",
+            "parallel_efficiency": steps / secs / (cores * rate1),
+            "single_thread": {"value": rate1, "sample": f"8 games x {per1} steps, {t1:.1f}s"},
+            "threads_value": {"value": st / tt, "sample": f"{th_games} games x {per_th} steps as {cores} threads of one process, {tt:.1f}s "
+                                                        "(allocator contention: the oracle allocates containers per step)"}}
 
 
 def pmc_traffic(kernel, games_per_launch, mode, ran_as=None):
@@ -147,7 +180,8 @@ def fused_kernel_name(r):
 
 
 def workload_name(args):
-    s = f"{args.games} parallel {MODES[args.mode]} games per GPU, device RandomAgent, auto-reset, MJAI logging on"
+    pol = "device RandomAgent" if args.policy == "random" else f"greedy device policy (calls {args.call_rate}/256)"
+    s = f"{args.games} parallel {MODES[args.mode]} games per GPU, {pol}, auto-reset, MJAI logging on"
     if args.encode:
         s += ", Observation.encode() of every acting seat written to a resident tensor after every step"
     return s
@@ -155,10 +189,12 @@ def workload_name(args):
 
 def metric_name(args):
     """BASELINE.json's metric for the configuration it is quoted on; a descriptive one for every other workload."""
-    if args.mode < 3 and args.games == 65536 and not args.encode:
+    if args.mode < 3 and args.games == 65536 and not args.encode and args.policy == "random":
         return "env.step()/s (whole node) at 65 536 parallel 4p games; bit-exact MJAI parity"
     seats = "3p" if args.mode >= 3 else "4p"
     extra = " with feature-encoding tensor output" if args.encode else ""
+    if args.policy != "random":
+        extra += f" under the {args.policy} device policy"
     return f"env.step()/s (whole node) at {args.games} parallel {seats} games per GPU{extra}; bit-exact MJAI parity"
 
 
@@ -183,6 +219,12 @@ def main(argv=None):
     saved_stdout = os.dup(1)
     os.dup2(2, 1)
 
+    # The CPU baseline starts worker processes: it runs FIRST, before this process imports torch or touches HIP (a process
+    # that has initialised the GPU must not fork + exec on this pool); it is outside the timed region either way.
+    cpu_line = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        cpu_line = cpu_baseline(args.mode, 64 | 128, 0xC0FFEE)   # abi.RULE_TENHOU (the GPU run's rule set), the GPU run's policy seed
+
     import torch
 
     from riichienv_amd import abi, shard, vecenv
@@ -204,9 +246,20 @@ def main(argv=None):
     env = vecenv.VecRiichiEnv(args.games, game_mode=args.mode, seed=0, rule_bits=abi.RULE_TENHOU, device=local_rank,
                               game_offset=shard.shard_offset(rank, args.games), event_ring=64)
     env.reset()
+    greedy = args.policy == "greedy"
+    if greedy and args.encode:
+        print("bench.py: --policy greedy has no --encode leg", file=sys.stderr)
+        return 2
+
+    def roll(k):
+        if greedy:
+            env.step_greedy(policy_seed, k, auto_reset=True, call_rate_256=args.call_rate)
+        else:
+            env.step_random(policy_seed, k, auto_reset=True)
+
     if args.preroll > 0:
-        env.step_random(policy_seed, args.preroll, auto_reset=True)   # to steady state (see PREROLL), untimed
-    env.step_random(policy_seed, args.warmup, auto_reset=True)
+        roll(args.preroll)   # to steady state (see PREROLL), untimed
+    roll(args.warmup)
 
     def barrier():
         if dist is not None:
@@ -229,7 +282,7 @@ def main(argv=None):
     else:
         # exactly K steps of every game and nothing else inside the region: HIP events on the handle's stream around the rollout
         # (returns when the second event has completed); the step counters are read outside
-        r = env.time_rollout(policy_seed, args.steps)
+        r = env.time_rollout_greedy(policy_seed, args.steps, args.call_rate) if greedy else env.time_rollout(policy_seed, args.steps)
     barrier()
     t1 = time.perf_counter()
     steps_local = float(env.total_steps() - before)
@@ -248,7 +301,23 @@ def main(argv=None):
         acting = int(sum(bin(int(a)).count("1") for a, d in zip(act, dn) if not d))
         enc_ms = env.bench_encode(obs.data_ptr(), 50, extended=False, only_active=2)
         extras["encode"] = (acting, enc_ms)
-    if rank == 0 and world == 1 and not args.no_extras and not args.encode:
+    if rank == 0 and world == 1 and not args.no_extras and not args.encode and not greedy:
+        # the policy that plays to win (the RandomAgent wins once in ~250 rounds, a trainer's policy does not):
+        # a second environment, pre-rolled under that policy, 300 timed steps
+        genv = vecenv.VecRiichiEnv(args.games, game_mode=args.mode, seed=0, rule_bits=abi.RULE_TENHOU, device=local_rank,
+                                   game_offset=shard.shard_offset(rank, args.games), event_ring=64)
+        genv.reset()
+        genv.step_greedy(policy_seed, 1500, auto_reset=True, call_rate_256=args.call_rate)
+        gs0, gf0 = genv.total_steps(), genv.total_full_path()
+        gr = genv.time_rollout_greedy(policy_seed, 300, args.call_rate)
+        gs1, gf1 = genv.total_steps(), genv.total_full_path()
+        extras["greedy_policy"] = {"value": (gs1 - gs0) / (gr.total_ms * 1e-3), "ms_per_step": gr.total_ms / 300, "steps": 300,
+                                   "full_path_frac": (gf1 - gf0) / max(1, gs1 - gs0), "call_rate_256": args.call_rate,
+                                   "kernel": fused_kernel_name(gr) + " (greedy policy instantiation)",
+                                   "what": "the same rollout under rmj_step_greedy: shanten-greedy discards, every win / riichi / kan / kita "
+                                           "taken, pon / chi at the call rate - rounds end with wins, not exhaustive draws"}
+        genv.close()
+    if rank == 0 and world == 1 and not args.no_extras and not args.encode and not greedy:
         k = min(args.steps, 300)
         env.set_rollout_streams(1)
         r1 = env.bench_rollout(policy_seed, 0, k)
@@ -285,6 +354,8 @@ def main(argv=None):
         # (the committed counter summary is of the fused rollout kernel, per step of all games; the per-step launches of the
         #  feature rollout have no counter profile of their own)
         kernel_name = fused_kernel_name(r) if steps_per_launch > 1 else "k_step4<false>"
+        if greedy:
+            kernel_name += " (greedy)"
         traffic, traffic_src = (None, None) if args.encode else pmc_traffic("k_step4", games_per_launch, args.mode, ran_as=kernel_name)
         if traffic is not None:
             traffic *= steps_per_launch
@@ -320,8 +391,8 @@ def main(argv=None):
                                       "kernel_ms": enc_ms, "bytes_per_launch": b_obs * acting, "acting_seats": acting,
                                       "bytes_per_observation": b_obs}
         out.update(extras)
-        if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(args.mode, abi.RULE_TENHOU, policy_seed)
+        if cpu_line is not None:
+            out["cpu_baseline"] = cpu_line
         sys.stdout.flush()
         os.dup2(saved_stdout, 1)
         print(json.dumps(out), flush=True)

@@ -207,6 +207,18 @@ int rmj_step_device(rmj_handle h, const rmj_action_t* d_actions);
  * a policy that is a barrier between steps gets; RMJ_STEP4=1 / 0 in the environment at create selects the earlier
  * schedules (one launch per step and part on up to four streams; one game per wavefront). */
 int rmj_step_random(rmj_handle h, uint64_t policy_seed, uint32_t n_steps, int auto_reset);
+/* The device policy that PLAYS mahjong (what the consumer of this path runs is a learned policy that wins,
+ * riichienv-ml/src/riichienv_ml/trainers/_ppo_worker.py:147-239; the uniform RandomAgent wins once in ~250 rounds): for every
+ * seat that is to act, over its ordered legal list, the first entry of the best class
+ *   Tsumo / Ron > Kita > Riichi > Ankan > Kakan > Daiminkan > [Pon > Chi, only when ((key >> 40) & 255) < call_rate_256] >
+ *   Discard > Pass > Kyushu kyuhai
+ * (Kita before Riichi: the 3P reference offers Kita in the riichi stage and can leave the seat without a legal action),
+ * and among the Discard entries (when there are two or more) the one whose removal leaves the concealed hand with the lowest
+ * shanten (calculate_shanten / _3p, shanten.rs:228-241 / :454-468, of the remaining tiles with len_div3 = (hand_len - 1) / 3),
+ * ties broken by key mod #ties in list order; key = splitmix64(splitmix64(policy_seed + global game) + 4 * step_no + seat),
+ * the RandomAgent's key.  Scheduling, auto_reset and outputs exactly like rmj_step_random (same kernels, compiled with this
+ * policy in place of the random pick).  Needs the four-games-per-wave kernels (the default; RMJ_STEP4=0 -> RMJ_ERR_ARG). */
+int rmj_step_greedy(rmj_handle h, uint64_t policy_seed, uint32_t n_steps, int auto_reset, uint32_t call_rate_256);
 /* Fill actions[n][4] with what the device policy would choose for the CURRENT state (no step). */
 int rmj_random_actions(rmj_handle h, uint64_t policy_seed, rmj_action_t* actions);
 /* Same into a device buffer [n][4], asynchronous on the handle's stream (feeds rmj_step_device without a host trip). */
@@ -450,6 +462,8 @@ int rmj_bench_rollout(rmj_handle h, uint64_t policy_seed, uint32_t warmup, uint3
  * (no counter launches, no host round trips besides the final event wait); env_steps / full_path_steps stay 0 - read
  * rmj_total_steps / rmj_total_full_path before and after.  What bench.py times. */
 int rmj_time_rollout(rmj_handle h, uint64_t policy_seed, uint32_t steps, RmjBenchResult* out);
+/* the same around rmj_step_greedy(h, policy_seed, steps, 1, call_rate_256) */
+int rmj_time_rollout_greedy(rmj_handle h, uint64_t policy_seed, uint32_t steps, uint32_t call_rate_256, RmjBenchResult* out);
 /* The unfused counterpart: per step one policy launch (packed actions into a device buffer) and one step launch that
  * validates them against the stored legal lists like GameState::step does for an external agent (state/mod.rs:339-402);
  * finished games restart; one stream, the whole batch per launch.  step_kernel_ms = policy + step launch. */

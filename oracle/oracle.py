@@ -47,6 +47,7 @@ def lib():
         L.orc_game_log_len.argtypes = [C.c_void_p, C.c_int]
         L.orc_game_log_get.argtypes = [C.c_void_p, C.c_int, C.c_uint32, C.c_char_p, C.c_uint32]
         L.orc_game_random_actions.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64, C.POINTER(C.c_uint64)]
+        L.orc_game_greedy_actions.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64, C.c_uint32, C.POINTER(C.c_uint64)]
         L.orc_eval_hands.argtypes = [C.POINTER(abi.HandCase), C.c_uint32, C.POINTER(abi.HandResult)]
         L.orc_agari_counts.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]
         L.orc_is_tenpai_free.argtypes = [C.c_void_p]
@@ -251,6 +252,12 @@ class Game:
     def random_actions(self, policy_seed, global_game):
         arr = (C.c_uint64 * 4)()
         self.L.orc_game_random_actions(self.h, policy_seed, global_game, arr)
+        return [arr[i] for i in range(4)]
+
+    def greedy_actions(self, policy_seed, global_game, call_rate_256=64):
+        """the greedy policy of rmj_step_greedy restated on the oracle's own lists and shanten"""
+        arr = (C.c_uint64 * 4)()
+        self.L.orc_game_greedy_actions(self.h, policy_seed, global_game, call_rate_256, arr)
         return [arr[i] for i in range(4)]
 
 

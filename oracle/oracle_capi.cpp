@@ -1073,6 +1073,68 @@ void orc_game_random_actions(void* gp, uint64_t policy_seed, uint64_t global_gam
     }
 }
 
+// The greedy policy of rmj_step_greedy, restated (definition: include/riichi_mi355x.h; device twin: r4_policy_greedy).  Test
+// infrastructure like the rest of this file: the checker's own legal lists and its own shanten (riichi_shanten.hpp).
+static int greedy_class(ActionType t, bool call) {
+    switch (t) {
+        case AT_TSUMO: case AT_RON: return 0;
+        case AT_KITA: return 1;
+        case AT_RIICHI: return 2;
+        case AT_ANKAN: return 3;
+        case AT_KAKAN: return 4;
+        case AT_DAIMINKAN: return 5;
+        case AT_PON: return call ? 6 : 12;
+        case AT_CHI: return call ? 7 : 12;
+        case AT_DISCARD: return 8;
+        case AT_PASS: return 9;
+        case AT_KYUSHU: return 10;
+        default: return 15;
+    }
+}
+static size_t greedy_pick(const GameState& g, uint8_t p, const std::vector<Action>& l, uint64_t key, uint32_t call_rate) {
+    const bool call = (uint32_t)((key >> 40) & 0xFF) < call_rate;
+    int best_c = 99;
+    size_t best_i = 0;
+    for (size_t i = 0; i < l.size(); i++) {
+        const int c = greedy_class(l[i].type, call);
+        if (c < best_c) { best_c = c; best_i = i; }
+    }
+    if (best_c != 8) return best_i;
+    std::vector<size_t> cand;
+    for (size_t i = 0; i < l.size(); i++)
+        if (l[i].type == AT_DISCARD) cand.push_back(i);
+    if (cand.size() < 2) return best_i;
+    const auto& hand = g.players[p].hand;
+    const int len3 = ((int)hand.size() - 1) / 3;
+    int smin = 99;
+    std::vector<int> sh(cand.size());
+    for (size_t k = 0; k < cand.size(); k++) {
+        uint8_t cnt[34] = {0};
+        bool removed = false;
+        for (uint8_t t : hand) {
+            if (!removed && (int)t == l[cand[k]].tile) { removed = true; continue; }
+            cnt[t / 4]++;
+        }
+        sh[k] = calc_shanten_from_counts(cnt, len3, g.sanma);
+        smin = std::min(smin, sh[k]);
+    }
+    std::vector<size_t> tie;
+    for (size_t k = 0; k < cand.size(); k++)
+        if (sh[k] == smin) tie.push_back(cand[k]);
+    return tie[key % tie.size()];
+}
+void orc_game_greedy_actions(void* gp, uint64_t policy_seed, uint64_t global_game, uint32_t call_rate_256, rmj_action_t* out /*[4]*/) {
+    GameState* g = (GameState*)gp;
+    for (int p = 0; p < 4; p++) out[p] = RMJ_NO_ACTION;
+    if (g->is_done) return;
+    for (uint8_t p : g->active_players) {
+        auto l = g->_get_legal_actions_internal(p);
+        if (l.empty()) continue;
+        const uint64_t key = splitmix64(splitmix64(policy_seed + global_game) + (uint64_t)g->step_count * 4 + p);
+        out[p] = pack_action(l[greedy_pick(*g, p, l, key, call_rate_256)]);
+    }
+}
+
 // RiichiEnv.win_results (env.rs:606-607): out[4] by seat, returns the seat mask
 int orc_game_win_results(void* h, RmjWinResult* out) {
     auto* g = (GameState*)h;

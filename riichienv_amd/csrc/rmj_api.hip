@@ -23,6 +23,7 @@ using namespace rmj;
 #define STEP_F_RANDOM 1u
 #define STEP_F_AUTORESET 2u
 #define STEP_F_IDS 4u /* `actions` holds int32 action ids [n][4] (Observation.find_action semantics) */
+#define STEP_F_GREEDY 8u /* with STEP_F_RANDOM: the greedy policy (rmj_step_greedy, r4_policy_greedy) instead of the RandomAgent; bits 8..15 = call rate / 256 */
 
 template <int N>
 struct BlockSharedT {
@@ -768,7 +769,7 @@ struct rmj_env {
     int queue_chunk = 64;      // steps per ticket; RMJ_QUEUE_CHUNK at create, 0 = off (every wave keeps one quad for the rollout)
     uint32_t* d_qheads = nullptr;   // [8][RMJ_Q_STRIDE] ticket counters, one line per XCD
     uint32_t* d_qdone = nullptr;    // [quads] chunks finished
-    uint32_t q_slots = 0;           // waves of k_step4_queue the device holds at once
+    uint32_t q_slots = 0;           // waves of k_step4_queue the device holds at once (the smaller of the two policy instantiations)
     int queue_force = 0;            // RMJ_QUEUE_FORCE at create (tests): tickets for every batch of >= 64 quads
     uint32_t queue_skip_xcds = 0;   // test hook: XCDs whose waves leave the queue kernel at once (RMJ_QUEUE_TEST_SKIP_XCDS at create)
     int queue_min_chunk = 8;        // shortest ticket (steps): a rollout of >= 2 tickets per quad runs as tickets; RMJ_QUEUE_MIN_CHUNK at create
@@ -1065,6 +1066,7 @@ int rmj_reset(rmj_handle h, const uint8_t* select, const uint8_t* walls, const u
 // one k_step launch over games [g0, g1) of the handle
 static inline void launch_step_range(rmj_env* h, hipStream_t st, const uint64_t* d_actions, uint64_t policy_seed, uint32_t flags,
                                      uint32_t g0, uint32_t g1, bool allow_quad = true) {
+    const bool greedy = (flags & STEP_F_GREEDY) != 0u;   // (four-games-per-wave kernels only: the callers check h->quad)
 #ifdef RMJ_TUNE_LDS
     static const unsigned extra_lds = getenv("RMJ_EXTRA_LDS") ? (unsigned)atoi(getenv("RMJ_EXTRA_LDS")) : 0u;  // occupancy experiments
 #else
@@ -1072,8 +1074,13 @@ static inline void launch_step_range(rmj_env* h, hipStream_t st, const uint64_t*
 #endif
     if (h->quad && allow_quad) {   // four games per wave (device policy, packed actions or action ids)
         const dim3 grid((g1 - g0 + 3u) / 4u);
-        if (h->cfg.game_mode >= 3) hipLaunchKernelGGL(rmj3::k_step4<false>, grid, dim3(64), 0, st, (const Env*)h->d_env, policy_seed, flags, g0, g1, 1u, d_actions);
-        else hipLaunchKernelGGL(rmj4::k_step4<false>, grid, dim3(64), 0, st, (const Env*)h->d_env, policy_seed, flags, g0, g1, 1u, d_actions);
+        if (h->cfg.game_mode >= 3) {
+            if (greedy) hipLaunchKernelGGL((rmj3::k_step4<false, 1>), grid, dim3(64), 0, st, (const Env*)h->d_env, policy_seed, flags, g0, g1, 1u, d_actions);
+            else hipLaunchKernelGGL((rmj3::k_step4<false, 0>), grid, dim3(64), 0, st, (const Env*)h->d_env, policy_seed, flags, g0, g1, 1u, d_actions);
+        } else {
+            if (greedy) hipLaunchKernelGGL((rmj4::k_step4<false, 1>), grid, dim3(64), 0, st, (const Env*)h->d_env, policy_seed, flags, g0, g1, 1u, d_actions);
+            else hipLaunchKernelGGL((rmj4::k_step4<false, 0>), grid, dim3(64), 0, st, (const Env*)h->d_env, policy_seed, flags, g0, g1, 1u, d_actions);
+        }
         return;
     }
     if (h->cfg.game_mode >= 3) hipLaunchKernelGGL(rmj3::k_step, step_grid(g1 - g0), dim3(64 * RMJ_STEP_WPB), extra_lds, st, (const Env*)h->d_env, d_actions, policy_seed, flags, g0, g1);
@@ -1170,20 +1177,40 @@ static bool rollout_queued(rmj_env* h, uint32_t n_steps) {
     if (h->q_slots == 0) {
         int per_cu = 0, cus = 0;
         const bool sanma = h->cfg.game_mode >= 3;
-        if ((sanma ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, rmj3::k_step4_queue, 64, 0)
-                   : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, rmj4::k_step4_queue, 64, 0)) != hipSuccess ||
+        int per_cu1 = 0;
+        if ((sanma ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, rmj3::k_step4_queue<0>, 64, 0)
+                   : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, rmj4::k_step4_queue<0>, 64, 0)) != hipSuccess ||
+            (sanma ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu1, rmj3::k_step4_queue<1>, 64, 0)
+                   : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu1, rmj4::k_step4_queue<1>, 64, 0)) != hipSuccess ||
             hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, h->cfg.device) != hipSuccess)
             return false;
+        if (per_cu1 > 0 && per_cu1 < per_cu) per_cu = per_cu1;
         h->q_slots = (uint32_t)(per_cu > 0 ? per_cu : 1) * (uint32_t)(cus > 0 ? cus : 1);
     }
     if (h->queue_force) return quads >= 64u;   // RMJ_QUEUE_FORCE=1 (tests): any batch with a quad per XCD queue to spare
     return quads > h->q_slots && quads < 8u * h->q_slots;
 }
-int rmj_step_random(rmj_handle h, uint64_t policy_seed, uint32_t n_steps, int auto_reset) {
+// device-policy rollout: pol 0 = RandomAgent (rmj_step_random), 1 = the greedy policy (rmj_step_greedy)
+#define RMJ_LAUNCH_POL(NS, KERNEL, POL, ...)                                              \
+    do {                                                                                  \
+        if ((POL) == 1) hipLaunchKernelGGL((NS::KERNEL<1>), __VA_ARGS__);                 \
+        else hipLaunchKernelGGL((NS::KERNEL<0>), __VA_ARGS__);                            \
+    } while (0)
+#define RMJ_LAUNCH_LOOP_POL(NS, POL, ...)                                                 \
+    do {                                                                                  \
+        if ((POL) == 1) hipLaunchKernelGGL((NS::k_step4<true, 1>), __VA_ARGS__);          \
+        else hipLaunchKernelGGL((NS::k_step4<true, 0>), __VA_ARGS__);                     \
+    } while (0)
+static int step_policy_impl(rmj_handle h, uint64_t policy_seed, uint32_t n_steps, int auto_reset, int pol, uint32_t call_rate) {
     if (!h) return fail(RMJ_ERR_ARG, "null handle");
     HIPCHK(hipSetDevice(h->cfg.device));
     uint32_t flags = STEP_F_RANDOM | (auto_reset ? STEP_F_AUTORESET : 0u);
+    if (pol == 1) {
+        if (!h->quad) return fail(RMJ_ERR_ARG, "the greedy device policy runs in the four-games-per-wave kernels (RMJ_STEP4=0 selects the one-game kernel)");
+        flags |= STEP_F_GREEDY | ((call_rate > 255u ? 255u : call_rate) << 8);
+    }
     const uint32_t n = h->cfg.n_games;
+    const bool sanma = h->cfg.game_mode >= 3;
     if (h->quad >= 2 && n_steps >= 2 && h->want_streams >= 2) {   // (rmj_set_rollout_streams(h, 1): one launch per step, one stream)
         // four games per wave, the whole rollout in ONE launch: every wave steps its own games n_steps times (k_step4<true>)
         const dim3 grid((n + 3u) / 4u);
@@ -1197,18 +1224,18 @@ int rmj_step_random(rmj_handle h, uint64_t policy_seed, uint32_t n_steps, int au
             HIPCHK(hipMemsetAsync(h->d_qdone, 0, (size_t)grid.x * sizeof(uint32_t), h->stream));
             const dim3 gq(grid.x < h->q_slots ? grid.x : h->q_slots);
             const uint32_t chunk = rollout_chunk(h, n_steps);
-            if (h->cfg.game_mode >= 3) {
-                hipLaunchKernelGGL(rmj3::k_step4_queue, gq, dim3(64), 0, h->stream, (const Env*)h->d_env, policy_seed, flags, n, n_steps, chunk, h->d_qheads, h->d_qdone, h->queue_skip_xcds);
-                hipLaunchKernelGGL(rmj3::k_step4_fixup, grid, dim3(64), 0, h->stream, (const Env*)h->d_env, policy_seed, flags, n, n_steps, (const uint32_t*)h->d_qdone);
+            if (sanma) {
+                RMJ_LAUNCH_POL(rmj3, k_step4_queue, pol, gq, dim3(64), 0, h->stream, (const Env*)h->d_env, policy_seed, flags, n, n_steps, chunk, h->d_qheads, h->d_qdone, h->queue_skip_xcds);
+                RMJ_LAUNCH_POL(rmj3, k_step4_fixup, pol, grid, dim3(64), 0, h->stream, (const Env*)h->d_env, policy_seed, flags, n, n_steps, (const uint32_t*)h->d_qdone);
             } else {
-                hipLaunchKernelGGL(rmj4::k_step4_queue, gq, dim3(64), 0, h->stream, (const Env*)h->d_env, policy_seed, flags, n, n_steps, chunk, h->d_qheads, h->d_qdone, h->queue_skip_xcds);
-                hipLaunchKernelGGL(rmj4::k_step4_fixup, grid, dim3(64), 0, h->stream, (const Env*)h->d_env, policy_seed, flags, n, n_steps, (const uint32_t*)h->d_qdone);
+                RMJ_LAUNCH_POL(rmj4, k_step4_queue, pol, gq, dim3(64), 0, h->stream, (const Env*)h->d_env, policy_seed, flags, n, n_steps, chunk, h->d_qheads, h->d_qdone, h->queue_skip_xcds);
+                RMJ_LAUNCH_POL(rmj4, k_step4_fixup, pol, grid, dim3(64), 0, h->stream, (const Env*)h->d_env, policy_seed, flags, n, n_steps, (const uint32_t*)h->d_qdone);
             }
             HIPCHK(hipGetLastError());
             return RMJ_OK;
         }
-        if (h->cfg.game_mode >= 3) hipLaunchKernelGGL(rmj3::k_step4<true>, grid, dim3(64), 0, h->stream, (const Env*)h->d_env, policy_seed, flags, 0u, n, n_steps, (const uint64_t*)nullptr);
-        else hipLaunchKernelGGL(rmj4::k_step4<true>, grid, dim3(64), 0, h->stream, (const Env*)h->d_env, policy_seed, flags, 0u, n, n_steps, (const uint64_t*)nullptr);
+        if (sanma) RMJ_LAUNCH_LOOP_POL(rmj3, pol, grid, dim3(64), 0, h->stream, (const Env*)h->d_env, policy_seed, flags, 0u, n, n_steps, (const uint64_t*)nullptr);
+        else RMJ_LAUNCH_LOOP_POL(rmj4, pol, grid, dim3(64), 0, h->stream, (const Env*)h->d_env, policy_seed, flags, 0u, n, n_steps, (const uint64_t*)nullptr);
         HIPCHK(hipGetLastError());
         return RMJ_OK;
     }
@@ -1230,6 +1257,12 @@ int rmj_step_random(rmj_handle h, uint64_t policy_seed, uint32_t n_steps, int au
     }
     HIPCHK(hipGetLastError());
     return RMJ_OK;
+}
+int rmj_step_random(rmj_handle h, uint64_t policy_seed, uint32_t n_steps, int auto_reset) {
+    return step_policy_impl(h, policy_seed, n_steps, auto_reset, 0, 0u);
+}
+int rmj_step_greedy(rmj_handle h, uint64_t policy_seed, uint32_t n_steps, int auto_reset, uint32_t call_rate_256) {
+    return step_policy_impl(h, policy_seed, n_steps, auto_reset, 1, call_rate_256);
 }
 // The feature-output rollout of BASELINE configs[4]: every step of the device-policy rollout is followed by Observation.encode()
 // of the seats that are to act, written into the resident tensor d_out [n][4][74][W] (only_active as in rmj_encode_device).
@@ -2049,11 +2082,11 @@ int rmj_apply_events(rmj_handle h, const RmjEvent* events) {
 }
 
 // ---- measurement -----------------------------------------------------------------------------
-static int bench_rollout_impl(rmj_handle h, uint64_t policy_seed, uint32_t warmup, uint32_t steps, RmjBenchResult* out, bool count) {
+static int bench_rollout_impl(rmj_handle h, uint64_t policy_seed, uint32_t warmup, uint32_t steps, RmjBenchResult* out, bool count, int pol = 0, uint32_t rate = 0u) {
     DevTmp tmp;  // owns the two timing events on every return path
     if (!h || !out) return fail(RMJ_ERR_ARG, "null argument");
     HIPCHK(hipSetDevice(h->cfg.device));
-    int rc = warmup ? rmj_step_random(h, policy_seed, warmup, 1) : RMJ_OK;
+    int rc = warmup ? step_policy_impl(h, policy_seed, warmup, 1, pol, rate) : RMJ_OK;
     if (rc) return rc;
     uint64_t before = 0, after = 0, full0 = 0, full1 = 0;
     if (count && ((rc = rmj_total_steps(h, &before)) || (rc = rmj_total_full_path(h, &full0)))) return rc;
@@ -2061,7 +2094,7 @@ static int bench_rollout_impl(rmj_handle h, uint64_t policy_seed, uint32_t warmu
     HIPCHK(tmp.event(&e0));
     HIPCHK(tmp.event(&e1));
     HIPCHK(hipEventRecord(e0, h->stream));
-    if ((rc = rmj_step_random(h, policy_seed, steps, 1))) return rc;
+    if ((rc = step_policy_impl(h, policy_seed, steps, 1, pol, rate))) return rc;
     HIPCHK(hipEventRecord(e1, h->stream));
     HIPCHK(hipEventSynchronize(e1));
     float ms = 0.f;
@@ -2088,6 +2121,10 @@ int rmj_bench_rollout(rmj_handle h, uint64_t policy_seed, uint32_t warmup, uint3
 // outside the region.
 int rmj_time_rollout(rmj_handle h, uint64_t policy_seed, uint32_t steps, RmjBenchResult* out) {
     return bench_rollout_impl(h, policy_seed, 0u, steps, out, false);
+}
+// the same around rmj_step_greedy(h, policy_seed, steps, 1, call_rate_256)
+int rmj_time_rollout_greedy(rmj_handle h, uint64_t policy_seed, uint32_t steps, uint32_t call_rate_256, RmjBenchResult* out) {
+    return bench_rollout_impl(h, policy_seed, 0u, steps, out, false, 1, call_rate_256);
 }
 int rmj_set_rollout_streams(rmj_handle h, int k) {
     if (!h || k < 1 || k > RMJ_MAX_ROLLOUT_STREAMS) return fail(RMJ_ERR_ARG, "rollout streams must be 1..8");

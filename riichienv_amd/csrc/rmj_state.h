@@ -89,7 +89,13 @@ struct alignas(16) GState {  // 4*128 + 128 = 640 bytes
     // (Observation.events) of seat p's latest observation; advanced whenever observations are published for an acting seat
     uint32_t obs_from[4], obs_upto[4];
     uint8_t win_mask;         // seats with an entry in the win-result slab (win_results of the reference; cleared per round)
-    uint8_t pad[128 - 8 - 8 - 20 - 16 - 4 - 6 - 3 - 4 - 4 - 3 - 4 - 32 - 1];
+    // derived cache (never exported): the slots of seat tp_seat's 14-tile hand whose discard keeps the hand tenpai, as computed for
+    // the Riichi entry of the list published in step tp_step - 1; the Riichi declaration of the next step reuses it for the
+    // riichi-stage list (the hand cannot change in between).  Valid iff tp_step == step_count and tp_seat == current player.
+    uint8_t tp_seat;
+    uint16_t tp_mask;
+    uint32_t tp_step;
+    uint8_t pad[128 - 8 - 8 - 20 - 16 - 4 - 6 - 3 - 4 - 4 - 3 - 4 - 32 - 1 - 1 - 2 - 4];
 };
 
 #ifdef __cplusplus

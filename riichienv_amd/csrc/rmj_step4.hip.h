@@ -213,10 +213,118 @@ __device__ __forceinline__ R4Shape r4_shape_sorted(const R4& q, const PState* P,
     o.pairs = __popc(rballot(first && !last_of_kind, rb)) + (ex_single ? 1 : 0);
     return o;
 }
+// One suit word of a hand judged on its own (agari.rs:183-245, boolean): `tot` = its tile count mod 3; 0: sets only, 2: a pair and
+// sets (three pair candidates by pair_residue), 1: never.  s = 3: honors.
+__device__ __forceinline__ bool r4_word_ok(uint32_t w, int s, int tot) {
+    bool ok = false;
+    if (tot != 1) {
+        if (s == 3) {
+            ok = tot == 0 ? honors_ok0(w) : honors_ok2(w);
+        } else {
+            int j = pair_residue(w);
+            uint32_t y = w;
+            bool go = true;
+            if (tot == 2) {
+                go = ((w >> (3 * j)) & 7u) >= 2u;
+                y = w - (2u << (3 * j));
+            }
+            ok = go && mentsu_ok(y);
+            if (tot == 2 && !ok) {
+#pragma unroll 1
+                for (int k = 0; k < 2 && !ok; k++) {
+                    j += 3;
+                    if (((w >> (3 * j)) & 7u) >= 2u) ok = mentsu_ok(w - (2u << (3 * j)));
+                }
+            }
+        }
+    }
+    return ok;
+}
+// HandEvaluator::get_waits (hand_evaluator.rs:196-213) of the row's 3n+1-tile histogram h (row-uniform), in row form - the wait
+// probe that made a row leave tier 0 whenever a hand came within reach of tenpai (half of all exits once the policy plays to
+// win).  Adding tile t changes ONE suit word, so the standard form factorises like in wave_waits: lanes 0..3 judge the four
+// unmodified words; a suit can take the winning tile only if the three others are consistent with exactly one pair among the
+// four (at most two suits qualify: tile counts mod 3 are {1,0,0,0} or {2,2,0,0}); per qualifying suit one pass, lane = rank.
+// Chiitoi (six pairs and a single: closed form) and kokushi (lane = terminal kind) only behind their kind / pair gates.
+// Quirk Q7: a type already held four times (concealed) is never a wait.
+__device__ __noinline__ uint64_t r4_waits_probe(uint32_t ha, uint32_t hb, uint32_t hc, uint32_t hd) {
+    const int lane = threadIdx.x & 63, r = lane & 15, rb = lane & 48;
+    const PH h = {ha, hb, hc, hd};
+    const int t0 = field_sum(h.a) % 3, t1 = field_sum(h.b) % 3, t2 = field_sum(h.c) % 3, t3 = field_sum(h.d) % 3;
+    const uint32_t res2 = (uint32_t)(t0 == 2) | ((uint32_t)(t1 == 2) << 1) | ((uint32_t)(t2 == 2) << 2) | ((uint32_t)(t3 == 2) << 3);
+    const uint32_t res0 = (uint32_t)(t0 == 0) | ((uint32_t)(t1 == 0) << 1) | ((uint32_t)(t2 == 0) << 2) | ((uint32_t)(t3 == 0) << 3);
+    const int my_s = r & 3;
+    const int my_t = my_s == 0 ? t0 : (my_s == 1 ? t1 : (my_s == 2 ? t2 : t3));
+    const uint32_t okb = rballot(r < 4 && r4_word_ok(ph_get(h, my_s), my_s, my_t), rb) & 0xFu;   // unmodified words that are consistent
+    // suit s can take the tile: its count becomes 0 or 2 mod 3, the others are consistent, one pair among the four
+    uint32_t V = 0u;
+#pragma unroll
+    for (int s4 = 0; s4 < 4; s4++) {
+        const uint32_t others = 0xFu & ~(1u << s4);
+        const bool was2 = (res2 >> s4) & 1u, was0 = (res0 >> s4) & 1u;           // new residue: was 2 -> 0, was 1 -> 2, was 0 -> 1 (never)
+        const int pairs_after = __popc(res2 & others) + ((!was2 && !was0) ? 1 : 0);
+        if (!was0 && (okb & others) == others && pairs_after == 1) V |= 1u << s4;
+    }
+    uint64_t W = 0ull;
+    while (__ballot(V != 0u)) {
+        if (V) {
+            const int s = __ffs((int)V) - 1;
+            V &= V - 1u;
+            const uint32_t w = ph_get(h, s);
+            const bool in = r < (s == 3 ? 7 : 9);
+            const uint32_t sh3 = in ? 3u * (uint32_t)r : 0u;
+            const bool live = in && ((w >> sh3) & 7u) < 4u;
+            const int tot = ((res2 >> s) & 1u) ? 0 : 2;
+            const bool ok = live && r4_word_ok(w + (1u << sh3), s, tot);
+            W |= (uint64_t)(rballot(ok, rb) & 0x1FFu) << (9 * s);
+        }
+    }
+    // chiitoi / kokushi (13 concealed tiles only: six pairs resp. twelve terminal kinds)
+    const int pairs = __popc(h.a & O9_2 & ~(h.a << 1)) + __popc(h.b & O9_2 & ~(h.b << 1)) + __popc(h.c & O9_2 & ~(h.c << 1)) +
+                      __popc(h.d & O7_2 & ~(h.d << 1));  // fields equal to 2 or 6
+    const uint32_t pres_d = (h.d | (h.d >> 1) | (h.d >> 2)) & O7_1;
+    const int kinds = __popc(pres_d) + ((h.a & 7u) != 0u) + ((h.a >> 24) != 0u) + ((h.b & 7u) != 0u) + ((h.b >> 24) != 0u) +
+                      ((h.c & 7u) != 0u) + ((h.c >> 24) != 0u);
+    if (__ballot(pairs >= 6 || kinds >= 12)) {
+        if (pairs >= 6) {
+            // is_chiitoi(h + t): every field of h is 0 or 2 except field t, which is 1, and there are six pairs
+            const uint32_t odd_a = h.a & O9_1, odd_b = h.b & O9_1, odd_c = h.c & O9_1, odd_d = h.d & O7_1;
+            const uint32_t four = (h.a & O9_4) | (h.b & O9_4) | (h.c & O9_4) | (h.d & O7_4);
+            const int n_odd = __popc(odd_a) + __popc(odd_b) + __popc(odd_c) + __popc(odd_d);
+            const int n_two = __popc(h.a & O9_2) + __popc(h.b & O9_2) + __popc(h.c & O9_2) + __popc(h.d & O7_2);   // fields with bit 1: 2 or 3
+            if (four == 0u && n_odd == 1 && n_two == 6) {
+                const int t = odd_a ? (__ffs((int)odd_a) - 1) / 3 : (odd_b ? 9 + (__ffs((int)odd_b) - 1) / 3 : (odd_c ? 18 + (__ffs((int)odd_c) - 1) / 3 : 27 + (__ffs((int)odd_d) - 1) / 3));
+                if (ph_cnt(h, t) == 1) W |= 1ull << t;
+            }
+        }
+        if (kinds >= 12) {
+            // lane = terminal kind (13 of them): 1m 9m 1p 9p 1s 9s E S W N P F C
+            const int t = r < 6 ? (r >> 1) * 9 + (r & 1) * 8 : 27 + (r - 6);
+            bool kw = false;
+            if (r < 13 && ph_cnt(h, t) < 4) {
+                PH x = h;
+                ph_add(x, t);
+                kw = is_kokushi(x);
+            }
+            const uint32_t kb = rballot(kw, rb);
+            // scatter the 13 lane bits to their types
+            uint64_t kmask = 0ull;
+#pragma unroll
+            for (int i = 0; i < 13; i++) {
+                const int ti = i < 6 ? (i >> 1) * 9 + (i & 1) * 8 : 27 + (i - 6);
+                kmask |= (uint64_t)((kb >> i) & 1u) << ti;
+            }
+            W |= kmask;
+        }
+    }
+    return W;
+}
+
 // fill_waits13 of tier 0 for the sorted 13-tile hand P->hand[0 .. n): the isolated-tile bound, else the table shanten (the
 // only user of a histogram); a hand with a possible wait (shanten <= 0) needs the probe -> the row bails.  Writes the cache
 // like fill_waits13 (waits13 = 0 for every shanten >= 1).
 __device__ __forceinline__ void r4_fill_waits13(R4& q, PState* P, int n) {
+    uint64_t W = 0ull;
     const R4Shape sp = r4_shape_sorted(q, P, n, -1);
     const int iso = sp.iso, yaochu = sp.yaochu;
     int lb = iso >= 6 ? 4 : (iso == 5 ? 3 : (iso == 4 ? 2 : 0));
@@ -251,11 +359,14 @@ __device__ __forceinline__ void r4_fill_waits13(R4& q, PState* P, int n) {
                 h13.a = (uint32_t)rbc((int)a, l15); h13.b = (uint32_t)rbc((int)b, l15); h13.c = (uint32_t)rbc((int)c, l15); h13.d = (uint32_t)rbc((int)d, l15);
             }
             sh = r4_shanten(q, h13, len3);
-            if (sh <= 0) { R4BAIL(q, 2); return; }
+            if (sh <= 0) {
+                W = r4_waits_probe(h13.a, h13.b, h13.c, h13.d);
+                sh = 0;
+            }
         }
     }
     if (q.r == 0) {
-        P->waits13 = 0ull;
+        P->waits13 = W;
         P->sh13 = (uint8_t)sh;
         P->flags |= PF_WAITS_VALID;
     }
@@ -265,6 +376,7 @@ __device__ __forceinline__ void r4_fill_waits13(R4& q, PState* P, int n) {
 // The same from a histogram, for a hand whose 13 tiles are not one sorted run (right after a Kita the previous drawn tile
 // sits behind the twelve sorted ones).
 __device__ __forceinline__ void r4_fill_waits13_h(R4& q, PState* P, const PH& h13) {
+    uint64_t W = 0ull;
     const uint32_t T9 = 1u | (1u << 24);
     const int yaochu = __popc((h13.a | (h13.a >> 1) | (h13.a >> 2)) & T9) + __popc((h13.b | (h13.b >> 1) | (h13.b >> 2)) & T9) +
                        __popc((h13.c | (h13.c >> 1) | (h13.c >> 2)) & T9) + __popc((h13.d | (h13.d >> 1) | (h13.d >> 2)) & O7_1);
@@ -285,11 +397,14 @@ __device__ __forceinline__ void r4_fill_waits13_h(R4& q, PState* P, const PH& h1
             sh = 1;
         } else {
             sh = r4_shanten(q, h13, len3);
-            if (sh <= 0) { R4BAIL(q, 3); return; }
+            if (sh <= 0) {
+                W = r4_waits_probe(h13.a, h13.b, h13.c, h13.d);
+                sh = 0;
+            }
         }
     }
     if (q.r == 0) {
-        P->waits13 = 0ull;
+        P->waits13 = W;
         P->sh13 = (uint8_t)sh;
         P->flags |= PF_WAITS_VALID;
     }
@@ -378,7 +493,8 @@ __device__ __forceinline__ void r4_put(R4& q, int seat, int pos, uint64_t a, int
 
 // _resolve_discard (state/mod.rs:1317-1413) incl. claim generation (legal_actions.rs:254-508) for the row's game.
 // nl[] = list length of seat r (lanes r < 4) after the call; returns through G->phase / active_mask like the reference.
-__device__ __forceinline__ void r4_resolve_discard(R4& q, int pid, int tile, bool tsumogiri, int pf, int& nl_mine, uint64_t& w_mine) {
+// known_sh: the exact shanten of the 13 tiles the discard leaves when the policy has just computed it (99: unknown)
+__device__ __forceinline__ void r4_resolve_discard(R4& q, int pid, int tile, bool tsumogiri, int pf, int& nl_mine, uint64_t& w_mine, int known_sh = 99) {
     GState* G = q.G;
     PState* P = &G->p[pid];
     const int r = q.r, rb = q.rb;
@@ -405,10 +521,16 @@ __device__ __forceinline__ void r4_resolve_discard(R4& q, int pid, int tile, boo
             G->last_discard_pid = (uint8_t)pid;
             G->last_discard_tile = (uint8_t)tile;
             G->drawn_tile = 0xFF;
-            if (!tsumogiri) {
-                P->last_tedashi = (uint8_t)tile;
+            if (!tsumogiri) P->last_tedashi = (uint8_t)tile;
+            if (known_sh != 99 && known_sh >= 1) {
+                // a hand with a wait has shanten 0: the cache of the remaining 13 tiles is "no waits, shanten known_sh" - no refill,
+                // no table lookup when the next discard arrives, and an exact number for the riichi bound after the next draw
+                P->waits13 = 0ull;
+                P->sh13 = (uint8_t)known_sh;
+                fl |= PF_WAITS_VALID;
+            } else if (!tsumogiri) {
                 const int lb = P->sh13;
-                if ((fl & PF_WAITS_VALID) && lb >= 3) P->sh13 = (uint8_t)(lb - 1);
+                if ((fl & PF_WAITS_VALID) && lb >= 3 && known_sh == 99) P->sh13 = (uint8_t)(lb - 1);
                 else fl &= ~(uint32_t)PF_WAITS_VALID;
             }
             G->needs_tsumo = 1;
@@ -579,6 +701,7 @@ __device__ __forceinline__ void r4_resolve_discard(R4& q, int pid, int tile, boo
     }
 }
 
+__device__ __forceinline__ uint32_t r4_tenpai_keep(const R4& q, const PState* P, const PH& full, int hl);
 // _get_legal_actions_internal, WaitAct branch (legal_actions.rs:11-252), for the row's current player.  Everything that
 // needs a yaku evaluation or a wait probe (a complete hand, a possible Riichi, a kan in riichi) makes the row bail.
 __device__ __forceinline__ void r4_gen_act_legal(R4& q, int& nl_mine) {
@@ -592,12 +715,12 @@ __device__ __forceinline__ void r4_gen_act_legal(R4& q, int& nl_mine) {
     const int drawn_tile = G->drawn_tile;
     const bool drawn = drawn_tile != 0xFF;
     const int drawable = G->drawable_count;
-    if (hl + 3 * nmelds == 13 || r_stage) { R4BAIL(q, 11); return; }
+    if (hl + 3 * nmelds == 13) { R4BAIL(q, 11); return; }
     const int ht = r < hl ? (int)P->hand[r] : 0xFF;
     const int hty = ht >> 2;
     int n = 0;
     // 1. Tsumo: is the drawn type a wait of the 13 other tiles?  (cache, else the cheap refill; a complete hand bails)
-    if (drawn) {
+    if (drawn && !r_stage) {
         const uint32_t b = rballot(r < hl && ht == drawn_tile, rb);
         const int idx = b ? 31 - __clz((int)b) : -1;
         const int same_type = __popc(rballot(r < hl && hty == (drawn_tile >> 2), rb));
@@ -623,7 +746,8 @@ __device__ __forceinline__ void r4_gen_act_legal(R4& q, int& nl_mine) {
         }
     } else {
         const bool all_closed = rballot(r < nmelds && P->meld_type[r & 3] != RMJ_MELD_ANKAN, rb) == 0u;
-        const bool riichi_pre = P->score >= 1000 && (KSANMA ? drawable > 0 : drawable >= 4) && all_closed;
+        const bool riichi_pre = !r_stage && P->score >= 1000 && (KSANMA ? drawable > 0 : drawable >= 4) && all_closed;
+        bool need_tp = r_stage;   // riichi stage: only the discards that keep the hand tenpai (legal_actions.rs:77-100)
         if (riichi_pre) {
             const int sh13 = (drawn && (P->flags & PF_WAITS_VALID)) ? (int)P->sh13 : -1;
             if (sh13 < 2) {
@@ -634,19 +758,34 @@ __device__ __forceinline__ void r4_gen_act_legal(R4& q, int& nl_mine) {
                 const int yk = __popc((full.a | (full.a >> 1) | (full.a >> 2)) & T9) + __popc((full.b | (full.b >> 1) | (full.b >> 2)) & T9) +
                                __popc((full.c | (full.c >> 1) | (full.c >> 2)) & T9) + __popc((full.d | (full.d >> 1) | (full.d >> 2)) & O7_1);
                 if (!(r4_isolated(full) >= 3 && yk < 12)) {
-                    if (r4_shanten(q, full, hl / 3) <= 0) { R4BAIL(q, 14); return; }
+                    if (r4_shanten(q, full, hl / 3) <= 0) need_tp = true;
                 }
             }
         }
-        const bool ok = r < hl && !forb;
+        uint32_t tp = 0u;   // bit j: the hand without hand[j] has a wait
+        if (r_stage && G->tp_seat == pid && G->tp_step == G->step_count) {   // computed for the Riichi entry one step ago (GState::tp_mask)
+            tp = G->tp_mask;
+            need_tp = false;
+        }
+        if (__ballot(need_tp)) {
+            if (need_tp) {
+                tp = r4_tenpai_keep(q, P, full, hl);
+                if (r == 0 && !r_stage) { G->tp_seat = (uint8_t)pid; G->tp_mask = (uint16_t)tp; G->tp_step = G->step_count + 1u; }
+            }
+        }
+        const bool ok = r < hl && !forb && (!r_stage || ((tp >> r) & 1u));
         const uint32_t vb = rballot(ok, rb);
         if (ok) r4_put(q, pid, n + __popc(vb & ((1u << r) - 1u)), mk_action(RMJ_DISCARD, ht, 0), r4_tile_id(hty));
         n += __popc(vb);
+        if (riichi_pre && tp != 0u) {   // legal_actions.rs:113-140
+            if (r == 0) r4_put(q, pid, n, mk_action(RMJ_RIICHI, RMJ_TILE_NONE, 0), KSANMA ? 27 : 37);
+            n += 1;
+        }
     }
     R4M(61);
     // 3. Kan
     if (drawable > 0 && drawn) {
-        if (!r_decl) {
+        if (!r_decl && !r_stage) {
             const bool any4 = (((full.a | full.b | full.c) & O9_4) | (full.d & O7_4)) != 0u;
             if (any4) {
                 // Ankan of every type held four times, in type order (legal_actions.rs:150-166).  With the hand a sorted run plus
@@ -678,12 +817,12 @@ __device__ __forceinline__ void r4_gen_act_legal(R4& q, int& nl_mine) {
                     n += __popc(kb);
                 }
             }
-        } else {
+        } else if (r_decl) {
             if (ph_cnt(full, drawn_tile >> 2) == 4) { R4BAIL(q, 16); return; }   // ankan after riichi: wait probes
         }
     }
     // 4. Kyushu kyuhai: first turn, no calls, nine kinds of terminals and honors (the type set is OR-ed over the row)
-    if (G->is_first_turn && (G->p[0].n_melds | G->p[1].n_melds | G->p[2].n_melds | G->p[3].n_melds) == 0) {
+    if (G->is_first_turn && !r_stage && (G->p[0].n_melds | G->p[1].n_melds | G->p[2].n_melds | G->p[3].n_melds) == 0) {
         const bool term = r < hl && is_terminal_tile136(ht);
         const uint32_t lo = row_or16(term && hty < 32 ? 1u << hty : 0u), hi = row_or16(term && hty >= 32 ? 1u << (hty - 32) : 0u);
         const int kinds = __popc((uint32_t)rbc((int)lo, rb + 15)) + __popc((uint32_t)rbc((int)hi, rb + 15));
@@ -704,8 +843,230 @@ __device__ __forceinline__ void r4_gen_act_legal(R4& q, int& nl_mine) {
     wave_sync();
 }
 
-// One step of four consecutive games per wave (device policy only: rmj_step_random / rmj_bench_rollout); `load`: fetch the records from HBM first (the rollout loop keeps them in LDS)
+// ---------------------------------------------------------------------------------------------------------------------------
+// The device policy that PLAYS (rmj_step_greedy; the oracle's twin is orc_game_greedy_actions): for every seat that is to act,
+// over its ordered legal list, the first entry of the best class -
+//   Tsumo / Ron  >  Kita  >  Riichi  >  Ankan  >  Kakan  >  Daiminkan  >  [Pon > Chi when ((key >> 40) & 255) < call_rate]  >
+//   Discard  >  Pass  >  Kyushu kyuhai
+// (Kita before Riichi: the 3P reference offers Kita in the riichi stage and can leave a seat that takes it without any legal
+// action - quirk Q15 -; a seat that has set its Norths aside before it declares cannot get there)
+// - and among the Discard entries the one that leaves the hand with the lowest shanten (shanten.rs:228-241 / :454-468 of the hand
+// without the tile), ties broken by key mod #ties in list order; key = splitmix64(splitmix64(seed + global game) + 4 * step + seat)
+// like the RandomAgent's.  What scripts/soak_greedy.py plays on the CPU, now resident: games reach tenpai, declare riichi and end
+// with wins, so the rare transitions of the step (yaku checks, settlements, wait probes) are no longer rare.
+// Lane = list entry while a seat's list is scanned (16 entries per pass), lane = discard candidate for the shanten of "hand minus
+// my tile": the three suits a discard leaves alone are looked up once per row (lanes 0..3), their pair merges are computed entry
+// per lane (lanes 0..9), and every candidate looks up its own suit and finishes with one triple (min,+) for the entry (pair, m).
+__device__ __forceinline__ uint32_t r4_prio(uint32_t ty, bool call) {
+    const uint32_t lo = call ? 0x90205678u : 0x90205CC8u, hi = 0xFFFF1A43u;   // nibble per action type, see the order above
+    return __builtin_amdgcn_ubfe(ty < 8u ? lo : hi, (ty & 7u) * 4u, 4u);
+}
+// entry (pair = 1, mentsu = m) of merge(merge(nv, other), side) as ONE triple (min,+) over packed cost vectors (idx = p * 5 + k,
+// 4 bits, 15 = infeasible): the same number as sh_merge + sh_merge_entry (every partial sum that reaches 15 stays >= 15)
+__device__ __forceinline__ uint32_t sh_triple_1m(uint64_t nv, uint64_t other, uint64_t side, int m) {
+    const uint32_t n0 = (uint32_t)nv & 0xFFFFFu, n1 = (uint32_t)(nv >> 20) & 0xFFFFFu;
+    const uint32_t o0 = (uint32_t)other & 0xFFFFFu, o1 = (uint32_t)(other >> 20) & 0xFFFFFu;
+    const uint32_t s0 = ((uint32_t)side & 0xFFFFFu) | 0xFFF00000u, s1 = ((uint32_t)(side >> 20) & 0xFFFFFu) | 0xFFF00000u;
+    uint32_t S0[5], S1[5], N0[5], N1[5], O0[5], O1[5];
+#pragma unroll
+    for (int j = 0; j < 5; j++) {   // side entry (p, m - j); 15 when j > m
+        const uint32_t off = m >= j ? 4u * (uint32_t)(m - j) : 20u;
+        S0[j] = (s0 >> off) & 15u; S1[j] = (s1 >> off) & 15u;
+        N0[j] = __builtin_amdgcn_ubfe(n0, 4u * j, 4u); N1[j] = __builtin_amdgcn_ubfe(n1, 4u * j, 4u);
+        O0[j] = __builtin_amdgcn_ubfe(o0, 4u * j, 4u); O1[j] = __builtin_amdgcn_ubfe(o1, 4u * j, 4u);
+    }
+    uint32_t best = 15u;
+#pragma unroll
+    for (int k1 = 0; k1 < 5; k1++)
+#pragma unroll
+        for (int k2 = 0; k1 + k2 < 5; k2++) {
+            const int j = k1 + k2;
+            best = min(best, N0[k1] + O0[k2] + S1[j]);
+            best = min(best, N1[k1] + O0[k2] + S0[j]);
+            best = min(best, N0[k1] + O1[k2] + S0[j]);
+        }
+    return best;
+}
+__device__ __forceinline__ uint32_t row_min16u(uint32_t v) {  // minimum over a 16-lane row of values up to 2^31 - 1, in lane 15 of the row
+    v = min(v, (uint32_t)__builtin_amdgcn_update_dpp(0x7FFFFFFF, (int)v, 0x111, 0xf, 0xf, false));
+    v = min(v, (uint32_t)__builtin_amdgcn_update_dpp(0x7FFFFFFF, (int)v, 0x112, 0xf, 0xf, false));
+    v = min(v, (uint32_t)__builtin_amdgcn_update_dpp(0x7FFFFFFF, (int)v, 0x114, 0xf, 0xf, false));
+    v = min(v, (uint32_t)__builtin_amdgcn_update_dpp(0x7FFFFFFF, (int)v, 0x118, 0xf, 0xf, false));
+    return v;
+}
+// sh_vec for the words of real hands (at most 14 tiles, at most four of a kind): the digit clamps of sh_rank are not needed, five
+// instructions per rank instead of nine; the final min keeps the table load in bounds whatever a poked state holds.
+__device__ __forceinline__ uint64_t sh_vec_fast(uint32_t word, int q, const ShantenTables& T) {
+    const uint32_t* R = q < 3 ? T.rank9 : T.rank7;
+    uint32_t h = 0u, sum = 0u;
+#pragma unroll
+    for (int i = 0; i < 9; i++) {
+        if (i < 7 || q < 3) {
+            const uint32_t c = __builtin_amdgcn_ubfe(word, 3u * i, 3u);
+            h += R[(i * 15 + (sum > 14u ? 14u : sum)) * 5 + (c > 4u ? 4u : c)];
+            sum += c;
+        }
+    }
+    return q < 3 ? T.suit[h < SH_SUIT_ENTRIES ? h : SH_SUIT_ENTRIES - 1] : T.honor[h < SH_HONOR_ENTRIES ? h : SH_HONOR_ENTRIES - 1];
+}
+// entry (p, k) of the (min,+) merge of two packed cost vectors for a lane-local (p, k), like sh_merge_entry, with the second
+// vector pre-rotated so that every partner entry sits at a compile-time nibble (entries that do not exist read 15): 4 instead of
+// ~10 instructions per combination
+__device__ __forceinline__ uint32_t sh_merge_entry_rot(uint64_t x, uint64_t y, int p, int k) {
+    const uint32_t x0 = (uint32_t)x & 0xFFFFFu, x1 = (uint32_t)(x >> 20) & 0xFFFFFu;
+    const uint32_t y0 = (uint32_t)y & 0xFFFFFu, y1 = (uint32_t)(y >> 20) & 0xFFFFFu;
+    const uint32_t sft = 4u * (uint32_t)(4 - k), fill = (1u << sft) - 1u;
+    const uint32_t ya = ((p ? y1 : y0) << sft) | fill;          // partner of x[0][k1]: y[p][k - k1] at nibble 4 - k1
+    const uint32_t yb = p ? ((y0 << sft) | fill) : 0xFFFFFFFFu;  // partner of x[1][k1]: y[p - 1][k - k1]
+    uint32_t best = 15u;
+#pragma unroll
+    for (int k1 = 0; k1 < 5; k1++) {
+        best = min(best, __builtin_amdgcn_ubfe(x0, 4u * k1, 4u) + __builtin_amdgcn_ubfe(ya, 4u * (4 - k1), 4u));
+        best = min(best, __builtin_amdgcn_ubfe(x1, 4u * k1, 4u) + __builtin_amdgcn_ubfe(yb, 4u * (4 - k1), 4u));
+    }
+    return best;
+}
+// Shanten (shanten.rs:228-241 / :454-468) of the row's hand h (hl tiles, row-uniform) WITHOUT one tile of type t34, per lane
+// (`cand` lanes; 99 elsewhere): the three suits a discard leaves alone are looked up once per row (lanes 0..3), their pair merges
+// are computed entry per lane (lanes 0..9), and every candidate looks up its own suit and finishes with one triple (min,+) for
+// the entry (pair, m).  3P: the hands are compared after the relocation of 1m / 9m into empty honor slots; a candidate whose
+// relocated hand differs from the row's in more than one word (only when all nine slots are taken) takes the plain per-lane lookup.
+__device__ __forceinline__ int r4_shanten_minus(const R4& q, const ShantenTables& T, const PH& h, int hl, bool cand, int t34) {
+    const int r = q.r, rb = q.rb;
+    const int len3 = (hl - 1) / 3, m = len3 > 4 ? 4 : len3;
+    const PH B = KSANMA ? sh_relocate_3p(h) : h;
+    // the row's base: suit vectors by lanes 0..3, pair merges ab / cd entry per lane (0..9)
+    const uint64_t vq = r < 4 ? sh_vec_fast(ph_get(B, r & 3), r & 3, T) : 0ull;
+    const uint64_t v0 = rbc64(vq, rb), v1 = rbc64(vq, rb + 1), v2 = rbc64(vq, rb + 2), v3 = rbc64(vq, rb + 3);
+    uint64_t ab, cd;
+    {
+        const int pp = r >= 5 ? 1 : 0, kk = r - 5 * pp;
+        uint32_t ea = 0u, ec = 0u;
+        if (r < 10) {
+            ea = sh_merge_entry_rot(v0, v1, pp, kk);
+            ec = sh_merge_entry_rot(v2, v3, pp, kk);
+        }
+        const uint32_t sh_lo = (uint32_t)(r & 7) * 4u;
+        const uint32_t a_lo = row_or16(r < 8 ? ea << sh_lo : 0u), a_hi = row_or16((r >= 8 && r < 10) ? ea << sh_lo : 0u);
+        const uint32_t c_lo = row_or16(r < 8 ? ec << sh_lo : 0u), c_hi = row_or16((r >= 8 && r < 10) ? ec << sh_lo : 0u);
+        ab = (uint64_t)(uint32_t)rbc((int)a_lo, rb + 15) | ((uint64_t)(uint32_t)rbc((int)a_hi, rb + 15) << 32);
+        cd = (uint64_t)(uint32_t)rbc((int)c_lo, rb + 15) | ((uint64_t)(uint32_t)rbc((int)c_hi, rb + 15) << 32);
+    }
+    int sres = 99;
+    bool slow = false;
+    PH x = h;
+    if (cand) {
+        ph_sub(x, t34);
+        const PH X = KSANMA ? sh_relocate_3p(x) : x;
+        int qd = t_suit(t34);
+        if (KSANMA) {   // the relocation may move the change into the honor word (1m / 9m) or touch two words (all slots taken)
+            const int nd4 = (X.a != B.a) + (X.b != B.b) + (X.c != B.c) + (X.d != B.d);
+            qd = X.b != B.b ? 1 : (X.c != B.c ? 2 : (X.d != B.d ? 3 : 0));
+            slow = nd4 != 1;
+        }
+        if (!slow) {
+            const uint64_t nv = sh_vec_fast(ph_get(X, qd), qd, T);
+            const uint64_t other = qd == 0 ? v1 : (qd == 1 ? v0 : (qd == 2 ? v3 : v2));
+            sres = (int)sh_triple_1m(nv, other, qd < 2 ? cd : ab, m) - 1;
+        }
+    }
+    if (KSANMA && __ballot(slow)) {
+        if (slow) sres = sh_normal(sh_relocate_3p(x), len3, T);
+    }
+    if (cand && sres > 0 && len3 >= 4) {
+        const int c7 = sh_chiitoi(x, KSANMA);
+        sres = c7 < sres ? c7 : sres;
+        if (sres > 0) {
+            const int k13 = sh_kokushi(x);
+            sres = k13 < sres ? k13 : sres;
+        }
+    }
+    return sres;
+}
+// tenpai_after_discard (legal_actions.rs:113-140 / :77-100) for every slot of the row's acting seat (hl = 14 - 3 melds tiles,
+// histogram `full`): bit j = "the hand without hand[j] has a wait".  The table shanten of the 13 remaining tiles sieves the
+// slots (a hand with a wait has shanten 0); the survivors - one to three types - get the exact wait probe, once per type.
+__device__ __forceinline__ uint32_t r4_tenpai_keep(const R4& q, const PState* P, const PH& full, int hl) {
+    const int r = q.r, rb = q.rb;
+    const ShantenTables T = sh_tables_of(*q.E);
+    const int ty = r < hl ? (int)(P->hand[r] >> 2) : 0;
+    const int sm = r4_shanten_minus(q, T, full, hl, r < hl, ty);
+    uint32_t todo = rballot(r < hl && sm <= 0, rb);
+    uint32_t out = 0u;
+    while (__ballot(todo != 0u)) {
+        if (todo) {
+            const int j = __ffs((int)todo) - 1;
+            const int tj = rbc(ty, rb + j);
+            const uint32_t same = rballot(r < hl && ty == tj, rb);
+            todo &= ~same;
+            PH h13 = full;
+            ph_sub(h13, tj);
+            if (r4_waits_probe(h13.a, h13.b, h13.c, h13.d) != 0ull) out |= same;
+        }
+    }
+    return out;
+}
 template <bool LOOP>
+__device__ __forceinline__ uint64_t r4_list_entry(const uint64_t* src) {
+    return LOOP ? __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : *src;
+}
+// returns (lane = seat) the seat's action; rows that are not `on` get nothing
+template <bool LOOP>
+__device__ __forceinline__ uint64_t r4_policy_greedy(R4& q, bool on, const uint64_t* Lg, uint64_t gs, uint32_t call_rate, int& pol_seat, int& pol_sh) {
+    GState* G = q.G;
+    const int r = q.r, rb = q.rb;
+    const ShantenTables T = sh_tables_of(*q.E);
+    uint64_t mine = RMJ_NO_ACTION;
+    pol_seat = -1;
+    pol_sh = 99;
+    uint32_t todo = on ? ((uint32_t)G->active_mask & 0xFu) : 0u;
+    while (__ballot(todo != 0u)) {
+        if (todo) {
+            const int p = __ffs((int)todo) - 1;
+            todo &= todo - 1u;
+            const int n = G->nlegal[p];
+            const uint64_t key = sm64(gs + (uint64_t)G->step_count * 4ull + (uint64_t)p);
+            const bool call = (uint32_t)((key >> 40) & 0xFFull) < call_rate;
+            // ---- scan: best (class, index) over the list, 16 entries per pass
+            uint32_t best = 0xFFFFu;
+            uint64_t e0 = 0ull;      // lane's entry of the first pass (the Discard entries of a list sit in its first 15 slots)
+            uint32_t disc = 0u;      // Discard entries of the first pass
+            for (int base = 0; base < n; base += 16) {
+                const bool in = base + r < n;
+                const uint64_t e = in ? r4_list_entry<LOOP>(Lg + p * RMJ_MAX_LEGAL + base + r) : 0ull;
+                const uint32_t ty = (uint32_t)e & 0xFFu;
+                uint32_t sc = in ? r4_prio(ty > 15u ? 15u : ty, call) * 64u + (uint32_t)(base + r) : 0xFFFFu;
+                sc = row_min16u(sc);
+                sc = (uint32_t)rbc((int)sc, rb + 15);
+                best = sc < best ? sc : best;
+                if (base == 0) { e0 = e; disc = rballot(in && ty == RMJ_DISCARD, rb); }
+            }
+            int ci = (int)(best & 63u);
+            const int nd = __popc(disc);
+            if (n > 0 && (best >> 6) == 8u && nd >= 2) {
+                // ---- shanten of the hand without each candidate
+                const PState* P = &G->p[p];
+                const int hl = P->hand_len;
+                const PH h = r4_hist(q, P, -1);
+                const bool cand = (disc >> r) & 1u;
+                const int sres = r4_shanten_minus(q, T, h, hl, cand, (int)((e0 >> 8) & 0xFFull) >> 2);
+                const uint32_t key_s = (uint32_t)(sres + 2);                      // (-1 .. 14) -> 1 .. 16, non-candidates 101
+                const uint32_t smin = (uint32_t)rbc((int)row_min16u(cand ? key_s : 200u), rb + 15);
+                const uint32_t tie = rballot(cand && key_s == smin, rb);
+                const uint32_t kth = mod_small_magic(key, (uint32_t)__popc(tie));
+                const uint32_t pick = rballot(((tie >> r) & 1u) && (uint32_t)__popc(tie & ((1u << r) - 1u)) == kth, rb);
+                ci = __ffs((int)pick) - 1;
+                pol_seat = p;                 // the shanten of the 13 tiles this discard leaves: the wait cache takes it (r4_resolve_discard)
+                pol_sh = (int)smin - 2;
+            }
+            if (n > 0 && r == p) mine = r4_list_entry<LOOP>(Lg + p * RMJ_MAX_LEGAL + ci);
+        }
+    }
+    return mine;
+}
+
+// One step of four consecutive games per wave (device policy only: rmj_step_random / rmj_bench_rollout); `load`: fetch the records from HBM first (the rollout loop keeps them in LDS)
+template <bool LOOP, int POL>
 __device__ __forceinline__ void step4_body(const Env* Ep, Quad4Shared& sh, uint64_t policy_seed, uint32_t flags, uint32_t g_base, uint32_t g_end,
                                            bool load, uint64_t gs_row, const uint64_t* __restrict__ actions = nullptr, uint32_t quad = 0xFFFFFFFFu) {
     CEnv& E = *(CEnv*)Ep;
@@ -749,12 +1110,15 @@ __device__ __forceinline__ void step4_body(const Env* Ep, Quad4Shared& sh, uint6
             pf = Wg[wi];
         }
     }
-    // ---- policy (lane = seat): RandomAgent keyed per (game, step, seat), see k_step
+    // ---- policy (lane = seat): RandomAgent keyed per (game, step, seat), see k_step; POL = 1: the greedy policy (r4_policy_greedy)
     uint64_t mine = RMJ_NO_ACTION;
-    if (q.live) {
-        if (G->is_done) {
-            R4BAIL(q, 18);   // finished game: restart (auto-reset) or nothing to do - both handled by the full path
-        } else if (flags & STEP_F_RANDOM) {
+    if (q.live && G->is_done) R4BAIL(q, 18);   // finished game: restart (auto-reset) or nothing to do - both handled by the full path
+    int pol_seat = -1, pol_sh = 99;   // greedy policy: shanten of the hand the chosen discard of seat pol_seat leaves
+    if (POL == 1) {
+        const uint64_t gs = LOOP ? gs_row : sm64(policy_seed + E.game_offset + (uint64_t)g);
+        mine = r4_policy_greedy<LOOP>(q, q.live && !q.bail, Lg, gs, (flags >> 8) & 0xFFu, pol_seat, pol_sh);
+    } else if (q.live && !q.bail) {
+        if (flags & STEP_F_RANDOM) {
             if (r < 4) {
                 const uint32_t n = G->nlegal[r];
                 if (((G->active_mask >> r) & 1u) && n != 0u) {
@@ -828,7 +1192,15 @@ __device__ __forceinline__ void step4_body(const Env* Ep, Quad4Shared& sh, uint6
             const uint32_t act = (uint32_t)rbc((int)(uint32_t)mine, rb + pid);   // type and tile live in the low dword
             const uint32_t ty = act & 0xFFu;
             PState* P = &G->p[pid];
-            if (act == 0xFFFFFFFFu || ((act >> 8) & 0xFFu) == RMJ_TILE_NONE) {
+            if (ty == RMJ_RIICHI && ((act >> 8) & 0xFFu) == RMJ_TILE_NONE && P->score >= 1000 &&
+                (KSANMA ? G->drawable_count > 0 : G->drawable_count >= 4) && !(P->flags & (PF_RIICHI_DECLARED | PF_RIICHI_STAGE))) {
+                // ---- Riichi declared (state/mod.rs:440-457): the seat enters the riichi stage and stays to act; its next list
+                // (below) holds the discards that keep the hand tenpai
+                q.dirty = 1u << pid;
+                if (r == 0) P->flags |= PF_RIICHI_STAGE;
+                wave_sync();
+                r4_emit_simple(q, RMJ_EV_REACH, (uint32_t)pid, 0);
+            } else if (act == 0xFFFFFFFFu || ((act >> 8) & 0xFFu) == RMJ_TILE_NONE) {
                 R4BAIL(q, 19);
             } else if (ty == RMJ_DISCARD) {
                 q.dirty = 1u << pid;
@@ -870,7 +1242,7 @@ __device__ __forceinline__ void step4_body(const Env* Ep, Quad4Shared& sh, uint6
                     if (r == 0) P->hand_len = (uint8_t)(hl - 1);
                     wave_sync();
                     R4M(42);
-                    r4_resolve_discard(q, pid, tile, tsumogiri, pf, nl_mine, w_mine);
+                    r4_resolve_discard(q, pid, tile, tsumogiri, pf, nl_mine, w_mine, (POL == 1 && pol_seat == pid) ? pol_sh : 99);
                     R4M(56);
                 }
             } else if (KSANMA && ty == RMJ_KITA) {
@@ -1176,11 +1548,11 @@ __device__ __forceinline__ void step4_body(const Env* Ep, Quad4Shared& sh, uint6
 }
 // The step as an out-of-line function with its own static LDS: the rollout loop calls it once per step, so nothing of a
 // step is hoisted out of the loop or kept live across it (the loop inlined: 48 VGPR + 37 SGPR spills).
-template <bool LOOP>
+template <bool LOOP, int POL>
 __device__ __noinline__ void step4_call(const Env* Ep, uint64_t policy_seed, uint32_t flags, uint32_t g_base, uint32_t g_end, uint32_t load,
                                         uint64_t gs_row, uint32_t quad = 0xFFFFFFFFu) {
     __shared__ Quad4Shared sh;
-    step4_body<LOOP>(uni_ptr(Ep), sh, uni(policy_seed), uni(flags), uni(g_base), uni(g_end), uni(load) != 0u, gs_row, nullptr, uni(quad));
+    step4_body<LOOP, POL>(uni_ptr(Ep), sh, uni(policy_seed), uni(flags), uni(g_base), uni(g_end), uni(load) != 0u, gs_row, nullptr, uni(quad));
 }
 #ifndef RMJ_STEP4_WAVES
 #define RMJ_STEP4_WAVES 6
@@ -1189,21 +1561,22 @@ __device__ __noinline__ void step4_call(const Env* Ep, uint64_t policy_seed, uin
 // synchronisation between the steps of DIFFERENT games: the wave keeps its four records in LDS and steps its own games
 // n_steps times (publishing every step's outputs exactly like n_steps launches would).  A launch per step ends with the
 // slowest wave (the one that restarts a round), and at 65 536 games (16 384 waves = two generations of resident waves)
-// that tail costs as much as the work; the loop pays it once per rollout.
-template <bool LOOP>
+// that tail costs as much as the work; the loop pays it once per rollout.  POL: 0 = RandomAgent / the caller's actions, 1 = the
+// greedy policy (r4_policy_greedy).
+template <bool LOOP, int POL>
 __global__ __launch_bounds__(64, RMJ_STEP4_WAVES) void k_step4(const Env* __restrict__ Ep, uint64_t policy_seed, uint32_t flags, uint32_t g_base,
                                                                    uint32_t g_end, uint32_t n_steps, const uint64_t* __restrict__ actions) {
     if (LOOP) {
         const uint32_t g = g_base + blockIdx.x * 4u + ((threadIdx.x & 63u) >> 4);
         const uint64_t gs_row = sm64(policy_seed + ((CEnv*)Ep)->game_offset + (uint64_t)g);   // policy key of the row's game
 #pragma unroll 1
-        for (uint32_t it = 0; it < n_steps; it++) step4_call<true>(Ep, policy_seed, flags, g_base, g_end, it == 0 ? 1u : 0u, gs_row);
+        for (uint32_t it = 0; it < n_steps; it++) step4_call<true, POL>(Ep, policy_seed, flags, g_base, g_end, it == 0 ? 1u : 0u, gs_row);
     } else {
         __shared__ Quad4Shared sh;
 #ifdef RMJ_TL4
         const unsigned long long rt0 = __builtin_amdgcn_s_memrealtime();
 #endif
-        step4_body<false>(Ep, sh, policy_seed, flags, g_base, g_end, true, 0ull, actions);
+        step4_body<false, POL>(Ep, sh, policy_seed, flags, g_base, g_end, true, 0ull, actions);
 #ifdef RMJ_TL4
         const unsigned long long rt1 = __builtin_amdgcn_s_memrealtime();
         if ((threadIdx.x & 63) == 0) {
@@ -1223,6 +1596,8 @@ __global__ __launch_bounds__(64, RMJ_STEP4_WAVES) void k_step4(const Env* __rest
 // wave's record / lists / wall reach the next - stores are write-through to it, the hand-over is "drain stores, publish the chunk
 // count with an agent-scope atomic", the pick-up "poll it, invalidate this CU's L1 (acquire), load".  No cross-XCD traffic, no
 // L2 write-back.  Results are those of k_step4<true>: every game steps n_steps times with the same policy keys.
+// The queue keys (HW_REG_XCC_ID & 7, quad % 8) assume at most eight XCC ids: rmj_create probes the ids the device reports and the
+// host uses this kernel only when none exceeds 7 (rollout_queued), otherwise every wave keeps its quad (k_step4<true>).
 #define RMJ_Q_STRIDE 32u   /* u32 words per XCD queue head (its own 128-byte line) */
 // (out of line: inlined into the ticket loop, the one-lane branches below were restructured into a loop nest that re-used a stale
 // ticket - the kernel then ran quads twice at once)
@@ -1239,6 +1614,7 @@ __device__ __noinline__ void q_wait_for(const uint32_t* slot, uint32_t want) {
 // (74 VGPRs: 6 waves per SIMD = 6 144 slots.  Compiled for 7 - 71 VGPRs, four scratch accesses in the ticket loop - it is not faster:
 //  1 617 / 1 504 M env.step/s against 1 642 / 1 529 M in 4P / 3P; the seventh wave was worth its 10 % mostly because it shortened the tail.
 //  Launch bounds for 4 / 5 / 8 waves: 1 532 / 1 279, 1 530 / 1 454, 1 426 / 1 382 - 6 is the optimum)
+template <int POL>
 __global__ __launch_bounds__(64, RMJ_STEP4_WAVES) void k_step4_queue(const Env* __restrict__ Ep, uint64_t policy_seed, uint32_t flags, uint32_t n_games,
                                                                          uint32_t n_steps, uint32_t chunk, uint32_t* __restrict__ heads, uint32_t* __restrict__ done,
                                                                          uint32_t skip_xcds) {
@@ -1260,7 +1636,7 @@ __global__ __launch_bounds__(64, RMJ_STEP4_WAVES) void k_step4_queue(const Env* 
         const uint32_t g = quad * 4u + (lane >> 4);
         const uint64_t gs_row = sm64(policy_seed + ((CEnv*)Ep)->game_offset + (uint64_t)g);
 #pragma unroll 1
-        for (uint32_t it = 0; it < steps; it++) step4_call<true>(Ep, policy_seed, flags, 0u, n_games, it == 0 ? 1u : 0u, gs_row, quad);
+        for (uint32_t it = 0; it < steps; it++) step4_call<true, POL>(Ep, policy_seed, flags, 0u, n_games, it == 0 ? 1u : 0u, gs_row, quad);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this chunk's stores are in the XCD's L2
         wave_sync();
         if (lane == 0u) __hip_atomic_store(done + quad, c + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1270,13 +1646,14 @@ __global__ __launch_bounds__(64, RMJ_STEP4_WAVES) void k_step4_queue(const Env* 
 // Safety net of k_step4_queue: where blocks run is not ours to decide - a quad whose XCD received no block at all (a partitioned
 // device, a dispatcher that skips an XCD) has done[quad] == 0 and is stepped here, by one wave for the whole rollout like
 // k_step4<true> (nothing of it has run yet, so no other cache holds newer data).  Every other wave exits at once.
+template <int POL>
 __global__ __launch_bounds__(64, RMJ_STEP4_WAVES) void k_step4_fixup(const Env* __restrict__ Ep, uint64_t policy_seed, uint32_t flags, uint32_t n_games,
                                                                          uint32_t n_steps, const uint32_t* __restrict__ done) {
     if (uni(__hip_atomic_load(done + blockIdx.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) != 0u) return;
     const uint32_t g = blockIdx.x * 4u + ((threadIdx.x & 63u) >> 4);
     const uint64_t gs_row = sm64(policy_seed + ((CEnv*)Ep)->game_offset + (uint64_t)g);
 #pragma unroll 1
-    for (uint32_t it = 0; it < n_steps; it++) step4_call<true>(Ep, policy_seed, flags, 0u, n_games, it == 0 ? 1u : 0u, gs_row);
+    for (uint32_t it = 0; it < n_steps; it++) step4_call<true, POL>(Ep, policy_seed, flags, 0u, n_games, it == 0 ? 1u : 0u, gs_row);
 }
 
 }  // namespace RMJ_NS

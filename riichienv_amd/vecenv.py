@@ -27,7 +27,7 @@ EXPORTS = [
     "rmj_get_waits", "rmj_get_scores", "rmj_get_ranks", "rmj_get_step_counts", "rmj_total_steps", "rmj_peek_state",
     "rmj_poke_state", "rmj_get_event_counts", "rmj_get_events", "rmj_format_event", "rmj_eval_hands",
     "rmj_agari_counts", "rmj_calculate_score", "rmj_shanten", "rmj_effective_tiles", "rmj_best_ukeire", "rmj_apply_events", "rmj_device_views", "rmj_step_ids_device", "rmj_clone", "rmj_copy_games", "rmj_copy_games_device",
-    "rmj_scores_device", "rmj_sync", "rmj_set_stream", "rmj_encode", "rmj_encode_device", "rmj_encode_extended", "rmj_encode_extended_device", "rmj_encode_aux", "rmj_encode_aux_device", "rmj_encode_seq", "rmj_encode_seq_device", "rmj_bench_rollout", "rmj_time_rollout",
+    "rmj_scores_device", "rmj_sync", "rmj_set_stream", "rmj_encode", "rmj_encode_device", "rmj_encode_extended", "rmj_encode_extended_device", "rmj_encode_aux", "rmj_encode_aux_device", "rmj_encode_seq", "rmj_encode_seq_device", "rmj_bench_rollout", "rmj_time_rollout", "rmj_step_greedy", "rmj_time_rollout_greedy",
     "rmj_bench_rollout_validated", "rmj_bench_encode", "rmj_set_rollout_streams", "rmj_total_full_path",
     "rmj_random_actions_device", "rmj_peek_outputs", "rmj_sample_ids_device",
     "rmj_encode_seq_delta", "rmj_encode_seq_delta_device", "rmj_step_random_encode",
@@ -119,6 +119,8 @@ def load_lib():
     L.rmj_bench_rollout.argtypes = [vp, C.c_uint64, C.c_uint32, C.c_uint32, C.POINTER(abi.BenchResult)]
     L.rmj_bench_rollout_validated.argtypes = [vp, C.c_uint64, C.c_uint32, C.c_uint32, C.POINTER(abi.BenchResult)]
     L.rmj_time_rollout.argtypes = [vp, C.c_uint64, C.c_uint32, C.POINTER(abi.BenchResult)]
+    L.rmj_step_greedy.argtypes = [vp, C.c_uint64, C.c_uint32, C.c_int, C.c_uint32]
+    L.rmj_time_rollout_greedy.argtypes = [vp, C.c_uint64, C.c_uint32, C.c_uint32, C.POINTER(abi.BenchResult)]
     L.rmj_bench_encode.argtypes = [vp, C.c_int, C.c_int, vp, C.c_uint32, C.POINTER(C.c_double)]
     L.rmj_set_rollout_streams.argtypes = [vp, C.c_int]
     L.rmj_total_full_path.argtypes = [vp, C.POINTER(C.c_uint64)]
@@ -270,6 +272,10 @@ class VecRiichiEnv:
 
     def step_random(self, policy_seed, n_steps=1, auto_reset=False):
         _chk(self.L.rmj_step_random(self.h, policy_seed, n_steps, int(auto_reset)))
+
+    def step_greedy(self, policy_seed, n_steps=1, auto_reset=False, call_rate_256=64):
+        """n_steps steps of every game under the device policy that plays to win (header: rmj_step_greedy)"""
+        _chk(self.L.rmj_step_greedy(self.h, policy_seed, n_steps, int(auto_reset), call_rate_256))
 
     def step_random_encode(self, policy_seed, n_steps, d_out_ptr, auto_reset=True, only_active=2):
         """n_steps x (step of every game + encode() of the acting seats into the device tensor at d_out_ptr): header
@@ -456,6 +462,11 @@ class VecRiichiEnv:
         """HIP-event time of rmj_step_random(seed, steps, auto_reset) alone (header: rmj_time_rollout); counters stay 0."""
         r = abi.BenchResult()
         _chk(self.L.rmj_time_rollout(self.h, policy_seed, steps, C.byref(r)))
+        return r
+
+    def time_rollout_greedy(self, policy_seed, steps, call_rate_256=64) -> abi.BenchResult:
+        r = abi.BenchResult()
+        _chk(self.L.rmj_time_rollout_greedy(self.h, policy_seed, steps, call_rate_256, C.byref(r)))
         return r
 
     def bench_rollout_validated(self, policy_seed, warmup, steps) -> abi.BenchResult:

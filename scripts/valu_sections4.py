@@ -28,8 +28,6 @@ GAMES = 65536
 
 
 def run():
-    os.environ["RMJ_STEP_STREAMS"] = "1"
-    os.environ["RMJ_STEP4"] = "1"
     from riichienv_amd import vecenv
     vecenv.LIB_PATH = os.path.join(ROOT, "riichienv_amd", "libriichi_mi355x_cuts.so")
     L = vecenv.load_lib()
@@ -37,15 +35,25 @@ def run():
     env = vecenv.VecRiichiEnv(GAMES, game_mode=int(os.environ.get("RMJ_MODE", "2")), seed=0)
     env.reset()
     L.rmj_prof_set_cut(-1, -1, -1)
-    env.step_random(0xC0FFEE, 500, auto_reset=True)
+    greedy = os.environ.get("RMJ_POLICY", "random") == "greedy"      # RMJ_POLICY=greedy: the sections under rmj_step_greedy
+    step = (lambda k: env.step_greedy(0xC0FFEE, k, auto_reset=True, call_rate_256=64)) if greedy else \
+           (lambda k: env.step_random(0xC0FFEE, k, auto_reset=True))
+    step(1000 if greedy else 500)       # warm-up as ONE fused launch (a launch per step under the counters takes ~0.5 s each)
     env.total_steps()
-    for cut in CUTS:
+    env.set_rollout_streams(1)          # from here on every step is its own launch of k_step4<false>
+    base = env
+    cuts = [c for c in CUTS if not (greedy and c == 43)]   # (mark 43 faults under the greedy instantiation of the accounting build: skipped)
+    for cut in cuts + [-1]:          # (-1: reference launch, same states: everything, stores and bails included)
+        # a cut behind the publication leaves new lists next to old records: every cut runs on a fresh copy of the same states
+        env = base.clone()
+        env.set_rollout_streams(1)
+        step = (lambda k: env.step_greedy(0xC0FFEE, k, auto_reset=True, call_rate_256=64)) if greedy else \
+               (lambda k: env.step_random(0xC0FFEE, k, auto_reset=True))
         L.rmj_prof_set_cut(cut, -1, -1)
-        env.step_random(0xC0FFEE, 1, auto_reset=True)
+        step(1)
         env.total_steps()
-    L.rmj_prof_set_cut(-1, -1, -1)
-    env.step_random(0xC0FFEE, 1, auto_reset=True)      # reference launch, same states: everything, stores and bails included
-    env.total_steps()
+        L.rmj_prof_set_cut(-1, -1, -1)
+        env.close()
 
 
 def report(root):
@@ -58,12 +66,13 @@ def report(root):
                 d = int(r["Dispatch_Id"])
                 rows.setdefault(d, {})
                 rows[d][r["Counter_Name"]] = rows[d].get(r["Counter_Name"], 0.0) + float(r["Counter_Value"])
-    ids = sorted(rows)[-(len(CUTS) + 1):]
+    cuts = [c for c in CUTS if not (os.environ.get("RMJ_POLICY", "random") == "greedy" and c == 43)]
+    ids = sorted(rows)[-(len(cuts) + 1):]
     W = GAMES // 4
     full = rows[ids[-1]]
     out = {"games": GAMES, "waves": W, "whole_step_per_wave": {k: v / W for k, v in full.items()}, "reach_mark": {}}
     print("whole step (tier 0 + bailed games, publication and stores), per wave of four games:", {k: round(v / W, 1) for k, v in full.items()})
-    for cut, d in zip(CUTS, ids[:-1]):
+    for cut, d in zip(cuts, ids[:-1]):
         per = {k: v / W for k, v in rows[d].items()}
         out["reach_mark"][str(cut)] = {"name": NAMES[cut], **per}
         print(f"{cut:3d} {NAMES[cut]:52s} VALU {per.get('SQ_INSTS_VALU', 0):7.1f}  SALU {per.get('SQ_INSTS_SALU', 0):7.1f}  LDS {per.get('SQ_INSTS_LDS', 0):6.1f}")

@@ -323,6 +323,8 @@ __device__ __noinline__ uint64_t r4_waits_probe(uint32_t ha, uint32_t hb, uint32
 // fill_waits13 of tier 0 for the sorted 13-tile hand P->hand[0 .. n): the isolated-tile bound, else the table shanten (the
 // only user of a histogram); a hand with a possible wait (shanten <= 0) needs the probe -> the row bails.  Writes the cache
 // like fill_waits13 (waits13 = 0 for every shanten >= 1).
+// RICH: the tier-0 build with the wait probe and the riichi transitions (see step4_body); without it a possible wait makes the row bail
+template <bool RICH>
 __device__ __forceinline__ void r4_fill_waits13(R4& q, PState* P, int n) {
     uint64_t W = 0ull;
     const R4Shape sp = r4_shape_sorted(q, P, n, -1);
@@ -360,6 +362,7 @@ __device__ __forceinline__ void r4_fill_waits13(R4& q, PState* P, int n) {
             }
             sh = r4_shanten(q, h13, len3);
             if (sh <= 0) {
+                if (!RICH) { R4BAIL(q, 2); return; }
                 W = r4_waits_probe(h13.a, h13.b, h13.c, h13.d);
                 sh = 0;
             }
@@ -375,6 +378,7 @@ __device__ __forceinline__ void r4_fill_waits13(R4& q, PState* P, int n) {
 
 // The same from a histogram, for a hand whose 13 tiles are not one sorted run (right after a Kita the previous drawn tile
 // sits behind the twelve sorted ones).
+template <bool RICH>
 __device__ __forceinline__ void r4_fill_waits13_h(R4& q, PState* P, const PH& h13) {
     uint64_t W = 0ull;
     const uint32_t T9 = 1u | (1u << 24);
@@ -398,6 +402,7 @@ __device__ __forceinline__ void r4_fill_waits13_h(R4& q, PState* P, const PH& h1
         } else {
             sh = r4_shanten(q, h13, len3);
             if (sh <= 0) {
+                if (!RICH) { R4BAIL(q, 2); return; }
                 W = r4_waits_probe(h13.a, h13.b, h13.c, h13.d);
                 sh = 0;
             }
@@ -494,6 +499,7 @@ __device__ __forceinline__ void r4_put(R4& q, int seat, int pos, uint64_t a, int
 // _resolve_discard (state/mod.rs:1317-1413) incl. claim generation (legal_actions.rs:254-508) for the row's game.
 // nl[] = list length of seat r (lanes r < 4) after the call; returns through G->phase / active_mask like the reference.
 // known_sh: the exact shanten of the 13 tiles the discard leaves when the policy has just computed it (99: unknown)
+template <bool RICH>
 __device__ __forceinline__ void r4_resolve_discard(R4& q, int pid, int tile, bool tsumogiri, int pf, int& nl_mine, uint64_t& w_mine, int known_sh = 99) {
     GState* G = q.G;
     PState* P = &G->p[pid];
@@ -563,7 +569,7 @@ __device__ __forceinline__ void r4_resolve_discard(R4& q, int pid, int tile, boo
                 const int i = __ffs((int)need_m) - 1;
                 need_m &= need_m - 1u;
                 PState* Q = &G->p[i];
-                r4_fill_waits13(q, Q, Q->hand_len);
+                r4_fill_waits13<RICH>(q, Q, Q->hand_len);
                 if (q.bail) need_m = 0u;
             }
         }
@@ -704,6 +710,7 @@ __device__ __forceinline__ void r4_resolve_discard(R4& q, int pid, int tile, boo
 __device__ __forceinline__ uint32_t r4_tenpai_keep(const R4& q, const PState* P, const PH& full, int hl);
 // _get_legal_actions_internal, WaitAct branch (legal_actions.rs:11-252), for the row's current player.  Everything that
 // needs a yaku evaluation or a wait probe (a complete hand, a possible Riichi, a kan in riichi) makes the row bail.
+template <bool RICH>
 __device__ __forceinline__ void r4_gen_act_legal(R4& q, int& nl_mine) {
     GState* G = q.G;
     const int r = q.r, rb = q.rb;
@@ -715,7 +722,7 @@ __device__ __forceinline__ void r4_gen_act_legal(R4& q, int& nl_mine) {
     const int drawn_tile = G->drawn_tile;
     const bool drawn = drawn_tile != 0xFF;
     const int drawable = G->drawable_count;
-    if (hl + 3 * nmelds == 13) { R4BAIL(q, 11); return; }
+    if (hl + 3 * nmelds == 13 || (!RICH && r_stage)) { R4BAIL(q, 11); return; }
     const int ht = r < hl ? (int)P->hand[r] : 0xFF;
     const int hty = ht >> 2;
     int n = 0;
@@ -728,8 +735,8 @@ __device__ __forceinline__ void r4_gen_act_legal(R4& q, int& nl_mine) {
         if (!(pflags & PF_WAITS_VALID)) {
             // the drawn tile is the last one and the 13 others are normally one sorted run; after a Kita they are not
             const int nx = __builtin_amdgcn_update_dpp(0xFFFF, ht, 0x101 /* row_shl:1 */, 0xf, 0xf, false);
-            if (idx != hl - 1 || rballot(r < hl - 2 && ht > nx, rb)) r4_fill_waits13_h(q, P, r4_hist(q, P, idx));
-            else r4_fill_waits13(q, P, hl - 1);
+            if (idx != hl - 1 || rballot(r < hl - 2 && ht > nx, rb)) r4_fill_waits13_h<RICH>(q, P, r4_hist(q, P, idx));
+            else r4_fill_waits13<RICH>(q, P, hl - 1);
             if (q.bail) return;
         }
         if ((P->waits13 >> (drawn_tile >> 2)) & 1ull) { R4BAIL(q, 13); return; }
@@ -758,7 +765,10 @@ __device__ __forceinline__ void r4_gen_act_legal(R4& q, int& nl_mine) {
                 const int yk = __popc((full.a | (full.a >> 1) | (full.a >> 2)) & T9) + __popc((full.b | (full.b >> 1) | (full.b >> 2)) & T9) +
                                __popc((full.c | (full.c >> 1) | (full.c >> 2)) & T9) + __popc((full.d | (full.d >> 1) | (full.d >> 2)) & O7_1);
                 if (!(r4_isolated(full) >= 3 && yk < 12)) {
-                    if (r4_shanten(q, full, hl / 3) <= 0) need_tp = true;
+                    if (r4_shanten(q, full, hl / 3) <= 0) {
+                        if (!RICH) { R4BAIL(q, 14); return; }
+                        need_tp = true;
+                    }
                 }
             }
         }
@@ -767,7 +777,7 @@ __device__ __forceinline__ void r4_gen_act_legal(R4& q, int& nl_mine) {
             tp = G->tp_mask;
             need_tp = false;
         }
-        if (__ballot(need_tp)) {
+        if (RICH && __ballot(need_tp)) {
             if (need_tp) {
                 tp = r4_tenpai_keep(q, P, full, hl);
                 if (r == 0 && !r_stage) { G->tp_seat = (uint8_t)pid; G->tp_mask = (uint16_t)tp; G->tp_step = G->step_count + 1u; }
@@ -1070,6 +1080,10 @@ template <bool LOOP, int POL>
 __device__ __forceinline__ void step4_body(const Env* Ep, Quad4Shared& sh, uint64_t policy_seed, uint32_t flags, uint32_t g_base, uint32_t g_end,
                                            bool load, uint64_t gs_row, const uint64_t* __restrict__ actions = nullptr, uint32_t quad = 0xFFFFFFFFu) {
     CEnv& E = *(CEnv*)Ep;
+    // RICH tier 0 (the wait probe, the Riichi offer / declaration / riichi-stage list in row form): for policies that play - the
+    // greedy instantiation and the per-step kernels an external policy drives.  The fused RandomAgent rollout keeps the lean
+    // tier 0: those exits are 0.3 % of its game-steps, and the extra code costs it 6 % (1.61 -> 1.51 G env.step/s, measured).
+    constexpr bool RICH = (POL == 1) || !LOOP;
 #ifdef RMJ_TL4
     uint64_t tl_prev = __builtin_readcyclecounter();
 #endif
@@ -1192,7 +1206,7 @@ __device__ __forceinline__ void step4_body(const Env* Ep, Quad4Shared& sh, uint6
             const uint32_t act = (uint32_t)rbc((int)(uint32_t)mine, rb + pid);   // type and tile live in the low dword
             const uint32_t ty = act & 0xFFu;
             PState* P = &G->p[pid];
-            if (ty == RMJ_RIICHI && ((act >> 8) & 0xFFu) == RMJ_TILE_NONE && P->score >= 1000 &&
+            if (RICH && ty == RMJ_RIICHI && ((act >> 8) & 0xFFu) == RMJ_TILE_NONE && P->score >= 1000 &&
                 (KSANMA ? G->drawable_count > 0 : G->drawable_count >= 4) && !(P->flags & (PF_RIICHI_DECLARED | PF_RIICHI_STAGE))) {
                 // ---- Riichi declared (state/mod.rs:440-457): the seat enters the riichi stage and stays to act; its next list
                 // (below) holds the discards that keep the hand tenpai
@@ -1242,7 +1256,7 @@ __device__ __forceinline__ void step4_body(const Env* Ep, Quad4Shared& sh, uint6
                     if (r == 0) P->hand_len = (uint8_t)(hl - 1);
                     wave_sync();
                     R4M(42);
-                    r4_resolve_discard(q, pid, tile, tsumogiri, pf, nl_mine, w_mine, (POL == 1 && pol_seat == pid) ? pol_sh : 99);
+                    r4_resolve_discard<RICH>(q, pid, tile, tsumogiri, pf, nl_mine, w_mine, (POL == 1 && pol_seat == pid) ? pol_sh : 99);
                     R4M(56);
                 }
             } else if (KSANMA && ty == RMJ_KITA) {
@@ -1276,7 +1290,7 @@ __device__ __forceinline__ void step4_body(const Env* Ep, Quad4Shared& sh, uint6
                                 const int i = __ffs((int)need_m) - 1;
                                 need_m &= need_m - 1u;
                                 PState* Q = &G->p[i];
-                                r4_fill_waits13(q, Q, Q->hand_len);
+                                r4_fill_waits13<RICH>(q, Q, Q->hand_len);
                                 if (q.bail) need_m = 0u;
                             }
                         }
@@ -1441,7 +1455,7 @@ __device__ __forceinline__ void step4_body(const Env* Ep, Quad4Shared& sh, uint6
         if (!q.bail && G->phase == RMJ_WAIT_ACT) {
             nl_mine = 0;
             w_mine = 0ull;
-            r4_gen_act_legal(q, nl_mine);
+            r4_gen_act_legal<RICH>(q, nl_mine);
         }
     }
     R4M(45);

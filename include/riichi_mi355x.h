@@ -227,6 +227,13 @@ int rmj_random_actions_device(rmj_handle h, uint64_t policy_seed, rmj_action_t* 
 /* ------------------------------------------------------------------ observations */
 int rmj_get_status(rmj_handle h, uint8_t* active_mask, uint8_t* phase, uint8_t* done); /* each [n] */
 int rmj_get_legal(rmj_handle h, rmj_action_t* legal /*[n][4][64]*/, uint8_t* counts /*[n][4]*/);
+/* The lists a host agent loop reads per step without the [n][4][64] slab (2 KB per game): one row per seat that is to act, in
+ * (game, seat) order: index[row] = game * 4 + seat, list = entries[offsets[row] .. offsets[row + 1]) (what Observation.legal_actions()
+ * returns for that seat, observation/mod.rs:93-111).  Gathered on the device, copied through pinned staging memory owned by the
+ * handle (~110 B per game).  *n_rows / *n_entries: totals of this state; when they exceed cap_rows / cap_entries only the first
+ * cap_rows rows / cap_entries entries were written.  offsets has cap_rows + 1 slots. */
+int rmj_get_legal_compact(rmj_handle h, uint32_t* index, uint32_t* offsets, rmj_action_t* entries, uint32_t cap_rows, uint32_t cap_entries,
+                          uint32_t* n_rows, uint32_t* n_entries);
 int rmj_get_mask(rmj_handle h, uint8_t* mask /*[n][4][82]*/);
 int rmj_get_waits(rmj_handle h, uint64_t* waits /*[n][4] bit t = tile type t; 0 for seats without an observation (not active, env.rs:870-871) */);
 int rmj_get_scores(rmj_handle h, int32_t* scores /*[n][4]*/);
@@ -359,6 +366,12 @@ int rmj_step_ids_device(rmj_handle h, const int32_t* d_action_ids, int auto_rese
 int rmj_sample_ids_device(rmj_handle h, const float* d_logits, uint32_t stride, uint64_t seed, int32_t* d_ids);
 /* scores() (env.rs:401-404) into a device buffer [n][4]; d_event_counts [n] may be NULL */
 int rmj_scores_device(rmj_handle h, int32_t* d_scores, uint32_t* d_event_counts);
+/* RiichiEnv.points(rule_name) (riichienv-python/src/env.rs:691-727, ranks :673-689) of every game, computed on the device in f64
+ * like the reference: (score - base) / 1000 * weight + uma[rank - 1]; rule 0 = "basic", 1 = "ouza-tyoujyo", 2 = "ouza-normal"
+ * (3P: "basic" only; anything else -> RMJ_ERR_ARG like the reference's ValueError).  d_points / points: [n][4] f64, 0 for the
+ * fourth seat of a 3P game.  The device version is asynchronous on the handle's stream (the reward of a trainer-side loop). */
+int rmj_points_device(rmj_handle h, int rule, double* d_points);
+int rmj_get_points(rmj_handle h, int rule, double* points);
 int rmj_sync(rmj_handle h); /* wait for the handle's stream */
 /* Issue all further work of the handle on the caller's HIP stream (e.g. the stream of the policy's framework), so that
  * kernels of the library and of the policy are ordered by the stream itself and no host synchronisation is needed
@@ -468,6 +481,12 @@ int rmj_time_rollout_greedy(rmj_handle h, uint64_t policy_seed, uint32_t steps, 
  * validates them against the stored legal lists like GameState::step does for an external agent (state/mod.rs:339-402);
  * finished games restart; one stream, the whole batch per launch.  step_kernel_ms = policy + step launch. */
 int rmj_bench_rollout_validated(rmj_handle h, uint64_t policy_seed, uint32_t warmup, uint32_t steps, RmjBenchResult* out);
+/* Kernel-gate benchmark of the hand-math kernels (the groups of the reference's
+ * riichienv-core/benches/agari_bench.rs:142-376): average duration (ms) of ONE launch over n device-resident inputs (uploaded
+ * once, nothing copied back), HIP events around `reps` launches.  which: 0 = rmj_eval_hands (a = RmjHandCase[n]),
+ * 1 = rmj_agari_counts (a = counts[n][34]), 2 = rmj_shanten, 3 = rmj_effective_tiles, 4 = rmj_best_ukeire (b = visible[n][34]),
+ * 5 = rmj_calculate_score (a = han | fu | is_oya | is_tsumo | num_players, five byte arrays of n; b = honba u32[n]). */
+int rmj_bench_hand_kernel(int device, int which, const void* a, const void* b, uint32_t n, int sanma, uint32_t reps, double* avg_ms);
 /* Average duration (ms) of one encoder launch over `reps` back-to-back launches, HIP events on the handle's stream;
  * extended = 0: rmj_encode_device, 1: rmj_encode_extended_device (same d_out / only_active meaning). */
 int rmj_bench_encode(rmj_handle h, int extended, int only_active, float* d_out, uint32_t reps, double* avg_ms);

@@ -167,6 +167,81 @@ __global__ void k_gather_steps(const GState* core, uint32_t n, uint64_t* out) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) out[i] = core[i].step_count;
 }
+// ---- compact legal lists for a host agent loop (rmj_get_legal_compact): rows = the seats that are to act, in (game, seat) order,
+// entries = their lists one after the other.  Pass 1: per game the rows / entries it contributes, block prefix sums; pass 2: the
+// block totals scanned by one block; pass 3: every game writes its rows.  Deterministic order, no atomics.
+#define LC_BLOCK 256
+__device__ __forceinline__ uint32_t lc_rows_of(uint32_t status, const uint8_t* nl, uint32_t& entries) {
+    const uint32_t am = (status >> 16) & 1u ? 0u : (status & 0xFu);
+    uint32_t rows = 0;
+    entries = 0;
+    for (int p = 0; p < 4; p++)
+        if (((am >> p) & 1u) && nl[p]) { rows++; entries += nl[p]; }
+    return rows;
+}
+__global__ __launch_bounds__(LC_BLOCK) void k_lc_count(const uint32_t* __restrict__ status, const uint8_t* __restrict__ nlegal, uint32_t n, uint32_t* __restrict__ pre /*[n][2]*/,
+                                                       uint32_t* __restrict__ blk /*[blocks][2]*/) {
+    __shared__ uint32_t sr[LC_BLOCK], se[LC_BLOCK];
+    const uint32_t g = blockIdx.x * LC_BLOCK + threadIdx.x;
+    uint32_t e = 0, r = 0;
+    if (g < n) r = lc_rows_of(status[g], nlegal + (size_t)g * 4, e);
+    sr[threadIdx.x] = r; se[threadIdx.x] = e;
+    __syncthreads();
+    for (int off = 1; off < LC_BLOCK; off <<= 1) {     // inclusive Hillis-Steele scan
+        uint32_t ar = 0, ae = 0;
+        if ((int)threadIdx.x >= off) { ar = sr[threadIdx.x - off]; ae = se[threadIdx.x - off]; }
+        __syncthreads();
+        sr[threadIdx.x] += ar; se[threadIdx.x] += ae;
+        __syncthreads();
+    }
+    if (g < n) { pre[2 * (size_t)g] = sr[threadIdx.x] - r; pre[2 * (size_t)g + 1] = se[threadIdx.x] - e; }
+    if (threadIdx.x == LC_BLOCK - 1) { blk[2 * blockIdx.x] = sr[threadIdx.x]; blk[2 * blockIdx.x + 1] = se[threadIdx.x]; }
+}
+__global__ void k_lc_scan(uint32_t* blk, uint32_t blocks, uint32_t* totals /*[2]*/) {   // one thread: a few thousand blocks at most
+    if (blockIdx.x || threadIdx.x) return;
+    uint32_t r = 0, e = 0;
+    for (uint32_t b = 0; b < blocks; b++) {
+        const uint32_t cr = blk[2 * b], ce = blk[2 * b + 1];
+        blk[2 * b] = r; blk[2 * b + 1] = e;
+        r += cr; e += ce;
+    }
+    totals[0] = r; totals[1] = e;
+}
+__global__ __launch_bounds__(LC_BLOCK) void k_lc_gather(const uint32_t* __restrict__ status, const uint8_t* __restrict__ nlegal, const uint64_t* __restrict__ legal, uint32_t n,
+                                                        const uint32_t* __restrict__ pre, const uint32_t* __restrict__ blk, uint32_t cap_rows, uint32_t cap_entries,
+                                                        uint32_t* __restrict__ index, uint32_t* __restrict__ offs, uint64_t* __restrict__ entries) {
+    const uint32_t g = blockIdx.x * LC_BLOCK + threadIdx.x;
+    if (g >= n) return;
+    const uint32_t st = status[g];
+    const uint32_t am = (st >> 16) & 1u ? 0u : (st & 0xFu);
+    uint32_t row = blk[2 * blockIdx.x] + pre[2 * (size_t)g], ent = blk[2 * blockIdx.x + 1] + pre[2 * (size_t)g + 1];
+    for (int p = 0; p < 4; p++) {
+        const uint32_t k = nlegal[(size_t)g * 4 + p];
+        if (!((am >> p) & 1u) || !k) continue;
+        if (row < cap_rows) { index[row] = g * 4u + (uint32_t)p; offs[row] = ent; }
+        for (uint32_t j = 0; j < k; j++)
+            if (ent + j < cap_entries) entries[ent + j] = legal[((size_t)g * 4 + p) * RMJ_MAX_LEGAL + j];
+        row++;
+        ent += k;
+    }
+}
+// RiichiEnv.points (env.rs:691-727) with ranks (env.rs:673-689: by score, ties by seat) for every game: f64 like the reference
+__global__ void k_points(const GState* core, uint32_t n, int np, double weight, double base, double u0, double u1, double u2, double u3, double* out) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    int32_t sc[4];
+    for (int p = 0; p < 4; p++) sc[p] = core[i].p[p].score;
+    for (int p = 0; p < 4; p++) {
+        double v = 0.0;
+        if (p < np) {
+            int rank = 0;   // seats ahead: a higher score, or the same score and a lower seat index
+            for (int o = 0; o < np; o++) rank += (sc[o] > sc[p]) || (sc[o] == sc[p] && o < p);
+            const double uma = rank == 0 ? u0 : (rank == 1 ? u1 : (rank == 2 ? u2 : u3));
+            v = ((double)sc[p] - base) / 1000.0 * weight + uma;
+        }
+        out[(size_t)i * 4 + p] = v;
+    }
+}
 __global__ void k_gather_scores(const GState* core, uint32_t n, int32_t* out, uint32_t* evc) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) {
@@ -314,20 +389,36 @@ __global__ __launch_bounds__(256) void k_eval_hands(const RmjHandCase* cases, ui
     if (lane == 0) out[k] = r;
 }
 
+// agari.rs:65-73 + hand_evaluator.rs:178-213 over raw histograms.  Round 3: FOUR hands per wave - one 16-lane row per hand like
+// the step kernel's tier 0: the hand's 34 counts arrive as three coalesced byte loads per row (round 2: one hand per wave, every lane
+// walked the same 34 bytes one by one), the row OR-reduces them into the packed histogram, is_agari is closed-form per row and the
+// waits come from the row-form probe of the step kernel (r4_waits_probe).
 __global__ __launch_bounds__(256) void k_agari_counts(const uint8_t* counts, uint32_t n, uint8_t* agari, uint8_t* tenpai, uint64_t* waits) {
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const uint32_t k = blockIdx.x * WPB + wave;
-    if (k >= n) return;
+    const int lane = threadIdx.x & 63, r = lane & 15, rb = lane & 48;
+    const uint32_t k = (blockIdx.x * 4u + (threadIdx.x >> 6)) * 4u + (uint32_t)(lane >> 4);
+    const bool live = k < n;
     PH h = {0, 0, 0, 0};
-    for (int t = 0; t < 34; t++) {
-        uint32_t cnt = counts[(size_t)k * 34 + t];
-        int s = t_suit(t);
-        ph_addv(h, s, (cnt & 7u) << (3 * (t - 9 * s)));
+    {
+        uint32_t w[4] = {0u, 0u, 0u, 0u};
+#pragma unroll
+        for (int j = 0; j < 3; j++) {
+            const int t = r + 16 * j;
+            if (live && t < 34) {
+                const int s = t_suit(t);
+                const uint32_t f = ((uint32_t)counts[(size_t)k * 34 + t] & 7u) << (3 * (t - 9 * s));
+                w[0] |= s == 0 ? f : 0u; w[1] |= s == 1 ? f : 0u; w[2] |= s == 2 ? f : 0u; w[3] |= s == 3 ? f : 0u;
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < 4; q++) w[q] = (uint32_t)rmj4::rbc((int)rmj4::row_or16(w[q]), rb + 15);
+        h.a = w[0]; h.b = w[1]; h.c = w[2]; h.d = w[3];
     }
-    bool ag = is_agari(h);
-    uint64_t w = 0;
-    if (ph_total(h) == 13) w = wave_waits(h, lane);
-    if (lane == 0) {
+    const bool ag = is_agari(h);
+    uint64_t w = 0ull;
+    if (__ballot(live && ph_total(h) == 13)) {
+        if (live && ph_total(h) == 13) w = rmj4::r4_waits_probe(h.a, h.b, h.c, h.d);
+    }
+    if (live && r == 0) {
         agari[k] = ag;
         tenpai[k] = w != 0ull;
         waits[k] = w;
@@ -679,24 +770,37 @@ __global__ __launch_bounds__(64) void k_encode_aux(Env E, int which, float* __re
 
 
 // shanten.rs:244-261 / :470-484 (calculate_shanten / calculate_shanten_3p over raw histograms): one thread per hand
-__global__ void k_shanten(ShantenTables T, const uint8_t* counts, uint32_t n, int sanma, int8_t* out) {
-    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+// one thread per hand; the block's 256 hands (8 704 contiguous bytes) are fetched as coalesced 16-byte loads into LDS first
+// (round 2: every thread read its own 34 bytes at a 34-byte stride)
+__global__ __launch_bounds__(256) void k_shanten(ShantenTables T, const uint8_t* counts, uint32_t n, int sanma, int8_t* out) {
+    __shared__ __attribute__((aligned(16))) uint8_t tile[256 * 34 + 16];
+    const uint32_t base = blockIdx.x * 256u;
+    const uint32_t here = n - base < 256u ? n - base : 256u;
+    const size_t off0 = (size_t)base * 34;                       // 8 704 * block: 16-byte aligned when `counts` is
+    const uint32_t bytes = here * 34u;
+    if ((reinterpret_cast<uintptr_t>(counts) & 15u) == 0u) {
+        for (uint32_t i = threadIdx.x; i * 16u < bytes; i += 256u) {
+            if (i * 16u + 16u <= bytes) reinterpret_cast<uint4*>(tile)[i] = reinterpret_cast<const uint4*>(counts + off0)[i];
+            else for (uint32_t b = i * 16u; b < bytes; b++) tile[b] = counts[off0 + b];
+        }
+    } else {
+        for (uint32_t b = threadIdx.x; b < bytes; b += 256u) tile[b] = counts[off0 + b];
+    }
+    __syncthreads();
+    const uint32_t i = base + threadIdx.x;
     if (i >= n) return;
     PH h = {0, 0, 0, 0};
     int total = 0;
+    const uint8_t* mine = tile + threadIdx.x * 34;
+#pragma unroll
     for (int t = 0; t < 34; t++) {
-        uint32_t c = counts[(size_t)i * 34 + t];
+        const uint32_t c = mine[t];
         total += (int)c;
-        int s = t_suit(t);
+        const int s = t_suit(t);
         ph_addv(h, s, (c & 7u) << (3 * (t - 9 * s)));
     }
     out[i] = (int8_t)sh_shanten(h, total / 3, sanma != 0, T);
 }
-
-// shanten.rs:265-405 / :488-626 (calculate_effective_tiles(_3p)_with_discard, calculate_best_ukeire(_3p)) over raw
-// histograms: ONE WAVE PER HAND, lane = drawn tile type; the loop over discard candidates runs over held types.
-//   mode 0: effective tiles (3n+1 hand: plain; 3n+2: best over the discards that do not raise shanten; else 0xFFFFFFFF)
-//   mode 1: best ukeire against `visible`
 __global__ __launch_bounds__(256) void k_ukeire(ShantenTables T, const uint8_t* counts, const uint8_t* visible, uint32_t n, int sanma,
                                                 int mode, uint32_t* out) {
     const int lane = threadIdx.x & 63;
@@ -774,8 +878,12 @@ struct rmj_env {
     uint32_t queue_skip_xcds = 0;   // test hook: XCDs whose waves leave the queue kernel at once (RMJ_QUEUE_TEST_SKIP_XCDS at create)
     int queue_min_chunk = 8;        // shortest ticket (steps): a rollout of >= 2 tickets per quad runs as tickets; RMJ_QUEUE_MIN_CHUNK at create
     uint32_t max_xcc_id = 0;        // largest HW_REG_XCC_ID seen by a probe launch at create: the ticket rollout assumes ids 0..7 (one L2 per queue)
+    void* h_pin = nullptr;          // pinned host staging of the host-buffer entry points (rmj_get_legal_compact), grown on demand
+    size_t pin_bytes = 0;
     int enc_streams = 0;            // RMJ_ENC_STREAMS at create (0: want_streams): parts of the step + encode rollout
     int enc_parts_quad = -1;        // RMJ_ENC_PARTS_QUAD at create (-1: follow `quad`)
+    int enc_fused = 1;              // RMJ_ENC_FUSED at create: the step + encode rollout as ONE launch (k_step4_enc / k_step4_queue_enc); 0 = parts on streams
+    uint32_t q_slots_enc = 0;       // waves of k_step4_queue_enc the device holds at once
 };
 // device staging memory of at least `bytes` bytes, owned by the handle
 static int scratch_for(rmj_env* h, size_t bytes, void** out) {
@@ -858,6 +966,7 @@ static int create_impl(rmj_env* h, const RmjConfig* cfg, uint64_t** d_seeds_out)
     if (const char* e = getenv("RMJ_QUEUE_MIN_CHUNK")) h->queue_min_chunk = atoi(e) > 0 ? atoi(e) : 1;
     if (const char* e = getenv("RMJ_ENC_STREAMS")) h->enc_streams = atoi(e);
     if (const char* e = getenv("RMJ_ENC_PARTS_QUAD")) h->enc_parts_quad = atoi(e) != 0;
+    if (const char* e = getenv("RMJ_ENC_FUSED")) h->enc_fused = atoi(e);
     const size_t B = cfg->n_games;
     Env& d = h->d;
     HIPCHK(hipStreamCreateWithFlags(&h->own_stream, hipStreamNonBlocking));
@@ -954,6 +1063,7 @@ int rmj_destroy(rmj_handle h) {
     if (!h) return RMJ_OK;
     hipSetDevice(h->cfg.device);
     if (h->stream) hipStreamSynchronize(h->stream);
+    if (h->h_pin) hipHostFree(h->h_pin);
     hipFree(h->d.core); hipFree(h->d.wall); hipFree(h->d.legal); hipFree(h->d.nlegal); hipFree(h->d_decay); if (h->d_scratch) hipFree(h->d_scratch); hipFree(h->d.mask);
     hipFree(h->d.waits); hipFree(h->d.status); hipFree(h->d.events); hipFree(h->d.win); hipFree(h->d_actions); hipFree(h->d_counter); hipFree(h->d_obs_offs); hipFree(h->d_env); hipFree(h->d_qheads); hipFree(h->d_qdone);
     if (h->own_stream) hipStreamDestroy(h->own_stream);
@@ -983,6 +1093,7 @@ int rmj_clone(rmj_handle h, rmj_handle* out) {
     c->queue_min_chunk = h->queue_min_chunk;
     c->enc_streams = h->enc_streams;
     c->enc_parts_quad = h->enc_parts_quad;
+    c->enc_fused = h->enc_fused;
     const size_t B = h->cfg.n_games, ring = (size_t)h->d.ring_mask + 1u;
     const struct { void* dst; const void* src; size_t bytes; } slabs[] = {
         {c->d.core, h->d.core, B * sizeof(GState)}, {c->d.wall, h->d.wall, B * RMJ_WALL_STRIDE},
@@ -1133,6 +1244,34 @@ int rmj_scores_device(rmj_handle h, int32_t* d_scores, uint32_t* d_event_counts)
     HIPCHK(hipGetLastError());
     return RMJ_OK;
 }
+// RiichiEnv.points(rule_name) (env.rs:691-727) of every game on the device: rule 0 = "basic", 1 = "ouza-tyoujyo", 2 = "ouza-normal"
+// (3P knows "basic" only, like the reference); d_points [n][4] f64, seats beyond the player count get 0.  Asynchronous on the
+// handle's stream: the reward a trainer-side loop reads without leaving the GPU.
+int rmj_points_device(rmj_handle h, int rule, double* d_points) {
+    if (!h || !d_points) return fail(RMJ_ERR_ARG, "null argument");
+    const bool sanma = h->cfg.game_mode >= 3;
+    if (rule < 0 || rule > (sanma ? 0 : 2)) return fail(RMJ_ERR_ARG, sanma ? "Unknown preset rule for 3P" : "Unknown preset rule");
+    HIPCHK(hipSetDevice(h->cfg.device));
+    const uint32_t n = h->cfg.n_games;
+    static const double UMA4[3][4] = {{50.0, 10.0, -10.0, -50.0}, {100.0, 40.0, -40.0, -100.0}, {50.0, 20.0, -20.0, -50.0}};
+    const double w = sanma ? 1.0 : (rule == 0 ? 1.0 : 0.0), base = sanma ? 35000.0 : 25000.0;
+    const double u0 = sanma ? 40.0 : UMA4[rule][0], u1 = sanma ? 0.0 : UMA4[rule][1], u2 = sanma ? -40.0 : UMA4[rule][2], u3 = sanma ? 0.0 : UMA4[rule][3];
+    hipLaunchKernelGGL(k_points, dim3((n + 255) / 256), dim3(256), 0, h->stream, h->d.core, n, sanma ? 3 : 4, w, base, u0, u1, u2, u3, d_points);
+    HIPCHK(hipGetLastError());
+    return RMJ_OK;
+}
+int rmj_get_points(rmj_handle h, int rule, double* points) {
+    DevTmp tmp;
+    if (!h || !points) return fail(RMJ_ERR_ARG, "null argument");
+    double* d;
+    HIPCHK(hipSetDevice(h->cfg.device));
+    HIPCHK(tmp.alloc(&d, (size_t)h->cfg.n_games * 4 * sizeof(double)));
+    int rc = rmj_points_device(h, rule, d);
+    if (rc) return rc;
+    HIPCHK(hipStreamSynchronize(h->stream));
+    HIPCHK(hipMemcpy(points, d, (size_t)h->cfg.n_games * 4 * sizeof(double), hipMemcpyDeviceToHost));
+    return RMJ_OK;
+}
 int rmj_set_stream(rmj_handle h, void* stream, int own) {
     if (!h) return fail(RMJ_ERR_ARG, "null handle");
     HIPCHK(hipSetDevice(h->cfg.device));
@@ -1273,6 +1412,45 @@ int rmj_step_random_encode(rmj_handle h, uint64_t policy_seed, uint32_t n_steps,
     HIPCHK(hipSetDevice(h->cfg.device));
     const uint32_t flags = STEP_F_RANDOM | (auto_reset ? STEP_F_AUTORESET : 0u);
     const uint32_t n = h->cfg.n_games;
+    if (h->enc_fused && h->quad >= 2 && h->want_streams >= 2 && n_steps >= 2 && only_active == 2) {
+        // Round 3: ONE launch - every wave steps its four games and writes the rows of the seats that are to act, step after step
+        // (k_step4_enc); as (quad, chunk) tickets when the batch is between one and eight chip-fulls of waves (k_step4_queue_enc)
+        const bool sanma = h->cfg.game_mode >= 3;
+        const dim3 grid((n + 3u) / 4u);
+        if (h->q_slots_enc == 0) {
+            int per_cu = 0, cus = 0;
+            if ((sanma ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, rmj3::k_step4_queue_enc<0>, 64, 0)
+                       : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, rmj4::k_step4_queue_enc<0>, 64, 0)) != hipSuccess ||
+                hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, h->cfg.device) != hipSuccess)
+                return fail(RMJ_ERR_HIP, "occupancy query failed");
+            h->q_slots_enc = (uint32_t)(per_cu > 0 ? per_cu : 1) * (uint32_t)(cus > 0 ? cus : 1);
+        }
+        const uint32_t chunk = rollout_chunk(h, n_steps);
+        const bool queued = h->queue_chunk > 0 && h->max_xcc_id <= 7u && n_steps >= 2u * chunk &&
+                            (h->queue_force ? grid.x >= 64u : (grid.x > h->q_slots_enc && grid.x < 8u * h->q_slots_enc));
+        if (queued) {
+            if (!h->d_qheads) {
+                HIPCHK(hipMalloc(&h->d_qheads, 8 * RMJ_Q_STRIDE * sizeof(uint32_t)));
+                HIPCHK(hipMalloc(&h->d_qdone, (size_t)grid.x * sizeof(uint32_t)));
+            }
+            HIPCHK(hipMemsetAsync(h->d_qheads, 0, 8 * RMJ_Q_STRIDE * sizeof(uint32_t), h->stream));
+            HIPCHK(hipMemsetAsync(h->d_qdone, 0, (size_t)grid.x * sizeof(uint32_t), h->stream));
+            const dim3 gq(grid.x < h->q_slots_enc ? grid.x : h->q_slots_enc);
+            if (sanma) {
+                hipLaunchKernelGGL((rmj3::k_step4_queue_enc<0>), gq, dim3(64), 0, h->stream, (const Env*)h->d_env, policy_seed, flags, n, n_steps, chunk, h->d_qheads, h->d_qdone, h->queue_skip_xcds, d_out);
+                hipLaunchKernelGGL((rmj3::k_step4_fixup_enc<0>), grid, dim3(64), 0, h->stream, (const Env*)h->d_env, policy_seed, flags, n, n_steps, (const uint32_t*)h->d_qdone, d_out);
+            } else {
+                hipLaunchKernelGGL((rmj4::k_step4_queue_enc<0>), gq, dim3(64), 0, h->stream, (const Env*)h->d_env, policy_seed, flags, n, n_steps, chunk, h->d_qheads, h->d_qdone, h->queue_skip_xcds, d_out);
+                hipLaunchKernelGGL((rmj4::k_step4_fixup_enc<0>), grid, dim3(64), 0, h->stream, (const Env*)h->d_env, policy_seed, flags, n, n_steps, (const uint32_t*)h->d_qdone, d_out);
+            }
+        } else if (sanma) {
+            hipLaunchKernelGGL((rmj3::k_step4_enc<0>), grid, dim3(64), 0, h->stream, (const Env*)h->d_env, policy_seed, flags, 0u, n, n_steps, d_out);
+        } else {
+            hipLaunchKernelGGL((rmj4::k_step4_enc<0>), grid, dim3(64), 0, h->stream, (const Env*)h->d_env, policy_seed, flags, 0u, n, n_steps, d_out);
+        }
+        HIPCHK(hipGetLastError());
+        return RMJ_OK;
+    }
     // The encoder is bound by its stores, the step by instruction issue: parts of the batch on k streams put the step of one
     // part under the encoder of another (measured, 65 536 3P games: one stream 283 M env.step/s, four parts 383 M with the
     // four-game kernel and 323 M with the one-game kernel).  RMJ_ENC_STREAMS / RMJ_ENC_PARTS_QUAD: experiment knobs.
@@ -1338,6 +1516,55 @@ int rmj_get_legal(rmj_handle h, rmj_action_t* legal, uint8_t* counts) {
     size_t B = h->cfg.n_games;
     if (legal) SYNC_FETCH(legal, h->d.legal, B * 4 * RMJ_MAX_LEGAL * sizeof(uint64_t));
     if (counts) SYNC_FETCH(counts, h->d.nlegal, B * 4);
+    return RMJ_OK;
+}
+// What a host agent loop reads per step, without the 2 KB per game of the full [n][4][64] list slab: one row per seat that is to
+// act, in (game, seat) order - index[row] = game * 4 + seat, its list = entries[offsets[row] .. offsets[row + 1]) - gathered on the
+// device and brought down through pinned staging memory (~110 B per game instead of 2 055).  n_rows / n_entries report the totals;
+// when they exceed the capacities only the first cap_rows rows / cap_entries entries were written (call again with more room).
+int rmj_get_legal_compact(rmj_handle h, uint32_t* index, uint32_t* offsets /*[cap_rows + 1]*/, rmj_action_t* entries, uint32_t cap_rows, uint32_t cap_entries,
+                          uint32_t* n_rows, uint32_t* n_entries) {
+    if (!h || !index || !offsets || !entries || !n_rows || !n_entries) return fail(RMJ_ERR_ARG, "null argument");
+    HIPCHK(hipSetDevice(h->cfg.device));
+    const uint32_t n = h->cfg.n_games, blocks = (n + LC_BLOCK - 1) / LC_BLOCK;
+    // device scratch: pre [n][2] | blk [blocks][2] | totals [2] | index [cap_rows] | offs [cap_rows] | entries [cap_entries]
+    const size_t o_blk = (size_t)n * 8, o_tot = o_blk + (size_t)blocks * 8, o_idx = o_tot + 16, o_off = o_idx + (size_t)cap_rows * 4;
+    const size_t o_ent = (o_off + (size_t)cap_rows * 4 + 15) & ~(size_t)15, total = o_ent + (size_t)cap_entries * 8;
+    void* sp;
+    int rc = scratch_for(h, total, &sp);
+    if (rc) return rc;
+    uint8_t* base = (uint8_t*)sp;
+    uint32_t *pre = (uint32_t*)base, *blk = (uint32_t*)(base + o_blk), *tot = (uint32_t*)(base + o_tot), *d_idx = (uint32_t*)(base + o_idx), *d_off = (uint32_t*)(base + o_off);
+    uint64_t* d_ent = (uint64_t*)(base + o_ent);
+    hipLaunchKernelGGL(k_lc_count, dim3(blocks), dim3(LC_BLOCK), 0, h->stream, (const uint32_t*)h->d.status, (const uint8_t*)h->d.nlegal, n, pre, blk);
+    hipLaunchKernelGGL(k_lc_scan, dim3(1), dim3(64), 0, h->stream, blk, blocks, tot);
+    hipLaunchKernelGGL(k_lc_gather, dim3(blocks), dim3(LC_BLOCK), 0, h->stream, (const uint32_t*)h->d.status, (const uint8_t*)h->d.nlegal, (const uint64_t*)h->d.legal, n,
+                       (const uint32_t*)pre, (const uint32_t*)blk, cap_rows, cap_entries, d_idx, d_off, d_ent);
+    HIPCHK(hipGetLastError());
+    const size_t need_pin = 16 + (size_t)cap_rows * 8 + (size_t)cap_entries * 8;
+    if (need_pin > h->pin_bytes) {
+        if (h->h_pin) hipHostFree(h->h_pin);
+        h->h_pin = nullptr; h->pin_bytes = 0;
+        HIPCHK(hipHostMalloc(&h->h_pin, need_pin, hipHostMallocDefault));
+        h->pin_bytes = need_pin;
+    }
+    uint8_t* pin = (uint8_t*)h->h_pin;
+    HIPCHK(hipMemcpyAsync(pin, tot, 8, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    const uint32_t rows = ((uint32_t*)pin)[0], ents = ((uint32_t*)pin)[1];
+    *n_rows = rows; *n_entries = ents;
+    const uint32_t wr = rows < cap_rows ? rows : cap_rows, we = ents < cap_entries ? ents : cap_entries;
+    uint8_t *p_idx = pin + 16, *p_off = p_idx + (size_t)cap_rows * 4, *p_ent = p_off + (size_t)cap_rows * 4;
+    if (wr) {
+        HIPCHK(hipMemcpyAsync(p_idx, d_idx, (size_t)wr * 4, hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(hipMemcpyAsync(p_off, d_off, (size_t)wr * 4, hipMemcpyDeviceToHost, h->stream));
+    }
+    if (we) HIPCHK(hipMemcpyAsync(p_ent, d_ent, (size_t)we * 8, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    memcpy(index, p_idx, (size_t)wr * 4);
+    memcpy(offsets, p_off, (size_t)wr * 4);
+    offsets[wr] = rows <= cap_rows ? ents : (wr ? offsets[wr - 1] : 0u);   // end of the last row written (exact when nothing was cut)
+    memcpy(entries, p_ent, (size_t)we * 8);
     return RMJ_OK;
 }
 int rmj_get_mask(rmj_handle h, uint8_t* mask) {
@@ -1773,7 +2000,7 @@ int rmj_agari_counts(int device, const uint8_t* counts, uint32_t n, uint8_t* is_
     HIPCHK(tmp.alloc(&d_t, n));
     HIPCHK(tmp.alloc(&d_w, (size_t)n * 8));
     HIPCHK(hipMemcpy(d_c, counts, (size_t)n * 34, hipMemcpyHostToDevice));
-    hipLaunchKernelGGL(k_agari_counts, game_grid(n), dim3(256), 0, 0, d_c, n, d_a, d_t, d_w);
+    hipLaunchKernelGGL(k_agari_counts, dim3((n + 15) / 16), dim3(256), 0, 0, d_c, n, d_a, d_t, d_w);
     HIPCHK(hipGetLastError());
     HIPCHK(hipDeviceSynchronize());
     HIPCHK(hipMemcpy(is_agari_out, d_a, n, hipMemcpyDeviceToHost));
@@ -2204,6 +2431,55 @@ int rmj_bench_encode(rmj_handle h, int extended, int only_active, float* d_out, 
         if ((rc = launch_encode(h, only_active, d_out, extended != 0))) return rc;
     HIPCHK(hipEventRecord(e1, h->stream));
     HIPCHK(hipEventSynchronize(e1));
+    float ms = 0.f;
+    HIPCHK(hipEventElapsedTime(&ms, e0, e1));
+    *avg_ms = (double)ms / reps;
+    return RMJ_OK;
+}
+// Kernel-gate benchmark (the groups of riichienv-core/benches/agari_bench.rs:142-376): average duration of
+// ONE launch of a hand-math kernel over `n` device-resident inputs, HIP events around `reps` back-to-back launches after a warm-up
+// launch; nothing is copied back.  which: 0 = k_eval_hands (a = RmjHandCase[n]), 1 = k_agari_counts (a = counts[n][34]),
+// 2 = k_shanten, 3 = k_ukeire effective tiles, 4 = k_ukeire best ukeire (b = visible[n][34]), 5 = k_score (a = han, fu, oya, tsumo,
+// num_players as five byte arrays of n one after the other; b = honba u32[n]).
+int rmj_bench_hand_kernel(int device, int which, const void* a, const void* b, uint32_t n, int sanma, uint32_t reps, double* avg_ms) {
+    DevTmp tmp;
+    if (!a || !avg_ms || n == 0 || reps == 0 || which < 0 || which > 5 || ((which == 4 || which == 5) && !b)) return fail(RMJ_ERR_ARG, "bad argument");
+    int rc = ensure_device(device);
+    if (rc) return rc;
+    ShantenTables T;
+    if ((rc = shanten_tables_for(device, &T))) return rc;
+    const size_t in_a = which == 0 ? (size_t)n * sizeof(RmjHandCase) : (which == 5 ? (size_t)n * 5 : (size_t)n * 34);
+    const size_t in_b = which == 4 ? (size_t)n * 34 : (which == 5 ? (size_t)n * 4 : 0);
+    uint8_t *d_a = nullptr, *d_b = nullptr, *d_o = nullptr;
+    HIPCHK(tmp.alloc(&d_a, in_a));
+    HIPCHK(hipMemcpy(d_a, a, in_a, hipMemcpyHostToDevice));
+    if (in_b) {
+        HIPCHK(tmp.alloc(&d_b, in_b));
+        HIPCHK(hipMemcpy(d_b, b, in_b, hipMemcpyHostToDevice));
+    }
+    HIPCHK(tmp.alloc(&d_o, (size_t)n * (which == 0 ? sizeof(RmjHandResult) : 16)));
+    hipEvent_t e0, e1;
+    HIPCHK(tmp.event(&e0));
+    HIPCHK(tmp.event(&e1));
+    auto launch = [&]() {
+        switch (which) {
+            case 0: hipLaunchKernelGGL(k_eval_hands, game_grid(n), dim3(256), 0, 0, (const RmjHandCase*)d_a, n, (RmjHandResult*)d_o); break;
+            case 1: hipLaunchKernelGGL(k_agari_counts, dim3((n + 15) / 16), dim3(256), 0, 0, (const uint8_t*)d_a, n, d_o, d_o + n, (uint64_t*)(d_o + 8 * (size_t)n)); break;
+            case 2: hipLaunchKernelGGL(k_shanten, dim3((n + 255) / 256), dim3(256), 0, 0, T, (const uint8_t*)d_a, n, sanma, (int8_t*)d_o); break;
+            case 3: hipLaunchKernelGGL(k_ukeire, dim3((n + 3) / 4), dim3(256), 0, 0, T, (const uint8_t*)d_a, (const uint8_t*)nullptr, n, sanma, 0, (uint32_t*)d_o); break;
+            case 4: hipLaunchKernelGGL(k_ukeire, dim3((n + 3) / 4), dim3(256), 0, 0, T, (const uint8_t*)d_a, (const uint8_t*)d_b, n, sanma, 1, (uint32_t*)d_o); break;
+            default: hipLaunchKernelGGL(k_score, dim3((n + 255) / 256), dim3(256), 0, 0, (const uint8_t*)d_a, (const uint8_t*)d_a + n, (const uint8_t*)d_a + 2 * (size_t)n,
+                                        (const uint8_t*)d_a + 3 * (size_t)n, (const uint32_t*)d_b, (const uint8_t*)d_a + 4 * (size_t)n, n, (uint32_t*)d_o); break;
+        }
+    };
+    launch();
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipDeviceSynchronize());
+    HIPCHK(hipEventRecord(e0, 0));
+    for (uint32_t i = 0; i < reps; i++) launch();
+    HIPCHK(hipEventRecord(e1, 0));
+    HIPCHK(hipEventSynchronize(e1));
+    HIPCHK(hipGetLastError());
     float ms = 0.f;
     HIPCHK(hipEventElapsedTime(&ms, e0, e1));
     *avg_ms = (double)ms / reps;

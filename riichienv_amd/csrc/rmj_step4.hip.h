@@ -43,11 +43,16 @@ struct Quad4Tier0 {
     uint64_t lst[4][4][R4_LIST];                   // staged legal lists per (game, seat)
     uint32_t mk[4][4][4];                          // 82-bit action-id masks per (game, seat), built with LDS atomics
 };
+struct Quad4Enc {          // byte staging of Observation.encode() inside the fused step + encode rollout (after the step: the union is free)
+    alignas(16) uint8_t raw[(ENC_CH * (KSANMA ? ENC_W3 : ENC_W4) + 4 + 15) / 16 * 16];
+    uint32_t hist[ENC_HIST_WORDS];
+};
 struct Quad4Shared {
     GState st[4];
     union {
         WaveScratch x;   // scratch of the full path (bailed games, after the tier-0 rows have been stored)
         Quad4Tier0 t;
+        Quad4Enc e;
     } u;
 };
 
@@ -1668,6 +1673,93 @@ __global__ __launch_bounds__(64, RMJ_STEP4_WAVES) void k_step4_fixup(const Env* 
     const uint64_t gs_row = sm64(policy_seed + ((CEnv*)Ep)->game_offset + (uint64_t)g);
 #pragma unroll 1
     for (uint32_t it = 0; it < n_steps; it++) step4_call<true, POL>(Ep, policy_seed, flags, 0u, n_games, it == 0 ? 1u : 0u, gs_row);
+}
+
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// The fused rollout WITH feature output (BASELINE configs[4]: sanma with the feature tensor): after every step of its four games
+// the wave writes Observation.encode() of the seats that are to act now into the resident tensor out[n][4][74][W] - the same rows
+// with the same contents as rmj_step_random + rmj_encode_device(only_active = 2) per step, without a launch boundary between the
+// issue-bound step and the store-bound encoder: while one wave streams its rows out, the others step.  The records are already in
+// LDS (no second fetch), the encoder's byte staging lives in the union the step has finished with.  Compiled for five waves per
+// SIMD: the encoder wants 85-96 registers.
+#define RMJ_STEP4_ENC_WAVES 5
+template <int POL>
+__device__ __noinline__ void step4_call_enc(const Env* Ep, uint64_t policy_seed, uint32_t flags, uint32_t g_base, uint32_t g_end, uint32_t load,
+                                            uint64_t gs_row, uint32_t quad, float* out) {
+    __shared__ Quad4Shared sh;
+    __shared__ float lut[ENC_LUT];
+    constexpr int W = KSANMA ? ENC_W3 : ENC_W4;
+    const int lane = threadIdx.x & 63;
+    g_base = uni(g_base); g_end = uni(g_end); quad = uni(quad);
+    out = uni_ptr(out);
+    if (uni(load) != 0u) enc_lut_init(lut, lane);
+    step4_body<true, POL>(uni_ptr(Ep), sh, uni(policy_seed), uni(flags), g_base, g_end, uni(load) != 0u, gs_row, nullptr, quad);
+    wave_sync();
+    const uint32_t g0 = g_base + (quad == 0xFFFFFFFFu ? blockIdx.x : quad) * 4u;
+#pragma unroll 1
+    for (int row = 0; row < 4; row++) {
+        const uint32_t g = g0 + (uint32_t)row;
+        if (g >= g_end) break;
+        const GState& S = sh.st[row];
+        uint32_t am = U((uint32_t)S.is_done) ? 0u : (U((uint32_t)S.active_mask) & (KSANMA ? 7u : 15u));
+        while (am) {
+            const int seat = __builtin_ctz(am);
+            am &= am - 1u;
+            float* dst = out + ((size_t)g * 4 + (size_t)seat) * ENC_CH * W;
+            const int head = (int)(((16u - (uint32_t)(reinterpret_cast<uintptr_t>(dst) & 15u)) & 15u) >> 2);  // 0 or 2 floats
+            EncByteSink<W> o{sh.u.e.raw + ((4 - head) & 3), lut, lane, -1.0f};
+            encode_seat_to<KSANMA>(S, seat, lane, sh.u.e.hist, o, true);
+            enc_emit_bytes<W>(dst, o.cells, lut, lane, head);
+            wave_sync();
+        }
+    }
+}
+template <int POL>
+__global__ __launch_bounds__(64, RMJ_STEP4_ENC_WAVES) void k_step4_enc(const Env* __restrict__ Ep, uint64_t policy_seed, uint32_t flags, uint32_t g_base,
+                                                                           uint32_t g_end, uint32_t n_steps, float* __restrict__ out) {
+    const uint32_t g = g_base + blockIdx.x * 4u + ((threadIdx.x & 63u) >> 4);
+    const uint64_t gs_row = sm64(policy_seed + ((CEnv*)Ep)->game_offset + (uint64_t)g);
+#pragma unroll 1
+    for (uint32_t it = 0; it < n_steps; it++) step4_call_enc<POL>(Ep, policy_seed, flags, g_base, g_end, it == 0 ? 1u : 0u, gs_row, 0xFFFFFFFFu, out);
+}
+// the same as tickets (see k_step4_queue): a quad's chunks - its records, lists and tensor rows - stay on one XCD
+template <int POL>
+__global__ __launch_bounds__(64, RMJ_STEP4_ENC_WAVES) void k_step4_queue_enc(const Env* __restrict__ Ep, uint64_t policy_seed, uint32_t flags, uint32_t n_games,
+                                                                                 uint32_t n_steps, uint32_t chunk, uint32_t* __restrict__ heads, uint32_t* __restrict__ done,
+                                                                                 uint32_t skip_xcds, float* __restrict__ out) {
+    const uint32_t xcd = (uint32_t)__builtin_amdgcn_s_getreg((3 << 11) | 20) & 7u;   // HW_REG_XCC_ID[3:0]
+    if ((skip_xcds >> xcd) & 1u) return;
+    const uint32_t n_quads = (n_games + 3u) / 4u;
+    const uint32_t mine = n_quads > xcd ? (n_quads - xcd + 7u) / 8u : 0u;
+    const uint32_t n_chunks = (n_steps + chunk - 1u) / chunk;
+    const uint32_t lane = threadIdx.x & 63u;
+    if (mine == 0u) return;
+#pragma unroll 1
+    for (;;) {
+        const uint32_t t = q_take_ticket(heads + xcd * RMJ_Q_STRIDE);
+        if (t >= mine * n_chunks) break;
+        const uint32_t c = t / mine, quad = (t - c * mine) * 8u + xcd;
+        if (c > 0u) q_wait_for(done + quad, c);
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        const uint32_t steps = n_steps - c * chunk < chunk ? n_steps - c * chunk : chunk;
+        const uint32_t g = quad * 4u + (lane >> 4);
+        const uint64_t gs_row = sm64(policy_seed + ((CEnv*)Ep)->game_offset + (uint64_t)g);
+#pragma unroll 1
+        for (uint32_t it = 0; it < steps; it++) step4_call_enc<POL>(Ep, policy_seed, flags, 0u, n_games, it == 0 ? 1u : 0u, gs_row, quad, out);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        wave_sync();
+        if (lane == 0u) __hip_atomic_store(done + quad, c + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+template <int POL>
+__global__ __launch_bounds__(64, RMJ_STEP4_ENC_WAVES) void k_step4_fixup_enc(const Env* __restrict__ Ep, uint64_t policy_seed, uint32_t flags, uint32_t n_games,
+                                                                                 uint32_t n_steps, const uint32_t* __restrict__ done, float* __restrict__ out) {
+    if (uni(__hip_atomic_load(done + blockIdx.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) != 0u) return;
+    const uint32_t g = blockIdx.x * 4u + ((threadIdx.x & 63u) >> 4);
+    const uint64_t gs_row = sm64(policy_seed + ((CEnv*)Ep)->game_offset + (uint64_t)g);
+#pragma unroll 1
+    for (uint32_t it = 0; it < n_steps; it++) step4_call_enc<POL>(Ep, policy_seed, flags, 0u, n_games, it == 0 ? 1u : 0u, gs_row, 0xFFFFFFFFu, out);
 }
 
 }  // namespace RMJ_NS

@@ -124,6 +124,20 @@ class TorchVecEnv:
         self.sync()
         return self._scores
 
+    def points(self, rule_name="basic"):
+        """RiichiEnv.points(rule_name) (env.rs:691-727) of every game as a float64 tensor [n, 4] on the device (rmj_points_device):
+        the terminal reward of a trainer loop (riichienv-ml trainers/_ppo_worker.py reads env.points / env.ranks on the host)"""
+        rules = vecenv.VecRiichiEnv.POINT_RULES
+        if rule_name not in rules or (self.sanma and rule_name != "basic"):
+            raise ValueError(f"Unknown preset rule{' for 3P' if self.sanma else ''}: {rule_name}")
+        if not hasattr(self, "_points"):
+            self._points = self.torch.zeros((self.n, 4), dtype=self.torch.float64, device=self.device)
+            if not self.shared:
+                self.torch.cuda.current_stream(self.device).synchronize()
+        vecenv._chk(self.env.L.rmj_points_device(self.env.h, rules[rule_name], C.c_void_p(self._points.data_ptr())))
+        self.sync()
+        return self._points
+
     def ranks(self):
         """ranks() of env.rs:673-689 (1 = first; ties broken by seat) computed on the device from scores()"""
         sc = self.scores().to(self.torch.int64)

@@ -27,7 +27,7 @@ EXPORTS = [
     "rmj_get_waits", "rmj_get_scores", "rmj_get_ranks", "rmj_get_step_counts", "rmj_total_steps", "rmj_peek_state",
     "rmj_poke_state", "rmj_get_event_counts", "rmj_get_events", "rmj_format_event", "rmj_eval_hands",
     "rmj_agari_counts", "rmj_calculate_score", "rmj_shanten", "rmj_effective_tiles", "rmj_best_ukeire", "rmj_apply_events", "rmj_device_views", "rmj_step_ids_device", "rmj_clone", "rmj_copy_games", "rmj_copy_games_device",
-    "rmj_scores_device", "rmj_sync", "rmj_set_stream", "rmj_encode", "rmj_encode_device", "rmj_encode_extended", "rmj_encode_extended_device", "rmj_encode_aux", "rmj_encode_aux_device", "rmj_encode_seq", "rmj_encode_seq_device", "rmj_bench_rollout", "rmj_time_rollout", "rmj_step_greedy", "rmj_time_rollout_greedy",
+    "rmj_scores_device", "rmj_sync", "rmj_set_stream", "rmj_encode", "rmj_encode_device", "rmj_encode_extended", "rmj_encode_extended_device", "rmj_encode_aux", "rmj_encode_aux_device", "rmj_encode_seq", "rmj_encode_seq_device", "rmj_bench_rollout", "rmj_time_rollout", "rmj_step_greedy", "rmj_time_rollout_greedy", "rmj_bench_hand_kernel", "rmj_points_device", "rmj_get_points", "rmj_get_legal_compact",
     "rmj_bench_rollout_validated", "rmj_bench_encode", "rmj_set_rollout_streams", "rmj_total_full_path",
     "rmj_random_actions_device", "rmj_peek_outputs", "rmj_sample_ids_device",
     "rmj_encode_seq_delta", "rmj_encode_seq_delta_device", "rmj_step_random_encode",
@@ -120,6 +120,10 @@ def load_lib():
     L.rmj_bench_rollout_validated.argtypes = [vp, C.c_uint64, C.c_uint32, C.c_uint32, C.POINTER(abi.BenchResult)]
     L.rmj_time_rollout.argtypes = [vp, C.c_uint64, C.c_uint32, C.POINTER(abi.BenchResult)]
     L.rmj_step_greedy.argtypes = [vp, C.c_uint64, C.c_uint32, C.c_int, C.c_uint32]
+    L.rmj_get_legal_compact.argtypes = [vp, vp, vp, vp, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
+    L.rmj_points_device.argtypes = [vp, C.c_int, vp]
+    L.rmj_get_points.argtypes = [vp, C.c_int, vp]
+    L.rmj_bench_hand_kernel.argtypes = [C.c_int, C.c_int, vp, vp, C.c_uint32, C.c_int, C.c_uint32, C.POINTER(C.c_double)]
     L.rmj_time_rollout_greedy.argtypes = [vp, C.c_uint64, C.c_uint32, C.c_uint32, C.POINTER(abi.BenchResult)]
     L.rmj_bench_encode.argtypes = [vp, C.c_int, C.c_int, vp, C.c_uint32, C.POINTER(C.c_double)]
     L.rmj_set_rollout_streams.argtypes = [vp, C.c_int]
@@ -317,6 +321,23 @@ class VecRiichiEnv:
         _chk(self.L.rmj_get_legal(self.h, l.ctypes.data, c.ctypes.data))
         return l, c
 
+    def legal_compact(self):
+        """(index [k] = game * 4 + seat, offsets [k + 1], entries [m]): the ordered legal lists of the seats that are to act, in
+        (game, seat) order - rmj_get_legal_compact: ~110 B per game over PCIe instead of the 2 KB of legal()"""
+        cap_r = getattr(self, "_lc_rows", 0) or (self.n + self.n // 2 + 16)
+        cap_e = getattr(self, "_lc_ents", 0) or (self.n * 24 + 1024)
+        while True:
+            if getattr(self, "_lc_buf", None) is None or self._lc_buf[0].size < cap_r or self._lc_buf[2].size < cap_e:
+                self._lc_buf = (np.zeros(cap_r, np.uint32), np.zeros(cap_r + 1, np.uint32), np.zeros(cap_e, np.uint64))
+            idx, off, ent = self._lc_buf
+            nr, ne = C.c_uint32(), C.c_uint32()
+            _chk(self.L.rmj_get_legal_compact(self.h, idx.ctypes.data, off.ctypes.data, ent.ctypes.data, idx.size, ent.size, C.byref(nr), C.byref(ne)))
+            if nr.value <= idx.size and ne.value <= ent.size:
+                self._lc_rows, self._lc_ents = idx.size, ent.size
+                return idx[: nr.value], off[: nr.value + 1], ent[: ne.value]
+            cap_r, cap_e = max(cap_r, nr.value + nr.value // 8), max(cap_e, ne.value + ne.value // 8)
+            self._lc_buf = None
+
     def mask(self):
         m = np.zeros((self.n, 4, 82), np.uint8)
         _chk(self.L.rmj_get_mask(self.h, m.ctypes.data))
@@ -336,6 +357,16 @@ class VecRiichiEnv:
         r = np.zeros((self.n, 4), np.uint8)
         _chk(self.L.rmj_get_ranks(self.h, r.ctypes.data))
         return r
+
+    POINT_RULES = {"basic": 0, "ouza-tyoujyo": 1, "ouza-normal": 2}
+
+    def points(self, rule_name="basic"):
+        """RiichiEnv.points(rule_name) (env.rs:691-727) of every game: float64 [n, 4] computed on the device"""
+        if rule_name not in self.POINT_RULES or (self.game_mode >= 3 and rule_name != "basic"):
+            raise ValueError(f"Unknown preset rule{' for 3P' if self.game_mode >= 3 else ''}: {rule_name}")
+        out = np.zeros((self.n, 4), np.float64)
+        _chk(self.L.rmj_get_points(self.h, self.POINT_RULES[rule_name], out.ctypes.data))
+        return out
 
     def step_counts(self):
         s = np.zeros(self.n, np.uint64)

@@ -94,3 +94,24 @@ def test_longest_legal_lists_fit():
     env.check("many kans")
     n = len(env.g.legal(0))
     assert 14 <= n <= abi.MAX_LEGAL
+
+
+@pytest.mark.parametrize("mode,n", [(2, 1000), (5, 777), (0, 3)])
+def test_legal_compact_equals_the_list_slab(mode, n):
+    """rmj_get_legal_compact: one row per seat that is to act, (game, seat) order, entries = that seat's ordered list - the same
+    content as the [n][4][64] slab of rmj_get_legal, incl. finished games (no rows) and a ragged last block"""
+    from riichienv_amd import vecenv
+
+    env = vecenv.VecRiichiEnv(n, game_mode=mode, seed=77, event_ring=64)
+    env.reset()
+    for k in range(12):
+        env.step_random(9, 37 if k else 1, auto_reset=(k % 3 != 2))
+        act, ph, dn = env.status()
+        legal, cnt = env.legal()
+        idx, off, ent = env.legal_compact()
+        rows = [(g, s) for g in range(n) for s in range(4) if (act[g] >> s) & 1 and not dn[g] and cnt[g, s] > 0]
+        assert [int(x) for x in idx] == [g * 4 + s for g, s in rows]
+        assert off[0] == 0 and int(off[-1]) == len(ent) == sum(int(cnt[g, s]) for g, s in rows)
+        for i, (g, s) in enumerate(rows):
+            assert (ent[off[i]: off[i + 1]] == legal[g, s, : cnt[g, s]]).all(), (k, g, s)
+    env.close()

@@ -172,20 +172,23 @@ def test_65536_games_3p_with_feature_tensor():
     assert checked >= len(sample) // 2
 
 
-def test_fused_feature_rollout_equals_step_then_encode():
-    """rmj_step_random_encode (four parts on four streams, step + encode per part and step) must leave exactly the tensor
-    and the states of the unfused loop rmj_step_random(1) + rmj_encode_device per step."""
+@pytest.mark.parametrize("mode,n,fused", [(5, 32768, "1"), (2, 32768, "1"), (5, 4099, "1"), (5, 32768, "0")])
+def test_fused_feature_rollout_equals_step_then_encode(mode, n, fused, monkeypatch):
+    """rmj_step_random_encode - round 3: ONE launch in which every wave steps its four games and writes the rows of the seats that
+    are to act (k_step4_enc, as tickets k_step4_queue_enc; RMJ_ENC_FUSED=0: four parts on four streams, step + encode launches per
+    part) - must leave exactly the tensor and the states of the unfused loop rmj_step_random(1) + rmj_encode_device per step."""
     import torch
 
     from riichienv_amd import vecenv
 
-    n, steps, mode = 32768, 120, 5
+    steps, w = 120, (27 if mode >= 3 else 34)
+    monkeypatch.setenv("RMJ_ENC_FUSED", fused)
     a = vecenv.VecRiichiEnv(n, game_mode=mode, seed=SEED, event_ring=64)
     b = vecenv.VecRiichiEnv(n, game_mode=mode, seed=SEED, event_ring=64)
     a.reset()
     b.reset()
-    oa = torch.zeros((n, 4, 74, 27), dtype=torch.float32, device="cuda:0")
-    ob = torch.zeros((n, 4, 74, 27), dtype=torch.float32, device="cuda:0")
+    oa = torch.zeros((n, 4, 74, w), dtype=torch.float32, device="cuda:0")
+    ob = torch.zeros((n, 4, 74, w), dtype=torch.float32, device="cuda:0")
     a.step_random_encode(PSEED, steps, oa.data_ptr(), auto_reset=True, only_active=2)
     for _ in range(steps):
         b.step_random(PSEED, 1, auto_reset=True)

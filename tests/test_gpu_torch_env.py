@@ -198,3 +198,32 @@ def test_readme_loop_compact_logits(shared):
         assert (ids[g[has], s[has]].long() == top[has]).all()
         assert int((ids >= 0).sum()) == int(has.sum())
         env.step(ids)
+
+
+@pytest.mark.parametrize("mode", [2, 5])
+def test_points_on_device(mode):
+    """rmj_points_device / rmj_get_points against RiichiEnv.points restated from env.rs:673-727 in float64 (ranks by score, ties by
+    seat; (score - base) / 1000 * weight + uma[rank - 1]); unknown rules raise like the reference."""
+    torch = pytest.importorskip("torch")
+    from riichienv_amd.torch_env import TorchVecEnv
+
+    n = 2048
+    env = TorchVecEnv(n, game_mode=mode, seed=5)
+    for k in range(300):
+        env.step(env.sample_ids(seed=k))
+    sc = env.scores().cpu().numpy().astype(np.int64)
+    npl = 3 if mode >= 3 else 4
+    presets = {"basic": (1.0, 35000.0, [40.0, 0.0, -40.0])} if npl == 3 else \
+        {"basic": (1.0, 25000.0, [50.0, 10.0, -10.0, -50.0]), "ouza-tyoujyo": (0.0, 25000.0, [100.0, 40.0, -40.0, -100.0]),
+         "ouza-normal": (0.0, 25000.0, [50.0, 20.0, -20.0, -50.0])}
+    assert len({tuple(r) for r in sc[:, :npl]}) > 10          # the games have diverged
+    for name, (w, base, uma) in presets.items():
+        want = np.zeros((n, 4))
+        for g in range(n):
+            order = sorted(range(npl), key=lambda p: (-sc[g, p], p))
+            for rank, p in enumerate(order):
+                want[g, p] = (float(sc[g, p]) - base) / 1000.0 * w + uma[rank]
+        assert (env.points(name).cpu().numpy() == want).all(), name
+        assert (env.env.points(name) == want).all(), name
+    with pytest.raises(ValueError):
+        env.points("ouza-normal" if npl == 3 else "nope")

@@ -274,11 +274,10 @@ def main(argv=None):
     barrier()
     t0 = time.perf_counter()
     if args.encode:
-        # every step of every game is followed by encode() of its acting seats into the resident tensor; like the plain
-        # rollout, the batch runs as four parts on four streams (step, encode, step, encode ... per part)
-        env.step_random_encode(policy_seed, args.steps, obs.data_ptr(), auto_reset=True, only_active=2)
-        env.sync()
-        r = None
+        # every step of every game is followed by encode() of its acting seats into the resident tensor: ONE launch in which
+        # every wave steps its four games and writes their rows (k_step4_enc / k_step4_queue_enc; RMJ_ENC_FUSED=0: four parts on
+        # four streams, step + encode launches per part); HIP events on the handle's stream around it
+        r = env.time_rollout_encode(policy_seed, args.steps, obs.data_ptr())
     else:
         # exactly K steps of every game and nothing else inside the region: HIP events on the handle's stream around the rollout
         # (returns when the second event has completed); the step counters are read outside
@@ -340,7 +339,12 @@ def main(argv=None):
     if rank == 0:
         b_step = B_STEP_3P if sanma else B_STEP_4P
         steps_per_launch = 1
-        if args.encode:
+        acting_now = extras["encode"][0] if "encode" in extras else 0
+        if args.encode and int(r.launches) == 1 and args.steps > 1:
+            # the step + encode rollout is ONE launch: per step of all games it moves the step's algorithmic bytes and one
+            # Observation.encode() per seat that is to act (counted on the final state: ~1.0 per game)
+            in_flight, kernel_ms, steps_per_launch = 1, r.total_ms, args.steps
+        elif args.encode:
             in_flight, kernel_ms = 1, r_enc_step
         elif int(r.launches) == 1 and args.steps > 1:
             # the rollout is ONE launch in which every wave steps its four games `steps` times: the launch processes
@@ -354,12 +358,16 @@ def main(argv=None):
         # (the committed counter summary is of the fused rollout kernel, per step of all games; the per-step launches of the
         #  feature rollout have no counter profile of their own)
         kernel_name = fused_kernel_name(r) if steps_per_launch > 1 else "k_step4<false>"
+        if args.encode and steps_per_launch > 1:
+            kernel_name = "k_step4_queue_enc" if int(r.queued) else "k_step4_enc"
         if greedy:
             kernel_name += " (greedy)"
-        traffic, traffic_src = (None, None) if args.encode else pmc_traffic("k_step4", games_per_launch, args.mode, ran_as=kernel_name)
+        traffic, traffic_src = pmc_traffic("k_step4_enc" if args.encode else "k_step4", games_per_launch, args.mode, ran_as=kernel_name)
         if traffic is not None:
             traffic *= steps_per_launch
         bytes_per_launch = b_step * games_per_launch * steps_per_launch
+        if args.encode and steps_per_launch > 1:
+            bytes_per_launch += (B_OBS_3P if sanma else B_OBS_4P) * acting_now * steps_per_launch
         achieved = in_flight * bytes_per_launch / (kernel_ms * 1e-3)
         out = {
             "metric": metric_name(args),

@@ -357,6 +357,11 @@ int rmj_device_views(rmj_handle h, RmjDeviceViews* out);
 /* step with the policy's action ids ([n][4] int32 on the device, -1 = no action): Observation.find_action
  * (observation/python.rs:119-122) + RiichiEnv.step; auto_reset != 0 restarts finished games like rmj_step_random */
 int rmj_step_ids_device(rmj_handle h, const int32_t* d_action_ids, int auto_reset);
+/* rmj_step_ids_device + rmj_encode_device(h, 2, d_out) as ONE launch: the step under the policy's ids, then Observation.encode() of
+ * the seats that are to act next into the resident tensor d_out [n][4][74][34 | 27] (rows of the other seats untouched) - the
+ * trainer loop's iteration (riichienv-ml trainers/_ppo_worker.py:151-239: step, then obs.encode() of the returned observations)
+ * with one launch gap instead of two. */
+int rmj_step_ids_encode_device(rmj_handle h, const int32_t* d_action_ids, int auto_reset, float* d_out);
 /* Masked categorical sampling for a policy on the same GPU (what riichienv-ml's PPO worker does per game on the host with
  * obs.mask(), trainers/_ppo_worker.py:164-239): for every seat that is to act, one action id drawn from
  * softmax(logits) restricted to the seat's legal ids (Gumbel-max on the resident mask slab); d_logits [n][4][stride] f32 on
@@ -475,6 +480,8 @@ int rmj_bench_rollout(rmj_handle h, uint64_t policy_seed, uint32_t warmup, uint3
  * (no counter launches, no host round trips besides the final event wait); env_steps / full_path_steps stay 0 - read
  * rmj_total_steps / rmj_total_full_path before and after.  What bench.py times. */
 int rmj_time_rollout(rmj_handle h, uint64_t policy_seed, uint32_t steps, RmjBenchResult* out);
+/* the same around rmj_step_random_encode(h, policy_seed, steps, 1, 2, d_out): launches = 1 when the rollout ran as one launch */
+int rmj_time_rollout_encode(rmj_handle h, uint64_t policy_seed, uint32_t steps, float* d_out, RmjBenchResult* out);
 /* the same around rmj_step_greedy(h, policy_seed, steps, 1, call_rate_256) */
 int rmj_time_rollout_greedy(rmj_handle h, uint64_t policy_seed, uint32_t steps, uint32_t call_rate_256, RmjBenchResult* out);
 /* The unfused counterpart: per step one policy launch (packed actions into a device buffer) and one step launch that

@@ -23,6 +23,8 @@ using namespace rmj;
 #define STEP_F_RANDOM 1u
 #define STEP_F_AUTORESET 2u
 #define STEP_F_IDS 4u /* `actions` holds int32 action ids [n][4] (Observation.find_action semantics) */
+#define STEP_F_QUIET 0x10000u   /* fused rollouts, every step but the last: no mask rows, no nlegal / waits / status words (nobody can read them) */
+#define STEP_F_ALLROWS 0x20000u /* fused rollouts, last step: all four mask rows are rewritten (the quiet steps left them stale) */
 #define STEP_F_GREEDY 8u /* with STEP_F_RANDOM: the greedy policy (rmj_step_greedy, r4_policy_greedy) instead of the RandomAgent; bits 8..15 = call rate / 256 */
 
 template <int N>
@@ -1215,6 +1217,20 @@ int rmj_step_ids_device(rmj_handle h, const int32_t* d_action_ids, int auto_rese
     HIPCHK(hipGetLastError());
     return RMJ_OK;
 }
+// rmj_step_ids_device + rmj_encode_device(only_active = 2) as ONE launch (k_step4_act_enc): the step of every game under the policy's
+// action ids, then Observation.encode() of the seats that are to act next into the resident tensor d_out [n][4][74][W].
+int rmj_step_ids_encode_device(rmj_handle h, const int32_t* d_action_ids, int auto_reset, float* d_out) {
+    if (!h || !d_action_ids || !d_out) return fail(RMJ_ERR_ARG, "null argument");
+    if (!h->quad) return fail(RMJ_ERR_ARG, "rmj_step_ids_encode_device runs in the four-games-per-wave kernels (RMJ_STEP4=0 selects the one-game kernel)");
+    HIPCHK(hipSetDevice(h->cfg.device));
+    const uint32_t flags = STEP_F_IDS | (auto_reset ? STEP_F_AUTORESET : 0u);
+    const uint32_t n = h->cfg.n_games;
+    const dim3 grid((n + 3u) / 4u);
+    if (h->cfg.game_mode >= 3) hipLaunchKernelGGL(rmj3::k_step4_act_enc, grid, dim3(64), 0, h->stream, (const Env*)h->d_env, flags, 0u, n, reinterpret_cast<const uint64_t*>(d_action_ids), d_out);
+    else hipLaunchKernelGGL(rmj4::k_step4_act_enc, grid, dim3(64), 0, h->stream, (const Env*)h->d_env, flags, 0u, n, reinterpret_cast<const uint64_t*>(d_action_ids), d_out);
+    HIPCHK(hipGetLastError());
+    return RMJ_OK;
+}
 int rmj_sample_ids_device(rmj_handle h, const float* d_logits, uint32_t stride, uint64_t seed, int32_t* d_ids) {
     if (!h || !d_ids) return fail(RMJ_ERR_ARG, "null argument");
     const uint32_t A = h->cfg.game_mode >= 3 ? RMJ_ACTION_SPACE_3P : RMJ_ACTION_SPACE_4P;
@@ -2348,6 +2364,32 @@ int rmj_bench_rollout(rmj_handle h, uint64_t policy_seed, uint32_t warmup, uint3
 // outside the region.
 int rmj_time_rollout(rmj_handle h, uint64_t policy_seed, uint32_t steps, RmjBenchResult* out) {
     return bench_rollout_impl(h, policy_seed, 0u, steps, out, false);
+}
+// the same around rmj_step_random_encode(h, policy_seed, steps, 1, 2, d_out) (BASELINE configs[4]); queued: the one-launch rollout ran as tickets
+int rmj_time_rollout_encode(rmj_handle h, uint64_t policy_seed, uint32_t steps, float* d_out, RmjBenchResult* out) {
+    DevTmp tmp;
+    if (!h || !out || !d_out) return fail(RMJ_ERR_ARG, "null argument");
+    HIPCHK(hipSetDevice(h->cfg.device));
+    hipEvent_t e0, e1;
+    HIPCHK(tmp.event(&e0));
+    HIPCHK(tmp.event(&e1));
+    HIPCHK(hipEventRecord(e0, h->stream));
+    int rc = rmj_step_random_encode(h, policy_seed, steps, 1, 2, d_out);
+    if (rc) return rc;
+    HIPCHK(hipEventRecord(e1, h->stream));
+    HIPCHK(hipEventSynchronize(e1));
+    float ms = 0.f;
+    HIPCHK(hipEventElapsedTime(&ms, e0, e1));
+    memset(out, 0, sizeof(*out));
+    const bool fused = h->enc_fused && h->quad >= 2 && h->want_streams >= 2 && steps >= 2;
+    const uint32_t quads = (h->cfg.n_games + 3u) / 4u, chunk = rollout_chunk(h, steps);
+    out->total_ms = ms;
+    out->step_kernel_ms = steps ? ms / steps : 0.0;
+    out->launches = fused ? 1u : 2u * steps;
+    out->launches_in_flight = 1u;
+    out->queued = (fused && h->queue_chunk > 0 && h->max_xcc_id <= 7u && steps >= 2u * chunk && h->q_slots_enc &&
+                   (h->queue_force ? quads >= 64u : (quads > h->q_slots_enc && quads < 8u * h->q_slots_enc))) ? 1u : 0u;
+    return RMJ_OK;
 }
 // the same around rmj_step_greedy(h, policy_seed, steps, 1, call_rate_256)
 int rmj_time_rollout_greedy(rmj_handle h, uint64_t policy_seed, uint32_t steps, uint32_t call_rate_256, RmjBenchResult* out) {

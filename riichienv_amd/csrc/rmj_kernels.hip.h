@@ -25,7 +25,7 @@ __device__ __noinline__ void ol_step_full(CtxV v, uint64_t mine, uint32_t flags)
     if (S.is_done && (flags & STEP_F_AUTORESET)) ol_env_reset_default(v);
     else step_game<false>(c, mine, (flags & STEP_F_RANDOM) != 0);
     TLF(c, 11);
-    finalize_outputs<false>(c, true);
+    finalize_outputs<false>(c, true, true, (flags & STEP_F_ALLROWS) != 0u);
     TLF(c, 12);
     store_state(S, c.E.core + c.g, c.lane);
     TLF(c, 13);

@@ -2246,7 +2246,7 @@ __device__ inline void apply_event(Ctx& c, const RmjEvent* ev) {
 // After a transition: produce the observation-side outputs for the new state
 // (get_observations(active_players), env.rs:870-871 -> state/mod.rs:189-263; mask: observation/python.rs:98-111)
 template <bool FAST = false>
-__device__ __forceinline__ void finalize_outputs(Ctx& c, bool claims_fresh, bool observe = true) {
+__device__ __forceinline__ void finalize_outputs(Ctx& c, bool claims_fresh, bool observe = true, bool all_rows = false) {
     GState& S = c.S;
     const int lane = c.lane;
     const int phase = U((int)S.phase);
@@ -2287,7 +2287,8 @@ __device__ __forceinline__ void finalize_outputs(Ctx& c, bool claims_fresh, bool
     // are not to act are all zero and stay so: only the rows of the seats that had a list before this step (S.nlegal
     // still holds the previous publication) or have one now are rewritten - 82 B per row in 16-bit units.
     const uint32_t am = (uint32_t)__builtin_amdgcn_readfirstlane((int)S.active_mask);
-    const uint32_t rows = (((uint32_t)__ballot(lane < 4 && S.nlegal[lane & 3] != 0)) | am) & 0xFu;
+    // (all_rows: the last step of a fused rollout - its quiet steps published no mask rows, so every row is rewritten)
+    const uint32_t rows = all_rows ? 0xFu : ((((uint32_t)__ballot(lane < 4 && S.nlegal[lane & 3] != 0)) | am) & 0xFu);
     for (int i = lane; i < (4 * 82 + 3) / 4; i += 64) reinterpret_cast<uint32_t*>(c.X.maskbuf)[i] = 0u;
     wave_sync();
     for (uint32_t m = am; m; m &= m - 1u) {

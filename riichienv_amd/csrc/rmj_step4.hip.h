@@ -1471,9 +1471,13 @@ __device__ __forceinline__ void step4_body(const Env* Ep, Quad4Shared& sh, uint6
         const uint32_t am = G->active_mask;
         const bool acts = r < 4 && ((am >> r) & 1u);
         const int n_me = acts ? nl_mine : 0;
-        // masks: 82-bit id sets per seat by LDS atomics, rows of seats that had or have a list are rewritten
-        const uint32_t rows = (rballot(r < 4 && G->nlegal[r & 3] != 0, rb) | am) & 0xFu;
-        q.T->mk[row][r >> 2][r & 3] = 0u;
+        // masks: 82-bit id sets per seat by LDS atomics, rows of seats that had or have a list are rewritten.
+        // Inside a fused rollout only the LAST step's observation can be read by anybody (the policy reads the lists and the
+        // record): the steps before it (STEP_F_QUIET) publish lists, record and events only - no mask rows, no nlegal / waits /
+        // status words - and the last one (STEP_F_ALLROWS) rewrites all four mask rows, whatever the quiet steps left behind.
+        const bool quiet = LOOP && (flags & STEP_F_QUIET) != 0u;
+        const uint32_t rows = quiet ? 0u : ((LOOP && (flags & STEP_F_ALLROWS)) ? 0xFu : ((rballot(r < 4 && G->nlegal[r & 3] != 0, rb) | am) & 0xFu));
+        if (!quiet) q.T->mk[row][r >> 2][r & 3] = 0u;
         wave_sync();
         for (uint32_t m = am; m; m &= m - 1u) {
             const int p = __ffs((int)m) - 1;
@@ -1482,7 +1486,7 @@ __device__ __forceinline__ void step4_body(const Env* Ep, Quad4Shared& sh, uint6
                 const uint64_t e = q.T->lst[row][p][r];
                 (E.legal + (size_t)g * 4 * RMJ_MAX_LEGAL)[p * RMJ_MAX_LEGAL + r] = e & 0x00FFFFFFFFFFFFFFull;
                 const int id = (int)(e >> 56);     // the id travels with the staged entry (r4_put)
-                atomicOr(&q.T->mk[row][p][id >> 5], 1u << (id & 31));
+                if (!quiet) atomicOr(&q.T->mk[row][p][id >> 5], 1u << (id & 31));
             }
         }
         wave_sync();
@@ -1500,15 +1504,15 @@ __device__ __forceinline__ void step4_body(const Env* Ep, Quad4Shared& sh, uint6
             }
         }
         if (r < 4) {
-            E.nlegal[(size_t)g * 4 + r] = (uint8_t)n_me;
+            if (!quiet) E.nlegal[(size_t)g * 4 + r] = (uint8_t)n_me;
             G->nlegal[r] = (uint8_t)n_me;
-            E.waits[(size_t)g * 4 + r] = acts ? w_mine : 0ull;
+            if (!quiet) E.waits[(size_t)g * 4 + r] = acts ? w_mine : 0ull;
             if (acts && !G->is_done) {
                 G->obs_from[r] = G->obs_upto[r];
                 G->obs_upto[r] = G->ev_count;
             }
         }
-        if (r == 0) E.status[g] = (uint32_t)G->active_mask | ((uint32_t)G->phase << 8) | ((uint32_t)G->is_done << 16);
+        if (r == 0 && !quiet) E.status[g] = (uint32_t)G->active_mask | ((uint32_t)G->phase << 8) | ((uint32_t)G->is_done << 16);
         // staged events -> ring
         if (r < 2 * q.evn) {
             const int e = r >> 1, hh = r & 1;
@@ -1589,7 +1593,8 @@ __global__ __launch_bounds__(64, RMJ_STEP4_WAVES) void k_step4(const Env* __rest
         const uint32_t g = g_base + blockIdx.x * 4u + ((threadIdx.x & 63u) >> 4);
         const uint64_t gs_row = sm64(policy_seed + ((CEnv*)Ep)->game_offset + (uint64_t)g);   // policy key of the row's game
 #pragma unroll 1
-        for (uint32_t it = 0; it < n_steps; it++) step4_call<true, POL>(Ep, policy_seed, flags, g_base, g_end, it == 0 ? 1u : 0u, gs_row);
+        for (uint32_t it = 0; it < n_steps; it++)
+            step4_call<true, POL>(Ep, policy_seed, flags | (it + 1u < n_steps ? STEP_F_QUIET : STEP_F_ALLROWS), g_base, g_end, it == 0 ? 1u : 0u, gs_row);
     } else {
         __shared__ Quad4Shared sh;
 #ifdef RMJ_TL4
@@ -1654,8 +1659,10 @@ __global__ __launch_bounds__(64, RMJ_STEP4_WAVES) void k_step4_queue(const Env* 
         const uint32_t steps = n_steps - c * chunk < chunk ? n_steps - c * chunk : chunk;
         const uint32_t g = quad * 4u + (lane >> 4);
         const uint64_t gs_row = sm64(policy_seed + ((CEnv*)Ep)->game_offset + (uint64_t)g);
+        const bool last_chunk = c + 1u == n_chunks;
 #pragma unroll 1
-        for (uint32_t it = 0; it < steps; it++) step4_call<true, POL>(Ep, policy_seed, flags, 0u, n_games, it == 0 ? 1u : 0u, gs_row, quad);
+        for (uint32_t it = 0; it < steps; it++)
+            step4_call<true, POL>(Ep, policy_seed, flags | ((last_chunk && it + 1u == steps) ? STEP_F_ALLROWS : STEP_F_QUIET), 0u, n_games, it == 0 ? 1u : 0u, gs_row, quad);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this chunk's stores are in the XCD's L2
         wave_sync();
         if (lane == 0u) __hip_atomic_store(done + quad, c + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1672,7 +1679,8 @@ __global__ __launch_bounds__(64, RMJ_STEP4_WAVES) void k_step4_fixup(const Env* 
     const uint32_t g = blockIdx.x * 4u + ((threadIdx.x & 63u) >> 4);
     const uint64_t gs_row = sm64(policy_seed + ((CEnv*)Ep)->game_offset + (uint64_t)g);
 #pragma unroll 1
-    for (uint32_t it = 0; it < n_steps; it++) step4_call<true, POL>(Ep, policy_seed, flags, 0u, n_games, it == 0 ? 1u : 0u, gs_row);
+    for (uint32_t it = 0; it < n_steps; it++)
+        step4_call<true, POL>(Ep, policy_seed, flags | (it + 1u < n_steps ? STEP_F_QUIET : STEP_F_ALLROWS), 0u, n_games, it == 0 ? 1u : 0u, gs_row);
 }
 
 
@@ -1684,9 +1692,9 @@ __global__ __launch_bounds__(64, RMJ_STEP4_WAVES) void k_step4_fixup(const Env* 
 // LDS (no second fetch), the encoder's byte staging lives in the union the step has finished with.  Compiled for five waves per
 // SIMD: the encoder wants 85-96 registers.
 #define RMJ_STEP4_ENC_WAVES 5
-template <int POL>
+template <bool LOOP, int POL>
 __device__ __noinline__ void step4_call_enc(const Env* Ep, uint64_t policy_seed, uint32_t flags, uint32_t g_base, uint32_t g_end, uint32_t load,
-                                            uint64_t gs_row, uint32_t quad, float* out) {
+                                            uint64_t gs_row, uint32_t quad, float* out, const uint64_t* actions = nullptr) {
     __shared__ Quad4Shared sh;
     __shared__ float lut[ENC_LUT];
     constexpr int W = KSANMA ? ENC_W3 : ENC_W4;
@@ -1694,7 +1702,7 @@ __device__ __noinline__ void step4_call_enc(const Env* Ep, uint64_t policy_seed,
     g_base = uni(g_base); g_end = uni(g_end); quad = uni(quad);
     out = uni_ptr(out);
     if (uni(load) != 0u) enc_lut_init(lut, lane);
-    step4_body<true, POL>(uni_ptr(Ep), sh, uni(policy_seed), uni(flags), g_base, g_end, uni(load) != 0u, gs_row, nullptr, quad);
+    step4_body<LOOP, POL>(uni_ptr(Ep), sh, uni(policy_seed), uni(flags), g_base, g_end, uni(load) != 0u, gs_row, LOOP ? nullptr : uni_ptr(actions), quad);
     wave_sync();
     const uint32_t g0 = g_base + (quad == 0xFFFFFFFFu ? blockIdx.x : quad) * 4u;
 #pragma unroll 1
@@ -1721,7 +1729,15 @@ __global__ __launch_bounds__(64, RMJ_STEP4_ENC_WAVES) void k_step4_enc(const Env
     const uint32_t g = g_base + blockIdx.x * 4u + ((threadIdx.x & 63u) >> 4);
     const uint64_t gs_row = sm64(policy_seed + ((CEnv*)Ep)->game_offset + (uint64_t)g);
 #pragma unroll 1
-    for (uint32_t it = 0; it < n_steps; it++) step4_call_enc<POL>(Ep, policy_seed, flags, g_base, g_end, it == 0 ? 1u : 0u, gs_row, 0xFFFFFFFFu, out);
+    for (uint32_t it = 0; it < n_steps; it++)
+        step4_call_enc<true, POL>(Ep, policy_seed, flags | (it + 1u < n_steps ? STEP_F_QUIET : STEP_F_ALLROWS), g_base, g_end, it == 0 ? 1u : 0u, gs_row, 0xFFFFFFFFu, out);
+}
+// One step driven by the caller's action ids / packed actions + the rows of the seats that are to act next: what a trainer loop
+// issues per iteration (rmj_step_ids_encode_device) - one launch instead of a step launch and an encoder launch, the encoder's
+// stores under the tail of the step (the last third of a per-step launch belongs to the few waves that carry a full-path game).
+__global__ __launch_bounds__(64, RMJ_STEP4_ENC_WAVES) void k_step4_act_enc(const Env* __restrict__ Ep, uint32_t flags, uint32_t g_base, uint32_t g_end,
+                                                                               const uint64_t* __restrict__ actions, float* __restrict__ out) {
+    step4_call_enc<false, 0>(Ep, 0ull, flags, g_base, g_end, 1u, 0ull, 0xFFFFFFFFu, out, actions);
 }
 // the same as tickets (see k_step4_queue): a quad's chunks - its records, lists and tensor rows - stay on one XCD
 template <int POL>
@@ -1745,8 +1761,10 @@ __global__ __launch_bounds__(64, RMJ_STEP4_ENC_WAVES) void k_step4_queue_enc(con
         const uint32_t steps = n_steps - c * chunk < chunk ? n_steps - c * chunk : chunk;
         const uint32_t g = quad * 4u + (lane >> 4);
         const uint64_t gs_row = sm64(policy_seed + ((CEnv*)Ep)->game_offset + (uint64_t)g);
+        const bool last_chunk = c + 1u == n_chunks;
 #pragma unroll 1
-        for (uint32_t it = 0; it < steps; it++) step4_call_enc<POL>(Ep, policy_seed, flags, 0u, n_games, it == 0 ? 1u : 0u, gs_row, quad, out);
+        for (uint32_t it = 0; it < steps; it++)
+            step4_call_enc<true, POL>(Ep, policy_seed, flags | ((last_chunk && it + 1u == steps) ? STEP_F_ALLROWS : STEP_F_QUIET), 0u, n_games, it == 0 ? 1u : 0u, gs_row, quad, out);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         wave_sync();
         if (lane == 0u) __hip_atomic_store(done + quad, c + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1759,7 +1777,8 @@ __global__ __launch_bounds__(64, RMJ_STEP4_ENC_WAVES) void k_step4_fixup_enc(con
     const uint32_t g = blockIdx.x * 4u + ((threadIdx.x & 63u) >> 4);
     const uint64_t gs_row = sm64(policy_seed + ((CEnv*)Ep)->game_offset + (uint64_t)g);
 #pragma unroll 1
-    for (uint32_t it = 0; it < n_steps; it++) step4_call_enc<POL>(Ep, policy_seed, flags, 0u, n_games, it == 0 ? 1u : 0u, gs_row, 0xFFFFFFFFu, out);
+    for (uint32_t it = 0; it < n_steps; it++)
+        step4_call_enc<true, POL>(Ep, policy_seed, flags | (it + 1u < n_steps ? STEP_F_QUIET : STEP_F_ALLROWS), 0u, n_games, it == 0 ? 1u : 0u, gs_row, 0xFFFFFFFFu, out);
 }
 
 }  // namespace RMJ_NS

@@ -157,6 +157,20 @@ class TorchVecEnv:
         vecenv._chk(self.env.L.rmj_step_ids_device(self.env.h, C.c_void_p(ids.data_ptr()), int(auto_reset)))
         self.sync()
 
+    def step_obs(self, action_ids, auto_reset=True):
+        """step(action_ids) and obs(only_active=True) as ONE launch (rmj_step_ids_encode_device): returns the resident tensor
+        [n, 4, 74, W] whose rows of the seats that are to act next have just been written.  Base encoding only."""
+        if self.extended:
+            raise vecenv.RmjError("step_obs() covers Observation.encode(); use step() + obs() for encode_extended()")
+        t = self.torch
+        ids = action_ids.to(device=self.device, dtype=t.int32).contiguous()
+        assert ids.shape == (self.n, 4)
+        if not self.shared:
+            t.cuda.current_stream(self.device).synchronize()
+        vecenv._chk(self.env.L.rmj_step_ids_encode_device(self.env.h, C.c_void_p(ids.data_ptr()), int(auto_reset), C.c_void_p(self._obs.data_ptr())))
+        self.sync()
+        return self._obs
+
     def sync(self):
         """own stream: wait for the library's work; shared stream: nothing to do, torch's stream orders it"""
         if not self.shared:
@@ -255,6 +269,15 @@ class ShardedTorchVecEnv:
         def one(e, _i):
             ids = policy(e, *e.obs_compact(sync_count=False)) if compact else policy(e, e.obs(only_active=True))
             e.step(ids, auto_reset=auto_reset)
+        self.for_each(one)
+
+    def step_policy_one_launch(self, policy, auto_reset=True):
+        """One step of every game with step + encode as ONE launch per shard (TorchVecEnv.step_obs): per shard,
+        `policy(shard, obs [per, 4, 74, W]) -> int32 ids [per, 4]` on the observations the previous call left, then step_obs."""
+        def one(e, _i):
+            if getattr(e, "_cur_obs", None) is None:
+                e._cur_obs = e.obs(only_active=True)
+            e._cur_obs = e.step_obs(policy(e, e._cur_obs), auto_reset=auto_reset)
         self.for_each(one)
 
     def synchronize(self):

@@ -51,6 +51,54 @@ def run(n, ext, shared, fused=False):
           f"loop {steps / (t1 - t0) / 1e6:.1f} M env.step/s, {(t1 - t0) / K * 1e3:.2f} ms per iteration{parts}")
 
 
+def run_one_launch(n):
+    """the loop with step + encode as ONE launch per iteration (TorchVecEnv.step_obs -> rmj_step_ids_encode_device) and the fused sampler"""
+    env = TorchVecEnv(n, game_mode=2, seed=0, share_stream=True)
+    env.obs(only_active=True)
+    for k in range(20):
+        env.step_obs(env.sample_ids(seed=k + 1))
+    torch.cuda.synchronize()
+    steps0 = env.env.total_steps()
+    K = 100
+    t0 = time.perf_counter()
+    for k in range(K):
+        env.step_obs(env.sample_ids(seed=100 + k))
+    torch.cuda.synchronize()
+    t1 = time.perf_counter()
+    steps = env.env.total_steps() - steps0
+    print(f"games {n} channels 74 fused masked sampler + step and encode as one launch (rmj_step_ids_encode_device), shared stream: "
+          f"loop {steps / (t1 - t0) / 1e6:.1f} M env.step/s, {(t1 - t0) / K * 1e3:.2f} ms per iteration")
+
+
+def run_parts_one_launch(n, parts):
+    """shards on streams, step + encode as one launch per shard and iteration"""
+    from riichienv_amd.torch_env import ShardedTorchVecEnv
+
+    env = ShardedTorchVecEnv(n, parts=parts, game_mode=2, seed=0)
+    it = 0
+
+    def one_round():
+        nonlocal it
+        it += 1
+        env.step_policy_one_launch(lambda e, obs: e.sample_ids(seed=it))
+
+    for _ in range(20):
+        one_round()
+    torch.cuda.synchronize()
+    env.synchronize()
+    steps0 = sum(e.env.total_steps() for e in env.shards)
+    K = 100
+    t0 = time.perf_counter()
+    for _ in range(K):
+        one_round()
+    torch.cuda.synchronize()
+    env.synchronize()
+    t1 = time.perf_counter()
+    steps = sum(e.env.total_steps() for e in env.shards) - steps0
+    print(f"games {n} as {parts} shards on {parts} streams, step and encode as one launch per shard, fused masked sampler: "
+          f"loop {steps / (t1 - t0) / 1e6:.1f} M env.step/s, {(t1 - t0) / K * 1e3:.2f} ms per iteration")
+
+
 def run_parts(n, parts, compact=False):
     """The same loop on ShardedTorchVecEnv: the batch as `parts` shards (by game index) on `parts` torch streams - the store-bound
     encoder of one shard runs under the issue-bound step of another (what rmj_step_random_encode does inside the library)."""
@@ -88,9 +136,12 @@ def main():
     run(n, ext, False, fused=True)
     run(n, ext, True, fused=True)
     if not ext:
+        run_one_launch(n)
         for parts in (2, 4):
             run_parts(n, parts)
         run_parts(n, 4, compact=True)
+        for parts in (2, 4):
+            run_parts_one_launch(n, parts)
 
 
 if __name__ == "__main__":

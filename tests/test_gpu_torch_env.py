@@ -227,3 +227,26 @@ def test_points_on_device(mode):
         assert (env.env.points(name) == want).all(), name
     with pytest.raises(ValueError):
         env.points("ouza-normal" if npl == 3 else "nope")
+
+
+@pytest.mark.parametrize("mode", [2, 5])
+def test_step_obs_equals_step_then_obs(mode):
+    """rmj_step_ids_encode_device (one launch) leaves the tensor and the games of step() + obs(only_active=True)"""
+    torch = pytest.importorskip("torch")
+    from riichienv_amd.torch_env import TorchVecEnv
+
+    n = 4096
+    a = TorchVecEnv(n, game_mode=mode, seed=41, share_stream=True)
+    b = TorchVecEnv(n, game_mode=mode, seed=41, share_stream=True)
+    oa = a.obs(only_active=True)
+    ob = b.obs(only_active=True)
+    for k in range(150):
+        ids = a.sample_ids(seed=k).clone()
+        oa = a.step_obs(ids)
+        b.step(ids)
+        ob = b.obs(only_active=True)
+        if k % 25 == 0:
+            assert torch.equal(oa, ob), k
+    torch.cuda.synchronize()
+    assert torch.equal(oa, ob) and torch.equal(a.mask, b.mask) and torch.equal(a.scores(), b.scores())
+    assert (a.env.step_counts() == b.env.step_counts()).all() and float(oa.abs().sum()) > 0

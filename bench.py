@@ -115,22 +115,51 @@ print(s, t)
 """
 
 
+def usable_cores():
+    """CPUs this process may actually use: the smaller of the scheduler affinity and the cgroup CPU quota (cpu.max / cfs_quota_us).
+    os.cpu_count() reports the host's hardware threads (256 on the GPU box) even when the container is limited to a few of them -
+    round 2's "9.5 x one thread on 256 threads" was that limit, not allocator contention: 256 single-threaded worker PROCESSES
+    reach the same total."""
+    n = os.cpu_count() or 1
+    try:
+        n = min(n, len(os.sched_getaffinity(0)))
+    except (AttributeError, OSError):
+        pass
+    quota = None
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:                       # cgroup v2: "<quota> <period>" or "max <period>"
+            q, per = f.read().split()[:2]
+            if q != "max":
+                quota = float(q) / float(per)
+    except (OSError, ValueError):
+        try:
+            with open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us") as f, open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as g:   # cgroup v1
+                q, per = float(f.read()), float(g.read())
+                if q > 0:
+                    quota = q / per
+        except (OSError, ValueError):
+            pass
+    if quota is not None:
+        n = max(1, min(n, int(quota + 0.5)))
+    return n
+
+
 def cpu_baseline(game_mode, rule_bits, policy_seed, target_s=15.0):
     """Oracle (CPU restatement of riichienv-core, kind="port") on the host cores: bounded sample.  Must run BEFORE this process
-    touches the GPU: the all-cores figure comes from one single-threaded worker PROCESS per hardware thread (children of this
-    process), because the oracle allocates std::map / vector / string per step and 256 threads of one process spend their time in
-    the allocator (round 2: 9.5x one thread on 256 threads).  Reported beside it: the same workload as threads of one process
-    (`threads_value`) and parallel_efficiency = value / (cores x single-thread rate)."""
+    touches the GPU (it starts worker processes).  The all-cores figure comes from one single-threaded worker PROCESS per usable
+    core - `cores` = usable_cores(), the container's CPU allowance, not the host's hardware threads (`hardware_threads`).  Reported
+    beside it: the same workload as threads of one process (`threads_value`) and parallel_efficiency = value / (cores x
+    single-thread rate)."""
     from oracle import oracle
 
-    cores = os.cpu_count() or 1
+    cores = usable_cores()
     # one thread, ~3 s: the per-core rate (SURVEY.md §8(d))
     s1, t1 = oracle.bench_rollout(game_mode, rule_bits, False, 8, 0, policy_seed, 200, 1)
     per1 = int(max(200, min(200000, (s1 / max(t1, 1e-9)) * 3.0 / 8)))
     s1, t1 = oracle.bench_rollout(game_mode, rule_bits, False, 8, 0, policy_seed, per1, 1)
     rate1 = s1 / t1
-    # all cores: `cores` processes x 8 games, sized for ~target_s seconds at HALF the single-thread rate (SMT siblings share a core)
-    per_game = int(max(200, min(200000, 0.5 * rate1 * target_s / 8)))
+    # all cores: `cores` processes x 8 games, sized for ~target_s seconds at 0.8 x the single-thread rate
+    per_game = int(max(200, min(200000, 0.8 * rate1 * target_s / 8)))
     t0 = time.perf_counter()
     procs = [subprocess.Popen([sys.executable, "-c", _WORKER, ROOT, str(game_mode), str(rule_bits), str(policy_seed), str(8 * i), "8",
                                str(per_game)], stdout=subprocess.PIPE, text=True) for i in range(cores)]
@@ -144,13 +173,13 @@ def cpu_baseline(game_mode, rule_bits, policy_seed, target_s=15.0):
     th_games = cores * 8
     per_th = max(100, per_game // 32)
     st, tt = oracle.bench_rollout(game_mode, rule_bits, False, th_games, 0, policy_seed, per_th, cores)
-    return {"value": steps / secs, "unit": "env.step/s", "cores": cores, "kind": "port",
+    return {"value": steps / secs, "unit": "env.step/s", "cores": cores, "hardware_threads": os.cpu_count() or 1, "kind": "port",
             "sample": f"{cores} worker processes x 8 games x {per_game} steps (one thread each), slowest worker {secs:.1f}s "
                       f"({wall:.1f}s with process start), oracle/ C++ restatement with MJAI logging on (Rust toolchain unavailable)",
             "parallel_efficiency": steps / secs / (cores * rate1),
             "single_thread": {"value": rate1, "sample": f"8 games x {per1} steps, {t1:.1f}s"},
             "threads_value": {"value": st / tt, "sample": f"{th_games} games x {per_th} steps as {cores} threads of one process, {tt:.1f}s "
-                                                        "(allocator contention: the oracle allocates containers per step)"}}
+                                                        "(the oracle allocates containers per step)"}}
 
 
 def pmc_traffic(kernel, games_per_launch, mode, ran_as=None):

@@ -97,7 +97,8 @@ def cpu_leg(which, secs, seed=0):
 
 
 def cpu_all(secs):
-    cores = os.cpu_count() or 1
+    from bench import usable_cores
+    cores = usable_cores()                   # the container's CPU allowance, not the host's hardware threads
     rows = {}
     for _, which in KERNELS:
         n1, t1 = cpu_leg(which, secs)

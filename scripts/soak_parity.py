@@ -2,7 +2,8 @@
 """Parity soak (not part of the test suite): long device-policy rollouts of every game mode under both rule sets and
 several seeds, compared with the oracle game by game - final state, legal lists, masks, waits, step counts and the whole
 MJAI log of every game.  usage: python scripts/soak_parity.py [games] [steps] [seeds] [first seed index]
-(RMJ_QUEUE_FORCE=1 with >= 256 games runs the rollouts as (quad, chunk) tickets, kernel k_step4_queue, instead of one quad per wave)"""
+(RMJ_QUEUE_FORCE=1 with >= 256 games runs the rollouts as (quad, chunk) tickets, kernel k_step4_queue, instead of one quad per wave;
+RMJ_SOAK_POLICY=greedy: the device policy that plays to win, rmj_step_greedy, against the oracle's twin orc_game_greedy_actions)"""
 import os
 import sys
 import time
@@ -18,6 +19,8 @@ n = int(sys.argv[1]) if len(sys.argv) > 1 else 128
 steps = int(sys.argv[2]) if len(sys.argv) > 2 else 5000
 seeds = int(sys.argv[3]) if len(sys.argv) > 3 else 2
 first = int(sys.argv[4]) if len(sys.argv) > 4 else 0
+GREEDY = os.environ.get("RMJ_SOAK_POLICY", "random") == "greedy"
+RATE = int(os.environ.get("RMJ_SOAK_CALL_RATE", "64"))
 total = 0
 t0 = time.time()
 for mode in range(6):
@@ -29,13 +32,16 @@ for mode in range(6):
             env.reset()
             for o in games:
                 o.reset()
-            env.step_random(pseed, steps, auto_reset=True)
+            if GREEDY:
+                env.step_greedy(pseed, steps, auto_reset=True, call_rate_256=RATE)
+            else:
+                env.step_random(pseed, steps, auto_reset=True)
             for g, o in enumerate(games):
                 for _ in range(steps):
                     if o.status()[2]:
                         o.reset()
                         continue
-                    o.step(o.random_actions(pseed, g))
+                    o.step(o.greedy_actions(pseed, g, RATE) if GREEDY else o.random_actions(pseed, g))
             _compare(env, games, range(n), steps)
             assert list(env.step_counts()) == [o.step_count for o in games]
             cnt = env.event_counts()

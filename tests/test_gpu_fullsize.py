@@ -121,6 +121,35 @@ def test_65536_games_4p_red_half(offset):
     assert not FUSED or env.bench_rollout(PSEED, 0, 4).launches == 1     # the fused rollout
 
 
+@pytest.mark.parametrize("mode", [2, 5])
+def test_65536_games_under_the_greedy_policy(mode):
+    """The headline batch size under the policy that plays to win (rmj_step_greedy as bench.py --policy greedy drives it: one launch of
+    ticket chunks, auto-reset): sampled games against the oracle playing the same policy - state, lists, masks, waits, log tail."""
+    from oracle import oracle
+    from riichienv_amd import vecenv
+
+    n, steps, rate, ring = 65536, 600, 64, 256
+    env = vecenv.VecRiichiEnv(n, game_mode=mode, seed=SEED, rule_bits=abi.RULE_TENHOU, event_ring=ring)
+    env.reset()
+    env.step_greedy(PSEED, steps, auto_reset=True, call_rate_256=rate)
+    counts = env.step_counts()
+    wins = 0
+    for g in sample_games(n, k=96):
+        o = oracle.Game(game_mode=mode, seed=game_seed(SEED, g), rule_bits=abi.RULE_TENHOU)
+        o.reset()
+        for _ in range(steps):
+            if o.status()[2]:
+                o.reset()
+                continue
+            o.step(o.greedy_actions(PSEED, g, rate))
+        compare_game(env, g, o, ring, ("greedy", mode))
+        assert int(counts[g]) == o.step_count
+        wins += sum('"hora"' in e for e in o.log())
+    assert wins > 20          # the sampled games end their rounds with wins
+    if FUSED:
+        assert int(env.bench_rollout(PSEED, 0, 100).queued) == 1
+
+
 def test_65536_games_4p_mjsoul_rules_single_stream_equals_split():
     """The same batch stepped on ONE stream must end in the same sampled states as the four-stream split (different rule
     set for breadth: Mahjong Soul yakuman / pao options)."""

@@ -504,14 +504,16 @@ __device__ __forceinline__ void r4_put(R4& q, int seat, int pos, uint64_t a, int
 // _resolve_discard (state/mod.rs:1317-1413) incl. claim generation (legal_actions.rs:254-508) for the row's game.
 // nl[] = list length of seat r (lanes r < 4) after the call; returns through G->phase / active_mask like the reference.
 // known_sh: the exact shanten of the 13 tiles the discard leaves when the policy has just computed it (99: unknown)
-template <bool RICH>
+template <bool RICH, bool LOOP>
 __device__ __forceinline__ void r4_resolve_discard(R4& q, int pid, int tile, bool tsumogiri, int pf, int& nl_mine, uint64_t& w_mine, int known_sh = 99) {
     GState* G = q.G;
     PState* P = &G->p[pid];
     const int r = q.r, rb = q.rb;
     // (kan dora indicators waiting for this discard: flipping them here was measured - 0.05 % fewer exits, 2.7 % slower, the
     //  load and the loop cost registers in the hottest function)
-    if (G->pending_kan_dora > 0) { R4BAIL(q, 8); return; }
+    // RICH: the indicators of earlier open kans are flipped here, in front of the dahai event, like the full path does
+    // (state/mod.rs:1357-1361); the lean tier leaves a discard after a kan to the full path
+    if (!RICH && G->pending_kan_dora > 0) { R4BAIL(q, 8); return; }
     const int tt = tile >> 2;
     {
         uint32_t fl = P->flags;
@@ -560,6 +562,34 @@ __device__ __forceinline__ void r4_resolve_discard(R4& q, int pid, int tile, boo
         }
     }
     wave_sync();
+    if (RICH) {   // flush_pending_kan_dora / _reveal_kan_dora (state/mod.rs:2021-2046)
+        int pk = G->pending_kan_dora;
+        while (__ballot(pk > 0)) {
+            if (pk > 0) {
+                pk -= 1;
+                const int count = G->n_dora;
+                const int widx = KSANMA ? 8 + 2 * count : 4 + 2 * count;
+                const bool flip = count < 5 && (KSANMA || widx < (int)G->live_end);
+                int t = 0;
+                if (flip) {
+                    const uint8_t* Wg = q.E->wall + (size_t)q.g * RMJ_WALL_STRIDE;
+                    if (LOOP) {
+                        const uint32_t w = __hip_atomic_load(reinterpret_cast<const uint32_t*>(Wg) + (widx >> 2), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        t = (int)((w >> (8 * (widx & 3))) & 0xFFu);
+                    } else {
+                        t = Wg[widx];
+                    }
+                }
+                if (r == 0) {
+                    G->pending_kan_dora = (uint8_t)pk;
+                    if (flip) { G->dora[count] = (uint8_t)t; G->n_dora = (uint8_t)(count + 1); }
+                }
+                wave_sync();
+                if (flip) r4_emit_simple(q, RMJ_EV_DORA, 0u, (uint32_t)t);
+            }
+        }
+        if (q.bail) return;   // (event staging full)
+    }
     r4_emit_simple(q, RMJ_EV_DAHAI, (uint32_t)pid, (uint32_t)tile, tsumogiri ? 1u : 0u);
     R4M(50);
     if (q.bail) return;
@@ -591,8 +621,12 @@ __device__ __forceinline__ void r4_resolve_discard(R4& q, int pid, int tile, boo
     const bool in_discards = (dtm >> tt) & 1ull;
     const bool in_missed = (qfl & PF_MISSED_DOUJUN) || ((qfl & PF_RIICHI_DECLARED) && (qfl & PF_MISSED_RIICHI));
     const bool furiten = (W & dtm) != 0ull || (qfl & (PF_MISSED_RIICHI | PF_MISSED_DOUJUN));
-    if (rballot(other && !in_discards && !in_missed && !furiten && ((W >> tt) & 1ull), rb)) { R4BAIL(q, 9); return; }
     const uint32_t riichi_m = rballot(r < 4 && (qfl & PF_RIICHI_DECLARED), rb) & 0xFu;
+    // A seat in riichi that waits on the tile and is not furiten may win without a look at its yaku (riichi is one, the shape is
+    // the cached wait: calc.is_win of legal_actions.rs:254-310 is true): RICH offers that Ron here; any other seat that could
+    // win needs the evaluator - full path.
+    const uint32_t ron_m = rballot(other && !in_discards && !in_missed && !furiten && ((W >> tt) & 1ull), rb) & 0xFu;
+    if (ron_m && (!RICH || (ron_m & ~riichi_m))) { R4BAIL(q, 9); return; }
     w_mine = r < 4 ? W : 0ull;
     const bool can_call = G->drawable_count > 0;
     const bool kuikae = (q.E->rule_bits & RMJ_RULE_KUIKAE_FORBIDDEN) != 0;
@@ -677,6 +711,13 @@ __device__ __forceinline__ void r4_resolve_discard(R4& q, int pid, int tile, boo
     R4M(54);
     // ---- E: Pass, lengths, stale counts (lane = seat)
     int n_me = r < 4 ? nl_get(r) : 0;
+    if (RICH && ron_m) {   // (a seat in riichi has no other claim: its list is Ron, Pass)
+        if (r < 4 && ((ron_m >> r) & 1u)) {
+            q.T->lst[q.row][r][0] = mk_action(RMJ_RON, tile, 0) | ((uint64_t)(KSANMA ? 56 : 79) << 56);
+            n_me = 1;
+        }
+        if (r == 0) G->ron_offer_mask = (uint8_t)ron_m;
+    }
     if (rballot(r < 4 && n_me + 1 > R4_LIST, rb)) { R4BAIL(q, 10); return; }
     if (r < 4) {
         G->stale_n[r] = (uint8_t)(n_me > 62 ? 62 : n_me);
@@ -744,7 +785,14 @@ __device__ __forceinline__ void r4_gen_act_legal(R4& q, int& nl_mine) {
             else r4_fill_waits13<RICH>(q, P, hl - 1);
             if (q.bail) return;
         }
-        if ((P->waits13 >> (drawn_tile >> 2)) & 1ull) { R4BAIL(q, 13); return; }
+        if ((P->waits13 >> (drawn_tile >> 2)) & 1ull) {
+            // a complete hand.  Concealed (no meld but Ankan): menzen tsumo is a yaku, so the win is legal without the evaluator
+            // (calc.is_win of legal_actions.rs:44-61 is true) - RICH lists Tsumo here; an open hand needs its yaku: full path.
+            const bool concealed = rballot(r < nmelds && P->meld_type[r & 3] != RMJ_MELD_ANKAN, rb) == 0u;
+            if (!RICH || !concealed) { R4BAIL(q, 13); return; }
+            if (r == 0) r4_put(q, pid, n, mk_action(RMJ_TSUMO, drawn_tile, 0), KSANMA ? 56 : 79);
+            n += 1;
+        }
     }
     R4M(60);
     // 2. Discards (+ Riichi -> bail)
@@ -1261,7 +1309,7 @@ __device__ __forceinline__ void step4_body(const Env* Ep, Quad4Shared& sh, uint6
                     if (r == 0) P->hand_len = (uint8_t)(hl - 1);
                     wave_sync();
                     R4M(42);
-                    r4_resolve_discard<RICH>(q, pid, tile, tsumogiri, pf, nl_mine, w_mine, (POL == 1 && pol_seat == pid) ? pol_sh : 99);
+                    r4_resolve_discard<RICH, LOOP>(q, pid, tile, tsumogiri, pf, nl_mine, w_mine, (POL == 1 && pol_seat == pid) ? pol_sh : 99);
                     R4M(56);
                 }
             } else if (KSANMA && ty == RMJ_KITA) {

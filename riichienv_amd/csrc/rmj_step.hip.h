@@ -2250,6 +2250,7 @@ __device__ __forceinline__ void finalize_outputs(Ctx& c, bool claims_fresh, bool
     GState& S = c.S;
     const int lane = c.lane;
     const int phase = U((int)S.phase);
+    if (!FAST) S.tp_seat = 0xFF;   // whatever the rich tier 0 cached for a riichi-stage list (GState::tp_*) is void after a full-path publication
     if (U((int)S.is_done)) {
         for (int p = 0; p < 4; p++) { c.X.nl[p] = 0; c.X.wout[p] = 0; }
     } else if (!FAST && U((int)S.active_mask) == 0) {

@@ -501,6 +501,69 @@ __device__ __forceinline__ void r4_put(R4& q, int seat, int pos, uint64_t a, int
     if (pos < R4_LIST) q.T->lst[q.row][seat][pos] = a | ((uint64_t)(uint32_t)id << 56);
 }
 
+// wall tile `idx` of the row's game (fused rollouts read their own earlier stores past the vector L1, see step4_body)
+template <bool LOOP>
+__device__ __forceinline__ int r4_wall_tile(const R4& q, int idx) {
+    const uint8_t* Wg = q.E->wall + (size_t)q.g * RMJ_WALL_STRIDE;
+    if (LOOP) {
+        const uint32_t w = __hip_atomic_load(reinterpret_cast<const uint32_t*>(Wg) + (idx >> 2), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        return (int)((w >> (8 * (idx & 3))) & 0xFFu);
+    }
+    return Wg[idx];
+}
+// _reveal_kan_dora (state/mod.rs:2021-2046) `extra` more times after the pending ones (flush_pending_kan_dora)
+template <bool LOOP>
+__device__ __forceinline__ void r4_flush_kan_dora(R4& q, int extra) {
+    GState* G = q.G;
+    int pk = (int)G->pending_kan_dora + extra;
+    while (__ballot(pk > 0)) {
+        if (pk > 0) {
+            pk -= 1;
+            const int count = G->n_dora;
+            const int widx = KSANMA ? 8 + 2 * count : 4 + 2 * count;
+            const bool flip = count < 5 && (KSANMA || widx < (int)G->live_end);
+            const int t = flip ? r4_wall_tile<LOOP>(q, widx) : 0;
+            if (q.r == 0) {
+                G->pending_kan_dora = (uint8_t)(pk >= extra ? pk - extra : 0);
+                if (flip) { G->dora[count] = (uint8_t)t; G->n_dora = (uint8_t)(count + 1); }
+            }
+            wave_sync();
+            if (flip) r4_emit_simple(q, RMJ_EV_DORA, 0u, (uint32_t)t);
+        }
+    }
+}
+// _resolve_kan from the replacement draw on (state/mod.rs:1475-1547): every seat loses ippatsu, the first turn is over, the
+// replacement tile comes from the front of the dead wall, then the meld event (w0 / cons / n; 0: a Kakan announced itself
+// earlier), the indicators (an Ankan flips its own at once, an open kan leaves it pending), the tsumo event
+template <bool LOOP>
+__device__ __forceinline__ void r4_kan_draw(R4& q, int pid, PState* P, bool ankan, uint32_t ev_w0, uint32_t ev_cons, uint32_t ev_n) {
+    GState* G = q.G;
+    const int r = q.r;
+    if (G->drawable_count == 0) { R4BAIL(q, 29); return; }
+    if (r < 4) G->p[r].flags &= ~PF_IPPATSU;
+    const int rc = G->rinshan_count;
+    const int t = r4_wall_tile<LOOP>(q, rc);
+    if (r == 0) {
+        G->is_first_turn = 0;
+        G->rinshan_count = (uint8_t)(rc + 1);
+        G->drawable_count -= 1;
+        const int h2 = P->hand_len;
+        if (h2 < 14) { P->hand[h2] = (uint8_t)t; P->hand_len = (uint8_t)(h2 + 1); }
+        G->drawn_tile = (uint8_t)t;
+        G->is_rinshan = 1;
+    }
+    wave_sync();
+    if (ev_w0) r4_emit(q, ev_w0, ev_cons, (ev_n << 4) & 0xFFu);
+    r4_flush_kan_dora<LOOP>(q, ankan ? 1 : 0);
+    if (!ankan && r == 0) G->pending_kan_dora += 1;
+    wave_sync();
+    r4_emit_simple(q, RMJ_EV_TSUMO, (uint32_t)pid, (uint32_t)t);
+    if (r == 0) {
+        G->phase = RMJ_WAIT_ACT;
+        G->active_mask = (uint8_t)(1u << pid);
+    }
+    wave_sync();
+}
 // _resolve_discard (state/mod.rs:1317-1413) incl. claim generation (legal_actions.rs:254-508) for the row's game.
 // nl[] = list length of seat r (lanes r < 4) after the call; returns through G->phase / active_mask like the reference.
 // known_sh: the exact shanten of the 13 tiles the discard leaves when the policy has just computed it (99: unknown)
@@ -563,31 +626,7 @@ __device__ __forceinline__ void r4_resolve_discard(R4& q, int pid, int tile, boo
     }
     wave_sync();
     if (RICH) {   // flush_pending_kan_dora / _reveal_kan_dora (state/mod.rs:2021-2046)
-        int pk = G->pending_kan_dora;
-        while (__ballot(pk > 0)) {
-            if (pk > 0) {
-                pk -= 1;
-                const int count = G->n_dora;
-                const int widx = KSANMA ? 8 + 2 * count : 4 + 2 * count;
-                const bool flip = count < 5 && (KSANMA || widx < (int)G->live_end);
-                int t = 0;
-                if (flip) {
-                    const uint8_t* Wg = q.E->wall + (size_t)q.g * RMJ_WALL_STRIDE;
-                    if (LOOP) {
-                        const uint32_t w = __hip_atomic_load(reinterpret_cast<const uint32_t*>(Wg) + (widx >> 2), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        t = (int)((w >> (8 * (widx & 3))) & 0xFFu);
-                    } else {
-                        t = Wg[widx];
-                    }
-                }
-                if (r == 0) {
-                    G->pending_kan_dora = (uint8_t)pk;
-                    if (flip) { G->dora[count] = (uint8_t)t; G->n_dora = (uint8_t)(count + 1); }
-                }
-                wave_sync();
-                if (flip) r4_emit_simple(q, RMJ_EV_DORA, 0u, (uint32_t)t);
-            }
-        }
+        if (__ballot(G->pending_kan_dora > 0)) r4_flush_kan_dora<LOOP>(q, 0);
         if (q.bail) return;   // (event staging full)
     }
     r4_emit_simple(q, RMJ_EV_DAHAI, (uint32_t)pid, (uint32_t)tile, tsumogiri ? 1u : 0u);
@@ -1282,7 +1321,7 @@ __device__ __forceinline__ void step4_body(const Env* Ep, Quad4Shared& sh, uint6
                 const int nxt = __builtin_amdgcn_update_dpp(0xFFFF, t, 0x101 /* row_shl:1 */, 0xf, 0xf, false);
                 const uint32_t uns = rballot(r < hl - 2 && t > nxt, rb);
                 // 3P: right after a Kita the tile drawn before it sits behind the sorted run, in front of the replacement draw
-                const bool two_loose = KSANMA && hl >= 3 && uns == (1u << (hl - 3));
+                const bool two_loose = (KSANMA || RICH) && hl >= 3 && uns == (1u << (hl - 3));   // (RICH: the tile drawn before a kan stays in front of the replacement draw)
                 if (idx < 0 || (uns && !two_loose)) {
                     R4BAIL(q, 20);
                 } else {
@@ -1383,8 +1422,86 @@ __device__ __forceinline__ void step4_body(const Env* Ep, Quad4Shared& sh, uint6
                         r4_emit_simple(q, RMJ_EV_TSUMO, (uint32_t)pid, (uint32_t)rt);
                     }
                 }
+            } else if (RICH && (ty == RMJ_ANKAN || ty == RMJ_KAKAN)) {
+                // ---- Ankan / Kakan (state/mod.rs:472-683, _resolve_kan :1415-1547) when nobody can rob the tile; everything is
+                // done on the LDS copy, so any complication found on the way (a seat that could win on the tile, a full event
+                // stage) simply bails: the full path starts over from the untouched record
+                q.dirty = 0xFu;
+                const uint64_t full_act = rbc64(mine, rb + pid);
+                const int hl = P->hand_len;
+                const int t = r < hl ? (int)P->hand[r] : 0xFFFF;
+                const int tile = (int)((act >> 8) & 0xFFu);
+                const int tt = tile >> 2;
+                const bool ankan = ty == RMJ_ANKAN;
+                // the tiles that leave the hand: the four of the Ankan, the one of the Kakan
+                const uint32_t c0 = a_c(full_act, 0), c1 = a_c(full_act, 1), c2 = a_c(full_act, 2), c3 = a_c(full_act, 3);
+                const bool gone = r < hl && (ankan ? ((uint32_t)t == c0 || (uint32_t)t == c1 || (uint32_t)t == c2 || (uint32_t)t == c3) : t == tile);
+                const uint32_t rm = rballot(gone, rb);
+                const uint32_t pon_hit = rballot(r < (int)P->n_melds && P->meld_type[r & 3] == RMJ_MELD_PON && (P->meld_tiles[r & 3][0] >> 2) == tt, rb);
+                if (a_n(full_act) != (ankan ? 4u : 3u) || __popc(rm) != (ankan ? 4 : 1) || (!ankan && !pon_hit) || P->n_melds >= (ankan ? 4 : 5) ||
+                    G->drawable_count == 0) {
+                    R4BAIL(q, 23);
+                } else {
+                    // who could rob it: a Kakan by any seat that waits on the tile and is not furiten (chankan), an Ankan only under the
+                    // kokushi rule - such a seat needs the evaluator.  Stale wait caches are refilled first.
+                    const bool rob_rule = !ankan || (q.E->rule_bits & RMJ_RULE_RON_ON_ANKAN_KOKUSHI) != 0;
+                    if (rob_rule) {
+                        const PState& S0 = G->p[r & 3];
+                        uint32_t need_m = rballot(r < KNP && r != pid && (S0.hand_len + 3 * S0.n_melds == 13) && !(S0.flags & PF_WAITS_VALID), rb) & 0xFu;
+                        while (__ballot(need_m != 0u)) {
+                            if (need_m) {
+                                const int i = __ffs((int)need_m) - 1;
+                                need_m &= need_m - 1u;
+                                PState* Q = &G->p[i];
+                                r4_fill_waits13<RICH>(q, Q, Q->hand_len);
+                                if (q.bail) need_m = 0u;
+                            }
+                        }
+                        if (!q.bail) {
+                            const PState& S4 = G->p[r & 3];
+                            const bool other = r < KNP && r != pid && (S4.hand_len + 3 * S4.n_melds == 13);
+                            const uint64_t W = other ? S4.waits13 : 0ull;
+                            const bool blocked = ankan ? ((S4.discard_type_mask >> tt) & 1ull) != 0ull
+                                                       : ((W & S4.discard_type_mask) != 0ull || (S4.flags & (PF_MISSED_RIICHI | PF_MISSED_DOUJUN)) != 0u);
+                            if (rballot(other && !blocked && ((W >> tt) & 1ull), rb)) R4BAIL(q, 30);
+                        }
+                    }
+                    if (!q.bail) {
+                        wave_sync();
+                        if (r < hl && !gone) P->hand[r - __popc(rm & ((1u << r) - 1u))] = (uint8_t)t;
+                        uint32_t kc0 = c0, kc1 = c1, kc2 = c2;   // consume tiles of the event
+                        if (r == 0) {
+                            P->hand_len = (uint8_t)(hl - __popc(rm));
+                            P->flags &= ~PF_WAITS_VALID;
+                            if (rob_rule) G->ron_offer_mask = 0;   // (the reference clears it where it looks for robbers)
+                            if (ankan) {
+                                push_meld(*P, RMJ_MELD_ANKAN, c0, c1, c2, c3, 4, 0xFF, 0xFF);
+                            } else {
+                                const int m = __ffs((int)pon_hit) - 1;
+                                uint32_t v[4] = {P->meld_tiles[m][0], P->meld_tiles[m][1], P->meld_tiles[m][2], (uint32_t)tile};
+#pragma unroll
+                                for (int a = 0; a < 3; a++)
+#pragma unroll
+                                    for (int b = 0; b < 3; b++)
+                                        if (v[b] > v[b + 1]) { const uint32_t x = v[b]; v[b] = v[b + 1]; v[b + 1] = x; }
+                                for (int a = 0; a < 4; a++) P->meld_tiles[m][a] = (uint8_t)v[a];
+                                P->meld_type[m] = RMJ_MELD_KAKAN;
+                            }
+                        }
+                        wave_sync();
+                        if (ankan) {
+                            r4_kan_draw<LOOP>(q, pid, P, true, (uint32_t)RMJ_EV_ANKAN | ((uint32_t)pid << 8) | ((uint32_t)tile << 24),
+                                              kc0 | (kc1 << 8) | (kc2 << 16) | (c3 << 24), 4u);
+                        } else {
+                            // the Kakan announces itself before anything else, then the indicators of earlier open kans (state/mod.rs:568-587)
+                            r4_emit(q, (uint32_t)RMJ_EV_KAKAN | ((uint32_t)pid << 8) | ((uint32_t)tile << 24), kc0 | (kc1 << 8) | (kc2 << 16), (3u << 4) & 0xFFu);
+                            if (__ballot(G->pending_kan_dora > 0)) r4_flush_kan_dora<LOOP>(q, 0);
+                            if (!q.bail) r4_kan_draw<LOOP>(q, pid, P, false, 0u, 0u, 0u);
+                        }
+                    }
+                }
             } else {
-                R4BAIL(q, 23);   // Riichi, kans, Tsumo, Kyushu: full path
+                R4BAIL(q, 23);   // Riichi (with a tile), Tsumo, Kyushu; lean tier: kans
             }
         } else {
             // ---- WaitResponse (state/mod.rs:900-1314), lane = seat
@@ -1410,8 +1527,49 @@ __device__ __forceinline__ void step4_body(const Env* Ep, Quad4Shared& sh, uint6
                 if (claimer >= 0) {
                     const uint64_t claim = rbc64(mine, rb + claimer);
                     const uint32_t ty = a_type(claim);
-                    if (ty == RMJ_DAIMINKAN) {
+                    if (ty == RMJ_DAIMINKAN && !RICH) {
                         R4BAIL(q, 25);
+                    } else if (ty == RMJ_DAIMINKAN) {
+                        // ---- Daiminkan (state/mod.rs:1143-1160 + _resolve_kan): the call itself like Pon, then the replacement draw
+                        PState* C = &G->p[claimer];
+                        r4_accept_riichi(q);
+                        const int ldp = G->last_discard_pid, tile = G->last_discard_tile;
+                        if (r < 4) {
+                            uint32_t fl = G->p[r].flags & ~(uint32_t)PF_IPPATSU;
+                            if (r == claimer) fl &= ~(uint32_t)(PF_MISSED_DOUJUN | PF_WAITS_VALID);
+                            if (r == ldp) fl &= ~(uint32_t)PF_NAGASHI;
+                            G->p[r].flags = (uint8_t)fl;
+                        }
+                        const int hl = C->hand_len;
+                        const int hc = r < hl ? (int)C->hand[r] : 0xFFFF;
+                        const uint32_t c0 = a_c(claim, 0), c1 = a_c(claim, 1), c2 = a_c(claim, 2);
+                        const bool gone = r < hl && ((uint32_t)hc == c0 || (uint32_t)hc == c1 || (uint32_t)hc == c2);
+                        const uint32_t rm = rballot(gone, rb);
+                        if (__popc(rm) != 3 || a_n(claim) != 3u || C->n_melds >= 4) {
+                            R4BAIL(q, 25);
+                        } else {
+                            wave_sync();
+                            if (r < hl && !gone) C->hand[r - __popc(rm & ((1u << r) - 1u))] = (uint8_t)hc;
+                            if (r == 0) {
+                                C->hand_len = (uint8_t)(hl - 3);
+                                G->is_rinshan = 0;
+                                G->current_player = (uint8_t)claimer;
+                                G->active_mask = (uint8_t)(1u << claimer);
+                                C->n_forbidden = 0;
+                                push_meld(*C, RMJ_MELD_DAIMINKAN, c0, c1, c2, (uint32_t)tile, 4, ldp, tile);
+                                int nd = 0, nw = 0;   // pao_check (state/mod.rs:1443-1472)
+                                for (int m = 0; m < C->n_melds; m++) {
+                                    const int tm = C->meld_tiles[m][0] >> 2;
+                                    if (C->meld_type[m] != RMJ_MELD_CHI) { nd += (tm >= 31 && tm <= 33); nw += (tm >= 27 && tm <= 30); }
+                                }
+                                const int tv = tile >> 2;
+                                if (tv >= 31 && tv <= 33) { if (nd == 3) C->pao37 = (uint8_t)ldp; }
+                                else if (tv >= 27 && tv <= 30) { if (nw == 4) C->pao50 = (uint8_t)ldp; }
+                            }
+                            wave_sync();
+                            r4_kan_draw<LOOP>(q, claimer, C, false, (uint32_t)RMJ_EV_DAIMINKAN | ((uint32_t)claimer << 8) | ((uint32_t)ldp << 16) | ((uint32_t)tile << 24),
+                                              c0 | (c1 << 8) | (c2 << 16), 3u);
+                        }
                     } else {
                         PState* C = &G->p[claimer];
                         r4_accept_riichi(q);

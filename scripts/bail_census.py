@@ -31,7 +31,7 @@ NAMES = {1: "event stage full", 2: "refill: possible wait (tables <= 0)", 3: "re
          7: "exhaustive draw", 8: "pending kan dora at discard", 9: "ron possible on the discard", 10: "claim list too long", 11: "actor holds 13 / riichi stage",
          12: "tsumo check: odd hand", 13: "complete hand (tsumo)", 14: "riichi possible (14-tile shanten <= 0)", 15: "ankan available", 16: "ankan in riichi",
          17: "act list too long", 18: "finished game (restart)", 19: "no action / no tile", 20: "discard: tile not found / unsorted", 21: "kita: precondition",
-         22: "kita: ron possible", 23: "riichi / kan / tsumo / kyushu action", 24: "ron settlement", 25: "daiminkan response", 26: "pending kan resolves", 27: "action from a seat that is not to act", 28: "illegal action"}
+         22: "kita: ron possible", 23: "riichi / kan / tsumo / kyushu action", 24: "ron settlement", 25: "daiminkan response", 26: "pending kan resolves", 27: "action from a seat that is not to act", 28: "illegal action", 29: "kan without a replacement tile", 30: "kan: a seat could rob the tile"}
 tot = sum(buf)
 print(f"mode {mode}, policy {policy}" + (f" (call rate {rate}/256)" if policy != "random" else "") + f": {steps} game-steps, {tot} bails ({100.0 * tot / steps:.2f} %)")
 for i in sorted(range(32), key=lambda k: -buf[k]):

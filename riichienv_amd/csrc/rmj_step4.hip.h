@@ -1322,11 +1322,21 @@ __device__ __forceinline__ void step4_body(const Env* Ep, Quad4Shared& sh, uint6
                 const uint32_t uns = rballot(r < hl - 2 && t > nxt, rb);
                 // 3P: right after a Kita the tile drawn before it sits behind the sorted run, in front of the replacement draw
                 const bool two_loose = (KSANMA || RICH) && hl >= 3 && uns == (1u << (hl - 3));   // (RICH: the tile drawn before a kan stays in front of the replacement draw)
-                if (idx < 0 || (uns && !two_loose)) {
+                if (idx < 0 || (uns && !two_loose && !RICH)) {
                     R4BAIL(q, 20);
                 } else {
                     int np;
-                    if (!uns) {
+                    if (uns && !two_loose) {
+                        // any other order (rich tier: several replacement draws in a row - Kita, kan - leave more than two loose tiles;
+                        // a poked hand): the new slot of a tile = the number of remaining tiles before it in (id, slot) order
+                        int cnt = 0;
+#pragma unroll 1
+                        for (int k = 0; k < hl; k++) {
+                            const int tk = rbc(t, rb + k);
+                            cnt += (k != idx && (tk < t || (tk == t && k < r))) ? 1 : 0;
+                        }
+                        np = cnt;
+                    } else if (!uns) {
                         const int d = rbc(t, rb + hl - 1);
                         const int before_d = __popc(rballot(r < hl - 1 && r != idx && t <= d, rb));
                         np = r - (idx < r ? 1 : 0) + ((idx != hl - 1 && d < t) ? 1 : 0);

@@ -306,7 +306,13 @@ __device__ inline MeldAgg agg_from_views(const RmjHandCase& hc) {
     return m;
 }
 
-__global__ __launch_bounds__(256) void k_eval_hands(const RmjHandCase* cases, uint32_t n, RmjHandResult* out) {
+// Round 3: the evaluator kernel is compiled for six waves per SIMD.  Left alone it takes 236 VGPRs = two waves per SIMD, and the kernel
+// waits on dependent LDS round trips: 40.8 M hands/s at 2 waves, 53 at 3, 58 at 4, 70.8 at 6, 69.9 at 7, 68.4 at 8 (2^18 fixture hands).
+#ifndef RMJ_EVAL_WAVES
+#define RMJ_EVAL_WAVES 6
+#endif
+#define RMJ_EVAL_OCC __attribute__((amdgpu_waves_per_eu(RMJ_EVAL_WAVES, RMJ_EVAL_WAVES)))
+__global__ __launch_bounds__(256) RMJ_EVAL_OCC void k_eval_hands(const RmjHandCase* cases, uint32_t n, RmjHandResult* out) {
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const uint32_t k = blockIdx.x * WPB + wave;
     if (k >= n) return;
@@ -803,7 +809,12 @@ __global__ __launch_bounds__(256) void k_shanten(ShantenTables T, const uint8_t*
     }
     out[i] = (int8_t)sh_shanten(h, total / 3, sanma != 0, T);
 }
-__global__ __launch_bounds__(256) void k_ukeire(ShantenTables T, const uint8_t* counts, const uint8_t* visible, uint32_t n, int sanma,
+// (82 VGPRs = five waves per SIMD left alone; compiled for six: +5 %, eight: the same)
+#ifndef RMJ_UKE_WAVES
+#define RMJ_UKE_WAVES 6
+#endif
+#define RMJ_UKE_OCC __attribute__((amdgpu_waves_per_eu(RMJ_UKE_WAVES, RMJ_UKE_WAVES)))
+__global__ __launch_bounds__(256) RMJ_UKE_OCC void k_ukeire(ShantenTables T, const uint8_t* counts, const uint8_t* visible, uint32_t n, int sanma,
                                                 int mode, uint32_t* out) {
     const int lane = threadIdx.x & 63;
     const uint32_t i = blockIdx.x * 4 + (threadIdx.x >> 6);

@@ -1907,7 +1907,9 @@ __global__ __launch_bounds__(64, RMJ_STEP4_WAVES) void k_step4_fixup(const Env* 
 // issue-bound step and the store-bound encoder: while one wave streams its rows out, the others step.  The records are already in
 // LDS (no second fetch), the encoder's byte staging lives in the union the step has finished with.  Compiled for five waves per
 // SIMD: the encoder wants 85-96 registers.
+#ifndef RMJ_STEP4_ENC_WAVES
 #define RMJ_STEP4_ENC_WAVES 5
+#endif
 template <bool LOOP, int POL>
 __device__ __noinline__ void step4_call_enc(const Env* Ep, uint64_t policy_seed, uint32_t flags, uint32_t g_base, uint32_t g_end, uint32_t load,
                                             uint64_t gs_row, uint32_t quad, float* out, const uint64_t* actions = nullptr) {

@@ -50,6 +50,7 @@ def parse_args(argv=None):
     ap.add_argument("--call-rate", type=int, default=64, help="greedy policy: pon / chi taken with probability call_rate / 256")
     ap.add_argument("--preroll", type=int, default=PREROLL,
                     help="untimed steps before the warm-up that bring every game to steady state (0: time the opening phase)")
+    ap.add_argument("--padded-rows", action="store_true", help="--encode: rows padded to a multiple of 256 B instead of the dense [games][4][74][W] tensor")
     ap.add_argument("--encode", action="store_true",
                     help="also produce the feature tensor of the acting seats every step (BASELINE configs[4]: sanma with "
                          "feature-encoding tensor output): one step launch + one encode launch per step")
@@ -80,6 +81,8 @@ def launcher_command(args, port, script=None):
         cmd.append("--no-extras")
     if args.encode:
         cmd.append("--encode")
+    if args.padded_rows:
+        cmd.append("--padded-rows")
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC only on this pool (RCCL barrier between the ranks)
     env["MASTER_ADDR"] = "127.0.0.1"
@@ -212,7 +215,8 @@ def workload_name(args):
     pol = "device RandomAgent" if args.policy == "random" else f"greedy device policy (calls {args.call_rate}/256)"
     s = f"{args.games} parallel {MODES[args.mode]} games per GPU, {pol}, auto-reset, MJAI logging on"
     if args.encode:
-        s += ", Observation.encode() of every acting seat written to a resident tensor after every step"
+        s += ", Observation.encode() of every acting seat written to a resident tensor after every step" + \
+             (" (rows padded to a multiple of 256 B)" if args.padded_rows else "")
     return s
 
 
@@ -297,7 +301,12 @@ def main(argv=None):
 
     obs = None
     if args.encode:
-        obs = torch.zeros((args.games, 4, 74, 27 if sanma else 34), dtype=torch.float32, device=f"cuda:{local_rank}")
+        # --padded-rows: every row padded to a multiple of 256 B (rmj_set_encode_row_stride; [games][4][2 048] floats in 3P, the first
+        # 74 x 27 of a row are the tensor).  A torch fill of that pattern is 1.3-1.4 x faster than with unaligned dense rows, the encoder
+        # kernels gain 0-5 %: the default stays the dense [games][4][74][W] tensor
+        stride = env.padded_row_stride() if args.padded_rows else 74 * (27 if sanma else 34)
+        env.set_encode_row_stride(stride)
+        obs = torch.zeros((args.games, 4, stride), dtype=torch.float32, device=f"cuda:{local_rank}")
     full0 = env.total_full_path()
     before = env.total_steps()
     barrier()

@@ -302,6 +302,12 @@ int rmj_calculate_score(int device, const uint8_t* han, const uint8_t* fu, const
 /* only_active: 0 = every seat, 1 = acting seats (rows of the others are zeroed), 2 = acting seats, rows of the others
  * are left untouched (no HBM traffic for them; meant for resident device buffers) */
 int rmj_encode(rmj_handle h, int only_active, float* out);
+/* Row stride of the outputs of the BASE encoder (this function, rmj_encode_device, rmj_encode_compact_device, rmj_step_random_encode,
+ * rmj_step_ids_encode_device): every (game, seat) row of 74 x W floats starts `floats` floats after the previous one (out[n][4][floats],
+ * compact: out[capacity][floats]); 0 = dense (74 x W, the default).  Rows padded to a multiple of 256 B - 2 048 floats in 3P, 2 560 in
+ * 4P - are written at 1.3-1.4 x the rate of the unaligned dense rows (the acting seats' rows are one row in four of the tensor; DESIGN.md
+ * section 11.7); the pad floats are never written.  `floats` must be even and >= 74 x W. */
+int rmj_set_encode_row_stride(rmj_handle h, uint32_t floats);
 int rmj_encode_device(rmj_handle h, int only_active, float* d_out); /* device pointer, asynchronous on the handle's stream */
 /* Device-policy rollout WITH feature output (BASELINE configs[4]): n_steps x (one step of every game, then encode() of the
  * seats that are to act into the resident tensor d_out).  Same results as calling rmj_step_random(h, seed, 1, auto_reset)

@@ -533,7 +533,8 @@ __global__ __launch_bounds__(64) RMJ_ENC_OCC void k_encode_base(Env E, int only_
     if (lane < (int)(sizeof(GState) / 16)) rec = reinterpret_cast<const uint4*>(E.core + g)[lane];
     const uint32_t stw = E.status[g];
     const uint32_t am = ((stw >> 16) & 0xFFu) ? 0u : (stw & 0xFu);
-    float* base = out + (size_t)g * 4 * ENC_CH * W;
+    const size_t RS = E.enc_stride;   // row stride in floats (>= 74 x W; rows padded to a multiple of 256 B leave at 1.3-1.4 x the rate)
+    float* base = out + (size_t)g * 4 * RS;
     uint32_t slot = 0u;
     if (COMPACT) {
         if (blockIdx.x == 0) {   // the size of the batch: all block totals
@@ -543,7 +544,8 @@ __global__ __launch_bounds__(64) RMJ_ENC_OCC void k_encode_base(Env E, int only_
         if (am == 0u) return;
         slot = offs[g] + obs_block_prefix(totals, g / OBS_SCAN_BLOCK, lane);
     } else if (only_active && am == 0u) {
-        if (only_active == 1) enc_zero16(base, 4 * ENC_CH * W, lane);
+        if (only_active == 1)
+            for (int z = 0; z < 4; z++) enc_zero16(base + (size_t)z * RS, ENC_CH * W, lane);
         return;
     }
     enc_lut_init(lut, lane);
@@ -551,12 +553,12 @@ __global__ __launch_bounds__(64) RMJ_ENC_OCC void k_encode_base(Env E, int only_
     wave_sync();
     const GState& S = st;
     for (int seat = 0; seat < 4; seat++) {
-        float* dst = base + (size_t)seat * ENC_CH * W;
+        float* dst = base + (size_t)seat * RS;
         const bool acts = (am >> seat) & 1u;
         if (COMPACT) {
             if (seat >= NPP || !acts) continue;
             if (slot >= capacity) return;                  // (the count tells the caller that the buffer was too small)
-            dst = out + (size_t)slot * ENC_CH * W;
+            dst = out + (size_t)slot * RS;
             if (lane == 0) index[slot] = (int32_t)(g * 4u + (uint32_t)seat);
             slot += 1u;
         } else if (seat >= NPP || (only_active && !acts)) {
@@ -1025,6 +1027,8 @@ static int create_impl(rmj_env* h, const RmjConfig* cfg, uint64_t** d_seeds_out)
     d.skip_log = cfg->skip_mjai_logging;
     d.ctor_round_wind = cfg->round_wind;
     d.game_offset = cfg->game_offset;
+    d.enc_stride = (uint32_t)(ENC_CH * (cfg->game_mode >= 3 ? ENC_W3 : ENC_W4));
+    d.pad_ = 0;
     int rc;
     if ((rc = shanten_tables_for(cfg->device, &d.sh))) return rc;
     HIPCHK(hipMalloc(&h->d_env, sizeof(Env)));
@@ -1107,6 +1111,7 @@ int rmj_clone(rmj_handle h, rmj_handle* out) {
     c->enc_streams = h->enc_streams;
     c->enc_parts_quad = h->enc_parts_quad;
     c->enc_fused = h->enc_fused;
+    if (h->d.enc_stride != c->d.enc_stride) { int rc2 = rmj_set_encode_row_stride(c, h->d.enc_stride); if (rc2) { rmj_destroy(c); return rc2; } }
     const size_t B = h->cfg.n_games, ring = (size_t)h->d.ring_mask + 1u;
     const struct { void* dst; const void* src; size_t bytes; } slabs[] = {
         {c->d.core, h->d.core, B * sizeof(GState)}, {c->d.wall, h->d.wall, B * RMJ_WALL_STRIDE},
@@ -1297,6 +1302,22 @@ int rmj_get_points(rmj_handle h, int rule, double* points) {
     if (rc) return rc;
     HIPCHK(hipStreamSynchronize(h->stream));
     HIPCHK(hipMemcpy(points, d, (size_t)h->cfg.n_games * 4 * sizeof(double), hipMemcpyDeviceToHost));
+    return RMJ_OK;
+}
+// Row stride of the base encoder's outputs (rmj_encode(_device), rmj_encode_compact_device, rmj_step_random_encode, rmj_step_ids_encode_device):
+// every (game, seat) row - 74 x W floats - starts `floats` floats after the previous one; 0 restores the dense layout (74 x W).  Padding
+// the rows to a multiple of 256 B (2 048 floats in 3P, 2 560 in 4P) costs 2 % more memory and lets the acting seats' rows - one row in
+// four of the tensor - leave at 1.3-1.4 x the rate: unaligned rows of 7 992 / 10 064 B are written at 3.8 TB/s, aligned ones at 5.0-5.3
+// (torch fills of the same pattern, scripts/micro/row_stride_fill.py).  The pad floats are never written.
+int rmj_set_encode_row_stride(rmj_handle h, uint32_t floats) {
+    if (!h) return fail(RMJ_ERR_ARG, "null handle");
+    const uint32_t dense = (uint32_t)(ENC_CH * (h->cfg.game_mode >= 3 ? ENC_W3 : ENC_W4));
+    if (floats == 0) floats = dense;
+    if (floats < dense || (floats & 1u)) return fail(RMJ_ERR_ARG, "row stride must be an even number of floats >= 74 x W");
+    HIPCHK(hipSetDevice(h->cfg.device));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    h->d.enc_stride = floats;
+    HIPCHK(hipMemcpy(h->d_env, &h->d, sizeof(Env), hipMemcpyHostToDevice));
     return RMJ_OK;
 }
 int rmj_set_stream(rmj_handle h, void* stream, int own) {
@@ -2124,7 +2145,7 @@ int rmj_bench_encode_compact(rmj_handle h, float* d_out, int32_t* d_index, uint3
 int rmj_encode(rmj_handle h, int only_active, float* out) {
     if (!h || !out) return fail(RMJ_ERR_ARG, "null argument");
     HIPCHK(hipSetDevice(h->cfg.device));
-    size_t bytes = (size_t)h->cfg.n_games * 4 * (h->cfg.game_mode >= 3 ? ENC_FLOATS3 : ENC_FLOATS) * sizeof(float);
+    size_t bytes = (size_t)h->cfg.n_games * 4 * (size_t)h->d.enc_stride * sizeof(float);
     void* sp;
     int rc = scratch_for(h, bytes, &sp);
     if (rc) return rc;

@@ -25,6 +25,8 @@ struct Env {
     uint32_t skip_log;
     uint32_t ctor_round_wind;
     uint64_t game_offset;
+    uint32_t enc_stride;  // floats from one (game, seat) row of the base encoder's output to the next (rmj_set_encode_row_stride; default 74 x W)
+    uint32_t pad_;
     ShantenTables sh;     // replacement-number tables (prefilter of the riichi probe)
 };
 

@@ -1932,7 +1932,7 @@ __device__ __noinline__ void step4_call_enc(const Env* Ep, uint64_t policy_seed,
         while (am) {
             const int seat = __builtin_ctz(am);
             am &= am - 1u;
-            float* dst = out + ((size_t)g * 4 + (size_t)seat) * ENC_CH * W;
+            float* dst = out + ((size_t)g * 4 + (size_t)seat) * (size_t)((CEnv*)Ep)->enc_stride;
             const int head = (int)(((16u - (uint32_t)(reinterpret_cast<uintptr_t>(dst) & 15u)) & 15u) >> 2);  // 0 or 2 floats
             EncByteSink<W> o{sh.u.e.raw + ((4 - head) & 3), lut, lane, -1.0f};
             encode_seat_to<KSANMA>(S, seat, lane, sh.u.e.hist, o, true);

@@ -35,7 +35,7 @@ class TorchVecEnv:
     obs(), mask, status … describe the state AFTER the last step; step(action_ids) takes an int32 tensor [n, 4] on the
     same device (-1 for seats that do not act)."""
 
-    def __init__(self, n_games, game_mode=2, seed=0, device=0, extended=False, skip_mjai_logging=True, share_stream=True, **kw):
+    def __init__(self, n_games, game_mode=2, seed=0, device=0, extended=False, skip_mjai_logging=True, share_stream=True, pad_rows=False, **kw):
         """share_stream: issue the library's kernels on torch's current stream of `device` (rmj_set_stream): policy and
         environment are then ordered by the stream, without host synchronisation between them.  With False the library keeps
         its own stream and every call synchronises."""
@@ -63,7 +63,18 @@ class TorchVecEnv:
         self.mask = wrap(v.mask, (self.n, 4, abi.ACTION_SPACE_4P), "|u1")      # zero-copy, rewritten by every step
         self.legal = wrap(v.legal, (self.n, 4, abi.MAX_LEGAL), "<i8")          # packed actions (bit pattern of the u64)
         self.waits = wrap(v.waits, (self.n, 4), "<i8")
-        self._obs = torch.zeros((self.n, 4, self.channels, self.width), dtype=torch.float32, device=self.device)
+        # pad_rows: every (game, seat) row of the 74-channel tensor padded to a multiple of 256 B (rmj_set_encode_row_stride): the
+        # acting seats' rows are written 1.3-1.4 x faster; obs() then returns a strided view [n, 4, 74, W] of the padded buffer
+        self.pad_rows = bool(pad_rows) and not extended
+        if self.pad_rows:
+            self.row_stride = self.env.padded_row_stride()
+            self.env.set_encode_row_stride(self.row_stride)
+            self._obs_buf = torch.zeros((self.n, 4, self.row_stride), dtype=torch.float32, device=self.device)
+            self._obs = self._obs_buf[:, :, : 74 * self.width].unflatten(-1, (74, self.width))
+        else:
+            self.row_stride = self.channels * self.width
+            self._obs_buf = torch.zeros((self.n, 4, self.channels, self.width), dtype=torch.float32, device=self.device)
+            self._obs = self._obs_buf
         self._scores = torch.zeros((self.n, 4), dtype=torch.int32, device=self.device)
         self.shared = bool(share_stream)
         if self.shared:
@@ -89,7 +100,7 @@ class TorchVecEnv:
         of the seats that must act (rows of the other seats keep their previous contents: mask them with active())."""
         L = self.env.L
         fn = L.rmj_encode_extended_device if self.extended else L.rmj_encode_device
-        vecenv._chk(fn(self.env.h, 2 if only_active else 0, C.c_void_p(self._obs.data_ptr())))
+        vecenv._chk(fn(self.env.h, 2 if only_active else 0, C.c_void_p(self._obs_buf.data_ptr())))
         self.sync()
         return self._obs
 
@@ -103,13 +114,14 @@ class TorchVecEnv:
             raise vecenv.RmjError("obs_compact() covers Observation.encode(); use obs() for encode_extended()")
         cap = int(capacity or getattr(self, "_cap", 0) or (self.n + self.n // 2 + 1))
         if getattr(self, "_cobs", None) is None or self._cobs.shape[0] < cap:
-            self._cobs = t.zeros((cap, 74, self.width), dtype=t.float32, device=self.device)
+            self._cobs_buf = t.zeros((cap, self.row_stride), dtype=t.float32, device=self.device)
+            self._cobs = self._cobs_buf[:, : 74 * self.width].unflatten(-1, (74, self.width))
             self._cidx = t.zeros((cap,), dtype=t.int32, device=self.device)
             self._ccnt = t.zeros((1,), dtype=t.int32, device=self.device)
             self._cap = cap
             if not self.shared:
                 t.cuda.current_stream(self.device).synchronize()   # the buffers were zeroed on torch's stream
-        self.env.encode_compact_device(self._cobs.data_ptr(), self._cidx.data_ptr(), self._cap, self._ccnt.data_ptr())
+        self.env.encode_compact_device(self._cobs_buf.data_ptr(), self._cidx.data_ptr(), self._cap, self._ccnt.data_ptr())
         self.sync()
         if not sync_count:
             return self._cobs, self._cidx, self._ccnt
@@ -167,7 +179,7 @@ class TorchVecEnv:
         assert ids.shape == (self.n, 4)
         if not self.shared:
             t.cuda.current_stream(self.device).synchronize()
-        vecenv._chk(self.env.L.rmj_step_ids_encode_device(self.env.h, C.c_void_p(ids.data_ptr()), int(auto_reset), C.c_void_p(self._obs.data_ptr())))
+        vecenv._chk(self.env.L.rmj_step_ids_encode_device(self.env.h, C.c_void_p(ids.data_ptr()), int(auto_reset), C.c_void_p(self._obs_buf.data_ptr())))
         self.sync()
         return self._obs
 

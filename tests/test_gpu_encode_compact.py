@@ -83,3 +83,55 @@ def test_capacity_smaller_than_the_batch_writes_only_capacity_rows():
     assert int(count.item()) >= n          # the count reports the whole batch
     assert (index[:cap] >= 0).all() and (index[cap:] == -1).all()
     assert float(out[cap:].max().item()) == -7.0 and float(out[:cap].min().item()) >= 0.0
+
+
+@pytest.mark.parametrize("mode", [2, 5])
+def test_padded_row_stride_equals_dense_rows(mode):
+    """rmj_set_encode_row_stride: with every (game, seat) row padded to a multiple of 256 B the base encoder - per-step launch, dense
+    compact batch, the one-launch step + encode rollout, the one-launch step under action ids - writes the same 74 x W floats at the
+    start of every row and never touches the pad."""
+    import torch
+
+    from riichienv_amd import vecenv
+    from riichienv_amd.torch_env import TorchVecEnv
+
+    n, w = 4099, (27 if mode >= 3 else 34)
+    a = vecenv.VecRiichiEnv(n, game_mode=mode, seed=91, event_ring=64)
+    b = vecenv.VecRiichiEnv(n, game_mode=mode, seed=91, event_ring=64)
+    stride = b.padded_row_stride()
+    assert stride % 64 == 0 and 74 * w <= stride < 74 * w + 64
+    b.set_encode_row_stride(stride)
+    for e in (a, b):
+        e.reset()
+    oa = torch.zeros((n, 4, 74 * w), dtype=torch.float32, device="cuda:0")
+    ob = torch.full((n, 4, stride), -7.0, dtype=torch.float32, device="cuda:0")
+    ob[:, :, : 74 * w] = 0.0
+    a.step_random_encode(5, 150, oa.data_ptr(), auto_reset=True, only_active=2)      # one launch, rows of the acting seats
+    b.step_random_encode(5, 150, ob.data_ptr(), auto_reset=True, only_active=2)
+    a.sync(); b.sync()
+    assert torch.equal(oa, ob[:, :, : 74 * w]) and bool((ob[:, :, 74 * w:] == -7.0).all()) and float(oa.abs().sum()) > 0
+    # host copies (every seat) and the per-step encoder
+    assert (a.encode() == b.encode()).all()
+    # the dense compact batch
+    cap = n * 2
+    ca = torch.zeros((cap, 74 * w), dtype=torch.float32, device="cuda:0")
+    cb = torch.full((cap, stride), -7.0, dtype=torch.float32, device="cuda:0")
+    ia, ib = (torch.zeros((cap,), dtype=torch.int32, device="cuda:0") for _ in range(2))
+    na, nb = (torch.zeros((1,), dtype=torch.int32, device="cuda:0") for _ in range(2))
+    a.encode_compact_device(ca.data_ptr(), ia.data_ptr(), cap, na.data_ptr())
+    b.encode_compact_device(cb.data_ptr(), ib.data_ptr(), cap, nb.data_ptr())
+    a.sync(); b.sync()
+    k = int(na.item())
+    assert k == int(nb.item()) and k > n // 2 and torch.equal(ia[:k], ib[:k])
+    assert torch.equal(ca[:k], cb[:k, : 74 * w]) and bool((cb[:, 74 * w:] == -7.0).all())
+    a.close(); b.close()
+    # the torch wrapper: a strided view of the padded buffer, step_obs / obs / obs_compact
+    ta = TorchVecEnv(512, game_mode=mode, seed=3)
+    tb = TorchVecEnv(512, game_mode=mode, seed=3, pad_rows=True)
+    assert tb.obs().shape == ta.obs().shape == (512, 4, 74, w)
+    for k in range(60):
+        ids = ta.sample_ids(seed=k).clone()
+        xa, xb = ta.step_obs(ids), tb.step_obs(ids)
+    assert torch.equal(xa, xb) and torch.equal(ta.obs(), tb.obs())
+    (pa, qa), (pb, qb) = ta.obs_compact(), tb.obs_compact()
+    assert torch.equal(pa, pb) and torch.equal(qa, qb)

@@ -7,7 +7,8 @@ and the oracle beside it - one thread, and one worker process per hardware threa
 
 Inputs: the 1 218 fixture hands of tests/golden/agari_{4p,3p}.json tiled to 2^20 + 2^20 uniformly random
 13 / 14-tile hands (seed 1).  The CPU legs run FIRST (they start worker processes; a process that has touched the GPU must not).
-usage: python scripts/bench_hand_kernels.py [log2 of the hands per set, default 20] [cpu seconds per leg, default 3]"""
+usage: python scripts/bench_hand_kernels.py [log2 of the hands per set, default 20] [cpu seconds per leg, default 3] [nocpu]
+(nocpu: GPU legs only - for `rocprofv3 --kernel-trace --stats -- python3 scripts/bench_hand_kernels.py 20 0 nocpu`)"""
 import ctypes as C
 import json
 import os
@@ -114,7 +115,10 @@ def cpu_all(secs):
 def main():
     lg = int(sys.argv[1]) if len(sys.argv) > 1 else 20
     secs = float(sys.argv[2]) if len(sys.argv) > 2 else 3.0
-    cpu = cpu_all(secs)                      # before anything touches the GPU
+    if len(sys.argv) > 3 and sys.argv[3] == "nocpu":   # under rocprofv3 (its library has touched the GPU already: no worker processes)
+        cpu = {w: {"one_thread_hands_per_s": 0.0, "all_cores_hands_per_s": 0.0, "cores": 0} for _, w in KERNELS}
+    else:
+        cpu = cpu_all(secs)                  # before anything touches the GPU
     from riichienv_amd import vecenv
     L = vecenv.load_lib()
     n = 1 << lg

@@ -24,7 +24,10 @@ def batched_rollout(n=4096, steps=300):
     env = rv.VecRiichiEnv(n, game_mode=2, seed=0, skip_mjai_logging=True)
     env.reset()
     env.step_random(policy_seed=1, n_steps=steps, auto_reset=True)
-    return int(env.total_steps()), env.scores()[:2]
+    # ... or with the device policy that plays to win (shanten-greedy discards, every win / riichi / kan taken, a quarter of the calls)
+    env.step_greedy(policy_seed=1, n_steps=steps, auto_reset=True, call_rate_256=64)
+    idx, off, ent = env.legal_compact()     # what a host agent loop reads: the ordered lists of the seats that are to act
+    return int(env.total_steps()), env.scores()[:2], env.points("basic")[:1].round(1).tolist(), len(idx)
 
 
 def policy_loop(n=2048, iters=50):
@@ -36,9 +39,8 @@ def policy_loop(n=2048, iters=50):
     env = TorchVecEnv(n, game_mode=2, seed=0)
     for it in range(iters):
         obs, index = env.obs_compact()                 # [k, 74, 34] f32 + game * 4 + seat of every row
-        logits = torch.zeros((n, 4, 82), device=env.device)
-        logits.view(-1, 82)[index.long()] = obs.mean(dim=(1, 2), keepdim=False)[:, None]     # (stand-in for a network)
-        env.step(env.sample_ids(seed=it, logits=logits))
+        logits = obs.mean(dim=(1, 2))[:, None].expand(-1, 82).contiguous()                     # [k, 82] (stand-in for a network)
+        env.step(env.sample_ids(seed=it, logits=logits, index=index))                           # compact logits + the index they belong to
     return tuple(obs.shape[1:]), int(env.env.total_steps())
 
 

@@ -361,8 +361,8 @@ def test_quickstart_example_runs():
     spec.loader.exec_module(q)
     scores, ranks = q.reference_loop()
     assert len(scores) == 4 and sorted(ranks) == [1, 2, 3, 4]
-    total, _ = q.batched_rollout(1024, 100)
-    assert total == 1024 * 100
+    total, _, points, rows = q.batched_rollout(1024, 100)
+    assert 1024 * 190 <= total <= 1024 * 200 and len(points[0]) == 4 and rows > 0   # (a game waits at most a few steps for its restart)
     shape, steps = q.policy_loop(512, 10)
     assert shape == (74, 34) and steps > 0
     hand, n_dec, first = q.hands_and_logs()

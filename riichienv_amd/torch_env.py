@@ -183,6 +183,20 @@ class TorchVecEnv:
         self.sync()
         return self._obs
 
+    def bind_stream(self, stream=None):
+        """Issue the library's further work on `stream` (a torch.cuda.Stream; default: torch's current stream of the device) -
+        rmj_set_stream.  Work already issued is waited for first.  This is what puts the environment INSIDE a HIP graph: bind the
+        side stream the graph will be captured on, run one warm-up iteration there, then capture `sample_ids` / `step_obs` /
+        `step` / `obs` / `scores` / `points` together with the policy's kernels (`with torch.cuda.graph(g, stream=s): ...`) - these
+        calls only launch kernels on the bound stream (no allocation, no host synchronisation), and the sampler's noise is keyed by
+        every game's own step count, so each replay of the graph draws fresh actions.  `obs_compact(sync_count=True)` reads a count
+        on the host and cannot be captured."""
+        t = self.torch
+        s = stream if stream is not None else t.cuda.current_stream(self.device)
+        vecenv._chk(self.env.L.rmj_set_stream(self.env.h, C.c_void_p(s.cuda_stream), 0))
+        self.shared = True
+        return s
+
     def sync(self):
         """own stream: wait for the library's work; shared stream: nothing to do, torch's stream orders it"""
         if not self.shared:

@@ -128,7 +128,53 @@ def run_parts(n, parts, compact=False):
           f"loop {steps / (t1 - t0) / 1e6:.1f} M env.step/s, {(t1 - t0) / K * 1e3:.2f} ms per iteration")
 
 
+def run_graph(n, per_graph=16, with_policy=True):
+    """policy (one torch matmul over the observation rows) -> fused sampler -> step + encode, eager against the same iterations captured
+    once as a HIP graph on a side stream the environment is bound to (TorchVecEnv.bind_stream) and replayed"""
+    env = TorchVecEnv(n, game_mode=2, seed=0, share_stream=True)
+    env.obs(only_active=True)
+    w = (torch.randn(74 * 34, 82, device="cuda") * 0.05).contiguous()
+
+    def iteration():
+        logits = (env._obs.reshape(n * 4, 74 * 34) @ w).view(n, 4, 82) if with_policy else None
+        env.step_obs(env.sample_ids(logits=logits, seed=7))
+
+    def timed(fn, reps):
+        torch.cuda.synchronize()
+        s0 = env.env.total_steps()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            fn()
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        return (env.env.total_steps() - s0) / (t1 - t0), (t1 - t0) / reps
+
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        env.bind_stream()
+        for _ in range(20):
+            iteration()
+        side.synchronize()
+        eager, t_e = timed(iteration, 25 * per_graph)
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, stream=side):
+            for _ in range(per_graph):
+                iteration()
+        for _ in range(3):
+            g.replay()
+        graph, t_g = timed(g.replay, 25)
+    what = "torch matmul policy + fused sampler + step and encode" if with_policy else "fused sampler + step and encode"
+    print(f"games {n} {what}, one stream: eager {eager / 1e6:.1f} M env.step/s ({t_e * 1e6:.0f} us per iteration), "
+          f"as a HIP graph of {per_graph} iterations {graph / 1e6:.1f} M env.step/s ({t_g / per_graph * 1e6:.0f} us per iteration)", flush=True)
+
+
 def main():
+    if len(sys.argv) > 1 and sys.argv[1] == "graph":
+        for n in (1024, 4096, 16384, 65536):
+            run_graph(n, with_policy=False)
+            run_graph(n, with_policy=True)
+        return
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 65536
     ext = len(sys.argv) > 2 and sys.argv[2] == "ext"
     run(n, ext, False)

@@ -250,3 +250,49 @@ def test_step_obs_equals_step_then_obs(mode):
     torch.cuda.synchronize()
     assert torch.equal(oa, ob) and torch.equal(a.mask, b.mask) and torch.equal(a.scores(), b.scores())
     assert (a.env.step_counts() == b.env.step_counts()).all() and float(oa.abs().sum()) > 0
+
+
+@pytest.mark.parametrize("mode", [2, 5])
+def test_env_loop_inside_a_hip_graph(mode):
+    """policy -> sampler -> step + encode captured ONCE as a HIP graph (torch.cuda.CUDAGraph on a side stream the environment is
+    bound to) and replayed: same games, same tensors as the eager loop of a twin environment"""
+    torch = pytest.importorskip("torch")
+    from riichienv_amd.torch_env import TorchVecEnv
+
+    n, per_graph, replays = 2048, 8, 40
+    width = 27 if mode >= 3 else 34
+    torch.manual_seed(3)
+    w = (torch.randn(74 * width, 82, device="cuda") * 0.05).contiguous()
+
+    def iteration(e):
+        logits = (e._obs.reshape(n * 4, 74 * width) @ w).view(n, 4, 82)      # (rows of seats that do not act are ignored)
+        return e.step_obs(e.sample_ids(logits=logits.contiguous(), seed=9))
+
+    a = TorchVecEnv(n, game_mode=mode, seed=77, share_stream=True)
+    b = TorchVecEnv(n, game_mode=mode, seed=77, share_stream=True)
+    a.obs(only_active=True)
+    b.obs(only_active=True)
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        a.bind_stream()
+        iteration(a)                      # warm-up on the capture stream: every lazy buffer exists before the capture
+    iteration(b)
+    side.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g, stream=side):
+        for _ in range(per_graph):
+            iteration(a)
+    s0 = int(a.env.total_steps())
+    for _ in range(replays):
+        g.replay()
+    torch.cuda.synchronize()
+    da = int(a.env.total_steps()) - s0
+    a.bind_stream(torch.cuda.current_stream())
+    sb0 = int(b.env.total_steps())
+    for _ in range(replays * per_graph):
+        iteration(b)
+    torch.cuda.synchronize()
+    assert da == int(b.env.total_steps()) - sb0 and da > replays * per_graph * n // 2      # (the capture itself stepped nothing)
+    assert torch.equal(a._obs, b._obs) and torch.equal(a.mask, b.mask) and torch.equal(a.scores(), b.scores())
+    assert (a.env.step_counts() == b.env.step_counts()).all()

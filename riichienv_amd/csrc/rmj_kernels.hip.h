@@ -184,8 +184,11 @@ __global__ __launch_bounds__(256, 4) void k_apply_event(const Env* __restrict__ 
     GState& S = sh.st[wave];
     load_state(S, E.core + g, lane);
     Ctx c{S, E, sh.x[wave], g, lane, E.wall + (size_t)g * RMJ_WALL_STRIDE, E.legal + (size_t)g * 4 * RMJ_MAX_LEGAL};
+    // reach_accepted and dora move points and indicators only (event_handler.rs:311-319): whatever the seats were offered - the claims
+    // on a riichi declaration tile, say - stands, and so do the published lists, masks and status
+    const bool passive = mine[0].type == RMJ_EV_REACH_ACCEPTED || mine[0].type == RMJ_EV_DORA;
     apply_event(c, mine);
-    finalize_outputs<false>(c, true, false);  // apply_event hands out no observation (env.rs:880-887)
+    if (!passive) finalize_outputs<false>(c, true, false);  // apply_event hands out no observation (env.rs:880-887)
     store_state(S, E.core + g, lane);
 }
 

@@ -111,6 +111,26 @@ def test_replay_own_logs(mode):
     _run_streams(mode, streams)
 
 
+@pytest.mark.parametrize("mode,rate", [(2, 64), (5, 32)])
+def test_replay_logs_of_winning_play(mode, rate):
+    """Logs of the greedy policy (riichi declared and accepted, ippatsu, kan dora, Ron / Tsumo / multi-Ron settlements, renchan, games
+    that end) fed back through apply_events: a RandomAgent's logs hold next to none of these."""
+    from oracle import oracle
+
+    streams, kinds = [], set()
+    for g in range(24):
+        o = oracle.Game(game_mode=mode, seed=900 + g)
+        o.reset()
+        for _ in range(300 + 25 * g):
+            if o.status()[2]:
+                break
+            o.step([int(x) for x in o.greedy_actions(31, g, rate)])
+        streams.append([json.loads(x) for x in o.log()])
+        kinds |= {e["type"] for e in streams[-1]}
+    assert {"hora", "reach", "reach_accepted", "end_kyoku"} <= kinds, kinds
+    _run_streams(mode, streams)
+
+
 @pytest.mark.parametrize("mode,npl", [(2, 4), (5, 3)])
 def test_start_kyoku_after_a_depleted_round(mode, npl):
     """riichienv-core/src/tests.rs:576-834 on the device: start_kyoku rewinds the wall and resets drawable_count (left at 1 by the

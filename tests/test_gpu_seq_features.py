@@ -100,8 +100,8 @@ def test_compat_observation_seq_features():
         o3.encode_seq_numeric()
 
 
-@pytest.mark.parametrize("mode,seed", [(2, 29), (0, 100)])
-def test_seq_features_per_observation_delta(mode, seed):
+@pytest.mark.parametrize("mode,seed,policy", [(2, 29, "random"), (0, 100, "random"), (2, 31, "greedy"), (1, 32, "greedy")])
+def test_seq_features_per_observation_delta(mode, seed, policy):
     """rmj_encode_seq_delta: the features over Observation.events as the reference's LIVE environment hands them out - the
     seat's log since its previous observation (state/mod.rs:211-218).  The harness keeps the oracle seats' cursors exactly
     like get_observation does (advanced for every acting seat after reset and after every step) and feeds the Python
@@ -161,10 +161,16 @@ def test_seq_features_per_observation_delta(mode, seed):
                     if v.drawn_tile >= 0 and v.current_player == p and sf.get_drawn_tile(ev, p) is None:
                         seen_reach_without_draw += 1
                     seen_start += any('"start_kyoku"' in s for s in ev)
-        acts = np.array([games[g].random_actions(pseed, g) for g in range(n)], dtype=np.uint64)
+        if policy == "greedy":   # play that declares riichi, calls kans and wins (orc_game_greedy_actions); finished games idle
+            from riichienv_amd import abi
+            acts = np.array([[abi.NO_ACTION] * 4 if games[g].status()[2] else [int(x) for x in games[g].greedy_actions(pseed, g, 64)]
+                             for g in range(n)], dtype=np.uint64)
+        else:
+            acts = np.array([games[g].random_actions(pseed, g) for g in range(n)], dtype=np.uint64)
         env.step(acts)
         for g in range(n):
-            games[g].step([int(x) for x in acts[g]])
+            if policy == "random" or not games[g].status()[2]:
+                games[g].step([int(x) for x in acts[g]])
             observe(g)
     assert seen_start > 0
     if mode == 2:

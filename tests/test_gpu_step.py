@@ -272,8 +272,8 @@ def test_two_stream_rollout_equals_single_stream(mode):
         assert r.launches == 1 and r.launches_in_flight == 1
 
 
-@pytest.mark.parametrize("mode", [2, 5])
-def test_noisy_host_actions_parity(mode):
+@pytest.mark.parametrize("mode,policy", [(2, "random"), (5, "random"), (2, "greedy"), (5, "greedy")])
+def test_noisy_host_actions_parity(mode, policy):
     """GameState::step validates what it is given (state/mod.rs:339-402): a seeded fraction of the host's actions is replaced
     by actions the reference rejects or ignores - a discard of a tile the seat does not hold, another seat's legal action, a
     Pass outside WaitResponse, an action from a seat that is not to act, a missing action - and every step (illegal-action
@@ -291,7 +291,11 @@ def test_noisy_host_actions_parity(mode):
     rng = np.random.default_rng(seed)
     noisy = 0
     for step in range(1, 900):
-        acts = np.array([games[g].random_actions(pseed, g) for g in range(n)], dtype=np.uint64)
+        if policy == "greedy":   # the base play declares riichi, holds tenpai hands and wins: the noise then lands in those states
+            acts = np.array([[abi.NO_ACTION] * 4 if games[g].status()[2] else [int(x) for x in games[g].greedy_actions(pseed, g, 64)]
+                             for g in range(n)], dtype=np.uint64)
+        else:
+            acts = np.array([games[g].random_actions(pseed, g) for g in range(n)], dtype=np.uint64)
         for g in range(n):
             oa, _, od = games[g].status()
             if od or rng.random() > 0.02:

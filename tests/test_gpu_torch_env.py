@@ -296,3 +296,59 @@ def test_env_loop_inside_a_hip_graph(mode):
     assert da == int(b.env.total_steps()) - sb0 and da > replays * per_graph * n // 2      # (the capture itself stepped nothing)
     assert torch.equal(a._obs, b._obs) and torch.equal(a.mask, b.mask) and torch.equal(a.scores(), b.scores())
     assert (a.env.step_counts() == b.env.step_counts()).all()
+
+
+@pytest.mark.parametrize("mode", [2, 5])
+def test_ids_without_a_legal_action_are_illegal_actions(mode):
+    """An id no legal action of the seat carries (Observation.find_action returns None, observation/python.rs:119-122), a missing id
+    (-1) for a seat that is to act, an id for a seat that is not: the step takes the reference's illegal-action path (penalty round
+    end, state/mod.rs:339-402).  The oracle is given an action it rejects the same way."""
+    torch = pytest.importorskip("torch")
+    from oracle import oracle
+    from riichienv_amd.torch_env import TorchVecEnv
+    from tests.test_gpu_step import _compare
+
+    n, seed = 48, 8300 + mode
+    sanma = mode >= 3
+    env = TorchVecEnv(n, game_mode=mode, seed=seed, skip_mjai_logging=False, share_stream=True, event_ring=16384)
+    games = [oracle.Game(game_mode=mode, seed=game_seed(seed, g)) for g in range(n)]
+    for o in games:
+        o.reset()
+    enc_fn = games[0].L.orc_action_encode_3p if sanma else games[0].L.orc_action_encode
+    rng = np.random.default_rng(seed)
+    bogus = abi.pack_action(0x7F)
+    bad = 0
+    for step in range(1, 500):
+        ids = np.full((n, 4), -1, dtype=np.int32)
+        for g, o in enumerate(games):
+            oa, _, od = o.status()
+            if od:
+                continue
+            acts = [abi.NO_ACTION] * 4
+            for s in range(4):
+                if not (oa >> s) & 1:
+                    if rng.random() < 0.003:        # a seat that is not to act sends an id: ignored
+                        ids[g, s] = int(rng.integers(30))
+                    continue
+                legal = o.legal(s)
+                a = legal[int(rng.integers(len(legal)))]
+                ids[g, s] = enc_fn(a)
+                acts[s] = next(x for x in legal if enc_fn(x) == ids[g, s])
+                u = rng.random()
+                if u < 0.004:                       # an id nothing legal has
+                    have = {enc_fn(x) for x in legal}
+                    ids[g, s] = next(i for i in range(82) if i not in have)
+                    acts[s] = bogus
+                    bad += 1
+                elif u < 0.006:                     # no id at all
+                    ids[g, s] = -1
+                    acts[s] = abi.NO_ACTION
+                    bad += 1
+            o.step(acts)
+        env.step(torch.from_numpy(ids).to(env.device), auto_reset=False)
+        torch.cuda.synchronize()
+        _compare(env.env, games, range(n), step, check_state=False)
+        _compare(env.env, games, [step % n, (3 * step) % n], step, check_state=True)
+    assert bad > 20
+    for g, o in enumerate(games):
+        assert env.env.mjai_log(g) == o.log(), g

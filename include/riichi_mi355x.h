@@ -402,8 +402,11 @@ int rmj_set_stream(rmj_handle h, void* hip_stream, int own);
  * env.rs:56-72 is not reproduced (start_game clears the device log, later events are not appended).
  * RMJ_EVF_REPLAY_PASS in the first record's `pad`: the bookkeeping of the reference's log walker on top of the event
  * (KyokuStepIterator, replay/mod.rs:129-177; apply_log_action, state/event_handler.rs:391-392): a seat that was offered Ron on
- * the last discard and does not win with this event has passed (same-turn furiten, permanent in riichi), and a discard ends
- * the discarder's same-turn furiten - what (observation, action) datasets built from logs need. */
+ * the last discard and does not win with this event has passed (same-turn furiten, permanent in riichi), a discard ends
+ * the discarder's same-turn furiten, and the tile dealt after a kan (3P: after a kita too) is a rinshan draw (is_after_kan,
+ * event_handler.rs:428: a win on it whose only yaku is rinshan kaihou is offered) - what (observation, action) datasets built
+ * from logs need.  reach_accepted / dora events leave the published lists untouched (the claims on a riichi declaration tile
+ * are decided after reach_accepted). */
 #define RMJ_EVF_REPLAY_PASS 1u
 int rmj_apply_events(rmj_handle h, const RmjEvent* events /*[n][3]*/);
 

@@ -222,6 +222,18 @@ void orc_game_apply_event(void* gp, const RmjEvent* ev, int nrec) {
     }
     // ... and the walker's discard (apply_log_action, state/event_handler.rs:391-392) ends the discarder's same-turn furiten
     if ((e.pad & 1) && e.type == RMJ_EV_DAHAI && actor < g->NP) g->players[actor].missed_agari_doujun = false;
+    // ... and the walker knows a replacement draw (apply_log_action: is_after_kan, state/event_handler.rs:415, :428-430, :565, :658,
+    // state_3p/event_handler.rs:606 - kita too): the tile dealt after a kan is a rinshan draw, any other deal is not
+    if (e.type == RMJ_EV_START_KYOKU) g->replay_after_kan = false;
+    if (e.pad & 1) {
+        switch (e.type) {
+            case RMJ_EV_DAHAI: case RMJ_EV_PON: case RMJ_EV_CHI: g->replay_after_kan = false; break;
+            case RMJ_EV_DAIMINKAN: case RMJ_EV_ANKAN: case RMJ_EV_KAKAN: g->replay_after_kan = true; break;
+            case RMJ_EV_KITA: if (g->sanma) g->replay_after_kan = true; break;
+            case RMJ_EV_TSUMO: g->is_rinshan_flag = g->replay_after_kan; g->replay_after_kan = false; break;
+            default: break;
+        }
+    }
     switch (e.type) {
         case RMJ_EV_START_GAME:  // env.rs:56-72 (reset) + event_handler.rs:20-25
             g->reset();

@@ -277,6 +277,7 @@ struct GameState {
     std::optional<std::pair<uint8_t, Action>> pending_kan;
     uint8_t oya = 0, honba = 0, kyoku_idx = 0, round_wind = 0;
     bool is_rinshan_flag = false, is_first_turn = true;
+    bool replay_after_kan = false;   // is_after_kan of the log walker (apply_log_action, state/event_handler.rs:415-430, :565, :658)
     int riichi_pending_acceptance = -1;
     int drawn_tile = -1;
     std::map<uint8_t, WinResult> win_results;

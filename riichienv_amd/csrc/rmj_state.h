@@ -83,7 +83,8 @@ struct alignas(16) GState {  // 4*128 + 128 = 640 bytes
     // resurface, in front of a chankan / kita Ron offer, if the caller kans or declares kita before discarding).
     uint8_t stale_n[4];
     uint8_t nlegal[4];        // copy of the nlegal slab row: the policy / validation need it as soon as the record arrives
-    uint8_t pad0_[3];
+    uint8_t replay_after_kan;   // is_after_kan of the reference's log walker (apply_log_action): set by rmj_apply_events in replay mode only
+    uint8_t pad0_[2];
     uint32_t full_count;      // measurement only: steps of this game that took the full path of k_step (bench.py)
     // player_event_counts of the reference (state/mod.rs:65, 211-218): the events [obs_from[p], obs_upto[p]) are the delta
     // (Observation.events) of seat p's latest observation; advanced whenever observations are published for an acting seat

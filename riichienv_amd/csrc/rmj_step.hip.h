@@ -2043,6 +2043,14 @@ __device__ inline void apply_event(Ctx& c, const RmjEvent* ev) {
     }
     // ... and the walker's discard (apply_log_action, state/event_handler.rs:391-392) ends the discarder's same-turn furiten
     if ((ev[0].pad & 1u) && ty == RMJ_EV_DAHAI) P.flags &= ~PF_MISSED_DOUJUN;
+    // ... and the walker knows a replacement draw (apply_log_action: is_after_kan, state/event_handler.rs:415, :428-430, :565, :658,
+    // state_3p/event_handler.rs:606 - kita too): the tile dealt after a kan is a rinshan draw, any other deal is not
+    if (ty == RMJ_EV_START_KYOKU) S.replay_after_kan = 0;
+    if (ev[0].pad & 1u) {
+        if (ty == RMJ_EV_DAHAI || ty == RMJ_EV_PON || ty == RMJ_EV_CHI) S.replay_after_kan = 0;
+        else if (ty == RMJ_EV_DAIMINKAN || ty == RMJ_EV_ANKAN || ty == RMJ_EV_KAKAN || (KSANMA && ty == RMJ_EV_KITA)) S.replay_after_kan = 1;
+        else if (ty == RMJ_EV_TSUMO) { S.is_rinshan = S.replay_after_kan; S.replay_after_kan = 0; }
+    }
     switch (ty) {
         case RMJ_EV_START_GAME:  // env.rs:56-72 + event_handler.rs:20-25
             S.ev_count = 0;

@@ -265,3 +265,67 @@ def test_pass_samples_carry_the_missed_ron_furiten():
             if int(smp["seat"][j]) == 1 and abi.unpack_action(int(smp["action"][j]))[0] == abi.PASS:
                 got[int(smp["game"][j])].append(bool(smp["mask"][j][79]))      # id 79 = Ron / Tsumo
     assert got == {0: [True, True], 1: [True]}
+
+
+@pytest.mark.parametrize("mode,rate", [(2, 96), (5, 64)])
+def test_logs_of_winning_play_yield_every_decision(mode, rate):
+    """The same over logs that hold what the one real hanchan does not hold often enough: claims on a riichi declaration tile (the
+    claimer decides AFTER reach_accepted), kans of every kind with their indicators, kita, wins of every kind - logs of the oracle
+    playing the greedy policy.  Every decision event of every log must produce a sample with the oracle's legal list, mask and tensor."""
+    import json
+
+    from oracle import oracle
+    from riichienv_amd import replay
+
+    sanma = mode >= 3
+    logs = []
+    for g in range(8):
+        o = oracle.Game(game_mode=mode, seed=1300 + g)
+        o.reset()
+        for _ in range(2500):
+            if o.status()[2]:
+                break
+            o.step([int(x) for x in o.greedy_actions(53, g, rate)])
+        logs.append([json.loads(x) for x in o.log()])
+    types = ("dahai", "pon", "chi", "reach", "hora", "ankan", "daiminkan", "kakan", "kita")
+    # what the same pipeline yields on the oracle: a decision event counts when the replayed state offers its action to the actor (the
+    # event handler sets up no chankan claims, event_handler.rs:290-305, so the Ron on a robbed kan is not offered; later winners of a
+    # multi-Ron find a finished round - the reference's iterator yields the first winner only, replay/mod.rs:483-485).  A win on the
+    # replacement tile IS offered: replay mode keeps the walker's is_after_kan (apply_log_action, event_handler.rs:428).
+    want, raw = dict.fromkeys(types, 0), dict.fromkeys(types, 0)
+    for log in logs:
+        r = oracle.Game(game_mode=mode, seed=1)
+        r.reset()
+        for e in log:
+            if e["type"] in want:
+                raw[e["type"]] += 1
+                a, _, dn = r.status()
+                s = int(e["actor"])
+                if (a >> s) & 1 and not dn:
+                    v = r.peek()
+                    want[e["type"]] += mjai.select_action_from_mjai(r.legal(s), e, None if v.drawn_tile < 0 else int(v.drawn_tile), sanma) is not None
+            r.apply_event(e, replay=True)
+    assert raw["hora"] > 20 and raw["reach"] > 20 and raw["pon"] > 10 and raw["daiminkan"] + raw["kakan"] + raw["ankan"] > 3, raw
+    assert all(want[t] == raw[t] for t in types if t != "hora") and raw["hora"] - want["hora"] <= 4, (want, raw)
+    rb = replay.ReplayBatch(logs, game_mode=mode, include_pass=False)
+    games = [oracle.Game(game_mode=mode, seed=1) for _ in logs]
+    for o in games:
+        o.reset()
+    cursor = [0] * len(logs)
+    got = dict.fromkeys(types, 0)
+    for smp in rb.samples():
+        k = smp["index"]
+        for j in range(len(smp["game"])):
+            g, s = int(smp["game"][j]), int(smp["seat"][j])
+            o = games[g]
+            while cursor[g] < k:
+                o.apply_event(logs[g][cursor[g]], replay=True)
+                cursor[g] += 1
+            ev = logs[g][k]
+            got[ev["type"]] += 1
+            v = o.peek()
+            sel = mjai.select_action_from_mjai(o.legal(s), ev, None if v.drawn_tile < 0 else int(v.drawn_tile), sanma)
+            assert sel == int(smp["action"][j]), (g, k, ev)
+            assert (smp["mask"][j] == np.asarray(o.mask(s))[: len(smp["mask"][j])]).all(), (g, k, ev)
+            assert smp["obs"][j].tobytes() == o.encode(s, sanma).tobytes(), (g, k, s)
+    assert got == want, (got, want)

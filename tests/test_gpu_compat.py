@@ -367,3 +367,44 @@ def test_quickstart_example_runs():
     assert shape == (74, 34) and steps > 0
     hand, n_dec, first = q.hands_and_logs()
     assert hand[:4] == (2, 40, 1300, 700) and n_dec > 20 and len(first) == 3
+
+
+@pytest.mark.parametrize("mode,rule_name", [("4p-red-half", "tenhou"), ("3p-red-half", "mjsoul")])
+def test_scalar_env_against_the_oracle_under_winning_play(mode, rule_name):
+    """The drop-in loop of the reference (obs = env.step({pid: action})) with the reference's objects - Observation.legal_actions(),
+    .new_events(), .hand, env.scores(), env.mjai_log - against the oracle playing the same game: the greedy policy picks the
+    actions (riichi, kans, kita, wins of every kind), every observation of every step is compared, the whole log at the end."""
+    from oracle import oracle
+    from riichienv_amd import abi
+    from riichienv_amd.compat import Action, GameRule, RiichiEnv
+
+    rule = GameRule.default_mjsoul() if rule_name == "mjsoul" else GameRule.default_tenhou()
+    env = RiichiEnv(game_mode=mode, seed=4242, rule=rule)
+    o = oracle.Game(game_mode=env._mode, seed=4242, rule_bits=rule.bits())
+    o.reset()
+    obs = env.reset()
+    cursor = [0] * 4
+    steps = wins = 0
+    while not env.done():
+        oa, _, od = o.status()
+        assert not od and sorted(obs.keys()) == [s for s in range(4) if (oa >> s) & 1], steps
+        v = o.peek()
+        for pid, ob in obs.items():
+            assert [a._pack() for a in ob.legal_actions()] == o.legal(pid), (steps, pid)
+            log = o.log(pid)
+            assert ob.new_events() == log[cursor[pid]:], (steps, pid, ob.new_events()[:3], log[cursor[pid]:][:3])
+            cursor[pid] = len(log)
+            assert list(ob.hand) == [int(t) for t in v.players[pid].hand[: v.players[pid].hand_len]], (steps, pid)
+            assert bytes(ob.mask()) == bytes(bytearray(o.mask(pid))[: len(ob.mask())]), (steps, pid)
+        acts = [int(x) for x in o.greedy_actions(77, 0, 64)]
+        obs = env.step({pid: Action._from_packed(acts[pid]) for pid in obs})
+        o.step(acts)
+        steps += 1
+        assert steps < 6000
+    assert o.status()[2]
+    assert [json.dumps(e, sort_keys=True, separators=(",", ":")) for e in env.mjai_log] == \
+        [json.dumps(json.loads(s), sort_keys=True, separators=(",", ":")) for s in o.log()]
+    v = o.peek()
+    assert list(env.scores())[: env.num_players] == [v.players[p].score for p in range(env.num_players)]
+    wins = sum(1 for e in env.mjai_log if e["type"] == "hora")
+    assert wins >= 3 and any(e["type"] == "reach_accepted" for e in env.mjai_log)

@@ -40,12 +40,20 @@ def test_greedy_policy_step_by_step(mode, rule, rate):
     env = vecenv.VecRiichiEnv(n, game_mode=mode, seed=seed, rule_bits=rule, event_ring=16384)
     env.reset()
     games = _oracle_games(mode, rule, seed, n)
+    wins_checked = 0
     for k in range(1, steps + 1):
         _oracle_play(games, pseed, 1, rate, auto_reset=False)
         env.step_greedy(pseed, 1, auto_reset=False, call_rate_256=rate)
         _compare(env, games, range(n), k, check_state=False)
         _compare(env, games, [k % n, (7 * k) % n], k, check_state=True)
+        # RiichiEnv.win_results (env.rs:606-607): the winners' WinResult - yaku ids in order, han, fu, payments, pao payer - of every
+        # game whose oracle holds one, and of a rotating game that may hold none
+        for g in [g for g in range(n) if g == k % n or games[g].win_results()]:
+            want = games[g].win_results()
+            assert env.win_results(g) == want, (k, g, env.win_results(g), want)
+            wins_checked += len(want)
     _compare(env, games, range(n), -1, check_state=True)
+    assert wins_checked > 40, wins_checked
     kinds = set()
     for g, o in enumerate(games):
         log = o.log()

@@ -1168,9 +1168,17 @@ __device__ __forceinline__ uint64_t r4_policy_greedy(R4& q, bool on, const uint6
 }
 
 // One step of four consecutive games per wave (device policy only: rmj_step_random / rmj_bench_rollout); `load`: fetch the records from HBM first (the rollout loop keeps them in LDS)
-template <bool LOOP, int POL>
-__device__ __forceinline__ void step4_body(const Env* Ep, Quad4Shared& sh, uint64_t policy_seed, uint32_t flags, uint32_t g_base, uint32_t g_end,
-                                           bool load, uint64_t gs_row, const uint64_t* __restrict__ actions = nullptr, uint32_t quad = 0xFFFFFFFFu) {
+// INLR (fused RandomAgent rollouts): a row whose discard drew claims answers them in the SAME call - the policy picks the seats'
+// responses from the staged lists and the WaitResponse branch runs right behind the WaitAct branch - so that every call starts with
+// (nearly) all four rows in WaitAct instead of 44 % of the waves paying for both branches with part of their rows idle in each.
+// Rows then advance one or two game-steps per call: `left` = the steps the row's game still has to take in this rollout / ticket
+// (row-uniform), the result = how many it took (0: none left).  `final_chunk`: the rollout ends when `left` runs out (the last
+// step publishes masks and status, STEP_F_ALLROWS; every other step is quiet) - with INLR the caller passes `flags` without those bits.
+template <bool LOOP, int POL, bool INLR = false>
+__device__ __forceinline__ uint32_t step4_body(const Env* Ep, Quad4Shared& sh, uint64_t policy_seed, uint32_t flags, uint32_t g_base, uint32_t g_end,
+                                               bool load, uint64_t gs_row, const uint64_t* __restrict__ actions = nullptr, uint32_t quad = 0xFFFFFFFFu,
+                                               uint32_t left = 1u, bool final_chunk = true) {
+    static_assert(!INLR || (LOOP && POL == 0), "inline responses: fused RandomAgent rollouts only");
     CEnv& E = *(CEnv*)Ep;
     // RICH tier 0 (the wait probe, the Riichi offer / declaration / riichi-stage list in row form): for policies that play - the
     // greedy instantiation and the per-step kernels an external policy drives.  The fused RandomAgent rollout keeps the lean
@@ -1199,7 +1207,7 @@ __device__ __forceinline__ void step4_body(const Env* Ep, Quad4Shared& sh, uint6
     {
     R4 q;
     q.G = &sh.st[row]; q.T = &sh.u.t; q.E = &E; q.lane = lane; q.r = r; q.rb = rb; q.row = row; q.g = g;
-    q.live = (uint32_t)row < n_here;
+    q.live = (uint32_t)row < n_here && (!INLR || left != 0u);
     GState* G = q.G;
     const uint64_t* Lg = E.legal + (size_t)g * 4 * RMJ_MAX_LEGAL;
     q.bail = false; q.evn = 0; q.dirty = 0xFu;
@@ -1290,6 +1298,7 @@ __device__ __forceinline__ void step4_body(const Env* Ep, Quad4Shared& sh, uint6
     int nl_mine = 0;          // lane = seat: length of the seat's list produced by this step
     uint64_t w_mine = 0ull;   // lane = seat: waits published for the seat
     const bool t0 = q.live && !q.bail;
+    bool second = false;      // INLR: this row answers the claims on its own discard in this call (its second game-step)
     if (t0) {
         if (r == 0) G->step_count += 1;
         const int phase = G->phase;
@@ -1513,11 +1522,34 @@ __device__ __forceinline__ void step4_body(const Env* Ep, Quad4Shared& sh, uint6
             } else {
                 R4BAIL(q, 23);   // Riichi (with a tile), Tsumo, Kyushu; lean tier: kans
             }
-        } else {
+        }
+        uint64_t mine_r = mine;   // the seats' responses (lane = seat)
+        if (INLR) {
+            // the discard drew claims and the game has a step left: what the NEXT call would do first - the claim-offered seats get
+            // their observation (event cursors, state/mod.rs:211-218), the policy keys (game, step, seat) pick from the staged lists
+            second = phase == RMJ_WAIT_ACT && !q.bail && G->phase == RMJ_WAIT_RESPONSE && left >= 2u;
+            if (second) {
+                const uint32_t am2 = G->active_mask;
+                const uint32_t sc = G->step_count;
+                mine_r = RMJ_NO_ACTION;
+                if (r < 4 && ((am2 >> r) & 1u)) {
+                    G->obs_from[r] = G->obs_upto[r];
+                    G->obs_upto[r] = G->ev_count;
+                    if (nl_mine > 0) {
+                        const uint64_t key = sm64(gs_row + (uint64_t)sc * 4ull + (uint64_t)r);
+                        const uint32_t ch = mod_small_magic(key, nl_mine > 64 ? 64u : (uint32_t)nl_mine);
+                        mine_r = q.T->lst[row][r][ch] & 0x00FFFFFFFFFFFFFFull;
+                    }
+                }
+                wave_sync();
+                if (r == 0) G->step_count = sc + 1u;
+            }
+        }
+        if (phase != RMJ_WAIT_ACT || second) {
             // ---- WaitResponse (state/mod.rs:900-1314), lane = seat
             q.dirty = 0xFu;
-            const bool has = r < 4 && mine != RMJ_NO_ACTION;
-            const uint32_t my_ty = a_type(mine);
+            const bool has = r < 4 && mine_r != RMJ_NO_ACTION;
+            const uint32_t my_ty = a_type(mine_r);
             const uint32_t act_m = G->active_mask;
             const bool is_act = has && ((act_m >> r) & 1u);
             const uint32_t roned = rballot(has && my_ty == RMJ_RON, rb) & 0xFu;
@@ -1535,7 +1567,7 @@ __device__ __forceinline__ void step4_body(const Env* Ep, Quad4Shared& sh, uint6
                 const int claimer = pon_m ? __ffs((int)pon_m) - 1 : (chi_m ? __ffs((int)chi_m) - 1 : -1);
                 wave_sync();
                 if (claimer >= 0) {
-                    const uint64_t claim = rbc64(mine, rb + claimer);
+                    const uint64_t claim = rbc64(mine_r, rb + claimer);
                     const uint32_t ty = a_type(claim);
                     if (ty == RMJ_DAIMINKAN && !RICH) {
                         R4BAIL(q, 25);
@@ -1683,6 +1715,10 @@ __device__ __forceinline__ void step4_body(const Env* Ep, Quad4Shared& sh, uint6
     R4T(3);
     // ---- publication of the rows that completed in tier 0
     const bool done0 = q.live && t0 && !q.bail;
+    // INLR: the steps this call took for the row's game (a bailed row takes ONE in the full path, from the untouched record, whatever
+    // tier 0 had got to), and the row's own publication flags: quiet unless this was the last step of the rollout
+    const uint32_t used = !q.live ? 0u : ((INLR && second && !q.bail) ? 2u : 1u);
+    const uint32_t fl_pub = INLR ? (flags | ((final_chunk && left == used) ? STEP_F_ALLROWS : STEP_F_QUIET)) : flags;
     if (done0) {
         const uint32_t am = G->active_mask;
         const bool acts = r < 4 && ((am >> r) & 1u);
@@ -1691,8 +1727,8 @@ __device__ __forceinline__ void step4_body(const Env* Ep, Quad4Shared& sh, uint6
         // Inside a fused rollout only the LAST step's observation can be read by anybody (the policy reads the lists and the
         // record): the steps before it (STEP_F_QUIET) publish lists, record and events only - no mask rows, no nlegal / waits /
         // status words - and the last one (STEP_F_ALLROWS) rewrites all four mask rows, whatever the quiet steps left behind.
-        const bool quiet = LOOP && (flags & STEP_F_QUIET) != 0u;
-        const uint32_t rows = quiet ? 0u : ((LOOP && (flags & STEP_F_ALLROWS)) ? 0xFu : ((rballot(r < 4 && G->nlegal[r & 3] != 0, rb) | am) & 0xFu));
+        const bool quiet = LOOP && (fl_pub & STEP_F_QUIET) != 0u;
+        const uint32_t rows = quiet ? 0u : ((LOOP && (fl_pub & STEP_F_ALLROWS)) ? 0xFu : ((rballot(r < 4 && G->nlegal[r & 3] != 0, rb) | am) & 0xFu));
         if (!quiet) q.T->mk[row][r >> 2][r & 3] = 0u;
         wave_sync();
         for (uint32_t m = am; m; m &= m - 1u) {
@@ -1768,7 +1804,7 @@ __device__ __forceinline__ void step4_body(const Env* Ep, Quad4Shared& sh, uint6
         if (lane == 0) sh.u.x.tl_prev = __builtin_readcyclecounter();
         wave_sync();
 #endif
-        ol_step_full(ctx_pack(c), lane < 4 ? m_full : RMJ_NO_ACTION, flags);
+        ol_step_full(ctx_pack(c), lane < 4 ? m_full : RMJ_NO_ACTION, INLR ? (uint32_t)__builtin_amdgcn_readlane((int)fl_pub, 16 * br) : flags);
         wave_sync();
 #ifdef RMJ_TL4
         if (!LOOP && lane < 16) rmj::g_tl4[(size_t)blockIdx.x * RMJ_TL4_ROW + 16 + lane] += (unsigned long long)sh.u.x.tl_acc[lane];
@@ -1783,6 +1819,7 @@ __device__ __forceinline__ void step4_body(const Env* Ep, Quad4Shared& sh, uint6
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         wave_sync();
     }
+    return used;
     }
 }
 // The step as an out-of-line function with its own static LDS: the rollout loop calls it once per step, so nothing of a
@@ -1792,6 +1829,35 @@ __device__ __noinline__ void step4_call(const Env* Ep, uint64_t policy_seed, uin
                                         uint64_t gs_row, uint32_t quad = 0xFFFFFFFFu) {
     __shared__ Quad4Shared sh;
     step4_body<LOOP, POL>(uni_ptr(Ep), sh, uni(policy_seed), uni(flags), uni(g_base), uni(g_end), uni(load) != 0u, gs_row, nullptr, uni(quad));
+}
+// ... with inline responses (step4_body<.., INLR>): `left` steps to go per row, returns the steps taken per row
+#ifndef RMJ_INLINE_RESP
+#define RMJ_INLINE_RESP 1
+#endif
+template <int POL>
+__device__ __noinline__ uint32_t step4_call_inl(const Env* Ep, uint64_t policy_seed, uint32_t flags, uint32_t g_base, uint32_t g_end, uint32_t load,
+                                                uint64_t gs_row, uint32_t quad, uint32_t left, uint32_t final_chunk) {
+    __shared__ Quad4Shared sh;
+    return step4_body<true, POL, true>(uni_ptr(Ep), sh, uni(policy_seed), uni(flags), uni(g_base), uni(g_end), uni(load) != 0u, gs_row, nullptr, uni(quad),
+                                       left, uni(final_chunk) != 0u);
+}
+// the steps [0, steps) of a quad's rollout / ticket: the RandomAgent answers claims inline (rows run ahead of each other by a step or
+// two and wait at the end), the greedy policy steps all rows in lock-step
+template <int POL>
+__device__ __forceinline__ void step4_run(const Env* Ep, uint64_t policy_seed, uint32_t flags, uint32_t g_base, uint32_t g_end, uint64_t gs_row,
+                                          uint32_t quad, uint32_t steps, bool final_chunk, uint32_t g_row) {
+    if (RMJ_INLINE_RESP && POL == 0) {
+        uint32_t left = g_row < g_end ? steps : 0u, load = 1u;
+#pragma unroll 1
+        while (__ballot(left != 0u)) {
+            left -= step4_call_inl<0>(Ep, policy_seed, flags, g_base, g_end, load, gs_row, quad, left, final_chunk ? 1u : 0u);
+            load = 0u;
+        }
+    } else {
+#pragma unroll 1
+        for (uint32_t it = 0; it < steps; it++)
+            step4_call<true, POL>(Ep, policy_seed, flags | ((final_chunk && it + 1u == steps) ? STEP_F_ALLROWS : STEP_F_QUIET), g_base, g_end, it == 0 ? 1u : 0u, gs_row, quad);
+    }
 }
 #ifndef RMJ_STEP4_WAVES
 #define RMJ_STEP4_WAVES 6
@@ -1808,9 +1874,7 @@ __global__ __launch_bounds__(64, RMJ_STEP4_WAVES) void k_step4(const Env* __rest
     if (LOOP) {
         const uint32_t g = g_base + blockIdx.x * 4u + ((threadIdx.x & 63u) >> 4);
         const uint64_t gs_row = sm64(policy_seed + ((CEnv*)Ep)->game_offset + (uint64_t)g);   // policy key of the row's game
-#pragma unroll 1
-        for (uint32_t it = 0; it < n_steps; it++)
-            step4_call<true, POL>(Ep, policy_seed, flags | (it + 1u < n_steps ? STEP_F_QUIET : STEP_F_ALLROWS), g_base, g_end, it == 0 ? 1u : 0u, gs_row);
+        step4_run<POL>(Ep, policy_seed, flags, g_base, g_end, gs_row, 0xFFFFFFFFu, n_steps, true, g);
     } else {
         __shared__ Quad4Shared sh;
 #ifdef RMJ_TL4
@@ -1876,9 +1940,7 @@ __global__ __launch_bounds__(64, RMJ_STEP4_WAVES) void k_step4_queue(const Env* 
         const uint32_t g = quad * 4u + (lane >> 4);
         const uint64_t gs_row = sm64(policy_seed + ((CEnv*)Ep)->game_offset + (uint64_t)g);
         const bool last_chunk = c + 1u == n_chunks;
-#pragma unroll 1
-        for (uint32_t it = 0; it < steps; it++)
-            step4_call<true, POL>(Ep, policy_seed, flags | ((last_chunk && it + 1u == steps) ? STEP_F_ALLROWS : STEP_F_QUIET), 0u, n_games, it == 0 ? 1u : 0u, gs_row, quad);
+        step4_run<POL>(Ep, policy_seed, flags, 0u, n_games, gs_row, quad, steps, last_chunk, g);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this chunk's stores are in the XCD's L2
         wave_sync();
         if (lane == 0u) __hip_atomic_store(done + quad, c + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1894,9 +1956,7 @@ __global__ __launch_bounds__(64, RMJ_STEP4_WAVES) void k_step4_fixup(const Env* 
     if (uni(__hip_atomic_load(done + blockIdx.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) != 0u) return;
     const uint32_t g = blockIdx.x * 4u + ((threadIdx.x & 63u) >> 4);
     const uint64_t gs_row = sm64(policy_seed + ((CEnv*)Ep)->game_offset + (uint64_t)g);
-#pragma unroll 1
-    for (uint32_t it = 0; it < n_steps; it++)
-        step4_call<true, POL>(Ep, policy_seed, flags | (it + 1u < n_steps ? STEP_F_QUIET : STEP_F_ALLROWS), 0u, n_games, it == 0 ? 1u : 0u, gs_row);
+    step4_run<POL>(Ep, policy_seed, flags, 0u, n_games, gs_row, 0xFFFFFFFFu, n_steps, true, g);
 }
 
 

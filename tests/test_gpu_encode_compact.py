@@ -106,6 +106,7 @@ def test_padded_row_stride_equals_dense_rows(mode):
     oa = torch.zeros((n, 4, 74 * w), dtype=torch.float32, device="cuda:0")
     ob = torch.full((n, 4, stride), -7.0, dtype=torch.float32, device="cuda:0")
     ob[:, :, : 74 * w] = 0.0
+    torch.cuda.synchronize()
     a.step_random_encode(5, 150, oa.data_ptr(), auto_reset=True, only_active=2)      # one launch, rows of the acting seats
     b.step_random_encode(5, 150, ob.data_ptr(), auto_reset=True, only_active=2)
     a.sync(); b.sync()
@@ -118,6 +119,7 @@ def test_padded_row_stride_equals_dense_rows(mode):
     cb = torch.full((cap, stride), -7.0, dtype=torch.float32, device="cuda:0")
     ia, ib = (torch.zeros((cap,), dtype=torch.int32, device="cuda:0") for _ in range(2))
     na, nb = (torch.zeros((1,), dtype=torch.int32, device="cuda:0") for _ in range(2))
+    torch.cuda.synchronize()      # (the fills run on torch's stream, the library on its own)
     a.encode_compact_device(ca.data_ptr(), ia.data_ptr(), cap, na.data_ptr())
     b.encode_compact_device(cb.data_ptr(), ib.data_ptr(), cap, nb.data_ptr())
     a.sync(); b.sync()

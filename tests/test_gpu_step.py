@@ -263,7 +263,8 @@ def test_two_stream_rollout_equals_single_stream(mode):
     assert (a.status()[0] == b.status()[0]).all()
     la, ca = a.legal()
     lb, cb = b.legal()
-    assert (ca == cb).all() and (la == lb).all()
+    live = np.arange(la.shape[-1])[None, None, :] < ca[:, :, None]      # (slab entries behind a seat's count are leftovers of earlier lists)
+    assert (ca == cb).all() and (np.where(live, la, 0) == np.where(live, lb, 0)).all()
     assert (a.mask() == b.mask()).all()
     for g in (0, B // 4 - 1, B // 4, B // 2, 3 * B // 4 - 1, B - 1):
         assert a.mjai_log(g) == b.mjai_log(g)

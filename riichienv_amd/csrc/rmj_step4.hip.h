@@ -1178,7 +1178,7 @@ template <bool LOOP, int POL, bool INLR = false>
 __device__ __forceinline__ uint32_t step4_body(const Env* Ep, Quad4Shared& sh, uint64_t policy_seed, uint32_t flags, uint32_t g_base, uint32_t g_end,
                                                bool load, uint64_t gs_row, const uint64_t* __restrict__ actions = nullptr, uint32_t quad = 0xFFFFFFFFu,
                                                uint32_t left = 1u, bool final_chunk = true) {
-    static_assert(!INLR || (LOOP && POL == 0), "inline responses: fused RandomAgent rollouts only");
+    static_assert(!INLR || LOOP, "inline responses: fused device-policy rollouts only");
     CEnv& E = *(CEnv*)Ep;
     // RICH tier 0 (the wait probe, the Riichi offer / declaration / riichi-stage list in row form): for policies that play - the
     // greedy instantiation and the per-step kernels an external policy drives.  The fused RandomAgent rollout keeps the lean
@@ -1527,22 +1527,48 @@ __device__ __forceinline__ uint32_t step4_body(const Env* Ep, Quad4Shared& sh, u
         if (INLR) {
             // the discard drew claims and the game has a step left: what the NEXT call would do first - the claim-offered seats get
             // their observation (event cursors, state/mod.rs:211-218), the policy keys (game, step, seat) pick from the staged lists
-            second = phase == RMJ_WAIT_ACT && !q.bail && G->phase == RMJ_WAIT_RESPONSE && left >= 2u;
-            if (second) {
-                const uint32_t am2 = G->active_mask;
+            // (the lean tier never leaves a Ron offer or a pending kan / kita behind: those discards bail)
+            second = phase == RMJ_WAIT_ACT && !q.bail && G->phase == RMJ_WAIT_RESPONSE && left >= 2u && (!RICH || G->pending_kan_pid == 0xFF);
+            if (POL == 1 ? __ballot(second) != 0ull : second) {
+                const uint32_t am2 = second ? (uint32_t)G->active_mask & 0xFu : 0u;
                 const uint32_t sc = G->step_count;
-                mine_r = RMJ_NO_ACTION;
-                if (r < 4 && ((am2 >> r) & 1u)) {
-                    G->obs_from[r] = G->obs_upto[r];
-                    G->obs_upto[r] = G->ev_count;
-                    if (nl_mine > 0) {
-                        const uint64_t key = sm64(gs_row + (uint64_t)sc * 4ull + (uint64_t)r);
-                        const uint32_t ch = mod_small_magic(key, nl_mine > 64 ? 64u : (uint32_t)nl_mine);
-                        mine_r = q.T->lst[row][r][ch] & 0x00FFFFFFFFFFFFFFull;
+                uint64_t pick = RMJ_NO_ACTION;
+                if (POL == 1) {
+                    // the greedy policy's answer (r4_policy_greedy without its discard part): the best class of the seat's list
+                    const uint32_t call_rate = (flags >> 8) & 0xFFu;
+                    uint32_t todo = am2;
+                    while (__ballot(todo != 0u)) {
+                        if (todo) {
+                            const int p = __ffs((int)todo) - 1;
+                            todo &= todo - 1u;
+                            const int n = rbc(nl_mine, rb + p);
+                            const uint64_t key = sm64(gs_row + (uint64_t)sc * 4ull + (uint64_t)p);
+                            const bool call = (uint32_t)((key >> 40) & 0xFFull) < call_rate;
+                            const bool in = r < n;
+                            const uint64_t e = in ? q.T->lst[row][p][r] & 0x00FFFFFFFFFFFFFFull : 0ull;
+                            const uint32_t ty = (uint32_t)e & 0xFFu;
+                            uint32_t scv = in ? r4_prio(ty > 15u ? 15u : ty, call) * 64u + (uint32_t)r : 0xFFFFu;
+                            scv = (uint32_t)rbc((int)row_min16u(scv), rb + 15);
+                            const uint64_t chosen = rbc64(e, rb + (int)(scv & 15u));
+                            if (n > 0 && r == p) pick = chosen;
+                        }
                     }
+                } else if (r < 4 && ((am2 >> r) & 1u) && nl_mine > 0) {
+                    const uint64_t key = sm64(gs_row + (uint64_t)sc * 4ull + (uint64_t)r);
+                    const uint32_t ch = mod_small_magic(key, nl_mine > 64 ? 64u : (uint32_t)nl_mine);
+                    pick = q.T->lst[row][r][ch] & 0x00FFFFFFFFFFFFFFull;
                 }
-                wave_sync();
-                if (r == 0) G->step_count = sc + 1u;
+                // a Ron among the answers is a settlement (full path): the row stops after its discard, the next call takes it from there
+                if (RICH && rballot(r < 4 && pick != RMJ_NO_ACTION && a_type(pick) == RMJ_RON, rb)) second = false;
+                if (second) {
+                    mine_r = pick;
+                    if (r < 4 && ((am2 >> r) & 1u)) {
+                        G->obs_from[r] = G->obs_upto[r];
+                        G->obs_upto[r] = G->ev_count;
+                    }
+                    wave_sync();
+                    if (r == 0) G->step_count = sc + 1u;
+                }
             }
         }
         if (phase != RMJ_WAIT_ACT || second) {
@@ -1832,7 +1858,7 @@ __device__ __noinline__ void step4_call(const Env* Ep, uint64_t policy_seed, uin
 }
 // ... with inline responses (step4_body<.., INLR>): `left` steps to go per row, returns the steps taken per row
 #ifndef RMJ_INLINE_RESP
-#define RMJ_INLINE_RESP 1
+#define RMJ_INLINE_RESP 3   /* bit 0: the RandomAgent's rollouts, bit 1: the greedy policy's */
 #endif
 template <int POL>
 __device__ __noinline__ uint32_t step4_call_inl(const Env* Ep, uint64_t policy_seed, uint32_t flags, uint32_t g_base, uint32_t g_end, uint32_t load,
@@ -1846,11 +1872,11 @@ __device__ __noinline__ uint32_t step4_call_inl(const Env* Ep, uint64_t policy_s
 template <int POL>
 __device__ __forceinline__ void step4_run(const Env* Ep, uint64_t policy_seed, uint32_t flags, uint32_t g_base, uint32_t g_end, uint64_t gs_row,
                                           uint32_t quad, uint32_t steps, bool final_chunk, uint32_t g_row) {
-    if (RMJ_INLINE_RESP && POL == 0) {
+    if (RMJ_INLINE_RESP & (POL == 0 ? 1 : 2)) {
         uint32_t left = g_row < g_end ? steps : 0u, load = 1u;
 #pragma unroll 1
         while (__ballot(left != 0u)) {
-            left -= step4_call_inl<0>(Ep, policy_seed, flags, g_base, g_end, load, gs_row, quad, left, final_chunk ? 1u : 0u);
+            left -= step4_call_inl<POL>(Ep, policy_seed, flags, g_base, g_end, load, gs_row, quad, left, final_chunk ? 1u : 0u);
             load = 0u;
         }
     } else {

@@ -197,10 +197,11 @@ int rmj_step_device(rmj_handle h, const rmj_action_t* d_actions);
  * over the ordered legal list.  Runs n_steps batched steps; with auto_reset != 0 a finished game is
  * re-`reset()` (defaults) at the start of the next step instead of stepping.
  * Games are independent, so a rollout of >= 2 steps needs no synchronisation between the steps of different games: it
- * is issued as ONE launch in which every wavefront keeps its four games' records in LDS and steps them n_steps times,
- * publishing every step's outputs (lists, masks, status, events, record) exactly like n_steps launches would (kernel
- * k_step4<true>, four games per wavefront).  Every game is stepped exactly n_steps times and the results do not depend on
- * it.  A rollout of >= 32 steps of a batch between one and eight chip-fulls of wavefronts is handed out in pieces instead: a grid
+ * is issued as ONE launch in which every wavefront keeps its four games' records in LDS and steps them n_steps times
+ * (kernel k_step4<true>, four games per wavefront); a game whose discard draws claims answers them in the same pass of the
+ * wave, so its four games run a step or two ahead of each other inside the launch.  Every game is stepped exactly n_steps times
+ * and what the launch leaves behind - records, legal lists up to their counts, masks, waits, status, events - is what n_steps
+ * launches of one step leave (entries of the list slab behind a seat's count are unspecified leftovers).  A rollout of >= 32 steps of a batch between one and eight chip-fulls of wavefronts is handed out in pieces instead: a grid
  * that fits the chip once pulls (quad, chunk of up to 64 steps) tickets from per-XCD queues (kernel k_step4_queue; a quad's chunks stay on one XCD, whose L2
  * carries the record from one wavefront to the next), so a batch that is not a whole multiple of the chip's wave slots leaves no
  * half-empty tail (65 536 games: +10 %); RMJ_QUEUE_CHUNK at create sets the chunk length, 0 switches the tickets off.  rmj_set_rollout_streams(h, 1) (or RMJ_STEP_STREAMS=1) makes every step its own launch on the handle's stream - what

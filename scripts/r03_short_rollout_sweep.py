@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Short fused rollouts: env.step/s of a K-step rollout of 65 536 steady-state games against the shortest ticket the library may cut
-(RMJ_QUEUE_MIN_CHUNK; 0 here = tickets off, every wave keeps its quad).  usage: python scripts/r03_short_rollout_sweep.py"""
+(RMJ_QUEUE_MIN_CHUNK; 0 here = tickets off, every wave keeps its quad).  usage: python scripts/r03_short_rollout_sweep.py [floors, comma-separated] [rollout lengths, comma-separated]"""
 import os
 import sys
 
@@ -10,7 +10,9 @@ sys.path.insert(0, ROOT)
 
 def main():
     from riichienv_amd import vecenv
-    for floor in (0, 2, 4, 8, 16):
+    floors = [int(x) for x in sys.argv[1].split(',')] if len(sys.argv) > 1 else [0, 2, 4, 8, 16]
+    ks = [int(x) for x in sys.argv[2].split(',')] if len(sys.argv) > 2 else [8, 20, 40, 100, 300]
+    for floor in floors:
         if floor == 0:
             os.environ["RMJ_QUEUE_CHUNK"] = "0"
         else:
@@ -20,7 +22,7 @@ def main():
         env.reset()
         env.step_random(0xC0FFEE, 600, auto_reset=True)
         row = []
-        for k in (8, 20, 40, 100, 300):
+        for k in ks:
             best = 0.0
             for _ in range(5):
                 r = env.bench_rollout(0xC0FFEE, 0, k)

@@ -28,11 +28,12 @@ B_OBS_3P = 74 * 27 * 4    # 7 992 B
 HBM_PEAK = 8.0e12         # B/s, /opt/skills/guides/MI355X_MICROARCH.md (HBM3E peak, spec)
 MODES = ['4p-red-single', '4p-red-east', '4p-red-half', '3p-red-single', '3p-red-east', '3p-red-half']
 STEADY_MIN = 200          # steady-state window of >= 200 batched steps after the warm-up has reached round ends
-PREROLL = 2000            # untimed steps of every game BEFORE the warm-up, whatever --warmup says: the first ~60 steps of a game
-                          # cannot end a round and games started together end their first rounds in bursts (after 600 steps a
-                          # 20-step window still saw 4 % of the game-steps in the full path, the long-run share is 1.7 %); after
-                          # 2 000 steps (~17 rounds of RandomAgent play, 80 ms at 65 536 games) round ends, settlements and
-                          # restarts are spread like in the steady state the metric is defined on.  Reported as "preroll_steps".
+PREROLL = 6000            # untimed steps of every game BEFORE the warm-up, whatever --warmup says: the first ~60 steps of a game
+                          # cannot end a round and games started together end their rounds in bursts (after 600 steps a 20-step
+                          # window still saw 4 % of the game-steps in the full path, after 2 000 steps 2.3 %, the long-run share
+                          # is 1.7 %); after 6 000 steps (~50 rounds of RandomAgent play, 0.22 s at 65 536 games) a 20-step window
+                          # holds the long-run share (measured: 0.0169 at 6 000, 0.0167 at 8 000, 0.0165 at 12 000; DESIGN.md
+                          # section 11.1) - the steady state the metric is defined on.  Reported as "preroll_steps".
 
 
 def parse_args(argv=None):

@@ -20,7 +20,7 @@ stats() { # tag, bench args...
   rm -rf gpurun_out/${TAG}_st_$t
 }
 stats "" --steps 1000 --warmup 1000 --preroll 1000 --no-cpu-baseline --no-extras
-stats _driver_flags --steps 20 --warmup 20 --preroll 2000 --no-cpu-baseline --no-extras
+stats _driver_flags --steps 20 --warmup 20 --preroll 6000 --no-cpu-baseline --no-extras
 stats _3p_encode --mode 5 --encode --steps 300 --warmup 300 --preroll 300 --no-cpu-baseline
 stats _greedy --policy greedy --steps 1000 --warmup 1000 --preroll 1000 --no-cpu-baseline --no-extras
 # PMC (one counter group per run, --pmc alone): every launch of the kernel is a rollout of exactly 300 steps (preroll = warmup = steps)

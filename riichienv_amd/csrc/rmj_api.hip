@@ -886,6 +886,7 @@ struct rmj_env {
                                // rollout of >= 2 steps is ONE launch in which every wave steps its own games (k_step4<true>); RMJ_STEP4 at create
     // long fused rollouts hand the work out in (quad, chunk) tickets to a grid that fits the chip once (k_step4_queue)
     int queue_chunk = 64;      // steps per ticket; RMJ_QUEUE_CHUNK at create, 0 = off (every wave keeps one quad for the rollout)
+    hipEvent_t ev_time[2] = {nullptr, nullptr};   // rmj_time_rollout* / rmj_bench_rollout: created on first use, so that a timed region holds no event create / destroy
     uint32_t* d_qheads = nullptr;   // [8][RMJ_Q_STRIDE] ticket counters, one line per XCD
     uint32_t* d_qdone = nullptr;    // [quads] chunks finished
     uint32_t q_slots = 0;           // waves of k_step4_queue the device holds at once (the smaller of the two policy instantiations)
@@ -1083,6 +1084,7 @@ int rmj_destroy(rmj_handle h) {
     if (h->h_pin) hipHostFree(h->h_pin);
     hipFree(h->d.core); hipFree(h->d.wall); hipFree(h->d.legal); hipFree(h->d.nlegal); hipFree(h->d_decay); if (h->d_scratch) hipFree(h->d_scratch); hipFree(h->d.mask);
     hipFree(h->d.waits); hipFree(h->d.status); hipFree(h->d.events); hipFree(h->d.win); hipFree(h->d_actions); hipFree(h->d_counter); hipFree(h->d_obs_offs); hipFree(h->d_env); hipFree(h->d_qheads); hipFree(h->d_qdone);
+    for (int i = 0; i < 2; i++) if (h->ev_time[i]) hipEventDestroy(h->ev_time[i]);
     if (h->own_stream) hipStreamDestroy(h->own_stream);
     for (int i = 0; i < RMJ_MAX_ROLLOUT_STREAMS - 1; i++) {
         if (h->xstream[i]) { hipStreamSynchronize(h->xstream[i]); hipStreamDestroy(h->xstream[i]); }
@@ -2358,16 +2360,15 @@ int rmj_apply_events(rmj_handle h, const RmjEvent* events) {
 
 // ---- measurement -----------------------------------------------------------------------------
 static int bench_rollout_impl(rmj_handle h, uint64_t policy_seed, uint32_t warmup, uint32_t steps, RmjBenchResult* out, bool count, int pol = 0, uint32_t rate = 0u) {
-    DevTmp tmp;  // owns the two timing events on every return path
     if (!h || !out) return fail(RMJ_ERR_ARG, "null argument");
     HIPCHK(hipSetDevice(h->cfg.device));
     int rc = warmup ? step_policy_impl(h, policy_seed, warmup, 1, pol, rate) : RMJ_OK;
     if (rc) return rc;
     uint64_t before = 0, after = 0, full0 = 0, full1 = 0;
     if (count && ((rc = rmj_total_steps(h, &before)) || (rc = rmj_total_full_path(h, &full0)))) return rc;
-    hipEvent_t e0, e1;
-    HIPCHK(tmp.event(&e0));
-    HIPCHK(tmp.event(&e1));
+    for (int i = 0; i < 2; i++)
+        if (!h->ev_time[i]) HIPCHK(hipEventCreate(&h->ev_time[i]));
+    hipEvent_t e0 = h->ev_time[0], e1 = h->ev_time[1];
     HIPCHK(hipEventRecord(e0, h->stream));
     if ((rc = step_policy_impl(h, policy_seed, steps, 1, pol, rate))) return rc;
     HIPCHK(hipEventRecord(e1, h->stream));

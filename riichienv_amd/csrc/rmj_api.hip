@@ -1083,7 +1083,7 @@ int rmj_destroy(rmj_handle h) {
     if (h->stream) hipStreamSynchronize(h->stream);
     if (h->h_pin) hipHostFree(h->h_pin);
     hipFree(h->d.core); hipFree(h->d.wall); hipFree(h->d.legal); hipFree(h->d.nlegal); hipFree(h->d_decay); if (h->d_scratch) hipFree(h->d_scratch); hipFree(h->d.mask);
-    hipFree(h->d.waits); hipFree(h->d.status); hipFree(h->d.events); hipFree(h->d.win); hipFree(h->d_actions); hipFree(h->d_counter); hipFree(h->d_obs_offs); hipFree(h->d_env); hipFree(h->d_qheads); hipFree(h->d_qdone);
+    hipFree(h->d.waits); hipFree(h->d.status); hipFree(h->d.events); hipFree(h->d.win); hipFree(h->d_actions); hipFree(h->d_counter); hipFree(h->d_obs_offs); hipFree(h->d_env); hipFree(h->d_qheads);   // (d_qdone lives in the same allocation)
     for (int i = 0; i < 2; i++) if (h->ev_time[i]) hipEventDestroy(h->ev_time[i]);
     if (h->own_stream) hipStreamDestroy(h->own_stream);
     for (int i = 0; i < RMJ_MAX_ROLLOUT_STREAMS - 1; i++) {
@@ -1405,12 +1405,12 @@ static int step_policy_impl(rmj_handle h, uint64_t policy_seed, uint32_t n_steps
         const dim3 grid((n + 3u) / 4u);
         if (rollout_queued(h, n_steps)) {
             // ... or, for a long rollout of a batch that does not fill the chip a whole number of times, in (quad, chunk) tickets
+            // ticket counters (one line per XCD) + the quads' chunk counts: one allocation, zeroed by ONE memset in front of every rollout
             if (!h->d_qheads) {
-                HIPCHK(hipMalloc(&h->d_qheads, 8 * RMJ_Q_STRIDE * sizeof(uint32_t)));
-                HIPCHK(hipMalloc(&h->d_qdone, (size_t)grid.x * sizeof(uint32_t)));
+                HIPCHK(hipMalloc(&h->d_qheads, (8 * RMJ_Q_STRIDE + (size_t)grid.x) * sizeof(uint32_t)));
+                h->d_qdone = h->d_qheads + 8 * RMJ_Q_STRIDE;
             }
-            HIPCHK(hipMemsetAsync(h->d_qheads, 0, 8 * RMJ_Q_STRIDE * sizeof(uint32_t), h->stream));
-            HIPCHK(hipMemsetAsync(h->d_qdone, 0, (size_t)grid.x * sizeof(uint32_t), h->stream));
+            HIPCHK(hipMemsetAsync(h->d_qheads, 0, (8 * RMJ_Q_STRIDE + (size_t)grid.x) * sizeof(uint32_t), h->stream));
             const dim3 gq(grid.x < h->q_slots ? grid.x : h->q_slots);
             const uint32_t chunk = rollout_chunk(h, n_steps);
             if (sanma) {
@@ -1479,12 +1479,12 @@ int rmj_step_random_encode(rmj_handle h, uint64_t policy_seed, uint32_t n_steps,
         const bool queued = h->queue_chunk > 0 && h->max_xcc_id <= 7u && n_steps >= 2u * chunk &&
                             (h->queue_force ? grid.x >= 64u : (grid.x > h->q_slots_enc && grid.x < 8u * h->q_slots_enc));
         if (queued) {
+            // ticket counters (one line per XCD) + the quads' chunk counts: one allocation, zeroed by ONE memset in front of every rollout
             if (!h->d_qheads) {
-                HIPCHK(hipMalloc(&h->d_qheads, 8 * RMJ_Q_STRIDE * sizeof(uint32_t)));
-                HIPCHK(hipMalloc(&h->d_qdone, (size_t)grid.x * sizeof(uint32_t)));
+                HIPCHK(hipMalloc(&h->d_qheads, (8 * RMJ_Q_STRIDE + (size_t)grid.x) * sizeof(uint32_t)));
+                h->d_qdone = h->d_qheads + 8 * RMJ_Q_STRIDE;
             }
-            HIPCHK(hipMemsetAsync(h->d_qheads, 0, 8 * RMJ_Q_STRIDE * sizeof(uint32_t), h->stream));
-            HIPCHK(hipMemsetAsync(h->d_qdone, 0, (size_t)grid.x * sizeof(uint32_t), h->stream));
+            HIPCHK(hipMemsetAsync(h->d_qheads, 0, (8 * RMJ_Q_STRIDE + (size_t)grid.x) * sizeof(uint32_t), h->stream));
             const dim3 gq(grid.x < h->q_slots_enc ? grid.x : h->q_slots_enc);
             if (sanma) {
                 hipLaunchKernelGGL((rmj3::k_step4_queue_enc<0>), gq, dim3(64), 0, h->stream, (const Env*)h->d_env, policy_seed, flags, n, n_steps, chunk, h->d_qheads, h->d_qdone, h->queue_skip_xcds, d_out);

@@ -14,6 +14,7 @@
 
 #include "../../include/riichi_mi355x.h"
 #include "rmj_common.hip.h"
+#include "rmj_eval4.hip.h"
 #include "rmj_encode.hip.h"
 #include "rmj_seq.hip.h"
 
@@ -306,95 +307,152 @@ __device__ inline MeldAgg agg_from_views(const RmjHandCase& hc) {
     return m;
 }
 
-// Round 3: the evaluator kernel is compiled for six waves per SIMD.  Left alone it takes 236 VGPRs = two waves per SIMD, and the kernel
-// waits on dependent LDS round trips: 40.8 M hands/s at 2 waves, 53 at 3, 58 at 4, 70.8 at 6, 69.9 at 7, 68.4 at 8 (2^18 fixture hands).
-#ifndef RMJ_EVAL_WAVES
-#define RMJ_EVAL_WAVES 6
-#endif
-#define RMJ_EVAL_OCC __attribute__((amdgpu_waves_per_eu(RMJ_EVAL_WAVES, RMJ_EVAL_WAVES)))
-__global__ __launch_bounds__(256) RMJ_EVAL_OCC void k_eval_hands(const RmjHandCase* cases, uint32_t n, RmjHandResult* out) {
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const uint32_t k = blockIdx.x * WPB + wave;
-    if (k >= n) return;
-    const RmjHandCase& hc = cases[k];
-    CalcIn in;
-    in.ma = agg_from_views(hc);
-    PH full = {0, 0, 0, 0};
-    int aka = in.ma.aka;
-    int nt = hc.n_tiles > 14 ? 14 : hc.n_tiles;
-    for (int j = 0; j < nt; j++) {
-        ph_add(full, hc.tiles[j] >> 2);
-        aka += is_aka(hc.tiles[j]);
+// Round 4: HandEvaluator::calc + waits for FOUR hands per wave, one 16-lane row per hand (e4_calc, rmj_eval4.hip.h).  The wave's four
+// 88-byte cases arrive as one contiguous 352-byte block (coalesced dword loads into LDS), lane r of a row is tile r / meld r / dora
+// indicator r while the case is parsed, the 64-byte results leave as one dword per lane (256 contiguous bytes per wave).  Round 3's
+// kernel - one wave per hand, lane = candidate head walking every division x winning group serially, 236 registers squeezed into 80
+// with 576 B of scratch per lane - ran at 71 M hands/s.
+struct EvalShared {
+    alignas(16) uint32_t in[4 * sizeof(RmjHandCase) / 4];
+    alignas(16) uint32_t out[4][16];
+};
+static_assert(sizeof(RmjHandCase) == 88 && sizeof(RmjHandResult) == 64, "k_eval_hands stages cases / results by these sizes");
+__global__ __launch_bounds__(256) void k_eval_hands(const RmjHandCase* cases, uint32_t n, RmjHandResult* out) {
+    __shared__ EvalShared shw[WPB];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, r = lane & 15, rb = lane & 48, row = lane >> 4;
+    const uint32_t k0 = (blockIdx.x * WPB + wave) * 4u;   // first hand of the wave
+    if (k0 >= n) return;
+    EvalShared& sh = shw[wave];
+    const uint32_t k = k0 + (uint32_t)row;
+    const bool live = k < n;
+    {
+        const uint32_t words = (n - k0 < 4u ? n - k0 : 4u) * (uint32_t)(sizeof(RmjHandCase) / 4);
+        const uint32_t* src = reinterpret_cast<const uint32_t*>(cases + k0);
+        for (uint32_t i = lane; i < words; i += 64) sh.in[i] = src[i];
     }
-    PH hand = full;
-    for (int i = 0; i < in.ma.n; i++) {  // HandEvaluator::new, hand_evaluator.rs:43-62
-        const RmjMeldView& v = hc.melds[i];
-        if (v.meld_type >= RMJ_MELD_DAIMINKAN) {
-            int t34 = v.tiles[0] >> 2;
-            if (ph_cnt(hand, t34) == 4) ph_sub(hand, t34);
-        }
-        for (int q = 0; q < v.n_tiles && q < 4; q++) ph_add(full, v.tiles[q] >> 2);
-    }
+    wave_sync();
+    const RmjHandCase& hc = *reinterpret_cast<const RmjHandCase*>(reinterpret_cast<const uint8_t*>(sh.in) + (size_t)row * sizeof(RmjHandCase));
+    const int nt = live ? (hc.n_tiles > 14 ? 14 : hc.n_tiles) : 0;
+    const int nm = live ? (hc.n_melds > 4 ? 4 : hc.n_melds) : 0;
     const bool sanma = hc.is_sanma != 0;
-    const int total = ph_total(hand) + 3 * in.ma.n;
-    uint64_t waits = 0;
-    if (total == 13) waits = wave_waits(hand, lane);
-    const int win34 = hc.win_tile >> 2;
+    // ---- lane = concealed tile: histogram of the given tiles, red fives
+    uint32_t ca = 0, cb = 0, cc = 0, cd = 0;
+    const int tile = r < nt ? (int)hc.tiles[r] : 0;
+    if (r < nt) {
+        const int t = tile >> 2, s = t_suit(t);
+        const uint32_t one = 1u << (3 * (t - 9 * s));
+        ca = s == 0 ? one : 0u; cb = s == 1 ? one : 0u; cc = s == 2 ? one : 0u; cd = s == 3 ? one : 0u;
+    }
+    PH conc;
+    conc.a = e4_rsum(ca, rb); conc.b = e4_rsum(cb, rb); conc.c = e4_rsum(cc, rb); conc.d = e4_rsum(cd, rb);
+    int aka = __popc(e4_ballot(r < nt && is_aka(tile), rb));
+    // ---- lane = meld: the packed aggregate (agg_from_views), the tiles it adds to the dora histogram, HandEvaluator::new's kan fix
+    //      (hand_evaluator.rs:43-62: a concealed hand that still lists all four tiles of a kan loses one)
+    E4Meld mp;
+    uint32_t ma_ = 0, mb_ = 0, mc_ = 0, md_ = 0;   // meld tiles (one-hot sums)
+    uint32_t fa_ = 0, fb_ = 0, fc_ = 0, fd_ = 0;   // kan fix
+    {
+        const bool mv = r < nm;
+        const RmjMeldView& v = hc.melds[r & 3];
+        const int ntm = mv ? (v.n_tiles > 4 ? 4 : v.n_tiles) : 0;
+        const uint32_t t0id = v.tiles[0], t1id = v.tiles[1], t2id = v.tiles[2], t3id = v.tiles[3];
+        const bool chi = v.meld_type == RMJ_MELD_CHI;
+        int lo1 = 99, lo2 = 99;   // the two lowest types among the meld's tiles
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const int t = (int)(q == 0 ? t0id : (q == 1 ? t1id : (q == 2 ? t2id : t3id))) >> 2;
+            if (q < ntm) {
+                if (t < lo1) { lo2 = lo1; lo1 = t; } else if (t < lo2) lo2 = t;
+                const int s = t_suit(t);
+                const uint32_t one = 1u << (3 * (t - 9 * s));
+                ma_ += s == 0 ? one : 0u; mb_ += s == 1 ? one : 0u; mc_ += s == 2 ? one : 0u; md_ += s == 3 ? one : 0u;
+            }
+        }
+        const int t0 = chi ? lo1 : (int)(t0id >> 2);
+        const bool trip = ntm >= 3 && (chi ? lo1 == lo2 : (t0id >> 2) == (t1id >> 2));
+        mp = e4_meld_lane(mv, v.meld_type, ntm, t0id, t1id, t2id, t3id, t0, trip, v.opened != 0);
+        if (mv && v.meld_type >= RMJ_MELD_DAIMINKAN) {
+            const int t = (int)(t0id >> 2);
+            if (t < 34 && ph_cnt(conc, t) == 4) {
+                const int s = t_suit(t);
+                const uint32_t one = 1u << (3 * (t - 9 * s));
+                fa_ = s == 0 ? one : 0u; fb_ = s == 1 ? one : 0u; fc_ = s == 2 ? one : 0u; fd_ = s == 3 ? one : 0u;
+            }
+        }
+    }
+    const E4Meld ma = e4_meld_reduce(mp, rb);
+    aka += e4m_aka(ma);
+    PH hand = conc, full = conc;
+    hand.a -= e4_rsum(fa_, rb); hand.b -= e4_rsum(fb_, rb); hand.c -= e4_rsum(fc_, rb); hand.d -= e4_rsum(fd_, rb);
+    full.a += e4_rsum(ma_, rb); full.b += e4_rsum(mb_, rb); full.c += e4_rsum(mc_, rb); full.d += e4_rsum(md_, rb);
+    const int total = ph_total(hand) + 3 * nm;
+    uint64_t waits = 0ull;
+    if (__ballot(live && total == 13)) {
+        if (live && total == 13) waits = rmj4::r4_waits_probe(hand.a, hand.b, hand.c, hand.d);
+    }
+    const int win34 = (hc.win_tile >> 2) < 34 ? (hc.win_tile >> 2) : 33;
     PH h14 = hand, f14 = full;
     if (total == 13) {
         ph_add(h14, win34);
         ph_add(f14, win34);
         aka += is_aka(hc.win_tile);
     }
-    RmjHandResult r;
-    memset(&r, 0, sizeof(r));
-    r.waits = waits;
-    r.is_tenpai = waits != 0ull;
-    bool ag = is_agari(h14);
-    r.is_agari = ag;
-    if (ag) {
-        int dora = 0, ura = 0;
-        for (int q = 0; q < hc.n_dora && q < 5; q++) {
-            int nt34 = next_dora34(hc.dora[q] >> 2, sanma);
-            dora += ph_cnt(f14, nt34);
-            if (sanma && nt34 == 30) dora += hc.kita_count;
+    // ---- lane = indicator: dora (lanes 0..4) and ura (lanes 8..12) counts over the full histogram
+    int dora, ura;
+    {
+        const bool is_d = r < 5 && r < hc.n_dora, is_u = r >= 8 && r < 13 && r - 8 < hc.n_ura;
+        int cnt = 0;
+        if (is_d || is_u) {
+            const int ind = is_d ? hc.dora[r & 7] : hc.ura[(r - 8) & 7];
+            const int nt34 = next_dora34((ind >> 2) < 34 ? (ind >> 2) : 33, sanma);
+            cnt = ph_cnt(f14, nt34);
+            if (sanma && nt34 == 30) cnt += hc.kita_count;
         }
-        for (int q = 0; q < hc.n_ura && q < 5; q++) {
-            int nt34 = next_dora34(hc.ura[q] >> 2, sanma);
-            ura += ph_cnt(f14, nt34);
-            if (sanma && nt34 == 30) ura += hc.kita_count;
-        }
-        in.hand14 = h14;
-        in.win34 = win34;
-        uint32_t cf = 0;
-        if (hc.tsumo) cf |= CF_TSUMO;
-        if (hc.riichi) cf |= CF_RIICHI;
-        if (hc.double_riichi) cf |= CF_DOUBLE_RIICHI;
-        if (hc.ippatsu) cf |= CF_IPPATSU;
-        if (hc.haitei) cf |= CF_HAITEI;
-        if (hc.houtei) cf |= CF_HOUTEI;
-        if (hc.rinshan) cf |= CF_RINSHAN;
-        if (hc.chankan) cf |= CF_CHANKAN;
-        if (hc.tsumo_first_turn) cf |= CF_FIRST_TURN;
-        in.cf = cf;
-        in.dora = dora & 0xFF; in.aka = aka & 0xFF; in.ura = ura & 0xFF;
-        in.nuki = sanma ? hc.kita_count : 0;
-        in.round_wind34 = 27 + (hc.round_wind & 3);
-        in.seat_wind34 = 27 + (hc.player_wind & 3);
-        in.sanma = sanma;
-        in.honba = hc.honba;
-        CalcOut o = wave_calc(in, lane);
-        r.is_win = o.is_win;
-        r.yakuman = o.yakuman;
-        r.has_win_shape = 1;
-        r.han = (uint32_t)o.han;
-        r.fu = (uint32_t)o.fu;
-        r.ron_agari = o.ron;
-        r.tsumo_agari_oya = o.tsumo_oya;
-        r.tsumo_agari_ko = o.tsumo_ko;
-        r.n_yaku = (uint8_t)yaku_list(o.kind, o.ym, r.yaku, 20);
+        dora = (int)e4_rsum(is_d ? (uint32_t)cnt : 0u, rb);
+        ura = (int)e4_rsum(is_u ? (uint32_t)cnt : 0u, rb);
     }
-    if (lane == 0) out[k] = r;
+    E4In in;
+    in.on = live;
+    in.hand14 = h14;
+    in.ma = ma;
+    in.win34 = win34;
+    uint32_t cf = 0;
+    if (hc.tsumo) cf |= CF_TSUMO;
+    if (hc.riichi) cf |= CF_RIICHI;
+    if (hc.double_riichi) cf |= CF_DOUBLE_RIICHI;
+    if (hc.ippatsu) cf |= CF_IPPATSU;
+    if (hc.haitei) cf |= CF_HAITEI;
+    if (hc.houtei) cf |= CF_HOUTEI;
+    if (hc.rinshan) cf |= CF_RINSHAN;
+    if (hc.chankan) cf |= CF_CHANKAN;
+    if (hc.tsumo_first_turn) cf |= CF_FIRST_TURN;
+    in.cf = cf;
+    in.dora = dora & 0xFF; in.aka = aka & 0xFF; in.ura = ura & 0xFF;
+    in.nuki = sanma ? hc.kita_count : 0;
+    in.round_wind34 = 27 + (hc.round_wind & 3);
+    in.seat_wind34 = 27 + (hc.player_wind & 3);
+    in.sanma = sanma;
+    in.honba = hc.honba;
+    const E4Out o = e4_calc(in, r, rb);
+    // ---- the 64-byte result: dword r by lane r, the ordered yaku list through LDS bytes
+    uint32_t w = 0u;
+    if (r == 6) w = o.shape ? (uint32_t)o.han : 0u;
+    if (r == 7) w = o.shape ? (uint32_t)o.fu : 0u;
+    if (r == 8) w = o.ron;
+    if (r == 9) w = o.tsumo_oya;
+    if (r == 10) w = o.tsumo_ko;
+    if (r == 12) w = (uint32_t)waits;
+    if (r == 13) w = (uint32_t)(waits >> 32);
+    if (r == 14) w = (uint32_t)(waits != 0ull) | ((uint32_t)o.shape << 8);
+    sh.out[row][r] = w;
+    wave_sync();
+    int ny = 0;
+    if (__ballot(live && o.shape)) {
+        if (live && o.shape) ny = e4_yaku_list(o.kind, o.ym, reinterpret_cast<uint8_t*>(&sh.out[row][1]), r, rb);
+    }
+    if (r == 0) sh.out[row][0] = (uint32_t)o.is_win | ((uint32_t)o.yakuman << 8) | ((uint32_t)o.shape << 16) | ((uint32_t)ny << 24);
+    wave_sync();
+    if (live) reinterpret_cast<uint32_t*>(out + k)[r] = sh.out[row][r];
 }
 
 // agari.rs:65-73 + hand_evaluator.rs:178-213 over raw histograms.  Round 3: FOUR hands per wave - one 16-lane row per hand like
@@ -2031,7 +2089,7 @@ int rmj_eval_hands(int device, const RmjHandCase* cases, uint32_t n, RmjHandResu
     HIPCHK(tmp.alloc(&d_in, (size_t)n * sizeof(RmjHandCase)));
     HIPCHK(tmp.alloc(&d_out, (size_t)n * sizeof(RmjHandResult)));
     HIPCHK(hipMemcpy(d_in, cases, (size_t)n * sizeof(RmjHandCase), hipMemcpyHostToDevice));
-    hipLaunchKernelGGL(k_eval_hands, game_grid(n), dim3(256), 0, 0, d_in, n, d_out);
+    hipLaunchKernelGGL(k_eval_hands, dim3((n + 15u) / 16u), dim3(256), 0, 0, d_in, n, d_out);
     HIPCHK(hipGetLastError());
     HIPCHK(hipDeviceSynchronize());
     HIPCHK(hipMemcpy(out, d_out, (size_t)n * sizeof(RmjHandResult), hipMemcpyDeviceToHost));
@@ -2538,7 +2596,7 @@ int rmj_bench_hand_kernel(int device, int which, const void* a, const void* b, u
     HIPCHK(tmp.event(&e1));
     auto launch = [&]() {
         switch (which) {
-            case 0: hipLaunchKernelGGL(k_eval_hands, game_grid(n), dim3(256), 0, 0, (const RmjHandCase*)d_a, n, (RmjHandResult*)d_o); break;
+            case 0: hipLaunchKernelGGL(k_eval_hands, dim3((n + 15u) / 16u), dim3(256), 0, 0, (const RmjHandCase*)d_a, n, (RmjHandResult*)d_o); break;
             case 1: hipLaunchKernelGGL(k_agari_counts, dim3((n + 15) / 16), dim3(256), 0, 0, (const uint8_t*)d_a, n, d_o, d_o + n, (uint64_t*)(d_o + 8 * (size_t)n)); break;
             case 2: hipLaunchKernelGGL(k_shanten, dim3((n + 255) / 256), dim3(256), 0, 0, T, (const uint8_t*)d_a, n, sanma, (int8_t*)d_o); break;
             case 3: hipLaunchKernelGGL(k_ukeire, dim3((n + 3) / 4), dim3(256), 0, 0, T, (const uint8_t*)d_a, (const uint8_t*)nullptr, n, sanma, 0, (uint32_t*)d_o); break;

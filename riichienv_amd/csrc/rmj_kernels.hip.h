@@ -19,11 +19,21 @@ __device__ __noinline__ void ol_step_full(CtxV v, uint64_t mine, uint32_t flags)
     CTX_FROM(v);
     flags = uni(flags);
     GState& S = c.S;
-    load_state(S, c.E.core + c.g, c.lane);
-    TLF(c, 0);
-    S.full_count += 1;
-    if (S.is_done && (flags & STEP_F_AUTORESET)) ol_env_reset_default(v);
-    else step_game<false>(c, mine, (flags & STEP_F_RANDOM) != 0);
+    if (flags & STEP_F_CONT_RYU) {
+        // entered AT the exhaustive draw (k_step4): tier 0 has taken the step up to _deal_next's empty wall - the discard, its claims or
+        // the seats' passes, riichi acceptance, the turn counter - on the record in LDS; what is left is state/mod.rs:1571-1574
+        wave_sync();
+        S.full_count += 1;
+        S.is_rinshan = 0;
+        trigger_ryukyoku(c, RMJ_RK_EXHAUSTIVE, 0);
+        if (U(S.turn_count) >= (uint32_t)KNP) S.is_first_turn = 0;
+    } else {
+        load_state(S, c.E.core + c.g, c.lane);
+        TLF(c, 0);
+        S.full_count += 1;
+        if (S.is_done && (flags & STEP_F_AUTORESET)) ol_env_reset_default(v);
+        else step_game<false>(c, mine, (flags & STEP_F_RANDOM) != 0);
+    }
     TLF(c, 11);
     finalize_outputs<false>(c, true, true, (flags & STEP_F_ALLROWS) != 0u);
     TLF(c, 12);

@@ -84,6 +84,7 @@ struct R4 {
     uint32_t g;
     bool live;        // the row still runs in tier 0
     bool bail;        // the row goes to the full path
+    int cont;         // with bail: the full path is entered AT this point of the step, on the record tier 0 leaves in LDS (STEP_F_CONT_*), instead of starting over
     int evn;          // staged events
     uint32_t dirty;
 };
@@ -467,7 +468,7 @@ __device__ __forceinline__ void r4_check_abortive(R4& q) {
 __device__ __forceinline__ void r4_deal_next(R4& q, int pf) {
     GState* G = q.G;
     const int drawable = G->drawable_count;
-    if (drawable == 0) { R4BAIL(q, 7); return; }   // exhaustive draw
+    if (drawable == 0) { R4BAIL(q, 7); q.cont = 1; return; }   // exhaustive draw: the full path takes over right here (trigger_ryukyoku)
     const int live_end = G->live_end;
     const int pid = G->current_player;
     PState* P = &G->p[pid];
@@ -1210,7 +1211,7 @@ __device__ __forceinline__ uint32_t step4_body(const Env* Ep, Quad4Shared& sh, u
     q.live = (uint32_t)row < n_here && (!INLR || left != 0u);
     GState* G = q.G;
     const uint64_t* Lg = E.legal + (size_t)g * 4 * RMJ_MAX_LEGAL;
-    q.bail = false; q.evn = 0; q.dirty = 0xFu;
+    q.bail = false; q.cont = 0; q.evn = 0; q.dirty = 0xFu;
     // the next live-wall draw (valid while nothing moves live_end: kans bail)
     int pf = 0;
     if (q.live) {
@@ -1743,7 +1744,7 @@ __device__ __forceinline__ uint32_t step4_body(const Env* Ep, Quad4Shared& sh, u
     const bool done0 = q.live && t0 && !q.bail;
     // INLR: the steps this call took for the row's game (a bailed row takes ONE in the full path, from the untouched record, whatever
     // tier 0 had got to), and the row's own publication flags: quiet unless this was the last step of the rollout
-    const uint32_t used = !q.live ? 0u : ((INLR && second && !q.bail) ? 2u : 1u);
+    const uint32_t used = !q.live ? 0u : ((INLR && second && (!q.bail || q.cont)) ? 2u : 1u);
     const uint32_t fl_pub = INLR ? (flags | ((final_chunk && left == used) ? STEP_F_ALLROWS : STEP_F_QUIET)) : flags;
     if (done0) {
         const uint32_t am = G->active_mask;
@@ -1798,6 +1799,11 @@ __device__ __forceinline__ uint32_t step4_body(const Env* Ep, Quad4Shared& sh, u
             dst[hh] = reinterpret_cast<const uint4*>(q.T->ev[row][e])[hh];
         }
     }
+    if (q.live && q.cont && r < 2 * q.evn) {   // a row that continues in the full path: its staged events go out now (the full path's scratch overlays the staging area)
+        const int e = r >> 1, hh = r & 1;
+        uint4* dst = reinterpret_cast<uint4*>(E.events + (size_t)g * (E.ring_mask + 1u) + q.T->evidx[row][e]);
+        dst[hh] = reinterpret_cast<const uint4*>(q.T->ev[row][e])[hh];
+    }
     wave_sync();
     R4M(46);
     R4T(4);
@@ -1815,6 +1821,7 @@ __device__ __forceinline__ uint32_t step4_body(const Env* Ep, Quad4Shared& sh, u
     R4T(5);
     // ---- bailed games: the complete state machine, one game at a time, from the untouched HBM record
     uint64_t bm = __ballot(q.live && q.bail && r == 0);
+    const uint32_t fl_full = (INLR ? fl_pub : flags) | (q.cont == 1 ? STEP_F_CONT_RYU : 0u);   // (per row)
 #ifdef RMJ_TL4
     if (!LOOP && lane == 0) rmj::g_tl4[(size_t)blockIdx.x * RMJ_TL4_ROW + 7] = (unsigned long long)__popcll(bm);
 #endif
@@ -1830,7 +1837,7 @@ __device__ __forceinline__ uint32_t step4_body(const Env* Ep, Quad4Shared& sh, u
         if (lane == 0) sh.u.x.tl_prev = __builtin_readcyclecounter();
         wave_sync();
 #endif
-        ol_step_full(ctx_pack(c), lane < 4 ? m_full : RMJ_NO_ACTION, INLR ? (uint32_t)__builtin_amdgcn_readlane((int)fl_pub, 16 * br) : flags);
+        ol_step_full(ctx_pack(c), lane < 4 ? m_full : RMJ_NO_ACTION, (uint32_t)__builtin_amdgcn_readlane((int)fl_full, 16 * br));
         wave_sync();
 #ifdef RMJ_TL4
         if (!LOOP && lane < 16) rmj::g_tl4[(size_t)blockIdx.x * RMJ_TL4_ROW + 16 + lane] += (unsigned long long)sh.u.x.tl_acc[lane];

@@ -27,6 +27,7 @@ using namespace rmj;
 #define STEP_F_QUIET 0x10000u   /* fused rollouts, every step but the last: no mask rows, no nlegal / waits / status words (nobody can read them) */
 #define STEP_F_ALLROWS 0x20000u /* fused rollouts, last step: all four mask rows are rewritten (the quiet steps left them stale) */
 #define STEP_F_CONT_RYU 0x40000u /* ol_step_full: continue at the exhaustive draw on the record k_step4's tier 0 left in LDS (no reload, no replay of the discard) */
+#define STEP_F_CONT_FIN 0x80000u /* ol_step_full: the step is complete on the record in LDS, only the observation outputs are produced */
 #define STEP_F_GREEDY 8u /* with STEP_F_RANDOM: the greedy policy (rmj_step_greedy, r4_policy_greedy) instead of the RandomAgent; bits 8..15 = call rate / 256 */
 
 template <int N>
@@ -2645,7 +2646,7 @@ extern "C" int rmj_prof_set_cut(int cut, int cut2, int cut3) {
 }
 #endif
 
-#ifdef RMJ_CUTS
+#if defined(RMJ_CUTS) || defined(RMJ_CENSUS)
 extern "C" int rmj_prof_bail_census(uint32_t* out32, int reset) {
     HIPCHK(hipDeviceSynchronize());
     HIPCHK(hipMemcpyFromSymbol(out32, HIP_SYMBOL(rmj::g_bail_reason), 32 * sizeof(uint32_t)));

@@ -97,6 +97,9 @@ __device__ uint32_t g_bail_reason[32];  // bail census of k_step4 (R4BAIL sites)
 #define PROF_START(X, lane) do {} while (0)
 #define PROF_FLUSH(X, lane, g) do {} while (0)
 #else
+#ifdef RMJ_CENSUS
+__device__ uint32_t g_bail_reason[32];  // bail census of k_step4 (R4BAIL sites) without the accounting marks
+#endif
 #define PROF(X, lane, id) do {} while (0)
 #define PROF_START(X, lane) do {} while (0)
 #define PROF_FLUSH(X, lane, g) do {} while (0)

@@ -20,12 +20,17 @@
 namespace RMJ_NS {
 
 #define R4_LIST 16 /* staged list entries per (game, seat); a longer list makes the row bail */
+#ifndef RMJ_ROW_ROUND_END
+#define RMJ_ROW_ROUND_END 1   /* exhaustive draws, next rounds and restarts stay in tier 0 (r4_round_end); 0: they enter the full path at the exit */
+#endif
 #ifdef RMJ_CUTS   /* instruction accounting build (scripts/valu_sections4.py, scripts/bail_census.py) */
 #define R4M(id) do { if (rmj::g_cut == (id)) __builtin_amdgcn_endpgm(); } while (0)   /* the wave ends at mark g_cut */
 #define R4BAIL(q, id) do { (q).bail = true; if ((q).r == 0) atomicAdd(&rmj::g_bail_reason[id], 1u); } while (0)   /* bail census */
 #else
 #define R4M(id) do {} while (0)
-#ifdef RMJ_TL4
+#ifdef RMJ_CENSUS   /* bail census on the shipped instruction stream (no accounting marks): scripts/bail_census.py; the reason travels in a register and is counted where the full path is entered */
+#define R4BAIL(q, id) do { (q).bail = true; (q).why = (id); } while (0)
+#elif defined(RMJ_TL4)
 #define R4BAIL(q, id) do { (q).bail = true; if ((q).r == 0) rmj::g_tl4[(size_t)blockIdx.x * RMJ_TL4_ROW + 10 + (q).row] = (unsigned long long)(id) + 1ull; } while (0)
 #else
 #define R4BAIL(q, id) do { (q).bail = true; } while (0)
@@ -47,6 +52,9 @@ struct Quad4Enc {          // byte staging of Observation.encode() inside the fu
     alignas(16) uint8_t raw[(ENC_CH * (KSANMA ? ENC_W3 : ENC_W4) + 4 + 15) / 16 * 16];
     uint32_t hist[ENC_HIST_WORDS];
 };
+#ifndef R4_RS_WORDS
+#define R4_RS_WORDS 100   /* round-end scratch (r4_round_end): 32 words of packed bucket counters + 136 16-bit sort words.  Measured (profiles/r04_lds_sweep.txt): up to 6 336 B of LDS per wave the fused rollout runs at 1.81-1.82 G env.step/s, at 6 512 B at 1.70 G */
+#endif
 struct Quad4Shared {
     GState st[4];
     union {
@@ -54,7 +62,14 @@ struct Quad4Shared {
         Quad4Tier0 t;
         Quad4Enc e;
     } u;
+    uint32_t rs[R4_RS_WORDS];   // outside the union: a round ends while the other rows' lists and events are still staged
+    uint32_t rfl[4];            // rows whose round ends in this call: their publication flags (pass 2 of step4_body) ...
+    uint32_t rmode[4];          // ... and what ends it (R4_RE_*; 0: nothing)
 };
+// The wave's working set (every block of the four-games-per-wave kernels is one wave).  One namespace-scope variable instead of a
+// static in each entry point: the out-of-line pieces of a step (r4_round_end) address it directly, as LDS.
+static_assert(sizeof(Quad4Shared) <= 6336, "LDS per wave: one allocation step more costs the fused rollouts 7 % (R4_RS_WORDS)");
+__shared__ Quad4Shared g_q4;
 
 // ballot of the lane's own row: pick the half of the 64-bit mask (one select on the lane-constant "upper half" predicate),
 // then a 16-bit field extract at bit 0 / 16 - three vector instructions instead of a 64-bit shift by a lane-varying amount
@@ -85,6 +100,10 @@ struct R4 {
     bool live;        // the row still runs in tier 0
     bool bail;        // the row goes to the full path
     int cont;         // with bail: the full path is entered AT this point of the step, on the record tier 0 leaves in LDS (STEP_F_CONT_*), instead of starting over
+    uint32_t rend;    // R4_RE_*: the row's game ends a round in this call (r4_round_end)
+#ifdef RMJ_CENSUS
+    int why;          // the R4BAIL site that made the row bail
+#endif
     int evn;          // staged events
     uint32_t dirty;
 };
@@ -468,7 +487,14 @@ __device__ __forceinline__ void r4_check_abortive(R4& q) {
 __device__ __forceinline__ void r4_deal_next(R4& q, int pf) {
     GState* G = q.G;
     const int drawable = G->drawable_count;
-    if (drawable == 0) { R4BAIL(q, 7); q.cont = 1; return; }   // exhaustive draw: the full path takes over right here (trigger_ryukyoku)
+    if (drawable == 0) {   // exhaustive draw
+#if RMJ_ROW_ROUND_END
+        q.rend = 1u /* R4_RE_DRAW */;   // the round ends in row form, behind the transitions of this call (r4_round_end)
+#else
+        R4BAIL(q, 7); q.cont = 1;       // the full path takes over right here (trigger_ryukyoku)
+#endif
+        return;
+    }
     const int live_end = G->live_end;
     const int pid = G->current_player;
     PState* P = &G->p[pid];
@@ -947,6 +973,327 @@ __device__ __forceinline__ void r4_gen_act_legal(R4& q, int& nl_mine) {
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------
+// Round ends in ROW FORM (round 4).  Until here an exhaustive draw - 97 % of the exits of a RandomAgent rollout - sent its row to the
+// full path: the whole step again from the HBM record, then ~42 k cycles of wave-uniform code for ONE game while the three other rows
+// of the wave waited.  Here the rows that end a round stay in tier 0:
+//   * _trigger_ryukyoku (state/mod.rs:1846-1968, exhaustive draw): the four tenpai flags from the wait caches (the discarder's is
+//     refilled by the row-form probe), nagashi mangan / tenpai payments as lane = seat arithmetic, the ryukyoku event;
+//   * _initialize_next_round (state/mod.rs:1595-1688): the end-of-game decision per row;
+//   * RiichiEnv.reset defaults for a finished game under auto-reset (env.rs:799-851);
+//   * _initialize_round (state/mod.rs:1695-1844): record reset per row, then - one game at a time with all 64 lanes, it is 136
+//     elements wide - the wall (keys, a 128-bucket counting sort with byte counters, every tile scatters itself to the wall slab, to
+//     its hand slot, to the indicator), the four hands sorted by counting (lane = 16 * seat + slot), start_kyoku / tehai / tsumo.
+// The dealer's first list then comes from r4_gen_act_legal like any other WaitAct state, and the row is published with the others.
+// Events of a round end go straight to the ring (up to nine per step: the staging area holds four).
+// Out of line: its registers and code are not the hot path's.
+#define R4_RE_DRAW 1u      /* exhaustive draw */
+#define R4_RE_RESTART 2u   /* a finished game restarts (auto-reset) */
+#define R4_RE_PUB 3u       /* pass 2 of step4_body: the round has been dealt, the row's observation is still to be published */
+#define R4_RET_ROUND 0x100u /* step4_body's result: some row of the wave ends a round - the caller runs r4_round_end and pass 2 */
+// one MJAI record of the row's game straight to the ring: lane r < 8 holds dword r
+__device__ __forceinline__ void r4_emit_now(R4& q, bool on, uint32_t w) {
+    if (q.E->skip_log) return;
+    const uint32_t evc = q.G->ev_count;
+    wave_sync();
+    if (on) {
+        uint32_t* dst = reinterpret_cast<uint32_t*>(q.E->events + (size_t)q.g * (q.E->ring_mask + 1u) + (evc & q.E->ring_mask));
+        if (q.r < 8) dst[q.r] = q.r == 7 ? ((w & 0x00FFFFFFu) | ((uint32_t)KNP << 24)) : w;
+        if (q.r == 0) q.G->ev_count = evc + 1u;
+    }
+    wave_sync();
+}
+__device__ __noinline__ void r4_round_end(const Env* Ep, uint32_t g0) {
+    const int lane = threadIdx.x & 63, row = lane >> 4, r = lane & 15, rb = lane & 48;
+    Quad4Shared& sh = g_q4;
+    const uint32_t mode = sh.rmode[row];
+    CEnv& E = *(CEnv*)uni_ptr(Ep);
+    g0 = uni(g0);
+    GState* G = &sh.st[row];
+    R4 q;
+    q.G = G; q.T = &sh.u.t; q.E = &E; q.lane = lane; q.r = r; q.rb = rb; q.row = row; q.g = g0 + (uint32_t)row;
+    q.live = mode != 0u; q.bail = false; q.cont = 0; q.rend = mode; q.evn = 0; q.dirty = 0xFu;
+    const bool draw = mode == R4_RE_DRAW, restart = mode == R4_RE_RESTART;
+    bool newround = restart;            // the row's game starts a round below, with these parameters (row-uniform)
+    int n_oya = 0, n_rw = 0, n_honba = 0;
+    uint32_t n_sticks = 0u;
+    const bool seat = r < KNP;
+    if (__ballot(draw)) {
+        // ---- tenpai of the seats (HandEvaluator::is_tenpai through the wait cache, like seat_tenpai): stale caches first
+        {
+            const PState& S0 = G->p[r & 3];
+            uint32_t need_m = draw ? (rballot(seat && (S0.hand_len + 3 * S0.n_melds == 13) && !(S0.flags & PF_WAITS_VALID), rb) & 0xFu) : 0u;
+            while (__ballot(need_m != 0u)) {
+                if (need_m) {
+                    const int i = __ffs((int)need_m) - 1;
+                    need_m &= need_m - 1u;
+                    PState* Q = &G->p[i];
+                    r4_fill_waits13<true>(q, Q, Q->hand_len);
+                }
+            }
+        }
+        PState& S4 = G->p[r & 3];
+        const uint32_t tenpai_m = rballot(draw && seat && (S4.hand_len + 3 * S4.n_melds == 13) && S4.waits13 != 0ull, rb) & 0xFu;
+        const uint32_t nag_m = rballot(draw && seat && (S4.flags & PF_NAGASHI), rb) & 0xFu;
+        const int oya = G->oya;
+        int reason = RMJ_RK_EXHAUSTIVE;
+        if (draw && seat) {
+            int32_t sc = S4.score, sd = S4.score_delta;
+            if (nag_m) {   // nagashi mangan: every eligible seat takes a mangan tsumo from the others (calculate_score(5, 30, ., true, 0))
+#pragma unroll
+                for (int w = 0; w < KNP; w++) {
+                    if ((nag_m >> w) & 1u) {
+                        const int32_t d = r == w ? (w == oya ? 4000 * (KNP - 1) : 4000 + 2000 * (KNP - 2)) : -((w == oya || r == oya) ? 4000 : 2000);
+                        sc += d; sd += d;
+                    }
+                }
+            } else {
+                const int ntp = __popc(tenpai_m);
+                if (ntp > 0 && ntp < KNP) {
+                    const int pool = KSANMA ? 2000 : 3000;   // state_3p/game_mode.rs:39-41
+                    const int pk = ntp == 1 ? pool : (ntp == 2 ? pool / 2 : pool / 3), nn = KNP - ntp;
+                    const int pn = nn == 1 ? pool : (nn == 2 ? pool / 2 : pool / 3);
+                    const int32_t d = ((tenpai_m >> r) & 1u) ? pk : -pn;
+                    sc += d; sd = d;
+                }
+            }
+            S4.score = sc; S4.score_delta = sd;
+        }
+        if (nag_m) reason = RMJ_RK_NAGASHI;
+        wave_sync();
+        const bool renchan = nag_m ? ((nag_m >> oya) & 1u) != 0u : ((tenpai_m >> oya) & 1u) != 0u;
+        {   // the ryukyoku event: deltas = the seats' score_delta
+            const int32_t dv = (r >= 2 && r < 2 + KNP) ? G->p[(r - 2) & 3].score_delta : 0;
+            const uint32_t w = r == 0 ? (uint32_t)RMJ_EV_RYUKYOKU : (r == 6 ? (uint32_t)reason : (uint32_t)dv);
+            r4_emit_now(q, draw, (r == 1 || r == 7) ? 0u : w);
+        }
+        // ---- _initialize_next_round(renchan, is_draw = true)
+        {
+            const int32_t goal = KSANMA ? 40000 : 30000;
+            const int32_t s0 = G->p[0].score, s1 = G->p[1].score, s2 = G->p[2].score, s3 = KNP > 3 ? G->p[3].score : 0;
+            const bool neg = s0 < 0 || s1 < 0 || s2 < 0 || (KNP > 3 && s3 < 0);
+            int32_t mx = s0 > s1 ? s0 : s1;
+            mx = mx > s2 ? mx : s2;
+            if (KNP > 3) mx = mx > s3 ? mx : s3;
+            const int32_t ds = oya == 0 ? s0 : (oya == 1 ? s1 : (oya == 2 ? s2 : s3));
+            bool top = true;
+            top = top && (oya == 0 || ds > s0 || (ds == s0 && oya <= 0));
+            top = top && (oya == 1 || ds > s1 || (ds == s1 && oya <= 1));
+            top = top && (oya == 2 || ds > s2 || (ds == s2 && oya <= 2));
+            if (KNP > 3) top = top && (oya == 3 || ds > s3 || (ds == s3 && oya <= 3));
+            const uint32_t gm = E.game_mode;
+            const int rw = G->round_wind;
+            bool last_regular = false;
+            if (gm == 1u || gm == 4u) last_regular = rw == 0 && oya == KNP - 1;
+            if (gm == 2u || gm == 5u) last_regular = rw == 1 && oya == KNP - 1;
+            bool end = neg || (renchan && last_regular && top && ds >= goal);
+            int next_honba = G->honba, next_oya = oya, next_rw = rw;
+            next_honba = next_honba + 1 > 255 ? 255 : next_honba + 1;   // a draw keeps counting whoever deals next
+            if (!renchan) {
+                next_oya = next_oya + 1 == KNP ? 0 : next_oya + 1;
+                if (next_oya == 0) next_rw += 1;
+            }
+            if (!end) {
+                if (gm == 1u || gm == 4u) end = next_rw >= 1 && (mx >= goal || next_rw > 1);
+                else if (gm == 2u || gm == 5u) end = next_rw >= 2 && (mx >= goal || next_rw > 2);
+                else if (gm == 0u || gm == 3u) end = true;
+                else end = next_rw >= 1;
+            }
+            if (draw && end && r == 0) G->is_done = 1;   // process_end_game
+            r4_emit_now(q, draw, r == 0 ? (uint32_t)RMJ_EV_END_KYOKU : 0u);
+            if (__ballot(draw && end)) r4_emit_now(q, draw && end, r == 0 ? (uint32_t)RMJ_EV_END_GAME : 0u);
+            if (draw && !end) {
+                newround = true;
+                n_oya = next_oya; n_rw = next_rw; n_honba = next_honba; n_sticks = G->riichi_sticks;
+            }
+        }
+    }
+    if (__ballot(restart)) {   // GameState::reset clears the logs (state/mod.rs:171-187), then start_game
+        if (restart) {
+            if (r == 0) G->ev_count = 0u;
+            if (r < 4) { G->obs_from[r] = 0u; G->obs_upto[r] = 0u; }
+        }
+        wave_sync();
+        r4_emit_now(q, restart, r == 0 ? (uint32_t)RMJ_EV_START_GAME : 0u);
+    }
+    if (!__ballot(newround)) return;
+    // ---- _initialize_round, the per-row part: PlayerState::reset_round (state/player.rs:66-86) by lane = seat, the globals by lane 0
+    if (newround) {
+        if (r < 4) {
+            PState& P = G->p[r];
+            P.hand_len = 0; P.n_melds = 0; P.n_discards = 0;
+            P.flags = PF_NAGASHI;
+            P.pao37 = 0xFF; P.pao50 = 0xFF;
+            P.n_forbidden = 0;
+            P.riichi_decl_idx = 0xFF; P.riichi_sutehai = 0xFF; P.last_tedashi = 0xFF;
+            P.score_delta = 0;
+            P.discard_from_hand_bits = 0; P.discard_is_riichi_bits = 0;
+            P.discard_type_mask = 0;
+            P.n_kita = 0;
+            if (restart && r < KNP) P.score = KSANMA ? 35000 : 25000;   // state_3p/game_mode.rs:31-33
+            G->stale_n[r] = 0;
+        }
+        if (r == 0) {
+            G->oya = (uint8_t)n_oya; G->kyoku_idx = (uint8_t)n_oya; G->current_player = (uint8_t)n_oya;
+            G->honba = (uint8_t)n_honba; G->riichi_sticks = n_sticks; G->round_wind = (uint8_t)n_rw;
+            G->is_done = 0;
+            G->pending_kan_pid = 0xFF; G->pending_kan_action = 0;
+            G->is_rinshan = 0; G->rinshan_count = 0; G->pending_kan_dora = 0;
+            G->is_first_turn = 1; G->riichi_pending = 0xFF; G->turn_count = 0;
+            G->last_discard_pid = 0xFF; G->last_discard_tile = 0;
+            G->ron_offer_mask = 0; G->win_mask = 0;
+            G->tp_seat = 0xFF;
+            G->wall_total = KSANMA ? 108 : 136;
+            G->n_dora = 1;
+        }
+    }
+    wave_sync();
+    // ---- the wall and the deal, one game at a time with all 64 lanes
+    constexpr int N = KSANMA ? 108 : 136;
+    uint32_t* const cnt = sh.rs;                                    // [32] = 128 byte counters, then the bucket offsets in place
+    uint16_t* const gk = reinterpret_cast<uint16_t*>(sh.rs + 32);   // [136] sort words grouped by bucket: key bits 56..49 | element index
+    uint64_t todo = __ballot(newround && r == 0);
+    while (todo) {
+        const int br = (__ffsll((long long)todo) - 1) >> 4;
+        todo &= todo - 1ull;
+        GState* Gb = &sh.st[br];
+        const uint32_t gb = g0 + (uint32_t)br;
+        uint8_t* Wg = E.wall + (size_t)gb * RMJ_WALL_STRIDE;
+        const int oya = Gb->oya;
+        const uint32_t hidx = Gb->hand_index;
+        const uint64_t hs = sm64(Gb->wall_seed + (uint64_t)hidx);   // the build's seed -> wall (shuffle_wall): ids sorted by (key, id)
+        if (lane < 32) cnt[lane] = 0u;
+        uint64_t key[3];
+        uint32_t pos[3];
+#pragma unroll
+        for (int k = 0; k < 3; k++) key[k] = sm64(hs + (uint64_t)(lane + 64 * k) * 0x9E3779B97F4A7C15ull);
+        wave_sync();
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+            const uint32_t b = (uint32_t)(key[k] >> 57);
+            pos[k] = 0u;
+            if (lane + 64 * k < N) pos[k] = (atomicAdd(&cnt[b >> 2], 1u << (8u * (b & 3u))) >> (8u * (b & 3u))) & 0xFFu;
+        }
+        wave_sync();
+        {   // exclusive prefix sum over the 128 byte counters, two per lane, written back in place (offsets <= 136 fit a byte)
+            const uint32_t wv = cnt[lane >> 1];
+            const uint32_t v0 = (wv >> (16u * (lane & 1))) & 0xFFu, v1 = (wv >> (16u * (lane & 1) + 8u)) & 0xFFu;
+            uint32_t incl = v0 + v1;
+#pragma unroll
+            for (int off = 1; off < 64; off <<= 1) {
+                const uint32_t up = (uint32_t)__shfl_up((int)incl, off, 64);
+                if (lane >= off) incl += up;
+            }
+            const uint32_t excl = incl - (v0 + v1);
+            wave_sync();
+            reinterpret_cast<uint16_t*>(cnt)[lane] = (uint16_t)(excl | ((excl + v0) << 8));
+        }
+        wave_sync();
+        const uint8_t* off8 = reinterpret_cast<const uint8_t*>(cnt);
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+            const int i = lane + 64 * k;
+            if (i < N) gk[off8[key[k] >> 57] + pos[k]] = (uint16_t)((((uint32_t)(key[k] >> 49) & 0xFFu) << 8) | (uint32_t)i);
+        }
+        wave_sync();
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+            const int i = lane + 64 * k;
+            if (i < N) {
+                const uint32_t b = (uint32_t)(key[k] >> 57);
+                const uint32_t kw = (((uint32_t)(key[k] >> 49) & 0xFFu) << 8) | (uint32_t)i;
+                const int lo = off8[b], hi = b == 127u ? N : (int)off8[b + 1u];
+                int rk = lo;
+                for (int t = lo; t < hi; t++) {
+                    const uint32_t kt = gk[t];
+                    bool less = kt < kw;
+                    if ((kt >> 8) == (kw >> 8) && kt != kw) {   // 15 key bits equal (one bucket mate in 256): the full keys decide
+                        const uint32_t it = kt & 0xFFu;
+                        const uint64_t kf = sm64(hs + (uint64_t)it * 0x9E3779B97F4A7C15ull);
+                        less = kf < key[k] || (kf == key[k] && it < (uint32_t)i);
+                    }
+                    rk += less ? 1 : 0;
+                }
+                const int id = (KSANMA && i >= 4) ? i + 28 : i;   // i-th id of the tile universe (3P: no 2m-8m, types.rs:378-382)
+                const int wpos = N - 1 - rk;                       // w[rank] = id, then reversed (load_wall orientation)
+                Wg[wpos] = (uint8_t)id;
+                if (wpos == (KSANMA ? 8 : 4)) Gb->dora[0] = (uint8_t)id;   // state_3p/wall.rs:104-112
+                // deal: pop #n = W[N - 1 - n] = the element of rank n; three rounds of four tiles per seat from the dealer, then one each
+                const int n = rk;
+                if (n < 12 * KNP) {
+                    const int rr = n >= 8 * KNP ? 2 : (n >= 4 * KNP ? 1 : 0), rem = n - rr * 4 * KNP;
+                    int p = (rem >> 2) + oya;
+                    p = p >= KNP ? p - KNP : p;
+                    Gb->p[p].hand[rr * 4 + (rem & 3)] = (uint8_t)id;
+                } else if (n < 13 * KNP) {
+                    int p = (n - 12 * KNP) + oya;
+                    p = p >= KNP ? p - KNP : p;
+                    Gb->p[p].hand[12] = (uint8_t)id;
+                } else if (n == 13 * KNP) {   // the dealer's first draw
+                    Gb->p[oya].hand[13] = (uint8_t)id;
+                    Gb->drawn_tile = (uint8_t)id;
+                }
+            }
+        }
+        if (lane < (RMJ_WALL_STRIDE - N)) Wg[N + lane] = 0;
+        wave_sync();
+        {   // the four hands sorted by counting: lane = 16 * seat + slot
+            const int sp = lane >> 4, sl = lane & 15;
+            const bool in = sp < KNP && sl < 13;
+            const int t = in ? (int)Gb->p[sp & 3].hand[sl] : 0xFFFF;
+            int rk = 0;
+#pragma unroll
+            for (int k = 0; k < 13; k++) rk += rbc(t, rb + k) < t ? 1 : 0;
+            wave_sync();
+            if (in) Gb->p[sp & 3].hand[rk] = (uint8_t)t;
+            if (sp < KNP && sl == 0) Gb->p[sp & 3].hand_len = sp == oya ? 14 : 13;
+        }
+        if (lane == 0) {
+            Gb->hand_index = hidx + 1u;
+            Gb->live_end = (uint8_t)(N - 13 * KNP - 1);
+            Gb->drawable_count = (uint8_t)(N - 13 * KNP - 14 - 1);
+            Gb->needs_tsumo = 0;
+            Gb->phase = RMJ_WAIT_ACT;
+            Gb->active_mask = (uint8_t)(1u << oya);
+        }
+        wave_sync();
+        if (!E.skip_log) {   // start_kyoku + its two tehai records + the dealer's tsumo
+            const uint32_t evc = Gb->ev_count, ring = E.ring_mask + 1u;
+            RmjEvent* ring0 = E.events + (size_t)gb * ring;
+            if (lane < 8) {
+                const uint32_t ks = Gb->riichi_sticks;
+                uint32_t w = 0u;
+                if (lane == 0) w = (uint32_t)RMJ_EV_START_KYOKU | ((uint32_t)oya << 8) | ((uint32_t)(oya + 1) << 16) | ((uint32_t)Gb->dora[0] << 24);
+                if (lane == 1) w = ((uint32_t)Gb->round_wind & 3u) | ((uint32_t)Gb->honba << 8) | ((ks & 0xFFu) << 16) | (((ks >> 8) & 0xFFu) << 24);
+                if (lane >= 2 && lane < 2 + KNP) w = (uint32_t)Gb->p[(lane - 2) & 3].score;
+                if (lane == 7) w = (uint32_t)KNP << 24;
+                reinterpret_cast<uint32_t*>(ring0 + (evc & E.ring_mask))[lane] = w;
+            }
+            {   // lane = byte of the two tehai records
+                const int rec = lane >> 5, b = lane & 31;
+                uint32_t v = 0u;
+                if (b == 0) v = RMJ_EV_TEHAI;
+                if (b == 1) v = (uint32_t)rec;
+                if (b >= 4 && b < 30) {
+                    const int j = b - 4, sp = 2 * rec + (j >= 13 ? 1 : 0), k = j >= 13 ? j - 13 : j;
+                    v = sp < KNP ? Gb->p[sp & 3].hand[k] : 0u;
+                }
+                if (b == 31) v = (uint32_t)KNP;
+                reinterpret_cast<uint8_t*>(ring0 + ((evc + 1u + (uint32_t)rec) & E.ring_mask))[b] = (uint8_t)v;
+            }
+            if (lane < 8) {
+                uint32_t w = 0u;
+                if (lane == 0) w = (uint32_t)RMJ_EV_TSUMO | ((uint32_t)oya << 8) | ((uint32_t)Gb->drawn_tile << 24);
+                if (lane == 7) w = (uint32_t)KNP << 24;
+                reinterpret_cast<uint32_t*>(ring0 + ((evc + 3u) & E.ring_mask))[lane] = w;
+            }
+            wave_sync();
+            if (lane == 0) Gb->ev_count = evc + 4u;
+        }
+        wave_sync();
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------
 // The device policy that PLAYS (rmj_step_greedy; the oracle's twin is orc_game_greedy_actions): for every seat that is to act,
 // over its ordered legal list, the first entry of the best class -
 //   Tsumo / Ron  >  Kita  >  Riichi  >  Ankan  >  Kakan  >  Daiminkan  >  [Pon > Chi when ((key >> 40) & 255) < call_rate]  >
@@ -1175,10 +1522,11 @@ __device__ __forceinline__ uint64_t r4_policy_greedy(R4& q, bool on, const uint6
 // Rows then advance one or two game-steps per call: `left` = the steps the row's game still has to take in this rollout / ticket
 // (row-uniform), the result = how many it took (0: none left).  `final_chunk`: the rollout ends when `left` runs out (the last
 // step publishes masks and status, STEP_F_ALLROWS; every other step is quiet) - with INLR the caller passes `flags` without those bits.
-template <bool LOOP, int POL, bool INLR = false>
+template <bool LOOP, int POL, bool INLR = false, bool PASS2 = false>
 __device__ __forceinline__ uint32_t step4_body(const Env* Ep, Quad4Shared& sh, uint64_t policy_seed, uint32_t flags, uint32_t g_base, uint32_t g_end,
                                                bool load, uint64_t gs_row, const uint64_t* __restrict__ actions = nullptr, uint32_t quad = 0xFFFFFFFFu,
                                                uint32_t left = 1u, bool final_chunk = true) {
+    constexpr bool pass2 = PASS2;   // see q.live below
     static_assert(!INLR || LOOP, "inline responses: fused device-policy rollouts only");
     CEnv& E = *(CEnv*)Ep;
     // RICH tier 0 (the wait probe, the Riichi offer / declaration / riichi-stage list in row form): for policies that play - the
@@ -1208,10 +1556,16 @@ __device__ __forceinline__ uint32_t step4_body(const Env* Ep, Quad4Shared& sh, u
     {
     R4 q;
     q.G = &sh.st[row]; q.T = &sh.u.t; q.E = &E; q.lane = lane; q.r = r; q.rb = rb; q.row = row; q.g = g;
-    q.live = (uint32_t)row < n_here && (!INLR || left != 0u);
+    // pass 2 (RMJ_ROW_ROUND_END): the rows whose round ended in pass 1 and has been dealt since (r4_round_end, run by the caller between the
+    // passes - a call in here would cost every step ten more callee-saved registers): they skip policy and transitions, get their
+    // first list and are published like any other row
+    q.live = pass2 ? ((uint32_t)row < n_here && sh.rmode[row] != 0u) : ((uint32_t)row < n_here && (!INLR || left != 0u));
     GState* G = q.G;
     const uint64_t* Lg = E.legal + (size_t)g * 4 * RMJ_MAX_LEGAL;
-    q.bail = false; q.cont = 0; q.evn = 0; q.dirty = 0xFu;
+    q.bail = false; q.cont = 0; q.rend = 0u; q.evn = 0; q.dirty = 0xFu;
+#ifdef RMJ_CENSUS
+    q.why = 0;
+#endif
     // the next live-wall draw (valid while nothing moves live_end: kans bail)
     int pf = 0;
     if (q.live) {
@@ -1227,12 +1581,16 @@ __device__ __forceinline__ uint32_t step4_body(const Env* Ep, Quad4Shared& sh, u
     }
     // ---- policy (lane = seat): RandomAgent keyed per (game, step, seat), see k_step; POL = 1: the greedy policy (r4_policy_greedy)
     uint64_t mine = RMJ_NO_ACTION;
-    if (q.live && G->is_done) R4BAIL(q, 18);   // finished game: restart (auto-reset) or nothing to do - both handled by the full path
+    if (pass2) {
+        if (q.live) q.rend = R4_RE_PUB;
+    } else if (q.live && G->is_done) {   // finished game: restart (auto-reset: in row form) or nothing to do (full path)
+        if (RMJ_ROW_ROUND_END && (flags & STEP_F_AUTORESET)) q.rend = R4_RE_RESTART; else R4BAIL(q, 18);
+    }
     int pol_seat = -1, pol_sh = 99;   // greedy policy: shanten of the hand the chosen discard of seat pol_seat leaves
     if (POL == 1) {
         const uint64_t gs = LOOP ? gs_row : sm64(policy_seed + E.game_offset + (uint64_t)g);
-        mine = r4_policy_greedy<LOOP>(q, q.live && !q.bail, Lg, gs, (flags >> 8) & 0xFFu, pol_seat, pol_sh);
-    } else if (q.live && !q.bail) {
+        mine = r4_policy_greedy<LOOP>(q, q.live && !q.bail && q.rend == 0u, Lg, gs, (flags >> 8) & 0xFFu, pol_seat, pol_sh);
+    } else if (q.live && !q.bail && q.rend == 0u) {
         if (flags & STEP_F_RANDOM) {
             if (r < 4) {
                 const uint32_t n = G->nlegal[r];
@@ -1300,7 +1658,7 @@ __device__ __forceinline__ uint32_t step4_body(const Env* Ep, Quad4Shared& sh, u
     uint64_t w_mine = 0ull;   // lane = seat: waits published for the seat
     const bool t0 = q.live && !q.bail;
     bool second = false;      // INLR: this row answers the claims on its own discard in this call (its second game-step)
-    if (t0) {
+    if (t0 && q.rend == 0u) {
         if (r == 0) G->step_count += 1;
         const int phase = G->phase;
         if (phase == RMJ_WAIT_ACT) {
@@ -1730,22 +2088,33 @@ __device__ __forceinline__ uint32_t step4_body(const Env* Ep, Quad4Shared& sh, u
             }
         }
         R4M(43);
+    }
     R4T(2);
+    // rows whose round ended (an exhaustive draw above, a finished game under auto-reset) stop here in pass 1: ryukyoku, next round or end
+    // of game and the deal happen between the passes (r4_round_end), their observation is pass 2's
+    const bool wait_deal = RMJ_ROW_ROUND_END && !pass2 && t0 && !q.bail && q.rend != 0u;
+    if (q.rend) q.dirty = 0xFu;
+    if (t0 && !wait_deal) {
         // ---- the next observation: a WaitAct state needs the acting seat's list
-        if (!q.bail && G->phase == RMJ_WAIT_ACT) {
+        if (!q.bail && G->phase == RMJ_WAIT_ACT && !(q.rend && G->is_done)) {
             nl_mine = 0;
             w_mine = 0ull;
             r4_gen_act_legal<RICH>(q, nl_mine);
+            if (q.rend && q.bail) q.cont = 2;   // (a dealt hand tier 0 has no list for: the full path publishes the state as it stands)
         }
     }
     R4M(45);
     R4T(3);
     // ---- publication of the rows that completed in tier 0
-    const bool done0 = q.live && t0 && !q.bail;
+    const bool done0 = q.live && t0 && !q.bail && !wait_deal;
     // INLR: the steps this call took for the row's game (a bailed row takes ONE in the full path, from the untouched record, whatever
     // tier 0 had got to), and the row's own publication flags: quiet unless this was the last step of the rollout
-    const uint32_t used = !q.live ? 0u : ((INLR && second && (!q.bail || q.cont)) ? 2u : 1u);
-    const uint32_t fl_pub = INLR ? (flags | ((final_chunk && left == used) ? STEP_F_ALLROWS : STEP_F_QUIET)) : flags;
+    const uint32_t used = (!q.live || pass2) ? 0u : ((INLR && second && (!q.bail || q.cont)) ? 2u : 1u);
+    const uint32_t fl_pub = pass2 ? sh.rfl[row] : (INLR ? (flags | ((final_chunk && left == used) ? STEP_F_ALLROWS : STEP_F_QUIET)) : flags);
+    if (RMJ_ROW_ROUND_END && r == 0) {
+        sh.rmode[row] = wait_deal ? q.rend : 0u;
+        sh.rfl[row] = fl_pub;
+    }
     if (done0) {
         const uint32_t am = G->active_mask;
         const bool acts = r < 4 && ((am >> r) & 1u);
@@ -1799,7 +2168,7 @@ __device__ __forceinline__ uint32_t step4_body(const Env* Ep, Quad4Shared& sh, u
             dst[hh] = reinterpret_cast<const uint4*>(q.T->ev[row][e])[hh];
         }
     }
-    if (q.live && q.cont && r < 2 * q.evn) {   // a row that continues in the full path: its staged events go out now (the full path's scratch overlays the staging area)
+    if (q.live && (q.cont || wait_deal) && r < 2 * q.evn) {   // a row that continues in the full path or in r4_round_end: its staged events go out now (the full path's scratch overlays the staging area)
         const int e = r >> 1, hh = r & 1;
         uint4* dst = reinterpret_cast<uint4*>(E.events + (size_t)g * (E.ring_mask + 1u) + q.T->evidx[row][e]);
         dst[hh] = reinterpret_cast<const uint4*>(q.T->ev[row][e])[hh];
@@ -1821,7 +2190,7 @@ __device__ __forceinline__ uint32_t step4_body(const Env* Ep, Quad4Shared& sh, u
     R4T(5);
     // ---- bailed games: the complete state machine, one game at a time, from the untouched HBM record
     uint64_t bm = __ballot(q.live && q.bail && r == 0);
-    const uint32_t fl_full = (INLR ? fl_pub : flags) | (q.cont == 1 ? STEP_F_CONT_RYU : 0u);   // (per row)
+    const uint32_t fl_full = (INLR ? fl_pub : flags) | (q.cont == 1 ? STEP_F_CONT_RYU : 0u) | (q.cont == 2 ? STEP_F_CONT_FIN : 0u);   // (per row)
 #ifdef RMJ_TL4
     if (!LOOP && lane == 0) rmj::g_tl4[(size_t)blockIdx.x * RMJ_TL4_ROW + 7] = (unsigned long long)__popcll(bm);
 #endif
@@ -1829,6 +2198,12 @@ __device__ __forceinline__ uint32_t step4_body(const Env* Ep, Quad4Shared& sh, u
         const int br = (__ffsll((long long)bm) - 1) >> 4;
         bm &= bm - 1ull;
         const uint32_t gg = g0 + (uint32_t)br;
+#ifdef RMJ_CENSUS
+        {
+            const int why_b = __builtin_amdgcn_readlane(q.cont == 2 ? 31 : q.why, 16 * br);
+            if (lane == 0) atomicAdd(&rmj::g_bail_reason[why_b & 31], 1u);
+        }
+#endif
         // the seats' actions of that game move to lanes 0..3
         const uint64_t m_full = rbc64(mine, 16 * br + (lane & 3));
         Ctx c{sh.st[br], E, sh.u.x, gg, lane, E.wall + (size_t)gg * RMJ_WALL_STRIDE, E.legal + (size_t)gg * 4 * RMJ_MAX_LEGAL};
@@ -1852,16 +2227,28 @@ __device__ __forceinline__ uint32_t step4_body(const Env* Ep, Quad4Shared& sh, u
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         wave_sync();
     }
-    return used;
+    return used | (__ballot(wait_deal) ? R4_RET_ROUND : 0u);
     }
 }
 // The step as an out-of-line function with its own static LDS: the rollout loop calls it once per step, so nothing of a
 // step is hoisted out of the loop or kept live across it (the loop inlined: 48 VGPR + 37 SGPR spills).
 template <bool LOOP, int POL>
-__device__ __noinline__ void step4_call(const Env* Ep, uint64_t policy_seed, uint32_t flags, uint32_t g_base, uint32_t g_end, uint32_t load,
-                                        uint64_t gs_row, uint32_t quad = 0xFFFFFFFFu) {
-    __shared__ Quad4Shared sh;
-    step4_body<LOOP, POL>(uni_ptr(Ep), sh, uni(policy_seed), uni(flags), uni(g_base), uni(g_end), uni(load) != 0u, gs_row, nullptr, uni(quad));
+__device__ __noinline__ uint32_t step4_call(const Env* Ep, uint64_t policy_seed, uint32_t flags, uint32_t g_base, uint32_t g_end, uint32_t load,
+                                            uint64_t gs_row, uint32_t quad = 0xFFFFFFFFu) {
+    Quad4Shared& sh = g_q4;
+    return step4_body<LOOP, POL>(uni_ptr(Ep), sh, uni(policy_seed), uni(flags), uni(g_base), uni(g_end), uni(load) != 0u, gs_row, nullptr, uni(quad));
+}
+// Pass 2 of a step whose wave ended rounds (R4_RET_ROUND): r4_round_end has dealt them, their rows get the dealer's first list and are
+// published (step4_body<.., PASS2>: no policy, no transitions - a small function, out of line, entered once in ~25 wave-steps)
+template <bool LOOP, int POL>
+__device__ __noinline__ void step4_pass2(const Env* Ep, uint32_t flags, uint32_t g_base, uint32_t g_end, uint32_t quad = 0xFFFFFFFFu) {
+    Quad4Shared& sh = g_q4;
+    step4_body<LOOP, POL, false, true>(uni_ptr(Ep), sh, 0ull, uni(flags), uni(g_base), uni(g_end), false, 0ull, nullptr, uni(quad));
+}
+template <bool LOOP, int POL>
+__device__ __forceinline__ void step4_finish_rounds(const Env* Ep, uint32_t flags, uint32_t g_base, uint32_t g_end, uint32_t quad = 0xFFFFFFFFu) {
+    r4_round_end(Ep, g_base + (quad == 0xFFFFFFFFu ? blockIdx.x : quad) * 4u);
+    step4_pass2<LOOP, POL>(Ep, flags, g_base, g_end, quad);
 }
 // ... with inline responses (step4_body<.., INLR>): `left` steps to go per row, returns the steps taken per row
 #ifndef RMJ_INLINE_RESP
@@ -1870,7 +2257,7 @@ __device__ __noinline__ void step4_call(const Env* Ep, uint64_t policy_seed, uin
 template <int POL>
 __device__ __noinline__ uint32_t step4_call_inl(const Env* Ep, uint64_t policy_seed, uint32_t flags, uint32_t g_base, uint32_t g_end, uint32_t load,
                                                 uint64_t gs_row, uint32_t quad, uint32_t left, uint32_t final_chunk) {
-    __shared__ Quad4Shared sh;
+    Quad4Shared& sh = g_q4;
     return step4_body<true, POL, true>(uni_ptr(Ep), sh, uni(policy_seed), uni(flags), uni(g_base), uni(g_end), uni(load) != 0u, gs_row, nullptr, uni(quad),
                                        left, uni(final_chunk) != 0u);
 }
@@ -1883,13 +2270,18 @@ __device__ __forceinline__ void step4_run(const Env* Ep, uint64_t policy_seed, u
         uint32_t left = g_row < g_end ? steps : 0u, load = 1u;
 #pragma unroll 1
         while (__ballot(left != 0u)) {
-            left -= step4_call_inl<POL>(Ep, policy_seed, flags, g_base, g_end, load, gs_row, quad, left, final_chunk ? 1u : 0u);
+            const uint32_t ret = step4_call_inl<POL>(Ep, policy_seed, flags, g_base, g_end, load, gs_row, quad, left, final_chunk ? 1u : 0u);
+            left -= ret & 0xFFu;
             load = 0u;
+            if (RMJ_ROW_ROUND_END && __ballot((ret & R4_RET_ROUND) != 0u)) step4_finish_rounds<true, POL>(Ep, flags, g_base, g_end, quad);   // (wave-uniform bit)
         }
     } else {
 #pragma unroll 1
-        for (uint32_t it = 0; it < steps; it++)
-            step4_call<true, POL>(Ep, policy_seed, flags | ((final_chunk && it + 1u == steps) ? STEP_F_ALLROWS : STEP_F_QUIET), g_base, g_end, it == 0 ? 1u : 0u, gs_row, quad);
+        for (uint32_t it = 0; it < steps; it++) {
+            const uint32_t fl = flags | ((final_chunk && it + 1u == steps) ? STEP_F_ALLROWS : STEP_F_QUIET);
+            const uint32_t ret = step4_call<true, POL>(Ep, policy_seed, fl, g_base, g_end, it == 0 ? 1u : 0u, gs_row, quad);
+            if (RMJ_ROW_ROUND_END && __ballot((ret & R4_RET_ROUND) != 0u)) step4_finish_rounds<true, POL>(Ep, fl, g_base, g_end, quad);
+        }
     }
 }
 #ifndef RMJ_STEP4_WAVES
@@ -1909,11 +2301,12 @@ __global__ __launch_bounds__(64, RMJ_STEP4_WAVES) void k_step4(const Env* __rest
         const uint64_t gs_row = sm64(policy_seed + ((CEnv*)Ep)->game_offset + (uint64_t)g);   // policy key of the row's game
         step4_run<POL>(Ep, policy_seed, flags, g_base, g_end, gs_row, 0xFFFFFFFFu, n_steps, true, g);
     } else {
-        __shared__ Quad4Shared sh;
+        Quad4Shared& sh = g_q4;
 #ifdef RMJ_TL4
         const unsigned long long rt0 = __builtin_amdgcn_s_memrealtime();
 #endif
-        step4_body<false, POL>(Ep, sh, policy_seed, flags, g_base, g_end, true, 0ull, actions);
+        const uint32_t ret = step4_body<false, POL>(Ep, sh, policy_seed, flags, g_base, g_end, true, 0ull, actions);
+        if (RMJ_ROW_ROUND_END && __ballot((ret & R4_RET_ROUND) != 0u)) step4_finish_rounds<false, POL>(Ep, flags, g_base, g_end);
 #ifdef RMJ_TL4
         const unsigned long long rt1 = __builtin_amdgcn_s_memrealtime();
         if ((threadIdx.x & 63) == 0) {
@@ -2006,14 +2399,17 @@ __global__ __launch_bounds__(64, RMJ_STEP4_WAVES) void k_step4_fixup(const Env* 
 template <bool LOOP, int POL>
 __device__ __noinline__ void step4_call_enc(const Env* Ep, uint64_t policy_seed, uint32_t flags, uint32_t g_base, uint32_t g_end, uint32_t load,
                                             uint64_t gs_row, uint32_t quad, float* out, const uint64_t* actions = nullptr) {
-    __shared__ Quad4Shared sh;
+    Quad4Shared& sh = g_q4;
     __shared__ float lut[ENC_LUT];
     constexpr int W = KSANMA ? ENC_W3 : ENC_W4;
     const int lane = threadIdx.x & 63;
     g_base = uni(g_base); g_end = uni(g_end); quad = uni(quad);
     out = uni_ptr(out);
     if (uni(load) != 0u) enc_lut_init(lut, lane);
-    step4_body<LOOP, POL>(uni_ptr(Ep), sh, uni(policy_seed), uni(flags), g_base, g_end, uni(load) != 0u, gs_row, LOOP ? nullptr : uni_ptr(actions), quad);
+    {
+        const uint32_t ret = step4_body<LOOP, POL>(uni_ptr(Ep), sh, uni(policy_seed), uni(flags), g_base, g_end, uni(load) != 0u, gs_row, LOOP ? nullptr : uni_ptr(actions), quad);
+        if (RMJ_ROW_ROUND_END && __ballot((ret & R4_RET_ROUND) != 0u)) step4_finish_rounds<LOOP, POL>(uni_ptr(Ep), uni(flags), g_base, g_end, quad);
+    }
     wave_sync();
     const uint32_t g0 = g_base + (quad == 0xFFFFFFFFu ? blockIdx.x : quad) * 4u;
 #pragma unroll 1

@@ -267,6 +267,35 @@ int rmj_get_events(rmj_handle h, uint32_t game, uint32_t first, uint32_t max_eve
 /* Formats one event (START_KYOKU consumes the 2 TEHAI continuation records that follow it; returns
  * the number of records consumed, or <0).  seat = -1 -> full log string, 0..3 -> per-seat masked view. */
 int rmj_format_event(const RmjEvent* ev, uint32_t n_avail, int seat, char* buf, uint32_t cap);
+/* The logs of MANY games at once (RiichiEnv.mjai_log / the per-seat logs of every env, riichienv-python/src/env.rs:729-739,
+ * state/mod.rs:2094-2148).
+ * rmj_drain_events: the records every game wrote since cursor[g] (a count of records, 0 = from the start), gathered on the device
+ * into one dense buffer and copied down once: game g's records are out[offsets[g] .. offsets[g + 1]) (offsets has n + 1 slots),
+ * cursor[g] becomes the game's record count.  A game whose ring was lapped since its cursor has lost its oldest records: the window
+ * then starts at the oldest one still there and the loss is added to RmjEventViews.lost[g] (a restart by auto-reset / rmj_reset starts
+ * the game's count at 0 again: pass a cursor of 0 for such games, or drain before the restart).  When more than cap_events records
+ * are waiting nothing is drained, *n_events holds the number, the result is RMJ_ERR_RANGE.
+ * rmj_format_events: the strings of such a buffer, formatted by a pool of host threads: game g's log - its events' strings, each
+ * followed by '\n' - is buf[text_offsets[g] .. text_offsets[g + 1]); *needed = bytes of all logs; RMJ_ERR_RANGE (nothing written) when
+ * cap is smaller.  seat as in rmj_format_event.
+ * rmj_drain_format: both in one call through pinned staging owned by the handle (no intermediate copy); ms, when given, receives the
+ * milliseconds of the device gather, the copy to the host and the formatting. */
+int rmj_drain_events(rmj_handle h, uint32_t* cursor /*[n] in/out*/, RmjEvent* out, uint32_t cap_events, uint32_t* offsets /*[n + 1]*/, uint32_t* n_events);
+int rmj_format_events(const RmjEvent* ev, const uint32_t* offsets, uint32_t n_games, int seat, char* buf, uint64_t cap, uint64_t* text_offsets /*[n + 1]*/,
+                      uint64_t* needed);
+int rmj_drain_format(rmj_handle h, uint32_t* cursor /*[n] in/out*/, int seat, char* buf, uint64_t cap, uint64_t* text_offsets /*[n + 1]*/, uint64_t* needed,
+                     uint32_t* n_events, double* ms /*[3] or NULL*/);
+/* Device views of the event stream for a consumer on the same GPU: game g's record i (i < count) sits at events[g * ring + (i & (ring - 1))]
+ * while count - i <= ring; count = *(const uint32_t*)((const char*)ev_count + g * ev_count_stride). */
+typedef struct RmjEventViews {
+    uint32_t n_games, ring;
+    const RmjEvent* events;      /* [n][ring] */
+    const uint32_t* ev_count;    /* first game's record count; the others follow at ev_count_stride bytes */
+    uint32_t ev_count_stride, reserved;
+    const uint32_t* lost;        /* [n] records lost to a late drain, cumulative */
+} RmjEventViews;
+int rmj_event_views(rmj_handle h, RmjEventViews* out);
+int rmj_get_events_lost(rmj_handle h, uint32_t* lost /*[n]*/); /* host copy of RmjEventViews.lost */
 
 /* ------------------------------------------------------------------ batched hand math (kernel gate) */
 typedef struct RmjHandCase {
@@ -376,6 +405,16 @@ int rmj_step_ids_encode_device(rmj_handle h, const int32_t* d_action_ids, int au
  * d_ids [n][4] int32, -1 for seats that do not act: the input of rmj_step_ids_device.  Counter-based noise: the same
  * (seed, state) gives the same ids.  Asynchronous on the handle's stream. */
 int rmj_sample_ids_device(rmj_handle h, const float* d_logits, uint32_t stride, uint64_t seed, int32_t* d_ids);
+/* Round boundaries and per-round score deltas for a trainer on the same GPU (what riichienv-ml's PPO worker computes on the host
+ * between steps: trainers/_ppo_worker.py:100-116 GRP features, :240-266 the reward at a kyoku boundary, :283-291 rank rewards).
+ * Call after every step (asynchronous on the handle's stream): d_ended [n] u8 = 0 the round goes on, 1 a round ended in this step and
+ * the next one was dealt, 2 the round AND the game ended; for ended != 0, d_delta [n][4] i32 = the seats' scores now minus their
+ * scores when that round was dealt, d_meta [n][4] i32 = round_wind, oya, honba, riichi_sticks at that deal (chang / ju / ben /
+ * liqibang); zeros otherwise.  d_kyoku_idx [n] u8 = RiichiEnv.kyoku_idx.  Any output may be NULL.  The first call (and
+ * rmj_round_track_reset) only takes the baseline; a finished game that was restarted (auto-reset / rmj_reset) re-opens without a
+ * boundary.  Unlike the worker's kyoku_idx comparison a renchan counts as a boundary too (the wall's hand index moves). */
+int rmj_round_track_device(rmj_handle h, uint8_t* d_ended, int32_t* d_delta, int32_t* d_meta, uint8_t* d_kyoku_idx);
+int rmj_round_track_reset(rmj_handle h);
 /* scores() (env.rs:401-404) into a device buffer [n][4]; d_event_counts [n] may be NULL */
 int rmj_scores_device(rmj_handle h, int32_t* d_scores, uint32_t* d_event_counts);
 /* RiichiEnv.points(rule_name) (riichienv-python/src/env.rs:691-727, ranks :673-689) of every game, computed on the device in f64

@@ -25,7 +25,7 @@ def build() -> str:
 def lib():
     global _LIB
     if _LIB is None:
-        path = os.path.join(_HERE, "liboracle.so")
+        path = os.path.join(_HERE, os.environ.get("RMJ_ORACLE_LIB", "liboracle.so"))   # (liboracle_asan.so: scripts/run_sanitizers.sh)
         if not os.path.exists(path):
             build()
         L = C.CDLL(path)

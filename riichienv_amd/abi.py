@@ -197,6 +197,11 @@ class WinResult(C.Structure):
                 ("tsumo_agari_oya", C.c_uint32), ("tsumo_agari_ko", C.c_uint32), ("pao_payer", C.c_int8), ("pad", C.c_uint8 * 3)]
 
 
+class EventViews(C.Structure):   # RmjEventViews
+    _fields_ = [("n_games", C.c_uint32), ("ring", C.c_uint32), ("events", C.c_void_p), ("ev_count", C.c_void_p),
+                ("ev_count_stride", C.c_uint32), ("reserved", C.c_uint32), ("lost", C.c_void_p)]
+
+
 class Config(C.Structure):
     _fields_ = [("n_games", C.c_uint32), ("game_mode", C.c_uint8), ("skip_mjai_logging", C.c_uint8),
                 ("round_wind", C.c_uint8), ("reserved0", C.c_uint8), ("rule_bits", C.c_uint32),

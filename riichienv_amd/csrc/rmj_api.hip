@@ -7,6 +7,7 @@
 // (block b runs on XCD b % 8) and its 640-byte record is re-read from that XCD's L2 / MALL.
 #include <hip/hip_runtime.h>
 
+#include <chrono>
 #include <cstdio>
 #include <cstring>
 #include <string>
@@ -17,6 +18,7 @@
 #include "rmj_eval4.hip.h"
 #include "rmj_encode.hip.h"
 #include "rmj_seq.hip.h"
+#include "rmj_host.h"
 
 using namespace rmj;
 
@@ -223,7 +225,7 @@ __global__ __launch_bounds__(LC_BLOCK) void k_lc_gather(const uint32_t* __restri
     for (int p = 0; p < 4; p++) {
         const uint32_t k = nlegal[(size_t)g * 4 + p];
         if (!((am >> p) & 1u) || !k) continue;
-        if (row < cap_rows) { index[row] = g * 4u + (uint32_t)p; offs[row] = ent; }
+        if (row < cap_rows) { index[row] = g * 4u + (uint32_t)p; offs[row] = ent; offs[row + 1] = ent + k; }   // (the next row writes the same value at row + 1)
         for (uint32_t j = 0; j < k; j++)
             if (ent + j < cap_entries) entries[ent + j] = legal[((size_t)g * 4 + p) * RMJ_MAX_LEGAL + j];
         row++;
@@ -954,7 +956,9 @@ struct rmj_env {
     uint32_t queue_skip_xcds = 0;   // test hook: XCDs whose waves leave the queue kernel at once (RMJ_QUEUE_TEST_SKIP_XCDS at create)
     int queue_min_chunk = 8;        // shortest ticket (steps): a rollout of >= 2 tickets per quad runs as tickets; RMJ_QUEUE_MIN_CHUNK at create
     uint32_t max_xcc_id = 0;        // largest HW_REG_XCC_ID seen by a probe launch at create: the ticket rollout assumes ids 0..7 (one L2 per queue)
-    void* h_pin = nullptr;          // pinned host staging of the host-buffer entry points (rmj_get_legal_compact), grown on demand
+    uint32_t* d_ev_lost = nullptr;  // [n_games] records a game's ring lost to a late drain (rmj_drain_events), cumulative
+    void* d_track = nullptr;        // round tracker (rmj_round_track_device): hand index / scores / meta where every game's round began
+    void* h_pin = nullptr;          // pinned host staging of the host-buffer entry points (rmj_get_legal_compact, rmj_drain_*), grown on demand
     size_t pin_bytes = 0;
     int enc_streams = 0;            // RMJ_ENC_STREAMS at create (0: want_streams): parts of the step + encode rollout
     int enc_parts_quad = -1;        // RMJ_ENC_PARTS_QUAD at create (-1: follow `quad`)
@@ -1144,6 +1148,7 @@ int rmj_destroy(rmj_handle h) {
     if (h->h_pin) hipHostFree(h->h_pin);
     hipFree(h->d.core); hipFree(h->d.wall); hipFree(h->d.legal); hipFree(h->d.nlegal); hipFree(h->d_decay); if (h->d_scratch) hipFree(h->d_scratch); hipFree(h->d.mask);
     hipFree(h->d.waits); hipFree(h->d.status); hipFree(h->d.events); hipFree(h->d.win); hipFree(h->d_actions); hipFree(h->d_counter); hipFree(h->d_obs_offs); hipFree(h->d_env); hipFree(h->d_qheads);   // (d_qdone lives in the same allocation)
+    hipFree(h->d_ev_lost); hipFree(h->d_track);
     for (int i = 0; i < 2; i++) if (h->ev_time[i]) hipEventDestroy(h->ev_time[i]);
     if (h->own_stream) hipStreamDestroy(h->own_stream);
     for (int i = 0; i < RMJ_MAX_ROLLOUT_STREAMS - 1; i++) {
@@ -1639,7 +1644,7 @@ int rmj_get_legal_compact(rmj_handle h, uint32_t* index, uint32_t* offsets /*[ca
     const uint32_t n = h->cfg.n_games, blocks = (n + LC_BLOCK - 1) / LC_BLOCK;
     // device scratch: pre [n][2] | blk [blocks][2] | totals [2] | index [cap_rows] | offs [cap_rows] | entries [cap_entries]
     const size_t o_blk = (size_t)n * 8, o_tot = o_blk + (size_t)blocks * 8, o_idx = o_tot + 16, o_off = o_idx + (size_t)cap_rows * 4;
-    const size_t o_ent = (o_off + (size_t)cap_rows * 4 + 15) & ~(size_t)15, total = o_ent + (size_t)cap_entries * 8;
+    const size_t o_ent = (o_off + ((size_t)cap_rows + 1) * 4 + 15) & ~(size_t)15, total = o_ent + (size_t)cap_entries * 8;
     void* sp;
     int rc = scratch_for(h, total, &sp);
     if (rc) return rc;
@@ -1651,7 +1656,7 @@ int rmj_get_legal_compact(rmj_handle h, uint32_t* index, uint32_t* offsets /*[ca
     hipLaunchKernelGGL(k_lc_gather, dim3(blocks), dim3(LC_BLOCK), 0, h->stream, (const uint32_t*)h->d.status, (const uint8_t*)h->d.nlegal, (const uint64_t*)h->d.legal, n,
                        (const uint32_t*)pre, (const uint32_t*)blk, cap_rows, cap_entries, d_idx, d_off, d_ent);
     HIPCHK(hipGetLastError());
-    const size_t need_pin = 16 + (size_t)cap_rows * 8 + (size_t)cap_entries * 8;
+    const size_t need_pin = 16 + (size_t)cap_rows * 8 + 4 + (size_t)cap_entries * 8;
     if (need_pin > h->pin_bytes) {
         if (h->h_pin) hipHostFree(h->h_pin);
         h->h_pin = nullptr; h->pin_bytes = 0;
@@ -1664,16 +1669,16 @@ int rmj_get_legal_compact(rmj_handle h, uint32_t* index, uint32_t* offsets /*[ca
     const uint32_t rows = ((uint32_t*)pin)[0], ents = ((uint32_t*)pin)[1];
     *n_rows = rows; *n_entries = ents;
     const uint32_t wr = rows < cap_rows ? rows : cap_rows, we = ents < cap_entries ? ents : cap_entries;
-    uint8_t *p_idx = pin + 16, *p_off = p_idx + (size_t)cap_rows * 4, *p_ent = p_off + (size_t)cap_rows * 4;
+    uint8_t *p_idx = pin + 16, *p_off = p_idx + (size_t)cap_rows * 4, *p_ent = p_off + ((size_t)cap_rows + 1) * 4;
     if (wr) {
         HIPCHK(hipMemcpyAsync(p_idx, d_idx, (size_t)wr * 4, hipMemcpyDeviceToHost, h->stream));
-        HIPCHK(hipMemcpyAsync(p_off, d_off, (size_t)wr * 4, hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(hipMemcpyAsync(p_off, d_off, ((size_t)wr + 1) * 4, hipMemcpyDeviceToHost, h->stream));
     }
     if (we) HIPCHK(hipMemcpyAsync(p_ent, d_ent, (size_t)we * 8, hipMemcpyDeviceToHost, h->stream));
     HIPCHK(hipStreamSynchronize(h->stream));
     memcpy(index, p_idx, (size_t)wr * 4);
-    memcpy(offsets, p_off, (size_t)wr * 4);
-    offsets[wr] = rows <= cap_rows ? ents : (wr ? offsets[wr - 1] : 0u);   // end of the last row written (exact when nothing was cut)
+    if (wr) memcpy(offsets, p_off, ((size_t)wr + 1) * 4);   // offsets[wr] = the end of the last row written
+    else offsets[0] = 0u;
     memcpy(entries, p_ent, (size_t)we * 8);
     return RMJ_OK;
 }
@@ -1792,80 +1797,7 @@ int rmj_get_events(rmj_handle h, uint32_t game, uint32_t first, uint32_t max_eve
     return RMJ_OK;
 }
 
-// ---- state peek / poke ------------------------------------------------------------------
-static void to_view(const GState& S, const uint8_t* W, RmjStateView* v) {
-    memset(v, 0, sizeof(*v));
-    int len = (int)S.live_end - (int)S.rinshan_count;
-    if (len < 0) len = 0;
-    v->wall_len = (uint8_t)len;
-    for (int i = 0; i < len && i < 136; i++) v->wall[i] = W[S.rinshan_count + i];
-    v->n_dora = S.n_dora;
-    for (int i = 0; i < 5; i++) v->dora[i] = i < S.n_dora ? S.dora[i] : 0;
-    v->rinshan_draw_count = S.rinshan_count;
-    v->pending_kan_dora_count = S.pending_kan_dora;
-    v->drawable_count = S.drawable_count;
-    v->wall_seed = S.wall_seed;
-    v->hand_index = S.hand_index;
-    for (int p = 0; p < 4; p++) {
-        const PState& P = S.p[p];
-        RmjPlayerView& q = v->players[p];
-        q.hand_len = P.hand_len;
-        for (int i = 0; i < P.hand_len && i < 14; i++) q.hand[i] = P.hand[i];
-        q.n_melds = P.n_melds;
-        for (int m = 0; m < P.n_melds && m < 4; m++) {
-            RmjMeldView& mv = q.melds[m];
-            mv.meld_type = P.meld_type[m];
-            mv.n_tiles = P.meld_type[m] >= RMJ_MELD_DAIMINKAN ? 4 : 3;
-            for (int k = 0; k < mv.n_tiles; k++) mv.tiles[k] = P.meld_tiles[m][k];
-            mv.opened = P.meld_type[m] != RMJ_MELD_ANKAN;
-            mv.from_who = P.meld_from[m] == 0xFF ? -1 : (int8_t)P.meld_from[m];
-            mv.called_tile = P.meld_called[m] == 0xFF ? -1 : (int16_t)P.meld_called[m];
-        }
-        q.n_discards = P.n_discards;
-        for (int i = 0; i < P.n_discards && i < RMJ_MAX_DISCARDS; i++) q.discards[i] = P.discards[i];
-        q.discard_from_hand_bits = P.discard_from_hand_bits;
-        q.discard_is_riichi_bits = P.discard_is_riichi_bits;
-        q.riichi_declaration_index = P.riichi_decl_idx == 0xFF ? -1 : (int8_t)P.riichi_decl_idx;
-        q.score = P.score;
-        q.score_delta = P.score_delta;
-        q.riichi_declared = (P.flags & PF_RIICHI_DECLARED) != 0;
-        q.riichi_stage = (P.flags & PF_RIICHI_STAGE) != 0;
-        q.double_riichi_declared = (P.flags & PF_DOUBLE_RIICHI) != 0;
-        q.missed_agari_riichi = (P.flags & PF_MISSED_RIICHI) != 0;
-        q.missed_agari_doujun = (P.flags & PF_MISSED_DOUJUN) != 0;
-        q.nagashi_eligible = (P.flags & PF_NAGASHI) != 0;
-        q.ippatsu_cycle = (P.flags & PF_IPPATSU) != 0;
-        q.pao_daisangen = P.pao37 == 0xFF ? -1 : (int8_t)P.pao37;
-        q.pao_daisuushi = P.pao50 == 0xFF ? -1 : (int8_t)P.pao50;
-        q.n_forbidden = P.n_forbidden;
-        for (int i = 0; i < P.n_forbidden && i < 2; i++) q.forbidden[i] = P.forbidden[i];
-        q.riichi_sutehai = P.riichi_sutehai == 0xFF ? -1 : (int16_t)P.riichi_sutehai;
-        q.last_tedashi = P.last_tedashi == 0xFF ? -1 : (int16_t)P.last_tedashi;
-        q.n_kita = P.n_kita;
-        for (int i = 0; i < P.n_kita && i < 4; i++) q.kita[i] = P.kita[i];
-    }
-    v->current_player = S.current_player;
-    v->is_done = S.is_done;
-    v->needs_tsumo = S.needs_tsumo;
-    v->phase = S.phase;
-    v->active_mask = S.active_mask;
-    v->turn_count = S.turn_count;
-    v->riichi_sticks = S.riichi_sticks;
-    v->last_discard_pid = S.last_discard_pid == 0xFF ? -1 : (int16_t)S.last_discard_pid;
-    v->last_discard_tile = S.last_discard_pid == 0xFF ? -1 : (int16_t)S.last_discard_tile;
-    v->pending_kan_pid = S.pending_kan_pid == 0xFF ? -1 : (int16_t)S.pending_kan_pid;
-    v->pending_kan_action = S.pending_kan_pid == 0xFF ? 0 : S.pending_kan_action;
-    v->oya = S.oya;
-    v->honba = S.honba;
-    v->kyoku_idx = S.kyoku_idx;
-    v->round_wind = S.round_wind;
-    v->is_rinshan_flag = S.is_rinshan;
-    v->is_first_turn = S.is_first_turn;
-    v->riichi_pending_acceptance = S.riichi_pending == 0xFF ? -1 : (int16_t)S.riichi_pending;
-    v->drawn_tile = S.drawn_tile == 0xFF ? -1 : (int16_t)S.drawn_tile;
-    v->last_error_pid = S.last_error_pid == 0xFF ? -1 : (int16_t)S.last_error_pid;
-}
-
+// ---- state peek / poke (conversions: rmj_host.h) -------------------------------------------
 int rmj_peek_state(rmj_handle h, uint32_t game, RmjStateView* out) {
     if (!h || !out) return fail(RMJ_ERR_ARG, "null argument");
     if (game >= h->cfg.n_games) return fail(RMJ_ERR_RANGE, "game index out of range");
@@ -1873,7 +1805,7 @@ int rmj_peek_state(rmj_handle h, uint32_t game, RmjStateView* out) {
     uint8_t W[RMJ_WALL_STRIDE];
     SYNC_FETCH(&st, h->d.core + game, sizeof(GState));
     HIPCHK(hipMemcpy(W, h->d.wall + (size_t)game * RMJ_WALL_STRIDE, RMJ_WALL_STRIDE, hipMemcpyDeviceToHost));
-    to_view(st, W, out);
+    rmjh::to_view(st, W, out);
     return RMJ_OK;
 }
 
@@ -1884,81 +1816,7 @@ int rmj_poke_state(rmj_handle h, uint32_t game, const RmjStateView* v) {
     uint8_t W[RMJ_WALL_STRIDE];
     SYNC_FETCH(&S, h->d.core + game, sizeof(GState));
     HIPCHK(hipMemcpy(W, h->d.wall + (size_t)game * RMJ_WALL_STRIDE, RMJ_WALL_STRIDE, hipMemcpyDeviceToHost));
-    S.rinshan_count = v->rinshan_draw_count;
-    int len = v->wall_len;
-    if (S.rinshan_count + len > 136) return fail(RMJ_ERR_ARG, "wall too long");
-    for (int p = 0; p < 4; p++) S.stale_n[p] = 0;
-    for (int i = 0; i < len; i++) W[S.rinshan_count + i] = v->wall[i];
-    S.live_end = (uint8_t)(S.rinshan_count + len);
-    S.n_dora = v->n_dora > 5 ? 5 : v->n_dora;
-    for (int i = 0; i < S.n_dora; i++) S.dora[i] = v->dora[i];
-    S.pending_kan_dora = v->pending_kan_dora_count;
-    S.drawable_count = v->drawable_count;
-    S.hand_index = (uint32_t)v->hand_index;
-    for (int p = 0; p < 4; p++) {
-        PState& P = S.p[p];
-        const RmjPlayerView& q = v->players[p];
-        if (q.hand_len > 14 || q.n_melds > 4 || q.n_discards > RMJ_MAX_DISCARDS) return fail(RMJ_ERR_ARG, "player view out of range");
-        P.hand_len = q.hand_len;
-        for (int i = 0; i < q.hand_len; i++) P.hand[i] = q.hand[i];
-        P.n_melds = q.n_melds;
-        for (int m = 0; m < q.n_melds; m++) {
-            const RmjMeldView& mv = q.melds[m];
-            P.meld_type[m] = mv.meld_type;
-            uint8_t t[4] = {0, 0, 0, 0};
-            int nt = mv.n_tiles > 4 ? 4 : mv.n_tiles;
-            for (int k = 0; k < nt; k++) t[k] = mv.tiles[k];
-            for (int a = 0; a < nt; a++)
-                for (int b = 0; b + 1 < nt; b++)
-                    if (t[b] > t[b + 1]) std::swap(t[b], t[b + 1]);
-            for (int k = 0; k < 4; k++) P.meld_tiles[m][k] = t[k];
-            P.meld_from[m] = mv.from_who < 0 ? 0xFF : (uint8_t)mv.from_who;
-            P.meld_called[m] = mv.called_tile < 0 ? 0xFF : (uint8_t)mv.called_tile;
-        }
-        P.n_discards = q.n_discards;
-        P.discard_type_mask = 0;
-        for (int i = 0; i < q.n_discards; i++) {
-            P.discards[i] = q.discards[i];
-            P.discard_type_mask |= 1ull << (q.discards[i] >> 2);
-        }
-        P.discard_from_hand_bits = q.discard_from_hand_bits;
-        P.discard_is_riichi_bits = q.discard_is_riichi_bits;
-        P.riichi_decl_idx = q.riichi_declaration_index < 0 ? 0xFF : (uint8_t)q.riichi_declaration_index;
-        P.score = q.score;
-        P.score_delta = q.score_delta;
-        P.flags = (q.riichi_declared ? PF_RIICHI_DECLARED : 0) | (q.riichi_stage ? PF_RIICHI_STAGE : 0) |
-                  (q.double_riichi_declared ? PF_DOUBLE_RIICHI : 0) | (q.missed_agari_riichi ? PF_MISSED_RIICHI : 0) |
-                  (q.missed_agari_doujun ? PF_MISSED_DOUJUN : 0) | (q.nagashi_eligible ? PF_NAGASHI : 0) |
-                  (q.ippatsu_cycle ? PF_IPPATSU : 0);
-        P.pao37 = q.pao_daisangen < 0 ? 0xFF : (uint8_t)q.pao_daisangen;
-        P.pao50 = q.pao_daisuushi < 0 ? 0xFF : (uint8_t)q.pao_daisuushi;
-        P.n_forbidden = q.n_forbidden > 2 ? 2 : q.n_forbidden;
-        for (int i = 0; i < P.n_forbidden; i++) P.forbidden[i] = q.forbidden[i];
-        P.riichi_sutehai = q.riichi_sutehai < 0 ? 0xFF : (uint8_t)q.riichi_sutehai;
-        P.last_tedashi = q.last_tedashi < 0 ? 0xFF : (uint8_t)q.last_tedashi;
-        P.n_kita = q.n_kita > 4 ? 4 : q.n_kita;
-        for (int i = 0; i < P.n_kita; i++) P.kita[i] = q.kita[i];
-    }
-    S.current_player = v->current_player;
-    S.is_done = v->is_done;
-    S.needs_tsumo = v->needs_tsumo;
-    S.phase = v->phase;
-    S.active_mask = v->active_mask;
-    S.turn_count = v->turn_count;
-    S.riichi_sticks = v->riichi_sticks;
-    S.last_discard_pid = v->last_discard_pid < 0 ? 0xFF : (uint8_t)v->last_discard_pid;
-    S.last_discard_tile = v->last_discard_pid < 0 ? 0 : (uint8_t)v->last_discard_tile;
-    S.pending_kan_pid = v->pending_kan_pid < 0 ? 0xFF : (uint8_t)v->pending_kan_pid;
-    S.pending_kan_action = v->pending_kan_pid < 0 ? 0 : v->pending_kan_action;
-    S.oya = v->oya;
-    S.honba = v->honba;
-    S.kyoku_idx = v->kyoku_idx;
-    S.round_wind = v->round_wind;
-    S.is_rinshan = v->is_rinshan_flag;
-    S.is_first_turn = v->is_first_turn;
-    S.riichi_pending = v->riichi_pending_acceptance < 0 ? 0xFF : (uint8_t)v->riichi_pending_acceptance;
-    S.drawn_tile = v->drawn_tile < 0 ? 0xFF : (uint8_t)v->drawn_tile;
-    S.last_error_pid = v->last_error_pid < 0 ? 0xFF : (uint8_t)v->last_error_pid;
+    if (const char* err = rmjh::from_view(S, W, v)) return fail(RMJ_ERR_ARG, err);
     HIPCHK(hipMemcpy(h->d.core + game, &S, sizeof(GState), hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(h->d.wall + (size_t)game * RMJ_WALL_STRIDE, W, RMJ_WALL_STRIDE, hipMemcpyHostToDevice));
     if (h->cfg.game_mode >= 3) hipLaunchKernelGGL(rmj3::k_refresh, dim3(1), dim3(64), 0, h->stream, (const Env*)h->d_env, game);
@@ -1968,115 +1826,274 @@ int rmj_poke_state(rmj_handle h, uint32_t game, const RmjStateView* v) {
     return RMJ_OK;
 }
 
-// ---- MJAI formatting (state/mod.rs:2094-2148; parser.rs:301-334) -------------------------
-static std::string mjai_tile(uint8_t tid) {
-    if (tid == 16) return "5mr";
-    if (tid == 52) return "5pr";
-    if (tid == 88) return "5sr";
-    if (tid < 108) {
-        static const char sc[3] = {'m', 'p', 's'};
-        std::string s;
-        s += (char)('1' + (tid % 36) / 4);
-        s += sc[tid / 36];
-        return s;
-    }
-    static const char* hon[7] = {"E", "S", "W", "N", "P", "F", "C"};
-    int num = (tid - 108) / 4;
-    if (num < 7) return hon[num];
-    return std::to_string(num + 1) + "z";
+// ---- MJAI formatting (state/mod.rs:2094-2148; parser.rs:301-334; formatter: rmj_host.h) -----
+int rmj_format_event(const RmjEvent* ev, uint32_t n_avail, int seat, char* buf, uint32_t cap) {
+    if (!ev || !buf || n_avail == 0 || cap == 0) return RMJ_ERR_ARG;
+    rmjh::Out o{buf, buf + (cap - 1), 0};
+    const int used = rmjh::format_event(o, ev, n_avail, seat);
+    if (used < 0) return used;
+    if (o.need + 1 > cap) return RMJ_ERR_RANGE;
+    *o.p = 0;
+    return used;
 }
-static std::string jtiles(const uint8_t* t, int n) {
-    std::string s = "[";
-    for (int i = 0; i < n; i++) {
-        if (i) s += ",";
-        s += "\"" + mjai_tile(t[i]) + "\"";
-    }
-    return s + "]";
-}
-static std::string jints(const int32_t* v, int n) {
-    std::string s = "[";
-    for (int i = 0; i < n; i++) {
-        if (i) s += ",";
-        s += std::to_string(v[i]);
-    }
-    return s + "]";
+int rmj_format_events(const RmjEvent* ev, const uint32_t* offsets, uint32_t n_games, int seat, char* buf, uint64_t cap, uint64_t* text_offsets,
+                      uint64_t* needed) {
+    if (!ev || !offsets || !text_offsets || !needed) return RMJ_ERR_ARG;
+    *needed = rmjh::format_events(ev, offsets, n_games, seat, buf, cap, text_offsets, 0);
+    return (buf && *needed <= cap) ? RMJ_OK : RMJ_ERR_RANGE;
 }
 
-int rmj_format_event(const RmjEvent* ev, uint32_t n_avail, int seat, char* buf, uint32_t cap) {
-    if (!ev || !buf || n_avail == 0) return RMJ_ERR_ARG;
-    std::string s;
-    int used = 1;
-    const RmjEvent& e = ev[0];
-    auto A = [&](int a) { return std::to_string(a); };
-    int ncons = e.flags >> 4;
-    const int np = (e.pad == 3) ? 3 : 4;  // seats, written into the pad byte by the device
-    switch (e.type) {
-        case RMJ_EV_START_GAME: s = "{\"type\":\"start_game\"}"; break;
-        case RMJ_EV_END_KYOKU: s = "{\"type\":\"end_kyoku\"}"; break;
-        case RMJ_EV_END_GAME: s = "{\"type\":\"end_game\"}"; break;
-        case RMJ_EV_START_KYOKU: {
-            if (n_avail < 3 || ev[1].type != RMJ_EV_TEHAI || ev[2].type != RMJ_EV_TEHAI) return RMJ_ERR_ARG;
-            used = 3;
-            static const char* winds[4] = {"E", "S", "W", "N"};
-            uint32_t kyotaku = e.consumed[2] | (e.consumed[3] << 8);
-            s = std::string("{\"bakaze\":\"") + winds[e.consumed[0] & 3] + "\",\"dora_marker\":\"" + mjai_tile(e.tile) + "\",\"honba\":" +
-                A(e.consumed[1]) + ",\"kyoku\":" + A(e.target) + ",\"kyotaku\":" + A((int)kyotaku) + ",\"oya\":" + A(e.actor) +
-                ",\"scores\":" + jints(e.deltas, np) + ",\"tehais\":[";
-            for (int p = 0; p < np; p++) {
-                const uint8_t* pl = reinterpret_cast<const uint8_t*>(&ev[1 + p / 2]) + 4 + 13 * (p & 1);
-                if (p) s += ",";
-                if (seat < 0 || seat == p) s += jtiles(pl, 13);
-                else {
-                    s += "[";
-                    for (int k = 0; k < 13; k++) s += k ? ",\"?\"" : "\"?\"";
-                    s += "]";
-                }
-            }
-            s += "],\"type\":\"start_kyoku\"}";
-            break;
-        }
-        case RMJ_EV_TSUMO:
-            s = "{\"actor\":" + A(e.actor) + ",\"pai\":\"" + ((seat < 0 || seat == e.actor) ? mjai_tile(e.tile) : std::string("?")) +
-                "\",\"type\":\"tsumo\"}";
-            break;
-        case RMJ_EV_DAHAI:
-            s = "{\"actor\":" + A(e.actor) + ",\"pai\":\"" + mjai_tile(e.tile) + "\",\"tsumogiri\":" + ((e.flags & 1) ? "true" : "false") +
-                ",\"type\":\"dahai\"}";
-            break;
-        case RMJ_EV_REACH: s = "{\"actor\":" + A(e.actor) + ",\"type\":\"reach\"}"; break;
-        case RMJ_EV_REACH_ACCEPTED: s = "{\"actor\":" + A(e.actor) + ",\"type\":\"reach_accepted\"}"; break;
-        case RMJ_EV_CHI:
-        case RMJ_EV_PON:
-        case RMJ_EV_DAIMINKAN:
-            s = "{\"actor\":" + A(e.actor) + ",\"consumed\":" + jtiles(e.consumed, ncons) + ",\"pai\":\"" + mjai_tile(e.tile) +
-                "\",\"target\":" + A(e.target) + ",\"type\":\"" +
-                (e.type == RMJ_EV_CHI ? "chi" : (e.type == RMJ_EV_PON ? "pon" : "daiminkan")) + "\"}";
-            break;
-        case RMJ_EV_ANKAN:
-        case RMJ_EV_KAKAN:
-            s = "{\"actor\":" + A(e.actor) + ",\"consumed\":" + jtiles(e.consumed, ncons) + ",\"pai\":\"" + mjai_tile(e.tile) +
-                "\",\"type\":\"" + (e.type == RMJ_EV_ANKAN ? "ankan" : "kakan") + "\"}";
-            break;
-        case RMJ_EV_KITA:
-            s = "{\"actor\":" + A(e.actor) + ",\"pai\":\"" + mjai_tile(e.tile) + "\",\"type\":\"kita\"}";
-            break;
-        case RMJ_EV_DORA: s = "{\"dora_marker\":\"" + mjai_tile(e.tile) + "\",\"type\":\"dora\"}"; break;
-        case RMJ_EV_HORA:
-            s = "{\"actor\":" + A(e.actor) + ",\"deltas\":" + jints(e.deltas, np) + ",\"target\":" + A(e.target) +
-                ((e.flags & 1) ? ",\"tsumo\":true" : "") + ",\"type\":\"hora\",\"ura_markers\":" + jtiles(e.ura, e.n_ura) + "}";
-            break;
-        case RMJ_EV_RYUKYOKU: {
-            static const char* reasons[7] = {"exhaustive_draw", "nagashimangan", "kyushu_kyuhai", "sufuurenta", "suukansansen", "suucha_riichi",
-                                             "sanchaho"};
-            std::string r = e.flags < 7 ? reasons[e.flags] : ("Error: Illegal Action by Player " + A(e.actor));
-            s = "{\"deltas\":" + jints(e.deltas, np) + ",\"reason\":\"" + r + "\",\"type\":\"ryukyoku\"}";
-            break;
-        }
-        default: return RMJ_ERR_ARG;
+// ---- per-round rewards for a trainer on the same GPU -------------------------------------------
+// What riichienv-ml's PPO worker derives on the host between steps (trainers/_ppo_worker.py:100-116, 240-266, 283-291): when a
+// round has ended, the seats' score deltas over that round and the round's opening facts (the GRP features chang / ju / ben /
+// liqibang); when the game has ended, its final scores (rank rewards).  A tracker per handle remembers where every game's current
+// round began; one small launch after a step compares: the wall's hand index moves with every deal (state/wall.rs:36-40), is_done
+// with the end of the game.  ended: 0 = the round goes on, 1 = a round ended and the next one was dealt, 2 = the round and the game
+// ended; a finished game that was restarted (auto-reset, rmj_reset) re-opens silently.
+struct RoundTrack {            // device arrays of the tracker (rmj_env::d_track)
+    uint32_t* hand_index;      // [n] hand index when the game's current round was dealt
+    uint8_t* was_done;         // [n]
+    int32_t* start_scores;     // [n][4]
+    int32_t* start_meta;       // [n][4] round_wind, oya, honba, riichi_sticks at the deal
+};
+__global__ void k_round_track(const GState* __restrict__ core, uint32_t n, RoundTrack T, int baseline, uint8_t* __restrict__ ended, int32_t* __restrict__ delta,
+                              int32_t* __restrict__ meta, uint8_t* __restrict__ kyoku_idx) {
+    const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= n) return;
+    const GState& S = core[g];
+    const uint32_t hi = S.hand_index;
+    const bool done = S.is_done != 0;
+    int32_t sc[4];
+    for (int p = 0; p < 4; p++) sc[p] = S.p[p].score;
+    uint8_t e = 0;
+    bool rebase = baseline != 0;
+    if (!baseline) {
+        const bool wd = T.was_done[g] != 0;
+        if (wd && !done) rebase = true;                                  // restarted: a new game opens
+        else if (done && !wd) e = 2;                                     // the round that ended the game
+        else if (!done && hi != T.hand_index[g]) { e = 1; rebase = true; }
     }
-    if (s.size() + 1 > cap) return RMJ_ERR_RANGE;
-    memcpy(buf, s.c_str(), s.size() + 1);
-    return used;
+    if (ended) ended[g] = e;
+    if (kyoku_idx) kyoku_idx[g] = S.kyoku_idx;
+    for (int p = 0; p < 4; p++) {
+        if (delta) delta[(size_t)g * 4 + p] = e ? sc[p] - T.start_scores[(size_t)g * 4 + p] : 0;
+        if (meta) meta[(size_t)g * 4 + p] = e ? T.start_meta[(size_t)g * 4 + p] : 0;
+    }
+    if (rebase) {
+        T.hand_index[g] = hi;
+        for (int p = 0; p < 4; p++) T.start_scores[(size_t)g * 4 + p] = sc[p];
+        T.start_meta[(size_t)g * 4 + 0] = S.round_wind; T.start_meta[(size_t)g * 4 + 1] = S.oya;
+        T.start_meta[(size_t)g * 4 + 2] = S.honba; T.start_meta[(size_t)g * 4 + 3] = (int32_t)S.riichi_sticks;
+    }
+    T.was_done[g] = done ? 1 : 0;
+}
+static int round_track_impl(rmj_env* h, int baseline, uint8_t* d_ended, int32_t* d_delta, int32_t* d_meta, uint8_t* d_kyoku_idx);
+
+// ---- bulk drain of the event rings ----------------------------------------------------------
+// RiichiEnv.mjai_log / per-seat logs of EVERY game (riichienv-python/src/env.rs:729-739, state/mod.rs:2094-2148): the records each
+// game wrote since the caller's cursor, gathered on the device into one dense buffer (two-level scan of the counts, one wave per
+// game copies its window of the ring) and brought down with one copy.  A game whose ring was lapped since its cursor lost its oldest
+// records: the loss is counted per game (RmjEventViews.lost, cumulative) and the window starts at the oldest record still there.
+__global__ __launch_bounds__(LC_BLOCK) void k_ev_count(const GState* __restrict__ core, uint32_t n, uint32_t ring, const uint32_t* __restrict__ cursor,
+                                                       uint32_t* __restrict__ first, uint32_t* __restrict__ pre, uint32_t* __restrict__ blk, uint32_t* __restrict__ lost, int commit) {
+    __shared__ uint32_t sc[LC_BLOCK];
+    const uint32_t g = blockIdx.x * LC_BLOCK + threadIdx.x;
+    uint32_t c = 0;
+    if (g < n) {
+        const uint32_t total = core[g].ev_count, cur = cursor[g] < total ? cursor[g] : total;
+        const uint32_t lo = (total - cur > ring) ? total - ring : cur;
+        if (commit && lo != cur) lost[g] += lo - cur;
+        first[g] = lo;
+        c = total - lo;
+    }
+    sc[threadIdx.x] = c;
+    __syncthreads();
+    for (int off = 1; off < LC_BLOCK; off <<= 1) {
+        uint32_t a = 0;
+        if ((int)threadIdx.x >= off) a = sc[threadIdx.x - off];
+        __syncthreads();
+        sc[threadIdx.x] += a;
+        __syncthreads();
+    }
+    if (g < n) pre[g] = sc[threadIdx.x] - c;
+    if (threadIdx.x == LC_BLOCK - 1) blk[blockIdx.x] = sc[threadIdx.x];
+}
+__global__ void k_ev_scan(uint32_t* blk, uint32_t blocks, uint32_t* total) {
+    if (blockIdx.x || threadIdx.x) return;
+    uint32_t r = 0;
+    for (uint32_t b = 0; b < blocks; b++) { const uint32_t c = blk[b]; blk[b] = r; r += c; }
+    total[0] = r;
+}
+// one wave per game: lane = (record, half) - 16 bytes per lane, 32 records per pass
+__global__ __launch_bounds__(256) void k_ev_gather(const GState* __restrict__ core, const RmjEvent* __restrict__ events, uint32_t n, uint32_t ring,
+                                                   const uint32_t* __restrict__ first, const uint32_t* __restrict__ pre, const uint32_t* __restrict__ blk,
+                                                   uint32_t cap, RmjEvent* __restrict__ out, uint32_t* __restrict__ offs, uint32_t* __restrict__ cursor) {
+    const uint32_t g = blockIdx.x * 4u + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (g >= n) return;
+    const uint32_t total = core[g].ev_count, lo = first[g], base = blk[g / LC_BLOCK] + pre[g];
+    const uint4* src = reinterpret_cast<const uint4*>(events + (size_t)g * ring);
+    uint4* dst = reinterpret_cast<uint4*>(out);
+    for (uint32_t i = lo + (uint32_t)(lane >> 1); i < total; i += 32u) {
+        const uint32_t o = base + (i - lo);
+        if (o < cap) dst[2 * (size_t)o + (lane & 1)] = src[2 * (size_t)(i & (ring - 1u)) + (lane & 1)];
+    }
+    if (lane == 0) {
+        offs[g] = base;
+        if (g == n - 1u) offs[n] = base + (total - lo);
+        cursor[g] = total;
+    }
+}
+// the device part of a drain: cursor (host, in / out) -> the handle's scratch holds [cursor | first | pre | blk | total | offsets | records]
+struct DrainPlan { uint32_t *d_cur, *d_first, *d_pre, *d_blk, *d_tot, *d_off; RmjEvent* d_ev; uint32_t cap; };
+static int drain_device(rmj_env* h, const uint32_t* cursor, uint32_t cap_events, DrainPlan* P, uint32_t* n_events, int commit) {
+    const uint32_t n = h->cfg.n_games, blocks = (n + LC_BLOCK - 1) / LC_BLOCK;
+    if (!h->d_ev_lost) {
+        HIPCHK(hipMalloc(&h->d_ev_lost, (size_t)n * 4));
+        HIPCHK(hipMemsetAsync(h->d_ev_lost, 0, (size_t)n * 4, h->stream));
+    }
+    const size_t o_first = (size_t)n * 4, o_pre = o_first + (size_t)n * 4, o_blk = o_pre + (size_t)n * 4, o_tot = o_blk + (size_t)blocks * 4;
+    const size_t o_off = o_tot + 16, o_ev = (o_off + ((size_t)n + 1) * 4 + 31) & ~(size_t)31;
+    // the records: a first pass sizes them (the scan total), the buffer is sized by the caller's cap or, when it passes 0, by the total
+    void* sp;
+    int rc = scratch_for(h, o_ev + (size_t)cap_events * sizeof(RmjEvent), &sp);
+    if (rc) return rc;
+    uint8_t* base = (uint8_t*)sp;
+    P->d_cur = (uint32_t*)base; P->d_first = (uint32_t*)(base + o_first); P->d_pre = (uint32_t*)(base + o_pre); P->d_blk = (uint32_t*)(base + o_blk);
+    P->d_tot = (uint32_t*)(base + o_tot); P->d_off = (uint32_t*)(base + o_off); P->d_ev = (RmjEvent*)(base + o_ev); P->cap = cap_events;
+    HIPCHK(hipMemcpyAsync(P->d_cur, cursor, (size_t)n * 4, hipMemcpyHostToDevice, h->stream));
+    hipLaunchKernelGGL(k_ev_count, dim3(blocks), dim3(LC_BLOCK), 0, h->stream, (const GState*)h->d.core, n, h->ring, (const uint32_t*)P->d_cur, P->d_first, P->d_pre, P->d_blk, h->d_ev_lost, commit);
+    hipLaunchKernelGGL(k_ev_scan, dim3(1), dim3(64), 0, h->stream, P->d_blk, blocks, P->d_tot);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(n_events, P->d_tot, 4, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    return RMJ_OK;
+}
+static void drain_gather(rmj_env* h, const DrainPlan& P) {
+    const uint32_t n = h->cfg.n_games;
+    hipLaunchKernelGGL(k_ev_gather, dim3((n + 3u) / 4u), dim3(256), 0, h->stream, (const GState*)h->d.core, (const RmjEvent*)h->d.events, n, h->ring,
+                       (const uint32_t*)P.d_first, (const uint32_t*)P.d_pre, (const uint32_t*)P.d_blk, P.cap, P.d_ev, P.d_off, P.d_cur);
+}
+static int pin_for(rmj_env* h, size_t bytes) {
+    if (bytes > h->pin_bytes) {
+        if (h->h_pin) hipHostFree(h->h_pin);
+        h->h_pin = nullptr; h->pin_bytes = 0;
+        HIPCHK(hipHostMalloc(&h->h_pin, bytes, hipHostMallocDefault));
+        h->pin_bytes = bytes;
+    }
+    return RMJ_OK;
+}
+int rmj_drain_events(rmj_handle h, uint32_t* cursor, RmjEvent* out, uint32_t cap_events, uint32_t* offsets, uint32_t* n_events) {
+    if (!h || !cursor || !offsets || !n_events || (!out && cap_events)) return fail(RMJ_ERR_ARG, "null argument");
+    HIPCHK(hipSetDevice(h->cfg.device));
+    const uint32_t n = h->cfg.n_games;
+    DrainPlan P;
+    int rc = drain_device(h, cursor, cap_events, &P, n_events, 0);
+    if (rc) return rc;
+    if (*n_events > cap_events) return fail(RMJ_ERR_RANGE, "rmj_drain_events: more records than cap_events (n_events holds the number; nothing was drained)");
+    rc = drain_device(h, cursor, cap_events, &P, n_events, 1);   // (nothing ran in between: same counts; this pass books the losses)
+    if (rc) return rc;
+    drain_gather(h, P);
+    HIPCHK(hipGetLastError());
+    rc = pin_for(h, ((size_t)n * 2 + 1) * 4 + (size_t)*n_events * sizeof(RmjEvent));
+    if (rc) return rc;
+    uint8_t* pin = (uint8_t*)h->h_pin;
+    HIPCHK(hipMemcpyAsync(pin, P.d_off, ((size_t)n + 1) * 4, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipMemcpyAsync(pin + ((size_t)n + 1) * 4, P.d_cur, (size_t)n * 4, hipMemcpyDeviceToHost, h->stream));
+    if (*n_events) HIPCHK(hipMemcpyAsync(out, P.d_ev, (size_t)*n_events * sizeof(RmjEvent), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    memcpy(offsets, pin, ((size_t)n + 1) * 4);
+    memcpy(cursor, pin + ((size_t)n + 1) * 4, (size_t)n * 4);
+    return RMJ_OK;
+}
+// drain + format in one call: the records go to pinned staging owned by the handle and are formatted from there by a pool of host
+// threads (one log per game, events separated by '\n').  ms (optional, [3]): device gather, copy to the host, formatting.
+int rmj_drain_format(rmj_handle h, uint32_t* cursor, int seat, char* buf, uint64_t cap, uint64_t* text_offsets, uint64_t* needed, uint32_t* n_events,
+                     double* ms) {
+    if (!h || !cursor || !text_offsets || !needed || !n_events) return fail(RMJ_ERR_ARG, "null argument");
+    HIPCHK(hipSetDevice(h->cfg.device));
+    const uint32_t n = h->cfg.n_games;
+    std::vector<uint32_t> cur0(cursor, cursor + n);
+    DrainPlan P;
+    auto now = [] { return std::chrono::steady_clock::now(); };
+    auto t0 = now();
+    // size pass with no record buffer, then the gather into a buffer of exactly that size
+    int rc = drain_device(h, cursor, 0, &P, n_events, 0);
+    if (rc) return rc;
+    rc = drain_device(h, cursor, *n_events, &P, n_events, (buf != nullptr) ? 1 : 0);
+    if (rc) return rc;
+    drain_gather(h, P);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(h->stream));
+    auto t1 = now();
+    const size_t o_ev = (((size_t)n * 2 + 1) * 4 + 31) & ~(size_t)31;
+    rc = pin_for(h, o_ev + (size_t)*n_events * sizeof(RmjEvent));
+    if (rc) return rc;
+    uint8_t* pin = (uint8_t*)h->h_pin;
+    HIPCHK(hipMemcpyAsync(pin, P.d_off, ((size_t)n + 1) * 4, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipMemcpyAsync(pin + ((size_t)n + 1) * 4, P.d_cur, (size_t)n * 4, hipMemcpyDeviceToHost, h->stream));
+    if (*n_events) HIPCHK(hipMemcpyAsync(pin + o_ev, P.d_ev, (size_t)*n_events * sizeof(RmjEvent), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    auto t2 = now();
+    *needed = rmjh::format_events((const RmjEvent*)(pin + o_ev), (const uint32_t*)pin, n, seat, buf, cap, text_offsets, 0);
+    auto t3 = now();
+    if (ms) {
+        ms[0] = std::chrono::duration<double, std::milli>(t1 - t0).count();
+        ms[1] = std::chrono::duration<double, std::milli>(t2 - t1).count();
+        ms[2] = std::chrono::duration<double, std::milli>(t3 - t2).count();
+    }
+    if (!buf || *needed > cap) {   // nothing was handed over: the caller's cursors stand
+        memcpy(cursor, cur0.data(), (size_t)n * 4);
+        return fail(RMJ_ERR_RANGE, "rmj_drain_format: text buffer too small (needed holds the size; cursors unchanged)");
+    }
+    memcpy(cursor, pin + ((size_t)n + 1) * 4, (size_t)n * 4);
+    return RMJ_OK;
+}
+static int round_track_impl(rmj_env* h, int baseline, uint8_t* d_ended, int32_t* d_delta, int32_t* d_meta, uint8_t* d_kyoku_idx) {
+    const uint32_t n = h->cfg.n_games;
+    if (!h->d_track) {
+        HIPCHK(hipMalloc(&h->d_track, (size_t)n * (4 + 16 + 16 + 4)));
+        baseline = 1;
+    }
+    RoundTrack T;
+    uint8_t* b = (uint8_t*)h->d_track;
+    T.hand_index = (uint32_t*)b; T.start_scores = (int32_t*)(b + (size_t)n * 4); T.start_meta = (int32_t*)(b + (size_t)n * 20); T.was_done = b + (size_t)n * 36;
+    hipLaunchKernelGGL(k_round_track, dim3((n + 255u) / 256u), dim3(256), 0, h->stream, (const GState*)h->d.core, n, T, baseline, d_ended, d_delta, d_meta, d_kyoku_idx);
+    HIPCHK(hipGetLastError());
+    return RMJ_OK;
+}
+int rmj_round_track_device(rmj_handle h, uint8_t* d_ended, int32_t* d_delta, int32_t* d_meta, uint8_t* d_kyoku_idx) {
+    if (!h) return fail(RMJ_ERR_ARG, "null handle");
+    HIPCHK(hipSetDevice(h->cfg.device));
+    return round_track_impl(h, 0, d_ended, d_delta, d_meta, d_kyoku_idx);
+}
+int rmj_round_track_reset(rmj_handle h) {
+    if (!h) return fail(RMJ_ERR_ARG, "null handle");
+    HIPCHK(hipSetDevice(h->cfg.device));
+    return round_track_impl(h, 1, nullptr, nullptr, nullptr, nullptr);
+}
+int rmj_get_events_lost(rmj_handle h, uint32_t* lost) {
+    if (!h || !lost) return fail(RMJ_ERR_ARG, "null argument");
+    HIPCHK(hipSetDevice(h->cfg.device));
+    if (!h->d_ev_lost) { memset(lost, 0, (size_t)h->cfg.n_games * 4); return RMJ_OK; }
+    HIPCHK(hipStreamSynchronize(h->stream));
+    HIPCHK(hipMemcpy(lost, h->d_ev_lost, (size_t)h->cfg.n_games * 4, hipMemcpyDeviceToHost));
+    return RMJ_OK;
+}
+int rmj_event_views(rmj_handle h, RmjEventViews* out) {
+    if (!h || !out) return fail(RMJ_ERR_ARG, "null argument");
+    HIPCHK(hipSetDevice(h->cfg.device));
+    if (!h->d_ev_lost) {
+        HIPCHK(hipMalloc(&h->d_ev_lost, (size_t)h->cfg.n_games * 4));
+        HIPCHK(hipMemsetAsync(h->d_ev_lost, 0, (size_t)h->cfg.n_games * 4, h->stream));
+    }
+    out->n_games = h->cfg.n_games;
+    out->ring = h->ring;
+    out->events = h->d.events;
+    out->ev_count = &h->d.core[0].ev_count;
+    out->ev_count_stride = (uint32_t)sizeof(GState);
+    out->lost = h->d_ev_lost;
+    return RMJ_OK;
 }
 
 // ---- batched hand math ---------------------------------------------------------------------

@@ -169,6 +169,55 @@ class TorchVecEnv:
         vecenv._chk(self.env.L.rmj_step_ids_device(self.env.h, C.c_void_p(ids.data_ptr()), int(auto_reset)))
         self.sync()
 
+    # ---- rewards (rmj_round_track_device): what riichienv-ml's PPO worker derives between steps on the host
+    def round_track(self):
+        """Call once after every step: (ended [n] u8, delta [n, 4] i32, meta [n, 4] i32, kyoku_idx [n] u8) - ended 1: a round ended in
+        the last step and the next one was dealt, 2: the round and the game ended; delta = the seats' score change over that round,
+        meta = (round_wind, oya, honba, riichi_sticks) when it was dealt (the GRP features chang / ju / ben / liqibang of
+        trainers/_ppo_worker.py:100-116).  The first call only takes the baseline.  Resident tensors, rewritten by every call."""
+        t = self.torch
+        if not hasattr(self, "_rt"):
+            self._rt = (t.zeros((self.n,), dtype=t.uint8, device=self.device), t.zeros((self.n, 4), dtype=t.int32, device=self.device),
+                        t.zeros((self.n, 4), dtype=t.int32, device=self.device), t.zeros((self.n,), dtype=t.uint8, device=self.device))
+            if not self.shared:
+                t.cuda.current_stream(self.device).synchronize()
+        e, d, m, k = self._rt
+        vecenv._chk(self.env.L.rmj_round_track_device(self.env.h, C.c_void_p(e.data_ptr()), C.c_void_p(d.data_ptr()), C.c_void_p(m.data_ptr()),
+                                                     C.c_void_p(k.data_ptr())))
+        self.sync()
+        return self._rt
+
+    RANK_REWARDS_4P = (10.0, 4.0, -4.0, -10.0)   # trainers/_ppo_worker.py:283-291
+    RANK_REWARDS_3P = (10.0, 0.0, -10.0)
+
+    def step_rl(self, action_ids, auto_reset=True, kyoku_scale=1.0 / 1000.0, rank_rewards=None, with_obs=True):
+        """One Gym-style transition of every game: (obs, reward, terminated, info).
+        reward [n, 4] f32 per seat = kyoku_scale x the seat's score change over a round, paid in the step that ends the round
+        (the worker's reward at a kyoku boundary, _ppo_worker.py:240-266, with the identity in place of its learned GRP model: the
+        model's inputs are in info), plus the rank reward of _ppo_worker.py:283-291 in the step that ends the game (rank_rewards:
+        a per-rank tuple, default 10 / 4 / -4 / -10; () for none).  terminated [n] bool: the game ended in this step (with auto_reset
+        it restarts at the next one).  info: ended, delta, meta, kyoku_idx (round_track), scores, ranks of the games that ended.
+        obs: the resident feature tensor (step_obs) - rows of the seats that act next; None with with_obs=False (extended encoders:
+        call obs() yourself)."""
+        t = self.torch
+        if not hasattr(self, "_rt"):
+            self.round_track()                       # baseline before the first transition
+        if with_obs and not self.extended:
+            obs = self.step_obs(action_ids, auto_reset=auto_reset)
+        else:
+            self.step(action_ids, auto_reset=auto_reset)
+            obs = None
+        ended, delta, meta, kidx = self.round_track()
+        reward = delta.to(t.float32) * float(kyoku_scale)
+        terminated = ended == 2
+        rr = rank_rewards if rank_rewards is not None else (self.RANK_REWARDS_3P if self.sanma else self.RANK_REWARDS_4P)
+        ranks = self.ranks()
+        if len(rr):
+            table = t.tensor([0.0] + list(rr) + [0.0] * (4 - len(rr)), dtype=t.float32, device=self.device)
+            reward = reward + t.where(terminated[:, None], table[ranks], t.zeros_like(reward))
+        info = {"ended": ended, "delta": delta, "meta": meta, "kyoku_idx": kidx, "scores": self.scores(), "ranks": ranks}
+        return obs, reward, terminated, info
+
     def step_obs(self, action_ids, auto_reset=True):
         """step(action_ids) and obs(only_active=True) as ONE launch (rmj_step_ids_encode_device): returns the resident tensor
         [n, 4, 74, W] whose rows of the seats that are to act next have just been written.  Base encoding only."""
@@ -219,23 +268,31 @@ class TorchVecEnv:
         # kernel must have read them before they are released (shared stream: torch's stream orders it)
         self.sync()
 
-    def sample_ids(self, logits=None, seed=0, index=None):
+    def sample_ids(self, logits=None, seed=0, index=None, count=None):
         """One id per acting seat drawn from softmax(logits) over the seat's legal ids, -1 elsewhere, by ONE kernel of the
         library (rmj_sample_ids_device: Gumbel-max on the resident mask slab) - no torch indexing / multinomial in the loop.
         logits: float32 [n, 4, A'] with A' >= 82 (60 in 3P) on this device, or None for the uniform policy; with `index`
         (the second result of obs_compact(): game * 4 + seat per row) logits are the compact rows [k, A'] a policy computed
         from the compact observation batch, scattered here into the [n, 4, A'] layout (rows of seats that do not act are never
-        read by the sampler)."""
+        read by the sampler).  `count`: the device count tensor of obs_compact(sync_count=False) - rows of `index` behind it hold stale
+        (game, seat) values that may repeat live ones, so they are sent to a sink row instead of racing with the live rows; without
+        `count` every row of `index` must be live (the sync_count=True form)."""
         t = self.torch
         if not hasattr(self, "_ids"):
             self._ids = t.full((self.n, 4), -1, dtype=t.int32, device=self.device)
         if logits is not None and index is not None:
             a = int(logits.shape[-1])
             if getattr(self, "_full_logits", None) is None or self._full_logits.shape[-1] != a:
-                self._full_logits = t.zeros((self.n * 4, a), dtype=t.float32, device=self.device)
+                self._full_logits = t.zeros((self.n * 4 + 1, a), dtype=t.float32, device=self.device)   # (+ the sink row)
             k = int(index.shape[0])
-            self._full_logits[index.to(t.int64)] = logits.reshape(-1, a)[:k].to(t.float32)
-            logits = self._full_logits.view(self.n, 4, a)
+            dst = index.to(t.int64)
+            if count is not None:
+                live = t.arange(k, device=self.device) < count.to(t.int64).reshape(-1)[0]
+                dst = t.where(live, dst, t.full_like(dst, self.n * 4))
+            elif k > self.n * 4:
+                raise ValueError("sample_ids: more index rows than (game, seat) pairs - pass the device count of obs_compact(sync_count=False)")
+            self._full_logits[dst] = logits.reshape(-1, a)[:k].to(t.float32)
+            logits = self._full_logits[: self.n * 4].view(self.n, 4, a)
         ptr, stride = None, 0
         if logits is not None:
             assert logits.dtype == t.float32 and logits.is_contiguous() and tuple(logits.shape[:2]) == (self.n, 4)
@@ -321,3 +378,90 @@ class ShardedTorchVecEnv:
 
         self.synchronize()
         return np.concatenate([e.env.step_counts() for e in self.shards])
+
+
+class GymVectorAdapter:
+    """A Gymnasium-VectorEnv-shaped face of TorchVecEnv for single-agent learners (the hero-versus-opponents set-up of
+    riichienv-ml's PPO worker, trainers/_ppo_worker.py:113-466): env i exposes ONE seat, hero[i]; the other seats are played by
+    `opponent(env, active_mask) -> ids [n, 4]` (default: the library's uniform sampler over the legal ids).  reset() / step(actions)
+    return what gymnasium.vector.VectorEnv returns - (obs, info) and (obs, reward, terminated, truncated, info) - with torch tensors
+    on the device; gymnasium itself is not needed (and not installed in this image).
+
+    step(actions [n] int): the hero's action id for every env, then the environment advances - opponents' turns, claims, round ends -
+    until the hero is to act again in every env or its game is over.  Envs that reach the hero's turn early wait: they send no action
+    (-1) and stay where they are while the others catch up.  reward [n] = the hero's share of step_rl's rewards summed over the inner
+    steps; terminated [n]: the game ended (it restarts with the next step: autoreset like gymnasium's NEXT_STEP mode).
+    observation: {"features": [n, 74, W] f32 (the hero's Observation.encode()), "mask": [n, A] bool}."""
+
+    def __init__(self, env: TorchVecEnv, hero=0, opponent=None, max_inner=256):
+        self.env, self.t = env, env.torch
+        t = self.t
+        self.num_envs = env.n
+        self.hero = (t.full((env.n,), int(hero), dtype=t.int64, device=env.device) if isinstance(hero, int)
+                     else hero.to(device=env.device, dtype=t.int64))
+        self.opponent = opponent
+        self.max_inner = int(max_inner)
+        self.action_space_n = abi.ACTION_SPACE_3P if env.sanma else abi.ACTION_SPACE_4P
+        self.single_observation_shape = {"features": (74, env.width), "mask": (self.action_space_n,)}
+        self._seat = t.arange(4, device=env.device)[None, :]
+        self._seed = 0
+
+    def _hero_turn(self):
+        return self.env.active().gather(1, self.hero[:, None])[:, 0]
+
+    def _obs(self):
+        e, t = self.env, self.t
+        feats = e.obs(only_active=True)
+        idx = self.hero[:, None, None, None].expand(-1, 1, feats.shape[2], feats.shape[3])
+        mask = e.mask.gather(1, self.hero[:, None, None].expand(-1, 1, e.mask.shape[2]))[:, 0, : self.action_space_n] != 0
+        return {"features": feats.gather(1, idx)[:, 0], "mask": mask & self._hero_turn()[:, None]}
+
+    def _advance(self, hero_ids, reward, terminated):
+        """inner steps until every env is at its hero's decision (or over); hero_ids [n]: the hero's id for the FIRST inner step, -1 = none"""
+        e, t = self.env, self.t
+        first = True
+        for _ in range(self.max_inner):
+            act = e.active()
+            hero_now = act.gather(1, self.hero[:, None])[:, 0]
+            over = e.done() | terminated
+            wait = hero_now & ((hero_ids < 0) if first else t.ones_like(hero_now))   # at the hero's decision with nothing to send: stay
+            if bool((wait | over).all()):
+                break
+            self._seed += 1
+            ids = (self.opponent(e, act) if self.opponent is not None else e.sample_ids(None, seed=self._seed)).clone().to(t.int32)
+            if first:
+                ids = t.where(self._seat == self.hero[:, None], hero_ids.to(t.int32)[:, None].expand(-1, 4), ids)
+            ids = t.where((wait | over)[:, None], t.full_like(ids, -1), ids)
+            _o, r, term, _info = e.step_rl(ids, auto_reset=False, with_obs=False)
+            reward += r.gather(1, self.hero[:, None])[:, 0]
+            terminated |= term
+            first = False
+        return reward, terminated
+
+    def reset(self, seed=None):
+        e, t = self.env, self.t
+        self._seed = int(seed or 0) * 1000003
+        e.env.reset()
+        if hasattr(e, "_rt"):
+            vecenv._chk(e.env.L.rmj_round_track_reset(e.env.h))
+        else:
+            e.round_track()
+        self._terminated = t.zeros((e.n,), dtype=t.bool, device=e.device)
+        self._advance(t.full((e.n,), -1, dtype=t.int64, device=e.device), t.zeros((e.n,), dtype=t.float32, device=e.device),
+                      t.zeros((e.n,), dtype=t.bool, device=e.device))
+        return self._obs(), {}
+
+    def step(self, actions):
+        e, t = self.env, self.t
+        if bool(self._terminated.any()):   # games that ended in the previous step restart now (their action is ignored)
+            e.env.reset(select=self._terminated.to(t.uint8).cpu().numpy())
+            vecenv._chk(e.env.L.rmj_round_track_device(e.env.h, None, None, None, None))   # re-opens the restarted games silently
+            lead = self._terminated
+            self._advance(t.full((e.n,), -1, dtype=t.int64, device=e.device), t.zeros((e.n,), dtype=t.float32, device=e.device), ~lead)
+        acts = actions.to(device=e.device, dtype=t.int64)
+        ids = t.where(self._terminated | ~self._hero_turn(), t.full_like(acts, -1), acts)
+        reward = t.zeros((e.n,), dtype=t.float32, device=e.device)
+        reward, terminated = self._advance(ids, reward, t.zeros((e.n,), dtype=t.bool, device=e.device))
+        self._terminated = terminated
+        info = {"scores": e.scores(), "ranks": e.ranks()}
+        return self._obs(), reward, terminated, t.zeros_like(terminated), info

@@ -33,6 +33,7 @@ EXPORTS = [
     "rmj_encode_seq_delta", "rmj_encode_seq_delta_device", "rmj_step_random_encode",
     "rmj_encode_compact_device", "rmj_step_random_encode_compact", "rmj_bench_encode_compact",
     "rmj_get_win_results",
+    "rmj_drain_events", "rmj_format_events", "rmj_drain_format", "rmj_event_views", "rmj_round_track_device", "rmj_round_track_reset", "rmj_get_events_lost",
 ]
 
 
@@ -141,6 +142,13 @@ def load_lib():
     L.rmj_get_win_results.argtypes = [vp, C.c_uint32, C.POINTER(abi.WinResult), C.POINTER(C.c_uint8)]
     L.rmj_encode_seq_delta.argtypes = [vp, C.c_int, C.POINTER(abi.SeqBuffers)]          # same field layout as RmjSeqBuffers
     L.rmj_encode_seq_delta_device.argtypes = [vp, C.c_int, C.POINTER(abi.SeqBuffers)]
+    L.rmj_drain_events.argtypes = [vp, vp, vp, C.c_uint32, vp, C.POINTER(C.c_uint32)]
+    L.rmj_format_events.argtypes = [vp, vp, C.c_uint32, C.c_int, vp, C.c_uint64, vp, C.POINTER(C.c_uint64)]
+    L.rmj_drain_format.argtypes = [vp, vp, C.c_int, vp, C.c_uint64, vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint32), vp]
+    L.rmj_event_views.argtypes = [vp, C.POINTER(abi.EventViews)]
+    L.rmj_get_events_lost.argtypes = [vp, vp]
+    L.rmj_round_track_device.argtypes = [vp, vp, vp, vp, vp]
+    L.rmj_round_track_reset.argtypes = [vp]
     _LIB = L
     return L
 
@@ -429,6 +437,68 @@ class VecRiichiEnv:
                 raise RmjError(f"cannot format event {i} of game {g} (type {buf[i].type})")
             out.append(s.value.decode())
             i += used
+        return out
+
+    # ---- the logs of all games at once (rmj_drain_events / rmj_format_events / rmj_drain_format)
+    def drain_events(self, cursor=None, cap_events=None):
+        """The records every game wrote since `cursor` ([n] u32 record counts, updated in place; None: the env's own running cursor,
+        which starts at 0): (events [total] structured array of 32-byte records, offsets [n + 1])."""
+        cur = self._log_cursor() if cursor is None else cursor
+        if cap_events is None:
+            cap_events = int((self.event_counts().astype(np.int64) - cur.astype(np.int64)).clip(0, None).sum())
+        ev = np.zeros((max(cap_events, 1), C.sizeof(abi.Event)), np.uint8)
+        offs = np.zeros(self.n + 1, np.uint32)
+        n_ev = C.c_uint32()
+        _chk(self.L.rmj_drain_events(self.h, cur.ctypes.data, ev.ctypes.data, int(cap_events), offs.ctypes.data, C.byref(n_ev)))
+        return ev[: n_ev.value], offs
+
+    def format_events(self, events, offsets, seat=-1):
+        """MJAI strings of a drained buffer: a list (one entry per game) of lists of event strings."""
+        n = len(offsets) - 1
+        toffs = np.zeros(n + 1, np.uint64)
+        need = C.c_uint64()
+        ev = np.ascontiguousarray(events)
+        self.L.rmj_format_events(ev.ctypes.data, offsets.ctypes.data, n, int(seat), None, 0, toffs.ctypes.data, C.byref(need))
+        buf = np.zeros(max(int(need.value), 1), np.uint8)
+        _chk(self.L.rmj_format_events(ev.ctypes.data, offsets.ctypes.data, n, int(seat), buf.ctypes.data, int(need.value), toffs.ctypes.data, C.byref(need)))
+        return self._split_logs(buf, toffs)
+
+    @staticmethod
+    def _split_logs(buf, toffs):
+        raw = buf.tobytes()
+        return [raw[int(toffs[g]): int(toffs[g + 1])].decode().split("\n")[:-1] for g in range(len(toffs) - 1)]
+
+    def _log_cursor(self):
+        if getattr(self, "_cursor", None) is None:
+            self._cursor = np.zeros(self.n, np.uint32)
+        return self._cursor
+
+    def drain_logs(self, seat=-1, cursor=None, timings=None, raw=False):
+        """The MJAI strings every game logged since the last drain (RiichiEnv.mjai_log of every env, env.rs:729-739; seat >= 0: the
+        seat's masked log) as a list of lists of strings - drained on the device, one copy down, formatted by host threads in C.
+        `cursor`: explicit [n] u32 record counts instead of the env's running cursor.  raw=True: (bytes buffer, text offsets [n + 1])
+        without splitting (one log = its events, each followed by a newline).  timings: a list that receives [gather, copy, format] ms."""
+        cur = self._log_cursor() if cursor is None else cursor
+        toffs = np.zeros(self.n + 1, np.uint64)
+        need, n_ev = C.c_uint64(), C.c_uint32()
+        ms = (C.c_double * 3)()
+        # size pass (buf = NULL leaves the cursors alone), then the real one
+        self.L.rmj_drain_format(self.h, cur.ctypes.data, int(seat), None, 0, toffs.ctypes.data, C.byref(need), C.byref(n_ev), None)
+        buf = np.zeros(max(int(need.value), 1), np.uint8)
+        _chk(self.L.rmj_drain_format(self.h, cur.ctypes.data, int(seat), buf.ctypes.data, int(need.value), toffs.ctypes.data, C.byref(need), C.byref(n_ev), ms))
+        if timings is not None:
+            timings[:] = [ms[0], ms[1], ms[2]]
+        self.last_drain_events = n_ev.value
+        return (buf, toffs) if raw else self._split_logs(buf, toffs)
+
+    def mjai_logs(self, seat=-1):
+        """The whole logs of all games still in their rings (cursor 0 for every game; the env's running cursor is not moved)."""
+        return self.drain_logs(seat=seat, cursor=np.zeros(self.n, np.uint32))
+
+    def events_lost(self):
+        """[n] records each game's ring lost to late drains so far (RmjEventViews.lost)"""
+        out = np.zeros(self.n, np.uint32)
+        _chk(self.L.rmj_get_events_lost(self.h, out.ctypes.data))
         return out
 
     def set_encode_row_stride(self, floats=0):

@@ -1,0 +1,93 @@
+"""GPU: the bulk drain of the MJAI event rings (rmj_drain_events / rmj_drain_format: RiichiEnv.mjai_log of every env at once,
+riichienv-python/src/env.rs:729-739, state/mod.rs:2094-2148) against the per-game reader and the oracle's logs."""
+import numpy as np
+import pytest
+
+from riichienv_amd import vecenv
+from riichienv_amd.shard import game_seed
+
+pytestmark = pytest.mark.gpu
+
+
+def _oracle_logs(mode, seed, pseed, games, steps):
+    from oracle import oracle
+
+    out = {}
+    for g in games:
+        o = oracle.Game(game_mode=mode, seed=game_seed(seed, g))
+        o.reset()
+        for _ in range(steps):
+            if o.status()[2]:
+                break
+            o.step(o.random_actions(pseed, g))
+        out[g] = o
+    return out
+
+
+@pytest.mark.parametrize("mode", [2, 5])
+def test_drained_logs_equal_the_per_game_logs_and_the_oracle(mode):
+    n, seed, pseed, steps = 512, 31 + mode, 77, 260
+    env = vecenv.VecRiichiEnv(n, game_mode=mode, seed=seed, event_ring=2048)
+    env.reset()
+    env.step_random(pseed, steps, auto_reset=False)
+    logs = env.mjai_logs()
+    assert len(logs) == n
+    for g in (0, 1, 17, 255, 256, n - 1):
+        assert logs[g] == env.mjai_log(g), g
+    for g, o in _oracle_logs(mode, seed, pseed, (0, 3, 130, n - 1), steps).items():
+        assert logs[g] == o.log(), g
+    # the per-seat view (masked tsumo / tehais)
+    seat1 = env.mjai_logs(seat=1)
+    for g in (0, 99, n - 1):
+        assert seat1[g] == env.mjai_log(g, seat=1), g
+    assert int(env.events_lost().sum()) == 0
+    env.close()
+
+
+def test_incremental_drains_concatenate_to_the_whole_log():
+    n, pseed = 300, 5
+    env = vecenv.VecRiichiEnv(n, game_mode=2, seed=9, event_ring=4096)
+    env.reset()
+    parts = [[] for _ in range(n)]
+    for k in (1, 40, 7, 150):
+        env.step_random(pseed, k, auto_reset=False)
+        t = []
+        for g, chunk in enumerate(env.drain_logs(timings=t)):
+            parts[g] += chunk
+        assert len(t) == 3
+    whole = env.mjai_logs()
+    assert parts == whole
+    assert all(len(x) == 0 for x in env.drain_logs())          # nothing new
+    # the binary form: records + offsets, formatted separately
+    ev, offs = env.drain_events(cursor=np.zeros(n, np.uint32))
+    assert offs[0] == 0 and offs[-1] == len(ev) == int(env.event_counts().sum())
+    assert env.format_events(ev, offs) == whole
+    env.close()
+
+
+def test_a_lapped_ring_is_counted_and_the_window_still_formats():
+    n = 128
+    env = vecenv.VecRiichiEnv(n, game_mode=2, seed=3, event_ring=64)
+    env.reset()
+    env.step_random(11, 400, auto_reset=False)
+    cnt = env.event_counts().astype(np.int64)
+    assert (cnt > 64).any()
+    cur = np.zeros(n, np.uint32)
+    logs = env.drain_logs(cursor=cur)
+    assert (cur == cnt).all()
+    lost = env.events_lost().astype(np.int64)
+    assert (lost == np.maximum(cnt - 64, 0)).all()
+    for g in range(0, n, 13):
+        tail = env.mjai_log(g, first=max(0, int(cnt[g]) - 64)) if cnt[g] <= 64 else None
+        if tail is not None:
+            assert logs[g] == tail
+        else:
+            assert 0 < len(logs[g]) <= 64 and all(s.startswith("{") and s.endswith("}") for s in logs[g])
+    # too small a record buffer: nothing is drained, the number is reported
+    import ctypes as C
+    cur2 = np.zeros(n, np.uint32)
+    offs = np.zeros(n + 1, np.uint32)
+    n_ev = C.c_uint32()
+    rc = env.L.rmj_drain_events(env.h, cur2.ctypes.data, np.zeros((1, 32), np.uint8).ctypes.data, 1, offs.ctypes.data, C.byref(n_ev))
+    assert rc != 0 and n_ev.value == int(np.minimum(cnt, 64).sum()) and (cur2 == 0).all()
+    env.close()

@@ -49,6 +49,9 @@ def parse_args(argv=None):
                     help="device policy of the rollout: the RandomAgent of BASELINE's configs, or the greedy policy that plays to win "
                          "(rmj_step_greedy: shanten-greedy discards, every win / riichi / kan / kita taken, calls at --call-rate)")
     ap.add_argument("--call-rate", type=int, default=64, help="greedy policy: pon / chi taken with probability call_rate / 256")
+    ap.add_argument("--oversubscribe", action="store_true",
+                    help="allow more ranks than GPUs: rank r works on GPU r %% visible GPUs and the ranks meet over gloo (RCCL refuses two ranks "
+                         "on one device) - exercises the world > 1 path on a 1-GPU box; never a measurement")
     ap.add_argument("--preroll", type=int, default=PREROLL,
                     help="untimed steps before the warm-up that bring every game to steady state (0: time the opening phase)")
     ap.add_argument("--padded-rows", action="store_true", help="--encode: rows padded to a multiple of 256 B instead of the dense [games][4][74][W] tensor")
@@ -84,6 +87,8 @@ def launcher_command(args, port, script=None):
         cmd.append("--encode")
     if args.padded_rows:
         cmd.append("--padded-rows")
+    if getattr(args, "oversubscribe", False):
+        cmd.append("--oversubscribe")
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC only on this pool (RCCL barrier between the ranks)
     env["MASTER_ADDR"] = "127.0.0.1"
@@ -264,7 +269,10 @@ def main(argv=None):
     from riichienv_amd import abi, shard, vecenv
 
     have = vecenv.load_lib().rmj_device_count() if torch.cuda.device_count() > 0 else 0
-    if have < world:
+    shared_gpus = args.oversubscribe and 0 < have < world
+    if shared_gpus:
+        local_rank = local_rank % have
+    if have < world and not shared_gpus:
         print(f"bench.py: {world} ranks need {world} GPUs on this node, {have} visible (the product path has no CPU fallback)",
               file=sys.stderr)
         return 3
@@ -273,7 +281,10 @@ def main(argv=None):
         import torch.distributed as dist
 
         torch.cuda.set_device(local_rank)
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        if shared_gpus:
+            dist.init_process_group(backend="gloo")
+        else:
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
 
     policy_seed = 0xC0FFEE
     sanma = args.mode >= 3
@@ -325,7 +336,7 @@ def main(argv=None):
     t1 = time.perf_counter()
     steps_local = float(env.total_steps() - before)
     full_steps = env.total_full_path() - full0
-    wall, steps_total = shard.reduce_measurement(dist, t1 - t0, steps_local, device="cuda")
+    wall, steps_total = shard.reduce_measurement(dist, t1 - t0, steps_local, device="cpu" if shared_gpus else "cuda")
 
     # ---- side measurements, outside the timed region (rank 0 of a 1-GPU run only)
     extras = {}
@@ -367,6 +378,23 @@ def main(argv=None):
                                        "what": "one policy launch writing packed actions + one step launch that validates them "
                                                "against the stored legal lists (state/mod.rs:339-402), one stream"}
         env.set_rollout_streams(4)
+        # the logs of all games: a second environment with rings that hold a 300-step rollout, its whole MJAI log
+        # drained on the device, copied down once and formatted by host threads in C (rmj_drain_format)
+        lenv = vecenv.VecRiichiEnv(args.games, game_mode=args.mode, seed=0, rule_bits=abi.RULE_TENHOU, device=local_rank,
+                                   game_offset=shard.shard_offset(rank, args.games), event_ring=512)
+        lenv.reset()
+        lenv.step_random(policy_seed, 300, auto_reset=True)
+        tms = []
+        t_l0 = time.perf_counter()
+        buf_l, toffs_l = lenv.drain_logs(timings=tms, raw=True)
+        t_l1 = time.perf_counter()
+        extras["log_drain"] = {"games": args.games, "rollout_steps": 300, "events": int(lenv.last_drain_events), "text_bytes": int(toffs_l[-1]),
+                               "wall_s": t_l1 - t_l0, "gather_ms": tms[0], "copy_ms": tms[1], "format_ms": tms[2],
+                               "events_per_s": lenv.last_drain_events / max(t_l1 - t_l0, 1e-9), "lost_events": int(lenv.events_lost().sum()),
+                               "what": "rmj_drain_format: every game's MJAI log of a 300-step rollout (a size pass and the drain), "
+                                       "device gather + one pinned copy + C formatter on the host's threads"}
+        del buf_l
+        lenv.close()
         if args.steps < 1000:
             kl = 1000
             rl = env.bench_rollout(policy_seed, 0, kl)
@@ -418,7 +446,12 @@ def main(argv=None):
                        "parity": "bit-exact vs the oracle on identical walls; seed -> wall is the build's own shuffle (DESIGN.md §6)"},
             # short runs (the first ~60 steps of a game cannot end a round) are not the steady state the metric is defined on
             # steady state = every game has played through several round ends before the timed region (pre-roll + warm-up)
-            "steady_state": bool(args.preroll + args.warmup >= 300),
+            # the metric is defined over a window of >= 200 batched steps behind a warm-up that has reached round ends.  A shorter
+            # timed window (the driver's --steps 20) of games that ARE in that state is marked separately: its rate includes the launch's
+            # ramp-up and tail once per window, the steady-state figure of the same run is `long_rollout`
+            **({"oversubscribed": True, "note": "ranks share GPUs (--oversubscribe): a functional run of the world > 1 path, not a measurement"} if shared_gpus else {}),
+            "steady_state": bool(args.preroll + args.warmup >= 300 and args.steps >= STEADY_MIN),
+            "window_ok": bool(args.preroll + args.warmup >= 300),
             "preroll_steps": args.preroll,
             "full_path_frac": full_steps / max(steps_local, 1.0),
             "roofline": {"bound": "hbm", "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",

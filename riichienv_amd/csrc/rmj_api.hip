@@ -14,6 +14,7 @@
 #include <vector>
 
 #include "../../include/riichi_mi355x.h"
+#include "../../include/riichi_mi355x_bench.h"
 #include "rmj_common.hip.h"
 #include "rmj_eval4.hip.h"
 #include "rmj_encode.hip.h"

@@ -1022,8 +1022,29 @@ class ReplayBatch:
         a = Action(ActionType(t), tile, cons)
         return a.encode_3p() if self.sanma else a.encode()
 
+    def _robbed_kan_tile(self, log, k):
+        """The tile a `hora` at index k robs: the log's previous action is a kakan (chankan) or an ankan (kokushi) by the hora's
+        target - `dora` events in between do not count - else None.  The event-stream state machine sets up no claims behind a kan
+        (event_handler.rs:290-305), so this decision is not in the published lists; the reference's walker still yields it:
+        apply_log_action leaves the kan tile in last_discard (state/event_handler.rs:649-661) and the Hule arm builds a Ron on it
+        (replay/mod.rs:483-527)."""
+        ev = log[k]
+        if ev.get("actor") is None or ev.get("target") is None or int(ev["actor"]) == int(ev["target"]):
+            return None
+        j = k - 1
+        while j >= 0 and log[j].get("type") == "dora":
+            j -= 1
+        if j < 0 or int(log[j].get("actor", -1)) != int(ev["target"]):
+            return None
+        if log[j].get("type") == "kakan":
+            return abi.mjai_to_tid(log[j]["pai"], self.masked_ok)
+        if log[j].get("type") == "ankan" and log[j].get("consumed"):
+            return abi.mjai_to_tid(log[j]["consumed"][0], self.masked_ok)
+        return None
+
     def _decisions_before(self, k, legal, cnt, active, drawn):
-        """(game, seat, packed action) of every decision taken by event k of each log, given the state before it."""
+        """(game, seat, packed action) of every decision taken by event k of each log, given the state before it.  A fourth member
+        marks a decision the published lists do not hold (the Ron on a robbed kan): the walker's own list, see samples()."""
         out = []
         for g, log in enumerate(self.logs):
             if k >= len(log):
@@ -1031,6 +1052,12 @@ class ReplayBatch:
             ev = log[k]
             ty = ev.get("type")
             act_mask = int(active[g])
+            if ty == "hora" and not self._done[g] and not (act_mask >> int(ev.get("actor", 0))) & 1:
+                tile = self._robbed_kan_tile(log, k)
+                if tile is not None and not (k > 0 and log[k - 1].get("type") == "hora"):   # (the first winner only, replay/mod.rs:483-485)
+                    ron, pas = abi.pack_action(abi.RON, tile), abi.pack_action(abi.PASS)
+                    out.append((g, int(ev["actor"]), ron, [ron, pas]))
+                    continue
             if ty in _ACTOR_DECISIONS or (ty == "ryukyoku" and act_mask and cnt[g].sum() > 0):
                 seats = [int(ev["actor"])] if "actor" in ev else [s for s in range(4) if (act_mask >> s) & 1]
                 for s in seats:
@@ -1061,6 +1088,7 @@ class ReplayBatch:
         for k in range(steps):
             act, ph, done = self.env.status()
             self._phase = ph
+            self._done = done.astype(bool)
             legal, cnt = self.env.legal()
             active = np.where(done.astype(bool), 0, act)
             drawn = [None] * self.n
@@ -1074,10 +1102,18 @@ class ReplayBatch:
                 mask = self.env.mask()
                 gs = np.array([d[0] for d in dec])
                 ss = np.array([d[1] for d in dec])
+                m = mask[gs, ss][:, :nmask].copy()
+                lg = [legal[g, s, : cnt[g, s]].copy() for g, s in zip(gs, ss)]
+                for j, d in enumerate(dec):
+                    if len(d) > 3:   # the Ron on a robbed kan: what get_observation_for_replay builds (state/mod.rs:265-325) - the walker's
+                        # current_claims are empty outside its pass look-ahead, so the seat's list is the pushed Ron and Pass
+                        lg[j] = np.array(d[3], dtype=np.uint64)
+                        m[j] = 0
+                        for a in d[3]:
+                            m[j, self._encode_id(int(a))] = 1
                 yield {"index": k, "game": gs, "seat": ss, "action": np.array([d[2] for d in dec], dtype=np.uint64),
                        "action_id": np.array([self._encode_id(d[2]) for d in dec], dtype=np.int64),
-                       "mask": mask[gs, ss][:, :nmask].copy(), "obs": enc[gs, ss].copy(),
-                       "legal": [legal[g, s, : cnt[g, s]].copy() for g, s in zip(gs, ss)]}
+                       "mask": m, "obs": enc[gs, ss].copy(), "legal": lg}
             self.env.apply_events([l[k] if k < len(l) else None for l in self.logs], masked_ok=self.masked_ok, replay=True)
 
 

@@ -250,7 +250,7 @@ class VecRiichiEnv:
     def clone(self):
         """rmj_clone: a new VecRiichiEnv whose games are in exactly this one's state (RiichiEnv.clone, env.rs:358-372)"""
         out = object.__new__(VecRiichiEnv)
-        out.__dict__.update({k: v for k, v in self.__dict__.items() if k != "h"})
+        out.__dict__.update({k: v for k, v in self.__dict__.items() if k not in ("h", "_lc_buf", "_cursor")})   # (buffers and cursors are per environment)
         h = C.c_void_p()
         _chk(self.L.rmj_clone(self.h, C.byref(h)))
         out.h = h
@@ -334,7 +334,8 @@ class VecRiichiEnv:
 
     def legal_compact(self):
         """(index [k] = game * 4 + seat, offsets [k + 1], entries [m]): the ordered legal lists of the seats that are to act, in
-        (game, seat) order - rmj_get_legal_compact: ~110 B per game over PCIe instead of the 2 KB of legal()"""
+        (game, seat) order - rmj_get_legal_compact: ~110 B per game over PCIe instead of the 2 KB of legal().  The arrays are VIEWS of
+        buffers this environment reuses: valid until its next legal_compact() call (copy them to keep them)."""
         cap_r = getattr(self, "_lc_rows", 0) or (self.n + self.n // 2 + 16)
         cap_e = getattr(self, "_lc_ents", 0) or (self.n * 24 + 1024)
         while True:

@@ -1,0 +1,70 @@
+"""GPU: the in-process multi-GPU host (riichienv_amd.multi_gpu.MultiGpuVecEnv: one handle and one host thread per device) with two
+shards on ONE device against a single handle, and bench.py's world > 1 path with two ranks sharing the GPU (--oversubscribe: gloo,
+RCCL refuses two ranks on one device).  No scaling curve has been measured: a multi-GPU node was never available to the build."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from riichienv_amd import vecenv
+from riichienv_amd.multi_gpu import MultiGpuVecEnv
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.mark.parametrize("mode", [2, 5])
+def test_two_shards_on_two_threads_equal_one_handle(mode):
+    n, seed, pseed = 512, 41 + mode, 99
+    one = vecenv.VecRiichiEnv(n, game_mode=mode, seed=seed, event_ring=2048)
+    two = MultiGpuVecEnv(n, devices=[0, 0], game_mode=mode, seed=seed, event_ring=2048)
+    one.reset()
+    two.reset()
+    for k in (1, 150, 33):
+        one.step_random(pseed, k, auto_reset=True)
+        two.step_random(pseed, k, auto_reset=True)
+    assert two.total_steps() == one.total_steps()
+    for a, b in zip(two.status(), one.status()):
+        assert (a == b).all()
+    la, ca = two.legal()
+    lb, cb = one.legal()
+    assert (ca == cb).all()
+    for g in range(n):
+        for s in range(4):
+            assert (la[g, s, : ca[g, s]] == lb[g, s, : cb[g, s]]).all()
+    assert (two.mask() == one.mask()).all() and (two.scores() == one.scores()).all() and (two.step_counts() == one.step_counts()).all()
+    # host-driven steps through the fan-out
+    acts = one.random_actions(pseed)
+    assert (two.random_actions(pseed) == acts).all()
+    one.step(acts)
+    two.step(acts)
+    for a, b in zip(two.status(), one.status()):
+        assert (a == b).all()
+    logs = two.mjai_logs()
+    for g in (0, 255, 256, n - 1):
+        assert logs[g] == one.mjai_log(g) == two.mjai_log(g), g
+    two.close()
+    one.close()
+
+
+def test_bench_with_two_ranks_sharing_the_gpu():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", MASTER_ADDR="127.0.0.1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--games", "8192", "--steps", "60", "--warmup", "20",
+           "--preroll", "400", "--no-cpu-baseline", "--no-extras", "--oversubscribe"]
+    p = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900)
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.strip().startswith("{")]
+    assert len(lines) == 1, p.stdout
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["oversubscribed"] is True and line["scaling"] == "weak"
+    # two ranks x 8 192 games x 60 steps, nearly every game advances every step: the SUM over ranks, the MAX of their times
+    steps = line["value"] * line["ms_per_step"] * 1e-3 * 60
+    assert 0.9 * 2 * 8192 * 60 <= steps <= 2 * 8192 * 60 * 1.0001, steps

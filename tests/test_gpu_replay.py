@@ -293,10 +293,11 @@ def test_logs_of_winning_play_yield_every_decision(mode, rate):
     # multi-Ron find a finished round - the reference's iterator yields the first winner only, replay/mod.rs:483-485).  A win on the
     # replacement tile IS offered: replay mode keeps the walker's is_after_kan (apply_log_action, event_handler.rs:428).
     want, raw = dict.fromkeys(types, 0), dict.fromkeys(types, 0)
-    for log in logs:
+    robbed = set()      # (log, index) of the hora that rob a kan: yielded like the reference's walker does (replay/mod.rs:483-527)
+    for li, log in enumerate(logs):
         r = oracle.Game(game_mode=mode, seed=1)
         r.reset()
-        for e in log:
+        for k, e in enumerate(log):
             if e["type"] in want:
                 raw[e["type"]] += 1
                 a, _, dn = r.status()
@@ -304,6 +305,13 @@ def test_logs_of_winning_play_yield_every_decision(mode, rate):
                 if (a >> s) & 1 and not dn:
                     v = r.peek()
                     want[e["type"]] += mjai.select_action_from_mjai(r.legal(s), e, None if v.drawn_tile < 0 else int(v.drawn_tile), sanma) is not None
+                elif e["type"] == "hora" and not dn and e["actor"] != e["target"]:
+                    j = k - 1
+                    while log[j]["type"] == "dora":
+                        j -= 1
+                    if log[j]["type"] in ("kakan", "ankan") and log[j]["actor"] == e["target"] and log[k - 1]["type"] != "hora":
+                        robbed.add((li, k))
+                        want["hora"] += 1
             r.apply_event(e, replay=True)
     assert raw["hora"] > 20 and raw["reach"] > 20 and raw["pon"] > 10 and raw["daiminkan"] + raw["kakan"] + raw["ankan"] > 3, raw
     assert all(want[t] == raw[t] for t in types if t != "hora") and raw["hora"] - want["hora"] <= 4, (want, raw)
@@ -324,8 +332,65 @@ def test_logs_of_winning_play_yield_every_decision(mode, rate):
             ev = logs[g][k]
             got[ev["type"]] += 1
             v = o.peek()
+            if (g, k) in robbed:     # the walker's observation of a robbed kan: [Ron on the kan tile, Pass] and nothing else in the mask
+                t, tile, cons = abi.unpack_action(int(smp["action"][j]))
+                kan = logs[g][k - 1] if logs[g][k - 1]["type"] != "dora" else logs[g][k - 2]
+                assert t == abi.RON and s == int(ev["actor"]) and tile == abi.mjai_to_tid(kan["pai"] if kan["type"] == "kakan" else kan["consumed"][0])
+                assert [abi.unpack_action(int(a))[0] for a in smp["legal"][j]] == [abi.RON, abi.PASS]
+                ids = np.flatnonzero(smp["mask"][j])
+                assert list(ids) == ([56, 58] if sanma else [79, 81]) and int(smp["action_id"][j]) == ids[0]
+                assert smp["obs"][j].tobytes() == o.encode(s, sanma).tobytes(), (g, k, s)
+                robbed.discard((g, k))
+                continue
             sel = mjai.select_action_from_mjai(o.legal(s), ev, None if v.drawn_tile < 0 else int(v.drawn_tile), sanma)
             assert sel == int(smp["action"][j]), (g, k, ev)
             assert (smp["mask"][j] == np.asarray(o.mask(s))[: len(smp["mask"][j])]).all(), (g, k, ev)
             assert smp["obs"][j].tobytes() == o.encode(s, sanma).tobytes(), (g, k, s)
-    assert got == want, (got, want)
+    assert got == want and not robbed, (got, want, robbed)
+
+
+@pytest.mark.parametrize("mode,picks", [(2, (27, 57, 70)), (5, (2, 151, 158))])
+def test_the_ron_on_a_robbed_kakan_is_a_sample(mode, picks, tmp_path):
+    """games in which a kakan is robbed (oracle, greedy policy, calls at 160 / 256 - seeds found by search): the
+    reference's iterator yields the chankan Ron (replay/mod.rs:483-527 builds it from last_discard = the kakan tile,
+    state/event_handler.rs:649-661; get_observation_for_replay pushes it into the seat's - empty - claims, state/mod.rs:265-325),
+    so must ReplayBatch and Kyoku.steps(): every hora of these logs that is the first of its round is a decision."""
+    import json
+
+    from oracle import oracle
+    from riichienv_amd import replay
+
+    sanma = mode >= 3
+    logs = []
+    for g in picks:
+        o = oracle.Game(game_mode=mode, seed=5000 + g)
+        o.reset()
+        for _ in range(2500):
+            if o.status()[2]:
+                break
+            o.step([int(x) for x in o.greedy_actions(71, g, 160)])
+        logs.append([json.loads(x) for x in o.log()])
+    first_hora = [[k for k, e in enumerate(log) if e["type"] == "hora" and log[k - 1]["type"] != "hora"] for log in logs]
+    chankan = [[k for k in ks if log[k]["actor"] != log[k]["target"] and
+                [e for e in log[:k] if e["type"] != "dora"][-1]["type"] == "kakan"] for log, ks in zip(logs, first_hora)]
+    assert all(len(c) >= 1 for c in chankan), chankan
+    rb = replay.ReplayBatch(logs, game_mode=mode, include_pass=False)
+    seen = [set() for _ in logs]
+    for smp in rb.samples():
+        for j in range(len(smp["game"])):
+            g, k = int(smp["game"][j]), smp["index"]
+            if logs[g][k]["type"] == "hora":
+                seen[g].add(k)
+                t, tile, _ = abi.unpack_action(int(smp["action"][j]))
+                assert int(smp["seat"][j]) == logs[g][k]["actor"]
+                if k in chankan[g]:
+                    assert t == abi.RON and smp["mask"][j].sum() == 2 and len(smp["legal"][j]) == 2
+    assert [sorted(s) for s in seen] == first_hora, (seen, first_hora)
+    # the per-round iterator of the reference's dataset loop (LogKyoku.steps): the chankan is one of the winner's decisions
+    path = tmp_path / "chankan.jsonl"
+    path.write_text("\n".join(json.dumps(e) for e in logs[0]) + "\n")
+    n_ron = 0
+    for ky in replay.MjaiReplay.from_jsonl(str(path)).take_kyokus():
+        for seat, obs, act in ky.steps(skip_single_action=False):
+            n_ron += int(act.action_type) == abi.RON
+    assert n_ron >= len([k for k in first_hora[0] if logs[0][k]["actor"] != logs[0][k]["target"]])

@@ -3,6 +3,7 @@
 #pragma once
 #include "../../include/riichi_mi355x.h"
 #include "rmj_hand.hip.h"
+#include "rmj_eval4.hip.h"
 #include "rmj_shanten.hip.h"
 #include "rmj_state.h"
 
@@ -274,7 +275,6 @@ __device__ __forceinline__ int next_dora34(int t, bool sanma) {  // hand_evaluat
     if (t < 31) return t == 30 ? 27 : t + 1;
     return t == 33 ? 31 : t + 1;
 }
-__device__ __forceinline__ bool is_aka(int t) { return t == 16 || t == 52 || t == 88; }
 
 // concealed histogram of a seat (optionally skipping hand index `skip`)
 __device__ __forceinline__ PH build_ph(const PState& P, int skip = -1) {

@@ -5,11 +5,8 @@
 //     question the reference answers by backtracking, agari.rs:183-245);
 //   * waits = 34 lanes x one candidate tile each, gathered with a wavefront ballot
 //     (hand_evaluator.rs:196-213);
-//   * yaku/fu: lane = candidate head (agari.rs:75-94), each lane walks the <=16 body
-//     decompositions in the reference's DFS order (koutsu before shuntsu, agari.rs:96-141),
-//     evaluates every (division, winning-group) pair (yaku.rs:298-556) and the wave picks the
-//     lexicographic (han, fu) maximum with first-wins ties — identical to the reference's
-//     sequential "strictly better replaces" scan.
+//   * yaku/fu: rmj_eval4.hip.h (row form: lane = decision string of the division search, then lane = (division, winning
+//     group) candidate; the row maximum of (han, fu, reference order) is the reference's "strictly better replaces" scan).
 //
 // Reference semantics followed: agari.rs, hand_evaluator.rs, hand_evaluator_3p.rs, yaku.rs,
 // yaku_3p.rs, score.rs (riichienv-core/src).
@@ -326,376 +323,15 @@ __device__ inline ScoreOut calc_score(uint32_t han, uint32_t fu, bool is_oya, bo
     return s;
 }
 
+__device__ __forceinline__ bool is_aka(int t) { return t == 16 || t == 52 || t == 88; }
+// body code of a division: 4 x 8 bit, each (koutsu << 6) | lowest type
+__device__ __forceinline__ int b_tile(uint32_t body, int i) { return (body >> (8 * i)) & 0x3F; }
+__device__ __forceinline__ bool b_kou(uint32_t body, int i) { return (body >> (8 * i + 6)) & 1u; }
 __device__ __forceinline__ bool t_is_terminal(int t) { return (MASK_TERM >> t) & 1ull; }
 __device__ __forceinline__ bool t_is_numterm(int t) { return (MASK_NUMTERM >> t) & 1ull; }
 
-// yaku.rs:843-890 (+ yaku_3p.rs nukidora)
-__device__ inline void static_yaku(const CalcIn& in, int& han, uint64_t& ym) {
-    uint32_t cf = in.cf;
-    bool tsumo = cf & CF_TSUMO;
-    if ((cf & CF_RIICHI) && !(cf & CF_DOUBLE_RIICHI)) { han += 1; ym |= YB(2); }
-    if (cf & CF_DOUBLE_RIICHI) { han += 2; ym |= YB(18); }
-    if (cf & CF_IPPATSU) { han += 1; ym |= YB(30); }
-    if (in.ma.menzen && tsumo) { han += 1; ym |= YB(1); }
-    if ((cf & CF_HAITEI) && tsumo) { han += 1; ym |= YB(5); }
-    if ((cf & CF_HOUTEI) && !tsumo) { han += 1; ym |= YB(6); }
-    if ((cf & CF_RINSHAN) && tsumo) { han += 1; ym |= YB(4); }
-    if ((cf & CF_CHANKAN) && !tsumo) { han += 1; ym |= YB(3); }
-    if (in.dora > 0) { han += in.dora; ym |= YB(31); }
-    if (in.aka > 0) { han += in.aka; ym |= YB(32); }
-    if (in.ura > 0) { han += in.ura; ym |= YB(33); }
-    if (in.sanma && in.nuki > 0) { han += in.nuki; ym |= YB(34); }
-}
-
-// hand-level predicates shared by every candidate (yaku.rs:692-705, 777-841, 1057-1146, 1212-1228)
-struct HandFlags {
-    bool tanyao, chinitsu, honitsu, honroutou, tsuuiisou, chinroutou, ryuuiisou, chuuren, chuuren9;
-};
-__device__ inline HandFlags hand_flags(const CalcIn& in) {
-    HandFlags f;
-    uint64_t hp = ph_presence(in.hand14);
-    uint64_t all = hp | in.ma.types;
-    f.tanyao = (all & MASK_TERM) == 0ull;
-    int suits = ((all & MASK_MAN) != 0) + ((all & MASK_PIN) != 0) + ((all & MASK_SOU) != 0);
-    bool honor = (all & MASK_HONORS) != 0;
-    f.chinitsu = (suits == 1) && !honor;
-    f.honitsu = (suits == 1) && honor;
-    f.honroutou = (all & ~MASK_TERM) == 0ull;
-    f.tsuuiisou = (all & ~MASK_HONORS) == 0ull;
-    f.chinroutou = (all & ~MASK_NUMTERM) == 0ull;
-    f.ryuuiisou = (all & ~MASK_GREEN) == 0ull;
-    // chuuren: concealed hand only (yaku.rs:1101-1131)
-    int hs = ((hp & MASK_MAN) != 0) + ((hp & MASK_PIN) != 0) + ((hp & MASK_SOU) != 0);
-    bool ch = (hs == 1) && (hp & MASK_HONORS) == 0ull;
-    uint32_t x = (hp & MASK_MAN) ? in.hand14.a : ((hp & MASK_PIN) ? in.hand14.b : in.hand14.c);
-    ch = ch && ((x & 7u) >= 3u) && (((x >> 24) & 7u) >= 3u);
-#pragma unroll
-    for (int k = 1; k < 8; k++) ch = ch && (((x >> (3 * k)) & 7u) != 0u);
-    f.chuuren = ch;
-    bool nine = false;
-    if (in.win34 < 27) {  // yaku.rs:1133-1146 — counts of the WIN TILE's suit
-        int ws = in.win34 / 9, val = in.win34 - 9 * ws;
-        uint32_t c = (ph_get(in.hand14, ws) >> (3 * val)) & 7u;
-        nine = (val == 0 || val == 8) ? (c == 4u) : (c == 2u);
-    }
-    f.chuuren9 = nine;
-    return f;
-}
-
-// body code: 4 x 8 bit, each (koutsu << 6) | tile34
-__device__ __forceinline__ int b_tile(uint32_t body, int i) { return (body >> (8 * i)) & 0x3F; }
-__device__ __forceinline__ bool b_kou(uint32_t body, int i) { return (body >> (8 * i + 6)) & 1u; }
-
-// yaku.rs:892-1055.  wg: -1 = pair wait, else body index.
-__device__ inline void yakuman_eval(const CalcIn& in, const HandFlags& hf, int head, uint32_t body, int nb, int wg, bool div_valid,
-                                    int& han, int& ycount, uint64_t& ym) {
-    int yc = 0;
-    bool tsumo = in.cf & CF_TSUMO;
-    if (hf.tsuuiisou) { yc += 1; ym |= YB(39); }
-    if (hf.chinroutou) { yc += 1; ym |= YB(41); }
-    if (hf.ryuuiisou) { yc += 1; ym |= YB(40); }
-    if (in.ma.n_kan == 4) { yc += 1; ym |= YB(44); }
-    if (in.ma.menzen && (nb + in.ma.n) == 4 && hf.chuuren) {
-        if (hf.chuuren9) { yc += 2; ym |= YB(47); } else { yc += 1; ym |= YB(45); }
-    }
-    if ((in.cf & CF_FIRST_TURN) && in.ma.menzen && tsumo) {
-        yc += 1;
-        ym |= (in.seat_wind34 == 27) ? YB(35) : YB(36);
-    }
-    int closed = in.ma.n_ankan;
-    bool hk = (in.ma.types >> 31) & 1, ht = (in.ma.types >> 32) & 1, ck = (in.ma.types >> 33) & 1;
-    int wind_k = 0, wind_p = 0;
-    uint32_t wk = 0;  // winds with koutsu (bits 0..3)
-#pragma unroll
-    for (int i = 0; i < 4; i++) {
-        if (i < nb && b_kou(body, i)) {
-            int t = b_tile(body, i);
-            if (!(!tsumo && i == wg)) closed++;
-            hk = hk || t == 31;
-            ht = ht || t == 32;
-            ck = ck || t == 33;
-            if (t >= 27 && t <= 30) wk |= 1u << (t - 27);
-        }
-        if (i < in.ma.n && in.ma.mtype[i] != 0 /*CHI*/) {
-            int t = in.ma.t0[i];
-            if (t >= 27 && t <= 30) wk |= 1u << (t - 27);
-        }
-    }
-    if (closed == 4) {
-        if (wg < 0) { yc += 2; ym |= YB(48); } else { yc += 1; ym |= YB(38); }
-    }
-    if (hk && ht && ck) { yc += 1; ym |= YB(37); }
-    wind_k = __popc(wk);
-    if (div_valid && head >= 27 && head <= 30 && !((wk >> (head - 27)) & 1u)) wind_p = 1;
-    if (wind_k == 4) { yc += 2; ym |= YB(50); } else if (wind_k == 3 && wind_p == 1) { yc += 1; ym |= YB(43); }
-    if (yc > 0) {
-        han = 13 * yc;
-        ycount = yc;
-    }
-}
-
-struct Cand {
-    int han, fu, ycount, kind;
-    uint64_t ym;
-};
-
-// One (division, winning group) candidate: yaku.rs:298-556
-__device__ inline Cand eval_candidate(const CalcIn& in, const HandFlags& hf, int head, uint32_t body, int nb, int wg) {
-    Cand r;
-    r.han = 0; r.fu = 0; r.ycount = 0; r.kind = 0; r.ym = 0;
-    yakuman_eval(in, hf, head, body, nb, wg, true, r.han, r.ycount, r.ym);
-    if (r.han >= 13) {
-        r.kind = 1;
-        return r;
-    }
-    const bool tsumo = in.cf & CF_TSUMO;
-    const bool menzen = in.ma.menzen;
-    const int win = in.win34;
-    int han = 0;
-    uint64_t ym = 0;
-    static_yaku(in, han, ym);
-    if (hf.tanyao) { han += 1; ym |= YB(12); }
-    // body statistics
-    int n_kou = 0, closed = in.ma.n_ankan;
-    bool any_kou = false;
-    uint32_t shun_man = 0, shun_pin = 0, shun_sou = 0;  // bit r = shuntsu starting at rank r present
-    uint32_t kou_man = 0, kou_pin = 0, kou_sou = 0;     // bit r = koutsu of rank r present
-    uint32_t shun_cnt = 0;                               // 4 x 8-bit? use identical-pair detection below
-    int fu_body = 0;
-    bool junchan = t_is_numterm(head), chanta = t_is_terminal(head);
-    bool chanta_honor = head >= 27;
-    int yk_p = 0, yk_f = 0, yk_c = 0, yk_round = 0, yk_seat = 0;
-    int n_eq = 0;  // number of equal (i<j) shuntsu pairs, for iipeikou/ryanpeikou
-#pragma unroll
-    for (int i = 0; i < 4; i++) {
-        if (i < nb) {
-            int t = b_tile(body, i);
-            if (b_kou(body, i)) {
-                any_kou = true;
-                n_kou++;
-                bool ron_open = (!tsumo && i == wg);
-                if (!ron_open) closed++;
-                int f = ron_open ? 2 : 4;
-                if (t_is_terminal(t)) f *= 2;
-                fu_body += f;
-                if (t < 9) kou_man |= 1u << t; else if (t < 18) kou_pin |= 1u << (t - 9); else if (t < 27) kou_sou |= 1u << (t - 18);
-                junchan = junchan && t_is_numterm(t);
-                chanta = chanta && t_is_terminal(t);
-                chanta_honor = chanta_honor || t >= 27;
-                yk_p += (t == 31); yk_f += (t == 32); yk_c += (t == 33);
-                yk_round += (t == in.round_wind34); yk_seat += (t == in.seat_wind34);
-            } else {
-                if (t < 9) shun_man |= 1u << t; else if (t < 18) shun_pin |= 1u << (t - 9); else shun_sou |= 1u << (t - 18);
-                junchan = junchan && (t_is_numterm(t) || t_is_numterm(t + 2));
-                chanta = chanta && (t_is_terminal(t) || t_is_terminal(t + 2));
-#pragma unroll
-                for (int j = 0; j < 4; j++)
-                    if (j < i && !b_kou(body, j) && b_tile(body, j) == t) n_eq++;
-            }
-        }
-    }
-    (void)shun_cnt;
-    // melds
-    uint32_t chi_man = 0, chi_pin = 0, chi_sou = 0, mk_man = 0, mk_pin = 0, mk_sou = 0;
-    bool hk = false, ht = false, ck = false;
-#pragma unroll
-    for (int i = 0; i < 4; i++) {
-        if (i < in.ma.n) {
-            int t = in.ma.t0[i];
-            if (in.ma.mtype[i] == 0) {
-                if (t < 9) chi_man |= 1u << t; else if (t < 18) chi_pin |= 1u << (t - 9); else if (t < 27) chi_sou |= 1u << (t - 18);
-            } else {
-                if (t < 9) mk_man |= 1u << t; else if (t < 18) mk_pin |= 1u << (t - 9); else if (t < 27) mk_sou |= 1u << (t - 18);
-                yk_p += (t == 31); yk_f += (t == 32); yk_c += (t == 33);
-                yk_round += (t == in.round_wind34); yk_seat += (t == in.seat_wind34);
-                hk = hk || t == 31; ht = ht || t == 32; ck = ck || t == 33;
-            }
-            junchan = junchan && (in.ma.mtypes[i] & MASK_NUMTERM) != 0ull;
-            chanta = chanta && (in.ma.mtypes[i] & MASK_TERM) != 0ull;
-            chanta_honor = chanta_honor || (in.ma.mtypes[i] & MASK_HONORS) != 0ull;
-        }
-    }
-    // pinfu (yaku.rs:644-690) or fu (yaku.rs:561-642)
-    bool head_yakuhai = head >= 31 || head == in.round_wind34 || head == in.seat_wind34;
-    bool pinfu = false;
-    if (menzen && in.ma.n == 0 && !any_kou && !head_yakuhai && wg >= 0 && !b_kou(body, wg)) {
-        int t = b_tile(body, wg);
-        if (win == t) pinfu = (t % 9) != 6;
-        else if (win == t + 2) pinfu = (t % 9) != 0;
-    }
-    int fu;
-    if (pinfu) {
-        han += 1; ym |= YB(14);
-        fu = tsumo ? 20 : 30;
-    } else {
-        fu = 20;
-        if (tsumo) fu += 2; else if (menzen) fu += 10;
-        if (head == in.round_wind34) fu += 2;
-        if (head == in.seat_wind34) fu += 2;
-        if (head >= 31) fu += 2;
-        if (wg < 0) fu += 2;
-        else if (!b_kou(body, wg)) {
-            int t = b_tile(body, wg);
-            if (win == t + 1 || (win == t + 2 && (t % 9 == 0)) || (win == t && (t % 9 == 6))) fu += 2;
-        }
-        fu += fu_body + in.ma.fu;
-        if (fu == 20 && !tsumo) fu = 30;
-        fu = (fu + 9) / 10 * 10;
-    }
-    // yakuhai, order P F C round seat (yaku.rs:356-386; round==seat -> 11 then 10, quirk Q10)
-    if (yk_p > 0) { han += yk_p; ym |= YB(7); }
-    if (yk_f > 0) { han += yk_f; ym |= YB(8); }
-    if (yk_c > 0) { han += yk_c; ym |= YB(9); }
-    if (yk_round > 0) { han += yk_round; ym |= YB(11); }
-    if (yk_seat > 0) { han += yk_seat; ym |= YB(10); }
-    // shousangen (yaku.rs:388-424)
-    {
-        bool a = hk || (yk_p > 0), b = ht || (yk_f > 0), c = ck || (yk_c > 0);
-        // note: yk_* already include meld koutsu; body koutsu are counted in yk_* as well
-        int dk = (int)a + b + c;
-        int dp = (head == 31) + (head == 32) + (head == 33);
-        if (!(a && b && c) && dk == 2 && dp == 1) { han += 2; ym |= YB(23); }
-    }
-    if (n_kou + in.ma.n_nonchi == 4) { han += 2; ym |= YB(21); }
-    if (closed == 3) { han += 2; ym |= YB(22); }
-    if (in.ma.n_kan == 3) { han += 2; ym |= YB(20); }
-    if (menzen) {  // iipeikou / ryanpeikou (yaku.rs:476-503): sorted starts, greedy adjacent pairs == sum floor(cnt/2)
-        // with <= 4 shuntsu: equal-pair count E in {0,1,2,3,6} -> pairs {0,1,2,1,2}
-        int pairs = (n_eq == 6 || n_eq == 2) ? 2 : (n_eq >= 1 ? 1 : 0);
-        if (pairs == 2) { han += 3; ym |= YB(28); } else if (pairs == 1) { han += 1; ym |= YB(13); }
-    }
-    {
-        uint32_t sm = shun_man | chi_man, sp = shun_pin | chi_pin, ss = shun_sou | chi_sou;
-        const uint32_t ITT = (1u << 0) | (1u << 3) | (1u << 6);
-        if ((sm & ITT) == ITT || (sp & ITT) == ITT || (ss & ITT) == ITT) { han += menzen ? 2 : 1; ym |= YB(16); }
-        if ((sm & sp & ss & 0x7Fu) != 0u) { han += menzen ? 2 : 1; ym |= YB(17); }
-        uint32_t km = kou_man | mk_man, kp = kou_pin | mk_pin, ks = kou_sou | mk_sou;
-        if ((km & kp & ks & 0x1FFu) != 0u) { han += 2; ym |= YB(19); }
-    }
-    if (hf.chinitsu) { han += menzen ? 6 : 5; ym |= YB(29); }
-    else if (hf.honitsu) { han += menzen ? 3 : 2; ym |= YB(27); }
-    if (hf.honroutou) { han += 2; ym |= YB(24); }
-    else if (junchan) { han += menzen ? 3 : 2; ym |= YB(26); }
-    else if (chanta && chanta_honor) { han += menzen ? 2 : 1; ym |= YB(15); }
-    r.han = han; r.fu = fu; r.ycount = 0; r.kind = 0; r.ym = ym;
-    return r;
-}
-
-// Wave-cooperative HandEvaluator::calc core (hand_evaluator.rs:96-175) for a hand already known
-// to be a winning shape.  All inputs wave-uniform; result wave-uniform.
-__device__ inline CalcOut wave_calc(const CalcIn& in, int lane) {
-    CalcOut out;
-    out.shape = true;
-    const HandFlags hf = hand_flags(in);
-    // ---- per-lane enumeration: lane = head
-    int best_han = 0, best_fu = 0, best_yc = 0, best_kind = 0;
-    uint64_t best_ym = 0;
-    bool has_div = false;
-    if (lane < 34 && ph_cnt(in.hand14, lane) >= 2) {
-        PH base = in.hand14;
-        ph_sub(base, lane);
-        ph_sub(base, lane);
-        const int head = lane;
-        // 16 choice strings, b0 = first decision (MSB) so that numeric order == DFS order (koutsu first)
-        for (int path = 0; path < 16; path++) {
-            PH h = base;
-            uint32_t body = 0;
-            int nb = 0;
-            bool valid = true;
-            bool done = false;
-#pragma unroll
-            for (int lvl = 0; lvl < 4; lvl++) {
-                int choice = (path >> (3 - lvl)) & 1;  // 0 = koutsu, 1 = shuntsu
-                if (ph_empty(h)) {
-                    done = true;
-                }
-                if (!done && valid) {
-                    int i = ph_first(h);
-                    int c = ph_cnt(h, i);
-                    if (choice == 0) {
-                        if (c >= 3) {
-                            ph_sub(h, i); ph_sub(h, i); ph_sub(h, i);
-                            body |= (uint32_t)((1 << 6) | i) << (8 * nb);
-                            nb++;
-                        } else valid = false;
-                    } else {
-                        bool seq_ok = i < 27 && (i % 9) <= 6;
-                        if (seq_ok && ph_cnt(h, i + 1) > 0 && ph_cnt(h, i + 2) > 0) {
-                            ph_sub(h, i); ph_sub(h, i + 1); ph_sub(h, i + 2);
-                            body |= (uint32_t)i << (8 * nb);
-                            nb++;
-                        } else valid = false;
-                    }
-                } else if (done) {
-                    if (choice != 0) valid = false;  // canonical: unused decisions must be 0
-                }
-            }
-            if (valid && !ph_empty(h)) valid = false;
-            if (!valid) continue;
-            has_div = true;
-            // winning groups in the reference's order: pair first, then body indices (yaku.rs:275-296)
-            for (int wg = -1; wg < nb; wg++) {
-                bool hit;
-                if (wg < 0) hit = (head == in.win34);
-                else {
-                    int t = b_tile(body, wg);
-                    hit = b_kou(body, wg) ? (t == in.win34) : (in.win34 >= t && in.win34 <= t + 2);
-                }
-                if (!hit) continue;
-                Cand c = eval_candidate(in, hf, head, body, nb, wg);
-                if (c.han > best_han || (c.han == best_han && c.fu > best_fu)) {
-                    best_han = c.han; best_fu = c.fu; best_yc = c.ycount; best_kind = c.kind; best_ym = c.ym;
-                }
-            }
-        }
-    }
-    bool any_div = __ballot(has_div) != 0ull;
-    int han, fu, yc, kind;
-    uint64_t ym;
-    if (any_div) {
-        // argmax (han, fu), first-wins == lowest head lane
-        uint32_t key = ((uint32_t)best_han << 16) | ((uint32_t)best_fu << 8) | (uint32_t)(63 - lane);
-        if (!(lane < 34)) key = 0;
-        uint32_t m = key;
-#pragma unroll
-        for (int off = 32; off >= 1; off >>= 1) {
-            uint32_t o = __shfl_xor(m, off, 64);
-            m = o > m ? o : m;
-        }
-        int win_lane = 63 - (int)(m & 0xFFu);
-        han = __shfl(best_han, win_lane, 64);
-        fu = __shfl(best_fu, win_lane, 64);
-        yc = __shfl(best_yc, win_lane, 64);
-        kind = __shfl(best_kind, win_lane, 64);
-        uint32_t lo = __shfl((uint32_t)(best_ym & 0xFFFFFFFFull), win_lane, 64);
-        uint32_t hi = __shfl((uint32_t)(best_ym >> 32), win_lane, 64);
-        ym = ((uint64_t)hi << 32) | lo;
-        if ((m >> 8) == 0u) { han = 0; fu = 0; yc = 0; kind = 0; ym = 0; }  // no candidate contained the win tile
-    } else if (is_kokushi(in.hand14)) {  // yaku.rs:237-255
-        kind = 3; fu = 0;
-        if (ph_cnt(in.hand14, in.win34) == 2) { han = 26; yc = 2; ym = YB(49); }
-        else { han = 13; yc = 1; ym = YB(42); }
-    } else if (is_chiitoi(in.hand14)) {  // yaku.rs:256-294 (quirk Q4: yakuman overwrites han, static added on top)
-        kind = 2; fu = 25; han = 2; yc = 0; ym = YB(25);
-        if (hf.tanyao) { han += 1; ym |= YB(12); }
-        if (hf.chinitsu) { han += 6; ym |= YB(29); } else if (hf.honitsu) { han += 3; ym |= YB(27); }
-        if (hf.honroutou) { han += 2; ym |= YB(24); }
-        yakuman_eval(in, hf, 0, 0u, 0, -1, false, han, yc, ym);
-        static_yaku(in, han, ym);
-    } else {
-        kind = 0; han = 0; fu = 0; yc = 0; ym = 0;
-    }
-    han &= 0xFF;  // YakuResult.han is u8 in the reference
-    out.han = han; out.fu = fu; out.yakuman_count = yc; out.kind = kind; out.ym = ym;
-    bool is_oya = in.seat_wind34 == 27;
-    uint32_t scoring_han = (yc == 0 && han >= 13) ? 13u : (uint32_t)han;  // hand_evaluator.rs:144-148
-    ScoreOut sc = calc_score(scoring_han, (uint32_t)fu, is_oya, in.cf & CF_TSUMO, in.honba, in.sanma ? 3u : 4u);
-    bool has_yaku = (ym & ~YMASK_DORA) != 0ull;
-    out.is_win = (has_yaku || yc > 0) && han >= 1;
-    out.yakuman = yc > 0;
-    out.ron = sc.ron; out.tsumo_oya = sc.tsumo_oya; out.tsumo_ko = sc.tsumo_ko;
-    return out;
-}
+// (the yaku / fu evaluation itself: rmj_eval4.hip.h - four hands per wave, one 16-lane row per hand; round 4 retired the one-hand-per-wave
+//  evaluator that lived here: lane = candidate head, 236 registers, 71 M hands/s)
 
 // yaku id emission orders: list = order table filtered by the mask
 __device__ __constant__ const uint8_t ORDER_STATIC[12] = {2, 18, 30, 1, 5, 6, 4, 3, 31, 32, 33, 34};

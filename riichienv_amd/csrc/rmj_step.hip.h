@@ -242,15 +242,40 @@ __device__ __forceinline__ CalcOut seat_calc_impl(Ctx& c, int seat, int skip_idx
                 if (sanma && nt == 30) ura += kita_count;
             }
         }
-    in.hand14 = h;
-    in.win34 = win34;
-    in.cf = cf;
-    in.dora = dora & 0xFF; in.aka = aka; in.ura = ura & 0xFF; in.nuki = sanma ? kita_count : 0;
-    in.round_wind34 = 27 + (S.round_wind & 3);
-    in.seat_wind34 = 27 + ((seat + KNP - S.oya) % KNP);
-    in.sanma = sanma;
-    in.honba = honba;
-    return wave_calc(in, c.lane);
+    // the evaluation itself in row form (e4_calc): every row of the wave holds the same hand here, so all rows compute - and return -
+    // the same result; its ~10 x shorter instruction stream is what matters to the wave that carries a Ron / Tsumo through the full path
+    E4In e;
+    e.on = true;
+    e.hand14 = h;
+    {   // the meld aggregate as packed words (MeldAgg -> E4Meld)
+        E4Meld m = {0u, 0u, 0u, 0u, 0u};
+        for (int i = 0; i < in.ma.n; i++) {
+            const int t0 = in.ma.t0[i];
+            const bool chi = in.ma.mtype[i] == RMJ_MELD_CHI;
+            const uint32_t bit = t0 < 27 ? 1u << t0 : 0u;
+            if (chi) m.chi |= bit; else m.kou |= bit;
+            if (!(in.ma.mtypes[i] & MASK_NUMTERM)) m.chi |= E4M_NO_NUMTERM;
+            if (!(in.ma.mtypes[i] & MASK_TERM)) m.chi |= E4M_NO_TERM;
+            if (!chi && t0 >= 27 && t0 < 34) m.thi |= 1u << (8 + t0 - 27);
+        }
+        if (!in.ma.menzen) m.chi |= E4M_OPENED;
+        m.tlo = (uint32_t)in.ma.types;
+        m.thi |= (uint32_t)(in.ma.types >> 32) & 3u;
+        m.cnt = (uint32_t)in.ma.n | ((uint32_t)in.ma.n_kan << 3) | ((uint32_t)in.ma.n_ankan << 6) | ((uint32_t)in.ma.n_nonchi << 9) |
+                (((uint32_t)in.ma.fu & 0xFFu) << 12) | (((uint32_t)in.ma.aka & 0xFu) << 20);
+        e.ma = m;
+    }
+    e.win34 = win34;
+    e.cf = cf;
+    e.dora = dora & 0xFF; e.aka = aka; e.ura = ura & 0xFF; e.nuki = sanma ? kita_count : 0;
+    e.round_wind34 = 27 + (S.round_wind & 3);
+    e.seat_wind34 = 27 + ((seat + KNP - S.oya) % KNP);
+    e.sanma = sanma;
+    e.honba = honba;
+    const E4Out o = e4_calc(e, c.lane & 15, c.lane & 48);
+    out.shape = o.shape; out.is_win = o.is_win; out.yakuman = o.yakuman; out.han = o.han; out.fu = o.fu; out.yakuman_count = o.yakuman_count;
+    out.kind = o.kind; out.ym = o.ym; out.ron = o.ron; out.tsumo_oya = o.tsumo_oya; out.tsumo_ko = o.tsumo_ko;
+    return out;
 }
 __device__ __noinline__ CalcOut ol_seat_calc(CtxV v, int seat, int skip_idx, int win_tile, uint32_t cf, uint32_t honba, bool use_ura,
                                              int kita_count) {

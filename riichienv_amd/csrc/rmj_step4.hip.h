@@ -2306,6 +2306,9 @@ __global__ __launch_bounds__(64, RMJ_STEP4_WAVES) void k_step4(const Env* __rest
         const unsigned long long rt0 = __builtin_amdgcn_s_memrealtime();
 #endif
         const uint32_t ret = step4_body<false, POL>(Ep, sh, policy_seed, flags, g_base, g_end, true, 0ull, actions);
+#ifdef RMJ_TL4
+        if ((threadIdx.x & 63) == 0) rmj::g_tl4[(size_t)blockIdx.x * RMJ_TL4_ROW + 15] = __ballot((ret & R4_RET_ROUND) != 0u) ? 1ull : 0ull;   // the wave ends rounds
+#endif
         if (RMJ_ROW_ROUND_END && __ballot((ret & R4_RET_ROUND) != 0u)) step4_finish_rounds<false, POL>(Ep, flags, g_base, g_end);
 #ifdef RMJ_TL4
         const unsigned long long rt1 = __builtin_amdgcn_s_memrealtime();

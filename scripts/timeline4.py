@@ -38,7 +38,8 @@ def main():
     n = 40
     sec = np.zeros(7)
     acc = {k: 0.0 for k in ("last_start", "last_end", "last_end_no_bail", "life", "life_bail_p50", "life_bail_p90", "life_bail_max",
-                            "life_other_p50", "life_other_max", "bail_waves", "multi_bail_waves", "bail_rows")}
+                            "life_other_p50", "life_other_max", "bail_waves", "multi_bail_waves", "bail_rows",
+                            "round_end_waves", "life_round_end_p50", "life_round_end_p90", "life_round_end_max", "last_end_plain")}
     alive = np.zeros(12)
     sites = {}
     fsec = np.zeros(16)
@@ -55,9 +56,15 @@ def main():
         acc["last_end"] += (t1.max() - z) / 100.0
         acc["last_end_no_bail"] += (t1[~b].max() - z) / 100.0
         acc["life"] += life.mean()
-        p = np.percentile(life[b], [50, 90, 100])
+        p = np.percentile(life[b], [50, 90, 100]) if b.any() else [0.0, 0.0, 0.0]
         acc["life_bail_p50"] += p[0]; acc["life_bail_p90"] += p[1]; acc["life_bail_max"] += p[2]
-        p = np.percentile(life[~b], [50, 100])
+        re_ = buf[:, 15] > 0                                           # waves that ended rounds in row form (r4_round_end + pass 2)
+        acc["round_end_waves"] += int(re_.sum())
+        pr = np.percentile(life[re_], [50, 90, 100]) if re_.any() else [0.0, 0.0, 0.0]
+        acc["life_round_end_p50"] += pr[0]; acc["life_round_end_p90"] += pr[1]; acc["life_round_end_max"] += pr[2]
+        plain = ~b & ~re_
+        acc["last_end_plain"] += (t1[plain].max() - z) / 100.0
+        p = np.percentile(life[~b & ~(buf[:, 15] > 0)], [50, 100])
         acc["life_other_p50"] += p[0]; acc["life_other_max"] += p[1]
         acc["bail_waves"] += int(b.sum())
         acc["multi_bail_waves"] += int((buf[:, 7] > 1).sum())
@@ -74,7 +81,8 @@ def main():
             sites[int(s_)] = sites.get(int(s_), 0) + int(c_)
     out = {"waves_per_launch": waves, "launches": n,
            "sections_core_cycles_per_wave": {name: sec[k] / n for k, name in enumerate(NAMES)},
-           "us": {k: v / n for k, v in acc.items() if k not in ("bail_waves", "multi_bail_waves", "bail_rows")},
+           "us": {k: v / n for k, v in acc.items() if k not in ("bail_waves", "multi_bail_waves", "bail_rows", "round_end_waves")},
+           "waves_that_end_rounds_in_row_form_per_launch": acc["round_end_waves"] / n,
            "full_path_games_per_launch": acc["bail_rows"] / n, "waves_with_a_full_path_game_per_launch": acc["bail_waves"] / n, "of_those_with_two_or_more": acc["multi_bail_waves"] / n,
            "waves_alive_in_twelfths_of_the_launch": [h / n for h in alive],
            "full_path_games_per_launch_by_tier0_exit": {str(k): v / n for k, v in sorted(sites.items())},

@@ -47,6 +47,10 @@ static inline dim3 step_grid(uint32_t n) { return dim3((n + RMJ_STEP_WPB - 1) / 
 #define RMJ_SPLIT_MIN_GAMES 16384u
 #define RMJ_SPLIT_MIN_PART 8192u   // games per part at least
 #define RMJ_MAX_ROLLOUT_STREAMS 8
+// games per wave by batch size (STEP_F_ROWS_SHIFT; profiles/r04_rows_sweep.txt, fused 4p-red-single rollouts, M env.step/s at 4 | 2 | 1 games
+// per wave: 2 048 games 226 | 254 | 278, 4 096: 435 | 478 | 456, 8 192: 814 | 770 | 522, 16 384: 1 288 | 882 | 599)
+#define RMJ_ROWS1_MAX_GAMES 2560u
+#define RMJ_ROWS2_MAX_GAMES 6144u
 
 __device__ __forceinline__ void load_state(GState& S, const GState* src, int lane) {
     if (lane < (int)(sizeof(GState) / 16)) reinterpret_cast<uint4*>(&S)[lane] = reinterpret_cast<const uint4*>(src)[lane];
@@ -955,6 +959,8 @@ struct rmj_env {
     uint32_t q_slots = 0;           // waves of k_step4_queue the device holds at once (the smaller of the two policy instantiations)
     int queue_force = 0;            // RMJ_QUEUE_FORCE at create (tests): tickets for every batch of >= 64 quads
     uint32_t queue_skip_xcds = 0;   // test hook: XCDs whose waves leave the queue kernel at once (RMJ_QUEUE_TEST_SKIP_XCDS at create)
+    uint32_t rows_pw = 4;           // games per wave of the non-ticket four-games-per-wave kernels: 4, or 2 / 1 for batches that leave the chip
+                                    // latency bound (chosen at create from the batch size; RMJ_ROWS overrides)
     int queue_min_chunk = 8;        // shortest ticket (steps): a rollout of >= 2 tickets per quad runs as tickets; RMJ_QUEUE_MIN_CHUNK at create
     uint32_t max_xcc_id = 0;        // largest HW_REG_XCC_ID seen by a probe launch at create: the ticket rollout assumes ids 0..7 (one L2 per queue)
     uint32_t* d_ev_lost = nullptr;  // [n_games] records a game's ring lost to a late drain (rmj_drain_events), cumulative
@@ -1045,6 +1051,8 @@ static int create_impl(rmj_env* h, const RmjConfig* cfg, uint64_t** d_seeds_out)
     if (const char* e = getenv("RMJ_QUEUE_FORCE")) h->queue_force = atoi(e);
     if (const char* e = getenv("RMJ_QUEUE_TEST_SKIP_XCDS")) h->queue_skip_xcds = (uint32_t)strtoul(e, nullptr, 0) & 0xFFu;
     if (const char* e = getenv("RMJ_QUEUE_MIN_CHUNK")) h->queue_min_chunk = atoi(e) > 0 ? atoi(e) : 1;
+    h->rows_pw = cfg->n_games <= RMJ_ROWS1_MAX_GAMES ? 1u : (cfg->n_games <= RMJ_ROWS2_MAX_GAMES ? 2u : 4u);
+    if (const char* e = getenv("RMJ_ROWS")) { const int r = atoi(e); if (r == 1 || r == 2 || r == 4) h->rows_pw = (uint32_t)r; }
     if (const char* e = getenv("RMJ_ENC_STREAMS")) h->enc_streams = atoi(e);
     if (const char* e = getenv("RMJ_ENC_PARTS_QUAD")) h->enc_parts_quad = atoi(e) != 0;
     if (const char* e = getenv("RMJ_ENC_FUSED")) h->enc_fused = atoi(e);
@@ -1269,8 +1277,10 @@ static inline void launch_step_range(rmj_env* h, hipStream_t st, const uint64_t*
 #else
     const unsigned extra_lds = 0u;
 #endif
-    if (h->quad && allow_quad) {   // four games per wave (device policy, packed actions or action ids)
-        const dim3 grid((g1 - g0 + 3u) / 4u);
+    if (h->quad && allow_quad) {   // four games per wave (device policy, packed actions or action ids); small batches: two or one (rows_pw)
+        const uint32_t rows = h->rows_pw;
+        flags |= (rows == 4u ? 0u : rows) << STEP_F_ROWS_SHIFT;
+        const dim3 grid((g1 - g0 + rows - 1u) / rows);
         if (h->cfg.game_mode >= 3) {
             if (greedy) hipLaunchKernelGGL((rmj3::k_step4<false, 1>), grid, dim3(64), 0, st, (const Env*)h->d_env, policy_seed, flags, g0, g1, 1u, d_actions);
             else hipLaunchKernelGGL((rmj3::k_step4<false, 0>), grid, dim3(64), 0, st, (const Env*)h->d_env, policy_seed, flags, g0, g1, 1u, d_actions);
@@ -1489,8 +1499,11 @@ static int step_policy_impl(rmj_handle h, uint64_t policy_seed, uint32_t n_steps
             HIPCHK(hipGetLastError());
             return RMJ_OK;
         }
-        if (sanma) RMJ_LAUNCH_LOOP_POL(rmj3, pol, grid, dim3(64), 0, h->stream, (const Env*)h->d_env, policy_seed, flags, 0u, n, n_steps, (const uint64_t*)nullptr);
-        else RMJ_LAUNCH_LOOP_POL(rmj4, pol, grid, dim3(64), 0, h->stream, (const Env*)h->d_env, policy_seed, flags, 0u, n, n_steps, (const uint64_t*)nullptr);
+        const uint32_t rows = h->rows_pw;
+        const dim3 grid_r((n + rows - 1u) / rows);
+        flags |= (rows == 4u ? 0u : rows) << STEP_F_ROWS_SHIFT;
+        if (sanma) RMJ_LAUNCH_LOOP_POL(rmj3, pol, grid_r, dim3(64), 0, h->stream, (const Env*)h->d_env, policy_seed, flags, 0u, n, n_steps, (const uint64_t*)nullptr);
+        else RMJ_LAUNCH_LOOP_POL(rmj4, pol, grid_r, dim3(64), 0, h->stream, (const Env*)h->d_env, policy_seed, flags, 0u, n, n_steps, (const uint64_t*)nullptr);
         HIPCHK(hipGetLastError());
         return RMJ_OK;
     }

@@ -20,6 +20,14 @@
 namespace RMJ_NS {
 
 #define R4_LIST 16 /* staged list entries per (game, seat); a longer list makes the row bail */
+// Games per wave of the non-ticket kernels (flags bits 20..21: 0 = four, 1 = one, 2 = two): a batch that gives the chip fewer than two
+// waves per SIMD at four games per wave is latency bound - the same rows spread over more waves hide each other's LDS / HBM round trips
+// (the instruction stream of a wave does not shrink with its rows, so this only pays while the vector units idle).
+#define STEP_F_ROWS_SHIFT 20
+__device__ __forceinline__ uint32_t r4_rows(uint32_t flags) {
+    const uint32_t c = (flags >> STEP_F_ROWS_SHIFT) & 3u;
+    return c == 0u ? 4u : c;
+}
 #ifndef RMJ_ROW_ROUND_END
 #define RMJ_ROW_ROUND_END 1   /* exhaustive draws, next rounds and restarts stay in tier 0 (r4_round_end); 0: they enter the full path at the exit */
 #endif
@@ -1538,9 +1546,10 @@ __device__ __forceinline__ uint32_t step4_body(const Env* Ep, Quad4Shared& sh, u
 #endif
     const int lane = threadIdx.x & 63;
     const int row = lane >> 4, r = lane & 15, rb = lane & 48;
-    const uint32_t g0 = g_base + (quad == 0xFFFFFFFFu ? blockIdx.x : quad) * 4u;   // (k_step4_queue names the quad, the others own quad = block)
+    const uint32_t rows_pw = r4_rows(flags);
+    const uint32_t g0 = g_base + (quad == 0xFFFFFFFFu ? blockIdx.x : quad) * rows_pw;   // (k_step4_queue names the quad, the others own quad = block)
     const uint32_t g = g0 + (uint32_t)row;
-    const uint32_t n_here = g_end - g0 < 4u ? g_end - g0 : 4u;   // games of this wave
+    const uint32_t n_here = g0 >= g_end ? 0u : (g_end - g0 < rows_pw ? g_end - g0 : rows_pw);   // games of this wave
     if (load) {   // ---- records: every row fetches its own 640 B (40 chunks of 16 B, three per lane)
         if ((uint32_t)row < n_here) {
 #pragma unroll
@@ -2247,7 +2256,7 @@ __device__ __noinline__ void step4_pass2(const Env* Ep, uint32_t flags, uint32_t
 }
 template <bool LOOP, int POL>
 __device__ __forceinline__ void step4_finish_rounds(const Env* Ep, uint32_t flags, uint32_t g_base, uint32_t g_end, uint32_t quad = 0xFFFFFFFFu) {
-    r4_round_end(Ep, g_base + (quad == 0xFFFFFFFFu ? blockIdx.x : quad) * 4u);
+    r4_round_end(Ep, g_base + (quad == 0xFFFFFFFFu ? blockIdx.x : quad) * r4_rows(flags));
     step4_pass2<LOOP, POL>(Ep, flags, g_base, g_end, quad);
 }
 // ... with inline responses (step4_body<.., INLR>): `left` steps to go per row, returns the steps taken per row
@@ -2297,7 +2306,8 @@ template <bool LOOP, int POL>
 __global__ __launch_bounds__(64, RMJ_STEP4_WAVES) void k_step4(const Env* __restrict__ Ep, uint64_t policy_seed, uint32_t flags, uint32_t g_base,
                                                                    uint32_t g_end, uint32_t n_steps, const uint64_t* __restrict__ actions) {
     if (LOOP) {
-        const uint32_t g = g_base + blockIdx.x * 4u + ((threadIdx.x & 63u) >> 4);
+        const uint32_t row_ = (threadIdx.x & 63u) >> 4;
+        const uint32_t g = row_ < r4_rows(flags) ? g_base + blockIdx.x * r4_rows(flags) + row_ : 0xFFFFFFFFu;   // (rows beyond the wave's games idle)
         const uint64_t gs_row = sm64(policy_seed + ((CEnv*)Ep)->game_offset + (uint64_t)g);   // policy key of the row's game
         step4_run<POL>(Ep, policy_seed, flags, g_base, g_end, gs_row, 0xFFFFFFFFu, n_steps, true, g);
     } else {

@@ -31,6 +31,7 @@ using namespace rmj;
 #define STEP_F_ALLROWS 0x20000u /* fused rollouts, last step: all four mask rows are rewritten (the quiet steps left them stale) */
 #define STEP_F_CONT_RYU 0x40000u /* ol_step_full: continue at the exhaustive draw on the record k_step4's tier 0 left in LDS (no reload, no replay of the discard) */
 #define STEP_F_CONT_FIN 0x80000u /* ol_step_full: the step is complete on the record in LDS, only the observation outputs are produced */
+#define STEP_F_CONT_CLAIMS 0x400000u /* ol_step_full: continue behind the dahai event of the discard made on the record in LDS (claim generation, then the rest of _resolve_discard) */
 #define STEP_F_GREEDY 8u /* with STEP_F_RANDOM: the greedy policy (rmj_step_greedy, r4_policy_greedy) instead of the RandomAgent; bits 8..15 = call rate / 256 */
 
 template <int N>
@@ -959,6 +960,9 @@ struct rmj_env {
     uint32_t q_slots = 0;           // waves of k_step4_queue the device holds at once (the smaller of the two policy instantiations)
     int queue_force = 0;            // RMJ_QUEUE_FORCE at create (tests): tickets for every batch of >= 64 quads
     uint32_t queue_skip_xcds = 0;   // test hook: XCDs whose waves leave the queue kernel at once (RMJ_QUEUE_TEST_SKIP_XCDS at create)
+    void* d_heavy = nullptr;        // heavy-first launch order of whole-batch per-step launches (HeavyOrder): two counters, lists, flag arrays
+    uint32_t heavy_phase = 0;       // which half the next launch reads
+    int heavy_first = 1;            // RMJ_HEAVY_FIRST at create (0: plain block order)
     uint32_t rows_pw = 4;           // games per wave of the non-ticket four-games-per-wave kernels: 4, or 2 / 1 for batches that leave the chip
                                     // latency bound (chosen at create from the batch size; RMJ_ROWS overrides)
     int queue_min_chunk = 8;        // shortest ticket (steps): a rollout of >= 2 tickets per quad runs as tickets; RMJ_QUEUE_MIN_CHUNK at create
@@ -1051,6 +1055,7 @@ static int create_impl(rmj_env* h, const RmjConfig* cfg, uint64_t** d_seeds_out)
     if (const char* e = getenv("RMJ_QUEUE_FORCE")) h->queue_force = atoi(e);
     if (const char* e = getenv("RMJ_QUEUE_TEST_SKIP_XCDS")) h->queue_skip_xcds = (uint32_t)strtoul(e, nullptr, 0) & 0xFFu;
     if (const char* e = getenv("RMJ_QUEUE_MIN_CHUNK")) h->queue_min_chunk = atoi(e) > 0 ? atoi(e) : 1;
+    if (const char* e = getenv("RMJ_HEAVY_FIRST")) h->heavy_first = atoi(e);
     h->rows_pw = cfg->n_games <= RMJ_ROWS1_MAX_GAMES ? 1u : (cfg->n_games <= RMJ_ROWS2_MAX_GAMES ? 2u : 4u);
     if (const char* e = getenv("RMJ_ROWS")) { const int r = atoi(e); if (r == 1 || r == 2 || r == 4) h->rows_pw = (uint32_t)r; }
     if (const char* e = getenv("RMJ_ENC_STREAMS")) h->enc_streams = atoi(e);
@@ -1157,7 +1162,7 @@ int rmj_destroy(rmj_handle h) {
     if (h->h_pin) hipHostFree(h->h_pin);
     hipFree(h->d.core); hipFree(h->d.wall); hipFree(h->d.legal); hipFree(h->d.nlegal); hipFree(h->d_decay); if (h->d_scratch) hipFree(h->d_scratch); hipFree(h->d.mask);
     hipFree(h->d.waits); hipFree(h->d.status); hipFree(h->d.events); hipFree(h->d.win); hipFree(h->d_actions); hipFree(h->d_counter); hipFree(h->d_obs_offs); hipFree(h->d_env); hipFree(h->d_qheads);   // (d_qdone lives in the same allocation)
-    hipFree(h->d_ev_lost); hipFree(h->d_track);
+    hipFree(h->d_ev_lost); hipFree(h->d_track); hipFree(h->d_heavy);
     for (int i = 0; i < 2; i++) if (h->ev_time[i]) hipEventDestroy(h->ev_time[i]);
     if (h->own_stream) hipStreamDestroy(h->own_stream);
     for (int i = 0; i < RMJ_MAX_ROLLOUT_STREAMS - 1; i++) {
@@ -1184,6 +1189,8 @@ int rmj_clone(rmj_handle h, rmj_handle* out) {
     c->queue_chunk = h->queue_chunk;
     c->queue_force = h->queue_force;
     c->queue_min_chunk = h->queue_min_chunk;
+    c->rows_pw = h->rows_pw;
+    c->heavy_first = h->heavy_first;
     c->enc_streams = h->enc_streams;
     c->enc_parts_quad = h->enc_parts_quad;
     c->enc_fused = h->enc_fused;
@@ -1280,13 +1287,34 @@ static inline void launch_step_range(rmj_env* h, hipStream_t st, const uint64_t*
     if (h->quad && allow_quad) {   // four games per wave (device policy, packed actions or action ids); small batches: two or one (rows_pw)
         const uint32_t rows = h->rows_pw;
         flags |= (rows == 4u ? 0u : rows) << STEP_F_ROWS_SHIFT;
-        const dim3 grid((g1 - g0 + rows - 1u) / rows);
+        const uint32_t units = (g1 - g0 + rows - 1u) / rows;
+        // whole-batch launches in heavy-first order (HeavyOrder): the previous launch's notes name the units that will end a round,
+        // restart or may settle a Ron - they get the first blocks
+        HeavyOrder ho = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0u};
+        if (h->heavy_first && g0 == 0u && g1 == h->cfg.n_games && units >= 2048u) {
+            const uint32_t front = units / 4u;
+            const size_t o_list = 384, o_flag = o_list + 2 * (size_t)front * 4, bytes = o_flag + 2 * (size_t)units;   // three counters, a line each
+            if (!h->d_heavy) {
+                if (hipMalloc(&h->d_heavy, bytes) == hipSuccess) hipMemsetAsync(h->d_heavy, 0, bytes, st);
+                else h->d_heavy = nullptr;
+            }
+            if (h->d_heavy) {
+                uint8_t* b = (uint8_t*)h->d_heavy;
+                const uint32_t k = h->heavy_phase, in = k & 1u, out = in ^ 1u;
+                ho.in_cnt = (const uint32_t*)(b + 128 * (k % 3u)); ho.out_cnt = (uint32_t*)(b + 128 * ((k + 1u) % 3u)); ho.zero_cnt = (uint32_t*)(b + 128 * ((k + 2u) % 3u));
+                ho.in_list = (const uint32_t*)(b + o_list) + (size_t)front * in; ho.out_list = (uint32_t*)(b + o_list) + (size_t)front * out;
+                ho.in_flag = b + o_flag + (size_t)units * in; ho.out_flag = b + o_flag + (size_t)units * out;
+                ho.front = front;
+                h->heavy_phase = (k + 1u) % 6u;   // (period of the counter and the list rotation)
+            }
+        }
+        const dim3 grid(units + ho.front);
         if (h->cfg.game_mode >= 3) {
-            if (greedy) hipLaunchKernelGGL((rmj3::k_step4<false, 1>), grid, dim3(64), 0, st, (const Env*)h->d_env, policy_seed, flags, g0, g1, 1u, d_actions);
-            else hipLaunchKernelGGL((rmj3::k_step4<false, 0>), grid, dim3(64), 0, st, (const Env*)h->d_env, policy_seed, flags, g0, g1, 1u, d_actions);
+            if (greedy) hipLaunchKernelGGL((rmj3::k_step4<false, 1>), grid, dim3(64), 0, st, (const Env*)h->d_env, policy_seed, flags, g0, g1, 1u, d_actions, ho);
+            else hipLaunchKernelGGL((rmj3::k_step4<false, 0>), grid, dim3(64), 0, st, (const Env*)h->d_env, policy_seed, flags, g0, g1, 1u, d_actions, ho);
         } else {
-            if (greedy) hipLaunchKernelGGL((rmj4::k_step4<false, 1>), grid, dim3(64), 0, st, (const Env*)h->d_env, policy_seed, flags, g0, g1, 1u, d_actions);
-            else hipLaunchKernelGGL((rmj4::k_step4<false, 0>), grid, dim3(64), 0, st, (const Env*)h->d_env, policy_seed, flags, g0, g1, 1u, d_actions);
+            if (greedy) hipLaunchKernelGGL((rmj4::k_step4<false, 1>), grid, dim3(64), 0, st, (const Env*)h->d_env, policy_seed, flags, g0, g1, 1u, d_actions, ho);
+            else hipLaunchKernelGGL((rmj4::k_step4<false, 0>), grid, dim3(64), 0, st, (const Env*)h->d_env, policy_seed, flags, g0, g1, 1u, d_actions, ho);
         }
         return;
     }
@@ -1502,8 +1530,9 @@ static int step_policy_impl(rmj_handle h, uint64_t policy_seed, uint32_t n_steps
         const uint32_t rows = h->rows_pw;
         const dim3 grid_r((n + rows - 1u) / rows);
         flags |= (rows == 4u ? 0u : rows) << STEP_F_ROWS_SHIFT;
-        if (sanma) RMJ_LAUNCH_LOOP_POL(rmj3, pol, grid_r, dim3(64), 0, h->stream, (const Env*)h->d_env, policy_seed, flags, 0u, n, n_steps, (const uint64_t*)nullptr);
-        else RMJ_LAUNCH_LOOP_POL(rmj4, pol, grid_r, dim3(64), 0, h->stream, (const Env*)h->d_env, policy_seed, flags, 0u, n, n_steps, (const uint64_t*)nullptr);
+        const HeavyOrder no_order = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0u};
+        if (sanma) RMJ_LAUNCH_LOOP_POL(rmj3, pol, grid_r, dim3(64), 0, h->stream, (const Env*)h->d_env, policy_seed, flags, 0u, n, n_steps, (const uint64_t*)nullptr, no_order);
+        else RMJ_LAUNCH_LOOP_POL(rmj4, pol, grid_r, dim3(64), 0, h->stream, (const Env*)h->d_env, policy_seed, flags, 0u, n, n_steps, (const uint64_t*)nullptr, no_order);
         HIPCHK(hipGetLastError());
         return RMJ_OK;
     }

@@ -42,6 +42,18 @@ __device__ __forceinline__ ShantenTables sh_tables_of(CEnv& E) {
     return T;
 }
 
+// heavy-first launch order of the per-step kernel (k_step4<false>, rmj_step4.hip.h)
+struct HeavyOrder {        // device pointers (rmj_env::d_heavy), nullptr members = plain order
+    const uint32_t* in_cnt;
+    const uint32_t* in_list;
+    const uint8_t* in_flag;
+    uint32_t* out_cnt;
+    uint32_t* zero_cnt;   // the counter the launch AFTER the next one will fill: cleared here (no memset between the launches)
+    uint32_t* out_list;
+    uint8_t* out_flag;
+    uint32_t front;
+};
+
 #define RMJ_EV_STAGE 4
 struct WaveScratch {      // per-wave LDS scratch
     uint8_t tiles[144];

@@ -27,6 +27,12 @@ __device__ __noinline__ void ol_step_full(CtxV v, uint64_t mine, uint32_t flags)
         S.is_rinshan = 0;
         trigger_ryukyoku(c, RMJ_RK_EXHAUSTIVE, 0);
         if (U(S.turn_count) >= (uint32_t)KNP) S.is_first_turn = 0;
+    } else if (flags & STEP_F_CONT_CLAIMS) {
+        // entered behind a discard tier 0 has made (pass 2 of a row that paused at the Ron check and then met something tier 0 does not
+        // do): claim generation and the rest of _resolve_discard, state/mod.rs:1363-1413
+        wave_sync();
+        S.full_count += 1;
+        resolve_discard_tail<false>(c, U((int)S.last_discard_pid));
     } else if (flags & STEP_F_CONT_FIN) {
         // the step is complete on the record in LDS (a round dealt by r4_round_end whose first list tier 0 cannot write): outputs only
         wave_sync();

@@ -1388,6 +1388,8 @@ __device__ __noinline__ void ol_resolve_kan(CtxV v, int pid, uint64_t action) {
 }
 
 // state/mod.rs:1317-1413
+template <bool FAST>
+__device__ __forceinline__ void resolve_discard_tail(Ctx& c, int pid);
 template <bool FAST = false>
 __device__ __forceinline__ void resolve_discard(Ctx& c, int pid, int tile, bool tsumogiri) {
     GState& S = c.S;
@@ -1437,6 +1439,13 @@ __device__ __forceinline__ void resolve_discard(Ctx& c, int pid, int tile, bool 
     S.active_mask = 0;
     S.ron_offer_mask = 0;
     PROF(c.X, c.lane, 4);
+    resolve_discard_tail<FAST>(c, pid);
+}
+// ... from the claims on (also the full path's entry behind a discard made by k_step4's tier 0: STEP_F_CONT_CLAIMS)
+template <bool FAST>
+__device__ __forceinline__ void resolve_discard_tail(Ctx& c, int pid) {
+    GState& S = c.S;
+    const int tile = U((int)S.last_discard_tile);
     const uint32_t claim_active = gen_claims_all<FAST>(c, pid, tile);
     if (FAST && c.bail) return;
     PROF(c.X, c.lane, 5);

@@ -20,6 +20,13 @@
 namespace RMJ_NS {
 
 #define R4_LIST 16 /* staged list entries per (game, seat); a longer list makes the row bail */
+// what makes a row stop in pass 1 of a step (Quad4Shared::rmode; the caller runs r4_round_end / r4_yaku_answers, then pass 2)
+#define R4_RE_DRAW 1u      /* exhaustive draw */
+#define R4_RE_RESTART 2u   /* a finished game restarts (auto-reset) */
+#define R4_RE_PUB 3u       /* pass 2 of step4_body: the round has been dealt, the row's observation is still to be published */
+#define R4_RE_YAKU_CLAIMS 4u /* paused in r4_resolve_discard: seats without a riichi wait on the discard - their yaku decide (pass 2 resumes there) */
+#define R4_RE_YAKU_TSUMO 5u  /* paused in r4_gen_act_legal: an open hand is complete - its yaku decide whether Tsumo is offered */
+#define R4_RET_ROUND 0x100u /* step4_body's result: some row of the wave ends a round - the caller runs r4_round_end and pass 2 */
 // Games per wave of the non-ticket kernels (flags bits 20..21: 0 = four, 1 = one, 2 = two): a batch that gives the chip fewer than two
 // waves per SIMD at four games per wave is latency bound - the same rows spread over more waves hide each other's LDS / HBM round trips
 // (the instruction stream of a wave does not shrink with its rows, so this only pays while the vector units idle).
@@ -73,6 +80,7 @@ struct Quad4Shared {
     uint32_t rs[R4_RS_WORDS];   // outside the union: a round ends while the other rows' lists and events are still staged
     uint32_t rfl[4];            // rows whose round ends in this call: their publication flags (pass 2 of step4_body) ...
     uint32_t rmode[4];          // ... and what ends it (R4_RE_*; 0: nothing)
+    uint32_t yk[4];             // answers of r4_yaku_answers: R4_RE_YAKU_CLAIMS: seats that may Ron | seats with a shape but no yaku << 4; _TSUMO: bit 0 = offer
 };
 // The wave's working set (every block of the four-games-per-wave kernels is one wave).  One namespace-scope variable instead of a
 // static in each entry point: the out-of-line pieces of a step (r4_round_end) address it directly, as LDS.
@@ -108,7 +116,10 @@ struct R4 {
     bool live;        // the row still runs in tier 0
     bool bail;        // the row goes to the full path
     int cont;         // with bail: the full path is entered AT this point of the step, on the record tier 0 leaves in LDS (STEP_F_CONT_*), instead of starting over
-    uint32_t rend;    // R4_RE_*: the row's game ends a round in this call (r4_round_end)
+    uint32_t rend;    // R4_RE_*: the row's game ends a round in this call (r4_round_end), or pauses for a yaku check (R4_RE_YAKU_*)
+    bool pause_ok;    // pass 1: a row that needs the evaluator pauses (its caller runs r4_yaku_answers, pass 2 resumes it); else it bails
+    uint32_t yk;      // pass 2: the answers of r4_yaku_answers for this row ...
+    uint32_t yk_mode; // ... and what they answer (R4_RE_YAKU_*; 0: none)
 #ifdef RMJ_CENSUS
     int why;          // the R4BAIL site that made the row bail
 #endif
@@ -496,11 +507,8 @@ __device__ __forceinline__ void r4_deal_next(R4& q, int pf) {
     GState* G = q.G;
     const int drawable = G->drawable_count;
     if (drawable == 0) {   // exhaustive draw
-#if RMJ_ROW_ROUND_END
-        q.rend = 1u /* R4_RE_DRAW */;   // the round ends in row form, behind the transitions of this call (r4_round_end)
-#else
-        R4BAIL(q, 7); q.cont = 1;       // the full path takes over right here (trigger_ryukyoku)
-#endif
+        if (RMJ_ROW_ROUND_END && q.pause_ok) q.rend = 1u /* R4_RE_DRAW */;   // the round ends in row form, behind the transitions of this call (r4_round_end)
+        else { R4BAIL(q, 7); q.cont = 1; }                                    // the full path takes over right here (trigger_ryukyoku)
         return;
     }
     const int live_end = G->live_end;
@@ -599,21 +607,104 @@ __device__ __forceinline__ void r4_kan_draw(R4& q, int pid, PState* P, bool anka
     }
     wave_sync();
 }
+// Yaku check of a complete hand for tier 0 (round 4): seat `seat` of the row's game wins on `tile` (136-id; a Ron tile is added to the 13
+// held ones, a drawn tile is held already) under the condition flags cf - the legality form of seat_calc (no ura, no kita count:
+// legal_actions.rs:44-61, 254-310) through the row-form evaluator, the rows' seats side by side.  Every lane of the wave calls, rows
+// with on = 0 idle.  Result (row-uniform): bit 0 = WinResult.is_win, bit 1 = the hand has a win shape, bit 2 = yakuman or han >= 1.
+__device__ __forceinline__ uint32_t r4_yaku_check(uint32_t on, uint32_t seat, uint32_t tile, uint32_t cf) {
+    const int lane = threadIdx.x & 63, row = lane >> 4, r = lane & 15, rb = lane & 48;
+    const GState* G = &g_q4.st[row];
+    const PState* P = &G->p[seat & 3u];
+    const bool act = on != 0u;
+    const int hl = act ? (int)P->hand_len : 0, nm = act ? (int)P->n_melds : 0;
+    // lane = hand slot
+    const int tid = r < hl ? (int)P->hand[r] : 0;
+    uint32_t ca = 0, cb = 0, cc = 0, cd = 0;
+    if (r < hl) {
+        const int t = tid >> 2, su = t_suit(t);
+        const uint32_t one = 1u << (3 * (t - 9 * su));
+        ca = su == 0 ? one : 0u; cb = su == 1 ? one : 0u; cc = su == 2 ? one : 0u; cd = su == 3 ? one : 0u;
+    }
+    PH h;
+    h.a = e4_rsum(ca, rb); h.b = e4_rsum(cb, rb); h.c = e4_rsum(cc, rb); h.d = e4_rsum(cd, rb);
+    int aka = __popc(e4_ballot(r < hl && is_aka(tid), rb));
+    // lane = meld
+    uint32_t ma_ = 0, mb_ = 0, mc_ = 0, md_ = 0;
+    E4Meld mp;
+    {
+        const bool mv = r < nm;
+        const int m = r & 3;
+        const uint32_t type = P->meld_type[m];
+        const int nt = type >= RMJ_MELD_DAIMINKAN ? 4 : 3;
+        const uint32_t t0 = P->meld_tiles[m][0], t1 = P->meld_tiles[m][1], t2 = P->meld_tiles[m][2], t3 = P->meld_tiles[m][3];
+        if (mv) {
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const int t = (int)(k == 0 ? t0 : (k == 1 ? t1 : (k == 2 ? t2 : t3))) >> 2;
+                if (k < nt) {
+                    const int su = t_suit(t);
+                    const uint32_t one = 1u << (3 * (t - 9 * su));
+                    ma_ += su == 0 ? one : 0u; mb_ += su == 1 ? one : 0u; mc_ += su == 2 ? one : 0u; md_ += su == 3 ? one : 0u;
+                }
+            }
+        }
+        mp = e4_meld_lane(mv, type, nt, t0, t1, t2, t3, (int)(t0 >> 2), type != RMJ_MELD_CHI, type != RMJ_MELD_ANKAN);
+    }
+    const E4Meld ma = e4_meld_reduce(mp, rb);
+    aka += e4m_aka(ma);
+    PH full = h;
+    full.a += e4_rsum(ma_, rb); full.b += e4_rsum(mb_, rb); full.c += e4_rsum(mc_, rb); full.d += e4_rsum(md_, rb);
+    const int win34 = (int)(tile >> 2) < 34 ? (int)(tile >> 2) : 33;
+    if (hl + 3 * nm == 13) {
+        ph_add(h, win34);
+        ph_add(full, win34);
+        aka += is_aka((int)tile);
+    }
+    // lane = indicator
+    int dora;
+    {
+        const bool is_d = act && r < 5 && r < (int)G->n_dora;
+        int cnt = 0;
+        if (is_d) cnt = ph_cnt(full, next_dora34(((int)G->dora[r & 7] >> 2) < 34 ? ((int)G->dora[r & 7] >> 2) : 33, KSANMA));
+        dora = (int)e4_rsum((uint32_t)cnt, rb);
+    }
+    E4In in;
+    in.on = act;
+    in.hand14 = h;
+    in.ma = ma;
+    in.win34 = win34;
+    in.cf = cf;
+    in.dora = dora & 0xFF; in.aka = aka; in.ura = 0; in.nuki = 0;
+    in.round_wind34 = 27 + ((int)G->round_wind & 3);
+    {
+        int sw = (int)(seat & 3u) + KNP - (int)G->oya;
+        sw = sw >= KNP ? sw - KNP : sw;
+        in.seat_wind34 = 27 + (sw & 3);
+    }
+    in.sanma = KSANMA;
+    in.honba = G->honba;
+    const E4Out o = e4_calc(in, r, rb);
+    return (o.is_win ? 1u : 0u) | (o.shape ? 2u : 0u) | ((o.yakuman || o.han >= 1) ? 4u : 0u);
+}
+
 // _resolve_discard (state/mod.rs:1317-1413) incl. claim generation (legal_actions.rs:254-508) for the row's game.
 // nl[] = list length of seat r (lanes r < 4) after the call; returns through G->phase / active_mask like the reference.
 // known_sh: the exact shanten of the 13 tiles the discard leaves when the policy has just computed it (99: unknown)
-template <bool RICH, bool LOOP>
+// RESUME (pass 2): the discard itself - bookkeeping, indicators, the dahai event, the wait-cache refills - was done in pass 1, which
+// paused at the Ron check (R4_RE_YAKU_CLAIMS); the function picks up there with the evaluator's answers (q.yk)
+template <bool RICH, bool LOOP, bool RESUME = false>
 __device__ __forceinline__ void r4_resolve_discard(R4& q, int pid, int tile, bool tsumogiri, int pf, int& nl_mine, uint64_t& w_mine, int known_sh = 99) {
     GState* G = q.G;
     PState* P = &G->p[pid];
     const int r = q.r, rb = q.rb;
+    if (!RESUME) {
     // (kan dora indicators waiting for this discard: flipping them here was measured - 0.05 % fewer exits, 2.7 % slower, the
     //  load and the loop cost registers in the hottest function)
     // RICH: the indicators of earlier open kans are flipped here, in front of the dahai event, like the full path does
     // (state/mod.rs:1357-1361); the lean tier leaves a discard after a kan to the full path
     if (!RICH && G->pending_kan_dora > 0) { R4BAIL(q, 8); return; }
-    const int tt = tile >> 2;
     {
+        const int tt = tile >> 2;
         uint32_t fl = P->flags;
         const bool stage = fl & PF_RIICHI_STAGE;
         int nd = P->n_discards;
@@ -685,6 +776,8 @@ __device__ __forceinline__ void r4_resolve_discard(R4& q, int pid, int tile, boo
     }
     R4M(51);
     if (q.bail) return;
+    }   // (!RESUME)
+    const int tt = tile >> 2;
     // ---- B (lane = seat): Ron eligibility: a seat that waits on the tile and is not furiten needs the yaku check -> bail
     const PState& S4 = G->p[r & 3];
     const bool other = r < KNP && r != pid;
@@ -699,13 +792,28 @@ __device__ __forceinline__ void r4_resolve_discard(R4& q, int pid, int tile, boo
     // A seat in riichi that waits on the tile and is not furiten may win without a look at its yaku (riichi is one, the shape is
     // the cached wait: calc.is_win of legal_actions.rs:254-310 is true): RICH offers that Ron here; any other seat that could
     // win needs the evaluator - full path.
-    const uint32_t ron_m = rballot(other && !in_discards && !in_missed && !furiten && ((W >> tt) & 1ull), rb) & 0xFu;
-    if (ron_m && (!RICH || (ron_m & ~riichi_m))) { R4BAIL(q, 9); return; }
+    uint32_t ron_m = rballot(other && !in_discards && !in_missed && !furiten && ((W >> tt) & 1ull), rb) & 0xFu;
+    if (ron_m && !RICH) { R4BAIL(q, 9); return; }
+    if (RICH && (ron_m & ~riichi_m)) {
+        // seats that wait on the tile without a riichi: their yaku decide.  Pass 1 pauses here - the evaluator runs between the passes
+        // (r4_yaku_answers), pass 2 resumes with its answers: a shape without a yaku costs the seat its turn's Ron chances
+        // (state/mod.rs:1386-1389)
+        if (!RESUME) {
+            if (q.pause_ok) q.rend = R4_RE_YAKU_CLAIMS; else R4BAIL(q, 9);
+            return;
+        }
+        const uint32_t ok_m = (ron_m & riichi_m) | (q.yk & ron_m & ~riichi_m), miss_m = (q.yk >> 4) & ron_m & ~riichi_m;
+        if (r < 4 && ((miss_m >> r) & 1u)) G->p[r].flags |= PF_MISSED_DOUJUN;
+        q.dirty |= miss_m;
+        ron_m = ok_m;
+        wave_sync();
+    }
     w_mine = r < 4 ? W : 0ull;
     const bool can_call = G->drawable_count > 0;
     const bool kuikae = (q.E->rule_bits & RMJ_RULE_KUIKAE_FORBIDDEN) != 0;
     R4M(52);
-    int nl0 = 0, nl1 = 0, nl2 = 0, nl3 = 0;   // list length of each seat so far (row-uniform; no indexed array: no scratch)
+    // list length of each seat so far (row-uniform; no indexed array: no scratch); a Ron is the first entry of its seat's list
+    int nl0 = (RICH && (ron_m & 1u)) ? 1 : 0, nl1 = (RICH && (ron_m & 2u)) ? 1 : 0, nl2 = (RICH && (ron_m & 4u)) ? 1 : 0, nl3 = (RICH && (ron_m & 8u)) ? 1 : 0;
     auto nl_get = [&](int i) { return i == 0 ? nl0 : (i == 1 ? nl1 : (i == 2 ? nl2 : nl3)); };
     auto nl_set = [&](int i, int v) {
         nl0 = i == 0 ? v : nl0; nl1 = i == 1 ? v : nl1; nl2 = i == 2 ? v : nl2; nl3 = i == 3 ? v : nl3;
@@ -785,11 +893,8 @@ __device__ __forceinline__ void r4_resolve_discard(R4& q, int pid, int tile, boo
     R4M(54);
     // ---- E: Pass, lengths, stale counts (lane = seat)
     int n_me = r < 4 ? nl_get(r) : 0;
-    if (RICH && ron_m) {   // (a seat in riichi has no other claim: its list is Ron, Pass)
-        if (r < 4 && ((ron_m >> r) & 1u)) {
-            q.T->lst[q.row][r][0] = mk_action(RMJ_RON, tile, 0) | ((uint64_t)(KSANMA ? 56 : 79) << 56);
-            n_me = 1;
-        }
+    if (RICH && ron_m) {   // (slot 0 of the seat's list was kept free above; a seat in riichi has no other claim: its list is Ron, Pass)
+        if (r < 4 && ((ron_m >> r) & 1u)) q.T->lst[q.row][r][0] = mk_action(RMJ_RON, tile, 0) | ((uint64_t)(KSANMA ? 56 : 79) << 56);
         if (r == 0) G->ron_offer_mask = (uint8_t)ron_m;
     }
     if (rballot(r < 4 && n_me + 1 > R4_LIST, rb)) { R4BAIL(q, 10); return; }
@@ -863,9 +968,17 @@ __device__ __forceinline__ void r4_gen_act_legal(R4& q, int& nl_mine) {
             // a complete hand.  Concealed (no meld but Ankan): menzen tsumo is a yaku, so the win is legal without the evaluator
             // (calc.is_win of legal_actions.rs:44-61 is true) - RICH lists Tsumo here; an open hand needs its yaku: full path.
             const bool concealed = rballot(r < nmelds && P->meld_type[r & 3] != RMJ_MELD_ANKAN, rb) == 0u;
-            if (!RICH || !concealed) { R4BAIL(q, 13); return; }
-            if (r == 0) r4_put(q, pid, n, mk_action(RMJ_TSUMO, drawn_tile, 0), KSANMA ? 56 : 79);
-            n += 1;
+            if (!RICH) { R4BAIL(q, 13); return; }
+            bool offer = concealed;
+            if (!concealed) {   // an open hand needs a yaku (legal_actions.rs:44-61): pass 1 pauses, pass 2 has the evaluator's answer
+                if (q.yk_mode == R4_RE_YAKU_TSUMO) offer = (q.yk & 1u) != 0u;
+                else if (q.pause_ok) { q.rend = R4_RE_YAKU_TSUMO; return; }
+                else { R4BAIL(q, 13); return; }
+            }
+            if (offer) {
+                if (r == 0) r4_put(q, pid, n, mk_action(RMJ_TSUMO, drawn_tile, 0), KSANMA ? 56 : 79);
+                n += 1;
+            }
         }
     }
     R4M(60);
@@ -994,10 +1107,6 @@ __device__ __forceinline__ void r4_gen_act_legal(R4& q, int& nl_mine) {
 // The dealer's first list then comes from r4_gen_act_legal like any other WaitAct state, and the row is published with the others.
 // Events of a round end go straight to the ring (up to nine per step: the staging area holds four).
 // Out of line: its registers and code are not the hot path's.
-#define R4_RE_DRAW 1u      /* exhaustive draw */
-#define R4_RE_RESTART 2u   /* a finished game restarts (auto-reset) */
-#define R4_RE_PUB 3u       /* pass 2 of step4_body: the round has been dealt, the row's observation is still to be published */
-#define R4_RET_ROUND 0x100u /* step4_body's result: some row of the wave ends a round - the caller runs r4_round_end and pass 2 */
 // one MJAI record of the row's game straight to the ring: lane r < 8 holds dword r
 __device__ __forceinline__ void r4_emit_now(R4& q, bool on, uint32_t w) {
     if (q.E->skip_log) return;
@@ -1019,7 +1128,7 @@ __device__ __noinline__ void r4_round_end(const Env* Ep, uint32_t g0) {
     GState* G = &sh.st[row];
     R4 q;
     q.G = G; q.T = &sh.u.t; q.E = &E; q.lane = lane; q.r = r; q.rb = rb; q.row = row; q.g = g0 + (uint32_t)row;
-    q.live = mode != 0u; q.bail = false; q.cont = 0; q.rend = mode; q.evn = 0; q.dirty = 0xFu;
+    q.live = mode != 0u; q.bail = false; q.cont = 0; q.rend = mode; q.evn = 0; q.dirty = 0xFu; q.pause_ok = false; q.yk = 0u; q.yk_mode = 0u;
     const bool draw = mode == R4_RE_DRAW, restart = mode == R4_RE_RESTART;
     bool newround = restart;            // the row's game starts a round below, with these parameters (row-uniform)
     int n_oya = 0, n_rw = 0, n_honba = 0;
@@ -1299,6 +1408,59 @@ __device__ __noinline__ void r4_round_end(const Env* Ep, uint32_t g0) {
         }
         wave_sync();
     }
+}
+
+// The evaluator between the passes of a step (out of line; no call sits in the step function itself - a call there costs every step
+// its callee-saved registers): rows that paused for a yaku check (R4_RE_YAKU_CLAIMS: the seats without a riichi that wait on the
+// discard; R4_RE_YAKU_TSUMO: the drawer's complete open hand) get their answers into Quad4Shared::yk.  One loop serves both kinds: each
+// pass evaluates one (seat, tile) per row.
+__device__ __noinline__ void r4_yaku_answers() {
+    const int lane = threadIdx.x & 63, row = lane >> 4, r = lane & 15, rb = lane & 48;
+    Quad4Shared& sh = g_q4;
+    const GState* G = &sh.st[row];
+    const uint32_t mode = sh.rmode[row];
+    const bool claims = mode == R4_RE_YAKU_CLAIMS, tsumo = mode == R4_RE_YAKU_TSUMO;
+    uint32_t todo = 0u;
+    const int tile = claims ? (int)G->last_discard_tile : (int)G->drawn_tile;
+    if (__ballot(claims)) {   // the candidates of section B of r4_resolve_discard (lane = seat)
+        const int pid = G->last_discard_pid, tt = tile >> 2;
+        const PState& S4 = G->p[r & 3];
+        const bool other = claims && r < KNP && r != pid;
+        const uint32_t qfl = S4.flags;
+        const bool holds13 = other && (S4.hand_len + 3 * S4.n_melds == 13);
+        const uint64_t W = holds13 ? S4.waits13 : 0ull;
+        const uint64_t dtm = S4.discard_type_mask;
+        const bool in_discards = (dtm >> tt) & 1ull;
+        const bool in_missed = (qfl & PF_MISSED_DOUJUN) || ((qfl & PF_RIICHI_DECLARED) && (qfl & PF_MISSED_RIICHI));
+        const bool furiten = (W & dtm) != 0ull || (qfl & (PF_MISSED_RIICHI | PF_MISSED_DOUJUN));
+        const uint32_t riichi_m = rballot(r < 4 && (qfl & PF_RIICHI_DECLARED), rb) & 0xFu;
+        todo = rballot(other && !in_discards && !in_missed && !furiten && ((W >> tt) & 1ull), rb) & 0xFu & ~riichi_m;
+    }
+    if (tsumo) todo = 1u << G->current_player;
+    uint32_t ok_m = 0u, miss_m = 0u, han_m = 0u;
+    while (__ballot(todo != 0u)) {
+        const uint32_t on = todo != 0u ? 1u : 0u;
+        const int i = on ? __ffs((int)todo) - 1 : 0;
+        todo &= todo - 1u;
+        const uint32_t fl_i = G->p[i].flags;
+        uint32_t cf = ((fl_i & PF_RIICHI_DECLARED) ? CF_RIICHI : 0u) | ((fl_i & PF_DOUBLE_RIICHI) ? CF_DOUBLE_RIICHI : 0u) | ((fl_i & PF_IPPATSU) ? CF_IPPATSU : 0u);
+        if (tsumo) {
+            cf |= CF_TSUMO;
+            if (G->drawable_count == 0 && !G->is_rinshan) cf |= CF_HAITEI;
+            if (G->is_rinshan) cf |= CF_RINSHAN;
+            if (G->is_first_turn && G->p[i].n_discards == 0) cf |= CF_FIRST_TURN;   // quirk Q5
+        } else if (G->drawable_count == 0 && !G->is_rinshan) {
+            cf |= CF_HOUTEI;
+        }
+        const uint32_t res = r4_yaku_check(on, (uint32_t)i, (uint32_t)tile, cf);
+        if (on) {
+            if (res & 1u) ok_m |= 1u << i;
+            else if (res & 2u) miss_m |= 1u << i;
+            if (res & 4u) han_m |= 1u << i;
+        }
+    }
+    if (r == 0) sh.yk[row] = tsumo ? (((ok_m & han_m) != 0u) ? 1u : 0u) : (ok_m | (miss_m << 4));
+    wave_sync();
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------
@@ -1590,8 +1752,14 @@ __device__ __forceinline__ uint32_t step4_body(const Env* Ep, Quad4Shared& sh, u
     }
     // ---- policy (lane = seat): RandomAgent keyed per (game, step, seat), see k_step; POL = 1: the greedy policy (r4_policy_greedy)
     uint64_t mine = RMJ_NO_ACTION;
+    q.pause_ok = RMJ_ROW_ROUND_END && !pass2;
+    q.yk = 0u; q.yk_mode = 0u;
     if (pass2) {
-        if (q.live) q.rend = R4_RE_PUB;
+        if (q.live) {
+            q.rend = R4_RE_PUB;
+            const uint32_t md = sh.rmode[row];
+            if (md >= R4_RE_YAKU_CLAIMS) { q.yk_mode = md; q.yk = sh.yk[row]; }
+        }
     } else if (q.live && G->is_done) {   // finished game: restart (auto-reset: in row form) or nothing to do (full path)
         if (RMJ_ROW_ROUND_END && (flags & STEP_F_AUTORESET)) q.rend = R4_RE_RESTART; else R4BAIL(q, 18);
     }
@@ -2101,8 +2269,17 @@ __device__ __forceinline__ uint32_t step4_body(const Env* Ep, Quad4Shared& sh, u
     R4T(2);
     // rows whose round ended (an exhaustive draw above, a finished game under auto-reset) stop here in pass 1: ryukyoku, next round or end
     // of game and the deal happen between the passes (r4_round_end), their observation is pass 2's
-    const bool wait_deal = RMJ_ROW_ROUND_END && !pass2 && t0 && !q.bail && q.rend != 0u;
+    bool wait_deal = RMJ_ROW_ROUND_END && !pass2 && t0 && !q.bail && q.rend != 0u;
     if (q.rend) q.dirty = 0xFu;
+    if (pass2 && RICH && __ballot(t0 && q.yk_mode == R4_RE_YAKU_CLAIMS)) {
+        // pass 2 of a row that paused at its discard's Ron check: the rest of _resolve_discard with the evaluator's answers.  Whatever makes
+        // it leave tier 0 now continues in the full path from HERE (the claims of the discard already made: STEP_F_CONT_CLAIMS), an
+        // exhaustive draw at the exhaustive draw (STEP_F_CONT_RYU, set by r4_deal_next)
+        if (t0 && q.yk_mode == R4_RE_YAKU_CLAIMS) {
+            r4_resolve_discard<RICH, LOOP, true>(q, G->last_discard_pid, G->last_discard_tile, false, pf, nl_mine, w_mine);
+            if (q.bail && q.cont == 0) q.cont = 3;
+        }
+    }
     if (t0 && !wait_deal) {
         // ---- the next observation: a WaitAct state needs the acting seat's list
         if (!q.bail && G->phase == RMJ_WAIT_ACT && !(q.rend && G->is_done)) {
@@ -2111,6 +2288,7 @@ __device__ __forceinline__ uint32_t step4_body(const Env* Ep, Quad4Shared& sh, u
             r4_gen_act_legal<RICH>(q, nl_mine);
             if (q.rend && q.bail) q.cont = 2;   // (a dealt hand tier 0 has no list for: the full path publishes the state as it stands)
         }
+        if (RMJ_ROW_ROUND_END && !pass2 && !q.bail && q.rend != 0u) wait_deal = true;   // (paused at the list's Tsumo check)
     }
     R4M(45);
     R4T(3);
@@ -2199,7 +2377,7 @@ __device__ __forceinline__ uint32_t step4_body(const Env* Ep, Quad4Shared& sh, u
     R4T(5);
     // ---- bailed games: the complete state machine, one game at a time, from the untouched HBM record
     uint64_t bm = __ballot(q.live && q.bail && r == 0);
-    const uint32_t fl_full = (INLR ? fl_pub : flags) | (q.cont == 1 ? STEP_F_CONT_RYU : 0u) | (q.cont == 2 ? STEP_F_CONT_FIN : 0u);   // (per row)
+    const uint32_t fl_full = (INLR ? fl_pub : flags) | (q.cont == 1 ? STEP_F_CONT_RYU : 0u) | (q.cont == 2 ? STEP_F_CONT_FIN : 0u) | (q.cont == 3 ? STEP_F_CONT_CLAIMS : 0u);   // (per row)
 #ifdef RMJ_TL4
     if (!LOOP && lane == 0) rmj::g_tl4[(size_t)blockIdx.x * RMJ_TL4_ROW + 7] = (unsigned long long)__popcll(bm);
 #endif
@@ -2256,7 +2434,9 @@ __device__ __noinline__ void step4_pass2(const Env* Ep, uint32_t flags, uint32_t
 }
 template <bool LOOP, int POL>
 __device__ __forceinline__ void step4_finish_rounds(const Env* Ep, uint32_t flags, uint32_t g_base, uint32_t g_end, uint32_t quad = 0xFFFFFFFFu) {
-    r4_round_end(Ep, g_base + (quad == 0xFFFFFFFFu ? blockIdx.x : quad) * r4_rows(flags));
+    const uint32_t md = g_q4.rmode[(threadIdx.x & 63u) >> 4];
+    if (__ballot(md == R4_RE_DRAW || md == R4_RE_RESTART)) r4_round_end(Ep, g_base + (quad == 0xFFFFFFFFu ? blockIdx.x : quad) * r4_rows(flags));
+    if (__ballot(md >= R4_RE_YAKU_CLAIMS)) r4_yaku_answers();
     step4_pass2<LOOP, POL>(Ep, flags, g_base, g_end, quad);
 }
 // ... with inline responses (step4_body<.., INLR>): `left` steps to go per row, returns the steps taken per row
@@ -2302,9 +2482,16 @@ __device__ __forceinline__ void step4_run(const Env* Ep, uint64_t policy_seed, u
 // slowest wave (the one that restarts a round), and at 65 536 games (16 384 waves = two generations of resident waves)
 // that tail costs as much as the work; the loop pays it once per rollout.  POL: 0 = RandomAgent / the caller's actions, 1 = the
 // greedy policy (r4_policy_greedy).
+// Heavy-first launch order of the per-step kernel (LOOP = false, whole-batch launches).  A launch ends with its slowest wave, and
+// which waves will be slow is known one step ahead: a game whose wall is exhausted ends its round with the next discard (r4_round_end:
+// twice a plain wave's lifetime), a finished game restarts, an offered Ron may be taken (settlement: full path).  Every wave leaves a
+// note for the next launch - its unit in a list (one atomic) and a flag - and the next launch starts with `front` blocks that take the
+// listed units; the blocks behind them serve the others in place and leave at once where a front block has been.  Hints only: the two
+// arrays are written by one launch and read by the next, so every unit is served exactly once whatever happened in between.
+// (struct HeavyOrder: rmj_common.hip.h)
 template <bool LOOP, int POL>
 __global__ __launch_bounds__(64, RMJ_STEP4_WAVES) void k_step4(const Env* __restrict__ Ep, uint64_t policy_seed, uint32_t flags, uint32_t g_base,
-                                                                   uint32_t g_end, uint32_t n_steps, const uint64_t* __restrict__ actions) {
+                                                                   uint32_t g_end, uint32_t n_steps, const uint64_t* __restrict__ actions, HeavyOrder ho) {
     if (LOOP) {
         const uint32_t row_ = (threadIdx.x & 63u) >> 4;
         const uint32_t g = row_ < r4_rows(flags) ? g_base + blockIdx.x * r4_rows(flags) + row_ : 0xFFFFFFFFu;   // (rows beyond the wave's games idle)
@@ -2315,11 +2502,36 @@ __global__ __launch_bounds__(64, RMJ_STEP4_WAVES) void k_step4(const Env* __rest
 #ifdef RMJ_TL4
         const unsigned long long rt0 = __builtin_amdgcn_s_memrealtime();
 #endif
-        const uint32_t ret = step4_body<false, POL>(Ep, sh, policy_seed, flags, g_base, g_end, true, 0ull, actions);
+        uint32_t unit = blockIdx.x;
+        if (ho.in_cnt) {
+            if (blockIdx.x == 0 && (threadIdx.x & 63) == 0) *ho.zero_cnt = 0u;
+            if (blockIdx.x < ho.front) {
+                if (blockIdx.x >= uni(*ho.in_cnt)) return;
+                unit = uni(ho.in_list[blockIdx.x]);
+            } else {
+                unit = blockIdx.x - ho.front;
+                if (uni((uint32_t)ho.in_flag[unit])) return;
+            }
+        }
+        const uint32_t ret = step4_body<false, POL>(Ep, sh, policy_seed, flags, g_base, g_end, true, 0ull, actions, unit);
 #ifdef RMJ_TL4
         if ((threadIdx.x & 63) == 0) rmj::g_tl4[(size_t)blockIdx.x * RMJ_TL4_ROW + 15] = __ballot((ret & R4_RET_ROUND) != 0u) ? 1ull : 0ull;   // the wave ends rounds
 #endif
-        if (RMJ_ROW_ROUND_END && __ballot((ret & R4_RET_ROUND) != 0u)) step4_finish_rounds<false, POL>(Ep, flags, g_base, g_end);
+        if (RMJ_ROW_ROUND_END && __ballot((ret & R4_RET_ROUND) != 0u)) step4_finish_rounds<false, POL>(Ep, flags, g_base, g_end, unit);
+        if (ho.out_cnt) {   // the note for the next launch
+            const int row = (threadIdx.x & 63) >> 4;
+            const GState& S = sh.st[row];
+            const uint32_t gq = g_base + unit * r4_rows(flags) + (uint32_t)row;
+            const bool hv = (uint32_t)row < r4_rows(flags) && gq < g_end &&
+                            (S.is_done ? (flags & STEP_F_AUTORESET) != 0u : ((S.phase == RMJ_WAIT_ACT && S.drawable_count == 0) || S.ron_offer_mask != 0));
+            const bool any = __ballot(hv) != 0ull;
+            if ((threadIdx.x & 63) == 0) {
+                uint32_t idx = 0xFFFFFFFFu;
+                if (any) idx = atomicAdd(ho.out_cnt, 1u);
+                if (idx < ho.front) ho.out_list[idx] = unit;
+                ho.out_flag[unit] = idx < ho.front ? 1 : 0;
+            }
+        }
 #ifdef RMJ_TL4
         const unsigned long long rt1 = __builtin_amdgcn_s_memrealtime();
         if ((threadIdx.x & 63) == 0) {

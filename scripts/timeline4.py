@@ -28,6 +28,7 @@ def main():
     os.environ["RMJ_STEP_STREAMS"] = "1"
     L = vecenv.load_lib()
     waves = (games + 3) // 4
+    waves += waves // 4          # (heavy-first order: the front blocks)
     buf = np.zeros((waves, 32), dtype=np.uint64)
     L.rmj_tl4_fetch(buf.ctypes.data_as(C.c_void_p), waves)       # allocates the rows before any kernel runs
     env = vecenv.VecRiichiEnv(games, game_mode=mode, seed=0)
@@ -48,6 +49,8 @@ def main():
         env.step_random(0xC0FFEE, 1, auto_reset=True)
         L.rmj_tl4_fetch(buf.ctypes.data_as(C.c_void_p), waves)
         sec += buf[:, :7].astype(np.float64).mean(axis=0)
+        ran = buf[:, 9] > 0          # blocks that served a unit (heavy-first order: the others left at once)
+        buf_all, buf = buf, buf[ran]
         t0, t1 = buf[:, 8].astype(np.int64), buf[:, 9].astype(np.int64)
         z = t0.min()
         life = (t1 - t0) / 100.0
@@ -79,6 +82,7 @@ def main():
         why = buf[:, 10:14].astype(np.int64).ravel()
         for s_, c_ in zip(*np.unique(why[why > 0] - 1, return_counts=True)):
             sites[int(s_)] = sites.get(int(s_), 0) + int(c_)
+        buf = buf_all
     out = {"waves_per_launch": waves, "launches": n,
            "sections_core_cycles_per_wave": {name: sec[k] / n for k, name in enumerate(NAMES)},
            "us": {k: v / n for k, v in acc.items() if k not in ("bail_waves", "multi_bail_waves", "bail_rows", "round_end_waves")},

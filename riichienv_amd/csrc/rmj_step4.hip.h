@@ -26,6 +26,8 @@ namespace RMJ_NS {
 #define R4_RE_PUB 3u       /* pass 2 of step4_body: the round has been dealt, the row's observation is still to be published */
 #define R4_RE_YAKU_CLAIMS 4u /* paused in r4_resolve_discard: seats without a riichi wait on the discard - their yaku decide (pass 2 resumes there) */
 #define R4_RE_YAKU_TSUMO 5u  /* paused in r4_gen_act_legal: an open hand is complete - its yaku decide whether Tsumo is offered */
+#define R4_RE_WIN_TSUMO 6u   /* the drawer's Tsumo: settled between the passes (r4_round_end) */
+#define R4_RE_WIN_RON 7u     /* Ron answers on the discard / the kan: settled between the passes; the winners' seats in Quad4Shared::yk */
 #define R4_RET_ROUND 0x100u /* step4_body's result: some row of the wave ends a round - the caller runs r4_round_end and pass 2 */
 // Games per wave of the non-ticket kernels (flags bits 20..21: 0 = four, 1 = one, 2 = two): a batch that gives the chip fewer than two
 // waves per SIMD at four games per wave is latency bound - the same rows spread over more waves hide each other's LDS / HBM round trips
@@ -35,6 +37,9 @@ __device__ __forceinline__ uint32_t r4_rows(uint32_t flags) {
     const uint32_t c = (flags >> STEP_F_ROWS_SHIFT) & 3u;
     return c == 0u ? 4u : c;
 }
+#ifndef RMJ_ROW_SETTLE
+#define RMJ_ROW_SETTLE 1      /* Tsumo / Ron settlements of the rich tier stay in tier 0 too (r4_round_end); 0: they bail to the full path */
+#endif
 #ifndef RMJ_ROW_ROUND_END
 #define RMJ_ROW_ROUND_END 1   /* exhaustive draws, next rounds and restarts stay in tier 0 (r4_round_end); 0: they enter the full path at the exit */
 #endif
@@ -611,7 +616,10 @@ __device__ __forceinline__ void r4_kan_draw(R4& q, int pid, PState* P, bool anka
 // held ones, a drawn tile is held already) under the condition flags cf - the legality form of seat_calc (no ura, no kita count:
 // legal_actions.rs:44-61, 254-310) through the row-form evaluator, the rows' seats side by side.  Every lane of the wave calls, rows
 // with on = 0 idle.  Result (row-uniform): bit 0 = WinResult.is_win, bit 1 = the hand has a win shape, bit 2 = yakuman or han >= 1.
-__device__ __forceinline__ uint32_t r4_yaku_check(uint32_t on, uint32_t seat, uint32_t tile, uint32_t cf) {
+// SETTLE: the settlement form (state/mod.rs:700-745, 990-1030): the caller's honba, ura indicators off the wall when `use_ura`
+// (_get_ura_indicators, state/mod.rs:2048-2057; 3P: pre-extracted W[9 + 2k]), the seat's Norths as Conditions.kita_count.
+template <bool SETTLE>
+__device__ __forceinline__ E4Out r4_seat_eval(uint32_t on, uint32_t seat, uint32_t tile, uint32_t cf, uint32_t honba, bool use_ura, const uint8_t* Wg) {
     const int lane = threadIdx.x & 63, row = lane >> 4, r = lane & 15, rb = lane & 48;
     const GState* G = &g_q4.st[row];
     const PState* P = &G->p[seat & 3u];
@@ -661,12 +669,29 @@ __device__ __forceinline__ uint32_t r4_yaku_check(uint32_t on, uint32_t seat, ui
         aka += is_aka((int)tile);
     }
     // lane = indicator
-    int dora;
+    int dora, ura = 0;
+    const int kita = (SETTLE && KSANMA && act) ? (int)P->n_kita : 0;
     {
         const bool is_d = act && r < 5 && r < (int)G->n_dora;
         int cnt = 0;
-        if (is_d) cnt = ph_cnt(full, next_dora34(((int)G->dora[r & 7] >> 2) < 34 ? ((int)G->dora[r & 7] >> 2) : 33, KSANMA));
+        if (is_d) {
+            const int nt = next_dora34(((int)G->dora[r & 7] >> 2) < 34 ? ((int)G->dora[r & 7] >> 2) : 33, KSANMA);
+            cnt = ph_cnt(full, nt);
+            if (SETTLE && KSANMA && nt == 30) cnt += kita;   // hand_evaluator_3p.rs:110-116
+        }
         dora = (int)e4_rsum((uint32_t)cnt, rb);
+        if (SETTLE) {
+            const int idx = KSANMA ? 9 + 2 * r : 5 + 2 * r;
+            int ucnt = 0;
+            if (is_d && use_ura && (KSANMA || idx < (int)G->live_end)) {
+                const uint32_t ww = __hip_atomic_load(reinterpret_cast<const uint32_t*>(Wg) + (idx >> 2), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const int wt = (int)((ww >> (8 * (idx & 3))) & 0xFFu) >> 2;
+                const int nt = next_dora34(wt < 34 ? wt : 33, KSANMA);
+                ucnt = ph_cnt(full, nt);
+                if (KSANMA && nt == 30) ucnt += kita;
+            }
+            ura = (int)e4_rsum((uint32_t)ucnt, rb);
+        }
     }
     E4In in;
     in.on = act;
@@ -674,7 +699,7 @@ __device__ __forceinline__ uint32_t r4_yaku_check(uint32_t on, uint32_t seat, ui
     in.ma = ma;
     in.win34 = win34;
     in.cf = cf;
-    in.dora = dora & 0xFF; in.aka = aka; in.ura = 0; in.nuki = 0;
+    in.dora = dora & 0xFF; in.aka = aka; in.ura = ura & 0xFF; in.nuki = kita;
     in.round_wind34 = 27 + ((int)G->round_wind & 3);
     {
         int sw = (int)(seat & 3u) + KNP - (int)G->oya;
@@ -682,8 +707,11 @@ __device__ __forceinline__ uint32_t r4_yaku_check(uint32_t on, uint32_t seat, ui
         in.seat_wind34 = 27 + (sw & 3);
     }
     in.sanma = KSANMA;
-    in.honba = G->honba;
-    const E4Out o = e4_calc(in, r, rb);
+    in.honba = SETTLE ? honba : (uint32_t)G->honba;
+    return e4_calc(in, r, rb);
+}
+__device__ __forceinline__ uint32_t r4_yaku_check(uint32_t on, uint32_t seat, uint32_t tile, uint32_t cf) {
+    const E4Out o = r4_seat_eval<false>(on, seat, tile, cf, 0u, false, nullptr);
     return (o.is_win ? 1u : 0u) | (o.shape ? 2u : 0u) | ((o.yakuman || o.han >= 1) ? 4u : 0u);
 }
 
@@ -1119,6 +1147,8 @@ __device__ __forceinline__ void r4_emit_now(R4& q, bool on, uint32_t w) {
     }
     wave_sync();
 }
+// RICH: with the settlements of the rich tier (the lean tier's Tsumo / Ron actions bail to the full path: its copy has no evaluator)
+template <bool RICH>
 __device__ __noinline__ void r4_round_end(const Env* Ep, uint32_t g0) {
     const int lane = threadIdx.x & 63, row = lane >> 4, r = lane & 15, rb = lane & 48;
     Quad4Shared& sh = g_q4;
@@ -1130,10 +1160,170 @@ __device__ __noinline__ void r4_round_end(const Env* Ep, uint32_t g0) {
     q.G = G; q.T = &sh.u.t; q.E = &E; q.lane = lane; q.r = r; q.rb = rb; q.row = row; q.g = g0 + (uint32_t)row;
     q.live = mode != 0u; q.bail = false; q.cont = 0; q.rend = mode; q.evn = 0; q.dirty = 0xFu; q.pause_ok = false; q.yk = 0u; q.yk_mode = 0u;
     const bool draw = mode == R4_RE_DRAW, restart = mode == R4_RE_RESTART;
+    const bool win_t = mode == R4_RE_WIN_TSUMO, win_r = mode == R4_RE_WIN_RON, win = win_t || win_r;
     bool newround = restart;            // the row's game starts a round below, with these parameters (row-uniform)
     int n_oya = 0, n_rw = 0, n_honba = 0;
     uint32_t n_sticks = 0u;
     const bool seat = r < KNP;
+    const int oya = G->oya;
+    bool oya_won = false;               // _initialize_next_round's first argument: the dealer won / is tenpai at the draw
+    if (RICH && RMJ_ROW_SETTLE && __ballot(win)) {
+        // ---- settlement of a Tsumo (state/mod.rs:690-880) or of the Ron answers (state/mod.rs:945-1142), rows side by side: one winner
+        // per row and pass (the Tsumo, then the Ron winners by distance from the discarder), the evaluation in row form with the settlement's
+        // conditions (r4_seat_eval<true>), the payments by lane = seat.
+        const uint8_t* Wg = E.wall + (size_t)q.g * RMJ_WALL_STRIDE;
+        const uint32_t rules = E.rule_bits;
+        const bool from_discard = G->last_discard_pid != 0xFF;
+        const int target = (win_r && from_discard) ? (int)G->last_discard_pid : (int)G->current_player;
+        const int win_tile = win_t ? (G->drawn_tile != 0xFF ? (int)G->drawn_tile : 0) : (from_discard ? (int)G->last_discard_tile : 0);
+        const uint32_t ron_m = win_r ? (sh.yk[row] & 0xFu) : 0u;
+        const uint32_t honba0 = G->honba;
+        int32_t total_d = 0;            // lane = seat: what the round's settlements pay the seat
+        bool honba_taken = false, deposit_taken = false;   // the first winner's hand counts the honba, the first win takes the deposit
+        for (int dist = 0; dist < KNP; dist++) {
+            int w = target + dist;
+            w = w >= KNP ? w - KNP : w;
+            const bool on = dist == 0 ? win_t : (win_r && ((ron_m >> w) & 1u) != 0u);
+            if (!__ballot(on)) continue;
+            const PState& Wp = G->p[w & 3];
+            const uint32_t wfl = on ? (uint32_t)Wp.flags : 0u;
+            const bool riichi = (wfl & PF_RIICHI_DECLARED) != 0u;
+            uint32_t cf = (riichi ? CF_RIICHI : 0u) | ((wfl & PF_DOUBLE_RIICHI) ? CF_DOUBLE_RIICHI : 0u) | ((wfl & PF_IPPATSU) ? CF_IPPATSU : 0u);
+            const bool last_tile = G->drawable_count == 0 && !G->is_rinshan;
+            if (win_t) {
+                cf |= CF_TSUMO;
+                if (last_tile) cf |= CF_HAITEI;
+                if (G->is_rinshan) cf |= CF_RINSHAN;
+                const bool no_melds = (G->p[0].n_melds | G->p[1].n_melds | G->p[2].n_melds | G->p[3].n_melds) == 0;
+                if (G->is_first_turn && no_melds) cf |= CF_FIRST_TURN;   // quirk Q5 (settlement form)
+            } else {
+                if (last_tile) cf |= CF_HOUTEI;
+                // a pending kita is a chankan-style claim but awards no chankan yaku (state_3p/mod.rs:896-902)
+                if (G->pending_kan_pid != 0xFF && a_type(G->pending_kan_action) != RMJ_KITA) cf |= CF_CHANKAN;
+            }
+            const uint32_t hb = honba_taken ? 0u : honba0;
+            if (on) honba_taken = true;
+            E4Out o = r4_seat_eval<true>(on ? 1u : 0u, (uint32_t)w, (uint32_t)win_tile, cf, hb, riichi, Wg);
+            const bool w_oya = w == oya;
+            if (o.yakuman && o.han > 13) {   // double-yakuman cap, state/mod.rs:720-745 / 1005-1030
+                int cap = 0;
+                if (((o.ym >> 47) & 1ull) && !(rules & RMJ_RULE_JUNSEI_CHUUREN_DOUBLE)) cap += 13;
+                if (((o.ym >> 48) & 1ull) && !(rules & RMJ_RULE_SUUANKOU_TANKI_DOUBLE)) cap += 13;
+                if (((o.ym >> 49) & 1ull) && !(rules & RMJ_RULE_KOKUSHI13_DOUBLE)) cap += 13;
+                if (((o.ym >> 50) & 1ull) && !(rules & RMJ_RULE_DAISUUSHII_DOUBLE)) cap += 13;
+                if (cap > 0) {
+                    const int hh = o.han > cap ? o.han - cap : 0;
+                    o.han = hh < 13 ? 13 : hh;
+                    const ScoreOut s2 = calc_score((uint32_t)o.han, 0u, w_oya, win_t, hb, (uint32_t)KNP);
+                    o.ron = s2.ron; o.tsumo_oya = s2.tsumo_oya; o.tsumo_ko = s2.tsumo_ko;
+                }
+            }
+            const bool won = on && o.is_win;   // (a listed Tsumo / Ron wins: the list entry was evaluated on this hand; ura and Norths only add han)
+            // yakuman values and pao liability (37 daisangen, 50 daisuushii) of the winner
+            int total_val = 0, pao_val = 0, pao_seat = -1;
+            if (won && o.yakuman) {
+                const uint64_t ids = (0x7FFull << 35) | (0xFull << 47);
+                total_val = __popcll(o.ym & ids);
+                if (((o.ym >> 47) & 1ull) && (rules & RMJ_RULE_JUNSEI_CHUUREN_DOUBLE)) total_val += 1;
+                if (((o.ym >> 48) & 1ull) && (rules & RMJ_RULE_SUUANKOU_TANKI_DOUBLE)) total_val += 1;
+                if (((o.ym >> 49) & 1ull) && (rules & RMJ_RULE_KOKUSHI13_DOUBLE)) total_val += 1;
+                const int v50 = (rules & RMJ_RULE_DAISUUSHII_DOUBLE) ? 2 : 1;
+                if (((o.ym >> 50) & 1ull) && v50 == 2) total_val += 1;
+                if (((o.ym >> 37) & 1ull) && Wp.pao37 != 0xFF) { pao_val += 1; pao_seat = Wp.pao37; }
+                if (((o.ym >> 50) & 1ull) && Wp.pao50 != 0xFF) { pao_val += v50; pao_seat = Wp.pao50; }
+            }
+            const int32_t sticks = (won && !deposit_taken) ? (int32_t)(G->riichi_sticks * 1000u) : 0;
+            int32_t d = 0;              // lane = seat: this winner's payments
+            {
+                if (won && win_t && r < KNP && r != w) {
+                    if (pao_val > 0) {
+                        // state_3p/mod.rs:713-721: (np-1)*16000 for the dealer, 16000+(np-2)*8000 otherwise
+                        const int32_t unit = w_oya ? (KNP - 1) * 16000 : 16000 + (KNP - 2) * 8000;
+                        const int32_t honba_total = (int32_t)hb * (KNP - 1) * 100;
+                        if (rules & RMJ_RULE_PAO_LIABILITY_ONLY) {
+                            const int32_t non = total_val - pao_val;
+                            if (non > 0) d -= (w_oya || r == oya) ? non * 16000 : non * 8000;
+                            if (r == pao_seat) d -= pao_val * unit + honba_total;
+                        } else if (r == pao_seat) {
+                            d -= total_val * unit + honba_total;
+                        }
+                    } else {
+                        d = -(int32_t)(w_oya ? o.tsumo_ko : (r == oya ? o.tsumo_oya : o.tsumo_ko));
+                    }
+                }
+                const int32_t tw = -(int32_t)e4_rsum((uint32_t)d, rb);   // what the others pay
+                if (won && win_t && r == w) d = tw + sticks;
+            }
+            if (won && win_r) {
+                const int32_t score = (int32_t)o.ron;
+                int payer = target;
+                int32_t pao_amt = 0;
+                if (pao_seat >= 0) {
+                    payer = pao_seat;
+                    const int32_t unit = w_oya ? 48000 : 32000;
+                    const int32_t honba_ron = (int32_t)hb * (KNP - 1) * 100;
+                    const int32_t split_base = (rules & RMJ_RULE_PAO_LIABILITY_ONLY) ? pao_val * unit : total_val * unit;
+                    pao_amt = split_base / 2 + honba_ron;
+                }
+                if (r == w) d += score + sticks;
+                if (r == payer) d -= pao_amt;
+                if (r == target) d -= score - pao_amt;
+            }
+            if (won) {
+                total_d += d;
+                if (w_oya) oya_won = true;
+                if (!deposit_taken && r == 0) G->riichi_sticks = 0u;
+                deposit_taken = true;
+            }
+            wave_sync();
+            {   // win_results.insert(seat, val) (state/mod.rs:855-863, 1100-1107): the capped result with its ordered yaku list, the pao payer
+                uint8_t* yl = reinterpret_cast<uint8_t*>(sh.rs + 6 * row);
+                if (r < 5) sh.rs[6 * row + r] = 0u;
+                wave_sync();
+                const int ny = e4_yaku_list(o.kind, o.ym, yl, r, rb);
+                wave_sync();
+                if (won && r < 12) {
+                    uint32_t v;
+                    if (r == 0) v = 1u | (o.yakuman ? 0x100u : 0u) | (o.shape ? 0x10000u : 0u) | ((uint32_t)ny << 24);
+                    else if (r < 6) v = sh.rs[6 * row + r - 1];
+                    else if (r == 6) v = (uint32_t)o.han;
+                    else if (r == 7) v = (uint32_t)o.fu;
+                    else if (r == 8) v = o.ron;
+                    else if (r == 9) v = o.tsumo_oya;
+                    else if (r == 10) v = o.tsumo_ko;
+                    else v = (uint32_t)(pao_seat & 0xFF);
+                    reinterpret_cast<uint32_t*>(E.win + (size_t)q.g * 4 + w)[r] = v;
+                }
+                if (won && r == 0) G->win_mask |= (uint8_t)(1u << w);
+                wave_sync();
+            }
+            {   // the hora event: this winner's deltas, the ura indicators of a riichi hand
+                const int idx = KSANMA ? 9 + 2 * r : 5 + 2 * r;
+                const bool uv = won && riichi && r < 5 && r < (int)G->n_dora && (KSANMA || idx < (int)G->live_end);
+                uint32_t ub = 0u;
+                if (uv) {
+                    const uint32_t ww = __hip_atomic_load(reinterpret_cast<const uint32_t*>(Wg) + (idx >> 2), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    ub = (ww >> (8 * (idx & 3))) & 0xFFu;
+                }
+                const uint32_t nu = (uint32_t)__popc(rballot(uv, rb));
+                const uint32_t u0 = (uint32_t)rbc((int)ub, rb), u1 = (uint32_t)rbc((int)ub, rb + 1), u2 = (uint32_t)rbc((int)ub, rb + 2);
+                const uint32_t u3 = (uint32_t)rbc((int)ub, rb + 3), u4 = (uint32_t)rbc((int)ub, rb + 4);
+                const int32_t dv = rbc(d, rb + ((r - 2) & 3));
+                uint32_t wv = 0u;
+                if (r == 0) wv = (uint32_t)RMJ_EV_HORA | ((uint32_t)w << 8) | ((uint32_t)target << 16);
+                else if (r >= 2 && r < 6) wv = (uint32_t)dv;
+                else if (r == 6) wv = (win_t ? 1u : 0u) | (nu << 8) | (u0 << 16) | (u1 << 24);
+                else if (r == 7) wv = u2 | (u3 << 8) | (u4 << 16);
+                r4_emit_now(q, won, wv);
+            }
+        }
+        if (win && r < 4) {
+            PState& S4 = G->p[r];
+            S4.score += total_d;
+            S4.score_delta = total_d;
+        }
+        wave_sync();
+    }
     if (__ballot(draw)) {
         // ---- tenpai of the seats (HandEvaluator::is_tenpai through the wait cache, like seat_tenpai): stale caches first
         {
@@ -1151,7 +1341,6 @@ __device__ __noinline__ void r4_round_end(const Env* Ep, uint32_t g0) {
         PState& S4 = G->p[r & 3];
         const uint32_t tenpai_m = rballot(draw && seat && (S4.hand_len + 3 * S4.n_melds == 13) && S4.waits13 != 0ull, rb) & 0xFu;
         const uint32_t nag_m = rballot(draw && seat && (S4.flags & PF_NAGASHI), rb) & 0xFu;
-        const int oya = G->oya;
         int reason = RMJ_RK_EXHAUSTIVE;
         if (draw && seat) {
             int32_t sc = S4.score, sd = S4.score_delta;
@@ -1177,13 +1366,16 @@ __device__ __noinline__ void r4_round_end(const Env* Ep, uint32_t g0) {
         }
         if (nag_m) reason = RMJ_RK_NAGASHI;
         wave_sync();
-        const bool renchan = nag_m ? ((nag_m >> oya) & 1u) != 0u : ((tenpai_m >> oya) & 1u) != 0u;
+        if (draw) oya_won = nag_m ? ((nag_m >> oya) & 1u) != 0u : ((tenpai_m >> oya) & 1u) != 0u;
         {   // the ryukyoku event: deltas = the seats' score_delta
             const int32_t dv = (r >= 2 && r < 2 + KNP) ? G->p[(r - 2) & 3].score_delta : 0;
             const uint32_t w = r == 0 ? (uint32_t)RMJ_EV_RYUKYOKU : (r == 6 ? (uint32_t)reason : (uint32_t)dv);
             r4_emit_now(q, draw, (r == 1 || r == 7) ? 0u : w);
         }
-        // ---- _initialize_next_round(renchan, is_draw = true)
+    }
+    const bool decide = draw || win;
+    if (__ballot(decide)) {
+        // ---- _initialize_next_round(oya_won, is_draw) (state/mod.rs:1595-1700)
         {
             const int32_t goal = KSANMA ? 40000 : 30000;
             const int32_t s0 = G->p[0].score, s1 = G->p[1].score, s2 = G->p[2].score, s3 = KNP > 3 ? G->p[3].score : 0;
@@ -1202,10 +1394,10 @@ __device__ __noinline__ void r4_round_end(const Env* Ep, uint32_t g0) {
             bool last_regular = false;
             if (gm == 1u || gm == 4u) last_regular = rw == 0 && oya == KNP - 1;
             if (gm == 2u || gm == 5u) last_regular = rw == 1 && oya == KNP - 1;
-            bool end = neg || (renchan && last_regular && top && ds >= goal);
+            bool end = neg || (oya_won && last_regular && top && ds >= goal);
             int next_honba = G->honba, next_oya = oya, next_rw = rw;
-            next_honba = next_honba + 1 > 255 ? 255 : next_honba + 1;   // a draw keeps counting whoever deals next
-            if (!renchan) {
+            next_honba = (oya_won || draw) ? (next_honba + 1 > 255 ? 255 : next_honba + 1) : 0;   // (a draw keeps counting whoever deals next)
+            if (!oya_won) {
                 next_oya = next_oya + 1 == KNP ? 0 : next_oya + 1;
                 if (next_oya == 0) next_rw += 1;
             }
@@ -1215,10 +1407,10 @@ __device__ __noinline__ void r4_round_end(const Env* Ep, uint32_t g0) {
                 else if (gm == 0u || gm == 3u) end = true;
                 else end = next_rw >= 1;
             }
-            if (draw && end && r == 0) G->is_done = 1;   // process_end_game
-            r4_emit_now(q, draw, r == 0 ? (uint32_t)RMJ_EV_END_KYOKU : 0u);
-            if (__ballot(draw && end)) r4_emit_now(q, draw && end, r == 0 ? (uint32_t)RMJ_EV_END_GAME : 0u);
-            if (draw && !end) {
+            if (decide && end && r == 0) G->is_done = 1;   // process_end_game
+            r4_emit_now(q, decide, r == 0 ? (uint32_t)RMJ_EV_END_KYOKU : 0u);
+            if (__ballot(decide && end)) r4_emit_now(q, decide && end, r == 0 ? (uint32_t)RMJ_EV_END_GAME : 0u);
+            if (decide && !end) {
                 newround = true;
                 n_oya = next_oya; n_rw = next_rw; n_honba = next_honba; n_sticks = G->riichi_sticks;
             }
@@ -1758,7 +1950,7 @@ __device__ __forceinline__ uint32_t step4_body(const Env* Ep, Quad4Shared& sh, u
         if (q.live) {
             q.rend = R4_RE_PUB;
             const uint32_t md = sh.rmode[row];
-            if (md >= R4_RE_YAKU_CLAIMS) { q.yk_mode = md; q.yk = sh.yk[row]; }
+            if (md == R4_RE_YAKU_CLAIMS || md == R4_RE_YAKU_TSUMO) { q.yk_mode = md; q.yk = sh.yk[row]; }
         }
     } else if (q.live && G->is_done) {   // finished game: restart (auto-reset: in row form) or nothing to do (full path)
         if (RMJ_ROW_ROUND_END && (flags & STEP_F_AUTORESET)) q.rend = R4_RE_RESTART; else R4BAIL(q, 18);
@@ -2055,8 +2247,10 @@ __device__ __forceinline__ uint32_t step4_body(const Env* Ep, Quad4Shared& sh, u
                         }
                     }
                 }
+            } else if (RICH && RMJ_ROW_SETTLE && ty == RMJ_TSUMO && q.pause_ok) {
+                q.rend = R4_RE_WIN_TSUMO;   // the settlement, the next round or the end of the game between the passes (r4_round_end)
             } else {
-                R4BAIL(q, 23);   // Riichi (with a tile), Tsumo, Kyushu; lean tier: kans
+                R4BAIL(q, 23);   // Riichi (with a tile), Kyushu; lean tier: kans, Tsumo
             }
         }
         uint64_t mine_r = mine;   // the seats' responses (lane = seat)
@@ -2116,8 +2310,18 @@ __device__ __forceinline__ uint32_t step4_body(const Env* Ep, Quad4Shared& sh, u
             const bool is_act = has && ((act_m >> r) & 1u);
             const uint32_t roned = rballot(has && my_ty == RMJ_RON, rb) & 0xFu;
             const uint32_t offer = G->ron_offer_mask;
-            if (roned & act_m) {
-                R4BAIL(q, 24);                                    // Ron settlement
+            if (roned & act_m) {                                  // Ron settlement
+                if (RICH && RMJ_ROW_SETTLE && q.pause_ok && !(!KSANMA && __popc(roned & act_m) >= 3 && (E.rule_bits & RMJ_RULE_SANCHAHO_DRAW))) {
+                    if (r < 4 && ((offer & ~roned) >> r) & 1u) {  // a Ron offer that was not taken (state/mod.rs:905-915 runs before the settlement)
+                        uint32_t fl = G->p[r].flags | PF_MISSED_DOUJUN;
+                        if (fl & PF_RIICHI_DECLARED) fl |= PF_MISSED_RIICHI;
+                        G->p[r].flags = (uint8_t)fl;
+                    }
+                    if (r == 0) sh.yk[row] = roned & act_m;
+                    q.rend = R4_RE_WIN_RON;                       // between the passes (r4_round_end)
+                } else {
+                    R4BAIL(q, 24);                                // (three Rons under the sanchaho rule: an abortive draw)
+                }
             } else {
                 if (r < 4 && ((offer & ~roned) >> r) & 1u) {      // a Ron offer that was not taken
                     uint32_t fl = G->p[r].flags | PF_MISSED_DOUJUN;
@@ -2434,9 +2638,11 @@ __device__ __noinline__ void step4_pass2(const Env* Ep, uint32_t flags, uint32_t
 }
 template <bool LOOP, int POL>
 __device__ __forceinline__ void step4_finish_rounds(const Env* Ep, uint32_t flags, uint32_t g_base, uint32_t g_end, uint32_t quad = 0xFFFFFFFFu) {
+    constexpr bool RICH = (POL == 1) || !LOOP;   // (step4_body's tier)
     const uint32_t md = g_q4.rmode[(threadIdx.x & 63u) >> 4];
-    if (__ballot(md == R4_RE_DRAW || md == R4_RE_RESTART)) r4_round_end(Ep, g_base + (quad == 0xFFFFFFFFu ? blockIdx.x : quad) * r4_rows(flags));
-    if (__ballot(md >= R4_RE_YAKU_CLAIMS)) r4_yaku_answers();
+    if (__ballot(md == R4_RE_DRAW || md == R4_RE_RESTART || md == R4_RE_WIN_TSUMO || md == R4_RE_WIN_RON))
+        r4_round_end<RICH>(Ep, g_base + (quad == 0xFFFFFFFFu ? blockIdx.x : quad) * r4_rows(flags));
+    if (RICH && __ballot(md == R4_RE_YAKU_CLAIMS || md == R4_RE_YAKU_TSUMO)) r4_yaku_answers();   // (the lean tier never pauses for a yaku check)
     step4_pass2<LOOP, POL>(Ep, flags, g_base, g_end, quad);
 }
 // ... with inline responses (step4_body<.., INLR>): `left` steps to go per row, returns the steps taken per row

@@ -75,7 +75,19 @@ def report(root):
     for cut, d in zip(cuts, ids[:-1]):
         per = {k: v / W for k, v in rows[d].items()}
         out["reach_mark"][str(cut)] = {"name": NAMES[cut], **per}
-        print(f"{cut:3d} {NAMES[cut]:52s} VALU {per.get('SQ_INSTS_VALU', 0):7.1f}  SALU {per.get('SQ_INSTS_SALU', 0):7.1f}  LDS {per.get('SQ_INSTS_LDS', 0):6.1f}")
+        line = f"{cut:3d} {NAMES[cut]:52s} VALU {per.get('SQ_INSTS_VALU', 0):7.1f}  SALU {per.get('SQ_INSTS_SALU', 0):7.1f}  LDS {per.get('SQ_INSTS_LDS', 0):6.1f}"
+        if per.get("SQ_ACTIVE_INST_VALU"):   # lane use: a second run with --pmc SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU (cumulative up to the mark)
+            line += f"  lanes/VALU-cycle {per['SQ_THREAD_CYCLES_VALU'] / per['SQ_ACTIVE_INST_VALU']:5.1f} of 64"
+        print(line)
+    # lane use of each section = difference of the cumulative counters between consecutive marks (marks in program order)
+    prev = None
+    for cut, d in zip(cuts, ids[:-1]):
+        cur = rows[d]
+        if prev is not None and cur.get("SQ_ACTIVE_INST_VALU") and cur["SQ_ACTIVE_INST_VALU"] > prev[1].get("SQ_ACTIVE_INST_VALU", 0):
+            da = cur["SQ_ACTIVE_INST_VALU"] - prev[1]["SQ_ACTIVE_INST_VALU"]
+            dt = cur["SQ_THREAD_CYCLES_VALU"] - prev[1]["SQ_THREAD_CYCLES_VALU"]
+            print(f"    section {prev[0]:3d} -> {cut:3d}: {dt / da:5.1f} lanes per VALU cycle ({dt / da / 64:.2f}), {da / W:8.1f} VALU cycles per wave")
+        prev = (cut, cur)
     json.dump(out, open(os.path.join(root, "valu_sections4.json"), "w"), indent=1)
 
 

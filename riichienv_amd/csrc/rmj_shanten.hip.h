@@ -389,6 +389,47 @@ __device__ __forceinline__ int sh_shanten_mod(const ShBase& B, int q, uint64_t n
     return s;
 }
 
+// Up to four (min,+) merges at once, one per 16-lane row: lane i < 10 of a row computes entry i of merge(a, b) for the row's
+// (row-uniform) inputs, the nibbles are OR-reduced over the row and handed to every lane of it.  ~100 VALU for four merges where
+// sh_merge takes ~210 for one (every lane of a wave computing the same 45 terms).
+__device__ __forceinline__ uint32_t sh_row_or16(uint32_t v) {
+    v |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, false);
+    v |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, false);
+    v |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, false);
+    v |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, false);
+    return v;   // lane 15 of the row holds the OR
+}
+__device__ __forceinline__ uint64_t sh_merge_rows(uint64_t a, uint64_t b, int lane) {
+    const int i = lane & 15;
+    const int p = i >= 5 ? 1 : 0, k = i - 5 * p;
+    uint32_t e = 0u;
+    if (i < 10)
+        e = sh_merge_entry((uint32_t)a & 0xFFFFFu, (uint32_t)(a >> 20) & 0xFFFFFu, (uint32_t)b & 0xFFFFFu, (uint32_t)(b >> 20) & 0xFFFFFu, p, k);
+    uint32_t lo = i < 8 ? e << (4 * i) : 0u, hi = (i >= 8 && i < 10) ? e << (4 * (i - 8)) : 0u;
+    lo = sh_row_or16(lo);
+    hi = sh_row_or16(hi);
+    return (uint64_t)lo | ((uint64_t)hi << 32);   // valid in lane 15 of every row
+}
+__device__ __forceinline__ uint64_t sh_rl64(uint64_t v, int src) {
+    return (uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)v, src) | ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(v >> 32), src) << 32);
+}
+// entry (pair, m) of merge(a, b) - the replacement number of a hand whose suits are split between a and b
+__device__ __forceinline__ int sh_entry_pm(uint64_t a, uint64_t b, int m) {
+    return (int)sh_merge_entry((uint32_t)a & 0xFFFFFu, (uint32_t)(a >> 20) & 0xFFFFFu, (uint32_t)b & 0xFFFFFu, (uint32_t)(b >> 20) & 0xFFFFFu, 1, m);
+}
+// normal / chiitoi / kokushi minimum (shanten.rs:228-241) given the normal form's replacement number
+__device__ __forceinline__ int sh_finish(int rep, const PH& x, int len_div3) {
+    int s = rep - 1;
+    if (s <= 0 || len_div3 < 4) return s;
+    const int c = sh_chiitoi(x, false);
+    s = c < s ? c : s;
+    if (s > 0) {
+        const int k = sh_kokushi(x);
+        s = k < s ? k : s;
+    }
+    return s;
+}
+
 // calculate_effective_tiles(_3p)_with_discard ("eff") and calculate_best_ukeire(_3p) ("uke"), shanten.rs:265-405 /
 // :488-626, for ONE wave-uniform hand: lane = drawn tile type (my_cnt / my_vis = this lane's held / visible count), the
 // loop over discard candidates runs over held types.  eff on a 3n hand yields 0xFFFFFFFF (the reference asserts).
@@ -405,7 +446,16 @@ __device__ inline void sh_ukeire_both(const ShantenTables& T, const PH& h, uint3
         // hand in one suit: sh_shanten_mod on a base of h, resp. of h minus the discard
         const int q = t < 34 ? t_suit(t) : 0, r = t < 34 ? t - 9 * q : 0;
         const uint32_t one = 1u << (3 * r);
-        const ShBase Bh = sh_base_wave(h, T, lane);
+        ShBase Bh;
+        {   // sh_base_wave with the two pair merges lane-parallel (rows 0 and 1)
+            const uint64_t mine = sh_vec(ph_get(h, lane & 3), lane & 3, T);
+#pragma unroll
+            for (int k = 0; k < 4; k++) Bh.v[k] = sh_rl64(mine, k);
+            const bool r0 = (lane >> 4) == 0;
+            const uint64_t M = sh_merge_rows(r0 ? Bh.v[0] : Bh.v[2], r0 ? Bh.v[1] : Bh.v[3], lane);
+            Bh.ab = sh_rl64(M, 15);
+            Bh.cd = sh_rl64(M, 31);
+        }
         const int m_h = total / 3 > 4 ? 4 : total / 3;
         const int cur = cur_in != -99 ? cur_in : ([&] {
             int s0 = (int)sh_merge_entry((uint32_t)Bh.ab & 0xFFFFFu, (uint32_t)(Bh.ab >> 20) & 0xFFFFFu, (uint32_t)Bh.cd & 0xFFFFFu,
@@ -430,16 +480,40 @@ __device__ inline void sh_ukeire_both(const ShantenTables& T, const PH& h, uint3
         if (want_eff && total % 3 == 0) eff = 0xFFFFFFFFu;
         const bool eff_loop = want_eff && total % 3 == 2;
         if (!eff_loop && !want_uke) return;
+        // Round 4: every hand of the walk is h - d + t.  (min,+) is associative, so its replacement number is ONE entry of a merge of two
+        // vectors that are known before the pair is looked at:
+        //   t in the suit of d            : entry(vec(h_q - d + t), O_q)      O_q = the three other suits of h merged (per hand)
+        //   t in the partner suit of d's  : entry(vec(h_q + t),     W_d)      W_d = vec(h_qd - d) (+) the other half of h (per d)
+        //   t in the other half           : entry(P_t,              H_d)      P_t = vec(h_q + t) (+) partner suit of h (per lane), H_d = vec(h_qd - d) (+) its partner suit (per d)
+        // - one table lookup per same-suit pair and no merge per pair; the merges per hand / per d run lane-parallel (sh_merge_rows).
+        const int m_loop = total / 3 > 4 ? 4 : total / 3;            // hands of the loop hold total tiles again (h - d + t)
+        const int m_sub = (total - 1) / 3 > 4 ? 4 : (total - 1) / 3;
+        uint64_t O_mine;                                              // O_q of this lane's suit
+        {
+            const int rw = lane >> 4;                                 // row rw computes O_rw
+            const uint64_t pa = rw == 0 ? Bh.v[1] : (rw == 1 ? Bh.v[0] : (rw == 2 ? Bh.v[3] : Bh.v[2]));
+            const uint64_t ot = rw < 2 ? Bh.cd : Bh.ab;
+            const uint64_t Om = sh_merge_rows(pa, ot, lane);
+            const uint64_t O0 = sh_rl64(Om, 15), O1 = sh_rl64(Om, 31), O2 = sh_rl64(Om, 47), O3 = sh_rl64(Om, 63);
+            O_mine = q == 0 ? O0 : (q == 1 ? O1 : (q == 2 ? O2 : O3));
+        }
         int nsh_l = 127;
         uint64_t nv_d = 0;
         if (t < 34 && ph_cnt(h, t) > 0) {
             PH sub = h;
             ph_sub(sub, t);
             nv_d = sh_vec(ph_get(h, q) - one, q, T);
-            nsh_l = sh_shanten_mod(Bh, q, nv_d, sub, (total - 1) / 3);
+            nsh_l = sh_finish(sh_entry_pm(nv_d, O_mine, m_sub), sub, (total - 1) / 3);
         }
         if (nsh_out) *nsh_out = nsh_l;
         uint64_t cand = __ballot(nsh_l <= cur);
+        if (!cand) return;
+        const bool drawable = t < 34 && ph_cnt(h, t) < 4;
+        uint64_t vt = 0, Pt = 0;
+        if (drawable) {
+            vt = sh_vec(ph_get(h, q) + one, q, T);
+            Pt = sh_merge(vt, q == 0 ? Bh.v[1] : (q == 1 ? Bh.v[0] : (q == 2 ? Bh.v[3] : Bh.v[2])));
+        }
         while (cand) {
             const int d = __ffsll((long long)cand) - 1;
             cand &= cand - 1ull;
@@ -447,18 +521,21 @@ __device__ inline void sh_ukeire_both(const ShantenTables& T, const PH& h, uint3
             const int qd = t_suit(d);
             PH sub = h;
             ph_sub(sub, d);
-            ShBase Bs = Bh;  // base of h minus d: the discarder's suit vector comes from lane d
-            const uint64_t V = (uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)nv_d, d) |
-                               ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(nv_d >> 32), d) << 32);
-            if (qd == 0) { Bs.v[0] = V; Bs.ab = sh_merge(V, Bh.v[1]); }
-            else if (qd == 1) { Bs.v[1] = V; Bs.ab = sh_merge(Bh.v[0], V); }
-            else if (qd == 2) { Bs.v[2] = V; Bs.cd = sh_merge(V, Bh.v[3]); }
-            else { Bs.v[3] = V; Bs.cd = sh_merge(Bh.v[2], V); }
+            const uint64_t V = sh_rl64(nv_d, d);
+            // row 0: H_d, row 1: W_d
+            const uint64_t pd = qd == 0 ? Bh.v[1] : (qd == 1 ? Bh.v[0] : (qd == 2 ? Bh.v[3] : Bh.v[2]));
+            const uint64_t xd = qd < 2 ? Bh.cd : Bh.ab;
+            const uint64_t HW = sh_merge_rows(V, (lane >> 4) == 0 ? pd : xd, lane);
+            const uint64_t Hd = sh_rl64(HW, 15), Wd = sh_rl64(HW, 31);
             bool f = false;
             if (t < 34 && ph_cnt(sub, t) < 4) {
                 PH x = sub;
                 ph_add(x, t);
-                f = sh_shanten_mod(Bs, q, sh_vec(ph_get(sub, q) + one, q, T), x, total / 3) < nsh;
+                uint64_t a, b;
+                if (q == qd) { a = sh_vec(ph_get(sub, q) + one, q, T); b = O_mine; }
+                else if ((q ^ 1) == qd) { a = vt; b = Wd; }
+                else { a = Pt; b = Hd; }
+                f = sh_finish(sh_entry_pm(a, b, m_loop), x, total / 3) < nsh;
             }
             const uint64_t fb = __ballot(f);
             if (eff_loop) {

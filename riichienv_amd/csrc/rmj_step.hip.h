@@ -1866,10 +1866,13 @@ __device__ __forceinline__ void step_game(Ctx& c, const uint64_t mine, bool trus
         const uint64_t a_pid = act_at(mine, pid);
         if (a_pid == RMJ_NO_ACTION) continue;
         int n = U((int)S.nlegal[pid]);
-        bool active = (U((uint32_t)S.active_mask) >> pid) & 1u;
+        // whose list counts: the reference regenerates the sender's legal actions (state/mod.rs:339-402) - in WaitAct those of the
+        // current player whether active_players names it or not (a poked state may not: tests/test_riichi_autoplay.py; its list is
+        // kept by finalize_outputs without being published), in WaitResponse those of the seats that were offered something
+        bool active = phase == RMJ_WAIT_ACT ? pid == U((int)S.current_player) : (((U((uint32_t)S.active_mask) >> pid) & 1u) != 0u);
         bool valid;
         if (!active || n == 0) {
-            // _get_legal_actions_internal for a non-active seat: [] in WaitAct, [Pass] in WaitResponse
+            // _get_legal_actions_internal for any other seat: [] in WaitAct, [Pass] in WaitResponse
             valid = phase == RMJ_WAIT_RESPONSE && a_match(mk_action(RMJ_PASS, RMJ_TILE_NONE, 0), a_pid);
         } else {
             bool hit = lane < n && a_match(c.Lg[pid * RMJ_MAX_LEGAL + lane], a_pid);
@@ -2335,18 +2338,21 @@ __device__ __forceinline__ void finalize_outputs(Ctx& c, bool claims_fresh, bool
     // are not to act are all zero and stay so: only the rows of the seats that had a list before this step (S.nlegal
     // still holds the previous publication) or have one now are rewritten - 82 B per row in 16-bit units.
     const uint32_t am = (uint32_t)__builtin_amdgcn_readfirstlane((int)S.active_mask);
+    // a current player that active_players does not name (poked states only): its list is stored for the validation of what it sends,
+    // like the reference regenerates it on demand, but nothing of it is published (its seat has no observation)
+    const uint32_t hidden = (!FAST && phase == RMJ_WAIT_ACT && !U((int)S.is_done) && am != 0u) ? ((1u << U((int)S.current_player)) & ~am & 0xFu) : 0u;
     // (all_rows: the last step of a fused rollout - its quiet steps published no mask rows, so every row is rewritten)
     const uint32_t rows = all_rows ? 0xFu : ((((uint32_t)__ballot(lane < 4 && S.nlegal[lane & 3] != 0)) | am) & 0xFu);
     for (int i = lane; i < (4 * 82 + 3) / 4; i += 64) reinterpret_cast<uint32_t*>(c.X.maskbuf)[i] = 0u;
     wave_sync();
-    for (uint32_t m = am; m; m &= m - 1u) {
+    for (uint32_t m = am | hidden; m; m &= m - 1u) {
         const int p = __ffs((int)m) - 1;
         const int n = U(c.X.nl[p]);
         if (lane < n) {
             uint64_t a = c.X.legal[p][lane];
             c.Lg[p * RMJ_MAX_LEGAL + lane] = a;
             int id = KSANMA ? a_encode_3p(a) : a_encode(a);  // 60 ids in 3P (observation_3p/python.rs:100-112)
-            if (id >= 0 && id < (KSANMA ? 60 : 82)) c.X.maskbuf[p * 82 + id] = 1;
+            if (id >= 0 && id < (KSANMA ? 60 : 82) && ((am >> p) & 1u)) c.X.maskbuf[p * 82 + id] = 1;
         }
     }
     wave_sync();
@@ -2359,7 +2365,7 @@ __device__ __forceinline__ void finalize_outputs(Ctx& c, bool claims_fresh, bool
         const bool acts = (am >> lane) & 1u;
         const int n = acts ? c.X.nl[lane] : 0;
         c.E.nlegal[(size_t)c.g * 4 + lane] = (uint8_t)n;
-        S.nlegal[lane] = (uint8_t)n;
+        S.nlegal[lane] = ((hidden >> lane) & 1u) ? (uint8_t)c.X.nl[lane] : (uint8_t)n;
         c.E.waits[(size_t)c.g * 4 + lane] = acts ? c.X.wout[lane] : 0ull;
         if (observe && acts && !S.is_done) {  // get_observation advances the seat's event cursor (state/mod.rs:211-218)
             S.obs_from[lane] = S.obs_upto[lane];

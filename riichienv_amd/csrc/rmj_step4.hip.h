@@ -2581,7 +2581,8 @@ __device__ __forceinline__ uint32_t step4_body(const Env* Ep, Quad4Shared& sh, u
     R4T(5);
     // ---- bailed games: the complete state machine, one game at a time, from the untouched HBM record
     uint64_t bm = __ballot(q.live && q.bail && r == 0);
-    const uint32_t fl_full = (INLR ? fl_pub : flags) | (q.cont == 1 ? STEP_F_CONT_RYU : 0u) | (q.cont == 2 ? STEP_F_CONT_FIN : 0u) | (q.cont == 3 ? STEP_F_CONT_CLAIMS : 0u);   // (per row)
+    const uint32_t fl_full = ((INLR || pass2) ? fl_pub : flags) |   // (pass 2 of an inline-response rollout: the row's publication flags come from pass 1 - the caller's `flags` carry neither STEP_F_QUIET nor _ALLROWS there)
+                             (q.cont == 1 ? STEP_F_CONT_RYU : 0u) | (q.cont == 2 ? STEP_F_CONT_FIN : 0u) | (q.cont == 3 ? STEP_F_CONT_CLAIMS : 0u);   // (per row)
 #ifdef RMJ_TL4
     if (!LOOP && lane == 0) rmj::g_tl4[(size_t)blockIdx.x * RMJ_TL4_ROW + 7] = (unsigned long long)__popcll(bm);
 #endif
@@ -2649,9 +2650,21 @@ __device__ __forceinline__ void step4_finish_rounds(const Env* Ep, uint32_t flag
 #ifndef RMJ_INLINE_RESP
 #define RMJ_INLINE_RESP 3   /* bit 0: the RandomAgent's rollouts, bit 1: the greedy policy's */
 #endif
+#ifndef RMJ_INLINE_STEP
+#define RMJ_INLINE_STEP 0   /* experiment: the step inlined into the rollout loop, its uniform inputs laundered per iteration */
+#endif
+#if RMJ_INLINE_STEP
+#define R4_STEP_CALL __forceinline__
+#else
+#define R4_STEP_CALL __noinline__
+#endif
 template <int POL>
-__device__ __noinline__ uint32_t step4_call_inl(const Env* Ep, uint64_t policy_seed, uint32_t flags, uint32_t g_base, uint32_t g_end, uint32_t load,
+__device__ R4_STEP_CALL uint32_t step4_call_inl(const Env* Ep, uint64_t policy_seed, uint32_t flags, uint32_t g_base, uint32_t g_end, uint32_t load,
                                                 uint64_t gs_row, uint32_t quad, uint32_t left, uint32_t final_chunk) {
+#if RMJ_INLINE_STEP
+    Ep = uni_ptr(Ep); policy_seed = uni(policy_seed); flags = uni(flags); g_base = uni(g_base); g_end = uni(g_end); quad = uni(quad); final_chunk = uni(final_chunk);
+    asm volatile("" : "+s"(Ep), "+s"(policy_seed), "+s"(flags), "+s"(g_base), "+s"(g_end), "+s"(quad), "+s"(final_chunk));
+#endif
     Quad4Shared& sh = g_q4;
     return step4_body<true, POL, true>(uni_ptr(Ep), sh, uni(policy_seed), uni(flags), uni(g_base), uni(g_end), uni(load) != 0u, gs_row, nullptr, uni(quad),
                                        left, uni(final_chunk) != 0u);

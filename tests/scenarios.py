@@ -680,6 +680,13 @@ def sc_riichi_autoplay_waits_for_the_discard_possible_hands(make):
     _riichi_autoplay(make, [list(range(2, 54, 4)), list(range(3, 55, 4)), list(range(0, 48, 4))], consistent=True)
 
 
+def sc_riichi_autoplay_unnamed_current_player(make):
+    """tests/test_riichi_autoplay.py:4-95 as the reference test pokes it - active_players stays [0] while seat 3 is the current player
+    and sends the discard: the reference regenerates the legal actions of whoever sends an action (state/mod.rs:339-402), so the discard
+    is legal (quirk Q17).  Hands a game can hold (the reference's thirteen copies of one tile are outside the HIP path's 3-bit counters)."""
+    _riichi_autoplay(make, [list(range(2, 54, 4)), list(range(3, 55, 4)), list(range(0, 48, 4))], consistent=False)
+
+
 _KOKUSHI_WAIT_E = sorted([0, 32, 36, 68, 72, 104, 112, 116, 120, 124, 128, 132] + [1])   # thirteen kinds but East, 1m paired
 
 
@@ -1750,7 +1757,7 @@ SCENARIOS = [sc_win_results_of_the_final_round, sc_paishan_dora_indices, sc_kaka
              sc_mjsoul_pao_ron_real_record, sc_mjsoul_pao_ron_real_record_with_riichi_stick, sc_rules_chankan_kokushi_tenhou,
              sc_rules_chankan_kokushi_mjsoul, sc_rules_standard_chankan_kakan, sc_game_modes_initialization_params,
              sc_game_modes_south_round_wind, sc_riichi_setup_leaves_only_discards,
-             sc_riichi_autoplay_waits_for_the_discard_possible_hands, sc_kokushi_ankan_ron, sc_kokushi_ankan_ron_tenhou,
+             sc_riichi_autoplay_waits_for_the_discard_possible_hands, sc_riichi_autoplay_unnamed_current_player, sc_kokushi_ankan_ron, sc_kokushi_ankan_ron_tenhou,
              sc_non_kokushi_ankan_no_ron, sc_ankan_generation, sc_ankan_generation_riichi, sc_chankan_stale_claims_repro,
              sc_env_scoring_ron_deltas, sc_env_scoring_tsumo_deltas, sc_env_scoring_ura_markers, sc_env_initialization,
              sc_env_basic_step_processing, sc_env_pon_claim, sc_env_pon_red_dora_claim, sc_env_chi_claim, sc_env_chi_claim_with_red_dora,

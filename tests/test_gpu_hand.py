@@ -186,7 +186,7 @@ def test_effective_tiles_and_ukeire_parity(sanma):
     from tests.test_oracle_shanten import H_4P_13, UKEIRE_KATS, _types, _vis
 
     rng = np.random.default_rng(77 + int(sanma))
-    hands, vis = _ukeire_hands(rng, 120, sanma)
+    hands, vis = _ukeire_hands(rng, 1800, sanma)   # (round 4: the 4P walk evaluates every pair as one entry of a pre-merged pair of vectors)
     assert (vecenv.effective_tiles(hands, sanma=sanma) == oracle.effective_tiles(hands, sanma=sanma)).all()
     assert (vecenv.best_ukeire(hands, vis, sanma=sanma) == oracle.best_ukeire(hands, vis, sanma=sanma)).all()
     for hand, v, sm, want in UKEIRE_KATS:

@@ -2650,21 +2650,9 @@ __device__ __forceinline__ void step4_finish_rounds(const Env* Ep, uint32_t flag
 #ifndef RMJ_INLINE_RESP
 #define RMJ_INLINE_RESP 3   /* bit 0: the RandomAgent's rollouts, bit 1: the greedy policy's */
 #endif
-#ifndef RMJ_INLINE_STEP
-#define RMJ_INLINE_STEP 0   /* experiment: the step inlined into the rollout loop, its uniform inputs laundered per iteration */
-#endif
-#if RMJ_INLINE_STEP
-#define R4_STEP_CALL __forceinline__
-#else
-#define R4_STEP_CALL __noinline__
-#endif
 template <int POL>
-__device__ R4_STEP_CALL uint32_t step4_call_inl(const Env* Ep, uint64_t policy_seed, uint32_t flags, uint32_t g_base, uint32_t g_end, uint32_t load,
+__device__ __noinline__ uint32_t step4_call_inl(const Env* Ep, uint64_t policy_seed, uint32_t flags, uint32_t g_base, uint32_t g_end, uint32_t load,
                                                 uint64_t gs_row, uint32_t quad, uint32_t left, uint32_t final_chunk) {
-#if RMJ_INLINE_STEP
-    Ep = uni_ptr(Ep); policy_seed = uni(policy_seed); flags = uni(flags); g_base = uni(g_base); g_end = uni(g_end); quad = uni(quad); final_chunk = uni(final_chunk);
-    asm volatile("" : "+s"(Ep), "+s"(policy_seed), "+s"(flags), "+s"(g_base), "+s"(g_end), "+s"(quad), "+s"(final_chunk));
-#endif
     Quad4Shared& sh = g_q4;
     return step4_body<true, POL, true>(uni_ptr(Ep), sh, uni(policy_seed), uni(flags), uni(g_base), uni(g_end), uni(load) != 0u, gs_row, nullptr, uni(quad),
                                        left, uni(final_chunk) != 0u);

@@ -17,7 +17,7 @@ run random_perstep_520 RMJ_STEP4=1 -- 256 3000 1 520
 run random_rows1_521 RMJ_ROWS=1 -- 256 6000 1 521
 run random_rows2_522 RMJ_ROWS=2 -- 256 6000 1 522
 # greedy policy (wins, riichi, kans: settlements and yaku checks between the passes), call rates 0 .. 256 of 256
-for kr in "600 0" "664 64" "728 128" "856 256" "632 32" "792 192"; do set -- $kr; run greedy_$1 RMJ_SOAK_POLICY=greedy RMJ_SOAK_CALL_RATE=$2 RMJ_QUEUE_FORCE=0 -- 512 4000 1 $1; done
+for kr in "600 0" "664 64" "728 128" "855 255" "632 32" "792 192"; do set -- $kr; run greedy_$1 RMJ_SOAK_POLICY=greedy RMJ_SOAK_CALL_RATE=$2 RMJ_QUEUE_FORCE=0 -- 512 4000 1 $1; done
 run greedy_tickets_665 RMJ_SOAK_POLICY=greedy RMJ_SOAK_CALL_RATE=64 RMJ_QUEUE_FORCE=1 -- 512 4000 1 665
 wait
 # wave 2

@@ -364,12 +364,12 @@ __device__ inline void encode_ext_scalars(const GState& S, int pid, float* tab, 
         h.a = w[0]; h.b = w[1]; h.c = w[2]; h.d = w[3];
     }
     const int total = ph_total(h);
-    const int cur_sh = sh_shanten(h, total / 3, SANMA, T);
+    int cur_sh = 0;      // shanten of the hand (the ukeire walk computes it from the suit vectors it needs anyway)
     int nsh_type = 127;  // lane = tile type: shanten after discarding one tile of the type (filled by the ukeire walk)
     // 78..93 shanten efficiency
     {
         uint32_t eff, uke;
-        sh_ukeire_both(T, h, my_cnt, my_vis, SANMA, lane, true, true, eff, uke, cur_sh, &nsh_type);
+        sh_ukeire_both(T, h, my_cnt, my_vis, SANMA, lane, true, true, eff, uke, -99, &nsh_type, &cur_sh);
         for (int c = 0; c < NPP; c++) {
             const int base = 78 + c * 4;
             if (c == 0) {

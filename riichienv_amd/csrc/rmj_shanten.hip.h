@@ -250,20 +250,18 @@ __device__ __forceinline__ int sh_kokushi(const PH& h) {
 }
 // shanten.rs:407-435: relocate 1m / 9m counts into empty honor slots (3P)
 __device__ __forceinline__ PH sh_relocate_3p(const PH& h) {
+    // branch-free form of the reference's scan: 1m takes the first empty honor slot, 9m the next one; without a slot the count stays
     PH t = h;
-    uint32_t mc[2] = {h.a & 7u, (h.a >> 24) & 7u};
+    uint32_t E = ~(h.d | (h.d >> 1) | (h.d >> 2)) & O7_1;   // bit 3 * slot of every empty honor slot
+    const uint32_t m0 = h.a & 7u, m1 = (h.a >> 24) & 7u;
     t.a &= ~(7u | (7u << 24));
-    int slot = 0;
-#pragma unroll
-    for (int i = 0; i < 2; i++) {
-        if (mc[i] == 0u) continue;
-        while (slot < 7 && ((t.d >> (3 * slot)) & 7u) != 0u) slot++;
-        if (slot < 7) {
-            t.d |= mc[i] << (3 * slot);
-            slot++;
-        } else {
-            t.a |= mc[i] << (i == 0 ? 0 : 24);
-        }
+    if (m0 != 0u) {
+        if (E != 0u) { t.d |= m0 << (__ffs((int)E) - 1); E &= E - 1u; }
+        else t.a |= m0;
+    }
+    if (m1 != 0u) {
+        if (E != 0u) t.d |= m1 << (__ffs((int)E) - 1);
+        else t.a |= m1 << 24;
     }
     return t;
 }
@@ -349,8 +347,7 @@ __device__ __forceinline__ int sh_shanten_wave(const PH& h, int len_div3, const 
     return sres;
 }
 
-// ---- shanten of a hand that differs from a known hand in ONE suit (4P): the three other suit vectors and their pair
-// merge are reused, only the changed suit is looked up and merged again (1 rank + 1 merge + 1 entry instead of 4 + 3).
+// ---- the suit vectors of a hand and their pair merges (the ukeire walk judges hands that differ from it in one or two suits)
 struct ShBase {
     uint64_t v[4];   // packed cost vectors of man / pin / sou / honors
     uint64_t ab, cd; // merge(v0, v1), merge(v2, v3)
@@ -358,37 +355,6 @@ struct ShBase {
 __device__ __forceinline__ uint64_t sh_vec(uint32_t word, int q, const ShantenTables& T) {
     return q < 3 ? T.suit[sh_rank(word, 9, T.rank9)] : T.honor[sh_rank(word, 7, T.rank7)];
 }
-// wave-uniform hand -> base; lanes 0..3 look one suit up each, the vectors are broadcast
-__device__ __forceinline__ ShBase sh_base_wave(const PH& h, const ShantenTables& T, int lane) {
-    const int q = lane & 3;
-    const uint64_t mine = sh_vec(ph_get(h, q), q, T);
-    ShBase B;
-#pragma unroll
-    for (int k = 0; k < 4; k++)
-        B.v[k] = (uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)mine, k) |
-                 ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(mine >> 32), k) << 32);
-    B.ab = sh_merge(B.v[0], B.v[1]);
-    B.cd = sh_merge(B.v[2], B.v[3]);
-    return B;
-}
-// shanten (shanten.rs:228-241, 4P) of the hand x = base hand with suit q replaced by the vector nv
-__device__ __forceinline__ int sh_shanten_mod(const ShBase& B, int q, uint64_t nv, const PH& x, int len_div3) {
-    const uint64_t other = q == 0 ? B.v[1] : (q == 1 ? B.v[0] : (q == 2 ? B.v[3] : B.v[2]));
-    const uint64_t side = q < 2 ? B.cd : B.ab;
-    const uint64_t X = sh_merge(nv, other);
-    const int m = len_div3 > 4 ? 4 : len_div3;
-    int s = (int)sh_merge_entry((uint32_t)X & 0xFFFFFu, (uint32_t)(X >> 20) & 0xFFFFFu, (uint32_t)side & 0xFFFFFu,
-                                (uint32_t)(side >> 20) & 0xFFFFFu, 1, m) - 1;
-    if (s <= 0 || len_div3 < 4) return s;
-    const int c = sh_chiitoi(x, false);
-    s = c < s ? c : s;
-    if (s > 0) {
-        const int k = sh_kokushi(x);
-        s = k < s ? k : s;
-    }
-    return s;
-}
-
 // Up to four (min,+) merges at once, one per 16-lane row: lane i < 10 of a row computes entry i of merge(a, b) for the row's
 // (row-uniform) inputs, the nibbles are OR-reduced over the row and handed to every lane of it.  ~100 VALU for four merges where
 // sh_merge takes ~210 for one (every lane of a wave computing the same 45 terms).
@@ -417,19 +383,6 @@ __device__ __forceinline__ uint64_t sh_rl64(uint64_t v, int src) {
 __device__ __forceinline__ int sh_entry_pm(uint64_t a, uint64_t b, int m) {
     return (int)sh_merge_entry((uint32_t)a & 0xFFFFFu, (uint32_t)(a >> 20) & 0xFFFFFu, (uint32_t)b & 0xFFFFFu, (uint32_t)(b >> 20) & 0xFFFFFu, 1, m);
 }
-// normal / chiitoi / kokushi minimum (shanten.rs:228-241) given the normal form's replacement number
-__device__ __forceinline__ int sh_finish(int rep, const PH& x, int len_div3) {
-    int s = rep - 1;
-    if (s <= 0 || len_div3 < 4) return s;
-    const int c = sh_chiitoi(x, false);
-    s = c < s ? c : s;
-    if (s > 0) {
-        const int k = sh_kokushi(x);
-        s = k < s ? k : s;
-    }
-    return s;
-}
-
 // calculate_effective_tiles(_3p)_with_discard ("eff") and calculate_best_ukeire(_3p) ("uke"), shanten.rs:265-405 /
 // :488-626, for ONE wave-uniform hand: lane = drawn tile type (my_cnt / my_vis = this lane's held / visible count), the
 // loop over discard candidates runs over held types.  eff on a 3n hand yields 0xFFFFFFFF (the reference asserts).
@@ -437,18 +390,34 @@ __device__ __forceinline__ int sh_finish(int rep, const PH& x, int len_div3) {
 // pass serves both, and the shanten after each discard is evaluated for all d at once (lane = d): 2 + #held-types
 // per-lane table evaluations instead of 2 + 4 x #held-types for the two separate walks.
 __device__ inline void sh_ukeire_both(const ShantenTables& T, const PH& h, uint32_t my_cnt, uint32_t my_vis, bool sm, int lane,
-                                      bool want_eff, bool want_uke, uint32_t& eff, uint32_t& uke, int cur_in = -99, int* nsh_out = nullptr) {
+                                      bool want_eff, bool want_uke, uint32_t& eff, uint32_t& uke, int cur_in = -99, int* nsh_out = nullptr,
+                                      int* cur_out = nullptr) {   // cur_out: the shanten of h itself (computed here unless the caller passed it as cur_in)
     const int t = lane;
     const bool t_ok = t < 34 && (!sm || t == 0 || t >= 8);  // SANMA_VALID_TILE_TYPES (shanten.rs:244-247)
     const int total = ph_total(h);
-    if (!sm) {
-        // 4P: every hand judged here is the hand h with one tile removed and / or one added, i.e. it differs from a known
-        // hand in one suit: sh_shanten_mod on a base of h, resp. of h minus the discard
-        const int q = t < 34 ? t_suit(t) : 0, r = t < 34 ? t - 9 * q : 0;
-        const uint32_t one = 1u << (3 * r);
+    // 3P (round 4): the same walk on the RELOCATED hand (shanten.rs:407-452: the counts of 1m / 9m move into empty honor slots, the manzu
+    // suit is left empty) - exact while every hand of the walk relocates both terminals, i.e. while h leaves three honor slots free
+    // (h - d + t then has two) and holds no 2m..8m; 1m / 9m then belong to the honor "suit" and a hand's honor word is that of its own
+    // relocation.  Anything else takes the general walk below.
+    const bool fast = !sm || (__popc(~(h.d | (h.d >> 1) | (h.d >> 2)) & O7_1) >= 3 && (h.a & ~(7u | (7u << 24))) == 0u);
+    if (fast) {
+        // every hand judged here is the hand h with one tile removed and / or one added, i.e. it differs from h in at most two suits
+        const int q = t < 34 ? ((sm && (t == 0 || t == 8)) ? 3 : t_suit(t)) : 0;   // the suit whose vector the tile type changes
+        auto word = [&](const PH& y, int qq) -> uint32_t {                            // suit qq of hand y as the tables see it
+            if (!sm) return ph_get(y, qq);
+            return qq == 0 ? 0u : (qq == 3 ? sh_relocate_3p(y).d : ph_get(y, qq));
+        };
+        auto finish = [&](int rep, const PH& x, int len_div3) -> int {                // shanten.rs:228-241 / :454-468
+            int s0 = rep - 1;
+            if (s0 <= 0 || len_div3 < 4) return s0;
+            const int c = sh_chiitoi(x, sm);
+            s0 = c < s0 ? c : s0;
+            if (s0 > 0) { const int k = sh_kokushi(x); s0 = k < s0 ? k : s0; }
+            return s0;
+        };
         ShBase Bh;
         {   // sh_base_wave with the two pair merges lane-parallel (rows 0 and 1)
-            const uint64_t mine = sh_vec(ph_get(h, lane & 3), lane & 3, T);
+            const uint64_t mine = sh_vec(word(h, lane & 3), lane & 3, T);
 #pragma unroll
             for (int k = 0; k < 4; k++) Bh.v[k] = sh_rl64(mine, k);
             const bool r0 = (lane >> 4) == 0;
@@ -457,24 +426,28 @@ __device__ inline void sh_ukeire_both(const ShantenTables& T, const PH& h, uint3
             Bh.cd = sh_rl64(M, 31);
         }
         const int m_h = total / 3 > 4 ? 4 : total / 3;
-        const int cur = cur_in != -99 ? cur_in : ([&] {
-            int s0 = (int)sh_merge_entry((uint32_t)Bh.ab & 0xFFFFFu, (uint32_t)(Bh.ab >> 20) & 0xFFFFFu, (uint32_t)Bh.cd & 0xFFFFFu,
-                                         (uint32_t)(Bh.cd >> 20) & 0xFFFFFu, 1, m_h) - 1;
-            if (s0 <= 0 || total / 3 < 4) return s0;
-            const int c = sh_chiitoi(h, false);
-            s0 = c < s0 ? c : s0;
-            if (s0 > 0) { const int k = sh_kokushi(h); s0 = k < s0 ? k : s0; }
-            return s0;
-        })();
+        const int cur = cur_in != -99 ? cur_in : finish(sh_entry_pm(Bh.ab, Bh.cd, m_h), h, total / 3);
+        if (cur_out) *cur_out = cur;
+        // O_q: the three other suits of h merged (row q computes O_q)
+        uint64_t O_mine;
+        {
+            const int rw = lane >> 4;
+            const uint64_t pa = rw == 0 ? Bh.v[1] : (rw == 1 ? Bh.v[0] : (rw == 2 ? Bh.v[3] : Bh.v[2]));
+            const uint64_t ot = rw < 2 ? Bh.cd : Bh.ab;
+            const uint64_t Om = sh_merge_rows(pa, ot, lane);
+            const uint64_t O0 = sh_rl64(Om, 15), O1 = sh_rl64(Om, 31), O2 = sh_rl64(Om, 47), O3 = sh_rl64(Om, 63);
+            O_mine = q == 0 ? O0 : (q == 1 ? O1 : (q == 2 ? O2 : O3));
+        }
+        const bool drawable = t_ok && ph_cnt(h, t) < 4;
+        uint64_t vt = 0;          // vector of this lane's suit with the lane's type drawn
+        PH hp = h;
+        if (drawable) ph_add(hp, t);
         eff = 0;
         uke = 0;
-        if (want_eff && total % 3 == 1) {
-            bool f = false;
-            if (t < 34 && ph_cnt(h, t) < 4) {
-                PH x = h;
-                ph_add(x, t);
-                f = sh_shanten_mod(Bh, q, sh_vec(ph_get(h, q) + one, q, T), x, (total + 1) / 3) < cur;
-            }
+        const bool eff13 = want_eff && total % 3 == 1;
+        if (eff13) {
+            if (drawable) vt = sh_vec(word(hp, q), q, T);
+            const bool f = drawable && finish(sh_entry_pm(vt, O_mine, (total + 1) / 3 > 4 ? 4 : (total + 1) / 3), hp, (total + 1) / 3) < cur;
             eff = (uint32_t)__popcll(__ballot(f));
         }
         if (want_eff && total % 3 == 0) eff = 0xFFFFFFFFu;
@@ -482,43 +455,31 @@ __device__ inline void sh_ukeire_both(const ShantenTables& T, const PH& h, uint3
         if (!eff_loop && !want_uke) return;
         // Round 4: every hand of the walk is h - d + t.  (min,+) is associative, so its replacement number is ONE entry of a merge of two
         // vectors that are known before the pair is looked at:
-        //   t in the suit of d            : entry(vec(h_q - d + t), O_q)      O_q = the three other suits of h merged (per hand)
-        //   t in the partner suit of d's  : entry(vec(h_q + t),     W_d)      W_d = vec(h_qd - d) (+) the other half of h (per d)
-        //   t in the other half           : entry(P_t,              H_d)      P_t = vec(h_q + t) (+) partner suit of h (per lane), H_d = vec(h_qd - d) (+) its partner suit (per d)
+        //   t in the suit of d            : entry(vec(suit of h - d + t), O_q)   O_q = the three other suits of h merged (per hand)
+        //   t in the partner suit of d's  : entry(vec(suit of h + t),     W_d)   W_d = vec(suit of h - d) (+) the other half of h (per d)
+        //   t in the other half           : entry(P_t,                    H_d)   P_t = vec(suit of h + t) (+) partner suit of h (per lane), H_d = vec(suit of h - d) (+) its partner suit (per d)
         // - one table lookup per same-suit pair and no merge per pair; the merges per hand / per d run lane-parallel (sh_merge_rows).
         const int m_loop = total / 3 > 4 ? 4 : total / 3;            // hands of the loop hold total tiles again (h - d + t)
         const int m_sub = (total - 1) / 3 > 4 ? 4 : (total - 1) / 3;
-        uint64_t O_mine;                                              // O_q of this lane's suit
-        {
-            const int rw = lane >> 4;                                 // row rw computes O_rw
-            const uint64_t pa = rw == 0 ? Bh.v[1] : (rw == 1 ? Bh.v[0] : (rw == 2 ? Bh.v[3] : Bh.v[2]));
-            const uint64_t ot = rw < 2 ? Bh.cd : Bh.ab;
-            const uint64_t Om = sh_merge_rows(pa, ot, lane);
-            const uint64_t O0 = sh_rl64(Om, 15), O1 = sh_rl64(Om, 31), O2 = sh_rl64(Om, 47), O3 = sh_rl64(Om, 63);
-            O_mine = q == 0 ? O0 : (q == 1 ? O1 : (q == 2 ? O2 : O3));
-        }
         int nsh_l = 127;
         uint64_t nv_d = 0;
         if (t < 34 && ph_cnt(h, t) > 0) {
             PH sub = h;
             ph_sub(sub, t);
-            nv_d = sh_vec(ph_get(h, q) - one, q, T);
-            nsh_l = sh_finish(sh_entry_pm(nv_d, O_mine, m_sub), sub, (total - 1) / 3);
+            nv_d = sh_vec(word(sub, q), q, T);
+            nsh_l = finish(sh_entry_pm(nv_d, O_mine, m_sub), sub, (total - 1) / 3);
         }
         if (nsh_out) *nsh_out = nsh_l;
         uint64_t cand = __ballot(nsh_l <= cur);
         if (!cand) return;
-        const bool drawable = t < 34 && ph_cnt(h, t) < 4;
-        uint64_t vt = 0, Pt = 0;
-        if (drawable) {
-            vt = sh_vec(ph_get(h, q) + one, q, T);
-            Pt = sh_merge(vt, q == 0 ? Bh.v[1] : (q == 1 ? Bh.v[0] : (q == 2 ? Bh.v[3] : Bh.v[2])));
-        }
+        uint64_t Pt = 0;
+        if (drawable && !eff13) vt = sh_vec(word(hp, q), q, T);   // (only hands with a discard that keeps the shanten get here)
+        if (drawable) Pt = sh_merge(vt, q == 0 ? Bh.v[1] : (q == 1 ? Bh.v[0] : (q == 2 ? Bh.v[3] : Bh.v[2])));
         while (cand) {
             const int d = __ffsll((long long)cand) - 1;
             cand &= cand - 1ull;
             const int nsh = __builtin_amdgcn_readlane(nsh_l, d);
-            const int qd = t_suit(d);
+            const int qd = (sm && (d == 0 || d == 8)) ? 3 : t_suit(d);
             PH sub = h;
             ph_sub(sub, d);
             const uint64_t V = sh_rl64(nv_d, d);
@@ -528,14 +489,14 @@ __device__ inline void sh_ukeire_both(const ShantenTables& T, const PH& h, uint3
             const uint64_t HW = sh_merge_rows(V, (lane >> 4) == 0 ? pd : xd, lane);
             const uint64_t Hd = sh_rl64(HW, 15), Wd = sh_rl64(HW, 31);
             bool f = false;
-            if (t < 34 && ph_cnt(sub, t) < 4) {
+            if (t_ok && ph_cnt(sub, t) < 4) {
                 PH x = sub;
                 ph_add(x, t);
                 uint64_t a, b;
-                if (q == qd) { a = sh_vec(ph_get(sub, q) + one, q, T); b = O_mine; }
+                if (q == qd) { a = sh_vec(word(x, q), q, T); b = O_mine; }
                 else if ((q ^ 1) == qd) { a = vt; b = Wd; }
                 else { a = Pt; b = Hd; }
-                f = sh_finish(sh_entry_pm(a, b, m_loop), x, total / 3) < nsh;
+                f = finish(sh_entry_pm(a, b, m_loop), x, total / 3) < nsh;
             }
             const uint64_t fb = __ballot(f);
             if (eff_loop) {
@@ -556,6 +517,7 @@ __device__ inline void sh_ukeire_both(const ShantenTables& T, const PH& h, uint3
         return;
     }
     const int cur = cur_in != -99 ? cur_in : sh_shanten(h, total / 3, sm, T);  // the caller may know it already
+    if (cur_out) *cur_out = cur;
     // does drawing this lane's type lower the shanten of `base` (a 3n+1 hand)?
     auto improves = [&](const PH& base, int base_total, int base_sh) -> bool {
         if (!(t_ok && ph_cnt(base, t) < 4)) return false;

@@ -20,6 +20,9 @@
 namespace RMJ_NS {
 
 #define R4_LIST 16 /* staged list entries per (game, seat); a longer list makes the row bail */
+/* The drawer's list (WaitAct: the only list of its game) may run on into the next seat's slots where that seat is never the last of a
+   row - 3P, whose lists are the long ones (fourteen discards + a Kita per North + Riichi: 0.2 % of the game-steps beyond 16 entries) */
+#define R4_ACT_CAP (KSANMA ? 2 * R4_LIST : R4_LIST)
 // what makes a row stop in pass 1 of a step (Quad4Shared::rmode; the caller runs r4_round_end / r4_yaku_answers, then pass 2)
 #define R4_RE_DRAW 1u      /* exhaustive draw */
 #define R4_RE_RESTART 2u   /* a finished game restarts (auto-reset) */
@@ -546,7 +549,7 @@ __device__ __forceinline__ int r4_tile_id(int t34) {   // discard id of a tile t
     return KSANMA ? (t34 == 0 ? 0 : (t34 == 8 ? 1 : t34 - 7)) : t34;
 }
 __device__ __forceinline__ void r4_put(R4& q, int seat, int pos, uint64_t a, int id) {
-    if (pos < R4_LIST) q.T->lst[q.row][seat][pos] = a | ((uint64_t)(uint32_t)id << 56);
+    if (pos < R4_ACT_CAP) (&q.T->lst[q.row][seat][0])[pos] = a | ((uint64_t)(uint32_t)id << 56);   // (claim lists stay below R4_LIST: r4_resolve_discard checks)
 }
 
 // wall tile `idx` of the row's game (fused rollouts read their own earlier stores past the vector L1, see step4_body)
@@ -1116,7 +1119,7 @@ __device__ __forceinline__ void r4_gen_act_legal(R4& q, int& nl_mine) {
         if (hit) r4_put(q, pid, n + __popc(kb & ((1u << r) - 1u)), mk_action(RMJ_KITA, ht, 0), 59);
         n += __popc(kb);
     }
-    if (n > R4_LIST) { R4BAIL(q, 17); return; }
+    if (n > R4_ACT_CAP) { R4BAIL(q, 17); return; }
     nl_mine = r == pid ? n : 0;
     wave_sync();
 }
@@ -2027,6 +2030,7 @@ __device__ __forceinline__ uint32_t step4_body(const Env* Ep, Quad4Shared& sh, u
     uint64_t w_mine = 0ull;   // lane = seat: waits published for the seat
     const bool t0 = q.live && !q.bail;
     bool second = false;      // INLR: this row answers the claims on its own discard in this call (its second game-step)
+    bool noop = false;        // WaitAct and nothing from the seat that is to act: the step changes nothing (state/mod.rs:404-408)
     if (t0 && q.rend == 0u) {
         if (r == 0) G->step_count += 1;
         const int phase = G->phase;
@@ -2043,7 +2047,11 @@ __device__ __forceinline__ uint32_t step4_body(const Env* Ep, Quad4Shared& sh, u
                 if (r == 0) P->flags |= PF_RIICHI_STAGE;
                 wave_sync();
                 r4_emit_simple(q, RMJ_EV_REACH, (uint32_t)pid, 0);
-            } else if (act == 0xFFFFFFFFu || ((act >> 8) & 0xFFu) == RMJ_TILE_NONE) {
+            } else if (act == 0xFFFFFFFFu) {
+                // no action for the current player (a policy that skipped it; 3P: a seat the reference leaves without any legal action
+                // after a Kita in its riichi stage, quirk Q15 - such a game stays like this for good, one bail per step before round 4)
+                noop = true;
+            } else if (((act >> 8) & 0xFFu) == RMJ_TILE_NONE) {
                 R4BAIL(q, 19);
             } else if (ty == RMJ_DISCARD) {
                 q.dirty = 1u << pid;
@@ -2489,7 +2497,9 @@ __device__ __forceinline__ uint32_t step4_body(const Env* Ep, Quad4Shared& sh, u
         if (!q.bail && G->phase == RMJ_WAIT_ACT && !(q.rend && G->is_done)) {
             nl_mine = 0;
             w_mine = 0ull;
-            r4_gen_act_legal<RICH>(q, nl_mine);
+            // (an untouched state whose list was empty has an empty list; a holder of 13 tiles - poked states - also publishes its waits: r4_gen_act_legal decides)
+            const PState& Pc = G->p[G->current_player & 3];
+            if (!(noop && G->nlegal[G->current_player & 3] == 0 && Pc.hand_len + 3 * Pc.n_melds == 14)) r4_gen_act_legal<RICH>(q, nl_mine);
             if (q.rend && q.bail) q.cont = 2;   // (a dealt hand tier 0 has no list for: the full path publishes the state as it stands)
         }
         if (RMJ_ROW_ROUND_END && !pass2 && !q.bail && q.rend != 0u) wait_deal = true;   // (paused at the list's Tsumo check)
@@ -2525,6 +2535,12 @@ __device__ __forceinline__ uint32_t step4_body(const Env* Ep, Quad4Shared& sh, u
                 const uint64_t e = q.T->lst[row][p][r];
                 (E.legal + (size_t)g * 4 * RMJ_MAX_LEGAL)[p * RMJ_MAX_LEGAL + r] = e & 0x00FFFFFFFFFFFFFFull;
                 const int id = (int)(e >> 56);     // the id travels with the staged entry (r4_put)
+                if (!quiet) atomicOr(&q.T->mk[row][p][id >> 5], 1u << (id & 31));
+            }
+            if (R4_ACT_CAP > R4_LIST && r + R4_LIST < n) {   // (3P: a drawer's list that runs on into the next seat's slots)
+                const uint64_t e = (&q.T->lst[row][p][0])[r + R4_LIST];
+                (E.legal + (size_t)g * 4 * RMJ_MAX_LEGAL)[p * RMJ_MAX_LEGAL + r + R4_LIST] = e & 0x00FFFFFFFFFFFFFFull;
+                const int id = (int)(e >> 56);
                 if (!quiet) atomicOr(&q.T->mk[row][p][id >> 5], 1u << (id & 31));
             }
         }

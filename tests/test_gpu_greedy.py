@@ -109,3 +109,23 @@ def _oracle_games_at(mode, rule, seed, globals_):
     for o in games:
         o.reset()
     return games
+
+
+@pytest.mark.parametrize("mode,bound", [(2, 0.001), (5, 0.004)])
+def test_wins_and_round_ends_stay_in_the_four_games_per_wave_tier(mode, bound):
+    """Round 4: settlements, yaku checks, exhaustive draws, next rounds and restarts are row-form code between the passes of a step
+    (r4_round_end, r4_yaku_answers) - the serial full path is left with ankan in riichi, robbed kans, abortive draws (4P 0.02 %,
+    3P 0.10 % of the game-steps, profiles/r04_bail_census.txt).  Guards against a change that silently sends those steps back
+    (their parity is what the greedy rollout tests above and scripts/soak_parity.py compare)."""
+    from riichienv_amd import vecenv
+
+    env = vecenv.VecRiichiEnv(16384, game_mode=mode, seed=5, event_ring=64)
+    env.reset()
+    env.step_greedy(0xBEEF, 1200, auto_reset=True, call_rate_256=64)          # into the steady state: wins, riichi, kans, restarts
+    s0, f0 = env.total_steps(), env.total_full_path()
+    env.step_greedy(0xBEEF, 300, auto_reset=True, call_rate_256=64)           # fused (tickets)
+    for _ in range(40):
+        env.step_greedy(0xBEEF, 1, auto_reset=True, call_rate_256=64)         # one launch per step
+    steps, full = env.total_steps() - s0, env.total_full_path() - f0
+    assert steps > 16384 * 300 and full / steps < bound, (steps, full)
+    env.close()

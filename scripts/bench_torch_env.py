@@ -51,9 +51,10 @@ def run(n, ext, shared, fused=False):
           f"loop {steps / (t1 - t0) / 1e6:.1f} M env.step/s, {(t1 - t0) / K * 1e3:.2f} ms per iteration{parts}")
 
 
-def run_one_launch(n):
-    """the loop with step + encode as ONE launch per iteration (TorchVecEnv.step_obs -> rmj_step_ids_encode_device) and the fused sampler"""
-    env = TorchVecEnv(n, game_mode=2, seed=0, share_stream=True)
+def run_one_launch(n, pad=False):
+    """the loop with step + encode as ONE launch per iteration (TorchVecEnv.step_obs -> rmj_step_ids_encode_device) and the fused sampler;
+    pad: every (game, seat) row of the feature tensor padded to a multiple of 256 B (TorchVecEnv(pad_rows=True): a strided view)"""
+    env = TorchVecEnv(n, game_mode=2, seed=0, share_stream=True, pad_rows=pad)
     env.obs(only_active=True)
     for k in range(20):
         env.step_obs(env.sample_ids(seed=k + 1))
@@ -66,7 +67,7 @@ def run_one_launch(n):
     torch.cuda.synchronize()
     t1 = time.perf_counter()
     steps = env.env.total_steps() - steps0
-    print(f"games {n} channels 74 fused masked sampler + step and encode as one launch (rmj_step_ids_encode_device), shared stream: "
+    print(f"games {n} channels 74 fused masked sampler + step and encode as one launch (rmj_step_ids_encode_device){', rows padded to 256 B' if pad else ''}, shared stream: "
           f"loop {steps / (t1 - t0) / 1e6:.1f} M env.step/s, {(t1 - t0) / K * 1e3:.2f} ms per iteration")
 
 
@@ -183,6 +184,7 @@ def main():
     run(n, ext, True, fused=True)
     if not ext:
         run_one_launch(n)
+        run_one_launch(n, pad=True)
         for parts in (2, 4):
             run_parts(n, parts)
         run_parts(n, 4, compact=True)

@@ -2051,6 +2051,9 @@ __device__ __forceinline__ uint32_t step4_body(const Env* Ep, Quad4Shared& sh, u
                 // no action for the current player (a policy that skipped it; 3P: a seat the reference leaves without any legal action
                 // after a Kita in its riichi stage, quirk Q15 - such a game stays like this for good, one bail per step before round 4)
                 noop = true;
+            } else if (RICH && RMJ_ROW_SETTLE && ty == RMJ_TSUMO && q.pause_ok) {
+                // (with or without the tile: a caller's Tsumo matched the list's entry by type)
+                q.rend = R4_RE_WIN_TSUMO;   // the settlement, the next round or the end of the game between the passes (r4_round_end)
             } else if (((act >> 8) & 0xFFu) == RMJ_TILE_NONE) {
                 R4BAIL(q, 19);
             } else if (ty == RMJ_DISCARD) {
@@ -2255,8 +2258,6 @@ __device__ __forceinline__ uint32_t step4_body(const Env* Ep, Quad4Shared& sh, u
                         }
                     }
                 }
-            } else if (RICH && RMJ_ROW_SETTLE && ty == RMJ_TSUMO && q.pause_ok) {
-                q.rend = R4_RE_WIN_TSUMO;   // the settlement, the next round or the end of the game between the passes (r4_round_end)
             } else {
                 R4BAIL(q, 23);   // Riichi (with a tile), Kyushu; lean tier: kans, Tsumo
             }

@@ -106,7 +106,7 @@ __device__ uint32_t* g_prof_buf;  // [n_games][64]: 0..31 cycles, 32..63 visit c
 // the number of instructions executed between the two marks.
 __device__ int g_cut = -1, g_cut2 = -1, g_cut3 = -1;
 __device__ uint32_t g_bail_reason[32];  // bail census of k_step4 (R4BAIL sites)
-#define PROF(X, lane, id) do { if (rmj::g_cut == (id) || rmj::g_cut2 == (id) || rmj::g_cut3 == (id)) __builtin_amdgcn_endpgm(); } while (0)
+#define PROF(X, lane, id) do { if (rmj::g_cut == (id) || rmj::g_cut2 == (id) || rmj::g_cut3 == (id)) asm volatile("s_endpgm" ::: "memory"); } while (0)   /* (asm, not the noreturn builtin: see R4M) */
 #define PROF_START(X, lane) do {} while (0)
 #define PROF_FLUSH(X, lane, g) do {} while (0)
 #else

@@ -47,7 +47,10 @@ __device__ __forceinline__ uint32_t r4_rows(uint32_t flags) {
 #define RMJ_ROW_ROUND_END 1   /* exhaustive draws, next rounds and restarts stay in tier 0 (r4_round_end); 0: they enter the full path at the exit */
 #endif
 #ifdef RMJ_CUTS   /* instruction accounting build (scripts/valu_sections4.py, scripts/bail_census.py) */
-#define R4M(id) do { if (rmj::g_cut == (id)) __builtin_amdgcn_endpgm(); } while (0)   /* the wave ends at mark g_cut */
+/* (an asm s_endpgm, not __builtin_amdgcn_endpgm: the builtin is noreturn, and a noreturn call inside divergent control flow lets the
+   compiler drop the EXEC restore behind the region - rows that were masked off there stayed off for the rest of the step in the greedy
+   instantiation: ADVICE r3 "mark 43", journal r04 section 16) */
+#define R4M(id) do { if (rmj::g_cut == (id)) asm volatile("s_endpgm" ::: "memory"); } while (0)   /* the wave ends at mark g_cut */
 #define R4BAIL(q, id) do { (q).bail = true; if ((q).r == 0) atomicAdd(&rmj::g_bail_reason[id], 1u); } while (0)   /* bail census */
 #else
 #define R4M(id) do {} while (0)

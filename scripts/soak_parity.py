@@ -18,7 +18,7 @@ from tests.test_gpu_step import _compare  # noqa: E402
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 128
 steps = int(sys.argv[2]) if len(sys.argv) > 2 else 5000
 seeds = int(sys.argv[3]) if len(sys.argv) > 3 else 2
-first = int(sys.argv[4]) if len(sys.argv) > 4 else 0
+first = (int(sys.argv[4]) if len(sys.argv) > 4 else 0) + int(os.environ.get("RMJ_SOAK_OFFSET", "0"))   # (RMJ_SOAK_OFFSET: the same run plan on other seeds)
 GREEDY = os.environ.get("RMJ_SOAK_POLICY", "random") == "greedy"
 RATE = int(os.environ.get("RMJ_SOAK_CALL_RATE", "64"))
 total = 0

@@ -59,6 +59,11 @@ enum { RMJ_MELD_CHI = 0, RMJ_MELD_PON = 1, RMJ_MELD_DAIMINKAN = 2, RMJ_MELD_ANKA
 #define RMJ_RULE_PAO_LIABILITY_ONLY 32u
 #define RMJ_RULE_SANCHAHO_DRAW 64u
 #define RMJ_RULE_KUIKAE_FORBIDDEN 128u
+/* Not a GameRule field: seed -> wall as the reference's crates define it (state/wall.rs:36-56: StdRng::seed_from_u64 =
+ * PCG32 seed expansion + ChaCha12, SliceRandom::shuffle, salt = next_u64, wall_digest = SHA-256(salt || wall); see
+ * rmj_get_wall_digest).  Without the bit the wall of a seed is the build's own counter-based permutation,
+ * which costs nothing per round; with it a round start pays one serial Fisher-Yates pass. */
+#define RMJ_RULE_REFERENCE_RNG 256u
 #define RMJ_RULE_TENHOU (RMJ_RULE_SANCHAHO_DRAW | RMJ_RULE_KUIKAE_FORBIDDEN)          /* rule.rs:31-44 */
 #define RMJ_RULE_MJSOUL (1u | 2u | 4u | 8u | 16u | 32u | RMJ_RULE_KUIKAE_FORBIDDEN) /* rule.rs:46-57 */
 
@@ -241,6 +246,12 @@ int rmj_get_scores(rmj_handle h, int32_t* scores /*[n][4]*/);
 int rmj_get_ranks(rmj_handle h, uint8_t* ranks /*[n][4], 1-based, ties by seat (env.rs:673-689)*/);
 int rmj_get_step_counts(rmj_handle h, uint64_t* steps /*[n]*/);
 int rmj_total_steps(rmj_handle h, uint64_t* total);
+/* state.wall.salt / state.wall.wall_digest (riichienv-core/src/state/wall.rs:15-16, 48-55; state_3p/wall.rs:52-53, 91-99): the salt as 16
+ * hex digits and SHA-256(salt || wall before the reversal) as 64, NUL-terminated.  Set by a seeded shuffle under RMJ_RULE_REFERENCE_RNG, left
+ * alone by an injected wall (load_wall), cleared by a start_kyoku event (event_handler.rs:81-82); empty strings otherwise.  The digest is
+ * computed on the device when asked for (salt and wall are state; the hash is a function of them). */
+int rmj_get_wall_digest(rmj_handle h, uint32_t game, char* salt /*[17]*/, char* digest /*[65]*/);
+int rmj_get_wall_digests(rmj_handle h, uint32_t first, uint32_t n, char* salts /*[n][17]*/, char* digests /*[n][65]*/);
 int rmj_peek_state(rmj_handle h, uint32_t game, RmjStateView* out);
 /* The observation outputs of ONE game (get_observations of its acting seats, env.rs:741-765): legal [4][64] + counts [4],
  * mask [4][82], waits [4], status = active_mask | phase << 8 | is_done << 16.  For sampled checks of large batches. */

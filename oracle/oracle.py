@@ -68,8 +68,59 @@ def lib():
         L.orc_bench_rollout.restype = C.c_uint64
         L.orc_bench_rollout.argtypes = [C.c_int, C.c_uint32, C.c_int, C.c_uint32, C.c_uint64, C.c_uint64, C.c_uint32,
                                         C.c_int, C.POINTER(C.c_double)]
+        L.orc_game_wall_meta.argtypes = [C.c_void_p, C.c_char_p, C.c_char_p]
+        L.orc_chacha_block.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64, C.c_int, C.c_void_p]
+        L.orc_seed_from_u64.argtypes = [C.c_uint64, C.c_void_p]
+        L.orc_stdrng_words.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p]
+        L.orc_sha256.argtypes = [C.c_char_p, C.c_uint64, C.c_void_p]
+        L.orc_random_range_u32.restype = C.c_uint32
+        L.orc_random_range_u32.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint32)]
+        L.orc_reference_wall.restype = C.c_uint32
+        L.orc_reference_wall.argtypes = [C.c_uint64, C.c_int, C.c_void_p, C.c_char_p, C.c_char_p]
         _LIB = L
     return _LIB
+
+
+# ---- ref_rng.hpp (the restated rand / chacha20 / sha2 algorithms behind state/wall.rs:36-56)
+def chacha_block(key_words, counter=0, stream=0, rounds=12):
+    k = np.ascontiguousarray(key_words, dtype=np.uint32)
+    out = np.zeros(16, np.uint32)
+    lib().orc_chacha_block(k.ctypes.data, counter, stream, rounds, out.ctypes.data)
+    return out
+
+
+def seed_from_u64(s: int) -> bytes:
+    out = np.zeros(32, np.uint8)
+    lib().orc_seed_from_u64(s, out.ctypes.data)
+    return out.tobytes()
+
+
+def stdrng_words(seed32: bytes, n: int):
+    sd = np.frombuffer(seed32, np.uint8).copy()
+    out = np.zeros(n, np.uint32)
+    lib().orc_stdrng_words(sd.ctypes.data, n, out.ctypes.data)
+    return out
+
+
+def sha256(msg: bytes) -> bytes:
+    out = np.zeros(32, np.uint8)
+    lib().orc_sha256(msg, len(msg), out.ctypes.data)
+    return out.tobytes()
+
+
+def random_range_u32(seed32: bytes, skip_words: int, bound: int):
+    sd = np.frombuffer(seed32, np.uint8).copy()
+    used = C.c_uint32()
+    v = lib().orc_random_range_u32(sd.ctypes.data, skip_words, bound, C.byref(used))
+    return v, used.value
+
+
+def reference_wall(hand_seed: int, sanma=False):
+    """(w before the reversal, salt, digest, u32 words drawn) of state/wall.rs:36-56 for StdRng::seed_from_u64(hand_seed)"""
+    w = np.zeros(108 if sanma else 136, np.uint8)
+    salt, dg = C.create_string_buffer(17), C.create_string_buffer(65)
+    n = lib().orc_reference_wall(hand_seed, int(sanma), w.ctypes.data, salt, dg)
+    return w, salt.value.decode(), dg.value.decode(), n
 
 
 def eval_hands(cases):
@@ -175,6 +226,12 @@ class Game:
 
     def waits(self, pid):
         return self.L.orc_game_waits(self.h, pid)
+
+    def wall_meta(self):
+        """(salt, wall_digest) of the current wall: state/wall.rs:15-16"""
+        salt, dg = C.create_string_buffer(17), C.create_string_buffer(65)
+        self.L.orc_game_wall_meta(self.h, salt, dg)
+        return salt.value.decode(), dg.value.decode()
 
     def status(self):
         a, p, d = C.c_uint8(), C.c_uint8(), C.c_uint8()

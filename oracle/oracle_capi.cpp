@@ -268,6 +268,8 @@ void orc_game_apply_event(void* gp, const RmjEvent* ev, int nrec) {
             g->wall.dora_indicators.assign(1, e.tile);
             g->wall.rinshan_draw_count = 0;
             g->wall.pending_kan_dora_count = 0;
+            g->wall.wall_digest.clear();  // event_handler.rs:81-82
+            g->wall.salt.clear();
             g->wall.drawable_count = (uint8_t)(g->wall.tiles.size() - 14);
             for (int i = 0; i < g->NP; i++) g->players[i].reset_round();
             for (int i = 0; i < g->NP; i++) g->players[i].score = e.deltas[i];
@@ -440,7 +442,47 @@ void orc_tid_to_mjai(uint8_t tid, char* buf) { std::strcpy(buf, tid_to_mjai(tid)
 void* orc_game_new(int game_mode, int skip_log, uint64_t seed, int has_seed, int round_wind, uint32_t rule_bits) {
     std::optional<uint64_t> s;
     if (has_seed) s = seed;
-    return new GameState((uint8_t)game_mode, skip_log != 0, s, (uint8_t)round_wind, GameRule::from_bits(rule_bits));
+    return new GameState((uint8_t)game_mode, skip_log != 0, s, (uint8_t)round_wind, GameRule::from_bits(rule_bits),
+                         (rule_bits & RMJ_RULE_REFERENCE_RNG) != 0);
+}
+// WallState.salt / wall_digest (state/wall.rs:15-16): NUL-terminated, salt[17], digest[65]; both empty without RMJ_RULE_REFERENCE_RNG
+void orc_game_wall_meta(void* gp, char* salt, char* digest) {
+    GameState* g = (GameState*)gp;
+    std::strcpy(salt, g->wall.salt.c_str());
+    std::strcpy(digest, g->wall.wall_digest.c_str());
+}
+// ---- the pieces of ref_rng.hpp, exported so that tests can pin them on published vectors
+void orc_chacha_block(const uint32_t* key8, uint64_t counter, uint64_t stream, int rounds, uint32_t* out16) {
+    refrng::chacha_block(key8, counter, stream, rounds, out16);
+}
+void orc_seed_from_u64(uint64_t s, uint8_t* seed32) { refrng::seed_from_u64(s, seed32); }
+void orc_stdrng_words(const uint8_t* seed32, uint32_t n, uint32_t* out) {
+    refrng::StdRng r = refrng::StdRng::from_seed(seed32);
+    for (uint32_t i = 0; i < n; i++) out[i] = r.next_u32();
+}
+void orc_sha256(const uint8_t* msg, uint64_t n, uint8_t* out32) {
+    refrng::Sha256 h;
+    h.update(msg, (size_t)n);
+    h.finalize(out32);
+}
+uint32_t orc_random_range_u32(const uint8_t* seed32, uint32_t skip_words, uint32_t bound, uint32_t* words_used) {
+    refrng::StdRng r = refrng::StdRng::from_seed(seed32);
+    for (uint32_t i = 0; i < skip_words; i++) r.next_u32();
+    uint64_t before = r.words_drawn;
+    uint32_t v = refrng::random_range_u32(r, bound);
+    *words_used = (uint32_t)(r.words_drawn - before);
+    return v;
+}
+// w[n] (before the reversal), salt[17], digest[65]; returns the u32 words the generator handed out
+uint32_t orc_reference_wall(uint64_t hand_seed, int sanma, uint8_t* w, char* salt, char* digest) {
+    std::vector<uint8_t> ids;
+    for (int i = 0; i < 136; i++)
+        if (!(sanma && i / 4 >= 1 && i / 4 <= 7)) ids.push_back((uint8_t)i);
+    refrng::RefWall r = refrng::reference_wall(hand_seed, ids);
+    std::memcpy(w, r.w.data(), r.w.size());
+    std::strcpy(salt, r.salt.c_str());
+    std::strcpy(digest, r.digest.c_str());
+    return (uint32_t)r.words_drawn;
 }
 void orc_game_free(void* g) { delete (GameState*)g; }
 

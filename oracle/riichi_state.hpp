@@ -10,17 +10,20 @@
 //   riichienv-core/src/action.rs               (Action, encode)
 //   riichienv-python/src/env.rs:799-872        (reset/step binding semantics)
 //
-// Deviation (documented in DESIGN.md): seed -> wall.  The reference shuffles
-// with rand 0.10 StdRng (ChaCha12), which is not in /root/reference and is not
-// pinned by any reference test.  Parity is defined on identical WALLS.  When no
-// wall is injected the build's own counter-based permutation is used (see
-// build_wall below); the HIP path implements the same definition.
+// seed -> wall (documented in DESIGN.md §6).  The reference shuffles with rand 0.10
+// StdRng (ChaCha12) + SliceRandom::shuffle; the crates are not in /root/reference and
+// no reference test pins seed -> wall.  Two definitions exist here and in the HIP path:
+//   * default: the build's own counter-based permutation (build_wall below);
+//   * WallState::reference_rng (RMJ_RULE_REFERENCE_RNG): the restatement of the crates'
+//     published algorithms in ref_rng.hpp, with salt and wall_digest (state/wall.rs:36-56).
+// Parity with the reference itself is defined on identical WALLS (load_wall).
 #pragma once
 #include <map>
 #include <optional>
 #include <string>
 #include <vector>
 
+#include "ref_rng.hpp"
 #include "riichi_core.hpp"
 
 namespace orc {
@@ -162,6 +165,8 @@ struct WallState {
     std::optional<uint64_t> seed;
     uint64_t hand_index = 0;
     bool sanma = false;  // state_3p/wall.rs: 108 tiles, dora/ura pre-extracted
+    bool reference_rng = false;      // RMJ_RULE_REFERENCE_RNG: StdRng + shuffle + salt + digest as the reference (ref_rng.hpp)
+    std::string wall_digest, salt;   // state/wall.rs:15-16 (empty without reference_rng and after load_wall-less event replays)
     uint8_t dora_tiles[5] = {0, 0, 0, 0, 0}, ura_tiles[5] = {0, 0, 0, 0, 0};
 
     void finish_load() {
@@ -181,13 +186,20 @@ struct WallState {
         pending_kan_dora_count = 0;
         drawable_count = 0;
     }
-    // state/wall.rs:36-67 (RNG replaced, digest/salt skipped — see header)
+    // state/wall.rs:36-67, state_3p/wall.rs:75-110
     void shuffle() {
         std::vector<uint8_t> ids;
         for (int i = 0; i < 136; i++)
             if (!(sanma && i / 4 >= 1 && i / 4 <= 7)) ids.push_back((uint8_t)i);  // types.rs:378-382
         uint64_t s = seed ? *seed : 0;
-        std::vector<uint8_t> w = build_wall(s, hand_index, ids);
+        std::vector<uint8_t> w;
+        if (reference_rng) {
+            refrng::RefWall r = refrng::reference_wall(splitmix64(s + hand_index), ids);  // wall.rs:40-42, 45-55
+            w = r.w;
+            salt = r.salt;
+            wall_digest = r.digest;
+        } else
+            w = build_wall(s, hand_index, ids);  // the build's own definition: no salt, no digest
         hand_index += 1;
         std::reverse(w.begin(), w.end());
         tiles = w;
@@ -293,11 +305,13 @@ struct GameState {
     uint64_t step_count = 0;
 
     // state/mod.rs:98-167
-    GameState(uint8_t game_mode_, bool skip_log, std::optional<uint64_t> seed, uint8_t round_wind_, GameRule rule_)
+    GameState(uint8_t game_mode_, bool skip_log, std::optional<uint64_t> seed, uint8_t round_wind_, GameRule rule_,
+              bool reference_rng = false)
         : game_mode(game_mode_), skip_mjai_logging(skip_log), rule(rule_) {
         sanma = game_mode_ >= 3;
         NP = sanma ? 3 : 4;
         wall.sanma = sanma;
+        wall.reference_rng = reference_rng;
         wall.seed = seed;
         round_wind = round_wind_;
         for (auto& p : players) p.score = start_score();

@@ -25,6 +25,7 @@ MELD_NAMES = {"chi": 0, "pon": 1, "daiminkan": 2, "ankan": 3, "kakan": 4}
 
 RULE_TENHOU = 64 | 128
 RULE_MJSOUL = 1 | 2 | 4 | 8 | 16 | 32 | 128
+RULE_REFERENCE_RNG = 256  # not a GameRule field: seed -> wall through the reference's StdRng / shuffle / salt / digest (include/riichi_mi355x.h)
 
 
 def pack_action(atype: int, tile: int | None = None, consume=()) -> int:

@@ -263,6 +263,27 @@ __global__ void k_gather_scores(const GState* core, uint32_t n, int32_t* out, ui
     }
 }
 
+// WallState.salt / wall_digest (state/wall.rs:15-16, 48-55) of games [first, first + n): out[i] = {valid, salt (u64), SHA-256 (8 x u32, big
+// endian words)} as 11 dwords; one lane per game.  valid = GState::wall_meta (RMJ_RULE_REFERENCE_RNG shuffles only).
+__global__ __launch_bounds__(64) void k_wall_digest(const GState* __restrict__ core, const uint8_t* __restrict__ wall, const uint32_t* __restrict__ frozen,
+                                                    uint32_t first, uint32_t n, int tiles, uint32_t* __restrict__ out) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t g = first + i;
+    const uint8_t* W = wall + (size_t)g * RMJ_WALL_STRIDE;
+    uint32_t* o = out + (size_t)i * 11;
+    const uint32_t valid = core[g].wall_meta;
+    uint64_t salt = 0;
+    uint32_t dg[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (valid) {
+        for (int k = 0; k < 8; k++) salt |= (uint64_t)W[136 + k] << (8 * k);
+        if (valid == 2) { for (int k = 0; k < 8; k++) dg[k] = frozen[(size_t)g * 8 + k]; }   // the wall it belonged to is gone
+        else sha256_wall(W, tiles, salt, dg);
+    }
+    o[0] = valid; o[1] = (uint32_t)salt; o[2] = (uint32_t)(salt >> 32);
+    for (int k = 0; k < 8; k++) o[3 + k] = dg[k];
+}
+
 // ---------------------------------------------------------------- batched hand math kernels (one wave per case)
 __device__ inline MeldAgg agg_from_views(const RmjHandCase& hc) {
     MeldAgg m;
@@ -1080,6 +1101,8 @@ static int create_impl(rmj_env* h, const RmjConfig* cfg, uint64_t** d_seeds_out)
     HIPCHK(hipMalloc(&d.events, B * (size_t)r2 * sizeof(RmjEvent)));
     HIPCHK(hipMalloc(&d.win, B * 4 * sizeof(RmjWinResult)));
     HIPCHK(hipMemsetAsync(d.win, 0, B * 4 * sizeof(RmjWinResult), h->stream));
+    HIPCHK(hipMalloc(&d.wall_dg, B * 32));
+    HIPCHK(hipMemsetAsync(d.wall_dg, 0, B * 32, h->stream));
     HIPCHK(hipMalloc(&h->d_actions, B * 4 * sizeof(uint64_t)));
     HIPCHK(hipMalloc(&h->d_counter, sizeof(unsigned long long)));
     {   // The ticket rollout (k_step4_queue) hands a quad from wave to wave through ONE XCD's L2 and keys its eight queues by
@@ -1160,7 +1183,7 @@ int rmj_destroy(rmj_handle h) {
     hipSetDevice(h->cfg.device);
     if (h->stream) hipStreamSynchronize(h->stream);
     if (h->h_pin) hipHostFree(h->h_pin);
-    hipFree(h->d.core); hipFree(h->d.wall); hipFree(h->d.legal); hipFree(h->d.nlegal); hipFree(h->d_decay); if (h->d_scratch) hipFree(h->d_scratch); hipFree(h->d.mask);
+    hipFree(h->d.core); hipFree(h->d.wall); hipFree(h->d.wall_dg); hipFree(h->d.legal); hipFree(h->d.nlegal); hipFree(h->d_decay); if (h->d_scratch) hipFree(h->d_scratch); hipFree(h->d.mask);
     hipFree(h->d.waits); hipFree(h->d.status); hipFree(h->d.events); hipFree(h->d.win); hipFree(h->d_actions); hipFree(h->d_counter); hipFree(h->d_obs_offs); hipFree(h->d_env); hipFree(h->d_qheads);   // (d_qdone lives in the same allocation)
     hipFree(h->d_ev_lost); hipFree(h->d_track); hipFree(h->d_heavy);
     for (int i = 0; i < 2; i++) if (h->ev_time[i]) hipEventDestroy(h->ev_time[i]);
@@ -1200,7 +1223,8 @@ int rmj_clone(rmj_handle h, rmj_handle* out) {
         {c->d.core, h->d.core, B * sizeof(GState)}, {c->d.wall, h->d.wall, B * RMJ_WALL_STRIDE},
         {c->d.legal, h->d.legal, B * 4 * RMJ_MAX_LEGAL * sizeof(uint64_t)}, {c->d.nlegal, h->d.nlegal, B * 4}, {c->d.mask, h->d.mask, B * 4 * 82},
         {c->d.waits, h->d.waits, B * 4 * sizeof(uint64_t)}, {c->d.status, h->d.status, B * sizeof(uint32_t)},
-        {c->d.events, h->d.events, B * ring * sizeof(RmjEvent)}, {c->d.win, h->d.win, B * 4 * sizeof(RmjWinResult)}};
+        {c->d.events, h->d.events, B * ring * sizeof(RmjEvent)}, {c->d.win, h->d.win, B * 4 * sizeof(RmjWinResult)},
+        {c->d.wall_dg, h->d.wall_dg, B * 32}};
     for (const auto& s : slabs) {
         if (hipMemcpyAsync(s.dst, s.src, s.bytes, hipMemcpyDeviceToDevice, c->stream) != hipSuccess) {
             rmj_destroy(c);
@@ -1762,6 +1786,41 @@ int rmj_get_scores(rmj_handle h, int32_t* scores) {
     memcpy(scores, sc.data(), sc.size() * 4);
     return RMJ_OK;
 }
+// state.wall.salt / state.wall.wall_digest of the reference (state/wall.rs:15-16): 17 / 65 bytes per game, NUL-terminated; both empty for a
+// wall without them (no RMJ_RULE_REFERENCE_RNG, or after a start_kyoku event: event_handler.rs:81-82)
+int rmj_get_wall_digests(rmj_handle h, uint32_t first, uint32_t n, char* salts /*[n][17]*/, char* digests /*[n][65]*/) {
+    if (!h || !salts || !digests) return fail(RMJ_ERR_ARG, "null argument");
+    if (first > h->cfg.n_games || n > h->cfg.n_games - first) return fail(RMJ_ERR_RANGE, "game range out of bounds");
+    if (n == 0) return RMJ_OK;
+    HIPCHK(hipSetDevice(h->cfg.device));
+    void* sp;
+    int rcs = scratch_for(h, (size_t)n * 44, &sp);
+    if (rcs) return rcs;
+    hipLaunchKernelGGL(k_wall_digest, dim3((n + 63) / 64), dim3(64), 0, h->stream, h->d.core, h->d.wall, h->d.wall_dg, first, n,
+                       h->cfg.game_mode >= 3 ? 108 : 136, (uint32_t*)sp);
+    HIPCHK(hipGetLastError());
+    std::vector<uint32_t> host((size_t)n * 11);
+    HIPCHK(hipStreamSynchronize(h->stream));
+    HIPCHK(hipMemcpy(host.data(), sp, (size_t)n * 44, hipMemcpyDeviceToHost));
+    static const char* HX = "0123456789abcdef";
+    for (uint32_t i = 0; i < n; i++) {
+        const uint32_t* o = host.data() + (size_t)i * 11;
+        char* s = salts + (size_t)i * 17;
+        char* d = digests + (size_t)i * 65;
+        if (!o[0]) { s[0] = 0; d[0] = 0; continue; }
+        const uint64_t salt = (uint64_t)o[1] | ((uint64_t)o[2] << 32);
+        for (int k = 0; k < 16; k++) s[k] = HX[(salt >> (60 - 4 * k)) & 15];   // format!("{:016x}")
+        s[16] = 0;
+        for (int k = 0; k < 64; k++) d[k] = HX[(o[3 + (k >> 3)] >> (28 - 4 * (k & 7))) & 15];   // format!("{:x}", hasher.finalize())
+        d[64] = 0;
+    }
+    return RMJ_OK;
+}
+int rmj_get_wall_digest(rmj_handle h, uint32_t game, char* salt /*[17]*/, char* digest /*[65]*/) {
+    if (!h) return fail(RMJ_ERR_ARG, "null argument");
+    if (game >= h->cfg.n_games) return fail(RMJ_ERR_RANGE, "game index out of range");
+    return rmj_get_wall_digests(h, game, 1, salt, digest);
+}
 int rmj_get_ranks(rmj_handle h, uint8_t* ranks) {  // env.rs:673-689
     if (!h || !ranks) return fail(RMJ_ERR_ARG, "null argument");
     std::vector<int32_t> sc;
@@ -1859,6 +1918,17 @@ int rmj_poke_state(rmj_handle h, uint32_t game, const RmjStateView* v) {
     uint8_t W[RMJ_WALL_STRIDE];
     SYNC_FETCH(&S, h->d.core + game, sizeof(GState));
     HIPCHK(hipMemcpy(W, h->d.wall + (size_t)game * RMJ_WALL_STRIDE, RMJ_WALL_STRIDE, hipMemcpyDeviceToHost));
+    if (S.wall_meta == 1) {   // the view may carry another wall: salt and digest stay those of the shuffled one (state/wall.rs:69-80)
+        void* sp;
+        int rcs = scratch_for(h, 44, &sp);
+        if (rcs) return rcs;
+        hipLaunchKernelGGL(k_wall_digest, dim3(1), dim3(64), 0, h->stream, h->d.core, h->d.wall, h->d.wall_dg, game, 1u,
+                           h->cfg.game_mode >= 3 ? 108 : 136, (uint32_t*)sp);
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipMemcpyAsync(h->d.wall_dg + (size_t)game * 8, (const uint32_t*)sp + 3, 32, hipMemcpyDeviceToDevice, h->stream));
+        HIPCHK(hipStreamSynchronize(h->stream));
+        S.wall_meta = 2;
+    }
     if (const char* err = rmjh::from_view(S, W, v)) return fail(RMJ_ERR_ARG, err);
     HIPCHK(hipMemcpy(h->d.core + game, &S, sizeof(GState), hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(h->d.wall + (size_t)game * RMJ_WALL_STRIDE, W, RMJ_WALL_STRIDE, hipMemcpyHostToDevice));

@@ -19,6 +19,7 @@ struct Env {
     uint32_t* status;     // [B]  active_mask | phase<<8 | done<<16
     RmjEvent* events;     // [B][ring]
     RmjWinResult* win;    // [B][4]  win_results of the round that ended the game (rare path only)
+    uint32_t* wall_dg;    // [B][8]  RMJ_RULE_REFERENCE_RNG: wall_digest of a wall that is no longer in the wall slab (GState::wall_meta == 2)
     uint32_t ring_mask;   // ring-1
     uint32_t n_games;
     uint32_t rule_bits;
@@ -124,6 +125,9 @@ __device__ __forceinline__ void wave_sync() {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
 }
 __device__ __forceinline__ uint64_t lanemask_lt(int lane) { return (1ull << lane) - 1ull; }
+}  // namespace rmj
+#include "rmj_refrng.hip.h"
+namespace rmj {
 
 // ---------------------------------------------------------------- packed actions
 __device__ __forceinline__ uint64_t mk_action(uint32_t type, uint32_t tile, uint32_t n, uint32_t c0 = 0, uint32_t c1 = 0, uint32_t c2 = 0,

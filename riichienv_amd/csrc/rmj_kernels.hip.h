@@ -143,6 +143,13 @@ __global__ __launch_bounds__(64 * RMJ_STEP_WPB, RMJ_STEP_WAVES) void k_step(cons
     PROF_FLUSH(c.X, lane, g);
 }
 
+__device__ __noinline__ void freeze_wall_digest(const uint8_t* W, int total, uint32_t* out) {
+    uint64_t salt = 0;
+    for (int k = 0; k < 8; k++) salt |= (uint64_t)W[136 + k] << (8 * k);
+    uint32_t dg[8];
+    sha256_wall(W, total, salt, dg);
+    for (int k = 0; k < 8; k++) out[k] = dg[k];
+}
 __global__ __launch_bounds__(256, 4) void k_reset(const Env* __restrict__ Ep, ResetArgs A) {
     CEnv& E = *(CEnv*)Ep;
     __shared__ BlockShared sh;
@@ -181,6 +188,11 @@ __global__ __launch_bounds__(256, 4) void k_reset(const Env* __restrict__ Ep, Re
         if (A.walls) {
             const int total = KSANMA ? 108 : 136;  // 3P: the first 108 entries of the [136] row
             for (int i = lane; i < total; i += 64) c.X.tiles[i] = A.walls[(size_t)g * 136 + (total - 1 - i)];  // load_wall: reverse
+            if (lane < 8) c.X.tiles[136 + lane] = c.W[136 + lane];   // salt / digest stay what they were (state/wall.rs:69-80) ...
+            if (S.wall_meta == 1) {                                   // ... so the digest of the wall that goes away is evaluated now
+                if (lane == 0) freeze_wall_digest(c.W, total, E.wall_dg + (size_t)g * 8);
+                S.wall_meta = 2;
+            }
             wave_sync();
         } else {
             shuffle_wall(c);
@@ -253,6 +265,7 @@ __global__ __launch_bounds__(64) void k_copy_games(const Env* __restrict__ Dp, c
     copy_words(D.status + a, S.status + b, sizeof(uint32_t), lane);
     copy_words(D.events + a * ring, S.events + b * ring, ring * sizeof(RmjEvent), lane);
     copy_words(D.win + a * 4, S.win + b * 4, 4 * sizeof(RmjWinResult), lane);
+    copy_words(D.wall_dg + a * 8, S.wall_dg + b * 8, 32, lane);
 }
 
 }  // namespace RMJ_NS

@@ -96,7 +96,13 @@ struct alignas(16) GState {  // 4*128 + 128 = 640 bytes
     uint8_t tp_seat;
     uint16_t tp_mask;
     uint32_t tp_step;
-    uint8_t pad[128 - 8 - 8 - 20 - 16 - 4 - 6 - 3 - 4 - 4 - 3 - 4 - 32 - 1 - 1 - 2 - 4];
+    // WallState.salt / wall_digest (state/wall.rs:48-55): 1 after a shuffle under RMJ_RULE_REFERENCE_RNG (the salt is kept in bytes
+    // 136..143 of the wall row; the digest is a function of salt and wall, evaluated when asked for: rmj_get_wall_digest); 2 once
+    // that wall has been replaced (load_wall / poke leave salt and digest alone, state/wall.rs:69-80): the digest was evaluated
+    // before the replacement and sits in Env::wall_dg; 0 = empty strings (never shuffled that way, or cleared by a start_kyoku
+    // event, event_handler.rs:81-82)
+    uint8_t wall_meta;
+    uint8_t pad[128 - 8 - 8 - 20 - 16 - 4 - 6 - 3 - 4 - 4 - 3 - 4 - 32 - 1 - 1 - 2 - 4 - 1];
 };
 
 #ifdef __cplusplus

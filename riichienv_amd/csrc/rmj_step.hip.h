@@ -961,7 +961,16 @@ __device__ inline void shuffle_wall(Ctx& c) {
     const int lane = c.lane;
     uint64_t hs = sm64(S.wall_seed + (uint64_t)S.hand_index);
     S.hand_index += 1;
-    const int N = KSANMA ? 108 : 136;  // 3P: ids without 2m-8m (types.rs:378-382)
+    constexpr int N = KSANMA ? 108 : 136;  // 3P: ids without 2m-8m (types.rs:378-382)
+    if (rule(c, RMJ_RULE_REFERENCE_RNG)) {   // the reference's own definition (rmj_refrng.hip.h); salt behind the wall, digest on demand
+        uint8_t* w = c.X.maskbuf;            // scratch (free until finalize): key stream / indices in X.legal, w before the reversal in maskbuf
+        const uint64_t salt = refrng_wall<N, KSANMA>(hs, lane, reinterpret_cast<uint32_t*>(&c.X.legal[0][0]), w);
+        for (int i = lane; i < 144; i += 64) c.X.tiles[i] = i < N ? w[N - 1 - i] : (i >= 136 ? (uint8_t)(salt >> (8 * (i - 136))) : (uint8_t)0);
+        if (lane == 0) S.wall_meta = 1;
+        wave_sync();
+        return;
+    }
+    if (lane < 8) c.X.tiles[136 + lane] = 0;
     // scratch (free until finalize): grouped keys in X.legal[0..135], bucket counters behind them, source index in maskbuf
     uint64_t* gk = &c.X.legal[0][0];
     uint32_t* cnt = reinterpret_cast<uint32_t*>(&c.X.legal[0][0] + 144);  // 129 counters (+1 sentinel)
@@ -1067,7 +1076,7 @@ __device__ inline void init_round(Ctx& c, int oya, int round_wind, int honba, ui
     for (int p = 0; p < 4; p++) S.stale_n[p] = 0;
     // publish the wall to HBM (W) and deal from LDS
     for (int i = lane; i < RMJ_WALL_STRIDE / 4; i += 64)
-        reinterpret_cast<uint32_t*>(c.W)[i] = (i < 34) ? reinterpret_cast<const uint32_t*>(c.X.tiles)[i] : 0u;
+        reinterpret_cast<uint32_t*>(c.W)[i] = reinterpret_cast<const uint32_t*>(c.X.tiles)[i];   // [136..143]: the salt (or 0)
     const int np = KNP;
     const int total = KSANMA ? 108 : 136;
     S.wall_total = (uint8_t)total;
@@ -2124,6 +2133,7 @@ __device__ inline void apply_event(Ctx& c, const RmjEvent* ev) {
             S.dora[0] = (uint8_t)tile;
             S.win_mask = 0;
             for (int i = lane; i < RMJ_WALL_STRIDE / 4; i += 64) reinterpret_cast<uint32_t*>(c.W)[i] = 0u;  // placeholder wall
+            S.wall_meta = 0;   // wall_digest.clear(); salt.clear() (event_handler.rs:81-82)
             for (int p = 0; p < 4; p++) {  // PlayerState::reset_round, state/player.rs:66-86
                 PState& Q = S.p[p];
                 Q.hand_len = 0; Q.n_melds = 0; Q.n_discards = 0;

@@ -1476,6 +1476,38 @@ __device__ __noinline__ void r4_round_end(const Env* Ep, uint32_t g0) {
         const int oya = Gb->oya;
         const uint32_t hidx = Gb->hand_index;
         const uint64_t hs = sm64(Gb->wall_seed + (uint64_t)hidx);   // the build's seed -> wall (shuffle_wall): ids sorted by (key, id)
+        // tile `id` has rank `rk` in w (w[rk] = id): the wall row in load_wall orientation, the indicator, and the deal:
+        // pop #n = W[N - 1 - n] = the element of rank n; three rounds of four tiles per seat from the dealer, then one each
+        auto place = [&](int rk, int id) {
+            const int wpos = N - 1 - rk;
+            Wg[wpos] = (uint8_t)id;
+            if (wpos == (KSANMA ? 8 : 4)) Gb->dora[0] = (uint8_t)id;   // state_3p/wall.rs:104-112
+            const int n = rk;
+            if (n < 12 * KNP) {
+                const int rr = n >= 8 * KNP ? 2 : (n >= 4 * KNP ? 1 : 0), rem = n - rr * 4 * KNP;
+                int p = (rem >> 2) + oya;
+                p = p >= KNP ? p - KNP : p;
+                Gb->p[p].hand[rr * 4 + (rem & 3)] = (uint8_t)id;
+            } else if (n < 13 * KNP) {
+                int p = (n - 12 * KNP) + oya;
+                p = p >= KNP ? p - KNP : p;
+                Gb->p[p].hand[12] = (uint8_t)id;
+            } else if (n == 13 * KNP) {   // the dealer's first draw
+                Gb->p[oya].hand[13] = (uint8_t)id;
+                Gb->drawn_tile = (uint8_t)id;
+            }
+        };
+        if (E.rule_bits & RMJ_RULE_REFERENCE_RNG) {   // the reference's own seed -> wall (rmj_refrng.hip.h)
+            uint8_t* const wl = reinterpret_cast<uint8_t*>(sh.rs) + 256;   // 64 dwords of scratch (key stream, then idx[N]), then w[N]: 392 of the 400 bytes
+            const uint64_t salt = refrng_wall<N, KSANMA>(hs, lane, sh.rs, wl);
+#pragma unroll
+            for (int k = 0; k < 3; k++) {
+                const int i = lane + 64 * k;
+                if (i < N) place(i, wl[i]);
+            }
+            if (lane < (RMJ_WALL_STRIDE - N)) Wg[N + lane] = (N + lane >= 136) ? (uint8_t)(salt >> (8 * (N + lane - 136))) : (uint8_t)0;
+            if (lane == 0) Gb->wall_meta = 1;
+        } else {
         if (lane < 32) cnt[lane] = 0u;
         uint64_t key[3];
         uint32_t pos[3];
@@ -1528,28 +1560,11 @@ __device__ __noinline__ void r4_round_end(const Env* Ep, uint32_t g0) {
                     }
                     rk += less ? 1 : 0;
                 }
-                const int id = (KSANMA && i >= 4) ? i + 28 : i;   // i-th id of the tile universe (3P: no 2m-8m, types.rs:378-382)
-                const int wpos = N - 1 - rk;                       // w[rank] = id, then reversed (load_wall orientation)
-                Wg[wpos] = (uint8_t)id;
-                if (wpos == (KSANMA ? 8 : 4)) Gb->dora[0] = (uint8_t)id;   // state_3p/wall.rs:104-112
-                // deal: pop #n = W[N - 1 - n] = the element of rank n; three rounds of four tiles per seat from the dealer, then one each
-                const int n = rk;
-                if (n < 12 * KNP) {
-                    const int rr = n >= 8 * KNP ? 2 : (n >= 4 * KNP ? 1 : 0), rem = n - rr * 4 * KNP;
-                    int p = (rem >> 2) + oya;
-                    p = p >= KNP ? p - KNP : p;
-                    Gb->p[p].hand[rr * 4 + (rem & 3)] = (uint8_t)id;
-                } else if (n < 13 * KNP) {
-                    int p = (n - 12 * KNP) + oya;
-                    p = p >= KNP ? p - KNP : p;
-                    Gb->p[p].hand[12] = (uint8_t)id;
-                } else if (n == 13 * KNP) {   // the dealer's first draw
-                    Gb->p[oya].hand[13] = (uint8_t)id;
-                    Gb->drawn_tile = (uint8_t)id;
-                }
+                place(rk, (KSANMA && i >= 4) ? i + 28 : i);   // i-th id of the tile universe (3P: no 2m-8m, types.rs:378-382)
             }
         }
         if (lane < (RMJ_WALL_STRIDE - N)) Wg[N + lane] = 0;
+        }
         wave_sync();
         {   // the four hands sorted by counting: lane = 16 * seat + slot
             const int sp = lane >> 4, sl = lane & 15;

@@ -27,7 +27,7 @@ EXPORTS = [
     "rmj_get_waits", "rmj_get_scores", "rmj_get_ranks", "rmj_get_step_counts", "rmj_total_steps", "rmj_peek_state",
     "rmj_poke_state", "rmj_get_event_counts", "rmj_get_events", "rmj_format_event", "rmj_eval_hands",
     "rmj_agari_counts", "rmj_calculate_score", "rmj_shanten", "rmj_effective_tiles", "rmj_best_ukeire", "rmj_apply_events", "rmj_device_views", "rmj_step_ids_device", "rmj_clone", "rmj_copy_games", "rmj_copy_games_device",
-    "rmj_scores_device", "rmj_sync", "rmj_set_stream", "rmj_encode", "rmj_encode_device", "rmj_encode_extended", "rmj_encode_extended_device", "rmj_encode_aux", "rmj_encode_aux_device", "rmj_encode_seq", "rmj_encode_seq_device", "rmj_bench_rollout", "rmj_time_rollout", "rmj_step_greedy", "rmj_time_rollout_greedy", "rmj_time_rollout_encode", "rmj_step_ids_encode_device", "rmj_set_encode_row_stride", "rmj_bench_hand_kernel", "rmj_points_device", "rmj_get_points", "rmj_get_legal_compact",
+    "rmj_scores_device", "rmj_sync", "rmj_set_stream", "rmj_encode", "rmj_encode_device", "rmj_encode_extended", "rmj_encode_extended_device", "rmj_encode_aux", "rmj_encode_aux_device", "rmj_encode_seq", "rmj_encode_seq_device", "rmj_bench_rollout", "rmj_time_rollout", "rmj_step_greedy", "rmj_time_rollout_greedy", "rmj_time_rollout_encode", "rmj_step_ids_encode_device", "rmj_set_encode_row_stride", "rmj_bench_hand_kernel", "rmj_points_device", "rmj_get_points", "rmj_get_legal_compact", "rmj_get_wall_digest", "rmj_get_wall_digests",
     "rmj_bench_rollout_validated", "rmj_bench_encode", "rmj_set_rollout_streams", "rmj_total_full_path",
     "rmj_random_actions_device", "rmj_peek_outputs", "rmj_sample_ids_device",
     "rmj_encode_seq_delta", "rmj_encode_seq_delta_device", "rmj_step_random_encode",
@@ -80,6 +80,8 @@ def load_lib():
     vp = C.c_void_p
     L.rmj_create.argtypes = [C.POINTER(abi.Config), C.POINTER(vp)]
     L.rmj_destroy.argtypes = [vp]
+    L.rmj_get_wall_digest.argtypes = [vp, C.c_uint32, C.c_char_p, C.c_char_p]
+    L.rmj_get_wall_digests.argtypes = [vp, C.c_uint32, C.c_uint32, vp, vp]
     L.rmj_reset.argtypes = [vp] * 8
     L.rmj_step.argtypes = [vp, vp]
     L.rmj_clone.argtypes = [vp, C.POINTER(vp)]
@@ -394,6 +396,19 @@ class VecRiichiEnv:
         v = abi.StateView()
         _chk(self.L.rmj_peek_state(self.h, g, C.byref(v)))
         return v
+
+    def wall_digest(self, g):
+        """(salt, wall_digest) of game g's wall (state/wall.rs:15-16); ("", "") without RULE_REFERENCE_RNG."""
+        salt, dg = C.create_string_buffer(17), C.create_string_buffer(65)
+        _chk(self.L.rmj_get_wall_digest(self.h, int(g), salt, dg))
+        return salt.value.decode(), dg.value.decode()
+
+    def wall_digests(self, first=0, n=None):
+        """[(salt, wall_digest)] of games [first, first + n): one launch, one lane per game."""
+        n = self.n - first if n is None else n
+        salts, dgs = np.zeros((n, 17), np.uint8), np.zeros((n, 65), np.uint8)
+        _chk(self.L.rmj_get_wall_digests(self.h, first, n, salts.ctypes.data, dgs.ctypes.data))
+        return [(bytes(salts[i]).split(b"\0")[0].decode(), bytes(dgs[i]).split(b"\0")[0].decode()) for i in range(n)]
 
     def poke(self, g, v: abi.StateView):
         _chk(self.L.rmj_poke_state(self.h, g, C.byref(v)))

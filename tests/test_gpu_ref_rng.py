@@ -1,0 +1,172 @@
+"""A1 under RMJ_RULE_REFERENCE_RNG: the reference's seed -> wall (state/wall.rs:36-56, state_3p/wall.rs:75-110: StdRng::seed_from_u64 +
+SliceRandom::shuffle + salt + SHA-256 digest) on the device against the oracle's restatement (oracle/ref_rng.hpp; what of it is pinned on
+published vectors: tests/test_oracle_ref_rng.py) - constructor, reset, the next rounds of the full path and of the row-form round end,
+restarts, 4P and 3P; salt / digest strings; what load_wall and a start_kyoku event do to them."""
+import hashlib
+
+import numpy as np
+import pytest
+
+from riichienv_amd import abi
+from riichienv_amd.shard import game_seed
+from tests.parity_util import diff_dict, normalize_view
+
+pytestmark = pytest.mark.gpu
+REF = abi.RULE_REFERENCE_RNG
+
+
+def _meta_equal(env, games, n):
+    dev = env.wall_digests()
+    for g in range(n):
+        assert dev[g] == games[g].wall_meta(), g
+    return dev
+
+
+@pytest.mark.parametrize("mode", [2, 5])
+def test_constructor_and_reset_walls(mode):
+    from oracle import oracle
+    from riichienv_amd import vecenv
+
+    n, seed = 256, 42
+    rule = abi.RULE_TENHOU | REF
+    env = vecenv.VecRiichiEnv(n, game_mode=mode, seed=seed, rule_bits=rule)
+    games = [oracle.Game(game_mode=mode, seed=game_seed(seed, g), rule_bits=rule) for g in range(n)]
+    for g in range(n):
+        d = diff_dict(normalize_view(env.peek(g)), normalize_view(games[g].peek()))
+        assert not d, (g, d[:10])
+    dev = _meta_equal(env, games, n)
+    assert all(len(s) == 16 and len(d) == 64 for s, d in dev) and len({d for _, d in dev}) == n
+    assert env.wall_digest(3) == dev[3]
+    # the digest is SHA-256 of the salt's hex digits and the wall before the reversal: rebuild the wall from the oracle's shuffle
+    for g in (0, 7, n - 1):
+        ep = game_seed(seed, g)   # splitmix64(seed + g) is the episode seed; the first hand seed is splitmix64(episode + 0)
+        w, salt, dg, _ = oracle.reference_wall(game_seed(ep, 0), sanma=mode >= 3)
+        assert (salt, dg) == dev[g]
+        assert dg == hashlib.sha256(salt.encode() + w.tobytes()).hexdigest()
+    env.reset()          # k_reset, second shuffle of every episode seed
+    for o in games:
+        o.reset()
+    for g in range(0, n, 5):
+        d = diff_dict(normalize_view(env.peek(g)), normalize_view(games[g].peek()))
+        assert not d, (g, d[:10])
+    dev2 = _meta_equal(env, games, n)
+    assert all(a != b for a, b in zip(dev, dev2))
+    # an injected wall leaves salt and digest alone (state/wall.rs:69-80)
+    rng = np.random.default_rng(3)
+    total = 108 if mode >= 3 else 136
+    ids = [i for i in range(136) if not (mode >= 3 and 1 <= i // 4 <= 7)]
+    walls = np.zeros((n, 136), np.uint8)
+    for g in range(n):
+        walls[g, :total] = rng.permutation(ids)
+    env.reset(walls=walls)
+    for g, o in enumerate(games):
+        o.reset(wall=[int(x) for x in walls[g, :total]] + [0] * (136 - total))
+    assert _meta_equal(env, games, n) == dev2
+    for g in range(0, n, 9):
+        d = diff_dict(normalize_view(env.peek(g)), normalize_view(games[g].peek()))
+        assert not d, (g, d[:10])
+
+
+@pytest.mark.parametrize("mode,steps", [(2, 700), (5, 700), (0, 400)])
+def test_rollouts_deal_the_reference_walls(mode, steps):
+    """fused RandomAgent rollout (row-form round ends: r4_round_end deals), auto-reset restarts included: logs, states, salts, digests"""
+    from oracle import oracle
+    from riichienv_amd import vecenv
+
+    n, seed, pseed = 64, 7 + mode, 99
+    rule = abi.RULE_TENHOU | REF
+    env = vecenv.VecRiichiEnv(n, game_mode=mode, seed=seed, rule_bits=rule, event_ring=4096)
+    games = [oracle.Game(game_mode=mode, seed=game_seed(seed, g), rule_bits=rule) for g in range(n)]
+    env.reset()
+    for o in games:
+        o.reset()
+    env.step_random(pseed, steps, auto_reset=True)
+    for g, o in enumerate(games):
+        for _ in range(steps):
+            if o.status()[2]:
+                o.reset()
+                continue
+            o.step(o.random_actions(pseed, g))
+    kyoku = 0
+    for g, o in enumerate(games):
+        d = diff_dict(normalize_view(env.peek(g)), normalize_view(o.peek()))
+        assert not d, (g, d[:10])
+        assert env.mjai_log(g) == o.log(), g
+        kyoku += sum('"start_kyoku"' in e for e in o.log())
+    assert kyoku >= 3 * n if mode != 0 else kyoku >= n
+    _meta_equal(env, games, n)
+
+
+@pytest.mark.parametrize("mode", [2, 5])
+def test_per_step_launches_and_greedy_policy(mode):
+    """every step its own launch (the rich tier: settlements in row form, bails into the full path's shuffle_wall) + the greedy policy"""
+    from oracle import oracle
+    from riichienv_amd import vecenv
+
+    n, seed, pseed = 48, 21, 5
+    rule = abi.RULE_MJSOUL | REF
+    env = vecenv.VecRiichiEnv(n, game_mode=mode, seed=seed, rule_bits=rule, event_ring=4096)
+    games = [oracle.Game(game_mode=mode, seed=game_seed(seed, g), rule_bits=rule) for g in range(n)]
+    env.reset()
+    for o in games:
+        o.reset()
+    for step in range(500):
+        acts = np.array([games[g].random_actions(pseed, g) for g in range(n)], dtype=np.uint64)
+        env.step(acts)
+        for g in range(n):
+            games[g].step([int(x) for x in acts[g]])
+    _meta_equal(env, games, n)
+    for g, o in enumerate(games):
+        assert env.mjai_log(g) == o.log(), g
+    env.step_greedy(pseed, 300, auto_reset=False, call_rate_256=64)
+    for g, o in enumerate(games):
+        for _ in range(300):
+            if o.status()[2]:
+                break
+            o.step(o.greedy_actions(pseed, g, 64))
+    _meta_equal(env, games, n)
+    for g, o in enumerate(games):
+        d = diff_dict(normalize_view(env.peek(g)), normalize_view(o.peek()))
+        assert not d, (g, d[:10])
+        assert env.mjai_log(g) == o.log(), g
+
+
+def test_start_kyoku_event_clears_salt_and_digest_and_default_walls_have_none():
+    from oracle import oracle
+    from riichienv_amd import vecenv
+
+    n = 8
+    env = vecenv.VecRiichiEnv(n, game_mode=2, seed=1, rule_bits=abi.RULE_TENHOU | REF)
+    games = [oracle.Game(game_mode=2, seed=game_seed(1, g), rule_bits=abi.RULE_TENHOU | REF) for g in range(n)]
+    assert all(len(s) == 16 for s, _ in env.wall_digests())
+    ev = {"type": "start_kyoku", "bakaze": "E", "kyoku": 1, "honba": 0, "kyotaku": 0, "oya": 0, "dora_marker": "1m",
+          "scores": [25000] * 4, "tehais": [["1m"] * 13, ["2m"] * 13, ["3m"] * 13, ["4m"] * 13]}
+    env.apply_events([ev] * n)
+    for o in games:
+        o.apply_event(ev)
+    assert env.wall_digests() == [("", "")] * n
+    _meta_equal(env, games, n)
+    plain = vecenv.VecRiichiEnv(n, game_mode=2, seed=1)
+    assert plain.wall_digests() == [("", "")] * n
+
+
+def test_poke_keeps_salt_and_digest_of_the_shuffled_wall():
+    from oracle import oracle
+    from riichienv_amd import vecenv
+
+    rule = abi.RULE_TENHOU | REF
+    env = vecenv.VecRiichiEnv(4, game_mode=2, seed=9, rule_bits=rule)
+    o = oracle.Game(game_mode=2, seed=game_seed(9, 1), rule_bits=rule)
+    before = env.wall_digest(1)
+    assert before == o.wall_meta()
+    v = o.peek()
+    w = list(v.wall[: v.wall_len])
+    w[0], w[1] = w[1], w[0]
+    for i, t in enumerate(w):
+        v.wall[i] = t
+    env.poke(1, v)
+    o.poke(v)
+    assert env.wall_digest(1) == before == o.wall_meta()
+    assert list(env.peek(1).wall[:4]) == w[:4]
+    fork = env.clone()
+    assert fork.wall_digest(1) == before

@@ -1,0 +1,185 @@
+"""Pins of oracle/ref_rng.hpp: the third-party algorithms behind the reference's seed -> wall (state/wall.rs:36-56; crates
+rand 0.10.0 / rand_core 0.10.0 / chacha20 0.10.0 / sha2 0.10.9 of Cargo.lock, none of them in /root/reference).
+
+Pinned on PUBLISHED vectors: the ChaCha block function (8 / 12 / 20 rounds), StdRng's construction and word order (rand's
+own value-stability vector), SHA-256.  UNPINNED (restated, self-consistency only): seed_from_u64's PCG32 expansion and the index
+draws of SliceRandom::shuffle - the tests below check their defining properties, not reference outputs."""
+import hashlib
+import struct
+
+import numpy as np
+import pytest
+
+from oracle import oracle
+from riichienv_amd import abi
+
+
+def _hex(words):
+    return struct.pack("<16I", *[int(x) for x in words]).hex()
+
+
+def test_chacha_block_published_vectors():
+    # draft-strombergson-chacha-test-vectors, TC1 (all-zero key and IV), 256-bit key, first key stream block
+    z = [0] * 8
+    assert _hex(oracle.chacha_block(z, rounds=8)) == (
+        "3e00ef2f895f40d67f5bb8e81f09a5a12c840ec3ce9a7f3b181be188ef711a1e984ce172b9216f419f445367456d5619314a42a3da86b001387bfdb80e0cfe42")
+    assert _hex(oracle.chacha_block(z, rounds=12)) == (
+        "9bf49a6a0755f953811fce125f2683d50429c3bb49e074147e0089a52eae155f0564f879d27ae3c02ce82834acfa8c793a629f2ca0de6919610be82f411326be")
+    assert _hex(oracle.chacha_block(z, rounds=20)) == (
+        "76b8e0ada0f13d90405d6ae55386bd28bdd219b8a08ded1aa836efcc8b770dc7da41597c5157488d7724e03fb8d84a376a43b8f41518a11cc387b669b2ee6586")
+    # RFC 7539 §2.3.2 (ChaCha20 block: key 00..1f, counter 1, nonce 00:00:00:09 00:00:00:4a 00:00:00:00).  With the 64-bit counter
+    # layout words 12-13 are the counter and 14-15 the stream id: counter = 1 | 0x09000000 << 32, stream = 0x4a000000
+    key = struct.unpack("<8I", bytes(range(32)))
+    out = oracle.chacha_block(key, counter=1 | (0x09000000 << 32), stream=0x4A000000, rounds=20)
+    assert _hex(out) == ("10f1e7e4d13b5915500fdd1fa32071c4c7d1f4c733c068030422aa9ac3d46c4e"
+                         "d2826446079faa0914c2d705d98b02a2b5129cd1de164eb9cbd083e8a2503c4e")
+
+
+def test_stdrng_construction_value_stability_vector():
+    # rand, src/rngs/std.rs `test_stdrng_construction`: StdRng::from_seed(seed).next_u64() and, for the generator made by
+    # StdRng::from_rng of it (32 seed bytes = the next eight words), next_u64()
+    seed = bytes([1, 0, 0, 0, 23, 0, 0, 0, 200, 1, 0, 0, 210, 30, 0, 0] + [0] * 16)
+    w = oracle.stdrng_words(seed, 10)
+    assert int(w[0]) | int(w[1]) << 32 == 10719222850664546238
+    seed1 = struct.pack("<8I", *[int(x) for x in w[2:10]])
+    w1 = oracle.stdrng_words(seed1, 2)
+    assert int(w1[0]) | int(w1[1]) << 32 == 14064965282130556830
+
+
+def test_chacha20_rng_construction_vector():
+    # rand_chacha `test_chacha_construction` (ChaCha20): same stream construction with 20 rounds
+    seed = bytes([0, 0, 0, 0, 0, 0, 0, 0, 1, 0, 0, 0, 0, 0, 0, 0, 2, 0, 0, 0, 0, 0, 0, 0, 3, 0, 0, 0, 0, 0, 0, 0])
+    out = oracle.chacha_block(struct.unpack("<8I", seed), rounds=20)
+    assert int(out[0]) == 137206642
+
+
+def test_stdrng_stream_is_the_key_stream_across_blocks():
+    seed = bytes(range(7, 39))
+    w = oracle.stdrng_words(seed, 200)
+    key = struct.unpack("<8I", seed)
+    ks = np.concatenate([oracle.chacha_block(key, counter=b, rounds=12) for b in range(13)])
+    assert (w == ks[:200]).all()
+
+
+def test_sha256_fips_examples_and_hashlib():
+    assert oracle.sha256(b"abc").hex() == "ba7816bf8f01cfea414140de5dae2223b00361a396177a9cb410ff61f20015ad"
+    assert oracle.sha256(b"").hex() == "e3b0c44298fc1c149afbf4c8996fb92427ae41e4649b934ca495991b7852b855"
+    assert oracle.sha256(b"abcdbcdecdefdefgefghfghighijhijkijkljklmklmnlmnomnopnopq").hex() == (
+        "248d6a61d20638b8e5c026930c3e6039a33ce45964ff2167f6ecedd419db06c1")
+    rng = np.random.default_rng(5)
+    for n in [1, 55, 56, 57, 63, 64, 65, 119, 120, 124, 152, 1000]:
+        m = rng.integers(0, 256, n, dtype=np.uint8).tobytes()
+        assert oracle.sha256(m) == hashlib.sha256(m).digest()
+
+
+def test_seed_from_u64_is_pcg32_xsh_rr():
+    """self-consistency with an independent restatement (rand_core's `seed_from_u64`: PCG32 steps, MUL / INC of the crate)"""
+    def pcg(state):
+        out = b""
+        for _ in range(8):
+            state = (state * 6364136223846793005 + 11634580027462260723) & (2**64 - 1)
+            x = (((state >> 18) ^ state) >> 27) & 0xFFFFFFFF
+            r = state >> 59
+            out += struct.pack("<I", ((x >> r) | (x << (32 - r))) & 0xFFFFFFFF if r else x)
+        return out
+    for s in [0, 1, 42, 2**64 - 1, 0x9E3779B97F4A7C15]:
+        assert oracle.seed_from_u64(s) == pcg(s)
+
+
+def test_random_range_is_canon_on_u32_samples():
+    seed = bytes(range(32))
+    w = [int(x) for x in oracle.stdrng_words(seed, 64)]
+    for skip in range(40):
+        for bound in [2, 479001600, 136 ** 4, 0xFFFFFFFF, 3]:
+            v, used = oracle.random_range_u32(seed, skip, bound)
+            m = w[skip] * bound
+            hi, lo = m >> 32, m & 0xFFFFFFFF
+            if lo > (2**32 - bound):
+                assert used == 2
+                hi += (lo + ((w[skip + 1] * bound) >> 32)) >> 32
+            else:
+                assert used == 1
+            assert v == hi and v < bound
+
+
+@pytest.mark.parametrize("sanma", [False, True])
+def test_reference_wall_properties(sanma):
+    ids = [i for i in range(136) if not (sanma and 1 <= i // 4 <= 7)]
+    seen = set()
+    for hs in range(200):
+        w, salt, dg, words = oracle.reference_wall(hs * 0x9E3779B97F4A7C15 & (2**64 - 1), sanma)
+        assert sorted(w.tolist()) == ids
+        assert len(salt) == 16 and int(salt, 16) >= 0
+        assert dg == hashlib.sha256(salt.encode() + w.tobytes()).hexdigest()   # state/wall.rs:50-55
+        assert words <= 2 * 40 + 2
+        seen.add(w.tobytes())
+    assert len(seen) == 200
+
+
+def _independent_shuffle(ids, words):
+    """rand's shuffle restated a second time, directly from the description: indices cut from chunks, chunks from Canon."""
+    it = iter(words)
+
+    def rr(bound):
+        m = next(it) * bound
+        hi, lo = m >> 32, m & 0xFFFFFFFF
+        if lo > ((-bound) & 0xFFFFFFFF):
+            hi += (lo + ((next(it) * bound) >> 32)) >> 32
+        return hi
+    v = list(ids)
+    i = 1   # index 0 swaps with itself without a sample
+    while i < len(v):
+        m = i + 1
+        prod, cur = m, m + 1
+        while prod * cur <= 0xFFFFFFFF:
+            prod *= cur
+            cur += 1
+        cnt = cur - m
+        chunk = rr(prod)
+        for k in range(cnt):
+            if i >= len(v):
+                break
+            n = i + 1
+            if k == cnt - 1:
+                idx = chunk
+            else:
+                idx, chunk = chunk % n, chunk // n
+            v[i], v[idx] = v[idx], v[i]
+            i += 1
+    return v, it
+
+
+@pytest.mark.parametrize("sanma", [False, True])
+def test_reference_wall_against_second_restatement(sanma):
+    ids = [i for i in range(136) if not (sanma and 1 <= i // 4 <= 7)]
+    for hs in [0, 1, 42, 0xDEADBEEF, 2**63 + 12345]:
+        w, salt, dg, words = oracle.reference_wall(hs, sanma)
+        stream = [int(x) for x in oracle.stdrng_words(oracle.seed_from_u64(hs), 128)]
+        v, it = _independent_shuffle(ids, stream)
+        assert v == w.tolist()
+        lo, hi = next(it), next(it)
+        assert salt == "%016x" % (hi << 32 | lo)
+
+
+def test_game_with_reference_rng_flag():
+    """the flag switches the seeded shuffle only: salt / digest per round (tests.rs:155-170: digests differ between rounds),
+    load_wall leaves them alone (state/wall.rs:69-80), games without the flag have neither"""
+    g = oracle.Game(game_mode=2, seed=42, rule_bits=abi.RULE_TENHOU | abi.RULE_REFERENCE_RNG)
+    salt0, dg0 = g.wall_meta()
+    assert len(salt0) == 16 and len(dg0) == 64
+    v = g.peek()
+    # wall after the reversal = reversed(w); the first hand_seed is splitmix64(seed + 0)
+    def sm(x):
+        z = (x + 0x9E3779B97F4A7C15) & (2**64 - 1)
+        z = ((z ^ (z >> 30)) * 0xBF58476D1CE4E5B9) & (2**64 - 1)
+        z = ((z ^ (z >> 27)) * 0x94D049BB133111EB) & (2**64 - 1)
+        return z ^ (z >> 31)
+    w, salt, dg, _ = oracle.reference_wall(sm(42), False)
+    assert (salt, dg) == (salt0, dg0)
+    assert v.dora[0] == w[::-1][4]
+    h = oracle.Game(game_mode=2, seed=42)
+    assert h.wall_meta() == ("", "")
+    g.reset()          # second shuffle of the same episode seed: hand_index 1
+    assert g.wall_meta() == oracle.reference_wall(sm(43), False)[1:3]
+    g.reset(wall=list(range(136)))
+    assert g.wall_meta() == oracle.reference_wall(sm(43), False)[1:3]   # stale, like the reference

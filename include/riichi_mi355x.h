@@ -272,7 +272,8 @@ typedef struct RmjWinResult { /* WinResult, types.rs:282-293 */
 } RmjWinResult;
 int rmj_get_win_results(rmj_handle h, uint32_t game, RmjWinResult* out /*[4]*/, uint8_t* seat_mask);
 
-/* MJAI events: total number emitted so far per game, and a window of records. */
+/* MJAI events: records of the CURRENT game's log per slot (len(mjai_log): a reset / auto-reset starts it again, state/mod.rs:171-187),
+ * and a window of them (`first` counts from the current game's first record). */
 int rmj_get_event_counts(rmj_handle h, uint32_t* counts /*[n]*/);
 int rmj_get_events(rmj_handle h, uint32_t game, uint32_t first, uint32_t max_events, RmjEvent* out, uint32_t* n_out);
 /* Formats one event (START_KYOKU consumes the 2 TEHAI continuation records that follow it; returns
@@ -280,30 +281,41 @@ int rmj_get_events(rmj_handle h, uint32_t game, uint32_t first, uint32_t max_eve
 int rmj_format_event(const RmjEvent* ev, uint32_t n_avail, int seat, char* buf, uint32_t cap);
 /* The logs of MANY games at once (RiichiEnv.mjai_log / the per-seat logs of every env, riichienv-python/src/env.rs:729-739,
  * state/mod.rs:2094-2148).
- * rmj_drain_events: the records every game wrote since cursor[g] (a count of records, 0 = from the start), gathered on the device
- * into one dense buffer and copied down once: game g's records are out[offsets[g] .. offsets[g + 1]) (offsets has n + 1 slots),
- * cursor[g] becomes the game's record count.  A game whose ring was lapped since its cursor has lost its oldest records: the window
- * then starts at the oldest one still there and the loss is added to RmjEventViews.lost[g] (a restart by auto-reset / rmj_reset starts
- * the game's count at 0 again: pass a cursor of 0 for such games, or drain before the restart).  When more than cap_events records
- * are waiting nothing is drained, *n_events holds the number, the result is RMJ_ERR_RANGE.
+ * Every game SLOT writes one record stream: its position (the number of records the slot has emitted since rmj_create) never goes
+ * back - a restart by auto-reset / rmj_reset / a start_game event only moves the position at which the current game's log begins
+ * (rmj_get_log_positions: base) - and record i sits in ring slot i & (ring - 1) whichever game wrote it.  Cursors are such positions,
+ * so a cursor stays valid across restarts and a window may hold the end of one game and the start of the next.
+ * rmj_drain_events: the records every slot wrote since cursor[g] (0 = from the start of the stream), gathered on the device into
+ * one dense buffer and copied down once: slot g's records are out[offsets[g] .. offsets[g + 1]) (offsets has n + 1 slots),
+ * cursor[g] becomes the slot's position.  A slot whose ring was lapped since its cursor has lost its oldest records: the window
+ * then starts at the oldest one still there and the loss is added to RmjEventViews.lost[g] - by the call that hands the window
+ * over, not by a failed call, and not under RMJ_DRAIN_PEEK (cursors are then input only: a look at the rings).  When more than
+ * cap_events records are waiting nothing is drained, *n_events holds the number, the result is RMJ_ERR_RANGE.
  * rmj_format_events: the strings of such a buffer, formatted by a pool of host threads: game g's log - its events' strings, each
  * followed by '\n' - is buf[text_offsets[g] .. text_offsets[g + 1]); *needed = bytes of all logs; RMJ_ERR_RANGE (nothing written) when
  * cap is smaller.  seat as in rmj_format_event.
  * rmj_drain_format: both in one call through pinned staging owned by the handle (no intermediate copy); ms, when given, receives the
- * milliseconds of the device gather, the copy to the host and the formatting. */
-int rmj_drain_events(rmj_handle h, uint32_t* cursor /*[n] in/out*/, RmjEvent* out, uint32_t cap_events, uint32_t* offsets /*[n + 1]*/, uint32_t* n_events);
+ * milliseconds of the device gather, the copy to the host and the formatting.  A size call (buf = NULL: RMJ_ERR_RANGE, *needed set)
+ * keeps what it gathered; the call that follows with the same cursors and seat only formats (the drain is "as of the size call").
+ * rmj_get_log_positions: per slot, where the current game's log begins (base) and the stream position (pos); either may be NULL. */
+#define RMJ_DRAIN_PEEK 1u
+int rmj_get_log_positions(rmj_handle h, uint32_t* base /*[n]*/, uint32_t* pos /*[n]*/);
+int rmj_drain_events(rmj_handle h, uint32_t* cursor /*[n] in/out*/, RmjEvent* out, uint32_t cap_events, uint32_t* offsets /*[n + 1]*/, uint32_t* n_events,
+                     uint32_t flags);
 int rmj_format_events(const RmjEvent* ev, const uint32_t* offsets, uint32_t n_games, int seat, char* buf, uint64_t cap, uint64_t* text_offsets /*[n + 1]*/,
                       uint64_t* needed);
 int rmj_drain_format(rmj_handle h, uint32_t* cursor /*[n] in/out*/, int seat, char* buf, uint64_t cap, uint64_t* text_offsets /*[n + 1]*/, uint64_t* needed,
-                     uint32_t* n_events, double* ms /*[3] or NULL*/);
-/* Device views of the event stream for a consumer on the same GPU: game g's record i (i < count) sits at events[g * ring + (i & (ring - 1))]
- * while count - i <= ring; count = *(const uint32_t*)((const char*)ev_count + g * ev_count_stride). */
+                     uint32_t* n_events, double* ms /*[3] or NULL*/, uint32_t flags);
+/* Device views of the event stream for a consumer on the same GPU: slot g's record i (a stream position, i < count) sits at
+ * events[g * ring + (i & (ring - 1))] while count - i <= ring; count = *(const uint32_t*)((const char*)ev_count + g * ev_count_stride);
+ * the current game's log begins at position *(const uint32_t*)((const char*)ev_base + g * ev_count_stride). */
 typedef struct RmjEventViews {
     uint32_t n_games, ring;
     const RmjEvent* events;      /* [n][ring] */
     const uint32_t* ev_count;    /* first game's record count; the others follow at ev_count_stride bytes */
     uint32_t ev_count_stride, reserved;
     const uint32_t* lost;        /* [n] records lost to a late drain, cumulative */
+    const uint32_t* ev_base;     /* first slot's log base; the others follow at ev_count_stride bytes */
 } RmjEventViews;
 int rmj_event_views(rmj_handle h, RmjEventViews* out);
 int rmj_get_events_lost(rmj_handle h, uint32_t* lost /*[n]*/); /* host copy of RmjEventViews.lost */

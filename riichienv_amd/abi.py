@@ -200,7 +200,7 @@ class WinResult(C.Structure):
 
 class EventViews(C.Structure):   # RmjEventViews
     _fields_ = [("n_games", C.c_uint32), ("ring", C.c_uint32), ("events", C.c_void_p), ("ev_count", C.c_void_p),
-                ("ev_count_stride", C.c_uint32), ("reserved", C.c_uint32), ("lost", C.c_void_p)]
+                ("ev_count_stride", C.c_uint32), ("reserved", C.c_uint32), ("lost", C.c_void_p), ("ev_base", C.c_void_p)]
 
 
 class Config(C.Structure):

@@ -259,8 +259,12 @@ __global__ void k_gather_scores(const GState* core, uint32_t n, int32_t* out, ui
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) {
         for (int p = 0; p < 4; p++) out[(size_t)i * 4 + p] = core[i].p[p].score;
-        if (evc) evc[i] = core[i].ev_count;
+        if (evc) evc[i] = core[i].ev_count - core[i].ev_base;   // len(mjai_log) of the current game
     }
+}
+__global__ void k_log_positions(const GState* core, uint32_t n, uint32_t* base, uint32_t* pos) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) { base[i] = core[i].ev_base; pos[i] = core[i].ev_count; }
 }
 
 // WallState.salt / wall_digest (state/wall.rs:15-16, 48-55) of games [first, first + n): out[i] = {valid, salt (u64), SHA-256 (8 x u32, big
@@ -990,6 +994,12 @@ struct rmj_env {
     uint32_t max_xcc_id = 0;        // largest HW_REG_XCC_ID seen by a probe launch at create: the ticket rollout assumes ids 0..7 (one L2 per queue)
     uint32_t* d_ev_lost = nullptr;  // [n_games] records a game's ring lost to a late drain (rmj_drain_events), cumulative
     void* d_track = nullptr;        // round tracker (rmj_round_track_device): hand index / scores / meta where every game's round began
+    // staging of rmj_drain_format's size call (the records sit in h_pin): reused by the call that brings the text buffer
+    bool stage_valid = false;
+    int stage_seat = 0;
+    uint32_t stage_events = 0;
+    double stage_ms[2] = {0, 0};
+    std::vector<uint32_t> stage_cursor;
     void* h_pin = nullptr;          // pinned host staging of the host-buffer entry points (rmj_get_legal_compact, rmj_drain_*), grown on demand
     size_t pin_bytes = 0;
     int enc_streams = 0;            // RMJ_ENC_STREAMS at create (0: want_streams): parts of the step + encode rollout
@@ -1724,6 +1734,7 @@ int rmj_get_legal_compact(rmj_handle h, uint32_t* index, uint32_t* offsets /*[ca
                        (const uint32_t*)pre, (const uint32_t*)blk, cap_rows, cap_entries, d_idx, d_off, d_ent);
     HIPCHK(hipGetLastError());
     const size_t need_pin = 16 + (size_t)cap_rows * 8 + 4 + (size_t)cap_entries * 8;
+    h->stage_valid = false;   // (the pinned staging is shared with rmj_drain_format's size call)
     if (need_pin > h->pin_bytes) {
         if (h->h_pin) hipHostFree(h->h_pin);
         h->h_pin = nullptr; h->pin_bytes = 0;
@@ -1888,13 +1899,14 @@ int rmj_get_events(rmj_handle h, uint32_t game, uint32_t first, uint32_t max_eve
     if (game >= h->cfg.n_games) return fail(RMJ_ERR_RANGE, "game index out of range");
     GState st;
     SYNC_FETCH(&st, h->d.core + game, sizeof(GState));
-    uint32_t total = st.ev_count;
-    uint32_t lo = total > h->ring ? total - h->ring : 0;
+    // `first` counts from the current game's first record (GameState.mjai_log: a reset starts it again); the ring runs on stream positions
+    const uint32_t total = st.ev_count - st.ev_base;
+    const uint32_t lo = total > h->ring ? total - h->ring : 0;
     if (first < lo) return fail(RMJ_ERR_RANGE, "requested events already overwritten in the ring (create with a larger event_ring)");
     uint32_t n = 0;
     std::vector<RmjEvent> ring(h->ring);
     HIPCHK(hipMemcpy(ring.data(), h->d.events + (size_t)game * h->ring, (size_t)h->ring * sizeof(RmjEvent), hipMemcpyDeviceToHost));
-    for (uint32_t i = first; i < total && n < max_events; i++) out[n++] = ring[i & (h->ring - 1)];
+    for (uint32_t i = first; i < total && n < max_events; i++) out[n++] = ring[(st.ev_base + i) & (h->ring - 1)];
     *n_out = n;
     return RMJ_OK;
 }
@@ -2004,20 +2016,23 @@ static int round_track_impl(rmj_env* h, int baseline, uint8_t* d_ended, int32_t*
 
 // ---- bulk drain of the event rings ----------------------------------------------------------
 // RiichiEnv.mjai_log / per-seat logs of EVERY game (riichienv-python/src/env.rs:729-739, state/mod.rs:2094-2148): the records each
-// game wrote since the caller's cursor, gathered on the device into one dense buffer (two-level scan of the counts, one wave per
-// game copies its window of the ring) and brought down with one copy.  A game whose ring was lapped since its cursor lost its oldest
-// records: the loss is counted per game (RmjEventViews.lost, cumulative) and the window starts at the oldest record still there.
+// game slot wrote since the caller's cursor, gathered on the device into one dense buffer (two-level scan of the counts, one wave per
+// game copies its window of the ring) and brought down with one copy.  Cursors are positions in the slot's record stream
+// (GState::ev_count never goes back: a restart moves ev_base), so a window may hold the end of one game and the start of the next.
+// A slot whose ring was lapped since its cursor lost its oldest records: the window starts at the oldest record still there; the loss is
+// booked per slot (RmjEventViews.lost, cumulative) by the drain that hands the window over, not by peeks or failed calls.
 __global__ __launch_bounds__(LC_BLOCK) void k_ev_count(const GState* __restrict__ core, uint32_t n, uint32_t ring, const uint32_t* __restrict__ cursor,
-                                                       uint32_t* __restrict__ first, uint32_t* __restrict__ pre, uint32_t* __restrict__ blk, uint32_t* __restrict__ lost, int commit) {
+                                                       uint32_t* __restrict__ first, uint32_t* __restrict__ pre, uint32_t* __restrict__ blk) {
     __shared__ uint32_t sc[LC_BLOCK];
     const uint32_t g = blockIdx.x * LC_BLOCK + threadIdx.x;
     uint32_t c = 0;
     if (g < n) {
-        const uint32_t total = core[g].ev_count, cur = cursor[g] < total ? cursor[g] : total;
-        const uint32_t lo = (total - cur > ring) ? total - ring : cur;
-        if (commit && lo != cur) lost[g] += lo - cur;
-        first[g] = lo;
-        c = total - lo;
+        const uint32_t total = core[g].ev_count;
+        uint32_t behind = total - cursor[g];           // wrap-safe distance; a cursor "ahead" of the stream (not this slot's) reads as nothing new
+        if (behind > 0x80000000u) behind = 0u;
+        const uint32_t take = behind > ring ? ring : behind;
+        first[g] = total - take;
+        c = take;
     }
     sc[threadIdx.x] = c;
     __syncthreads();
@@ -2037,45 +2052,54 @@ __global__ void k_ev_scan(uint32_t* blk, uint32_t blocks, uint32_t* total) {
     for (uint32_t b = 0; b < blocks; b++) { const uint32_t c = blk[b]; blk[b] = r; r += c; }
     total[0] = r;
 }
-// one wave per game: lane = (record, half) - 16 bytes per lane, 32 records per pass
+// one wave per game: lane = (record, half) - 16 bytes per lane, 32 records per pass.  newcur[g] = the position behind the window;
+// `until` (optional): positions the window stops at (the staged totals of a size call)
 __global__ __launch_bounds__(256) void k_ev_gather(const GState* __restrict__ core, const RmjEvent* __restrict__ events, uint32_t n, uint32_t ring,
                                                    const uint32_t* __restrict__ first, const uint32_t* __restrict__ pre, const uint32_t* __restrict__ blk,
-                                                   uint32_t cap, RmjEvent* __restrict__ out, uint32_t* __restrict__ offs, uint32_t* __restrict__ cursor) {
+                                                   uint32_t cap, RmjEvent* __restrict__ out, uint32_t* __restrict__ offs, uint32_t* __restrict__ newcur) {
     const uint32_t g = blockIdx.x * 4u + (threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
     if (g >= n) return;
-    const uint32_t total = core[g].ev_count, lo = first[g], base = blk[g / LC_BLOCK] + pre[g];
+    const uint32_t total = core[g].ev_count, lo = first[g], base = blk[g / LC_BLOCK] + pre[g], cnt = total - lo;
     const uint4* src = reinterpret_cast<const uint4*>(events + (size_t)g * ring);
     uint4* dst = reinterpret_cast<uint4*>(out);
-    for (uint32_t i = lo + (uint32_t)(lane >> 1); i < total; i += 32u) {
-        const uint32_t o = base + (i - lo);
-        if (o < cap) dst[2 * (size_t)o + (lane & 1)] = src[2 * (size_t)(i & (ring - 1u)) + (lane & 1)];
+    for (uint32_t k = (uint32_t)(lane >> 1); k < cnt; k += 32u) {
+        const uint32_t o = base + k;
+        if (o < cap) dst[2 * (size_t)o + (lane & 1)] = src[2 * (size_t)((lo + k) & (ring - 1u)) + (lane & 1)];
     }
     if (lane == 0) {
         offs[g] = base;
-        if (g == n - 1u) offs[n] = base + (total - lo);
-        cursor[g] = total;
+        if (g == n - 1u) offs[n] = base + cnt;
+        newcur[g] = total;
     }
 }
-// the device part of a drain: cursor (host, in / out) -> the handle's scratch holds [cursor | first | pre | blk | total | offsets | records]
-struct DrainPlan { uint32_t *d_cur, *d_first, *d_pre, *d_blk, *d_tot, *d_off; RmjEvent* d_ev; uint32_t cap; };
-static int drain_device(rmj_env* h, const uint32_t* cursor, uint32_t cap_events, DrainPlan* P, uint32_t* n_events, int commit) {
+// the drain is handed over: what its windows skipped is lost
+__global__ void k_ev_book(const uint32_t* __restrict__ cursor, const uint32_t* __restrict__ first, uint32_t n, uint32_t* __restrict__ lost) {
+    const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= n) return;
+    const uint32_t skipped = first[g] - cursor[g];
+    if (skipped && skipped <= 0x80000000u) lost[g] += skipped;
+}
+// the device part of a drain: the handle's scratch holds [cursor | first | pre | blk | total | offsets | new cursor | records]
+struct DrainPlan { uint32_t *d_cur, *d_first, *d_pre, *d_blk, *d_tot, *d_off, *d_new; RmjEvent* d_ev; uint32_t cap; };
+static int drain_device(rmj_env* h, const uint32_t* cursor, uint32_t cap_events, DrainPlan* P, uint32_t* n_events) {
     const uint32_t n = h->cfg.n_games, blocks = (n + LC_BLOCK - 1) / LC_BLOCK;
     if (!h->d_ev_lost) {
         HIPCHK(hipMalloc(&h->d_ev_lost, (size_t)n * 4));
         HIPCHK(hipMemsetAsync(h->d_ev_lost, 0, (size_t)n * 4, h->stream));
     }
     const size_t o_first = (size_t)n * 4, o_pre = o_first + (size_t)n * 4, o_blk = o_pre + (size_t)n * 4, o_tot = o_blk + (size_t)blocks * 4;
-    const size_t o_off = o_tot + 16, o_ev = (o_off + ((size_t)n + 1) * 4 + 31) & ~(size_t)31;
+    const size_t o_off = o_tot + 16, o_new = o_off + ((size_t)n + 1) * 4, o_ev = (o_new + (size_t)n * 4 + 31) & ~(size_t)31;
     // the records: a first pass sizes them (the scan total), the buffer is sized by the caller's cap or, when it passes 0, by the total
     void* sp;
     int rc = scratch_for(h, o_ev + (size_t)cap_events * sizeof(RmjEvent), &sp);
     if (rc) return rc;
     uint8_t* base = (uint8_t*)sp;
     P->d_cur = (uint32_t*)base; P->d_first = (uint32_t*)(base + o_first); P->d_pre = (uint32_t*)(base + o_pre); P->d_blk = (uint32_t*)(base + o_blk);
-    P->d_tot = (uint32_t*)(base + o_tot); P->d_off = (uint32_t*)(base + o_off); P->d_ev = (RmjEvent*)(base + o_ev); P->cap = cap_events;
+    P->d_tot = (uint32_t*)(base + o_tot); P->d_off = (uint32_t*)(base + o_off); P->d_new = (uint32_t*)(base + o_new); P->d_ev = (RmjEvent*)(base + o_ev);
+    P->cap = cap_events;
     HIPCHK(hipMemcpyAsync(P->d_cur, cursor, (size_t)n * 4, hipMemcpyHostToDevice, h->stream));
-    hipLaunchKernelGGL(k_ev_count, dim3(blocks), dim3(LC_BLOCK), 0, h->stream, (const GState*)h->d.core, n, h->ring, (const uint32_t*)P->d_cur, P->d_first, P->d_pre, P->d_blk, h->d_ev_lost, commit);
+    hipLaunchKernelGGL(k_ev_count, dim3(blocks), dim3(LC_BLOCK), 0, h->stream, (const GState*)h->d.core, n, h->ring, (const uint32_t*)P->d_cur, P->d_first, P->d_pre, P->d_blk);
     hipLaunchKernelGGL(k_ev_scan, dim3(1), dim3(64), 0, h->stream, P->d_blk, blocks, P->d_tot);
     HIPCHK(hipGetLastError());
     HIPCHK(hipMemcpyAsync(n_events, P->d_tot, 4, hipMemcpyDeviceToHost, h->stream));
@@ -2085,81 +2109,132 @@ static int drain_device(rmj_env* h, const uint32_t* cursor, uint32_t cap_events,
 static void drain_gather(rmj_env* h, const DrainPlan& P) {
     const uint32_t n = h->cfg.n_games;
     hipLaunchKernelGGL(k_ev_gather, dim3((n + 3u) / 4u), dim3(256), 0, h->stream, (const GState*)h->d.core, (const RmjEvent*)h->d.events, n, h->ring,
-                       (const uint32_t*)P.d_first, (const uint32_t*)P.d_pre, (const uint32_t*)P.d_blk, P.cap, P.d_ev, P.d_off, P.d_cur);
+                       (const uint32_t*)P.d_first, (const uint32_t*)P.d_pre, (const uint32_t*)P.d_blk, P.cap, P.d_ev, P.d_off, P.d_new);
+}
+static void drain_book(rmj_env* h, const DrainPlan& P) {
+    const uint32_t n = h->cfg.n_games;
+    hipLaunchKernelGGL(k_ev_book, dim3((n + 255u) / 256u), dim3(256), 0, h->stream, (const uint32_t*)P.d_cur, (const uint32_t*)P.d_first, n, h->d_ev_lost);
 }
 static int pin_for(rmj_env* h, size_t bytes) {
     if (bytes > h->pin_bytes) {
         if (h->h_pin) hipHostFree(h->h_pin);
         h->h_pin = nullptr; h->pin_bytes = 0;
+        h->stage_valid = false;
         HIPCHK(hipHostMalloc(&h->h_pin, bytes, hipHostMallocDefault));
         h->pin_bytes = bytes;
     }
     return RMJ_OK;
 }
-int rmj_drain_events(rmj_handle h, uint32_t* cursor, RmjEvent* out, uint32_t cap_events, uint32_t* offsets, uint32_t* n_events) {
+int rmj_get_log_positions(rmj_handle h, uint32_t* base, uint32_t* pos) {
+    if (!h) return fail(RMJ_ERR_ARG, "null handle");
+    HIPCHK(hipSetDevice(h->cfg.device));
+    const uint32_t n = h->cfg.n_games;
+    void* sp;
+    int rc = scratch_for(h, (size_t)n * 8, &sp);
+    if (rc) return rc;
+    uint32_t* d = (uint32_t*)sp;
+    hipLaunchKernelGGL(k_log_positions, dim3((n + 255u) / 256u), dim3(256), 0, h->stream, (const GState*)h->d.core, n, d, d + n);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(h->stream));
+    if (base) HIPCHK(hipMemcpy(base, d, (size_t)n * 4, hipMemcpyDeviceToHost));
+    if (pos) HIPCHK(hipMemcpy(pos, d + n, (size_t)n * 4, hipMemcpyDeviceToHost));
+    return RMJ_OK;
+}
+int rmj_drain_events(rmj_handle h, uint32_t* cursor, RmjEvent* out, uint32_t cap_events, uint32_t* offsets, uint32_t* n_events, uint32_t flags) {
     if (!h || !cursor || !offsets || !n_events || (!out && cap_events)) return fail(RMJ_ERR_ARG, "null argument");
     HIPCHK(hipSetDevice(h->cfg.device));
     const uint32_t n = h->cfg.n_games;
+    h->stage_valid = false;
     DrainPlan P;
-    int rc = drain_device(h, cursor, cap_events, &P, n_events, 0);
+    int rc = drain_device(h, cursor, cap_events, &P, n_events);
     if (rc) return rc;
     if (*n_events > cap_events) return fail(RMJ_ERR_RANGE, "rmj_drain_events: more records than cap_events (n_events holds the number; nothing was drained)");
-    rc = drain_device(h, cursor, cap_events, &P, n_events, 1);   // (nothing ran in between: same counts; this pass books the losses)
-    if (rc) return rc;
     drain_gather(h, P);
+    if (!(flags & RMJ_DRAIN_PEEK)) drain_book(h, P);
     HIPCHK(hipGetLastError());
     rc = pin_for(h, ((size_t)n * 2 + 1) * 4 + (size_t)*n_events * sizeof(RmjEvent));
     if (rc) return rc;
     uint8_t* pin = (uint8_t*)h->h_pin;
     HIPCHK(hipMemcpyAsync(pin, P.d_off, ((size_t)n + 1) * 4, hipMemcpyDeviceToHost, h->stream));
-    HIPCHK(hipMemcpyAsync(pin + ((size_t)n + 1) * 4, P.d_cur, (size_t)n * 4, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipMemcpyAsync(pin + ((size_t)n + 1) * 4, P.d_new, (size_t)n * 4, hipMemcpyDeviceToHost, h->stream));
     if (*n_events) HIPCHK(hipMemcpyAsync(out, P.d_ev, (size_t)*n_events * sizeof(RmjEvent), hipMemcpyDeviceToHost, h->stream));
     HIPCHK(hipStreamSynchronize(h->stream));
     memcpy(offsets, pin, ((size_t)n + 1) * 4);
-    memcpy(cursor, pin + ((size_t)n + 1) * 4, (size_t)n * 4);
+    if (!(flags & RMJ_DRAIN_PEEK)) memcpy(cursor, pin + ((size_t)n + 1) * 4, (size_t)n * 4);
     return RMJ_OK;
 }
 // drain + format in one call: the records go to pinned staging owned by the handle and are formatted from there by a pool of host
-// threads (one log per game, events separated by '\n').  ms (optional, [3]): device gather, copy to the host, formatting.
+// threads (one log per slot, events separated by '\n').  ms (optional, [3]): device gather, copy to the host, formatting.
+// A size call (buf = NULL) leaves its gathered records staged; the call that follows with the same cursors, seat and flags formats that
+// staging instead of draining again (the drain is then "as of the size call": what was logged since stays for the next drain).
 int rmj_drain_format(rmj_handle h, uint32_t* cursor, int seat, char* buf, uint64_t cap, uint64_t* text_offsets, uint64_t* needed, uint32_t* n_events,
-                     double* ms) {
+                     double* ms, uint32_t flags) {
     if (!h || !cursor || !text_offsets || !needed || !n_events) return fail(RMJ_ERR_ARG, "null argument");
     HIPCHK(hipSetDevice(h->cfg.device));
     const uint32_t n = h->cfg.n_games;
-    std::vector<uint32_t> cur0(cursor, cursor + n);
-    DrainPlan P;
+    const size_t o_ev = (((size_t)n * 3 + 1) * 4 + 31) & ~(size_t)31;   // pinned: [offsets n + 1 | new cursors n | first n | pad | records]
     auto now = [] { return std::chrono::steady_clock::now(); };
     auto t0 = now();
-    // size pass with no record buffer, then the gather into a buffer of exactly that size
-    int rc = drain_device(h, cursor, 0, &P, n_events, 0);
-    if (rc) return rc;
-    rc = drain_device(h, cursor, *n_events, &P, n_events, (buf != nullptr) ? 1 : 0);
-    if (rc) return rc;
-    drain_gather(h, P);
-    HIPCHK(hipGetLastError());
-    HIPCHK(hipStreamSynchronize(h->stream));
-    auto t1 = now();
-    const size_t o_ev = (((size_t)n * 2 + 1) * 4 + 31) & ~(size_t)31;
-    rc = pin_for(h, o_ev + (size_t)*n_events * sizeof(RmjEvent));
-    if (rc) return rc;
+    const bool reuse = buf && h->stage_valid && h->stage_seat == seat && h->stage_cursor.size() == n &&
+                       memcmp(h->stage_cursor.data(), cursor, (size_t)n * 4) == 0;
+    if (!reuse) {
+        h->stage_valid = false;
+        DrainPlan P;
+        int rc = drain_device(h, cursor, 0, &P, n_events);   // size pass with no record buffer ...
+        if (rc) return rc;
+        rc = drain_device(h, cursor, *n_events, &P, n_events);   // ... then the gather into a buffer of exactly that size (nothing ran in between)
+        if (rc) return rc;
+        drain_gather(h, P);
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipStreamSynchronize(h->stream));
+        auto t1 = now();
+        rc = pin_for(h, o_ev + (size_t)*n_events * sizeof(RmjEvent));
+        if (rc) return rc;
+        uint8_t* pin = (uint8_t*)h->h_pin;
+        HIPCHK(hipMemcpyAsync(pin, P.d_off, ((size_t)n + 1) * 4, hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(hipMemcpyAsync(pin + ((size_t)n + 1) * 4, P.d_new, (size_t)n * 4, hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(hipMemcpyAsync(pin + ((size_t)n * 2 + 1) * 4, P.d_first, (size_t)n * 4, hipMemcpyDeviceToHost, h->stream));
+        if (*n_events) HIPCHK(hipMemcpyAsync(pin + o_ev, P.d_ev, (size_t)*n_events * sizeof(RmjEvent), hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(hipStreamSynchronize(h->stream));
+        auto t2 = now();
+        h->stage_ms[0] = std::chrono::duration<double, std::milli>(t1 - t0).count();
+        h->stage_ms[1] = std::chrono::duration<double, std::milli>(t2 - t1).count();
+        h->stage_cursor.assign(cursor, cursor + n);
+        h->stage_seat = seat;
+        h->stage_events = *n_events;
+        h->stage_valid = true;
+    }
     uint8_t* pin = (uint8_t*)h->h_pin;
-    HIPCHK(hipMemcpyAsync(pin, P.d_off, ((size_t)n + 1) * 4, hipMemcpyDeviceToHost, h->stream));
-    HIPCHK(hipMemcpyAsync(pin + ((size_t)n + 1) * 4, P.d_cur, (size_t)n * 4, hipMemcpyDeviceToHost, h->stream));
-    if (*n_events) HIPCHK(hipMemcpyAsync(pin + o_ev, P.d_ev, (size_t)*n_events * sizeof(RmjEvent), hipMemcpyDeviceToHost, h->stream));
-    HIPCHK(hipStreamSynchronize(h->stream));
+    *n_events = h->stage_events;
     auto t2 = now();
     *needed = rmjh::format_events((const RmjEvent*)(pin + o_ev), (const uint32_t*)pin, n, seat, buf, cap, text_offsets, 0);
     auto t3 = now();
     if (ms) {
-        ms[0] = std::chrono::duration<double, std::milli>(t1 - t0).count();
-        ms[1] = std::chrono::duration<double, std::milli>(t2 - t1).count();
+        ms[0] = h->stage_ms[0];
+        ms[1] = h->stage_ms[1];
         ms[2] = std::chrono::duration<double, std::milli>(t3 - t2).count();
     }
-    if (!buf || *needed > cap) {   // nothing was handed over: the caller's cursors stand
-        memcpy(cursor, cur0.data(), (size_t)n * 4);
+    if (!buf || *needed > cap)   // nothing was handed over: cursors and loss counters stand, the staging waits for the call with a buffer
         return fail(RMJ_ERR_RANGE, "rmj_drain_format: text buffer too small (needed holds the size; cursors unchanged)");
+    h->stage_valid = false;
+    if (!(flags & RMJ_DRAIN_PEEK)) {
+        // book what the windows skipped (first - cursor) and move the cursors behind the windows
+        const uint32_t* firsts = (const uint32_t*)(pin + ((size_t)n * 2 + 1) * 4);
+        bool any = false;
+        for (uint32_t g = 0; g < n && !any; g++) any = firsts[g] != cursor[g];
+        if (any) {
+            void* sp;
+            int rc = scratch_for(h, (size_t)n * 8, &sp);
+            if (rc) return rc;
+            uint32_t* d = (uint32_t*)sp;
+            HIPCHK(hipMemcpyAsync(d, cursor, (size_t)n * 4, hipMemcpyHostToDevice, h->stream));
+            HIPCHK(hipMemcpyAsync(d + n, firsts, (size_t)n * 4, hipMemcpyHostToDevice, h->stream));
+            hipLaunchKernelGGL(k_ev_book, dim3((n + 255u) / 256u), dim3(256), 0, h->stream, (const uint32_t*)d, (const uint32_t*)(d + n), n, h->d_ev_lost);
+            HIPCHK(hipGetLastError());
+            HIPCHK(hipStreamSynchronize(h->stream));
+        }
+        memcpy(cursor, pin + ((size_t)n + 1) * 4, (size_t)n * 4);
     }
-    memcpy(cursor, pin + ((size_t)n + 1) * 4, (size_t)n * 4);
     return RMJ_OK;
 }
 static int round_track_impl(rmj_env* h, int baseline, uint8_t* d_ended, int32_t* d_delta, int32_t* d_meta, uint8_t* d_kyoku_idx) {
@@ -2206,6 +2281,7 @@ int rmj_event_views(rmj_handle h, RmjEventViews* out) {
     out->ev_count = &h->d.core[0].ev_count;
     out->ev_count_stride = (uint32_t)sizeof(GState);
     out->lost = h->d_ev_lost;
+    out->ev_base = &h->d.core[0].ev_base;
     return RMJ_OK;
 }
 

@@ -4,8 +4,8 @@ namespace RMJ_NS {
 // RiichiEnv.reset defaults (env.rs:799-851) executed on device: reset() + _initialize_round(0,0,0,0,None,default scores)
 __device__ __noinline__ void ol_env_reset_default(CtxV v) {
     CTX_FROM(v);
-    c.S.ev_count = 0;  // GameState::reset clears the logs (state/mod.rs:171-187)
-    if (c.lane < 4) { c.S.obs_from[c.lane] = 0; c.S.obs_upto[c.lane] = 0; }
+    c.S.ev_base = c.S.ev_count;  // GameState::reset clears the logs (state/mod.rs:171-187): the new game's log starts here
+    if (c.lane < 4) { c.S.obs_from[c.lane] = c.S.ev_count; c.S.obs_upto[c.lane] = c.S.ev_count; }
     emit_simple(c, RMJ_EV_START_GAME);
     const int32_t st = KSANMA ? 35000 : 25000;  // state_3p/game_mode.rs:31-33
     const int32_t sc[4] = {st, st, st, st};
@@ -180,8 +180,8 @@ __global__ __launch_bounds__(256, 4) void k_reset(const Env* __restrict__ Ep, Re
         shuffle_wall(c);
         init_round(c, 0, (int)E.ctor_round_wind, 0, 0, nullptr);
     } else {          // env.rs:799-851
-        S.ev_count = 0;
-        if (lane < 4) { S.obs_from[lane] = 0; S.obs_upto[lane] = 0; }
+        S.ev_base = S.ev_count;
+        if (lane < 4) { S.obs_from[lane] = S.ev_count; S.obs_upto[lane] = S.ev_count; }
         emit_simple(c, RMJ_EV_START_GAME);
         if (A.scores)
             for (int p = 0; p < 4; p++) sc[p] = A.scores[(size_t)g * 4 + p];

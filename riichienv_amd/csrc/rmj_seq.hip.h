@@ -219,7 +219,8 @@ __global__ __launch_bounds__(64) void k_encode_seq(Env E, int game_style, RmjSeq
     const GState& S = st;
     const uint32_t mask = E.ring_mask, R = mask + 1u;
     const RmjEvent* ring = E.events + (size_t)g * R;
-    const int64_t ec = (int64_t)S.ev_count, lo = ec > (int64_t)R ? ec - (int64_t)R : 0;
+    // stream positions as int64 from the current game's first record (GState::ev_base; congruent to the u32 positions mod 2^32)
+    const int64_t eb = (int64_t)S.ev_base, ec = eb + (int64_t)(uint32_t)(S.ev_count - S.ev_base), lo = ec - eb > (int64_t)R ? ec - (int64_t)R : eb;
     // ---- the round's events: [start, ec).  start = the last START_KYOKU still in the ring (-1: overwritten)
     int64_t start = -1;
     for (int64_t hi = ec; hi > lo && start < 0; hi -= 64) {
@@ -277,12 +278,13 @@ __global__ __launch_bounds__(64) void k_encode_seq_delta(Env E, int game_style, 
     const GState& S = st;
     const uint32_t mask = E.ring_mask, R = mask + 1u;
     const RmjEvent* ring = E.events + (size_t)g * R;
-    const int64_t ec = (int64_t)S.ev_count, lo = ec > (int64_t)R ? ec - (int64_t)R : 0;
+    // stream positions as int64 from the current game's first record (GState::ev_base; congruent to the u32 positions mod 2^32)
+    const int64_t eb = (int64_t)S.ev_base, ec = eb + (int64_t)(uint32_t)(S.ev_count - S.ev_base), lo = ec - eb > (int64_t)R ? ec - (int64_t)R : eb;
     const uint32_t used_common = seq_used_common(S);
     for (int p = 0; p < 4; p++) {
         uint16_t* prog = O.progression + ((size_t)g * 4 + p) * RMJ_SEQ_DELTA_PROG * 5;
         const bool acts = ((S.active_mask >> p) & 1u) && !S.is_done;
-        const int64_t from = (int64_t)S.obs_from[p], to = (int64_t)S.obs_upto[p];
+        const int64_t from = eb + (int64_t)(uint32_t)(S.obs_from[p] - S.ev_base), to = eb + (int64_t)(uint32_t)(S.obs_upto[p] - S.ev_base);
         const bool lost = acts && from < lo;   // the ring no longer holds the whole delta
         SeqScan q;
         int32_t st_honba = S.honba, st_kyotaku = (int32_t)S.riichi_sticks;

@@ -62,7 +62,7 @@ struct alignas(16) GState {  // 4*128 + 128 = 640 bytes
     uint64_t pending_kan_action;
     uint32_t hand_index;      // WallState.hand_index
     uint32_t step_count;      // env.step calls that advanced this game
-    uint32_t ev_count;        // MJAI events emitted so far
+    uint32_t ev_count;        // MJAI records this game slot has emitted so far (stream position; the current game began at ev_base)
     uint32_t turn_count;
     uint32_t riichi_sticks;
     uint8_t current_player, phase, active_mask, is_done;
@@ -102,7 +102,12 @@ struct alignas(16) GState {  // 4*128 + 128 = 640 bytes
     // before the replacement and sits in Env::wall_dg; 0 = empty strings (never shuffled that way, or cleared by a start_kyoku
     // event, event_handler.rs:81-82)
     uint8_t wall_meta;
-    uint8_t pad[128 - 8 - 8 - 20 - 16 - 4 - 6 - 3 - 4 - 4 - 3 - 4 - 32 - 1 - 1 - 2 - 4 - 1];
+    uint8_t pad[3];
+    // ev_count is a position in the game SLOT's record stream and never goes back: a restart (auto-reset, rmj_reset, a start_game
+    // event) sets ev_base = ev_count instead of clearing the count, so the ring goes on behind the finished game's last records and a
+    // drain cursor stays valid across restarts.  The current game's log (GameState.mjai_log: cleared by reset, state/mod.rs:171-187) is
+    // the records [ev_base, ev_count); obs_from / obs_upto are stream positions too.  (u32, wraps after 2^32 records of one slot.)
+    uint32_t ev_base;
 };
 
 #ifdef __cplusplus

@@ -2099,7 +2099,7 @@ __device__ inline void apply_event(Ctx& c, const RmjEvent* ev) {
     }
     switch (ty) {
         case RMJ_EV_START_GAME:  // env.rs:56-72 + event_handler.rs:20-25
-            S.ev_count = 0;
+            S.ev_base = S.ev_count;
             S.current_player = 0xFF;
             S.active_mask = 0;
             break;

@@ -1424,8 +1424,9 @@ __device__ __noinline__ void r4_round_end(const Env* Ep, uint32_t g0) {
     }
     if (__ballot(restart)) {   // GameState::reset clears the logs (state/mod.rs:171-187), then start_game
         if (restart) {
-            if (r == 0) G->ev_count = 0u;
-            if (r < 4) { G->obs_from[r] = 0u; G->obs_upto[r] = 0u; }
+            const uint32_t evc0 = G->ev_count;
+            if (r == 0) G->ev_base = evc0;
+            if (r < 4) { G->obs_from[r] = evc0; G->obs_upto[r] = evc0; }
         }
         wave_sync();
         r4_emit_now(q, restart, r == 0 ? (uint32_t)RMJ_EV_START_GAME : 0u);

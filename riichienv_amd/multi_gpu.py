@@ -110,7 +110,8 @@ class MultiGpuVecEnv:
         return self._workers[i].submit(lambda: self.shards[i].mjai_log(l, seat)).result()
 
     def drain_logs(self, seat=-1):
-        """the MJAI strings every game logged since the last drain, all shards at once (rmj_drain_format per shard)"""
+        """the MJAI strings every game slot logged since the last drain, all shards at once (rmj_drain_format per shard); the
+        shards' running cursors are stream positions and survive auto-reset restarts (VecRiichiEnv.drain_logs)"""
         return [log for part in self._map(lambda i, e: e.drain_logs(seat=seat)) for log in part]
 
     def mjai_logs(self, seat=-1):

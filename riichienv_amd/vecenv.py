@@ -33,7 +33,7 @@ EXPORTS = [
     "rmj_encode_seq_delta", "rmj_encode_seq_delta_device", "rmj_step_random_encode",
     "rmj_encode_compact_device", "rmj_step_random_encode_compact", "rmj_bench_encode_compact",
     "rmj_get_win_results",
-    "rmj_drain_events", "rmj_format_events", "rmj_drain_format", "rmj_event_views", "rmj_round_track_device", "rmj_round_track_reset", "rmj_get_events_lost",
+    "rmj_drain_events", "rmj_format_events", "rmj_drain_format", "rmj_event_views", "rmj_round_track_device", "rmj_round_track_reset", "rmj_get_events_lost", "rmj_get_log_positions",
 ]
 
 
@@ -144,9 +144,10 @@ def load_lib():
     L.rmj_get_win_results.argtypes = [vp, C.c_uint32, C.POINTER(abi.WinResult), C.POINTER(C.c_uint8)]
     L.rmj_encode_seq_delta.argtypes = [vp, C.c_int, C.POINTER(abi.SeqBuffers)]          # same field layout as RmjSeqBuffers
     L.rmj_encode_seq_delta_device.argtypes = [vp, C.c_int, C.POINTER(abi.SeqBuffers)]
-    L.rmj_drain_events.argtypes = [vp, vp, vp, C.c_uint32, vp, C.POINTER(C.c_uint32)]
+    L.rmj_drain_events.argtypes = [vp, vp, vp, C.c_uint32, vp, C.POINTER(C.c_uint32), C.c_uint32]
+    L.rmj_get_log_positions.argtypes = [vp, vp, vp]
     L.rmj_format_events.argtypes = [vp, vp, C.c_uint32, C.c_int, vp, C.c_uint64, vp, C.POINTER(C.c_uint64)]
-    L.rmj_drain_format.argtypes = [vp, vp, C.c_int, vp, C.c_uint64, vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint32), vp]
+    L.rmj_drain_format.argtypes = [vp, vp, C.c_int, vp, C.c_uint64, vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint32), vp, C.c_uint32]
     L.rmj_event_views.argtypes = [vp, C.POINTER(abi.EventViews)]
     L.rmj_get_events_lost.argtypes = [vp, vp]
     L.rmj_round_track_device.argtypes = [vp, vp, vp, vp, vp]
@@ -202,6 +203,7 @@ class VecRiichiEnv:
             assert self._seeds.shape == (self.n,)
             cfg.seeds = self._seeds.ctypes.data_as(C.POINTER(C.c_uint64))
         cfg.event_ring = event_ring
+        self.event_ring = 1 << max(0, int(event_ring) - 1).bit_length()   # the library rounds the ring up to a power of two
         self.game_mode = cfg.game_mode
         self.game_offset = int(game_offset)
         self.h = C.c_void_p()
@@ -243,6 +245,8 @@ class VecRiichiEnv:
             keep.append(a)
             ptrs.append(p)
         _chk(self.L.rmj_reset(self.h, *ptrs))
+        if select is None and getattr(self, "_cursor", None) is not None:
+            self._cursor = self.log_positions()[0].copy()   # a reset of every game: the running drain cursor starts at the new logs
 
     # ---- RiichiEnv.step (env.rs:857-872), batched
     def step(self, actions):
@@ -456,16 +460,25 @@ class VecRiichiEnv:
         return out
 
     # ---- the logs of all games at once (rmj_drain_events / rmj_format_events / rmj_drain_format)
-    def drain_events(self, cursor=None, cap_events=None):
-        """The records every game wrote since `cursor` ([n] u32 record counts, updated in place; None: the env's own running cursor,
-        which starts at 0): (events [total] structured array of 32-byte records, offsets [n + 1])."""
+    def log_positions(self):
+        """(base, pos) [n] u32 each: every slot's record stream position and where its current game's log begins (a restart moves
+        the base, never the position back: header, rmj_get_log_positions)."""
+        base, pos = np.zeros(self.n, np.uint32), np.zeros(self.n, np.uint32)
+        _chk(self.L.rmj_get_log_positions(self.h, base.ctypes.data, pos.ctypes.data))
+        return base, pos
+
+    def drain_events(self, cursor=None, cap_events=None, peek=False):
+        """The records every slot wrote since `cursor` ([n] u32 stream positions, updated in place unless peek; None: the env's own
+        running cursor, which starts at 0): (events [total] array of 32-byte records, offsets [n + 1]).  The cursor stays valid across
+        auto-reset / reset restarts: a window then holds the end of one game and the start of the next."""
         cur = self._log_cursor() if cursor is None else cursor
         if cap_events is None:
-            cap_events = int((self.event_counts().astype(np.int64) - cur.astype(np.int64)).clip(0, None).sum())
+            behind = (self.log_positions()[1] - cur).astype(np.int64)     # u32 wrap-safe distance
+            cap_events = int(np.minimum(np.where(behind > 2 ** 31, 0, behind), self.event_ring).sum())
         ev = np.zeros((max(cap_events, 1), C.sizeof(abi.Event)), np.uint8)
         offs = np.zeros(self.n + 1, np.uint32)
         n_ev = C.c_uint32()
-        _chk(self.L.rmj_drain_events(self.h, cur.ctypes.data, ev.ctypes.data, int(cap_events), offs.ctypes.data, C.byref(n_ev)))
+        _chk(self.L.rmj_drain_events(self.h, cur.ctypes.data, ev.ctypes.data, int(cap_events), offs.ctypes.data, C.byref(n_ev), 1 if peek else 0))
         return ev[: n_ev.value], offs
 
     def format_events(self, events, offsets, seat=-1):
@@ -485,31 +498,37 @@ class VecRiichiEnv:
         return [raw[int(toffs[g]): int(toffs[g + 1])].decode().split("\n")[:-1] for g in range(len(toffs) - 1)]
 
     def _log_cursor(self):
+        """the env's running drain cursor (stream positions): it starts where every slot's CURRENT game began when it is first used
+        (call it before stepping to have the first drain start at the games' first records), and again after a reset of all games"""
         if getattr(self, "_cursor", None) is None:
-            self._cursor = np.zeros(self.n, np.uint32)
+            self._cursor = self.log_positions()[0].copy()
         return self._cursor
 
-    def drain_logs(self, seat=-1, cursor=None, timings=None, raw=False):
-        """The MJAI strings every game logged since the last drain (RiichiEnv.mjai_log of every env, env.rs:729-739; seat >= 0: the
+    def drain_logs(self, seat=-1, cursor=None, timings=None, raw=False, peek=False):
+        """The MJAI strings every slot logged since the last drain (RiichiEnv.mjai_log of every env, env.rs:729-739; seat >= 0: the
         seat's masked log) as a list of lists of strings - drained on the device, one copy down, formatted by host threads in C.
-        `cursor`: explicit [n] u32 record counts instead of the env's running cursor.  raw=True: (bytes buffer, text offsets [n + 1])
-        without splitting (one log = its events, each followed by a newline).  timings: a list that receives [gather, copy, format] ms."""
+        Restarts in between are part of the stream (... end_game, start_game ...); what a late drain lost is counted (events_lost).
+        `cursor`: explicit [n] u32 stream positions instead of the env's running cursor.  peek: cursors and loss counters are left alone.
+        raw=True: (bytes buffer, text offsets [n + 1]) without splitting (one log = its events, each followed by a newline).
+        timings: a list that receives [gather, copy, format] ms."""
         cur = self._log_cursor() if cursor is None else cursor
         toffs = np.zeros(self.n + 1, np.uint64)
         need, n_ev = C.c_uint64(), C.c_uint32()
         ms = (C.c_double * 3)()
-        # size pass (buf = NULL leaves the cursors alone), then the real one
-        self.L.rmj_drain_format(self.h, cur.ctypes.data, int(seat), None, 0, toffs.ctypes.data, C.byref(need), C.byref(n_ev), None)
+        fl = 1 if peek else 0
+        # size call (stages the records, moves nothing), then the call that formats the staging into the buffer
+        self.L.rmj_drain_format(self.h, cur.ctypes.data, int(seat), None, 0, toffs.ctypes.data, C.byref(need), C.byref(n_ev), None, fl)
         buf = np.zeros(max(int(need.value), 1), np.uint8)
-        _chk(self.L.rmj_drain_format(self.h, cur.ctypes.data, int(seat), buf.ctypes.data, int(need.value), toffs.ctypes.data, C.byref(need), C.byref(n_ev), ms))
+        _chk(self.L.rmj_drain_format(self.h, cur.ctypes.data, int(seat), buf.ctypes.data, int(need.value), toffs.ctypes.data, C.byref(need), C.byref(n_ev), ms, fl))
         if timings is not None:
             timings[:] = [ms[0], ms[1], ms[2]]
         self.last_drain_events = n_ev.value
         return (buf, toffs) if raw else self._split_logs(buf, toffs)
 
     def mjai_logs(self, seat=-1):
-        """The whole logs of all games still in their rings (cursor 0 for every game; the env's running cursor is not moved)."""
-        return self.drain_logs(seat=seat, cursor=np.zeros(self.n, np.uint32))
+        """The current game's log of every slot as far as its ring still holds it (RiichiEnv.mjai_log of every env): a peek from the
+        slots' log bases - no cursor moves, no loss is booked."""
+        return self.drain_logs(seat=seat, cursor=self.log_positions()[0].copy(), peek=True)
 
     def events_lost(self):
         """[n] records each game's ring lost to late drains so far (RmjEventViews.lost)"""

@@ -59,7 +59,7 @@ def test_incremental_drains_concatenate_to_the_whole_log():
     assert parts == whole
     assert all(len(x) == 0 for x in env.drain_logs())          # nothing new
     # the binary form: records + offsets, formatted separately
-    ev, offs = env.drain_events(cursor=np.zeros(n, np.uint32))
+    ev, offs = env.drain_events(cursor=env.log_positions()[0].copy())
     assert offs[0] == 0 and offs[-1] == len(ev) == int(env.event_counts().sum())
     assert env.format_events(ev, offs) == whole
     env.close()
@@ -72,9 +72,12 @@ def test_a_lapped_ring_is_counted_and_the_window_still_formats():
     env.step_random(11, 400, auto_reset=False)
     cnt = env.event_counts().astype(np.int64)
     assert (cnt > 64).any()
-    cur = np.zeros(n, np.uint32)
+    base, pos = env.log_positions()
+    assert ((pos - base).astype(np.int64) == cnt).all()
+    cur = base.copy()
+    assert env.mjai_logs() and int(env.events_lost().sum()) == 0    # a peek books nothing
     logs = env.drain_logs(cursor=cur)
-    assert (cur == cnt).all()
+    assert (cur == pos).all()
     lost = env.events_lost().astype(np.int64)
     assert (lost == np.maximum(cnt - 64, 0)).all()
     for g in range(0, n, 13):
@@ -85,9 +88,48 @@ def test_a_lapped_ring_is_counted_and_the_window_still_formats():
             assert 0 < len(logs[g]) <= 64 and all(s.startswith("{") and s.endswith("}") for s in logs[g])
     # too small a record buffer: nothing is drained, the number is reported
     import ctypes as C
-    cur2 = np.zeros(n, np.uint32)
+    cur2 = base.copy()
     offs = np.zeros(n + 1, np.uint32)
     n_ev = C.c_uint32()
-    rc = env.L.rmj_drain_events(env.h, cur2.ctypes.data, np.zeros((1, 32), np.uint8).ctypes.data, 1, offs.ctypes.data, C.byref(n_ev))
-    assert rc != 0 and n_ev.value == int(np.minimum(cnt, 64).sum()) and (cur2 == 0).all()
+    rc = env.L.rmj_drain_events(env.h, cur2.ctypes.data, np.zeros((1, 32), np.uint8).ctypes.data, 1, offs.ctypes.data, C.byref(n_ev), 0)
+    assert rc != 0 and n_ev.value == int(np.minimum(cnt, 64).sum()) and (cur2 == base).all()
+    assert (env.events_lost().astype(np.int64) == lost).all()       # the failed call booked nothing either
+    env.close()
+
+
+@pytest.mark.parametrize("mode", [0, 3])
+def test_drains_across_auto_reset_restarts_lose_nothing(mode):
+    """a restart used to set the record count back to 0 and a running cursor then skipped the new game's first records
+    without counting them.  The stream position never goes back now: periodic drains of games that restart in between concatenate to
+    end_game / start_game sequences equal to the oracle's successive logs, and nothing is lost or booked as lost."""
+    from oracle import oracle
+
+    n, seed, pseed = 96, 5, 21
+    env = vecenv.VecRiichiEnv(n, game_mode=mode, seed=seed, event_ring=512)
+    env.reset()
+    env._log_cursor()                      # the running cursor starts here, at the first records of the games just dealt
+    got = [[] for _ in range(n)]
+    for k in (90, 100, 64, 100, 100):
+        env.step_random(pseed, k, auto_reset=True)
+        for g, chunk in enumerate(env.drain_logs()):
+            got[g] += chunk
+    assert int(env.events_lost().sum()) == 0
+    restarts = 0
+    for g in range(0, n, 7):
+        o = oracle.Game(game_mode=mode, seed=game_seed(seed, g))
+        o.reset()
+        want = []
+        for _ in range(454):
+            if o.status()[2]:
+                want += o.log()
+                o.reset()
+                restarts += 1
+                continue
+            o.step(o.random_actions(pseed, g))
+        want += o.log()
+        assert got[g] == want, g
+        assert env.mjai_log(g) == o.log(), g                 # the per-game reader still sees the current game only
+    assert restarts >= 10
+    base, pos = env.log_positions()
+    assert ((pos - base) == env.event_counts()).all() and (env._log_cursor() == pos).all()
     env.close()

@@ -8,6 +8,10 @@ N>1: one process per GPU, games sharded by global index, no collective on the da
 per GPU).  `python bench.py --gpus N` without a torchrun environment starts the N rank processes itself
 (torch.distributed.run as a child process, before this process has imported torch or touched HIP) and relays rank 0's
 JSON line; under `python -m torch.distributed.run ... bench.py --gpus N` it is one of the ranks.
+A one-GPU run imports no torch: device memory and synchronisation go through the library's own bench hooks.  The default
+one-GPU line also carries a steady-state leg of the same environment (`long_rollout`), the other single-GPU configurations of
+BASELINE.json (`configs`: [1], one shard of [3], [4] with the feature tensor) and a lossless log leg (`log_drain`); a multi-rank
+line carries `ranks_seen` / `per_rank_value` (one all_gather) and rank 0's `cpu_baseline`.
 """
 import argparse
 import glob
@@ -54,6 +58,10 @@ def parse_args(argv=None):
                          "on one device) - exercises the world > 1 path on a 1-GPU box; never a measurement")
     ap.add_argument("--preroll", type=int, default=PREROLL,
                     help="untimed steps before the warm-up that bring every game to steady state (0: time the opening phase)")
+    ap.add_argument("--reference-rng", action="store_true",
+                    help="deal every wall through the reference's own seed -> wall chain (RMJ_RULE_REFERENCE_RNG: PCG32 seed expansion, "
+                         "ChaCha12, rand's shuffle, salt) instead of the build's counter-based shuffle")
+    ap.add_argument("--no-configs", action="store_true", help="skip the legs of the other BASELINE.json configurations (configs[1], [3], [4])")
     ap.add_argument("--padded-rows", action="store_true", help="--encode: rows padded to a multiple of 256 B instead of the dense [games][4][74][W] tensor")
     ap.add_argument("--encode", action="store_true",
                     help="also produce the feature tensor of the acting seats every step (BASELINE configs[4]: sanma with "
@@ -87,6 +95,8 @@ def launcher_command(args, port, script=None):
         cmd.append("--encode")
     if args.padded_rows:
         cmd.append("--padded-rows")
+    if getattr(args, "reference_rng", False):
+        cmd.append("--reference-rng")
     if getattr(args, "oversubscribe", False):
         cmd.append("--oversubscribe")
     env = dict(os.environ)
@@ -237,6 +247,151 @@ def metric_name(args):
     return f"env.step()/s (whole node) at {args.games} parallel {seats} games per GPU{extra}; bit-exact MJAI parity"
 
 
+class Dev:
+    """HIP through the library's own bench hooks (include/riichi_mi355x_bench.h): a one-GPU run needs no torch."""
+
+    def __init__(self, lib, device):
+        import ctypes as C
+
+        self.C, self.L, self.device, self.bufs = C, lib, int(device), []
+
+    def alloc(self, nbytes):
+        p = self.C.c_void_p()
+        rc = self.L.rmj_bench_device_alloc(self.device, int(nbytes), self.C.byref(p))
+        if rc:
+            raise RuntimeError("rmj_bench_device_alloc failed: " + self.L.rmj_last_error().decode())
+        self.bufs.append(p)
+        return p.value
+
+    def free_all(self):
+        for p in self.bufs:
+            self.L.rmj_bench_device_free(self.device, p)
+        self.bufs = []
+
+    def sync(self):
+        if self.L.rmj_bench_device_sync(self.device):
+            raise RuntimeError("rmj_bench_device_sync failed: " + self.L.rmj_last_error().decode())
+
+
+def acting_seats(env):
+    act, _, dn = env.status()
+    return int(sum(bin(int(a)).count("1") for a, d in zip(act, dn) if not d))
+
+
+def rollout_roofline(r, games, steps, sanma, encode=False, acting=0, greedy=False, enc_step_ms=None):
+    """The roofline object of a timed device rollout (RmjBenchResult `r`): algorithmic bytes per launch (B_step x games x steps of the
+    launch, + one Observation.encode() per acting seat and step with --encode) / the launch's duration from HIP events on the
+    handle's stream / the HBM peak."""
+    b_step = B_STEP_3P if sanma else B_STEP_4P
+    steps_per_launch = 1
+    if encode and int(r.launches) == 1 and steps > 1:
+        in_flight, kernel_ms, steps_per_launch = 1, r.total_ms, steps          # step + encode rollout as ONE launch
+    elif encode:
+        in_flight, kernel_ms = 1, enc_step_ms
+    elif int(r.launches) == 1 and steps > 1:
+        in_flight, kernel_ms, steps_per_launch = 1, r.total_ms, steps          # every wave steps its games `steps` times in one launch
+    else:
+        in_flight, kernel_ms = max(1, int(r.launches_in_flight)), r.step_kernel_ms   # per-step launches on `in_flight` streams
+    games_per_launch = games // in_flight
+    kernel_name = fused_kernel_name(r) if steps_per_launch > 1 else "k_step4<false>"
+    if encode and steps_per_launch > 1:
+        kernel_name = "k_step4_queue_enc" if int(r.queued) else "k_step4_enc"
+    if greedy:
+        kernel_name += " (greedy)"
+    bytes_per_launch = b_step * games_per_launch * steps_per_launch
+    if encode and steps_per_launch > 1:
+        bytes_per_launch += (B_OBS_3P if sanma else B_OBS_4P) * acting * steps_per_launch
+    achieved = in_flight * bytes_per_launch / (kernel_ms * 1e-3)
+    return {"bound": "hbm", "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": achieved / HBM_PEAK,
+            "kernel": kernel_name, "kernel_ms": kernel_ms, "bytes_per_launch": bytes_per_launch, "bytes_per_game_step": b_step,
+            "games_per_launch": games_per_launch, "steps_per_launch": steps_per_launch, "launches_in_flight": in_flight}
+
+
+def config_leg(vecenv, abi, shard, dev, name, games, mode, steps, policy_seed, device, rank, encode=False, preroll=PREROLL):
+    """One BASELINE.json configuration as a steady-state leg of its own: a fresh environment, `preroll` untimed steps, then `steps`
+    (>= 300) timed steps of the device RandomAgent rollout between device-wide synchronisations."""
+    sanma = mode >= 3
+    env = vecenv.VecRiichiEnv(games, game_mode=mode, seed=0, rule_bits=abi.RULE_TENHOU, device=device,
+                              game_offset=shard.shard_offset(rank, games), event_ring=64)
+    env.reset()
+    env.step_random(policy_seed, preroll, auto_reset=True)
+    obs = None
+    if encode:
+        stride = 74 * (27 if sanma else 34)
+        env.set_encode_row_stride(stride)
+        obs = dev.alloc(games * 4 * stride * 4)
+        env.time_rollout_encode(policy_seed, 5, obs)
+    s0, f0 = env.total_steps(), env.total_full_path()
+    dev.sync()
+    t0 = time.perf_counter()
+    r = env.time_rollout_encode(policy_seed, steps, obs) if encode else env.time_rollout(policy_seed, steps)
+    dev.sync()
+    t1 = time.perf_counter()
+    made, full = env.total_steps() - s0, env.total_full_path() - f0
+    acting = acting_seats(env) if encode else 0
+    out = {"config": name, "workload": f"{games} parallel {MODES[mode]} games, device RandomAgent, auto-reset, MJAI logging on" +
+                                       (", Observation.encode() of every acting seat after every step" if encode else ""),
+           "value": made / (t1 - t0), "unit": "env.step/s", "steps": steps, "ms_per_step": (t1 - t0) * 1e3 / steps,
+           "steady_state": bool(preroll >= 300 and steps >= STEADY_MIN), "preroll_steps": preroll, "full_path_frac": full / max(made, 1),
+           "roofline": rollout_roofline(r, games, steps, sanma, encode=encode, acting=acting)}
+    out["kernel_ms"], out["frac"] = out["roofline"]["kernel_ms"], out["roofline"]["frac"]
+    if encode:
+        b_obs = B_OBS_3P if sanma else B_OBS_4P
+        enc_ms = env.bench_encode(obs, 50, extended=False, only_active=2)
+        out["roofline_encode"] = {"bound": "hbm", "achieved": b_obs * acting / (enc_ms * 1e-3) / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
+                                  "frac": b_obs * acting / (enc_ms * 1e-3) / HBM_PEAK, "kernel": "k_encode_base", "kernel_ms": enc_ms,
+                                  "bytes_per_launch": b_obs * acting, "acting_seats": acting, "bytes_per_observation": b_obs}
+    env.close()
+    dev.free_all()
+    return out
+
+
+def log_leg(vecenv, abi, shard, games, mode, policy_seed, device, rank, rounds=3, chunk=100, ring=512):
+    """Lossless logs end to end: `rounds` x (a `chunk`-step auto-reset rollout + a drain of every slot's records, formatted to MJAI
+    text on the host's threads) - the ring holds a chunk, the drains' cursors survive the restarts in between (stream positions), and
+    the loss counters must stay 0."""
+    import numpy as np
+
+    env = vecenv.VecRiichiEnv(games, game_mode=mode, seed=0, rule_bits=abi.RULE_TENHOU, device=device,
+                              game_offset=shard.shard_offset(rank, games), event_ring=ring)
+    env.reset()
+    env._log_cursor()
+    env.step_random(policy_seed, chunk, auto_reset=True)      # untimed first round: sizes the text buffer, warms the pinned staging
+    buf0, toffs0 = env.drain_logs(raw=True)
+    text = np.empty(int(toffs0[-1]) * 2 + (1 << 20), np.uint8)
+    del buf0
+    s0 = env.total_steps()
+    ev = tb = 0
+    gather = copy = fmt = roll_s = drain_s = 0.0
+    t0 = time.perf_counter()
+    for _ in range(rounds):
+        ta = time.perf_counter()
+        env.step_random(policy_seed, chunk, auto_reset=True)
+        env.sync()
+        tb_ = time.perf_counter()
+        tms = []
+        _, toffs = env.drain_logs(raw=True, timings=tms, out=text)
+        tc = time.perf_counter()
+        roll_s += tb_ - ta
+        drain_s += tc - tb_
+        ev += int(env.last_drain_events)
+        tb += int(toffs[-1])
+        gather += tms[0]; copy += tms[1]; fmt += tms[2]
+    wall = time.perf_counter() - t0
+    made = env.total_steps() - s0
+    lost = int(env.events_lost().sum())
+    env.close()
+    if lost != 0:
+        raise RuntimeError(f"bench.py log_drain: {lost} records lost although the ring ({ring}) holds a {chunk}-step chunk")
+    return {"games": games, "rollout_steps": rounds * chunk, "drain_every_steps": chunk, "event_ring": ring, "events": ev, "text_bytes": tb,
+            "lost_events": lost, "wall_s": wall, "rollout_s": roll_s, "drain_s": drain_s, "gather_ms": gather, "copy_ms": copy, "format_ms": fmt,
+            "events_per_s": ev / max(drain_s, 1e-9), "format_events_per_s": ev / max(fmt * 1e-3, 1e-9),
+            "end_to_end_env_steps_per_s": made / max(wall, 1e-9),
+            "what": f"{rounds} x ({chunk}-step auto-reset rollout + rmj_drain_format of every slot: device gather, one pinned copy, C formatter "
+                    "on the host's threads into a reused text buffer); every record logged in the region is retrieved and formatted, "
+                    "restarts included; end_to_end = env.steps of the region / (rollout + drain wall time)"}
+
+
 def main(argv=None):
     args = parse_args(argv)
     if args.gpus < 1:
@@ -258,17 +413,21 @@ def main(argv=None):
     saved_stdout = os.dup(1)
     os.dup2(2, 1)
 
-    # The CPU baseline starts worker processes: it runs FIRST, before this process imports torch or touches HIP (a process
-    # that has initialised the GPU must not fork + exec on this pool); it is outside the timed region either way.
+    # The CPU baseline starts worker processes: it runs FIRST on rank 0 (at any world size: the other ranks wait for it at the
+    # rendezvous), before this process imports torch or touches HIP (a process that has initialised the GPU must not fork +
+    # exec on this pool); it is outside the timed region either way.
     cpu_line = None
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+    if rank == 0 and not args.no_cpu_baseline:
         cpu_line = cpu_baseline(args.mode, 64 | 128, 0xC0FFEE)   # abi.RULE_TENHOU (the GPU run's rule set), the GPU run's policy seed
-
-    import torch
 
     from riichienv_amd import abi, shard, vecenv
 
-    have = vecenv.load_lib().rmj_device_count() if torch.cuda.device_count() > 0 else 0
+    lib = vecenv.load_lib()
+    use_dist = world > 1 or bool(os.environ.get("RMJ_BENCH_FORCE_DIST"))   # (the variable: the RCCL path with one rank on a 1-GPU box)
+    torch = None
+    if use_dist:
+        import torch   # the ranks meet over torch.distributed (RCCL); a one-GPU run has no use for torch
+    have = lib.rmj_device_count()
     shared_gpus = args.oversubscribe and 0 < have < world
     if shared_gpus:
         local_rank = local_rank % have
@@ -277,7 +436,7 @@ def main(argv=None):
               file=sys.stderr)
         return 3
     dist = None
-    if world > 1 or os.environ.get("RMJ_BENCH_FORCE_DIST"):   # (the variable: exercise the RCCL path with one rank on a 1-GPU box)
+    if use_dist:
         import torch.distributed as dist
 
         torch.cuda.set_device(local_rank)
@@ -285,10 +444,12 @@ def main(argv=None):
             dist.init_process_group(backend="gloo")
         else:
             dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+    dev = Dev(lib, local_rank)
 
     policy_seed = 0xC0FFEE
     sanma = args.mode >= 3
-    env = vecenv.VecRiichiEnv(args.games, game_mode=args.mode, seed=0, rule_bits=abi.RULE_TENHOU, device=local_rank,
+    rule = abi.RULE_TENHOU | (abi.RULE_REFERENCE_RNG if args.reference_rng else 0)
+    env = vecenv.VecRiichiEnv(args.games, game_mode=args.mode, seed=0, rule_bits=rule, device=local_rank,
                               game_offset=shard.shard_offset(rank, args.games), event_ring=64)
     env.reset()
     greedy = args.policy == "greedy"
@@ -309,16 +470,17 @@ def main(argv=None):
     def barrier():
         if dist is not None:
             dist.barrier()
-        torch.cuda.synchronize()
+        if torch is not None:
+            torch.cuda.synchronize()
+        dev.sync()           # hipDeviceSynchronize through the library (all a one-GPU run needs)
 
     obs = None
     if args.encode:
         # --padded-rows: every row padded to a multiple of 256 B (rmj_set_encode_row_stride; [games][4][2 048] floats in 3P, the first
-        # 74 x 27 of a row are the tensor).  A torch fill of that pattern is 1.3-1.4 x faster than with unaligned dense rows, the encoder
-        # kernels gain 0-5 %: the default stays the dense [games][4][74][W] tensor
+        # 74 x 27 of a row are the tensor); the default is the dense [games][4][74][W] tensor
         stride = env.padded_row_stride() if args.padded_rows else 74 * (27 if sanma else 34)
         env.set_encode_row_stride(stride)
-        obs = torch.zeros((args.games, 4, stride), dtype=torch.float32, device=f"cuda:{local_rank}")
+        obs = dev.alloc(args.games * 4 * stride * 4)
     full0 = env.total_full_path()
     before = env.total_steps()
     barrier()
@@ -327,7 +489,7 @@ def main(argv=None):
         # every step of every game is followed by encode() of its acting seats into the resident tensor: ONE launch in which
         # every wave steps its four games and writes their rows (k_step4_enc / k_step4_queue_enc; RMJ_ENC_FUSED=0: four parts on
         # four streams, step + encode launches per part); HIP events on the handle's stream around it
-        r = env.time_rollout_encode(policy_seed, args.steps, obs.data_ptr())
+        r = env.time_rollout_encode(policy_seed, args.steps, obs)
     else:
         # exactly K steps of every game and nothing else inside the region: HIP events on the handle's stream around the rollout
         # (returns when the second event has completed); the step counters are read outside
@@ -336,7 +498,8 @@ def main(argv=None):
     t1 = time.perf_counter()
     steps_local = float(env.total_steps() - before)
     full_steps = env.total_full_path() - full0
-    wall, steps_total = shard.reduce_measurement(dist, t1 - t0, steps_local, device="cpu" if shared_gpus else "cuda")
+    gm = shard.gather_measurement(dist, rank, t1 - t0, steps_local, device="cpu" if (shared_gpus or torch is None) else "cuda")
+    wall, steps_total = gm["wall"], gm["steps"]
 
     # ---- side measurements, outside the timed region (rank 0 of a 1-GPU run only)
     extras = {}
@@ -346,12 +509,10 @@ def main(argv=None):
         # the features is a barrier between steps, so this mode cannot keep several launches in flight)
         rs = [env.bench_rollout(policy_seed, 0, 1) for _ in range(20)]
         r_enc_step = sum(x.step_kernel_ms for x in rs) / len(rs)
-        act, _, dn = env.status()
-        acting = int(sum(bin(int(a)).count("1") for a, d in zip(act, dn) if not d))
-        enc_ms = env.bench_encode(obs.data_ptr(), 50, extended=False, only_active=2)
-        extras["encode"] = (acting, enc_ms)
-    if rank == 0 and world == 1 and not args.no_extras and not args.encode and not greedy:
-        # the policy that plays to win (VERDICT r2 #3: the RandomAgent wins once in ~250 rounds, a trainer's policy does not):
+        extras["encode"] = (acting_seats(env), env.bench_encode(obs, 50, extended=False, only_active=2))
+    side = rank == 0 and world == 1 and not args.no_extras and not args.encode and not greedy
+    if side:
+        # the policy that plays to win (the RandomAgent wins once in ~250 rounds, a trainer's policy does not):
         # a second environment, pre-rolled under that policy, 300 timed steps
         genv = vecenv.VecRiichiEnv(args.games, game_mode=args.mode, seed=0, rule_bits=abi.RULE_TENHOU, device=local_rank,
                                    game_offset=shard.shard_offset(rank, args.games), event_ring=64)
@@ -366,8 +527,7 @@ def main(argv=None):
                                    "what": "the same rollout under rmj_step_greedy: shanten-greedy discards, every win / riichi / kan / kita "
                                            "taken, pon / chi at the call rate - rounds end with wins, not exhaustive draws"}
         genv.close()
-    if rank == 0 and world == 1 and not args.no_extras and not args.encode and not greedy:
-        k = min(args.steps, 300)
+        k = max(min(args.steps, 300), 20)
         env.set_rollout_streams(1)
         r1 = env.bench_rollout(policy_seed, 0, k)
         extras["single_stream"] = {"value": r1.env_steps / (r1.total_ms * 1e-3), "ms_per_step": r1.total_ms / k, "steps": k,
@@ -378,64 +538,38 @@ def main(argv=None):
                                        "what": "one policy launch writing packed actions + one step launch that validates them "
                                                "against the stored legal lists (state/mod.rs:339-402), one stream"}
         env.set_rollout_streams(4)
-        # the logs of all games: a second environment with rings that hold a 300-step rollout, its whole MJAI log
-        # drained on the device, copied down once and formatted by host threads in C (rmj_drain_format)
-        lenv = vecenv.VecRiichiEnv(args.games, game_mode=args.mode, seed=0, rule_bits=abi.RULE_TENHOU, device=local_rank,
-                                   game_offset=shard.shard_offset(rank, args.games), event_ring=512)
-        lenv.reset()
-        lenv.step_random(policy_seed, 300, auto_reset=True)
-        tms = []
-        t_l0 = time.perf_counter()
-        buf_l, toffs_l = lenv.drain_logs(timings=tms, raw=True)
-        t_l1 = time.perf_counter()
-        extras["log_drain"] = {"games": args.games, "rollout_steps": 300, "events": int(lenv.last_drain_events), "text_bytes": int(toffs_l[-1]),
-                               "wall_s": t_l1 - t_l0, "gather_ms": tms[0], "copy_ms": tms[1], "format_ms": tms[2],
-                               "events_per_s": lenv.last_drain_events / max(t_l1 - t_l0, 1e-9), "lost_events": int(lenv.events_lost().sum()),
-                               "what": "rmj_drain_format: every game's MJAI log of a 300-step rollout (a size pass and the drain), "
-                                       "device gather + one pinned copy + C formatter on the host's threads"}
-        del buf_l
-        lenv.close()
-        if args.steps < 1000:
-            kl = 1000
-            rl = env.bench_rollout(policy_seed, 0, kl)
-            extras["long_rollout"] = {"value": rl.env_steps / (rl.total_ms * 1e-3), "ms_per_step": rl.total_ms / kl, "steps": kl,
-                                      "kernel": fused_kernel_name(rl),
-                                      "what": "the same rollout over 1 000 steps as one launch (a short timed region pays the launch's "
-                                              "ramp-up and tail, ~0.1 ms, once per K steps)"}
+        extras["log_drain"] = log_leg(vecenv, abi, shard, args.games, args.mode, policy_seed, local_rank, rank)
+        # the steady-state figure of the SAME environment: >= 300 steps as one launch between device-wide synchronisations (a short
+        # timed region pays the launch's ramp-up and tail, ~0.1 ms, once per K steps)
+        kl = max(1000, args.steps)
+        ls0, lf0 = env.total_steps(), env.total_full_path()
+        dev.sync()
+        tl0 = time.perf_counter()
+        rl = env.time_rollout(policy_seed, kl)
+        dev.sync()
+        tl1 = time.perf_counter()
+        lmade = env.total_steps() - ls0
+        extras["long_rollout"] = {"value": lmade / (tl1 - tl0), "ms_per_step": (tl1 - tl0) * 1e3 / kl, "steps": kl, "steady_state": True,
+                                  "kernel": fused_kernel_name(rl), "full_path_frac": (env.total_full_path() - lf0) / max(lmade, 1),
+                                  "roofline": rollout_roofline(rl, args.games, kl, sanma),
+                                  "what": f"the same rollout over {kl} steps as one launch, wall clock between device synchronisations"}
+        # every other single-GPU configuration of BASELINE.json, each a steady-state leg of its own (>= 300 timed steps)
+        if args.games == 65536 and args.mode == 2 and not args.no_configs:
+            extras["configs"] = [
+                config_leg(vecenv, abi, shard, dev, "configs[1]", 4096, 0, 2000, policy_seed, local_rank, rank),
+                config_leg(vecenv, abi, shard, dev, "configs[3] (one shard of the eight: 524 288 games on this GPU)", 524288, 2, 300,
+                           policy_seed, local_rank, rank),
+                config_leg(vecenv, abi, shard, dev, "configs[4]", 65536, 5, 300, policy_seed, local_rank, rank, encode=True)]
 
     if rank == 0:
-        b_step = B_STEP_3P if sanma else B_STEP_4P
-        steps_per_launch = 1
         acting_now = extras["encode"][0] if "encode" in extras else 0
-        if args.encode and int(r.launches) == 1 and args.steps > 1:
-            # the step + encode rollout is ONE launch: per step of all games it moves the step's algorithmic bytes and one
-            # Observation.encode() per seat that is to act (counted on the final state: ~1.0 per game)
-            in_flight, kernel_ms, steps_per_launch = 1, r.total_ms, args.steps
-        elif args.encode:
-            in_flight, kernel_ms = 1, r_enc_step
-        elif int(r.launches) == 1 and args.steps > 1:
-            # the rollout is ONE launch in which every wave steps its four games `steps` times: the launch processes
-            # steps x games game-steps; its duration comes from HIP events around it on the handle's stream
-            in_flight, kernel_ms, steps_per_launch = 1, r.total_ms, args.steps
-        else:
-            # per-step launches on `in_flight` streams (parts of the batch): bytes and duration are per launch, the
-            # bandwidth the chip delivers is in_flight launches' worth
-            in_flight, kernel_ms = max(1, int(r.launches_in_flight)), r.step_kernel_ms
-        games_per_launch = args.games // in_flight
+        roof = rollout_roofline(r, args.games, args.steps, sanma, encode=args.encode, acting=acting_now, greedy=greedy, enc_step_ms=r_enc_step)
         # (the committed counter summary is of the fused rollout kernel, per step of all games; the per-step launches of the
         #  feature rollout have no counter profile of their own)
-        kernel_name = fused_kernel_name(r) if steps_per_launch > 1 else "k_step4<false>"
-        if args.encode and steps_per_launch > 1:
-            kernel_name = "k_step4_queue_enc" if int(r.queued) else "k_step4_enc"
-        if greedy:
-            kernel_name += " (greedy)"
-        traffic, traffic_src = pmc_traffic("k_step4_enc" if args.encode else "k_step4", games_per_launch, args.mode, ran_as=kernel_name)
+        traffic, traffic_src = pmc_traffic("k_step4_enc" if args.encode else "k_step4", roof["games_per_launch"], args.mode, ran_as=roof["kernel"])
         if traffic is not None:
-            traffic *= steps_per_launch
-        bytes_per_launch = b_step * games_per_launch * steps_per_launch
-        if args.encode and steps_per_launch > 1:
-            bytes_per_launch += (B_OBS_3P if sanma else B_OBS_4P) * acting_now * steps_per_launch
-        achieved = in_flight * bytes_per_launch / (kernel_ms * 1e-3)
+            traffic *= roof["steps_per_launch"]
+        roof.update({"traffic": traffic, "traffic_unit": "bytes/launch", "traffic_source": traffic_src})
         out = {
             "metric": metric_name(args),
             "value": steps_total / wall, "unit": "env.step/s", "n_gpus": world, "steps": args.steps,
@@ -443,23 +577,21 @@ def main(argv=None):
             "scaling": "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
             "config": {"workload": workload_name(args), "games_per_gpu": args.games,
                        "sharding": "by game index, no collectives", "feature_tensor_output": bool(args.encode),
-                       "parity": "bit-exact vs the oracle on identical walls; seed -> wall is the build's own shuffle (DESIGN.md §6)"},
-            # short runs (the first ~60 steps of a game cannot end a round) are not the steady state the metric is defined on
-            # steady state = every game has played through several round ends before the timed region (pre-roll + warm-up)
+                       "parity": "bit-exact vs the oracle on identical walls; seed -> wall: " +
+                                 ("the reference's StdRng / shuffle / salt chain (RMJ_RULE_REFERENCE_RNG)" if args.reference_rng else
+                                  "the build's own shuffle (the reference's chain is opt-in: RMJ_RULE_REFERENCE_RNG, DESIGN.md §6)")},
+            # proof that N processes took part: the rank ids the all_gather of the measurement returned, and each rank's own rate
+            "ranks_seen": gm["ranks_seen"], "per_rank_value": gm["per_rank_value"], "per_rank_wall_s": gm["per_rank_wall_s"],
+            "host_runtime": "torch.distributed (RCCL)" if dist is not None and not shared_gpus else ("torch.distributed (gloo)" if dist is not None else "none (C-ABI only)"),
+            **({"oversubscribed": True, "note": "ranks share GPUs (--oversubscribe): a functional run of the world > 1 path, not a measurement"} if shared_gpus else {}),
             # the metric is defined over a window of >= 200 batched steps behind a warm-up that has reached round ends.  A shorter
             # timed window (the driver's --steps 20) of games that ARE in that state is marked separately: its rate includes the launch's
             # ramp-up and tail once per window, the steady-state figure of the same run is `long_rollout`
-            **({"oversubscribed": True, "note": "ranks share GPUs (--oversubscribe): a functional run of the world > 1 path, not a measurement"} if shared_gpus else {}),
             "steady_state": bool(args.preroll + args.warmup >= 300 and args.steps >= STEADY_MIN),
             "window_ok": bool(args.preroll + args.warmup >= 300),
             "preroll_steps": args.preroll,
             "full_path_frac": full_steps / max(steps_local, 1.0),
-            "roofline": {"bound": "hbm", "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK, "traffic": traffic, "traffic_unit": "bytes/launch",
-                         "traffic_source": traffic_src, "kernel": kernel_name,
-                         "kernel_ms": kernel_ms, "bytes_per_launch": bytes_per_launch, "bytes_per_game_step": b_step,
-                         "games_per_launch": games_per_launch, "steps_per_launch": steps_per_launch,
-                         "launches_in_flight": in_flight},
+            "roofline": roof,
         }
         if "encode" in extras:
             acting, enc_ms = extras.pop("encode")
@@ -477,6 +609,8 @@ def main(argv=None):
         os.dup2(saved_stdout, 1)
         print(json.dumps(out), flush=True)
         os.dup2(2, 1)
+    env.close()
+    dev.free_all()
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

@@ -61,6 +61,11 @@ int rmj_bench_hand_kernel(int device, int which, const void* a, const void* b, u
 int rmj_bench_encode(rmj_handle h, int extended, int only_active, float* d_out, uint32_t reps, double* avg_ms);
 /* the same for rmj_encode_compact_device (slot scan + encoder launch) */
 int rmj_bench_encode_compact(rmj_handle h, float* d_out, int32_t* d_index, uint32_t capacity, uint32_t* d_count, uint32_t reps, double* avg_ms);
+/* Device memory and a device-wide synchronisation for a harness that has no other way to HIP: bench.py runs its one-GPU legs without
+ * torch (zero-filled allocation; hipDeviceSynchronize). */
+int rmj_bench_device_alloc(int device, uint64_t bytes, void** out);
+int rmj_bench_device_free(int device, void* p);
+int rmj_bench_device_sync(int device);
 /* Sum over games of the steps that took the full path of the step kernel since the handle was created. */
 int rmj_total_full_path(rmj_handle h, uint64_t* total);
 

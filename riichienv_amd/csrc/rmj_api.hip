@@ -10,6 +10,7 @@
 #include <chrono>
 #include <cstdio>
 #include <cstring>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -261,6 +262,10 @@ __global__ void k_gather_scores(const GState* core, uint32_t n, int32_t* out, ui
         for (int p = 0; p < 4; p++) out[(size_t)i * 4 + p] = core[i].p[p].score;
         if (evc) evc[i] = core[i].ev_count - core[i].ev_base;   // len(mjai_log) of the current game
     }
+}
+__global__ void k_track_mark(uint8_t* mark, const uint8_t* __restrict__ select, uint32_t first, uint32_t n) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n && (!select || select[first + i])) mark[first + i] = 1;
 }
 __global__ void k_log_positions(const GState* core, uint32_t n, uint32_t* base, uint32_t* pos) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1304,6 +1309,8 @@ int rmj_reset(rmj_handle h, const uint8_t* select, const uint8_t* walls, const u
     A.select = d_sel; A.walls = d_walls; A.oya = d_oya; A.round_wind = d_rw; A.scores = d_sc; A.honba = d_honba; A.kyotaku = d_ky;
     if (h->cfg.game_mode >= 3) hipLaunchKernelGGL(rmj3::k_reset, game_grid(h->cfg.n_games), dim3(256), 0, h->stream, (const Env*)h->d_env, A);
     else hipLaunchKernelGGL(rmj4::k_reset, game_grid(h->cfg.n_games), dim3(256), 0, h->stream, (const Env*)h->d_env, A);
+    if (h->d_track)   // the round tracker must not read the reset as the end of a round (rmj_round_track_device)
+        hipLaunchKernelGGL(k_track_mark, dim3((h->cfg.n_games + 255u) / 256u), dim3(256), 0, h->stream, (uint8_t*)h->d_track + B * 37, (const uint8_t*)d_sel, 0u, h->cfg.n_games);
     HIPCHK(hipGetLastError());
     HIPCHK(hipStreamSynchronize(h->stream));
     return RMJ_OK;
@@ -1946,6 +1953,7 @@ int rmj_poke_state(rmj_handle h, uint32_t game, const RmjStateView* v) {
     HIPCHK(hipMemcpy(h->d.wall + (size_t)game * RMJ_WALL_STRIDE, W, RMJ_WALL_STRIDE, hipMemcpyHostToDevice));
     if (h->cfg.game_mode >= 3) hipLaunchKernelGGL(rmj3::k_refresh, dim3(1), dim3(64), 0, h->stream, (const Env*)h->d_env, game);
     else hipLaunchKernelGGL(rmj4::k_refresh, dim3(1), dim3(64), 0, h->stream, (const Env*)h->d_env, game);
+    if (h->d_track) hipLaunchKernelGGL(k_track_mark, dim3(1), dim3(64), 0, h->stream, (uint8_t*)h->d_track + (size_t)h->cfg.n_games * 37, (const uint8_t*)nullptr, game, 1u);
     HIPCHK(hipGetLastError());
     HIPCHK(hipStreamSynchronize(h->stream));
     return RMJ_OK;
@@ -1980,7 +1988,9 @@ struct RoundTrack {            // device arrays of the tracker (rmj_env::d_track
     uint8_t* was_done;         // [n]
     int32_t* start_scores;     // [n][4]
     int32_t* start_meta;       // [n][4] round_wind, oya, honba, riichi_sticks at the deal
+    uint8_t* mark;             // [n] set by rmj_reset / rmj_poke_state for the games they touch: the tracker takes the new state as its baseline
 };
+
 __global__ void k_round_track(const GState* __restrict__ core, uint32_t n, RoundTrack T, int baseline, uint8_t* __restrict__ ended, int32_t* __restrict__ delta,
                               int32_t* __restrict__ meta, uint8_t* __restrict__ kyoku_idx) {
     const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1992,7 +2002,9 @@ __global__ void k_round_track(const GState* __restrict__ core, uint32_t n, Round
     for (int p = 0; p < 4; p++) sc[p] = S.p[p].score;
     uint8_t e = 0;
     bool rebase = baseline != 0;
-    if (!baseline) {
+    const bool marked = T.mark[g] != 0;   // rmj_reset / rmj_poke_state touched the game since the last call: no round of THIS game ended
+    if (marked) { T.mark[g] = 0; rebase = true; }
+    if (!baseline && !marked) {
         const bool wd = T.was_done[g] != 0;
         if (wd && !done) rebase = true;                                  // restarted: a new game opens
         else if (done && !wd) e = 2;                                     // the round that ended the game
@@ -2241,11 +2253,12 @@ static int round_track_impl(rmj_env* h, int baseline, uint8_t* d_ended, int32_t*
     const uint32_t n = h->cfg.n_games;
     if (!h->d_track) {
         HIPCHK(hipMalloc(&h->d_track, (size_t)n * (4 + 16 + 16 + 4)));
+        HIPCHK(hipMemsetAsync(h->d_track, 0, (size_t)n * (4 + 16 + 16 + 4), h->stream));
         baseline = 1;
     }
     RoundTrack T;
     uint8_t* b = (uint8_t*)h->d_track;
-    T.hand_index = (uint32_t*)b; T.start_scores = (int32_t*)(b + (size_t)n * 4); T.start_meta = (int32_t*)(b + (size_t)n * 20); T.was_done = b + (size_t)n * 36;
+    T.hand_index = (uint32_t*)b; T.start_scores = (int32_t*)(b + (size_t)n * 4); T.start_meta = (int32_t*)(b + (size_t)n * 20); T.was_done = b + (size_t)n * 36; T.mark = b + (size_t)n * 37;
     hipLaunchKernelGGL(k_round_track, dim3((n + 255u) / 256u), dim3(256), 0, h->stream, (const GState*)h->d.core, n, T, baseline, d_ended, d_delta, d_meta, d_kyoku_idx);
     HIPCHK(hipGetLastError());
     return RMJ_OK;
@@ -2538,7 +2551,9 @@ int rmj_encode_extended(rmj_handle h, int only_active, float* out) {
 static int shanten_tables_for(int device, ShantenTables* out) {
     static ShantenTables cache[64];
     static bool have[64] = {false};
+    static std::mutex mu;   // handles are created from several host threads (MultiGpuVecEnv: one per shard, shards may share a device)
     if (device < 0 || device >= 64) return fail(RMJ_ERR_ARG, "device ordinal");
+    std::lock_guard<std::mutex> lock(mu);
     if (!have[device]) {
         const ShantenHostTables& H = shanten_host_tables();
         uint64_t *ds, *dh;
@@ -2697,6 +2712,27 @@ int rmj_time_rollout_greedy(rmj_handle h, uint64_t policy_seed, uint32_t steps, 
 int rmj_set_rollout_streams(rmj_handle h, int k) {
     if (!h || k < 1 || k > RMJ_MAX_ROLLOUT_STREAMS) return fail(RMJ_ERR_ARG, "rollout streams must be 1..8");
     h->want_streams = k;
+    return RMJ_OK;
+}
+// device memory / synchronisation for a harness that has no other way to HIP (bench.py runs one GPU without torch)
+int rmj_bench_device_alloc(int device, uint64_t bytes, void** out) {
+    if (!out) return fail(RMJ_ERR_ARG, "null argument");
+    int rc = ensure_device(device);
+    if (rc) return rc;
+    HIPCHK(hipMalloc(out, (size_t)bytes));
+    HIPCHK(hipMemset(*out, 0, (size_t)bytes));
+    return RMJ_OK;
+}
+int rmj_bench_device_free(int device, void* p) {
+    int rc = ensure_device(device);
+    if (rc) return rc;
+    HIPCHK(hipFree(p));
+    return RMJ_OK;
+}
+int rmj_bench_device_sync(int device) {
+    int rc = ensure_device(device);
+    if (rc) return rc;
+    HIPCHK(hipDeviceSynchronize());
     return RMJ_OK;
 }
 int rmj_total_full_path(rmj_handle h, uint64_t* total) {

@@ -53,3 +53,20 @@ def reduce_measurement(dist, wall_s: float, steps: float, device=None) -> tuple[
     dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     dist.all_reduce(t, op=dist.ReduceOp.SUM)
     return float(tmax[0]), float(t[1])
+
+
+def gather_measurement(dist, rank: int, wall_s: float, steps: float, device=None) -> dict:
+    """What a multi-rank bench line reports beyond reduce_measurement, from ONE all_gather of (rank, wall, steps): the ranks that
+    took part (`ranks_seen`, in gather order - a proof that the reduction saw N processes), each rank's own rate
+    (`per_rank_value`), and the whole-job figures MAX(wall) / SUM(steps)."""
+    if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
+        return {"wall": float(wall_s), "steps": float(steps), "ranks_seen": [int(rank)], "per_rank_value": [float(steps) / max(float(wall_s), 1e-12)],
+                "per_rank_wall_s": [float(wall_s)]}
+    import torch
+
+    mine = torch.tensor([float(rank), float(wall_s), float(steps)], dtype=torch.float64, device=device)
+    parts = [torch.zeros_like(mine) for _ in range(dist.get_world_size())]
+    dist.all_gather(parts, mine)
+    rows = [[float(x) for x in p.cpu()] for p in parts]
+    return {"wall": max(r[1] for r in rows), "steps": sum(r[2] for r in rows), "ranks_seen": [int(r[0]) for r in rows],
+            "per_rank_value": [r[2] / max(r[1], 1e-12) for r in rows], "per_rank_wall_s": [r[1] for r in rows]}

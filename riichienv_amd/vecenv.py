@@ -28,7 +28,7 @@ EXPORTS = [
     "rmj_poke_state", "rmj_get_event_counts", "rmj_get_events", "rmj_format_event", "rmj_eval_hands",
     "rmj_agari_counts", "rmj_calculate_score", "rmj_shanten", "rmj_effective_tiles", "rmj_best_ukeire", "rmj_apply_events", "rmj_device_views", "rmj_step_ids_device", "rmj_clone", "rmj_copy_games", "rmj_copy_games_device",
     "rmj_scores_device", "rmj_sync", "rmj_set_stream", "rmj_encode", "rmj_encode_device", "rmj_encode_extended", "rmj_encode_extended_device", "rmj_encode_aux", "rmj_encode_aux_device", "rmj_encode_seq", "rmj_encode_seq_device", "rmj_bench_rollout", "rmj_time_rollout", "rmj_step_greedy", "rmj_time_rollout_greedy", "rmj_time_rollout_encode", "rmj_step_ids_encode_device", "rmj_set_encode_row_stride", "rmj_bench_hand_kernel", "rmj_points_device", "rmj_get_points", "rmj_get_legal_compact", "rmj_get_wall_digest", "rmj_get_wall_digests",
-    "rmj_bench_rollout_validated", "rmj_bench_encode", "rmj_set_rollout_streams", "rmj_total_full_path",
+    "rmj_bench_rollout_validated", "rmj_bench_encode", "rmj_set_rollout_streams", "rmj_total_full_path", "rmj_bench_device_alloc", "rmj_bench_device_free", "rmj_bench_device_sync",
     "rmj_random_actions_device", "rmj_peek_outputs", "rmj_sample_ids_device",
     "rmj_encode_seq_delta", "rmj_encode_seq_delta_device", "rmj_step_random_encode",
     "rmj_encode_compact_device", "rmj_step_random_encode_compact", "rmj_bench_encode_compact",
@@ -134,6 +134,9 @@ def load_lib():
     L.rmj_bench_encode.argtypes = [vp, C.c_int, C.c_int, vp, C.c_uint32, C.POINTER(C.c_double)]
     L.rmj_set_rollout_streams.argtypes = [vp, C.c_int]
     L.rmj_total_full_path.argtypes = [vp, C.POINTER(C.c_uint64)]
+    L.rmj_bench_device_alloc.argtypes = [C.c_int, C.c_uint64, C.POINTER(vp)]
+    L.rmj_bench_device_free.argtypes = [C.c_int, vp]
+    L.rmj_bench_device_sync.argtypes = [C.c_int]
     L.rmj_random_actions_device.argtypes = [vp, C.c_uint64, vp]
     L.rmj_peek_outputs.argtypes = [vp, C.c_uint32, vp, vp, vp, vp, C.POINTER(C.c_uint32)]
     L.rmj_sample_ids_device.argtypes = [vp, vp, C.c_uint32, C.c_uint64, vp]
@@ -494,7 +497,7 @@ class VecRiichiEnv:
 
     @staticmethod
     def _split_logs(buf, toffs):
-        raw = buf.tobytes()
+        raw = buf[: int(toffs[-1])].tobytes()
         return [raw[int(toffs[g]): int(toffs[g + 1])].decode().split("\n")[:-1] for g in range(len(toffs) - 1)]
 
     def _log_cursor(self):
@@ -504,13 +507,14 @@ class VecRiichiEnv:
             self._cursor = self.log_positions()[0].copy()
         return self._cursor
 
-    def drain_logs(self, seat=-1, cursor=None, timings=None, raw=False, peek=False):
+    def drain_logs(self, seat=-1, cursor=None, timings=None, raw=False, peek=False, out=None):
         """The MJAI strings every slot logged since the last drain (RiichiEnv.mjai_log of every env, env.rs:729-739; seat >= 0: the
         seat's masked log) as a list of lists of strings - drained on the device, one copy down, formatted by host threads in C.
         Restarts in between are part of the stream (... end_game, start_game ...); what a late drain lost is counted (events_lost).
         `cursor`: explicit [n] u32 stream positions instead of the env's running cursor.  peek: cursors and loss counters are left alone.
         raw=True: (bytes buffer, text offsets [n + 1]) without splitting (one log = its events, each followed by a newline).
-        timings: a list that receives [gather, copy, format] ms."""
+        timings: a list that receives [gather, copy, format] ms.  out: a uint8 array to format into when it is large enough (a text
+        buffer reused from drain to drain: fresh pages cost more than the formatting)."""
         cur = self._log_cursor() if cursor is None else cursor
         toffs = np.zeros(self.n + 1, np.uint64)
         need, n_ev = C.c_uint64(), C.c_uint32()
@@ -518,8 +522,8 @@ class VecRiichiEnv:
         fl = 1 if peek else 0
         # size call (stages the records, moves nothing), then the call that formats the staging into the buffer
         self.L.rmj_drain_format(self.h, cur.ctypes.data, int(seat), None, 0, toffs.ctypes.data, C.byref(need), C.byref(n_ev), None, fl)
-        buf = np.zeros(max(int(need.value), 1), np.uint8)
-        _chk(self.L.rmj_drain_format(self.h, cur.ctypes.data, int(seat), buf.ctypes.data, int(need.value), toffs.ctypes.data, C.byref(need), C.byref(n_ev), ms, fl))
+        buf = out if out is not None and out.dtype == np.uint8 and out.size >= int(need.value) else np.zeros(max(int(need.value), 1), np.uint8)
+        _chk(self.L.rmj_drain_format(self.h, cur.ctypes.data, int(seat), buf.ctypes.data, int(buf.size), toffs.ctypes.data, C.byref(need), C.byref(n_ev), ms, fl))
         if timings is not None:
             timings[:] = [ms[0], ms[1], ms[2]]
         self.last_drain_events = n_ev.value

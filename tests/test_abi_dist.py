@@ -40,6 +40,7 @@ def test_bench_under_torchrun_with_rccl_world_of_one():
     # 4 096 games x 40 steps, nearly every game advances every step
     assert 0.9 * 4096 * 40 <= line["value"] * line["ms_per_step"] * 1e-3 * 40 <= 4096 * 40 * 1.0001
     assert line["roofline"]["frac"] > 0 and "cpu_baseline" not in line
+    assert line["ranks_seen"] == [0] and len(line["per_rank_value"]) == 1 and line["host_runtime"].startswith("torch.distributed (RCCL)")
 
 
 def test_bench_default_launch_with_the_drivers_flags():
@@ -57,3 +58,18 @@ def test_bench_default_launch_with_the_drivers_flags():
     assert r["kernel"] == "k_step4_queue" and r["steps_per_launch"] == 20 and r["games_per_launch"] == 65536
     assert r["traffic_source"] is None or "k_step4" in r["traffic_source"]
     assert line["value"] > 5e8
+    # a one-GPU run needs no torch: the harness reaches HIP through the library's own hooks
+    assert line["host_runtime"] == "none (C-ABI only)" and line["ranks_seen"] == [0]
+    # the steady-state leg of the same environment, the other single-GPU configurations of BASELINE.json, the lossless log leg
+    lr = line["long_rollout"]
+    assert lr["steady_state"] is True and lr["steps"] >= 300 and lr["value"] > line["value"] and 0 < lr["roofline"]["frac"] < 1
+    cfgs = {c["config"].split(" ")[0]: c for c in line["configs"]}
+    assert set(cfgs) == {"configs[1]", "configs[3]", "configs[4]"}
+    for c in cfgs.values():
+        assert c["steady_state"] is True and c["steps"] >= 300 and c["kernel_ms"] > 0 and 0 < c["frac"] < 1 and c["value"] > 1e8
+        ro = c["roofline"]
+        assert abs(ro["achieved"] - ro["launches_in_flight"] * ro["bytes_per_launch"] / (ro["kernel_ms"] * 1e-3) / 1e9) < 1e-6 * ro["achieved"]
+    assert "4096 parallel 4p-red-single" in cfgs["configs[1]"]["workload"] and "524288 parallel 4p-red-half" in cfgs["configs[3]"]["workload"]
+    assert "65536 parallel 3p-red-half" in cfgs["configs[4]"]["workload"] and cfgs["configs[4]"]["roofline_encode"]["frac"] > 0
+    ld = line["log_drain"]
+    assert ld["lost_events"] == 0 and ld["events"] > 1e7 and ld["end_to_end_env_steps_per_s"] > 0 and ld["format_events_per_s"] > 0

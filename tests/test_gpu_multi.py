@@ -58,13 +58,16 @@ def test_bench_with_two_ranks_sharing_the_gpu():
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", MASTER_ADDR="127.0.0.1")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
            "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--games", "8192", "--steps", "60", "--warmup", "20",
-           "--preroll", "400", "--no-cpu-baseline", "--no-extras", "--oversubscribe"]
+           "--preroll", "400", "--no-extras", "--oversubscribe"]
     p = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900)
     assert p.returncode == 0, p.stderr[-3000:]
     lines = [ln for ln in p.stdout.splitlines() if ln.strip().startswith("{")]
     assert len(lines) == 1, p.stdout
     line = json.loads(lines[0])
     assert line["n_gpus"] == 2 and line["oversubscribed"] is True and line["scaling"] == "weak"
+    # the line proves its ranks: the ids one all_gather returned, each rank's own rate, and rank 0's CPU baseline at world > 1
+    assert line["ranks_seen"] == [0, 1] and len(line["per_rank_value"]) == 2 and all(v > 0 for v in line["per_rank_value"])
+    assert line["value"] <= sum(line["per_rank_value"]) * 1.0001 and line["cpu_baseline"]["kind"] == "port" and line["cpu_baseline"]["value"] > 0
     # two ranks x 8 192 games x 60 steps, nearly every game advances every step: the SUM over ranks, the MAX of their times
     steps = line["value"] * line["ms_per_step"] * 1e-3 * 60
     assert 0.9 * 2 * 8192 * 60 <= steps <= 2 * 8192 * 60 * 1.0001, steps

@@ -140,3 +140,36 @@ def test_sample_ids_from_compact_logits_without_a_host_count():
     full[:k] = logits
     got = tv.sample_ids(full, seed=123, index=cidx, count=ccnt)
     assert torch.equal(got, want)
+
+
+def test_round_tracker_takes_a_manual_reset_or_poke_as_a_new_baseline():
+    """resetting (or poking) a LIVE game used to look like a round end (hand_index moved) and paid out
+    new start scores - old start scores.  rmj_reset / rmj_poke_state mark the games they touch; the tracker rebases on them."""
+    from riichienv_amd.torch_env import TorchVecEnv
+
+    n = 64
+    tv = TorchVecEnv(n, game_mode=2, seed=3, skip_mjai_logging=True)
+    tv.round_track()
+    tv.env.step_greedy(5, 40, auto_reset=True, call_rate_256=64)
+    tv.round_track()
+    sel = np.zeros(n, np.uint8)
+    sel[::2] = 1
+    sc = np.tile(np.array([40000, 30000, 20000, 10000], np.int32), (n, 1))
+    tv.env.reset(select=sel, scores=sc)                     # live games, other scores, hand_index + 1
+    v = tv.env.peek(1)
+    v.players[0].score += 5000                              # a poke of a game that was not reset
+    tv.env.poke(1, v)
+    ended, delta, meta, _ = (x.cpu().numpy() for x in tv.round_track())
+    assert not ended[::2].any() and not delta[::2].any() and not ended[1] and not delta[1].any()
+    # the next real round end of a reset game pays against the scores it was reset to
+    for _ in range(200):
+        tv.env.step_greedy(5, 1, auto_reset=False, call_rate_256=64)
+        ended, delta, meta, _ = (x.cpu().numpy() for x in tv.round_track())
+        hit = [g for g in range(0, n, 2) if ended[g]]
+        if hit:
+            g = hit[0]
+            now = [int(tv.env.peek(g).players[p].score) for p in range(4)]
+            assert list(delta[g]) == [now[p] - int(sc[g][p]) for p in range(4)]
+            break
+    else:
+        raise AssertionError("no reset game ended a round in 200 steps")

@@ -51,9 +51,10 @@ def _worker(rank, world, port, mode, q):
         gathered = [None] * world
         dist.all_gather_object(gathered, mine)
         wall, steps = shard.reduce_measurement(dist, 1.0 + rank, float(sum(m[1] for m in mine)))
+        gm = shard.gather_measurement(dist, rank, 1.0 + rank, float(sum(m[1] for m in mine)))
         dist.barrier()
         if rank == 0:
-            q.put((gathered, wall, steps))
+            q.put((gathered, wall, steps, gm))
     finally:
         dist.destroy_process_group()
 
@@ -75,7 +76,7 @@ def test_two_rank_shards_equal_one_rank(mode):
     for p in procs:
         p.join(300)
         assert p.exitcode == 0
-    gathered, wall, steps = q.get()
+    gathered, wall, steps, gm = q.get()
     two = [x for part in gathered for x in part]
     one = _run_shard(0, 2 * GAMES_PER_RANK, mode)        # the whole batch on one rank
     assert two == one                                    # incl. the CRC of every game's MJAI log
@@ -83,6 +84,10 @@ def test_two_rank_shards_equal_one_rank(mode):
     assert wall == 2.0                                   # MAX over ranks
     assert steps == float(sum(x[1] for x in one))        # SUM over ranks
     assert steps > 0
+    # the fields a multi-rank bench line carries to show that N ranks took part (bench.py: ranks_seen, per_rank_value)
+    assert gm["ranks_seen"] == [0, 1] and gm["wall"] == 2.0 and gm["steps"] == steps
+    per = [float(sum(x[1] for x in part)) for part in gathered]
+    assert gm["per_rank_value"] == [per[0] / 1.0, per[1] / 2.0] and gm["per_rank_wall_s"] == [1.0, 2.0]
 
 
 def test_shard_helpers():
@@ -96,4 +101,5 @@ def test_shard_helpers():
     with pytest.raises(ValueError):
         shard.shard_offset(-1, 4)
     assert shard.reduce_measurement(None, 0.5, 10) == (0.5, 10.0)
+    assert shard.gather_measurement(None, 0, 0.5, 10) == {"wall": 0.5, "steps": 10.0, "ranks_seen": [0], "per_rank_value": [20.0], "per_rank_wall_s": [0.5]}
     assert abi.NO_ACTION == 0xFFFFFFFFFFFFFFFF

@@ -995,6 +995,7 @@ struct rmj_env {
     int heavy_first = 1;            // RMJ_HEAVY_FIRST at create (0: plain block order)
     uint32_t rows_pw = 4;           // games per wave of the non-ticket four-games-per-wave kernels: 4, or 2 / 1 for batches that leave the chip
                                     // latency bound (chosen at create from the batch size; RMJ_ROWS overrides)
+    int queue_tail = 1;             // ticket lengths descend towards the expected end of a quad's rollout (q_ticket_plan); RMJ_QUEUE_TAIL=0: equal tickets
     int queue_min_chunk = 8;        // shortest ticket (steps): a rollout of >= 2 tickets per quad runs as tickets; RMJ_QUEUE_MIN_CHUNK at create
     uint32_t max_xcc_id = 0;        // largest HW_REG_XCC_ID seen by a probe launch at create: the ticket rollout assumes ids 0..7 (one L2 per queue)
     uint32_t* d_ev_lost = nullptr;  // [n_games] records a game's ring lost to a late drain (rmj_drain_events), cumulative
@@ -1090,6 +1091,7 @@ static int create_impl(rmj_env* h, const RmjConfig* cfg, uint64_t** d_seeds_out)
     if (const char* e = getenv("RMJ_QUEUE_CHUNK")) h->queue_chunk = atoi(e);
     if (const char* e = getenv("RMJ_QUEUE_FORCE")) h->queue_force = atoi(e);
     if (const char* e = getenv("RMJ_QUEUE_TEST_SKIP_XCDS")) h->queue_skip_xcds = (uint32_t)strtoul(e, nullptr, 0) & 0xFFu;
+    if (const char* e = getenv("RMJ_QUEUE_TAIL")) h->queue_tail = atoi(e) != 0;
     if (const char* e = getenv("RMJ_QUEUE_MIN_CHUNK")) h->queue_min_chunk = atoi(e) > 0 ? atoi(e) : 1;
     if (const char* e = getenv("RMJ_HEAVY_FIRST")) h->heavy_first = atoi(e);
     h->rows_pw = cfg->n_games <= RMJ_ROWS1_MAX_GAMES ? 1u : (cfg->n_games <= RMJ_ROWS2_MAX_GAMES ? 2u : 4u);
@@ -1227,6 +1229,7 @@ int rmj_clone(rmj_handle h, rmj_handle* out) {
     c->queue_chunk = h->queue_chunk;
     c->queue_force = h->queue_force;
     c->queue_min_chunk = h->queue_min_chunk;
+    c->queue_tail = h->queue_tail;
     c->rows_pw = h->rows_pw;
     c->heavy_first = h->heavy_first;
     c->enc_streams = h->enc_streams;
@@ -1501,7 +1504,9 @@ static int rollout_streams(const rmj_env* h, uint32_t n_steps) {
 // chunk hand-overs cost more than it (524 288 games: -2 %).
 // steps per ticket: the configured chunk, shorter for a short rollout (its tail is one chunk long: at least 16 chunks per quad)
 static uint32_t rollout_chunk(const rmj_env* h, uint32_t n_steps) {
-    const uint32_t cap = (uint32_t)h->queue_chunk, lo = (uint32_t)h->queue_min_chunk, fine = n_steps / 16u < lo ? lo : n_steps / 16u;
+    uint32_t cap = (uint32_t)h->queue_chunk;
+    const uint32_t lo = (uint32_t)h->queue_min_chunk, fine = n_steps / 16u < lo ? lo : n_steps / 16u;
+    if (cap < (n_steps + 39u) / 40u) cap = (n_steps + 39u) / 40u;   // at most 64 tickets per quad (q_ticket_plan)
     return fine < cap ? fine : cap;
 }
 static bool rollout_queued(rmj_env* h, uint32_t n_steps) {
@@ -1551,18 +1556,20 @@ static int step_policy_impl(rmj_handle h, uint64_t policy_seed, uint32_t n_steps
         if (rollout_queued(h, n_steps)) {
             // ... or, for a long rollout of a batch that does not fill the chip a whole number of times, in (quad, chunk) tickets
             // ticket counters (one line per XCD) + the quads' chunk counts: one allocation, zeroed by ONE memset in front of every rollout
+            // (+ the games' step counts of this rollout, carried from ticket to ticket: k_step4_queue)
             if (!h->d_qheads) {
-                HIPCHK(hipMalloc(&h->d_qheads, (8 * RMJ_Q_STRIDE + (size_t)grid.x) * sizeof(uint32_t)));
+                HIPCHK(hipMalloc(&h->d_qheads, (8 * RMJ_Q_STRIDE + (size_t)grid.x + (size_t)grid.x * 4) * sizeof(uint32_t)));
                 h->d_qdone = h->d_qheads + 8 * RMJ_Q_STRIDE;
             }
-            HIPCHK(hipMemsetAsync(h->d_qheads, 0, (8 * RMJ_Q_STRIDE + (size_t)grid.x) * sizeof(uint32_t), h->stream));
+            uint32_t* const d_qprog = h->d_qdone + grid.x;
+            HIPCHK(hipMemsetAsync(h->d_qheads, 0, (8 * RMJ_Q_STRIDE + (size_t)grid.x) * sizeof(uint32_t), h->stream));   // (prog is written before it is read)
             const dim3 gq(grid.x < h->q_slots ? grid.x : h->q_slots);
             const uint32_t chunk = rollout_chunk(h, n_steps);
             if (sanma) {
-                RMJ_LAUNCH_POL(rmj3, k_step4_queue, pol, gq, dim3(64), 0, h->stream, (const Env*)h->d_env, policy_seed, flags, n, n_steps, chunk, h->d_qheads, h->d_qdone, h->queue_skip_xcds);
+                RMJ_LAUNCH_POL(rmj3, k_step4_queue, pol, gq, dim3(64), 0, h->stream, (const Env*)h->d_env, policy_seed, flags, n, n_steps, chunk, h->d_qheads, h->d_qdone, h->queue_skip_xcds, d_qprog, (uint32_t)h->queue_tail);
                 RMJ_LAUNCH_POL(rmj3, k_step4_fixup, pol, grid, dim3(64), 0, h->stream, (const Env*)h->d_env, policy_seed, flags, n, n_steps, (const uint32_t*)h->d_qdone);
             } else {
-                RMJ_LAUNCH_POL(rmj4, k_step4_queue, pol, gq, dim3(64), 0, h->stream, (const Env*)h->d_env, policy_seed, flags, n, n_steps, chunk, h->d_qheads, h->d_qdone, h->queue_skip_xcds);
+                RMJ_LAUNCH_POL(rmj4, k_step4_queue, pol, gq, dim3(64), 0, h->stream, (const Env*)h->d_env, policy_seed, flags, n, n_steps, chunk, h->d_qheads, h->d_qdone, h->queue_skip_xcds, d_qprog, (uint32_t)h->queue_tail);
                 RMJ_LAUNCH_POL(rmj4, k_step4_fixup, pol, grid, dim3(64), 0, h->stream, (const Env*)h->d_env, policy_seed, flags, n, n_steps, (const uint32_t*)h->d_qdone);
             }
             HIPCHK(hipGetLastError());
@@ -1630,7 +1637,7 @@ int rmj_step_random_encode(rmj_handle h, uint64_t policy_seed, uint32_t n_steps,
         if (queued) {
             // ticket counters (one line per XCD) + the quads' chunk counts: one allocation, zeroed by ONE memset in front of every rollout
             if (!h->d_qheads) {
-                HIPCHK(hipMalloc(&h->d_qheads, (8 * RMJ_Q_STRIDE + (size_t)grid.x) * sizeof(uint32_t)));
+                HIPCHK(hipMalloc(&h->d_qheads, (8 * RMJ_Q_STRIDE + (size_t)grid.x + (size_t)grid.x * 4) * sizeof(uint32_t)));   // (one size for both rollouts: step_policy_impl)
                 h->d_qdone = h->d_qheads + 8 * RMJ_Q_STRIDE;
             }
             HIPCHK(hipMemsetAsync(h->d_qheads, 0, (8 * RMJ_Q_STRIDE + (size_t)grid.x) * sizeof(uint32_t), h->stream));
@@ -2915,6 +2922,26 @@ int rmj_tl4_fetch(uint64_t* out, uint32_t n_waves) {
     }
     HIPCHK(hipMemcpy(out, buf, (size_t)(n_waves < cap ? n_waves : cap) * RMJ_TL4_ROW * 8, hipMemcpyDeviceToHost));
     HIPCHK(hipMemset(buf, 0, (size_t)cap * RMJ_TL4_ROW * 8));   // blocks that leave at once (heavy-first order) write nothing
+    HIPCHK(hipDeviceSynchronize());
+    return RMJ_OK;
+}
+#endif
+
+#ifdef RMJ_QTL
+// ticket timeline build only (scripts/timeline_queue.py): rows of the waves of the last k_step4_queue launch (allocates on first call)
+int rmj_qtl_fetch(uint64_t* out, uint32_t n_waves) {
+    static unsigned long long* buf = nullptr;
+    static uint32_t cap = 0;
+    HIPCHK(hipDeviceSynchronize());
+    if (!buf) {
+        cap = n_waves;
+        HIPCHK(hipMalloc(&buf, (size_t)cap * RMJ_QTL_ROW * 8));
+        HIPCHK(hipMemset(buf, 0, (size_t)cap * RMJ_QTL_ROW * 8));
+        HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(rmj::g_qtl), &buf, sizeof(buf)));
+        return RMJ_OK;
+    }
+    HIPCHK(hipMemcpy(out, buf, (size_t)(n_waves < cap ? n_waves : cap) * RMJ_QTL_ROW * 8, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemset(buf, 0, (size_t)cap * RMJ_QTL_ROW * 8));
     HIPCHK(hipDeviceSynchronize());
     return RMJ_OK;
 }

@@ -43,6 +43,37 @@ __device__ __forceinline__ ShantenTables sh_tables_of(CEnv& E) {
     return T;
 }
 
+// Ticket lengths (in calls of the step function) of the fused ticket rollout, k_step4_queue: `cap` calls while much is left, a
+// geometric descent (x 0.6) towards the call at which a quad is EXPECTED to finish (0.89 calls per step: the RandomAgent's inline
+// responses advance a row 1.15 steps per call, the rows of a quad end within a call or two of each other), so that the tickets handed
+// out last are one or two calls long and the launch does not end with a few waves on long tickets; behind that point 1, 2, 4, ... for
+// the few quads that are not through yet, until the lengths cover n_steps calls (a call advances every unfinished row by at least one
+// step).  `tail` = 0: equal tickets of `cap` calls.  Returns the number of tickets per quad; len[c] for c < 64.
+__host__ __device__ inline uint32_t q_ticket_plan(uint32_t n_steps, uint32_t cap, uint32_t tail, uint16_t* len /*[64] or nullptr*/) {
+    uint32_t n = 0, covered = 0;
+    if (!tail) {
+        while (covered < n_steps && n < 64u) { if (len) len[n] = (uint16_t)(cap > 65535u ? 65535u : cap); covered += cap; n++; }
+        return n ? n : 1u;
+    }
+    uint32_t rem = (n_steps * 89u + 99u) / 100u, grow = 1u;
+    while (covered < n_steps && n < 64u) {
+        uint32_t s;
+        if (rem > 0u) {
+            s = (rem * 2u + 4u) / 5u;              // ceil(0.4 rem)
+            if (s > cap) s = cap;
+            if (s < 1u) s = 1u;
+            rem -= s < rem ? s : rem;
+        } else {
+            s = grow > cap ? cap : grow;
+            grow *= 2u;
+        }
+        if (len) len[n] = (uint16_t)(s > 65535u ? 65535u : s);   // (the host keeps cap >= n_steps / 40: 64 tickets cover any rollout; the quad's last ticket runs unbounded anyway)
+        covered += s;
+        n++;
+    }
+    return n ? n : 1u;
+}
+
 // heavy-first launch order of the per-step kernel (k_step4<false>, rmj_step4.hip.h)
 struct HeavyOrder {        // device pointers (rmj_env::d_heavy), nullptr members = plain order
     const uint32_t* in_cnt;
@@ -85,6 +116,10 @@ __device__ unsigned long long* g_tl4;
         if ((c).lane == 0) { (c).X.tl_acc[k] += (uint32_t)(t__ - (c).X.tl_prev); (c).X.tl_prev = t__; } } while (0)
 #else
 #define TLF(c, k) do {} while (0)
+#endif
+#ifdef RMJ_QTL   /* ticket timeline build of k_step4_queue (-DRMJ_QTL, scripts/timeline_queue.py, never the shipped library) */
+__device__ unsigned long long* g_qtl;
+#define RMJ_QTL_ROW 256   /* u64 per wave: [0] kernel entry, [1] exit, [2] tickets, then 4 per ticket */
 #endif
 // Section timing of the step kernel (profiling build only: -DRMJ_PROFILE, never the shipped library): wave cycles
 // between consecutive PROF marks are accumulated per section id by lane 0.

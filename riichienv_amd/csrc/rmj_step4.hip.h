@@ -97,6 +97,9 @@ struct Quad4Shared {
 // static in each entry point: the out-of-line pieces of a step (r4_round_end) address it directly, as LDS.
 static_assert(sizeof(Quad4Shared) <= 6336, "LDS per wave: one allocation step more costs the fused rollouts 7 % (R4_RS_WORDS)");
 __shared__ Quad4Shared g_q4;
+#ifdef RMJ_QTL
+__shared__ uint32_t g_qtl_cnt[2];   // ticket timeline build: calls of the step function in the current ticket, and the live rows summed over them
+#endif
 
 // ballot of the lane's own row: pick the half of the 64-bit mask (one select on the lane-constant "upper half" predicate),
 // then a 16-bit field extract at bit 0 / 16 - three vector instructions instead of a 64-bit shift by a lane-varying amount
@@ -1928,10 +1931,24 @@ __device__ __forceinline__ uint32_t step4_body(const Env* Ep, Quad4Shared& sh, u
     const uint32_t n_here = g0 >= g_end ? 0u : (g_end - g0 < rows_pw ? g_end - g0 : rows_pw);   // games of this wave
     if (load) {   // ---- records: every row fetches its own 640 B (40 chunks of 16 B, three per lane)
         if ((uint32_t)row < n_here) {
+            if (LOOP) {
+                // A fused rollout may take its quad over from a wave of another CU (tickets: k_step4_queue).  Everything tier 0 reads of a
+                // game's global state - the record here, the wall tile and the list entry further down - goes past the vector L1
+                // (agent-scope loads, served by the XCD's L2 that the previous holder's write-through stores reached), so a pick-up needs
+                // no L1 invalidate: that invalidate wipes the cache for all 24 waves of the CU, and at one ticket per few wave-steps
+                // it cost the 20-step window 8 % (profiles/r05_ticket_acquire_ab.txt).  The rare paths that read more with plain
+                // loads (ol_step_full, the rich tier's settlement) invalidate when they are entered.
+                uint64_t v[5];
 #pragma unroll
-            for (int k = 0; k < 3; k++) {
-                const int off = r + 16 * k;
-                if (off < (int)(sizeof(GState) / 16)) reinterpret_cast<uint4*>(&sh.st[row])[off] = reinterpret_cast<const uint4*>(E.core + g)[off];
+                for (int k = 0; k < 5; k++) v[k] = __hip_atomic_load(reinterpret_cast<const uint64_t*>(E.core + g) + r + 16 * k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+                for (int k = 0; k < 5; k++) reinterpret_cast<uint64_t*>(&sh.st[row])[r + 16 * k] = v[k];
+            } else {
+#pragma unroll
+                for (int k = 0; k < 3; k++) {
+                    const int off = r + 16 * k;
+                    if (off < (int)(sizeof(GState) / 16)) reinterpret_cast<uint4*>(&sh.st[row])[off] = reinterpret_cast<const uint4*>(E.core + g)[off];
+                }
             }
         }
         wave_sync();
@@ -2640,6 +2657,7 @@ __device__ __forceinline__ uint32_t step4_body(const Env* Ep, Quad4Shared& sh, u
         if (lane == 0) sh.u.x.tl_prev = __builtin_readcyclecounter();
         wave_sync();
 #endif
+        if (LOOP) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");   // the full path reads wall, lists and record with plain loads: drop what the L1 may hold of an earlier visit of this game to this CU (see the record fetch above)
         ol_step_full(ctx_pack(c), lane < 4 ? m_full : RMJ_NO_ACTION, (uint32_t)__builtin_amdgcn_readlane((int)fl_full, 16 * br));
         wave_sync();
 #ifdef RMJ_TL4
@@ -2677,8 +2695,10 @@ template <bool LOOP, int POL>
 __device__ __forceinline__ void step4_finish_rounds(const Env* Ep, uint32_t flags, uint32_t g_base, uint32_t g_end, uint32_t quad = 0xFFFFFFFFu) {
     constexpr bool RICH = (POL == 1) || !LOOP;   // (step4_body's tier)
     const uint32_t md = g_q4.rmode[(threadIdx.x & 63u) >> 4];
-    if (__ballot(md == R4_RE_DRAW || md == R4_RE_RESTART || md == R4_RE_WIN_TSUMO || md == R4_RE_WIN_RON))
+    if (__ballot(md == R4_RE_DRAW || md == R4_RE_RESTART || md == R4_RE_WIN_TSUMO || md == R4_RE_WIN_RON)) {
+        if (LOOP && RICH) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");   // (the settlement reads the ura indicators off the wall slab with plain loads)
         r4_round_end<RICH>(Ep, g_base + (quad == 0xFFFFFFFFu ? blockIdx.x : quad) * r4_rows(flags));
+    }
     if (RICH && __ballot(md == R4_RE_YAKU_CLAIMS || md == R4_RE_YAKU_TSUMO)) r4_yaku_answers();   // (the lean tier never pauses for a yaku check)
     step4_pass2<LOOP, POL>(Ep, flags, g_base, g_end, quad);
 }
@@ -2695,25 +2715,37 @@ __device__ __noinline__ uint32_t step4_call_inl(const Env* Ep, uint64_t policy_s
 }
 // the steps [0, steps) of a quad's rollout / ticket: the RandomAgent answers claims inline (rows run ahead of each other by a step or
 // two and wait at the end), the greedy policy steps all rows in lock-step
+// max_calls: the ticket ends after that many calls of the step function even if rows have steps left (k_step4_queue: a ticket is a
+// number of CALLS, the rows carry what is left of their rollout to the quad's next ticket - no row idles at the end of a ticket while
+// the others catch up); the result = the row's steps still to take.
 template <int POL>
-__device__ __forceinline__ void step4_run(const Env* Ep, uint64_t policy_seed, uint32_t flags, uint32_t g_base, uint32_t g_end, uint64_t gs_row,
-                                          uint32_t quad, uint32_t steps, bool final_chunk, uint32_t g_row) {
+__device__ __forceinline__ uint32_t step4_run(const Env* Ep, uint64_t policy_seed, uint32_t flags, uint32_t g_base, uint32_t g_end, uint64_t gs_row,
+                                              uint32_t quad, uint32_t steps, bool final_chunk, uint32_t g_row, uint32_t max_calls = 0xFFFFFFFFu) {
     if (RMJ_INLINE_RESP & (POL == 0 ? 1 : 2)) {
         uint32_t left = g_row < g_end ? steps : 0u, load = 1u;
+#ifdef RMJ_QTL
+        if ((threadIdx.x & 63u) == 0u) { g_qtl_cnt[0] = 0u; g_qtl_cnt[1] = 0u; }
+#endif
 #pragma unroll 1
-        while (__ballot(left != 0u)) {
+        while (__ballot(left != 0u) && max_calls-- != 0u) {
+#ifdef RMJ_QTL
+            { const uint64_t lv = __ballot(left != 0u && (threadIdx.x & 15u) == 0u); if ((threadIdx.x & 63u) == 0u) { g_qtl_cnt[0] += 1u; g_qtl_cnt[1] += (uint32_t)__popcll(lv); } }
+#endif
             const uint32_t ret = step4_call_inl<POL>(Ep, policy_seed, flags, g_base, g_end, load, gs_row, quad, left, final_chunk ? 1u : 0u);
             left -= ret & 0xFFu;
             load = 0u;
             if (RMJ_ROW_ROUND_END && __ballot((ret & R4_RET_ROUND) != 0u)) step4_finish_rounds<true, POL>(Ep, flags, g_base, g_end, quad);   // (wave-uniform bit)
         }
+        return left;
     } else {
+        const uint32_t n = steps < max_calls ? steps : max_calls;   // (lock-step: every call is one step of every row)
 #pragma unroll 1
-        for (uint32_t it = 0; it < steps; it++) {
+        for (uint32_t it = 0; it < n; it++) {
             const uint32_t fl = flags | ((final_chunk && it + 1u == steps) ? STEP_F_ALLROWS : STEP_F_QUIET);
             const uint32_t ret = step4_call<true, POL>(Ep, policy_seed, fl, g_base, g_end, it == 0 ? 1u : 0u, gs_row, quad);
             if (RMJ_ROW_ROUND_END && __ballot((ret & R4_RET_ROUND) != 0u)) step4_finish_rounds<true, POL>(Ep, fl, g_base, g_end, quad);
         }
+        return g_row < g_end ? steps - n : 0u;
     }
 }
 #ifndef RMJ_STEP4_WAVES
@@ -2804,41 +2836,84 @@ __device__ __noinline__ uint32_t q_take_ticket(uint32_t* head) {
     if ((threadIdx.x & 63u) == 0u) t = __hip_atomic_fetch_add(head, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     return (uint32_t)__builtin_amdgcn_readfirstlane((int)t);
 }
-__device__ __noinline__ void q_wait_for(const uint32_t* slot, uint32_t want) {
+#define RMJ_Q_FIN 0x80000000u   /* done[quad]: every row of the quad has taken its n_steps - the quad's later tickets are empty */
+// waits until the quad's ticket c - 1 has ended (done = chunks ended | RMJ_Q_FIN); returns the word
+__device__ __noinline__ uint32_t q_wait_for(const uint32_t* slot, uint32_t want) {
+    uint32_t v = 0u;
     if ((threadIdx.x & 63u) == 0u)
-        while (__hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < want) __builtin_amdgcn_s_sleep(8);
+        for (;;) {
+            v = __hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if ((v & RMJ_Q_FIN) || v >= want) break;
+            __builtin_amdgcn_s_sleep(8);
+        }
     wave_sync();
+    return (uint32_t)__builtin_amdgcn_readfirstlane((int)v);
 }
+// A ticket = up to `chunk` CALLS of the step function on one quad.  With inline responses a row advances one or two game-steps per
+// call, so a ticket that had to bring every row to the same step count ended with rows idling while the others caught up (8-step
+// tickets: 3.62 of 4 rows live per call, 64-step tickets 3.85 - profiles/r05_ticket_timeline.txt); instead every game carries the
+// steps it has taken in this rollout from ticket to ticket (prog[game], zeroed with the ticket counters) and a ticket simply ends
+// after `chunk` calls.  A quad needs at most ceil(n_steps / chunk) tickets (a call advances every unfinished row); once all its
+// rows are through, done[quad] carries RMJ_Q_FIN and the quad's remaining tickets are empty (one poll, no record fetched).
 // (74 VGPRs: 6 waves per SIMD = 6 144 slots.  Compiled for 7 - 71 VGPRs, four scratch accesses in the ticket loop - it is not faster:
 //  1 617 / 1 504 M env.step/s against 1 642 / 1 529 M in 4P / 3P; the seventh wave was worth its 10 % mostly because it shortened the tail.
 //  Launch bounds for 4 / 5 / 8 waves: 1 532 / 1 279, 1 530 / 1 454, 1 426 / 1 382 - 6 is the optimum)
 template <int POL>
 __global__ __launch_bounds__(64, RMJ_STEP4_WAVES) void k_step4_queue(const Env* __restrict__ Ep, uint64_t policy_seed, uint32_t flags, uint32_t n_games,
                                                                          uint32_t n_steps, uint32_t chunk, uint32_t* __restrict__ heads, uint32_t* __restrict__ done,
-                                                                         uint32_t skip_xcds) {
+                                                                         uint32_t skip_xcds, uint32_t* __restrict__ prog, uint32_t tail) {
     const uint32_t xcd = (uint32_t)__builtin_amdgcn_s_getreg((3 << 11) | 20) & 7u;   // HW_REG_XCC_ID[3:0]
     if ((skip_xcds >> xcd) & 1u) return;   // test hook (RMJ_QUEUE_TEST_SKIP_XCDS): pretend these XCDs received no block -> k_step4_fixup
     const uint32_t n_quads = (n_games + 3u) / 4u;
     const uint32_t mine = n_quads > xcd ? (n_quads - xcd + 7u) / 8u : 0u;             // quads xcd, xcd + 8, ...
-    const uint32_t n_chunks = (n_steps + chunk - 1u) / chunk;
+    __shared__ uint16_t plan[64];
     const uint32_t lane = threadIdx.x & 63u;
+    if (lane == 0u) (void)q_ticket_plan(n_steps, chunk, tail, plan);
+    wave_sync();
+    const uint32_t n_chunks = q_ticket_plan(n_steps, chunk, tail, nullptr);
     if (mine == 0u) return;
+#ifdef RMJ_QTL   /* ticket timeline build (scripts/timeline_queue.py, never the shipped library): per wave and ticket [ticket | xcd << 32, taken, begun, ended] on the 100 MHz clock */
+    uint32_t qtl_n = 0u;
+    unsigned long long* const qtl = rmj::g_qtl + (size_t)blockIdx.x * RMJ_QTL_ROW;
+    if (lane == 0u) { qtl[0] = __builtin_amdgcn_s_memrealtime(); qtl[3] = (unsigned long long)(uint32_t)__builtin_amdgcn_s_getreg((31 << 11) | 4); }   // HW_REG_HW_ID
+#endif
 #pragma unroll 1
     for (;;) {
         const uint32_t t = q_take_ticket(heads + xcd * RMJ_Q_STRIDE);
         if (t >= mine * n_chunks) break;
+#ifdef RMJ_QTL
+        const unsigned long long qt0 = __builtin_amdgcn_s_memrealtime();
+#endif
         const uint32_t c = t / mine, quad = (t - c * mine) * 8u + xcd;
-        if (c > 0u) q_wait_for(done + quad, c);   // the quad's previous chunk (handed out `mine` tickets ago) must have ended
+        if (c > 0u && (q_wait_for(done + quad, c) & RMJ_Q_FIN)) continue;   // the quad's previous ticket (handed out `mine` tickets ago) must have ended; nothing left: an empty ticket
+#ifdef RMJ_Q_ACQ   /* (A/B only, profiles/r05_ticket_acquire_ab.txt: the agent-scope acquire = an L1 invalidate per pick-up, as in rounds 2-4) */
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-        const uint32_t steps = n_steps - c * chunk < chunk ? n_steps - c * chunk : chunk;
+#endif
+#ifdef RMJ_QTL
+        const unsigned long long qt1 = __builtin_amdgcn_s_memrealtime();
+#endif
         const uint32_t g = quad * 4u + (lane >> 4);
         const uint64_t gs_row = sm64(policy_seed + ((CEnv*)Ep)->game_offset + (uint64_t)g);
-        const bool last_chunk = c + 1u == n_chunks;
-        step4_run<POL>(Ep, policy_seed, flags, 0u, n_games, gs_row, quad, steps, last_chunk, g);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this chunk's stores are in the XCD's L2
+        uint32_t taken = 0u;
+        if (c > 0u && g < n_games) taken = __hip_atomic_load(prog + g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        // (the quad's last possible ticket runs until every row is through, whatever a call achieved)
+        const uint32_t left = step4_run<POL>(Ep, policy_seed, flags, 0u, n_games, gs_row, quad, n_steps - taken, true, g, c + 1u == n_chunks ? 0xFFFFFFFFu : (uint32_t)plan[c]);
+        if ((lane & 15u) == 0u && g < n_games) prog[g] = n_steps - left;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this ticket's stores are in the XCD's L2
         wave_sync();
-        if (lane == 0u) __hip_atomic_store(done + quad, c + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const bool fin = __ballot(left != 0u) == 0ull;
+        if (lane == 0u) __hip_atomic_store(done + quad, (c + 1u) | (fin ? RMJ_Q_FIN : 0u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#ifdef RMJ_QTL
+        if (lane == 0u && 4u + 4u * qtl_n + 3u < RMJ_QTL_ROW) {
+            qtl[4u + 4u * qtl_n] = (unsigned long long)t | ((unsigned long long)xcd << 32) | ((unsigned long long)(g_qtl_cnt[0] & 0xFFu) << 40) | ((unsigned long long)(g_qtl_cnt[1] & 0xFFFFu) << 48);
+            qtl[5u + 4u * qtl_n] = qt0; qtl[6u + 4u * qtl_n] = qt1; qtl[7u + 4u * qtl_n] = __builtin_amdgcn_s_memrealtime();
+        }
+        qtl_n += 1u;
+#endif
     }
+#ifdef RMJ_QTL
+    if (lane == 0u) { qtl[1] = __builtin_amdgcn_s_memrealtime(); qtl[2] = qtl_n; }
+#endif
 }
 
 // Safety net of k_step4_queue: where blocks run is not ours to decide - a quad whose XCD received no block at all (a partitioned
@@ -2931,7 +3006,7 @@ __global__ __launch_bounds__(64, RMJ_STEP4_ENC_WAVES) void k_step4_queue_enc(con
         const uint32_t t = q_take_ticket(heads + xcd * RMJ_Q_STRIDE);
         if (t >= mine * n_chunks) break;
         const uint32_t c = t / mine, quad = (t - c * mine) * 8u + xcd;
-        if (c > 0u) q_wait_for(done + quad, c);
+        if (c > 0u) (void)q_wait_for(done + quad, c);
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
         const uint32_t steps = n_steps - c * chunk < chunk ? n_steps - c * chunk : chunk;
         const uint32_t g = quad * 4u + (lane >> 4);

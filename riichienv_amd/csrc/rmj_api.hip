@@ -983,10 +983,10 @@ struct rmj_env {
     int quad = 2;              // device-policy steps: 0 = one game per wave (k_step), 1 = four games per wave (k_step4), 2 = and a
                                // rollout of >= 2 steps is ONE launch in which every wave steps its own games (k_step4<true>); RMJ_STEP4 at create
     // long fused rollouts hand the work out in (quad, chunk) tickets to a grid that fits the chip once (k_step4_queue)
-    int queue_chunk = 64;      // steps per ticket; RMJ_QUEUE_CHUNK at create, 0 = off (every wave keeps one quad for the rollout)
+    int queue_chunk = 32;      // calls per ticket (round 5: a ticket is a number of calls of the step function, profiles/r05_ticket_schedule_sweep.txt); RMJ_QUEUE_CHUNK at create, 0 = off (every wave keeps one quad for the rollout)
     hipEvent_t ev_time[2] = {nullptr, nullptr};   // rmj_time_rollout* / rmj_bench_rollout: created on first use, so that a timed region holds no event create / destroy
     uint32_t* d_qheads = nullptr;   // [8][RMJ_Q_STRIDE] ticket counters, one line per XCD
-    uint32_t* d_qdone = nullptr;    // [quads] chunks finished
+    int q_cur = 0;                  // which of the two counter sets of the ticket rollout is zeroed and next in turn
     uint32_t q_slots = 0;           // waves of k_step4_queue the device holds at once (the smaller of the two policy instantiations)
     int queue_force = 0;            // RMJ_QUEUE_FORCE at create (tests): tickets for every batch of >= 64 quads
     uint32_t queue_skip_xcds = 0;   // test hook: XCDs whose waves leave the queue kernel at once (RMJ_QUEUE_TEST_SKIP_XCDS at create)
@@ -995,8 +995,8 @@ struct rmj_env {
     int heavy_first = 1;            // RMJ_HEAVY_FIRST at create (0: plain block order)
     uint32_t rows_pw = 4;           // games per wave of the non-ticket four-games-per-wave kernels: 4, or 2 / 1 for batches that leave the chip
                                     // latency bound (chosen at create from the batch size; RMJ_ROWS overrides)
-    int queue_tail = 1;             // ticket lengths descend towards the expected end of a quad's rollout (q_ticket_plan); RMJ_QUEUE_TAIL=0: equal tickets
-    int queue_min_chunk = 8;        // shortest ticket (steps): a rollout of >= 2 tickets per quad runs as tickets; RMJ_QUEUE_MIN_CHUNK at create
+    int queue_tail = 0;             // ticket lengths descend towards the expected end of a quad's rollout (q_ticket_plan); RMJ_QUEUE_TAIL=0: equal tickets
+    int queue_min_chunk = 5;        // shortest ticket (steps): a rollout of >= 2 tickets per quad runs as tickets; RMJ_QUEUE_MIN_CHUNK at create
     uint32_t max_xcc_id = 0;        // largest HW_REG_XCC_ID seen by a probe launch at create: the ticket rollout assumes ids 0..7 (one L2 per queue)
     uint32_t* d_ev_lost = nullptr;  // [n_games] records a game's ring lost to a late drain (rmj_drain_events), cumulative
     void* d_track = nullptr;        // round tracker (rmj_round_track_device): hand index / scores / meta where every game's round began
@@ -1555,22 +1555,29 @@ static int step_policy_impl(rmj_handle h, uint64_t policy_seed, uint32_t n_steps
         const dim3 grid((n + 3u) / 4u);
         if (rollout_queued(h, n_steps)) {
             // ... or, for a long rollout of a batch that does not fill the chip a whole number of times, in (quad, chunk) tickets
-            // ticket counters (one line per XCD) + the quads' chunk counts: one allocation, zeroed by ONE memset in front of every rollout
-            // (+ the games' step counts of this rollout, carried from ticket to ticket: k_step4_queue)
+            // ticket counters (one line per XCD) + the quads' ticket counts, in THREE sets: two for this rollout, used in turn - the launch
+            // that works on one zeroes the other for its successor, so no memset sits between rollouts - and one for the step + encode
+            // rollout (which memsets its own); behind them the games' step counts of the running rollout, carried from ticket to ticket
+            const size_t set_words = 8 * RMJ_Q_STRIDE + (size_t)grid.x;
             if (!h->d_qheads) {
-                HIPCHK(hipMalloc(&h->d_qheads, (8 * RMJ_Q_STRIDE + (size_t)grid.x + (size_t)grid.x * 4) * sizeof(uint32_t)));
-                h->d_qdone = h->d_qheads + 8 * RMJ_Q_STRIDE;
+                HIPCHK(hipMalloc(&h->d_qheads, (3 * set_words + (size_t)grid.x * 4) * sizeof(uint32_t)));
+                HIPCHK(hipMemsetAsync(h->d_qheads, 0, 3 * set_words * sizeof(uint32_t), h->stream));
+                h->q_cur = 0;
             }
-            uint32_t* const d_qprog = h->d_qdone + grid.x;
-            HIPCHK(hipMemsetAsync(h->d_qheads, 0, (8 * RMJ_Q_STRIDE + (size_t)grid.x) * sizeof(uint32_t), h->stream));   // (prog is written before it is read)
+            uint32_t* const heads = h->d_qheads + (size_t)h->q_cur * set_words;
+            uint32_t* const done = heads + 8 * RMJ_Q_STRIDE;
+            uint32_t* const next = h->d_qheads + (size_t)(1 - h->q_cur) * set_words;
+            uint32_t* const d_qprog = h->d_qheads + 3 * set_words;   // (written before it is read)
+            h->q_cur = 1 - h->q_cur;
             const dim3 gq(grid.x < h->q_slots ? grid.x : h->q_slots);
+            const dim3 gfix((grid.x + 63u) / 64u);
             const uint32_t chunk = rollout_chunk(h, n_steps);
             if (sanma) {
-                RMJ_LAUNCH_POL(rmj3, k_step4_queue, pol, gq, dim3(64), 0, h->stream, (const Env*)h->d_env, policy_seed, flags, n, n_steps, chunk, h->d_qheads, h->d_qdone, h->queue_skip_xcds, d_qprog, (uint32_t)h->queue_tail);
-                RMJ_LAUNCH_POL(rmj3, k_step4_fixup, pol, grid, dim3(64), 0, h->stream, (const Env*)h->d_env, policy_seed, flags, n, n_steps, (const uint32_t*)h->d_qdone);
+                RMJ_LAUNCH_POL(rmj3, k_step4_queue, pol, gq, dim3(64), 0, h->stream, (const Env*)h->d_env, policy_seed, flags, n, n_steps, chunk, heads, done, h->queue_skip_xcds, d_qprog, (uint32_t)h->queue_tail, next, (uint32_t)set_words);
+                RMJ_LAUNCH_POL(rmj3, k_step4_fixup, pol, gfix, dim3(64), 0, h->stream, (const Env*)h->d_env, policy_seed, flags, n, n_steps, (const uint32_t*)done);
             } else {
-                RMJ_LAUNCH_POL(rmj4, k_step4_queue, pol, gq, dim3(64), 0, h->stream, (const Env*)h->d_env, policy_seed, flags, n, n_steps, chunk, h->d_qheads, h->d_qdone, h->queue_skip_xcds, d_qprog, (uint32_t)h->queue_tail);
-                RMJ_LAUNCH_POL(rmj4, k_step4_fixup, pol, grid, dim3(64), 0, h->stream, (const Env*)h->d_env, policy_seed, flags, n, n_steps, (const uint32_t*)h->d_qdone);
+                RMJ_LAUNCH_POL(rmj4, k_step4_queue, pol, gq, dim3(64), 0, h->stream, (const Env*)h->d_env, policy_seed, flags, n, n_steps, chunk, heads, done, h->queue_skip_xcds, d_qprog, (uint32_t)h->queue_tail, next, (uint32_t)set_words);
+                RMJ_LAUNCH_POL(rmj4, k_step4_fixup, pol, gfix, dim3(64), 0, h->stream, (const Env*)h->d_env, policy_seed, flags, n, n_steps, (const uint32_t*)done);
             }
             HIPCHK(hipGetLastError());
             return RMJ_OK;
@@ -1636,18 +1643,22 @@ int rmj_step_random_encode(rmj_handle h, uint64_t policy_seed, uint32_t n_steps,
                             (h->queue_force ? grid.x >= 64u : (grid.x > h->q_slots_enc && grid.x < 8u * h->q_slots_enc));
         if (queued) {
             // ticket counters (one line per XCD) + the quads' chunk counts: one allocation, zeroed by ONE memset in front of every rollout
+            const size_t set_words = 8 * RMJ_Q_STRIDE + (size_t)grid.x;   // (three counter sets, the third is this rollout's: step_policy_impl)
             if (!h->d_qheads) {
-                HIPCHK(hipMalloc(&h->d_qheads, (8 * RMJ_Q_STRIDE + (size_t)grid.x + (size_t)grid.x * 4) * sizeof(uint32_t)));   // (one size for both rollouts: step_policy_impl)
-                h->d_qdone = h->d_qheads + 8 * RMJ_Q_STRIDE;
+                HIPCHK(hipMalloc(&h->d_qheads, (3 * set_words + (size_t)grid.x * 4) * sizeof(uint32_t)));
+                HIPCHK(hipMemsetAsync(h->d_qheads, 0, 3 * set_words * sizeof(uint32_t), h->stream));
+                h->q_cur = 0;
             }
-            HIPCHK(hipMemsetAsync(h->d_qheads, 0, (8 * RMJ_Q_STRIDE + (size_t)grid.x) * sizeof(uint32_t), h->stream));
+            uint32_t* const e_heads = h->d_qheads + 2 * set_words;
+            uint32_t* const e_done = e_heads + 8 * RMJ_Q_STRIDE;
+            HIPCHK(hipMemsetAsync(e_heads, 0, set_words * sizeof(uint32_t), h->stream));
             const dim3 gq(grid.x < h->q_slots_enc ? grid.x : h->q_slots_enc);
             if (sanma) {
-                hipLaunchKernelGGL((rmj3::k_step4_queue_enc<0>), gq, dim3(64), 0, h->stream, (const Env*)h->d_env, policy_seed, flags, n, n_steps, chunk, h->d_qheads, h->d_qdone, h->queue_skip_xcds, d_out);
-                hipLaunchKernelGGL((rmj3::k_step4_fixup_enc<0>), grid, dim3(64), 0, h->stream, (const Env*)h->d_env, policy_seed, flags, n, n_steps, (const uint32_t*)h->d_qdone, d_out);
+                hipLaunchKernelGGL((rmj3::k_step4_queue_enc<0>), gq, dim3(64), 0, h->stream, (const Env*)h->d_env, policy_seed, flags, n, n_steps, chunk, e_heads, e_done, h->queue_skip_xcds, d_out);
+                hipLaunchKernelGGL((rmj3::k_step4_fixup_enc<0>), grid, dim3(64), 0, h->stream, (const Env*)h->d_env, policy_seed, flags, n, n_steps, (const uint32_t*)e_done, d_out);
             } else {
-                hipLaunchKernelGGL((rmj4::k_step4_queue_enc<0>), gq, dim3(64), 0, h->stream, (const Env*)h->d_env, policy_seed, flags, n, n_steps, chunk, h->d_qheads, h->d_qdone, h->queue_skip_xcds, d_out);
-                hipLaunchKernelGGL((rmj4::k_step4_fixup_enc<0>), grid, dim3(64), 0, h->stream, (const Env*)h->d_env, policy_seed, flags, n, n_steps, (const uint32_t*)h->d_qdone, d_out);
+                hipLaunchKernelGGL((rmj4::k_step4_queue_enc<0>), gq, dim3(64), 0, h->stream, (const Env*)h->d_env, policy_seed, flags, n, n_steps, chunk, e_heads, e_done, h->queue_skip_xcds, d_out);
+                hipLaunchKernelGGL((rmj4::k_step4_fixup_enc<0>), grid, dim3(64), 0, h->stream, (const Env*)h->d_env, policy_seed, flags, n, n_steps, (const uint32_t*)e_done, d_out);
             }
         } else if (sanma) {
             hipLaunchKernelGGL((rmj3::k_step4_enc<0>), grid, dim3(64), 0, h->stream, (const Env*)h->d_env, policy_seed, flags, 0u, n, n_steps, d_out);

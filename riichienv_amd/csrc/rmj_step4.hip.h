@@ -2861,7 +2861,12 @@ __device__ __noinline__ uint32_t q_wait_for(const uint32_t* slot, uint32_t want)
 template <int POL>
 __global__ __launch_bounds__(64, RMJ_STEP4_WAVES) void k_step4_queue(const Env* __restrict__ Ep, uint64_t policy_seed, uint32_t flags, uint32_t n_games,
                                                                          uint32_t n_steps, uint32_t chunk, uint32_t* __restrict__ heads, uint32_t* __restrict__ done,
-                                                                         uint32_t skip_xcds, uint32_t* __restrict__ prog, uint32_t tail) {
+                                                                         uint32_t skip_xcds, uint32_t* __restrict__ prog, uint32_t tail, uint32_t* __restrict__ zero_next,
+                                                                         uint32_t zero_words) {
+    {   // the counters of the NEXT ticket rollout (the other of two sets: nobody touches it during this launch): no memset between rollouts
+        const uint32_t per = (zero_words + gridDim.x - 1u) / gridDim.x, lo = blockIdx.x * per;
+        for (uint32_t i = lo + (threadIdx.x & 63u); i < lo + per && i < zero_words; i += 64u) zero_next[i] = 0u;
+    }
     const uint32_t xcd = (uint32_t)__builtin_amdgcn_s_getreg((3 << 11) | 20) & 7u;   // HW_REG_XCC_ID[3:0]
     if ((skip_xcds >> xcd) & 1u) return;   // test hook (RMJ_QUEUE_TEST_SKIP_XCDS): pretend these XCDs received no block -> k_step4_fixup
     const uint32_t n_quads = (n_games + 3u) / 4u;
@@ -2918,14 +2923,22 @@ __global__ __launch_bounds__(64, RMJ_STEP4_WAVES) void k_step4_queue(const Env* 
 
 // Safety net of k_step4_queue: where blocks run is not ours to decide - a quad whose XCD received no block at all (a partitioned
 // device, a dispatcher that skips an XCD) has done[quad] == 0 and is stepped here, by one wave for the whole rollout like
-// k_step4<true> (nothing of it has run yet, so no other cache holds newer data).  Every other wave exits at once.
+// k_step4<true> (nothing of it has run yet, so no other cache holds newer data).  One wave looks at 64 quads (a launch of one
+// block per quad cost the 20-step window as much as 1 % of its time to find nothing).
 template <int POL>
 __global__ __launch_bounds__(64, RMJ_STEP4_WAVES) void k_step4_fixup(const Env* __restrict__ Ep, uint64_t policy_seed, uint32_t flags, uint32_t n_games,
                                                                          uint32_t n_steps, const uint32_t* __restrict__ done) {
-    if (uni(__hip_atomic_load(done + blockIdx.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) != 0u) return;
-    const uint32_t g = blockIdx.x * 4u + ((threadIdx.x & 63u) >> 4);
-    const uint64_t gs_row = sm64(policy_seed + ((CEnv*)Ep)->game_offset + (uint64_t)g);
-    step4_run<POL>(Ep, policy_seed, flags, 0u, n_games, gs_row, 0xFFFFFFFFu, n_steps, true, g);
+    const uint32_t n_quads = (n_games + 3u) / 4u, lane = threadIdx.x & 63u, mine = blockIdx.x * 64u + lane;
+    uint64_t todo = __ballot(mine < n_quads && __hip_atomic_load(done + (mine < n_quads ? mine : 0u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u);
+#pragma unroll 1
+    while (todo) {
+        const uint32_t quad = blockIdx.x * 64u + (uint32_t)(__ffsll((long long)todo) - 1);
+        todo &= todo - 1ull;
+        const uint32_t g = quad * 4u + (lane >> 4);
+        const uint64_t gs_row = sm64(policy_seed + ((CEnv*)Ep)->game_offset + (uint64_t)g);
+        (void)step4_run<POL>(Ep, policy_seed, flags, 0u, n_games, gs_row, quad, n_steps, true, g);
+        wave_sync();
+    }
 }
 
 

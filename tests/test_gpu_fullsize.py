@@ -291,7 +291,7 @@ def test_queued_rollout_survives_xcds_without_blocks():
 def test_default_rollout_runs_as_tickets_and_equals_the_plain_one(mode):
     """the default library on a batch of more than one chip-full of waves (32 768 games = 8 192 quads): a 400-step rollout runs as
     k_step4_queue (RmjBenchResult.queued) and leaves every game where the one-quad-per-wave rollout leaves it; so does a short
-    rollout (the driver's 20-step bench run: tickets of 8 steps); fewer than 16 steps keep one quad per wave"""
+    rollout (the driver's 20-step bench run: tickets of 5 calls of the step function); fewer than 10 steps keep one quad per wave"""
     n = 32768
     plain = _rollout_with({"RMJ_QUEUE_CHUNK": "0"}, mode, n, 400)
     dflt = _rollout_with({}, mode, n, 400)
@@ -299,8 +299,8 @@ def test_default_rollout_runs_as_tickets_and_equals_the_plain_one(mode):
     if FUSED:     # (RMJ_STEP4=0 / 1 select the per-step kernels: no fused rollout, no tickets)
         assert int(dflt.bench_rollout(PSEED, 0, 200).queued) == 1 and int(plain.bench_rollout(PSEED, 0, 200).queued) == 0
         assert int(dflt.bench_rollout(PSEED, 0, 100).queued) == 1 and int(dflt.bench_rollout(PSEED, 0, 20).queued) == 1
-        assert int(dflt.bench_rollout(PSEED, 0, 15).queued) == 0
-        for k in (100, 20, 15):        # the plain environment catches up, then a 20- and a 17-step rollout on both
+        assert int(dflt.bench_rollout(PSEED, 0, 15).queued) == 1 and int(dflt.bench_rollout(PSEED, 0, 9).queued) == 0
+        for k in (100, 20, 15, 9):     # the plain environment catches up, then a 20- and a 17-step rollout on both
             plain.step_random(PSEED, k, auto_reset=True)
         for e in (plain, dflt):
             e.step_random(PSEED, 20, auto_reset=True)

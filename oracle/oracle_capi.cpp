@@ -967,6 +967,15 @@ void orc_game_encode_extended(void* gp, int pid, float* arr) {
     const int W = sanma ? 27 : 34, NP = g->NP;
     std::memset(arr, 0, sizeof(float) * 215 * W);
     orc_game_encode(gp, pid, arr);
+    {   // encode_base_into (observation/encode.rs:12-293, observation_3p/encode.rs) is Observation.encode() (python.rs:457-806) except
+        // for channel 30: it does not count a meld's called tile twice - "already counted in discards" (encode.rs:94-111)
+        int used = (int)g->players[pid].hand.size() + (int)g->wall.dora_indicators.size();
+        for (int q = 0; q < NP; q++) {
+            used += (int)g->players[q].discards.size();
+            for (auto& m : g->players[q].melds) used += (int)m.tiles.size() - (m.called_tile >= 0 ? 1 : 0);
+        }
+        for (int k = 0; k < W; k++) arr[30 * W + k] = (float)std::max((sanma ? 108 : 136) - used, 0) / 70.0f;
+    }
     auto col = [&](int t34) -> int { return sanma ? (t34 == 0 ? 0 : (t34 >= 8 && t34 < 34 ? t34 - 7 : -1)) : (t34 < 34 ? t34 : -1); };
     auto bc = [&](int ch, float v) {
         for (int k = 0; k < W; k++) arr[ch * W + k] = v;

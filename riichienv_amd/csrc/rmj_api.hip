@@ -734,10 +734,10 @@ __global__ __launch_bounds__(64) RMJ_ENCX_OCC void k_encode_ext(Env E, int only_
         return;
     }
     auto head_of = [](const float* p) { return (int)(((16u - (uint32_t)(reinterpret_cast<uintptr_t>(p) & 15u)) & 15u) >> 2); };
-    {   // channels 0..73
+    {   // channels 0..73 (encode_base_into: its own tiles-left count, see encode_seat_to)
         const int head = head_of(dst);
         EncByteSink<W> o{raw + ((4 - head) & 3), lut, lane, -1.0f};
-        encode_seat_to<SANMA>(S, seat, lane, hist, o, true);
+        encode_seat_to<SANMA>(S, seat, lane, hist, o, true, true);
         enc_emit_bytes<W>(dst, o.cells, lut, lane, head);
         wave_sync();
     }

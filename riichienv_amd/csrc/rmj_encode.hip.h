@@ -152,8 +152,11 @@ __device__ __forceinline__ void enc_emit_bytes(float* dst, const uint8_t* cells,
     }
     if (lane < N - tail0) dst[tail0 + lane] = lut[cells[tail0 + lane]];
 }
+// ext_base: the base block as encode_extended writes it (encode_base_into, observation/encode.rs:94-111, observation_3p/encode.rs:106-122):
+// its "tiles left" does not count a meld's called tile twice (it is in the discards already); Observation.encode() itself
+// (observation/python.rs:568-587) counts every meld tile.  The two differ in channel 30 only.
 template <bool SANMA, class SINK>
-__device__ inline void encode_seat_to(const GState& S, int pid, int lane, uint32_t* hist, SINK& o, bool first) {
+__device__ inline void encode_seat_to(const GState& S, int pid, int lane, uint32_t* hist, SINK& o, bool first, bool ext_base = false) {
     constexpr int ENC_W = SANMA ? ENC_W3 : ENC_W4;
     constexpr int NPP = SANMA ? 3 : 4;
     auto enc_bcast = [&](float*, int ch, float v, int) { o.bcast(ch, v); };
@@ -224,7 +227,8 @@ __device__ inline void encode_seat_to(const GState& S, int pid, int lane, uint32
     for (int q = 0; q < NPP; q++) {
         const PState& Q = S.p[q];
         tiles_used += Q.n_discards;
-        for (int m = 0; m < Q.n_melds; m++) tiles_used += (Q.meld_type[m] >= RMJ_MELD_DAIMINKAN) ? 4 : 3;
+        for (int m = 0; m < Q.n_melds; m++)
+            tiles_used += ((Q.meld_type[m] >= RMJ_MELD_DAIMINKAN) ? 4 : 3) - ((ext_base && Q.meld_called[m] != 0xFF) ? 1 : 0);
         rank += (Q.score > my_score);
     }
     int tiles_left = (SANMA ? 108 : 136) - tiles_used;

@@ -40,6 +40,9 @@ __device__ __forceinline__ uint32_t r4_rows(uint32_t flags) {
     const uint32_t c = (flags >> STEP_F_ROWS_SHIFT) & 3u;
     return c == 0u ? 4u : c;
 }
+#ifndef RMJ_INLINE_STEP
+#define RMJ_INLINE_STEP 1     /* the step of the fused rollouts inlined into the rollout loop (see step4_call_inl); 0: out of line, as in rounds 2-4 */
+#endif
 #ifndef RMJ_ROW_SETTLE
 #define RMJ_ROW_SETTLE 1      /* Tsumo / Ron settlements of the rich tier stay in tier 0 too (r4_round_end); 0: they bail to the full path */
 #endif
@@ -1923,7 +1926,11 @@ __device__ __forceinline__ uint32_t step4_body(const Env* Ep, Quad4Shared& sh, u
 #ifdef RMJ_TL4
     uint64_t tl_prev = __builtin_readcyclecounter();
 #endif
-    const int lane = threadIdx.x & 63;
+    int lane_ = threadIdx.x & 63;
+#if RMJ_INLINE_STEP
+    if constexpr (INLR) asm volatile("" : "+v"(lane_));   // nothing derived from the lane id is hoisted out of the rollout loop and kept live across the step (step4_call_inl)
+#endif
+    const int lane = lane_;
     const int row = lane >> 4, r = lane & 15, rb = lane & 48;
     const uint32_t rows_pw = r4_rows(flags);
     const uint32_t g0 = g_base + (quad == 0xFFFFFFFFu ? blockIdx.x : quad) * rows_pw;   // (k_step4_queue names the quad, the others own quad = block)
@@ -2706,10 +2713,24 @@ __device__ __forceinline__ void step4_finish_rounds(const Env* Ep, uint32_t flag
 #ifndef RMJ_INLINE_RESP
 #define RMJ_INLINE_RESP 3   /* bit 0: the RandomAgent's rollouts, bit 1: the greedy policy's */
 #endif
+// Round 5: the step of the fused RandomAgent / greedy rollouts is INLINED into the rollout loop.  Out of line it paid, per call, 33
+// callee-saved SGPRs through v_writelane / v_readlane (64 vector instructions of ~1 445) and 13 callee-saved VGPRs through scratch; the
+// inlined loop of round 4 spilled far worse (45 VGPR + 66 SGPR) because everything derived from the LANE ID - row, rb, LDS addresses of the
+// row's record - is loop invariant too and was hoisted and kept live across the step.  With the lane id laundered per iteration as well
+// (step4_body) the loop spills 17 VGPR / 52 SGPR in the ticket kernel, mostly outside the hot sections: +5 % at every batch size
+// (profiles/r05_inline_step_ab.txt).  RMJ_INLINE_STEP=0 brings the out-of-line step back (A/B).
+#if RMJ_INLINE_STEP
+#define R4_CALL_ATTR __forceinline__
+#else
+#define R4_CALL_ATTR __noinline__
+#endif
 template <int POL>
-__device__ __noinline__ uint32_t step4_call_inl(const Env* Ep, uint64_t policy_seed, uint32_t flags, uint32_t g_base, uint32_t g_end, uint32_t load,
+__device__ R4_CALL_ATTR uint32_t step4_call_inl(const Env* Ep, uint64_t policy_seed, uint32_t flags, uint32_t g_base, uint32_t g_end, uint32_t load,
                                                 uint64_t gs_row, uint32_t quad, uint32_t left, uint32_t final_chunk) {
     Quad4Shared& sh = g_q4;
+#if RMJ_INLINE_STEP
+    asm volatile("" : "+v"(Ep), "+v"(policy_seed), "+v"(flags), "+v"(g_base), "+v"(g_end), "+v"(quad), "+v"(final_chunk));   // (the body reads them through readfirstlane)
+#endif
     return step4_body<true, POL, true>(uni_ptr(Ep), sh, uni(policy_seed), uni(flags), uni(g_base), uni(g_end), uni(load) != 0u, gs_row, nullptr, uni(quad),
                                        left, uni(final_chunk) != 0u);
 }

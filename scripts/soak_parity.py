@@ -21,10 +21,11 @@ seeds = int(sys.argv[3]) if len(sys.argv) > 3 else 2
 first = (int(sys.argv[4]) if len(sys.argv) > 4 else 0) + int(os.environ.get("RMJ_SOAK_OFFSET", "0"))   # (RMJ_SOAK_OFFSET: the same run plan on other seeds)
 GREEDY = os.environ.get("RMJ_SOAK_POLICY", "random") == "greedy"
 RATE = int(os.environ.get("RMJ_SOAK_CALL_RATE", "64"))
+EXTRA = int(os.environ.get("RMJ_SOAK_RULE_EXTRA", "0"))   # e.g. 256 = abi.RULE_REFERENCE_RNG on top of both rule sets
 total = 0
 t0 = time.time()
 for mode in range(6):
-    for rule, rname in ((abi.RULE_TENHOU, "tenhou"), (abi.RULE_MJSOUL, "mjsoul")):
+    for rule, rname in ((abi.RULE_TENHOU | EXTRA, "tenhou"), (abi.RULE_MJSOUL | EXTRA, "mjsoul")):
         for k in range(first, first + seeds):
             seed, pseed = 7000 + 131 * k + mode, 0xA5A5 + 977 * k
             env = vecenv.VecRiichiEnv(n, game_mode=mode, seed=seed, rule_bits=rule, event_ring=8192)

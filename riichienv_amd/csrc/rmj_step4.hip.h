@@ -1930,6 +1930,9 @@ __device__ __forceinline__ uint32_t step4_body(const Env* Ep, Quad4Shared& sh, u
 #if RMJ_INLINE_STEP
     if constexpr (INLR) asm volatile("" : "+v"(lane_));   // nothing derived from the lane id is hoisted out of the rollout loop and kept live across the step (step4_call_inl)
 #endif
+#if RMJ_INLINE_ENC
+    if constexpr (LOOP && !INLR && !PASS2) asm volatile("" : "+v"(lane_));
+#endif
     const int lane = lane_;
     const int row = lane >> 4, r = lane & 15, rb = lane & 48;
     const uint32_t rows_pw = r4_rows(flags);
@@ -2973,13 +2976,20 @@ __global__ __launch_bounds__(64, RMJ_STEP4_WAVES) void k_step4_fixup(const Env* 
 #ifndef RMJ_STEP4_ENC_WAVES
 #define RMJ_STEP4_ENC_WAVES 5
 #endif
+#ifndef RMJ_INLINE_ENC
+#define RMJ_INLINE_ENC 0     /* experiment: step + encode inlined into the rollout loops of k_step4_enc / k_step4_queue_enc (see step4_call_inl) */
+#endif
 template <bool LOOP, int POL>
-__device__ __noinline__ void step4_call_enc(const Env* Ep, uint64_t policy_seed, uint32_t flags, uint32_t g_base, uint32_t g_end, uint32_t load,
-                                            uint64_t gs_row, uint32_t quad, float* out, const uint64_t* actions = nullptr) {
+__device__ __forceinline__ void step4_enc_impl(const Env* Ep, uint64_t policy_seed, uint32_t flags, uint32_t g_base, uint32_t g_end, uint32_t load,
+                                               uint64_t gs_row, uint32_t quad, float* out, const uint64_t* actions = nullptr) {
     Quad4Shared& sh = g_q4;
     __shared__ float lut[ENC_LUT];
     constexpr int W = KSANMA ? ENC_W3 : ENC_W4;
-    const int lane = threadIdx.x & 63;
+    int lane_ = threadIdx.x & 63;
+#if RMJ_INLINE_ENC
+    if constexpr (LOOP) asm volatile("" : "+v"(lane_));
+#endif
+    const int lane = lane_;
     g_base = uni(g_base); g_end = uni(g_end); quad = uni(quad);
     out = uni_ptr(out);
     if (uni(load) != 0u) enc_lut_init(lut, lane);
@@ -3006,6 +3016,24 @@ __device__ __noinline__ void step4_call_enc(const Env* Ep, uint64_t policy_seed,
             wave_sync();
         }
     }
+}
+template <bool LOOP, int POL>
+__device__ __noinline__ void step4_call_enc_ool(const Env* Ep, uint64_t policy_seed, uint32_t flags, uint32_t g_base, uint32_t g_end, uint32_t load,
+                                                uint64_t gs_row, uint32_t quad, float* out, const uint64_t* actions = nullptr) {
+    step4_enc_impl<LOOP, POL>(Ep, policy_seed, flags, g_base, g_end, load, gs_row, quad, out, actions);
+}
+// what the rollout loops call: out of line (rounds 2-4), or - RMJ_INLINE_ENC - inlined with the loop-invariant inputs laundered per iteration
+template <bool LOOP, int POL>
+__device__ __forceinline__ void step4_call_enc(const Env* Ep, uint64_t policy_seed, uint32_t flags, uint32_t g_base, uint32_t g_end, uint32_t load,
+                                               uint64_t gs_row, uint32_t quad, float* out, const uint64_t* actions = nullptr) {
+#if RMJ_INLINE_ENC
+    if constexpr (LOOP) {
+        asm volatile("" : "+v"(Ep), "+v"(policy_seed), "+v"(g_base), "+v"(g_end), "+v"(quad), "+v"(out));
+        step4_enc_impl<LOOP, POL>(Ep, policy_seed, flags, g_base, g_end, load, gs_row, quad, out, actions);
+        return;
+    }
+#endif
+    step4_call_enc_ool<LOOP, POL>(Ep, policy_seed, flags, g_base, g_end, load, gs_row, quad, out, actions);
 }
 template <int POL>
 __global__ __launch_bounds__(64, RMJ_STEP4_ENC_WAVES) void k_step4_enc(const Env* __restrict__ Ep, uint64_t policy_seed, uint32_t flags, uint32_t g_base,

@@ -48,11 +48,12 @@ __device__ __forceinline__ ShantenTables sh_tables_of(CEnv& E) {
 // responses advance a row 1.15 steps per call, the rows of a quad end within a call or two of each other), so that the tickets handed
 // out last are one or two calls long and the launch does not end with a few waves on long tickets; behind that point 1, 2, 4, ... for
 // the few quads that are not through yet, until the lengths cover n_steps calls (a call advances every unfinished row by at least one
-// step).  `tail` = 0: equal tickets of `cap` calls.  Returns the number of tickets per quad; len[c] for c < 64.
-__host__ __device__ inline uint32_t q_ticket_plan(uint32_t n_steps, uint32_t cap, uint32_t tail, uint16_t* len /*[64] or nullptr*/) {
+// step).  `tail` = 0: equal tickets of `cap` calls.  Returns the number of tickets per quad; *len_out = the length of ticket `want`.
+__host__ __device__ inline uint32_t q_ticket_plan(uint32_t n_steps, uint32_t cap, uint32_t tail, uint32_t want = 0xFFFFFFFFu, uint32_t* len_out = nullptr) {
     uint32_t n = 0, covered = 0;
     if (!tail) {
-        while (covered < n_steps && n < 64u) { if (len) len[n] = (uint16_t)(cap > 65535u ? 65535u : cap); covered += cap; n++; }
+        while (covered < n_steps && n < 64u) { covered += cap; n++; }
+        if (len_out) *len_out = cap;
         return n ? n : 1u;
     }
     uint32_t rem = (n_steps * 89u + 99u) / 100u, grow = 1u;
@@ -67,11 +68,16 @@ __host__ __device__ inline uint32_t q_ticket_plan(uint32_t n_steps, uint32_t cap
             s = grow > cap ? cap : grow;
             grow *= 2u;
         }
-        if (len) len[n] = (uint16_t)(s > 65535u ? 65535u : s);   // (the host keeps cap >= n_steps / 40: 64 tickets cover any rollout; the quad's last ticket runs unbounded anyway)
+        if (n == want && len_out) *len_out = s;   // (the host keeps cap >= n_steps / 40: 64 tickets cover any rollout; the quad's last ticket runs unbounded anyway)
         covered += s;
         n++;
     }
     return n ? n : 1u;
+}
+__host__ __device__ inline uint32_t q_ticket_len(uint32_t n_steps, uint32_t cap, uint32_t c) {   // length of ticket c of the descending plan (scalar loop, <= 64 rounds)
+    uint32_t len = cap;
+    (void)q_ticket_plan(n_steps, cap, 1u, c, &len);
+    return len;
 }
 
 // heavy-first launch order of the per-step kernel (k_step4<false>, rmj_step4.hip.h)

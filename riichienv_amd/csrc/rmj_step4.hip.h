@@ -2895,11 +2895,8 @@ __global__ __launch_bounds__(64, RMJ_STEP4_WAVES) void k_step4_queue(const Env* 
     if ((skip_xcds >> xcd) & 1u) return;   // test hook (RMJ_QUEUE_TEST_SKIP_XCDS): pretend these XCDs received no block -> k_step4_fixup
     const uint32_t n_quads = (n_games + 3u) / 4u;
     const uint32_t mine = n_quads > xcd ? (n_quads - xcd + 7u) / 8u : 0u;             // quads xcd, xcd + 8, ...
-    __shared__ uint16_t plan[64];
     const uint32_t lane = threadIdx.x & 63u;
-    if (lane == 0u) (void)q_ticket_plan(n_steps, chunk, tail, plan);
-    wave_sync();
-    const uint32_t n_chunks = q_ticket_plan(n_steps, chunk, tail, nullptr);
+    const uint32_t n_chunks = q_ticket_plan(n_steps, chunk, tail);   // (no table in LDS: the wave's 6 336 bytes are spoken for, see Quad4Shared)
     if (mine == 0u) return;
 #ifdef RMJ_QTL   /* ticket timeline build (scripts/timeline_queue.py, never the shipped library): per wave and ticket [ticket | xcd << 32, taken, begun, ended] on the 100 MHz clock */
     uint32_t qtl_n = 0u;
@@ -2926,7 +2923,7 @@ __global__ __launch_bounds__(64, RMJ_STEP4_WAVES) void k_step4_queue(const Env* 
         uint32_t taken = 0u;
         if (c > 0u && g < n_games) taken = __hip_atomic_load(prog + g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         // (the quad's last possible ticket runs until every row is through, whatever a call achieved)
-        const uint32_t left = step4_run<POL>(Ep, policy_seed, flags, 0u, n_games, gs_row, quad, n_steps - taken, true, g, c + 1u == n_chunks ? 0xFFFFFFFFu : (uint32_t)plan[c]);
+        const uint32_t left = step4_run<POL>(Ep, policy_seed, flags, 0u, n_games, gs_row, quad, n_steps - taken, true, g, c + 1u == n_chunks ? 0xFFFFFFFFu : (tail ? q_ticket_len(n_steps, chunk, c) : chunk));
         if ((lane & 15u) == 0u && g < n_games) prog[g] = n_steps - left;
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this ticket's stores are in the XCD's L2
         wave_sync();

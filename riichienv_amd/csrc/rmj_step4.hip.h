@@ -2732,7 +2732,10 @@ __device__ R4_CALL_ATTR uint32_t step4_call_inl(const Env* Ep, uint64_t policy_s
                                                 uint64_t gs_row, uint32_t quad, uint32_t left, uint32_t final_chunk) {
     Quad4Shared& sh = g_q4;
 #if RMJ_INLINE_STEP
-    asm volatile("" : "+v"(Ep), "+v"(policy_seed), "+v"(flags), "+v"(g_base), "+v"(g_end), "+v"(quad), "+v"(final_chunk));   // (the body reads them through readfirstlane)
+    // laundered as SCALAR registers (a vector-register launder made the Env pointer live in - and spill from - VGPRs: a scratch reload at
+    // every event emission); readfirstlane first, so that the operands are scalar wherever this body is compiled
+    Ep = uni_ptr(Ep); policy_seed = uni(policy_seed); flags = uni(flags); g_base = uni(g_base); g_end = uni(g_end); quad = uni(quad); final_chunk = uni(final_chunk);
+    asm volatile("" : "+s"(Ep), "+s"(policy_seed), "+s"(flags), "+s"(g_base), "+s"(g_end), "+s"(quad), "+s"(final_chunk));
 #endif
     return step4_body<true, POL, true>(uni_ptr(Ep), sh, uni(policy_seed), uni(flags), uni(g_base), uni(g_end), uni(load) != 0u, gs_row, nullptr, uni(quad),
                                        left, uni(final_chunk) != 0u);
@@ -3046,6 +3049,10 @@ __global__ __launch_bounds__(64, RMJ_STEP4_ENC_WAVES) void k_step4_enc(const Env
 // stores under the tail of the step (the last third of a per-step launch belongs to the few waves that carry a full-path game).
 __global__ __launch_bounds__(64, RMJ_STEP4_ENC_WAVES) void k_step4_act_enc(const Env* __restrict__ Ep, uint32_t flags, uint32_t g_base, uint32_t g_end,
                                                                                const uint64_t* __restrict__ actions, float* __restrict__ out) {
+#ifdef RMJ_DEBUG_LDS_FILL   /* debugging aid: what does the kernel read of LDS it has not written? */
+    for (int i = threadIdx.x & 63; i < (int)(sizeof(Quad4Shared) / 4); i += 64) reinterpret_cast<uint32_t*>(&g_q4)[i] = RMJ_DEBUG_LDS_FILL;
+    wave_sync();
+#endif
     step4_call_enc<false, 0>(Ep, 0ull, flags, g_base, g_end, 1u, 0ull, 0xFFFFFFFFu, out, actions);
 }
 // the same as tickets (see k_step4_queue): a quad's chunks - its records, lists and tensor rows - stay on one XCD

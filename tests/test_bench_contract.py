@@ -33,6 +33,20 @@ def test_committed_bench_line_has_the_contract_fields():
     assert r["traffic"] is None or r["traffic"] > 0
     c = line["cpu_baseline"]
     assert c["kind"] == "port" and c["unit"] == "env.step/s" and c["cores"] >= 1 and c["value"] > 0 and "sample" in c
+    # round 5: the driver's own command (--steps 20 --warmup 5) carries every single-GPU configuration of BASELINE.json as a steady-state leg,
+    # the steady-state figure of the timed environment, a lossless log leg, and the proof of its ranks
+    assert line["steps"] == 20 and line["warmup"] == 5 and line["ranks_seen"] == [0] and len(line["per_rank_value"]) == 1
+    assert line["host_runtime"] == "none (C-ABI only)"
+    lr = line["long_rollout"]
+    assert lr["steady_state"] is True and lr["steps"] >= 300 and abs(lr["roofline"]["frac"] - lr["roofline"]["achieved"] / 8000.0) < 1e-9
+    names = [c["config"].split(" ")[0] for c in line["configs"]]
+    assert names == ["configs[1]", "configs[3]", "configs[4]"]
+    for c in line["configs"]:
+        assert c["steady_state"] is True and c["steps"] >= 300 and c["kernel_ms"] > 0 and 0 < c["frac"] < 1 and c["unit"] == "env.step/s"
+        assert abs(c["frac"] - c["roofline"]["achieved"] / c["roofline"]["peak"]) < 1e-9
+    assert "roofline_encode" in line["configs"][2] and "3p" in line["configs"][2]["workload"]
+    ld = line["log_drain"]
+    assert ld["lost_events"] == 0 and ld["events"] > 0 and ld["end_to_end_env_steps_per_s"] > 0 and ld["format_events_per_s"] > 0
 
 
 def test_gpus_flag_builds_the_n_rank_launch():

@@ -2791,8 +2791,11 @@ __device__ __forceinline__ uint32_t step4_run(const Env* Ep, uint64_t policy_see
 // listed units; the blocks behind them serve the others in place and leave at once where a front block has been.  Hints only: the two
 // arrays are written by one launch and read by the next, so every unit is served exactly once whatever happened in between.
 // (struct HeavyOrder: rmj_common.hip.h)
+#ifndef RMJ_DEBUG_STEP_WAVES
+#define RMJ_DEBUG_STEP_WAVES RMJ_STEP4_WAVES
+#endif
 template <bool LOOP, int POL>
-__global__ __launch_bounds__(64, RMJ_STEP4_WAVES) void k_step4(const Env* __restrict__ Ep, uint64_t policy_seed, uint32_t flags, uint32_t g_base,
+__global__ __launch_bounds__(64, RMJ_DEBUG_STEP_WAVES) void k_step4(const Env* __restrict__ Ep, uint64_t policy_seed, uint32_t flags, uint32_t g_base,
                                                                    uint32_t g_end, uint32_t n_steps, const uint64_t* __restrict__ actions, HeavyOrder ho) {
     if (LOOP) {
         const uint32_t row_ = (threadIdx.x & 63u) >> 4;
@@ -3053,7 +3056,11 @@ __global__ __launch_bounds__(64, RMJ_STEP4_ENC_WAVES) void k_step4_act_enc(const
     for (int i = threadIdx.x & 63; i < (int)(sizeof(Quad4Shared) / 4); i += 64) reinterpret_cast<uint32_t*>(&g_q4)[i] = RMJ_DEBUG_LDS_FILL;
     wave_sync();
 #endif
+#ifdef RMJ_DEBUG_ACT_ENC_INLINE
+    step4_enc_impl<false, 0>(Ep, 0ull, flags, g_base, g_end, 1u, 0ull, 0xFFFFFFFFu, out, actions);
+#else
     step4_call_enc<false, 0>(Ep, 0ull, flags, g_base, g_end, 1u, 0ull, 0xFFFFFFFFu, out, actions);
+#endif
 }
 // the same as tickets (see k_step4_queue): a quad's chunks - its records, lists and tensor rows - stay on one XCD
 template <int POL>

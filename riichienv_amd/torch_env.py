@@ -35,7 +35,7 @@ class TorchVecEnv:
     obs(), mask, status … describe the state AFTER the last step; step(action_ids) takes an int32 tensor [n, 4] on the
     same device (-1 for seats that do not act)."""
 
-    def __init__(self, n_games, game_mode=2, seed=0, device=0, extended=False, skip_mjai_logging=True, share_stream=True, pad_rows=False, **kw):
+    def __init__(self, n_games, game_mode=2, seed=0, device=0, extended=False, skip_mjai_logging=True, share_stream=True, pad_rows=True, **kw):
         """share_stream: issue the library's kernels on torch's current stream of `device` (rmj_set_stream): policy and
         environment are then ordered by the stream, without host synchronisation between them.  With False the library keeps
         its own stream and every call synchronises."""
@@ -63,8 +63,9 @@ class TorchVecEnv:
         self.mask = wrap(v.mask, (self.n, 4, abi.ACTION_SPACE_4P), "|u1")      # zero-copy, rewritten by every step
         self.legal = wrap(v.legal, (self.n, 4, abi.MAX_LEGAL), "<i8")          # packed actions (bit pattern of the u64)
         self.waits = wrap(v.waits, (self.n, 4), "<i8")
-        # pad_rows: every (game, seat) row of the 74-channel tensor padded to a multiple of 256 B (rmj_set_encode_row_stride): the
-        # acting seats' rows are written 1.3-1.4 x faster; obs() then returns a strided view [n, 4, 74, W] of the padded buffer
+        # pad_rows (the default since round 5): every (game, seat) row of the 74-channel tensor padded to a multiple of 256 B
+        # (rmj_set_encode_row_stride): the acting seats' rows are written 1.3-1.4 x faster (trainer loop 260 -> 274 M env.step/s); obs() then
+        # returns a strided view [n, 4, 74, W] of the padded buffer (same values, same indexing; .contiguous() copies).  pad_rows=False: dense
         self.pad_rows = bool(pad_rows) and not extended
         if self.pad_rows:
             self.row_stride = self.env.padded_row_stride()

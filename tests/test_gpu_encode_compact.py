@@ -128,8 +128,9 @@ def test_padded_row_stride_equals_dense_rows(mode):
     assert torch.equal(ca[:k], cb[:k, : 74 * w]) and bool((cb[:, 74 * w:] == -7.0).all())
     a.close(); b.close()
     # the torch wrapper: a strided view of the padded buffer, step_obs / obs / obs_compact
-    ta = TorchVecEnv(512, game_mode=mode, seed=3)
-    tb = TorchVecEnv(512, game_mode=mode, seed=3, pad_rows=True)
+    ta = TorchVecEnv(512, game_mode=mode, seed=3, pad_rows=False)
+    tb = TorchVecEnv(512, game_mode=mode, seed=3)                  # (padded rows are the default)
+    assert tb.pad_rows and not ta.pad_rows and ta.obs().is_contiguous() and not tb.obs().is_contiguous()
     assert tb.obs().shape == ta.obs().shape == (512, 4, 74, w)
     for k in range(60):
         ids = ta.sample_ids(seed=k).clone()

@@ -2584,7 +2584,14 @@ static int shanten_tables_for(int device, ShantenTables* out) {
         HIPCHK(hipMemcpy(dh, H.honor.data(), H.honor.size() * 8, hipMemcpyHostToDevice));
         HIPCHK(hipMemcpy(r9, H.rank9.data(), H.rank9.size() * 4, hipMemcpyHostToDevice));
         HIPCHK(hipMemcpy(r7, H.rank7.data(), H.rank7.size() * 4, hipMemcpyHostToDevice));
+        uint32_t* r2;
+        uint64_t* v6;
+        HIPCHK(hipMalloc(&r2, H.r2.size() * 4));
+        HIPCHK(hipMalloc(&v6, H.v6.size() * 8));
+        HIPCHK(hipMemcpy(r2, H.r2.data(), H.r2.size() * 4, hipMemcpyHostToDevice));
+        HIPCHK(hipMemcpy(v6, H.v6.data(), H.v6.size() * 8, hipMemcpyHostToDevice));
         cache[device].suit = ds; cache[device].honor = dh; cache[device].rank9 = r9; cache[device].rank7 = r7;
+        cache[device].r2 = r2; cache[device].v6 = v6;
         have[device] = true;
     }
     *out = cache[device];

@@ -39,7 +39,7 @@ struct Env {
 typedef const __attribute__((address_space(4))) Env CEnv;
 __device__ __forceinline__ ShantenTables sh_tables_of(CEnv& E) {
     ShantenTables T;
-    T.rank9 = E.sh.rank9; T.rank7 = E.sh.rank7; T.suit = E.sh.suit; T.honor = E.sh.honor;
+    T.rank9 = E.sh.rank9; T.rank7 = E.sh.rank7; T.suit = E.sh.suit; T.honor = E.sh.honor; T.r2 = E.sh.r2; T.v6 = E.sh.v6;
     return T;
 }
 

@@ -24,12 +24,23 @@ struct ShantenTables {             // device pointers
     const uint64_t* honor;         // [43130]
     const uint32_t* rank9;         // [9][15][5]
     const uint32_t* rank7;         // [7][15][5]
+    // Round 5, for the pair-dense ukeire walk (rmj_ukeire.hip.h): the same perfect hash as two dependent reads instead of nine,
+    // and the same cost vectors with 6-bit fields (sums of two costs do not carry into the next field)
+    const uint32_t* r2;            // [SH_R2_WORDS]: partial ranks keyed by the packed 3-bit fields themselves, see sh_gen_r2
+    const uint64_t* v6;            // [405350 + 43130]: low dword = pair 0 (k = 0..4, 6 bits each), high dword = pair 1; honors behind the suits
 };
+#define SH_R2_HI9 0u                       /* [32768] fields 0..4 of a suit word -> (partial rank | running sum << 20) */
+#define SH_R2_HI7 32768u                   /* [32768] the same for the honor word */
+#define SH_R2_LO9 65536u                   /* [15][4096] (running sum, fields 5..8) -> partial rank */
+#define SH_R2_LO7 (65536u + 15u * 4096u)   /* [15][64]   (running sum, fields 5..6) */
+#define SH_R2_WORDS (SH_R2_LO7 + 15u * 64u)
 
 // ---------------------------------------------------------------- host-side generator
 struct ShantenHostTables {
     std::vector<uint64_t> suit, honor;
     std::vector<uint32_t> rank9, rank7;
+    std::vector<uint32_t> r2;
+    std::vector<uint64_t> v6;
 };
 
 inline void sh_rank_table(int n, std::vector<uint32_t>& T) {
@@ -169,6 +180,49 @@ inline void sh_gen_honor(ShantenHostTables& H) {
     gen.go(0, 0);
 }
 
+// sh_rank's sum over the ranks [i0, i1) of a word, with its clamps, from running sum s0: (partial rank, running sum behind i1)
+inline void sh_rank_part(const std::vector<uint32_t>& T, uint32_t word, int i0, int i1, uint32_t s0, uint32_t& part, uint32_t& s_out) {
+    uint32_t h = 0, s = s0;
+    for (int i = i0; i < i1; i++) {
+        uint32_t c = (word >> (3 * (i - i0))) & 7u;
+        if (c > 4u) c = 4u;
+        if (s + c > 14u) c = 14u - s;
+        h += T[((size_t)i * 15 + s) * 5 + c];
+        s += c;
+    }
+    part = h;
+    s_out = s;
+}
+inline void sh_gen_r2(ShantenHostTables& H) {
+    H.r2.assign(SH_R2_WORDS, 0);
+    for (uint32_t w = 0; w < 32768u; w++) {
+        uint32_t part, s;
+        sh_rank_part(H.rank9, w, 0, 5, 0, part, s);
+        H.r2[SH_R2_HI9 + w] = part | (s << 20);
+        sh_rank_part(H.rank7, w, 0, 5, 0, part, s);
+        H.r2[SH_R2_HI7 + w] = part | (s << 20);
+    }
+    for (uint32_t s0 = 0; s0 < 15u; s0++) {
+        uint32_t part, s;
+        for (uint32_t w = 0; w < 4096u; w++) {
+            sh_rank_part(H.rank9, w, 5, 9, s0, part, s);
+            H.r2[SH_R2_LO9 + s0 * 4096u + w] = part;
+        }
+        for (uint32_t w = 0; w < 64u; w++) {
+            sh_rank_part(H.rank7, w, 5, 7, s0, part, s);
+            H.r2[SH_R2_LO7 + s0 * 64u + w] = part;
+        }
+    }
+    H.v6.assign(H.suit.size() + H.honor.size(), 0);
+    for (size_t i = 0; i < H.v6.size(); i++) {
+        const uint64_t v = i < H.suit.size() ? H.suit[i] : H.honor[i - H.suit.size()];
+        uint64_t o = 0;
+        for (int p = 0; p < 2; p++)
+            for (int k = 0; k < 5; k++) o |= ((v >> (4 * (p * 5 + k))) & 15ull) << (32 * p + 6 * k);
+        H.v6[i] = o;
+    }
+}
+
 inline const ShantenHostTables& shanten_host_tables() {
     static ShantenHostTables H;
     static bool done = false;
@@ -177,6 +231,7 @@ inline const ShantenHostTables& shanten_host_tables() {
         sh_rank_table(7, H.rank7);
         sh_gen_suit(H);
         sh_gen_honor(H);
+        sh_gen_r2(H);
         done = true;
     }
     return H;
@@ -389,6 +444,11 @@ __device__ __forceinline__ int sh_entry_pm(uint64_t a, uint64_t b, int m) {
 // Both quantities judge the same (discard d, draw t) pairs - "does t lower the shanten of the hand without d" - so one
 // pass serves both, and the shanten after each discard is evaluated for all d at once (lane = d): 2 + #held-types
 // per-lane table evaluations instead of 2 + 4 x #held-types for the two separate walks.
+#ifndef RMJ_UKEIRE_DENSE
+#define RMJ_UKEIRE_DENSE 1   // 1: the fast case runs the pair-dense walk of rmj_ukeire.hip.h (round 5); 0: the round-4 walk below (A/B)
+#endif
+__device__ inline void sh_ukeire_dense(const ShantenTables& T, const PH& h, uint32_t my_vis, bool sm, int lane, bool want_eff, bool want_uke,
+                                       uint32_t& eff, uint32_t& uke, int cur_in, int* nsh_out, int* cur_out);
 __device__ inline void sh_ukeire_both(const ShantenTables& T, const PH& h, uint32_t my_cnt, uint32_t my_vis, bool sm, int lane,
                                       bool want_eff, bool want_uke, uint32_t& eff, uint32_t& uke, int cur_in = -99, int* nsh_out = nullptr,
                                       int* cur_out = nullptr) {   // cur_out: the shanten of h itself (computed here unless the caller passed it as cur_in)
@@ -400,6 +460,10 @@ __device__ inline void sh_ukeire_both(const ShantenTables& T, const PH& h, uint3
     // (h - d + t then has two) and holds no 2m..8m; 1m / 9m then belong to the honor "suit" and a hand's honor word is that of its own
     // relocation.  Anything else takes the general walk below.
     const bool fast = !sm || (__popc(~(h.d | (h.d >> 1) | (h.d >> 2)) & O7_1) >= 3 && (h.a & ~(7u | (7u << 24))) == 0u);
+    if (RMJ_UKEIRE_DENSE && fast && total <= 14) {
+        sh_ukeire_dense(T, h, my_vis, sm, lane, want_eff, want_uke, eff, uke, cur_in, nsh_out, cur_out);
+        return;
+    }
     if (fast) {
         // every hand judged here is the hand h with one tile removed and / or one added, i.e. it differs from h in at most two suits
         const int q = t < 34 ? ((sm && (t == 0 || t == 8)) ? 3 : t_suit(t)) : 0;   // the suit whose vector the tile type changes
@@ -572,3 +636,5 @@ __device__ inline uint32_t sh_ukeire_wave(const ShantenTables& T, const PH& h, u
 }
 
 }  // namespace rmj
+
+#include "rmj_ukeire.hip.h"

@@ -335,6 +335,20 @@ def config_leg(vecenv, abi, shard, dev, name, games, mode, steps, policy_seed, d
            "steady_state": bool(preroll >= 300 and steps >= STEADY_MIN), "preroll_steps": preroll, "full_path_frac": full / max(made, 1),
            "roofline": rollout_roofline(r, games, steps, sanma, encode=encode, acting=acting)}
     out["kernel_ms"], out["frac"] = out["roofline"]["kernel_ms"], out["roofline"]["frac"]
+    if games <= 8192 and not encode:
+        # what a search / MCTS caller feels at this batch size: ONE step of all games as its own launch, host call to host-visible completion
+        for _ in range(20):
+            env.step_random(policy_seed, 1, auto_reset=True)
+        dev.sync()
+        reps = 300
+        ta = time.perf_counter()
+        for _ in range(reps):
+            env.step_random(policy_seed, 1, auto_reset=True)
+            env.sync()
+        tb = time.perf_counter()
+        out["single_step_latency_us"] = (tb - ta) * 1e6 / reps
+        out["single_step_latency_what"] = (f"rmj_step_random(n_steps=1) + rmj_sync, {games} games, mean of {reps} calls: launch, the step of every game "
+                                           "(observations, masks and lists published), completion seen by the host")
     if encode:
         b_obs = B_OBS_3P if sanma else B_OBS_4P
         enc_ms = env.bench_encode(obs, 50, extended=False, only_active=2)

@@ -57,6 +57,12 @@ __device__ __forceinline__ uint32_t r4_rows(uint32_t flags) {
 #define R4BAIL(q, id) do { (q).bail = true; if ((q).r == 0) atomicAdd(&rmj::g_bail_reason[id], 1u); } while (0)   /* bail census */
 #else
 #define R4M(id) do {} while (0)
+#ifndef RMJ_FULL_PRIO
+#define RMJ_FULL_PRIO 0
+#endif
+#ifndef RMJ_HEAVY_TENPAI
+#define RMJ_HEAVY_TENPAI 1   /* heavy-first order of the per-step kernel: games with a seat that waits without a riichi count as heavy (0: A/B) */
+#endif
 #ifdef RMJ_CENSUS   /* bail census on the shipped instruction stream (no accounting marks): scripts/bail_census.py; the reason travels in a register and is counted where the full path is entered */
 #define R4BAIL(q, id) do { (q).bail = true; (q).why = (id); } while (0)
 #elif defined(RMJ_TL4)
@@ -2668,7 +2674,13 @@ __device__ __forceinline__ uint32_t step4_body(const Env* Ep, Quad4Shared& sh, u
         wave_sync();
 #endif
         if (LOOP) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");   // the full path reads wall, lists and record with plain loads: drop what the L1 may hold of an earlier visit of this game to this CU (see the record fetch above)
+#if RMJ_FULL_PRIO
+        if (!LOOP || RMJ_FULL_PRIO > 1) __builtin_amdgcn_s_setprio(3);   // experiment: the few long waves of a per-step launch issue ahead of the others of their SIMD
+#endif
         ol_step_full(ctx_pack(c), lane < 4 ? m_full : RMJ_NO_ACTION, (uint32_t)__builtin_amdgcn_readlane((int)fl_full, 16 * br));
+#if RMJ_FULL_PRIO
+        if (!LOOP || RMJ_FULL_PRIO > 1) __builtin_amdgcn_s_setprio(0);
+#endif
         wave_sync();
 #ifdef RMJ_TL4
         if (!LOOP && lane < 16) rmj::g_tl4[(size_t)blockIdx.x * RMJ_TL4_ROW + 16 + lane] += (unsigned long long)sh.u.x.tl_acc[lane];
@@ -2821,14 +2833,23 @@ __global__ __launch_bounds__(64, RMJ_DEBUG_STEP_WAVES) void k_step4(const Env* _
         const uint32_t ret = step4_body<false, POL>(Ep, sh, policy_seed, flags, g_base, g_end, true, 0ull, actions, unit);
 #ifdef RMJ_TL4
         if ((threadIdx.x & 63) == 0) rmj::g_tl4[(size_t)blockIdx.x * RMJ_TL4_ROW + 15] = __ballot((ret & R4_RET_ROUND) != 0u) ? 1ull : 0ull;   // the wave ends rounds
+        if (__ballot((ret & R4_RET_ROUND) != 0u) && (threadIdx.x & 63) == 0)   // ... and why (bit R4_RE_* per row)
+            rmj::g_tl4[(size_t)blockIdx.x * RMJ_TL4_ROW + 14] = (1ull << g_q4.rmode[0]) | (1ull << g_q4.rmode[1]) | (1ull << g_q4.rmode[2]) | (1ull << g_q4.rmode[3]);
 #endif
         if (RMJ_ROW_ROUND_END && __ballot((ret & R4_RET_ROUND) != 0u)) step4_finish_rounds<false, POL>(Ep, flags, g_base, g_end, unit);
         if (ho.out_cnt) {   // the note for the next launch
             const int row = (threadIdx.x & 63) >> 4;
             const GState& S = sh.st[row];
             const uint32_t gq = g_base + unit * r4_rows(flags) + (uint32_t)row;
+            // Round 5: ... and a seat that waits without a riichi - a discard into its wait or its own winning draw makes the wave pause for
+            // the evaluator (R4_RE_YAKU_CLAIMS / _TSUMO: twice a plain wave's lifetime); served in place, 10-30 such waves per launch started
+            // at 40 us and ended it at 75-88 us instead of 70 (scripts/timeline4.py detail)
+            const PState& Pw = S.p[threadIdx.x & 3];
+            // (a seat whose cache is stale - it has just discarded from its hand or called - stays unpredicted: 2-6 waves per launch.  Its old
+            //  shanten bound is no predictor: "sh13 <= 1" holds for most hands - the list then takes an atomic from nearly every wave, 163 us per launch)
+            const bool waits_open = RMJ_HEAVY_TENPAI && (threadIdx.x & 15) < 4 && (Pw.flags & PF_WAITS_VALID) && Pw.waits13 != 0ull && !(Pw.flags & PF_RIICHI_DECLARED);
             const bool hv = (uint32_t)row < r4_rows(flags) && gq < g_end &&
-                            (S.is_done ? (flags & STEP_F_AUTORESET) != 0u : ((S.phase == RMJ_WAIT_ACT && S.drawable_count == 0) || S.ron_offer_mask != 0));
+                            (S.is_done ? (flags & STEP_F_AUTORESET) != 0u : ((S.phase == RMJ_WAIT_ACT && S.drawable_count == 0) || S.ron_offer_mask != 0 || waits_open));
             const bool any = __ballot(hv) != 0ull;
             if ((threadIdx.x & 63) == 0) {
                 uint32_t idx = 0xFFFFFFFFu;

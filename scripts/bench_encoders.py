@@ -43,5 +43,16 @@ for mode in (2, 5):
         "kernel_ms": ms, "acting_seats": acting, "bytes_per_launch": b, "achieved_GBps": b / (ms * 1e-3) / 1e9,
         "frac_of_8TBps": b / (ms * 1e-3) / 8e12, "note": "k_obs_offsets + k_encode_base per repetition"}
     del buf
+    # ... and with rows padded to a multiple of 256 B (TorchVecEnv's default layout since round 5): the same 74 x W floats per row
+    rs = env.padded_row_stride()
+    env.set_encode_row_stride(rs)
+    buf = torch.zeros((cap, rs), dtype=torch.float32, device="cuda:0")
+    ms = env.bench_encode_compact(buf.data_ptr(), index.data_ptr(), cap, count.data_ptr(), 40)
+    assert int(count.item()) == acting
+    out[f"k_encode_compact_padded_{'3p' if mode >= 3 else '4p'}"] = {
+        "kernel_ms": ms, "acting_seats": acting, "bytes_per_launch": b, "row_stride_bytes": rs * 4, "achieved_GBps": b / (ms * 1e-3) / 1e9,
+        "frac_of_8TBps": b / (ms * 1e-3) / 8e12, "note": "k_obs_offsets + k_encode_base per repetition; algorithmic bytes (74 x W x 4 per seat), the padding is not written"}
+    env.set_encode_row_stride(0)
+    del buf
     env.close()
 print(json.dumps(out))

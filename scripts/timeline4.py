@@ -72,6 +72,20 @@ def main():
         acc["bail_waves"] += int(b.sum())
         acc["multi_bail_waves"] += int((buf[:, 7] > 1).sum())
         acc["bail_rows"] += int(buf[:, 7].sum())
+        if len(sys.argv) > 3 and sys.argv[3] == "detail" and _ < 6:   # the waves that end last: when they started, what they were
+            order = np.argsort(t1)[::-1][:8]
+            heavy_front = waves - (games + 3) // 4
+            ids = np.nonzero(ran)[0]
+            print("launch %d: kernel span %.1f us" % (_, (t1.max() - z) / 100.0), file=sys.stderr)
+            for w in order:
+                print("   block %5d (%s) start %5.1f end %5.1f life %5.1f  round_end %d (reasons %s) bail %d  sections(core cycles) %s" % (
+                    ids[w], "front" if ids[w] < heavy_front else "in place", (t0[w] - z) / 100.0, (t1[w] - z) / 100.0, life[w], int(buf[w, 15]), [k for k in range(1, 8) if (int(buf[w, 14]) >> k) & 1], int(buf[w, 7]),
+                    [int(x) for x in buf[w, :7]]), file=sys.stderr)
+            late = re_ & ((t0 - z) / 100.0 > 25.0)
+            for k in range(1, 8):
+                hit = re_ & (((buf[:, 14].astype(np.int64) >> k) & 1) > 0)
+                print("   reason %d: %d waves, %d of them in place, %d started after 25 us" % (k, int(hit.sum()), int((hit & (ids >= heavy_front)).sum()), int((hit & late).sum())), file=sys.stderr)
+            print("   round-end waves %d, of them started after 25 us: %d (in place: %d)" % (int(re_.sum()), int(late.sum()), int((late & (ids >= heavy_front)).sum())), file=sys.stderr)
         edges = np.linspace(z, t1.max(), 13)
         for k in range(12):
             mid = 0.5 * (edges[k] + edges[k + 1])

@@ -45,6 +45,7 @@ def test_committed_bench_line_has_the_contract_fields():
         assert c["steady_state"] is True and c["steps"] >= 300 and c["kernel_ms"] > 0 and 0 < c["frac"] < 1 and c["unit"] == "env.step/s"
         assert abs(c["frac"] - c["roofline"]["achieved"] / c["roofline"]["peak"]) < 1e-9
     assert "roofline_encode" in line["configs"][2] and "3p" in line["configs"][2]["workload"]
+    assert 0 < line["configs"][0]["single_step_latency_us"] < 1e4   # the small batch: what one step as its own launch costs a caller
     ld = line["log_drain"]
     assert ld["lost_events"] == 0 and ld["events"] > 0 and ld["end_to_end_env_steps_per_s"] > 0 and ld["format_events_per_s"] > 0
 

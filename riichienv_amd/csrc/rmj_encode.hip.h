@@ -98,6 +98,9 @@ struct EncFloatSink {
 // broadcast over channel 26 + k (k < 37), 40 + c -> c / 4 (channel 63, c <= 203 even in a poked state).  2.5 KB instead of
 // 10 KB per observation, and the way out stays a plain stream of 16-byte stores (enc_emit_bytes).
 #define ENC_LUT 256
+#ifndef RMJ_ENC_EMIT_UNROLL
+#define RMJ_ENC_EMIT_UNROLL 1
+#endif
 template <int W>
 struct EncByteSink {
     uint8_t* cells;   // cell e of the tensor at cells[e]; cells + head is 4-byte aligned (head: see enc_emit_bytes)
@@ -139,17 +142,35 @@ __device__ __forceinline__ void enc_emit_bytes(float* dst, const uint8_t* cells,
     if (lane < head) dst[lane] = lut[cells[lane]];
     float4* d4 = reinterpret_cast<float4*>(dst + head);
     const uint32_t* c4 = reinterpret_cast<const uint32_t*>(cells + head);
-    for (int i = lane; i < body; i += 64) {
-        const uint32_t w = c4[i];
+    typedef float enc_v4f __attribute__((ext_vector_type(4)));
+    auto st16 = [&](int i, const enc_v4f& v4) {
         // streaming (non-temporal) 16-byte stores: the tensor is written once and read by another kernel much later
-        typedef float enc_v4f __attribute__((ext_vector_type(4)));
-        const enc_v4f v4 = {lut[w & 255u], lut[(w >> 8) & 255u], lut[(w >> 16) & 255u], lut[w >> 24]};
-#ifdef RMJ_ENC_NO_NT
+#if defined(RMJ_ENC_NOSTORE)   /* experiment: the encoder's work without its stores */
+        asm volatile("" :: "v"(v4), "v"(&d4[i]));
+#elif defined(RMJ_ENC_NO_NT)
         *reinterpret_cast<enc_v4f*>(&d4[i]) = v4;
 #else
         __builtin_nontemporal_store(v4, reinterpret_cast<enc_v4f*>(&d4[i]));
 #endif
+    };
+    auto dec = [&](uint32_t w) -> enc_v4f { return enc_v4f{lut[w & 255u], lut[(w >> 8) & 255u], lut[(w >> 16) & 255u], lut[w >> 24]}; };
+    int i = lane;
+#if RMJ_ENC_EMIT_UNROLL > 1
+    // RMJ_ENC_EMIT_UNROLL stores per trip: the code words of all of them are read first, then their table entries, then the stores
+    // leave back to back (one store per trip waits for two dependent LDS round trips in front of every store)
+    constexpr int U = RMJ_ENC_EMIT_UNROLL;
+    for (; i + 64 * (U - 1) < body; i += 64 * U) {
+        uint32_t w[U];
+#pragma unroll
+        for (int u = 0; u < U; u++) w[u] = c4[i + 64 * u];
+        enc_v4f v[U];
+#pragma unroll
+        for (int u = 0; u < U; u++) v[u] = dec(w[u]);
+#pragma unroll
+        for (int u = 0; u < U; u++) st16(i + 64 * u, v[u]);
     }
+#endif
+    for (; i < body; i += 64) st16(i, dec(c4[i]));
     if (lane < N - tail0) dst[tail0 + lane] = lut[cells[tail0 + lane]];
 }
 // ext_base: the base block as encode_extended writes it (encode_base_into, observation/encode.rs:94-111, observation_3p/encode.rs:106-122):

@@ -3077,6 +3077,10 @@ __global__ __launch_bounds__(64, RMJ_STEP4_ENC_WAVES) void k_step4_act_enc(const
     for (int i = threadIdx.x & 63; i < (int)(sizeof(Quad4Shared) / 4); i += 64) reinterpret_cast<uint32_t*>(&g_q4)[i] = RMJ_DEBUG_LDS_FILL;
     wave_sync();
 #endif
+#ifdef RMJ_ACT_ENC_STAGGER   /* experiment: every other wave starts late - do the waves of a generation run their step and store phases in lock-step? */
+    if (blockIdx.x & 1u)
+        for (int k = 0; k < RMJ_ACT_ENC_STAGGER; k++) __builtin_amdgcn_s_sleep(127);
+#endif
 #ifdef RMJ_DEBUG_ACT_ENC_INLINE
     step4_enc_impl<false, 0>(Ep, 0ull, flags, g_base, g_end, 1u, 0ull, 0xFFFFFFFFu, out, actions);
 #else

@@ -987,7 +987,7 @@ struct rmj_env {
     hipEvent_t ev_time[2] = {nullptr, nullptr};   // rmj_time_rollout* / rmj_bench_rollout: created on first use, so that a timed region holds no event create / destroy
     uint32_t* d_qheads = nullptr;   // [8][RMJ_Q_STRIDE] ticket counters, one line per XCD
     int q_cur = 0;                  // which of the two counter sets of the ticket rollout is zeroed and next in turn
-    uint32_t q_slots = 0;           // waves of k_step4_queue the device holds at once (the smaller of the two policy instantiations)
+    uint32_t q_slots_pol[2] = {0, 0};   // waves of k_step4_queue<policy> the device holds at once (the greedy instantiation is compiled for fewer)
     int queue_force = 0;            // RMJ_QUEUE_FORCE at create (tests): tickets for every batch of >= 64 quads
     uint32_t queue_skip_xcds = 0;   // test hook: XCDs whose waves leave the queue kernel at once (RMJ_QUEUE_TEST_SKIP_XCDS at create)
     void* d_heavy = nullptr;        // heavy-first launch order of whole-batch per-step launches (HeavyOrder): two counters, lists, flag arrays
@@ -1509,25 +1509,24 @@ static uint32_t rollout_chunk(const rmj_env* h, uint32_t n_steps) {
     if (cap < (n_steps + 39u) / 40u) cap = (n_steps + 39u) / 40u;   // at most 64 tickets per quad (q_ticket_plan)
     return fine < cap ? fine : cap;
 }
-static bool rollout_queued(rmj_env* h, uint32_t n_steps) {
+static bool rollout_queued(rmj_env* h, uint32_t n_steps, int pol) {
     const uint32_t quads = (h->cfg.n_games + 3u) / 4u;
     if (!(h->quad >= 2 && n_steps >= 2 && h->want_streams >= 2) || h->queue_chunk <= 0 || n_steps < 2u * rollout_chunk(h, n_steps)) return false;
     if (h->max_xcc_id > 7u) return false;   // more XCC ids than queues: no single L2 per queue (see rmj_create)
-    if (h->q_slots == 0) {
+    pol = pol == 1 ? 1 : 0;
+    if (h->q_slots_pol[pol] == 0) {
         int per_cu = 0, cus = 0;
         const bool sanma = h->cfg.game_mode >= 3;
-        int per_cu1 = 0;
-        if ((sanma ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, rmj3::k_step4_queue<0>, 64, 0)
-                   : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, rmj4::k_step4_queue<0>, 64, 0)) != hipSuccess ||
-            (sanma ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu1, rmj3::k_step4_queue<1>, 64, 0)
-                   : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu1, rmj4::k_step4_queue<1>, 64, 0)) != hipSuccess ||
-            hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, h->cfg.device) != hipSuccess)
-            return false;
-        if (per_cu1 > 0 && per_cu1 < per_cu) per_cu = per_cu1;
-        h->q_slots = (uint32_t)(per_cu > 0 ? per_cu : 1) * (uint32_t)(cus > 0 ? cus : 1);
+        const hipError_t e = pol == 1 ? (sanma ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, rmj3::k_step4_queue<1>, 64, 0)
+                                               : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, rmj4::k_step4_queue<1>, 64, 0))
+                                      : (sanma ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, rmj3::k_step4_queue<0>, 64, 0)
+                                               : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, rmj4::k_step4_queue<0>, 64, 0));
+        if (e != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, h->cfg.device) != hipSuccess) return false;
+        h->q_slots_pol[pol] = (uint32_t)(per_cu > 0 ? per_cu : 1) * (uint32_t)(cus > 0 ? cus : 1);
     }
+    const uint32_t slots = h->q_slots_pol[pol];
     if (h->queue_force) return quads >= 64u;   // RMJ_QUEUE_FORCE=1 (tests): any batch with a quad per XCD queue to spare
-    return quads > h->q_slots && quads < 8u * h->q_slots;
+    return quads > slots && quads < 8u * slots;
 }
 // device-policy rollout: pol 0 = RandomAgent (rmj_step_random), 1 = the greedy policy (rmj_step_greedy)
 #define RMJ_LAUNCH_POL(NS, KERNEL, POL, ...)                                              \
@@ -1553,7 +1552,7 @@ static int step_policy_impl(rmj_handle h, uint64_t policy_seed, uint32_t n_steps
     if (h->quad >= 2 && n_steps >= 2 && h->want_streams >= 2) {   // (rmj_set_rollout_streams(h, 1): one launch per step, one stream)
         // four games per wave, the whole rollout in ONE launch: every wave steps its own games n_steps times (k_step4<true>)
         const dim3 grid((n + 3u) / 4u);
-        if (rollout_queued(h, n_steps)) {
+        if (rollout_queued(h, n_steps, pol)) {
             // ... or, for a long rollout of a batch that does not fill the chip a whole number of times, in (quad, chunk) tickets
             // ticket counters (one line per XCD) + the quads' ticket counts, in THREE sets: two for this rollout, used in turn - the launch
             // that works on one zeroes the other for its successor, so no memset sits between rollouts - and one for the step + encode
@@ -1569,7 +1568,7 @@ static int step_policy_impl(rmj_handle h, uint64_t policy_seed, uint32_t n_steps
             uint32_t* const next = h->d_qheads + (size_t)(1 - h->q_cur) * set_words;
             uint32_t* const d_qprog = h->d_qheads + 3 * set_words;   // (written before it is read)
             h->q_cur = 1 - h->q_cur;
-            const dim3 gq(grid.x < h->q_slots ? grid.x : h->q_slots);
+            const dim3 gq(grid.x < h->q_slots_pol[pol == 1 ? 1 : 0] ? grid.x : h->q_slots_pol[pol == 1 ? 1 : 0]);
             const dim3 gfix((grid.x + 63u) / 64u);
             const uint32_t chunk = rollout_chunk(h, n_steps);
             if (sanma) {
@@ -2690,7 +2689,7 @@ static int bench_rollout_impl(rmj_handle h, uint64_t policy_seed, uint32_t warmu
     out->env_steps = after - before;
     out->launches_in_flight = fl;
     out->full_path_steps = full1 - full0;
-    out->queued = rollout_queued(h, steps) ? 1u : 0u;
+    out->queued = rollout_queued(h, steps, pol) ? 1u : 0u;
     out->reserved = 0u;
     return RMJ_OK;
 }

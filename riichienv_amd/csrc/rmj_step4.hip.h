@@ -2790,6 +2790,12 @@ __device__ __forceinline__ uint32_t step4_run(const Env* Ep, uint64_t policy_see
 #ifndef RMJ_STEP4_WAVES
 #define RMJ_STEP4_WAVES 6
 #endif
+// The greedy policy's fused rollouts at five waves per SIMD (96 VGPR): 49 instead of 59 vector registers spilled in the ticket kernel, +4.5 % (931-941 ->
+// 977-979 M env.step/s); the RandomAgent's rollouts lose 10 % at five (1 890 -> 1 700 M) and stay at six.
+#ifndef RMJ_STEP4_WAVES_GREEDY
+#define RMJ_STEP4_WAVES_GREEDY 5
+#endif
+#define RMJ_STEP4_WAVES_OF(POL) ((POL) == 1 ? RMJ_STEP4_WAVES_GREEDY : RMJ_STEP4_WAVES)
 // LOOP = false: one step per launch.  LOOP = true: games are independent, so a device-policy rollout needs no
 // synchronisation between the steps of DIFFERENT games: the wave keeps its four records in LDS and steps its own games
 // n_steps times (publishing every step's outputs exactly like n_steps launches would).  A launch per step ends with the
@@ -2807,7 +2813,7 @@ __device__ __forceinline__ uint32_t step4_run(const Env* Ep, uint64_t policy_see
 #define RMJ_DEBUG_STEP_WAVES RMJ_STEP4_WAVES
 #endif
 template <bool LOOP, int POL>
-__global__ __launch_bounds__(64, RMJ_DEBUG_STEP_WAVES) void k_step4(const Env* __restrict__ Ep, uint64_t policy_seed, uint32_t flags, uint32_t g_base,
+__global__ __launch_bounds__(64, (LOOP && POL == 1) ? RMJ_STEP4_WAVES_GREEDY : RMJ_DEBUG_STEP_WAVES) void k_step4(const Env* __restrict__ Ep, uint64_t policy_seed, uint32_t flags, uint32_t g_base,
                                                                    uint32_t g_end, uint32_t n_steps, const uint64_t* __restrict__ actions, HeavyOrder ho) {
     if (LOOP) {
         const uint32_t row_ = (threadIdx.x & 63u) >> 4;
@@ -2910,7 +2916,7 @@ __device__ __noinline__ uint32_t q_wait_for(const uint32_t* slot, uint32_t want)
 //  1 617 / 1 504 M env.step/s against 1 642 / 1 529 M in 4P / 3P; the seventh wave was worth its 10 % mostly because it shortened the tail.
 //  Launch bounds for 4 / 5 / 8 waves: 1 532 / 1 279, 1 530 / 1 454, 1 426 / 1 382 - 6 is the optimum)
 template <int POL>
-__global__ __launch_bounds__(64, RMJ_STEP4_WAVES) void k_step4_queue(const Env* __restrict__ Ep, uint64_t policy_seed, uint32_t flags, uint32_t n_games,
+__global__ __launch_bounds__(64, RMJ_STEP4_WAVES_OF(POL)) void k_step4_queue(const Env* __restrict__ Ep, uint64_t policy_seed, uint32_t flags, uint32_t n_games,
                                                                          uint32_t n_steps, uint32_t chunk, uint32_t* __restrict__ heads, uint32_t* __restrict__ done,
                                                                          uint32_t skip_xcds, uint32_t* __restrict__ prog, uint32_t tail, uint32_t* __restrict__ zero_next,
                                                                          uint32_t zero_words) {
@@ -2974,7 +2980,7 @@ __global__ __launch_bounds__(64, RMJ_STEP4_WAVES) void k_step4_queue(const Env* 
 // k_step4<true> (nothing of it has run yet, so no other cache holds newer data).  One wave looks at 64 quads (a launch of one
 // block per quad cost the 20-step window as much as 1 % of its time to find nothing).
 template <int POL>
-__global__ __launch_bounds__(64, RMJ_STEP4_WAVES) void k_step4_fixup(const Env* __restrict__ Ep, uint64_t policy_seed, uint32_t flags, uint32_t n_games,
+__global__ __launch_bounds__(64, RMJ_STEP4_WAVES_OF(POL)) void k_step4_fixup(const Env* __restrict__ Ep, uint64_t policy_seed, uint32_t flags, uint32_t n_games,
                                                                          uint32_t n_steps, const uint32_t* __restrict__ done) {
     const uint32_t n_quads = (n_games + 3u) / 4u, lane = threadIdx.x & 63u, mine = blockIdx.x * 64u + lane;
     uint64_t todo = __ballot(mine < n_quads && __hip_atomic_load(done + (mine < n_quads ? mine : 0u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u);

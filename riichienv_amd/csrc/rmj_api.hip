@@ -909,9 +909,10 @@ __global__ __launch_bounds__(256) void k_shanten(ShantenTables T, const uint8_t*
     }
     out[i] = (int8_t)sh_shanten(h, total / 3, sanma != 0, T);
 }
-// (82 VGPRs = five waves per SIMD left alone; compiled for six: +5 %, eight: the same)
+// (round 4's walk: 82 VGPRs = five waves per SIMD left alone; compiled for six: +5 %, eight: the same.  Round 5's pair-dense walk, 74 VGPRs left alone:
+//  five waves 0.388, six 0.412, seven 0.425, eight 0.430 G hands/s of best ukeire on random hands)
 #ifndef RMJ_UKE_WAVES
-#define RMJ_UKE_WAVES 6
+#define RMJ_UKE_WAVES 8
 #endif
 #define RMJ_UKE_OCC __attribute__((amdgpu_waves_per_eu(RMJ_UKE_WAVES, RMJ_UKE_WAVES)))
 __global__ __launch_bounds__(256) RMJ_UKE_OCC void k_ukeire(ShantenTables T, const uint8_t* counts, const uint8_t* visible, uint32_t n, int sanma,

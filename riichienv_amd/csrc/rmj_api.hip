@@ -695,7 +695,7 @@ __device__ __forceinline__ void enc_emit_fn(float* dst, int n_floats, int lane, 
 // block instead of 12 KB: the kernel waits on table lookups (the ukeire walk), and its duration is inversely proportional to
 // the resident waves (measured by capping them: 13 / 8 / 5 / 3 blocks per CU -> 1.05 / 1.63 / 2.24 / 3.67 ms).
 #ifndef RMJ_ENCX_WAVES
-#define RMJ_ENCX_WAVES 0
+#define RMJ_ENCX_WAVES 6   /* 3P (85 VGPR left alone = five waves): six waves 691 -> 661 us, seven 667, eight 755; 4P (63 VGPR) the same at any */
 #endif
 #if RMJ_ENCX_WAVES > 0
 #define RMJ_ENCX_OCC __attribute__((amdgpu_waves_per_eu(RMJ_ENCX_WAVES, RMJ_ENCX_WAVES)))

@@ -87,6 +87,7 @@ struct EncFloatSink {
         const int k = slot(ch);
         if (k >= 0 && lane < W) buf[k * W + lane] = v;
     }
+    __device__ __forceinline__ void bcast_always(int ch, float v) const { bcast(ch, v); }
     __device__ __forceinline__ void cell(int ch, float v) const {   // this lane's column = v (1.0 except for channel 63)
         const int k = slot(ch);
         if (k >= 0 && lane < W) buf[k * W + lane] = v;
@@ -98,6 +99,42 @@ struct EncFloatSink {
 // broadcast over channel 26 + k (k < 37), 40 + c -> c / 4 (channel 63, c <= 203 even in a poked state).  2.5 KB instead of
 // 10 KB per observation, and the way out stays a plain stream of 16-byte stores (enc_emit_bytes).
 #define ENC_LUT 256
+// Round 5: 23 (4P) / 18 (3P) of the broadcast channels are written for EVERY observation - counts, scores, round numbers; only the riichi
+// flags and the rank one-hot depend on the state - and their cells hold the channel's code whatever the value is (the value sits in the
+// table).  The staging area therefore starts from a constant image with those rows filled in instead of zeros, and the sink only notes
+// the value (bcast_always): one LDS byte store and its addressing less per channel.  One image per byte offset of `cells` in its 16-byte
+// aligned buffer (0..3: the row's distance to the next 16-byte boundary of the output).
+template <int W>
+struct EncCellImage {
+    static constexpr int NV = (ENC_CH * W + 4 + 15) / 16;
+    uint32_t w[4][NV * 4];
+};
+template <int W>
+constexpr bool enc_always_bcast(int ch) {
+    constexpr int NPP = W == ENC_W3 ? 3 : 4;
+    if (ch == 30 || ch == 37 || ch == 38 || ch == 48 || ch == 53 || ch == 54) return true;
+    constexpr int per_seat[5] = {26, 39, 43, 55, 59};
+    for (int k = 0; k < 5; k++)
+        if (ch >= per_seat[k] && ch < per_seat[k] + NPP) return true;
+    return false;
+}
+template <int W>
+constexpr EncCellImage<W> make_enc_cell_image() {
+    EncCellImage<W> t{};
+    for (int s = 0; s < 4; s++)
+        for (int ch = 26; ch <= 62; ch++)
+            if (enc_always_bcast<W>(ch))
+                for (int col = 0; col < W; col++) {
+                    const int e = s + ch * W + col;
+                    t.w[s][e >> 2] |= (uint32_t)(2 + ch - 26) << (8 * (e & 3));
+                }
+    return t;
+}
+__constant__ const EncCellImage<ENC_W4> g_enc_image4 = make_enc_cell_image<ENC_W4>();
+__constant__ const EncCellImage<ENC_W3> g_enc_image3 = make_enc_cell_image<ENC_W3>();
+#ifndef RMJ_ENC_IMAGE
+#define RMJ_ENC_IMAGE 1   /* 0: zeros + a byte store per broadcast (rounds 3-4; A/B) */
+#endif
 #ifndef RMJ_ENC_EMIT_UNROLL
 #define RMJ_ENC_EMIT_UNROLL 1
 #endif
@@ -110,8 +147,23 @@ struct EncByteSink {
     __device__ __forceinline__ bool wants(int) const { return true; }
     __device__ __forceinline__ void zero() {
         uint4* z = reinterpret_cast<uint4*>(reinterpret_cast<uintptr_t>(cells) & ~(uintptr_t)15);   // the 16-byte aligned raw buffer
+#if RMJ_ENC_IMAGE
+        const int shift = (int)(reinterpret_cast<uintptr_t>(cells) & 3u);
+        const uint4* img;
+        if constexpr (W == ENC_W3) img = reinterpret_cast<const uint4*>(g_enc_image3.w[shift]);
+        else img = reinterpret_cast<const uint4*>(g_enc_image4.w[shift]);
+        for (int i = lane; i < (ENC_CH * W + 4 + 15) / 16; i += 64) z[i] = img[i];
+#else
         for (int i = lane; i < (ENC_CH * W + 4 + 15) / 16; i += 64) z[i] = make_uint4(0u, 0u, 0u, 0u);
+#endif
         acc = -1.0f;
+    }
+    __device__ __forceinline__ void bcast_always(int ch, float v) {   // a channel of enc_always_bcast: its cells are in the image already
+#if RMJ_ENC_IMAGE
+        if (lane == ch - 26) acc = v;
+#else
+        bcast(ch, v);
+#endif
     }
     __device__ __forceinline__ void put(int ch, int col) const {
         if (col >= 0) cells[ch * W + col] = 1;
@@ -181,6 +233,7 @@ __device__ inline void encode_seat_to(const GState& S, int pid, int lane, uint32
     constexpr int ENC_W = SANMA ? ENC_W3 : ENC_W4;
     constexpr int NPP = SANMA ? 3 : 4;
     auto enc_bcast = [&](float*, int ch, float v, int) { o.bcast(ch, v); };
+    auto enc_always = [&](int ch, float v) { o.bcast_always(ch, v); };   // the channels of enc_always_bcast
     auto put = [&](int ch, int t34) { o.put(ch, enc_col<SANMA>(t34)); };   // scatter one cell (skips tiles without a column)
     auto cell = [&](int ch, float v) { o.cell(ch, v); };
     auto slot = [&](int ch) { return o.wants(ch) ? 0 : -1; };
@@ -254,17 +307,17 @@ __device__ inline void encode_seat_to(const GState& S, int pid, int lane, uint32
     }
     int tiles_left = (SANMA ? 108 : 136) - tiles_used;
     if (tiles_left < 0) tiles_left = 0;
-    enc_bcast(buf, 30, enc_div<70, 255>(tiles_left), lane);
+    enc_always(30, enc_div<70, 255>(tiles_left));
     for (int rel = 0; rel < NPP; rel++) {
         const PState& Q = S.p[(pid + rel) % NPP];
-        enc_bcast(buf, 26 + rel, enc_div<24, 255>((int)Q.n_discards), lane);
+        enc_always(26 + rel, enc_div<24, 255>((int)Q.n_discards));
         if (Q.flags & PF_RIICHI_DECLARED) enc_bcast(buf, 31 + rel, 1.0f, lane);
         int32_t sc = Q.score;
         int32_t s1 = sc < 0 ? 0 : (sc > 100000 ? 100000 : sc);
         int32_t s2 = sc < 0 ? 0 : (sc > 30000 ? 30000 : sc);
-        enc_bcast(buf, 39 + rel, enc_div<100000, 100000>(s1), lane);
-        enc_bcast(buf, 43 + rel, enc_div<30000, 30000>(s2), lane);
-        enc_bcast(buf, 59 + rel, (float)Q.n_melds / 4.0f, lane);
+        enc_always(39 + rel, enc_div<100000, 100000>(s1));
+        enc_always(43 + rel, enc_div<30000, 30000>(s2));
+        enc_always(59 + rel, (float)Q.n_melds / 4.0f);
     }
     wave_sync();
     // 10. winds (ch 35-36)
@@ -274,17 +327,17 @@ __device__ inline void encode_seat_to(const GState& S, int pid, int lane, uint32
         int seat = (pid + NPP - S.oya) % NPP;
         if (lane == 0) put(36, 27 + seat);
     }
-    enc_bcast(buf, 37, enc_div<10, 255>((int)S.honba), lane);
-    enc_bcast(buf, 38, enc_div<5, 4096>((int)(S.riichi_sticks > 0x7FFFFFFFu ? 0x7FFFFFFFu : S.riichi_sticks)), lane);
+    enc_always(37, enc_div<10, 255>((int)S.honba));
+    enc_always(38, enc_div<5, 4096>((int)(S.riichi_sticks > 0x7FFFFFFFu ? 0x7FFFFFFFu : S.riichi_sticks)));
     // 14-15. waits / tenpai (ch 47-48)
     if (slot(47) >= 0 || slot(48) >= 0) {   // (wave-uniform) only the window that holds the wait channels pays for the probe
         uint64_t W = enc_waits(P, lane);
         if (lane < ENC_W && ((W >> my34) & 1ull)) cell(47, 1.0f);
-        enc_bcast(buf, 48, W != 0ull ? 1.0f : 0.0f, lane);
+        enc_always(48, W != 0ull ? 1.0f : 0.0f);
     }
     if (rank < NPP) enc_bcast(buf, 49 + rank, 1.0f, lane);
-    enc_bcast(buf, 53, (float)S.kyoku_idx / 8.0f, lane);
-    enc_bcast(buf, 54, enc_div<7, 1275>((int)S.round_wind * 4 + (int)S.kyoku_idx), lane);
+    enc_always(53, (float)S.kyoku_idx / 8.0f);
+    enc_always(54, enc_div<7, 1275>((int)S.round_wind * 4 + (int)S.kyoku_idx));
     // 19. dora counts (ch 55-58): per seat, the number of visible tiles (own hand included for the observer) whose type is
     //     the dora of an indicator, counted per indicator (u8 accumulator in the reference); 21. tiles seen (ch 63)
     {
@@ -306,7 +359,7 @@ __device__ inline void encode_seat_to(const GState& S, int pid, int lane, uint32
         for (int rel = 0; rel < NPP; rel++) {
             int q = (pid + rel) % NPP;
             int d = q == 0 ? dcount[0] : (q == 1 ? dcount[1] : (q == 2 ? dcount[2] : dcount[3]));
-            enc_bcast(buf, 55 + rel, enc_div<12, 255>(d & 0xFF), lane);
+            enc_always(55 + rel, enc_div<12, 255>(d & 0xFF));
         }
     }
     // ch 70-73 stay 0: tsumogiri_flags is never filled (observation/mod.rs:105)

@@ -138,3 +138,33 @@ def test_padded_row_stride_equals_dense_rows(mode):
     assert torch.equal(xa, xb) and torch.equal(ta.obs(), tb.obs())
     (pa, qa), (pb, qb) = ta.obs_compact(), tb.obs_compact()
     assert torch.equal(pa, pb) and torch.equal(qa, qb)
+
+
+@pytest.mark.parametrize("mode", [2, 5])
+def test_odd_row_stride_covers_every_16_byte_phase(mode):
+    """A row stride of 74 x W + 1 floats puts consecutive rows at every distance (0..3 floats) from a 16-byte boundary: the byte-staged
+    encoder (one constant cell image per phase, round 5) must write the same floats as with dense rows - per-step encoder, fused
+    step + encode rollout, extended encoder's base block (host copy)."""
+    import torch
+
+    from riichienv_amd import vecenv
+
+    n, w = 1031, (27 if mode >= 3 else 34)
+    a = vecenv.VecRiichiEnv(n, game_mode=mode, seed=17, event_ring=64)
+    b = vecenv.VecRiichiEnv(n, game_mode=mode, seed=17, event_ring=64)
+    stride = 74 * w + 1
+    b.set_encode_row_stride(stride)
+    for e in (a, b):
+        e.reset()
+    oa = torch.zeros((n, 4, 74 * w), dtype=torch.float32, device="cuda:0")
+    ob = torch.full((n, 4, stride), -7.0, dtype=torch.float32, device="cuda:0")
+    ob[:, :, : 74 * w] = 0.0
+    torch.cuda.synchronize()
+    a.step_random_encode(9, 120, oa.data_ptr(), auto_reset=True, only_active=2)
+    b.step_random_encode(9, 120, ob.data_ptr(), auto_reset=True, only_active=2)
+    a.sync(); b.sync()
+    assert torch.equal(oa, ob[:, :, : 74 * w]) and bool((ob[:, :, 74 * w:] == -7.0).all()) and float(oa.abs().sum()) > 0
+    ea, eb = a.encode(), b.encode()          # every seat through the per-step encoder (host copies; b's rows at stride 74 x W + 1)
+    assert (ea == eb).all() and float(np.abs(ea).sum()) > 0
+    assert (a.encode_extended() == b.encode_extended()).all()
+    a.close(); b.close()

@@ -99,7 +99,7 @@ struct EncFloatSink {
 // broadcast over channel 26 + k (k < 37), 40 + c -> c / 4 (channel 63, c <= 203 even in a poked state).  2.5 KB instead of
 // 10 KB per observation, and the way out stays a plain stream of 16-byte stores (enc_emit_bytes).
 #define ENC_LUT 256
-// Round 5: 23 (4P) / 18 (3P) of the broadcast channels are written for EVERY observation - counts, scores, round numbers; only the riichi
+// Round 5 (an alternative, off by default - RMJ_ENC_IMAGE): 23 (4P) / 18 (3P) of the broadcast channels are written for EVERY observation - counts, scores, round numbers; only the riichi
 // flags and the rank one-hot depend on the state - and their cells hold the channel's code whatever the value is (the value sits in the
 // table).  The staging area therefore starts from a constant image with those rows filled in instead of zeros, and the sink only notes
 // the value (bcast_always): one LDS byte store and its addressing less per channel.  One image per byte offset of `cells` in its 16-byte
@@ -133,7 +133,7 @@ constexpr EncCellImage<W> make_enc_cell_image() {
 __constant__ const EncCellImage<ENC_W4> g_enc_image4 = make_enc_cell_image<ENC_W4>();
 __constant__ const EncCellImage<ENC_W3> g_enc_image3 = make_enc_cell_image<ENC_W3>();
 #ifndef RMJ_ENC_IMAGE
-#define RMJ_ENC_IMAGE 1   /* 0: zeros + a byte store per broadcast (rounds 3-4; A/B) */
+#define RMJ_ENC_IMAGE 0   /* 1: the image (measured: the trainer loop's step + encode launch +1.5 %, the stand-alone encoders -2...-4 % - the image's loads sit in front of every observation; left off) */
 #endif
 #ifndef RMJ_ENC_EMIT_UNROLL
 #define RMJ_ENC_EMIT_UNROLL 1

@@ -141,10 +141,11 @@ def test_padded_row_stride_equals_dense_rows(mode):
 
 
 @pytest.mark.parametrize("mode", [2, 5])
-def test_odd_row_stride_covers_every_16_byte_phase(mode):
-    """A row stride of 74 x W + 1 floats puts consecutive rows at every distance (0..3 floats) from a 16-byte boundary: the byte-staged
-    encoder (one constant cell image per phase, round 5) must write the same floats as with dense rows - per-step encoder, fused
-    step + encode rollout, extended encoder's base block (host copy)."""
+def test_row_stride_off_the_16_byte_grid(mode):
+    """A row stride of 74 x W + 2 floats (strides are even: rmj_set_encode_row_stride) puts consecutive rows alternately on and 8 bytes off
+    the 16-byte grid in 4P too (dense 3P rows already alternate): the byte-staged encoder - its cells shifted by two bytes, two floats
+    in front of the first 16-byte store - must write the same floats as with dense rows: fused step + encode rollout, per-step encoder,
+    the extended encoder's base block."""
     import torch
 
     from riichienv_amd import vecenv
@@ -152,7 +153,7 @@ def test_odd_row_stride_covers_every_16_byte_phase(mode):
     n, w = 1031, (27 if mode >= 3 else 34)
     a = vecenv.VecRiichiEnv(n, game_mode=mode, seed=17, event_ring=64)
     b = vecenv.VecRiichiEnv(n, game_mode=mode, seed=17, event_ring=64)
-    stride = 74 * w + 1
+    stride = 74 * w + 2
     b.set_encode_row_stride(stride)
     for e in (a, b):
         e.reset()
@@ -164,7 +165,7 @@ def test_odd_row_stride_covers_every_16_byte_phase(mode):
     b.step_random_encode(9, 120, ob.data_ptr(), auto_reset=True, only_active=2)
     a.sync(); b.sync()
     assert torch.equal(oa, ob[:, :, : 74 * w]) and bool((ob[:, :, 74 * w:] == -7.0).all()) and float(oa.abs().sum()) > 0
-    ea, eb = a.encode(), b.encode()          # every seat through the per-step encoder (host copies; b's rows at stride 74 x W + 1)
+    ea, eb = a.encode(), b.encode()          # every seat through the per-step encoder (host copies; b's rows at stride 74 x W + 2)
     assert (ea == eb).all() and float(np.abs(ea).sum()) > 0
     assert (a.encode_extended() == b.encode_extended()).all()
     a.close(); b.close()

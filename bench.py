@@ -61,6 +61,9 @@ def parse_args(argv=None):
     ap.add_argument("--reference-rng", action="store_true",
                     help="deal every wall through the reference's own seed -> wall chain (RMJ_RULE_REFERENCE_RNG: PCG32 seed expansion, "
                          "ChaCha12, rand's shuffle, salt) instead of the build's counter-based shuffle")
+    ap.add_argument("--in-process", type=int, default=0, metavar="K",
+                    help="ONE process, K shards of --games games each through MultiGpuVecEnv (a host thread per shard, shard i on device i mod the "
+                         "visible devices): the in-process counterpart of --gpus K; prints its own JSON line")
     ap.add_argument("--no-configs", action="store_true", help="skip the legs of the other BASELINE.json configurations (configs[1], [3], [4])")
     ap.add_argument("--padded-rows", action="store_true", help="--encode: rows padded to a multiple of 256 B instead of the dense [games][4][74][W] tensor")
     ap.add_argument("--encode", action="store_true",
@@ -406,10 +409,56 @@ def log_leg(vecenv, abi, shard, games, mode, policy_seed, device, rank, rounds=3
                     "restarts included; end_to_end = env.steps of the region / (rollout + drain wall time)"}
 
 
+def in_process_leg(args):
+    """`--in-process K`: the batch sharded inside ONE process (riichienv_amd.multi_gpu.MultiGpuVecEnv: a handle and a host thread per shard, no
+    collective) - W untimed warm-up steps, then exactly `--steps` steps of the device RandomAgent on every shard at once between two
+    synchronisations of all shards.  Weak scaling like the ranks of --gpus: every shard owns --games games, global game indices key seeds and policy."""
+    from riichienv_amd import abi, vecenv
+    from riichienv_amd.multi_gpu import MultiGpuVecEnv
+
+    k = args.in_process
+    have = vecenv.load_lib().rmj_device_count()
+    if have < 1:
+        print("bench.py: no GPU visible (the product path has no CPU fallback)", file=sys.stderr)
+        return 2
+    devices = [i % have for i in range(k)]
+    policy_seed = 0xC0FFEE
+    env = MultiGpuVecEnv(args.games * k, devices=devices, game_mode=args.mode, seed=0, rule_bits=abi.RULE_TENHOU, event_ring=64)
+    env.reset()
+    if args.preroll > 0:
+        env.step_random(policy_seed, args.preroll, auto_reset=True)
+    env.step_random(policy_seed, max(args.warmup, 1), auto_reset=True)
+    env._map(lambda i, e: e.sync())
+    s0 = env._map(lambda i, e: e.total_steps())
+    walls = [0.0] * k
+
+    def timed(i, e):
+        t0 = time.perf_counter()
+        e.step_random(policy_seed, args.steps, auto_reset=True)
+        e.sync()
+        walls[i] = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    env._map(timed)
+    wall = time.perf_counter() - t0
+    made = [b - a for a, b in zip(s0, env._map(lambda i, e: e.total_steps()))]
+    env.close()
+    line = {"metric": metric_name(args), "value": sum(made) / wall, "unit": "env.step/s", "n_gpus": len(set(devices)), "shards": k, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": wall * 1e3 / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8",
+            "data": "synthetic", "host": "in-process: MultiGpuVecEnv, one host thread and one C-ABI handle per shard, no collective",
+            "devices": devices, "per_shard_value": [m / max(w, 1e-12) for m, w in zip(made, walls)], "per_shard_wall_s": walls,
+            "config": {"workload": f"{k} x {args.games} parallel {MODES[args.mode]} games, device RandomAgent, auto-reset, MJAI logging on", "games_per_shard": args.games,
+                       "parallelism": f"{k} in-process shards on {len(set(devices))} device(s)"},
+            "note": "shards that share a device are time-sliced by it: on one GPU this line shows that the path runs, not a scaling figure"}
+    print(json.dumps(line))
+    return 0
+
+
 def main(argv=None):
     args = parse_args(argv)
     if args.gpus < 1:
         raise SystemExit("--gpus must be >= 1")
+    if args.in_process > 0:
+        return in_process_leg(args)
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         return launch_ranks(args)
 

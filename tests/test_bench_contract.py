@@ -85,3 +85,10 @@ def test_metric_names():
     assert bench.metric_name(bench.parse_args(["--gpus", "8"])) == base["metric"]
     m5 = bench.metric_name(bench.parse_args(["--mode", "5", "--encode"]))
     assert "3p" in m5 and "feature-encoding" in m5 and "4p" not in m5
+
+
+def test_in_process_flag_parses():
+    import bench
+
+    args = bench.parse_args(["--in-process", "8", "--games", "65536"])
+    assert args.in_process == 8 and args.gpus == 1 and bench.parse_args([]).in_process == 0

@@ -71,3 +71,18 @@ def test_bench_with_two_ranks_sharing_the_gpu():
     # two ranks x 8 192 games x 60 steps, nearly every game advances every step: the SUM over ranks, the MAX of their times
     steps = line["value"] * line["ms_per_step"] * 1e-3 * 60
     assert 0.9 * 2 * 8192 * 60 <= steps <= 2 * 8192 * 60 * 1.0001, steps
+
+
+def test_bench_in_process_shards():
+    """bench.py --in-process 2: the in-process counterpart of --gpus 2 (MultiGpuVecEnv, a host thread and a handle per shard); on a one-GPU
+    box both shards share the device."""
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--in-process", "2", "--games", "8192", "--steps", "60", "--warmup", "20", "--preroll", "400"]
+    p = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.strip().startswith("{")]
+    assert len(lines) == 1, p.stdout
+    line = json.loads(lines[0])
+    assert line["shards"] == 2 and line["scaling"] == "weak" and line["n_gpus"] >= 1 and len(line["devices"]) == 2
+    assert len(line["per_shard_value"]) == 2 and all(v > 0 for v in line["per_shard_value"]) and "in-process" in line["host"]
+    steps = line["value"] * line["ms_per_step"] * 1e-3 * 60
+    assert 0.9 * 2 * 8192 * 60 <= steps <= 2 * 8192 * 60 * 1.0001, steps

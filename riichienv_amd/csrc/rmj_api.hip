@@ -671,7 +671,7 @@ __global__ __launch_bounds__(64) RMJ_ENC_OCC void k_encode_base(Env E, int only_
 #else
         encode_seat_to<SANMA>(S, seat, lane, hist, o, true);
 #endif
-        enc_emit_bytes<W>(dst, o.cells, lut, lane, head);
+        enc_emit_bytes<W>(dst, o.cells, lut, lane, head, o.big);
         wave_sync();
     }
 }
@@ -738,7 +738,7 @@ __global__ __launch_bounds__(64) RMJ_ENCX_OCC void k_encode_ext(Env E, int only_
         const int head = head_of(dst);
         EncByteSink<W> o{raw + ((4 - head) & 3), lut, lane, -1.0f};
         encode_seat_to<SANMA>(S, seat, lane, hist, o, true, true);
-        enc_emit_bytes<W>(dst, o.cells, lut, lane, head);
+        enc_emit_bytes<W>(dst, o.cells, lut, lane, head, o.big);
         wave_sync();
     }
     {   // channels 74..93 and 178..214

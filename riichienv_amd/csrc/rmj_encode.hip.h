@@ -97,8 +97,11 @@ struct EncFloatSink {
 };
 // EncByteSink: one byte per cell of the 74 x W tensor, a code into a table of floats: 0 -> 0.0, 1 -> 1.0, 2 + k -> the value
 // broadcast over channel 26 + k (k < 37), 40 + c -> c / 4 (channel 63, c <= 203 even in a poked state).  2.5 KB instead of
-// 10 KB per observation, and the way out stays a plain stream of 16-byte stores (enc_emit_bytes).
-#define ENC_LUT 256
+// 10 KB per observation, and the way out stays a plain stream of 16-byte stores (enc_emit_bytes).  The table holds the codes below 64
+// (c <= 23; a played state has c <= 4); an observation with a larger count (`big`) leaves through the emit loop that decodes such codes
+// arithmetically (the same float: c x 0.25 is exact).
+#define ENC_LUT 64        /* round 5: 64 entries (256 B; rounds 3-4: 256 entries) - codes from 64 on (a per-column count above 23: poked states only) are decoded arithmetically */
+#define ENC_Q_BASE 40     /* code of a per-column count c: ENC_Q_BASE + c */
 // Round 5 (an alternative, off by default - RMJ_ENC_IMAGE): 23 (4P) / 18 (3P) of the broadcast channels are written for EVERY observation - counts, scores, round numbers; only the riichi
 // flags and the rank one-hot depend on the state - and their cells hold the channel's code whatever the value is (the value sits in the
 // table).  The staging area therefore starts from a constant image with those rows filled in instead of zeros, and the sink only notes
@@ -144,6 +147,7 @@ struct EncByteSink {
     float* lut;       // [ENC_LUT]; entries 0, 1 and 40.. are filled once per block (enc_lut_init)
     int lane;
     float acc;        // lane k < 37 collects the value broadcast over channel 26 + k (-1 = none)
+    bool big = false; // this lane staged a code outside the table
     __device__ __forceinline__ bool wants(int) const { return true; }
     __device__ __forceinline__ void zero() {
         uint4* z = reinterpret_cast<uint4*>(reinterpret_cast<uintptr_t>(cells) & ~(uintptr_t)15);   // the 16-byte aligned raw buffer
@@ -157,6 +161,7 @@ struct EncByteSink {
         for (int i = lane; i < (ENC_CH * W + 4 + 15) / 16; i += 64) z[i] = make_uint4(0u, 0u, 0u, 0u);
 #endif
         acc = -1.0f;
+        big = false;
     }
     __device__ __forceinline__ void bcast_always(int ch, float v) {   // a channel of enc_always_bcast: its cells are in the image already
 #if RMJ_ENC_IMAGE
@@ -175,23 +180,28 @@ struct EncByteSink {
     __device__ __forceinline__ void cell(int ch, float) const {   // this lane's column = 1
         if (lane < W) cells[ch * W + lane] = 1;
     }
-    __device__ __forceinline__ void cell_quarters(int ch, int c) const {   // this lane's column = c / 4
-        if (lane < W) cells[ch * W + lane] = (uint8_t)(40 + c);
+    __device__ __forceinline__ void cell_quarters(int ch, int c) {   // this lane's column = c / 4
+        if (lane < W) {
+            cells[ch * W + lane] = (uint8_t)(ENC_Q_BASE + c);
+            big = big || ENC_Q_BASE + c >= ENC_LUT;
+        }
     }
     __device__ __forceinline__ void flush() const {
         if (lane < 37 && acc >= 0.0f) lut[2 + lane] = acc;
     }
 };
 __device__ __forceinline__ void enc_lut_init(float* lut, int lane) {
-    for (int i = lane; i < ENC_LUT; i += 64) lut[i] = i < 2 ? (float)i : (i >= 40 ? (float)(i - 40) * 0.25f : 0.0f);
+    for (int i = lane; i < ENC_LUT; i += 64) lut[i] = i < 2 ? (float)i : (i >= ENC_Q_BASE ? (float)(i - ENC_Q_BASE) * 0.25f : 0.0f);
 }
 // NCH x W floats from the byte-staged form, in 16-byte stores: `head` = 0..3 floats precede the first 16-byte boundary of the
 // (4-byte aligned) `dst`; the cells are laid out so that cells + head is dword aligned
+// big (any lane): the staging area holds codes outside the table - every code is decoded with the range check (rare: poked states)
 template <int W, int NCH = ENC_CH>
-__device__ __forceinline__ void enc_emit_bytes(float* dst, const uint8_t* cells, const float* lut, int lane, int head) {
+__device__ __forceinline__ void enc_emit_bytes(float* dst, const uint8_t* cells, const float* lut, int lane, int head, bool big = false) {
     constexpr int N = NCH * W;
     const int body = (N - head) >> 2, tail0 = head + 4 * body;
-    if (lane < head) dst[lane] = lut[cells[lane]];
+    auto dec1 = [&](uint32_t code) -> float { return code < (uint32_t)ENC_LUT ? lut[code] : (float)((int)code - ENC_Q_BASE) * 0.25f; };
+    if (lane < head) dst[lane] = dec1(cells[lane]);
     float4* d4 = reinterpret_cast<float4*>(dst + head);
     const uint32_t* c4 = reinterpret_cast<const uint32_t*>(cells + head);
     typedef float enc_v4f __attribute__((ext_vector_type(4)));
@@ -207,7 +217,9 @@ __device__ __forceinline__ void enc_emit_bytes(float* dst, const uint8_t* cells,
     };
     auto dec = [&](uint32_t w) -> enc_v4f { return enc_v4f{lut[w & 255u], lut[(w >> 8) & 255u], lut[(w >> 16) & 255u], lut[w >> 24]}; };
     int i = lane;
+    const bool slow = __ballot(big) != 0ull;
 #if RMJ_ENC_EMIT_UNROLL > 1
+    if (!slow)
     // RMJ_ENC_EMIT_UNROLL stores per trip: the code words of all of them are read first, then their table entries, then the stores
     // leave back to back (one store per trip waits for two dependent LDS round trips in front of every store)
     constexpr int U = RMJ_ENC_EMIT_UNROLL;
@@ -222,8 +234,14 @@ __device__ __forceinline__ void enc_emit_bytes(float* dst, const uint8_t* cells,
         for (int u = 0; u < U; u++) st16(i + 64 * u, v[u]);
     }
 #endif
+    if (slow) {
+        for (; i < body; i += 64) {
+            const uint32_t w = c4[i];
+            st16(i, enc_v4f{dec1(w & 255u), dec1((w >> 8) & 255u), dec1((w >> 16) & 255u), dec1(w >> 24)});
+        }
+    }
     for (; i < body; i += 64) st16(i, dec(c4[i]));
-    if (lane < N - tail0) dst[tail0 + lane] = lut[cells[tail0 + lane]];
+    if (lane < N - tail0) dst[tail0 + lane] = dec1(cells[tail0 + lane]);
 }
 // ext_base: the base block as encode_extended writes it (encode_base_into, observation/encode.rs:94-111, observation_3p/encode.rs:106-122):
 // its "tiles left" does not count a meld's called tile twice (it is in the discards already); Observation.encode() itself

@@ -3003,8 +3003,10 @@ __global__ __launch_bounds__(64, RMJ_STEP4_WAVES_OF(POL)) void k_step4_fixup(con
 // issue-bound step and the store-bound encoder: while one wave streams its rows out, the others step.  The records are already in
 // LDS (no second fetch), the encoder's byte staging lives in the union the step has finished with.  Compiled for five waves per
 // SIMD: the encoder wants 85-96 registers.
+// (six waves per SIMD since the value table shrank to 64 entries - 6 512 B of LDS per wave, 80 VGPR without a spill: trainer loop +1.5 %, the 3P
+//  step + encode rollout the same: profiles/r05_enc_waves_ab.txt.  The launch is bound by its LDS and vector instruction streams together, not by occupancy.)
 #ifndef RMJ_STEP4_ENC_WAVES
-#define RMJ_STEP4_ENC_WAVES 5
+#define RMJ_STEP4_ENC_WAVES 6
 #endif
 #ifndef RMJ_INLINE_ENC
 #define RMJ_INLINE_ENC 0     /* experiment: step + encode inlined into the rollout loops of k_step4_enc / k_step4_queue_enc (see step4_call_inl) */
@@ -3042,7 +3044,7 @@ __device__ __forceinline__ void step4_enc_impl(const Env* Ep, uint64_t policy_se
             const int head = (int)(((16u - (uint32_t)(reinterpret_cast<uintptr_t>(dst) & 15u)) & 15u) >> 2);  // 0 or 2 floats
             EncByteSink<W> o{sh.u.e.raw + ((4 - head) & 3), lut, lane, -1.0f};
             encode_seat_to<KSANMA>(S, seat, lane, sh.u.e.hist, o, true);
-            enc_emit_bytes<W>(dst, o.cells, lut, lane, head);
+            enc_emit_bytes<W>(dst, o.cells, lut, lane, head, o.big);
             wave_sync();
         }
     }

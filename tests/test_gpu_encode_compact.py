@@ -169,3 +169,41 @@ def test_row_stride_off_the_16_byte_grid(mode):
     assert (ea == eb).all() and float(np.abs(ea).sum()) > 0
     assert (a.encode_extended() == b.encode_extended()).all()
     a.close(); b.close()
+
+
+@pytest.mark.parametrize("mode", [2, 5])
+def test_poked_state_with_counts_outside_the_value_table(mode):
+    """Channel 63 (tiles seen / 4) of a poked state whose rivers hold one tile type 60+ times: the byte-staged encoder decodes such codes
+    arithmetically (its value table ends at a count of 23) - base encoder and the extended encoder's base block equal the oracle's."""
+    import copy
+
+    from oracle import oracle
+    from riichienv_amd import vecenv
+
+    n = 8
+    env = vecenv.VecRiichiEnv(n, game_mode=mode, seed=23, event_ring=64)
+    env.reset()
+    env.step_random(3, 40, auto_reset=False)
+    ref = env.encode()
+    g = 2
+    v = env.peek(g)
+    w = copy.deepcopy(v)
+    np_ = 3 if mode >= 3 else 4
+    tile = 4 * 27 + 1                      # an East (a column of both layouts)
+    for q in range(np_):
+        w.players[q].n_discards = 20
+        for j in range(20):
+            w.players[q].discards[j] = tile if j % 5 else 4 * 31 + (j % 4)
+    env.poke(g, w)
+    o = oracle.Game(game_mode=mode, seed=1)
+    o.reset()
+    o.poke(w)
+    got, ext = env.encode(), env.encode_extended()
+    for pid in range(np_):
+        want = np.asarray(o.encode(pid, sanma=mode >= 3), np.float32).reshape(got[g, pid].shape)
+        assert (got[g, pid] == want).all(), pid
+        assert float(want[63].max()) >= 12.0               # 48 (3P) / 64 (4P) copies of the tile seen: the code lies outside the table
+        assert (ext[g, pid, :74] == np.asarray(o.encode_extended(pid), np.float32).reshape(ext[g, pid].shape)[:74]).all(), pid
+    others = [k for k in range(n) if k != g]
+    assert (got[others] == ref[others]).all()                # ... and the rows of the other games leave through the table as before
+    env.close()

@@ -91,42 +91,48 @@ __global__ void k_random_actions(Env E, uint64_t policy_seed, uint64_t* out) {
 // lanes hold ids lane and lane + 64 of the seat's mask row, add Gumbel noise to the policy's logits (Gumbel-max = a draw
 // from softmax(logits) restricted to the legal ids; no logits = uniform over the legal ids) and a wave arg-max picks the id.
 // The noise is counter-based: splitmix64(seed, global game, the game's step count, seat, id).
+// Round 5: four games per wave (one 16-lane row each; lane r of a row judges the ids r, r + 16, ...), like the step kernels - the keyed Gumbel
+// draw of an id costs the same wherever it runs, but a wave per game left 64 lanes to 82 ids of (mostly) one seat.  The same keys, the same
+// arg-max rule (ties to the lower id) as the wave-per-game kernel of rounds 3-4: identical ids.
 __global__ __launch_bounds__(256) void k_sample_ids(Env E, const float* __restrict__ logits, uint32_t stride, uint64_t seed,
                                                     int32_t* __restrict__ out) {
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const uint32_t g = blockIdx.x * 4 + wave;
-    if (g >= E.n_games) return;
-    const uint32_t st = E.status[g];
+    const int lane = threadIdx.x & 63, r = lane & 15;
+    const uint32_t g = (blockIdx.x * 4 + (threadIdx.x >> 6)) * 4 + (uint32_t)(lane >> 4);
+    const bool in = g < E.n_games;
+    const uint32_t gi = in ? g : 0u;
+    const uint32_t st = in ? E.status[gi] : 0x10000u;
     const uint32_t am = (st >> 16) & 0xFFu ? 0u : (st & 0xFu);   // done games have nobody to act
     const int A = E.game_mode >= 3 ? RMJ_ACTION_SPACE_3P : RMJ_ACTION_SPACE_4P;
-    const uint64_t base = sm64(seed ^ sm64(E.game_offset + g)) + ((uint64_t)E.core[g].step_count << 10);
-    int32_t res = -1;   // lane p ends up with seat p's id
+    const uint64_t base = sm64(seed ^ sm64(E.game_offset + gi)) + ((uint64_t)E.core[gi].step_count << 10);
+    const uint32_t nl4 = in ? *reinterpret_cast<const uint32_t*>(E.nlegal + (size_t)gi * 4) : 0u;   // the four list lengths of the game
+    int32_t res = -1;   // lane p of a row ends up with seat p's id
     for (int p = 0; p < 4; p++) {
-        if (!((am >> p) & 1u) || E.nlegal[(size_t)g * 4 + p] == 0) continue;   // wave-uniform
-        const uint8_t* m = E.mask + ((size_t)g * 4 + p) * 82;
-        const float* lg = logits ? logits + ((size_t)g * 4 + p) * stride : nullptr;
+        const bool act = ((am >> p) & 1u) && ((nl4 >> (8 * p)) & 0xFFu) != 0u;   // (row-uniform)
+        if (!__ballot(act)) continue;
+        const uint8_t* m = E.mask + ((size_t)gi * 4 + p) * 82;
+        const float* lg = logits ? logits + ((size_t)gi * 4 + p) * stride : nullptr;
         float best = -INFINITY;
         int bid = -1;
-#pragma unroll
-        for (int k = 0; k < 2; k++) {
-            const int id = lane + 64 * k;
-            if (id < A && m[id]) {
-                const uint64_t h = sm64(base + ((uint64_t)p << 8) + (uint64_t)id);
-                const float u = ((float)(uint32_t)(h >> 40) + 0.5f) * (1.0f / 16777216.0f);   // (0, 1), 24 bits
-                const float key = (lg ? lg[id] : 0.0f) - __logf(-__logf(u));
-                if (key > best || bid < 0) { best = key; bid = id; }
+        if (act) {
+            for (int id = r; id < A; id += 16) {
+                if (m[id]) {
+                    const uint64_t h = sm64(base + ((uint64_t)p << 8) + (uint64_t)id);
+                    const float u = ((float)(uint32_t)(h >> 40) + 0.5f) * (1.0f / 16777216.0f);   // (0, 1), 24 bits
+                    const float key = (lg ? lg[id] : 0.0f) - __logf(-__logf(u));
+                    if (key > best || bid < 0) { best = key; bid = id; }
+                }
             }
         }
-        // wave arg-max (ties to the lower id)
+        // row arg-max (ties to the lower id)
 #pragma unroll
-        for (int off = 32; off >= 1; off >>= 1) {
+        for (int off = 8; off >= 1; off >>= 1) {
             const float ob = __shfl_xor(best, off, 64);
             const int oi = __shfl_xor(bid, off, 64);
             if (oi >= 0 && (bid < 0 || ob > best || (ob == best && oi < bid))) { best = ob; bid = oi; }
         }
-        if (lane == p) res = bid;
+        if (act && r == p) res = bid;
     }
-    if (lane < 4) out[(size_t)g * 4 + lane] = res;
+    if (in && r < 4) out[(size_t)g * 4 + r] = res;
 }
 
 struct ResetArgs {
@@ -1404,7 +1410,7 @@ int rmj_sample_ids_device(rmj_handle h, const float* d_logits, uint32_t stride, 
     if (d_logits && stride < A) return fail(RMJ_ERR_ARG, "logits row shorter than the action space");
     HIPCHK(hipSetDevice(h->cfg.device));
     const uint32_t n = h->cfg.n_games;
-    hipLaunchKernelGGL(k_sample_ids, dim3((n + 3) / 4), dim3(256), 0, h->stream, h->d, d_logits, stride, seed, d_ids);
+    hipLaunchKernelGGL(k_sample_ids, dim3((n + 15) / 16), dim3(256), 0, h->stream, h->d, d_logits, stride, seed, d_ids);
     HIPCHK(hipGetLastError());
     return RMJ_OK;
 }

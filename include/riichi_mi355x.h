@@ -421,6 +421,11 @@ int rmj_step_ids_device(rmj_handle h, const int32_t* d_action_ids, int auto_rese
  * trainer loop's iteration (riichienv-ml trainers/_ppo_worker.py:151-239: step, then obs.encode() of the returned observations)
  * with one launch gap instead of two. */
 int rmj_step_ids_encode_device(rmj_handle h, const int32_t* d_action_ids, int auto_reset, float* d_out);
+/* rmj_sample_ids_device(h, d_logits, stride, seed, d_ids) + rmj_step_ids_encode_device(h, d_ids, auto_reset, d_out) as ONE launch (round 5):
+ * every wave draws the ids of its own four games from the policy's logits (the same keyed draw: the ids are the ones the two calls
+ * produce, and they are written to d_ids [n][4] for the caller's log-probabilities), steps under them and encodes the seats that act
+ * next - the whole environment side of a trainer iteration (trainers/_ppo_worker.py:151-239) between two policy forward passes. */
+int rmj_step_sample_encode_device(rmj_handle h, const float* d_logits, uint32_t stride, uint64_t seed, int auto_reset, int32_t* d_ids, float* d_out);
 /* Masked categorical sampling for a policy on the same GPU (what riichienv-ml's PPO worker does per game on the host with
  * obs.mask(), trainers/_ppo_worker.py:164-239): for every seat that is to act, one action id drawn from
  * softmax(logits) restricted to the seat's legal ids (Gumbel-max on the resident mask slab); d_logits [n][4][stride] f32 on

@@ -94,22 +94,21 @@ __global__ void k_random_actions(Env E, uint64_t policy_seed, uint64_t* out) {
 // Round 5: four games per wave (one 16-lane row each; lane r of a row judges the ids r, r + 16, ...), like the step kernels - the keyed Gumbel
 // draw of an id costs the same wherever it runs, but a wave per game left 64 lanes to 82 ids of (mostly) one seat.  The same keys, the same
 // arg-max rule (ties to the lower id) as the wave-per-game kernel of rounds 3-4: identical ids.
-__global__ __launch_bounds__(256) void k_sample_ids(Env E, const float* __restrict__ logits, uint32_t stride, uint64_t seed,
-                                                    int32_t* __restrict__ out) {
-    const int lane = threadIdx.x & 63, r = lane & 15;
-    const uint32_t g = (blockIdx.x * 4 + (threadIdx.x >> 6)) * 4 + (uint32_t)(lane >> 4);
-    const bool in = g < E.n_games;
+// One id per acting seat of the row's game g (in: the row has a game): lane p of the row returns seat p's id, -1 where nobody acts.
+__device__ __forceinline__ int32_t sample_ids_row(const uint32_t* status, const GState* core, const uint8_t* nlegal, const uint8_t* mask, uint64_t game_offset,
+                                                  int game_mode, uint32_t g, bool in, const float* __restrict__ logits, uint32_t stride, uint64_t seed, int lane) {
+    const int r = lane & 15;
     const uint32_t gi = in ? g : 0u;
-    const uint32_t st = in ? E.status[gi] : 0x10000u;
+    const uint32_t st = in ? status[gi] : 0x10000u;
     const uint32_t am = (st >> 16) & 0xFFu ? 0u : (st & 0xFu);   // done games have nobody to act
-    const int A = E.game_mode >= 3 ? RMJ_ACTION_SPACE_3P : RMJ_ACTION_SPACE_4P;
-    const uint64_t base = sm64(seed ^ sm64(E.game_offset + gi)) + ((uint64_t)E.core[gi].step_count << 10);
-    const uint32_t nl4 = in ? *reinterpret_cast<const uint32_t*>(E.nlegal + (size_t)gi * 4) : 0u;   // the four list lengths of the game
-    int32_t res = -1;   // lane p of a row ends up with seat p's id
+    const int A = game_mode >= 3 ? RMJ_ACTION_SPACE_3P : RMJ_ACTION_SPACE_4P;
+    const uint64_t base = sm64(seed ^ sm64(game_offset + gi)) + ((uint64_t)core[gi].step_count << 10);
+    const uint32_t nl4 = in ? *reinterpret_cast<const uint32_t*>(nlegal + (size_t)gi * 4) : 0u;   // the four list lengths of the game
+    int32_t res = -1;
     for (int p = 0; p < 4; p++) {
         const bool act = ((am >> p) & 1u) && ((nl4 >> (8 * p)) & 0xFFu) != 0u;   // (row-uniform)
         if (!__ballot(act)) continue;
-        const uint8_t* m = E.mask + ((size_t)gi * 4 + p) * 82;
+        const uint8_t* m = mask + ((size_t)gi * 4 + p) * 82;
         const float* lg = logits ? logits + ((size_t)gi * 4 + p) * stride : nullptr;
         float best = -INFINITY;
         int bid = -1;
@@ -132,6 +131,14 @@ __global__ __launch_bounds__(256) void k_sample_ids(Env E, const float* __restri
         }
         if (act && r == p) res = bid;
     }
+    return res;
+}
+__global__ __launch_bounds__(256) void k_sample_ids(Env E, const float* __restrict__ logits, uint32_t stride, uint64_t seed,
+                                                    int32_t* __restrict__ out) {
+    const int lane = threadIdx.x & 63, r = lane & 15;
+    const uint32_t g = (blockIdx.x * 4 + (threadIdx.x >> 6)) * 4 + (uint32_t)(lane >> 4);
+    const bool in = g < E.n_games;
+    const int32_t res = sample_ids_row(E.status, E.core, E.nlegal, E.mask, E.game_offset, E.game_mode, g, in, logits, stride, seed, lane);
     if (in && r < 4) out[(size_t)g * 4 + r] = res;
 }
 
@@ -1401,6 +1408,22 @@ int rmj_step_ids_encode_device(rmj_handle h, const int32_t* d_action_ids, int au
     const dim3 grid((n + 3u) / 4u);
     if (h->cfg.game_mode >= 3) hipLaunchKernelGGL(rmj3::k_step4_act_enc, grid, dim3(64), 0, h->stream, (const Env*)h->d_env, flags, 0u, n, reinterpret_cast<const uint64_t*>(d_action_ids), d_out);
     else hipLaunchKernelGGL(rmj4::k_step4_act_enc, grid, dim3(64), 0, h->stream, (const Env*)h->d_env, flags, 0u, n, reinterpret_cast<const uint64_t*>(d_action_ids), d_out);
+    HIPCHK(hipGetLastError());
+    return RMJ_OK;
+}
+// rmj_sample_ids_device + rmj_step_ids_encode_device as ONE launch (k_step4_sample_enc): every wave draws the ids of its own four games
+// (the same keyed draw: identical ids, written to d_ids for the caller), steps them and encodes the seats that act next.
+int rmj_step_sample_encode_device(rmj_handle h, const float* d_logits, uint32_t stride, uint64_t seed, int auto_reset, int32_t* d_ids, float* d_out) {
+    if (!h || !d_ids || !d_out) return fail(RMJ_ERR_ARG, "null argument");
+    if (!h->quad) return fail(RMJ_ERR_ARG, "rmj_step_sample_encode_device runs in the four-games-per-wave kernels (RMJ_STEP4=0 selects the one-game kernel)");
+    const uint32_t A = h->cfg.game_mode >= 3 ? RMJ_ACTION_SPACE_3P : RMJ_ACTION_SPACE_4P;
+    if (d_logits && stride < A) return fail(RMJ_ERR_ARG, "logits row shorter than the action space");
+    HIPCHK(hipSetDevice(h->cfg.device));
+    const uint32_t flags = STEP_F_IDS | (auto_reset ? STEP_F_AUTORESET : 0u);
+    const uint32_t n = h->cfg.n_games;
+    const dim3 grid((n + 3u) / 4u);
+    if (h->cfg.game_mode >= 3) hipLaunchKernelGGL(rmj3::k_step4_sample_enc, grid, dim3(64), 0, h->stream, (const Env*)h->d_env, flags, 0u, n, d_logits, stride, seed, d_ids, d_out);
+    else hipLaunchKernelGGL(rmj4::k_step4_sample_enc, grid, dim3(64), 0, h->stream, (const Env*)h->d_env, flags, 0u, n, d_logits, stride, seed, d_ids, d_out);
     HIPCHK(hipGetLastError());
     return RMJ_OK;
 }

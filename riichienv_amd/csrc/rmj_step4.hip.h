@@ -3095,6 +3095,22 @@ __global__ __launch_bounds__(64, RMJ_STEP4_ENC_WAVES) void k_step4_act_enc(const
     step4_call_enc<false, 0>(Ep, 0ull, flags, g_base, g_end, 1u, 0ull, 0xFFFFFFFFu, out, actions);
 #endif
 }
+// ... with the policy's draw in front (rmj_step_sample_encode_device): the wave samples one id per acting seat of its own four games from the
+// caller's logits (sample_ids_row: the keyed Gumbel draw of k_sample_ids, the same ids), hands them to the caller (d_ids) and steps under
+// them - every lane reads back the id it has just stored itself (program order), no second launch and no pass over all games in between.
+__global__ __launch_bounds__(64, RMJ_STEP4_ENC_WAVES) void k_step4_sample_enc(const Env* __restrict__ Ep, uint32_t flags, uint32_t g_base, uint32_t g_end,
+                                                                                  const float* __restrict__ logits, uint32_t stride, uint64_t seed,
+                                                                                  int32_t* __restrict__ ids, float* __restrict__ out) {
+    {
+        CEnv& E = *(CEnv*)Ep;
+        const int lane = threadIdx.x & 63;
+        const uint32_t g = g_base + blockIdx.x * 4u + (uint32_t)(lane >> 4);
+        const bool in = g < g_end;
+        const int32_t res = sample_ids_row(E.status, E.core, E.nlegal, E.mask, E.game_offset, (int)E.game_mode, g, in, logits, stride, seed, lane);
+        if (in && (lane & 15) < 4) ids[(size_t)g * 4 + (lane & 15)] = res;
+    }
+    step4_call_enc<false, 0>(Ep, 0ull, flags, g_base, g_end, 1u, 0ull, 0xFFFFFFFFu, out, reinterpret_cast<const uint64_t*>(ids));
+}
 // the same as tickets (see k_step4_queue): a quad's chunks - its records, lists and tensor rows - stay on one XCD
 template <int POL>
 __global__ __launch_bounds__(64, RMJ_STEP4_ENC_WAVES) void k_step4_queue_enc(const Env* __restrict__ Ep, uint64_t policy_seed, uint32_t flags, uint32_t n_games,

@@ -233,6 +233,26 @@ class TorchVecEnv:
         self.sync()
         return self._obs
 
+    def step_sample_obs(self, logits=None, seed=0, auto_reset=True):
+        """sample_ids(logits, seed) + step_obs(ids) as ONE launch (rmj_step_sample_encode_device): returns (ids [n, 4] int32 - the ids the
+        two calls would have produced -, the resident tensor [n, 4, 74, W] with the rows of the seats that act next).  logits: float32
+        [n, 4, A'] (A' >= 82; 60 in 3P) on this device, or None for the uniform policy.  Base encoding only."""
+        if self.extended:
+            raise vecenv.RmjError("step_sample_obs() covers Observation.encode(); use sample_ids() + step() + obs() for encode_extended()")
+        t = self.torch
+        if not hasattr(self, "_ids"):
+            self._ids = t.full((self.n, 4), -1, dtype=t.int32, device=self.device)
+        ptr, stride = None, 0
+        if logits is not None:
+            assert logits.dtype == t.float32 and logits.is_contiguous() and tuple(logits.shape[:2]) == (self.n, 4)
+            ptr, stride = C.c_void_p(logits.data_ptr()), int(logits.shape[2])
+            if not self.shared:
+                t.cuda.current_stream(self.device).synchronize()
+        vecenv._chk(self.env.L.rmj_step_sample_encode_device(self.env.h, ptr, stride, int(seed) & 0xFFFFFFFFFFFFFFFF, int(auto_reset),
+                                                             C.c_void_p(self._ids.data_ptr()), C.c_void_p(self._obs_buf.data_ptr())))
+        self.sync()
+        return self._ids, self._obs
+
     def bind_stream(self, stream=None):
         """Issue the library's further work on `stream` (a torch.cuda.Stream; default: torch's current stream of the device) -
         rmj_set_stream.  Work already issued is waited for first.  This is what puts the environment INSIDE a HIP graph: bind the

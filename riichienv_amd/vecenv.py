@@ -27,7 +27,7 @@ EXPORTS = [
     "rmj_get_waits", "rmj_get_scores", "rmj_get_ranks", "rmj_get_step_counts", "rmj_total_steps", "rmj_peek_state",
     "rmj_poke_state", "rmj_get_event_counts", "rmj_get_events", "rmj_format_event", "rmj_eval_hands",
     "rmj_agari_counts", "rmj_calculate_score", "rmj_shanten", "rmj_effective_tiles", "rmj_best_ukeire", "rmj_apply_events", "rmj_device_views", "rmj_step_ids_device", "rmj_clone", "rmj_copy_games", "rmj_copy_games_device",
-    "rmj_scores_device", "rmj_sync", "rmj_set_stream", "rmj_encode", "rmj_encode_device", "rmj_encode_extended", "rmj_encode_extended_device", "rmj_encode_aux", "rmj_encode_aux_device", "rmj_encode_seq", "rmj_encode_seq_device", "rmj_bench_rollout", "rmj_time_rollout", "rmj_step_greedy", "rmj_time_rollout_greedy", "rmj_time_rollout_encode", "rmj_step_ids_encode_device", "rmj_set_encode_row_stride", "rmj_bench_hand_kernel", "rmj_points_device", "rmj_get_points", "rmj_get_legal_compact", "rmj_get_wall_digest", "rmj_get_wall_digests",
+    "rmj_scores_device", "rmj_sync", "rmj_set_stream", "rmj_encode", "rmj_encode_device", "rmj_encode_extended", "rmj_encode_extended_device", "rmj_encode_aux", "rmj_encode_aux_device", "rmj_encode_seq", "rmj_encode_seq_device", "rmj_bench_rollout", "rmj_time_rollout", "rmj_step_greedy", "rmj_time_rollout_greedy", "rmj_time_rollout_encode", "rmj_step_ids_encode_device", "rmj_step_sample_encode_device", "rmj_set_encode_row_stride", "rmj_bench_hand_kernel", "rmj_points_device", "rmj_get_points", "rmj_get_legal_compact", "rmj_get_wall_digest", "rmj_get_wall_digests",
     "rmj_bench_rollout_validated", "rmj_bench_encode", "rmj_set_rollout_streams", "rmj_total_full_path", "rmj_bench_device_alloc", "rmj_bench_device_free", "rmj_bench_device_sync",
     "rmj_random_actions_device", "rmj_peek_outputs", "rmj_sample_ids_device",
     "rmj_encode_seq_delta", "rmj_encode_seq_delta_device", "rmj_step_random_encode",
@@ -129,6 +129,7 @@ def load_lib():
     L.rmj_bench_hand_kernel.argtypes = [C.c_int, C.c_int, vp, vp, C.c_uint32, C.c_int, C.c_uint32, C.POINTER(C.c_double)]
     L.rmj_set_encode_row_stride.argtypes = [vp, C.c_uint32]
     L.rmj_step_ids_encode_device.argtypes = [vp, vp, C.c_int, vp]
+    L.rmj_step_sample_encode_device.argtypes = [vp, vp, C.c_uint32, C.c_uint64, C.c_int, vp, vp]
     L.rmj_time_rollout_encode.argtypes = [vp, C.c_uint64, C.c_uint32, vp, C.POINTER(abi.BenchResult)]
     L.rmj_time_rollout_greedy.argtypes = [vp, C.c_uint64, C.c_uint32, C.c_uint32, C.POINTER(abi.BenchResult)]
     L.rmj_bench_encode.argtypes = [vp, C.c_int, C.c_int, vp, C.c_uint32, C.POINTER(C.c_double)]

@@ -71,6 +71,26 @@ def run_one_launch(n, pad=False):
           f"loop {steps / (t1 - t0) / 1e6:.1f} M env.step/s, {(t1 - t0) / K * 1e3:.2f} ms per iteration")
 
 
+def run_sample_step_one_launch(n, pad=True):
+    """the loop with the policy's draw, the step and the next observations as ONE launch per iteration (TorchVecEnv.step_sample_obs ->
+    rmj_step_sample_encode_device): the whole environment side of an iteration between two policy forward passes"""
+    env = TorchVecEnv(n, game_mode=2, seed=0, share_stream=True, pad_rows=pad)
+    env.obs(only_active=True)
+    for k in range(20):
+        env.step_sample_obs(None, seed=k + 1)
+    torch.cuda.synchronize()
+    steps0 = env.env.total_steps()
+    K = 100
+    t0 = time.perf_counter()
+    for k in range(K):
+        env.step_sample_obs(None, seed=100 + k)
+    torch.cuda.synchronize()
+    t1 = time.perf_counter()
+    steps = env.env.total_steps() - steps0
+    print(f"games {n} channels 74 sampler + step + encode as ONE launch (rmj_step_sample_encode_device){', rows padded to 256 B' if pad else ''}, shared stream: "
+          f"loop {steps / (t1 - t0) / 1e6:.1f} M env.step/s, {(t1 - t0) / K * 1e3:.2f} ms per iteration")
+
+
 def run_parts_one_launch(n, parts):
     """shards on streams, step + encode as one launch per shard and iteration"""
     from riichienv_amd.torch_env import ShardedTorchVecEnv
@@ -185,6 +205,7 @@ def main():
     if not ext:
         run_one_launch(n)
         run_one_launch(n, pad=True)
+        run_sample_step_one_launch(n)
         for parts in (2, 4):
             run_parts(n, parts)
         run_parts(n, 4, compact=True)

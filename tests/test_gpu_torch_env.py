@@ -352,3 +352,31 @@ def test_ids_without_a_legal_action_are_illegal_actions(mode):
     assert bad > 20
     for g, o in enumerate(games):
         assert env.env.mjai_log(g) == o.log(), g
+
+
+@pytest.mark.parametrize("mode", [2, 5])
+def test_step_sample_obs_equals_sample_then_step_obs(mode):
+    """rmj_step_sample_encode_device: the policy's draw, the step and the next observations as ONE launch give the ids, the tensors and the
+    states of sample_ids(logits, seed) followed by step_obs(ids), with and without logits."""
+    import torch
+
+    from riichienv_amd.torch_env import TorchVecEnv
+
+    n = 2050
+    a = TorchVecEnv(n, game_mode=mode, seed=31)
+    b = TorchVecEnv(n, game_mode=mode, seed=31)
+    a.obs(only_active=True); b.obs(only_active=True)
+    g = torch.Generator(device="cpu")
+    g.manual_seed(4)
+    for k in range(90):
+        logits = None if k % 3 == 0 else (torch.randn((n, 4, 82), generator=g) * 2.0).cuda()
+        ids_a = a.sample_ids(logits, seed=1000 + k).clone()
+        xa = a.step_obs(ids_a)
+        ids_b, xb = b.step_sample_obs(logits, seed=1000 + k)
+        assert torch.equal(ids_a, ids_b), k
+        assert torch.equal(xa, xb), k
+    assert (a.env.step_counts() == b.env.step_counts()).all() and (a.env.scores() == b.env.scores()).all()
+    la, ca = a.env.legal()
+    lb, cb = b.env.legal()
+    assert (ca == cb).all() and (la == lb).all() and (a.env.mask() == b.env.mask()).all()
+    assert int(a.env.step_counts().sum()) > 80 * n

@@ -370,7 +370,15 @@ struct EvalShared {
     alignas(16) uint32_t out[4][16];
 };
 static_assert(sizeof(RmjHandCase) == 88 && sizeof(RmjHandResult) == 64, "k_eval_hands stages cases / results by these sizes");
-__global__ __launch_bounds__(256) void k_eval_hands(const RmjHandCase* cases, uint32_t n, RmjHandResult* out) {
+#ifndef RMJ_EVAL_WAVES
+#define RMJ_EVAL_WAVES 6   /* 129 VGPR left alone = three waves per SIMD: 0.72 G hands/s; four 0.84, five 0.906, six 0.91-0.92, seven 0.905, eight 0.84 */
+#endif
+#if RMJ_EVAL_WAVES > 0
+#define RMJ_EVAL_OCC __attribute__((amdgpu_waves_per_eu(RMJ_EVAL_WAVES, RMJ_EVAL_WAVES)))
+#else
+#define RMJ_EVAL_OCC
+#endif
+__global__ __launch_bounds__(256) RMJ_EVAL_OCC void k_eval_hands(const RmjHandCase* cases, uint32_t n, RmjHandResult* out) {
     __shared__ EvalShared shw[WPB];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, r = lane & 15, rb = lane & 48, row = lane >> 4;
     const uint32_t k0 = (blockIdx.x * WPB + wave) * 4u;   // first hand of the wave

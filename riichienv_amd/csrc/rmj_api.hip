@@ -50,9 +50,10 @@ static inline dim3 step_grid(uint32_t n) { return dim3((n + RMJ_STEP_WPB - 1) / 
 #define RMJ_SPLIT_MIN_PART 8192u   // games per part at least
 #define RMJ_MAX_ROLLOUT_STREAMS 8
 // games per wave by batch size (STEP_F_ROWS_SHIFT; profiles/r04_rows_sweep.txt, fused 4p-red-single rollouts, M env.step/s at 4 | 2 | 1 games
-// per wave: 2 048 games 226 | 254 | 278, 4 096: 435 | 478 | 456, 8 192: 814 | 770 | 522, 16 384: 1 288 | 882 | 599)
-#define RMJ_ROWS1_MAX_GAMES 2560u
-#define RMJ_ROWS2_MAX_GAMES 6144u
+// per wave: 2 048 games 226 | 254 | 278, 4 096: 435 | 478 | 456, 8 192: 814 | 770 | 522, 16 384: 1 288 | 882 | 599; round 5, profiles/r05_rows_sweep.txt:
+// 2 048: 236 | 272 | 301, 3 072: 345 | 373 | 416, 4 096: 455 | 505 | 492, 6 144: 632 | 692 | 589, 8 192: 845 | 823 | 567)
+#define RMJ_ROWS1_MAX_GAMES 3584u
+#define RMJ_ROWS2_MAX_GAMES 7168u
 
 __device__ __forceinline__ void load_state(GState& S, const GState* src, int lane) {
     if (lane < (int)(sizeof(GState) / 16)) reinterpret_cast<uint4*>(&S)[lane] = reinterpret_cast<const uint4*>(src)[lane];

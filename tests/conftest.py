@@ -8,7 +8,7 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 GOLDEN = os.path.join(ROOT, "tests", "golden")
-# The library picks the games per wave by batch size (one or two below 6 144 games); the suite's small batches keep exercising the
+# The library picks the games per wave by batch size (one or two below 7 168 games); the suite's small batches keep exercising the
 # four-games-per-wave layout every production batch runs in - tests/test_gpu_rows.py covers the other two.
 os.environ.setdefault("RMJ_ROWS", "4")
 

@@ -19,7 +19,7 @@ def test_rollouts_with_fewer_games_per_wave(rows, mode, greedy, monkeypatch):
     if rows:
         monkeypatch.setenv("RMJ_ROWS", rows)
     else:
-        monkeypatch.delenv("RMJ_ROWS", raising=False)      # the default rule: 2 560 games and fewer -> one game per wave
+        monkeypatch.delenv("RMJ_ROWS", raising=False)      # the default rule: 3 584 games and fewer -> one game per wave
     n, seed, pseed, rate = 203, 61 + mode, 17, 96          # (a ragged last wave)
     env = vecenv.VecRiichiEnv(n, game_mode=mode, seed=seed, event_ring=4096)
     games = [oracle.Game(game_mode=mode, seed=game_seed(seed, g)) for g in range(n)]

@@ -60,6 +60,9 @@ __device__ __forceinline__ uint32_t r4_rows(uint32_t flags) {
 #ifndef RMJ_FULL_PRIO
 #define RMJ_FULL_PRIO 0
 #endif
+#ifndef RMJ_CHI_SKIP
+#define RMJ_CHI_SKIP 1   /* chi lists: a pattern no row of the wave can form is skipped as a whole (0: A/B) */
+#endif
 #ifndef RMJ_HEAVY_TENPAI
 #define RMJ_HEAVY_TENPAI 1   /* heavy-first order of the per-step kernel: games with a seat that waits without a riichi count as heavy (0: A/B) */
 #endif
@@ -918,6 +921,9 @@ __device__ __forceinline__ void r4_resolve_discard(R4& q, int pid, int tile, boo
                     const bool pat_ok = k == 0 ? (r9 >= 2) : (k == 1 ? (r9 >= 1 && r9 <= 7) : (r9 <= 6));
                     const uint32_t ma = k == 0 ? m_m2 : (k == 1 ? m_m1 : m_p1);
                     const uint32_t mbb = k == 0 ? m_m1 : (k == 1 ? m_p1 : m_p2);
+#if RMJ_CHI_SKIP
+                    if (!__ballot(pat_ok && ma != 0u && mbb != 0u)) continue;   // (wave-uniform) no row of the wave holds this pattern's two tiles: nothing to list
+#endif
                     int forb = __popc(m_0);
                     if (k == 2 && r9 <= 5) forb += __popc(m_p3);
                     if (k == 0 && r9 >= 3) forb += __popc(m_m3);

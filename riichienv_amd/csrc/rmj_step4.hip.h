@@ -254,33 +254,27 @@ __device__ __forceinline__ int r4_key(int t34) {
     return t34 < 27 ? t34 + 7 * ((t34 >= 9) + (t34 >= 18)) : 48 + 3 * (t34 - 27);
 }
 // Shape numbers of a SORTED run of `n` tiles of P's hand (13-tile hands are kept sorted; a 14th, drawn tile sits behind
-// them) plus an optional extra tile type `ex` (-1: none), without building a histogram: lane r looks at its two sorted
-// neighbours (DPP row shifts) and at the extra tile.
+// them) without building a histogram: lane r looks at its two sorted neighbours (DPP row shifts).
 struct R4Shape {
     int iso;      // tiles held exactly once with nothing within two ranks (isolated_tiles())
     int yaochu;   // kinds of terminals and honors
     int kinds;    // distinct tile types
     int pairs;    // types held at least twice
 };
-__device__ __forceinline__ R4Shape r4_shape_sorted(const R4& q, const PState* P, int n, int ex) {
+__device__ __forceinline__ R4Shape r4_shape_sorted(const R4& q, const PState* P, int n) {
     const int r = q.r, rb = q.rb;
     const bool in = r < n;
     const int t = in ? (int)(P->hand[r] >> 2) : 99;
     const int k = in ? r4_key(t) : 1000;
     const int kp = __builtin_amdgcn_update_dpp(-1000, k, 0x111 /* row_shr:1 */, 0xf, 0xf, false);   // lane r - 1 (row start: -1000)
-    int kn = __builtin_amdgcn_update_dpp(1000, k, 0x101 /* row_shl:1 */, 0xf, 0xf, false);           // lane r + 1 (row end: 1000)
-    const int ke = ex >= 0 ? r4_key(ex) : -2000;
+    const int kn = __builtin_amdgcn_update_dpp(1000, k, 0x101 /* row_shl:1 */, 0xf, 0xf, false);     // lane r + 1 (row end: 1000)
     const bool term = t >= 27 || t == 0 || t == 8 || t == 9 || t == 17 || t == 18 || t == 26;
     const bool first = in && k != kp, last_of_kind = in && k != kn;
-    const uint32_t ex_close = rballot(in && (k - ke <= 2 && ke - k <= 2), rb);     // some held tile within two of the extra one
-    const uint32_t ex_same = rballot(in && k == ke, rb);
-    const uint32_t ex_single = rballot(in && k == ke && first && last_of_kind, rb);   // the extra tile makes a pair of a single
-    R4Shape o;
-    o.iso = __popc(rballot(in && k - kp > 2 && kn - k > 2 && (k - ke > 2 || ke - k > 2), rb)) + ((ex >= 0 && !ex_close) ? 1 : 0);
-    const bool ex_term = ex >= 27 || ex == 0 || ex == 8 || ex == 9 || ex == 17 || ex == 18 || ex == 26;
-    o.yaochu = __popc(rballot(first && term, rb)) + ((ex >= 0 && ex_term && !ex_same) ? 1 : 0);
-    o.kinds = __popc(rballot(first, rb)) + ((ex >= 0 && !ex_same) ? 1 : 0);
-    o.pairs = __popc(rballot(first && !last_of_kind, rb)) + (ex_single ? 1 : 0);
+    R4Shape o;   // (round 5: the "one extra tile" form of rounds 3-4 had a single caller without an extra tile)
+    o.iso = __popc(rballot(in && k - kp > 2 && kn - k > 2, rb));
+    o.yaochu = __popc(rballot(first && term, rb));
+    o.kinds = __popc(rballot(first, rb));
+    o.pairs = __popc(rballot(first && !last_of_kind, rb));
     return o;
 }
 // One suit word of a hand judged on its own (agari.rs:183-245, boolean): `tot` = its tile count mod 3; 0: sets only, 2: a pair and
@@ -397,7 +391,7 @@ __device__ __noinline__ uint64_t r4_waits_probe(uint32_t ha, uint32_t hb, uint32
 template <bool RICH>
 __device__ __forceinline__ void r4_fill_waits13(R4& q, PState* P, int n) {
     uint64_t W = 0ull;
-    const R4Shape sp = r4_shape_sorted(q, P, n, -1);
+    const R4Shape sp = r4_shape_sorted(q, P, n);
     const int iso = sp.iso, yaochu = sp.yaochu;
     int lb = iso >= 6 ? 4 : (iso == 5 ? 3 : (iso == 4 ? 2 : 0));
     const int len3 = n / 3;

@@ -60,6 +60,9 @@ __device__ __forceinline__ uint32_t r4_rows(uint32_t flags) {
 #ifndef RMJ_FULL_PRIO
 #define RMJ_FULL_PRIO 0
 #endif
+#ifndef RMJ_RON_SKIP
+#define RMJ_RON_SKIP 1   /* Ron eligibility: skipped when no seat of any game of the wave waits on its game's discard (0: A/B) */
+#endif
 #ifndef RMJ_CHI_SKIP
 #define RMJ_CHI_SKIP 1   /* chi lists: a pattern no row of the wave can form is skipped as a whole (0: A/B) */
 #endif
@@ -827,15 +830,18 @@ __device__ __forceinline__ void r4_resolve_discard(R4& q, int pid, int tile, boo
     const uint32_t qfl = S4.flags;
     const bool holds13 = other && (S4.hand_len + 3 * S4.n_melds == 13);
     const uint64_t W = holds13 ? S4.waits13 : 0ull;
-    const uint64_t dtm = S4.discard_type_mask;
-    const bool in_discards = (dtm >> tt) & 1ull;
-    const bool in_missed = (qfl & PF_MISSED_DOUJUN) || ((qfl & PF_RIICHI_DECLARED) && (qfl & PF_MISSED_RIICHI));
-    const bool furiten = (W & dtm) != 0ull || (qfl & (PF_MISSED_RIICHI | PF_MISSED_DOUJUN));
     const uint32_t riichi_m = rballot(r < 4 && (qfl & PF_RIICHI_DECLARED), rb) & 0xFu;
     // A seat in riichi that waits on the tile and is not furiten may win without a look at its yaku (riichi is one, the shape is
     // the cached wait: calc.is_win of legal_actions.rs:254-310 is true): RICH offers that Ron here; any other seat that could
     // win needs the evaluator - full path.
-    uint32_t ron_m = rballot(other && !in_discards && !in_missed && !furiten && ((W >> tt) & 1ull), rb) & 0xFu;
+    uint32_t ron_m = 0u;
+    if (!RMJ_RON_SKIP || __ballot(((W >> tt) & 1ull) != 0ull)) {   // (wave-uniform) nobody in the wave's games waits on its game's tile (nearly every discard): no furiten arithmetic
+        const uint64_t dtm = S4.discard_type_mask;
+        const bool in_discards = (dtm >> tt) & 1ull;
+        const bool in_missed = (qfl & PF_MISSED_DOUJUN) || ((qfl & PF_RIICHI_DECLARED) && (qfl & PF_MISSED_RIICHI));
+        const bool furiten = (W & dtm) != 0ull || (qfl & (PF_MISSED_RIICHI | PF_MISSED_DOUJUN));
+        ron_m = rballot(other && !in_discards && !in_missed && !furiten && ((W >> tt) & 1ull), rb) & 0xFu;
+    }
     if (ron_m && !RICH) { R4BAIL(q, 9); return; }
     if (RICH && (ron_m & ~riichi_m)) {
         // seats that wait on the tile without a riichi: their yaku decide.  Pass 1 pauses here - the evaluator runs between the passes

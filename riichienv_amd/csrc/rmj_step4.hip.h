@@ -49,14 +49,6 @@ __device__ __forceinline__ uint32_t r4_rows(uint32_t flags) {
 #ifndef RMJ_ROW_ROUND_END
 #define RMJ_ROW_ROUND_END 1   /* exhaustive draws, next rounds and restarts stay in tier 0 (r4_round_end); 0: they enter the full path at the exit */
 #endif
-#ifdef RMJ_CUTS   /* instruction accounting build (scripts/valu_sections4.py, scripts/bail_census.py) */
-/* (an asm s_endpgm, not __builtin_amdgcn_endpgm: the builtin is noreturn, and a noreturn call inside divergent control flow lets the
-   compiler drop the EXEC restore behind the region - rows that were masked off there stayed off for the rest of the step in the greedy
-   instantiation: ADVICE r3 "mark 43", journal r04 section 16) */
-#define R4M(id) do { if (rmj::g_cut == (id)) asm volatile("s_endpgm" ::: "memory"); } while (0)   /* the wave ends at mark g_cut */
-#define R4BAIL(q, id) do { (q).bail = true; if ((q).r == 0) atomicAdd(&rmj::g_bail_reason[id], 1u); } while (0)   /* bail census */
-#else
-#define R4M(id) do {} while (0)
 #ifndef RMJ_FULL_PRIO
 #define RMJ_FULL_PRIO 0
 #endif
@@ -69,6 +61,14 @@ __device__ __forceinline__ uint32_t r4_rows(uint32_t flags) {
 #ifndef RMJ_HEAVY_TENPAI
 #define RMJ_HEAVY_TENPAI 1   /* heavy-first order of the per-step kernel: games with a seat that waits without a riichi count as heavy (0: A/B) */
 #endif
+#ifdef RMJ_CUTS   /* instruction accounting build (scripts/valu_sections4.py, scripts/bail_census.py) */
+/* (an asm s_endpgm, not __builtin_amdgcn_endpgm: the builtin is noreturn, and a noreturn call inside divergent control flow lets the
+   compiler drop the EXEC restore behind the region - rows that were masked off there stayed off for the rest of the step in the greedy
+   instantiation: ADVICE r3 "mark 43", journal r04 section 16) */
+#define R4M(id) do { if (rmj::g_cut == (id)) asm volatile("s_endpgm" ::: "memory"); } while (0)   /* the wave ends at mark g_cut */
+#define R4BAIL(q, id) do { (q).bail = true; if ((q).r == 0) atomicAdd(&rmj::g_bail_reason[id], 1u); } while (0)   /* bail census */
+#else
+#define R4M(id) do {} while (0)
 #ifdef RMJ_CENSUS   /* bail census on the shipped instruction stream (no accounting marks): scripts/bail_census.py; the reason travels in a register and is counted where the full path is entered */
 #define R4BAIL(q, id) do { (q).bail = true; (q).why = (id); } while (0)
 #elif defined(RMJ_TL4)

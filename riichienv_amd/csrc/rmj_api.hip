@@ -2963,6 +2963,16 @@ extern "C" int rmj_prof_bail_census(uint32_t* out32, int reset) {
 }
 #endif
 
+
+#ifdef RMJ_DEBUG_HWID
+// debugging build only: HW ids / times of the waves of the last k_step4_act_enc launch (4 u64 per block)
+extern "C" int rmj_debug_hwid_fetch(uint64_t* out, uint32_t n_blocks) {
+    HIPCHK(hipDeviceSynchronize());
+    HIPCHK(hipMemcpyFromSymbol(out, HIP_SYMBOL(rmj::g_dbg_hwid), (size_t)(n_blocks < RMJ_DEBUG_HWID ? n_blocks : RMJ_DEBUG_HWID) * 32));
+    return RMJ_OK;
+}
+#endif
+
 #ifdef RMJ_TL4
 // timeline build only (scripts/timeline4.py): rows of the waves of the last launch of k_step4<false> (allocates on first call)
 int rmj_tl4_fetch(uint64_t* out, uint32_t n_waves) {

@@ -123,6 +123,9 @@ __device__ unsigned long long* g_tl4;
 #else
 #define TLF(c, k) do {} while (0)
 #endif
+#ifdef RMJ_DEBUG_HWID   /* value = blocks recorded; see k_step4_act_enc */
+__device__ unsigned long long g_dbg_hwid[4 * RMJ_DEBUG_HWID];
+#endif
 #ifdef RMJ_QTL   /* ticket timeline build of k_step4_queue (-DRMJ_QTL, scripts/timeline_queue.py, never the shipped library) */
 __device__ unsigned long long* g_qtl;
 #define RMJ_QTL_ROW 256   /* u64 per wave: [0] kernel entry, [1] exit, [2] tickets, then 4 per ticket */

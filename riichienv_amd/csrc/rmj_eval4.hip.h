@@ -22,11 +22,7 @@
 namespace rmj {
 
 // ---------------------------------------------------------------- row helpers (r = lane & 15, rb = lane & 48)
-__device__ __forceinline__ uint32_t e4_ballot(bool p, int rb) {
-    const uint64_t b = __ballot(p);
-    const uint32_t w = (rb & 32) ? (uint32_t)(b >> 32) : (uint32_t)b;
-    return __builtin_amdgcn_ubfe(w, (uint32_t)(rb & 16), 16u);
-}
+__device__ __forceinline__ uint32_t e4_ballot(bool p, int rb) { return row_ballot16(p, rb); }   // (one byte permute: see row_ballot16)
 __device__ __forceinline__ int e4_bc(int v, int src_lane) { return __builtin_amdgcn_ds_bpermute(src_lane << 2, v); }
 __device__ __forceinline__ uint32_t e4_rsum(uint32_t v, int rb) { return (uint32_t)e4_bc((int)row_sum16(v), rb + 15); }
 __device__ __forceinline__ uint32_t e4_ror(uint32_t v, int rb) {

@@ -116,13 +116,10 @@ __shared__ Quad4Shared g_q4;
 __shared__ uint32_t g_qtl_cnt[2];   // ticket timeline build: calls of the step function in the current ticket, and the live rows summed over them
 #endif
 
-// ballot of the lane's own row: pick the half of the 64-bit mask (one select on the lane-constant "upper half" predicate),
-// then a 16-bit field extract at bit 0 / 16 - three vector instructions instead of a 64-bit shift by a lane-varying amount
-__device__ __forceinline__ uint32_t rballot(bool p, int rb) {
-    const uint64_t b = __ballot(p);
-    const uint32_t w = (rb & 32) ? (uint32_t)(b >> 32) : (uint32_t)b;
-    return __builtin_amdgcn_ubfe(w, (uint32_t)(rb & 16), 16u);
-}
+// ballot of the lane's own row (round 6: one byte permute of the two halves, row_ballot16 in rmj_hand.hip.h - the select + bit-field
+// extract of rounds 2-5 was compiled to a 64-bit shift by a vector register, which gfx950 gets wrong now and then when that register is
+// the wave's last allocated one)
+__device__ __forceinline__ uint32_t rballot(bool p, int rb) { return row_ballot16(p, rb); }
 __device__ __forceinline__ int rbc(int v, int src_lane) { return __builtin_amdgcn_ds_bpermute(src_lane << 2, v); }
 __device__ __forceinline__ uint64_t rbc64(uint64_t v, int src_lane) {
     return (uint64_t)(uint32_t)rbc((int)(uint32_t)v, src_lane) | ((uint64_t)(uint32_t)rbc((int)(uint32_t)(v >> 32), src_lane) << 32);
@@ -3095,10 +3092,27 @@ __global__ __launch_bounds__(64, RMJ_STEP4_ENC_WAVES) void k_step4_act_enc(const
     if (blockIdx.x & 1u)
         for (int k = 0; k < RMJ_ACT_ENC_STAGGER; k++) __builtin_amdgcn_s_sleep(127);
 #endif
+#ifdef RMJ_DEBUG_PAD_VGPR   /* debugging aid (round 6, journal r06 section 1): -DRMJ_DEBUG_PAD_VGPR=95 makes the kernel NAME v95, so its waves are allocated 96 vector registers while the out-of-line step compiles to the same instructions as without it */
+#define RMJ_STR2(x) #x
+#define RMJ_STR(x) RMJ_STR2(x)
+    asm volatile("v_mov_b32 v" RMJ_STR(RMJ_DEBUG_PAD_VGPR) ", 0" ::: "v" RMJ_STR(RMJ_DEBUG_PAD_VGPR));
+#endif
+#ifdef RMJ_DEBUG_HWID   /* debugging aid (round 6, scripts/debug_scratch_poison.py --hwid; value = blocks recorded): where and when every wave of the launch ran - taken around the call, the out-of-line function itself is untouched */
+    const unsigned long long hw_t0 = __builtin_amdgcn_s_memrealtime();
+#endif
 #ifdef RMJ_DEBUG_ACT_ENC_INLINE
     step4_enc_impl<false, 0>(Ep, 0ull, flags, g_base, g_end, 1u, 0ull, 0xFFFFFFFFu, out, actions);
 #else
     step4_call_enc<false, 0>(Ep, 0ull, flags, g_base, g_end, 1u, 0ull, 0xFFFFFFFFu, out, actions);
+#endif
+#ifdef RMJ_DEBUG_HWID
+    if ((threadIdx.x & 63) == 0 && blockIdx.x < RMJ_DEBUG_HWID) {
+        unsigned long long* o = rmj::g_dbg_hwid + (size_t)blockIdx.x * 4;
+        o[0] = hw_t0;
+        o[1] = __builtin_amdgcn_s_memrealtime();
+        o[2] = (unsigned long long)(uint32_t)__builtin_amdgcn_s_getreg((31 << 11) | 4) | ((unsigned long long)(uint32_t)__builtin_amdgcn_s_getreg((31 << 11) | 20) << 32);   // HW_ID | XCC_ID
+        o[3] = (unsigned long long)(uint32_t)__builtin_amdgcn_s_getreg((31 << 11) | 5) | ((unsigned long long)(uint32_t)__builtin_amdgcn_s_getreg((31 << 11) | 6) << 32);    // GPR_ALLOC | LDS_ALLOC
+    }
 #endif
 }
 // ... with the policy's draw in front (rmj_step_sample_encode_device): the wave samples one id per acting seat of its own four games from the

@@ -380,3 +380,32 @@ def test_step_sample_obs_equals_sample_then_step_obs(mode):
     lb, cb = b.env.legal()
     assert (ca == cb).all() and (la == lb).all() and (a.env.mask() == b.env.mask()).all()
     assert int(a.env.step_counts().sum()) > 80 * n
+
+
+@pytest.mark.parametrize("mode", [2, 5])
+def test_one_launch_paths_with_several_waves_per_simd_behind_foreign_kernels(mode):
+    """Regression of the round-5 flake (docs/journal_r06.md section 1): rmj_step_ids_encode_device / rmj_step_sample_encode_device must equal
+    step() + obs() at EVERY step when their launch has more than one wave per SIMD (8 192 games = 2 048 waves on 1 024 SIMDs) and runs right
+    behind another library's kernels (torch's copies) - the build that drew the row ballot's shift amount into the last allocated register
+    dropped list entries in ~40 games per step under exactly these conditions, in waves that were not the first of their SIMD."""
+    torch = pytest.importorskip("torch")
+    from riichienv_amd.torch_env import TorchVecEnv
+
+    n = 8192
+    a = TorchVecEnv(n, game_mode=mode, seed=43, share_stream=True)
+    b = TorchVecEnv(n, game_mode=mode, seed=43, share_stream=True)
+    c = TorchVecEnv(n, game_mode=mode, seed=43, share_stream=True)
+    for e in (a, b, c):
+        e.obs(only_active=True)
+    for k in range(60):
+        ids = b.sample_ids(seed=k).clone()
+        oa = a.step_obs(ids.clone())                       # one launch, first behind the copy
+        ic, oc = c.step_sample_obs(seed=k)                 # one launch, the draw inside
+        b.step(ids)
+        ob = b.obs(only_active=True)
+        torch.cuda.synchronize()
+        assert torch.equal(ic, ids), k
+        for name, e, o in (("step_obs", a, oa), ("step_sample_obs", c, oc)):
+            assert torch.equal(e.nlegal, b.nlegal), (name, k, (e.nlegal != b.nlegal).any(1).nonzero().flatten()[:8].tolist())
+            assert torch.equal(e.mask, b.mask) and torch.equal(o, ob) and torch.equal(e.legal, b.legal), (name, k)
+    assert (a.env.step_counts() == b.env.step_counts()).all() and (c.env.step_counts() == b.env.step_counts()).all()

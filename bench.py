@@ -310,11 +310,11 @@ def rollout_roofline(r, games, steps, sanma, encode=False, acting=0, greedy=Fals
             "games_per_launch": games_per_launch, "steps_per_launch": steps_per_launch, "launches_in_flight": in_flight}
 
 
-def config_leg(vecenv, abi, shard, dev, name, games, mode, steps, policy_seed, device, rank, encode=False, preroll=PREROLL):
+def config_leg(vecenv, abi, shard, dev, name, games, mode, steps, policy_seed, device, rank, encode=False, preroll=PREROLL, rule_extra=0):
     """One BASELINE.json configuration as a steady-state leg of its own: a fresh environment, `preroll` untimed steps, then `steps`
     (>= 300) timed steps of the device RandomAgent rollout between device-wide synchronisations."""
     sanma = mode >= 3
-    env = vecenv.VecRiichiEnv(games, game_mode=mode, seed=0, rule_bits=abi.RULE_TENHOU, device=device,
+    env = vecenv.VecRiichiEnv(games, game_mode=mode, seed=0, rule_bits=abi.RULE_TENHOU | rule_extra, device=device,
                               game_offset=shard.shard_offset(rank, games), event_ring=64)
     env.reset()
     env.step_random(policy_seed, preroll, auto_reset=True)
@@ -616,6 +616,15 @@ def main(argv=None):
                                   "kernel": fused_kernel_name(rl), "full_path_frac": (env.total_full_path() - lf0) / max(lmade, 1),
                                   "roofline": rollout_roofline(rl, args.games, kl, sanma),
                                   "what": f"the same rollout over {kl} steps as one launch, wall clock between device synchronisations"}
+        # the same workload with every wall dealt through the REFERENCE's seed -> wall chain (RMJ_RULE_REFERENCE_RNG: what compat.RiichiEnv(seed=...)
+        # and VecRiichiEnv(seeds=...) use by default; a base-seeded throughput run like this one keeps the build's own shuffle): a fresh
+        # environment, pre-rolled, 1 000 timed steps
+        if not args.reference_rng and not args.no_configs:
+            leg = config_leg(vecenv, abi, shard, dev, "reference_rng", args.games, args.mode, 1000, policy_seed, local_rank, rank,
+                             rule_extra=abi.RULE_REFERENCE_RNG)
+            leg["what"] = ("the headline workload with RMJ_RULE_REFERENCE_RNG: every round start deals through StdRng::seed_from_u64 (PCG32), ChaCha12, "
+                           "rand's chunked Fisher-Yates, salt and (on demand) the SHA-256 digest, state/wall.rs:36-67; compare with long_rollout")
+            extras["reference_rng"] = leg
         # every other single-GPU configuration of BASELINE.json, each a steady-state leg of its own (>= 300 timed steps)
         if args.games == 65536 and args.mode == 2 and not args.no_configs:
             extras["configs"] = [
@@ -642,7 +651,7 @@ def main(argv=None):
                        "sharding": "by game index, no collectives", "feature_tensor_output": bool(args.encode),
                        "parity": "bit-exact vs the oracle on identical walls; seed -> wall: " +
                                  ("the reference's StdRng / shuffle / salt chain (RMJ_RULE_REFERENCE_RNG)" if args.reference_rng else
-                                  "the build's own shuffle (the reference's chain is opt-in: RMJ_RULE_REFERENCE_RNG, DESIGN.md §6)")},
+                                  "the build's own shuffle (base-seeded throughput run; explicit per-game seeds and the drop-in shim deal the reference's chain, measured in the `reference_rng` leg: DESIGN.md §6)")},
             # proof that N processes took part: the rank ids the all_gather of the measurement returned, and each rank's own rate
             "ranks_seen": gm["ranks_seen"], "per_rank_value": gm["per_rank_value"], "per_rank_wall_s": gm["per_rank_wall_s"],
             "host_runtime": "torch.distributed (RCCL)" if dist is not None and not shared_gpus else ("torch.distributed (gloo)" if dist is not None else "none (C-ABI only)"),

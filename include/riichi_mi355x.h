@@ -62,7 +62,12 @@ enum { RMJ_MELD_CHI = 0, RMJ_MELD_PON = 1, RMJ_MELD_DAIMINKAN = 2, RMJ_MELD_ANKA
 /* Not a GameRule field: seed -> wall as the reference's crates define it (state/wall.rs:36-56: StdRng::seed_from_u64 =
  * PCG32 seed expansion + ChaCha12, SliceRandom::shuffle, salt = next_u64, wall_digest = SHA-256(salt || wall); see
  * rmj_get_wall_digest).  Without the bit the wall of a seed is the build's own counter-based permutation,
- * which costs nothing per round; with it a round start pays one serial Fisher-Yates pass. */
+ * which costs nothing per round; with it a round start pays one serial Fisher-Yates pass.
+ * STATUS OF THE CLAIM: the chain is restated from the published algorithms (rand 0.9 / rand_core 0.9 / chacha20 / sha2); ChaCha, StdRng's
+ * construction and SHA-256 are pinned on published vectors, seed_from_u64's PCG32 expansion and the index draws of shuffle on nothing outside
+ * this repository - equality of walls and digests with the Rust crates (rand 0.10 in the reference's Cargo.lock) is UNVERIFIED until one real
+ * (seed -> wall, salt, digest) vector printed by the reference is pinned in tests/golden/ref_rng_vectors.json (INTEGRATION.md has the Rust
+ * program; tests/test_oracle_ref_rng.py and tests/test_gpu_ref_rng.py consume it, and report xfail while it is absent). */
 #define RMJ_RULE_REFERENCE_RNG 256u
 #define RMJ_RULE_TENHOU (RMJ_RULE_SANCHAHO_DRAW | RMJ_RULE_KUIKAE_FORBIDDEN)          /* rule.rs:31-44 */
 #define RMJ_RULE_MJSOUL (1u | 2u | 4u | 8u | 16u | 32u | RMJ_RULE_KUIKAE_FORBIDDEN) /* rule.rs:46-57 */

@@ -377,13 +377,18 @@ class Observation:
 class RiichiEnv:
     """Scalar environment with the reference's method names, backed by one game on the GPU."""
 
-    def __init__(self, game_mode=None, skip_mjai_logging=False, seed=None, round_wind=None, rule=None, device=0):
+    def __init__(self, game_mode=None, skip_mjai_logging=False, seed=None, round_wind=None, rule=None, device=0, reference_rng=True):
+        """reference_rng (not a parameter of the reference; default on since round 6): RiichiEnv(seed=s) deals the walls the REFERENCE deals for s -
+        StdRng::seed_from_u64(splitmix64(s + hand_index)), rand's shuffle, salt, SHA-256 digest (state/wall.rs:36-67) - and `salt` / `wall_digest`
+        read like WallState's fields.  (The chain is restated from the published algorithms of rand 0.9 / rand_core 0.9 / chacha20 / sha2; its
+        primitives are pinned on published vectors, the seed expansion and the index draws on nothing outside this repository until
+        tests/golden/ref_rng_vectors.json exists - INTEGRATION.md has the 30-line Rust program that writes it.)  False: the build's own shuffle."""
         self._mode = vecenv._mode_id(game_mode)
         self._rule = rule or GameRule.default_tenhou()
         s = random.getrandbits(63) if seed is None else int(seed)
         self._v = vecenv.VecRiichiEnv(1, game_mode=self._mode, seeds=np.array([s], np.uint64), rule_bits=self._rule.bits(),
                                       skip_mjai_logging=skip_mjai_logging, round_wind=round_wind or 0, device=device,
-                                      event_ring=8192)
+                                      event_ring=8192, reference_rng=bool(reference_rng))
         self._seed, self._skip_log = (None if seed is None else int(seed)), bool(skip_mjai_logging)
         self._cursor = [0, 0, 0, 0]  # player_event_counts (state/mod.rs:211-218)
         self._applied = None         # host-side logs of apply_event / observe_event (see apply_event)
@@ -392,6 +397,17 @@ class RiichiEnv:
     @property
     def num_players(self):
         return self._np
+
+    @property
+    def salt(self):
+        """WallState.salt (state/wall.rs:15, 48-50): 16 hex digits of the current wall's shuffle; "" before a seeded shuffle, after a start_kyoku
+        event, or with reference_rng=False"""
+        return self._v.wall_digest(0)[0]
+
+    @property
+    def wall_digest(self):
+        """WallState.wall_digest (state/wall.rs:16, 51-55): SHA-256(salt || wall) as 64 hex digits; stale after a load_wall like the reference's"""
+        return self._v.wall_digest(0)[1]
 
     def clone(self):
         """RiichiEnv.clone / __copy__ / __deepcopy__ (env.rs:358-372): an independent environment in the same state"""

@@ -1009,7 +1009,6 @@ struct rmj_env {
     int queue_chunk = 32;      // calls per ticket (round 5: a ticket is a number of calls of the step function, profiles/r05_ticket_schedule_sweep.txt); RMJ_QUEUE_CHUNK at create, 0 = off (every wave keeps one quad for the rollout)
     hipEvent_t ev_time[2] = {nullptr, nullptr};   // rmj_time_rollout* / rmj_bench_rollout: created on first use, so that a timed region holds no event create / destroy
     uint32_t* d_qheads = nullptr;   // [8][RMJ_Q_STRIDE] ticket counters, one line per XCD
-    int q_cur = 0;                  // which of the two counter sets of the ticket rollout is zeroed and next in turn
     uint32_t q_slots_pol[2] = {0, 0};   // waves of k_step4_queue<policy> the device holds at once (the greedy instantiation is compiled for fewer)
     int queue_force = 0;            // RMJ_QUEUE_FORCE at create (tests): tickets for every batch of >= 64 quads
     uint32_t queue_skip_xcds = 0;   // test hook: XCDs whose waves leave the queue kernel at once (RMJ_QUEUE_TEST_SKIP_XCDS at create)
@@ -1593,29 +1592,27 @@ static int step_policy_impl(rmj_handle h, uint64_t policy_seed, uint32_t n_steps
         const dim3 grid((n + 3u) / 4u);
         if (rollout_queued(h, n_steps, pol)) {
             // ... or, for a long rollout of a batch that does not fill the chip a whole number of times, in (quad, chunk) tickets
-            // ticket counters (one line per XCD) + the quads' ticket counts, in THREE sets: two for this rollout, used in turn - the launch
-            // that works on one zeroes the other for its successor, so no memset sits between rollouts - and one for the step + encode
+            // ticket counters (one line per XCD) + the quads' ticket counts: one set for this rollout - zeroed once here, re-armed by every
+            // k_step4_fixup launch behind its ticket launch, so no memset sits between rollouts and a captured rollout can be replayed (round 6;
+            // round 5 alternated two sets from the host, which a graph replay of one launch found exhausted) - and one for the step + encode
             // rollout (which memsets its own); behind them the games' step counts of the running rollout, carried from ticket to ticket
             const size_t set_words = 8 * RMJ_Q_STRIDE + (size_t)grid.x;
             if (!h->d_qheads) {
                 HIPCHK(hipMalloc(&h->d_qheads, (3 * set_words + (size_t)grid.x * 4) * sizeof(uint32_t)));
                 HIPCHK(hipMemsetAsync(h->d_qheads, 0, 3 * set_words * sizeof(uint32_t), h->stream));
-                h->q_cur = 0;
             }
-            uint32_t* const heads = h->d_qheads + (size_t)h->q_cur * set_words;
+            uint32_t* const heads = h->d_qheads;
             uint32_t* const done = heads + 8 * RMJ_Q_STRIDE;
-            uint32_t* const next = h->d_qheads + (size_t)(1 - h->q_cur) * set_words;
             uint32_t* const d_qprog = h->d_qheads + 3 * set_words;   // (written before it is read)
-            h->q_cur = 1 - h->q_cur;
             const dim3 gq(grid.x < h->q_slots_pol[pol == 1 ? 1 : 0] ? grid.x : h->q_slots_pol[pol == 1 ? 1 : 0]);
             const dim3 gfix((grid.x + 63u) / 64u);
             const uint32_t chunk = rollout_chunk(h, n_steps);
             if (sanma) {
-                RMJ_LAUNCH_POL(rmj3, k_step4_queue, pol, gq, dim3(64), 0, h->stream, (const Env*)h->d_env, policy_seed, flags, n, n_steps, chunk, heads, done, h->queue_skip_xcds, d_qprog, (uint32_t)h->queue_tail, next, (uint32_t)set_words);
-                RMJ_LAUNCH_POL(rmj3, k_step4_fixup, pol, gfix, dim3(64), 0, h->stream, (const Env*)h->d_env, policy_seed, flags, n, n_steps, (const uint32_t*)done);
+                RMJ_LAUNCH_POL(rmj3, k_step4_queue, pol, gq, dim3(64), 0, h->stream, (const Env*)h->d_env, policy_seed, flags, n, n_steps, chunk, heads, done, h->queue_skip_xcds, d_qprog, (uint32_t)h->queue_tail);
+                RMJ_LAUNCH_POL(rmj3, k_step4_fixup, pol, gfix, dim3(64), 0, h->stream, (const Env*)h->d_env, policy_seed, flags, n, n_steps, done);
             } else {
-                RMJ_LAUNCH_POL(rmj4, k_step4_queue, pol, gq, dim3(64), 0, h->stream, (const Env*)h->d_env, policy_seed, flags, n, n_steps, chunk, heads, done, h->queue_skip_xcds, d_qprog, (uint32_t)h->queue_tail, next, (uint32_t)set_words);
-                RMJ_LAUNCH_POL(rmj4, k_step4_fixup, pol, gfix, dim3(64), 0, h->stream, (const Env*)h->d_env, policy_seed, flags, n, n_steps, (const uint32_t*)done);
+                RMJ_LAUNCH_POL(rmj4, k_step4_queue, pol, gq, dim3(64), 0, h->stream, (const Env*)h->d_env, policy_seed, flags, n, n_steps, chunk, heads, done, h->queue_skip_xcds, d_qprog, (uint32_t)h->queue_tail);
+                RMJ_LAUNCH_POL(rmj4, k_step4_fixup, pol, gfix, dim3(64), 0, h->stream, (const Env*)h->d_env, policy_seed, flags, n, n_steps, done);
             }
             HIPCHK(hipGetLastError());
             return RMJ_OK;
@@ -1685,7 +1682,6 @@ int rmj_step_random_encode(rmj_handle h, uint64_t policy_seed, uint32_t n_steps,
             if (!h->d_qheads) {
                 HIPCHK(hipMalloc(&h->d_qheads, (3 * set_words + (size_t)grid.x * 4) * sizeof(uint32_t)));
                 HIPCHK(hipMemsetAsync(h->d_qheads, 0, 3 * set_words * sizeof(uint32_t), h->stream));
-                h->q_cur = 0;
             }
             uint32_t* const e_heads = h->d_qheads + 2 * set_words;
             uint32_t* const e_done = e_heads + 8 * RMJ_Q_STRIDE;
@@ -2120,8 +2116,8 @@ __global__ void k_ev_scan(uint32_t* blk, uint32_t blocks, uint32_t* total) {
     for (uint32_t b = 0; b < blocks; b++) { const uint32_t c = blk[b]; blk[b] = r; r += c; }
     total[0] = r;
 }
-// one wave per game: lane = (record, half) - 16 bytes per lane, 32 records per pass.  newcur[g] = the position behind the window;
-// `until` (optional): positions the window stops at (the staged totals of a size call)
+// one wave per game: lane = (record, half) - 16 bytes per lane, 32 records per pass.  newcur[g] = the position behind the window
+// (the window = [first[g], ev_count): the size call of rmj_drain_format keeps what it gathered staged, so no second gather needs a stop position)
 __global__ __launch_bounds__(256) void k_ev_gather(const GState* __restrict__ core, const RmjEvent* __restrict__ events, uint32_t n, uint32_t ring,
                                                    const uint32_t* __restrict__ first, const uint32_t* __restrict__ pre, const uint32_t* __restrict__ blk,
                                                    uint32_t cap, RmjEvent* __restrict__ out, uint32_t* __restrict__ offs, uint32_t* __restrict__ newcur) {

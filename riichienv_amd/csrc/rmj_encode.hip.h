@@ -219,19 +219,21 @@ __device__ __forceinline__ void enc_emit_bytes(float* dst, const uint8_t* cells,
     int i = lane;
     const bool slow = __ballot(big) != 0ull;
 #if RMJ_ENC_EMIT_UNROLL > 1
-    if (!slow)
-    // RMJ_ENC_EMIT_UNROLL stores per trip: the code words of all of them are read first, then their table entries, then the stores
-    // leave back to back (one store per trip waits for two dependent LDS round trips in front of every store)
+    // RMJ_ENC_EMIT_UNROLL stores per trip (A/B switch, measured slower in round 5: journal r05 section 11): the code words of all of them are
+    // read first, then their table entries, then the stores leave back to back.  Only when every code is inside the table (`slow`: codes up to
+    // 255 would index past the 64-entry table).
     constexpr int U = RMJ_ENC_EMIT_UNROLL;
-    for (; i + 64 * (U - 1) < body; i += 64 * U) {
-        uint32_t w[U];
+    if (!slow) {
+        for (; i + 64 * (U - 1) < body; i += 64 * U) {
+            uint32_t w[U];
 #pragma unroll
-        for (int u = 0; u < U; u++) w[u] = c4[i + 64 * u];
-        enc_v4f v[U];
+            for (int u = 0; u < U; u++) w[u] = c4[i + 64 * u];
+            enc_v4f v[U];
 #pragma unroll
-        for (int u = 0; u < U; u++) v[u] = dec(w[u]);
+            for (int u = 0; u < U; u++) v[u] = dec(w[u]);
 #pragma unroll
-        for (int u = 0; u < U; u++) st16(i + 64 * u, v[u]);
+            for (int u = 0; u < U; u++) st16(i + 64 * u, v[u]);
+        }
     }
 #endif
     if (slow) {

@@ -2921,12 +2921,10 @@ __device__ __noinline__ uint32_t q_wait_for(const uint32_t* slot, uint32_t want)
 template <int POL>
 __global__ __launch_bounds__(64, RMJ_STEP4_WAVES_OF(POL)) void k_step4_queue(const Env* __restrict__ Ep, uint64_t policy_seed, uint32_t flags, uint32_t n_games,
                                                                          uint32_t n_steps, uint32_t chunk, uint32_t* __restrict__ heads, uint32_t* __restrict__ done,
-                                                                         uint32_t skip_xcds, uint32_t* __restrict__ prog, uint32_t tail, uint32_t* __restrict__ zero_next,
-                                                                         uint32_t zero_words) {
-    {   // the counters of the NEXT ticket rollout (the other of two sets: nobody touches it during this launch): no memset between rollouts
-        const uint32_t per = (zero_words + gridDim.x - 1u) / gridDim.x, lo = blockIdx.x * per;
-        for (uint32_t i = lo + (threadIdx.x & 63u); i < lo + per && i < zero_words; i += 64u) zero_next[i] = 0u;
-    }
+                                                                         uint32_t skip_xcds, uint32_t* __restrict__ prog, uint32_t tail) {
+    // (the counters arrive zeroed: k_step4_fixup, which runs behind every ticket launch, re-arms the set it has looked at - no memset between
+    //  rollouts, and the pair of launches is idempotent: a rollout captured in a HIP graph can be replayed.  Round 5 alternated two sets from
+    //  the host and had each launch zero the other, which a replay of ONE captured launch found exhausted: ADVICE r5)
     const uint32_t xcd = (uint32_t)__builtin_amdgcn_s_getreg((3 << 11) | 20) & 7u;   // HW_REG_XCC_ID[3:0]
     if ((skip_xcds >> xcd) & 1u) return;   // test hook (RMJ_QUEUE_TEST_SKIP_XCDS): pretend these XCDs received no block -> k_step4_fixup
     const uint32_t n_quads = (n_games + 3u) / 4u;
@@ -2984,9 +2982,14 @@ __global__ __launch_bounds__(64, RMJ_STEP4_WAVES_OF(POL)) void k_step4_queue(con
 // block per quad cost the 20-step window as much as 1 % of its time to find nothing).
 template <int POL>
 __global__ __launch_bounds__(64, RMJ_STEP4_WAVES_OF(POL)) void k_step4_fixup(const Env* __restrict__ Ep, uint64_t policy_seed, uint32_t flags, uint32_t n_games,
-                                                                         uint32_t n_steps, const uint32_t* __restrict__ done) {
+                                                                         uint32_t n_steps, uint32_t* __restrict__ done) {
     const uint32_t n_quads = (n_games + 3u) / 4u, lane = threadIdx.x & 63u, mine = blockIdx.x * 64u + lane;
     uint64_t todo = __ballot(mine < n_quads && __hip_atomic_load(done + (mine < n_quads ? mine : 0u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u);
+    // re-arm the counter set for the next ticket rollout (the ticket kernel has ended: stream order): this wave's 64 quad words, and - block 0 -
+    // the eight queue heads in front of them
+    if (mine < n_quads) done[mine] = 0u;
+    if (blockIdx.x == 0u)
+        for (uint32_t i = lane; i < 8u * RMJ_Q_STRIDE; i += 64u) (done - 8u * RMJ_Q_STRIDE)[i] = 0u;
 #pragma unroll 1
     while (todo) {
         const uint32_t quad = blockIdx.x * 64u + (uint32_t)(__ffsll((long long)todo) - 1);

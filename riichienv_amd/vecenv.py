@@ -189,9 +189,18 @@ class VecRiichiEnv:
     """N independent games on one GPU (one shard of a batch sharded by game index)."""
 
     def __init__(self, n_games, game_mode=0, seed=0, seeds=None, rule_bits=abi.RULE_TENHOU, skip_mjai_logging=False,
-                 round_wind=0, device=0, game_offset=0, event_ring=64):
+                 round_wind=0, device=0, game_offset=0, event_ring=64, reference_rng=None):
+        """seed -> wall.  `seeds=` (one episode seed per game, used as given like RiichiEnv(seed=...)) deals every wall through the
+        REFERENCE's chain - StdRng::seed_from_u64, rand's shuffle, salt, SHA-256 digest (state/wall.rs:36-67; RMJ_RULE_REFERENCE_RNG) -
+        so that a seed means the wall the reference deals for it; salt / wall_digest: wall_digest(g).  `seed=` (a base seed, the games
+        decorrelated by their global index: throughput runs, sharded batches) keeps the build's own counter-based shuffle, which costs a
+        round start nothing.  reference_rng=True / False overrides either default (False with `seeds=`: the opt-out for throughput)."""
         self.L = load_lib()
         self.n = int(n_games)
+        if reference_rng is None:
+            reference_rng = seeds is not None or bool(rule_bits & abi.RULE_REFERENCE_RNG)
+        rule_bits = (rule_bits | abi.RULE_REFERENCE_RNG) if reference_rng else (rule_bits & ~abi.RULE_REFERENCE_RNG)
+        self.reference_rng = bool(reference_rng)
         cfg = abi.Config()
         cfg.n_games = self.n
         cfg.game_mode = _mode_id(game_mode)
@@ -207,7 +216,7 @@ class VecRiichiEnv:
             assert self._seeds.shape == (self.n,)
             cfg.seeds = self._seeds.ctypes.data_as(C.POINTER(C.c_uint64))
         cfg.event_ring = event_ring
-        self.event_ring = 1 << max(0, int(event_ring) - 1).bit_length()   # the library rounds the ring up to a power of two
+        self.event_ring = max(64, 1 << max(0, int(event_ring) - 1).bit_length())   # the library rounds the ring up to a power of two, at least 64 records (rmj_create; event_ring = 0 gives 64)
         self.game_mode = cfg.game_mode
         self.game_offset = int(game_offset)
         self.h = C.c_void_p()

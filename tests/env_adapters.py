@@ -56,7 +56,8 @@ class GpuEnv:
         from riichienv_amd import vecenv
 
         self.e = vecenv.VecRiichiEnv(1, game_mode=game_mode, seeds=np.array([seed], np.uint64), rule_bits=rule_bits,
-                                     round_wind=round_wind, event_ring=4096)
+                                     round_wind=round_wind, event_ring=4096,
+                                     reference_rng=bool(rule_bits & abi.RULE_REFERENCE_RNG))   # the twin (oracle.Game) takes its definition of seed -> wall from rule_bits alone
 
     def reset(self, wall=None, oya=-1, round_wind=-1, scores=None, honba=-1, kyotaku=-1):
         self.e.reset(walls=None if wall is None else np.array(wall, np.uint8)[None],

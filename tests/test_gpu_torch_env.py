@@ -409,3 +409,49 @@ def test_one_launch_paths_with_several_waves_per_simd_behind_foreign_kernels(mod
             assert torch.equal(e.nlegal, b.nlegal), (name, k, (e.nlegal != b.nlegal).any(1).nonzero().flatten()[:8].tolist())
             assert torch.equal(e.mask, b.mask) and torch.equal(o, ob) and torch.equal(e.legal, b.legal), (name, k)
     assert (a.env.step_counts() == b.env.step_counts()).all() and (c.env.step_counts() == b.env.step_counts()).all()
+
+
+def test_ticket_rollout_inside_a_hip_graph_can_be_replayed():
+    """the fused ticket rollout (k_step4_queue + k_step4_fixup) must be idempotent as a pair of launches - a rollout captured ONCE in a
+    HIP graph and replayed steps every game again.  (Round 5 alternated two counter sets from the host: a replay of the one captured launch found
+    its tickets exhausted and silently stepped nothing.  Now k_step4_fixup re-arms the set it has looked at.)"""
+    import os
+
+    torch = pytest.importorskip("torch")
+    from riichienv_amd import vecenv
+    from riichienv_amd.torch_env import TorchVecEnv
+
+    n, k, pseed, replays = 4096, 40, 77, 3
+    old = {v: os.environ.get(v) for v in ("RMJ_QUEUE_FORCE", "RMJ_QUEUE_CHUNK")}
+    os.environ.update({"RMJ_QUEUE_FORCE": "1", "RMJ_QUEUE_CHUNK": "8"})
+    try:
+        a = TorchVecEnv(n, game_mode=2, seed=5, share_stream=True)
+    finally:
+        for v, x in old.items():
+            os.environ.pop(v, None) if x is None else os.environ.__setitem__(v, x)
+    if not int(a.env.bench_rollout(pseed, 0, k).queued):
+        pytest.skip("this build / device does not run the rollout as tickets")
+    b = vecenv.VecRiichiEnv(n, game_mode=2, seed=5)
+    b.reset()
+    b.step_random(pseed, k, auto_reset=True)              # (the bench call above)
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        a.bind_stream()
+        a.env.step_random(pseed, k, auto_reset=True)      # warm-up on the capture stream: every lazy buffer exists before the capture
+    side.synchronize()
+    s0 = int(a.env.total_steps())
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g, stream=side):
+        a.env.step_random(pseed, k, auto_reset=True)
+    assert int(a.env.total_steps()) == s0                 # (the capture itself stepped nothing)
+    per_replay = []
+    for _ in range(replays):
+        g.replay()
+        torch.cuda.synchronize()
+        per_replay.append(int(a.env.total_steps()))
+    assert per_replay[0] - s0 == n * k and all(per_replay[i + 1] - per_replay[i] == n * k for i in range(replays - 1)), (s0, per_replay)
+    for _ in range(1 + replays):
+        b.step_random(pseed, k, auto_reset=True)
+    a.bind_stream(torch.cuda.current_stream())
+    assert (a.env.step_counts() == b.step_counts()).all() and (a.env.scores() == b.scores()).all()

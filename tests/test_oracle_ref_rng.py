@@ -5,6 +5,7 @@ Pinned on PUBLISHED vectors: the ChaCha block function (8 / 12 / 20 rounds), Std
 own value-stability vector), SHA-256.  UNPINNED (restated, self-consistency only): seed_from_u64's PCG32 expansion and the index
 draws of SliceRandom::shuffle - the tests below check their defining properties, not reference outputs."""
 import hashlib
+import os
 import struct
 
 import numpy as np
@@ -183,3 +184,30 @@ def test_game_with_reference_rng_flag():
     assert g.wall_meta() == oracle.reference_wall(sm(43), False)[1:3]
     g.reset(wall=list(range(136)))
     assert g.wall_meta() == oracle.reference_wall(sm(43), False)[1:3]   # stale, like the reference
+
+
+def _sm64(x):
+    z = (x + 0x9E3779B97F4A7C15) & (2**64 - 1)
+    z = ((z ^ (z >> 30)) * 0xBF58476D1CE4E5B9) & (2**64 - 1)
+    z = ((z ^ (z >> 27)) * 0x94D049BB133111EB) & (2**64 - 1)
+    return z ^ (z >> 31)
+
+
+REF_VECTORS = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ref_rng_vectors.json")
+
+
+def test_reference_vectors_from_the_rust_crate():
+    """THE pin of A1: rows {seed, hand_index, players, wall, salt, digest} printed by the reference's own WallState / WallState3P (the 30-line
+    example of INTEGRATION.md, `cargo run --release --example ref_rng_vectors`).  Absent in this image (no Rust toolchain, crates not vendored):
+    xfail = "seed -> wall unpinned outside this repository" (DESIGN.md section 6)."""
+    if not os.path.exists(REF_VECTORS):
+        pytest.xfail("tests/golden/ref_rng_vectors.json not generated yet: run the Rust example of INTEGRATION.md with the reference's crates (rand 0.10)")
+    import json
+
+    rows = json.load(open(REF_VECTORS))
+    assert rows, "empty vector file"
+    for row in rows:
+        sanma = row["players"] == 3
+        w, salt, dg, _ = oracle.reference_wall(_sm64((row["seed"] + row["hand_index"]) & (2**64 - 1)), sanma)
+        assert [int(x) for x in w[::-1]] == row["wall"], (row["seed"], row["hand_index"], row["players"])
+        assert (salt, dg) == (row["salt"], row["digest"]), (row["seed"], row["hand_index"], row["players"])

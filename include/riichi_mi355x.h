@@ -203,7 +203,7 @@ int rmj_step(rmj_handle h, const rmj_action_t* actions);
 /* Same, `actions` is a device pointer (zero-copy from a GPU policy). */
 int rmj_step_device(rmj_handle h, const rmj_action_t* d_actions);
 /* Device-side uniform-random policy (RandomAgent, src/riichienv/agents/random_agent.py:6-15,
- * keyed per (game, step, seat) — SURVEY §8(c)): choice = mix(policy_seed, global_game, step_no, seat) % n_legal
+ * keyed per (game, step, seat) — SURVEY §8(c)): choice = mulhi(key32(policy_seed, global_game, step_no, seat), n_legal) (the key: see rmj_step_greedy below)
  * over the ordered legal list.  Runs n_steps batched steps; with auto_reset != 0 a finished game is
  * re-`reset()` (defaults) at the start of the next step instead of stepping.
  * Games are independent, so a rollout of >= 2 steps needs no synchronisation between the steps of different games: it
@@ -221,13 +221,14 @@ int rmj_step_random(rmj_handle h, uint64_t policy_seed, uint32_t n_steps, int au
 /* The device policy that PLAYS mahjong (what the consumer of this path runs is a learned policy that wins,
  * riichienv-ml/src/riichienv_ml/trainers/_ppo_worker.py:147-239; the uniform RandomAgent wins once in ~250 rounds): for every
  * seat that is to act, over its ordered legal list, the first entry of the best class
- *   Tsumo / Ron > Kita > Riichi > Ankan > Kakan > Daiminkan > [Pon > Chi, only when ((key >> 40) & 255) < call_rate_256] >
+ *   Tsumo / Ron > Kita > Riichi > Ankan > Kakan > Daiminkan > [Pon > Chi, only when (key >> 24) < call_rate_256] >
  *   Discard > Pass > Kyushu kyuhai
  * (Kita before Riichi: the 3P reference offers Kita in the riichi stage and can leave the seat without a legal action),
  * and among the Discard entries (when there are two or more) the one whose removal leaves the concealed hand with the lowest
  * shanten (calculate_shanten / _3p, shanten.rs:228-241 / :454-468, of the remaining tiles with len_div3 = (hand_len - 1) / 3),
- * ties broken by key mod #ties in list order; key = splitmix64(splitmix64(policy_seed + global game) + 4 * step_no + seat),
- * the RandomAgent's key.  Scheduling, auto_reset and outputs exactly like rmj_step_random (same kernels, compiled with this
+ * ties broken by mulhi(key * 0x9E3779B1, #ties) in list order; key = the RandomAgent's 32-bit key of (game, step_no, seat): fmix32 of
+ * (lo(gs) ^ (4 * step_no + seat) * 0x9E3779B1) + hi(gs) with gs = splitmix64(policy_seed + global game) - round 6; the RandomAgent takes
+ * list entry mulhi(key, n).  Scheduling, auto_reset and outputs exactly like rmj_step_random (same kernels, compiled with this
  * policy in place of the random pick).  Needs the four-games-per-wave kernels (the default; RMJ_STEP4=0 -> RMJ_ERR_ARG). */
 int rmj_step_greedy(rmj_handle h, uint64_t policy_seed, uint32_t n_steps, int auto_reset, uint32_t call_rate_256);
 /* Fill actions[n][4] with what the device policy would choose for the CURRENT state (no step). */

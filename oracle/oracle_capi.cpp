@@ -54,8 +54,16 @@ static void meld_to_view(const Meld& m, RmjMeldView& v) {
 }
 
 // policy choice shared (by definition, not by code) with the HIP path; see include/riichi_mi355x.h rmj_step_random
+// (round 6: a 32-bit finaliser over gs = splitmix64(seed + game) and the (step, seat) counter, a multiply-high instead of a modulo - the device
+// spends 13 vector instructions on a pick instead of ~55; csrc/rmj_common.hip.h policy_key32 / policy_pick / policy_calls / policy_tie)
+static inline uint32_t policy_key32(uint64_t gs, uint32_t step, uint32_t seat) {
+    uint32_t x = ((uint32_t)gs ^ ((step * 4u + seat) * 0x9E3779B1u)) + (uint32_t)(gs >> 32);
+    x ^= x >> 16; x *= 0x85EBCA6Bu; x ^= x >> 13; x *= 0xC2B2AE35u; x ^= x >> 16;
+    return x;
+}
+static inline uint32_t policy_pick(uint32_t key, uint32_t n) { return (uint32_t)(((uint64_t)key * (uint64_t)n) >> 32); }
 static inline uint64_t policy_choice(uint64_t seed, uint64_t game, uint64_t step, uint32_t seat, uint32_t n) {
-    return splitmix64(splitmix64(seed + game) + step * 4 + seat) % n;
+    return policy_pick(policy_key32(splitmix64(seed + game), (uint32_t)step, seat), n);
 }
 
 extern "C" {
@@ -1154,8 +1162,8 @@ static int greedy_class(ActionType t, bool call) {
         default: return 15;
     }
 }
-static size_t greedy_pick(const GameState& g, uint8_t p, const std::vector<Action>& l, uint64_t key, uint32_t call_rate) {
-    const bool call = (uint32_t)((key >> 40) & 0xFF) < call_rate;
+static size_t greedy_pick(const GameState& g, uint8_t p, const std::vector<Action>& l, uint32_t key, uint32_t call_rate) {
+    const bool call = (key >> 24) < call_rate;
     int best_c = 99;
     size_t best_i = 0;
     for (size_t i = 0; i < l.size(); i++) {
@@ -1184,7 +1192,7 @@ static size_t greedy_pick(const GameState& g, uint8_t p, const std::vector<Actio
     std::vector<size_t> tie;
     for (size_t k = 0; k < cand.size(); k++)
         if (sh[k] == smin) tie.push_back(cand[k]);
-    return tie[key % tie.size()];
+    return tie[policy_pick(key * 0x9E3779B1u, (uint32_t)tie.size())];
 }
 void orc_game_greedy_actions(void* gp, uint64_t policy_seed, uint64_t global_game, uint32_t call_rate_256, rmj_action_t* out /*[4]*/) {
     GameState* g = (GameState*)gp;
@@ -1193,7 +1201,7 @@ void orc_game_greedy_actions(void* gp, uint64_t policy_seed, uint64_t global_gam
     for (uint8_t p : g->active_players) {
         auto l = g->_get_legal_actions_internal(p);
         if (l.empty()) continue;
-        const uint64_t key = splitmix64(splitmix64(policy_seed + global_game) + (uint64_t)g->step_count * 4 + p);
+        const uint32_t key = policy_key32(splitmix64(policy_seed + global_game), (uint32_t)g->step_count, p);
         out[p] = pack_action(l[greedy_pick(*g, p, l, key, call_rate_256)]);
     }
 }

@@ -81,7 +81,7 @@ __global__ void k_random_actions(Env E, uint64_t policy_seed, uint64_t* out) {
         uint64_t a = RMJ_NO_ACTION;
         int n = E.nlegal[(size_t)g * 4 + p];
         if (((S.active_mask >> p) & 1u) && n > 0 && !S.is_done) {
-            uint64_t ch = sm64(gs + (uint64_t)S.step_count * 4ull + (uint64_t)p) % (uint64_t)n;
+            const uint32_t ch = policy_pick(policy_key32(gs, S.step_count, (uint32_t)p), (uint32_t)n);
             a = E.legal[((size_t)g * 4 + p) * RMJ_MAX_LEGAL + ch];
         }
         out[(size_t)g * 4 + p] = a;

@@ -266,6 +266,20 @@ __device__ __forceinline__ uint64_t sm64(uint64_t x) {  // state/wall.rs:83-88
     return z ^ (z >> 31);
 }
 
+// The device policies' key of (game, step, seat) - round 6 - and what they draw from it.  gs = splitmix64(policy_seed + global game), once per
+// game and call; per seat and step a 32-bit finaliser (murmur3's fmix32) over gs's halves and the counter, and a multiply-high instead of a
+// modulo: 13 vector instructions per pick where splitmix64 + a four-digit modulo by magic numbers took ~55 (the RandomAgent's pick was 112
+// vector cycles at 17 live lanes: profiles/r05_lane_use_random.txt).  The policy is this build's own definition (the reference's RandomAgent
+// is Python's random.choice); the oracle's twin: oracle_capi.cpp policy_key32 / policy_choice.
+__host__ __device__ __forceinline__ uint32_t policy_key32(uint64_t gs, uint32_t step, uint32_t seat) {
+    uint32_t x = ((uint32_t)gs ^ ((step * 4u + seat) * 0x9E3779B1u)) + (uint32_t)(gs >> 32);
+    x ^= x >> 16; x *= 0x85EBCA6Bu; x ^= x >> 13; x *= 0xC2B2AE35u; x ^= x >> 16;
+    return x;
+}
+__host__ __device__ __forceinline__ uint32_t policy_pick(uint32_t key, uint32_t n) { return (uint32_t)(((uint64_t)key * (uint64_t)n) >> 32); }   // uniform over [0, n)
+__host__ __device__ __forceinline__ bool policy_calls(uint32_t key, uint32_t call_rate_256) { return (key >> 24) < call_rate_256; }                // the greedy policy's Pon / Chi coin
+__host__ __device__ __forceinline__ uint32_t policy_tie(uint32_t key, uint32_t n) { return policy_pick(key * 0x9E3779B1u, n); }                      // ... and its tie break
+
 // x mod n for 1 <= n <= 64, exact, without the 64-bit software division: four 16-bit digits, each step reduces a value
 // below 2^22 with an fp32 reciprocal estimate (quotient off by at most one) and one correction either way.
 __device__ __forceinline__ uint32_t mod_small(uint64_t x, uint32_t n) {

@@ -83,7 +83,7 @@ __global__ __launch_bounds__(64 * RMJ_STEP_WPB, RMJ_STEP_WAVES) void k_step(cons
         uint32_t vz;
         asm volatile("v_mov_b32 %0, 0" : "=v"(vz));
         const uint64_t gs = sm64(policy_seed + E.game_offset + uni(g) + (uint64_t)vz);
-        const uint64_t sk = gs + (uint64_t)uni((uint32_t)S.step_count) * 4ull;
+        const uint32_t sc_u = uni((uint32_t)S.step_count);
         uint32_t am = S.is_done ? 0u : (uint32_t)S.active_mask;
         am = uni(am) & 0xFu;
         while (am) {
@@ -91,7 +91,7 @@ __global__ __launch_bounds__(64 * RMJ_STEP_WPB, RMJ_STEP_WAVES) void k_step(cons
             am &= am - 1u;
             const uint32_t n = uni((uint32_t)S.nlegal[p]);
             if (n == 0u) continue;
-            const uint32_t ch = mod_small_uniform(uni(sm64(sk + (uint64_t)p)), n > 64u ? 64u : n);
+            const uint32_t ch = uni(policy_pick(policy_key32(gs, sc_u, (uint32_t)p), n > 64u ? 64u : n));
             if (lane == p) mine = c.Lg[p * RMJ_MAX_LEGAL + ch];
         }
     } else if (flags & STEP_F_IDS) {

@@ -1695,13 +1695,13 @@ __device__ __noinline__ void r4_yaku_answers() {
 // ---------------------------------------------------------------------------------------------------------------------------
 // The device policy that PLAYS (rmj_step_greedy; the oracle's twin is orc_game_greedy_actions): for every seat that is to act,
 // over its ordered legal list, the first entry of the best class -
-//   Tsumo / Ron  >  Kita  >  Riichi  >  Ankan  >  Kakan  >  Daiminkan  >  [Pon > Chi when ((key >> 40) & 255) < call_rate]  >
+//   Tsumo / Ron  >  Kita  >  Riichi  >  Ankan  >  Kakan  >  Daiminkan  >  [Pon > Chi when (key >> 24) < call_rate]  >
 //   Discard  >  Pass  >  Kyushu kyuhai
 // (Kita before Riichi: the 3P reference offers Kita in the riichi stage and can leave a seat that takes it without any legal
 // action - quirk Q15 -; a seat that has set its Norths aside before it declares cannot get there)
 // - and among the Discard entries the one that leaves the hand with the lowest shanten (shanten.rs:228-241 / :454-468 of the hand
-// without the tile), ties broken by key mod #ties in list order; key = splitmix64(splitmix64(seed + global game) + 4 * step + seat)
-// like the RandomAgent's.  What scripts/soak_greedy.py plays on the CPU, now resident: games reach tenpai, declare riichi and end
+// without the tile), ties broken by policy_tie(key, #ties) in list order; key = policy_key32(splitmix64(seed + global game), step, seat)
+// like the RandomAgent's (rmj_common.hip.h).  What scripts/soak_greedy.py plays on the CPU, now resident: games reach tenpai, declare riichi and end
 // with wins, so the rare transitions of the step (yaku checks, settlements, wait probes) are no longer rare.
 // Lane = list entry while a seat's list is scanned (16 entries per pass), lane = discard candidate for the shanten of "hand minus
 // my tile": the three suits a discard leaves alone are looked up once per row (lanes 0..3), their pair merges are computed entry
@@ -1874,8 +1874,8 @@ __device__ __forceinline__ uint64_t r4_policy_greedy(R4& q, bool on, const uint6
             const int p = __ffs((int)todo) - 1;
             todo &= todo - 1u;
             const int n = G->nlegal[p];
-            const uint64_t key = sm64(gs + (uint64_t)G->step_count * 4ull + (uint64_t)p);
-            const bool call = (uint32_t)((key >> 40) & 0xFFull) < call_rate;
+            const uint32_t key = policy_key32(gs, G->step_count, (uint32_t)p);
+            const bool call = policy_calls(key, call_rate);
             // ---- scan: best (class, index) over the list, 16 entries per pass
             uint32_t best = 0xFFFFu;
             uint64_t e0 = 0ull;      // lane's entry of the first pass (the Discard entries of a list sit in its first 15 slots)
@@ -1902,7 +1902,7 @@ __device__ __forceinline__ uint64_t r4_policy_greedy(R4& q, bool on, const uint6
                 const uint32_t key_s = (uint32_t)(sres + 2);                      // (-1 .. 14) -> 1 .. 16, non-candidates 101
                 const uint32_t smin = (uint32_t)rbc((int)row_min16u(cand ? key_s : 200u), rb + 15);
                 const uint32_t tie = rballot(cand && key_s == smin, rb);
-                const uint32_t kth = mod_small_magic(key, (uint32_t)__popc(tie));
+                const uint32_t kth = policy_tie(key, (uint32_t)__popc(tie));
                 const uint32_t pick = rballot(((tie >> r) & 1u) && (uint32_t)__popc(tie & ((1u << r) - 1u)) == kth, rb);
                 ci = __ffs((int)pick) - 1;
                 pol_seat = p;                 // the shanten of the 13 tiles this discard leaves: the wait cache takes it (r4_resolve_discard)
@@ -2023,8 +2023,7 @@ __device__ __forceinline__ uint32_t step4_body(const Env* Ep, Quad4Shared& sh, u
                 const uint32_t n = G->nlegal[r];
                 if (((G->active_mask >> r) & 1u) && n != 0u) {
                     const uint64_t gs = LOOP ? gs_row : sm64(policy_seed + E.game_offset + (uint64_t)g);   // (the loop hashes the game once)
-                    const uint64_t key = sm64(gs + (uint64_t)G->step_count * 4ull + (uint64_t)r);
-                    const uint32_t ch = mod_small_magic(key, n > 64u ? 64u : n);
+                    const uint32_t ch = policy_pick(policy_key32(gs, G->step_count, (uint32_t)r), n > 64u ? 64u : n);
                     const uint64_t* src = Lg + r * RMJ_MAX_LEGAL + ch;
                     mine = LOOP ? __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : *src;
                 }
@@ -2336,8 +2335,7 @@ __device__ __forceinline__ uint32_t step4_body(const Env* Ep, Quad4Shared& sh, u
                             const int p = __ffs((int)todo) - 1;
                             todo &= todo - 1u;
                             const int n = rbc(nl_mine, rb + p);
-                            const uint64_t key = sm64(gs_row + (uint64_t)sc * 4ull + (uint64_t)p);
-                            const bool call = (uint32_t)((key >> 40) & 0xFFull) < call_rate;
+                            const bool call = policy_calls(policy_key32(gs_row, sc, (uint32_t)p), call_rate);
                             const bool in = r < n;
                             const uint64_t e = in ? q.T->lst[row][p][r] & 0x00FFFFFFFFFFFFFFull : 0ull;
                             const uint32_t ty = (uint32_t)e & 0xFFu;
@@ -2348,8 +2346,7 @@ __device__ __forceinline__ uint32_t step4_body(const Env* Ep, Quad4Shared& sh, u
                         }
                     }
                 } else if (r < 4 && ((am2 >> r) & 1u) && nl_mine > 0) {
-                    const uint64_t key = sm64(gs_row + (uint64_t)sc * 4ull + (uint64_t)r);
-                    const uint32_t ch = mod_small_magic(key, nl_mine > 64 ? 64u : (uint32_t)nl_mine);
+                    const uint32_t ch = policy_pick(policy_key32(gs_row, sc, (uint32_t)r), nl_mine > 64 ? 64u : (uint32_t)nl_mine);
                     pick = q.T->lst[row][r][ch] & 0x00FFFFFFFFFFFFFFull;
                 }
                 // a Ron among the answers is a settlement (full path): the row stops after its discard, the next call takes it from there

@@ -181,6 +181,7 @@ def test_65536_games_3p_with_feature_tensor():
     env = vecenv.VecRiichiEnv(n, game_mode=mode, seed=SEED, event_ring=ring)
     env.reset()
     obs = torch.zeros((n, 4, 74, 27), dtype=torch.float32, device="cuda:0")
+    torch.cuda.synchronize()   # (torch's fill and the library's own stream are not ordered otherwise)
     env.step_random(PSEED, steps - 50, auto_reset=True)           # split rollout
     for _ in range(50):                                            # then the bench's step + encode cadence
         env.step_random(PSEED, 1, auto_reset=True)
@@ -218,6 +219,7 @@ def test_fused_feature_rollout_equals_step_then_encode(mode, n, fused, monkeypat
     b.reset()
     oa = torch.zeros((n, 4, 74, w), dtype=torch.float32, device="cuda:0")
     ob = torch.zeros((n, 4, 74, w), dtype=torch.float32, device="cuda:0")
+    torch.cuda.synchronize()   # (the fills run on torch's stream, the rollout on the library's own: round 6 saw the 1 GB fill of `oa` overtake the first rows once)
     a.step_random_encode(PSEED, steps, oa.data_ptr(), auto_reset=True, only_active=2)
     for _ in range(steps):
         b.step_random(PSEED, 1, auto_reset=True)

@@ -363,6 +363,62 @@ def config_leg(vecenv, abi, shard, dev, name, games, mode, steps, policy_seed, d
     return out
 
 
+def external_policy_steps(envs, id_bufs, seed, k):
+    """k iterations of what an external (neural) policy drives: per iteration and environment one sampler launch (rmj_sample_ids_device: the masked draw a
+    policy's logits would feed; uniform here) and one step launch under its ids (rmj_step_ids_device = Observation.find_action + RiichiEnv.step, finished games
+    restart).  Everything is asynchronous on each environment's own stream; with two environments - the two HALVES of a batch - the step of one overlaps the
+    sampler / the launch ramp and tail of the other, which is how a trainer that alternates two groups hides them (riichienv-ml's actors: _ppo_worker.py:38)."""
+    import ctypes as C
+
+    for it in range(k):
+        for e, buf in zip(envs, id_bufs):
+            rc = e.L.rmj_sample_ids_device(e.h, None, 0, (seed + it) & 0xFFFFFFFFFFFFFFFF, buf)
+            if rc == 0:
+                rc = e.L.rmj_step_ids_device(e.h, buf, 1)
+            if rc:
+                raise RuntimeError(f"external_policy_steps: rc {rc}")
+
+
+def external_policy_leg(vecenv, abi, shard, dev, games, mode, steps, device, rank, preroll=PREROLL, seed=0x5EED):
+    """The per-step path of `env.step(actions)` under an external policy (env.rs:857-872), twice: the whole batch on one stream, and the batch as two halves
+    (environments of games / 2, game offsets 0 and games / 2: the same games) on two streams, alternating."""
+    import ctypes as C
+
+    out = {}
+    for name, parts in (("one_stream", 1), ("alternating_halves", 2)):
+        per = games // parts
+        envs = [vecenv.VecRiichiEnv(per, game_mode=mode, seed=0, rule_bits=abi.RULE_TENHOU, device=device,
+                                    game_offset=shard.shard_offset(rank, games) + i * per, event_ring=64) for i in range(parts)]
+        e0 = envs[0]
+        e0.L.rmj_sample_ids_device.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint64, C.c_void_p]
+        e0.L.rmj_step_ids_device.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
+        bufs = [C.c_void_p(dev.alloc(per * 4 * 4)) for _ in envs]
+        for e in envs:
+            e.reset()
+            e.step_random(0xC0FFEE, preroll, auto_reset=True)
+        external_policy_steps(envs, bufs, seed, 20)
+        for e in envs:
+            e.sync()
+        s0 = sum(e.total_steps() for e in envs)
+        dev.sync()
+        t0 = time.perf_counter()
+        external_policy_steps(envs, bufs, seed + 1000, steps)
+        for e in envs:
+            e.sync()
+        dev.sync()
+        t1 = time.perf_counter()
+        made = sum(e.total_steps() for e in envs) - s0
+        out[name] = {"value": made / (t1 - t0), "unit": "env.step/s", "ms_per_step": (t1 - t0) * 1e3 / steps, "steps": steps, "streams": parts,
+                     "launches_per_step": 2 * parts}
+        for e in envs:
+            e.close()
+        dev.free_all()
+    out["what"] = ("rmj_sample_ids_device (uniform) + rmj_step_ids_device per iteration - the launches an external policy causes; one_stream: the whole batch, "
+                   "alternating_halves: two environments of half the games on two streams, issued alternately (the step of one half overlaps the sampler and the "
+                   "ramp / tail of the other)")
+    return out
+
+
 def log_leg(vecenv, abi, shard, games, mode, policy_seed, device, rank, rounds=3, chunk=100, ring=512):
     """Lossless logs end to end: `rounds` x (a `chunk`-step auto-reset rollout + a drain of every slot's records, formatted to MJAI
     text on the host's threads) - the ring holds a chunk, the drains' cursors survive the restarts in between (stream positions), and
@@ -601,6 +657,8 @@ def main(argv=None):
                                        "what": "one policy launch writing packed actions + one step launch that validates them "
                                                "against the stored legal lists (state/mod.rs:339-402), one stream"}
         env.set_rollout_streams(4)
+        if not args.no_configs:
+            extras["external_policy"] = external_policy_leg(vecenv, abi, shard, dev, args.games, args.mode, max(min(args.steps, 300), 100), local_rank, rank)
         extras["log_drain"] = log_leg(vecenv, abi, shard, args.games, args.mode, policy_seed, local_rank, rank)
         # the steady-state figure of the SAME environment: >= 300 steps as one launch between device-wide synchronisations (a short
         # timed region pays the launch's ramp-up and tail, ~0.1 ms, once per K steps)

@@ -23,8 +23,9 @@
 namespace orc {
 namespace refrng {
 
-inline uint32_t rotl32(uint32_t x, int n) { return (x << n) | (x >> (32 - n)); }
-inline uint32_t rotr32(uint32_t x, int n) { return (x >> n) | (x << (32 - n)); }
+// (n may be 0 - PCG32's rotation is data dependent -: the complementary shift is taken mod 32; round 6, found by UBSan: "shift exponent 32")
+inline uint32_t rotl32(uint32_t x, int n) { return (x << (n & 31)) | (x >> ((32 - n) & 31)); }
+inline uint32_t rotr32(uint32_t x, int n) { return (x >> (n & 31)) | (x << ((32 - n) & 31)); }
 
 // ChaCha block (D. J. Bernstein; state layout of RFC 7539 with a 64-bit counter in words 12-13 and a 64-bit stream id in
 // 14-15, as rand_chacha / chacha20's `rng` module use it).  `rounds` = 8, 12 or 20.

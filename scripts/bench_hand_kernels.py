@@ -3,8 +3,8 @@
 riichienv-core/benches/agari_bench.rs:142-376: is_agari / is_tenpai, find_divisions + calc via HandEvaluator, calculate_score,
 shanten / ukeire): hands/s of every hand-math kernel on device-resident inputs (rmj_bench_hand_kernel: HIP events around the
 launches only), the fraction of the HBM roofline at the survey's 50 B per hand evaluation (34 B counts in + 16 B result out)
-and at the bytes the entry point really moves per hand (io_bytes: rmj_calculate_score reads 9 B and writes 16 B, so its "50 B"
-figure exceeds 1 - and its 26 MB working set stays in the 256 MB Infinity Cache between the timed launches, like every set here),
+and at the bytes the entry point really moves per hand (io_bytes).  roofline_frac is scored on min(io_bytes, 50) - rmj_calculate_score reads 9 B
+and writes 16 B, and every working set here (26-160 MB) stays in the 256 MB Infinity Cache between the timed launches: `cache_resident`,
 and the oracle beside it - one thread, and one worker process per hardware thread.
 
 Inputs: the 1 218 fixture hands of tests/golden/agari_{4p,3p}.json tiled to 2^20 + 2^20 uniformly random
@@ -147,12 +147,18 @@ def main():
             vecenv._chk(L.rmj_bench_hand_kernel(0, which, a, b, n, 0, 20 if which != 0 else 5, C.byref(ms)))
             rate = n / (ms.value * 1e-3)
             io = {0: C.sizeof(abi.HandCase) + C.sizeof(abi.HandResult), 1: 34 + 10, 2: 34 + 1, 3: 34 + 4, 4: 68 + 4, 5: 9 + 16}[which]
-            row = {"kernel": kname, "inputs": sname, "ms_per_launch": ms.value, "hands_per_s": rate, "roofline_frac": rate * B_HAND / HBM_PEAK,
-                   "io_bytes_per_hand": io, "io_frac_of_hbm_peak": rate * io / HBM_PEAK, "working_set_MB": n * io / 1e6,
+            # the roofline fraction is scored on the bytes the entry point really moves (never more than the survey's nominal 50 B), and a
+            # working set that fits the 256 MB Infinity Cache is labelled cache-resident: repeated launches over it are served by the MALL, so the
+            # figure is a fraction of the HBM PEAK RATE, not evidence of HBM traffic (a fraction above 1 would only say "not HBM")
+            bytes_scored = min(io, B_HAND)
+            ws_mb = n * io / 1e6
+            row = {"kernel": kname, "inputs": sname, "ms_per_launch": ms.value, "hands_per_s": rate, "roofline_frac": rate * bytes_scored / HBM_PEAK,
+                   "roofline_bytes_per_hand": bytes_scored, "nominal_50B_frac": rate * B_HAND / HBM_PEAK, "cache_resident": bool(ws_mb < 256.0),
+                   "io_bytes_per_hand": io, "io_frac_of_hbm_peak": rate * io / HBM_PEAK, "working_set_MB": ws_mb,
                    "cpu_one_thread_hands_per_s": cpu[which]["one_thread_hands_per_s"], "cpu_all_cores_hands_per_s": cpu[which]["all_cores_hands_per_s"],
                    "cpu_cores": cpu[which]["cores"]}
             out["rows"].append(row)
-            print(f"{kname:48s} {sname:15s} {ms.value:8.3f} ms  {rate / 1e9:7.3f} G hands/s  {100 * row['roofline_frac']:5.2f} % of 8 TB/s at 50 B/hand ({100 * row['io_frac_of_hbm_peak']:5.2f} % at the {io} B it moves) | "
+            print(f"{kname:48s} {sname:15s} {ms.value:8.3f} ms  {rate / 1e9:7.3f} G hands/s  {100 * row['roofline_frac']:5.2f} % of 8 TB/s at the {bytes_scored} B/hand scored ({100 * row['io_frac_of_hbm_peak']:5.2f} % at the {io} B it moves; {ws_mb:.0f} MB working set, {'cache-resident' if row['cache_resident'] else 'HBM'}) | "
                   f"oracle {row['cpu_one_thread_hands_per_s'] / 1e6:7.3f} M/s one thread, {row['cpu_all_cores_hands_per_s'] / 1e6:8.2f} M/s on {row['cpu_cores']} threads", flush=True)
     print(json.dumps(out))
 

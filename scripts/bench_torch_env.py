@@ -190,7 +190,88 @@ def run_graph(n, per_graph=16, with_policy=True):
           f"as a HIP graph of {per_graph} iterations {graph / 1e6:.1f} M env.step/s ({t_g / per_graph * 1e6:.0f} us per iteration)", flush=True)
 
 
+class QNetShape(torch.nn.Module):
+    """A policy of the reference's shape (riichienv-ml models/q_network.py:7-30 + backbone.py:47-70: Conv1d(74 -> 64, k 3) + 3 residual blocks of two
+    Conv1d(64 -> 64, k 3) over the 34 tile columns, Linear(64 * 34 -> 256), Linear(256 -> 82)), random weights, bf16.  CALLER side, not product: it only
+    exists so that the loop is measured with a network in it.  The k = 3 convolutions are written as GEMMs over three shifted copies of the columns
+    (hipBLASLt / MFMA; no MIOpen kernel search on a fresh box); BatchNorm in eval mode is an affine map folded into the weights."""
+
+    def __init__(self, width=34, c_in=74, c=64, blocks=3, fc=256, actions=82):
+        super().__init__()
+        mk = lambda i, o: torch.nn.Parameter(torch.randn(3 * i, o) * (1.0 / (3 * i)) ** 0.5)   # noqa: E731
+        self.w_in = mk(c_in, c)
+        self.w_res = torch.nn.ParameterList([mk(c, c) for _ in range(2 * blocks)])
+        self.fc1 = torch.nn.Linear(c * width, fc)
+        self.fc2 = torch.nn.Linear(fc, actions)
+        self.width = width
+
+    @staticmethod
+    def conv3(x, w):          # x [B, W, C] -> [B, W, C'] : y[:, j] = concat(x[:, j - 1], x[:, j], x[:, j + 1]) @ w  (zero padded)
+        z = torch.nn.functional.pad(x, (0, 0, 1, 1))
+        return torch.cat([z[:, :-2], z[:, 1:-1], z[:, 2:]], dim=-1) @ w
+
+    def forward(self, obs):   # obs [B, 74, W] float32 (strided rows are fine)
+        x = obs.to(torch.bfloat16).transpose(1, 2)            # [B, W, 74]
+        x = torch.relu(self.conv3(x, self.w_in))
+        for i in range(0, len(self.w_res), 2):
+            y = torch.relu(self.conv3(x, self.w_res[i]))
+            x = torch.relu(x + self.conv3(y, self.w_res[i + 1]))
+        x = torch.relu(self.fc1(x.transpose(1, 2).reshape(x.shape[0], -1)))
+        return self.fc2(x).float()
+
+
+def run_net(n, halves=False):
+    """The trainer loop with a REAL network in it: compact observations of the acting seats -> QNetShape (bf16) -> masked sampler ->
+    step + encode; one stream, or - halves - two shards on two streams issued alternately (the policy of one half next to the step of the other).
+    Reports the loop's rate and how much of an iteration belongs to the environment (HIP events around the library's launches)."""
+    from riichienv_amd.torch_env import ShardedTorchVecEnv
+
+    parts = 2 if halves else 1
+    env = ShardedTorchVecEnv(n, parts=parts, game_mode=2, seed=0)
+    net = QNetShape().to(env.device).to(torch.bfloat16).eval()
+    it = [0]
+    ev = [[torch.cuda.Event(enable_timing=True) for _ in range(3)] for _ in range(parts)]
+
+    def one(e, i, timed=False):
+        it[0] += 1
+        obs, index, cnt = e.obs_compact(sync_count=False)
+        k = min(obs.shape[0], e.n + e.n // 4)                                  # rows behind the device count are stale and ignored by the sampler
+        if timed:
+            ev[i][0].record()
+        with torch.no_grad():
+            logits = net(obs[:k])
+        if timed:
+            ev[i][1].record()
+        e.step(e.sample_ids(logits=logits, seed=it[0], index=index[:k], count=cnt))
+        if timed:
+            ev[i][2].record()
+
+    for _ in range(6):
+        env.for_each(lambda e, i: one(e, i))
+    torch.cuda.synchronize()
+    env.synchronize()
+    steps0 = sum(e.env.total_steps() for e in env.shards)
+    K = 20
+    t0 = time.perf_counter()
+    for r in range(K):
+        env.for_each(lambda e, i: one(e, i, timed=(r == K - 1)))
+    torch.cuda.synchronize()
+    env.synchronize()
+    t1 = time.perf_counter()
+    steps = sum(e.env.total_steps() for e in env.shards) - steps0
+    pol = sum(ev[i][0].elapsed_time(ev[i][1]) for i in range(parts)) / parts
+    envms = sum(ev[i][1].elapsed_time(ev[i][2]) for i in range(parts)) / parts
+    print(f"games {n} {'as two halves on two streams' if halves else 'on one stream'}, policy = QNetShape (74 x 34 -> 3 residual blocks of 64 channels -> 256 -> 82, bf16 GEMMs) on the "
+          f"compact batch of the acting seats + fused masked sampler + step: loop {steps / (t1 - t0) / 1e6:.2f} M env.step/s, {(t1 - t0) / K * 1e3:.2f} ms per iteration; "
+          f"of one {'half-' if halves else ''}iteration the network takes {pol:.2f} ms, sampler + step {envms:.2f} ms (HIP events)", flush=True)
+
+
 def main():
+    if len(sys.argv) > 1 and sys.argv[1] == "net":
+        n = int(sys.argv[2]) if len(sys.argv) > 2 else 65536
+        run_net(n)
+        run_net(n, halves=True)
+        return
     if len(sys.argv) > 1 and sys.argv[1] == "graph":
         for n in (1024, 4096, 16384, 65536):
             run_graph(n, with_policy=False)

@@ -86,3 +86,37 @@ def test_bench_in_process_shards():
     assert len(line["per_shard_value"]) == 2 and all(v > 0 for v in line["per_shard_value"]) and "in-process" in line["host"]
     steps = line["value"] * line["ms_per_step"] * 1e-3 * 60
     assert 0.9 * 2 * 8192 * 60 <= steps <= 2 * 8192 * 60 * 1.0001, steps
+
+
+@pytest.mark.parametrize("mode", [2, 5])
+def test_alternating_halves_driver_equals_the_whole_batch(mode):
+    """bench.py's `external_policy` leg (round 6): the batch as two environments of half the games on two streams, each iteration one sampler
+    launch + one step launch under its ids per half, issued alternately - must leave every game where the same loop over ONE environment of all
+    games on one stream leaves it (the sampler's noise and the walls are keyed by the GLOBAL game index)."""
+    import ctypes as C
+
+    torch = pytest.importorskip("torch")
+    sys.path.insert(0, ROOT)
+    import bench
+
+    n, k = 4096, 120
+    whole = [vecenv.VecRiichiEnv(n, game_mode=mode, seed=3, event_ring=64)]
+    halves = [vecenv.VecRiichiEnv(n // 2, game_mode=mode, seed=3, game_offset=i * (n // 2), event_ring=64) for i in range(2)]
+    L = whole[0].L
+    L.rmj_sample_ids_device.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint64, C.c_void_p]
+    L.rmj_step_ids_device.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
+    for e in whole + halves:
+        e.reset()
+    ids_w = [torch.full((n, 4), -1, dtype=torch.int32, device="cuda:0")]
+    ids_h = [torch.full((n // 2, 4), -1, dtype=torch.int32, device="cuda:0") for _ in range(2)]
+    torch.cuda.synchronize()
+    bench.external_policy_steps(whole, [C.c_void_p(t.data_ptr()) for t in ids_w], 17, k)
+    bench.external_policy_steps(halves, [C.c_void_p(t.data_ptr()) for t in ids_h], 17, k)
+    for e in whole + halves:
+        e.sync()
+    assert (np.concatenate([h.step_counts() for h in halves]) == whole[0].step_counts()).all()
+    assert (np.concatenate([h.scores() for h in halves]) == whole[0].scores()).all()
+    for a, b in zip(zip(*[h.status() for h in halves]), whole[0].status()):
+        assert (np.concatenate(a) == b).all()
+    assert (np.concatenate([h.mask() for h in halves]) == whole[0].mask()).all()
+    assert torch.equal(torch.cat(ids_h), ids_w[0]) and int(whole[0].total_steps()) > n * k // 2

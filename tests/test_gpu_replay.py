@@ -349,7 +349,7 @@ def test_logs_of_winning_play_yield_every_decision(mode, rate):
     assert got == want and not robbed, (got, want, robbed)
 
 
-@pytest.mark.parametrize("mode,picks", [(2, (27, 57, 70)), (5, (2, 151, 158))])
+@pytest.mark.parametrize("mode,picks", [(2, (17, 22, 39)), (5, (5, 10, 17))])   # (found again in round 6: the policy key changed)
 def test_the_ron_on_a_robbed_kakan_is_a_sample(mode, picks, tmp_path):
     """games in which a kakan is robbed (oracle, greedy policy, calls at 160 / 256 - seeds found by search): the
     reference's iterator yields the chankan Ron (replay/mod.rs:483-527 builds it from last_discard = the kakan tile,

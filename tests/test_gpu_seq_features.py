@@ -100,7 +100,7 @@ def test_compat_observation_seq_features():
         o3.encode_seq_numeric()
 
 
-@pytest.mark.parametrize("mode,seed,policy", [(2, 29, "random"), (0, 100, "random"), (2, 31, "greedy"), (1, 32, "greedy")])
+@pytest.mark.parametrize("mode,seed,policy", [(2, 34, "random"), (0, 100, "random"), (2, 31, "greedy"), (1, 32, "greedy")])   # (seed 34: a RandomAgent game that declares riichi within the window - searched again in round 6, the policy key changed)
 def test_seq_features_per_observation_delta(mode, seed, policy):
     """rmj_encode_seq_delta: the features over Observation.events as the reference's LIVE environment hands them out - the
     seat's log since its previous observation (state/mod.rs:211-218).  The harness keeps the oracle seats' cursors exactly

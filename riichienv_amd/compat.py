@@ -265,7 +265,8 @@ class Observation:
         self._aux_encoder = aux_encoder
         self._seq_encoder = seq_encoder
 
-    def action_space_size(self):  # observation/python.rs:114-117
+    @property
+    def action_space_size(self):  # observation/python.rs:113-116: a #[getter] (an attribute, not a method: found by transcribing tests/env/test_sanma.py:222-226 in round 6)
         return 60 if self.num_players == 3 else 82
 
     def select_action_from_mjai(self, mjai_data):  # observation/mjai_select.rs:88-194

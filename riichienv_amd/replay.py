@@ -368,7 +368,8 @@ class StepObservation:
     def __init__(self, player_id, num_players, tensor, mask, legal):
         self.player_id, self.num_players, self.tensor, self._mask, self._legal = player_id, num_players, tensor, mask, legal
 
-    def action_space_size(self):
+    @property
+    def action_space_size(self):   # (a getter, like the reference's Observation: observation/python.rs:113-116)
         return 60 if self.num_players == 3 else 82
 
     def legal_actions(self):

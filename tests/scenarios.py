@@ -1205,7 +1205,7 @@ def sc_no_tobi_with_positive_scores(make):
 
 
 def sc_riichi_sequence(make):
-    """docs/RULES.md:64-78, tests/env/rule_validation/test_riichi_sequence.py: reach -> dahai -> reach_accepted
+    """docs/RULES.md:64-78, tests/env/rule_validation/test_riichi_sequence.py:118-215 (test_mjai_reach_then_dahai_sequence): reach -> dahai -> reach_accepted
     -> tsumo; riichi discard restricted to tenpai-keeping tiles; stick paid on acceptance; ippatsu tsumo."""
     # seat 0: 123m 456m 789m 234p 5p + draw 9s -> riichi by discarding 9s (wait 5p) ; wall fixed so nobody calls
     hand = tiles("123456789m2345p")
@@ -1232,10 +1232,28 @@ def sc_riichi_sequence(make):
     assert v.players[0].riichi_declared == 1 and v.players[0].double_riichi_declared == 1
 
 
+def sc_riichi_stage_disables_ankan(make):
+    """tests/env/rule_validation/test_riichi_sequence.py:25-117 (test_riichi_stage_disables_ankan) and :216-273 (test_legal_actions_consistency_with_mortal_state):
+    333346m 23477p 345s + the fourth 3m: Riichi and Ankan are both offered; once riichi_stage is set (reach declared, discard pending) the list holds discards
+    only - no Ankan, no second Riichi.  (The reference fills the other seats with thirteen copies of one tile; they do not matter here and hold ordinary hands.)"""
+    hand = [8, 9, 10, 12, 20, 40, 44, 48, 60, 61, 80, 84, 88]
+    others = [tiles("19m19p19s1234567z"), tiles("2468m2468p2468s5z"), tiles("357m357p357s1122z")[:13]]
+    kw = dict(hands=others + [hand], current_player=3, active_players=[3], drawn_tile=11, riichi_declared=[False] * 4, points=[25000] * 4)
+    env = setup(make(seed=42), **kw)
+    types = {unpack_action(a)[0] for a in env.legal(3)}
+    assert RIICHI in types and ANKAN in types
+    env = setup(make(seed=42), mutate=lambda v: setattr(v.players[3], "riichi_stage", 1), **kw)
+    types = [unpack_action(a)[0] for a in env.legal(3)]
+    assert DISCARD in types and ANKAN not in types and RIICHI not in types and set(types) == {DISCARD}
+
+
 def sc_kyushu_kyuhai(make):
-    """tests/env/actions/test_kyushu_kyuhai.py: 9 terminal kinds on the first turn -> KyushuKyuhai legal; abortive
-    draw with renchan (honba+1)."""
+    """tests/env/actions/test_kyushu_kyuhai.py:7-43 (test_kyushu_kyuhai_abortive_draw): 9 terminal kinds on the first turn -> KyushuKyuhai legal; abortive
+    draw with renchan (honba+1); :44-74 (test_kyushu_kyuhai_not_available_after_meld): any meld on the table (here: a Pon of seat 1) takes the option away."""
     hand = tiles("19m19p19s1234z") + tiles("2m3p")[0:2]
+    env2 = setup(make(game_mode=0, seed=42), hands=[tiles("19m19p19s123z") + [4, 5, 6, 7][:4], None, None, None], drawn_tile=12,
+                 melds=[[], [(PON_M, [20, 21, 22], True, 0, 20)], [], []])
+    assert find(env2.legal(0), KYUSHU) is None and env2.mask(0)[80] == 0
     env = setup(make(game_mode=1), hands=[hand[:13], None, None, None], drawn_tile=128)
     k = find(env.legal(0), KYUSHU)
     assert k is not None
@@ -1764,7 +1782,7 @@ SCENARIOS = [sc_win_results_of_the_final_round, sc_paishan_dora_indices, sc_kaka
              sc_env_chi_claim_with_invalid_tile, sc_env_chi_claim_with_invalid_combo, sc_env_chi_multiple_patterns, sc_env_ron_claim,
              sc_env_ankan_riichi_legality, sc_daiminkan_pao_daisangen, sc_daiminkan_pao_daisuushii, sc_daiminkan_no_pao_insufficient_melds,
              sc_tenhou_tsumo_pao_composite, sc_tenhou_ron_pao_composite, sc_ryukyoku_deltas_are_reset_each_round_4p,
-             sc_riichi_stage_only_tenpai_maintaining_discards, sc_reach_accepted_event_includes_actor, sc_no_tobi_with_positive_scores, sc_riichi_sequence, sc_kyushu_kyuhai, sc_double_ron_honba_sticks,
+             sc_riichi_stage_only_tenpai_maintaining_discards, sc_reach_accepted_event_includes_actor, sc_no_tobi_with_positive_scores, sc_riichi_sequence, sc_riichi_stage_disables_ankan, sc_kyushu_kyuhai, sc_double_ron_honba_sticks,
              sc_tobi_and_agariyame,
              sc_furiten_ron, sc_temporary_furiten, sc_valid_ankan_after_riichi, sc_no_claims_during_riichi,
              sc_honba_reset_and_increment, sc_pao_ron_honba, sc_doujun_cleared_by_call,

@@ -53,3 +53,20 @@ def test_action_space_sizes_and_contiguous_3p_discards():
     valid = [0] + list(range(8, 34))
     assert len(valid) == 27
     assert sorted(both(True, abi.DISCARD, 4 * t) for t in valid) == list(range(27))
+
+
+def test_action_to_mjai_like_the_reference():
+    """tests/env/actions/test_action_to_mjai.py:7-24 (dahai / chi / reach), tests/test_core.py:190-217 and src/tests.rs:835-854 (a reach carries its actor only
+    when one is set; the attribute can be re-assigned) on the shim's host-side Action (action.rs:107-149)."""
+    import json
+
+    assert json.loads(Action(ActionType.DISCARD, tile=53).to_mjai()) == {"type": "dahai", "pai": "5p"}
+    assert json.loads(Action(ActionType.CHI, tile=53, consume_tiles=[49, 57]).to_mjai()) == {"type": "chi", "pai": "5p", "consumed": ["4p", "6p"]}
+    assert json.loads(Action(ActionType.RIICHI).to_mjai()) == {"type": "reach"}
+    a = Action(type=ActionType.RIICHI, actor=2)
+    assert json.loads(a.to_mjai()) == {"type": "reach", "actor": 2}
+    assert "actor" not in json.loads(Action(type=ActionType.RIICHI).to_mjai())
+    a.actor = 0
+    assert json.loads(a.to_mjai())["actor"] == 0
+    a.actor = None
+    assert "actor" not in json.loads(a.to_mjai())

@@ -92,7 +92,7 @@ def test_sanma_readme_loop_and_surface():
     env = RiichiEnv(game_mode="3p-red-half", seed=11)
     obs_dict = env.reset()
     o = obs_dict[0]
-    assert env.num_players == 3 and len(o.hands) == 3 and len(o.mask()) == 60 and o.action_space_size() == 60
+    assert env.num_players == 3 and len(o.hands) == 3 and len(o.mask()) == 60 and o.action_space_size == 60
     assert len(o.encode()) == 74 * 27 * 4 and len(o.encode_extended()) == 215 * 27 * 4
     a = o.legal_actions()[0]
     assert o.find_action(a.encode_3p()) is not None
@@ -408,3 +408,164 @@ def test_scalar_env_against_the_oracle_under_winning_play(mode, rule_name):
     assert list(env.scores())[: env.num_players] == [v.players[p].score for p in range(env.num_players)]
     wins = sum(1 for e in env.mjai_log if e["type"] == "hora")
     assert wins >= 3 and any(e["type"] == "reach_accepted" for e in env.mjai_log)
+
+
+def test_observe_event_3p_like_reference():
+    """tests/env/test_apply_event.py:292-458 (class TestApplyEvent3P: test_start_game_returns_none :298-302, test_start_kyoku_returns_none :303-308,
+    test_tsumo_returns_obs_for_actor :309-319, test_tsumo_returns_none_for_other_player :333-339, test_dahai_returns_obs_when_pon_available :340-352,
+    test_dahai_returns_none_when_no_reaction :353-363, test_hora_returns_none :364-370, test_ryukyoku_returns_none :371-377, test_tsumo_after_opponent_discard
+    :378-388, test_pon_then_discard_flow :389-401, test_kita_returns_none_for_other :402-422, test_multi_turn_sequence :423-458) and the 4P twins
+    test_start_game_returns_none :98-102, test_multi_turn_sequence :254-291: masked streams through compat.observe_event in a sanma game."""
+    from riichienv_amd.compat import ActionType, RiichiEnv
+    from tests.apply_events_util import TEHAIS_3P, TEHAIS_4P, start_kyoku
+
+    def env_for(seat, tehais=TEHAIS_3P, mode="3p-red-half"):
+        e = RiichiEnv(game_mode=mode)
+        assert e.observe_event({"type": "start_game"}, seat) is None
+        assert e.observe_event(start_kyoku(_masked(tehais, seat)), seat) is None
+        return e
+
+    e = env_for(0)
+    obs = e.observe_event({"type": "tsumo", "actor": 0, "pai": "3z"}, 0)
+    assert obs is not None and any(a.action_type == ActionType.DISCARD for a in obs.legal_actions())
+    assert e.observe_event({"type": "dahai", "actor": 0, "pai": "3z", "tsumogiri": True}, 0) is None      # no reaction to the own discard
+    assert e.observe_event({"type": "tsumo", "actor": 1, "pai": "?"}, 0) is None
+    obs = e.observe_event({"type": "dahai", "actor": 1, "pai": "4s", "tsumogiri": True}, 0)
+    assert obs is None or len(obs.legal_actions()) > 0
+    e = env_for(1)
+    assert e.observe_event({"type": "tsumo", "actor": 0, "pai": "?"}, 1) is None
+    obs = e.observe_event({"type": "dahai", "actor": 0, "pai": "1p", "tsumogiri": False}, 1)
+    assert obs is not None and {ActionType.PON, ActionType.PASS} <= {a.action_type for a in obs.legal_actions()}
+    obs = e.observe_event({"type": "pon", "actor": 1, "target": 0, "pai": "1p", "consumed": ["1p", "1p"]}, 1)
+    assert obs is not None and any(a.action_type == ActionType.DISCARD for a in obs.legal_actions())
+    e = env_for(2)
+    e.observe_event({"type": "tsumo", "actor": 0, "pai": "?"}, 2)
+    obs = e.observe_event({"type": "dahai", "actor": 0, "pai": "2p", "tsumogiri": False}, 2)
+    assert obs is None or len(obs.legal_actions()) > 0
+    e = env_for(1)
+    e.observe_event({"type": "tsumo", "actor": 0, "pai": "?"}, 1)
+    e.observe_event({"type": "dahai", "actor": 0, "pai": "3z", "tsumogiri": True}, 1)
+    obs = e.observe_event({"type": "tsumo", "actor": 1, "pai": "5z"}, 1)
+    assert obs is not None and len(obs.legal_actions()) > 0
+    e = env_for(1)
+    e.observe_event({"type": "tsumo", "actor": 0, "pai": "?"}, 1)
+    res = e.observe_event({"type": "kita", "actor": 0}, 1)
+    assert res is None or len(res.legal_actions()) > 0
+    for ev in ({"type": "hora", "actor": 0, "target": 0}, {"type": "ryukyoku"}):
+        assert env_for(0).observe_event(ev, 0) is None
+    # the 4P twin of the multi-turn flow (tests/env/test_apply_event.py:254-291)
+    e = env_for(0, TEHAIS_4P, "default")
+    assert e.observe_event({"type": "tsumo", "actor": 0, "pai": "4p"}, 0) is not None
+    assert e.observe_event({"type": "dahai", "actor": 0, "pai": "4p", "tsumogiri": True}, 0) is None
+    assert e.observe_event({"type": "tsumo", "actor": 1, "pai": "?"}, 0) is None
+    obs = e.observe_event({"type": "dahai", "actor": 1, "pai": "4s", "tsumogiri": True}, 0)
+    assert obs is None or len(obs.legal_actions()) > 0
+
+
+def test_non_action_events_never_return_an_observation():
+    """tests/env/test_apply_event.py:469-483 (TestApplyEventConsistency.test_non_action_events_always_none), 4P and 3P, every seat"""
+    from riichienv_amd.compat import RiichiEnv
+    from tests.apply_events_util import TEHAIS_3P, TEHAIS_4P, start_kyoku
+
+    for mode, tehais in (("default", TEHAIS_4P), ("3p-red-half", TEHAIS_3P)):
+        for pid in range(len(tehais)):
+            env = RiichiEnv(game_mode=mode)
+            for ev in ({"type": "start_game"}, start_kyoku(_masked(tehais, pid)), {"type": "dora", "dora_marker": "3p"},
+                       {"type": "hora", "actor": 0, "target": 0}, {"type": "ryukyoku"}):
+                assert env.observe_event(ev, pid) is None, (mode, pid, ev["type"])
+
+
+def test_apply_event_log_covers_calls_reach_and_round_end():
+    """tests/env/test_apply_event_mjai_log.py: test_events_accumulate_in_order :75-89 / :208-221, test_start_game_preserves_custom_fields :90-96,
+    test_pon_event_logged :97-116 / :222-246, test_chi_event_logged :117-142, test_reach_events_logged :143-156, test_full_round_event_count :157-176,
+    test_end_game_logged :177-196, test_start_game_clears_constructor_log :65-74 / :200-207, test_observe_event_logs_events_4p :250-273, test_observe_event_logs_events_3p :274-296,
+    test_observe_event_clears_on_start_game :297-311, test_tsumo_log_contains_pai_field :315-325, test_dahai_log_contains_tsumogiri_field :326-338,
+    test_start_kyoku_log_contains_tehais :339-348, test_multiple_start_game_resets_log :349-361 - everything apply_event / observe_event is given shows up in
+    mjai_log, in order, with its fields."""
+    from riichienv_amd.compat import RiichiEnv
+    from tests.apply_events_util import CHI_TEHAIS, TEHAIS_3P, TEHAIS_4P, start_kyoku
+
+    env = RiichiEnv(game_mode="default")
+    assert len(env.mjai_log) > 0
+    round4 = [{"type": "start_game", "names": ["A", "B", "C", "D"]}, start_kyoku(TEHAIS_4P),
+              {"type": "tsumo", "actor": 0, "pai": "5p"}, {"type": "dahai", "actor": 0, "pai": "5p", "tsumogiri": True},
+              {"type": "tsumo", "actor": 1, "pai": "6s"}, {"type": "dahai", "actor": 1, "pai": "6s", "tsumogiri": True},
+              {"type": "tsumo", "actor": 2, "pai": "4z"}, {"type": "dahai", "actor": 2, "pai": "4z", "tsumogiri": True},
+              {"type": "tsumo", "actor": 3, "pai": "2z"}, {"type": "dahai", "actor": 3, "pai": "2z", "tsumogiri": True}]
+    for ev in round4:
+        env.apply_event(ev)
+    log = env.mjai_log
+    assert len(log) == len(round4) and [e["type"] for e in log] == [e["type"] for e in round4]
+    assert log[0]["names"] == ["A", "B", "C", "D"] and log[2]["pai"] == "5p" and log[3]["tsumogiri"] is True and len(log[1]["tehais"]) == 4
+    # pon, then the caller's discard
+    env = RiichiEnv(game_mode="default")
+    for ev in ({"type": "start_game"}, start_kyoku(TEHAIS_4P), {"type": "tsumo", "actor": 0, "pai": "4p"},
+               {"type": "dahai", "actor": 0, "pai": "1m", "tsumogiri": False},
+               {"type": "pon", "actor": 1, "target": 0, "pai": "1m", "consumed": ["1m", "1m"]}, {"type": "dahai", "actor": 1, "pai": "5s", "tsumogiri": False}):
+        env.apply_event(ev)
+    pon = next(e for e in env.mjai_log if e["type"] == "pon")
+    assert (pon["actor"], pon["target"], pon["pai"], pon["consumed"]) == (1, 0, "1m", ["1m", "1m"])
+    assert [e["type"] for e in env.mjai_log][-2:] == ["pon", "dahai"]
+    # chi
+    env = RiichiEnv(game_mode="default")
+    for ev in ({"type": "start_game"}, start_kyoku(CHI_TEHAIS), {"type": "tsumo", "actor": 0, "pai": "4z"},
+               {"type": "dahai", "actor": 0, "pai": "3m", "tsumogiri": False}, {"type": "chi", "actor": 1, "target": 0, "pai": "3m", "consumed": ["4m", "5m"]}):
+        env.apply_event(ev)
+    chi = next(e for e in env.mjai_log if e["type"] == "chi")
+    assert (chi["actor"], chi["consumed"]) == (1, ["4m", "5m"])
+    # reach / reach_accepted, and the end of the round and of the game
+    env = RiichiEnv(game_mode="default")
+    for ev in ({"type": "start_game"}, start_kyoku(TEHAIS_4P), {"type": "tsumo", "actor": 0, "pai": "5p"}, {"type": "reach", "actor": 0},
+               {"type": "dahai", "actor": 0, "pai": "1m", "tsumogiri": False}, {"type": "reach_accepted", "actor": 0}):
+        env.apply_event(ev)
+    assert {"reach", "reach_accepted"} <= {e["type"] for e in env.mjai_log}
+    env = RiichiEnv(game_mode="default")
+    for ev in ({"type": "start_game"}, start_kyoku(TEHAIS_4P), {"type": "tsumo", "actor": 0, "pai": "5p"}, {"type": "hora", "actor": 0, "target": 0},
+               {"type": "end_kyoku"}, {"type": "end_game"}):
+        env.apply_event(ev)
+    assert [e["type"] for e in env.mjai_log][-2:] == ["end_kyoku", "end_game"]
+    # 3P through observe_event
+    env = RiichiEnv(game_mode="3p-red-half")
+    for ev in ({"type": "start_game"}, start_kyoku(TEHAIS_3P), {"type": "tsumo", "actor": 0, "pai": "3z"}, {"type": "dahai", "actor": 0, "pai": "3z", "tsumogiri": True}):
+        env.observe_event(ev, 0)
+    assert [e["type"] for e in env.mjai_log] == ["start_game", "start_kyoku", "tsumo", "dahai"] and len(env.mjai_log[1]["tehais"]) == 3
+    env.observe_event({"type": "start_game"}, 0)
+    assert [e["type"] for e in env.mjai_log] == ["start_game"]
+
+
+def test_new_events_like_reference():
+    """tests/env/test_riichienv.py:129-196 (test_new_events): with the other seats' hands emptied (no claims), one go-around shows each seat exactly the events since
+    its previous observation: 3 at the start (the own tsumo unmasked), then 5 / 7 / 9 for seats 1 / 2 / 3 (each ending in the seat's own tsumo), and seat 0 sees
+    the eight events dahai 0 ... tsumo 0 when its turn comes back."""
+    import json
+
+    from riichienv_amd.compat import Action, ActionType, Phase, RiichiEnv
+
+    env = RiichiEnv(seed=9)
+    obs = env.reset()
+    h = env.hands
+    h[1], h[2], h[3] = [], [], []
+    env.hands = h
+    assert env.phase == Phase.WaitAct
+    first = obs[0].new_events()
+    assert len(first) == 3 and json.loads(first[2])["pai"] != "?"
+    p0 = []
+
+    def collect(o):
+        if 0 in o:
+            p0.extend(json.loads(e) for e in o[0].new_events())
+
+    obs = env.step({0: Action(ActionType.DISCARD, tile=obs[0].hand[0])})
+    collect(obs)
+    assert env.phase == Phase.WaitAct and 1 in obs and 0 not in obs
+    for pid, want in ((1, 5), (2, 7), (3, 9)):
+        new = [json.loads(e) for e in obs[pid].new_events()]
+        assert len(new) == want and new[-1]["type"] == "tsumo" and new[-1]["actor"] == pid
+        obs = env.step({pid: Action(ActionType.DISCARD, tile=obs[pid].hand[0])})
+        collect(obs)
+        if env.phase == Phase.WaitResponse:
+            obs = env.step({p: Action(ActionType.PASS) for p in env.active_players})
+            collect(obs)
+    assert env.phase == Phase.WaitAct and 0 in obs and 3 not in obs
+    assert [(e["type"], e["actor"]) for e in p0] == [("dahai", 0), ("tsumo", 1), ("dahai", 1), ("tsumo", 2), ("dahai", 2), ("tsumo", 3), ("dahai", 3), ("tsumo", 0)]
+    assert [e["pai"] == "?" for e in p0 if e["type"] == "tsumo"] == [True, True, True, False]

@@ -201,7 +201,7 @@ def test_steps_reach_discard_observation_is_not_duplicated_state(n, tmp_path):
     for obs, act in steps:
         aid = act.encode_3p() if n == 3 else act.encode()
         mask = np.frombuffer(obs.mask(), dtype=np.uint8)
-        assert mask.shape[0] == obs.action_space_size() and mask[aid] == 1
+        assert mask.shape[0] == obs.action_space_size and mask[aid] == 1
         assert len(obs.encode()) == 74 * (27 if n == 3 else 34) * 4
 
 

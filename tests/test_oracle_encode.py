@@ -112,3 +112,56 @@ def test_extended_decay_and_scalars():
     assert e[74, 9] == w[3]
     assert np.allclose(e[189], 13 / 34.0) and (e[192] == 0).all() and (e[193] == 0).all()
     assert (e[194:197] == 0).all() and (e[206:215] == 0).all()
+
+
+def _ext_env_3p(discards=None, melds=None):
+    """make_obs of observation_3p/encode.rs:621-654: sanma hands 1m 9m 1-9p 1-2s (+ seat), given discards / melds, nothing else"""
+    from riichienv_amd import abi
+
+    env = OracleEnv(game_mode=5, seed=5)
+
+    def mut(v):
+        for p in range(3):
+            d = (discards or [[]] * 3)[p]
+            v.players[p].n_discards = len(d)
+            for i, t in enumerate(d):
+                v.players[p].discards[i] = t
+            ms = (melds or [[]] * 3)[p]
+            v.players[p].n_melds = len(ms)
+            for i, (mt, ts, called) in enumerate(ms):
+                m = v.players[p].melds[i]
+                m.meld_type, m.n_tiles, m.opened, m.from_who, m.called_tile = mt, len(ts), int(mt != abi.MELD_ANKAN), 0, called
+                for k, t in enumerate(ts):
+                    m.tiles[k] = t
+        v.n_dora = 0
+
+    base = [0, 32, 36, 40, 44, 48, 52, 56, 60, 64, 68, 72, 76]
+    setup(env, hands=[[t + p for t in base] for p in range(3)] + [None], drawn_tile=None, mutate=mut)
+    return env
+
+
+def test_extended_relative_order_kats_3p():
+    """observation_3p/encode.rs:667-791 (the five unit tests of the 3P extended blocks: test_discard_decay_relative_order_3p, test_shanten_relative_order_3p,
+    test_ankan_relative_order_3p, test_fuuro_relative_order_3p, test_self_channel_always_first_3p); channel offsets of observation_3p/python.rs:1117-1138 (the 4P
+    ones: decay 74, shanten 78, ankan 94, fuuro 98), columns = compact 3P tile indices (1m 0, 9m 1, 1p 2, ... 1s 11)."""
+    from riichienv_amd import abi
+
+    env = _ext_env_3p(discards=[[0], [36], []])
+    e0, e1 = env.g.encode_extended(0), env.g.encode_extended(1)
+    assert e0.shape == (215, 27)
+    assert e0[74 + 0, 0] > 0 and e0[74 + 1, 2] > 0             # seat 0: itself, then seat 1
+    assert e1[74 + 0, 2] > 0 and e1[74 + 2, 0] > 0             # seat 1: itself, seat 0 is two seats on
+    env = _ext_env_3p(discards=[[0, 32], [36], [40, 44, 48]])
+    e0, e1 = env.g.encode_extended(0), env.g.encode_extended(1)
+    assert abs(e0[78 + 3, 0] - e1[78 + 2 * 4 + 3, 0]) < 1e-6   # seat 0's turn count, seen by itself and by seat 1
+    assert (e0[78 + 4] == 0.5).all() and abs(e0[78, 0] - 0.5) > 1e-6
+    env = _ext_env_3p(melds=[[], [(abi.MELD_ANKAN, [36, 37, 38, 39], -1)], []])
+    e0, e2 = env.g.encode_extended(0), env.g.encode_extended(2)
+    assert e0[94 + 1, 2] == 1 and e0[94 + 0, 2] == 0 and e2[94 + 2, 2] == 1 and e2[94 + 1, 2] == 0
+    env = _ext_env_3p(melds=[[], [], [(abi.MELD_PON, [36, 37, 38], 36)]])
+    e0, e1 = env.g.encode_extended(0), env.g.encode_extended(1)
+    assert e0[98 + 40, 2] == 1 and e1[98 + 20, 2] == 1
+    d = [[0], [36], [72]]
+    env = _ext_env_3p(discards=d)
+    for pid, col in enumerate((0, 2, 11)):
+        assert env.g.encode_extended(pid)[74, col] > 0

@@ -83,3 +83,35 @@ def test_hand_kats_from_reference_unit_tests():
     res = oracle.eval_hands([abi.hand_case_from_fixture(c) for _, c, _ in HAND_KATS])
     for (name, _, want), r in zip(HAND_KATS, res):
         check(name, r, want)
+
+
+def _counts(types):
+    c = np.zeros(34, np.uint8)
+    for t in types:
+        c[t] += 1
+    return c
+
+
+UNIT_SHAPES = [  # riichienv-core/src/tests.rs:9-75: test_agari_standard :9-20 / test_basic_pinfu :23-50 (123m 456m 789m 123p 11s), test_chiitoitsu :53-62, test_kokushi :65-75
+    ("standard / pinfu shape", [0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 18, 18]),
+    ("chiitoitsu", [t for t in (0, 2, 4, 6, 8, 10, 12) for _ in range(2)]),
+    ("kokushi", [0, 8, 9, 17, 18, 26, 27, 28, 29, 30, 31, 32, 33, 0]),
+]
+
+
+def test_unit_shapes_of_the_reference_are_wins():
+    """tests.rs:9-75 (is_agari / is_chiitoitsu / is_kokushi on three textbook hands); the same hands without their last tile are tenpai and wait on it.
+    state/game_mode.rs:68-74, 77-90 (test_game_mode_config_four_player: 25 000 points to start with; test_sanma_excluded_tiles): a sanma deal holds
+    no 2m-8m, a 4P game starts at 25 000."""
+    counts = np.array([_counts(h) for _, h in UNIT_SHAPES] + [_counts(h[:-1]) for _, h in UNIT_SHAPES], dtype=np.uint8)
+    ag, tp, waits = oracle.agari_counts(counts)
+    n = len(UNIT_SHAPES)
+    assert list(ag[:n]) == [1] * n
+    for i, (name, h) in enumerate(UNIT_SHAPES):
+        assert tp[n + i] == 1 and (int(waits[n + i]) >> h[-1]) & 1, name
+    g3 = oracle.Game(game_mode=5, seed=3)
+    v = g3.peek()
+    tiles = list(v.wall[: v.wall_len]) + [t for p in range(3) for t in v.players[p].hand[: v.players[p].hand_len]]
+    assert len(tiles) == 108 and all(t < 4 or t >= 32 for t in tiles) and {t // 4 for t in tiles} == set(range(34)) - set(range(1, 8))
+    g4 = oracle.Game(game_mode=2, seed=3)
+    assert [g4.peek().players[p].score for p in range(4)] == [25000] * 4

@@ -58,6 +58,12 @@ __device__ __forceinline__ uint32_t r4_rows(uint32_t flags) {
 #ifndef RMJ_CHI_SKIP
 #define RMJ_CHI_SKIP 1   /* chi lists: a pattern no row of the wave can form is skipped as a whole (0: A/B) */
 #endif
+#ifndef RMJ_GROUP_FILTER13
+#define RMJ_GROUP_FILTER13 1   /* wait-cache refill: the group-residue test in front of the table shanten (r4_group_residues; 0: A/B) */
+#endif
+#ifndef RMJ_GROUP_FILTER14
+#define RMJ_GROUP_FILTER14 1   /* riichi bound of the drawer's list: the same on 14 tiles (0: A/B) */
+#endif
 #ifndef RMJ_HEAVY_TENPAI
 #define RMJ_HEAVY_TENPAI 1   /* heavy-first order of the per-step kernel: games with a seat that waits without a riichi count as heavy (0: A/B) */
 #endif
@@ -151,6 +157,7 @@ struct R4 {
 #endif
     int evn;          // staged events
     uint32_t dirty;
+    bool gf;          // the group-residue tests in front of the table shanten (r4_group_residues): a compile-time constant of the instantiation, see step4_body
 };
 
 __device__ __forceinline__ void r4_emit(R4& q, uint32_t w0, uint32_t w1, uint32_t w6) {
@@ -260,6 +267,7 @@ struct R4Shape {
     int yaochu;   // kinds of terminals and honors
     int kinds;    // distinct tile types
     int pairs;    // types held at least twice
+    bool start;   // per lane: this tile opens a connected group (nothing within two ranks below it)
 };
 __device__ __forceinline__ R4Shape r4_shape_sorted(const R4& q, const PState* P, int n) {
     const int r = q.r, rb = q.rb;
@@ -275,7 +283,21 @@ __device__ __forceinline__ R4Shape r4_shape_sorted(const R4& q, const PState* P,
     o.yaochu = __popc(rballot(first && term, rb));
     o.kinds = __popc(rballot(first, rb));
     o.pairs = __popc(rballot(first && !last_of_kind, rb));
+    o.start = in && k - kp > 2;
     return o;
+}
+// Sizes mod 3 of the connected groups of a sorted run of n tiles (a group = maximal chain of tiles whose neighbours are within two
+// ranks: every set, pair and taatsu lies inside one group).  Returns (#groups of size 1 mod 3) | (#groups of size 2 mod 3) << 4.
+// A standard-form tenpai of 3m + 1 tiles is m sets and a single ({1}), or m - 1 sets, a pair and a pair / taatsu: the two two-tile
+// blocks in one group ({1}) or in two ({2, 2}); every other residue pattern is at least one tile away from tenpai.  Adding one tile
+// anywhere (3m + 2 tiles one discard away from tenpai): {2}, {1, 1} or {2, 2, 1}.  (round 6: random 13-tile hands that still need the
+// table shanten after the isolated-tile bound: 5.8 % -> 0.6 %)
+__device__ __forceinline__ uint32_t r4_group_residues(bool start, int n, int r, int rb) {
+    const uint32_t S = rballot(start, rb);
+    const uint32_t rest = S >> (r + 1);
+    const int size = (rest ? __ffs((int)rest) : n - r);   // distance to the next group's first tile, or to the end of the run
+    const int res = size - 3 * ((size * 11) >> 5);        // size % 3 for size <= 14
+    return (uint32_t)__popc(rballot(start && res == 1, rb)) | ((uint32_t)__popc(rballot(start && res == 2, rb)) << 4);
 }
 // One suit word of a hand judged on its own (agari.rs:183-245, boolean): `tot` = its tile count mod 3; 0: sets only, 2: a pair and
 // sets (three pair candidates by pair_residue), 1: never.  s = 3: honors.
@@ -409,7 +431,14 @@ __device__ __forceinline__ void r4_fill_waits13(R4& q, PState* P, int n) {
         // tenpai holds twelve kinds of terminals and honors: two isolated tiles and fewer than twelve such kinds mean
         // shanten >= 1 - no waits, which is all the cache must know; sh13 = 1 is then a lower bound (its users only ever
         // skip work on ">= 2").  Only the remaining ~5 % of the hands take the table shanten.
-        if (iso >= 2 && yaochu < 12) {
+        // Of the rest, a standard-form tenpai needs its groups' sizes mod 3 to be {1} or {2, 2} (r4_group_residues); seven pairs
+        // and kokushi keep their own gates.
+        bool far = iso >= 2 && yaochu < 12;
+        if (RMJ_GROUP_FILTER13 && q.gf && !far && !(len3 == 4 && (sp.pairs >= 6 || yaochu >= 12))) {
+            const uint32_t gr = r4_group_residues(sp.start, n, q.r, q.rb);
+            far = gr != 0x01u && gr != 0x20u;
+        }
+        if (far) {
             sh = 1;
         } else {
             PH h13 = {0, 0, 0, 0};
@@ -1000,10 +1029,12 @@ __device__ __forceinline__ void r4_gen_act_legal(R4& q, int& nl_mine) {
     const int ht = r < hl ? (int)P->hand[r] : 0xFF;
     const int hty = ht >> 2;
     int n = 0;
+    int d_idx = -1;   // the drawn tile's slot
     // 1. Tsumo: is the drawn type a wait of the 13 other tiles?  (cache, else the cheap refill; a complete hand bails)
     if (drawn && !r_stage) {
         const uint32_t b = rballot(r < hl && ht == drawn_tile, rb);
         const int idx = b ? 31 - __clz((int)b) : -1;
+        d_idx = idx;
         const int same_type = __popc(rballot(r < hl && hty == (drawn_tile >> 2), rb));
         if (!(idx >= 0 && same_type <= 4 && (hl - 1) + 3 * nmelds == 13)) { R4BAIL(q, 12); return; }
         if (!(pflags & PF_WAITS_VALID)) {
@@ -1053,7 +1084,29 @@ __device__ __forceinline__ void r4_gen_act_legal(R4& q, int& nl_mine) {
                 const uint32_t T9 = 1u | (1u << 24);
                 const int yk = __popc((full.a | (full.a >> 1) | (full.a >> 2)) & T9) + __popc((full.b | (full.b >> 1) | (full.b >> 2)) & T9) +
                                __popc((full.c | (full.c >> 1) | (full.c >> 2)) & T9) + __popc((full.d | (full.d >> 1) | (full.d >> 2)) & O7_1);
-                if (!(r4_isolated(full) >= 3 && yk < 12)) {
+                // (round 6) and, in standard form, groups of sizes {2}, {1, 1} or {2, 2, 1} mod 3 (r4_group_residues: a tenpai 13 plus one
+                // tile) - which three isolated tiles never are; seven pairs need six pairs.  The drawn tile is merged into the sorted
+                // run by its rank; a hand that is not "sorted run + drawn tile" keeps the histogram bound.
+                bool may;
+                const int nx14 = __builtin_amdgcn_update_dpp(0xFFFF, ht, 0x101 /* row_shl:1 */, 0xf, 0xf, false);
+                if (RMJ_GROUP_FILTER14 && q.gf && d_idx == hl - 1 && rballot(r < hl - 2 && ht > nx14, rb) == 0u) {
+                    const bool in = r < hl;
+                    const int k = in ? r4_key(hty) : 1000;
+                    const int kd = rbc(k, rb + hl - 1);
+                    const int m = __popc(rballot(r < hl - 1 && k <= kd, rb));   // the drawn tile's place in the run
+                    const int ks = __builtin_amdgcn_update_dpp(-1000, k, 0x111 /* row_shr:1 */, 0xf, 0xf, false);
+                    const int k14 = !in ? 1000 : (r < m ? k : (r == m ? kd : ks));
+                    const int kp = __builtin_amdgcn_update_dpp(-1000, k14, 0x111 /* row_shr:1 */, 0xf, 0xf, false);
+                    const uint32_t gr = r4_group_residues(in && k14 - kp > 2, hl, r, rb);
+                    may = gr == 0x10u || gr == 0x02u || gr == 0x21u;
+                    if (!may && hl == 14) {
+                        const int kn = __builtin_amdgcn_update_dpp(1000, k14, 0x101 /* row_shl:1 */, 0xf, 0xf, false);
+                        may = yk >= 12 || __popc(rballot(in && k14 != kp && k14 == kn, rb)) >= 6;
+                    }
+                } else {
+                    may = !(r4_isolated(full) >= 3 && yk < 12);
+                }
+                if (may) {
                     if (r4_shanten(q, full, hl / 3) <= 0) {
                         if (!RICH) { R4BAIL(q, 14); return; }
                         need_tp = true;
@@ -1179,7 +1232,7 @@ __device__ __noinline__ void r4_round_end(const Env* Ep, uint32_t g0) {
     GState* G = &sh.st[row];
     R4 q;
     q.G = G; q.T = &sh.u.t; q.E = &E; q.lane = lane; q.r = r; q.rb = rb; q.row = row; q.g = g0 + (uint32_t)row;
-    q.live = mode != 0u; q.bail = false; q.cont = 0; q.rend = mode; q.evn = 0; q.dirty = 0xFu; q.pause_ok = false; q.yk = 0u; q.yk_mode = 0u;
+    q.live = mode != 0u; q.bail = false; q.cont = 0; q.rend = mode; q.evn = 0; q.dirty = 0xFu; q.pause_ok = false; q.yk = 0u; q.yk_mode = 0u; q.gf = false;
     const bool draw = mode == R4_RE_DRAW, restart = mode == R4_RE_RESTART;
     const bool win_t = mode == R4_RE_WIN_TSUMO, win_r = mode == R4_RE_WIN_RON, win = win_t || win_r;
     bool newround = restart;            // the row's game starts a round below, with these parameters (row-uniform)
@@ -1977,6 +2030,9 @@ __device__ __forceinline__ uint32_t step4_body(const Env* Ep, Quad4Shared& sh, u
     {
     R4 q;
     q.G = &sh.st[row]; q.T = &sh.u.t; q.E = &E; q.lane = lane; q.r = r; q.rb = rb; q.row = row; q.g = g;
+    // (round 6, one box, 65 536 games: with the tests the fused rollouts gain 1.5 % (2.11 -> 2.14 G); the kernels of one step per launch lose - the step at
+    //  80 registers has no room for them: 0.97 -> 0.88 G - and keep the isolated-tile bounds alone)
+    q.gf = LOOP;
     // pass 2 (RMJ_ROW_ROUND_END): the rows whose round ended in pass 1 and has been dealt since (r4_round_end, run by the caller between the
     // passes - a call in here would cost every step ten more callee-saved registers): they skip policy and transitions, get their
     // first list and are published like any other row

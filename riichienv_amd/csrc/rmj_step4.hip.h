@@ -58,6 +58,9 @@ __device__ __forceinline__ uint32_t r4_rows(uint32_t flags) {
 #ifndef RMJ_CHI_SKIP
 #define RMJ_CHI_SKIP 1   /* chi lists: a pattern no row of the wave can form is skipped as a whole (0: A/B) */
 #endif
+#ifndef RMJ_GROUP_FILTER_ALL
+#define RMJ_GROUP_FILTER_ALL 0   /* 1: the group-residue tests also in the kernels of one step per launch (A/B; see step4_body) */
+#endif
 #ifndef RMJ_GROUP_FILTER13
 #define RMJ_GROUP_FILTER13 1   /* wait-cache refill: the group-residue test in front of the table shanten (r4_group_residues; 0: A/B) */
 #endif
@@ -268,6 +271,7 @@ struct R4Shape {
     int kinds;    // distinct tile types
     int pairs;    // types held at least twice
     bool start;   // per lane: this tile opens a connected group (nothing within two ranks below it)
+    uint32_t S;   // the row's ballot of `start`
 };
 __device__ __forceinline__ R4Shape r4_shape_sorted(const R4& q, const PState* P, int n) {
     const int r = q.r, rb = q.rb;
@@ -276,14 +280,15 @@ __device__ __forceinline__ R4Shape r4_shape_sorted(const R4& q, const PState* P,
     const int k = in ? r4_key(t) : 1000;
     const int kp = __builtin_amdgcn_update_dpp(-1000, k, 0x111 /* row_shr:1 */, 0xf, 0xf, false);   // lane r - 1 (row start: -1000)
     const int kn = __builtin_amdgcn_update_dpp(1000, k, 0x101 /* row_shl:1 */, 0xf, 0xf, false);     // lane r + 1 (row end: 1000)
-    const bool term = t >= 27 || t == 0 || t == 8 || t == 9 || t == 17 || t == 18 || t == 26;
     const bool first = in && k != kp, last_of_kind = in && k != kn;
     R4Shape o;   // (round 5: the "one extra tile" form of rounds 3-4 had a single caller without an extra tile)
-    o.iso = __popc(rballot(in && k - kp > 2 && kn - k > 2, rb));
-    o.yaochu = __popc(rballot(first && term, rb));
+    o.start = in && k - kp > 2;
+    o.S = rballot(o.start, rb);
+    o.iso = __popc(rballot(o.start && kn - k > 2, rb));
+    const bool term = t >= 27 || t == 0 || t == 8 || t == 9 || t == 17 || t == 18 || t == 26;
+    o.yaochu = __popc(rballot(first && term, rb));   // (needed whenever the kokushi bound 12 - kinds can undercut the isolated-tile bound: no cheap gate)
     o.kinds = __popc(rballot(first, rb));
     o.pairs = __popc(rballot(first && !last_of_kind, rb));
-    o.start = in && k - kp > 2;
     return o;
 }
 // Sizes mod 3 of the connected groups of a sorted run of n tiles (a group = maximal chain of tiles whose neighbours are within two
@@ -292,8 +297,7 @@ __device__ __forceinline__ R4Shape r4_shape_sorted(const R4& q, const PState* P,
 // blocks in one group ({1}) or in two ({2, 2}); every other residue pattern is at least one tile away from tenpai.  Adding one tile
 // anywhere (3m + 2 tiles one discard away from tenpai): {2}, {1, 1} or {2, 2, 1}.  (round 6: random 13-tile hands that still need the
 // table shanten after the isolated-tile bound: 5.8 % -> 0.6 %)
-__device__ __forceinline__ uint32_t r4_group_residues(bool start, int n, int r, int rb) {
-    const uint32_t S = rballot(start, rb);
+__device__ __forceinline__ uint32_t r4_group_residues(bool start, uint32_t S, int n, int r, int rb) {
     const uint32_t rest = S >> (r + 1);
     const int size = (rest ? __ffs((int)rest) : n - r);   // distance to the next group's first tile, or to the end of the run
     const int res = size - 3 * ((size * 11) >> 5);        // size % 3 for size <= 14
@@ -435,7 +439,7 @@ __device__ __forceinline__ void r4_fill_waits13(R4& q, PState* P, int n) {
         // and kokushi keep their own gates.
         bool far = iso >= 2 && yaochu < 12;
         if (RMJ_GROUP_FILTER13 && q.gf && !far && !(len3 == 4 && (sp.pairs >= 6 || yaochu >= 12))) {
-            const uint32_t gr = r4_group_residues(sp.start, n, q.r, q.rb);
+            const uint32_t gr = r4_group_residues(sp.start, sp.S, n, q.r, q.rb);
             far = gr != 0x01u && gr != 0x20u;
         }
         if (far) {
@@ -1081,12 +1085,14 @@ __device__ __forceinline__ void r4_gen_act_legal(R4& q, int& nl_mine) {
                 // tenpai_after_discard: only a 14-tile shanten <= 0 can keep a tenpai 13 (those hands take the probes).  Such a
                 // hand has at most TWO isolated tiles (the discard and a tanki) and, as a kokushi shape, thirteen kinds with
                 // at most one missing: three isolated tiles and < 12 kinds of terminals / honors rule Riichi out without tables.
-                const uint32_t T9 = 1u | (1u << 24);
-                const int yk = __popc((full.a | (full.a >> 1) | (full.a >> 2)) & T9) + __popc((full.b | (full.b >> 1) | (full.b >> 2)) & T9) +
-                               __popc((full.c | (full.c >> 1) | (full.c >> 2)) & T9) + __popc((full.d | (full.d >> 1) | (full.d >> 2)) & O7_1);
+                auto yaochu_kinds = [&]() {
+                    const uint32_t T9 = 1u | (1u << 24);
+                    return __popc((full.a | (full.a >> 1) | (full.a >> 2)) & T9) + __popc((full.b | (full.b >> 1) | (full.b >> 2)) & T9) +
+                           __popc((full.c | (full.c >> 1) | (full.c >> 2)) & T9) + __popc((full.d | (full.d >> 1) | (full.d >> 2)) & O7_1);
+                };
                 // (round 6) and, in standard form, groups of sizes {2}, {1, 1} or {2, 2, 1} mod 3 (r4_group_residues: a tenpai 13 plus one
-                // tile) - which three isolated tiles never are; seven pairs need six pairs.  The drawn tile is merged into the sorted
-                // run by its rank; a hand that is not "sorted run + drawn tile" keeps the histogram bound.
+                // tile) - which three isolated tiles never are; seven pairs need six pairs, thirteen orphans twelve groups.  The drawn
+                // tile is merged into the sorted run by its rank; a hand that is not "sorted run + drawn tile" keeps the histogram bound.
                 bool may;
                 const int nx14 = __builtin_amdgcn_update_dpp(0xFFFF, ht, 0x101 /* row_shl:1 */, 0xf, 0xf, false);
                 if (RMJ_GROUP_FILTER14 && q.gf && d_idx == hl - 1 && rballot(r < hl - 2 && ht > nx14, rb) == 0u) {
@@ -1097,14 +1103,16 @@ __device__ __forceinline__ void r4_gen_act_legal(R4& q, int& nl_mine) {
                     const int ks = __builtin_amdgcn_update_dpp(-1000, k, 0x111 /* row_shr:1 */, 0xf, 0xf, false);
                     const int k14 = !in ? 1000 : (r < m ? k : (r == m ? kd : ks));
                     const int kp = __builtin_amdgcn_update_dpp(-1000, k14, 0x111 /* row_shr:1 */, 0xf, 0xf, false);
-                    const uint32_t gr = r4_group_residues(in && k14 - kp > 2, hl, r, rb);
+                    const bool start = in && k14 - kp > 2;
+                    const uint32_t S = rballot(start, rb);
+                    const uint32_t gr = r4_group_residues(start, S, hl, r, rb);
                     may = gr == 0x10u || gr == 0x02u || gr == 0x21u;
                     if (!may && hl == 14) {
                         const int kn = __builtin_amdgcn_update_dpp(1000, k14, 0x101 /* row_shl:1 */, 0xf, 0xf, false);
-                        may = yk >= 12 || __popc(rballot(in && k14 != kp && k14 == kn, rb)) >= 6;
+                        may = __popc(rballot(in && k14 != kp && k14 == kn, rb)) >= 6 || (__popc(S) >= 12 && yaochu_kinds() >= 12);
                     }
                 } else {
-                    may = !(r4_isolated(full) >= 3 && yk < 12);
+                    may = !(r4_isolated(full) >= 3 && yaochu_kinds() < 12);
                 }
                 if (may) {
                     if (r4_shanten(q, full, hl / 3) <= 0) {
@@ -2032,7 +2040,7 @@ __device__ __forceinline__ uint32_t step4_body(const Env* Ep, Quad4Shared& sh, u
     q.G = &sh.st[row]; q.T = &sh.u.t; q.E = &E; q.lane = lane; q.r = r; q.rb = rb; q.row = row; q.g = g;
     // (round 6, one box, 65 536 games: with the tests the fused rollouts gain 1.5 % (2.11 -> 2.14 G); the kernels of one step per launch lose - the step at
     //  80 registers has no room for them: 0.97 -> 0.88 G - and keep the isolated-tile bounds alone)
-    q.gf = LOOP;
+    q.gf = LOOP || RMJ_GROUP_FILTER_ALL;
     // pass 2 (RMJ_ROW_ROUND_END): the rows whose round ended in pass 1 and has been dealt since (r4_round_end, run by the caller between the
     // passes - a call in here would cost every step ten more callee-saved registers): they skip policy and transitions, get their
     // first list and are published like any other row

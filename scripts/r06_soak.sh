@@ -31,7 +31,7 @@ run random_rows2_522 RMJ_ROWS=2 -- 256 6000 1 1522
 for k in 1502 1503; do run random_$k RMJ_QUEUE_FORCE=0 -- 512 6000 1 $k; done
 run random_tickets_refrng_534 RMJ_SOAK_RULE_EXTRA=256 RMJ_QUEUE_FORCE=1 RMJ_QUEUE_MIN_CHUNK=3 RMJ_QUEUE_CHUNK=3 -- 512 6000 1 1534
 wait
-{ echo "# parity soak of the round-5 build (ticket rollout in calls without L1 invalidates, stream positions, RMJ_RULE_REFERENCE_RNG) (scripts/r06_soak.sh): every line = one scripts/soak_parity.py run, all twelve (mode, rule set) configurations"
+{ echo "# parity soak of the round-6 build (-disable-machine-licm, v_perm row ballots, 32-bit policy keys, group-residue tests in the fused rollouts; the ticket schedules and RMJ_RULE_REFERENCE_RNG as in round 5, other seeds) (scripts/r06_soak.sh): every line = one scripts/soak_parity.py run, all twelve (mode, rule set) configurations"
   for f in $OUT/*.log; do echo "== $(basename $f .log): $(grep -c ' ok (' $f) configurations ok; $(tail -1 $f)"; done
   cat $OUT/_done.txt | sort
   python3 - <<PY

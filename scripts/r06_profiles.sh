@@ -5,7 +5,7 @@ export TMPDIR=/tmp
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 cd $R
 python3 bench.py --steps 20 --warmup 5 > gpurun_out/${TAG}_bench_driver_flags.json 2> gpurun_out/${TAG}_bench.err        # the driver's command: every leg in one line
-python3 bench.py --no-cpu-baseline > gpurun_out/${TAG}_bench_n1.json 2>> gpurun_out/${TAG}_bench.err                      # default flags (2 000 timed steps)
+python3 bench.py > gpurun_out/${TAG}_bench_default_flags.json 2>> gpurun_out/${TAG}_bench.err                      # default flags (2 000 timed steps)
 python3 bench.py --policy greedy --no-cpu-baseline --no-extras > gpurun_out/${TAG}_bench_greedy.json 2>> gpurun_out/${TAG}_bench.err
 python3 bench.py --mode 5 --encode --no-cpu-baseline > gpurun_out/${TAG}_bench_3p_encode.json 2>> gpurun_out/${TAG}_bench.err
 python3 bench.py --mode 5 --no-cpu-baseline --no-extras > gpurun_out/${TAG}_bench_3p_mode5.json 2>> gpurun_out/${TAG}_bench.err

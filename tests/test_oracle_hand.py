@@ -115,3 +115,66 @@ def test_unit_shapes_of_the_reference_are_wins():
     assert len(tiles) == 108 and all(t < 4 or t >= 32 for t in tiles) and {t // 4 for t in tiles} == set(range(34)) - set(range(1, 8))
     g4 = oracle.Game(game_mode=2, seed=3)
     assert [g4.peek().players[p].score for p in range(4)] == [25000] * 4
+
+
+def _group_residues(tiles):
+    """sizes mod 3 of the connected groups of a hand (r4_group_residues, csrc/rmj_step4.hip.h): tiles of one suit within two ranks chain, honors only
+    with their own type"""
+    key = lambda t: t + 7 * ((t >= 9) + (t >= 18)) if t < 27 else 48 + 3 * (t - 27)   # noqa: E731  (r4_key)
+    ks = sorted(key(t) for t in tiles)
+    sizes, cur = [], 1
+    for a, b in zip(ks, ks[1:]):
+        if b - a > 2:
+            sizes.append(cur)
+            cur = 1
+        else:
+            cur += 1
+    sizes.append(cur)
+    return sum(1 for s in sizes if s % 3 == 1), sum(1 for s in sizes if s % 3 == 2), len(sizes)
+
+
+@pytest.mark.parametrize("n", [4, 5, 7, 8, 10, 11, 13, 14])
+def test_group_residue_bound_never_rules_out_a_tenpai(n):
+    """The bound the fused rollouts put in front of the table shanten (round 6, journal r06 section 5): a hand of 3m + 1 tiles with shanten <= 0 has
+    groups of sizes {1} or {2, 2} mod 3, one of 3m + 2 tiles {2}, {1, 1} or {2, 2, 1}; seven pairs need six pairs, thirteen orphans twelve kinds - and
+    (the riichi bound's gate) twelve kinds need twelve groups.  Checked against the oracle's shanten (shanten.rs:163-261) on random hands and on hands
+    built from sets."""
+    rng = np.random.default_rng(600 + n)
+    deck = np.repeat(np.arange(34), 4)
+    hands = [list(rng.permutation(deck)[:n]) for _ in range(6000)]
+    while len(hands) < 12000:     # near-tenpai hands: sets first, then loose tiles
+        cnt, tiles = np.zeros(34, int), []
+        while len(tiles) < n - 3:
+            if rng.random() < 0.5:
+                s, r = int(rng.integers(3)), int(rng.integers(7))
+                ts = [9 * s + r, 9 * s + r + 1, 9 * s + r + 2]
+            else:
+                ts = [int(rng.integers(34))] * 3
+            if all(cnt[t] < 4 for t in ts) and cnt[ts[0]] + (3 if ts[0] == ts[1] else 1) <= 4:
+                for t in ts:
+                    cnt[t] += 1
+                    tiles.append(t)
+        while len(tiles) < n:
+            t = int(rng.integers(34))
+            if cnt[t] < 4:
+                cnt[t] += 1
+                tiles.append(t)
+        hands.append(tiles[:n])
+    counts = np.zeros((len(hands), 34), np.uint8)
+    for i, h in enumerate(hands):
+        for t in h:
+            counts[i, t] += 1
+    assert counts.max() <= 4
+    sh = oracle.shanten(counts)
+    allowed = {(1, 0), (0, 2)} if n % 3 == 1 else {(0, 1), (2, 0), (1, 2)}
+    n_low = 0
+    for i, h in enumerate(hands):
+        r1, r2, groups = _group_residues(h)
+        kinds = sum(1 for t in (0, 8, 9, 17, 18, 26, 27, 28, 29, 30, 31, 32, 33) if counts[i, t])
+        if kinds >= 12:
+            assert groups >= 12
+        if sh[i] <= 0:
+            n_low += 1
+            ok = (r1, r2) in allowed or (n >= 13 and (int((counts[i] >= 2).sum()) >= 6 or kinds >= 12))
+            assert ok, (h, int(sh[i]), r1, r2)
+    assert n_low > 3000

@@ -97,6 +97,23 @@ def test_a_lapped_ring_is_counted_and_the_window_still_formats():
     env.close()
 
 
+@pytest.mark.parametrize("ring", [0, 16, 63])
+def test_a_ring_smaller_than_the_librarys_floor_drains(ring):
+    """the library keeps at least 64 records per slot (rmj_create); the host side sizes its drain buffers with the ring it asked for -
+    VecRiichiEnv now reports the real ring (max(64, next power of two)) and a drain of a lapped 64-record ring succeeds"""
+    n = 64
+    env = vecenv.VecRiichiEnv(n, game_mode=2, seed=5, event_ring=ring)
+    assert env.event_ring == 64
+    env.reset()
+    env.step_random(7, 300, auto_reset=False)
+    cnt = env.event_counts().astype(np.int64)
+    assert (cnt > 64).any()
+    ev, offs = env.drain_events()
+    assert offs[0] == 0 and offs[-1] == len(ev) == int(np.minimum(cnt, 64).sum())
+    assert (env.events_lost().astype(np.int64) == np.maximum(cnt - 64, 0)).all()
+    env.close()
+
+
 @pytest.mark.parametrize("mode", [0, 3])
 def test_drains_across_auto_reset_restarts_lose_nothing(mode):
     """a restart used to set the record count back to 0 and a running cursor then skipped the new game's first records

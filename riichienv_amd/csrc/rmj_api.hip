@@ -627,8 +627,12 @@ __device__ __forceinline__ uint32_t obs_block_prefix(const uint32_t* __restrict_
 // encode - with only_active that is the acting seat (one, rarely two or three), so the launch has a quarter of the blocks of
 // a (game, seat) grid and no early-exit blocks.  The tensor of a seat is staged as one byte per cell (EncByteSink: 2.5 KB,
 // 4.9 KB of LDS per block with the record, the histograms and the value table) and leaves as a stream of 16-byte stores.
+// Round 6: four waves per SIMD.  Left alone the kernel takes 100 VGPR (four waves) under the default flags and 60 (seven) under -disable-machine-licm; alone
+// it runs the same either way (3P 0.1347 -> 0.1378 ms, occupancy 5 -> 8 changed nothing in round 5), but next to step and sampler kernels of other
+// shards on other streams the seven-wave form crowds them out: the trainer loop as 4 shards on 4 streams 304 -> 345 M env.step/s, 2 shards 290 -> 315 M,
+// compact batch 305 -> 334 M with the cap (five waves: 336 / 292 / 320; round-5 binary: 340-350 / 312-320 / 311-316).
 #ifndef RMJ_ENC_WAVES
-#define RMJ_ENC_WAVES 0
+#define RMJ_ENC_WAVES 4
 #endif
 #if RMJ_ENC_WAVES > 0
 #define RMJ_ENC_OCC __attribute__((amdgpu_waves_per_eu(RMJ_ENC_WAVES, RMJ_ENC_WAVES)))

@@ -584,7 +584,16 @@ def main(argv=None):
 
     if args.preroll > 0:
         roll(args.preroll)   # to steady state (see PREROLL), untimed
-    roll(args.warmup)
+    if args.encode:
+        roll(args.warmup)
+    elif args.warmup > 0:
+        # the W untimed warm-up steps go through the entry point of the timed region (the same rollout, HIP events around it): its first call resolves the
+        # event functions of the HIP runtime and builds the ctypes call frame - ~40 us of host time that a 20-step window (0.78 ms) would otherwise carry
+        # (scripts/r06_window_order.py: first window 1.66-1.69 G, with this warm-up 1.74 G like every later one)
+        if greedy:
+            env.time_rollout_greedy(policy_seed, args.warmup, args.call_rate)
+        else:
+            env.time_rollout(policy_seed, args.warmup)
 
     def barrier():
         if dist is not None:

@@ -1011,7 +1011,7 @@ struct rmj_env {
                                // rollout of >= 2 steps is ONE launch in which every wave steps its own games (k_step4<true>); RMJ_STEP4 at create
     // long fused rollouts hand the work out in (quad, chunk) tickets to a grid that fits the chip once (k_step4_queue)
     int queue_chunk = 32;      // calls per ticket (round 5: a ticket is a number of calls of the step function, profiles/r05_ticket_schedule_sweep.txt); RMJ_QUEUE_CHUNK at create, 0 = off (every wave keeps one quad for the rollout)
-    hipEvent_t ev_time[2] = {nullptr, nullptr};   // rmj_time_rollout* / rmj_bench_rollout: created on first use, so that a timed region holds no event create / destroy
+    hipEvent_t ev_time[2] = {nullptr, nullptr};   // rmj_time_rollout* / rmj_bench_rollout: created with the handle, so that a timed region holds no event create / destroy
     uint32_t* d_qheads = nullptr;   // [8][RMJ_Q_STRIDE] ticket counters, one line per XCD
     uint32_t q_slots_pol[2] = {0, 0};   // waves of k_step4_queue<policy> the device holds at once (the greedy instantiation is compiled for fewer)
     int queue_force = 0;            // RMJ_QUEUE_FORCE at create (tests): tickets for every batch of >= 64 quads
@@ -1130,10 +1130,10 @@ static int create_impl(rmj_env* h, const RmjConfig* cfg, uint64_t** d_seeds_out)
     HIPCHK(hipStreamCreateWithFlags(&h->own_stream, hipStreamNonBlocking));
     h->stream = h->own_stream;
     HIPCHK(hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming));
-    for (int i = 0; i < RMJ_MAX_ROLLOUT_STREAMS - 1; i++) {
-        HIPCHK(hipStreamCreateWithFlags(&h->xstream[i], hipStreamNonBlocking));
-        HIPCHK(hipEventCreateWithFlags(&h->ev_join[i], hipEventDisableTiming));
-    }
+    // (the side streams of the split paths are created when such a path first runs: ensure_side_streams)
+    // the two events of rmj_time_rollout* / rmj_bench_rollout: here, not at their first use - the driver's timed region IS their first use, and two
+    // hipEventCreate calls between its host timestamps cost the 20-step window ~4 % (round 6, scripts/r06_window_order.py: first window 1.65-1.69 G, later ones 1.76 G)
+    for (int i = 0; i < 2; i++) HIPCHK(hipEventCreate(&h->ev_time[i]));
     HIPCHK(hipMalloc(&d.core, B * sizeof(GState)));
     HIPCHK(hipMalloc(&d.wall, B * RMJ_WALL_STRIDE));
     HIPCHK(hipMalloc(&d.legal, B * 4 * RMJ_MAX_LEGAL * sizeof(uint64_t)));
@@ -1541,6 +1541,17 @@ static int rollout_streams(const rmj_env* h, uint32_t n_steps) {
     const int fit = (int)(h->cfg.n_games / RMJ_SPLIT_MIN_PART);
     return k > fit ? fit : k;
 }
+// Side streams (and their join events) of the paths that split a batch over k streams - the per-step rollouts of RMJ_STEP4=0/1 builds and the unfused
+// step + encode rollout.  Round 6: created on first use, not in rmj_create: the default paths (fused rollouts, one stream) never touch them, and every live
+// stream makes hipDeviceSynchronize slower - with seven idle side streams the synchronisation behind the driver's 20-step window took ~45 us of a 0.78 ms
+// region (scripts/r06_window_order.py: the same window between stream synchronisations ran at 1.76 G env.step/s, between device synchronisations at 1.66 G).
+static int ensure_side_streams(rmj_env* h, int k) {
+    for (int i = 0; i < k - 1 && i < RMJ_MAX_ROLLOUT_STREAMS - 1; i++) {
+        if (!h->xstream[i]) HIPCHK(hipStreamCreateWithFlags(&h->xstream[i], hipStreamNonBlocking));
+        if (!h->ev_join[i]) HIPCHK(hipEventCreateWithFlags(&h->ev_join[i], hipEventDisableTiming));
+    }
+    return RMJ_OK;
+}
 // Does a fused rollout of n_steps run as tickets (k_step4_queue)?  Worth it when the batch is more than one and fewer than eight
 // chip-fulls of waves: below, every quad is resident at once and there is no tail; far above, the tail is a small share and the
 // chunk hand-overs cost more than it (524 288 games: -2 %).
@@ -1633,6 +1644,7 @@ static int step_policy_impl(rmj_handle h, uint64_t policy_seed, uint32_t n_steps
     const int k = rollout_streams(h, n_steps);
     if (k >= 2) {
         // games are independent: each part advances n_steps steps on its own stream (header: rmj_step_random)
+        if (int rc = ensure_side_streams(h, k)) return rc;
         HIPCHK(hipEventRecord(h->ev_fork, h->stream));
         for (int i = 1; i < k; i++) HIPCHK(hipStreamWaitEvent(h->xstream[i - 1], h->ev_fork, 0));
         for (uint32_t s = 0; s < n_steps; s++)
@@ -1715,6 +1727,7 @@ int rmj_step_random_encode(rmj_handle h, uint64_t policy_seed, uint32_t n_steps,
     if ((int)(n / RMJ_SPLIT_MIN_PART) < k) k = (int)(n / RMJ_SPLIT_MIN_PART);
     if (n_steps < 2 || n < RMJ_SPLIT_MIN_GAMES || k < 2) k = 1;
     if (k >= 2) {
+        if (int rc = ensure_side_streams(h, k)) return rc;
         HIPCHK(hipEventRecord(h->ev_fork, h->stream));
         for (int i = 1; i < k; i++) HIPCHK(hipStreamWaitEvent(h->xstream[i - 1], h->ev_fork, 0));
         for (uint32_t s = 0; s < n_steps; s++)

@@ -2729,7 +2729,12 @@ static int bench_rollout_impl(rmj_handle h, uint64_t policy_seed, uint32_t warmu
     HIPCHK(hipEventRecord(e0, h->stream));
     if ((rc = step_policy_impl(h, policy_seed, steps, 1, pol, rate))) return rc;
     HIPCHK(hipEventRecord(e1, h->stream));
-    HIPCHK(hipEventSynchronize(e1));
+    // (polling, not hipEventSynchronize: a blocked host thread is woken 10-20 us after the event completes - 2 % of the driver's 20-step window, which ends with this wait)
+    for (;;) {
+        const hipError_t qe = hipEventQuery(e1);
+        if (qe == hipSuccess) break;
+        if (qe != hipErrorNotReady) return fail(RMJ_ERR_HIP, std::string("hipEventQuery: ") + hipGetErrorString(qe));
+    }
     float ms = 0.f;
     HIPCHK(hipEventElapsedTime(&ms, e0, e1));
     if (count && ((rc = rmj_total_steps(h, &after)) || (rc = rmj_total_full_path(h, &full1)))) return rc;

@@ -2982,6 +2982,14 @@ extern "C" int rmj_prof_bail_census(uint32_t* out32, int reset) {
 #endif
 
 
+#ifdef RMJ_RE_PROF
+extern "C" int rmj_debug_re_prof(unsigned long long* out8, int reset) {
+    unsigned long long z[24] = {0};
+    if (out8) HIPCHK(hipMemcpyFromSymbol(out8, HIP_SYMBOL(rmj::g_re_prof), sizeof(z)));
+    if (reset) HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(rmj::g_re_prof), z, sizeof(z)));
+    return RMJ_OK;
+}
+#endif
 #ifdef RMJ_DEBUG_HWID
 // debugging build only: HW ids / times of the waves of the last k_step4_act_enc launch (4 u64 per block)
 extern "C" int rmj_debug_hwid_fetch(uint64_t* out, uint32_t n_blocks) {

@@ -123,6 +123,10 @@ __device__ unsigned long long* g_tl4;
 #else
 #define TLF(c, k) do {} while (0)
 #endif
+#ifdef RMJ_RE_PROF   /* round-end timing build (scripts/r06_round_end_prof.py, never the shipped library): ticks of the 100 MHz clock summed by lane 0 of every wave:
+                        [0] r4_round_end, [1] its calls, [2] step4_pass2, [3] its calls, [4] r4_round_end up to the wall loop, [5] the wall / deal / hand-sort / event loop, [6] games dealt */
+__device__ unsigned long long g_re_prof[24];   // [8 + mode]: rows by R4_RE_* mode at the calls of step4_finish_rounds
+#endif
 #ifdef RMJ_DEBUG_HWID   /* value = blocks recorded; see k_step4_act_enc */
 __device__ unsigned long long g_dbg_hwid[4 * RMJ_DEBUG_HWID];
 #endif

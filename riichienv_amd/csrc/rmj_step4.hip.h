@@ -1507,6 +1507,15 @@ __device__ __noinline__ void r4_round_end(const Env* Ep, uint32_t g0) {
         wave_sync();
         r4_emit_now(q, restart, r == 0 ? (uint32_t)RMJ_EV_START_GAME : 0u);
     }
+#ifdef RMJ_RE_PROF
+    {
+        const unsigned long long b0 = __ballot(draw && r == 0), b1 = __ballot(restart && r == 0), b2 = __ballot(newround && r == 0), b3 = __ballot(q.live && G->is_done && r == 0);
+        if (lane == 0) {
+            atomicAdd(&rmj::g_re_prof[20], (unsigned long long)__popcll(b0)); atomicAdd(&rmj::g_re_prof[21], (unsigned long long)__popcll(b1));
+            atomicAdd(&rmj::g_re_prof[22], (unsigned long long)__popcll(b2)); atomicAdd(&rmj::g_re_prof[23], (unsigned long long)__popcll(b3));
+        }
+    }
+#endif
     if (!__ballot(newround)) return;
     // ---- _initialize_round, the per-row part: PlayerState::reset_round (state/player.rs:66-86) by lane = seat, the globals by lane 0
     if (newround) {
@@ -1540,6 +1549,10 @@ __device__ __noinline__ void r4_round_end(const Env* Ep, uint32_t g0) {
     }
     wave_sync();
     // ---- the wall and the deal, one game at a time with all 64 lanes
+#ifdef RMJ_RE_PROF
+    const unsigned long long pw0 = __builtin_amdgcn_s_memrealtime();
+    { const unsigned long long bn = __ballot(newround && r == 0); if (lane == 0) atomicAdd(&rmj::g_re_prof[6], (unsigned long long)__popcll(bn)); }
+#endif
     constexpr int N = KSANMA ? 108 : 136;
     uint32_t* const cnt = sh.rs;                                    // [32] = 128 byte counters, then the bucket offsets in place
     uint16_t* const gk = reinterpret_cast<uint16_t*>(sh.rs + 32);   // [136] sort words grouped by bucket: key bits 56..49 | element index
@@ -1698,6 +1711,9 @@ __device__ __noinline__ void r4_round_end(const Env* Ep, uint32_t g0) {
         }
         wave_sync();
     }
+#ifdef RMJ_RE_PROF
+    if (lane == 0) atomicAdd(&rmj::g_re_prof[5], __builtin_amdgcn_s_memrealtime() - pw0);
+#endif
 }
 
 // The evaluator between the passes of a step (out of line; no call sits in the step function itself - a call there costs every step
@@ -2781,12 +2797,27 @@ template <bool LOOP, int POL>
 __device__ __forceinline__ void step4_finish_rounds(const Env* Ep, uint32_t flags, uint32_t g_base, uint32_t g_end, uint32_t quad = 0xFFFFFFFFu) {
     constexpr bool RICH = (POL == 1) || !LOOP;   // (step4_body's tier)
     const uint32_t md = g_q4.rmode[(threadIdx.x & 63u) >> 4];
+#ifdef RMJ_RE_PROF
+    if ((threadIdx.x & 15u) == 0u) atomicAdd(&rmj::g_re_prof[8 + (md & 15u)], 1ull);
+#endif
     if (__ballot(md == R4_RE_DRAW || md == R4_RE_RESTART || md == R4_RE_WIN_TSUMO || md == R4_RE_WIN_RON)) {
         if (LOOP && RICH) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");   // (the settlement reads the ura indicators off the wall slab with plain loads)
+#ifdef RMJ_RE_PROF
+        const unsigned long long pt0 = __builtin_amdgcn_s_memrealtime();
+#endif
         r4_round_end<RICH>(Ep, g_base + (quad == 0xFFFFFFFFu ? blockIdx.x : quad) * r4_rows(flags));
+#ifdef RMJ_RE_PROF
+        if ((threadIdx.x & 63u) == 0u) { atomicAdd(&rmj::g_re_prof[0], __builtin_amdgcn_s_memrealtime() - pt0); atomicAdd(&rmj::g_re_prof[1], 1ull); }
+#endif
     }
     if (RICH && __ballot(md == R4_RE_YAKU_CLAIMS || md == R4_RE_YAKU_TSUMO)) r4_yaku_answers();   // (the lean tier never pauses for a yaku check)
+#ifdef RMJ_RE_PROF
+    const unsigned long long pt1 = __builtin_amdgcn_s_memrealtime();
+#endif
     step4_pass2<LOOP, POL>(Ep, flags, g_base, g_end, quad);
+#ifdef RMJ_RE_PROF
+    if ((threadIdx.x & 63u) == 0u) { atomicAdd(&rmj::g_re_prof[2], __builtin_amdgcn_s_memrealtime() - pt1); atomicAdd(&rmj::g_re_prof[3], 1ull); }
+#endif
 }
 // ... with inline responses (step4_body<.., INLR>): `left` steps to go per row, returns the steps taken per row
 #ifndef RMJ_INLINE_RESP

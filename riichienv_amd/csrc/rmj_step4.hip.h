@@ -1230,9 +1230,18 @@ __device__ __forceinline__ void r4_emit_now(R4& q, bool on, uint32_t w) {
     wave_sync();
 }
 // RICH: with the settlements of the rich tier (the lean tier's Tsumo / Ron actions bail to the full path: its copy has no evaluator)
+#ifdef RMJ_RE_PROF
+#define RE_MARK(k) do { const unsigned long long t__ = __builtin_amdgcn_s_memrealtime(); if (lane == 0) atomicAdd(&rmj::g_re_prof[k], t__ - re_t); re_t = t__; } while (0)
+#else
+#define RE_MARK(k) do {} while (0)
+#endif
 template <bool RICH>
 __device__ __noinline__ void r4_round_end(const Env* Ep, uint32_t g0) {
     const int lane = threadIdx.x & 63, row = lane >> 4, r = lane & 15, rb = lane & 48;
+#ifdef RMJ_RE_PROF
+    unsigned long long re_t = __builtin_amdgcn_s_memrealtime();
+    if (lane == 0) atomicAdd(&rmj::g_re_prof[16], re_t);   // (sum of entry times: minus the callers' sum of call times = the prologue)
+#endif
     Quad4Shared& sh = g_q4;
     const uint32_t mode = sh.rmode[row];
     CEnv& E = *(CEnv*)uni_ptr(Ep);
@@ -1421,6 +1430,7 @@ __device__ __noinline__ void r4_round_end(const Env* Ep, uint32_t g0) {
             }
         }
         PState& S4 = G->p[r & 3];
+        RE_MARK(12);   // entry + the refills of stale wait caches
         const uint32_t tenpai_m = rballot(draw && seat && (S4.hand_len + 3 * S4.n_melds == 13) && S4.waits13 != 0ull, rb) & 0xFu;
         const uint32_t nag_m = rballot(draw && seat && (S4.flags & PF_NAGASHI), rb) & 0xFu;
         int reason = RMJ_RK_EXHAUSTIVE;
@@ -1455,6 +1465,7 @@ __device__ __noinline__ void r4_round_end(const Env* Ep, uint32_t g0) {
             r4_emit_now(q, draw, (r == 1 || r == 7) ? 0u : w);
         }
     }
+    RE_MARK(13);   // payments + the ryukyoku record
     const bool decide = draw || win;
     if (__ballot(decide)) {
         // ---- _initialize_next_round(oya_won, is_draw) (state/mod.rs:1595-1700)
@@ -1498,6 +1509,7 @@ __device__ __noinline__ void r4_round_end(const Env* Ep, uint32_t g0) {
             }
         }
     }
+    RE_MARK(14);   // next-round decision + end_kyoku / end_game records
     if (__ballot(restart)) {   // GameState::reset clears the logs (state/mod.rs:171-187), then start_game
         if (restart) {
             const uint32_t evc0 = G->ev_count;
@@ -1548,6 +1560,7 @@ __device__ __noinline__ void r4_round_end(const Env* Ep, uint32_t g0) {
         }
     }
     wave_sync();
+    RE_MARK(15);   // restart record + the per-row round reset
     // ---- the wall and the deal, one game at a time with all 64 lanes
 #ifdef RMJ_RE_PROF
     const unsigned long long pw0 = __builtin_amdgcn_s_memrealtime();
@@ -1712,7 +1725,7 @@ __device__ __noinline__ void r4_round_end(const Env* Ep, uint32_t g0) {
         wave_sync();
     }
 #ifdef RMJ_RE_PROF
-    if (lane == 0) atomicAdd(&rmj::g_re_prof[5], __builtin_amdgcn_s_memrealtime() - pw0);
+    if (lane == 0) { const unsigned long long te = __builtin_amdgcn_s_memrealtime(); atomicAdd(&rmj::g_re_prof[5], te - pw0); atomicAdd(&rmj::g_re_prof[18], te); }   // ([18]: sum of exit times of the calls that dealt)
 #endif
 }
 
@@ -2807,7 +2820,7 @@ __device__ __forceinline__ void step4_finish_rounds(const Env* Ep, uint32_t flag
 #endif
         r4_round_end<RICH>(Ep, g_base + (quad == 0xFFFFFFFFu ? blockIdx.x : quad) * r4_rows(flags));
 #ifdef RMJ_RE_PROF
-        if ((threadIdx.x & 63u) == 0u) { atomicAdd(&rmj::g_re_prof[0], __builtin_amdgcn_s_memrealtime() - pt0); atomicAdd(&rmj::g_re_prof[1], 1ull); }
+        if ((threadIdx.x & 63u) == 0u) { const unsigned long long tr = __builtin_amdgcn_s_memrealtime(); atomicAdd(&rmj::g_re_prof[0], tr - pt0); atomicAdd(&rmj::g_re_prof[1], 1ull); atomicAdd(&rmj::g_re_prof[17], pt0); atomicAdd(&rmj::g_re_prof[19], tr); }
 #endif
     }
     if (RICH && __ballot(md == R4_RE_YAKU_CLAIMS || md == R4_RE_YAKU_TSUMO)) r4_yaku_answers();   // (the lean tier never pauses for a yaku check)

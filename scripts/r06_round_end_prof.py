@@ -26,6 +26,8 @@ print(f"rollout {steps} steps: {r.total_ms:.2f} ms on {slots} wave slots = {r.to
 us = lambda t: t / 100.0  # noqa: E731
 print(f"r4_round_end: {v[1]} calls, {us(v[0]) / max(v[1], 1):.1f} us each, {us(v[0]) / slots / (r.total_ms * 1e3) * 100:.1f} % of the slot time "
       f"(before the wall loop {us(v[0] - v[5]) / max(v[1], 1):.1f} us, wall + deal + hand sorts + records {us(v[5]) / max(v[1], 1):.1f} us for {v[6] / max(v[1], 1):.2f} games per call)")
-print("rows by mode at step4_finish_rounds (0 none, 1 draw, 2.. see R4_RE_*):", v[8:20])
+print("rows by mode at step4_finish_rounds (0 none, 1 draw, 2 restart):", v[8:11])
+print("r4_round_end phases, us per call: entry + stale wait-cache refills %.1f | payments + ryukyoku record %.1f | decision + end records %.1f | restart + round reset %.1f" % tuple(us(v[k]) / max(v[1], 1) for k in (12, 13, 14, 15)))
+print("call -> first statement of r4_round_end: %.2f us per call (the callee's prologue: callee-saved registers to scratch)" % (us(v[16] - v[17]) / max(v[1], 1)))
 print("inside r4_round_end: draw rows, restart rows, new-round rows, rows of finished games:", v[20:24])
 print(f"step4_pass2: {v[3]} calls, {us(v[2]) / max(v[3], 1):.1f} us each, {us(v[2]) / slots / (r.total_ms * 1e3) * 100:.1f} % of the slot time")
